@@ -1,0 +1,269 @@
+/* neptune_backend.h — C ABI of the MI355X-native NEPTUNE back-end trajectory optimizer.
+ *
+ * This is the drop-in boundary for ONE path of caomuqing/neptune: the back-end optimizer that
+ * `Neptune::replanFull` drives (reference: neptune/src/neptune.cpp:1512-1529), i.e. the public
+ * surface of `class PolySolverGurobi` (neptune/include/solver_gurobi_poly.hpp:25-49) plus the
+ * separating-line LP it calls (submodules/separator/include/separator.hpp:18-48) and the hull
+ * construction that feeds it (neptune/src/neptune.cpp:224-452, 639-664).
+ *
+ * Plain C: POD structs, plain pointers and sizes, no C++/torch/Eigen types.  All floating point
+ * is IEEE fp64.  Every entry point returns an int status (>= 0 ok, < 0 misuse / HIP error; text
+ * via nep_last_error()) and never throws across the boundary.
+ *
+ * Two levels:
+ *   (1) per-agent handle  `nep_backend_*`  — one call per PolySolverGurobi method, host buffers
+ *       in / host buffers out, blocking (what a cgo/ctypes/C++ shim of the reference binds);
+ *   (2) batched handle    `nep_batch_*`    — all local agents of a node in one launch sequence on
+ *       a HIP stream, device-resident inputs/outputs (what bench.py and the multi-GPU driver use).
+ */
+#ifndef NEPTUNE_BACKEND_H
+#define NEPTUNE_BACKEND_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* Limits (compile-time capacities of the fixed-size records)                                  */
+/* ------------------------------------------------------------------------------------------ */
+#define NEP_MAX_POL 8       /* num_pol upper bound; every shipped yaml uses 8
+                               (neptune/param/neptune_mtlp_benchmark.yaml:73)                   */
+#define NEP_TRAJ_MAX_SEG 16 /* committed trajectory = remainder of previous plan + <= 8 new
+                               segments (neptune/src/utils.cpp:318-402)                         */
+#define NEP_HULL_MAX_V 16   /* vertices of one interval hull (V <= 16)              */
+#define NEP_HULL_MAX_CP 12  /* MINVO control points feeding one interval hull: <= 3 committed
+                               segments overlap one planning interval x 4 control points       */
+#define NEP_MAX_BEND 8      /* tether bend points kept per agent                               */
+#define NEP_STATE_DOUBLES 12 /* mt::state pos,vel,accel,jerk (mader_types.hpp:35-41)           */
+
+/* status of one replan (mirrors PolySolverGurobi::optimize, solver_gurobi_poly.cpp:804-887)   */
+#define NEP_OK 0            /* first solve succeeded                      -> optimize()==true  */
+#define NEP_RELAXED 1       /* first failed, relaxed re-solve succeeded   -> optimize()==true  */
+#define NEP_FAILED 2        /* both failed: output == initial guess       -> optimize()==false */
+
+/* error codes (< 0) */
+#define NEP_E_ARG (-1)
+#define NEP_E_STATE (-2)    /* call-sequence misuse (e.g. optimize before setInitTrajectory)   */
+#define NEP_E_HIP (-3)
+#define NEP_E_CAP (-4)      /* a capacity above was exceeded                                   */
+
+/* ------------------------------------------------------------------------------------------ */
+/* POD records                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* mt::PieceWisePol (mader_types.hpp:462-548) with [a b c d] per interval, t in real seconds
+ * measured from the interval start (solver_gurobi_poly.cpp:921, kinodynamic_search.cpp:535-545). */
+typedef struct nep_pwp {
+  int32_t n_seg;                              /* number of intervals (coeff_x.size())           */
+  int32_t _pad;
+  double times[NEP_TRAJ_MAX_SEG + 1];         /* n_seg+1 knots                                   */
+  double coeff[3][NEP_TRAJ_MAX_SEG][4];       /* [axis x,y,z][interval][a b c d]                 */
+} nep_pwp;
+
+/* Committed trajectory of one agent as exchanged between agents.  Mirrors mader_msgs/DynTraj
+ * (mader_msgs/msg/DynTraj.msg:1-9, PieceWisePolTraj.msg:1-4); this is the all-gather record.   */
+typedef struct nep_traj_rec {
+  int32_t id;                                 /* 1-based agent id                                */
+  int32_t is_agent;                           /* only is_agent==1 produces hulls (neptune.cpp:332) */
+  int32_t n_bend;                             /* bend points incl. base (neptune_ros.cpp:457-476) */
+  int32_t valid;                              /* 0: not (yet) received -> skipped like an id
+                                                 missing from trajs_ (neptune.cpp:244-262)        */
+  double bbox[3];
+  double pos[3];
+  double bend[NEP_MAX_BEND][2];
+  nep_pwp pwp;
+} nep_traj_rec;
+
+/* Constructor + setMaxValues/setMaxRuntime/setTetherLength arguments
+ * (solver_gurobi_poly.cpp:25-27,140-185; call site neptune.cpp:102-107).                        */
+typedef struct nep_backend_cfg {
+  int32_t num_pol;                /* <= NEP_MAX_POL */
+  int32_t deg_pol;                /* must be 3 (yaml: "Only 3 is supported") */
+  int32_t id;                     /* 1-based */
+  int32_t num_agents;             /* pb.size() */
+  double T_span;
+  double weight_term;
+  double rad_term;                /* stored, unused by the QP (solver_gurobi_poly.cpp:32,703-706) */
+  int32_t use_linear_constraints; /* must be 1; the bilinear variant is out of scope */
+  int32_t _pad;
+  const double* pb;               /* [num_agents][2] base positions, copied */
+} nep_backend_cfg;
+
+/* eu::ent_state of one knot (entangle_utils.hpp:23-29), flattened: only the fields the back end
+ * reads (solver_gurobi_poly.cpp:624-636): alphas (agent_id, case) pairs and active_cases[].    */
+typedef struct nep_ent_view {
+  int32_t n_states;               /* K+1 */
+  int32_t n_active;               /* length of each active_cases row (num_agents + statics)     */
+  const int32_t* alpha_off;       /* [n_states+1] CSR offsets into alphas                        */
+  const int32_t* alphas;          /* [alpha_off[n_states]][2]                                    */
+  const int32_t* active_cases;    /* [n_states][n_active]                                        */
+  const int32_t* bend_off;        /* [num_agents+1] CSR offsets into bend_xy                     */
+  const double* bend_xy;          /* [bend_off[num_agents]][2]  bendPtsForAgents                 */
+} nep_ent_view;
+
+typedef struct nep_stats {
+  int32_t status;                 /* NEP_OK / NEP_RELAXED / NEP_FAILED */
+  int32_t iters;                  /* interior-point iterations of the accepted solve            */
+  int32_t iters_first;            /* iterations spent in the first (failed or accepted) solve   */
+  int32_t n_lines;                /* separating lines that produced constraint rows             */
+  int32_t n_lp;                   /* separator LPs attempted (Separator::getNumOfLPsRun)        */
+  int32_t n_lp_failed;            /* LPs without a separating line -> constraint skipped
+                                     (solver_gurobi_poly.cpp:483-494)                           */
+  int32_t n_rows;                 /* inequality rows of the QP                                  */
+  int32_t qc_active;              /* terminal ball constraint present (solver_gurobi_poly.cpp:699) */
+  double objective;               /* objective_value (solver_gurobi_poly.cpp:882)               */
+  double solve_us;                /* device time of the last optimize, microseconds             */
+} nep_stats;
+
+/* ------------------------------------------------------------------------------------------ */
+/* (1) per-agent handle: one entry per PolySolverGurobi method                                 */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct nep_backend nep_backend_t;
+
+/* PolySolverGurobi::PolySolverGurobi (solver_gurobi_poly.cpp:25-134).  NULL on failure.        */
+nep_backend_t* nep_backend_create(const nep_backend_cfg* cfg);
+void nep_backend_destroy(nep_backend_t* h);
+
+/* setMaxValues (solver_gurobi_poly.cpp:140-175) */
+int nep_backend_set_max_values(nep_backend_t* h, double x_min, double x_max, double y_min,
+                               double y_max, double z_min, double z_max, double v_max,
+                               double a_max, double j_max);
+/* setMaxRuntime (:182-185).  Stored and reported; the batched interior point is iteration-
+ * bounded, not wall-clock bounded.                                             */
+int nep_backend_set_max_runtime(nep_backend_t* h, double seconds);
+/* setTetherLength (:177-180), stored only, as in the reference. */
+int nep_backend_set_tether_length(nep_backend_t* h, double tether_length);
+/* setStaticObstVert (:316-320): n polygons, CSR offsets (in vertices) + xy[off[n]][2].         */
+int nep_backend_set_static_obst_vert(nep_backend_t* h, int32_t n_obst, const int32_t* vert_off,
+                                     const double* xy);
+/* setInitTrajectory (:187-244).  K = pwp->n_seg <= num_pol.                                    */
+int nep_backend_set_init_trajectory(nep_backend_t* h, const nep_pwp* pwp_init);
+/* setHulls (:246-281): hulls[j][i], j < n_obst (other agents present), i < num_pol.  CSR over
+ * (j*num_pol+i).                                                                                */
+int nep_backend_set_hulls(nep_backend_t* h, int32_t n_obst, const int32_t* vert_off,
+                          const double* xy);
+/* setHullsNoInflation (:283-288): id-indexed, num_agents x num_pol, empty polygons allowed.    */
+int nep_backend_set_hulls_no_inflation(nep_backend_t* h, int32_t n_agents,
+                                       const int32_t* vert_off, const double* xy);
+/* setEntStateVector (:307-314).  ent == NULL clears (entangle check off).                      */
+int nep_backend_set_ent_state_vector(nep_backend_t* h, const nep_ent_view* ent);
+/* optimize (:804-887).  Returns NEP_OK / NEP_RELAXED / NEP_FAILED (or < 0); *objective_value is
+ * written only when the return is NEP_OK or NEP_RELAXED, exactly like the reference.           */
+int nep_backend_optimize(nep_backend_t* h, double* objective_value);
+/* generatePwpOut (:889-936): pwp_out->times shifted by t_start; states_out[cap][12] receives
+ * pos,vel,accel,jerk every dc; *n_states_out = number written.                                 */
+int nep_backend_generate_pwp_out(nep_backend_t* h, double t_start, double dc, nep_pwp* pwp_out,
+                                 double* states_out, int32_t states_cap, int32_t* n_states_out);
+/* Neptune::getPlanningStats side channel (neptune.cpp:1812-1819) + solver counters.            */
+int nep_backend_get_stats(nep_backend_t* h, nep_stats* out);
+
+/* Test hook: bypass the separator and use these lines for the next optimize():
+ * seg[i] in [0,K), nd[i] = (n1,n2,d) in the reference's scaling (row: n.q + d - 1 <= 0).
+ * n_lines < 0 restores the built-in separator.                                                 */
+int nep_backend_debug_set_lines(nep_backend_t* h, int32_t n_lines, const int32_t* seg,
+                                const double* nd);
+/* Test hook: copy out the lines used by the last optimize() (order = row order).              */
+int nep_backend_debug_get_lines(nep_backend_t* h, int32_t cap, int32_t* seg, double* nd,
+                                int32_t* n_out);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Stand-alone kernels of the path (batched, host buffers): used by the parity tests           */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Separator::solveModel 2-D, 2-set (separator_glpk.cpp:248-373), batched: problem p has point
+ * set A = a_xy[a_off[p]..a_off[p+1]) and B = b_xy[b_off[p]..b_off[p+1]).  nd_out[p] = (n1,n2,d),
+ * solved_out[p] = 1/0.  The 3-set overload (:375-498) is the same LP with A := A u A+.         */
+int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy,
+                        const int32_t* b_off, const double* b_xy, double* nd_out,
+                        int32_t* solved_out);
+
+/* Neptune::convexHullsOfCurve2d (neptune.cpp:269-452) for n_traj committed trajectories over
+ * num_pol intervals of [t_start, t_start+num_pol*T_span]: inflated hull and uninflated hull per
+ * (traj, interval).  hull_xy[(j*num_pol+i)][NEP_HULL_MAX_V][2], hull_nv[(j*num_pol+i)].        */
+int nep_hulls_batch(int32_t n_traj, const nep_traj_rec* trajs, double t_start, int32_t num_pol,
+                    double T_span, double drone_radius, double* hull_xy, int32_t* hull_nv,
+                    double* hull0_xy, int32_t* hull0_nv);
+
+/* ------------------------------------------------------------------------------------------ */
+/* (2) batched handle: all local agents of one node per launch sequence                        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct nep_batch nep_batch_t;
+
+typedef struct nep_batch_cfg {
+  int32_t num_agents;             /* N: agents in the scene (ids 1..N)                          */
+  int32_t first_local;            /* 0-based index of the first agent solved by this handle     */
+  int32_t n_local;                /* agents solved by this handle (N/G when sharded)            */
+  int32_t num_pol;
+  int32_t n_static;               /* S: inflated static obstacle polygons                       */
+  int32_t enable_entangle;        /* 0/1                                                        */
+  int32_t max_states;             /* capacity of the sampled state list per agent               */
+  int32_t n_scenes;               /* independent scenes processed per launch (>= 1); agent slot
+                                     (scene s, local agent a) = s*n_local + a                   */
+  double T_span, weight_term, dc, drone_radius;
+  double x_min, x_max, y_min, y_max, z_min, z_max, v_max, a_max;
+  const double* pb;               /* [N][2] bases (host, copied)                                */
+  const int32_t* static_off;      /* [S+1] (host, copied)                                       */
+  const double* static_xy;        /* [static_off[S]][2] (host, copied)                          */
+} nep_batch_cfg;
+
+/* Front-end result for one agent: initial guess + replan start time + entangle inputs.        */
+typedef struct nep_guess {
+  int32_t K;                                  /* num_pol_init_ (solver_gurobi_poly.cpp:194)      */
+  int32_t n_alpha;                            /* alphas per knot are stored dense below          */
+  double t_start;                             /* neptune.cpp:1422                                 */
+  double coeff[3][NEP_MAX_POL][4];            /* pwp_init, times are i*T_span                     */
+} nep_guess;
+
+typedef struct nep_solution {
+  nep_stats stats;
+  int32_t K;
+  int32_t n_states;
+  double times[NEP_MAX_POL + 1];              /* t_start + i*T_span                               */
+  double coeff[3][NEP_MAX_POL][4];            /* pwp_out                                          */
+} nep_solution;
+
+nep_batch_t* nep_batch_create(const nep_batch_cfg* cfg);
+void nep_batch_destroy(nep_batch_t* h);
+
+/* One full back-end replan for every (scene, local agent) slot, enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = default stream), asynchronous.
+ *   d_committed : device, [n_scenes][N] nep_traj_rec — snapshot of every agent's committed
+ *                 trajectory (own entry ignored)
+ *   d_guess     : device, [n_scenes][n_local] nep_guess
+ *   d_ent       : device or NULL, entangle inputs (layout: see nep_batch_ent_bytes)
+ *   d_solution  : device, [n_scenes][n_local] nep_solution                        (out)
+ *   d_states    : device, [n_scenes][n_local][max_states][12] or NULL             (out)
+ *   d_commit    : device or NULL, [n_scenes][n_local] nep_traj_rec: the new trajectory as the
+ *                 record the agent would publish (neptune_ros.cpp:434-480)         (out)      */
+int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess,
+                     const void* d_ent, nep_solution* d_solution, double* d_states,
+                     nep_traj_rec* d_commit, void* stream);
+
+/* Dense per-slot entangle block consumed by nep_batch_replan when enable_entangle != 0:
+ *   int32 case_id[NEP_MAX_POL][N]   (0 = no active case for that agent at that segment,
+ *                                    else the alphas case id, solver_gurobi_poly.cpp:624-631)
+ * bend points come from d_committed[j].bend / n_bend.                                          */
+int64_t nep_batch_ent_bytes(const nep_batch_t* h);
+
+/* Blocks until everything enqueued by this handle on `stream` has finished. */
+int nep_batch_wait(nep_batch_t* h, void* stream);
+
+/* Average device time (ms) of the dominant kernel over the launches since the last call,
+ * measured with HIP events on the launch stream; *n_launch = launches averaged.               */
+int nep_batch_kernel_time(nep_batch_t* h, int32_t which, double* avg_ms, int32_t* n_launch);
+int nep_batch_enable_timing(nep_batch_t* h, int32_t on);
+
+/* Test hooks: fetch intermediates of the last replan to host.                                 */
+int nep_batch_debug_hulls(nep_batch_t* h, int32_t slot, double* hull_xy, int32_t* hull_nv);
+int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* seg, double* nd,
+                          int32_t* n_out);
+
+const char* nep_last_error(void);
+const char* nep_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEPTUNE_BACKEND_H */

@@ -1,0 +1,282 @@
+"""Synthetic N-agent / M-obstacle scenes for the back-end path (host side, numpy only).
+
+There is no ROS and no front end in this build; this module plays the role of the reference's
+experiment drivers for the one path we accelerate:
+  * bases on a circle               — reference neptune/src/neptune_ros.cpp:138-151
+  * random 0.5 m square obstacles   — reference neptune/src/neptune_ros.cpp:212-250
+  * inflation of static obstacles   — reference neptune/src/neptune.cpp:639-664 (host, once)
+  * random goals                    — reference neptune/scripts/benchmark_mtlp.py:225-242
+  * initial guesses                 — jerk-lattice roll-outs with the primitive structure of
+                                      reference neptune/src/kinodynamic_search.cpp:1053-1097
+                                      (piecewise-constant jerk on {-5,-2.5,0,2.5,5}, T_span per step)
+Parameter values are those of reference neptune/param/neptune_mtlp_benchmark.yaml; the world is
+scaled with sqrt(N/5) to keep the shipped scene's agent density.
+"""
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import abi
+
+# MINVO position basis inverse on [0,1] (mader_types.hpp:152-157 inverted exactly; same literals
+# as csrc/nep_tables.h).  Host copy used only for scene rejection tests and tests' helpers.
+A_POS_INV = np.array([
+    [-0.03203276669713047, -0.09273093424558249, 0.3420572455666699, 1.1023313949144335],
+    [-0.05111494245568798, -0.046272612998418894, 0.5458234872124772, 1.0979806946005568],
+    [-0.07454781852812224, 0.203951949894552, 0.796048050105448, 1.0745478185281223],
+    [1.0, 1.0, 0.9999999999999996, 0.9999999999999993]])
+
+
+@dataclass
+class Params:
+    num_agents: int = 5
+    n_static: int = 0
+    num_pol: int = 8
+    T_span: float = 0.5
+    dc: float = 0.05
+    weight: float = 1000.0
+    v_max: float = 2.0
+    a_max: float = 3.0
+    j_max: float = 5.0
+    drone_radius: float = 0.6
+    z_min: float = -0.2
+    z_max: float = 5.1
+    x_min: float = -12.0
+    x_max: float = 12.0
+    y_min: float = -12.0
+    y_max: float = 12.0
+    tether_length: float = 40.0
+    goal_height: float = 1.0
+    enable_entangle: bool = False
+    pb: np.ndarray = field(default_factory=lambda: np.zeros((0, 2)))
+
+    @property
+    def max_states(self):
+        return int(math.ceil(self.num_pol * self.T_span / self.dc)) + 3
+
+
+def scaled_params(num_agents, n_static, **kw):
+    """World half-width 12*sqrt(N/5) m, base circle radius 10*sqrt(N/5)."""
+    sc = math.sqrt(max(num_agents, 1) / 5.0)
+    if num_agents <= 5:
+        sc = 1.0
+    p = Params(num_agents=num_agents, n_static=n_static, x_min=-12.0 * sc, x_max=12.0 * sc,
+               y_min=-12.0 * sc, y_max=12.0 * sc, **kw)
+    p.tether_length = 40.0 * sc
+    p.pb, _ = bases_on_circle(num_agents, 10.0 * sc)
+    return p
+
+
+def bases_on_circle(n, radius=10.0, dist_to_agent=2.5):
+    """neptune_ros.cpp:138-151 (cosf/sinf are single precision there; kept)."""
+    one_slice = 3.1415927 * 2 / n
+    pb = np.zeros((n, 2)); start = np.zeros((n, 2))
+    for i in range(n):
+        th = one_slice * i
+        c = float(np.cos(np.float32(th))); s = float(np.sin(np.float32(th)))
+        c2 = float(np.cos(np.float32(1.571 - th))); s2 = float(np.sin(np.float32(1.571 - th)))
+        pb[i] = (-radius * c - dist_to_agent * c2, -radius * s + dist_to_agent * s2)
+        start[i] = (-radius * c, -radius * s)
+    return pb, start
+
+
+def hull_ccw_lexmin(pts):
+    """Andrew monotone chain, CCW from the lexicographically smallest point, collinear dropped
+    (host restatement of cu::convexHullOfPoints2d, cgal_utils.cpp:157-174, for setup-time use)."""
+    P = sorted(set(map(tuple, np.asarray(pts, dtype=np.float64).reshape(-1, 2))))
+    if len(P) <= 1:
+        return np.array(P, dtype=np.float64).reshape(-1, 2)
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+    lo = []
+    for p in P:
+        while len(lo) >= 2 and cross(lo[-2], lo[-1], p) <= 0:
+            lo.pop()
+        lo.append(p)
+    up = []
+    for p in reversed(P):
+        while len(up) >= 2 and cross(up[-2], up[-1], p) <= 0:
+            up.pop()
+        up.append(p)
+    return np.array(lo[:-1] + up[:-1], dtype=np.float64)
+
+
+def inflate_static(verts, drone_radius):
+    """Neptune::setStaticObst, neptune.cpp:639-664: every vertex +-(2*drone_radius+0.2), hull."""
+    sd = 2 * drone_radius + 0.2
+    v = np.asarray(verts, dtype=np.float64).reshape(-1, 2)
+    pts = []
+    for x, y in v:
+        pts += [(x + sd, y + sd), (x + sd, y - sd), (x - sd, y - sd), (x - sd, y + sd)]
+    return hull_ccw_lexmin(pts)
+
+
+def random_static_obstacles(p, rng, voxel=0.2):
+    """neptune_ros.cpp:212-250 with the base-distance test applied to every base."""
+    pts = []
+    tries = 0
+    while len(pts) < p.n_static and tries < 100000:
+        tries += 1
+        x = rng.uniform(p.x_min, p.x_max); y = rng.uniform(p.y_min, p.y_max)
+        ok = True
+        for q in pts:
+            d = math.hypot(x - q[0], y - q[1])
+            if d < 3 * voxel or (d > 2 * p.drone_radius and d < voxel * 2.83 + 8 * p.drone_radius):
+                ok = False
+                break
+        if ok and len(p.pb) and np.min(np.hypot(p.pb[:, 0] - x, p.pb[:, 1] - y)) < 6.0:
+            ok = False
+        if ok:
+            pts.append((x, y))
+    raw = [np.array([[x + .25, y + .25], [x + .25, y - .25], [x - .25, y - .25], [x - .25, y + .25]])
+           for x, y in pts]
+    return raw, [inflate_static(v, p.drone_radius) for v in raw]
+
+
+LATTICE = np.array([-5.0, -2.5, 0.0, 2.5, 5.0])
+
+
+def _rollout_axis(p0, v0, a0, goal, T, K, v_max, a_max):
+    """Greedy per-axis jerk-lattice roll-out: segment coefficients [a b c d] with a=j/6, b=a0/2,
+    c=v0, d=p0 (kinodynamic_search.cpp:1096-1097)."""
+    co = np.zeros((K, 4))
+    for i in range(K):
+        best, bj = None, 0.0
+        remaining = K - i
+        for j in LATTICE:
+            a1 = a0 + j * T
+            v1 = v0 + a0 * T + 0.5 * j * T * T
+            pp1 = p0 + v0 * T + 0.5 * a0 * T * T + j * T ** 3 / 6
+            # desired speed: brake so that the goal is reached at rest
+            dist = goal - pp1
+            v_des = np.clip(1.2 * dist, -0.8 * v_max, 0.8 * v_max)
+            if remaining <= 3:
+                v_des *= (remaining - 1) / 3.0
+            cost = (v1 - v_des) ** 2 + 0.15 * a1 * a1
+            if abs(a1) > 0.85 * a_max:
+                cost += 100 * (abs(a1) - 0.85 * a_max) ** 2 + 10
+            if abs(v1) > 0.9 * v_max:
+                cost += 100 * (abs(v1) - 0.9 * v_max) ** 2 + 10
+            if best is None or cost < best:
+                best, bj = cost, j
+        co[i] = (bj / 6.0, a0 / 2.0, v0, p0)
+        p0, v0, a0 = (p0 + v0 * T + 0.5 * a0 * T * T + bj * T ** 3 / 6,
+                      v0 + a0 * T + 0.5 * bj * T * T, a0 + bj * T)
+    return co
+
+
+def rollout(p0, v0, a0, goal, par, K):
+    co = np.zeros((3, K, 4))
+    for ax in range(2):
+        co[ax] = _rollout_axis(p0[ax], v0[ax], a0[ax], goal[ax], par.T_span, K, par.v_max, par.a_max)
+    co[2, :, 3] = p0[2]  # constant height (the reference feeds a z B-spline profile, neptune.cpp:1427)
+    return co
+
+
+def pos_ctrl_pts(coeff_axis, T):
+    """[K][4] coefficients -> [K][4] MINVO position control points (solver_gurobi_poly.cpp:240)."""
+    M = A_POS_INV * np.array([T ** 3, T ** 2, T, 1.0])[:, None]
+    return coeff_axis @ M
+
+
+def _aabb_sep(lo1, hi1, lo2, hi2):
+    return (hi1[0] < lo2[0]) or (hi2[0] < lo1[0]) or (hi1[1] < lo2[1]) or (hi2[1] < lo1[1])
+
+
+def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_jitter=0.0):
+    """Returns dict(par, statics_raw, statics, starts, goals, guesses [N] (GUESS_DTYPE),
+    committed [N] (TRAJ_REC_DTYPE))."""
+    rng = np.random.default_rng(seed)
+    p = par if par is not None else scaled_params(num_agents, n_static)
+    N = p.num_agents
+    sc = (p.x_max - p.x_min) / 24.0
+    _, starts = bases_on_circle(N, 10.0 * sc if N > 5 else 10.0)
+    raw, statics = random_static_obstacles(p, rng)
+    st_lo = [s.min(0) for s in statics]; st_hi = [s.max(0) for s in statics]
+    T = p.T_span
+    infl = 2 * p.drone_radius  # bbox/2 + drone_radius with bbox = 2*drone_radius (neptune_ros.cpp:444-446)
+    guesses = np.zeros(N, dtype=abi.GUESS_DTYPE)
+    committed = np.zeros(N, dtype=abi.TRAJ_REC_DTYPE)
+    goals = np.zeros((N, 3))
+    prev_boxes = []  # per accepted agent: (lo[K+1][2], hi[K+1][2]) of inflated interval AABBs
+    close_range = 4.0
+    for i in range(N):
+        accepted = None
+        for attempt in range(300):
+            g = np.array([rng.uniform(p.x_min + 4.0, p.x_max - 4.0),
+                          rng.uniform(p.y_min + 4.0, p.y_max - 4.0), p.goal_height])
+            if np.hypot(*(g[:2] - p.pb[i])) > p.tether_length:
+                continue
+            if i and np.min(np.hypot(goals[:i, 0] - g[0], goals[:i, 1] - g[1])) < close_range:
+                continue
+            p0 = np.array([starts[i][0], starts[i][1], p.goal_height]); v0 = np.zeros(3); a0 = np.zeros(3)
+            co = rollout(p0, v0, a0, g, p, K)
+            if K >= 2 and rng.uniform() < warm_fraction:  # mid-flight replan: restart from a later knot
+                s = int(rng.integers(1, min(4, K)))
+                c = co[:, s - 1, :]
+                p0 = c[:, 0] * T ** 3 + c[:, 1] * T ** 2 + c[:, 2] * T + c[:, 3]
+                v0 = 3 * c[:, 0] * T ** 2 + 2 * c[:, 1] * T + c[:, 2]
+                a0 = 6 * c[:, 0] * T + 2 * c[:, 1]
+                co = rollout(p0, v0, a0, g, p, K)
+            cx = pos_ctrl_pts(co[0], T); cy = pos_ctrl_pts(co[1], T)
+            lo = np.stack([cx.min(1), cy.min(1)], 1); hi = np.stack([cx.max(1), cy.max(1)], 1)
+            if lo[:, 0].min() < p.x_min + 0.2 or hi[:, 0].max() > p.x_max - 0.2 or \
+               lo[:, 1].min() < p.y_min + 0.2 or hi[:, 1].max() > p.y_max - 0.2:
+                continue
+            ok = True
+            for k in range(K):
+                for s_lo, s_hi in zip(st_lo, st_hi):
+                    if not _aabb_sep(lo[k], hi[k], s_lo - 0.05, s_hi + 0.05):
+                        ok = False
+                        break
+                if not ok:
+                    break
+            if not ok:
+                continue
+            # other agents: interval k of agent j covers its segments k-1..k+1 (neptune.cpp:379-389)
+            for (plo, phi) in prev_boxes:
+                for k in range(K):
+                    k0, k1 = max(k - 1, 0), min(k + 1, K - 1)
+                    olo = plo[k0:k1 + 1].min(0) - infl - 0.05; ohi = phi[k0:k1 + 1].max(0) + infl + 0.05
+                    mlo = lo[k0:k1 + 1].min(0); mhi = hi[k0:k1 + 1].max(0)
+                    if not _aabb_sep(mlo, mhi, olo, ohi):
+                        ok = False
+                        break
+                if not ok:
+                    break
+            if ok:
+                accepted = (g, co, lo, hi)
+                break
+        if accepted is None:  # hover in place
+            g = np.array([starts[i][0], starts[i][1], p.goal_height])
+            co = np.zeros((3, K, 4)); co[:, :, 3] = g[:, None]
+            cx = pos_ctrl_pts(co[0], T); cy = pos_ctrl_pts(co[1], T)
+            lo = np.stack([cx.min(1), cy.min(1)], 1); hi = np.stack([cx.max(1), cy.max(1)], 1)
+            accepted = (g, co, lo, hi)
+        g, co, lo, hi = accepted
+        goals[i] = g
+        prev_boxes.append((lo, hi))
+        t_start = float(rng.uniform(0, t_jitter)) if t_jitter > 0 else 0.0
+        guesses[i]["K"] = K
+        guesses[i]["t_start"] = t_start
+        guesses[i]["coeff"][:, :K, :] = co
+        r = committed[i]
+        r["id"] = i + 1; r["is_agent"] = 1; r["valid"] = 1; r["n_bend"] = 1
+        r["bbox"] = 2 * p.drone_radius
+        r["pos"] = co[:, 0, 3]
+        r["bend"][0] = p.pb[i]
+        r["pwp"]["n_seg"] = K
+        r["pwp"]["times"][:K + 1] = t_start + np.arange(K + 1) * T
+        r["pwp"]["coeff"][:, :K, :] = co
+    return dict(par=p, statics_raw=raw, statics=statics, starts=starts, goals=goals,
+                guesses=guesses, committed=committed, seed=seed)
+
+
+def statics_csr(statics):
+    off = np.zeros(len(statics) + 1, dtype=np.int32)
+    for i, s in enumerate(statics):
+        off[i + 1] = off[i] + len(s)
+    xy = np.concatenate(statics).astype(np.float64) if len(statics) else np.zeros((0, 2))
+    return off, np.ascontiguousarray(xy)

@@ -1,0 +1,684 @@
+/* neptune_oracle.c — CPU restatement (plain C99, fp64) of the NEPTUNE back-end path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see neptune_oracle.h).  "parity unpinned" against a live
+ * Gurobi/GLPK/CGAL run; pinned by tests/golden/ instead.
+ *
+ * The QP is built in the reference's own variable space — 12K polynomial coefficients with the
+ * 9K+6 equality rows written out — following PolySolverGurobi::addObjective/addConstraints row
+ * for row, and solved by a dense primal-dual interior point.  The GPU product solves a reduced
+ * (null-space) form of the same problem, so agreement between the two checks the reduction.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (see oracle/Makefile).  -ffp-contract=off is
+ * required: hull and separator outputs are compared bit-for-bit with the HIP kernels.
+ */
+#include "neptune_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* MINVO basis                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+/* Inverses of mt::basisConverter::A_pos_mv_rest (mader_types.hpp:152-157) and A_vel_mv_rest
+ * (:159-163), t in [0,1]: exact rational inverse of the double-rounded literals, rounded to
+ * double (tests/golden/make_golden.py regenerates and checks them).  The reference inverts
+ * A_mv*diag(T^-3,T^-2,T^-1,1) with Eigen (solver_gurobi_poly.cpp:61,93); (A*C)^-1 = C^-1*A^-1. */
+static const double A_POS_INV[4][4] = {
+    {-0.03203276669713047, -0.09273093424558249, 0.3420572455666699, 1.1023313949144335},
+    {-0.05111494245568798, -0.046272612998418894, 0.5458234872124772, 1.0979806946005568},
+    {-0.07454781852812224, 0.203951949894552, 0.796048050105448, 1.0745478185281223},
+    {1.0, 1.0, 0.9999999999999996, 0.9999999999999993}};
+static const double A_VEL_INV[3][3] = {
+    {-0.07735026918962577, 0.16666666666666635, 1.077350269189625},
+    {-0.07735026918962577, 0.49999999999999967, 1.077350269189625},
+    {1.0000000000000002, 1.0000000000000009, 1.0000000000000016}};
+
+/* A_rest_pos_basis_inverse_ for interval length T (solver_gurobi_poly.cpp:39-45,61,93). */
+static void pos_inv_T(double T, double M[4][4]) {
+  double tp[4] = {T * T * T, T * T, T, 1.0};
+  for (int j = 0; j < 4; j++)
+    for (int k = 0; k < 4; k++) M[j][k] = tp[j] * A_POS_INV[j][k];
+}
+/* A_rest_vel_basis_inverse321_ (solver_gurobi_poly.cpp:47-51,62,94-97). */
+static void vel_inv321_T(double T, double M[3][3]) {
+  double tv[3] = {T * T, T, 1.0};
+  double m321[3] = {3.0, 2.0, 1.0};
+  for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 3; k++) M[j][k] = m321[j] * (tv[j] * A_VEL_INV[j][k]);
+}
+
+void orc_pos_ctrl_pts(const double P[4], double T, double Q[4]) {
+  double M[4][4];
+  pos_inv_T(T, M);
+  for (int k = 0; k < 4; k++) Q[k] = ((P[0] * M[0][k] + P[1] * M[1][k]) + P[2] * M[2][k]) + P[3] * M[3][k];
+}
+void orc_vel_ctrl_pts(const double P[4], double T, double Qv[3]) {
+  double M[3][3];
+  vel_inv321_T(T, M);
+  for (int k = 0; k < 3; k++) Qv[k] = (P[0] * M[0][k] + P[1] * M[1][k]) + P[2] * M[2][k];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* 2-D convex hull (cu::convexHullOfPoints2d, cgal_utils.cpp:157-174)                          */
+/* ------------------------------------------------------------------------------------------ */
+static double cross3(const double o[2], const double a[2], const double b[2]) {
+  return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]);
+}
+static int lex_less(const double a[2], const double b[2]) {
+  return a[0] < b[0] || (a[0] == b[0] && a[1] < b[1]);
+}
+/* Andrew monotone chain; CGAL::convex_hull_2 returns the extreme points counter-clockwise
+ * starting at the lexicographically smallest one, collinear points dropped. */
+int orc_convex_hull_2d(int n, const double (*pts)[2], double (*out)[2]) {
+  if (n <= 0) return 0;
+  double p[64][2];
+  if (n > 64) n = 64;
+  for (int i = 0; i < n; i++) { p[i][0] = pts[i][0]; p[i][1] = pts[i][1]; }
+  /* insertion sort, lexicographic (stable order is irrelevant: equal points are identical) */
+  for (int i = 1; i < n; i++) {
+    double kx = p[i][0], ky = p[i][1];
+    int j = i - 1;
+    double key[2] = {kx, ky};
+    while (j >= 0 && lex_less(key, p[j])) { p[j + 1][0] = p[j][0]; p[j + 1][1] = p[j][1]; j--; }
+    p[j + 1][0] = kx; p[j + 1][1] = ky;
+  }
+  /* unique */
+  int m = 0;
+  for (int i = 0; i < n; i++)
+    if (m == 0 || p[i][0] != p[m - 1][0] || p[i][1] != p[m - 1][1]) { p[m][0] = p[i][0]; p[m][1] = p[i][1]; m++; }
+  if (m == 1) { out[0][0] = p[0][0]; out[0][1] = p[0][1]; return 1; }
+  double h[130][2];
+  int k = 0;
+  for (int i = 0; i < m; i++) { /* lower hull */
+    while (k >= 2 && cross3(h[k - 2], h[k - 1], p[i]) <= 0.0) k--;
+    h[k][0] = p[i][0]; h[k][1] = p[i][1]; k++;
+  }
+  int lo = k + 1;
+  for (int i = m - 2; i >= 0; i--) { /* upper hull */
+    while (k >= lo && cross3(h[k - 2], h[k - 1], p[i]) <= 0.0) k--;
+    h[k][0] = p[i][0]; h[k][1] = p[i][1]; k++;
+  }
+  k--; /* last == first */
+  for (int i = 0; i < k; i++) { out[i][0] = h[i][0]; out[i][1] = h[i][1]; }
+  return k;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Hulls of a committed trajectory over one interval (neptune.cpp:349-452, 288-309)            */
+/* ------------------------------------------------------------------------------------------ */
+static int lower_bound_d(const double* a, int n, double v) { /* first i with a[i] >= v */
+  int lo = 0, hi = n;
+  while (lo < hi) { int mid = (lo + hi) / 2; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+static int upper_bound_d(const double* a, int n, double v) { /* first i with a[i] > v */
+  int lo = 0, hi = n;
+  while (lo < hi) { int mid = (lo + hi) / 2; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+void orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_span,
+                          const double delta[2], double (*hull)[2], int* nv, double (*hull0)[2],
+                          int* nv0) {
+  int n = pwp->n_seg;
+  double pts[4 * NEP_HULL_MAX_CP][2], pts0[NEP_HULL_MAX_CP][2];
+  int np = 0, np0 = 0;
+  /* neptune.cpp:379-389 */
+  int first = lower_bound_d(pwp->times, n + 1, t0) - 1;
+  int last = upper_bound_d(pwp->times, n + 1, t1) - 1;
+  if (first < 0) first = 0; if (first > n - 1) first = n - 1;
+  if (last < 0) last = 0; if (last > n - 1) last = n - 1;
+  for (int i = first; i <= last && np0 + 4 <= NEP_HULL_MAX_CP; i++) {
+    double _t; /* neptune.cpp:399-424 */
+    if (i != last) _t = pwp->times[i + 1] - pwp->times[i];
+    else if (t1 > pwp->times[i + 1]) _t = pwp->times[i + 1] - pwp->times[i];
+    else _t = t1 - pwp->times[i];
+    if (_t > T_span) _t = T_span; else if (_t < 0) _t = 0;
+    double c[4] = {_t * _t * _t, _t * _t, _t, 1.0};
+    for (int k = 0; k < 4; k++) { /* V = (P * C) * A^-1, neptune.cpp:426-429 */
+      double v[2];
+      for (int ax = 0; ax < 2; ax++) {
+        const double* P = pwp->coeff[ax][i];
+        v[ax] = (((P[0] * c[0]) * A_POS_INV[0][k] + (P[1] * c[1]) * A_POS_INV[1][k]) +
+                 (P[2] * c[2]) * A_POS_INV[2][k]) + (P[3] * c[3]) * A_POS_INV[3][k];
+      }
+      /* neptune.cpp:436-446: delta.norm()<1e-6 -> no inflation */
+      if (sqrt(delta[0] * delta[0] + delta[1] * delta[1]) < 1e-6) {
+        pts[np][0] = v[0]; pts[np][1] = v[1]; np++;
+      } else {
+        pts[np][0] = v[0] + delta[0]; pts[np][1] = v[1] + delta[1]; np++;
+        pts[np][0] = v[0] + delta[0]; pts[np][1] = v[1] - delta[1]; np++;
+        pts[np][0] = v[0] - delta[0]; pts[np][1] = v[1] - delta[1]; np++;
+        pts[np][0] = v[0] - delta[0]; pts[np][1] = v[1] + delta[1]; np++;
+      }
+      pts0[np0][0] = v[0]; pts0[np0][1] = v[1]; np0++;
+    }
+  }
+  double tmp[64][2];
+  int k = orc_convex_hull_2d(np, pts, tmp);
+  if (k > NEP_HULL_MAX_V) k = NEP_HULL_MAX_V;
+  for (int i = 0; i < k; i++) { hull[i][0] = tmp[i][0]; hull[i][1] = tmp[i][1]; }
+  *nv = k;
+  k = orc_convex_hull_2d(np0, pts0, tmp);
+  if (k > NEP_HULL_MAX_V) k = NEP_HULL_MAX_V;
+  for (int i = 0; i < k; i++) { hull0[i][0] = tmp[i][0]; hull0[i][1] = tmp[i][1]; }
+  *nv0 = k;
+}
+
+int orc_inflate_static(int nv, const double (*v)[2], double sd, double (*out)[2]) {
+  double pts[64][2];
+  int np = 0;
+  for (int j = 0; j < nv && np + 4 <= 64; j++) { /* neptune.cpp:648-657 */
+    pts[np][0] = v[j][0] + sd; pts[np][1] = v[j][1] + sd; np++;
+    pts[np][0] = v[j][0] + sd; pts[np][1] = v[j][1] - sd; np++;
+    pts[np][0] = v[j][0] - sd; pts[np][1] = v[j][1] - sd; np++;
+    pts[np][0] = v[j][0] - sd; pts[np][1] = v[j][1] + sd; np++;
+  }
+  return orc_convex_hull_2d(np, pts, out);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Separator (separator_glpk.cpp:248-373; 3-set :375-498 == A := A u A+)                       */
+/* ------------------------------------------------------------------------------------------ */
+#define SEP_MIN_GAP 1e-7
+
+/* The LP  find (n,d): n.a+d >= 1 (a in A), n.b+d <= -1 (b in B), zero objective, has as
+ * vertices exactly the lines through two points of one set that support the other set's
+ * nearest point (3 tight rows); GLPK returns whichever vertex its pivoting reaches.  This
+ * restatement returns the vertex with the largest geometric gap, ties to the first candidate
+ * in the order: pairs (p<q) of A, then pairs of B, each tried in both orientations. */
+static void sep_try(const double n[2], int nA, const double (*A)[2], int nB, const double (*B)[2],
+                    double* best_gap, double nd[3]) {
+  double len2 = n[0] * n[0] + n[1] * n[1];
+  if (!(len2 > 0.0)) return;
+  double minA = INFINITY, maxA = -INFINITY, minB = INFINITY, maxB = -INFINITY;
+  for (int i = 0; i < nA; i++) { double t = n[0] * A[i][0] + n[1] * A[i][1]; if (t < minA) minA = t; if (t > maxA) maxA = t; }
+  for (int i = 0; i < nB; i++) { double t = n[0] * B[i][0] + n[1] * B[i][1]; if (t < minB) minB = t; if (t > maxB) maxB = t; }
+  double len = sqrt(len2);
+  double g1 = (minA - maxB) / len; /* +n points toward A */
+  double g2 = (minB - maxA) / len; /* -n points toward A */
+  if (g1 >= g2) {
+    if (g1 > *best_gap) { double s = 2.0 / g1; *best_gap = g1; nd[0] = s * (n[0] / len); nd[1] = s * (n[1] / len); nd[2] = 1.0 - s * (minA / len); }
+  } else {
+    if (g2 > *best_gap) { double s = 2.0 / g2; *best_gap = g2; nd[0] = s * (-n[0] / len); nd[1] = s * (-n[1] / len); nd[2] = 1.0 - s * (-maxA / len); }
+  }
+}
+
+int orc_separator(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]) {
+  double best = SEP_MIN_GAP;
+  double cand[3] = {0, 0, 0};
+  for (int p = 0; p < nA; p++)
+    for (int q = p + 1; q < nA; q++) {
+      double n[2] = {-(A[q][1] - A[p][1]), A[q][0] - A[p][0]};
+      sep_try(n, nA, A, nB, B, &best, cand);
+    }
+  for (int p = 0; p < nB; p++)
+    for (int q = p + 1; q < nB; q++) {
+      double n[2] = {-(B[q][1] - B[p][1]), B[q][0] - B[p][0]};
+      sep_try(n, nA, A, nB, B, &best, cand);
+    }
+  if (!(best > SEP_MIN_GAP)) { /* degenerate sets (all pairs coincident): centroid direction */
+    double ca[2] = {0, 0}, cb[2] = {0, 0};
+    for (int i = 0; i < nA; i++) { ca[0] += A[i][0]; ca[1] += A[i][1]; }
+    for (int i = 0; i < nB; i++) { cb[0] += B[i][0]; cb[1] += B[i][1]; }
+    if (nA > 0 && nB > 0) {
+      double n[2] = {ca[0] / nA - cb[0] / nB, ca[1] / nA - cb[1] / nB};
+      sep_try(n, nA, A, nB, B, &best, cand);
+    }
+  }
+  if (best > SEP_MIN_GAP) { nd[0] = cand[0]; nd[1] = cand[1]; nd[2] = cand[2]; return 1; }
+  nd[0] = nd[1] = nd[2] = 0.0;
+  return 0;
+}
+
+/* Two-phase primal simplex, Bland's rule, dense tableau.  Rows: A: a.x+d - u = 1 ; B: -(b.x+d)
+ * - u = 1 with x = x+ - x- (6 columns), surplus u >= 0, one artificial per row. */
+int orc_separator_simplex(int nA, const double (*A)[2], int nB, const double (*B)[2],
+                          double nd[3]) {
+  int m = nA + nB;
+  if (m <= 0 || m > 40) return 0;
+  int nv = 6 + m + m; /* x+-(6), surplus(m), artificial(m) */
+  double* T = (double*)calloc((size_t)(m + 1) * (nv + 1), sizeof(double));
+  int* basis = (int*)malloc(sizeof(int) * m);
+#define TB(r, c) T[(r) * (nv + 1) + (c)]
+  for (int r = 0; r < m; r++) {
+    double px, py, sg;
+    if (r < nA) { px = A[r][0]; py = A[r][1]; sg = 1.0; } else { px = B[r - nA][0]; py = B[r - nA][1]; sg = -1.0; }
+    double c3[3] = {sg * px, sg * py, sg};
+    for (int j = 0; j < 3; j++) { TB(r, 2 * j) = c3[j]; TB(r, 2 * j + 1) = -c3[j]; }
+    TB(r, 6 + r) = -1.0;
+    TB(r, 6 + m + r) = 1.0;
+    TB(r, nv) = 1.0;
+    basis[r] = 6 + m + r;
+  }
+  /* phase-1 cost row: minimise sum of artificials -> reduced costs = -(sum of rows) */
+  for (int c = 0; c <= nv; c++) { double s = 0; for (int r = 0; r < m; r++) s += TB(r, c); TB(m, c) = -s; }
+  for (int r = 0; r < m; r++) TB(m, 6 + m + r) = 0.0;
+  int ok = 0;
+  for (int it = 0; it < 2000; it++) {
+    int enter = -1;
+    for (int c = 0; c < 6 + m; c++) if (TB(m, c) < -1e-9) { enter = c; break; } /* Bland */
+    if (enter < 0) break;
+    int leave = -1; double best = 0;
+    for (int r = 0; r < m; r++) if (TB(r, enter) > 1e-9) {
+      double ratio = TB(r, nv) / TB(r, enter);
+      if (leave < 0 || ratio < best - 1e-12 || (fabs(ratio - best) <= 1e-12 && basis[r] < basis[leave])) { leave = r; best = ratio; }
+    }
+    if (leave < 0) break; /* unbounded phase 1 cannot happen */
+    double pv = TB(leave, enter);
+    for (int c = 0; c <= nv; c++) TB(leave, c) /= pv;
+    for (int r = 0; r <= m; r++) if (r != leave) {
+      double f = TB(r, enter);
+      if (f != 0.0) for (int c = 0; c <= nv; c++) TB(r, c) -= f * TB(leave, c);
+    }
+    basis[leave] = enter;
+  }
+  if (-TB(m, nv) < 1e-7) { /* sum of artificials == 0 -> feasible */
+    double x[6] = {0, 0, 0, 0, 0, 0};
+    for (int r = 0; r < m; r++) if (basis[r] < 6) x[basis[r]] = TB(r, nv);
+    nd[0] = x[0] - x[1]; nd[1] = x[2] - x[3]; nd[2] = x[4] - x[5];
+    ok = 1;
+  }
+#undef TB
+  free(T); free(basis);
+  return ok;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Dense helpers                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static int chol(int n, double* A) { /* in place lower, row-major; returns 0 ok */
+  for (int j = 0; j < n; j++) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0.0)) return -1;
+    d = sqrt(d);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double v = A[i * n + j];
+      for (int k = 0; k < j; k++) v -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = v / d;
+    }
+  }
+  return 0;
+}
+static void chol_solve(int n, const double* L, double* b) {
+  for (int i = 0; i < n; i++) { double v = b[i]; for (int k = 0; k < i; k++) v -= L[i * n + k] * b[k]; b[i] = v / L[i * n + i]; }
+  for (int i = n - 1; i >= 0; i--) { double v = b[i]; for (int k = i + 1; k < n; k++) v -= L[k * n + i] * b[k]; b[i] = v / L[i * n + i]; }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* QP in the reference's variable space                                                        */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int nnz; int idx[8]; double val[8]; double rhs; } qrow;
+
+typedef struct {
+  int n, p, m;
+  double* P; double* q; double c0;     /* 1/2 th'P th + q'th + c0 */
+  double* E; double* e;                /* E th = e */
+  qrow* rows;                          /* row . th <= rhs */
+  int has_qc; double* C; double* cq; double cc; /* th'C th + 2 cq'th + cc <= 0 */
+} qp_t;
+
+static double qp_obj(const qp_t* Q, const double* th) {
+  int n = Q->n; double v = Q->c0;
+  for (int i = 0; i < n; i++) { double r = 0; for (int j = 0; j < n; j++) r += Q->P[i * n + j] * th[j]; v += 0.5 * th[i] * r + Q->q[i] * th[i]; }
+  return v;
+}
+static double qc_val(const qp_t* Q, const double* th, double* grad) {
+  int n = Q->n; double v = Q->cc;
+  for (int i = 0; i < n; i++) { double r = 0; for (int j = 0; j < n; j++) r += Q->C[i * n + j] * th[j]; if (grad) grad[i] = 2.0 * (r + Q->cq[i]); v += th[i] * r + 2.0 * Q->cq[i] * th[i]; }
+  return v;
+}
+
+/* Mehrotra predictor-corrector primal-dual interior point on
+ *   min 1/2 th'P th + q'th  s.t.  E th = e,  G th <= h,  c(th) <= 0.
+ * Returns 0 converged, 1 not converged (treated as "no solution", cf. the status whitelist
+ * solver_gurobi_poly.cpp:832-836). */
+static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
+  const int n = Q->n, p = Q->p, m = Q->m, qc = Q->has_qc;
+  const int mt = m + qc;
+  double* s = (double*)malloc(sizeof(double) * (mt + 1) * 12);
+  double* lam = s + (mt + 1), *ds = lam + (mt + 1), *dl = ds + (mt + 1), *rp = dl + (mt + 1), *rc = rp + (mt + 1),
+         *w = rc + (mt + 1), *gdx = w + (mt + 1), *dsa = gdx + (mt + 1), *dla = dsa + (mt + 1), *t1 = dla + (mt + 1), *t2 = t1 + (mt + 1);
+  double* M = (double*)malloc(sizeof(double) * ((size_t)n * n + (size_t)n * (p + 1) + (size_t)(p + 1) * (p + 1) + 8 * (size_t)(n + p + 1)));
+  double* MiEt = M + (size_t)n * n;              /* n x p (column c at MiEt[c*n..]) */
+  double* S = MiEt + (size_t)n * (p + 1);        /* p x p */
+  double* rd = S + (size_t)(p + 1) * (p + 1);
+  double* re = rd + (n + p + 1), *rhs = re + (n + p + 1), *dth = rhs + (n + p + 1), *dnu = dth + (n + p + 1),
+         *nu = dnu + (n + p + 1), *gq = nu + (n + p + 1), *tmpn = gq + (n + p + 1);
+  int ret = 1, it = 0;
+  double hscale = 1.0, qscale = 1.0, escale = 1.0;
+  for (int r = 0; r < m; r++) if (fabs(Q->rows[r].rhs) > hscale) hscale = fabs(Q->rows[r].rhs);
+  for (int i = 0; i < n; i++) if (fabs(Q->q[i]) > qscale) qscale = fabs(Q->q[i]);
+  for (int i = 0; i < p; i++) if (fabs(Q->e[i]) > escale) escale = fabs(Q->e[i]);
+  (void)hscale;
+  /* start: slack of the guess, floored; centred duals */
+  for (int r = 0; r < m; r++) {
+    const qrow* R = &Q->rows[r]; double a = 0;
+    for (int k = 0; k < R->nnz; k++) a += R->val[k] * th[R->idx[k]];
+    double sl = R->rhs - a; s[r] = sl > 0.1 ? sl : 0.1; lam[r] = 1.0 / s[r];
+  }
+  if (qc) { double c = qc_val(Q, th, NULL); s[m] = (-c > 1e-3) ? -c : 1e-3; lam[m] = 1.0 / s[m]; }
+  for (int i = 0; i < p; i++) nu[i] = 0.0;
+  int loose_ok = 0; double* th_loose = (double*)malloc(sizeof(double) * n);
+  int stall = 0;
+  for (it = 0; it < 100; it++) {
+    /* residuals */
+    for (int i = 0; i < n; i++) { double v = Q->q[i]; for (int j = 0; j < n; j++) v += Q->P[i * n + j] * th[j]; rd[i] = v; }
+    for (int r = 0; r < m; r++) {
+      const qrow* R = &Q->rows[r]; double a = 0;
+      for (int k = 0; k < R->nnz; k++) { a += R->val[k] * th[R->idx[k]]; rd[R->idx[k]] += R->val[k] * lam[r]; }
+      rp[r] = a + s[r] - R->rhs;
+    }
+    for (int i = 0; i < p; i++) { double a = 0; for (int j = 0; j < n; j++) { a += Q->E[i * n + j] * th[j]; rd[j] += Q->E[i * n + j] * nu[i]; } re[i] = a - Q->e[i]; }
+    if (qc) { double c = qc_val(Q, th, gq); rp[m] = c + s[m]; for (int i = 0; i < n; i++) rd[i] += lam[m] * gq[i]; }
+    double mu = 0; for (int r = 0; r < mt; r++) mu += s[r] * lam[r]; mu /= (mt > 0 ? mt : 1);
+    double nrp = 0, nrd = 0, nre = 0;
+    for (int r = 0; r < mt; r++) if (fabs(rp[r]) > nrp) nrp = fabs(rp[r]);
+    for (int i = 0; i < n; i++) if (fabs(rd[i]) > nrd) nrd = fabs(rd[i]);
+    for (int i = 0; i < p; i++) if (fabs(re[i]) > nre) nre = fabs(re[i]);
+    double obj = qp_obj(Q, th);
+    double gap = mu * mt;
+    if (nrp <= 1e-9 && nre <= 1e-9 * escale && nrd <= 1e-9 * qscale && gap <= 1e-10 * (1.0 + fabs(obj))) { ret = 0; break; }
+    if (nrp <= 1e-6 && nre <= 1e-6 * escale && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj))) { loose_ok = 1; memcpy(th_loose, th, sizeof(double) * n); }
+    /* normal matrix M = P + G'WG (+ QC terms) */
+    for (int i = 0; i < n * n; i++) M[i] = Q->P[i];
+    for (int r = 0; r < m; r++) {
+      const qrow* R = &Q->rows[r]; w[r] = lam[r] / s[r];
+      for (int a = 0; a < R->nnz; a++) for (int b = 0; b < R->nnz; b++) M[R->idx[a] * n + R->idx[b]] += w[r] * R->val[a] * R->val[b];
+    }
+    if (qc) { w[m] = lam[m] / s[m]; for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) M[i * n + j] += lam[m] * 2.0 * Q->C[i * n + j] + w[m] * gq[i] * gq[j]; }
+    if (chol(n, M)) break;
+    /* Schur complement on the equality rows */
+    for (int c = 0; c < p; c++) { double* col = MiEt + (size_t)c * n; for (int j = 0; j < n; j++) col[j] = Q->E[c * n + j]; chol_solve(n, M, col); }
+    double trS = 0;
+    for (int a = 0; a < p; a++) for (int b = 0; b < p; b++) { double v = 0; for (int j = 0; j < n; j++) v += Q->E[a * n + j] * MiEt[(size_t)b * n + j]; S[a * p + b] = v; if (a == b) trS += v; }
+    for (int a = 0; a < p; a++) S[a * p + a] += 1e-13 * (trS / (p > 0 ? p : 1)) + 1e-300;
+    if (p > 0 && chol(p, S)) break;
+    double alpha = 1.0, sigma = 0.0;
+    for (int pass = 0; pass < 2; pass++) {
+      /* r_c: affine = s*lam ; corrector = s*lam - sigma*mu + dsa*dla */
+      for (int r = 0; r < mt; r++) rc[r] = (pass == 0) ? s[r] * lam[r] : s[r] * lam[r] - sigma * mu + dsa[r] * dla[r];
+      /* rhs1 = -rd + G'(rc/s - W rp) */
+      for (int i = 0; i < n; i++) rhs[i] = -rd[i];
+      for (int r = 0; r < m; r++) { const qrow* R = &Q->rows[r]; double v = rc[r] / s[r] - w[r] * rp[r]; for (int k = 0; k < R->nnz; k++) rhs[R->idx[k]] += R->val[k] * v; }
+      if (qc) { double v = rc[m] / s[m] - w[m] * rp[m]; for (int i = 0; i < n; i++) rhs[i] += gq[i] * v; }
+      for (int i = 0; i < n; i++) dth[i] = rhs[i];
+      chol_solve(n, M, dth); /* y = M^-1 rhs1 */
+      for (int a = 0; a < p; a++) { double v = re[a]; for (int j = 0; j < n; j++) v += Q->E[a * n + j] * dth[j]; dnu[a] = v; } /* E y - rhs2, rhs2 = -re */
+      if (p > 0) chol_solve(p, S, dnu);
+      for (int c = 0; c < p; c++) { const double* col = MiEt + (size_t)c * n; for (int j = 0; j < n; j++) dth[j] -= col[j] * dnu[c]; }
+      for (int r = 0; r < m; r++) { const qrow* R = &Q->rows[r]; double a = 0; for (int k = 0; k < R->nnz; k++) a += R->val[k] * dth[R->idx[k]]; gdx[r] = a; }
+      if (qc) { double a = 0; for (int i = 0; i < n; i++) a += gq[i] * dth[i]; gdx[m] = a; }
+      for (int r = 0; r < mt; r++) { ds[r] = -rp[r] - gdx[r]; dl[r] = -rc[r] / s[r] + w[r] * (rp[r] + gdx[r]); }
+      alpha = 1.0;
+      for (int r = 0; r < mt; r++) {
+        if (ds[r] < 0) { double a = -s[r] / ds[r]; if (a < alpha) alpha = a; }
+        if (dl[r] < 0) { double a = -lam[r] / dl[r]; if (a < alpha) alpha = a; }
+      }
+      if (pass == 0) {
+        double mua = 0; for (int r = 0; r < mt; r++) mua += (s[r] + alpha * ds[r]) * (lam[r] + alpha * dl[r]);
+        mua /= (mt > 0 ? mt : 1);
+        double rr = mua / mu; sigma = rr * rr * rr;
+        for (int r = 0; r < mt; r++) { dsa[r] = ds[r]; dla[r] = dl[r]; }
+      }
+    }
+    alpha *= 0.995; if (alpha > 1.0) alpha = 1.0;
+    if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;
+    for (int i = 0; i < n; i++) th[i] += alpha * dth[i];
+    for (int i = 0; i < p; i++) nu[i] += alpha * dnu[i];
+    for (int r = 0; r < mt; r++) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; }
+    (void)t1; (void)t2; (void)tmpn;
+  }
+  if (ret != 0 && loose_ok) { memcpy(th, th_loose, sizeof(double) * n); ret = 0; }
+  *iters_out = it;
+  free(th_loose); free(M); free(s);
+  return ret;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* PolySolverGurobi::optimize                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+#define VAR(ax, seg, j) ((ax) * 4 * K + (seg) * 4 + (j))
+
+static void add_line_rows(qrow* rows, int* m, int K, int seg, const double M4[4][4], const double nd[3]) {
+  /* solver_gurobi_poly.cpp:485-489: ctrl_pt_x[k]*n1 + ctrl_pt_y[k]*n2 + d - 1 <= 0 */
+  for (int k = 0; k < 4; k++) {
+    qrow* R = &rows[(*m)++]; R->nnz = 8;
+    for (int j = 0; j < 4; j++) { R->idx[j] = VAR(0, seg, j); R->val[j] = nd[0] * M4[j][k]; R->idx[4 + j] = VAR(1, seg, j); R->val[4 + j] = nd[1] * M4[j][k]; }
+    R->rhs = 1.0 - nd[2];
+  }
+}
+
+int orc_optimize(const orc_params* par, int K, const double coeff_init[3][NEP_MAX_POL][4],
+                 int n_obst, const orc_polys* hulls, const orc_polys* statics,
+                 const orc_ent* ent, int override_n, const int* override_seg,
+                 const double (*override_nd)[3], orc_result* out) {
+  const double T = par->T_span, wgt = par->weight;
+  const int n = 12 * K;
+  double M4[4][4], V3[3][3];
+  pos_inv_T(T, M4); vel_inv321_T(T, V3);
+  const double tp[4] = {T * T * T, T * T, T, 1.0};       /* q_p_term :126 */
+  const double qv[4] = {3 * (T * T), 2 * T, 1.0, 0.0};   /* q_v_term :128 */
+  const double qa[4] = {6 * T, 2.0, 0.0, 0.0};           /* q_a_term :129 */
+  memset(out, 0, sizeof(*out));
+  /* setInitTrajectory :226-243 */
+  double final_pos[3], ctrl[NEP_MAX_POL][4][2];
+  for (int ax = 0; ax < 3; ax++) { const double* c = coeff_init[ax][K - 1]; final_pos[ax] = ((tp[0] * c[0] + tp[1] * c[1]) + tp[2] * c[2]) + tp[3] * c[3]; }
+  for (int i = 0; i < K; i++) for (int ax = 0; ax < 2; ax++) { double Q[4]; orc_pos_ctrl_pts(coeff_init[ax][i], T, Q); for (int k = 0; k < 4; k++) ctrl[i][k][ax] = Q[k]; }
+  double long_length = sqrt((par->maxs[0] - par->mins[0]) * (par->maxs[0] - par->mins[0]) + (par->maxs[1] - par->mins[1]) * (par->maxs[1] - par->mins[1])); /* :173 */
+
+  /* ---- rows (addConstraints :385-710) ---- */
+  int n_st = statics ? statics->n : 0;
+  int cap = 48 * K + 4 * (K * (n_obst + par->num_agents + n_st + par->num_agents * (NEP_MAX_BEND + 1)) + (override_n > 0 ? override_n : 0)) + 16;
+  qrow* rows = (qrow*)calloc((size_t)cap, sizeof(qrow));
+  int m = 0, nl = 0;
+  for (int i = 0; i < K; i++) {
+    for (int ax = 0; ax < 3; ax++) { /* :437-471 */
+      for (int k = 0; k < 4; k++) {
+        qrow* R = &rows[m++]; R->nnz = 4; for (int j = 0; j < 4; j++) { R->idx[j] = VAR(ax, i, j); R->val[j] = M4[j][k]; } R->rhs = par->maxs[ax];
+        R = &rows[m++]; R->nnz = 4; for (int j = 0; j < 4; j++) { R->idx[j] = VAR(ax, i, j); R->val[j] = -M4[j][k]; } R->rhs = -par->mins[ax];
+      }
+      for (int k = 0; k < 3; k++) {
+        qrow* R = &rows[m++]; R->nnz = 3; for (int j = 0; j < 3; j++) { R->idx[j] = VAR(ax, i, j); R->val[j] = V3[j][k]; } R->rhs = par->v_max;
+        R = &rows[m++]; R->nnz = 3; for (int j = 0; j < 3; j++) { R->idx[j] = VAR(ax, i, j); R->val[j] = -V3[j][k]; } R->rhs = par->v_max;
+      }
+      qrow* R = &rows[m++]; R->nnz = 2; R->idx[0] = VAR(ax, i, 0); R->val[0] = T * 6; R->idx[1] = VAR(ax, i, 1); R->val[1] = 2; R->rhs = par->a_max;
+      R = &rows[m++]; R->nnz = 2; R->idx[0] = VAR(ax, i, 0); R->val[0] = -(T * 6); R->idx[1] = VAR(ax, i, 1); R->val[1] = -2; R->rhs = par->a_max;
+    }
+    if (override_n >= 0) {
+      for (int l = 0; l < override_n; l++) if (override_seg[l] == i) {
+        out->line_seg[nl] = i; memcpy(out->line_nd[nl], override_nd[l], sizeof(double) * 3); nl++;
+        add_line_rows(rows, &m, K, i, M4, override_nd[l]);
+      }
+      continue;
+    }
+    double B4[4][2]; for (int k = 0; k < 4; k++) { B4[k][0] = ctrl[i][k][0]; B4[k][1] = ctrl[i][k][1]; }
+    /* inter-agent :477-495 */
+    for (int j = 0; j < n_obst; j++) {
+      int pi = j * par->num_pol + i; int o = hulls->off[pi], nv = hulls->off[pi + 1] - o; double nd[3];
+      out->n_lp++;
+      if (nv > 0 && orc_separator(nv, (const double(*)[2])(hulls->xy + 2 * o), 4, (const double(*)[2])B4, nd)) {
+        out->line_seg[nl] = i; memcpy(out->line_nd[nl], nd, sizeof(nd)); nl++; add_line_rows(rows, &m, K, i, M4, nd);
+      } else out->n_lp_failed++;
+    }
+    /* bases :521-553 */
+    const double base_radius = 0.7;
+    for (int j = 0; j < par->num_agents; j++) {
+      int close_to_base = 0;
+      for (int k = 0; k < 4; k++) { double dx = B4[k][0] - par->pb[2 * j], dy = B4[k][1] - par->pb[2 * j + 1]; if (sqrt(dx * dx + dy * dy) < base_radius * 3) { close_to_base = 1; break; } }
+      if (!close_to_base) continue;
+      double bx = par->pb[2 * j], by = par->pb[2 * j + 1];
+      double bh[4][2] = {{bx + base_radius, by + base_radius}, {bx + base_radius, by - base_radius}, {bx - base_radius, by + base_radius}, {bx - base_radius, by - base_radius}};
+      double nd[3]; out->n_lp++;
+      if (orc_separator(4, (const double(*)[2])bh, 4, (const double(*)[2])B4, nd)) { out->line_seg[nl] = i; memcpy(out->line_nd[nl], nd, sizeof(nd)); nl++; add_line_rows(rows, &m, K, i, M4, nd); }
+      else out->n_lp_failed++;
+    }
+    /* static obstacles :556-615 */
+    for (int j = 0; j < n_st; j++) {
+      int o = statics->off[j], nv = statics->off[j + 1] - o; const double(*S)[2] = (const double(*)[2])(statics->xy + 2 * o);
+      if (nv <= 0) continue;
+      int close_s = 0;
+      double dx = B4[0][0] - S[0][0], dy = B4[0][1] - S[0][1]; double dist = sqrt(dx * dx + dy * dy);
+      for (int k = 0; k < 3; k++) { double ex = B4[k + 1][0] - B4[k][0], ey = B4[k + 1][1] - B4[k][1]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = 1; break; } }
+      for (int k = 0; k < nv - 1; k++) { double ex = S[k + 1][0] - S[k][0], ey = S[k + 1][1] - S[k][1]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = 1; break; } }
+      if (!close_s) continue;
+      double nd[3]; out->n_lp++;
+      if (orc_separator(nv, S, 4, (const double(*)[2])B4, nd)) { out->line_seg[nl] = i; memcpy(out->line_nd[nl], nd, sizeof(nd)); nl++; add_line_rows(rows, &m, K, i, M4, nd); }
+      else out->n_lp_failed++;
+    }
+    /* entanglement :620-642, 715-764 */
+    if (ent && ent->enabled) {
+      double hulldist = 0;
+      for (int k = 0; k < 3; k++) { double ex = B4[k + 1][0] - B4[k][0], ey = B4[k + 1][1] - B4[k][1]; hulldist += sqrt(ex * ex + ey * ey); }
+      for (int j = 0; j < par->num_agents; j++) {
+        if (j == par->id - 1) continue;
+        int case_id = ent->case_id[i * par->num_agents + j];
+        if (case_id == 0) continue;
+        int nb = ent->bend_off[j + 1] - ent->bend_off[j]; const double(*bp)[2] = (const double(*)[2])(ent->bend_xy + 2 * ent->bend_off[j]);
+        int hp = j * par->num_pol + i; int ho = ent->hulls_noinfl->off[hp], hn = ent->hulls_noinfl->off[hp + 1] - ho;
+        for (int k = 1; k < nb + 1; k++) {
+          if (k == case_id) continue;
+          double pA[2], pB[2];
+          if (k == 1) {
+            if (hn <= 0) continue; const double* h0 = ent->hulls_noinfl->xy + 2 * ho;
+            pA[0] = (1 - long_length) * bp[nb - 1][0] + long_length * h0[0]; pA[1] = (1 - long_length) * bp[nb - 1][1] + long_length * h0[1];
+            pB[0] = h0[0]; pB[1] = h0[1];
+          } else if (k > 1 && k <= nb) { pA[0] = bp[k - 2][0]; pA[1] = bp[k - 2][1]; pB[0] = bp[k - 1][0]; pB[1] = bp[k - 1][1]; }
+          else continue;
+          double ax_ = pA[0] - B4[0][0], ay_ = pA[1] - B4[0][1], bx_ = pB[0] - B4[0][0], by_ = pB[1] - B4[0][1];
+          if (sqrt(ax_ * ax_ + ay_ * ay_) - hulldist > 0 && sqrt(bx_ * bx_ + by_ * by_) - hulldist > 0) continue; /* :743-745 */
+          double A2[2][2] = {{pA[0], pA[1]}, {pB[0], pB[1]}}; double nd[3]; out->n_lp++;
+          if (orc_separator(2, (const double(*)[2])A2, 4, (const double(*)[2])B4, nd)) { out->line_seg[nl] = i; memcpy(out->line_nd[nl], nd, sizeof(nd)); nl++; add_line_rows(rows, &m, K, i, M4, nd); }
+          else out->n_lp_failed++;
+        }
+      }
+    }
+  }
+  out->n_lines = nl; out->n_rows = m;
+
+  /* ---- equalities ---- */
+  int p_full = 9 * K + 6;
+  double* E = (double*)calloc((size_t)p_full * n, sizeof(double)); double* e = (double*)calloc((size_t)p_full, sizeof(double));
+  int p = 0;
+  for (int k1 = 1; k1 < 4; k1++) for (int ax = 0; ax < 3; ax++) { E[p * n + VAR(ax, 0, k1)] = 1.0; e[p] = coeff_init[ax][0][k1]; p++; } /* :390-396 */
+  for (int i = 0; i < K - 1; i++) for (int ax = 0; ax < 3; ax++) { /* :400-425 */
+    for (int k = 0; k < 4; k++) E[p * n + VAR(ax, i, k)] = tp[k]; E[p * n + VAR(ax, i + 1, 3)] = -1.0; p++;
+    for (int k = 0; k < 3; k++) E[p * n + VAR(ax, i, k)] = qv[k]; E[p * n + VAR(ax, i + 1, 2)] = -1.0; p++;
+    for (int k = 0; k < 2; k++) E[p * n + VAR(ax, i, k)] = qa[k]; E[p * n + VAR(ax, i + 1, 1)] = -2.0; p++;
+  }
+  int p_noterm = p;
+  for (int ax = 0; ax < 3; ax++) { /* :659-678 */
+    for (int k = 0; k < 3; k++) E[p * n + VAR(ax, K - 1, k)] = qv[k]; p++;
+    for (int k = 0; k < 2; k++) E[p * n + VAR(ax, K - 1, k)] = qa[k]; p++;
+  }
+  /* ---- objective :322-383 ---- */
+  double* P = (double*)calloc((size_t)n * n, sizeof(double)); double* q = (double*)calloc((size_t)n, sizeof(double)); double c0 = 0;
+  double q_jerk = 36 * T;
+  for (int i = 0; i < K; i++) for (int ax = 0; ax < 3; ax++) P[VAR(ax, i, 0) * n + VAR(ax, i, 0)] += 2.0 * q_jerk;
+  for (int ax = 0; ax < 3; ax++) {
+    for (int k1 = 0; k1 < 4; k1++) { for (int k2 = 0; k2 < 4; k2++) P[VAR(ax, K - 1, k1) * n + VAR(ax, K - 1, k2)] += 2.0 * wgt * (tp[k1] * tp[k2]); q[VAR(ax, K - 1, k1)] += -2.0 * wgt * tp[k1] * final_pos[ax]; }
+    c0 += wgt * final_pos[ax] * final_pos[ax];
+  }
+  /* ---- terminal ball :680-702 ---- */
+  double* C = (double*)calloc((size_t)n * n, sizeof(double)); double* cq = (double*)calloc((size_t)n, sizeof(double)); double cc = -0.10 * 0.10;
+  double dinit = 0; for (int ax = 0; ax < 3; ax++) { double d = coeff_init[ax][0][3] - final_pos[ax]; dinit += d * d; }
+  int has_qc = sqrt(dinit) < 1.0;
+  for (int ax = 0; ax < 3; ax++) { for (int k1 = 0; k1 < 4; k1++) { for (int k2 = 0; k2 < 4; k2++) C[VAR(ax, K - 1, k1) * n + VAR(ax, K - 1, k2)] += tp[k1] * tp[k2]; cq[VAR(ax, K - 1, k1)] += -tp[k1] * final_pos[ax]; } cc += final_pos[ax] * final_pos[ax]; }
+  out->qc_active = has_qc;
+
+  double* th = (double*)malloc(sizeof(double) * n);
+  for (int ax = 0; ax < 3; ax++) for (int i = 0; i < K; i++) for (int j = 0; j < 4; j++) th[VAR(ax, i, j)] = coeff_init[ax][i][j];
+  qp_t Q; Q.n = n; Q.p = p; Q.m = m; Q.P = P; Q.q = q; Q.c0 = c0; Q.E = E; Q.e = e; Q.rows = rows; Q.has_qc = has_qc; Q.C = C; Q.cq = cq; Q.cc = cc;
+  int it1 = 0, it2 = 0;
+  int fail = qp_solve(&Q, th, &it1);
+  out->iters_first = it1; out->iters = it1; out->status = NEP_OK;
+  if (fail) { /* :838-861 remove terminal v/a rows, add them to the cost */
+    for (int ax = 0; ax < 3; ax++) for (int k1 = 0; k1 < 3; k1++) for (int k2 = 0; k2 < 3; k2++) P[VAR(ax, K - 1, k1) * n + VAR(ax, K - 1, k2)] += 2.0 * wgt * (qv[k1] * qv[k2]);
+    for (int ax = 0; ax < 3; ax++) for (int k1 = 0; k1 < 2; k1++) for (int k2 = 0; k2 < 2; k2++) P[VAR(ax, K - 1, k1) * n + VAR(ax, K - 1, k2)] += 2.0 * wgt * (qa[k1] * qa[k2]);
+    Q.p = p_noterm;
+    for (int ax = 0; ax < 3; ax++) for (int i = 0; i < K; i++) for (int j = 0; j < 4; j++) th[VAR(ax, i, j)] = coeff_init[ax][i][j];
+    fail = qp_solve(&Q, th, &it2);
+    out->iters = it2; out->status = fail ? NEP_FAILED : NEP_RELAXED;
+  }
+  if (fail) { /* :856-859 */
+    for (int ax = 0; ax < 3; ax++) for (int i = 0; i < K; i++) for (int j = 0; j < 4; j++) out->coeff[ax][i][j] = coeff_init[ax][i][j];
+  } else {
+    for (int ax = 0; ax < 3; ax++) for (int i = 0; i < K; i++) for (int j = 0; j < 4; j++) out->coeff[ax][i][j] = th[VAR(ax, i, j)];
+    double dx = coeff_init[0][0][3] - final_pos[0], dy = coeff_init[1][0][3] - final_pos[1];
+    if (sqrt(dx * dx + dy * dy) < 1.0) for (int i = 0; i < K; i++) for (int j = 0; j < 4; j++) out->coeff[2][i][j] = coeff_init[2][i][j]; /* :879-880 */
+    out->objective = qp_obj(&Q, th); /* :882 */
+  }
+  free(th); free(C); free(cq); free(P); free(q); free(E); free(e); free(rows);
+  return out->status;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* generatePwpOut sampling (:911-934)                                                          */
+/* ------------------------------------------------------------------------------------------ */
+int orc_sample(int K, const double coeff[3][NEP_MAX_POL][4], double T_span, double dc,
+               double* states, int cap) {
+  double _t = 0; int i = 0, ns = 0;
+  while (i < K && ns < cap) {
+    double dt = _t - i * T_span;
+    double* st = states + (size_t)ns * NEP_STATE_DOUBLES;
+    for (int ax = 0; ax < 3; ax++) {
+      const double* c = coeff[ax][i];
+      st[ax] = ((c[0] * (dt * dt * dt) + c[1] * (dt * dt)) + c[2] * dt) + c[3];
+      st[3 + ax] = (c[0] * (3 * dt * dt) + c[1] * (2 * dt)) + c[2];
+      st[6 + ax] = c[0] * (6 * dt) + c[1] * 2;
+      st[9 + ax] = c[0] * 6;
+    }
+    ns++;
+    _t += dc;
+    if (_t > (i + 1) * T_span) i++;
+  }
+  return ns;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Whole replan from committed-trajectory records (neptune.cpp:1422-1435, 1514-1519)           */
+/* ------------------------------------------------------------------------------------------ */
+int orc_replan(const orc_params* par, double drone_radius, int n_rec, const nep_traj_rec* recs,
+               const nep_guess* guess, const orc_polys* statics, const int* case_id,
+               orc_result* out, double* hull_xy_out, int* hull_nv_out) {
+  const int np = par->num_pol;
+  int* off = (int*)calloc((size_t)n_rec * np + 1, sizeof(int));
+  double* xy = (double*)calloc((size_t)n_rec * np * NEP_HULL_MAX_V * 2, sizeof(double));
+  int* off0 = (int*)calloc((size_t)par->num_agents * np + 1, sizeof(int));
+  double* xy0 = (double*)calloc((size_t)par->num_agents * np * NEP_HULL_MAX_V * 2, sizeof(double));
+  int* boff = (int*)calloc((size_t)par->num_agents + 1, sizeof(int));
+  double* bxy = (double*)calloc((size_t)par->num_agents * NEP_MAX_BEND * 2, sizeof(double));
+  int n_obst = 0, nvtot = 0, nv0tot = 0;
+  /* neptune.cpp:235-263: ids 1..num_agents in order, own id and unknown ids skipped */
+  for (int id = 1; id <= par->num_agents; id++) {
+    const nep_traj_rec* r = NULL;
+    for (int k = 0; k < n_rec; k++) if (recs[k].id == id && recs[k].valid && recs[k].is_agent) { r = &recs[k]; break; }
+    int present = (id != par->id) && r != NULL;
+    for (int i = 0; i < np; i++) {
+      int nv = 0, nv0 = 0;
+      if (present) {
+        double delta[2] = {r->bbox[0] / 2.0 + drone_radius, r->bbox[1] / 2.0 + drone_radius}; /* neptune.cpp:340 */
+        double t0 = guess->t_start + i * par->T_span, t1 = guess->t_start + (i + 1) * par->T_span; /* :273-280 with deltaT = T_span */
+        double h[NEP_HULL_MAX_V][2], h0[NEP_HULL_MAX_V][2];
+        orc_hull_of_interval(&r->pwp, t0, t1, par->T_span, delta, h, &nv, h0, &nv0);
+        memcpy(xy + 2 * nvtot, h, sizeof(double) * 2 * nv); memcpy(xy0 + 2 * nv0tot, h0, sizeof(double) * 2 * nv0);
+        if (hull_xy_out) { memcpy(hull_xy_out + ((size_t)(n_obst * np + i) * NEP_HULL_MAX_V) * 2, h, sizeof(double) * 2 * nv); hull_nv_out[n_obst * np + i] = nv; }
+        nvtot += nv; off[n_obst * np + i + 1] = nvtot;
+      }
+      nv0tot += nv0; off0[(id - 1) * np + i + 1] = nv0tot;
+    }
+    if (present) n_obst++;
+    int nb = (r && id != par->id) ? r->n_bend : 0; if (nb > NEP_MAX_BEND) nb = NEP_MAX_BEND;
+    for (int b = 0; b < nb; b++) { bxy[2 * (boff[id - 1] + b)] = r->bend[b][0]; bxy[2 * (boff[id - 1] + b) + 1] = r->bend[b][1]; }
+    boff[id] = boff[id - 1] + nb;
+  }
+  orc_polys hulls = {n_obst * np, off, xy};
+  orc_polys hulls0 = {par->num_agents * np, off0, xy0};
+  orc_ent ent = {case_id != NULL, case_id, boff, bxy, &hulls0};
+  int st = orc_optimize(par, guess->K, guess->coeff, n_obst, &hulls, statics, case_id ? &ent : NULL, -1, NULL, NULL, out);
+  free(off); free(xy); free(off0); free(xy0); free(boff); free(bxy);
+  return st;
+}

@@ -1,0 +1,109 @@
+/* neptune_oracle.h — CPU restatement (plain C, fp64) of the NEPTUNE back-end path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under neptune_amd/ (the product) may include, link or call
+ * this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do, as the checker.
+ *
+ * PARITY STATUS: "parity unpinned" against a live reference run — the reference path needs
+ * Gurobi (closed), GLPK 4.65 (downloaded at build time, submodules/separator/cmake/
+ * glpk.cmake.in:6), CGAL 4.14.2 and Eigen, none of which exist in this image, and the reference
+ * has no tests/golden vectors for this path.  What pins this oracle instead:
+ * tests/golden/ (MINVO known answers; QP optima cross-checked by two independent SciPy solvers
+ * on the full 12K-variable formulation; LP feasibility cross-checked with HiGHS).
+ *
+ * Every function cites the reference lines it follows.
+ */
+#ifndef NEPTUNE_ORACLE_H
+#define NEPTUNE_ORACLE_H
+
+#include "../include/neptune_backend.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_params {
+  int num_pol, id, num_agents;
+  double T_span, weight;
+  double mins[3], maxs[3], v_max, a_max;
+  const double* pb; /* [num_agents][2] */
+} orc_params;
+
+/* one obstacle polygon list in CSR */
+typedef struct orc_polys {
+  int n;
+  const int* off;   /* [n+1] */
+  const double* xy; /* [off[n]][2] */
+} orc_polys;
+
+typedef struct orc_ent {
+  int enabled;
+  const int* case_id; /* [K][num_agents]: 0 = nothing to add for (segment, agent) */
+  const int* bend_off; /* [num_agents+1] */
+  const double* bend_xy;
+  const orc_polys* hulls_noinfl; /* num_agents*num_pol polygons, id-indexed */
+} orc_ent;
+
+typedef struct orc_result {
+  int status; /* NEP_OK / NEP_RELAXED / NEP_FAILED */
+  int iters, iters_first;
+  int n_lines, n_lp, n_lp_failed, n_rows, qc_active;
+  double objective;
+  double coeff[3][NEP_MAX_POL][4];
+  /* lines actually used, row order (segment-major, reference loop order) */
+  int line_seg[8192];
+  double line_nd[8192][3];
+} orc_result;
+
+/* MINVO control points.  solver_gurobi_poly.cpp:232-243 (position), :456-461 (velocity). */
+void orc_pos_ctrl_pts(const double P[4], double T, double Q[4]);
+void orc_vel_ctrl_pts(const double P[4], double T, double Qv[3]);
+
+/* cu::convexHullOfPoints2d (cgal_utils.cpp:157-174): CCW extreme points, starting at the
+ * lexicographically smallest point; returns vertex count. */
+int orc_convex_hull_2d(int n, const double (*pts)[2], double (*out)[2]);
+
+/* Neptune::vertexesOfInterval2d + convexHullOfInterval2d (neptune.cpp:288-309, 349-452) for one
+ * committed trajectory and one interval.  hull / hull0 receive the inflated / uninflated hulls. */
+void orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_span,
+                          const double delta[2], double (*hull)[2], int* nv, double (*hull0)[2],
+                          int* nv0);
+
+/* Neptune::setStaticObst inflation (neptune.cpp:639-664). */
+int orc_inflate_static(int nv, const double (*v)[2], double safe_dist, double (*out)[2]);
+
+/* separator::Separator::solveModel 2-D (separator_glpk.cpp:248-373).  Deterministic rule: the
+ * LP vertex (two tight rows of one set + one of the other) of maximum geometric gap; returns 1
+ * if separable.  nd = (n1, n2, d) with n.a+d >= 1 on A and n.b+d <= -1 on B. */
+int orc_separator(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]);
+
+/* Same LP solved by a textbook two-phase primal simplex with Bland's rule (the algorithm class
+ * GLPK's glp_simplex implements; GLPK's own pivoting rules are not reproducible without its
+ * source).  Used only to cross-check feasibility in tests. */
+int orc_separator_simplex(int nA, const double (*A)[2], int nB, const double (*B)[2],
+                          double nd[3]);
+
+/* PolySolverGurobi::optimize (solver_gurobi_poly.cpp:804-887) for one agent.
+ *   K, coeff_init: setInitTrajectory (:187-244)
+ *   hulls: setHulls, polygons j*num_pol+i (:246-281)
+ *   statics: setStaticObstVert (:316-320)
+ *   ent: setEntStateVector + setHullsNoInflation (:283-314), may be NULL
+ *   override_n >= 0: use the given lines instead of the separator (test hook). */
+int orc_optimize(const orc_params* par, int K, const double coeff_init[3][NEP_MAX_POL][4],
+                 int n_obst, const orc_polys* hulls, const orc_polys* statics,
+                 const orc_ent* ent, int override_n, const int* override_seg,
+                 const double (*override_nd)[3], orc_result* out);
+
+/* PolySolverGurobi::generatePwpOut sampling loop (:911-934); returns number of states. */
+int orc_sample(int K, const double coeff[3][NEP_MAX_POL][4], double T_span, double dc,
+               double* states, int cap);
+
+/* Whole replan of one agent from committed-trajectory records: hulls (neptune.cpp:224-285) for
+ * every other valid agent, then orc_optimize.  case_id as in orc_ent (or NULL). */
+int orc_replan(const orc_params* par, double drone_radius, int n_rec, const nep_traj_rec* recs,
+               const nep_guess* guess, const orc_polys* statics, const int* case_id,
+               orc_result* out, double* hull_xy_out, int* hull_nv_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

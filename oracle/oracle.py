@@ -1,0 +1,229 @@
+"""ctypes front of the CPU oracle (oracle/neptune_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
+product (neptune_amd/) never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from neptune_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+MAX_LINES = 8192
+
+
+class orc_params(C.Structure):
+    _fields_ = [("num_pol", C.c_int), ("id", C.c_int), ("num_agents", C.c_int),
+                ("T_span", C.c_double), ("weight", C.c_double),
+                ("mins", C.c_double * 3), ("maxs", C.c_double * 3),
+                ("v_max", C.c_double), ("a_max", C.c_double),
+                ("pb", C.POINTER(C.c_double))]
+
+
+class orc_polys(C.Structure):
+    _fields_ = [("n", C.c_int), ("off", C.POINTER(C.c_int)), ("xy", C.POINTER(C.c_double))]
+
+
+class orc_ent(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("case_id", C.POINTER(C.c_int)),
+                ("bend_off", C.POINTER(C.c_int)), ("bend_xy", C.POINTER(C.c_double)),
+                ("hulls_noinfl", C.POINTER(orc_polys))]
+
+
+class orc_result(C.Structure):
+    _fields_ = [("status", C.c_int), ("iters", C.c_int), ("iters_first", C.c_int),
+                ("n_lines", C.c_int), ("n_lp", C.c_int), ("n_lp_failed", C.c_int),
+                ("n_rows", C.c_int), ("qc_active", C.c_int),
+                ("objective", C.c_double),
+                ("coeff", ((C.c_double * 4) * abi.NEP_MAX_POL) * 3),
+                ("line_seg", C.c_int * MAX_LINES),
+                ("line_nd", (C.c_double * 3) * MAX_LINES)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libneptune_oracle.so")
+    src = os.path.join(_HERE, "neptune_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libneptune_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libneptune_oracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        L.orc_pos_ctrl_pts.argtypes = [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
+        L.orc_vel_ctrl_pts.argtypes = [C.POINTER(C.c_double), C.c_double, C.POINTER(C.c_double)]
+        L.orc_convex_hull_2d.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_convex_hull_2d.restype = C.c_int
+        L.orc_hull_of_interval.argtypes = [C.POINTER(abi.nep_pwp), C.c_double, C.c_double,
+                                           C.c_double, C.POINTER(C.c_double), C.c_void_p,
+                                           C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_inflate_static.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_void_p]
+        L.orc_inflate_static.restype = C.c_int
+        for f in (L.orc_separator, L.orc_separator_simplex):
+            f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+            f.restype = C.c_int
+        L.orc_optimize.argtypes = [C.POINTER(orc_params), C.c_int, C.c_void_p, C.c_int,
+                                   C.POINTER(orc_polys), C.POINTER(orc_polys), C.POINTER(orc_ent),
+                                   C.c_int, C.c_void_p, C.c_void_p, C.POINTER(orc_result)]
+        L.orc_optimize.restype = C.c_int
+        L.orc_sample.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_void_p, C.c_int]
+        L.orc_sample.restype = C.c_int
+        L.orc_replan.argtypes = [C.POINTER(orc_params), C.c_double, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.POINTER(orc_polys), C.c_void_p,
+                                 C.POINTER(orc_result), C.c_void_p, C.c_void_p]
+        L.orc_replan.restype = C.c_int
+        _LIB = L
+    return _LIB
+
+
+def _c(a, dt=np.float64):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def pos_ctrl_pts(P, T):
+    P = _c(P); Q = np.zeros(4)
+    lib().orc_pos_ctrl_pts(abi.dptr(P), float(T), abi.dptr(Q))
+    return Q
+
+
+def vel_ctrl_pts(P, T):
+    P = _c(P); Q = np.zeros(3)
+    lib().orc_vel_ctrl_pts(abi.dptr(P), float(T), abi.dptr(Q))
+    return Q
+
+
+def convex_hull_2d(pts):
+    pts = _c(pts).reshape(-1, 2)
+    out = np.zeros((max(len(pts), 1) + 2, 2))
+    k = lib().orc_convex_hull_2d(len(pts), pts.ctypes.data, out.ctypes.data)
+    return out[:k].copy()
+
+
+def hull_of_interval(pwp, t0, t1, T_span, delta):
+    d = _c(delta)
+    h = np.zeros((abi.NEP_HULL_MAX_V, 2)); h0 = np.zeros((abi.NEP_HULL_MAX_V, 2))
+    nv = C.c_int(0); nv0 = C.c_int(0)
+    lib().orc_hull_of_interval(C.byref(pwp), t0, t1, T_span, abi.dptr(d), h.ctypes.data,
+                               C.byref(nv), h0.ctypes.data, C.byref(nv0))
+    return h[:nv.value].copy(), h0[:nv0.value].copy()
+
+
+def inflate_static(verts, safe_dist):
+    v = _c(verts).reshape(-1, 2)
+    out = np.zeros((4 * len(v) + 2, 2))
+    k = lib().orc_inflate_static(len(v), v.ctypes.data, float(safe_dist), out.ctypes.data)
+    return out[:k].copy()
+
+
+def separator(A, B, simplex=False):
+    A = _c(A).reshape(-1, 2); B = _c(B).reshape(-1, 2)
+    nd = np.zeros(3)
+    f = lib().orc_separator_simplex if simplex else lib().orc_separator
+    ok = f(len(A), A.ctypes.data, len(B), B.ctypes.data, abi.dptr(nd))
+    return bool(ok), nd
+
+
+class Polys:
+    """CSR polygon list; keeps the numpy buffers alive."""
+
+    def __init__(self, polys):
+        self.off = np.zeros(len(polys) + 1, dtype=np.int32)
+        for i, p in enumerate(polys):
+            self.off[i + 1] = self.off[i] + len(p)
+        self.xy = _c(np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in polys])
+                     if len(polys) and self.off[-1] > 0 else np.zeros((0, 2)))
+        self.c = orc_polys(len(polys), self.off.ctypes.data_as(C.POINTER(C.c_int)), abi.dptr(self.xy))
+
+
+def make_params(p, agent_id):
+    """p: neptune_amd.scene.Params-like object."""
+    pb = _c(p.pb)
+    par = orc_params(p.num_pol, agent_id, len(pb), p.T_span, p.weight,
+                     (C.c_double * 3)(p.x_min, p.y_min, p.z_min),
+                     (C.c_double * 3)(p.x_max, p.y_max, p.z_max), p.v_max, p.a_max, abi.dptr(pb))
+    par._keep = pb
+    return par
+
+
+def result_dict(res, K):
+    co = np.ctypeslib.as_array(res.coeff).copy()[:, :K, :]
+    nl = res.n_lines
+    return dict(status=res.status, iters=res.iters, iters_first=res.iters_first, n_lines=nl,
+                n_lp=res.n_lp, n_lp_failed=res.n_lp_failed, n_rows=res.n_rows,
+                qc_active=res.qc_active, objective=res.objective, coeff=co,
+                line_seg=np.ctypeslib.as_array(res.line_seg)[:nl].copy(),
+                line_nd=np.ctypeslib.as_array(res.line_nd)[:nl].copy())
+
+
+def optimize(p, agent_id, coeff_init, hulls, statics, ent=None, lines=None):
+    """PolySolverGurobi::optimize on host.  coeff_init [3][K][4]; hulls: list over
+    (obstacle j, interval i) j-major of (V,2) arrays; statics: list of (V,2) inflated polygons;
+    lines: optional (seg[], nd[][3]) override."""
+    ci = np.zeros((3, abi.NEP_MAX_POL, 4)); K = coeff_init.shape[1]; ci[:, :K, :] = coeff_init
+    par = make_params(p, agent_id)
+    H = Polys(hulls); S = Polys(statics)
+    n_obst = len(hulls) // p.num_pol
+    res = orc_result()
+    entc = None
+    keep = []
+    if ent is not None:
+        case_id = _c(ent["case_id"], np.int32)
+        bend = ent["bend"]  # list per agent of (nb,2)
+        boff = np.zeros(len(bend) + 1, dtype=np.int32)
+        for i, b in enumerate(bend):
+            boff[i + 1] = boff[i] + len(b)
+        bxy = _c(np.concatenate([np.asarray(b, dtype=np.float64).reshape(-1, 2) for b in bend])
+                 if boff[-1] > 0 else np.zeros((0, 2)))
+        H0 = Polys(ent["hulls_noinfl"])
+        entc = orc_ent(1, case_id.ctypes.data_as(C.POINTER(C.c_int)),
+                       boff.ctypes.data_as(C.POINTER(C.c_int)), abi.dptr(bxy), C.pointer(H0.c))
+        keep += [case_id, boff, bxy, H0]
+    if lines is None:
+        on, oseg, ond = -1, None, None
+    else:
+        oseg = _c(lines[0], np.int32); ond = _c(lines[1]).reshape(-1, 3); on = len(oseg)
+    lib().orc_optimize(C.byref(par), K, ci.ctypes.data, n_obst, C.byref(H.c), C.byref(S.c),
+                       C.byref(entc) if entc is not None else None, on,
+                       oseg.ctypes.data if oseg is not None else None,
+                       ond.ctypes.data if ond is not None else None, C.byref(res))
+    return result_dict(res, K)
+
+
+def sample(coeff, T_span, dc, cap=512):
+    K = coeff.shape[1]
+    ci = np.zeros((3, abi.NEP_MAX_POL, 4)); ci[:, :K, :] = coeff
+    st = np.zeros((cap, abi.NEP_STATE_DOUBLES))
+    n = lib().orc_sample(K, ci.ctypes.data, T_span, dc, st.ctypes.data, cap)
+    return st[:n].copy()
+
+
+def replan(p, agent_id, recs, guess, statics, case_id=None, want_hulls=False):
+    """Whole replan of one agent from committed-trajectory records (numpy structured arrays with
+    abi.TRAJ_REC_DTYPE / abi.GUESS_DTYPE)."""
+    par = make_params(p, agent_id)
+    S = Polys(statics)
+    recs = np.ascontiguousarray(recs)
+    g = np.ascontiguousarray(guess)
+    res = orc_result()
+    hx = hn = None
+    if want_hulls:
+        hx = np.zeros((len(recs) * p.num_pol, abi.NEP_HULL_MAX_V, 2)); hn = np.zeros(len(recs) * p.num_pol, dtype=np.int32)
+    cid = _c(case_id, np.int32) if case_id is not None else None
+    lib().orc_replan(C.byref(par), p.drone_radius, len(recs), recs.ctypes.data, g.ctypes.data,
+                     C.byref(S.c), cid.ctypes.data if cid is not None else None, C.byref(res),
+                     hx.ctypes.data if want_hulls else None, hn.ctypes.data if want_hulls else None)
+    out = result_dict(res, int(g["K"]))
+    if want_hulls:
+        out["hull_xy"] = hx; out["hull_nv"] = hn
+    return out
