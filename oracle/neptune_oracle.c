@@ -332,86 +332,140 @@ static double qc_val(const qp_t* Q, const double* th, double* grad) {
   return v;
 }
 
+/* Householder QR with column pivoting of A (rows x cols, row-major, overwritten): on return
+ * the Householder vectors are in A/beta, perm holds the column order; returns the rank. */
+static int qr_pivot(int rows, int cols, double* A, double* beta, int* perm, double tol) {
+  int kmax = rows < cols ? rows : cols, rank = 0;
+  double r00 = 0;
+  for (int j = 0; j < cols; j++) perm[j] = j;
+  for (int k = 0; k < kmax; k++) {
+    int pj = k; double best = -1;
+    for (int j = k; j < cols; j++) { double nn = 0; for (int i = k; i < rows; i++) nn += A[i * cols + j] * A[i * cols + j]; if (nn > best) { best = nn; pj = j; } }
+    if (pj != k) { for (int i = 0; i < rows; i++) { double t = A[i * cols + k]; A[i * cols + k] = A[i * cols + pj]; A[i * cols + pj] = t; } int t = perm[k]; perm[k] = perm[pj]; perm[pj] = t; }
+    double nrm = sqrt(best);
+    if (k == 0) r00 = nrm;
+    if (!(nrm > tol * (r00 > 0 ? r00 : 1.0))) break;
+    double x0 = A[k * cols + k];
+    double alpha = x0 >= 0 ? -nrm : nrm;
+    double v0 = x0 - alpha;
+    /* v = [v0, A[k+1..][k]]; beta = 2/(v'v) */
+    double vv = v0 * v0; for (int i = k + 1; i < rows; i++) vv += A[i * cols + k] * A[i * cols + k];
+    beta[k] = vv > 0 ? 2.0 / vv : 0.0;
+    for (int j = k + 1; j < cols; j++) {
+      double d = v0 * A[k * cols + j]; for (int i = k + 1; i < rows; i++) d += A[i * cols + k] * A[i * cols + j];
+      d *= beta[k];
+      A[k * cols + j] -= d * v0; for (int i = k + 1; i < rows; i++) A[i * cols + j] -= d * A[i * cols + k];
+    }
+    A[k * cols + k] = alpha; /* R diagonal; v0 kept separately */
+    beta[kmax + k] = v0;
+    rank++;
+  }
+  return rank;
+}
+/* y := Q y or Q' y for the reflectors stored by qr_pivot (A rows x cols). */
+static void qr_apply(int rows, int cols, const double* A, const double* beta, int rank, int kmax, int transpose, double* y) {
+  for (int t = 0; t < rank; t++) {
+    int k = transpose ? t : rank - 1 - t;
+    double v0 = beta[kmax + k];
+    double d = v0 * y[k]; for (int i = k + 1; i < rows; i++) d += A[i * cols + k] * y[i];
+    d *= beta[k];
+    y[k] -= d * v0; for (int i = k + 1; i < rows; i++) y[i] -= d * A[i * cols + k];
+  }
+}
+
 /* Mehrotra predictor-corrector primal-dual interior point on
  *   min 1/2 th'P th + q'th  s.t.  E th = e,  G th <= h,  c(th) <= 0.
- * Returns 0 converged, 1 not converged (treated as "no solution", cf. the status whitelist
- * solver_gurobi_poly.cpp:832-836). */
+ * The equality rows are removed numerically first (Householder QR of E': th = th_p + Z y), then
+ * the interior point runs on y with the dense rows G Z.  Returns 0 converged, 1 no solution
+ * (cf. the status whitelist solver_gurobi_poly.cpp:832-836). */
 static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   const int n = Q->n, p = Q->p, m = Q->m, qc = Q->has_qc;
   const int mt = m + qc;
-  double* s = (double*)malloc(sizeof(double) * (mt + 1) * 12);
-  double* lam = s + (mt + 1), *ds = lam + (mt + 1), *dl = ds + (mt + 1), *rp = dl + (mt + 1), *rc = rp + (mt + 1),
-         *w = rc + (mt + 1), *gdx = w + (mt + 1), *dsa = gdx + (mt + 1), *dla = dsa + (mt + 1), *t1 = dla + (mt + 1), *t2 = t1 + (mt + 1);
-  double* M = (double*)malloc(sizeof(double) * ((size_t)n * n + (size_t)n * (p + 1) + (size_t)(p + 1) * (p + 1) + 8 * (size_t)(n + p + 1)));
-  double* MiEt = M + (size_t)n * n;              /* n x p (column c at MiEt[c*n..]) */
-  double* S = MiEt + (size_t)n * (p + 1);        /* p x p */
-  double* rd = S + (size_t)(p + 1) * (p + 1);
-  double* re = rd + (n + p + 1), *rhs = re + (n + p + 1), *dth = rhs + (n + p + 1), *dnu = dth + (n + p + 1),
-         *nu = dnu + (n + p + 1), *gq = nu + (n + p + 1), *tmpn = gq + (n + p + 1);
-  int ret = 1, it = 0;
-  double hscale = 1.0, qscale = 1.0, escale = 1.0;
-  for (int r = 0; r < m; r++) if (fabs(Q->rows[r].rhs) > hscale) hscale = fabs(Q->rows[r].rhs);
-  for (int i = 0; i < n; i++) if (fabs(Q->q[i]) > qscale) qscale = fabs(Q->q[i]);
-  for (int i = 0; i < p; i++) if (fabs(Q->e[i]) > escale) escale = fabs(Q->e[i]);
-  (void)hscale;
-  /* start: slack of the guess, floored; centred duals */
+  *iters_out = 0;
+  /* ---- null space of E ---- */
+  double* Et = (double*)malloc(sizeof(double) * ((size_t)n * (p + 1) + 4 * (size_t)(n + p + 2)));
+  double* beta = Et + (size_t)n * (p + 1); int* perm = (int*)malloc(sizeof(int) * (p + 1));
+  for (int i = 0; i < p; i++) for (int j = 0; j < n; j++) Et[j * p + i] = Q->E[i * n + j]; /* n x p */
+  int kmax = n < p ? n : p;
+  int rank = p > 0 ? qr_pivot(n, p, Et, beta, perm, 1e-11) : 0;
+  /* particular solution: E' = Q R Pi'  ->  E th = e  <=>  R' (Q' th)[:rank] = (Pi' e)[:rank] */
+  double* w1 = beta + 2 * (kmax + 1); double* thp = w1 + (n + p + 2);
+  for (int i = 0; i < n; i++) w1[i] = 0.0;
+  for (int i = 0; i < rank; i++) { double v = Q->e[perm[i]]; for (int k = 0; k < i; k++) v -= Et[k * p + i] * w1[k]; w1[i] = v / Et[i * p + i]; }
+  for (int i = 0; i < n; i++) thp[i] = w1[i];
+  qr_apply(n, p, Et, beta, rank, kmax, 0, thp); /* thp = Q [w;0] */
+  double escale = 1.0, eres = 0.0;
+  for (int i = 0; i < p; i++) { if (fabs(Q->e[i]) > escale) escale = fabs(Q->e[i]); double a = -Q->e[i]; for (int j = 0; j < n; j++) a += Q->E[i * n + j] * thp[j]; if (fabs(a) > eres) eres = fabs(a); }
+  if (eres > 1e-6 * escale) { free(Et); free(perm); return 1; } /* inconsistent equalities */
+  const int ny = n - rank;
+  /* Z columns: Q e_{rank+c} */
+  double* Z = (double*)malloc(sizeof(double) * ((size_t)n * (ny + 1)));
+  for (int c = 0; c < ny; c++) { double* col = w1; for (int i = 0; i < n; i++) col[i] = 0.0; col[rank + c] = 1.0; qr_apply(n, p, Et, beta, rank, kmax, 0, col); for (int i = 0; i < n; i++) Z[i * ny + c] = col[i]; }
+  /* reduced data */
+  double* Gy = (double*)malloc(sizeof(double) * ((size_t)(m + 1) * (ny + 1) + (size_t)(m + 2)));
+  double* hy = Gy + (size_t)(m + 1) * (ny + 1);
   for (int r = 0; r < m; r++) {
     const qrow* R = &Q->rows[r]; double a = 0;
-    for (int k = 0; k < R->nnz; k++) a += R->val[k] * th[R->idx[k]];
-    double sl = R->rhs - a; s[r] = sl > 0.1 ? sl : 0.1; lam[r] = 1.0 / s[r];
+    for (int c = 0; c < ny; c++) { double v = 0; for (int k = 0; k < R->nnz; k++) v += R->val[k] * Z[R->idx[k] * ny + c]; Gy[(size_t)r * ny + c] = v; }
+    for (int k = 0; k < R->nnz; k++) a += R->val[k] * thp[R->idx[k]];
+    hy[r] = R->rhs - a;
   }
-  if (qc) { double c = qc_val(Q, th, NULL); s[m] = (-c > 1e-3) ? -c : 1e-3; lam[m] = 1.0 / s[m]; }
-  for (int i = 0; i < p; i++) nu[i] = 0.0;
-  int loose_ok = 0; double* th_loose = (double*)malloc(sizeof(double) * n);
-  int stall = 0;
+  if (ny == 0) { /* a single point: feasible or not (Gurobi FeasibilityTol 1e-6) */
+    int ok = 1;
+    for (int r = 0; r < m; r++) if (hy[r] < -1e-6) ok = 0;
+    if (qc && qc_val(Q, thp, NULL) > 1e-6) ok = 0;
+    if (ok) memcpy(th, thp, sizeof(double) * n);
+    free(Gy); free(Z); free(Et); free(perm);
+    return ok ? 0 : 1;
+  }
+  double* Py = (double*)malloc(sizeof(double) * ((size_t)ny * ny * 3 + 12 * (size_t)(ny + n + 1)));
+  double* Cy = Py + (size_t)ny * ny, *M = Cy + (size_t)ny * ny;
+  double* qy = M + (size_t)ny * ny, *y = qy + (ny + n + 1), *rd = y + (ny + n + 1), *rhs = rd + (ny + n + 1), *dy = rhs + (ny + n + 1),
+         *gq = dy + (ny + n + 1), *tn = gq + (ny + n + 1), *cqy = tn + (ny + n + 1), *yl = cqy + (ny + n + 1), *gth = yl + (ny + n + 1);
+  /* Py = Z'PZ, qy = Z'(P thp + q), Cy = Z'CZ, cqy = Z'(C thp + cq), ccy */
+  for (int i = 0; i < n; i++) { double v = Q->q[i]; for (int j = 0; j < n; j++) v += Q->P[i * n + j] * thp[j]; tn[i] = v; }
+  for (int c = 0; c < ny; c++) { double v = 0; for (int i = 0; i < n; i++) v += Z[i * ny + c] * tn[i]; qy[c] = v; }
+  for (int a = 0; a < ny; a++) for (int b = 0; b < ny; b++) { double v = 0, vc = 0; for (int i = 0; i < n; i++) { double ri = 0, rc = 0; for (int j = 0; j < n; j++) { ri += Q->P[i * n + j] * Z[j * ny + b]; rc += Q->C[i * n + j] * Z[j * ny + b]; } v += Z[i * ny + a] * ri; vc += Z[i * ny + a] * rc; } Py[a * ny + b] = v; Cy[a * ny + b] = vc; }
+  double ccy = qc_val(Q, thp, gth); /* c(thp), grad at thp */
+  for (int c = 0; c < ny; c++) { double v = 0; for (int i = 0; i < n; i++) v += Z[i * ny + c] * 0.5 * gth[i]; cqy[c] = v; }
+  double obj0 = qp_obj(Q, thp);
+  /* start at the projection of the guess */
+  for (int c = 0; c < ny; c++) { double v = 0; for (int i = 0; i < n; i++) v += Z[i * ny + c] * (th[i] - thp[i]); y[c] = v; }
+  double* s = (double*)malloc(sizeof(double) * (mt + 1) * 10);
+  double* lam = s + (mt + 1), *ds = lam + (mt + 1), *dl = ds + (mt + 1), *rp = dl + (mt + 1), *rc = rp + (mt + 1),
+         *w = rc + (mt + 1), *gdx = w + (mt + 1), *dsa = gdx + (mt + 1), *dla = dsa + (mt + 1);
+#define QCY(yv, grad, out) do { double v_ = ccy; for (int a_ = 0; a_ < ny; a_++) { double r_ = 0; for (int b_ = 0; b_ < ny; b_++) r_ += Cy[a_ * ny + b_] * (yv)[b_]; if (grad) (grad)[a_] = 2.0 * (r_ + cqy[a_]); v_ += (yv)[a_] * r_ + 2.0 * cqy[a_] * (yv)[a_]; } out = v_; } while (0)
+  for (int r = 0; r < m; r++) { double a = 0; for (int c = 0; c < ny; c++) a += Gy[(size_t)r * ny + c] * y[c]; double sl = hy[r] - a; s[r] = sl > 0.1 ? sl : 0.1; lam[r] = 1.0 / s[r]; }
+  if (qc) { double c; QCY(y, (double*)NULL, c); s[m] = (-c > 1e-3) ? -c : 1e-3; lam[m] = 1.0 / s[m]; }
+  double qscale = 1.0; for (int c = 0; c < ny; c++) if (fabs(qy[c]) > qscale) qscale = fabs(qy[c]);
+  int ret = 1, it = 0, loose_ok = 0, stall = 0;
   for (it = 0; it < 100; it++) {
-    /* residuals */
-    for (int i = 0; i < n; i++) { double v = Q->q[i]; for (int j = 0; j < n; j++) v += Q->P[i * n + j] * th[j]; rd[i] = v; }
-    for (int r = 0; r < m; r++) {
-      const qrow* R = &Q->rows[r]; double a = 0;
-      for (int k = 0; k < R->nnz; k++) { a += R->val[k] * th[R->idx[k]]; rd[R->idx[k]] += R->val[k] * lam[r]; }
-      rp[r] = a + s[r] - R->rhs;
-    }
-    for (int i = 0; i < p; i++) { double a = 0; for (int j = 0; j < n; j++) { a += Q->E[i * n + j] * th[j]; rd[j] += Q->E[i * n + j] * nu[i]; } re[i] = a - Q->e[i]; }
-    if (qc) { double c = qc_val(Q, th, gq); rp[m] = c + s[m]; for (int i = 0; i < n; i++) rd[i] += lam[m] * gq[i]; }
+    for (int a = 0; a < ny; a++) { double v = qy[a]; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; rd[a] = v; }
+    for (int r = 0; r < m; r++) { double a = 0; const double* g = Gy + (size_t)r * ny; for (int c = 0; c < ny; c++) { a += g[c] * y[c]; rd[c] += g[c] * lam[r]; } rp[r] = a + s[r] - hy[r]; }
+    if (qc) { double c; QCY(y, gq, c); rp[m] = c + s[m]; for (int a = 0; a < ny; a++) rd[a] += lam[m] * gq[a]; }
     double mu = 0; for (int r = 0; r < mt; r++) mu += s[r] * lam[r]; mu /= (mt > 0 ? mt : 1);
-    double nrp = 0, nrd = 0, nre = 0;
+    double nrp = 0, nrd = 0;
     for (int r = 0; r < mt; r++) if (fabs(rp[r]) > nrp) nrp = fabs(rp[r]);
-    for (int i = 0; i < n; i++) if (fabs(rd[i]) > nrd) nrd = fabs(rd[i]);
-    for (int i = 0; i < p; i++) if (fabs(re[i]) > nre) nre = fabs(re[i]);
-    double obj = qp_obj(Q, th);
+    for (int a = 0; a < ny; a++) if (fabs(rd[a]) > nrd) nrd = fabs(rd[a]);
+    double obj = obj0; for (int a = 0; a < ny; a++) { double v = 0; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; obj += 0.5 * y[a] * v + qy[a] * y[a]; }
     double gap = mu * mt;
-    if (nrp <= 1e-9 && nre <= 1e-9 * escale && nrd <= 1e-9 * qscale && gap <= 1e-10 * (1.0 + fabs(obj))) { ret = 0; break; }
-    if (nrp <= 1e-6 && nre <= 1e-6 * escale && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj))) { loose_ok = 1; memcpy(th_loose, th, sizeof(double) * n); }
-    /* normal matrix M = P + G'WG (+ QC terms) */
-    for (int i = 0; i < n * n; i++) M[i] = Q->P[i];
-    for (int r = 0; r < m; r++) {
-      const qrow* R = &Q->rows[r]; w[r] = lam[r] / s[r];
-      for (int a = 0; a < R->nnz; a++) for (int b = 0; b < R->nnz; b++) M[R->idx[a] * n + R->idx[b]] += w[r] * R->val[a] * R->val[b];
-    }
-    if (qc) { w[m] = lam[m] / s[m]; for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) M[i * n + j] += lam[m] * 2.0 * Q->C[i * n + j] + w[m] * gq[i] * gq[j]; }
-    if (chol(n, M)) break;
-    /* Schur complement on the equality rows */
-    for (int c = 0; c < p; c++) { double* col = MiEt + (size_t)c * n; for (int j = 0; j < n; j++) col[j] = Q->E[c * n + j]; chol_solve(n, M, col); }
-    double trS = 0;
-    for (int a = 0; a < p; a++) for (int b = 0; b < p; b++) { double v = 0; for (int j = 0; j < n; j++) v += Q->E[a * n + j] * MiEt[(size_t)b * n + j]; S[a * p + b] = v; if (a == b) trS += v; }
-    for (int a = 0; a < p; a++) S[a * p + a] += 1e-13 * (trS / (p > 0 ? p : 1)) + 1e-300;
-    if (p > 0 && chol(p, S)) break;
+    if (nrp <= 1e-9 && nrd <= 1e-9 * qscale && gap <= 1e-10 * (1.0 + fabs(obj))) { ret = 0; break; }
+    if (nrp <= 1e-6 && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj))) { loose_ok = 1; memcpy(yl, y, sizeof(double) * ny); }
+    for (int i = 0; i < ny * ny; i++) M[i] = Py[i];
+    for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; w[r] = lam[r] / s[r]; for (int a = 0; a < ny; a++) { double wa = w[r] * g[a]; for (int b = 0; b <= a; b++) M[a * ny + b] += wa * g[b]; } }
+    for (int a = 0; a < ny; a++) for (int b = a + 1; b < ny; b++) M[a * ny + b] = M[b * ny + a];
+    if (qc) { w[m] = lam[m] / s[m]; for (int a = 0; a < ny; a++) for (int b = 0; b < ny; b++) M[a * ny + b] += lam[m] * 2.0 * Cy[a * ny + b] + w[m] * gq[a] * gq[b]; }
+    if (chol(ny, M)) break;
     double alpha = 1.0, sigma = 0.0;
     for (int pass = 0; pass < 2; pass++) {
-      /* r_c: affine = s*lam ; corrector = s*lam - sigma*mu + dsa*dla */
       for (int r = 0; r < mt; r++) rc[r] = (pass == 0) ? s[r] * lam[r] : s[r] * lam[r] - sigma * mu + dsa[r] * dla[r];
-      /* rhs1 = -rd + G'(rc/s - W rp) */
-      for (int i = 0; i < n; i++) rhs[i] = -rd[i];
-      for (int r = 0; r < m; r++) { const qrow* R = &Q->rows[r]; double v = rc[r] / s[r] - w[r] * rp[r]; for (int k = 0; k < R->nnz; k++) rhs[R->idx[k]] += R->val[k] * v; }
-      if (qc) { double v = rc[m] / s[m] - w[m] * rp[m]; for (int i = 0; i < n; i++) rhs[i] += gq[i] * v; }
-      for (int i = 0; i < n; i++) dth[i] = rhs[i];
-      chol_solve(n, M, dth); /* y = M^-1 rhs1 */
-      for (int a = 0; a < p; a++) { double v = re[a]; for (int j = 0; j < n; j++) v += Q->E[a * n + j] * dth[j]; dnu[a] = v; } /* E y - rhs2, rhs2 = -re */
-      if (p > 0) chol_solve(p, S, dnu);
-      for (int c = 0; c < p; c++) { const double* col = MiEt + (size_t)c * n; for (int j = 0; j < n; j++) dth[j] -= col[j] * dnu[c]; }
-      for (int r = 0; r < m; r++) { const qrow* R = &Q->rows[r]; double a = 0; for (int k = 0; k < R->nnz; k++) a += R->val[k] * dth[R->idx[k]]; gdx[r] = a; }
-      if (qc) { double a = 0; for (int i = 0; i < n; i++) a += gq[i] * dth[i]; gdx[m] = a; }
+      for (int a = 0; a < ny; a++) rhs[a] = -rd[a];
+      for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double v = rc[r] / s[r] - w[r] * rp[r]; for (int c = 0; c < ny; c++) rhs[c] += g[c] * v; }
+      if (qc) { double v = rc[m] / s[m] - w[m] * rp[m]; for (int a = 0; a < ny; a++) rhs[a] += gq[a] * v; }
+      for (int a = 0; a < ny; a++) dy[a] = rhs[a];
+      chol_solve(ny, M, dy);
+      for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = 0; for (int c = 0; c < ny; c++) a += g[c] * dy[c]; gdx[r] = a; }
+      if (qc) { double a = 0; for (int c = 0; c < ny; c++) a += gq[c] * dy[c]; gdx[m] = a; }
       for (int r = 0; r < mt; r++) { ds[r] = -rp[r] - gdx[r]; dl[r] = -rc[r] / s[r] + w[r] * (rp[r] + gdx[r]); }
       alpha = 1.0;
       for (int r = 0; r < mt; r++) {
@@ -427,14 +481,14 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     }
     alpha *= 0.995; if (alpha > 1.0) alpha = 1.0;
     if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;
-    for (int i = 0; i < n; i++) th[i] += alpha * dth[i];
-    for (int i = 0; i < p; i++) nu[i] += alpha * dnu[i];
+    for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];
     for (int r = 0; r < mt; r++) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; }
-    (void)t1; (void)t2; (void)tmpn;
   }
-  if (ret != 0 && loose_ok) { memcpy(th, th_loose, sizeof(double) * n); ret = 0; }
+#undef QCY
+  if (ret != 0 && loose_ok) { memcpy(y, yl, sizeof(double) * ny); ret = 0; }
+  if (ret == 0) for (int i = 0; i < n; i++) { double v = thp[i]; for (int c = 0; c < ny; c++) v += Z[i * ny + c] * y[c]; th[i] = v; }
   *iters_out = it;
-  free(th_loose); free(M); free(s);
+  free(s); free(Py); free(Gy); free(Z); free(Et); free(perm);
   return ret;
 }
 

@@ -1,0 +1,48 @@
+"""Shared helpers of the parity tests."""
+import json
+import os
+
+import numpy as np
+
+from neptune_amd import scene
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_qp_cases():
+    d = np.load(os.path.join(ROOT, "tests", "golden", "qp_cases.npz"), allow_pickle=True)
+    out = []
+    for i in range(int(d["n"])):
+        c = {k[len("c%d_" % i):]: d[k] for k in d.files if k.startswith("c%d_" % i)}
+        c["tag"] = str(c["tag"]); c["K"] = int(c["K"]); c["status"] = int(c["status"])
+        c["cost"] = float(c["cost"]); c["dth"] = float(c["dth"]); c["dcost"] = float(c["dcost"])
+        out.append(c)
+    return out
+
+
+def params_of_case(c):
+    """Params for a single-agent QP case (bases far away so that no base lines appear)."""
+    p = scene.Params(num_agents=1, pb=np.full((1, 2), 1e6))
+    p.x_min, p.y_min, p.z_min = [float(x) for x in c["mins"]]
+    p.x_max, p.y_max, p.z_max = [float(x) for x in c["maxs"]]
+    p.T_span = float(c["T"]); p.weight = float(c["weight"]); p.v_max = float(c["v_max"]); p.a_max = float(c["a_max"])
+    return p
+
+
+def golden_theta_out(c):
+    """Golden optimum with the reference's z override applied (solver_gurobi_poly.cpp:879-880)."""
+    K = c["K"]; ci = c["coeff_init"]; T = float(c["T"])
+    th = c["theta"].copy()
+    tp = np.array([T ** 3, T ** 2, T, 1.0]); final = ci[:, K - 1, :] @ tp
+    if c["status"] != 2 and np.hypot(ci[0, 0, 3] - final[0], ci[1, 0, 3] - final[1]) < 1.0:
+        th[2] = ci[2]
+    return th
+
+
+def theta_tol(c):
+    """Fixtures whose two SciPy solves could not be polished carry their disagreement."""
+    return max(5e-7, 2.0 * c["dth"]) if c["dth"] > 5e-7 and c["tag"] in ("tight K8 seed11", "nostop K2") else 2e-7
+
+
+def load_kat():
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "minvo_kat.json")))
