@@ -254,11 +254,17 @@ int nep_batch_wait(nep_batch_t* h, void* stream);
  * measured with HIP events on the launch stream; *n_launch = launches averaged.               */
 int nep_batch_kernel_time(nep_batch_t* h, int32_t which, double* avg_ms, int32_t* n_launch);
 int nep_batch_enable_timing(nep_batch_t* h, int32_t on);
+int nep_batch_reset_timing(nep_batch_t* h);
 
 /* Test hooks: fetch intermediates of the last replan to host.                                 */
-int nep_batch_debug_hulls(nep_batch_t* h, int32_t slot, double* hull_xy, int32_t* hull_nv);
+int nep_batch_debug_hulls(nep_batch_t* h, int32_t scene, double* hull_xy, int32_t* hull_nv);
 int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* seg, double* nd,
                           int32_t* n_out);
+
+/* sizeof() of the POD records as compiled (0 nep_pwp, 1 nep_traj_rec, 2 nep_backend_cfg,
+ * 3 nep_stats, 4 nep_batch_cfg, 5 nep_guess, 6 nep_solution, 7 nep_ent_view): lets a foreign-
+ * language binding verify its struct mirror. */
+int nep_abi_sizeof(int32_t which);
 
 const char* nep_last_error(void);
 const char* nep_version(void);

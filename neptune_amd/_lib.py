@@ -1,0 +1,76 @@
+"""Loader of the C-ABI shared library (include/neptune_backend.h).  Fails loudly: there is no
+CPU path behind these entry points."""
+import ctypes as C
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libneptune_backend.so")
+_lib = None
+
+# every symbol include/neptune_backend.h declares
+EXPORTS = [
+    "nep_backend_create", "nep_backend_destroy", "nep_backend_set_max_values", "nep_backend_set_max_runtime",
+    "nep_backend_set_tether_length", "nep_backend_set_static_obst_vert", "nep_backend_set_init_trajectory",
+    "nep_backend_set_hulls", "nep_backend_set_hulls_no_inflation", "nep_backend_set_ent_state_vector",
+    "nep_backend_optimize", "nep_backend_generate_pwp_out", "nep_backend_get_stats", "nep_backend_debug_set_lines",
+    "nep_backend_debug_get_lines", "nep_separator_batch", "nep_hulls_batch", "nep_batch_create", "nep_batch_destroy",
+    "nep_batch_replan", "nep_batch_ent_bytes", "nep_batch_wait", "nep_batch_kernel_time", "nep_batch_enable_timing",
+    "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
+    "nep_abi_sizeof",
+]
+
+
+class BackendError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or make -C neptune_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    d, i, vp = C.c_double, C.c_int32, C.c_void_p
+    pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    L.nep_last_error.restype = C.c_char_p
+    L.nep_version.restype = C.c_char_p
+    L.nep_abi_sizeof.argtypes = [i]; L.nep_abi_sizeof.restype = C.c_int
+    L.nep_backend_create.argtypes = [C.POINTER(abi.nep_backend_cfg)]; L.nep_backend_create.restype = vp
+    L.nep_backend_destroy.argtypes = [vp]; L.nep_backend_destroy.restype = None
+    L.nep_backend_set_max_values.argtypes = [vp] + [d] * 9
+    L.nep_backend_set_max_runtime.argtypes = [vp, d]
+    L.nep_backend_set_tether_length.argtypes = [vp, d]
+    L.nep_backend_set_static_obst_vert.argtypes = [vp, i, pi, pd]
+    L.nep_backend_set_init_trajectory.argtypes = [vp, C.POINTER(abi.nep_pwp)]
+    L.nep_backend_set_hulls.argtypes = [vp, i, pi, pd]
+    L.nep_backend_set_hulls_no_inflation.argtypes = [vp, i, pi, pd]
+    L.nep_backend_set_ent_state_vector.argtypes = [vp, C.POINTER(abi.nep_ent_view)]
+    L.nep_backend_optimize.argtypes = [vp, pd]
+    L.nep_backend_generate_pwp_out.argtypes = [vp, d, d, C.POINTER(abi.nep_pwp), pd, i, pi]
+    L.nep_backend_get_stats.argtypes = [vp, C.POINTER(abi.nep_stats)]
+    L.nep_backend_debug_set_lines.argtypes = [vp, i, pi, pd]
+    L.nep_backend_debug_get_lines.argtypes = [vp, i, pi, pd, pi]
+    L.nep_separator_batch.argtypes = [i, pi, pd, pi, pd, pd, pi]
+    L.nep_hulls_batch.argtypes = [i, vp, d, i, d, d, pd, pi, pd, pi]
+    L.nep_batch_create.argtypes = [C.POINTER(abi.nep_batch_cfg)]; L.nep_batch_create.restype = vp
+    L.nep_batch_destroy.argtypes = [vp]; L.nep_batch_destroy.restype = None
+    L.nep_batch_replan.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.nep_batch_ent_bytes.argtypes = [vp]; L.nep_batch_ent_bytes.restype = C.c_int64
+    L.nep_batch_wait.argtypes = [vp, vp]
+    L.nep_batch_kernel_time.argtypes = [vp, i, pd, pi]
+    L.nep_batch_enable_timing.argtypes = [vp, i]
+    L.nep_batch_reset_timing.argtypes = [vp]
+    L.nep_batch_debug_hulls.argtypes = [vp, i, pd, pi]
+    L.nep_batch_debug_lines.argtypes = [vp, i, i, pi, pd, pi]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc < 0:
+        raise BackendError("neptune backend error %d: %s" % (rc, lib().nep_last_error().decode()))
+    return rc

@@ -1,0 +1,254 @@
+"""Host-side mirror of the reference's back-end interface over the C ABI.
+
+`PolySolver` carries the public methods of the reference's `class PolySolverGurobi`
+(reference neptune/include/solver_gurobi_poly.hpp:28-49) with the same names, argument meaning,
+call order and failure behaviour (reference neptune/src/neptune.cpp:102-107,1514-1527), on numpy
+data instead of Eigen/ROS types.  `BatchBackend` drives all local agents of a node per launch
+(device-resident records; torch only supplies device memory and streams).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+from ._lib import BackendError, check, lib
+
+
+def _csr(polys):
+    off = np.zeros(len(polys) + 1, dtype=np.int32)
+    for k, p in enumerate(polys):
+        off[k + 1] = off[k] + len(p)
+    xy = (np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in polys])
+          if len(polys) and off[-1] > 0 else np.zeros((0, 2)))
+    return off, np.ascontiguousarray(xy, dtype=np.float64)
+
+
+def make_pwp(times, coeff):
+    """times [K+1], coeff [3][K][4] -> abi.nep_pwp (mt::PieceWisePol)."""
+    p = abi.nep_pwp()
+    K = coeff.shape[1]
+    p.n_seg = K
+    for i in range(K + 1):
+        p.times[i] = float(times[i])
+    arr = np.ctypeslib.as_array(p.coeff)
+    arr[:, :K, :] = coeff
+    return p
+
+
+class PolySolver:
+    """Drop-in for PolySolverGurobi (solver_gurobi_poly.hpp:25-49)."""
+
+    def __init__(self, num_pol, deg_pol, id, T_span, pb, weight_term, rad_term, use_linear_constraints):
+        self._pb = np.ascontiguousarray(pb, dtype=np.float64).reshape(-1, 2)
+        cfg = abi.nep_backend_cfg(num_pol, deg_pol, id, len(self._pb), T_span, weight_term, rad_term,
+                                  1 if use_linear_constraints else 0, 0, abi.dptr(self._pb))
+        self._h = lib().nep_backend_create(C.byref(cfg))
+        if not self._h:
+            raise BackendError(lib().nep_last_error().decode())
+        self.num_pol = num_pol
+        self.T_span = T_span
+        self.num_agents = len(self._pb)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().nep_backend_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ---- setters (same names as the reference) -----------------------------------------------
+    def setMaxValues(self, x_min, x_max, y_min, y_max, z_min, z_max, v_max, a_max, j_max):
+        check(lib().nep_backend_set_max_values(self._h, x_min, x_max, y_min, y_max, z_min, z_max, v_max, a_max, j_max))
+
+    def setMaxRuntime(self, runtime):
+        check(lib().nep_backend_set_max_runtime(self._h, runtime))
+
+    def setTetherLength(self, tether_length):
+        check(lib().nep_backend_set_tether_length(self._h, tether_length))
+
+    def setStaticObstVert(self, convex_hulls_of_static_obs):
+        off, xy = _csr(convex_hulls_of_static_obs)
+        check(lib().nep_backend_set_static_obst_vert(self._h, len(convex_hulls_of_static_obs), abi.iptr(off), abi.dptr(xy)))
+
+    def setInitTrajectory(self, times, coeff):
+        """pwp_init: times [K+1], coeff [3][K][4] ([a b c d] per interval, seconds)."""
+        self._K = coeff.shape[1]
+        p = make_pwp(times, np.asarray(coeff, dtype=np.float64))
+        check(lib().nep_backend_set_init_trajectory(self._h, C.byref(p)))
+
+    def setHulls(self, hulls):
+        """hulls[j][i]: (V,2) vertices, j over the other agents present, i < num_pol."""
+        flat = [h for obs in hulls for h in obs]
+        off, xy = _csr(flat)
+        check(lib().nep_backend_set_hulls(self._h, len(hulls), abi.iptr(off), abi.dptr(xy)))
+
+    def setHullsNoInflation(self, hulls):
+        """hulls[agent_id-1][i]; empty lists for self / unknown agents."""
+        flat = []
+        for obs in hulls:
+            obs = list(obs) + [np.zeros((0, 2))] * (self.num_pol - len(obs))
+            flat += obs[:self.num_pol]
+        off, xy = _csr(flat)
+        check(lib().nep_backend_set_hulls_no_inflation(self._h, len(hulls), abi.iptr(off), abi.dptr(xy)))
+
+    def setBetasVector(self, vec_of_agents):
+        """Dead in the reference (solver_gurobi_poly.cpp:290-305); accepted and ignored."""
+
+    def setEntStateVector(self, ent_state_vec, bend_pts_for_agents):
+        """ent_state_vec: list (K+1) of dicts {alphas: [(agent_id, case)], active_cases: [..]};
+        bend_pts_for_agents: list per agent of (nb,2)."""
+        if ent_state_vec is None:
+            check(lib().nep_backend_set_ent_state_vector(self._h, None))
+            return
+        ns = len(ent_state_vec)
+        na = max(len(e["active_cases"]) for e in ent_state_vec)
+        aoff = np.zeros(ns + 1, dtype=np.int32)
+        al = []
+        act = np.zeros((ns, na), dtype=np.int32)
+        for k, e in enumerate(ent_state_vec):
+            al += [tuple(a) for a in e["alphas"]]
+            aoff[k + 1] = len(al)
+            act[k, :len(e["active_cases"])] = e["active_cases"]
+        alphas = np.ascontiguousarray(np.array(al, dtype=np.int32).reshape(-1, 2))
+        boff, bxy = _csr(bend_pts_for_agents)
+        v = abi.nep_ent_view(ns, na, abi.iptr(aoff), abi.iptr(alphas), abi.iptr(act), abi.iptr(boff), abi.dptr(bxy))
+        check(lib().nep_backend_set_ent_state_vector(self._h, C.byref(v)))
+
+    # ---- solve ---------------------------------------------------------------------------------
+    def optimize(self):
+        """Returns (success, objective_value).  objective_value is None when the solve failed
+        (the reference leaves its out-parameter untouched, solver_gurobi_poly.cpp:856-859)."""
+        obj = C.c_double(float("nan"))
+        st = check(lib().nep_backend_optimize(self._h, C.byref(obj)))
+        self.status = st
+        return st != abi.NEP_FAILED, (obj.value if st != abi.NEP_FAILED else None)
+
+    def generatePwpOut(self, t_start, dc):
+        """Returns (times [K+1], coeff [3][K][4], traj_out [n][12] = pos,vel,accel,jerk)."""
+        p = abi.nep_pwp()
+        cap = int(np.ceil(self.num_pol * self.T_span / dc)) + 3
+        st = np.zeros((cap, abi.NEP_STATE_DOUBLES))
+        n = C.c_int32(0)
+        check(lib().nep_backend_generate_pwp_out(self._h, t_start, dc, C.byref(p), abi.dptr(st), cap, C.byref(n)))
+        K = p.n_seg
+        return (np.array(p.times[:K + 1]), np.ctypeslib.as_array(p.coeff)[:, :K, :].copy(), st[:n.value].copy())
+
+    def stats(self):
+        s = abi.nep_stats()
+        check(lib().nep_backend_get_stats(self._h, C.byref(s)))
+        return {f: getattr(s, f) for f, _ in abi.nep_stats._fields_}
+
+    # ---- test hooks ----------------------------------------------------------------------------
+    def debugSetLines(self, seg, nd):
+        if seg is None:
+            check(lib().nep_backend_debug_set_lines(self._h, -1, None, None))
+            return
+        seg = np.ascontiguousarray(seg, dtype=np.int32); nd = np.ascontiguousarray(nd, dtype=np.float64).reshape(-1, 3)
+        check(lib().nep_backend_debug_set_lines(self._h, len(seg), abi.iptr(seg), abi.dptr(nd)))
+
+    def debugGetLines(self, cap=8192):
+        seg = np.zeros(cap, dtype=np.int32); nd = np.zeros((cap, 3)); n = C.c_int32(0)
+        check(lib().nep_backend_debug_get_lines(self._h, cap, abi.iptr(seg), abi.dptr(nd), C.byref(n)))
+        return seg[:n.value].copy(), nd[:n.value].copy()
+
+
+def separator_batch(As, Bs):
+    """Batched separator::Separator::solveModel (2-D).  As/Bs: lists of (n,2) arrays."""
+    aoff, axy = _csr(As); boff, bxy = _csr(Bs)
+    n = len(As)
+    nd = np.zeros((n, 3)); ok = np.zeros(n, dtype=np.int32)
+    check(lib().nep_separator_batch(n, abi.iptr(aoff), abi.dptr(axy), abi.iptr(boff), abi.dptr(bxy), abi.dptr(nd), abi.iptr(ok)))
+    return ok.astype(bool), nd
+
+
+def hulls_batch(recs, t_start, num_pol, T_span, drone_radius):
+    """Neptune::convexHullsOfCurve2d for committed-trajectory records (TRAJ_REC_DTYPE array)."""
+    recs = np.ascontiguousarray(recs)
+    n = len(recs)
+    hx = np.zeros((n, num_pol, abi.NEP_HULL_MAX_V, 2)); hn = np.zeros((n, num_pol), dtype=np.int32)
+    h0 = np.zeros((n, num_pol, abi.NEP_HULL_MAX_V, 2)); n0 = np.zeros((n, num_pol), dtype=np.int32)
+    check(lib().nep_hulls_batch(n, recs.ctypes.data, t_start, num_pol, T_span, drone_radius, abi.dptr(hx), abi.iptr(hn), abi.dptr(h0), abi.iptr(n0)))
+    return hx, hn, h0, n0
+
+
+class BatchBackend:
+    """All local agents of `n_scenes` scenes per launch sequence (nep_batch_* entry points)."""
+
+    def __init__(self, par, statics, first_local=0, n_local=None, n_scenes=1, device=None):
+        import torch
+        self.torch = torch
+        self.par = par
+        N = par.num_agents
+        n_local = N - first_local if n_local is None else n_local
+        self.N, self.first_local, self.n_local, self.n_scenes = N, first_local, n_local, n_scenes
+        self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self._pb = np.ascontiguousarray(par.pb, dtype=np.float64)
+        soff, sxy = _csr(statics)
+        cfg = abi.nep_batch_cfg(N, first_local, n_local, par.num_pol, len(statics), 1 if par.enable_entangle else 0,
+                                par.max_states, n_scenes, par.T_span, par.weight, par.dc, par.drone_radius,
+                                par.x_min, par.x_max, par.y_min, par.y_max, par.z_min, par.z_max, par.v_max, par.a_max,
+                                abi.dptr(self._pb), abi.iptr(soff), abi.dptr(sxy))
+        with torch.cuda.device(self.device):
+            self._h = lib().nep_batch_create(C.byref(cfg))
+        if not self._h:
+            raise BackendError(lib().nep_last_error().decode())
+        self.slots = n_scenes * n_local
+        S = self.slots
+        self.d_solution = torch.zeros(S * abi.SOLUTION_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+        self.d_states = torch.zeros(S * par.max_states * abi.NEP_STATE_DOUBLES, dtype=torch.float64, device=self.device)
+        self.d_commit = torch.zeros(S * abi.TRAJ_REC_DTYPE.itemsize, dtype=torch.uint8, device=self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().nep_batch_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def to_device(self, arr):
+        """numpy structured array -> device byte tensor."""
+        a = np.ascontiguousarray(arr)
+        return self.torch.from_numpy(a.view(np.uint8).reshape(-1).copy()).to(self.device)
+
+    def replan(self, d_committed, d_guess, d_ent=None, stream=None, want_commit=True):
+        """Enqueues one replan of every slot; tensors are device byte tensors."""
+        torch = self.torch
+        st = stream if stream is not None else torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_replan(self._h, d_committed.data_ptr(), d_guess.data_ptr(),
+                                     d_ent.data_ptr() if d_ent is not None else None,
+                                     self.d_solution.data_ptr(), self.d_states.data_ptr(),
+                                     self.d_commit.data_ptr() if want_commit else None, st.cuda_stream))
+
+    def solutions(self):
+        self.torch.cuda.synchronize(self.device)
+        return self.d_solution.cpu().numpy().view(abi.SOLUTION_DTYPE).copy()
+
+    def states(self):
+        self.torch.cuda.synchronize(self.device)
+        return self.d_states.cpu().numpy().reshape(self.slots, self.par.max_states, abi.NEP_STATE_DOUBLES).copy()
+
+    def commits(self):
+        self.torch.cuda.synchronize(self.device)
+        return self.d_commit.cpu().numpy().view(abi.TRAJ_REC_DTYPE).copy()
+
+    def enable_timing(self, on=True):
+        check(lib().nep_batch_enable_timing(self._h, 1 if on else 0))
+
+    def reset_timing(self):
+        check(lib().nep_batch_reset_timing(self._h))
+
+    def kernel_time_ms(self, which):
+        """which: 0 hulls, 1 separator, 2 QP, 3 whole sequence -> (avg ms per launch, launches)."""
+        ms = C.c_double(0); n = C.c_int32(0)
+        check(lib().nep_batch_kernel_time(self._h, which, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def debug_hulls(self, scene=0):
+        hx = np.zeros((self.N, self.par.num_pol, abi.NEP_HULL_MAX_V, 2)); hn = np.zeros((self.N, self.par.num_pol), dtype=np.int32)
+        check(lib().nep_batch_debug_hulls(self._h, scene, abi.dptr(hx), abi.iptr(hn)))
+        return hx, hn
+
+    def debug_lines(self, slot, cap=8192):
+        seg = np.zeros(cap, dtype=np.int32); nd = np.zeros((cap, 3)); n = C.c_int32(0)
+        check(lib().nep_batch_debug_lines(self._h, slot, cap, abi.iptr(seg), abi.dptr(nd), C.byref(n)))
+        return seg[:n.value].copy(), nd[:n.value].copy()

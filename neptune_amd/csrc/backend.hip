@@ -1,0 +1,585 @@
+// backend.hip — host side of the C ABI declared in include/neptune_backend.h.
+//
+// Owns device memory, tables and launch sequencing; all arithmetic of the path runs in the HIP
+// kernels (geom_kernels.hip, qp_kernels.hip).  There is no CPU fallback: without a HIP device
+// every compute entry point returns NEP_E_HIP.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nep_device.h"
+
+using namespace nep;
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail(NEP_E_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+#define HIPCHK_NULL(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { g_err = std::string(#x) + ": " + hipGetErrorString(e_); return nullptr; } } while (0)
+
+template <class T> struct DevBuf {
+  T* p = nullptr; size_t n = 0;
+  int ensure(size_t count) {
+    if (count <= n && p) return 0;
+    if (p) hipFree(p);
+    p = nullptr; n = 0;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc((void**)&p, count * sizeof(T));
+    if (e != hipSuccess) { g_err = std::string("hipMalloc: ") + hipGetErrorString(e); return NEP_E_HIP; }
+    n = count;
+    return 0;
+  }
+  void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+};
+
+constexpr size_t kLdsBudget = 150 * 1024;  // of the 160 KiB per CU
+
+// Everything both handle kinds share: tables, scratch and the launch sequence of one replan.
+struct Engine {
+  SceneParams sp{};
+  int n_scenes = 1;
+  DevBuf<QpTable> d_tables;
+  DevBuf<int> d_sched_n, d_sched_seg; DevBuf<double> d_sched_dt;
+  DevBuf<double> d_pb, d_static_xy; DevBuf<int> d_static_nv;
+  DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
+  DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_lp_stats;
+  int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
+  double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
+  std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
+  // timing
+  bool timing = false; std::vector<hipEvent_t> ev; size_t ev_used = 0;
+
+  int build_tables() {
+    if (tab_T == sp.T_span && tab_w == sp.weight && d_tables.p) return 0;
+    std::vector<QpTable> t(2 * (kMaxK + 1));
+    std::memset(t.data(), 0, t.size() * sizeof(QpTable));
+    for (int mode = 0; mode < 2; mode++) for (int K = 1; K <= kMaxK; K++) build_qp_table(K, sp.T_span, sp.weight, mode, &t[mode * (kMaxK + 1) + K]);
+    if (int e = d_tables.ensure(t.size())) return e;
+    HIPCHK(hipMemcpy(d_tables.p, t.data(), t.size() * sizeof(QpTable), hipMemcpyHostToDevice));
+    tab_T = sp.T_span; tab_w = sp.weight;
+    return 0;
+  }
+  int build_schedule(double dc, int cap) {
+    if (dc == sched_dc && cap == sched_cap && d_sched_n.p) return 0;
+    h_sched_n.assign(kMaxK + 1, 0); h_sched_seg.assign((size_t)(kMaxK + 1) * cap, 0); h_sched_dt.assign((size_t)(kMaxK + 1) * cap, 0.0);
+    for (int K = 1; K <= kMaxK; K++) h_sched_n[K] = build_sample_schedule(K, sp.T_span, dc, cap, &h_sched_seg[(size_t)K * cap], &h_sched_dt[(size_t)K * cap]);
+    if (int e = d_sched_n.ensure(h_sched_n.size())) return e;
+    if (int e = d_sched_seg.ensure(h_sched_seg.size())) return e;
+    if (int e = d_sched_dt.ensure(h_sched_dt.size())) return e;
+    HIPCHK(hipMemcpy(d_sched_n.p, h_sched_n.data(), h_sched_n.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_sched_seg.p, h_sched_seg.data(), h_sched_seg.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_sched_dt.p, h_sched_dt.data(), h_sched_dt.size() * sizeof(double), hipMemcpyHostToDevice));
+    sched_dc = dc; sched_cap = cap; sp.max_states = cap; sp.dc = dc;
+    return 0;
+  }
+  // sizes the scratch for (n_scenes x n_local) slots with sp.n_hull hull lists per scene
+  int size_scratch() {
+    const int N = sp.num_agents, np = sp.num_pol;
+    const long slots = (long)n_scenes * sp.n_local;
+    sp.lines_cap = sp.n_hull + N + sp.n_static + (sp.ent_enabled ? N * kBend : 0);
+    if (sp.lines_cap < 8) sp.lines_cap = 8;
+    const long lines_total = (long)NEP_MAX_POL * sp.lines_cap;
+    const size_t fixed = qp_lds_fixed_bytes();
+    long max_lds_lines = (long)((kLdsBudget - fixed) / 8 - 2 * 384) / 11;
+    lds_lines = (int)(lines_total < max_lds_lines ? lines_total : max_lds_lines);
+    lds_lines = (lds_lines + 1) & ~1;
+    lds_rows = 384 + 4 * lds_lines;
+    lds_bytes = fixed + (size_t)(3L * lds_lines + 2L * lds_rows) * 8;
+    rows_cap = 384 + 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
+    if (int e = d_hull_xy.ensure((size_t)n_scenes * sp.n_hull * np * kHullV * 2)) return e;
+    if (int e = d_hull_nv.ensure((size_t)n_scenes * sp.n_hull * np)) return e;
+    if (int e = d_hull0_xy.ensure((size_t)n_scenes * N * np * 2)) return e;
+    if (int e = d_hull0_nv.ensure((size_t)n_scenes * N * np)) return e;
+    if (int e = d_bend_xy.ensure((size_t)n_scenes * N * kBend * 2)) return e;
+    if (int e = d_bend_n.ensure((size_t)n_scenes * N)) return e;
+    if (int e = d_line_nd.ensure((size_t)slots * lines_total * 3)) return e;
+    if (int e = d_line_cnt.ensure((size_t)slots * NEP_MAX_POL)) return e;
+    if (int e = d_lp_stats.ensure((size_t)slots * 2)) return e;
+    if (lines_total > lds_lines) { if (int e = d_row_scratch.ensure((size_t)slots * (2L * rows_cap + 3L * (rows_cap / 4)))) return e; }
+    return 0;
+  }
+  void fill(ProblemSet& ps) {
+    ps.pb = d_pb.p; ps.static_xy = d_static_xy.p; ps.static_nv = d_static_nv.p;
+    ps.hull_xy = d_hull_xy.p; ps.hull_nv = d_hull_nv.p; ps.hull0_xy = d_hull0_xy.p; ps.hull0_nv = d_hull0_nv.p;
+    ps.bend_xy = d_bend_xy.p; ps.bend_n = d_bend_n.p;
+    ps.line_nd = d_line_nd.p; ps.line_cnt = d_line_cnt.p; ps.lp_stats = d_lp_stats.p;
+    ps.row_scratch = d_row_scratch.p; ps.rows_cap = rows_cap; ps.lds_rows = lds_rows; ps.lds_lines = lds_lines;
+  }
+  int upload_statics(int n, const int32_t* off, const double* xy) {
+    std::vector<double> sx((size_t)(n > 0 ? n : 1) * kHullV * 2, 0.0); std::vector<int> nv(n > 0 ? n : 1, 0);
+    for (int j = 0; j < n; j++) {
+      int c = off[j + 1] - off[j];
+      if (c > kHullV) return fail(NEP_E_CAP, "static obstacle with more than NEP_HULL_MAX_V vertices");
+      nv[j] = c;
+      for (int v = 0; v < c; v++) { sx[((size_t)j * kHullV + v) * 2] = xy[2 * (off[j] + v)]; sx[((size_t)j * kHullV + v) * 2 + 1] = xy[2 * (off[j] + v) + 1]; }
+    }
+    if (int e = d_static_xy.ensure(sx.size())) return e;
+    if (int e = d_static_nv.ensure(nv.size())) return e;
+    HIPCHK(hipMemcpy(d_static_xy.p, sx.data(), sx.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_static_nv.p, nv.data(), nv.size() * sizeof(int), hipMemcpyHostToDevice));
+    sp.n_static = n;
+    return 0;
+  }
+  hipEvent_t next_event() {
+    if (ev_used == ev.size()) { hipEvent_t e; hipEventCreate(&e); ev.push_back(e); }
+    return ev[ev_used++];
+  }
+  // separator + QP (+ hulls when recs != nullptr) on `st`
+  int run(const nep_traj_rec* d_recs, int n_rec, ProblemSet& ps, hipStream_t st) {
+    const int slots = n_scenes * sp.n_local;
+    SampleSched sc{d_sched_n.p, d_sched_seg.p, d_sched_dt.p};
+    if (timing) hipEventRecord(next_event(), st);
+    if (d_recs) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st);
+    if (timing) hipEventRecord(next_event(), st);
+    if (!ps.lines_override) {
+      HIPCHK(hipMemsetAsync(d_lp_stats.p, 0, (size_t)slots * 2 * sizeof(int), st));
+      launch_separator(slots, sp, ps, st);
+    }
+    if (timing) hipEventRecord(next_event(), st);
+    launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
+    if (timing) hipEventRecord(next_event(), st);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  void release() {
+    d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
+    d_static_nv.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release();
+    d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_lp_stats.release();
+    for (auto e : ev) hipEventDestroy(e);
+    ev.clear();
+  }
+};
+
+bool have_device() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
+
+__global__ void sample_kernel(const nep_solution* __restrict__ sol, int K, const int* __restrict__ seg, const double* __restrict__ dt, int ns, double* __restrict__ out) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  const int i = seg[s]; const double d = dt[s];
+  double* st = out + (long)s * NEP_STATE_DOUBLES;
+  for (int ax = 0; ax < 3; ax++) {  // solver_gurobi_poly.cpp:921-929
+    const double* c = sol->coeff[ax][i];
+    st[ax] = ((c[0] * (d * d * d) + c[1] * (d * d)) + c[2] * d) + c[3];
+    st[3 + ax] = (c[0] * (3 * d * d) + c[1] * (2 * d)) + c[2];
+    st[6 + ax] = c[0] * (6 * d) + c[1] * 2;
+    st[9 + ax] = c[0] * 6;
+  }
+}
+
+}  // namespace
+
+// =================================================================================================
+// per-agent handle
+// =================================================================================================
+struct nep_backend {
+  Engine eng;
+  nep_backend_cfg cfg{};
+  std::vector<double> pb;
+  double max_runtime = 0.05, tether = 0, j_max = 0;
+  bool have_bounds = false, have_init = false, have_hulls = false, solved = false;
+  nep_guess guess{}; std::vector<double> guess_times;
+  int n_obst = 0;
+  std::vector<double> h_hull_xy; std::vector<int> h_hull_nv;      // [n_obst][num_pol][16][2]
+  std::vector<double> h_hull0_xy; std::vector<int> h_hull0_nv;    // [N][num_pol][2]
+  std::vector<int> h_case; std::vector<double> h_bend; std::vector<int> h_bend_n; bool have_ent = false;
+  int override_n = -1; std::vector<int> ov_seg; std::vector<double> ov_nd;
+  DevBuf<nep_guess> d_guess; DevBuf<nep_solution> d_sol; DevBuf<int> d_case; DevBuf<double> d_states;
+  nep_solution h_sol{}; nep_stats stats{};
+  hipStream_t stream = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+};
+
+extern "C" {
+
+const char* nep_last_error(void) { return g_err.c_str(); }
+const char* nep_version(void) { return "neptune-amd-backend 0.1 (gfx950)"; }
+
+nep_backend_t* nep_backend_create(const nep_backend_cfg* cfg) {
+  if (!cfg || !cfg->pb) { g_err = "null cfg"; return nullptr; }
+  if (cfg->deg_pol != 3) { g_err = "deg_pol must be 3 (reference yaml: only 3 is supported)"; return nullptr; }
+  if (!cfg->use_linear_constraints) { g_err = "use_linear_constraints=false (bilinear variant) is out of scope"; return nullptr; }
+  if (cfg->num_pol < 1 || cfg->num_pol > NEP_MAX_POL) { g_err = "num_pol out of range"; return nullptr; }
+  if (cfg->id < 1 || cfg->id > cfg->num_agents) { g_err = "id out of range"; return nullptr; }
+  if (!have_device()) { g_err = "no HIP device: the back end has no CPU path"; return nullptr; }
+  nep_backend* h = new nep_backend();
+  h->cfg = *cfg; h->pb.assign(cfg->pb, cfg->pb + 2 * cfg->num_agents); h->cfg.pb = nullptr;
+  Engine& E = h->eng;
+  E.sp.num_agents = cfg->num_agents; E.sp.num_pol = cfg->num_pol; E.sp.n_static = 0; E.sp.n_hull = 0; E.sp.ent_enabled = 0;
+  E.sp.n_local = 1; E.sp.first_local = cfg->id - 1; E.sp.skip_own = 0; E.sp.T_span = cfg->T_span; E.sp.weight = cfg->weight_term;
+  E.sp.drone_radius = 0; E.n_scenes = 1;
+  HIPCHK_NULL(hipStreamCreate(&h->stream));
+  HIPCHK_NULL(hipEventCreate(&h->e0)); HIPCHK_NULL(hipEventCreate(&h->e1));
+  if (E.d_pb.ensure(h->pb.size())) { delete h; return nullptr; }
+  HIPCHK_NULL(hipMemcpy(E.d_pb.p, h->pb.data(), h->pb.size() * sizeof(double), hipMemcpyHostToDevice));
+  int32_t off0[1] = {0};
+  if (E.upload_statics(0, off0, nullptr)) { delete h; return nullptr; }
+  if (E.build_tables()) { delete h; return nullptr; }
+  return h;
+}
+
+void nep_backend_destroy(nep_backend_t* h) {
+  if (!h) return;
+  h->eng.release(); h->d_guess.release(); h->d_sol.release(); h->d_case.release(); h->d_states.release();
+  if (h->e0) hipEventDestroy(h->e0); if (h->e1) hipEventDestroy(h->e1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int nep_backend_set_max_values(nep_backend_t* h, double x_min, double x_max, double y_min, double y_max, double z_min,
+                               double z_max, double v_max, double a_max, double j_max) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  SceneParams& sp = h->eng.sp;
+  sp.mins[0] = x_min; sp.mins[1] = y_min; sp.mins[2] = z_min; sp.maxs[0] = x_max; sp.maxs[1] = y_max; sp.maxs[2] = z_max;
+  sp.v_max = v_max; sp.a_max = a_max; h->j_max = j_max;
+  sp.long_length = std::sqrt((x_max - x_min) * (x_max - x_min) + (y_max - y_min) * (y_max - y_min));
+  h->have_bounds = true;
+  return 0;
+}
+int nep_backend_set_max_runtime(nep_backend_t* h, double s) { if (!h) return fail(NEP_E_ARG, "null handle"); h->max_runtime = s; return 0; }
+int nep_backend_set_tether_length(nep_backend_t* h, double t) { if (!h) return fail(NEP_E_ARG, "null handle"); h->tether = t; return 0; }
+
+int nep_backend_set_static_obst_vert(nep_backend_t* h, int32_t n, const int32_t* off, const double* xy) {
+  if (!h || n < 0 || (n > 0 && (!off || !xy))) return fail(NEP_E_ARG, "bad static obstacle arguments");
+  int32_t off0[1] = {0};
+  return h->eng.upload_statics(n, n ? off : off0, xy);
+}
+
+int nep_backend_set_init_trajectory(nep_backend_t* h, const nep_pwp* p) {
+  if (!h || !p) return fail(NEP_E_ARG, "null argument");
+  if (p->n_seg < 1 || p->n_seg > h->cfg.num_pol) return fail(NEP_E_CAP, "initial trajectory must have 1..num_pol intervals");
+  std::memset(&h->guess, 0, sizeof(h->guess));
+  h->guess.K = p->n_seg; h->guess.t_start = 0.0;
+  for (int ax = 0; ax < 3; ax++) for (int i = 0; i < p->n_seg; i++) for (int j = 0; j < 4; j++) h->guess.coeff[ax][i][j] = p->coeff[ax][i][j];
+  h->guess_times.assign(p->times, p->times + p->n_seg + 1);
+  h->have_init = true; h->solved = false;
+  return 0;
+}
+
+int nep_backend_set_hulls(nep_backend_t* h, int32_t n_obst, const int32_t* off, const double* xy) {
+  if (!h || n_obst < 0 || (n_obst > 0 && (!off || !xy))) return fail(NEP_E_ARG, "bad hull arguments");
+  const int np = h->cfg.num_pol;
+  h->h_hull_xy.assign((size_t)(n_obst > 0 ? n_obst : 1) * np * kHullV * 2, 0.0); h->h_hull_nv.assign((size_t)(n_obst > 0 ? n_obst : 1) * np, 0);
+  for (int p = 0; p < n_obst * np; p++) {
+    int c = off[p + 1] - off[p];
+    if (c > kHullV) return fail(NEP_E_CAP, "hull with more than NEP_HULL_MAX_V vertices");
+    h->h_hull_nv[p] = c;
+    for (int v = 0; v < c; v++) { h->h_hull_xy[((size_t)p * kHullV + v) * 2] = xy[2 * (off[p] + v)]; h->h_hull_xy[((size_t)p * kHullV + v) * 2 + 1] = xy[2 * (off[p] + v) + 1]; }
+  }
+  h->n_obst = n_obst; h->have_hulls = true;
+  return 0;
+}
+
+int nep_backend_set_hulls_no_inflation(nep_backend_t* h, int32_t n_agents, const int32_t* off, const double* xy) {
+  if (!h || n_agents != h->cfg.num_agents || !off) return fail(NEP_E_ARG, "hullsNoInflation must be indexed by agent id (num_agents lists)");
+  const int np = h->cfg.num_pol;
+  h->h_hull0_xy.assign((size_t)n_agents * np * 2, 0.0); h->h_hull0_nv.assign((size_t)n_agents * np, 0);
+  for (int p = 0; p < n_agents * np; p++) {
+    int c = off[p + 1] - off[p];
+    h->h_hull0_nv[p] = c;
+    if (c > 0) { h->h_hull0_xy[(size_t)p * 2] = xy[2 * off[p]]; h->h_hull0_xy[(size_t)p * 2 + 1] = xy[2 * off[p] + 1]; }  // only col(0) is read (:722-734)
+  }
+  return 0;
+}
+
+int nep_backend_set_ent_state_vector(nep_backend_t* h, const nep_ent_view* e) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  if (!e) { h->have_ent = false; return 0; }
+  const int N = h->cfg.num_agents;
+  if (e->n_active < N) return fail(NEP_E_ARG, "active_cases rows shorter than num_agents");
+  h->h_case.assign((size_t)NEP_MAX_POL * N, 0);
+  // case id of (knot i, agent j): solver_gurobi_poly.cpp:624-631 (last matching alpha wins)
+  for (int i = 0; i < e->n_states && i < NEP_MAX_POL; i++)
+    for (int j = 0; j < N; j++) {
+      if (e->active_cases[(size_t)i * e->n_active + j] != 1) continue;
+      int cid = 0;
+      for (int a = e->alpha_off[i]; a < e->alpha_off[i + 1]; a++) if (e->alphas[2 * a] == j + 1) cid = e->alphas[2 * a + 1];
+      h->h_case[(size_t)i * N + j] = cid;
+    }
+  h->h_bend.assign((size_t)N * kBend * 2, 0.0); h->h_bend_n.assign(N, 0);
+  for (int j = 0; j < N; j++) {
+    int nb = e->bend_off[j + 1] - e->bend_off[j];
+    if (nb > kBend) return fail(NEP_E_CAP, "more than NEP_MAX_BEND bend points");
+    h->h_bend_n[j] = nb;
+    for (int b = 0; b < nb; b++) { h->h_bend[((size_t)j * kBend + b) * 2] = e->bend_xy[2 * (e->bend_off[j] + b)]; h->h_bend[((size_t)j * kBend + b) * 2 + 1] = e->bend_xy[2 * (e->bend_off[j] + b) + 1]; }
+  }
+  h->have_ent = true;
+  return 0;
+}
+
+int nep_backend_debug_set_lines(nep_backend_t* h, int32_t n, const int32_t* seg, const double* nd) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  h->override_n = n;
+  if (n > 0) { h->ov_seg.assign(seg, seg + n); h->ov_nd.assign(nd, nd + 3 * n); } else { h->ov_seg.clear(); h->ov_nd.clear(); }
+  return 0;
+}
+
+int nep_backend_optimize(nep_backend_t* h, double* objective_value) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  if (!h->have_bounds) return fail(NEP_E_STATE, "optimize before setMaxValues");
+  if (!h->have_init) return fail(NEP_E_STATE, "optimize before setInitTrajectory");
+  Engine& E = h->eng;
+  const int N = h->cfg.num_agents, np = h->cfg.num_pol;
+  E.sp.n_hull = h->have_hulls ? h->n_obst : 0;
+  E.sp.ent_enabled = h->have_ent ? 1 : 0;
+  if (int e = E.build_schedule(E.sched_dc > 0 ? E.sched_dc : 0.05, E.sched_cap > 0 ? E.sched_cap : 128)) return e;
+  if (h->override_n >= 0) {  // line buckets sized for the override
+    int per_seg[NEP_MAX_POL] = {0}; for (int l = 0; l < h->override_n; l++) { int s = h->ov_seg[l]; if (s < 0 || s >= NEP_MAX_POL) return fail(NEP_E_ARG, "override line segment out of range"); per_seg[s]++; }
+    int mx = 8; for (int s = 0; s < NEP_MAX_POL; s++) if (per_seg[s] > mx) mx = per_seg[s];
+    E.sp.n_hull = mx;  // only used to size lines_cap below
+  }
+  if (int e = E.size_scratch()) return e;
+  if (h->override_n >= 0) E.sp.n_hull = 0;
+  ProblemSet ps{};
+  E.fill(ps);
+  if (int e = h->d_guess.ensure(1)) return e;
+  if (int e = h->d_sol.ensure(1)) return e;
+  HIPCHK(hipMemcpyAsync(h->d_guess.p, &h->guess, sizeof(nep_guess), hipMemcpyHostToDevice, h->stream));
+  ps.guess = h->d_guess.p; ps.solution = h->d_sol.p; ps.states = nullptr; ps.commit = nullptr; ps.case_id = nullptr;
+  if (h->have_hulls && h->n_obst > 0 && h->override_n < 0) {
+    HIPCHK(hipMemcpyAsync(E.d_hull_xy.p, h->h_hull_xy.data(), (size_t)h->n_obst * np * kHullV * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(E.d_hull_nv.p, h->h_hull_nv.data(), (size_t)h->n_obst * np * sizeof(int), hipMemcpyHostToDevice, h->stream));
+  }
+  if (h->have_ent) {
+    if (h->h_hull0_nv.size() != (size_t)N * np) return fail(NEP_E_STATE, "setEntStateVector without setHullsNoInflation");
+    if (int e = h->d_case.ensure(h->h_case.size())) return e;
+    HIPCHK(hipMemcpyAsync(h->d_case.p, h->h_case.data(), h->h_case.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(E.d_hull0_xy.p, h->h_hull0_xy.data(), h->h_hull0_xy.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(E.d_hull0_nv.p, h->h_hull0_nv.data(), h->h_hull0_nv.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(E.d_bend_xy.p, h->h_bend.data(), h->h_bend.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(E.d_bend_n.p, h->h_bend_n.data(), h->h_bend_n.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    ps.case_id = h->d_case.p;
+  }
+  ps.lines_override = 0;
+  if (h->override_n >= 0) {
+    std::vector<double> nd((size_t)NEP_MAX_POL * E.sp.lines_cap * 3, 0.0); std::vector<int> cnt(NEP_MAX_POL, 0);
+    for (int l = 0; l < h->override_n; l++) { int s = h->ov_seg[l]; int c = cnt[s]++; for (int k = 0; k < 3; k++) nd[((size_t)s * E.sp.lines_cap + c) * 3 + k] = h->ov_nd[3 * l + k]; }
+    HIPCHK(hipMemcpyAsync(E.d_line_nd.p, nd.data(), nd.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemcpyAsync(E.d_line_cnt.p, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(E.d_lp_stats.p, 0, 2 * sizeof(int), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));  // host vectors go out of scope
+    ps.lines_override = 1;
+  }
+  HIPCHK(hipEventRecord(h->e0, h->stream));
+  if (int e = E.run(nullptr, 0, ps, h->stream)) return e;
+  HIPCHK(hipEventRecord(h->e1, h->stream));
+  HIPCHK(hipMemcpyAsync(&h->h_sol, h->d_sol.p, sizeof(nep_solution), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  float ms = 0; hipEventElapsedTime(&ms, h->e0, h->e1);
+  h->stats = h->h_sol.stats; h->stats.solve_us = ms * 1000.0;
+  h->solved = true;
+  if (h->stats.status != NEP_FAILED && objective_value) *objective_value = h->stats.objective;  // :882 (untouched on failure)
+  return h->stats.status;
+}
+
+int nep_backend_generate_pwp_out(nep_backend_t* h, double t_start, double dc, nep_pwp* pwp_out, double* states_out,
+                                 int32_t states_cap, int32_t* n_states_out) {
+  if (!h || !pwp_out) return fail(NEP_E_ARG, "null argument");
+  if (!h->have_init) return fail(NEP_E_STATE, "generatePwpOut before setInitTrajectory");
+  const int K = h->guess.K;
+  std::memset(pwp_out, 0, sizeof(*pwp_out));
+  pwp_out->n_seg = K;
+  for (int i = 0; i <= K; i++) pwp_out->times[i] = h->guess_times[i] + t_start;  // :898
+  const double (*co)[NEP_MAX_POL][4] = h->solved ? h->h_sol.coeff : h->guess.coeff;   // pwp_out_ = pwp_init_ until solved
+  for (int ax = 0; ax < 3; ax++) for (int i = 0; i < K; i++) for (int j = 0; j < 4; j++) pwp_out->coeff[ax][i][j] = co[ax][i][j];
+  if (n_states_out) *n_states_out = 0;
+  if (states_out && states_cap > 0) {
+    Engine& E = h->eng;
+    if (!h->solved) {  // sample the guess: stage it as the solution
+      nep_solution s{}; s.K = K; std::memcpy(s.coeff, h->guess.coeff, sizeof(s.coeff));
+      if (int e = h->d_sol.ensure(1)) return e;
+      HIPCHK(hipMemcpy(h->d_sol.p, &s, sizeof(s), hipMemcpyHostToDevice));
+    }
+    int cap = (int)std::ceil(h->cfg.num_pol * h->cfg.T_span / dc) + 3;
+    if (int e = E.build_schedule(dc, cap)) return e;
+    int ns = E.h_sched_n[K]; if (ns > states_cap) ns = states_cap;
+    if (int e = h->d_states.ensure((size_t)cap * NEP_STATE_DOUBLES)) return e;
+    hipLaunchKernelGGL(sample_kernel, dim3((ns + 63) / 64), dim3(64), 0, h->stream, h->d_sol.p, K, E.d_sched_seg.p + (size_t)K * cap, E.d_sched_dt.p + (size_t)K * cap, ns, h->d_states.p);
+    HIPCHK(hipMemcpyAsync(states_out, h->d_states.p, (size_t)ns * NEP_STATE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (n_states_out) *n_states_out = ns;
+  }
+  return 0;
+}
+
+int nep_backend_get_stats(nep_backend_t* h, nep_stats* out) { if (!h || !out) return fail(NEP_E_ARG, "null argument"); *out = h->stats; return 0; }
+
+int nep_backend_debug_get_lines(nep_backend_t* h, int32_t cap, int32_t* seg, double* nd, int32_t* n_out) {
+  if (!h || !n_out) return fail(NEP_E_ARG, "null argument");
+  Engine& E = h->eng;
+  std::vector<int> cnt(NEP_MAX_POL); std::vector<double> buf((size_t)NEP_MAX_POL * E.sp.lines_cap * 3);
+  HIPCHK(hipMemcpy(cnt.data(), E.d_line_cnt.p, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(buf.data(), E.d_line_nd.p, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int s = 0; s < h->guess.K; s++) for (int c = 0; c < cnt[s]; c++) { if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
+  *n_out = n;
+  return 0;
+}
+
+// =================================================================================================
+// stand-alone kernels
+// =================================================================================================
+int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy, const int32_t* b_off, const double* b_xy,
+                        double* nd_out, int32_t* solved_out) {
+  if (n_prob < 0 || !a_off || !b_off || !nd_out || !solved_out) return fail(NEP_E_ARG, "bad arguments");
+  if (!have_device()) return fail(NEP_E_HIP, "no HIP device: the back end has no CPU path");
+  if (n_prob == 0) return 0;
+  DevBuf<int> da, db, ds; DevBuf<double> dax, dbx, dnd;
+  const int na = a_off[n_prob], nb = b_off[n_prob];
+  int e = 0;
+  if ((e = da.ensure(n_prob + 1)) || (e = db.ensure(n_prob + 1)) || (e = ds.ensure(n_prob)) || (e = dax.ensure((size_t)2 * na)) || (e = dbx.ensure((size_t)2 * nb)) || (e = dnd.ensure((size_t)3 * n_prob))) return e;
+  HIPCHK(hipMemcpy(da.p, a_off, (n_prob + 1) * sizeof(int), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(db.p, b_off, (n_prob + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (na) HIPCHK(hipMemcpy(dax.p, a_xy, (size_t)2 * na * sizeof(double), hipMemcpyHostToDevice));
+  if (nb) HIPCHK(hipMemcpy(dbx.p, b_xy, (size_t)2 * nb * sizeof(double), hipMemcpyHostToDevice));
+  launch_separator_explicit(n_prob, da.p, dax.p, db.p, dbx.p, dnd.p, ds.p, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(nd_out, dnd.p, (size_t)3 * n_prob * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(solved_out, ds.p, (size_t)n_prob * sizeof(int), hipMemcpyDeviceToHost));
+  da.release(); db.release(); ds.release(); dax.release(); dbx.release(); dnd.release();
+  return 0;
+}
+
+int nep_hulls_batch(int32_t n_traj, const nep_traj_rec* trajs, double t_start, int32_t num_pol, double T_span, double drone_radius,
+                    double* hull_xy, int32_t* hull_nv, double* hull0_xy, int32_t* hull0_nv) {
+  if (n_traj < 0 || !trajs || !hull_xy || !hull_nv || !hull0_xy || !hull0_nv || num_pol < 1) return fail(NEP_E_ARG, "bad arguments");
+  if (!have_device()) return fail(NEP_E_HIP, "no HIP device: the back end has no CPU path");
+  if (n_traj == 0) return 0;
+  DevBuf<nep_traj_rec> dr; DevBuf<double> dh, dh0; DevBuf<int> dn, dn0;
+  const size_t np = (size_t)n_traj * num_pol;
+  int e = 0;
+  if ((e = dr.ensure(n_traj)) || (e = dh.ensure(np * kHullV * 2)) || (e = dh0.ensure(np * kHullV * 2)) || (e = dn.ensure(np)) || (e = dn0.ensure(np))) return e;
+  HIPCHK(hipMemcpy(dr.p, trajs, (size_t)n_traj * sizeof(nep_traj_rec), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(dh.p, 0, np * kHullV * 2 * sizeof(double))); HIPCHK(hipMemset(dh0.p, 0, np * kHullV * 2 * sizeof(double)));
+  launch_hulls_explicit(dr.p, n_traj, t_start, num_pol, T_span, drone_radius, dh.p, dn.p, dh0.p, dn0.p, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(hull_xy, dh.p, np * kHullV * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hull0_xy, dh0.p, np * kHullV * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hull_nv, dn.p, np * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hull0_nv, dn0.p, np * sizeof(int), hipMemcpyDeviceToHost));
+  dr.release(); dh.release(); dh0.release(); dn.release(); dn0.release();
+  return 0;
+}
+
+}  // extern "C"
+
+// =================================================================================================
+// batched handle
+// =================================================================================================
+struct nep_batch {
+  Engine eng;
+  nep_batch_cfg cfg{};
+  int slots = 0;
+};
+
+extern "C" {
+
+nep_batch_t* nep_batch_create(const nep_batch_cfg* c) {
+  if (!c || !c->pb) { g_err = "null cfg"; return nullptr; }
+  if (c->num_pol < 1 || c->num_pol > NEP_MAX_POL || c->num_agents < 1 || c->n_local < 1 || c->first_local < 0 ||
+      c->first_local + c->n_local > c->num_agents || c->n_scenes < 1 || c->max_states < 1) { g_err = "bad batch configuration"; return nullptr; }
+  if (!have_device()) { g_err = "no HIP device: the back end has no CPU path"; return nullptr; }
+  nep_batch* h = new nep_batch();
+  h->cfg = *c; h->cfg.pb = nullptr; h->cfg.static_off = nullptr; h->cfg.static_xy = nullptr;
+  Engine& E = h->eng; SceneParams& sp = E.sp;
+  sp.num_agents = c->num_agents; sp.num_pol = c->num_pol; sp.n_hull = c->num_agents; sp.ent_enabled = c->enable_entangle;
+  sp.n_local = c->n_local; sp.first_local = c->first_local; sp.skip_own = 1;
+  sp.T_span = c->T_span; sp.weight = c->weight_term; sp.drone_radius = c->drone_radius;
+  sp.mins[0] = c->x_min; sp.mins[1] = c->y_min; sp.mins[2] = c->z_min; sp.maxs[0] = c->x_max; sp.maxs[1] = c->y_max; sp.maxs[2] = c->z_max;
+  sp.v_max = c->v_max; sp.a_max = c->a_max;
+  sp.long_length = std::sqrt((c->x_max - c->x_min) * (c->x_max - c->x_min) + (c->y_max - c->y_min) * (c->y_max - c->y_min));
+  E.n_scenes = c->n_scenes; h->slots = c->n_scenes * c->n_local;
+  bool ok = true;
+  ok = ok && !E.d_pb.ensure((size_t)2 * c->num_agents);
+  if (ok) ok = hipMemcpy(E.d_pb.p, c->pb, (size_t)2 * c->num_agents * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
+  int32_t off0[1] = {0};
+  if (ok) ok = !E.upload_statics(c->n_static, c->n_static ? c->static_off : off0, c->static_xy);
+  if (ok) ok = !E.build_tables();
+  if (ok) ok = !E.build_schedule(c->dc, c->max_states);
+  if (ok) ok = !E.size_scratch();
+  if (!ok) { if (g_err.empty()) g_err = "batch setup failed"; E.release(); delete h; return nullptr; }
+  return h;
+}
+
+void nep_batch_destroy(nep_batch_t* h) { if (!h) return; h->eng.release(); delete h; }
+
+int64_t nep_batch_ent_bytes(const nep_batch_t* h) { return h ? (int64_t)h->slots * NEP_MAX_POL * h->cfg.num_agents * sizeof(int32_t) : 0; }
+
+int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess, const void* d_ent,
+                     nep_solution* d_solution, double* d_states, nep_traj_rec* d_commit, void* stream) {
+  if (!h || !d_committed || !d_guess || !d_solution) return fail(NEP_E_ARG, "null argument");
+  Engine& E = h->eng;
+  ProblemSet ps{};
+  E.fill(ps);
+  ps.guess = d_guess; ps.solution = d_solution; ps.states = d_states; ps.commit = d_commit;
+  ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
+  ps.lines_override = 0;
+  return E.run(d_committed, h->cfg.num_agents, ps, (hipStream_t)stream);
+}
+
+int nep_batch_wait(nep_batch_t* h, void* stream) { if (!h) return fail(NEP_E_ARG, "null handle"); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+int nep_batch_enable_timing(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.timing = on != 0; h->eng.ev_used = 0; return 0; }
+
+// which: 0 hull kernel, 1 separator kernel, 2 QP kernel, 3 whole sequence
+int nep_batch_kernel_time(nep_batch_t* h, int32_t which, double* avg_ms, int32_t* n_launch) {
+  if (!h || !avg_ms || which < 0 || which > 3) return fail(NEP_E_ARG, "bad arguments");
+  Engine& E = h->eng;
+  const size_t calls = E.ev_used / 4;
+  double tot = 0;
+  for (size_t c = 0; c < calls; c++) {
+    float ms = 0;
+    hipEvent_t a = E.ev[4 * c + (which == 3 ? 0 : which)], b = E.ev[4 * c + (which == 3 ? 3 : which + 1)];
+    HIPCHK(hipEventSynchronize(b));
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    tot += ms;
+  }
+  *avg_ms = calls ? tot / calls : 0.0;
+  if (n_launch) *n_launch = (int32_t)calls;
+  return 0;
+}
+
+int nep_batch_reset_timing(nep_batch_t* h) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.ev_used = 0; return 0; }
+
+int nep_batch_debug_hulls(nep_batch_t* h, int32_t scene, double* hull_xy, int32_t* hull_nv) {
+  if (!h || !hull_xy || !hull_nv || scene < 0 || scene >= h->cfg.n_scenes) return fail(NEP_E_ARG, "bad arguments");
+  Engine& E = h->eng; const size_t np = (size_t)E.sp.n_hull * E.sp.num_pol;
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(hull_xy, E.d_hull_xy.p + (size_t)scene * np * kHullV * 2, np * kHullV * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hull_nv, E.d_hull_nv.p + (size_t)scene * np, np * sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* seg, double* nd, int32_t* n_out) {
+  if (!h || !n_out || slot < 0 || slot >= h->slots) return fail(NEP_E_ARG, "bad arguments");
+  Engine& E = h->eng;
+  std::vector<int> cnt(NEP_MAX_POL); std::vector<double> buf((size_t)NEP_MAX_POL * E.sp.lines_cap * 3);
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(cnt.data(), E.d_line_cnt.p + (size_t)slot * NEP_MAX_POL, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(buf.data(), E.d_line_nd.p + (size_t)slot * NEP_MAX_POL * E.sp.lines_cap * 3, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int s = 0; s < NEP_MAX_POL; s++) for (int c = 0; c < cnt[s]; c++) { if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
+  *n_out = n;
+  return 0;
+}
+
+// layout self-description for the ctypes mirror (tests/test_abi.py)
+int nep_abi_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return (int)sizeof(nep_pwp);
+    case 1: return (int)sizeof(nep_traj_rec);
+    case 2: return (int)sizeof(nep_backend_cfg);
+    case 3: return (int)sizeof(nep_stats);
+    case 4: return (int)sizeof(nep_batch_cfg);
+    case 5: return (int)sizeof(nep_guess);
+    case 6: return (int)sizeof(nep_solution);
+    case 7: return (int)sizeof(nep_ent_view);
+    default: return -1;
+  }
+}
+
+}  // extern "C"

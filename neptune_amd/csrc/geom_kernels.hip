@@ -1,0 +1,436 @@
+// geom_kernels.hip — MINVO control-point hulls and separating-line LPs for gfx950.
+//
+// Built with -ffp-contract=off: these kernels are compared BIT FOR BIT with the CPU oracle, so
+// the compiler must not fuse multiply-adds (the expressions below are written in the same
+// association order as the CPU checker under oracle/).  fp64 division and sqrt are IEEE-correct on
+// CDNA4, so with contraction off the two sides produce identical bits.
+//
+// K1/K2 (reference neptune/src/neptune.cpp:269-452 + cgal_utils.cpp:157-174): one wavefront per
+//   (scene, committed trajectory, planning interval) hull: rank sort across the 64 lanes, then
+//   a monotone chain walked by lane 0 out of LDS.
+// K3/K4 (reference submodules/separator/src/separator_glpk.cpp:248-498 called from
+//   solver_gurobi_poly.cpp:477-495,521-553,556-593,715-764): one wavefront per (agent slot,
+//   segment); each lane owns one candidate obstacle, stages its points in LDS (stride 17
+//   doubles: conflict-free for ds_read_b64) and enumerates the LP's vertices; results are
+//   compacted in reference loop order with a wave ballot.
+#include <hip/hip_runtime.h>
+
+#include "nep_device.h"
+
+namespace nep {
+
+__constant__ double cAPosInv[4][4] = {
+    {-0.03203276669713047, -0.09273093424558249, 0.3420572455666699, 1.1023313949144335},
+    {-0.05111494245568798, -0.046272612998418894, 0.5458234872124772, 1.0979806946005568},
+    {-0.07454781852812224, 0.203951949894552, 0.796048050105448, 1.0745478185281223},
+    {1.0, 1.0, 0.9999999999999996, 0.9999999999999993}};
+
+#define SEP_MIN_GAP 1e-7
+#define NEP_INF (__builtin_huge_val())
+
+// ---------------------------------------------------------------------------------------------
+// hulls
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double cross3(double ox, double oy, double ax, double ay, double bx, double by) {
+  return (ax - ox) * (by - oy) - (ay - oy) * (bx - ox);
+}
+__device__ __forceinline__ bool lex_less(double ax, double ay, double bx, double by) {
+  return ax < bx || (ax == bx && ay < by);
+}
+
+// Wave-cooperative convex hull of n <= 64 points held one per lane (px,py valid for lane<n).
+// sx/sy: LDS [64], hx/hy: LDS [132].  Returns the vertex count (uniform); vertices in hx/hy.
+__device__ int wave_hull(int n, double px, double py, double* sx, double* sy, double* hx, double* hy) {
+  const int lane = threadIdx.x & 63;
+  // rank sort (lexicographic; ties by lane index so that ranks are a permutation)
+  sx[lane] = px; sy[lane] = py;
+  __syncthreads();
+  int rank = 0;
+  if (lane < n) {
+    for (int j = 0; j < n; j++) {
+      double qx = sx[j], qy = sy[j];
+      if (lex_less(qx, qy, px, py) || (qx == px && qy == py && j < lane)) rank++;
+    }
+  }
+  __syncthreads();
+  if (lane < n) { sx[rank] = px; sy[rank] = py; }
+  __syncthreads();
+  int k = 0;
+  if (lane == 0 && n > 0) {
+    // unique (in place)
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+      double x = sx[i], y = sy[i];
+      if (m == 0 || x != sx[m - 1] || y != sy[m - 1]) { sx[m] = x; sy[m] = y; m++; }
+    }
+    if (m == 1) { hx[0] = sx[0]; hy[0] = sy[0]; k = 1; }
+    else {
+      for (int i = 0; i < m; i++) {  // lower hull
+        double x = sx[i], y = sy[i];
+        while (k >= 2 && cross3(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], x, y) <= 0.0) k--;
+        hx[k] = x; hy[k] = y; k++;
+      }
+      int lo = k + 1;
+      for (int i = m - 2; i >= 0; i--) {  // upper hull
+        double x = sx[i], y = sy[i];
+        while (k >= lo && cross3(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], x, y) <= 0.0) k--;
+        hx[k] = x; hy[k] = y; k++;
+      }
+      k--;
+    }
+  }
+  k = __shfl(k, 0);
+  __syncthreads();
+  return k;
+}
+
+// Body shared by the batched and the stand-alone hull kernels: one wave computes the inflated
+// and the uninflated hull of trajectory r over [ts + i T, ts + (i+1) T].  neptune.cpp:349-452.
+__device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, double T_span, double drone_radius,
+                          long out, bool full0, double* __restrict__ hull_xy, int* __restrict__ hull_nv,
+                          double* __restrict__ hull0_xy, int* __restrict__ hull0_nv) {
+  __shared__ double sx[64], sy[64], hx[132], hy[132];
+  __shared__ double cpx[kHullCP], cpy[kHullCP];
+  __shared__ int s_np0;
+  const int lane = threadIdx.x;
+  if (!(r->valid && r->is_agent) || r->pwp.n_seg <= 0) {   // neptune.cpp:244-262, 332
+    if (lane == 0) { hull_nv[out] = 0; if (hull0_nv) hull0_nv[out] = 0; }
+    return;
+  }
+  const double t0 = ts + i * T_span, t1 = ts + (i + 1) * T_span;   // neptune.cpp:273-280
+  const int n = r->pwp.n_seg;
+  if (lane == 0) {
+    // std::lower_bound / upper_bound on times (neptune.cpp:379-389)
+    int lo = 0, hi = n + 1;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (r->pwp.times[mid] < t0) lo = mid + 1; else hi = mid; }
+    int first = lo - 1;
+    lo = 0; hi = n + 1;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (r->pwp.times[mid] <= t1) lo = mid + 1; else hi = mid; }
+    int last = lo - 1;
+    if (first < 0) first = 0; if (first > n - 1) first = n - 1;
+    if (last < 0) last = 0; if (last > n - 1) last = n - 1;
+    int np0 = 0;
+    for (int s = first; s <= last && np0 + 4 <= kHullCP; s++) {
+      double _t;                                                     // neptune.cpp:399-424
+      if (s != last) _t = r->pwp.times[s + 1] - r->pwp.times[s];
+      else if (t1 > r->pwp.times[s + 1]) _t = r->pwp.times[s + 1] - r->pwp.times[s];
+      else _t = t1 - r->pwp.times[s];
+      if (_t > T_span) _t = T_span; else if (_t < 0) _t = 0;
+      const double c0 = _t * _t * _t, c1 = _t * _t, c2 = _t, c3 = 1.0;
+      for (int k = 0; k < 4; k++) {                                  // V = (P*C)*A^-1, :426-429
+        const double* Px = r->pwp.coeff[0][s];
+        const double* Py = r->pwp.coeff[1][s];
+        cpx[np0] = (((Px[0] * c0) * cAPosInv[0][k] + (Px[1] * c1) * cAPosInv[1][k]) + (Px[2] * c2) * cAPosInv[2][k]) + (Px[3] * c3) * cAPosInv[3][k];
+        cpy[np0] = (((Py[0] * c0) * cAPosInv[0][k] + (Py[1] * c1) * cAPosInv[1][k]) + (Py[2] * c2) * cAPosInv[2][k]) + (Py[3] * c3) * cAPosInv[3][k];
+        np0++;
+      }
+    }
+    s_np0 = np0;
+  }
+  __syncthreads();
+  const int np0 = s_np0;
+  const double dx = r->bbox[0] / 2.0 + drone_radius, dy = r->bbox[1] / 2.0 + drone_radius;  // neptune.cpp:340
+  const bool inflate = !(sqrt(dx * dx + dy * dy) < 1e-6);
+  // inflated points: 4 corners per control point (:442-445)
+  const int np = inflate ? 4 * np0 : np0;
+  double px = 0, py = 0;
+  if (lane < np) {
+    if (inflate) {
+      const int c = lane >> 2, q = lane & 3;
+      const double x = cpx[c], y = cpy[c];
+      px = (q < 2) ? x + dx : x - dx;
+      py = (q == 0 || q == 3) ? y + dy : y - dy;
+    } else { px = cpx[lane]; py = cpy[lane]; }
+  }
+  int k = wave_hull(np, px, py, sx, sy, hx, hy);
+  if (k > kHullV) k = kHullV;
+  if (lane < k) { hull_xy[(out * kHullV + lane) * 2] = hx[lane]; hull_xy[(out * kHullV + lane) * 2 + 1] = hy[lane]; }
+  if (lane == 0) hull_nv[out] = k;
+  if (hull0_nv) {
+    __syncthreads();
+    px = (lane < np0) ? cpx[lane] : 0; py = (lane < np0) ? cpy[lane] : 0;
+    int k0 = wave_hull(np0, px, py, sx, sy, hx, hy);
+    if (k0 > kHullV) k0 = kHullV;
+    if (full0) {
+      if (lane < k0) { hull0_xy[(out * kHullV + lane) * 2] = hx[lane]; hull0_xy[(out * kHullV + lane) * 2 + 1] = hy[lane]; }
+    } else if (lane == 0) { hull0_xy[out * 2] = hx[0]; hull0_xy[out * 2 + 1] = hy[0]; }  // only col(0) is read (:722-734)
+    if (lane == 0) hull0_nv[out] = k0;
+  }
+}
+
+// One block (= one wave) per (scene, committed trajectory, planning interval).
+__global__ __launch_bounds__(64) void hull_kernel(const nep_traj_rec* __restrict__ recs, int n_rec_per_scene,
+                                                  const nep_guess* __restrict__ guess, int n_local,
+                                                  int num_pol, double T_span, double drone_radius,
+                                                  double* __restrict__ hull_xy, int* __restrict__ hull_nv,
+                                                  double* __restrict__ hull0_xy, int* __restrict__ hull0_nv,
+                                                  double* __restrict__ bend_xy, int* __restrict__ bend_n) {
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x % num_pol;
+  const int jt = blockIdx.x / num_pol;          // scene*n_rec + j
+  const int scene = jt / n_rec_per_scene;
+  const nep_traj_rec* r = recs + jt;
+  if (lane == 0 && i == 0 && bend_n) {          // bend points travel with the record (neptune_ros.cpp:457-476)
+    int nb = r->n_bend; if (nb > kBend) nb = kBend; if (nb < 0) nb = 0;
+    bend_n[jt] = (r->valid && r->is_agent) ? nb : 0;
+    for (int b = 0; b < nb; b++) { bend_xy[((long)jt * kBend + b) * 2] = r->bend[b][0]; bend_xy[((long)jt * kBend + b) * 2 + 1] = r->bend[b][1]; }
+  }
+  // bulk-synchronous round: every agent of a scene replans from the same t_start
+  const double ts = guess[(long)scene * n_local].t_start;
+  hull_body(r, ts, i, T_span, drone_radius, (long)jt * num_pol + i, false, hull_xy, hull_nv, hull0_xy, hull0_nv);
+}
+
+void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_guess* guess,
+                  const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
+  int blocks = n_scenes * n_rec * sp.num_pol;
+  if (blocks <= 0) return;
+  hipLaunchKernelGGL(hull_kernel, dim3(blocks), dim3(64), 0, st, recs, n_rec, guess, sp.n_local,
+                     sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, ps.hull0_xy, ps.hull0_nv,
+                     ps.bend_xy, ps.bend_n);
+}
+
+// ---------------------------------------------------------------------------------------------
+// separator
+// ---------------------------------------------------------------------------------------------
+struct SepBest { double gap, n1, n2, d; };
+
+// One candidate pair (p,q) of set X (from_A: X = A).  A: ax/ay[0..nA), B: bx/by[0..nB).
+__device__ __forceinline__ void sep_pair(double px, double py, double qx, double qy, bool from_A,
+                                         int nA, const double* ax, const double* ay, int nB,
+                                         const double* bx, const double* by, SepBest& best) {
+  const double ex = qx - px, ey = qy - py;
+  const double nx = -ey, ny = ex;
+  const double len2 = nx * nx + ny * ny;
+  if (!(len2 > 0.0)) return;
+  double minA = NEP_INF, maxA = -NEP_INF, minB = NEP_INF, maxB = -NEP_INF;
+  for (int i = 0; i < nA; i++) { const double t = nx * (ax[i] - px) + ny * (ay[i] - py); if (t < minA) minA = t; if (t > maxA) maxA = t; }
+  for (int i = 0; i < nB; i++) { const double t = nx * (bx[i] - px) + ny * (by[i] - py); if (t < minB) minB = t; if (t > maxB) maxB = t; }
+  const double len = sqrt(len2);
+  double gp = -NEP_INF, gm = -NEP_INF, tAp = 0.0, tAm = 0.0;
+  if (from_A) {
+    if (minA >= 0.0) { gp = (0.0 - maxB) / len; tAp = 0.0; }
+    if (maxA <= 0.0) { gm = (minB - 0.0) / len; tAm = 0.0; }
+  } else {
+    if (maxB <= 0.0) { gp = (minA - 0.0) / len; tAp = minA; }
+    if (minB >= 0.0) { gm = (0.0 - maxA) / len; tAm = maxA; }
+  }
+  double g, sg, tA;
+  if (gp >= gm) { g = gp; sg = 1.0; tA = tAp; } else { g = gm; sg = -1.0; tA = tAm; }
+  if (g > best.gap) {
+    const double s = 2.0 / g;
+    const double n1 = s * (sg * nx / len), n2 = s * (sg * ny / len);
+    best.gap = g; best.n1 = n1; best.n2 = n2;
+    best.d = (1.0 - s * (sg * tA / len)) - (n1 * px + n2 * py);
+  }
+}
+
+__device__ bool separator_impl(int nA, const double* ax, const double* ay, bool a_ordered, int nB,
+                               const double* bx, const double* by, double nd[3]) {
+  SepBest best; best.gap = SEP_MIN_GAP; best.n1 = best.n2 = best.d = 0.0;
+  if (a_ordered && nA >= 3) {
+    for (int p = 0; p < nA - 1; p++) {
+      sep_pair(ax[p], ay[p], ax[p + 1], ay[p + 1], true, nA, ax, ay, nB, bx, by, best);
+      if (p == 0) sep_pair(ax[0], ay[0], ax[nA - 1], ay[nA - 1], true, nA, ax, ay, nB, bx, by, best);
+    }
+  } else {
+    for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) sep_pair(ax[p], ay[p], ax[q], ay[q], true, nA, ax, ay, nB, bx, by, best);
+  }
+  for (int p = 0; p < nB; p++) for (int q = p + 1; q < nB; q++) sep_pair(bx[p], by[p], bx[q], by[q], false, nA, ax, ay, nB, bx, by, best);
+  if (!(best.gap > SEP_MIN_GAP) && nA > 0 && nB > 0) {
+    double cax = 0, cay = 0, cbx = 0, cby = 0;
+    for (int i = 0; i < nA; i++) { cax += ax[i]; cay += ay[i]; }
+    for (int i = 0; i < nB; i++) { cbx += bx[i]; cby += by[i]; }
+    cax /= nA; cay /= nA; cbx /= nB; cby /= nB;
+    const double nx = cax - cbx, ny = cay - cby;
+    const double len2 = nx * nx + ny * ny;
+    if (len2 > 0.0) {
+      double minA = NEP_INF, maxB = -NEP_INF;
+      for (int i = 0; i < nA; i++) { const double t = nx * (ax[i] - cbx) + ny * (ay[i] - cby); if (t < minA) minA = t; }
+      for (int i = 0; i < nB; i++) { const double t = nx * (bx[i] - cbx) + ny * (by[i] - cby); if (t > maxB) maxB = t; }
+      const double len = sqrt(len2);
+      const double g = (minA - maxB) / len;
+      if (g > best.gap) {
+        const double s = 2.0 / g;
+        const double n1 = s * (nx / len), n2 = s * (ny / len);
+        best.gap = g; best.n1 = n1; best.n2 = n2;
+        best.d = (1.0 - s * (minA / len)) - (n1 * cbx + n2 * cby);
+      }
+    }
+  }
+  if (best.gap > SEP_MIN_GAP) { nd[0] = best.n1; nd[1] = best.n2; nd[2] = best.d; return true; }
+  nd[0] = nd[1] = nd[2] = 0.0;
+  return false;
+}
+
+constexpr int kAStride = 17;  // doubles per lane slot: 34 dwords -> distinct even banks per 32-lane group
+
+// One wave per (slot, segment).  Candidate order == reference loop order
+// (solver_gurobi_poly.cpp:477-495 agents, :521-553 bases, :556-593 statics, :620-637 entangle).
+__global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSet ps) {
+  __shared__ double sAx[64 * kAStride], sAy[64 * kAStride];
+  __shared__ double sBx[4], sBy[4];
+  const int lane = threadIdx.x;
+  const int seg = blockIdx.x % NEP_MAX_POL;
+  const int slot = blockIdx.x / NEP_MAX_POL;
+  const int scene = slot / sp.n_local;
+  const nep_guess* g = ps.guess + slot;
+  const int K = g->K;
+  int* cnt_out = ps.line_cnt + (long)slot * NEP_MAX_POL + seg;
+  if (seg >= K || seg >= sp.num_pol) { if (lane == 0) *cnt_out = 0; return; }
+  const double T = sp.T_span;
+  if (lane < 4) {  // ctrlPtsInit_[seg] (solver_gurobi_poly.cpp:232-243)
+    const double tp0 = T * T * T, tp1 = T * T, tp2 = T;
+    const double m0 = tp0 * cAPosInv[0][lane], m1 = tp1 * cAPosInv[1][lane], m2 = tp2 * cAPosInv[2][lane], m3 = 1.0 * cAPosInv[3][lane];
+    const double* Px = g->coeff[0][seg]; const double* Py = g->coeff[1][seg];
+    sBx[lane] = ((Px[0] * m0 + Px[1] * m1) + Px[2] * m2) + Px[3] * m3;
+    sBy[lane] = ((Py[0] * m0 + Py[1] * m1) + Py[2] * m2) + Py[3] * m3;
+  }
+  __syncthreads();
+  const double* bx = sBx; const double* by = sBy;
+  const int N = sp.num_agents, S = sp.n_static, nH = sp.n_hull;
+  const int own = sp.first_local + (slot % sp.n_local);
+  const int nE = (sp.ent_enabled && ps.case_id) ? N * kBend : 0;
+  const int total = nH + N + S + nE;
+  double* myAx = sAx + lane * kAStride; double* myAy = sAy + lane * kAStride;
+  double* bucket = ps.line_nd + ((long)slot * NEP_MAX_POL + seg) * sp.lines_cap * 3;
+  int base = 0, n_try = 0, n_fail = 0;
+  double hulldist = 0;  // :738-742
+  for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; hulldist += sqrt(ex * ex + ey * ey); }
+  for (int c0 = 0; c0 < total; c0 += 64) {
+    const int c = c0 + lane;
+    bool attempt = false, ordered = false;
+    int nA = 0;
+    if (c < nH) {
+      const int j = c;
+      if (!(sp.skip_own && j == own)) {
+        const long h = ((long)scene * nH + j) * sp.num_pol + seg;
+        nA = ps.hull_nv[h];
+        if (nA > 0) {
+          attempt = true; ordered = true;
+          const double* src = ps.hull_xy + h * kHullV * 2;
+          for (int v = 0; v < nA; v++) { myAx[v] = src[2 * v]; myAy[v] = src[2 * v + 1]; }
+        }
+      }
+    } else if (c < nH + N) {
+      const int j = c - nH;
+      const double base_radius = 0.7;
+      const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
+      bool close_to_base = false;
+      for (int k = 0; k < 4; k++) { const double ddx = bx[k] - pbx, ddy = by[k] - pby; if (sqrt(ddx * ddx + ddy * ddy) < base_radius * 3) { close_to_base = true; break; } }
+      if (close_to_base) {  // :536-540 (column order of base_hull)
+        attempt = true; nA = 4;
+        myAx[0] = pbx + base_radius; myAy[0] = pby + base_radius;
+        myAx[1] = pbx + base_radius; myAy[1] = pby - base_radius;
+        myAx[2] = pbx - base_radius; myAy[2] = pby + base_radius;
+        myAx[3] = pbx - base_radius; myAy[3] = pby - base_radius;
+      }
+    } else if (c < nH + N + S) {
+      const int j = c - nH - N;
+      const int nv = ps.static_nv[j];
+      if (nv > 0) {
+        const double* src = ps.static_xy + (long)j * kHullV * 2;
+        for (int v = 0; v < nv; v++) { myAx[v] = src[2 * v]; myAy[v] = src[2 * v + 1]; }
+        bool close_s = false;  // :558-578
+        const double ddx = bx[0] - myAx[0], ddy = by[0] - myAy[0];
+        double dist = sqrt(ddx * ddx + ddy * ddy);
+        for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
+        for (int k = 0; k < nv - 1; k++) { const double ex = myAx[k + 1] - myAx[k], ey = myAy[k + 1] - myAy[k]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
+        if (close_s) { attempt = true; ordered = true; nA = nv; }
+      }
+    } else if (c < total) {
+      const int e = c - nH - N - S;
+      const int j = e / kBend, k = e % kBend + 1;
+      if (j != own) {
+        const int case_id = ps.case_id[((long)slot * NEP_MAX_POL + seg) * N + j];
+        const int nb = ps.bend_n[(long)scene * N + j];
+        if (case_id != 0 && k != case_id && k <= nb) {  // :631-636
+          const double* bp = ps.bend_xy + ((long)scene * N + j) * kBend * 2;
+          const long h0 = ((long)scene * N + j) * sp.num_pol + seg;
+          bool have = true;
+          double pAx, pAy, pBx, pBy;
+          if (k == 1) {  // :719-724
+            if (ps.hull0_nv[h0] <= 0) have = false;
+            const double hx0 = ps.hull0_xy[h0 * 2], hy0 = ps.hull0_xy[h0 * 2 + 1];
+            pAx = (1 - sp.long_length) * bp[2 * (nb - 1)] + sp.long_length * hx0;
+            pAy = (1 - sp.long_length) * bp[2 * (nb - 1) + 1] + sp.long_length * hy0;
+            pBx = hx0; pBy = hy0;
+          } else {  // :725-730
+            pAx = bp[2 * (k - 2)]; pAy = bp[2 * (k - 2) + 1]; pBx = bp[2 * (k - 1)]; pBy = bp[2 * (k - 1) + 1];
+          }
+          if (have) {
+            const double ax_ = pAx - bx[0], ay_ = pAy - by[0], bx_ = pBx - bx[0], by_ = pBy - by[0];
+            if (!(sqrt(ax_ * ax_ + ay_ * ay_) - hulldist > 0 && sqrt(bx_ * bx_ + by_ * by_) - hulldist > 0)) {  // :743-745
+              attempt = true; nA = 2;
+              myAx[0] = pAx; myAy[0] = pAy; myAx[1] = pBx; myAy[1] = pBy;
+            }
+          }
+        }
+      }
+    }
+    double nd[3] = {0, 0, 0};
+    bool ok = false;
+    if (attempt && !ps.lines_override) ok = separator_impl(nA, myAx, myAy, ordered, 4, bx, by, nd);
+    const unsigned long long mask = __ballot(ok);
+    const unsigned long long below = mask & ((1ull << lane) - 1ull);
+    if (ok) {
+      const int pos = base + __popcll(below);
+      if (pos < sp.lines_cap) { bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2]; }
+    }
+    base += __popcll(mask);
+    n_try += __popcll(__ballot(attempt));
+    n_fail += __popcll(__ballot(attempt && !ok));
+  }
+  if (lane == 0 && !ps.lines_override) {
+    *cnt_out = base < sp.lines_cap ? base : sp.lines_cap;
+    atomicAdd(ps.lp_stats + 2 * slot, n_try);
+    atomicAdd(ps.lp_stats + 2 * slot + 1, n_fail);
+  }
+}
+
+void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
+  if (n_slots <= 0) return;
+  hipLaunchKernelGGL(separator_kernel, dim3(n_slots * NEP_MAX_POL), dim3(64), 0, st, sp, ps);
+}
+
+// Stand-alone batched LP (tests): one lane per problem, point sets read from global memory.
+__global__ void separator_explicit_kernel(int n_prob, const int* __restrict__ a_off, const double* __restrict__ a_xy,
+                                          const int* __restrict__ b_off, const double* __restrict__ b_xy,
+                                          double* __restrict__ nd_out, int* __restrict__ solved) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_prob) return;
+  double ax[kHullV], ay[kHullV], bx[kHullV], by[kHullV];
+  int nA = a_off[p + 1] - a_off[p], nB = b_off[p + 1] - b_off[p];
+  if (nA > kHullV) nA = kHullV; if (nB > kHullV) nB = kHullV;
+  for (int i = 0; i < nA; i++) { ax[i] = a_xy[2 * (a_off[p] + i)]; ay[i] = a_xy[2 * (a_off[p] + i) + 1]; }
+  for (int i = 0; i < nB; i++) { bx[i] = b_xy[2 * (b_off[p] + i)]; by[i] = b_xy[2 * (b_off[p] + i) + 1]; }
+  double nd[3];
+  const bool ok = separator_impl(nA, ax, ay, false, nB, bx, by, nd);
+  nd_out[3 * p] = nd[0]; nd_out[3 * p + 1] = nd[1]; nd_out[3 * p + 2] = nd[2];
+  solved[p] = ok ? 1 : 0;
+}
+
+void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy, const int* b_off,
+                               const double* b_xy, double* nd, int* solved, hipStream_t st) {
+  if (n_prob <= 0) return;
+  hipLaunchKernelGGL(separator_explicit_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, st, n_prob, a_off, a_xy, b_off, b_xy, nd, solved);
+}
+
+// Stand-alone hulls (tests / nep_hulls_batch): full vertex lists of both hulls.
+__global__ __launch_bounds__(64) void hull_explicit_kernel(const nep_traj_rec* __restrict__ recs, double t_start, int num_pol,
+                                                           double T_span, double drone_radius,
+                                                           double* __restrict__ hull_xy, int* __restrict__ hull_nv,
+                                                           double* __restrict__ hull0_xy, int* __restrict__ hull0_nv) {
+  const int i = blockIdx.x % num_pol;
+  const int jt = blockIdx.x / num_pol;
+  hull_body(recs + jt, t_start, i, T_span, drone_radius, (long)jt * num_pol + i, true, hull_xy, hull_nv, hull0_xy, hull0_nv);
+}
+
+void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start, int num_pol,
+                           double T_span, double drone_radius, double* hull_xy, int* hull_nv,
+                           double* hull0_xy, int* hull0_nv, hipStream_t st) {
+  if (n_traj * num_pol <= 0) return;
+  hipLaunchKernelGGL(hull_explicit_kernel, dim3(n_traj * num_pol), dim3(64), 0, st, recs, t_start, num_pol, T_span,
+                     drone_radius, hull_xy, hull_nv, hull0_xy, hull0_nv);
+}
+
+}  // namespace nep

@@ -1,0 +1,79 @@
+// nep_device.h — device-side views shared by the HIP kernels and the host launcher.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "nep_tables.h"
+
+namespace nep {
+
+constexpr int kHullV = NEP_HULL_MAX_V;   // 16
+constexpr int kHullCP = NEP_HULL_MAX_CP; // 12
+constexpr int kBend = NEP_MAX_BEND;      // 8
+
+// Scene-level constants (setMaxValues, ctor arguments; solver_gurobi_poly.cpp:25-175)
+struct SceneParams {
+  int num_agents;     // N (pb.size())
+  int num_pol;        // planning intervals
+  int n_static;       // S
+  int n_hull;         // hull lists per scene: N in batch mode, n_obst in per-agent mode
+  int ent_enabled;
+  int max_states;
+  int lines_cap;      // capacity of one (slot, segment) line bucket
+  int n_local;        // slots per scene
+  int first_local;    // index of first local agent (batch); per-agent mode: id-1
+  int skip_own;       // 1: hull list is indexed by agent, own entry skipped
+  double T_span, weight, dc, drone_radius;
+  double mins[3], maxs[3], v_max, a_max;
+  double long_length; // solver_gurobi_poly.cpp:173
+};
+
+// Buffers of one problem set (n_scenes x n_local slots).  All device pointers.
+struct ProblemSet {
+  // inputs
+  const nep_guess* guess;        // [slots]
+  const double* pb;              // [N][2]
+  const double* static_xy;       // [S][kHullV][2]
+  const int* static_nv;          // [S]
+  const int* case_id;            // [slots][NEP_MAX_POL][N] or null
+  // per scene (batch: written by the hull kernel; per-agent: uploaded by setHulls)
+  double* hull_xy;               // [scenes][n_hull][num_pol][kHullV][2]
+  int* hull_nv;                  // [scenes][n_hull][num_pol]
+  double* hull0_xy;              // [scenes][N][num_pol][2]  col(0) of the uninflated hull
+  int* hull0_nv;                 // [scenes][N][num_pol]
+  double* bend_xy;               // [scenes][N][kBend][2]
+  int* bend_n;                   // [scenes][N]
+  // separator output
+  double* line_nd;               // [slots][NEP_MAX_POL][lines_cap][3]
+  int* line_cnt;                 // [slots][NEP_MAX_POL]
+  int* lp_stats;                 // [slots][2]  (attempted, failed)
+  int lines_override;            // 1: line buckets were filled by the host (test hook)
+  // QP scratch when the row state does not fit LDS
+  double* row_scratch;           // [slots][2][rows_cap]
+  int rows_cap;
+  int lds_rows;                  // rows that fit the dynamic LDS carve
+  int lds_lines;
+  // outputs
+  nep_solution* solution;        // [slots]
+  double* states;                // [slots][max_states][12] or null
+  nep_traj_rec* commit;          // [slots] or null
+};
+
+struct SampleSched {             // per K: n, seg[], dt[]
+  const int* n;                  // [kMaxK+1]
+  const int* seg;                // [kMaxK+1][max_states]
+  const double* dt;              // [kMaxK+1][max_states]
+};
+
+void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_guess* guess,
+                  const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
+void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start, int num_pol,
+                           double T_span, double drone_radius, double* hull_xy, int* hull_nv,
+                           double* hull0_xy, int* hull0_nv, hipStream_t st);
+void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
+void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy, const int* b_off,
+                               const double* b_xy, double* nd, int* solved, hipStream_t st);
+void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
+               const SampleSched& sched, size_t lds_bytes, hipStream_t st);
+size_t qp_lds_fixed_bytes();
+
+}  // namespace nep

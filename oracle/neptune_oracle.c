@@ -184,52 +184,86 @@ int orc_inflate_static(int nv, const double (*v)[2], double sd, double (*out)[2]
 #define SEP_MIN_GAP 1e-7
 
 /* The LP  find (n,d): n.a+d >= 1 (a in A), n.b+d <= -1 (b in B), zero objective, has as
- * vertices exactly the lines through two points of one set that support the other set's
- * nearest point (3 tight rows); GLPK returns whichever vertex its pivoting reaches.  This
- * restatement returns the vertex with the largest geometric gap, ties to the first candidate
- * in the order: pairs (p<q) of A, then pairs of B, each tried in both orientations. */
-static void sep_try(const double n[2], int nA, const double (*A)[2], int nB, const double (*B)[2],
-                    double* best_gap, double nd[3]) {
-  double len2 = n[0] * n[0] + n[1] * n[1];
+ * vertices exactly the lines through two points of one set (both rows tight) that touch the
+ * nearest point of the other set (third tight row); GLPK returns whichever vertex its pivoting
+ * reaches.  This restatement returns the vertex with the largest geometric gap; ties go to the
+ * first candidate in the order: pairs of A, then pairs of B.  Pairs of A are (p<q) in
+ * lexicographic order; when A is known to be a convex polygon in boundary order only its edges
+ * can be tight and only they are tried, in the same relative order (0,1),(0,V-1),(1,2),...
+ * Projections are taken relative to p so that both points of the pair project to exactly 0. */
+static void sep_pair(const double p[2], const double q[2], int from_A, int nA, const double (*A)[2],
+                     int nB, const double (*B)[2], double* best_gap, double nd[3]) {
+  double ex = q[0] - p[0], ey = q[1] - p[1];
+  double nx = -ey, ny = ex;
+  double len2 = nx * nx + ny * ny;
   if (!(len2 > 0.0)) return;
   double minA = INFINITY, maxA = -INFINITY, minB = INFINITY, maxB = -INFINITY;
-  for (int i = 0; i < nA; i++) { double t = n[0] * A[i][0] + n[1] * A[i][1]; if (t < minA) minA = t; if (t > maxA) maxA = t; }
-  for (int i = 0; i < nB; i++) { double t = n[0] * B[i][0] + n[1] * B[i][1]; if (t < minB) minB = t; if (t > maxB) maxB = t; }
+  for (int i = 0; i < nA; i++) { double t = nx * (A[i][0] - p[0]) + ny * (A[i][1] - p[1]); if (t < minA) minA = t; if (t > maxA) maxA = t; }
+  for (int i = 0; i < nB; i++) { double t = nx * (B[i][0] - p[0]) + ny * (B[i][1] - p[1]); if (t < minB) minB = t; if (t > maxB) maxB = t; }
   double len = sqrt(len2);
-  double g1 = (minA - maxB) / len; /* +n points toward A */
-  double g2 = (minB - maxA) / len; /* -n points toward A */
-  if (g1 >= g2) {
-    if (g1 > *best_gap) { double s = 2.0 / g1; *best_gap = g1; nd[0] = s * (n[0] / len); nd[1] = s * (n[1] / len); nd[2] = 1.0 - s * (minA / len); }
+  double gp = -INFINITY, gm = -INFINITY, tAp = 0.0, tAm = 0.0; /* +n / -n points toward A */
+  if (from_A) {
+    if (minA >= 0.0) { gp = (0.0 - maxB) / len; tAp = 0.0; }
+    if (maxA <= 0.0) { gm = (minB - 0.0) / len; tAm = 0.0; }
   } else {
-    if (g2 > *best_gap) { double s = 2.0 / g2; *best_gap = g2; nd[0] = s * (-n[0] / len); nd[1] = s * (-n[1] / len); nd[2] = 1.0 - s * (-maxA / len); }
+    if (maxB <= 0.0) { gp = (minA - 0.0) / len; tAp = minA; }
+    if (minB >= 0.0) { gm = (0.0 - maxA) / len; tAm = maxA; }
+  }
+  double g, sg, tA;
+  if (gp >= gm) { g = gp; sg = 1.0; tA = tAp; } else { g = gm; sg = -1.0; tA = tAm; }
+  if (g > *best_gap) {
+    double s = 2.0 / g;
+    double n1 = s * (sg * nx / len), n2 = s * (sg * ny / len);
+    *best_gap = g; nd[0] = n1; nd[1] = n2;
+    nd[2] = (1.0 - s * (sg * tA / len)) - (n1 * p[0] + n2 * p[1]);
   }
 }
 
-int orc_separator(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]) {
+static int separator_impl(int nA, const double (*A)[2], int a_ordered, int nB, const double (*B)[2], double nd[3]) {
   double best = SEP_MIN_GAP;
   double cand[3] = {0, 0, 0};
-  for (int p = 0; p < nA; p++)
-    for (int q = p + 1; q < nA; q++) {
-      double n[2] = {-(A[q][1] - A[p][1]), A[q][0] - A[p][0]};
-      sep_try(n, nA, A, nB, B, &best, cand);
+  if (a_ordered && nA >= 3) {
+    for (int p = 0; p < nA - 1; p++) {
+      sep_pair(A[p], A[p + 1], 1, nA, A, nB, B, &best, cand);
+      if (p == 0) sep_pair(A[0], A[nA - 1], 1, nA, A, nB, B, &best, cand);
     }
-  for (int p = 0; p < nB; p++)
-    for (int q = p + 1; q < nB; q++) {
-      double n[2] = {-(B[q][1] - B[p][1]), B[q][0] - B[p][0]};
-      sep_try(n, nA, A, nB, B, &best, cand);
-    }
-  if (!(best > SEP_MIN_GAP)) { /* degenerate sets (all pairs coincident): centroid direction */
+  } else {
+    for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) sep_pair(A[p], A[q], 1, nA, A, nB, B, &best, cand);
+  }
+  for (int p = 0; p < nB; p++) for (int q = p + 1; q < nB; q++) sep_pair(B[p], B[q], 0, nA, A, nB, B, &best, cand);
+  if (!(best > SEP_MIN_GAP) && nA > 0 && nB > 0) {
+    /* degenerate sets (every pair coincident, e.g. a hovering agent against a point):
+     * direction between the centroids, supported at the extreme points */
     double ca[2] = {0, 0}, cb[2] = {0, 0};
     for (int i = 0; i < nA; i++) { ca[0] += A[i][0]; ca[1] += A[i][1]; }
     for (int i = 0; i < nB; i++) { cb[0] += B[i][0]; cb[1] += B[i][1]; }
-    if (nA > 0 && nB > 0) {
-      double n[2] = {ca[0] / nA - cb[0] / nB, ca[1] / nA - cb[1] / nB};
-      sep_try(n, nA, A, nB, B, &best, cand);
+    ca[0] /= nA; ca[1] /= nA; cb[0] /= nB; cb[1] /= nB;
+    double nx = ca[0] - cb[0], ny = ca[1] - cb[1];
+    double len2 = nx * nx + ny * ny;
+    if (len2 > 0.0) {
+      double minA = INFINITY, maxB = -INFINITY;
+      for (int i = 0; i < nA; i++) { double t = nx * (A[i][0] - cb[0]) + ny * (A[i][1] - cb[1]); if (t < minA) minA = t; }
+      for (int i = 0; i < nB; i++) { double t = nx * (B[i][0] - cb[0]) + ny * (B[i][1] - cb[1]); if (t > maxB) maxB = t; }
+      double len = sqrt(len2);
+      double g = (minA - maxB) / len;
+      if (g > best) {
+        double s = 2.0 / g;
+        double n1 = s * (nx / len), n2 = s * (ny / len);
+        best = g; cand[0] = n1; cand[1] = n2;
+        cand[2] = (1.0 - s * (minA / len)) - (n1 * cb[0] + n2 * cb[1]);
+      }
     }
   }
   if (best > SEP_MIN_GAP) { nd[0] = cand[0]; nd[1] = cand[1]; nd[2] = cand[2]; return 1; }
   nd[0] = nd[1] = nd[2] = 0.0;
   return 0;
+}
+
+int orc_separator(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]) {
+  return separator_impl(nA, A, 0, nB, B, nd);
+}
+int orc_separator_ordered(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]) {
+  return separator_impl(nA, A, 1, nB, B, nd);
 }
 
 /* Two-phase primal simplex, Bland's rule, dense tableau.  Rows: A: a.x+d - u = 1 ; B: -(b.x+d)
@@ -554,7 +588,7 @@ int orc_optimize(const orc_params* par, int K, const double coeff_init[3][NEP_MA
     for (int j = 0; j < n_obst; j++) {
       int pi = j * par->num_pol + i; int o = hulls->off[pi], nv = hulls->off[pi + 1] - o; double nd[3];
       out->n_lp++;
-      if (nv > 0 && orc_separator(nv, (const double(*)[2])(hulls->xy + 2 * o), 4, (const double(*)[2])B4, nd)) {
+      if (nv > 0 && orc_separator_ordered(nv, (const double(*)[2])(hulls->xy + 2 * o), 4, (const double(*)[2])B4, nd)) {
         out->line_seg[nl] = i; memcpy(out->line_nd[nl], nd, sizeof(nd)); nl++; add_line_rows(rows, &m, K, i, M4, nd);
       } else out->n_lp_failed++;
     }
@@ -580,7 +614,7 @@ int orc_optimize(const orc_params* par, int K, const double coeff_init[3][NEP_MA
       for (int k = 0; k < nv - 1; k++) { double ex = S[k + 1][0] - S[k][0], ey = S[k + 1][1] - S[k][1]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = 1; break; } }
       if (!close_s) continue;
       double nd[3]; out->n_lp++;
-      if (orc_separator(nv, S, 4, (const double(*)[2])B4, nd)) { out->line_seg[nl] = i; memcpy(out->line_nd[nl], nd, sizeof(nd)); nl++; add_line_rows(rows, &m, K, i, M4, nd); }
+      if (orc_separator_ordered(nv, S, 4, (const double(*)[2])B4, nd)) { out->line_seg[nl] = i; memcpy(out->line_nd[nl], nd, sizeof(nd)); nl++; add_line_rows(rows, &m, K, i, M4, nd); }
       else out->n_lp_failed++;
     }
     /* entanglement :620-642, 715-764 */

@@ -75,6 +75,9 @@ int orc_inflate_static(int nv, const double (*v)[2], double safe_dist, double (*
  * LP vertex (two tight rows of one set + one of the other) of maximum geometric gap; returns 1
  * if separable.  nd = (n1, n2, d) with n.a+d >= 1 on A and n.b+d <= -1 on B. */
 int orc_separator(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]);
+/* Same rule when A is a convex polygon given in boundary order (hulls, inflated statics): only
+ * its edges are candidate pairs. */
+int orc_separator_ordered(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]);
 
 /* Same LP solved by a textbook two-phase primal simplex with Bland's rule (the algorithm class
  * GLPK's glp_simplex implements; GLPK's own pivoting rules are not reproducible without its

@@ -70,7 +70,7 @@ def lib():
                                            C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
         L.orc_inflate_static.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_void_p]
         L.orc_inflate_static.restype = C.c_int
-        for f in (L.orc_separator, L.orc_separator_simplex):
+        for f in (L.orc_separator, L.orc_separator_simplex, L.orc_separator_ordered):
             f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
             f.restype = C.c_int
         L.orc_optimize.argtypes = [C.POINTER(orc_params), C.c_int, C.c_void_p, C.c_int,
@@ -126,10 +126,10 @@ def inflate_static(verts, safe_dist):
     return out[:k].copy()
 
 
-def separator(A, B, simplex=False):
+def separator(A, B, simplex=False, ordered=False):
     A = _c(A).reshape(-1, 2); B = _c(B).reshape(-1, 2)
     nd = np.zeros(3)
-    f = lib().orc_separator_simplex if simplex else lib().orc_separator
+    f = lib().orc_separator_simplex if simplex else (lib().orc_separator_ordered if ordered else lib().orc_separator)
     ok = f(len(A), A.ctypes.data, len(B), B.ctypes.data, abi.dptr(nd))
     return bool(ok), nd
 

@@ -1,0 +1,61 @@
+"""CPU: the C-ABI library loads, exports every symbol include/neptune_backend.h declares, and
+its records have the layout the ctypes mirror assumes.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from neptune_amd import _lib, abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def L():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.lib()
+
+
+def test_exports_every_declared_symbol(L):
+    hdr = open(os.path.join(ROOT, "include", "neptune_backend.h")).read()
+    declared = set(re.findall(r"^(?:int|void|int64_t|const char\*|nep_backend_t\*|nep_batch_t\*)\s+(nep_[a-z_0-9]+)\(", hdr, re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_struct_layouts(L):
+    for k, t in enumerate([abi.nep_pwp, abi.nep_traj_rec, abi.nep_backend_cfg, abi.nep_stats, abi.nep_batch_cfg,
+                           abi.nep_guess, abi.nep_solution, abi.nep_ent_view]):
+        assert C.sizeof(t) == L.nep_abi_sizeof(k), t.__name__
+    assert abi.TRAJ_REC_DTYPE.itemsize == C.sizeof(abi.nep_traj_rec)
+    assert abi.GUESS_DTYPE.itemsize == C.sizeof(abi.nep_guess)
+    assert abi.SOLUTION_DTYPE.itemsize == C.sizeof(abi.nep_solution)
+
+
+def test_fails_loudly_without_a_gpu(L):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    pb = np.zeros((1, 2))
+    cfg = abi.nep_backend_cfg(8, 3, 1, 1, 0.5, 1000.0, 0.5, 1, 0, abi.dptr(pb))
+    assert not L.nep_backend_create(C.byref(cfg))
+    assert b"no HIP device" in L.nep_last_error() or b"hip" in L.nep_last_error().lower()
+    nd = np.zeros(3); ok = np.zeros(1, dtype=np.int32); off = np.array([0, 1], dtype=np.int32); xy = np.zeros((1, 2))
+    rc = L.nep_separator_batch(1, abi.iptr(off), abi.dptr(xy), abi.iptr(off), abi.dptr(xy), abi.dptr(nd), abi.iptr(ok))
+    assert rc < 0
+
+
+def test_oracle_is_not_reachable_from_the_product():
+    """The product package must not import or link the oracle."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "neptune_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                code = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith(("//", "#", "*", "/*")))
+                assert "from oracle" not in code and "import oracle" not in code and "neptune_oracle" not in code, f

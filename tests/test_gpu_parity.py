@@ -1,0 +1,250 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the golden
+fixtures.  Bar: hull vertices and separating lines BIT-EXACT; QP control points / coefficients
+within 1e-6 (absolute, metres and polynomial coefficients) and cost within 1e-6 relative (the
+north star asks for 1e-4 on cost)."""
+import numpy as np
+import pytest
+
+import helpers
+from neptune_amd import abi, scene
+
+pytestmark = pytest.mark.gpu
+
+COEF_TOL = 1e-6
+COST_RTOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from neptune_amd import backend
+    return backend
+
+
+def _bounds(p):
+    return (p.x_min, p.x_max, p.y_min, p.y_max, p.z_min, p.z_max, p.v_max, p.a_max, p.j_max)
+
+
+def _solver(be, p, agent_id=1):
+    s = be.PolySolver(p.num_pol, 3, agent_id, p.T_span, p.pb, p.weight, 0.5, True)
+    s.setMaxValues(*_bounds(p)); s.setMaxRuntime(0.05); s.setTetherLength(p.tether_length)
+    return s
+
+
+def test_hulls_bit_exact(be, oracle):
+    for seed, jit in ((0, 0.0), (1, 0.37), (2, 0.2)):
+        sc = scene.make_scene(8, 0, seed=seed, t_jitter=0.0)
+        p = sc["par"]
+        t_start = jit
+        hx, hn, h0, n0 = be.hulls_batch(sc["committed"], t_start, p.num_pol, p.T_span, p.drone_radius)
+        for j in range(8):
+            pw = abi.nep_pwp.from_buffer_copy(sc["committed"][j]["pwp"].tobytes())
+            d = np.array([sc["committed"][j]["bbox"][0] / 2 + p.drone_radius, sc["committed"][j]["bbox"][1] / 2 + p.drone_radius])
+            for i in range(p.num_pol):
+                h, hu = oracle.hull_of_interval(pw, t_start + i * p.T_span, t_start + (i + 1) * p.T_span, p.T_span, d)
+                assert hn[j, i] == len(h) and n0[j, i] == len(hu)
+                np.testing.assert_array_equal(hx[j, i, :len(h)], h)
+                np.testing.assert_array_equal(h0[j, i, :len(hu)], hu)
+
+
+def test_separator_bit_exact_on_golden_lps(be, oracle):
+    d = np.load(helpers.ROOT + "/tests/golden/lp_cases.npz")
+    As = [A[~np.isnan(A[:, 0])] for A in d["A"]]; Bs = list(d["B"])
+    ok, nd = be.separator_batch(As, Bs)
+    n_ok = 0
+    for k, (A, B) in enumerate(zip(As, Bs)):
+        o, n = oracle.separator(A, B)
+        assert bool(ok[k]) == o
+        np.testing.assert_array_equal(nd[k], n)
+        if o:
+            assert (A @ nd[k, :2] + nd[k, 2]).min() >= 1 - 1e-9 and (B @ nd[k, :2] + nd[k, 2]).max() <= -1 + 1e-9
+            n_ok += 1
+        if bool(d["feasible"][k]) != o:
+            assert not o
+    assert n_ok > 200
+
+
+def test_separator_edge_cases(be, oracle):
+    sq = np.array([[1.0, 1.0], [1.0, -1.0], [-1.0, 1.0], [-1.0, -1.0]])
+    cases = [(sq, np.tile([[3.0, 0.5]], (4, 1))),                       # hovering agent (coincident control points)
+             (sq, np.array([[0.0, 0.0], [0.1, 0.1], [0.2, 0.0], [0.1, -0.1]])),   # inside: infeasible
+             (np.array([[0.0, 0.0]]), np.tile([[2.0, 2.0]], (4, 1))),    # point vs point
+             (np.array([[0.0, 0.0], [1.0, 0.0]]), np.array([[0.0, 2.0], [1.0, 2.0], [2.0, 3.0], [0.5, 4.0]])),
+             (sq, sq + np.array([2.0 + 1e-9, 0.0]))]                    # gap below the floor
+    ok, nd = be.separator_batch([c[0] for c in cases], [c[1] for c in cases])
+    for k, (A, B) in enumerate(cases):
+        o, n = oracle.separator(A, B)
+        assert bool(ok[k]) == o
+        np.testing.assert_array_equal(nd[k], n)
+    assert list(ok) == [True, False, True, True, False]
+
+
+def test_qp_against_golden(be, oracle):
+    seen = set()
+    for c in helpers.load_qp_cases():
+        p = helpers.params_of_case(c)
+        s = _solver(be, p)
+        K = c["K"]
+        s.setInitTrajectory(np.arange(K + 1) * p.T_span, c["coeff_init"])
+        s.debugSetLines(c["line_seg"], c["line_nd"])
+        ok, obj = s.optimize()
+        st = s.stats()
+        assert st["status"] == c["status"], c["tag"]
+        seen.add(st["status"])
+        times, coeff, traj = s.generatePwpOut(0.0, p.dc)
+        th = helpers.golden_theta_out(c)
+        assert np.abs(coeff - th).max() <= max(COEF_TOL, helpers.theta_tol(c)), (c["tag"], np.abs(coeff - th).max())
+        r = oracle.optimize(p, 1, c["coeff_init"], [], [], lines=(c["line_seg"], c["line_nd"]))
+        assert np.abs(coeff - r["coeff"]).max() <= COEF_TOL, (c["tag"], np.abs(coeff - r["coeff"]).max())
+        if c["status"] != 2:
+            assert ok and abs(obj - r["objective"]) <= COST_RTOL * (1 + abs(r["objective"])), c["tag"]
+            assert abs(obj - c["cost"]) <= 1e-5 * (1 + abs(c["cost"])), c["tag"]
+        else:
+            assert not ok and obj is None
+            np.testing.assert_array_equal(coeff, c["coeff_init"])      # output == initial guess
+        # generatePwpOut's samples of the GPU coefficients
+        ref = oracle.sample(coeff, p.T_span, p.dc)
+        assert len(ref) == len(traj)
+        np.testing.assert_allclose(traj, ref, rtol=0, atol=1e-12)
+        s.close()
+    assert seen == {0, 1, 2}
+
+
+def _check_scene(be, oracle, sc, n_scenes=1, first_local=0, n_local=None):
+    p = sc["par"]
+    bb = be.BatchBackend(p, sc["statics"], first_local=first_local, n_local=n_local)
+    n_local = bb.n_local
+    d_comm = bb.to_device(sc["committed"]); d_guess = bb.to_device(sc["guesses"][first_local:first_local + n_local])
+    bb.replan(d_comm, d_guess)
+    sol = bb.solutions(); states = bb.states(); com = bb.commits()
+    hx, hn = bb.debug_hulls(0)
+    worst = 0.0
+    for a in range(n_local):
+        aid = first_local + a + 1
+        r = oracle.replan(p, aid, sc["committed"], sc["guesses"][aid - 1], sc["statics"], want_hulls=True)
+        K = int(sol[a]["K"])
+        # hulls: oracle lists the present agents in id order (own skipped)
+        others = [j for j in range(p.num_agents) if j != aid - 1]
+        for oj, j in enumerate(others):
+            for i in range(p.num_pol):
+                nv = r["hull_nv"][oj * p.num_pol + i]
+                assert hn[j, i] == nv
+                np.testing.assert_array_equal(hx[j, i, :nv], r["hull_xy"][oj * p.num_pol + i, :nv])
+        seg, nd = bb.debug_lines(a)
+        np.testing.assert_array_equal(seg, r["line_seg"])
+        np.testing.assert_array_equal(nd, r["line_nd"])                 # bit-exact lines, reference loop order
+        st = sol[a]["stats"]
+        assert int(st["status"]) == r["status"] and int(st["n_lines"]) == r["n_lines"]
+        assert int(st["n_lp"]) == r["n_lp"] and int(st["n_lp_failed"]) == r["n_lp_failed"] and int(st["n_rows"]) == r["n_rows"]
+        co = np.array(sol[a]["coeff"])[:, :K, :]
+        err = np.abs(co - r["coeff"]).max(); worst = max(worst, err)
+        assert err <= COEF_TOL, (aid, err)
+        if r["status"] != 2:
+            assert abs(float(st["objective"]) - r["objective"]) <= COST_RTOL * (1 + abs(r["objective"]))
+        ref = oracle.sample(co, p.T_span, p.dc, cap=p.max_states)
+        assert int(sol[a]["n_states"]) == len(ref)
+        np.testing.assert_allclose(states[a, :len(ref)], ref, rtol=0, atol=1e-12)
+        t0 = float(sc["guesses"][aid - 1]["t_start"])
+        np.testing.assert_allclose(np.array(sol[a]["times"])[:K + 1], t0 + np.arange(K + 1) * p.T_span, atol=1e-12)
+        assert int(com[a]["id"]) == aid and int(com[a]["pwp"]["n_seg"]) == K
+        np.testing.assert_array_equal(np.array(com[a]["pwp"]["coeff"])[:, :K, :], co)
+    bb.close()
+    return worst
+
+
+def test_replan_config2_five_agents(be, oracle):
+    for seed in (0, 1, 2):
+        _check_scene(be, oracle, scene.make_scene(5, 0, seed=seed))
+
+
+def test_replan_config3_eight_agents_twenty_obstacles(be, oracle):
+    for seed in (0, 3):
+        _check_scene(be, oracle, scene.make_scene(8, 20, seed=seed))
+
+
+def test_replan_config1_single_agent(be, oracle):
+    _check_scene(be, oracle, scene.make_scene(1, 0, seed=0, K=3))
+
+
+def test_replan_short_guesses(be, oracle):
+    for K in (1, 2, 4, 6):
+        _check_scene(be, oracle, scene.make_scene(3, 4, seed=20 + K, K=K))
+
+
+def test_replan_sharded_slice(be, oracle):
+    """A rank that owns agents [4, 8) of an 8-agent scene produces what the full run produces."""
+    _check_scene(be, oracle, scene.make_scene(8, 20, seed=5), first_local=4, n_local=4)
+
+
+def test_per_agent_api_matches_batch(be, oracle):
+    sc = scene.make_scene(5, 3, seed=7)
+    p = sc["par"]
+    aid = 2
+    hx, hn, h0, n0 = be.hulls_batch(sc["committed"], 0.0, p.num_pol, p.T_span, p.drone_radius)
+    others = [j for j in range(5) if j != aid - 1]
+    s = _solver(be, p, aid)
+    s.setStaticObstVert(sc["statics"])
+    g = sc["guesses"][aid - 1]; K = int(g["K"])
+    s.setInitTrajectory(np.arange(K + 1) * p.T_span, np.array(g["coeff"])[:, :K, :])
+    s.setHulls([[hx[j, i, :hn[j, i]] for i in range(p.num_pol)] for j in others])
+    s.setHullsNoInflation([[h0[j, i, :n0[j, i]] for i in range(p.num_pol)] if j != aid - 1 else [] for j in range(5)])
+    ok, obj = s.optimize()
+    r = oracle.replan(p, aid, sc["committed"], g, sc["statics"])
+    seg, nd = s.debugGetLines()
+    np.testing.assert_array_equal(nd, r["line_nd"])
+    times, coeff, traj = s.generatePwpOut(12.5, p.dc)
+    assert ok and np.abs(coeff - r["coeff"]).max() <= COEF_TOL
+    np.testing.assert_allclose(times, 12.5 + np.arange(K + 1) * p.T_span)
+    assert s.stats()["solve_us"] > 0
+    s.close()
+
+
+def test_call_sequence_errors(be):
+    from neptune_amd._lib import BackendError
+    p = scene.scaled_params(2, 0)
+    s = be.PolySolver(p.num_pol, 3, 1, p.T_span, p.pb, p.weight, 0.5, True)
+    with pytest.raises(BackendError):
+        s.optimize()                                 # before setMaxValues / setInitTrajectory
+    with pytest.raises(BackendError):
+        be.PolySolver(p.num_pol, 5, 1, p.T_span, p.pb, p.weight, 0.5, True)   # deg_pol != 3
+    with pytest.raises(BackendError):
+        be.PolySolver(p.num_pol, 3, 1, p.T_span, p.pb, p.weight, 0.5, False)  # bilinear variant
+    s.close()
+
+
+def test_full_size_properties_64_agents(be):
+    """BASELINE config 4 size on one GPU (64 agents + 20 obstacles): size-independent properties
+    instead of the oracle: every line separates, the solution is feasible and C2, initial state is
+    kept, and the cost does not exceed the cost of any feasible guess."""
+    sc = scene.make_scene(64, 20, seed=0)
+    p = sc["par"]
+    bb = be.BatchBackend(p, sc["statics"])
+    bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]))
+    sol = bb.solutions()
+    T = p.T_span
+    M4 = scene.A_POS_INV * np.array([T ** 3, T ** 2, T, 1.0])[:, None]
+    n_ok = 0
+    for a in range(64):
+        g = sc["guesses"][a]; K = int(g["K"]); ci = np.array(g["coeff"])[:, :K, :]
+        st = sol[a]["stats"]; co = np.array(sol[a]["coeff"])[:, :K, :]
+        assert int(st["n_lp_failed"]) == 0
+        if int(st["status"]) == 2:
+            continue
+        n_ok += 1
+        np.testing.assert_allclose(co[:, 0, 1:], ci[:, 0, 1:], atol=1e-9)          # initial p, v, a
+        tp = np.array([T ** 3, T ** 2, T, 1.0]); tv = np.array([3 * T * T, 2 * T, 1.0, 0]); ta = np.array([6 * T, 2.0, 0, 0])
+        for i in range(K - 1):                                                      # C2 continuity
+            assert np.abs(co[:2, i] @ tp - co[:2, i + 1, 3]).max() < 1e-8
+            assert np.abs(co[:2, i] @ tv - co[:2, i + 1, 2]).max() < 1e-8
+            assert np.abs(co[:2, i] @ ta - 2 * co[:2, i + 1, 1]).max() < 1e-8
+        if int(st["status"]) == 0:
+            assert np.abs(co[:2, K - 1] @ tv).max() < 1e-8 and np.abs(co[:2, K - 1] @ ta).max() < 1e-8   # terminal rest
+        seg, nd = bb.debug_lines(a)
+        cpx = co[0] @ M4; cpy = co[1] @ M4
+        for s_, l in zip(seg, nd):
+            assert (l[0] * cpx[s_] + l[1] * cpy[s_] + l[2] - 1).max() <= 1e-7
+        assert cpx.min() >= p.x_min - 1e-7 and cpx.max() <= p.x_max + 1e-7
+    assert n_ok >= 60
+    bb.close()
