@@ -223,7 +223,7 @@ def replan(p, agent_id, recs, guess, statics, case_id=None, want_hulls=False):
     lib().orc_replan(C.byref(par), p.drone_radius, len(recs), recs.ctypes.data, g.ctypes.data,
                      C.byref(S.c), cid.ctypes.data if cid is not None else None, C.byref(res),
                      hx.ctypes.data if want_hulls else None, hn.ctypes.data if want_hulls else None)
-    out = result_dict(res, int(g["K"]))
+    out = result_dict(res, int(np.asarray(g["K"]).reshape(-1)[0]))
     if want_hulls:
         out["hull_xy"] = hx; out["hull_nv"] = hn
     return out
