@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the back-end path: whole-node back-end replans per second.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+          --master-port P bench.py --gpus N --steps K --warmup W)
+
+Workload (BASELINE.json north_star / configs[3] scene on the named GPU count): 64 agents + 20
+static polytope obstacles, K = 8 segments, reference yaml parameters, the 32 seeded scenes
+(seeds 0..31) in flight per step.  One step = one bulk-synchronous round: every
+agent of every scene does one full back-end replan (MINVO hulls of the other agents' committed
+trajectories -> separating-line LPs -> spline QP -> sampled states -> committed record), then the
+committed records are exchanged (all-gather over RCCL when N > 1) and become the obstacles of the
+next step.  Inputs are resident in HBM before the timed region.  Agents are block-sharded by id
+across ranks; total work is fixed, so "scaling" is "strong".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+
+def algorithmic_bytes(p, sc, hull_nv, n_states):
+    """fp64 compulsory traffic of one replan: guess + other agents' hull vertices
+    + statics + bases in; coefficients, cost, status and sampled states out."""
+    K = int(sc["guesses"][0]["K"])
+    guess = 8 * (12 * K + (K + 1))
+    N = p.num_agents
+    hull = 16.0 * hull_nv[:, :K].sum() * (N - 1) / N          # per agent: every other agent's hulls
+    statics = 16 * sum(len(s) for s in sc["statics"])
+    bases = 16 * N
+    out = 8 * (12 * K + 1) + 4 + 96 * n_states
+    return guess + hull + statics + bases + out
+
+
+def cpu_baseline(p, scenes, budget_s=12.0):
+    """The CPU oracle (kind "port": the reference needs Gurobi/GLPK/CGAL, absent here) timed on the
+    host cores on a bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle
+    oracle.lib()
+    cores = os.cpu_count() or 1
+    jobs = [(s, a) for s in scenes for a in range(p.num_agents)] * 64   # bounded by time below
+    t0 = time.perf_counter()
+    done = 0
+
+    def one(job):
+        s, a = job
+        return oracle.replan(p, a + 1, s["committed"], s["guesses"][a], s["statics"])["status"]
+    chunk = max(cores * 4, 64)
+    with ThreadPoolExecutor(cores) as ex:     # ctypes releases the GIL: one solver thread per core
+        for k in range(0, len(jobs), chunk):
+            list(ex.map(one, jobs[k:k + chunk]))
+            done += len(jobs[k:k + chunk])
+            if time.perf_counter() - t0 > budget_s:
+                break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "replans/s", "cores": cores, "kind": "port",
+            "sample": "%d replans of the same scenes (seeds 0..), one oracle thread per core, %.1f s" % (done, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--agents", type=int, default=64)
+    ap.add_argument("--obstacles", type=int, default=20)
+    ap.add_argument("--scenes", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from neptune_amd import abi, dist as ndist, scene
+    from neptune_amd.backend import BatchBackend
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the back end has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group("nccl", device_id=dev)
+
+    N, M, S = args.agents, args.obstacles, args.scenes
+    scenes = [scene.make_scene(N, M, seed=s) for s in range(S)]
+    p = scenes[0]["par"]
+    # one static-obstacle set per handle: scenes share the statics of seed 0 (bases are seed-free)
+    for s in scenes[1:]:
+        s["statics"] = scenes[0]["statics"]
+    first_local, n_local = ndist.shard(N, world, rank)
+    be = BatchBackend(p, scenes[0]["statics"], first_local=first_local, n_local=n_local, n_scenes=S, device=dev)
+    com, gue = ndist.stack_scenes(scenes)
+    d_committed = be.to_device(com)
+    d_guess = be.to_device(np.ascontiguousarray(gue[:, first_local:first_local + n_local]))
+    ex = ndist.RoundExchange(S, N, world, rank, device=dev)
+
+    def step():
+        be.replan(d_committed, d_guess)
+        ex.gather(be.d_commit, d_committed)
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            tdist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    be.enable_timing(True)
+    be.reset_timing()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+        dt = float(t.item())
+    qp_ms, n_launch = be.kernel_time_ms(2)
+    hull_ms, _ = be.kernel_time_ms(0)
+    sep_ms, _ = be.kernel_time_ms(1)
+    seq_ms, _ = be.kernel_time_ms(3)
+    be.enable_timing(False)
+
+    sol = be.solutions()
+    status = sol["stats"]["status"].astype(int)
+    iters = sol["stats"]["iters"].astype(int)
+    hx, hn = be.debug_hulls(0)
+    n_states = int(sol[0]["n_states"])
+    replans_per_step = S * N
+    value = replans_per_step * args.steps / dt
+
+    if rank == 0:
+        bytes_per_replan = algorithmic_bytes(p, scenes[0], hn, n_states)
+        launch_replans = S * n_local
+        achieved = bytes_per_replan * launch_replans / (qp_ms * 1e-3) / 1e9 if qp_ms > 0 else 0.0
+        out = {
+            "metric": "backend_replans_per_sec", "value": value, "unit": "replans/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d agents + %d static obstacles, K=8, %d seeded scenes in flight per step (seeds 0..%d)" % (N, M, S, S - 1),
+                       "agents": N, "obstacles": M, "scenes_in_flight": S, "replans_per_step": replans_per_step,
+                       "sharding": "agents block-sharded by id, %d per GPU, all-gather of committed records per step" % n_local,
+                       "params": "reference neptune_mtlp_benchmark.yaml (T_span 0.5, num_pol 8, weight 1000, v 2, a 3)"},
+            "solver": {"status_ok": int((status == 0).sum()), "status_relaxed": int((status == 1).sum()),
+                       "status_failed": int((status == 2).sum()), "ipm_iters_mean": float(iters.mean()),
+                       "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum())},
+            "p50_solve_ms": seq_ms,
+            "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "launches": n_launch},
+            "roofline": {"bound": "hbm", "kernel": "qp_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_replan": bytes_per_replan, "replans_per_launch": launch_replans,
+                         "note": "latency-bound path: ~%d dependent interior-point iterations per replan" % round(float(iters.mean()))},
+            "reference_budget": "reference TimeLimit 0.05 s/solve, replan timer 20 Hz/agent => <= %d replans/s for %d agents" % (20 * N, N),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(p, scenes)
+        print(json.dumps(out))
+    if world > 1:
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,62 @@
+"""Multi-GPU rounds: agents block-sharded by id across ranks, committed trajectories exchanged by
+one all-gather of fixed-size records per round.
+
+The reference runs one OS process per agent and broadcasts each committed trajectory on the
+latched ROS topic /trajs (reference neptune/src/neptune_ros.cpp:172,179,434-480, received at
+:379-430).  Here a rank owns n_local = N / world agents of every scene; after a round each rank
+holds [S][n_local] new records (abi.nep_traj_rec, the DynTraj.msg mirror) and one all-gather over
+RCCL/xGMI rebuilds the [S][N] snapshot every rank replans against next (bulk-synchronous Jacobi
+rounds instead of the reference's asynchronous last-writer-wins).
+"""
+import numpy as np
+
+from . import abi
+
+REC_BYTES = abi.TRAJ_REC_DTYPE.itemsize
+
+
+def shard(num_agents, world, rank):
+    """Block partition by agent id: returns (first_local, n_local).  N must divide evenly so that
+    the all-gather carries equal-size pieces."""
+    if num_agents % world:
+        raise ValueError("num_agents (%d) must be a multiple of the world size (%d)" % (num_agents, world))
+    n_local = num_agents // world
+    return rank * n_local, n_local
+
+
+class RoundExchange:
+    """all-gather of the committed-trajectory records.  Works on any torch device/backend
+    (nccl == RCCL on ROCm; gloo in the CPU tests)."""
+
+    def __init__(self, n_scenes, num_agents, world=1, rank=0, group=None, device="cpu"):
+        import torch
+        self.torch = torch
+        self.S, self.N, self.world, self.rank, self.group = n_scenes, num_agents, world, rank, group
+        self.first_local, self.n_local = shard(num_agents, world, rank)
+        self.piece = n_scenes * self.n_local * REC_BYTES
+        self.gathered = torch.empty(world * self.piece, dtype=torch.uint8, device=device) if world > 1 else None
+
+    def gather(self, commit_local, committed_out):
+        """commit_local: uint8 [S][n_local][REC]; committed_out: uint8 [S][N][REC] (overwritten)."""
+        torch = self.torch
+        S, N, nl, W = self.S, self.N, self.n_local, self.world
+        if W == 1:
+            committed_out.copy_(commit_local)
+            return committed_out
+        import torch.distributed as dist
+        if hasattr(dist, "all_gather_into_tensor") and commit_local.is_cuda:
+            dist.all_gather_into_tensor(self.gathered, commit_local, group=self.group)
+        else:
+            pieces = list(self.gathered.view(W, self.piece).unbind(0))
+            dist.all_gather(pieces, commit_local.contiguous(), group=self.group)
+        # [W][S][n_local][REC] -> [S][W*n_local][REC]
+        src = self.gathered.view(W, S, nl * REC_BYTES).permute(1, 0, 2)
+        committed_out.view(S, W, nl * REC_BYTES).copy_(src)
+        return committed_out
+
+
+def stack_scenes(scenes):
+    """[scene dicts] -> (committed [S][N], guesses [S][N]) numpy structured arrays."""
+    com = np.stack([s["committed"] for s in scenes])
+    gue = np.stack([s["guesses"] for s in scenes])
+    return com, gue
