@@ -280,3 +280,35 @@ def statics_csr(statics):
         off[i + 1] = off[i] + len(s)
     xy = np.concatenate(statics).astype(np.float64) if len(statics) else np.zeros((0, 2))
     return off, np.ascontiguousarray(xy)
+
+
+def synthetic_entangle(sc, seed, frac=0.1):
+    """Synthetic entanglement inputs for a scene: for ~frac of the agent
+    pairs one active case, 2-4 bend points per agent (bend[0] is the base, neptune_ros.cpp:453-457).
+    Returns case_id [N][NEP_MAX_POL][N] (row a = the block agent a+1 hands to the back end: the
+    alphas case of (segment, other agent), 0 = none; solver_gurobi_poly.cpp:624-631) and writes the
+    bend points into sc['committed']."""
+    rng = np.random.default_rng(seed)
+    p = sc["par"]; N = p.num_agents
+    com = sc["committed"]
+    for j in range(N):
+        nb = int(rng.integers(2, 5))
+        com[j]["n_bend"] = nb
+        com[j]["bend"][0] = p.pb[j]
+        for b in range(1, nb):
+            # a few decimetres off another agent's guessed path, so that the distance cull
+            # (:738-745, within the control polygon's length of its first point) lets LPs through
+            k = int(rng.integers(0, N)); i_k = int(rng.integers(1, 7))
+            q0 = np.array([sc["guesses"][k]["coeff"][0][i_k][3], sc["guesses"][k]["coeff"][1][i_k][3]])
+            ang = rng.uniform(0, 2 * np.pi); rad = rng.uniform(0.2, 0.5)
+            com[j]["bend"][b] = q0 + rad * np.array([np.cos(ang), np.sin(ang)])
+    case_id = np.zeros((N, abi.NEP_MAX_POL, N), dtype=np.int32)
+    for a in range(N):
+        for j in range(N):
+            if j == a or rng.uniform() > frac:
+                continue
+            nb = int(com[j]["n_bend"])
+            cid = int(rng.integers(1, nb + 2))           # 1 .. nb+1
+            s0 = int(rng.integers(0, abi.NEP_MAX_POL))
+            case_id[a, s0:, j] = cid                     # active from some knot on
+    return case_id

@@ -229,7 +229,8 @@ def test_full_size_properties_64_agents(be):
     for a in range(64):
         g = sc["guesses"][a]; K = int(g["K"]); ci = np.array(g["coeff"])[:, :K, :]
         st = sol[a]["stats"]; co = np.array(sol[a]["coeff"])[:, :K, :]
-        assert int(st["n_lp_failed"]) <= 8       # a failed LP silently drops its constraint (solver_gurobi_poly.cpp:491-494)
+        # a failed LP (guess passing over a base square) silently drops its constraint (solver_gurobi_poly.cpp:491-494)
+        assert int(st["n_lp_failed"]) <= 0.05 * int(st["n_lp"])
         if int(st["status"]) == 2:
             continue
         n_ok += 1
@@ -248,3 +249,58 @@ def test_full_size_properties_64_agents(be):
         assert cpx.min() >= p.x_min - 1e-7 and cpx.max() <= p.x_max + 1e-7
     assert n_ok >= 60
     bb.close()
+
+
+def test_entangle_lines_match_oracle(be, oracle):
+    """Config-5 style inputs (entangle check on, synthetic ent_state): the extra separating lines
+    of solver_gurobi_poly.cpp:620-637,715-764 and the resulting QP match the oracle."""
+    import dataclasses
+    sc = scene.make_scene(8, 6, seed=11)
+    case_id = scene.synthetic_entangle(sc, seed=5, frac=0.5)
+    p = dataclasses.replace(sc["par"], enable_entangle=True)
+    bb = be.BatchBackend(p, sc["statics"])
+    d_ent = bb.torch.from_numpy(case_id.reshape(-1).copy()).to(bb.device)
+    bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]), d_ent=d_ent)
+    sol = bb.solutions()
+    extra = 0
+    for a in range(8):
+        r = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"], case_id=case_id[a])
+        r0 = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"])
+        extra += r["n_lp"] - r0["n_lp"]
+        seg, nd = bb.debug_lines(a)
+        np.testing.assert_array_equal(seg, r["line_seg"])
+        np.testing.assert_array_equal(nd, r["line_nd"])
+        K = int(sol[a]["K"])
+        assert int(sol[a]["stats"]["status"]) == r["status"]
+        assert int(sol[a]["stats"]["n_lp"]) == r["n_lp"] and int(sol[a]["stats"]["n_lp_failed"]) == r["n_lp_failed"]
+        assert np.abs(np.array(sol[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= COEF_TOL
+    assert extra > 0, "the synthetic entangle inputs produced no entangle LP"
+    bb.close()
+
+
+def test_entangle_through_per_agent_api(be, oracle):
+    sc = scene.make_scene(4, 0, seed=13)
+    case_id = scene.synthetic_entangle(sc, seed=2, frac=1.0)
+    p = sc["par"]; aid = 1; N = 4
+    hx, hn, h0, n0 = be.hulls_batch(sc["committed"], 0.0, p.num_pol, p.T_span, p.drone_radius)
+    s = _solver(be, p, aid)
+    g = sc["guesses"][aid - 1]; K = int(g["K"])
+    s.setInitTrajectory(np.arange(K + 1) * p.T_span, np.array(g["coeff"])[:, :K, :])
+    others = [j for j in range(N) if j != aid - 1]
+    s.setHulls([[hx[j, i, :hn[j, i]] for i in range(p.num_pol)] for j in others])
+    s.setHullsNoInflation([[h0[j, i, :n0[j, i]] for i in range(p.num_pol)] if j != aid - 1 else [] for j in range(N)])
+    # eu::ent_state per knot: alphas (agent_id, case) + active_cases
+    ent = []
+    for i in range(K + 1):
+        ii = min(i, abi.NEP_MAX_POL - 1)
+        alphas = [(j + 1, int(case_id[aid - 1, ii, j])) for j in range(N) if case_id[aid - 1, ii, j]]
+        ent.append(dict(alphas=alphas, active_cases=[1 if case_id[aid - 1, ii, j] else 0 for j in range(N)]))
+    bend = [np.array(sc["committed"][j]["bend"])[:int(sc["committed"][j]["n_bend"])] for j in range(N)]
+    s.setEntStateVector(ent, bend)
+    ok, obj = s.optimize()
+    r = oracle.replan(p, aid, sc["committed"], g, sc["statics"], case_id=case_id[aid - 1])
+    seg, nd = s.debugGetLines()
+    np.testing.assert_array_equal(nd, r["line_nd"])
+    t, coeff, traj = s.generatePwpOut(0.0, p.dc)
+    assert np.abs(coeff - r["coeff"]).max() <= COEF_TOL
+    s.close()
