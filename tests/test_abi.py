@@ -59,3 +59,14 @@ def test_oracle_is_not_reachable_from_the_product():
                 txt = open(os.path.join(dirpath, f)).read()
                 code = "\n".join(l for l in txt.splitlines() if not l.lstrip().startswith(("//", "#", "*", "/*")))
                 assert "from oracle" not in code and "import oracle" not in code and "neptune_oracle" not in code, f
+
+
+def test_cpp_host_class_compiles_and_links(L):
+    """include/neptune_poly_solver.hpp (the PolySolverGurobi-shaped C++ class) builds with plain g++."""
+    import subprocess
+    exe = os.path.join(ROOT, "tests", "cpp", "replan_example")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "replan_example.cpp"),
+                           "-L" + os.path.join(ROOT, "neptune_amd"), "-lneptune_backend",
+                           "-Wl,-rpath,$ORIGIN/../../neptune_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
+    assert os.path.exists(exe)

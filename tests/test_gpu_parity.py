@@ -304,3 +304,34 @@ def test_entangle_through_per_agent_api(be, oracle):
     t, coeff, traj = s.generatePwpOut(0.0, p.dc)
     assert np.abs(coeff - r["coeff"]).max() <= COEF_TOL
     s.close()
+
+
+def test_cpp_host_class_reference_call_sequence(be, oracle):
+    """tests/cpp/replan_example.cpp drives neptune_amd::PolySolver exactly as neptune.cpp:102-107,
+    1514-1527 drives PolySolverGurobi; results match the oracle, failure leaves objective untouched."""
+    import os, subprocess
+    exe = os.path.join(helpers.ROOT, "tests", "cpp", "replan_example")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build()
+    for c in helpers.load_qp_cases():
+        if c["tag"] not in ("tight K8 seed12", "hop qc seed32", "nostop K1", "contradictory", "rest K2"):
+            continue
+        p = helpers.params_of_case(c); K = c["K"]
+        txt = "%d %r %r\n" % (K, p.T_span, p.weight)
+        txt += " ".join(repr(float(x)) for x in (p.x_min, p.x_max, p.y_min, p.y_max, p.z_min, p.z_max, p.v_max, p.a_max)) + "\n"
+        txt += " ".join(repr(float(x)) for x in c["coeff_init"].reshape(-1)) + "\n"
+        txt += "%d\n" % len(c["line_seg"])
+        for s_, l in zip(c["line_seg"], c["line_nd"]):
+            txt += "%d %r %r %r\n" % (int(s_), float(l[0]), float(l[1]), float(l[2]))
+        out = subprocess.run([exe], input=txt, capture_output=True, text=True, check=True).stdout.split("\n")
+        ok, obj, ns, t0 = out[0].split()
+        coeff = np.array([[float(x) for x in ln.split()] for ln in out[1:1 + 3 * K]]).reshape(3, K, 4)
+        r = oracle.optimize(p, 1, c["coeff_init"], [], [], lines=(c["line_seg"], c["line_nd"]))
+        assert int(ok) == (0 if r["status"] == 2 else 1), c["tag"]
+        assert np.abs(coeff - r["coeff"]).max() <= COEF_TOL, c["tag"]
+        assert float(t0) == 3.25
+        if r["status"] == 2:
+            assert float(obj) == -12345.0           # objective_value untouched (solver_gurobi_poly.cpp:856-859)
+        else:
+            assert abs(float(obj) - r["objective"]) <= COST_RTOL * (1 + abs(r["objective"]))
