@@ -261,6 +261,10 @@ int nep_batch_debug_hulls(nep_batch_t* h, int32_t scene, double* hull_xy, int32_
 int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* seg, double* nd,
                           int32_t* n_out);
 
+/* Development aid: shader-cycle counters of the QP kernel's phases for one slot (handle must be
+ * created with NEP_QP_PROFILE set in the environment). */
+int nep_batch_debug_phase_cycles(nep_batch_t* h, int32_t slot, int64_t* out16);
+
 /* sizeof() of the POD records as compiled (0 nep_pwp, 1 nep_traj_rec, 2 nep_backend_cfg,
  * 3 nep_stats, 4 nep_batch_cfg, 5 nep_guess, 6 nep_solution, 7 nep_ent_view): lets a foreign-
  * language binding verify its struct mirror. */

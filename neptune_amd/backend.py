@@ -243,6 +243,11 @@ class BatchBackend:
         check(lib().nep_batch_kernel_time(self._h, which, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def debug_phase_cycles(self, slot=0):
+        out = (C.c_int64 * 16)()
+        check(lib().nep_batch_debug_phase_cycles(self._h, slot, out))
+        return list(out)
+
     def debug_hulls(self, scene=0):
         hx = np.zeros((self.N, self.par.num_pol, abi.NEP_HULL_MAX_V, 2)); hn = np.zeros((self.N, self.par.num_pol), dtype=np.int32)
         check(lib().nep_batch_debug_hulls(self._h, scene, abi.dptr(hx), abi.iptr(hn)))

@@ -7,6 +7,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -48,6 +49,7 @@ struct Engine {
   DevBuf<double> d_pb, d_static_xy; DevBuf<int> d_static_nv;
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_lp_stats;
+  DevBuf<long long> d_dbg; bool profile_phases = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
@@ -84,13 +86,21 @@ struct Engine {
     sp.lines_cap = sp.n_hull + N + sp.n_static + (sp.ent_enabled ? N * kBend : 0);
     if (sp.lines_cap < 8) sp.lines_cap = 8;
     const long lines_total = (long)NEP_MAX_POL * sp.lines_cap;
+    // LDS carve of the QP kernel: 11 doubles per line (n1, n2, h + 4 x (s, lambda)).  The worst case
+    // (every base and every obstacle close to every segment) almost never happens, so the carve is
+    // sized for the expected count and the rest spills to global scratch; when the expectation
+    // fits half a CU's LDS two workgroups share a CU.
     const size_t fixed = qp_lds_fixed_bytes();
-    long max_lds_lines = (long)((kLdsBudget - fixed) / 8 - 2 * 384) / 11;
-    lds_lines = (int)(lines_total < max_lds_lines ? lines_total : max_lds_lines);
-    lds_lines = (lds_lines + 1) & ~1;
-    lds_rows = 384 + 4 * lds_lines;
-    lds_bytes = fixed + (size_t)(3L * lds_lines + 2L * lds_rows) * 8;
-    rows_cap = 384 + 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
+    const long per_line = 11 * 8;
+    const long l_half = ((long)(160 * 1024 / 2) - (long)fixed) / per_line - 2;
+    const long l_full = ((long)kLdsBudget - (long)fixed) / per_line - 2;
+    const long expect = (long)NEP_MAX_POL * (sp.n_hull + sp.n_static / 4 + 12 + (sp.ent_enabled ? sp.num_agents / 4 : 0));
+    long ll = expect <= l_half ? l_half : l_full;
+    if (ll > lines_total) ll = lines_total;
+    lds_lines = (int)((ll + 1) & ~1L);
+    lds_rows = 4 * lds_lines;
+    lds_bytes = fixed + (size_t)(lds_lines + 2) * per_line;   // + the dummy line of the padded row groups
+    rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
     if (int e = d_hull_xy.ensure((size_t)n_scenes * sp.n_hull * np * kHullV * 2)) return e;
     if (int e = d_hull_nv.ensure((size_t)n_scenes * sp.n_hull * np)) return e;
     if (int e = d_hull0_xy.ensure((size_t)n_scenes * N * np * 2)) return e;
@@ -100,7 +110,10 @@ struct Engine {
     if (int e = d_line_nd.ensure((size_t)slots * lines_total * 3)) return e;
     if (int e = d_line_cnt.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_lp_stats.ensure((size_t)slots * 2)) return e;
-    if (lines_total > lds_lines) { if (int e = d_row_scratch.ensure((size_t)slots * (2L * rows_cap + 3L * (rows_cap / 4)))) return e; }
+    profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
+    if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 16)) return e; }
+    if (lines_total > lds_lines) { if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e; }
+    else d_row_scratch.release();
     return 0;
   }
   void fill(ProblemSet& ps) {
@@ -109,6 +122,7 @@ struct Engine {
     ps.bend_xy = d_bend_xy.p; ps.bend_n = d_bend_n.p;
     ps.line_nd = d_line_nd.p; ps.line_cnt = d_line_cnt.p; ps.lp_stats = d_lp_stats.p;
     ps.row_scratch = d_row_scratch.p; ps.rows_cap = rows_cap; ps.lds_rows = lds_rows; ps.lds_lines = lds_lines;
+    ps.dbg = profile_phases ? d_dbg.p : nullptr;
   }
   int upload_statics(int n, const int32_t* off, const double* xy) {
     std::vector<double> sx((size_t)(n > 0 ? n : 1) * kHullV * 2, 0.0); std::vector<int> nv(n > 0 ? n : 1, 0);
@@ -564,6 +578,15 @@ int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* se
   int n = 0;
   for (int s = 0; s < NEP_MAX_POL; s++) for (int c = 0; c < cnt[s]; c++) { if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
   *n_out = n;
+  return 0;
+}
+
+// development aid: per-phase shader cycles of the QP kernel (only with NEP_QP_PROFILE set at create)
+int nep_batch_debug_phase_cycles(nep_batch_t* h, int32_t slot, int64_t* out16) {
+  if (!h || !out16 || slot < 0 || slot >= h->slots) return fail(NEP_E_ARG, "bad arguments");
+  if (!h->eng.profile_phases) return fail(NEP_E_STATE, "NEP_QP_PROFILE was not set when the handle was created");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out16, h->eng.d_dbg.p + (size_t)slot * 16, 16 * sizeof(long long), hipMemcpyDeviceToHost));
   return 0;
 }
 

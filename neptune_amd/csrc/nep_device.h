@@ -56,6 +56,7 @@ struct ProblemSet {
   nep_solution* solution;        // [slots]
   double* states;                // [slots][max_states][12] or null
   nep_traj_rec* commit;          // [slots] or null
+  long long* dbg;                // [slots][16] phase cycle counters (development aid) or null
 };
 
 struct SampleSched {             // per K: n, seg[], dt[]

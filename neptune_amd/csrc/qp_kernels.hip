@@ -12,104 +12,209 @@
 // so the normal matrix  H + G' W G  collapses to  Hax (+) sum_rho D[rho] (x) B[rho]'B[rho]  with
 // 4 weights per base row; rows only ever touch three R x 3 arrays staged in LDS.
 //
-// Thread roles: t < 3R owns the two box rows of (rho, axis); every thread also owns slice t&7
-// of the lines of control point (seg,k) = (t>>5, (t>>3)&3): the 8 slices of one control point
-// sit in consecutive lanes, so the scatter onto base rows is three xor-shuffles, not atomics.
-// Row state (s, lambda) lives in LDS (global scratch only if it does not fit).
+// Work split per iteration (4 row passes, ~15 workgroup barriers):
+//   * thread t < 3R owns the two box rows of (rho, axis), state in registers;
+//   * every thread owns slice t&7 of the lines of control point (seg,k) = (t>>5, (t>>3)&3): the 8
+//     slices of one control point sit in consecutive lanes, so the scatter onto base rows is three
+//     xor-shuffles, not atomics; line-row state (s, lambda) is staged in LDS;
+//   * all threads assemble the n x n normal matrix from the 4x64 base-row weights;
+//   * wave 0 factors it in registers (lane i = row i, pivots broadcast with v_readlane) and runs
+//     the forward/backward substitutions without a barrier.
+// The LDS carve is sized for the expected line count so that two workgroups share a CU; rows
+// beyond it spill to a global scratch (correct, slower).
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "nep_device.h"
 
 namespace nep {
 
 constexpr int BS = 256;
-constexpr int MS = 24;            // matrix stride / max n
-constexpr int kBoxRows = 6 * kMaxR;  // 384: line rows start here in the state arrays
+constexpr int MS = 25;            // LDS row stride of the normal matrix (n <= 24; odd -> no bank conflicts)
 constexpr int kMaxIt = 60;
 
 // ---- LDS carve (in doubles) -------------------------------------------------------------------
 constexpr int oB = 0;                       // [64][8]
-constexpr int oU = oB + kMaxR * kNZ;        // [64][3]
-constexpr int oOff = oU + kMaxR * 3;        // [64][3]
+constexpr int oOff = oB + kMaxR * kNZ;      // [64][3]
 constexpr int oCp = oOff + kMaxR * 3;       // [64][3] base-row values at z
 constexpr int oUa = oCp + kMaxR * 3;        // [64][3] B dx_aff
 constexpr int oUd = oUa + kMaxR * 3;        // [64][3] B dx
 constexpr int oAccL = oUd + kMaxR * 3;      // [32][8] line accumulators per control point
-constexpr int oAccB = oAccL + 32 * 8;       // [192][4] box accumulators per (rho,axis)
-constexpr int oM = oAccB + 192 * 4;         // [24][24]
-constexpr int oHax = oM + MS * MS;          // [8][8]
-constexpr int oTh = oHax + 64;              // [32][8]
-constexpr int oThU = oTh + 32 * kNZ;        // [32][3]
-constexpr int oZ = oThU + 32 * 3;           // [24]
-constexpr int oG = oZ + MS;                 // [24]
-constexpr int oRd = oG + MS;                // [24]
-constexpr int oRhs = oRd + MS;              // [24]
-constexpr int oDxa = oRhs + MS;             // [24]
-constexpr int oDx = oDxa + MS;              // [24]
-constexpr int oGq = oDx + MS;               // [24]
-constexpr int oZl = oGq + MS;               // [24] loose snapshot
-constexpr int oInvD = oZl + MS;             // [24]
-constexpr int oEp = oInvD + MS;             // [8]
+constexpr int oDc = oAccL + 32 * 8;         // [64][4] combined weights Dxx,Dxy,Dyy,Dzz
+constexpr int oTc = oDc + kMaxR * 4;        // [64][6] combined T_lambda[3], T1[3]
+constexpr int oM = oTc + kMaxR * 6;         // [24][25]
+constexpr int oHax = oM + 24 * MS;          // [8][8]
+constexpr int oZ = oHax + 64;               // [24]
+constexpr int oG = oZ + 24;                 // [24]
+constexpr int oRd = oG + 24;                // [24]
+constexpr int oRhs = oRd + 24;              // [24]
+constexpr int oDxa = oRhs + 24;             // [24]
+constexpr int oDx = oDxa + 24;              // [24]
+constexpr int oGq = oDx + 24;               // [24]
+constexpr int oZl = oGq + 24;               // [24] loose snapshot
+constexpr int oInvD = oZl + 24;             // [24]
+constexpr int oEp = oInvD + 24;             // [8]
 constexpr int oCoef = oEp + 8;              // [3][8][4] initial guess
 constexpr int oTheta = oCoef + 96;          // [3][8][4] result
 constexpr int oInit = oTheta + 96;          // [3][3] b0,c0,d0 per axis
 constexpr int oScal = oInit + 9;            // scalars, see enum
-constexpr int oRed = oScal + 32;            // [8] reduction scratch
-constexpr int oFixedEnd = oRed + 8;
+constexpr int oRed = oScal + 32;            // [16] reduction scratch
+constexpr int oFixedEnd = oRed + 16;
 constexpr int kFixedDoubles = (oFixedEnd + 1) & ~1;
 
-enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose };
+enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu };
 
 size_t qp_lds_fixed_bytes() { return (size_t)kFixedDoubles * sizeof(double) + 64 * sizeof(int); }
 
-__device__ __forceinline__ double wave_min(double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ double wave_max(double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ double wave_sum(double v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
-
-// block-wide reductions (all threads must call; result broadcast).  red: LDS [8]
-template <int OP>
-__device__ __forceinline__ double block_reduce(double v, double* red) {
-  v = OP == 0 ? wave_min(v) : (OP == 1 ? wave_max(v) : wave_sum(v));
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-  __syncthreads();
-  const double a = red[0], b = red[1], c = red[2], d = red[3];
-  return OP == 0 ? fmin(fmin(a, b), fmin(c, d)) : (OP == 1 ? fmax(fmax(a, b), fmax(c, d)) : (a + b) + (c + d));
+// Cross-lane primitives on the VALU (DPP) and scalar (v_readlane) paths: HIP's __shfl* go through
+// ds_bpermute (an LDS round trip per 32-bit half), which dominated the first version's reductions
+// and the register Cholesky.
+template <int CTRL>
+__device__ __forceinline__ double dpp(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double slice_sum(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); return v; }
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8
+constexpr int DPP_ROW_MIRROR = 0x140;  // lane i <-> 15-i inside each 16
+__device__ __forceinline__ double bcast(double v, int lane) {   // lane: wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane), hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// sum over each aligned group of 8 lanes (result in all 8)
+__device__ __forceinline__ double slice_sum(double v) { v += dpp<DPP_XOR1>(v); v += dpp<DPP_XOR2>(v); v += dpp<DPP_HALF_MIRROR>(v); return v; }
+__device__ __forceinline__ double wave_sum(double v) {
+  v = slice_sum(v); v += dpp<DPP_ROW_MIRROR>(v);
+  return (bcast(v, 0) + bcast(v, 16)) + (bcast(v, 32) + bcast(v, 48));
+}
+__device__ __forceinline__ double wave_max(double v) {
+  v = fmax(v, dpp<DPP_XOR1>(v)); v = fmax(v, dpp<DPP_XOR2>(v)); v = fmax(v, dpp<DPP_HALF_MIRROR>(v)); v = fmax(v, dpp<DPP_ROW_MIRROR>(v));
+  return fmax(fmax(bcast(v, 0), bcast(v, 16)), fmax(bcast(v, 32), bcast(v, 48)));
+}
 
-struct RowCtx {
-  // box role
-  bool has_box; int q, brho, bax; double bhi, blo;
-  // line role
-  bool has_line; int lbeg, lend, lk, lrho, slice;
-  const double *n1, *n2, *lh;
-};
+// 1/a to ~1 ulp: v_rcp_f64 seed + two Newton steps (the IEEE divide expands to ~3x the work).
+__device__ __forceinline__ double frcp(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  double e = __builtin_fma(-a, r, 1.0); r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-a, r, 1.0); r = __builtin_fma(r, e, r);
+  return r;
+}
 
-// Enumerates this thread's rows: f(state_index, rho, ax, ay, az, h, is_line)
-template <class F>
-__device__ __forceinline__ void for_rows(const RowCtx& c, F&& f) {
-  if (c.has_box) {
-    const double ex = c.bax == 0 ? 1.0 : 0.0, ey = c.bax == 1 ? 1.0 : 0.0, ez = c.bax == 2 ? 1.0 : 0.0;
-    f(2 * c.q, c.brho, ex, ey, ez, c.bhi, false);
-    f(2 * c.q + 1, c.brho, -ex, -ey, -ez, -c.blo, false);
+// One max and up to three sums across the workgroup in one round trip.  red: LDS [16].
+__device__ __forceinline__ void block_reduce4(double& mx, double& s0, double& s1, double& s2, double* red) {
+  mx = wave_max(mx); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { double* o = red + 4 * (threadIdx.x >> 6); o[0] = mx; o[1] = s0; o[2] = s1; o[3] = s2; }
+  __syncthreads();
+  mx = fmax(fmax(red[0], red[4]), fmax(red[8], red[12]));
+  s0 = (red[1] + red[5]) + (red[9] + red[13]);
+  s1 = (red[2] + red[6]) + (red[10] + red[14]);
+  s2 = (red[3] + red[7]) + (red[11] + red[15]);
+}
+
+
+// ---- wave-level dense SPD solve (wave 0 of the workgroup) ---------------------------------------
+// Cholesky with one matrix row per lane: lane i keeps L[i][0..i] in registers, the pivot column is
+// broadcast lane->wave with v_readlane; no workgroup barrier.  L goes back to LDS (lower triangle of
+// sM, stride MS) together with 1/L[i][i]; returns false on a non-positive pivot.  Kept out of line
+// so that its register rows do not inflate the row passes' allocation.
+typedef __attribute__((address_space(3))) double* lds_dptr;
+// Branch-free on purpose: per-lane predicates (lane >= k ...) would become exec-mask juggling per
+// update; entries a lane does not own are simply allowed to hold garbage — they are never
+// broadcast, stored into the used triangle, or selected.
+template <int N>
+__device__ __forceinline__ bool chol_impl(lds_dptr sM, lds_dptr sInvD, int lane) {
+  const int row = lane < N ? lane : N - 1;
+  double Lr[N];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) Lr[j] = sM[row * MS + j];
+  double dinv = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const double d = bcast(Lr[j], j);
+    if (!(d > 0.0)) ok = false;
+    const double inv = 1.0 / sqrt(d);
+    Lr[j] *= inv;
+    dinv = lane == j ? inv : dinv;
+#pragma unroll
+    for (int k = j + 1; k < N; k++) Lr[k] = __builtin_fma(-Lr[j], bcast(Lr[j], k), Lr[k]);
   }
-  if (c.has_line) {
-    for (int l = c.lbeg + c.slice; l < c.lend; l += 8) f(kBoxRows + 4 * l + c.lk, c.lrho, c.n1[l], c.n2[l], 0.0, c.lh[l], true);
+  if (lane < N) {
+#pragma unroll
+    for (int j = 0; j < N; j++) sM[lane * MS + j] = Lr[j];   // (entries right of the diagonal are scratch)
+    sInvD[lane] = dinv;
+  }
+  return ok;
+}
+template <int N>
+__device__ __forceinline__ double solve_impl(lds_dptr sM, lds_dptr sInvD, int lane, double b) {
+  const int row = lane < N ? lane : N - 1;
+  double Lr[N], Uc[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    Lr[j] = sM[row * MS + j];     // row i of L (valid for j < i)
+    Uc[j] = sM[j * MS + row];     // column i of L (valid for j > i)
+  }
+  const double dinv = sInvD[row];
+#pragma unroll
+  for (int j = 0; j < N; j++) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Lr[j], xj, b); b = lane == j ? xj : (lane > j ? upd : b); }
+#pragma unroll
+  for (int j = N - 1; j >= 0; j--) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Uc[j], xj, b); b = lane == j ? xj : (lane < j ? upd : b); }
+  return b;
+}
+
+// n = 3 nz with nz in 1..8: one straight-line instantiation per size (no per-step size tests).
+__device__ __noinline__ bool chol_wave(unsigned m_off, unsigned d_off, int n) {   // LDS byte offsets of sM / sInvD
+  // arguments of a real call arrive in VGPRs: make the wave-uniform ones scalar again
+  m_off = __builtin_amdgcn_readfirstlane(m_off); d_off = __builtin_amdgcn_readfirstlane(d_off); n = __builtin_amdgcn_readfirstlane(n);
+  const lds_dptr sM = (lds_dptr)m_off; const lds_dptr sInvD = (lds_dptr)d_off;
+  const int lane = threadIdx.x & 63;
+  switch (n) {
+    case 3: return chol_impl<3>(sM, sInvD, lane);
+    case 6: return chol_impl<6>(sM, sInvD, lane);
+    case 9: return chol_impl<9>(sM, sInvD, lane);
+    case 12: return chol_impl<12>(sM, sInvD, lane);
+    case 15: return chol_impl<15>(sM, sInvD, lane);
+    case 18: return chol_impl<18>(sM, sInvD, lane);
+    case 21: return chol_impl<21>(sM, sInvD, lane);
+    default: return chol_impl<24>(sM, sInvD, lane);
+  }
+}
+
+// x = (L L')^-1 b with L from chol_wave; lane i holds b[i] / returns x[i].
+__device__ __noinline__ double solve_wave(unsigned m_off, unsigned d_off, int n, double b) {
+  m_off = __builtin_amdgcn_readfirstlane(m_off); d_off = __builtin_amdgcn_readfirstlane(d_off); n = __builtin_amdgcn_readfirstlane(n);
+  const lds_dptr sM = (lds_dptr)m_off; const lds_dptr sInvD = (lds_dptr)d_off;
+  const int lane = threadIdx.x & 63;
+  switch (n) {
+    case 3: return solve_impl<3>(sM, sInvD, lane, b);
+    case 6: return solve_impl<6>(sM, sInvD, lane, b);
+    case 9: return solve_impl<9>(sM, sInvD, lane, b);
+    case 12: return solve_impl<12>(sM, sInvD, lane, b);
+    case 15: return solve_impl<15>(sM, sInvD, lane, b);
+    case 18: return solve_impl<18>(sM, sInvD, lane, b);
+    case 21: return solve_impl<21>(sM, sInvD, lane, b);
+    default: return solve_impl<24>(sM, sInvD, lane, b);
   }
 }
 
 __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* sB = smem + oB; double* sU = smem + oU; double* sOff = smem + oOff; double* sCp = smem + oCp;
-  double* sUa = smem + oUa; double* sUd = smem + oUd; double* sAccL = smem + oAccL; double* sAccB = smem + oAccB;
-  double* sM = smem + oM; double* sHax = smem + oHax; double* sTh = smem + oTh; double* sThU = smem + oThU;
+  double* sB = smem + oB; double* sOff = smem + oOff; double* sCp = smem + oCp;
+  double* sUa = smem + oUa; double* sUd = smem + oUd; double* sAccL = smem + oAccL;
+  double* sDc = smem + oDc; double* sTc = smem + oTc;
+  double* sM = smem + oM; double* sHax = smem + oHax;
   double* sZ = smem + oZ; double* sG = smem + oG; double* sRd = smem + oRd; double* sRhs = smem + oRhs;
   double* sDxa = smem + oDxa; double* sDx = smem + oDx; double* sGq = smem + oGq; double* sZl = smem + oZl;
   double* sInvD = smem + oInvD; double* sEp = smem + oEp; double* sCoef = smem + oCoef; double* sTheta = smem + oTheta;
   double* sInit = smem + oInit; double* sc = smem + oScal; double* sRed = smem + oRed;
-  int* sI = (int*)(smem + kFixedDoubles);      // [0..8] line offsets, [16] flags
-  double* dyn = smem + kFixedDoubles + 32;     // dynamic part: lines then row state
+  int* sI = (int*)(smem + kFixedDoubles);      // [0..8] line offsets, [16..] flags
+  double* dyn = smem + kFixedDoubles + 32;     // dynamic part: line coefficients then line-row state
 
   const int tid = threadIdx.x;
   const int slot = blockIdx.x;
@@ -127,13 +232,16 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
   }
   __syncthreads();
   const int L = sI[NEP_MAX_POL];
-  const int m_rows = kBoxRows + 4 * L;
-  const bool in_lds = (L <= ps.lds_lines) && (m_rows <= ps.lds_rows);
-  double* lines = in_lds ? dyn : ps.row_scratch + (long)slot * (2L * ps.rows_cap + 3L * (ps.rows_cap / 4));
-  const int lstride = in_lds ? ps.lds_lines : ps.rows_cap / 4;
-  double* sN1 = lines; double* sN2 = lines + lstride; double* sLh = lines + 2 * lstride;
-  double* stS = in_lds ? dyn + 3 * ps.lds_lines : lines + 3 * lstride;
-  double* stL = stS + (in_lds ? ps.lds_rows : ps.rows_cap);
+  // Line coefficients and line-row state live in the LDS carve when the replan's L lines fit it
+  // (the normal case: ds_read/ds_write through address_space(3) pointers), else in the per-slot
+  // global spill; the solver body below is instantiated once per placement.
+  const int LL = ps.lds_lines + 2;            // strides; the last two entries are a dummy line (tail of the 4-wide row groups)
+  const int GL = ps.rows_cap / 4 + 2;
+  double* gsp = ps.row_scratch ? ps.row_scratch + (long)slot * (11L * GL) : nullptr;
+  typedef __attribute__((address_space(3))) double* lds_ptr;
+  // the dynamic LDS region starts right after the (empty) static group segment
+  const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
+  const lds_ptr ldyn = (lds_ptr)(unsigned int)(lds0 + (kFixedDoubles + 32) * sizeof(double));
   if (tid < 9) {
     if (tid < 3) {
       const double* c = sCoef + (tid * 8 + (K - 1)) * 4;
@@ -141,57 +249,96 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
     }
     sInit[tid] = sCoef[((tid / 3) * 8 + 0) * 4 + 1 + (tid % 3)];                    // b0,c0,d0 (:390-396)
   }
-  for (int i = 0; i < K; i++) {  // gather the separator's buckets into one segment-major list
-    const int beg = sI[i], cnt = sI[i + 1] - beg;
-    const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
-    for (int l = tid; l < cnt; l += BS) { sN1[beg + l] = src[3 * l]; sN2[beg + l] = src[3 * l + 1]; sLh[beg + l] = 1.0 - src[3 * l + 2]; }
-  }
   __syncthreads();
-  const double f0 = sc[sFinal0], f1 = sc[sFinal1], f2 = sc[sFinal2];
-  const double dix = sCoef[3] - f0, diy = sCoef[32 + 3] - f1, diz = sCoef[64 + 3] - f2;
+  const double dix = sCoef[3] - sc[sFinal0], diy = sCoef[32 + 3] - sc[sFinal1], diz = sCoef[64 + 3] - sc[sFinal2];
   const bool has_qc = sqrt(dix * dix + diy * diy + diz * diz) < 1.0;   // :697-702
   const bool z_override = sqrt(dix * dix + diy * diy) < 1.0;           // :879-880
-  const int mt = m_rows - (kBoxRows - 6 * 8 * K) + (has_qc ? 1 : 0);   // actual inequality count (+ball)
+  const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);                    // inequality count (+ball)
 
   // ---- thread roles ---------------------------------------------------------------------------
   const int R = 8 * K;
-  RowCtx rc;
-  rc.has_box = tid < 3 * R; rc.q = tid; rc.bax = rc.has_box ? tid / R : 0; rc.brho = rc.has_box ? tid % R : 0;
-  {
-    const int rho = rc.brho, ax = rc.bax;
-    rc.bhi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
-    rc.blo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
-  }
-  const int pair = tid >> 3, li = pair >> 2;
-  rc.lk = pair & 3; rc.slice = tid & 7; rc.has_line = li < K; rc.lrho = 4 * li + rc.lk;
-  rc.lbeg = rc.has_line ? sI[li] : 0; rc.lend = rc.has_line ? sI[li + 1] : 0;
-  rc.n1 = sN1; rc.n2 = sN2; rc.lh = sLh;
+  const bool has_box = tid < 3 * R;
+  const int bax = has_box ? tid / R : 0, brho = has_box ? tid % R : 0;
+  const double bhi = brho < 4 * K ? sp.maxs[bax] : (brho < 7 * K ? sp.v_max : sp.a_max);
+  const double blo = brho < 4 * K ? sp.mins[bax] : (brho < 7 * K ? -sp.v_max : -sp.a_max);
+  const int pair = tid >> 3, li = pair >> 2, lk = pair & 3, slice = tid & 7;
+  const bool has_line = li < K;
+  const int lrho = 4 * li + lk;
+  const int lbeg = has_line ? sI[li] : 0, lend = has_line ? sI[li + 1] : 0;
+  // box row state: [0] upper (alpha=+e), [1] lower (alpha=-e)
+  double bs0 = 1, bl0 = 0, bs1 = 1, bl1 = 0;
 
+  long long tph[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; long long tlast = 0;
+  const bool prof = ps.dbg != nullptr;
+#define TICK(k) do { if (prof) { const long long t_ = clock64(); tph[k] += t_ - tlast; tlast = t_; } } while (0)
   int status = NEP_FAILED, iters_total = 0, iters_first = 0;
   double objective = 0.0;
 
+  auto run = [&](auto lds_tag) {
+  constexpr bool LDSL = decltype(lds_tag)::value;
+  // c: 0 n1, 1 n2, 2 h            (line coefficient)
+  auto LNr = [&](int l, int c) -> double { if constexpr (LDSL) return ldyn[c * LL + l]; else return gsp[c * GL + l]; };
+  auto LNw = [&](int l, int c, double v) { if constexpr (LDSL) ldyn[c * LL + l] = v; else gsp[c * GL + l] = v; };
+  // c: 0 s, 1 lambda; k: control point of the segment
+  auto STr = [&](int l, int k, int c) -> double { if constexpr (LDSL) return ldyn[(3 + c * 4 + k) * LL + l]; else return gsp[(3 + c * 4 + k) * GL + l]; };
+  auto STw = [&](int l, int k, int c, double v) { if constexpr (LDSL) ldyn[(3 + c * 4 + k) * LL + l] = v; else gsp[(3 + c * 4 + k) * GL + l] = v; };
+  for (int i = 0; i < K; i++) {  // gather the separator's buckets into one segment-major list
+    const int beg = sI[i], cnt = sI[i + 1] - beg;
+    const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
+    for (int l = tid; l < cnt; l += BS) { LNw(beg + l, 0, src[3 * l]); LNw(beg + l, 1, src[3 * l + 1]); LNw(beg + l, 2, 1.0 - src[3 * l + 2]); }
+  }
+  const int LD = (LDSL ? LL : GL) - 1;   // dummy line: harmless operands for the padded tail of a row group
+  if (tid < 4) { STw(LD, tid, 0, 1.0); STw(LD, tid, 1, 1.0); if (tid == 0) { LNw(LD, 0, 0.0); LNw(LD, 1, 0.0); LNw(LD, 2, 1.0); } }
+  __syncthreads();
+  // This thread's line rows, four independent rows at a time (loads first, then the four bodies:
+  // the dependent fp64 chains of different rows interleave).  body(valid, l, n1, n2, h, s, lam).
+  auto for_lines4 = [&](auto&& body) {
+    if (!has_line) return;
+    for (int l0 = lbeg + slice; l0 < lend; l0 += 32) {
+      int l[4]; bool v[4]; double n1[4], n2[4], h[4], s[4], lam[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        l[u] = l0 + 8 * u; v[u] = l[u] < lend; if (!v[u]) l[u] = LD;
+        n1[u] = LNr(l[u], 0); n2[u] = LNr(l[u], 1); h[u] = LNr(l[u], 2); s[u] = STr(l[u], lk, 0); lam[u] = STr(l[u], lk, 1);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) body(v[u], l[u], n1[u], n2[u], h[u], s[u], lam[u]);
+    }
+  };
   for (int mode = 0; mode < 2; mode++) {
     const QpTable* __restrict__ tb = tables + mode * (kMaxK + 1) + K;
     const int nz = tb->nz, n = 3 * nz;
     __syncthreads();
     for (int e = tid; e < kMaxR * kNZ; e += BS) sB[e] = (&tb->B[0][0])[e];
-    for (int e = tid; e < 32 * kNZ; e += BS) sTh[e] = (&tb->Th[0][0])[e];
-    if (tid < kMaxR * 3) sU[tid] = (&tb->U[0][0])[tid];
-    if (tid < 96) sThU[tid] = (&tb->ThU[0][0])[tid];
     if (tid < 64) sHax[tid] = (&tb->Hax[0][0])[tid];
     if (tid < 8) sEp[tid] = tb->ep[tid];
+    if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
     __syncthreads();
-    if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; sOff[rho * 3 + ax] = sU[rho * 3] * sInit[ax * 3] + sU[rho * 3 + 1] * sInit[ax * 3 + 1] + sU[rho * 3 + 2] * sInit[ax * 3 + 2]; }
+    // normal-matrix entries owned by this thread (lower triangle, row-major): decoded once per mode
+    int me_i[2], me_j[2], me_ci[2], me_cj[2], me_sel[2]; bool me_diag[2], me_on[2];
+    {
+      const int n_ent = n * (n + 1) / 2;
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        const int e = tid + u * BS;
+        me_on[u] = e < n_ent;
+        int i = 0;
+        if (me_on[u]) { i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while ((i + 1) * (i + 2) / 2 <= e) i++; while (i * (i + 1) / 2 > e) i--; }
+        const int j = me_on[u] ? e - i * (i + 1) / 2 : 0;
+        const int nzs = nz > 0 ? nz : 1;
+        const int ai = i / nzs, aj = j / nzs;
+        me_i[u] = i; me_j[u] = j; me_ci[u] = i % nzs; me_cj[u] = j % nzs;
+        me_diag[u] = ai == aj;
+        me_sel[u] = ai == aj ? (ai == 0 ? 0 : (ai == 1 ? 2 : 3)) : ((ai == 1 && aj == 0) ? 1 : -1);
+      }
+    }
     bool converged = false;
     int it = 0;
     if (nz == 0) {
       // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
-      __syncthreads();
-      double viol = 0.0;
-      for_rows(rc, [&](int, int rho, double ax, double ay, double az, double h, bool) {
-        const double a = ax * sOff[rho * 3] + ay * sOff[rho * 3 + 1] + az * sOff[rho * 3 + 2];
-        viol = fmax(viol, a - h);
-      });
+      double viol = 0.0, d0 = 0, d1 = 0, d2 = 0;
+      if (has_box) { const double a = sOff[brho * 3 + bax]; viol = fmax(a - bhi, blo - a); }
+      { const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; for_lines4([&](bool v, int, double n1, double n2, double h, double, double) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
       if (tid < 6) {  // terminal v = a = 0 must hold at the least-squares point
         const int ax = tid / 2, e = tid % 2;
         viol = fmax(viol, fabs(tb->res_u[e][0] * sInit[ax * 3] + tb->res_u[e][1] * sInit[ax * 3 + 1] + tb->res_u[e][2] * sInit[ax * 3 + 2]));
@@ -201,7 +348,7 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
         for (int ax = 0; ax < 3; ax++) { const double pe = tb->up[0] * sInit[ax * 3] + tb->up[1] * sInit[ax * 3 + 1] + tb->up[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; c += pe * pe; }
         viol = fmax(viol, c);
       }
-      viol = block_reduce<1>(viol, sRed);
+      block_reduce4(viol, d0, d1, d2, sRed);
       converged = viol <= 1e-6;
       if (tid == 0) {
         double o = 0;
@@ -239,15 +386,24 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
         sc[sObj0] = o;
         sI[16] = 0;  // loose snapshot present
         sI[17] = 0;  // stall counter
+        sc[sAlpha] = 0.0; sc[sSigMu] = 0.0;
       }
       __syncthreads();
-      if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; double v = sOff[rho * 3 + ax]; for (int c = 0; c < nz; c++) v += sB[rho * kNZ + c] * sZ[ax * nz + c]; sCp[rho * 3 + ax] = v; }
+      if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; double v = sOff[rho * 3 + ax]; for (int c = 0; c < nz; c++) v += sB[rho * kNZ + c] * sZ[ax * nz + c]; sCp[rho * 3 + ax] = v; sUa[rho * 3 + ax] = 0.0; sUd[rho * 3 + ax] = 0.0; }
       __syncthreads();
-      for_rows(rc, [&](int r, int rho, double ax, double ay, double az, double h, bool) {
-        const double a = ax * sCp[rho * 3] + ay * sCp[rho * 3 + 1] + az * sCp[rho * 3 + 2];
-        const double sl = h - a; const double s = sl > 0.1 ? sl : 0.1;
-        stS[r] = s; stL[r] = 1.0 / s;
-      });
+      if (has_box) {
+        const double a = sCp[brho * 3 + bax];
+        double sl = bhi - a; bs0 = sl > 0.1 ? sl : 0.1; bl0 = 1.0 / bs0;
+        sl = a - blo; bs1 = sl > 0.1 ? sl : 0.1; bl1 = 1.0 / bs1;
+      }
+      {
+        const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1];
+        for_lines4([&](bool, int l, double n1, double n2, double h, double, double) {
+          const double sl = h - (n1 * cx + n2 * cy);
+          const double s = sl > 0.1 ? sl : 0.1;
+          STw(l, lk, 0, s); STw(l, lk, 1, 1.0 / s);
+        });
+      }
       if (tid == 0) {
         double qs = 1.0; for (int e = 0; e < n; e++) qs = fmax(qs, fabs(sG[e]));
         sc[sQscale] = qs;
@@ -257,36 +413,67 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
           const double sq = (-c > 1e-3) ? -c : 1e-3;
           sc[sSq] = sq; sc[sLq] = 1.0 / sq;
         } else { sc[sSq] = 1.0; sc[sLq] = 0.0; }
+        sc[sDsq] = 0.0; sc[sDlq] = 0.0; sc[sDsqA] = 0.0; sc[sDlqA] = 0.0; sc[sRpq] = 0.0; sc[sWq] = 0.0;
       }
       __syncthreads();
 
+      // Row direction from the arrays of the previous solve (used by the merged update):
+      //   ds = -rp - gd ; dl = -rc/s + w (rp + gd), rc = s lam - sigma mu + dsa dla
       for (it = 0; it < kMaxIt; it++) {
-        // ---- (A) base-row values at z ---------------------------------------------------------
-        if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; double v = sOff[rho * 3 + ax]; for (int c = 0; c < nz; c++) v += sB[rho * kNZ + c] * sZ[ax * nz + c]; sCp[rho * 3 + ax] = v; }
-        __syncthreads();
-        // ---- (P1) residuals, weights, scatter onto base rows ----------------------------------
-        double bTl = 0, bD = 0, bT1 = 0;                                  // box: (rho,axis)
-        double lTx = 0, lTy = 0, lDxx = 0, lDxy = 0, lDyy = 0, l1x = 0, l1y = 0;  // lines: (seg,k)
-        double nrp = 0, sumsl = 0;
-        for_rows(rc, [&](int r, int rho, double ax, double ay, double az, double h, bool is_line) {
-          const double s = stS[r], lam = stL[r];
-          const double a = ax * sCp[rho * 3] + ay * sCp[rho * 3 + 1] + az * sCp[rho * 3 + 2];
-          const double rp = a + s - h;
-          const double w = lam / s;
-          const double v = lam - w * rp;
-          nrp = fmax(nrp, fabs(rp)); sumsl += s * lam;
-          if (is_line) { lTx += lam * ax; lTy += lam * ay; lDxx += w * ax * ax; lDxy += w * ax * ay; lDyy += w * ay * ay; l1x += v * ax; l1y += v * ay; }
-          else { const double sg = ax + ay + az; bTl += lam * sg; bD += w; bT1 += v * sg; }
-        });
+        if (prof) tlast = clock64();
+        // ---- (A) apply the previous step, then residuals / weights / scatter onto base rows ----
+        const double alpha_prev = sc[sAlpha], sm_prev = sc[sSigMu];
+        double bTl = 0, bD = 0, bT1 = 0;
+        double lTx = 0, lTy = 0, lDxx = 0, lDxy = 0, lDyy = 0, l1x = 0, l1y = 0;
+        double nrp = 0, sumsl = 0, dummy1 = 0, dummy2 = 0;
+        auto rowA = [&](double& s, double& lam, double a_old, double ga, double gd, double h, double& a_new_out) {
+          const double rp0 = a_old + s - h, is = frcp(s), w0 = lam * is;
+          const double dsa = -rp0 - ga, dla = -lam + w0 * (rp0 + ga);
+          const double rcv = s * lam - sm_prev + dsa * dla;
+          const double ds = -rp0 - gd, dl = -rcv * is + w0 * (rp0 + gd);
+          s = __builtin_fma(alpha_prev, ds, s); lam = __builtin_fma(alpha_prev, dl, lam);
+          a_new_out = __builtin_fma(alpha_prev, gd, a_old);
+        };
+        if (has_box) {
+          const double a_old = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax], gd = sUd[brho * 3 + bax];
+          double an;
+          rowA(bs0, bl0, a_old, ga, gd, bhi, an);
+          { const double rp = an + bs0 - bhi, w = bl0 * frcp(bs0), v = bl0 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs0 * bl0; bTl += bl0; bD += w; bT1 += v; }
+          rowA(bs1, bl1, -a_old, -ga, -gd, -blo, an);
+          { const double rp = an + bs1 + blo, w = bl1 * frcp(bs1), v = bl1 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs1 * bl1; bTl -= bl1; bD += w; bT1 -= v; }
+        }
+        {
+          const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1], uax = sUa[lrho * 3], uay = sUa[lrho * 3 + 1], udx = sUd[lrho * 3], udy = sUd[lrho * 3 + 1];
+          for_lines4([&](bool ok, int l, double n1, double n2, double h, double s, double lam) {
+            double an;
+            rowA(s, lam, n1 * cx + n2 * cy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, an);
+            STw(l, lk, 0, ok ? s : 1.0); STw(l, lk, 1, ok ? lam : 1.0);   // the dummy line of a padded tail stays (1,1)
+            const double rp = an + s - h, w = lam * frcp(s), v = lam - w * rp;
+            nrp = fmax(nrp, ok ? fabs(rp) : 0.0); sumsl += ok ? s * lam : 0.0;
+            const double lm = ok ? lam : 0.0, wm = ok ? w : 0.0, vm = ok ? v : 0.0;
+            lTx += lm * n1; lTy += lm * n2; lDxx += wm * n1 * n1; lDxy += wm * n1 * n2; lDyy += wm * n2 * n2; l1x += vm * n1; l1y += vm * n2;
+          });
+        }
         lTx = slice_sum(lTx); lTy = slice_sum(lTy); lDxx = slice_sum(lDxx); lDxy = slice_sum(lDxy); lDyy = slice_sum(lDyy); l1x = slice_sum(l1x); l1y = slice_sum(l1y);
-        if (rc.slice == 0) { double* o = sAccL + pair * 8; o[0] = lTx; o[1] = lTy; o[2] = lDxx; o[3] = lDxy; o[4] = lDyy; o[5] = l1x; o[6] = l1y; }
-        if (tid < 192) { double* o = sAccB + tid * 4; o[0] = bTl; o[1] = bD; o[2] = bT1; }
-        nrp = block_reduce<1>(nrp, sRed);
-        sumsl = block_reduce<2>(sumsl, sRed);   // (syncs inside also publish sAcc*)
-        // ---- ball constraint (scalar row, thread 0) -------------------------------------------
-        if (tid == 0) {
+        if (slice == 0) { double* o = sAccL + pair * 8; o[0] = lTx; o[1] = lTy; o[2] = lDxx; o[3] = lDxy; o[4] = lDyy; o[5] = l1x; o[6] = l1y; }
+        if (has_box) { sTc[brho * 6 + bax] = bTl; sTc[brho * 6 + 3 + bax] = bT1; sDc[brho * 4 + (bax == 0 ? 0 : (bax == 1 ? 2 : 3))] = bD; }
+        block_reduce4(nrp, sumsl, dummy1, dummy2, sRed);   // (its barriers also publish sAccL / sDc / sTc)
+        TICK(0);
+        // ---- base-row values move with the step; combine box + line accumulators ----------------
+        if (tid < 3 * R) sCp[brho * 3 + bax] = __builtin_fma(alpha_prev, sUd[brho * 3 + bax], sCp[brho * 3 + bax]);
+        if (tid < R) {   // add the line sums onto the position rows (box threads wrote their part above)
+          const int rho = tid; const double* al = sAccL + rho * 8;
+          if (rho < 4 * K) {
+            sDc[rho * 4 + 0] += al[2]; sDc[rho * 4 + 1] = al[3]; sDc[rho * 4 + 2] += al[4];
+            sTc[rho * 6 + 0] += al[0]; sTc[rho * 6 + 1] += al[1]; sTc[rho * 6 + 3] += al[5]; sTc[rho * 6 + 4] += al[6];
+          } else sDc[rho * 4 + 1] = 0.0;
+        }
+        // ---- ball constraint (scalar row, thread 255) --------------------------------------------
+        if (tid == BS - 1) {
           double rpq = 0;
           if (has_qc) {
+            // apply the previous step to the ball row (its slack moves linearly, infeasible-start)
+            sc[sSq] += alpha_prev * sc[sDsq]; sc[sLq] += alpha_prev * sc[sDlq];
             double c = -0.10 * 0.10;
             for (int ax = 0; ax < 3; ax++) {
               double pe = tb->up[0] * sInit[ax * 3] + tb->up[1] * sInit[ax * 3 + 1] + tb->up[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax];
@@ -298,201 +485,196 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
             sc[sWq] = sc[sLq] / sc[sSq];
           }
           sc[sRpq] = rpq;
-          sc[sMu] = (sumsl + (has_qc ? sc[sSq] * sc[sLq] : 0.0)) / mt;
+          sc[sSumSl] = sumsl + (has_qc ? sc[sSq] * sc[sLq] : 0.0);
+          sc[sMu] = sc[sSumSl] / mt;
           sc[sNrp] = fmax(nrp, fabs(rpq));
         }
-        // ---- dual residual, normal matrix, predictor right-hand side ---------------------------
-        if (tid < n) {
-          const int ax = tid / nz, c = tid % nz;
-          double v = sG[tid];
-          for (int e = 0; e < nz; e++) v += sHax[c * kNZ + e] * sZ[ax * nz + e];
-          double t1 = 0;
-          for (int rho = 0; rho < R; rho++) {
-            double tl = sAccB[(ax * R + rho) * 4], tt = sAccB[(ax * R + rho) * 4 + 2];
-            if (ax < 2 && rho < 4 * K) { tl += sAccL[rho * 8 + ax]; tt += sAccL[rho * 8 + 5 + ax]; }
-            v += sB[rho * kNZ + c] * tl; t1 += sB[rho * kNZ + c] * tt;
+        __syncthreads();
+        TICK(1);
+        // ---- dual residual + predictor rhs (8 partial sums per output), normal matrix -------------
+        if (tid < 8 * n) {
+          const int o = tid >> 3, sl8 = tid & 7, ax = o / nz, c = o % nz;
+          double v = 0, t1 = 0;
+          for (int rho = sl8; rho < R; rho += 8) { const double b = sB[rho * kNZ + c]; v += b * sTc[rho * 6 + ax]; t1 += b * sTc[rho * 6 + 3 + ax]; }
+          v = slice_sum(v); t1 = slice_sum(t1);
+          if (sl8 == 0) {
+            double hz = 0;
+            for (int e = 0; e < nz; e++) hz += sHax[c * kNZ + e] * sZ[ax * nz + e];
+            const double zo = sZ[o], go = sG[o];
+            v += go + hz;
+            if (has_qc) v += sc[sLq] * sGq[o];
+            sRd[o] = v; sRhs[o] = t1;
+            sDxa[o] = zo * (0.5 * hz + go);       // this coordinate's share of the objective (sDxa is free here)
           }
-          sRd[tid] = v; sRhs[tid] = t1;   // rhs completed after the ball terms are known
         }
-        for (int e = tid; e < n * n; e += BS) {
-          const int i = e / n, j = e % n;
-          const int ai = i / nz, ci = i % nz, aj = j / nz, cj = j % nz;
-          double v = 0;
-          if (ai == aj) {
-            v = sHax[ci * kNZ + cj];
-            for (int rho = 0; rho < R; rho++) {
-              double d = sAccB[(ai * R + rho) * 4 + 1];
-              if (ai < 2 && rho < 4 * K) d += sAccL[rho * 8 + (ai == 0 ? 2 : 4)];
-              v += d * sB[rho * kNZ + ci] * sB[rho * kNZ + cj];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          if (me_on[u]) {
+            const int ci = me_ci[u], cj = me_cj[u], sel = me_sel[u];
+            double a0 = me_diag[u] ? sHax[ci * kNZ + cj] : 0.0, a1 = 0.0;
+            if (sel >= 0) {
+              const int rl = sel == 1 ? 4 * K : R;       // multiples of 4 (R = 8K)
+              for (int rho = 0; rho < rl; rho += 4) {
+                a0 = __builtin_fma(sDc[(rho + 0) * 4 + sel] * sB[(rho + 0) * kNZ + ci], sB[(rho + 0) * kNZ + cj], a0);
+                a1 = __builtin_fma(sDc[(rho + 1) * 4 + sel] * sB[(rho + 1) * kNZ + ci], sB[(rho + 1) * kNZ + cj], a1);
+                a0 = __builtin_fma(sDc[(rho + 2) * 4 + sel] * sB[(rho + 2) * kNZ + ci], sB[(rho + 2) * kNZ + cj], a0);
+                a1 = __builtin_fma(sDc[(rho + 3) * 4 + sel] * sB[(rho + 3) * kNZ + ci], sB[(rho + 3) * kNZ + cj], a1);
+              }
             }
-          } else if (ai < 2 && aj < 2) {
-            for (int rho = 0; rho < 4 * K; rho++) v += sAccL[rho * 8 + 3] * sB[rho * kNZ + ci] * sB[rho * kNZ + cj];
+            double v = a0 + a1;
+            if (has_qc) { v += sc[sWq] * sGq[me_i[u]] * sGq[me_j[u]]; if (me_diag[u]) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
+            sM[me_i[u] * MS + me_j[u]] = v;
           }
-          sM[i * MS + j] = v;
         }
         __syncthreads();
-        if (has_qc) {
-          const double lq = sc[sLq], wq = sc[sWq];
-          for (int e = tid; e < n * n; e += BS) {
-            const int i = e / n, j = e % n;
-            double v = wq * sGq[i] * sGq[j];
-            if (i / nz == j / nz) v += lq * 2 * sEp[i % nz] * sEp[j % nz];
-            sM[i * MS + j] += v;
+        TICK(2);
+        // ---- convergence test (wave 0) ----------------------------------------------------------
+        if (tid < 64) {
+          const double nrd = wave_max(tid < n ? fabs(sRd[tid]) : 0.0);
+          const double o = sc[sObj0] + wave_sum(tid < n ? sDxa[tid] : 0.0);
+          if (tid == 0) {
+            sc[sObj] = o;
+            const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
+            int flag = 0;
+            if (nr <= 1e-9 && nrd <= 1e-9 * qs && gap <= 1e-10 * (1.0 + fabs(o))) flag = 1;
+            else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) { flag = 2; sc[sObjLoose] = o; }
+            if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
+            if (sI[17] >= 3) flag = 3;                           // stalled
+            sI[18] = flag;
           }
-          if (tid < n) sRd[tid] += lq * sGq[tid];
-          __syncthreads();
-        }
-        // ---- convergence test (thread 0) ------------------------------------------------------
-        if (tid == 0) {
-          double nrd = 0, o = sc[sObj0];
-          for (int e = 0; e < n; e++) nrd = fmax(nrd, fabs(sRd[e]));
-          for (int ax = 0; ax < 3; ax++) for (int a = 0; a < nz; a++) { double v = 0; for (int b = 0; b < nz; b++) v += sHax[a * kNZ + b] * sZ[ax * nz + b]; o += 0.5 * sZ[ax * nz + a] * v + sG[ax * nz + a] * sZ[ax * nz + a]; }
-          sc[sObj] = o;
-          const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
-          int flag = 0;
-          if (nr <= 1e-9 && nrd <= 1e-9 * qs && gap <= 1e-10 * (1.0 + fabs(o))) flag = 1;
-          else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) { flag = 2; sc[sObjLoose] = o; }
-          if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
-          sI[18] = flag;
         }
         __syncthreads();
         const int flag = sI[18];
         if (flag == 1) { converged = true; break; }
         if (flag == 3) break;
         if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
-        // ---- Cholesky of M (right-looking, in LDS) --------------------------------------------
-        bool chol_ok = true;
-        for (int j = 0; j < n; j++) {
-          const double d = sM[j * MS + j];
-          if (!(d > 0.0)) { chol_ok = false; break; }
-          const double inv = 1.0 / sqrt(d);
-          __syncthreads();
-          if (tid >= j && tid < n) sM[tid * MS + j] *= inv;
-          if (tid == 0) sInvD[j] = inv;
-          __syncthreads();
-          for (int e = tid; e < n * n; e += BS) { const int i = e / n, k = e % n; if (k > j && i >= k) sM[i * MS + k] -= sM[i * MS + j] * sM[k * MS + j]; }
-          __syncthreads();
+
+        TICK(3);
+        // ---- wave 0: Cholesky in registers (lane i = row i); L and 1/diag go back to LDS ----------
+        if (tid < 64) {
+          const bool chol_ok = chol_wave(lds0 + oM * 8, lds0 + oInvD * 8, n);
+          if (tid == 0) sI[19] = chol_ok ? 1 : 0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        if (!chol_ok) break;
-        // ---- predictor / corrector -----------------------------------------------------------
-        double alpha = 1.0;
-        for (int pass = 0; pass < 2; pass++) {
-          const double mu = sc[sMu];
-          if (pass == 1) {
-            // corrector right-hand side: T1' = sum (rc/s - w rp) alpha with rc = s lam - sigma mu + ds_a dl_a
-            const double sm = sc[sSigma] * mu;
-            double b1 = 0, c1x = 0, c1y = 0;
-            for_rows(rc, [&](int r, int rho, double ax, double ay, double az, double h, bool is_line) {
-              const double s = stS[r], lam = stL[r];
-              const double a = ax * sCp[rho * 3] + ay * sCp[rho * 3 + 1] + az * sCp[rho * 3 + 2];
-              const double rp = a + s - h, w = lam / s;
-              const double ga = ax * sUa[rho * 3] + ay * sUa[rho * 3 + 1] + az * sUa[rho * 3 + 2];
-              const double dsa = -rp - ga, dla = -lam + w * (rp + ga);
-              const double rcv = s * lam - sm + dsa * dla;
-              const double v = rcv / s - w * rp;
-              if (is_line) { c1x += v * ax; c1y += v * ay; } else b1 += v * (ax + ay + az);
-            });
-            c1x = slice_sum(c1x); c1y = slice_sum(c1y);
-            __syncthreads();
-            if (rc.slice == 0) { sAccL[pair * 8 + 5] = c1x; sAccL[pair * 8 + 6] = c1y; }
-            if (tid < 192) sAccB[tid * 4 + 2] = b1;
-            __syncthreads();
-            if (tid < n) {
-              const int ax = tid / nz, c = tid % nz;
-              double t1 = 0;
-              for (int rho = 0; rho < R; rho++) { double tt = sAccB[(ax * R + rho) * 4 + 2]; if (ax < 2 && rho < 4 * K) tt += sAccL[rho * 8 + 5 + ax]; t1 += sB[rho * kNZ + c] * tt; }
-              sRhs[tid] = t1;
-            }
-            __syncthreads();
-          }
-          // rhs = -rd + B'T1 (+ gq (rcq/sq - wq rpq))
-          if (tid < 64) {
-            double b = 0;
-            if (tid < n) {
-              b = -sRd[tid] + sRhs[tid];
-              if (has_qc) {
-                const double sq = sc[sSq], lq = sc[sLq];
-                const double rcq = (pass == 0) ? sq * lq : sq * lq - sc[sSigma] * mu + sc[sDsqA] * sc[sDlqA];
-                b += sGq[tid] * (rcq / sq - sc[sWq] * sc[sRpq]);
-              }
-            }
-            // L y = b, L' x = y inside wave 0 (lane i holds entry i)
-            for (int j = 0; j < n; j++) { const double xj = __shfl(b, j) * sInvD[j]; if (tid == j) b = xj; else if (tid > j && tid < n) b -= sM[tid * MS + j] * xj; }
-            for (int j = n - 1; j >= 0; j--) { const double xj = __shfl(b, j) * sInvD[j]; if (tid == j) b = xj; else if (tid < j) b -= sM[j * MS + tid] * xj; }
-            if (tid < n) (pass == 0 ? sDxa : sDx)[tid] = b;
-          }
-          __syncthreads();
-          double* sDir = pass == 0 ? sDxa : sDx; double* sUu = pass == 0 ? sUa : sUd;
-          if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; double v = 0; for (int c = 0; c < nz; c++) v += sB[rho * kNZ + c] * sDir[ax * nz + c]; sUu[rho * 3 + ax] = v; }
-          __syncthreads();
-          // step length
-          const double sm = (pass == 0) ? 0.0 : sc[sSigma] * mu;
-          double amin = 1.0;
-          for_rows(rc, [&](int r, int rho, double ax, double ay, double az, double h, bool) {
-            const double s = stS[r], lam = stL[r];
-            const double a = ax * sCp[rho * 3] + ay * sCp[rho * 3 + 1] + az * sCp[rho * 3 + 2];
-            const double rp = a + s - h, w = lam / s;
-            const double ga = ax * sUa[rho * 3] + ay * sUa[rho * 3 + 1] + az * sUa[rho * 3 + 2];
-            double ds, dl;
-            if (pass == 0) { ds = -rp - ga; dl = -lam + w * (rp + ga); }
-            else {
-              const double dsa = -rp - ga, dla = -lam + w * (rp + ga);
-              const double rcv = s * lam - sm + dsa * dla;
-              const double gd = ax * sUd[rho * 3] + ay * sUd[rho * 3 + 1] + az * sUd[rho * 3 + 2];
-              ds = -rp - gd; dl = -rcv / s + w * (rp + gd);
-            }
-            if (ds < 0) amin = fmin(amin, -s / ds);
-            if (dl < 0) amin = fmin(amin, -lam / dl);
-          });
-          if (tid == 0 && has_qc) {
-            const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
-            double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDir[e];
-            const double rcq = (pass == 0) ? sq * lq : sq * lq - sm + sc[sDsqA] * sc[sDlqA];
-            const double dsq = -rpq - gd, dlq = -rcq / sq + wq * (rpq + gd);
-            if (pass == 0) { sc[sDsqA] = dsq; sc[sDlqA] = dlq; } else { sc[sDsq] = dsq; sc[sDlq] = dlq; }
-            if (dsq < 0) amin = fmin(amin, -sq / dsq);
-            if (dlq < 0) amin = fmin(amin, -lq / dlq);
-          }
-          alpha = block_reduce<0>(amin, sRed);
-          if (pass == 0) {
-            // mu_aff -> sigma
-            double part = 0;
-            for_rows(rc, [&](int r, int rho, double ax, double ay, double az, double h, bool) {
-              const double s = stS[r], lam = stL[r];
-              const double a = ax * sCp[rho * 3] + ay * sCp[rho * 3 + 1] + az * sCp[rho * 3 + 2];
-              const double rp = a + s - h, w = lam / s;
-              const double ga = ax * sUa[rho * 3] + ay * sUa[rho * 3 + 1] + az * sUa[rho * 3 + 2];
-              const double ds = -rp - ga, dl = -lam + w * (rp + ga);
-              part += (s + alpha * ds) * (lam + alpha * dl);
-            });
-            if (tid == 0 && has_qc) part += (sc[sSq] + alpha * sc[sDsqA]) * (sc[sLq] + alpha * sc[sDlqA]);
-            part = block_reduce<2>(part, sRed);
-            if (tid == 0) { const double rr = (part / mt) / mu; sc[sSigma] = rr * rr * rr; }
-            __syncthreads();
-          }
+        TICK(4);
+        // ---- predictor ------------------------------------------------------------------------
+        if (tid < 64) {
+          double b = 0;
+          if (tid < n) { b = -sRd[tid] + sRhs[tid]; if (has_qc) b += sGq[tid] * (sc[sLq] - sc[sWq] * sc[sRpq]); }   // rcq/sq = lq for the affine step
+          b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n, b);
+          if (tid < n) sDxa[tid] = b;
         }
-        alpha = fmin(1.0, 0.995 * alpha);
-        if (tid == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
-        // ---- update ---------------------------------------------------------------------------
+        __syncthreads();
+        if (!sI[19]) break;
+        if (tid < 3 * R) { double v = 0; for (int c = 0; c < nz; c++) v += sB[brho * kNZ + c] * sDxa[bax * nz + c]; sUa[brho * 3 + bax] = v; }
+        __syncthreads();
+        TICK(5);
+        // ---- (P2) affine step: ratio test + the two sums that give mu_aff for any alpha ----------
+        double rmax = 0, c1 = 0, c2 = 0, dmy = 0;
+        auto rowP2 = [&](bool ok, double s, double lam, double a, double ga, double h) {
+          const double rp = a + s - h, is = frcp(s), w = lam * is;
+          const double ds = -rp - ga, dl = -lam + w * (rp + ga);
+          rmax = fmax(rmax, ok ? fmax(-ds * is, -dl * frcp(lam)) : 0.0);
+          c1 += ok ? s * dl + lam * ds : 0.0; c2 += ok ? ds * dl : 0.0;
+        };
+        if (has_box) { const double a = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax]; rowP2(true, bs0, bl0, a, ga, bhi); rowP2(true, bs1, bl1, -a, -ga, -blo); }
+        if (has_line) {
+          const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1], uax = sUa[lrho * 3], uay = sUa[lrho * 3 + 1];
+          for_lines4([&](bool ok, int, double n1, double n2, double h, double s, double lam) { rowP2(ok, s, lam, n1 * cx + n2 * cy, n1 * uax + n2 * uay, h); });
+        }
+        if (tid == BS - 1 && has_qc) {
+          const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
+          double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
+          const double dsq = -rpq - gd, dlq = -lq + wq * (rpq + gd);
+          sc[sDsqA] = dsq; sc[sDlqA] = dlq;
+          rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
+          c1 += sq * dlq + lq * dsq; c2 += dsq * dlq;
+        }
+        block_reduce4(rmax, c1, c2, dmy, sRed);
         {
-          const double sm = sc[sSigma] * sc[sMu];
-          for_rows(rc, [&](int r, int rho, double ax, double ay, double az, double h, bool) {
-            const double s = stS[r], lam = stL[r];
-            const double a = ax * sCp[rho * 3] + ay * sCp[rho * 3 + 1] + az * sCp[rho * 3 + 2];
-            const double rp = a + s - h, w = lam / s;
-            const double ga = ax * sUa[rho * 3] + ay * sUa[rho * 3 + 1] + az * sUa[rho * 3 + 2];
+          const double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
+          const double mu = sc[sMu];
+          const double mua = (sc[sSumSl] + aaff * c1 + aaff * aaff * c2) / mt;
+          const double rr = mua / mu;
+          if (tid == 0) { sc[sSigma] = rr * rr * rr; sc[sSigMu] = rr * rr * rr * mu; }
+        }
+        __syncthreads();
+        TICK(6);
+        // ---- (P4) corrector right-hand side ---------------------------------------------------
+        const double sm = sc[sSigMu];
+        {
+          double b1 = 0, c1x = 0, c1y = 0;
+          auto rowP4 = [&](double s, double lam, double a, double ga, double h) -> double {
+            const double rp = a + s - h, is = frcp(s), w = lam * is;
             const double dsa = -rp - ga, dla = -lam + w * (rp + ga);
             const double rcv = s * lam - sm + dsa * dla;
-            const double gd = ax * sUd[rho * 3] + ay * sUd[rho * 3 + 1] + az * sUd[rho * 3 + 2];
-            const double ds = -rp - gd, dl = -rcv / s + w * (rp + gd);
-            stS[r] = s + alpha * ds; stL[r] = lam + alpha * dl;
-          });
+            return rcv * is - w * rp;
+          };
+          if (has_box) { const double a = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax]; b1 = rowP4(bs0, bl0, a, ga, bhi) - rowP4(bs1, bl1, -a, -ga, -blo); }
+          if (has_line) {
+            const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1], uax = sUa[lrho * 3], uay = sUa[lrho * 3 + 1];
+            for_lines4([&](bool, int, double n1, double n2, double h, double s, double lam) { const double v = rowP4(s, lam, n1 * cx + n2 * cy, n1 * uax + n2 * uay, h); c1x += v * n1; c1y += v * n2; });
+          }
+          c1x = slice_sum(c1x); c1y = slice_sum(c1y);
+          if (slice == 0) { sAccL[pair * 8 + 5] = c1x; sAccL[pair * 8 + 6] = c1y; }
+          if (has_box) sTc[brho * 6 + 3 + bax] = b1;
         }
         __syncthreads();
-        if (tid < n) sZ[tid] += alpha * sDx[tid];
-        if (tid == 0 && has_qc) { sc[sSq] += alpha * sc[sDsq]; sc[sLq] += alpha * sc[sDlq]; }
+        if (tid < 8 * n) {
+          const int o = tid >> 3, sl8 = tid & 7, ax = o / nz, c = o % nz;
+          double t1 = 0;
+          for (int rho = sl8; rho < R; rho += 8) { double tt = sTc[rho * 6 + 3 + ax]; if (ax < 2 && rho < 4 * K) tt += sAccL[rho * 8 + 5 + ax]; t1 += sB[rho * kNZ + c] * tt; }
+          t1 = slice_sum(t1);
+          if (sl8 == 0) sRhs[o] = t1;
+        }
         __syncthreads();
-        if (sI[17] >= 3) break;
+        TICK(7);
+        if (tid < 64) {
+          double b = 0;
+          if (tid < n) {
+            b = -sRd[tid] + sRhs[tid];
+            if (has_qc) { const double sq = sc[sSq], lq = sc[sLq]; const double rcq = sq * lq - sm + sc[sDsqA] * sc[sDlqA]; b += sGq[tid] * (rcq / sq - sc[sWq] * sc[sRpq]); }
+          }
+          b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n, b);
+          if (tid < n) sDx[tid] = b;
+        }
+        __syncthreads();
+        if (tid < 3 * R) { double v = 0; for (int c = 0; c < nz; c++) v += sB[brho * kNZ + c] * sDx[bax * nz + c]; sUd[brho * 3 + bax] = v; }
+        __syncthreads();
+        TICK(8);
+        // ---- (P5) step length of the combined direction ------------------------------------------
+        rmax = 0; c1 = 0; c2 = 0; dmy = 0;
+        auto rowP5 = [&](bool ok, double s, double lam, double a, double ga, double gd, double h) {
+          const double rp = a + s - h, is = frcp(s), w = lam * is;
+          const double dsa = -rp - ga, dla = -lam + w * (rp + ga);
+          const double rcv = s * lam - sm + dsa * dla;
+          const double ds = -rp - gd, dl = -rcv * is + w * (rp + gd);
+          rmax = fmax(rmax, ok ? fmax(-ds * is, -dl * frcp(lam)) : 0.0);
+        };
+        if (has_box) { const double a = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax], gd = sUd[brho * 3 + bax]; rowP5(true, bs0, bl0, a, ga, gd, bhi); rowP5(true, bs1, bl1, -a, -ga, -gd, -blo); }
+        if (has_line) {
+          const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1], uax = sUa[lrho * 3], uay = sUa[lrho * 3 + 1], udx = sUd[lrho * 3], udy = sUd[lrho * 3 + 1];
+          for_lines4([&](bool ok, int, double n1, double n2, double h, double s, double lam) { rowP5(ok, s, lam, n1 * cx + n2 * cy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h); });
+        }
+        if (tid == BS - 1 && has_qc) {
+          const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
+          double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDx[e];
+          const double rcq = sq * lq - sm + sc[sDsqA] * sc[sDlqA];
+          const double dsq = -rpq - gd, dlq = -rcq / sq + wq * (rpq + gd);
+          sc[sDsq] = dsq; sc[sDlq] = dlq;
+          rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
+        }
+        block_reduce4(rmax, c1, c2, dmy, sRed);
+        {
+          double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
+          alpha = fmin(1.0, 0.995 * alpha);
+          if (tid == 0) { sc[sAlpha] = alpha; if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
+          if (tid < n) sZ[tid] += alpha * sDx[tid];
+        }
+        __syncthreads();
+        TICK(9);
       }
       if (!converged && sI[16]) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
     }
@@ -503,13 +685,15 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
       objective = sc[sObj];
       if (tid < 12 * K) {  // theta = Th z + ThU init
         const int ax = tid / (4 * K), r = tid % (4 * K);
-        double v = sThU[r * 3] * sInit[ax * 3] + sThU[r * 3 + 1] * sInit[ax * 3 + 1] + sThU[r * 3 + 2] * sInit[ax * 3 + 2];
-        for (int c = 0; c < nz; c++) v += sTh[r * kNZ + c] * sZ[ax * nz + c];
+        double v = tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2];
+        for (int c = 0; c < nz; c++) v += tb->Th[r][c] * sZ[ax * nz + c];
         sTheta[(ax * 8 + r / 4) * 4 + (r % 4)] = v;
       }
       break;
     }
   }
+  };   // run
+  if (L <= ps.lds_lines) run(std::true_type{}); else run(std::false_type{});
   __syncthreads();
   // ---- outputs -----------------------------------------------------------------------------------
   if (status == NEP_FAILED) { if (tid < 96) sTheta[tid] = sCoef[tid]; }                    // :856-859
@@ -539,6 +723,7 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
       }
     }
   }
+  if (prof && tid == 0) { for (int k = 0; k < 12; k++) ps.dbg[(long)slot * 16 + k] = tph[k]; ps.dbg[(long)slot * 16 + 12] = iters_total; }
   if (ps.commit) {  // the record the agent would publish (neptune_ros.cpp:434-480)
     nep_traj_rec* cr = ps.commit + slot;
     const int own = sp.first_local + (slot % sp.n_local);
