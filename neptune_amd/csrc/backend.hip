@@ -94,7 +94,8 @@ struct Engine {
     const long per_line = 11 * 8;
     const long l_half = ((long)(160 * 1024 / 2) - (long)fixed) / per_line - 2;
     const long l_full = ((long)kLdsBudget - (long)fixed) / per_line - 2;
-    const long expect = (long)NEP_MAX_POL * (sp.n_hull + sp.n_static / 4 + 12 + (sp.ent_enabled ? sp.num_agents / 4 : 0));
+    // expected lines per segment: every other agent's hull, plus a few nearby bases / statics / entangle lines
+    const long expect = (long)NEP_MAX_POL * (sp.n_hull + 4 + sp.n_static / 8 + (sp.ent_enabled ? sp.num_agents / 8 : 0));
     long ll = expect <= l_half ? l_half : l_full;
     if (ll > lines_total) ll = lines_total;
     lds_lines = (int)((ll + 1) & ~1L);

@@ -104,6 +104,16 @@ __device__ __forceinline__ double frcp(double a) {
   return r;
 }
 
+// 1/sqrt(a): v_rsq_f64 seed + two Newton steps (the IEEE sqrt + divide pair costs ~4x more and sits
+// on the Cholesky's critical path once per column).
+__device__ __forceinline__ double frsqrt(double a) {
+  double y = __builtin_amdgcn_rsq(a);
+  double h = 0.5 * a;
+  double e = __builtin_fma(-h * y, y, 0.5); y = __builtin_fma(y, e, y);
+  e = __builtin_fma(-h * y, y, 0.5); y = __builtin_fma(y, e, y);
+  return y;
+}
+
 // One max and up to three sums across the workgroup in one round trip.  red: LDS [16].
 __device__ __forceinline__ void block_reduce4(double& mx, double& s0, double& s1, double& s2, double* red) {
   mx = wave_max(mx); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
@@ -138,7 +148,7 @@ __device__ __forceinline__ bool chol_impl(lds_dptr sM, lds_dptr sInvD, int lane)
   for (int j = 0; j < N; j++) {
     const double d = bcast(Lr[j], j);
     if (!(d > 0.0)) ok = false;
-    const double inv = 1.0 / sqrt(d);
+    const double inv = frsqrt(d);
     Lr[j] *= inv;
     dinv = lane == j ? inv : dinv;
 #pragma unroll
@@ -203,7 +213,7 @@ __device__ __noinline__ double solve_wave(unsigned m_off, unsigned d_off, int n,
   }
 }
 
-__global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
+__global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sB = smem + oB; double* sOff = smem + oOff; double* sCp = smem + oCp;
   double* sUa = smem + oUa; double* sUd = smem + oUd; double* sAccL = smem + oAccL;
@@ -576,7 +586,8 @@ __global__ __launch_bounds__(BS) void qp_kernel(SceneParams sp, ProblemSet ps, c
         auto rowP2 = [&](bool ok, double s, double lam, double a, double ga, double h) {
           const double rp = a + s - h, is = frcp(s), w = lam * is;
           const double ds = -rp - ga, dl = -lam + w * (rp + ga);
-          rmax = fmax(rmax, ok ? fmax(-ds * is, -dl * frcp(lam)) : 0.0);
+          // -dl/lam = 1 - (rp + ga)/s for the affine direction: no second reciprocal
+          rmax = fmax(rmax, ok ? fmax(-ds * is, __builtin_fma(-(rp + ga), is, 1.0)) : 0.0);
           c1 += ok ? s * dl + lam * ds : 0.0; c2 += ok ? ds * dl : 0.0;
         };
         if (has_box) { const double a = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax]; rowP2(true, bs0, bl0, a, ga, bhi); rowP2(true, bs1, bl1, -a, -ga, -blo); }
