@@ -39,6 +39,26 @@ def algorithmic_bytes(p, sc, hull_nv, n_states):
     return guess + hull + statics + bases + out
 
 
+def measured_traffic(kernel="nep::qp_kernel"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
+    same command (profiles/): FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 (its calibration is for 16 B/lane streams; our 8 B/lane
+    reads are uncalibrated, so this is an upper bound).  None when no summary is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_summary_latest.txt")
+    if not os.path.exists(path):
+        return None
+    cur, vals = None, {}
+    for line in open(path):
+        if line.startswith("nep::"):
+            cur = line.strip()
+        elif cur == kernel and "mean" in line:
+            parts = line.split()
+            vals[parts[0]] = float(parts[2])
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        return (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return None
+
+
 def cpu_baseline(p, scenes, budget_s=12.0):
     """The CPU oracle (kind "port": the reference needs Gurobi/GLPK/CGAL, absent here) timed on the
     host cores on a bounded sample of the same workload."""
@@ -89,9 +109,11 @@ def main():
         raise SystemExit("bench.py needs a GPU: the back end has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as tdist
+    import torch.distributed as tdist
+    use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         tdist.init_process_group("nccl", device_id=dev)
 
     N, M, S = args.agents, args.obstacles, args.scenes
@@ -113,7 +135,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             tdist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -127,7 +149,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
@@ -163,7 +185,7 @@ def main():
             "p50_solve_ms": seq_ms,
             "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "launches": n_launch},
             "roofline": {"bound": "hbm", "kernel": "qp_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_replan": bytes_per_replan, "replans_per_launch": launch_replans,
                          "note": "latency-bound path: ~%d dependent interior-point iterations per replan" % round(float(iters.mean()))},
             "reference_budget": "reference TimeLimit 0.05 s/solve, replan timer 20 Hz/agent => <= %d replans/s for %d agents" % (20 * N, N),
@@ -171,7 +193,7 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(p, scenes)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         tdist.barrier()
         tdist.destroy_process_group()
 

@@ -40,10 +40,12 @@ class RoundExchange:
         """commit_local: uint8 [S][n_local][REC]; committed_out: uint8 [S][N][REC] (overwritten)."""
         torch = self.torch
         S, N, nl, W = self.S, self.N, self.n_local, self.world
-        if W == 1:
+        import torch.distributed as dist
+        if W == 1 and not (dist.is_available() and dist.is_initialized()):
             committed_out.copy_(commit_local)
             return committed_out
-        import torch.distributed as dist
+        if self.gathered is None:   # single rank launched under torch.distributed.run: same collective path
+            self.gathered = torch.empty(self.piece, dtype=torch.uint8, device=commit_local.device)
         if hasattr(dist, "all_gather_into_tensor") and commit_local.is_cuda:
             dist.all_gather_into_tensor(self.gathered, commit_local, group=self.group)
         else:
