@@ -39,42 +39,48 @@ __device__ __forceinline__ bool lex_less(double ax, double ay, double bx, double
 }
 
 // Wave-cooperative convex hull of n <= 64 points held one per lane (px,py valid for lane<n).
-// sx/sy: LDS [64], hx/hy: LDS [132].  Returns the vertex count (uniform); vertices in hx/hy.
-__device__ int wave_hull(int n, double px, double py, double* sx, double* sy, double* hx, double* hy) {
+// sxy: LDS [64][2] (sorted points), hxy: LDS [132][2] (hull).  Returns the vertex count (uniform).
+// Rank sort across the lanes, then the monotone chain walked by lane 0 with the top two stack
+// entries cached in registers (one LDS read per pop instead of four per test).
+__device__ int wave_hull(int n, double px, double py, double* sxy, double* hxy) {
   const int lane = threadIdx.x & 63;
   // rank sort (lexicographic; ties by lane index so that ranks are a permutation)
-  sx[lane] = px; sy[lane] = py;
+  sxy[2 * lane] = px; sxy[2 * lane + 1] = py;
   __syncthreads();
   int rank = 0;
   if (lane < n) {
     for (int j = 0; j < n; j++) {
-      double qx = sx[j], qy = sy[j];
+      const double qx = sxy[2 * j], qy = sxy[2 * j + 1];
       if (lex_less(qx, qy, px, py) || (qx == px && qy == py && j < lane)) rank++;
     }
   }
   __syncthreads();
-  if (lane < n) { sx[rank] = px; sy[rank] = py; }
+  if (lane < n) { sxy[2 * rank] = px; sxy[2 * rank + 1] = py; }
   __syncthreads();
   int k = 0;
   if (lane == 0 && n > 0) {
     // unique (in place)
     int m = 0;
+    double lx = 0, ly = 0;
     for (int i = 0; i < n; i++) {
-      double x = sx[i], y = sy[i];
-      if (m == 0 || x != sx[m - 1] || y != sy[m - 1]) { sx[m] = x; sy[m] = y; m++; }
+      const double x = sxy[2 * i], y = sxy[2 * i + 1];
+      if (m == 0 || x != lx || y != ly) { sxy[2 * m] = x; sxy[2 * m + 1] = y; lx = x; ly = y; m++; }
     }
-    if (m == 1) { hx[0] = sx[0]; hy[0] = sy[0]; k = 1; }
+    if (m == 1) { hxy[0] = sxy[0]; hxy[1] = sxy[1]; k = 1; }
     else {
+      double ax = 0, ay = 0, bx = 0, by = 0;   // h[k-2], h[k-1]
       for (int i = 0; i < m; i++) {  // lower hull
-        double x = sx[i], y = sy[i];
-        while (k >= 2 && cross3(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], x, y) <= 0.0) k--;
-        hx[k] = x; hy[k] = y; k++;
+        const double x = sxy[2 * i], y = sxy[2 * i + 1];
+        while (k >= 2 && cross3(ax, ay, bx, by, x, y) <= 0.0) { k--; bx = ax; by = ay; if (k >= 2) { ax = hxy[2 * (k - 2)]; ay = hxy[2 * (k - 2) + 1]; } }
+        hxy[2 * k] = x; hxy[2 * k + 1] = y; k++;
+        ax = bx; ay = by; bx = x; by = y;
       }
-      int lo = k + 1;
+      const int lo = k + 1;
       for (int i = m - 2; i >= 0; i--) {  // upper hull
-        double x = sx[i], y = sy[i];
-        while (k >= lo && cross3(hx[k - 2], hy[k - 2], hx[k - 1], hy[k - 1], x, y) <= 0.0) k--;
-        hx[k] = x; hy[k] = y; k++;
+        const double x = sxy[2 * i], y = sxy[2 * i + 1];
+        while (k >= lo && cross3(ax, ay, bx, by, x, y) <= 0.0) { k--; bx = ax; by = ay; if (k >= 2) { ax = hxy[2 * (k - 2)]; ay = hxy[2 * (k - 2) + 1]; } }
+        hxy[2 * k] = x; hxy[2 * k + 1] = y; k++;
+        ax = bx; ay = by; bx = x; by = y;
       }
       k--;
     }
@@ -89,9 +95,8 @@ __device__ int wave_hull(int n, double px, double py, double* sx, double* sy, do
 __device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, double T_span, double drone_radius,
                           long out, bool full0, double* __restrict__ hull_xy, int* __restrict__ hull_nv,
                           double* __restrict__ hull0_xy, int* __restrict__ hull0_nv) {
-  __shared__ double sx[64], sy[64], hx[132], hy[132];
-  __shared__ double cpx[kHullCP], cpy[kHullCP];
-  __shared__ int s_np0;
+  __shared__ __attribute__((aligned(16))) double sxy[128], hxy[264];
+  __shared__ double cpx[kHullCP], cpy[kHullCP], stimes[NEP_TRAJ_MAX_SEG + 2];
   const int lane = threadIdx.x;
   if (!(r->valid && r->is_agent) || r->pwp.n_seg <= 0) {   // neptune.cpp:244-262, 332
     if (lane == 0) { hull_nv[out] = 0; if (hull0_nv) hull0_nv[out] = 0; }
@@ -99,36 +104,31 @@ __device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, 
   }
   const double t0 = ts + i * T_span, t1 = ts + (i + 1) * T_span;   // neptune.cpp:273-280
   const int n = r->pwp.n_seg;
-  if (lane == 0) {
-    // std::lower_bound / upper_bound on times (neptune.cpp:379-389)
-    int lo = 0, hi = n + 1;
-    while (lo < hi) { int mid = (lo + hi) / 2; if (r->pwp.times[mid] < t0) lo = mid + 1; else hi = mid; }
-    int first = lo - 1;
-    lo = 0; hi = n + 1;
-    while (lo < hi) { int mid = (lo + hi) / 2; if (r->pwp.times[mid] <= t1) lo = mid + 1; else hi = mid; }
-    int last = lo - 1;
-    if (first < 0) first = 0; if (first > n - 1) first = n - 1;
-    if (last < 0) last = 0; if (last > n - 1) last = n - 1;
-    int np0 = 0;
-    for (int s = first; s <= last && np0 + 4 <= kHullCP; s++) {
-      double _t;                                                     // neptune.cpp:399-424
-      if (s != last) _t = r->pwp.times[s + 1] - r->pwp.times[s];
-      else if (t1 > r->pwp.times[s + 1]) _t = r->pwp.times[s + 1] - r->pwp.times[s];
-      else _t = t1 - r->pwp.times[s];
-      if (_t > T_span) _t = T_span; else if (_t < 0) _t = 0;
-      const double c0 = _t * _t * _t, c1 = _t * _t, c2 = _t, c3 = 1.0;
-      for (int k = 0; k < 4; k++) {                                  // V = (P*C)*A^-1, :426-429
-        const double* Px = r->pwp.coeff[0][s];
-        const double* Py = r->pwp.coeff[1][s];
-        cpx[np0] = (((Px[0] * c0) * cAPosInv[0][k] + (Px[1] * c1) * cAPosInv[1][k]) + (Px[2] * c2) * cAPosInv[2][k]) + (Px[3] * c3) * cAPosInv[3][k];
-        cpy[np0] = (((Py[0] * c0) * cAPosInv[0][k] + (Py[1] * c1) * cAPosInv[1][k]) + (Py[2] * c2) * cAPosInv[2][k]) + (Py[3] * c3) * cAPosInv[3][k];
-        np0++;
-      }
-    }
-    s_np0 = np0;
+  // std::lower_bound / upper_bound on the sorted knot vector (neptune.cpp:379-389) as two ballots
+  const bool inr = lane <= n;
+  const double tk = inr ? r->pwp.times[lane] : 0.0;
+  if (inr) stimes[lane] = tk;
+  int first = __popcll(__ballot(inr && tk < t0)) - 1;
+  int last = __popcll(__ballot(inr && tk <= t1)) - 1;
+  if (first < 0) first = 0; if (first > n - 1) first = n - 1;
+  if (last < 0) last = 0; if (last > n - 1) last = n - 1;
+  int nseg = last - first + 1; if (nseg > kHullCP / 4) nseg = kHullCP / 4; if (nseg < 0) nseg = 0;
+  const int np0 = 4 * nseg;
+  __syncthreads();
+  if (lane < 2 * np0) {   // one lane per (segment, control point, axis)
+    const int sl = lane >> 3, k = (lane >> 1) & 3, ax = lane & 1;
+    const int s = first + sl;
+    double _t;                                                     // neptune.cpp:399-424
+    if (s != last) _t = stimes[s + 1] - stimes[s];
+    else if (t1 > stimes[s + 1]) _t = stimes[s + 1] - stimes[s];
+    else _t = t1 - stimes[s];
+    if (_t > T_span) _t = T_span; else if (_t < 0) _t = 0;
+    const double c0 = _t * _t * _t, c1 = _t * _t, c2 = _t, c3 = 1.0;
+    const double* P = r->pwp.coeff[ax][s];                          // V = (P*C)*A^-1, :426-429
+    const double v = (((P[0] * c0) * cAPosInv[0][k] + (P[1] * c1) * cAPosInv[1][k]) + (P[2] * c2) * cAPosInv[2][k]) + (P[3] * c3) * cAPosInv[3][k];
+    if (ax == 0) cpx[sl * 4 + k] = v; else cpy[sl * 4 + k] = v;
   }
   __syncthreads();
-  const int np0 = s_np0;
   const double dx = r->bbox[0] / 2.0 + drone_radius, dy = r->bbox[1] / 2.0 + drone_radius;  // neptune.cpp:340
   const bool inflate = !(sqrt(dx * dx + dy * dy) < 1e-6);
   // inflated points: 4 corners per control point (:442-445)
@@ -142,18 +142,18 @@ __device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, 
       py = (q == 0 || q == 3) ? y + dy : y - dy;
     } else { px = cpx[lane]; py = cpy[lane]; }
   }
-  int k = wave_hull(np, px, py, sx, sy, hx, hy);
+  int k = wave_hull(np, px, py, sxy, hxy);
   if (k > kHullV) k = kHullV;
-  if (lane < k) { hull_xy[(out * kHullV + lane) * 2] = hx[lane]; hull_xy[(out * kHullV + lane) * 2 + 1] = hy[lane]; }
+  if (lane < k) { hull_xy[(out * kHullV + lane) * 2] = hxy[2 * lane]; hull_xy[(out * kHullV + lane) * 2 + 1] = hxy[2 * lane + 1]; }
   if (lane == 0) hull_nv[out] = k;
   if (hull0_nv) {
     __syncthreads();
     px = (lane < np0) ? cpx[lane] : 0; py = (lane < np0) ? cpy[lane] : 0;
-    int k0 = wave_hull(np0, px, py, sx, sy, hx, hy);
+    int k0 = wave_hull(np0, px, py, sxy, hxy);
     if (k0 > kHullV) k0 = kHullV;
     if (full0) {
-      if (lane < k0) { hull0_xy[(out * kHullV + lane) * 2] = hx[lane]; hull0_xy[(out * kHullV + lane) * 2 + 1] = hy[lane]; }
-    } else if (lane == 0) { hull0_xy[out * 2] = hx[0]; hull0_xy[out * 2 + 1] = hy[0]; }  // only col(0) is read (:722-734)
+      if (lane < k0) { hull0_xy[(out * kHullV + lane) * 2] = hxy[2 * lane]; hull0_xy[(out * kHullV + lane) * 2 + 1] = hxy[2 * lane + 1]; }
+    } else if (lane == 0) { hull0_xy[out * 2] = hxy[0]; hull0_xy[out * 2 + 1] = hxy[1]; }  // only col(0) is read (:722-734)
     if (lane == 0) hull0_nv[out] = k0;
   }
 }
@@ -192,7 +192,17 @@ void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_g
 // ---------------------------------------------------------------------------------------------
 // separator
 // ---------------------------------------------------------------------------------------------
-struct SepBest { double gap, n1, n2, d; };
+// Candidate bookkeeping: gaps are compared as num^2/len2 by cross-multiplication, so that only the
+// winning candidate needs a square root and divisions (fp64 sqrt/div expand to ~30 VALU ops each).
+struct SepBest { bool have; double num, len2, sg, tA, nx, ny, px, py; };
+
+__device__ __forceinline__ void sep_consider(SepBest& b, double num, double len2, double sg, double tA, double nx, double ny, double px, double py) {
+  if (!(num > 0.0)) return;
+  bool better;
+  if (!b.have) better = (num * num) > (SEP_MIN_GAP * SEP_MIN_GAP) * len2;
+  else better = (num * num) * b.len2 > (b.num * b.num) * len2;
+  if (better) { b.have = true; b.num = num; b.len2 = len2; b.sg = sg; b.tA = tA; b.nx = nx; b.ny = ny; b.px = px; b.py = py; }
+}
 
 // One candidate pair (p,q) of set X (from_A: X = A).  A: ax/ay[0..nA), B: bx/by[0..nB).
 __device__ __forceinline__ void sep_pair(double px, double py, double qx, double qy, bool from_A,
@@ -205,28 +215,21 @@ __device__ __forceinline__ void sep_pair(double px, double py, double qx, double
   double minA = NEP_INF, maxA = -NEP_INF, minB = NEP_INF, maxB = -NEP_INF;
   for (int i = 0; i < nA; i++) { const double t = nx * (ax[i] - px) + ny * (ay[i] - py); if (t < minA) minA = t; if (t > maxA) maxA = t; }
   for (int i = 0; i < nB; i++) { const double t = nx * (bx[i] - px) + ny * (by[i] - py); if (t < minB) minB = t; if (t > maxB) maxB = t; }
-  const double len = sqrt(len2);
-  double gp = -NEP_INF, gm = -NEP_INF, tAp = 0.0, tAm = 0.0;
+  double np_ = -NEP_INF, nm = -NEP_INF, tAp = 0.0, tAm = 0.0;
   if (from_A) {
-    if (minA >= 0.0) { gp = (0.0 - maxB) / len; tAp = 0.0; }
-    if (maxA <= 0.0) { gm = (minB - 0.0) / len; tAm = 0.0; }
+    if (minA >= 0.0) { np_ = 0.0 - maxB; tAp = 0.0; }
+    if (maxA <= 0.0) { nm = minB - 0.0; tAm = 0.0; }
   } else {
-    if (maxB <= 0.0) { gp = (minA - 0.0) / len; tAp = minA; }
-    if (minB >= 0.0) { gm = (0.0 - maxA) / len; tAm = maxA; }
+    if (maxB <= 0.0) { np_ = minA - 0.0; tAp = minA; }
+    if (minB >= 0.0) { nm = 0.0 - maxA; tAm = maxA; }
   }
-  double g, sg, tA;
-  if (gp >= gm) { g = gp; sg = 1.0; tA = tAp; } else { g = gm; sg = -1.0; tA = tAm; }
-  if (g > best.gap) {
-    const double s = 2.0 / g;
-    const double n1 = s * (sg * nx / len), n2 = s * (sg * ny / len);
-    best.gap = g; best.n1 = n1; best.n2 = n2;
-    best.d = (1.0 - s * (sg * tA / len)) - (n1 * px + n2 * py);
-  }
+  if (np_ >= nm) sep_consider(best, np_, len2, 1.0, tAp, nx, ny, px, py);
+  else sep_consider(best, nm, len2, -1.0, tAm, nx, ny, px, py);
 }
 
 __device__ bool separator_impl(int nA, const double* ax, const double* ay, bool a_ordered, int nB,
                                const double* bx, const double* by, double nd[3]) {
-  SepBest best; best.gap = SEP_MIN_GAP; best.n1 = best.n2 = best.d = 0.0;
+  SepBest best; best.have = false; best.num = 0; best.len2 = 1; best.sg = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
   if (a_ordered && nA >= 3) {
     for (int p = 0; p < nA - 1; p++) {
       sep_pair(ax[p], ay[p], ax[p + 1], ay[p + 1], true, nA, ax, ay, nB, bx, by, best);
@@ -236,7 +239,7 @@ __device__ bool separator_impl(int nA, const double* ax, const double* ay, bool 
     for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) sep_pair(ax[p], ay[p], ax[q], ay[q], true, nA, ax, ay, nB, bx, by, best);
   }
   for (int p = 0; p < nB; p++) for (int q = p + 1; q < nB; q++) sep_pair(bx[p], by[p], bx[q], by[q], false, nA, ax, ay, nB, bx, by, best);
-  if (!(best.gap > SEP_MIN_GAP) && nA > 0 && nB > 0) {
+  if (!best.have && nA > 0 && nB > 0) {
     double cax = 0, cay = 0, cbx = 0, cby = 0;
     for (int i = 0; i < nA; i++) { cax += ax[i]; cay += ay[i]; }
     for (int i = 0; i < nB; i++) { cbx += bx[i]; cby += by[i]; }
@@ -247,17 +250,18 @@ __device__ bool separator_impl(int nA, const double* ax, const double* ay, bool 
       double minA = NEP_INF, maxB = -NEP_INF;
       for (int i = 0; i < nA; i++) { const double t = nx * (ax[i] - cbx) + ny * (ay[i] - cby); if (t < minA) minA = t; }
       for (int i = 0; i < nB; i++) { const double t = nx * (bx[i] - cbx) + ny * (by[i] - cby); if (t > maxB) maxB = t; }
-      const double len = sqrt(len2);
-      const double g = (minA - maxB) / len;
-      if (g > best.gap) {
-        const double s = 2.0 / g;
-        const double n1 = s * (nx / len), n2 = s * (ny / len);
-        best.gap = g; best.n1 = n1; best.n2 = n2;
-        best.d = (1.0 - s * (minA / len)) - (n1 * cbx + n2 * cby);
-      }
+      sep_consider(best, minA - maxB, len2, 1.0, minA, nx, ny, cbx, cby);
     }
   }
-  if (best.gap > SEP_MIN_GAP) { nd[0] = best.n1; nd[1] = best.n2; nd[2] = best.d; return true; }
+  if (best.have) {   // the winning LP vertex in the reference's epsilon = 1 scaling
+    const double len = sqrt(best.len2);
+    const double g = best.num / len;
+    const double s = 2.0 / g;
+    const double n1 = s * (best.sg * best.nx / len), n2 = s * (best.sg * best.ny / len);
+    nd[0] = n1; nd[1] = n2;
+    nd[2] = (1.0 - s * (best.sg * best.tA / len)) - (n1 * best.px + n2 * best.py);
+    return true;
+  }
   nd[0] = nd[1] = nd[2] = 0.0;
   return false;
 }

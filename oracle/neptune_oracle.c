@@ -191,8 +191,20 @@ int orc_inflate_static(int nv, const double (*v)[2], double sd, double (*out)[2]
  * lexicographic order; when A is known to be a convex polygon in boundary order only its edges
  * can be tight and only they are tried, in the same relative order (0,1),(0,V-1),(1,2),...
  * Projections are taken relative to p so that both points of the pair project to exactly 0. */
+/* Candidate bookkeeping: gaps are compared as num^2/len2 by cross-multiplication, so that only
+ * the winning candidate needs a square root and divisions. */
+typedef struct { int have; double num, len2, sg, tA, nx, ny, px, py; } sep_best;
+
+static void sep_consider(sep_best* b, double num, double len2, double sg, double tA, double nx, double ny, double px, double py) {
+  if (!(num > 0.0)) return;
+  int better;
+  if (!b->have) better = (num * num) > (SEP_MIN_GAP * SEP_MIN_GAP) * len2;
+  else better = (num * num) * b->len2 > (b->num * b->num) * len2;
+  if (better) { b->have = 1; b->num = num; b->len2 = len2; b->sg = sg; b->tA = tA; b->nx = nx; b->ny = ny; b->px = px; b->py = py; }
+}
+
 static void sep_pair(const double p[2], const double q[2], int from_A, int nA, const double (*A)[2],
-                     int nB, const double (*B)[2], double* best_gap, double nd[3]) {
+                     int nB, const double (*B)[2], sep_best* best) {
   double ex = q[0] - p[0], ey = q[1] - p[1];
   double nx = -ey, ny = ex;
   double len2 = nx * nx + ny * ny;
@@ -200,38 +212,30 @@ static void sep_pair(const double p[2], const double q[2], int from_A, int nA, c
   double minA = INFINITY, maxA = -INFINITY, minB = INFINITY, maxB = -INFINITY;
   for (int i = 0; i < nA; i++) { double t = nx * (A[i][0] - p[0]) + ny * (A[i][1] - p[1]); if (t < minA) minA = t; if (t > maxA) maxA = t; }
   for (int i = 0; i < nB; i++) { double t = nx * (B[i][0] - p[0]) + ny * (B[i][1] - p[1]); if (t < minB) minB = t; if (t > maxB) maxB = t; }
-  double len = sqrt(len2);
-  double gp = -INFINITY, gm = -INFINITY, tAp = 0.0, tAm = 0.0; /* +n / -n points toward A */
+  double np_ = -INFINITY, nm = -INFINITY, tAp = 0.0, tAm = 0.0; /* gap numerators for +n / -n pointing toward A */
   if (from_A) {
-    if (minA >= 0.0) { gp = (0.0 - maxB) / len; tAp = 0.0; }
-    if (maxA <= 0.0) { gm = (minB - 0.0) / len; tAm = 0.0; }
+    if (minA >= 0.0) { np_ = 0.0 - maxB; tAp = 0.0; }
+    if (maxA <= 0.0) { nm = minB - 0.0; tAm = 0.0; }
   } else {
-    if (maxB <= 0.0) { gp = (minA - 0.0) / len; tAp = minA; }
-    if (minB >= 0.0) { gm = (0.0 - maxA) / len; tAm = maxA; }
+    if (maxB <= 0.0) { np_ = minA - 0.0; tAp = minA; }
+    if (minB >= 0.0) { nm = 0.0 - maxA; tAm = maxA; }
   }
-  double g, sg, tA;
-  if (gp >= gm) { g = gp; sg = 1.0; tA = tAp; } else { g = gm; sg = -1.0; tA = tAm; }
-  if (g > *best_gap) {
-    double s = 2.0 / g;
-    double n1 = s * (sg * nx / len), n2 = s * (sg * ny / len);
-    *best_gap = g; nd[0] = n1; nd[1] = n2;
-    nd[2] = (1.0 - s * (sg * tA / len)) - (n1 * p[0] + n2 * p[1]);
-  }
+  if (np_ >= nm) sep_consider(best, np_, len2, 1.0, tAp, nx, ny, p[0], p[1]);
+  else sep_consider(best, nm, len2, -1.0, tAm, nx, ny, p[0], p[1]);
 }
 
 static int separator_impl(int nA, const double (*A)[2], int a_ordered, int nB, const double (*B)[2], double nd[3]) {
-  double best = SEP_MIN_GAP;
-  double cand[3] = {0, 0, 0};
+  sep_best best; best.have = 0; best.num = 0; best.len2 = 1; best.sg = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
   if (a_ordered && nA >= 3) {
     for (int p = 0; p < nA - 1; p++) {
-      sep_pair(A[p], A[p + 1], 1, nA, A, nB, B, &best, cand);
-      if (p == 0) sep_pair(A[0], A[nA - 1], 1, nA, A, nB, B, &best, cand);
+      sep_pair(A[p], A[p + 1], 1, nA, A, nB, B, &best);
+      if (p == 0) sep_pair(A[0], A[nA - 1], 1, nA, A, nB, B, &best);
     }
   } else {
-    for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) sep_pair(A[p], A[q], 1, nA, A, nB, B, &best, cand);
+    for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) sep_pair(A[p], A[q], 1, nA, A, nB, B, &best);
   }
-  for (int p = 0; p < nB; p++) for (int q = p + 1; q < nB; q++) sep_pair(B[p], B[q], 0, nA, A, nB, B, &best, cand);
-  if (!(best > SEP_MIN_GAP) && nA > 0 && nB > 0) {
+  for (int p = 0; p < nB; p++) for (int q = p + 1; q < nB; q++) sep_pair(B[p], B[q], 0, nA, A, nB, B, &best);
+  if (!best.have && nA > 0 && nB > 0) {
     /* degenerate sets (every pair coincident, e.g. a hovering agent against a point):
      * direction between the centroids, supported at the extreme points */
     double ca[2] = {0, 0}, cb[2] = {0, 0};
@@ -244,17 +248,18 @@ static int separator_impl(int nA, const double (*A)[2], int a_ordered, int nB, c
       double minA = INFINITY, maxB = -INFINITY;
       for (int i = 0; i < nA; i++) { double t = nx * (A[i][0] - cb[0]) + ny * (A[i][1] - cb[1]); if (t < minA) minA = t; }
       for (int i = 0; i < nB; i++) { double t = nx * (B[i][0] - cb[0]) + ny * (B[i][1] - cb[1]); if (t > maxB) maxB = t; }
-      double len = sqrt(len2);
-      double g = (minA - maxB) / len;
-      if (g > best) {
-        double s = 2.0 / g;
-        double n1 = s * (nx / len), n2 = s * (ny / len);
-        best = g; cand[0] = n1; cand[1] = n2;
-        cand[2] = (1.0 - s * (minA / len)) - (n1 * cb[0] + n2 * cb[1]);
-      }
+      sep_consider(&best, minA - maxB, len2, 1.0, minA, nx, ny, cb[0], cb[1]);
     }
   }
-  if (best > SEP_MIN_GAP) { nd[0] = cand[0]; nd[1] = cand[1]; nd[2] = cand[2]; return 1; }
+  if (best.have) { /* the winning LP vertex in the reference's epsilon = 1 scaling */
+    double len = sqrt(best.len2);
+    double g = best.num / len;
+    double s = 2.0 / g;
+    double n1 = s * (best.sg * best.nx / len), n2 = s * (best.sg * best.ny / len);
+    nd[0] = n1; nd[1] = n2;
+    nd[2] = (1.0 - s * (best.sg * best.tA / len)) - (n1 * best.px + n2 * best.py);
+    return 1;
+  }
   nd[0] = nd[1] = nd[2] = 0.0;
   return 0;
 }
