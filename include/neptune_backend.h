@@ -174,7 +174,9 @@ int nep_backend_debug_get_lines(nep_backend_t* h, int32_t cap, int32_t* seg, dou
 
 /* Separator::solveModel 2-D, 2-set (separator_glpk.cpp:248-373), batched: problem p has point
  * set A = a_xy[a_off[p]..a_off[p+1]) and B = b_xy[b_off[p]..b_off[p+1]).  nd_out[p] = (n1,n2,d),
- * solved_out[p] = 1/0.  The 3-set overload (:375-498) is the same LP with A := A u A+.         */
+ * solved_out[p] = 1/0.  The 3-set overload (:375-498) is the same LP with A := A u A+.  As at
+ * every call site of the path, B must hold exactly 4 points (a segment's control points) and A at
+ * most NEP_HULL_MAX_V.                                                                          */
 int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy,
                         const int32_t* b_off, const double* b_xy, double* nd_out,
                         int32_t* solved_out);

@@ -85,6 +85,7 @@ struct Engine {
     const long slots = (long)n_scenes * sp.n_local;
     sp.lines_cap = sp.n_hull + N + sp.n_static + (sp.ent_enabled ? N * kBend : 0);
     if (sp.lines_cap < 8) sp.lines_cap = 8;
+    if ((long)NEP_MAX_POL * sp.lines_cap > 65535) return fail(NEP_E_CAP, "more than 65535 separator candidates per agent");
     const long lines_total = (long)NEP_MAX_POL * sp.lines_cap;
     // LDS carve of the QP kernel: 11 doubles per line (n1, n2, h + 4 x (s, lambda)).  The worst case
     // (every base and every obstacle close to every segment) almost never happens, so the carve is
@@ -430,7 +431,10 @@ int nep_backend_debug_get_lines(nep_backend_t* h, int32_t cap, int32_t* seg, dou
   HIPCHK(hipMemcpy(cnt.data(), E.d_line_cnt.p, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(buf.data(), E.d_line_nd.p, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
   int n = 0;
-  for (int s = 0; s < h->guess.K; s++) for (int c = 0; c < cnt[s]; c++) { if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
+  for (int s = 0; s < h->guess.K; s++) for (int c = 0; c < cnt[s]; c++) {
+    const double* e = &buf[((size_t)s * E.sp.lines_cap + c) * 3];
+    if (e[0] == 0.0 && e[1] == 0.0 && e[2] == 0.0) continue;   // LP without a separating line
+    if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
   *n_out = n;
   return 0;
 }
@@ -443,6 +447,10 @@ int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy
   if (n_prob < 0 || !a_off || !b_off || !nd_out || !solved_out) return fail(NEP_E_ARG, "bad arguments");
   if (!have_device()) return fail(NEP_E_HIP, "no HIP device: the back end has no CPU path");
   if (n_prob == 0) return 0;
+  for (int p = 0; p < n_prob; p++) {
+    if (b_off[p + 1] - b_off[p] != 4) return fail(NEP_E_ARG, "set B must be the 4 control points of a segment");
+    if (a_off[p + 1] - a_off[p] > kHullV) return fail(NEP_E_CAP, "set A has more than NEP_HULL_MAX_V points");
+  }
   DevBuf<int> da, db, ds; DevBuf<double> dax, dbx, dnd;
   const int na = a_off[n_prob], nb = b_off[n_prob];
   int e = 0;
@@ -577,7 +585,10 @@ int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* se
   HIPCHK(hipMemcpy(cnt.data(), E.d_line_cnt.p + (size_t)slot * NEP_MAX_POL, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(buf.data(), E.d_line_nd.p + (size_t)slot * NEP_MAX_POL * E.sp.lines_cap * 3, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
   int n = 0;
-  for (int s = 0; s < NEP_MAX_POL; s++) for (int c = 0; c < cnt[s]; c++) { if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
+  for (int s = 0; s < NEP_MAX_POL; s++) for (int c = 0; c < cnt[s]; c++) {
+    const double* e = &buf[((size_t)s * E.sp.lines_cap + c) * 3];
+    if (e[0] == 0.0 && e[1] == 0.0 && e[2] == 0.0) continue;   // LP without a separating line
+    if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
   *n_out = n;
   return 0;
 }

@@ -204,17 +204,35 @@ __device__ __forceinline__ void sep_consider(SepBest& b, double num, double len2
   if (better) { b.have = true; b.num = num; b.len2 = len2; b.sg = sg; b.tA = tA; b.nx = nx; b.ny = ny; b.px = px; b.py = py; }
 }
 
-// One candidate pair (p,q) of set X (from_A: X = A).  A: ax/ay[0..nA), B: bx/by[0..nB).
+// Point set A: interleaved (x,y) pairs (one ds_read_b128 per point); point set B: the segment's
+// four control points, held in registers.
+struct Pts4 { double x[4], y[4]; };
+
+// One candidate pair (p,q) of set X (from_A: X = A).
+// Edge p->q of a counter-clockwise convex polygon A (hulls, inflated statics): A lies on the left of
+// its own edges, so the A rows need no projection — the edge is tight by construction and only the
+// four B points decide the candidate.
+__device__ __forceinline__ void sep_edge_ccw(double px, double py, double qx, double qy, const Pts4& B, SepBest& best) {
+  const double ex = qx - px, ey = qy - py;
+  const double nx = -ey, ny = ex;
+  const double len2 = nx * nx + ny * ny;
+  if (!(len2 > 0.0)) return;
+  double maxB = -NEP_INF;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); if (t > maxB) maxB = t; }
+  sep_consider(best, 0.0 - maxB, len2, 1.0, 0.0, nx, ny, px, py);
+}
+
 __device__ __forceinline__ void sep_pair(double px, double py, double qx, double qy, bool from_A,
-                                         int nA, const double* ax, const double* ay, int nB,
-                                         const double* bx, const double* by, SepBest& best) {
+                                         int nA, const double2* __restrict__ A, const Pts4& B, SepBest& best) {
   const double ex = qx - px, ey = qy - py;
   const double nx = -ey, ny = ex;
   const double len2 = nx * nx + ny * ny;
   if (!(len2 > 0.0)) return;
   double minA = NEP_INF, maxA = -NEP_INF, minB = NEP_INF, maxB = -NEP_INF;
-  for (int i = 0; i < nA; i++) { const double t = nx * (ax[i] - px) + ny * (ay[i] - py); if (t < minA) minA = t; if (t > maxA) maxA = t; }
-  for (int i = 0; i < nB; i++) { const double t = nx * (bx[i] - px) + ny * (by[i] - py); if (t < minB) minB = t; if (t > maxB) maxB = t; }
+  for (int i = 0; i < nA; i++) { const double2 a = A[i]; const double t = nx * (a.x - px) + ny * (a.y - py); if (t < minA) minA = t; if (t > maxA) maxA = t; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); if (t < minB) minB = t; if (t > maxB) maxB = t; }
   double np_ = -NEP_INF, nm = -NEP_INF, tAp = 0.0, tAm = 0.0;
   if (from_A) {
     if (minA >= 0.0) { np_ = 0.0 - maxB; tAp = 0.0; }
@@ -227,29 +245,33 @@ __device__ __forceinline__ void sep_pair(double px, double py, double qx, double
   else sep_consider(best, nm, len2, -1.0, tAm, nx, ny, px, py);
 }
 
-__device__ bool separator_impl(int nA, const double* ax, const double* ay, bool a_ordered, int nB,
-                               const double* bx, const double* by, double nd[3]) {
+// nB == 4 in the path (the segment's control points); the stand-alone entry passes general B in A-like storage.
+__device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ordered, const Pts4& B, double nd[3]) {
   SepBest best; best.have = false; best.num = 0; best.len2 = 1; best.sg = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
   if (a_ordered && nA >= 3) {
     for (int p = 0; p < nA - 1; p++) {
-      sep_pair(ax[p], ay[p], ax[p + 1], ay[p + 1], true, nA, ax, ay, nB, bx, by, best);
-      if (p == 0) sep_pair(ax[0], ay[0], ax[nA - 1], ay[nA - 1], true, nA, ax, ay, nB, bx, by, best);
+      const double2 a0 = A[p], a1 = A[p + 1];
+      sep_edge_ccw(a0.x, a0.y, a1.x, a1.y, B, best);
+      if (p == 0) { const double2 al = A[nA - 1]; sep_edge_ccw(al.x, al.y, a0.x, a0.y, B, best); }   // closing edge, same orientation
     }
   } else {
-    for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) sep_pair(ax[p], ay[p], ax[q], ay[q], true, nA, ax, ay, nB, bx, by, best);
+    for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) { const double2 a0 = A[p], a1 = A[q]; sep_pair(a0.x, a0.y, a1.x, a1.y, true, nA, A, B, best); }
   }
-  for (int p = 0; p < nB; p++) for (int q = p + 1; q < nB; q++) sep_pair(bx[p], by[p], bx[q], by[q], false, nA, ax, ay, nB, bx, by, best);
-  if (!best.have && nA > 0 && nB > 0) {
+#pragma unroll
+  for (int p = 0; p < 4; p++)
+#pragma unroll
+    for (int q = p + 1; q < 4; q++) sep_pair(B.x[p], B.y[p], B.x[q], B.y[q], false, nA, A, B, best);
+  if (!best.have && nA > 0) {
     double cax = 0, cay = 0, cbx = 0, cby = 0;
-    for (int i = 0; i < nA; i++) { cax += ax[i]; cay += ay[i]; }
-    for (int i = 0; i < nB; i++) { cbx += bx[i]; cby += by[i]; }
-    cax /= nA; cay /= nA; cbx /= nB; cby /= nB;
+    for (int i = 0; i < nA; i++) { cax += A[i].x; cay += A[i].y; }
+    for (int i = 0; i < 4; i++) { cbx += B.x[i]; cby += B.y[i]; }
+    cax /= nA; cay /= nA; cbx /= 4; cby /= 4;
     const double nx = cax - cbx, ny = cay - cby;
     const double len2 = nx * nx + ny * ny;
     if (len2 > 0.0) {
       double minA = NEP_INF, maxB = -NEP_INF;
-      for (int i = 0; i < nA; i++) { const double t = nx * (ax[i] - cbx) + ny * (ay[i] - cby); if (t < minA) minA = t; }
-      for (int i = 0; i < nB; i++) { const double t = nx * (bx[i] - cbx) + ny * (by[i] - cby); if (t > maxB) maxB = t; }
+      for (int i = 0; i < nA; i++) { const double t = nx * (A[i].x - cbx) + ny * (A[i].y - cby); if (t < minA) minA = t; }
+      for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - cbx) + ny * (B.y[i] - cby); if (t > maxB) maxB = t; }
       sep_consider(best, minA - maxB, len2, 1.0, minA, nx, ny, cbx, cby);
     }
   }
@@ -266,22 +288,115 @@ __device__ bool separator_impl(int nA, const double* ax, const double* ay, bool 
   return false;
 }
 
-constexpr int kAStride = 17;  // doubles per lane slot: 34 dwords -> distinct even banks per 32-lane group
+constexpr int kAStride = 17;  // (x,y) pairs per lane slot: 68 dwords -> 16 lanes of a ds_read_b128 group hit distinct 4-bank slots
 
-// One wave per (slot, segment).  Candidate order == reference loop order
-// (solver_gurobi_poly.cpp:477-495 agents, :521-553 bases, :556-593 statics, :620-637 entangle).
+// Candidate c of segment seg, in the reference's loop order (solver_gurobi_poly.cpp:477-495 agents,
+// :521-553 bases, :556-593 statics, :620-637 entangle): does the reference call the separator for
+// it, and (stage == true) what is point set A.
+struct SepCtx {
+  const SceneParams* sp; const ProblemSet* ps;
+  int slot, scene, own, N, S, nH, total;
+};
+__device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, const double* by, double hulldist,
+                          bool stage, double2* myA, int& nA, bool& ordered) {
+  const SceneParams& sp = *cx.sp; const ProblemSet& ps = *cx.ps;
+  const int N = cx.N, S = cx.S, nH = cx.nH;
+  nA = 0; ordered = false;
+  if (c < nH) {
+    const int j = c;
+    if (sp.skip_own && j == cx.own) return false;
+    const long h = ((long)cx.scene * nH + j) * sp.num_pol + seg;
+    nA = ps.hull_nv[h];
+    if (nA <= 0) return false;
+    ordered = true;
+    if (stage) { const double2* src = (const double2*)(ps.hull_xy + h * kHullV * 2); for (int v = 0; v < nA; v++) myA[v] = src[v]; }
+    return true;
+  } else if (c < nH + N) {
+    const int j = c - nH;
+    const double base_radius = 0.7;
+    const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
+    bool close_to_base = false;
+    for (int k = 0; k < 4; k++) {
+      const double ddx = bx[k] - pbx, ddy = by[k] - pby;
+      // sqrt(ddx^2+ddy^2) >= max(|ddx|,|ddy|): beyond 2.2 on either axis the test below is false; skip its sqrt
+      if (fabs(ddx) > 2.2 || fabs(ddy) > 2.2) continue;
+      if (sqrt(ddx * ddx + ddy * ddy) < base_radius * 3) { close_to_base = true; break; }
+    }
+    if (!close_to_base) return false;
+    nA = 4;
+    if (stage) {  // :536-540 (column order of base_hull)
+      myA[0] = make_double2(pbx + base_radius, pby + base_radius);
+      myA[1] = make_double2(pbx + base_radius, pby - base_radius);
+      myA[2] = make_double2(pbx - base_radius, pby + base_radius);
+      myA[3] = make_double2(pbx - base_radius, pby - base_radius);
+    }
+    return true;
+  } else if (c < nH + N + S) {
+    const int j = c - nH - N;
+    const int nv = ps.static_nv[j];
+    if (nv <= 0) return false;
+    const double* src = ps.static_xy + (long)j * kHullV * 2;
+    bool close_s = false;  // :558-578
+    const double ddx = bx[0] - src[0], ddy = by[0] - src[1];
+    double dist = sqrt(ddx * ddx + ddy * ddy);
+    for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
+    for (int k = 0; k < nv - 1; k++) { const double ex = src[2 * (k + 1)] - src[2 * k], ey = src[2 * (k + 1) + 1] - src[2 * k + 1]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
+    if (!close_s) return false;
+    ordered = true; nA = nv;
+    if (stage) for (int v = 0; v < nv; v++) myA[v] = make_double2(src[2 * v], src[2 * v + 1]);
+    return true;
+  } else if (c < cx.total) {
+    const int e = c - nH - N - S;
+    const int j = e / kBend, k = e % kBend + 1;
+    if (j == cx.own) return false;
+    const int case_id = ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * N + j];
+    const int nb = ps.bend_n[(long)cx.scene * N + j];
+    if (!(case_id != 0 && k != case_id && k <= nb)) return false;  // :631-636
+    const double* bp = ps.bend_xy + ((long)cx.scene * N + j) * kBend * 2;
+    const long h0 = ((long)cx.scene * N + j) * sp.num_pol + seg;
+    double pAx, pAy, pBx, pBy;
+    if (k == 1) {  // :719-724
+      if (ps.hull0_nv[h0] <= 0) return false;
+      const double hx0 = ps.hull0_xy[h0 * 2], hy0 = ps.hull0_xy[h0 * 2 + 1];
+      pAx = (1 - sp.long_length) * bp[2 * (nb - 1)] + sp.long_length * hx0;
+      pAy = (1 - sp.long_length) * bp[2 * (nb - 1) + 1] + sp.long_length * hy0;
+      pBx = hx0; pBy = hy0;
+    } else {  // :725-730
+      pAx = bp[2 * (k - 2)]; pAy = bp[2 * (k - 2) + 1]; pBx = bp[2 * (k - 1)]; pBy = bp[2 * (k - 1) + 1];
+    }
+    const double ax_ = pAx - bx[0], ay_ = pAy - by[0], bx_ = pBx - bx[0], by_ = pBy - by[0];
+    if (sqrt(ax_ * ax_ + ay_ * ay_) - hulldist > 0 && sqrt(bx_ * bx_ + by_ * by_) - hulldist > 0) return false;  // :743-745
+    nA = 2;
+    if (stage) { myA[0] = make_double2(pAx, pAy); myA[1] = make_double2(pBx, pBy); }
+    return true;
+  }
+  return false;
+}
+
+// One wave per (agent slot, segment).  Step 1 runs the reference's proximity culls for every
+// candidate of the segment and builds, with ordered wave ballots, the list of LPs the reference
+// would actually call — in its loop order; step 2 hands those LPs out 64 at a time (one lane each,
+// point set A staged in the lane's LDS slot), so that lanes are not parked on rejected candidates
+// (with 63 other agents that is one full round plus a short tail instead of three rounds).  Line l
+// lands in bucket (slot, seg) at its call rank; an LP without a separating line leaves (0,0,0)
+// there — the QP kernel reads that as "constraint skipped" (solver_gurobi_poly.cpp:491-494).
 __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSet ps) {
-  __shared__ double sAx[64 * kAStride], sAy[64 * kAStride];
-  __shared__ double sBx[4], sBy[4];
+  extern __shared__ __attribute__((aligned(16))) double sdyn[];
+  double2* sA = (double2*)sdyn;                      // [64][kAStride] (x,y) pairs
+  double* sBx = sdyn + 2 * 64 * kAStride; double* sBy = sBx + 4;
+  unsigned short* sAtt = (unsigned short*)(sBy + 4);
   const int lane = threadIdx.x;
   const int seg = blockIdx.x % NEP_MAX_POL;
   const int slot = blockIdx.x / NEP_MAX_POL;
-  const int scene = slot / sp.n_local;
   const nep_guess* g = ps.guess + slot;
   const int K = g->K;
   int* cnt_out = ps.line_cnt + (long)slot * NEP_MAX_POL + seg;
   if (seg >= K || seg >= sp.num_pol) { if (lane == 0) *cnt_out = 0; return; }
   const double T = sp.T_span;
+  SepCtx cx; cx.sp = &sp; cx.ps = &ps; cx.slot = slot; cx.scene = slot / sp.n_local; cx.own = sp.first_local + (slot % sp.n_local);
+  cx.N = sp.num_agents; cx.S = sp.n_static; cx.nH = sp.n_hull;
+  cx.total = cx.nH + cx.N + cx.S + ((sp.ent_enabled && ps.case_id) ? cx.N * kBend : 0);
+  const int total = cx.total;
   if (lane < 4) {  // ctrlPtsInit_[seg] (solver_gurobi_poly.cpp:232-243)
     const double tp0 = T * T * T, tp1 = T * T, tp2 = T;
     const double m0 = tp0 * cAPosInv[0][lane], m1 = tp1 * cAPosInv[1][lane], m2 = tp2 * cAPosInv[2][lane], m3 = 1.0 * cAPosInv[3][lane];
@@ -291,124 +406,72 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
   }
   __syncthreads();
   const double* bx = sBx; const double* by = sBy;
-  const int N = sp.num_agents, S = sp.n_static, nH = sp.n_hull;
-  const int own = sp.first_local + (slot % sp.n_local);
-  const int nE = (sp.ent_enabled && ps.case_id) ? N * kBend : 0;
-  const int total = nH + N + S + nE;
-  double* myAx = sAx + lane * kAStride; double* myAy = sAy + lane * kAStride;
-  double* bucket = ps.line_nd + ((long)slot * NEP_MAX_POL + seg) * sp.lines_cap * 3;
-  int base = 0, n_try = 0, n_fail = 0;
   double hulldist = 0;  // :738-742
   for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; hulldist += sqrt(ex * ex + ey * ey); }
+  // ---- step 1: which LPs does the reference call, in order -------------------------------------
+  int n_att = 0;
   for (int c0 = 0; c0 < total; c0 += 64) {
     const int c = c0 + lane;
-    bool attempt = false, ordered = false;
-    int nA = 0;
-    if (c < nH) {
-      const int j = c;
-      if (!(sp.skip_own && j == own)) {
-        const long h = ((long)scene * nH + j) * sp.num_pol + seg;
-        nA = ps.hull_nv[h];
-        if (nA > 0) {
-          attempt = true; ordered = true;
-          const double* src = ps.hull_xy + h * kHullV * 2;
-          for (int v = 0; v < nA; v++) { myAx[v] = src[2 * v]; myAy[v] = src[2 * v + 1]; }
-        }
-      }
-    } else if (c < nH + N) {
-      const int j = c - nH;
-      const double base_radius = 0.7;
-      const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
-      bool close_to_base = false;
-      for (int k = 0; k < 4; k++) { const double ddx = bx[k] - pbx, ddy = by[k] - pby; if (sqrt(ddx * ddx + ddy * ddy) < base_radius * 3) { close_to_base = true; break; } }
-      if (close_to_base) {  // :536-540 (column order of base_hull)
-        attempt = true; nA = 4;
-        myAx[0] = pbx + base_radius; myAy[0] = pby + base_radius;
-        myAx[1] = pbx + base_radius; myAy[1] = pby - base_radius;
-        myAx[2] = pbx - base_radius; myAy[2] = pby + base_radius;
-        myAx[3] = pbx - base_radius; myAy[3] = pby - base_radius;
-      }
-    } else if (c < nH + N + S) {
-      const int j = c - nH - N;
-      const int nv = ps.static_nv[j];
-      if (nv > 0) {
-        const double* src = ps.static_xy + (long)j * kHullV * 2;
-        for (int v = 0; v < nv; v++) { myAx[v] = src[2 * v]; myAy[v] = src[2 * v + 1]; }
-        bool close_s = false;  // :558-578
-        const double ddx = bx[0] - myAx[0], ddy = by[0] - myAy[0];
-        double dist = sqrt(ddx * ddx + ddy * ddy);
-        for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
-        for (int k = 0; k < nv - 1; k++) { const double ex = myAx[k + 1] - myAx[k], ey = myAy[k + 1] - myAy[k]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
-        if (close_s) { attempt = true; ordered = true; nA = nv; }
-      }
-    } else if (c < total) {
-      const int e = c - nH - N - S;
-      const int j = e / kBend, k = e % kBend + 1;
-      if (j != own) {
-        const int case_id = ps.case_id[((long)slot * NEP_MAX_POL + seg) * N + j];
-        const int nb = ps.bend_n[(long)scene * N + j];
-        if (case_id != 0 && k != case_id && k <= nb) {  // :631-636
-          const double* bp = ps.bend_xy + ((long)scene * N + j) * kBend * 2;
-          const long h0 = ((long)scene * N + j) * sp.num_pol + seg;
-          bool have = true;
-          double pAx, pAy, pBx, pBy;
-          if (k == 1) {  // :719-724
-            if (ps.hull0_nv[h0] <= 0) have = false;
-            const double hx0 = ps.hull0_xy[h0 * 2], hy0 = ps.hull0_xy[h0 * 2 + 1];
-            pAx = (1 - sp.long_length) * bp[2 * (nb - 1)] + sp.long_length * hx0;
-            pAy = (1 - sp.long_length) * bp[2 * (nb - 1) + 1] + sp.long_length * hy0;
-            pBx = hx0; pBy = hy0;
-          } else {  // :725-730
-            pAx = bp[2 * (k - 2)]; pAy = bp[2 * (k - 2) + 1]; pBx = bp[2 * (k - 1)]; pBy = bp[2 * (k - 1) + 1];
-          }
-          if (have) {
-            const double ax_ = pAx - bx[0], ay_ = pAy - by[0], bx_ = pBx - bx[0], by_ = pBy - by[0];
-            if (!(sqrt(ax_ * ax_ + ay_ * ay_) - hulldist > 0 && sqrt(bx_ * bx_ + by_ * by_) - hulldist > 0)) {  // :743-745
-              attempt = true; nA = 2;
-              myAx[0] = pAx; myAy[0] = pAy; myAx[1] = pBx; myAy[1] = pBy;
-            }
-          }
-        }
-      }
-    }
-    double nd[3] = {0, 0, 0};
-    bool ok = false;
-    if (attempt && !ps.lines_override) ok = separator_impl(nA, myAx, myAy, ordered, 4, bx, by, nd);
-    const unsigned long long mask = __ballot(ok);
-    const unsigned long long below = mask & ((1ull << lane) - 1ull);
-    if (ok) {
-      const int pos = base + __popcll(below);
-      if (pos < sp.lines_cap) { bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2]; }
-    }
-    base += __popcll(mask);
-    n_try += __popcll(__ballot(attempt));
-    n_fail += __popcll(__ballot(attempt && !ok));
+    int nA; bool ord;
+    const bool att = c < total && cand_eval(cx, seg, c, bx, by, hulldist, false, nullptr, nA, ord);
+    const unsigned long long mask = __ballot(att);
+    if (att) sAtt[n_att + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)c;
+    n_att += __popcll(mask);
   }
-  if (lane == 0 && !ps.lines_override) {
-    *cnt_out = base < sp.lines_cap ? base : sp.lines_cap;
-    atomicAdd(ps.lp_stats + 2 * slot, n_try);
-    atomicAdd(ps.lp_stats + 2 * slot + 1, n_fail);
+  __syncthreads();
+  // ---- step 2: the LPs ---------------------------------------------------------------------------
+  double2* myA = sA + lane * kAStride;
+  Pts4 B4;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { B4.x[k] = sBx[k]; B4.y[k] = sBy[k]; }
+  double* bucket = ps.line_nd + ((long)slot * NEP_MAX_POL + seg) * sp.lines_cap * 3;
+  int n_fail = 0;
+  for (int a = lane; a < n_att; a += 64) {
+    const int c = sAtt[a];
+    int nA; bool ord;
+    cand_eval(cx, seg, c, bx, by, hulldist, true, myA, nA, ord);
+    double nd[3];
+    const bool ok = separator_impl(nA, myA, ord, B4, nd);
+    if (!ok) { n_fail++; nd[0] = nd[1] = nd[2] = 0.0; }
+    if (a < sp.lines_cap) { bucket[3 * a] = nd[0]; bucket[3 * a + 1] = nd[1]; bucket[3 * a + 2] = nd[2]; }
   }
+  for (int o = 32; o > 0; o >>= 1) n_fail += __shfl_xor(n_fail, o);
+  if (lane == 0) {
+    *cnt_out = n_att < sp.lines_cap ? n_att : sp.lines_cap;
+    atomicAdd(ps.lp_stats + 2 * slot, n_att);
+    if (n_fail) atomicAdd(ps.lp_stats + 2 * slot + 1, n_fail);
+  }
+}
+
+size_t separator_lds_bytes(const SceneParams& sp) {
+  const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
+  size_t b = (size_t)(2 * 64 * kAStride + 8) * sizeof(double) + (size_t)(total + 8) * sizeof(unsigned short);
+  return (b + 15) & ~(size_t)15;
 }
 
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
   if (n_slots <= 0) return;
-  hipLaunchKernelGGL(separator_kernel, dim3(n_slots * NEP_MAX_POL), dim3(64), 0, st, sp, ps);
+  const size_t lds = separator_lds_bytes(sp);
+  static size_t configured = 0;
+  if (lds > configured) { hipFuncSetAttribute((const void*)separator_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); configured = lds; }
+  hipLaunchKernelGGL(separator_kernel, dim3(n_slots * NEP_MAX_POL), dim3(64), lds, st, sp, ps);
 }
 
-// Stand-alone batched LP (tests): one lane per problem, point sets read from global memory.
+// Stand-alone batched LP (tests / nep_separator_batch): one lane per problem, A read from global
+// memory into a private array, B = four points (what every call site of the path passes).
 __global__ void separator_explicit_kernel(int n_prob, const int* __restrict__ a_off, const double* __restrict__ a_xy,
                                           const int* __restrict__ b_off, const double* __restrict__ b_xy,
                                           double* __restrict__ nd_out, int* __restrict__ solved) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_prob) return;
-  double ax[kHullV], ay[kHullV], bx[kHullV], by[kHullV];
-  int nA = a_off[p + 1] - a_off[p], nB = b_off[p + 1] - b_off[p];
-  if (nA > kHullV) nA = kHullV; if (nB > kHullV) nB = kHullV;
-  for (int i = 0; i < nA; i++) { ax[i] = a_xy[2 * (a_off[p] + i)]; ay[i] = a_xy[2 * (a_off[p] + i) + 1]; }
-  for (int i = 0; i < nB; i++) { bx[i] = b_xy[2 * (b_off[p] + i)]; by[i] = b_xy[2 * (b_off[p] + i) + 1]; }
+  double2 A[kHullV];
+  Pts4 B;
+  int nA = a_off[p + 1] - a_off[p];
+  if (nA > kHullV) nA = kHullV;
+  for (int i = 0; i < nA; i++) A[i] = make_double2(a_xy[2 * (a_off[p] + i)], a_xy[2 * (a_off[p] + i) + 1]);
+  for (int i = 0; i < 4; i++) { B.x[i] = b_xy[2 * (b_off[p] + i)]; B.y[i] = b_xy[2 * (b_off[p] + i) + 1]; }
   double nd[3];
-  const bool ok = separator_impl(nA, ax, ay, false, nB, bx, by, nd);
+  const bool ok = separator_impl(nA, A, false, B, nd);
   nd_out[3 * p] = nd[0]; nd_out[3 * p + 1] = nd[1]; nd_out[3 * p + 2] = nd[2];
   solved[p] = ok ? 1 : 0;
 }

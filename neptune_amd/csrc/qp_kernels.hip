@@ -716,8 +716,10 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   const int ns = ns_all < sp.max_states ? ns_all : sp.max_states;
   if (tid == 0) {
     sol->stats.status = status; sol->stats.iters = iters_total; sol->stats.iters_first = iters_first;
-    sol->stats.n_lines = L; sol->stats.n_lp = ps.lp_stats ? ps.lp_stats[2 * slot] : 0; sol->stats.n_lp_failed = ps.lp_stats ? ps.lp_stats[2 * slot + 1] : 0;
-    sol->stats.n_rows = 48 * K + 4 * L; sol->stats.qc_active = has_qc ? 1 : 0;
+    // bucket entries of LPs without a separating line are (0,0,0) = null rows (constraint skipped)
+    const int n_lp = (ps.lp_stats && !ps.lines_override) ? ps.lp_stats[2 * slot] : 0, n_lpf = (ps.lp_stats && !ps.lines_override) ? ps.lp_stats[2 * slot + 1] : 0;
+    sol->stats.n_lines = L - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
+    sol->stats.n_rows = 48 * K + 4 * (L - n_lpf); sol->stats.qc_active = has_qc ? 1 : 0;
     sol->stats.objective = objective; sol->stats.solve_us = 0.0;
     sol->K = K; sol->n_states = ns;
   }

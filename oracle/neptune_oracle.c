@@ -188,8 +188,9 @@ int orc_inflate_static(int nv, const double (*v)[2], double sd, double (*out)[2]
  * nearest point of the other set (third tight row); GLPK returns whichever vertex its pivoting
  * reaches.  This restatement returns the vertex with the largest geometric gap; ties go to the
  * first candidate in the order: pairs of A, then pairs of B.  Pairs of A are (p<q) in
- * lexicographic order; when A is known to be a convex polygon in boundary order only its edges
- * can be tight and only they are tried, in the same relative order (0,1),(0,V-1),(1,2),...
+ * lexicographic order; when A is known to be a counter-clockwise convex polygon (hulls, inflated
+ * statics) only its edges can be tight and only they are tried — (0,1),(V-1,0),(1,2),... — with the
+ * A rows taken as satisfied by convexity.
  * Projections are taken relative to p so that both points of the pair project to exactly 0. */
 /* Candidate bookkeeping: gaps are compared as num^2/len2 by cross-multiplication, so that only
  * the winning candidate needs a square root and divisions. */
@@ -224,12 +225,24 @@ static void sep_pair(const double p[2], const double q[2], int from_A, int nA, c
   else sep_consider(best, nm, len2, -1.0, tAm, nx, ny, p[0], p[1]);
 }
 
+/* Edge p->q of a counter-clockwise convex polygon A (CGAL's hull output order, and ours): A lies on
+ * the left of its own edges, so the edge is a tight pair by construction and only B decides. */
+static void sep_edge_ccw(const double p[2], const double q[2], int nB, const double (*B)[2], sep_best* best) {
+  double ex = q[0] - p[0], ey = q[1] - p[1];
+  double nx = -ey, ny = ex;
+  double len2 = nx * nx + ny * ny;
+  if (!(len2 > 0.0)) return;
+  double maxB = -INFINITY;
+  for (int i = 0; i < nB; i++) { double t = nx * (B[i][0] - p[0]) + ny * (B[i][1] - p[1]); if (t > maxB) maxB = t; }
+  sep_consider(best, 0.0 - maxB, len2, 1.0, 0.0, nx, ny, p[0], p[1]);
+}
+
 static int separator_impl(int nA, const double (*A)[2], int a_ordered, int nB, const double (*B)[2], double nd[3]) {
   sep_best best; best.have = 0; best.num = 0; best.len2 = 1; best.sg = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
   if (a_ordered && nA >= 3) {
     for (int p = 0; p < nA - 1; p++) {
-      sep_pair(A[p], A[p + 1], 1, nA, A, nB, B, &best);
-      if (p == 0) sep_pair(A[0], A[nA - 1], 1, nA, A, nB, B, &best);
+      sep_edge_ccw(A[p], A[p + 1], nB, B, &best);
+      if (p == 0) sep_edge_ccw(A[nA - 1], A[0], nB, B, &best); /* closing edge, same orientation */
     }
   } else {
     for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) sep_pair(A[p], A[q], 1, nA, A, nB, B, &best);

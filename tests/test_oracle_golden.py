@@ -110,3 +110,23 @@ def test_reduced_model_matches_oracle(oracle):
                                      c["line_seg"], c["line_nd"])
         assert st == r["status"], c["tag"]
         assert np.abs(th - r["coeff"]).max() < 1e-7, c["tag"]
+
+
+def test_ordered_polygon_rule_agrees_with_all_pairs(oracle):
+    """For a counter-clockwise convex polygon A the edge-only rule (A rows satisfied by convexity)
+    picks the same LP vertex as the exhaustive all-pairs rule."""
+    rng = np.random.default_rng(9)
+    n_sep = 0
+    for _ in range(300):
+        A = scene.hull_ccw_lexmin(rng.normal(size=(int(rng.integers(3, 14)), 2)) * rng.uniform(0.3, 2.0) + rng.uniform(-3, 3, size=2))
+        if len(A) < 3:
+            continue
+        B = rng.normal(size=(4, 2)) * rng.uniform(0.1, 1.0) + rng.uniform(-4, 4, size=2)
+        ok1, nd1 = oracle.separator(A, B)
+        ok2, nd2 = oracle.separator(A, B, ordered=True)
+        assert ok1 == ok2
+        if ok1:
+            n_sep += 1
+            np.testing.assert_allclose(nd1, nd2, rtol=1e-9, atol=1e-9)
+            assert (A @ nd2[:2] + nd2[2]).min() >= 1 - 1e-9 and (B @ nd2[:2] + nd2[2]).max() <= -1 + 1e-9
+    assert n_sep > 100
