@@ -178,22 +178,24 @@ __device__ __forceinline__ double solve_impl(lds_dptr sM, lds_dptr sInvD, int la
   return b;
 }
 
-// n = 3 nz with nz in 1..8: one straight-line instantiation per size (no per-step size tests).
-__device__ __noinline__ bool chol_wave(unsigned m_off, unsigned d_off, int n) {   // LDS byte offsets of sM / sInvD
+// One straight-line instantiation per size (no per-step size tests).  Sizes: 3 nz (ball constraint
+// couples the axes), or the two diagonal blocks 2 nz (x,y) and nz (z) factored by two waves at once.
+#define NEP_SIZE_SWITCH(CALL)                                                                      \
+  switch (n) {                                                                                     \
+    case 1: return CALL(1); case 2: return CALL(2); case 3: return CALL(3); case 4: return CALL(4);  \
+    case 5: return CALL(5); case 6: return CALL(6); case 7: return CALL(7); case 8: return CALL(8);  \
+    case 9: return CALL(9); case 10: return CALL(10); case 12: return CALL(12); case 14: return CALL(14); \
+    case 15: return CALL(15); case 16: return CALL(16); case 18: return CALL(18); case 21: return CALL(21); \
+    default: return CALL(24);                                                                      \
+  }
+__device__ __noinline__ bool chol_wave(unsigned m_off, unsigned d_off, int n) {   // LDS byte offsets of the block / its 1/diag
   // arguments of a real call arrive in VGPRs: make the wave-uniform ones scalar again
   m_off = __builtin_amdgcn_readfirstlane(m_off); d_off = __builtin_amdgcn_readfirstlane(d_off); n = __builtin_amdgcn_readfirstlane(n);
   const lds_dptr sM = (lds_dptr)m_off; const lds_dptr sInvD = (lds_dptr)d_off;
   const int lane = threadIdx.x & 63;
-  switch (n) {
-    case 3: return chol_impl<3>(sM, sInvD, lane);
-    case 6: return chol_impl<6>(sM, sInvD, lane);
-    case 9: return chol_impl<9>(sM, sInvD, lane);
-    case 12: return chol_impl<12>(sM, sInvD, lane);
-    case 15: return chol_impl<15>(sM, sInvD, lane);
-    case 18: return chol_impl<18>(sM, sInvD, lane);
-    case 21: return chol_impl<21>(sM, sInvD, lane);
-    default: return chol_impl<24>(sM, sInvD, lane);
-  }
+#define NEP_CHOL(N) chol_impl<N>(sM, sInvD, lane)
+  NEP_SIZE_SWITCH(NEP_CHOL)
+#undef NEP_CHOL
 }
 
 // x = (L L')^-1 b with L from chol_wave; lane i holds b[i] / returns x[i].
@@ -201,16 +203,9 @@ __device__ __noinline__ double solve_wave(unsigned m_off, unsigned d_off, int n,
   m_off = __builtin_amdgcn_readfirstlane(m_off); d_off = __builtin_amdgcn_readfirstlane(d_off); n = __builtin_amdgcn_readfirstlane(n);
   const lds_dptr sM = (lds_dptr)m_off; const lds_dptr sInvD = (lds_dptr)d_off;
   const int lane = threadIdx.x & 63;
-  switch (n) {
-    case 3: return solve_impl<3>(sM, sInvD, lane, b);
-    case 6: return solve_impl<6>(sM, sInvD, lane, b);
-    case 9: return solve_impl<9>(sM, sInvD, lane, b);
-    case 12: return solve_impl<12>(sM, sInvD, lane, b);
-    case 15: return solve_impl<15>(sM, sInvD, lane, b);
-    case 18: return solve_impl<18>(sM, sInvD, lane, b);
-    case 21: return solve_impl<21>(sM, sInvD, lane, b);
-    default: return solve_impl<24>(sM, sInvD, lane, b);
-  }
+#define NEP_SOLVE(N) solve_impl<N>(sM, sInvD, lane, b)
+  NEP_SIZE_SWITCH(NEP_SOLVE)
+#undef NEP_SOLVE
 }
 
 __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
@@ -324,22 +319,25 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     if (tid < 8) sEp[tid] = tb->ep[tid];
     if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
     __syncthreads();
-    // normal-matrix entries owned by this thread (lower triangle, row-major): decoded once per mode
-    int me_i[2], me_j[2], me_ci[2], me_cj[2], me_sel[2]; bool me_diag[2], me_on[2];
+    // Normal-matrix entries owned by this thread, decoded once per mode.  Only the blocks that can be
+    // non-zero are summed — xx, yx, yy, zz — each entry by a pair of adjacent lanes (even / odd base
+    // rows); the z-x and z-y blocks only ever hold the ball constraint's rank-one term.
+    int me_i[2], me_j[2], me_ci[2], me_cj[2], me_sel[2]; bool me_on[2];
+    const int tri_n = nz * (nz + 1) / 2, n_ent = 3 * tri_n + nz * nz;
     {
-      const int n_ent = n * (n + 1) / 2;
+      auto tri = [&](int e, int& r, int& c) { r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while ((r + 1) * (r + 2) / 2 <= e) r++; while (r * (r + 1) / 2 > e) r--; c = e - r * (r + 1) / 2; };
 #pragma unroll
       for (int u = 0; u < 2; u++) {
-        const int e = tid + u * BS;
-        me_on[u] = e < n_ent;
-        int i = 0;
-        if (me_on[u]) { i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while ((i + 1) * (i + 2) / 2 <= e) i++; while (i * (i + 1) / 2 > e) i--; }
-        const int j = me_on[u] ? e - i * (i + 1) / 2 : 0;
-        const int nzs = nz > 0 ? nz : 1;
-        const int ai = i / nzs, aj = j / nzs;
-        me_i[u] = i; me_j[u] = j; me_ci[u] = i % nzs; me_cj[u] = j % nzs;
-        me_diag[u] = ai == aj;
-        me_sel[u] = ai == aj ? (ai == 0 ? 0 : (ai == 1 ? 2 : 3)) : ((ai == 1 && aj == 0) ? 1 : -1);
+        const int e = (tid >> 1) + u * (BS / 2);
+        me_on[u] = e < n_ent && nz > 0;
+        int ci = 0, cj = 0, bi = 0, bj = 0, sel = 0;
+        if (me_on[u]) {
+          if (e < tri_n) { tri(e, ci, cj); sel = 0; }
+          else if (e < tri_n + nz * nz) { const int f = e - tri_n; ci = f / nz; cj = f % nz; bi = 1; sel = 1; }
+          else if (e < 2 * tri_n + nz * nz) { tri(e - tri_n - nz * nz, ci, cj); bi = 1; bj = 1; sel = 2; }
+          else { tri(e - 2 * tri_n - nz * nz, ci, cj); bi = 2; bj = 2; sel = 3; }
+        }
+        me_ci[u] = ci; me_cj[u] = cj; me_i[u] = bi * nz + ci; me_j[u] = bj * nz + cj; me_sel[u] = sel;
       }
     }
     bool converged = false;
@@ -519,22 +517,26 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         }
 #pragma unroll
         for (int u = 0; u < 2; u++) {
+          const int ci = me_ci[u], cj = me_cj[u], sel = me_sel[u], half = tid & 1;
+          double a0 = 0.0, a1 = 0.0;
           if (me_on[u]) {
-            const int ci = me_ci[u], cj = me_cj[u], sel = me_sel[u];
-            double a0 = me_diag[u] ? sHax[ci * kNZ + cj] : 0.0, a1 = 0.0;
-            if (sel >= 0) {
-              const int rl = sel == 1 ? 4 * K : R;       // multiples of 4 (R = 8K)
-              for (int rho = 0; rho < rl; rho += 4) {
-                a0 = __builtin_fma(sDc[(rho + 0) * 4 + sel] * sB[(rho + 0) * kNZ + ci], sB[(rho + 0) * kNZ + cj], a0);
-                a1 = __builtin_fma(sDc[(rho + 1) * 4 + sel] * sB[(rho + 1) * kNZ + ci], sB[(rho + 1) * kNZ + cj], a1);
-                a0 = __builtin_fma(sDc[(rho + 2) * 4 + sel] * sB[(rho + 2) * kNZ + ci], sB[(rho + 2) * kNZ + cj], a0);
-                a1 = __builtin_fma(sDc[(rho + 3) * 4 + sel] * sB[(rho + 3) * kNZ + ci], sB[(rho + 3) * kNZ + cj], a1);
-              }
+            const int rl = sel == 1 ? 4 * K : R;       // multiples of 4
+            for (int rho = half; rho < rl; rho += 4) {
+              a0 = __builtin_fma(sDc[rho * 4 + sel] * sB[rho * kNZ + ci], sB[rho * kNZ + cj], a0);
+              a1 = __builtin_fma(sDc[(rho + 2) * 4 + sel] * sB[(rho + 2) * kNZ + ci], sB[(rho + 2) * kNZ + cj], a1);
             }
-            double v = a0 + a1;
-            if (has_qc) { v += sc[sWq] * sGq[me_i[u]] * sGq[me_j[u]]; if (me_diag[u]) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
+          }
+          double v = a0 + a1;
+          v += dpp<DPP_XOR1>(v);                      // the pair's two halves
+          if (me_on[u] && half == 0) {
+            if (sel != 1) v += sHax[ci * kNZ + cj];
+            if (has_qc) { v += sc[sWq] * sGq[me_i[u]] * sGq[me_j[u]]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
             sM[me_i[u] * MS + me_j[u]] = v;
           }
+        }
+        for (int e = tid; e < 2 * nz * nz; e += BS) {   // z-x and z-y blocks
+          const int i = 2 * nz + e / (2 * nz), j = e % (2 * nz);
+          sM[i * MS + j] = has_qc ? sc[sWq] * sGq[i] * sGq[j] : 0.0;
         }
         __syncthreads();
         TICK(2);
@@ -561,9 +563,18 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 
         TICK(3);
         // ---- wave 0: Cholesky in registers (lane i = row i); L and 1/diag go back to LDS ----------
+        // without the ball constraint the (x,y) block and the z block are independent: two waves
+        const int n0 = has_qc ? n : 2 * nz;                       // wave 0's block
+        const unsigned zoff_m = lds0 + (oM + 2 * nz * MS + 2 * nz) * 8, zoff_d = lds0 + (oInvD + 2 * nz) * 8;
         if (tid < 64) {
-          const bool chol_ok = chol_wave(lds0 + oM * 8, lds0 + oInvD * 8, n);
+          const bool chol_ok = chol_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0);
           if (tid == 0) sI[19] = chol_ok ? 1 : 0;
+        } else if (tid < 128) {
+          bool chol_ok = true;
+          if (!has_qc) chol_ok = chol_wave(zoff_m, zoff_d, nz);
+          if (tid == 64) sI[20] = chol_ok ? 1 : 0;
+        }
+        if (tid < 128) {
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
           __builtin_amdgcn_wave_barrier();
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -572,12 +583,17 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         // ---- predictor ------------------------------------------------------------------------
         if (tid < 64) {
           double b = 0;
-          if (tid < n) { b = -sRd[tid] + sRhs[tid]; if (has_qc) b += sGq[tid] * (sc[sLq] - sc[sWq] * sc[sRpq]); }   // rcq/sq = lq for the affine step
-          b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n, b);
-          if (tid < n) sDxa[tid] = b;
+          if (tid < n0) { b = -sRd[tid] + sRhs[tid]; if (has_qc) b += sGq[tid] * (sc[sLq] - sc[sWq] * sc[sRpq]); }   // rcq/sq = lq for the affine step
+          b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0, b);
+          if (tid < n0) sDxa[tid] = b;
+        } else if (tid < 128 && !has_qc) {
+          const int l1 = tid - 64;
+          double b = l1 < nz ? -sRd[2 * nz + l1] + sRhs[2 * nz + l1] : 0.0;
+          b = solve_wave(zoff_m, zoff_d, nz, b);
+          if (l1 < nz) sDxa[2 * nz + l1] = b;
         }
         __syncthreads();
-        if (!sI[19]) break;
+        if (!sI[19] || !sI[20]) break;
         if (tid < 3 * R) { double v = 0; for (int c = 0; c < nz; c++) v += sB[brho * kNZ + c] * sDxa[bax * nz + c]; sUa[brho * 3 + bax] = v; }
         __syncthreads();
         TICK(5);
@@ -644,12 +660,17 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         TICK(7);
         if (tid < 64) {
           double b = 0;
-          if (tid < n) {
+          if (tid < n0) {
             b = -sRd[tid] + sRhs[tid];
             if (has_qc) { const double sq = sc[sSq], lq = sc[sLq]; const double rcq = sq * lq - sm + sc[sDsqA] * sc[sDlqA]; b += sGq[tid] * (rcq / sq - sc[sWq] * sc[sRpq]); }
           }
-          b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n, b);
-          if (tid < n) sDx[tid] = b;
+          b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0, b);
+          if (tid < n0) sDx[tid] = b;
+        } else if (tid < 128 && !has_qc) {
+          const int l1 = tid - 64;
+          double b = l1 < nz ? -sRd[2 * nz + l1] + sRhs[2 * nz + l1] : 0.0;
+          b = solve_wave(zoff_m, zoff_d, nz, b);
+          if (l1 < nz) sDx[2 * nz + l1] = b;
         }
         __syncthreads();
         if (tid < 3 * R) { double v = 0; for (int c = 0; c < nz; c++) v += sB[brho * kNZ + c] * sDx[bax * nz + c]; sUd[brho * 3 + bax] = v; }
