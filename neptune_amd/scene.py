@@ -200,7 +200,8 @@ def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_j
     guesses = np.zeros(N, dtype=abi.GUESS_DTYPE)
     committed = np.zeros(N, dtype=abi.TRAJ_REC_DTYPE)
     goals = np.zeros((N, 3))
-    prev_boxes = []  # per accepted agent: (lo[K+1][2], hi[K+1][2]) of inflated interval AABBs
+    prev_lo = np.zeros((N, K, 2)); prev_hi = np.zeros((N, K, 2)); prev_n = 0   # windowed control-point boxes of accepted agents
+    st_lo_a = np.array(st_lo).reshape(-1, 2); st_hi_a = np.array(st_hi).reshape(-1, 2)
     close_range = 4.0
     for i in range(N):
         accepted = None
@@ -225,39 +226,32 @@ def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_j
             if lo[:, 0].min() < p.x_min + 0.2 or hi[:, 0].max() > p.x_max - 0.2 or \
                lo[:, 1].min() < p.y_min + 0.2 or hi[:, 1].max() > p.y_max - 0.2:
                 continue
-            ok = True
-            for k in range(K):
-                for s_lo, s_hi in zip(st_lo, st_hi):
-                    if not _aabb_sep(lo[k], hi[k], s_lo - 0.05, s_hi + 0.05):
-                        ok = False
-                        break
-                if not ok:
-                    break
-            if not ok:
-                continue
-            # other agents: interval k of agent j covers its segments k-1..k+1 (neptune.cpp:379-389)
-            for (plo, phi) in prev_boxes:
-                for k in range(K):
-                    k0, k1 = max(k - 1, 0), min(k + 1, K - 1)
-                    olo = plo[k0:k1 + 1].min(0) - infl - 0.05; ohi = phi[k0:k1 + 1].max(0) + infl + 0.05
-                    mlo = lo[k0:k1 + 1].min(0); mhi = hi[k0:k1 + 1].max(0)
-                    if not _aabb_sep(mlo, mhi, olo, ohi):
-                        ok = False
-                        break
-                if not ok:
-                    break
-            if ok:
-                accepted = (g, co, lo, hi)
-                break
+            # windowed boxes of this guess: interval k of a trajectory covers its segments k-1..k+1
+            # (neptune.cpp:379-389), for it as an obstacle and for the conservative test below
+            wlo = np.stack([lo[max(k - 1, 0):min(k + 1, K - 1) + 1].min(0) for k in range(K)])
+            whi = np.stack([hi[max(k - 1, 0):min(k + 1, K - 1) + 1].max(0) for k in range(K)])
+            if len(st_lo_a):   # static obstacles: [S][2] boxes against every segment's box
+                sep = ((hi[:, None, 0] < st_lo_a[None, :, 0] - 0.05) | (st_hi_a[None, :, 0] + 0.05 < lo[:, None, 0]) |
+                       (hi[:, None, 1] < st_lo_a[None, :, 1] - 0.05) | (st_hi_a[None, :, 1] + 0.05 < lo[:, None, 1]))
+                if not sep.all():
+                    continue
+            if prev_n:         # previously accepted agents: [n][K][2] inflated windowed boxes
+                plo = prev_lo[:prev_n] - infl - 0.05; phi = prev_hi[:prev_n] + infl + 0.05
+                sep = ((whi[None, :, 0] < plo[:, :, 0]) | (phi[:, :, 0] < wlo[None, :, 0]) |
+                       (whi[None, :, 1] < plo[:, :, 1]) | (phi[:, :, 1] < wlo[None, :, 1]))
+                if not sep.all():
+                    continue
+            accepted = (g, co, lo, hi, wlo, whi)
+            break
         if accepted is None:  # hover in place
             g = np.array([starts[i][0], starts[i][1], p.goal_height])
             co = np.zeros((3, K, 4)); co[:, :, 3] = g[:, None]
             cx = pos_ctrl_pts(co[0], T); cy = pos_ctrl_pts(co[1], T)
             lo = np.stack([cx.min(1), cy.min(1)], 1); hi = np.stack([cx.max(1), cy.max(1)], 1)
-            accepted = (g, co, lo, hi)
-        g, co, lo, hi = accepted
+            accepted = (g, co, lo, hi, lo, hi)
+        g, co, lo, hi, wlo, whi = accepted
         goals[i] = g
-        prev_boxes.append((lo, hi))
+        prev_lo[prev_n] = wlo; prev_hi[prev_n] = whi; prev_n += 1
         t_start = float(rng.uniform(0, t_jitter)) if t_jitter > 0 else 0.0
         guesses[i]["K"] = K
         guesses[i]["t_start"] = t_start

@@ -335,3 +335,38 @@ def test_cpp_host_class_reference_call_sequence(be, oracle):
             assert float(obj) == -12345.0           # objective_value untouched (solver_gurobi_poly.cpp:856-859)
         else:
             assert abs(float(obj) - r["objective"]) <= COST_RTOL * (1 + abs(r["objective"]))
+
+
+def test_config5_size_256_agents_entangle_spill_path(be, oracle):
+    """BASELINE config 5 size on one GPU: 256 agents + 100 obstacles, entangle check on.  The ~2000
+    lines per agent exceed the LDS carve, so this exercises the global-spill placement of the QP
+    rows; a few agents are compared with the oracle, all of them through size-independent checks."""
+    import dataclasses
+    sc = scene.make_scene(256, 100, seed=1)
+    case_id = scene.synthetic_entangle(sc, seed=3, frac=0.1)
+    p = dataclasses.replace(sc["par"], enable_entangle=True)
+    bb = be.BatchBackend(p, sc["statics"])
+    d_ent = bb.torch.from_numpy(case_id.reshape(-1).copy()).to(bb.device)
+    bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]), d_ent=d_ent)
+    sol = bb.solutions()
+    st = sol["stats"]
+    assert (st["n_lines"] > 1500).all() and (st["status"] <= 2).all()
+    assert (st["status"] == 0).sum() >= 240
+    T = p.T_span
+    M4 = scene.A_POS_INV * np.array([T ** 3, T ** 2, T, 1.0])[:, None]
+    for a in (0, 17, 101, 255):
+        r = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"], case_id=case_id[a])
+        K = int(sol[a]["K"])
+        seg, nd = bb.debug_lines(a, cap=20000)
+        np.testing.assert_array_equal(nd, r["line_nd"])
+        assert int(st[a]["status"]) == r["status"] and int(st[a]["n_lp"]) == r["n_lp"]
+        assert np.abs(np.array(sol[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= COEF_TOL
+    for a in range(0, 256, 16):
+        if int(st[a]["status"]) == 2:
+            continue
+        K = int(sol[a]["K"]); co = np.array(sol[a]["coeff"])[:, :K, :]
+        seg, nd = bb.debug_lines(a, cap=20000)
+        cpx = co[0] @ M4; cpy = co[1] @ M4
+        viol = max((l[0] * cpx[s_] + l[1] * cpy[s_] + l[2] - 1).max() for s_, l in zip(seg, nd))
+        assert viol <= 1e-7
+    bb.close()
