@@ -273,9 +273,14 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   // box row state: [0] upper (alpha=+e), [1] lower (alpha=-e)
   double bs0 = 1, bl0 = 0, bs1 = 1, bl1 = 0;
 
+  // phase cycle counters: compiled in only with -DNEP_PROFILE_PHASES (they hold 26 VGPRs otherwise)
+#ifdef NEP_PROFILE_PHASES
   long long tph[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; long long tlast = 0;
   const bool prof = ps.dbg != nullptr;
 #define TICK(k) do { if (prof) { const long long t_ = clock64(); tph[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define TICK(k) do { } while (0)
+#endif
   int status = NEP_FAILED, iters_total = 0, iters_first = 0;
   double objective = 0.0;
 
@@ -428,7 +433,9 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       // Row direction from the arrays of the previous solve (used by the merged update):
       //   ds = -rp - gd ; dl = -rc/s + w (rp + gd), rc = s lam - sigma mu + dsa dla
       for (it = 0; it < kMaxIt; it++) {
+#ifdef NEP_PROFILE_PHASES
         if (prof) tlast = clock64();
+#endif
         // ---- (A) apply the previous step, then residuals / weights / scatter onto base rows ----
         const double alpha_prev = sc[sAlpha], sm_prev = sc[sSigMu];
         double bTl = 0, bD = 0, bT1 = 0;
@@ -757,7 +764,9 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       }
     }
   }
+#ifdef NEP_PROFILE_PHASES
   if (prof && tid == 0) { for (int k = 0; k < 12; k++) ps.dbg[(long)slot * 16 + k] = tph[k]; ps.dbg[(long)slot * 16 + 12] = iters_total; }
+#endif
   if (ps.commit) {  // the record the agent would publish (neptune_ros.cpp:434-480)
     nep_traj_rec* cr = ps.commit + slot;
     const int own = sp.first_local + (slot % sp.n_local);
