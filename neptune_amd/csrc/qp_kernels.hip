@@ -31,16 +31,14 @@
 namespace nep {
 
 constexpr int BS = 256;
+constexpr int SBS = 9;            // LDS row stride of the base-row table B (8 used; odd -> lanes on consecutive rows hit distinct banks)
 constexpr int MS = 25;            // LDS row stride of the normal matrix (n <= 24; odd -> no bank conflicts)
 constexpr int kMaxIt = 60;
 
 // ---- LDS carve (in doubles) -------------------------------------------------------------------
 constexpr int oB = 0;                       // [64][8]
-constexpr int oOff = oB + kMaxR * kNZ;      // [64][3]
-constexpr int oCp = oOff + kMaxR * 3;       // [64][3] base-row values at z
-constexpr int oUa = oCp + kMaxR * 3;        // [64][3] B dx_aff
-constexpr int oUd = oUa + kMaxR * 3;        // [64][3] B dx
-constexpr int oAccL = oUd + kMaxR * 3;      // [32][8] line accumulators per control point
+constexpr int oOff = oB + kMaxR * SBS;      // [64][3]
+constexpr int oAccL = oOff + kMaxR * 3;     // [32][8] line accumulators per control point
 constexpr int oDc = oAccL + 32 * 8;         // [64][4] combined weights Dxx,Dxy,Dyy,Dzz
 constexpr int oTc = oDc + kMaxR * 4;        // [64][6] combined T_lambda[3], T1[3]
 constexpr int oM = oTc + kMaxR * 6;         // [24][25]
@@ -59,8 +57,8 @@ constexpr int oCoef = oEp + 8;              // [3][8][4] initial guess
 constexpr int oTheta = oCoef + 96;          // [3][8][4] result
 constexpr int oInit = oTheta + 96;          // [3][3] b0,c0,d0 per axis
 constexpr int oScal = oInit + 9;            // scalars, see enum
-constexpr int oRed = oScal + 32;            // [16] reduction scratch
-constexpr int oFixedEnd = oRed + 16;
+constexpr int oRed = oScal + 32;            // [3][16] reduction scratch (one slot per reduction of an iteration)
+constexpr int oFixedEnd = oRed + 48;
 constexpr int kFixedDoubles = (oFixedEnd + 1) & ~1;
 
 enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu };
@@ -112,6 +110,19 @@ __device__ __forceinline__ double frsqrt(double a) {
   double e = __builtin_fma(-h * y, y, 0.5); y = __builtin_fma(y, e, y);
   e = __builtin_fma(-h * y, y, 0.5); y = __builtin_fma(y, e, y);
   return y;
+}
+
+// Workgroup reductions of one max and up to three sums in two halves, so that the barrier between
+// them can be shared with other hand-offs: reduce_put before the barrier, reduce_get after it.
+__device__ __forceinline__ void reduce_put(double mx, double s0, double s1, double s2, double* red) {
+  mx = wave_max(mx); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { double* o = red + 4 * (threadIdx.x >> 6); o[0] = mx; o[1] = s0; o[2] = s1; o[3] = s2; }
+}
+__device__ __forceinline__ void reduce_get(double& mx, double& s0, double& s1, double& s2, const double* red) {
+  mx = fmax(fmax(red[0], red[4]), fmax(red[8], red[12]));
+  s0 = (red[1] + red[5]) + (red[9] + red[13]);
+  s1 = (red[2] + red[6]) + (red[10] + red[14]);
+  s2 = (red[3] + red[7]) + (red[11] + red[15]);
 }
 
 // One max and up to three sums across the workgroup in one round trip.  red: LDS [16].
@@ -210,8 +221,7 @@ __device__ __noinline__ double solve_wave(unsigned m_off, unsigned d_off, int n,
 
 __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* sB = smem + oB; double* sOff = smem + oOff; double* sCp = smem + oCp;
-  double* sUa = smem + oUa; double* sUd = smem + oUd; double* sAccL = smem + oAccL;
+  double* sB = smem + oB; double* sOff = smem + oOff; double* sAccL = smem + oAccL;
   double* sDc = smem + oDc; double* sTc = smem + oTc;
   double* sM = smem + oM; double* sHax = smem + oHax;
   double* sZ = smem + oZ; double* sG = smem + oG; double* sRd = smem + oRd; double* sRhs = smem + oRhs;
@@ -319,7 +329,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     const QpTable* __restrict__ tb = tables + mode * (kMaxK + 1) + K;
     const int nz = tb->nz, n = 3 * nz;
     __syncthreads();
-    for (int e = tid; e < kMaxR * kNZ; e += BS) sB[e] = (&tb->B[0][0])[e];
+    for (int e = tid; e < kMaxR * kNZ; e += BS) sB[(e / kNZ) * SBS + (e % kNZ)] = (&tb->B[0][0])[e];
     if (tid < 64) sHax[tid] = (&tb->Hax[0][0])[tid];
     if (tid < 8) sEp[tid] = tb->ep[tid];
     if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
@@ -399,18 +409,20 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         sc[sObj0] = o;
         sI[16] = 0;  // loose snapshot present
         sI[17] = 0;  // stall counter
-        sc[sAlpha] = 0.0; sc[sSigMu] = 0.0;
       }
       __syncthreads();
-      if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; double v = sOff[rho * 3 + ax]; for (int c = 0; c < nz; c++) v += sB[rho * kNZ + c] * sZ[ax * nz + c]; sCp[rho * 3 + ax] = v; sUa[rho * 3 + ax] = 0.0; sUd[rho * 3 + ax] = 0.0; }
-      __syncthreads();
+      // each thread keeps the values of its own base rows (and their step projections) in registers
+      auto proj = [&](int rho, int ax, const double* vec) { double v = 0; for (int c = 0; c < nz; c++) v = __builtin_fma(sB[rho * SBS + c], vec[ax * nz + c], v); return v; };
+      double cpb = has_box ? sOff[brho * 3 + bax] + proj(brho, bax, sZ) : 0.0, uab = 0.0, udb = 0.0;
+      double cpx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sZ) : 0.0, cpy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sZ) : 0.0;
+      double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
       if (has_box) {
-        const double a = sCp[brho * 3 + bax];
+        const double a = cpb;
         double sl = bhi - a; bs0 = sl > 0.1 ? sl : 0.1; bl0 = 1.0 / bs0;
         sl = a - blo; bs1 = sl > 0.1 ? sl : 0.1; bl1 = 1.0 / bs1;
       }
       {
-        const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1];
+        const double cx = cpx, cy = cpy;
         for_lines4([&](bool, int l, double n1, double n2, double h, double, double) {
           const double sl = h - (n1 * cx + n2 * cy);
           const double s = sl > 0.1 ? sl : 0.1;
@@ -430,14 +442,17 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       }
       __syncthreads();
 
-      // Row direction from the arrays of the previous solve (used by the merged update):
-      //   ds = -rp - gd ; dl = -rc/s + w (rp + gd), rc = s lam - sigma mu + dsa dla
+      // Eight workgroup barriers per iteration.  Row direction of the previous solve, recomputed by the
+      // merged update:  ds = -rp - gd ; dl = -rc/s + w (rp + gd), rc = s lam - sigma mu + dsa dla.
+      double alpha_prev = 0.0, sm_prev = 0.0;
+      double* redA = sRed; double* redP2 = sRed + 16; double* redP5 = sRed + 32;
+      const int n0 = has_qc ? n : 2 * nz;                       // wave 0 factors this block, wave 1 the z block
+      const unsigned zoff_m = lds0 + (oM + 2 * nz * MS + 2 * nz) * 8, zoff_d = lds0 + (oInvD + 2 * nz) * 8;
       for (it = 0; it < kMaxIt; it++) {
 #ifdef NEP_PROFILE_PHASES
         if (prof) tlast = clock64();
 #endif
         // ---- (A) apply the previous step, then residuals / weights / scatter onto base rows ----
-        const double alpha_prev = sc[sAlpha], sm_prev = sc[sSigMu];
         double bTl = 0, bD = 0, bT1 = 0;
         double lTx = 0, lTy = 0, lDxx = 0, lDxy = 0, lDyy = 0, l1x = 0, l1y = 0;
         double nrp = 0, sumsl = 0, dummy1 = 0, dummy2 = 0;
@@ -450,32 +465,29 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           a_new_out = __builtin_fma(alpha_prev, gd, a_old);
         };
         if (has_box) {
-          const double a_old = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax], gd = sUd[brho * 3 + bax];
           double an;
-          rowA(bs0, bl0, a_old, ga, gd, bhi, an);
+          rowA(bs0, bl0, cpb, uab, udb, bhi, an);
           { const double rp = an + bs0 - bhi, w = bl0 * frcp(bs0), v = bl0 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs0 * bl0; bTl += bl0; bD += w; bT1 += v; }
-          rowA(bs1, bl1, -a_old, -ga, -gd, -blo, an);
+          rowA(bs1, bl1, -cpb, -uab, -udb, -blo, an);
           { const double rp = an + bs1 + blo, w = bl1 * frcp(bs1), v = bl1 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs1 * bl1; bTl -= bl1; bD += w; bT1 -= v; }
         }
-        {
-          const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1], uax = sUa[lrho * 3], uay = sUa[lrho * 3 + 1], udx = sUd[lrho * 3], udy = sUd[lrho * 3 + 1];
-          for_lines4([&](bool ok, int l, double n1, double n2, double h, double s, double lam) {
-            double an;
-            rowA(s, lam, n1 * cx + n2 * cy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, an);
-            STw(l, lk, 0, ok ? s : 1.0); STw(l, lk, 1, ok ? lam : 1.0);   // the dummy line of a padded tail stays (1,1)
-            const double rp = an + s - h, w = lam * frcp(s), v = lam - w * rp;
-            nrp = fmax(nrp, ok ? fabs(rp) : 0.0); sumsl += ok ? s * lam : 0.0;
-            const double lm = ok ? lam : 0.0, wm = ok ? w : 0.0, vm = ok ? v : 0.0;
-            lTx += lm * n1; lTy += lm * n2; lDxx += wm * n1 * n1; lDxy += wm * n1 * n2; lDyy += wm * n2 * n2; l1x += vm * n1; l1y += vm * n2;
-          });
-        }
+        for_lines4([&](bool ok, int l, double n1, double n2, double h, double s, double lam) {
+          double an;
+          rowA(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, an);
+          STw(l, lk, 0, ok ? s : 1.0); STw(l, lk, 1, ok ? lam : 1.0);   // the dummy line of a padded tail stays (1,1)
+          const double rp = an + s - h, w = lam * frcp(s), v = lam - w * rp;
+          nrp = fmax(nrp, ok ? fabs(rp) : 0.0); sumsl += ok ? s * lam : 0.0;
+          const double lm = ok ? lam : 0.0, wm = ok ? w : 0.0, vm = ok ? v : 0.0;
+          lTx += lm * n1; lTy += lm * n2; lDxx += wm * n1 * n1; lDxy += wm * n1 * n2; lDyy += wm * n2 * n2; l1x += vm * n1; l1y += vm * n2;
+        });
+        cpb = __builtin_fma(alpha_prev, udb, cpb); cpx = __builtin_fma(alpha_prev, udx, cpx); cpy = __builtin_fma(alpha_prev, udy, cpy);   // base rows move with the step
         lTx = slice_sum(lTx); lTy = slice_sum(lTy); lDxx = slice_sum(lDxx); lDxy = slice_sum(lDxy); lDyy = slice_sum(lDyy); l1x = slice_sum(l1x); l1y = slice_sum(l1y);
         if (slice == 0) { double* o = sAccL + pair * 8; o[0] = lTx; o[1] = lTy; o[2] = lDxx; o[3] = lDxy; o[4] = lDyy; o[5] = l1x; o[6] = l1y; }
         if (has_box) { sTc[brho * 6 + bax] = bTl; sTc[brho * 6 + 3 + bax] = bT1; sDc[brho * 4 + (bax == 0 ? 0 : (bax == 1 ? 2 : 3))] = bD; }
-        block_reduce4(nrp, sumsl, dummy1, dummy2, sRed);   // (its barriers also publish sAccL / sDc / sTc)
+        reduce_put(nrp, sumsl, dummy1, dummy2, redA);
+        __syncthreads();                                                                       // barrier 1
+        reduce_get(nrp, sumsl, dummy1, dummy2, redA);
         TICK(0);
-        // ---- base-row values move with the step; combine box + line accumulators ----------------
-        if (tid < 3 * R) sCp[brho * 3 + bax] = __builtin_fma(alpha_prev, sUd[brho * 3 + bax], sCp[brho * 3 + bax]);
         if (tid < R) {   // add the line sums onto the position rows (box threads wrote their part above)
           const int rho = tid; const double* al = sAccL + rho * 8;
           if (rho < 4 * K) {
@@ -504,13 +516,13 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           sc[sMu] = sc[sSumSl] / mt;
           sc[sNrp] = fmax(nrp, fabs(rpq));
         }
-        __syncthreads();
+        __syncthreads();                                                                       // barrier 2
         TICK(1);
         // ---- dual residual + predictor rhs (8 partial sums per output), normal matrix -------------
         if (tid < 8 * n) {
           const int o = tid >> 3, sl8 = tid & 7, ax = o / nz, c = o % nz;
           double v = 0, t1 = 0;
-          for (int rho = sl8; rho < R; rho += 8) { const double b = sB[rho * kNZ + c]; v += b * sTc[rho * 6 + ax]; t1 += b * sTc[rho * 6 + 3 + ax]; }
+          for (int rho = sl8; rho < R; rho += 8) { const double b = sB[rho * SBS + c]; v += b * sTc[rho * 6 + ax]; t1 += b * sTc[rho * 6 + 3 + ax]; }
           v = slice_sum(v); t1 = slice_sum(t1);
           if (sl8 == 0) {
             double hz = 0;
@@ -529,8 +541,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           if (me_on[u]) {
             const int rl = sel == 1 ? 4 * K : R;       // multiples of 4
             for (int rho = half; rho < rl; rho += 4) {
-              a0 = __builtin_fma(sDc[rho * 4 + sel] * sB[rho * kNZ + ci], sB[rho * kNZ + cj], a0);
-              a1 = __builtin_fma(sDc[(rho + 2) * 4 + sel] * sB[(rho + 2) * kNZ + ci], sB[(rho + 2) * kNZ + cj], a1);
+              a0 = __builtin_fma(sDc[rho * 4 + sel] * sB[rho * SBS + ci], sB[rho * SBS + cj], a0);
+              a1 = __builtin_fma(sDc[(rho + 2) * 4 + sel] * sB[(rho + 2) * SBS + ci], sB[(rho + 2) * SBS + cj], a1);
             }
           }
           double v = a0 + a1;
@@ -545,64 +557,50 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           const int i = 2 * nz + e / (2 * nz), j = e % (2 * nz);
           sM[i * MS + j] = has_qc ? sc[sWq] * sGq[i] * sGq[j] : 0.0;
         }
-        __syncthreads();
+        __syncthreads();                                                                       // barrier 3
         TICK(2);
-        // ---- convergence test (wave 0) ----------------------------------------------------------
+        // ---- wave 0: convergence test, Cholesky of its block, predictor; wave 1: the z block -------
         if (tid < 64) {
           const double nrd = wave_max(tid < n ? fabs(sRd[tid]) : 0.0);
           const double o = sc[sObj0] + wave_sum(tid < n ? sDxa[tid] : 0.0);
-          if (tid == 0) {
-            sc[sObj] = o;
-            const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
-            int flag = 0;
-            if (nr <= 1e-9 && nrd <= 1e-9 * qs && gap <= 1e-10 * (1.0 + fabs(o))) flag = 1;
-            else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) { flag = 2; sc[sObjLoose] = o; }
-            if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
-            if (sI[17] >= 3) flag = 3;                           // stalled
-            sI[18] = flag;
+          const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
+          int flag = 0;
+          if (nr <= 1e-9 && nrd <= 1e-9 * qs && gap <= 1e-10 * (1.0 + fabs(o))) flag = 1;
+          else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
+          if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
+          if (sI[17] >= 3) flag = 3;                           // stalled
+          if (tid == 0) { sc[sObj] = o; if (flag == 2) sc[sObjLoose] = o; sI[18] = flag; }
+          TICK(3);
+          if (flag != 1 && flag != 3) {                        // (uniform across the wave)
+            const bool chol_ok = chol_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0);
+            if (tid == 0) sI[19] = chol_ok ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            TICK(4);
+            double b = 0;
+            if (tid < n0) { b = -sRd[tid] + sRhs[tid]; if (has_qc) b += sGq[tid] * (sc[sLq] - sc[sWq] * sc[sRpq]); }   // rcq/sq = lq for the affine step
+            b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0, b);
+            if (tid < n0) sDxa[tid] = b;
           }
+        } else if (tid < 128) {
+          bool chol_ok = true;
+          if (!has_qc) {                                        // (runs also in the converging iteration: harmless)
+            chol_ok = chol_wave(zoff_m, zoff_d, nz);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int l1 = tid - 64;
+            double b = l1 < nz ? -sRd[2 * nz + l1] + sRhs[2 * nz + l1] : 0.0;
+            b = solve_wave(zoff_m, zoff_d, nz, b);
+            if (l1 < nz) sDxa[2 * nz + l1] = b;
+          }
+          if (tid == 64) sI[20] = chol_ok ? 1 : 0;
         }
-        __syncthreads();
+        __syncthreads();                                                                       // barrier 4
         const int flag = sI[18];
         if (flag == 1) { converged = true; break; }
         if (flag == 3) break;
-        if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
-
-        TICK(3);
-        // ---- wave 0: Cholesky in registers (lane i = row i); L and 1/diag go back to LDS ----------
-        // without the ball constraint the (x,y) block and the z block are independent: two waves
-        const int n0 = has_qc ? n : 2 * nz;                       // wave 0's block
-        const unsigned zoff_m = lds0 + (oM + 2 * nz * MS + 2 * nz) * 8, zoff_d = lds0 + (oInvD + 2 * nz) * 8;
-        if (tid < 64) {
-          const bool chol_ok = chol_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0);
-          if (tid == 0) sI[19] = chol_ok ? 1 : 0;
-        } else if (tid < 128) {
-          bool chol_ok = true;
-          if (!has_qc) chol_ok = chol_wave(zoff_m, zoff_d, nz);
-          if (tid == 64) sI[20] = chol_ok ? 1 : 0;
-        }
-        if (tid < 128) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-          __builtin_amdgcn_wave_barrier();
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        TICK(4);
-        // ---- predictor ------------------------------------------------------------------------
-        if (tid < 64) {
-          double b = 0;
-          if (tid < n0) { b = -sRd[tid] + sRhs[tid]; if (has_qc) b += sGq[tid] * (sc[sLq] - sc[sWq] * sc[sRpq]); }   // rcq/sq = lq for the affine step
-          b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0, b);
-          if (tid < n0) sDxa[tid] = b;
-        } else if (tid < 128 && !has_qc) {
-          const int l1 = tid - 64;
-          double b = l1 < nz ? -sRd[2 * nz + l1] + sRhs[2 * nz + l1] : 0.0;
-          b = solve_wave(zoff_m, zoff_d, nz, b);
-          if (l1 < nz) sDxa[2 * nz + l1] = b;
-        }
-        __syncthreads();
         if (!sI[19] || !sI[20]) break;
-        if (tid < 3 * R) { double v = 0; for (int c = 0; c < nz; c++) v += sB[brho * kNZ + c] * sDxa[bax * nz + c]; sUa[brho * 3 + bax] = v; }
-        __syncthreads();
+        if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
+        if (has_box) uab = proj(brho, bax, sDxa);
+        if (has_line) { uax = proj(lrho, 0, sDxa); uay = proj(lrho, 1, sDxa); }
         TICK(5);
         // ---- (P2) affine step: ratio test + the two sums that give mu_aff for any alpha ----------
         double rmax = 0, c1 = 0, c2 = 0, dmy = 0;
@@ -613,11 +611,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           rmax = fmax(rmax, ok ? fmax(-ds * is, __builtin_fma(-(rp + ga), is, 1.0)) : 0.0);
           c1 += ok ? s * dl + lam * ds : 0.0; c2 += ok ? ds * dl : 0.0;
         };
-        if (has_box) { const double a = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax]; rowP2(true, bs0, bl0, a, ga, bhi); rowP2(true, bs1, bl1, -a, -ga, -blo); }
-        if (has_line) {
-          const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1], uax = sUa[lrho * 3], uay = sUa[lrho * 3 + 1];
-          for_lines4([&](bool ok, int, double n1, double n2, double h, double s, double lam) { rowP2(ok, s, lam, n1 * cx + n2 * cy, n1 * uax + n2 * uay, h); });
-        }
+        if (has_box) { rowP2(true, bs0, bl0, cpb, uab, bhi); rowP2(true, bs1, bl1, -cpb, -uab, -blo); }
+        for_lines4([&](bool ok, int, double n1, double n2, double h, double s, double lam) { rowP2(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, h); });
         if (tid == BS - 1 && has_qc) {
           const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
           double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
@@ -626,18 +621,19 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
           c1 += sq * dlq + lq * dsq; c2 += dsq * dlq;
         }
-        block_reduce4(rmax, c1, c2, dmy, sRed);
+        reduce_put(rmax, c1, c2, dmy, redP2);
+        __syncthreads();                                                                       // barrier 5
+        reduce_get(rmax, c1, c2, dmy, redP2);
+        double sm;
         {
           const double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
           const double mu = sc[sMu];
           const double mua = (sc[sSumSl] + aaff * c1 + aaff * aaff * c2) / mt;
           const double rr = mua / mu;
-          if (tid == 0) { sc[sSigma] = rr * rr * rr; sc[sSigMu] = rr * rr * rr * mu; }
+          sm = rr * rr * rr * mu;                              // sigma * mu, identical in every thread
         }
-        __syncthreads();
         TICK(6);
         // ---- (P4) corrector right-hand side ---------------------------------------------------
-        const double sm = sc[sSigMu];
         {
           double b1 = 0, c1x = 0, c1y = 0;
           auto rowP4 = [&](double s, double lam, double a, double ga, double h) -> double {
@@ -646,42 +642,38 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
             const double rcv = s * lam - sm + dsa * dla;
             return rcv * is - w * rp;
           };
-          if (has_box) { const double a = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax]; b1 = rowP4(bs0, bl0, a, ga, bhi) - rowP4(bs1, bl1, -a, -ga, -blo); }
-          if (has_line) {
-            const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1], uax = sUa[lrho * 3], uay = sUa[lrho * 3 + 1];
-            for_lines4([&](bool, int, double n1, double n2, double h, double s, double lam) { const double v = rowP4(s, lam, n1 * cx + n2 * cy, n1 * uax + n2 * uay, h); c1x += v * n1; c1y += v * n2; });
-          }
+          if (has_box) b1 = rowP4(bs0, bl0, cpb, uab, bhi) - rowP4(bs1, bl1, -cpb, -uab, -blo);
+          for_lines4([&](bool, int, double n1, double n2, double h, double s, double lam) { const double v = rowP4(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, h); c1x += v * n1; c1y += v * n2; });
           c1x = slice_sum(c1x); c1y = slice_sum(c1y);
           if (slice == 0) { sAccL[pair * 8 + 5] = c1x; sAccL[pair * 8 + 6] = c1y; }
           if (has_box) sTc[brho * 6 + 3 + bax] = b1;
         }
-        __syncthreads();
+        __syncthreads();                                                                       // barrier 6
+        TICK(7);
+        // ---- corrector right-hand side (8 partial sums per entry), then the substitutions -----------
         if (tid < 8 * n) {
           const int o = tid >> 3, sl8 = tid & 7, ax = o / nz, c = o % nz;
           double t1 = 0;
-          for (int rho = sl8; rho < R; rho += 8) { double tt = sTc[rho * 6 + 3 + ax]; if (ax < 2 && rho < 4 * K) tt += sAccL[rho * 8 + 5 + ax]; t1 += sB[rho * kNZ + c] * tt; }
+          for (int rho = sl8; rho < R; rho += 8) { double tt = sTc[rho * 6 + 3 + ax]; if (ax < 2 && rho < 4 * K) tt += sAccL[rho * 8 + 5 + ax]; t1 += sB[rho * SBS + c] * tt; }
           t1 = slice_sum(t1);
           if (sl8 == 0) sRhs[o] = t1;
         }
-        __syncthreads();
-        TICK(7);
-        if (tid < 64) {
+        __syncthreads();                                                                       // barrier 6b
+        if (tid < 128) {
+          const bool w0 = tid < 64;
+          const int o = w0 ? tid : 2 * nz + (tid - 64);
+          const bool mine = w0 ? tid < n0 : (!has_qc && tid - 64 < nz);
           double b = 0;
-          if (tid < n0) {
-            b = -sRd[tid] + sRhs[tid];
-            if (has_qc) { const double sq = sc[sSq], lq = sc[sLq]; const double rcq = sq * lq - sm + sc[sDsqA] * sc[sDlqA]; b += sGq[tid] * (rcq / sq - sc[sWq] * sc[sRpq]); }
+          if (mine) {
+            b = -sRd[o] + sRhs[o];
+            if (has_qc) { const double sq = sc[sSq], lq = sc[sLq]; const double rcq = sq * lq - sm + sc[sDsqA] * sc[sDlqA]; b += sGq[o] * (rcq / sq - sc[sWq] * sc[sRpq]); }
           }
-          b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0, b);
-          if (tid < n0) sDx[tid] = b;
-        } else if (tid < 128 && !has_qc) {
-          const int l1 = tid - 64;
-          double b = l1 < nz ? -sRd[2 * nz + l1] + sRhs[2 * nz + l1] : 0.0;
-          b = solve_wave(zoff_m, zoff_d, nz, b);
-          if (l1 < nz) sDx[2 * nz + l1] = b;
+          if (w0) { b = solve_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0, b); if (mine) sDx[o] = b; }
+          else if (!has_qc) { b = solve_wave(zoff_m, zoff_d, nz, b); if (mine) sDx[o] = b; }
         }
-        __syncthreads();
-        if (tid < 3 * R) { double v = 0; for (int c = 0; c < nz; c++) v += sB[brho * kNZ + c] * sDx[bax * nz + c]; sUd[brho * 3 + bax] = v; }
-        __syncthreads();
+        __syncthreads();                                                                       // barrier 7
+        if (has_box) udb = proj(brho, bax, sDx);
+        if (has_line) { udx = proj(lrho, 0, sDx); udy = proj(lrho, 1, sDx); }
         TICK(8);
         // ---- (P5) step length of the combined direction ------------------------------------------
         rmax = 0; c1 = 0; c2 = 0; dmy = 0;
@@ -692,11 +684,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           const double ds = -rp - gd, dl = -rcv * is + w * (rp + gd);
           rmax = fmax(rmax, ok ? fmax(-ds * is, -dl * frcp(lam)) : 0.0);
         };
-        if (has_box) { const double a = sCp[brho * 3 + bax], ga = sUa[brho * 3 + bax], gd = sUd[brho * 3 + bax]; rowP5(true, bs0, bl0, a, ga, gd, bhi); rowP5(true, bs1, bl1, -a, -ga, -gd, -blo); }
-        if (has_line) {
-          const double cx = sCp[lrho * 3], cy = sCp[lrho * 3 + 1], uax = sUa[lrho * 3], uay = sUa[lrho * 3 + 1], udx = sUd[lrho * 3], udy = sUd[lrho * 3 + 1];
-          for_lines4([&](bool ok, int, double n1, double n2, double h, double s, double lam) { rowP5(ok, s, lam, n1 * cx + n2 * cy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h); });
-        }
+        if (has_box) { rowP5(true, bs0, bl0, cpb, uab, udb, bhi); rowP5(true, bs1, bl1, -cpb, -uab, -udb, -blo); }
+        for_lines4([&](bool ok, int, double n1, double n2, double h, double s, double lam) { rowP5(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h); });
         if (tid == BS - 1 && has_qc) {
           const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
           double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDx[e];
@@ -705,14 +694,16 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           sc[sDsq] = dsq; sc[sDlq] = dlq;
           rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
         }
-        block_reduce4(rmax, c1, c2, dmy, sRed);
+        reduce_put(rmax, c1, c2, dmy, redP5);
+        __syncthreads();                                                                       // barrier 8
+        reduce_get(rmax, c1, c2, dmy, redP5);
         {
           double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
           alpha = fmin(1.0, 0.995 * alpha);
-          if (tid == 0) { sc[sAlpha] = alpha; if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
+          if (tid == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
           if (tid < n) sZ[tid] += alpha * sDx[tid];
+          alpha_prev = alpha; sm_prev = sm;
         }
-        __syncthreads();
         TICK(9);
       }
       if (!converged && sI[16]) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
