@@ -487,7 +487,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   double* lam = s + (mt + 1), *ds = lam + (mt + 1), *dl = ds + (mt + 1), *rp = dl + (mt + 1), *rc = rp + (mt + 1),
          *w = rc + (mt + 1), *gdx = w + (mt + 1), *dsa = gdx + (mt + 1), *dla = dsa + (mt + 1);
 #define QCY(yv, grad, out) do { double v_ = ccy; for (int a_ = 0; a_ < ny; a_++) { double r_ = 0; for (int b_ = 0; b_ < ny; b_++) r_ += Cy[a_ * ny + b_] * (yv)[b_]; if (grad) (grad)[a_] = 2.0 * (r_ + cqy[a_]); v_ += (yv)[a_] * r_ + 2.0 * cqy[a_] * (yv)[a_]; } out = v_; } while (0)
-  for (int r = 0; r < m; r++) { double a = 0; for (int c = 0; c < ny; c++) a += Gy[(size_t)r * ny + c] * y[c]; double sl = hy[r] - a; s[r] = sl > 0.1 ? sl : 0.1; lam[r] = 1.0 / s[r]; }
+  for (int r = 0; r < m; r++) { double a = 0; for (int c = 0; c < ny; c++) a += Gy[(size_t)r * ny + c] * y[c]; double sl = hy[r] - a; s[r] = sl > 1.0 ? sl : 1.0; lam[r] = 1.0 / s[r]; }
   if (qc) { double c; QCY(y, (double*)NULL, c); s[m] = (-c > 1e-3) ? -c : 1e-3; lam[m] = 1.0 / s[m]; }
   double qscale = 1.0; for (int c = 0; c < ny; c++) if (fabs(qy[c]) > qscale) qscale = fabs(qy[c]);
   int ret = 1, it = 0, loose_ok = 0, stall = 0;

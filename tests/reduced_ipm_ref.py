@@ -129,7 +129,7 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
     Hax = tb["Hax"]
     cp = B @ z.T + off
     a = rowvals(cp)
-    s = np.maximum(h - a, 0.1); lam = 1.0 / s
+    s = np.maximum(h - a, 1.0); lam = 1.0 / s
     sq = lq = 0.0
     if has_qc:
         pend = z @ tb["ep"] + init @ tb["up"]
