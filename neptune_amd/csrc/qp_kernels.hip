@@ -699,7 +699,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         reduce_get(rmax, c1, c2, dmy, redP5);
         {
           double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
-          alpha = fmin(1.0, 0.995 * alpha);
+          alpha = fmin(1.0, 0.999 * alpha);
           if (tid == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
           if (tid < n) sZ[tid] += alpha * sDx[tid];
           alpha_prev = alpha; sm_prev = sm;

@@ -531,7 +531,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
         for (int r = 0; r < mt; r++) { dsa[r] = ds[r]; dla[r] = dl[r]; }
       }
     }
-    alpha *= 0.995; if (alpha > 1.0) alpha = 1.0;
+    alpha *= 0.999; if (alpha > 1.0) alpha = 1.0;
     if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;
     for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];
     for (int r = 0; r < mt; r++) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; }

@@ -212,7 +212,7 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
                 dsa, dla = ds, dl
                 if has_qc:
                     dsqa, dlqa = dsq, dlq
-        alpha = min(1.0, 0.995 * alpha)
+        alpha = min(1.0, 0.999 * alpha)
         if alpha < 1e-8:
             stall += 1
             if stall >= 3:

@@ -109,7 +109,7 @@ def test_reduced_model_matches_oracle(oracle):
         st, th, obj, it = R.optimize(c["K"], p.T_span, p.weight, c["coeff_init"], c["mins"], c["maxs"], p.v_max, p.a_max,
                                      c["line_seg"], c["line_nd"])
         assert st == r["status"], c["tag"]
-        assert np.abs(th - r["coeff"]).max() < 1e-7, c["tag"]
+        assert np.abs(th - r["coeff"]).max() < 1e-6, c["tag"]   # the stated bar (two interior-point paths, same optimum)
 
 
 def test_ordered_polygon_rule_agrees_with_all_pairs(oracle):
