@@ -184,9 +184,11 @@ void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_g
                   const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
   int blocks = n_scenes * n_rec * sp.num_pol;
   if (blocks <= 0) return;
+  // the uninflated hull is read only by the entangle rows (col(0), solver_gurobi_poly.cpp:722-734)
+  const bool need0 = sp.ent_enabled != 0;
   hipLaunchKernelGGL(hull_kernel, dim3(blocks), dim3(64), 0, st, recs, n_rec, guess, sp.n_local,
-                     sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, ps.hull0_xy, ps.hull0_nv,
-                     ps.bend_xy, ps.bend_n);
+                     sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
+                     need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
