@@ -370,3 +370,41 @@ def test_config5_size_256_agents_entangle_spill_path(be, oracle):
         viol = max((l[0] * cpx[s_] + l[1] * cpy[s_] + l[2] - 1).max() for s_, l in zip(seg, nd))
         assert viol <= 1e-7
     bb.close()
+
+
+def test_multi_scene_batch_and_chained_rounds(be, oracle):
+    """Several scenes per launch (slot = scene*n_local + agent) and two chained rounds: round 2
+    replans against the records committed by round 1, exactly as the oracle does on the host."""
+    from neptune_amd import dist as ndist
+    scenes = [scene.make_scene(6, 5, seed=40 + s) for s in range(3)]
+    for sc in scenes[1:]:
+        sc["statics"] = scenes[0]["statics"]          # one static set per handle
+    p = scenes[0]["par"]
+    com, gue = ndist.stack_scenes(scenes)
+    bb = be.BatchBackend(p, scenes[0]["statics"], n_scenes=3)
+    d_com = bb.to_device(com); d_gue = bb.to_device(gue)
+    ex = ndist.RoundExchange(3, 6, 1, 0, device=bb.device)
+    host_com = com.copy()
+    for rnd in range(2):
+        bb.replan(d_com, d_gue)
+        sol = bb.solutions().reshape(3, 6)
+        new_com = host_com.copy()
+        for s_ in range(3):
+            for a in range(6):
+                r = oracle.replan(p, a + 1, host_com[s_], gue[s_, a], scenes[0]["statics"])
+                K = int(sol[s_, a]["K"])
+                co = np.array(sol[s_, a]["coeff"])[:, :K, :]
+                assert int(sol[s_, a]["stats"]["status"]) == r["status"], (rnd, s_, a)
+                assert int(sol[s_, a]["stats"]["n_lines"]) == r["n_lines"]
+                assert np.abs(co - r["coeff"]).max() <= COEF_TOL, (rnd, s_, a)
+                # what the oracle side commits: the new trajectory with absolute knot times
+                rec = new_com[s_, a]
+                rec["pwp"]["coeff"][:, :K, :] = r["coeff"]; rec["pwp"]["n_seg"] = K
+                rec["pos"] = r["coeff"][:, 0, 3]
+        ex.gather(bb.d_commit, d_com)                   # device side: committed <- this round's records
+        dev_com = d_com.cpu().numpy().view(abi.TRAJ_REC_DTYPE).reshape(3, 6)
+        assert np.abs(np.array(dev_com["pwp"]["coeff"]) - np.array(new_com["pwp"]["coeff"])).max() <= COEF_TOL
+        np.testing.assert_array_equal(dev_com["id"], new_com["id"])
+        np.testing.assert_allclose(dev_com["pwp"]["times"], new_com["pwp"]["times"], atol=1e-12)
+        host_com = dev_com.copy()                        # keep both sides on identical inputs for round 2
+    bb.close()
