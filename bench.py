@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--obstacles", type=int, default=20)
     ap.add_argument("--scenes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--safety", action="store_true",
+                    help="also run the post-solve safety check + commit (SURVEY §8f rank 1) in every step")
     args = ap.parse_args()
 
     import torch
@@ -128,10 +130,24 @@ def main():
     d_committed = be.to_device(com)
     d_guess = be.to_device(np.ascontiguousarray(gue[:, first_local:first_local + n_local]))
     ex = ndist.RoundExchange(S, N, world, rank, device=dev)
+    d_committed_next = torch.empty_like(d_committed) if args.safety else None
+
+    d_new = torch.empty_like(d_committed) if args.safety else None
+    d_accept = torch.zeros(S * N, dtype=torch.int32, device=dev) if args.safety else None
+    d_guess_all = be.to_device(np.ascontiguousarray(gue)) if args.safety else None   # t_start source of the safety pass
+    safety_ev = []
 
     def step():
         be.replan(d_committed, d_guess)
-        ex.gather(be.d_commit, d_committed)
+        if not args.safety:
+            ex.gather(be.d_commit, d_committed)
+            return
+        ex.gather(be.d_commit, d_new)                   # everyone's new trajectory
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        be.safety_commit(d_committed, d_new, d_guess if world == 1 else d_guess_all, d_committed_next, d_accept)
+        e1.record(); safety_ev.append((e0, e1))
+        d_committed.copy_(d_committed_next)
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -144,6 +160,7 @@ def main():
     barrier()
     be.enable_timing(True)
     be.reset_timing()
+    safety_ev.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -184,6 +201,8 @@ def main():
                        "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum())},
             "p50_solve_ms": seq_ms,
             "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "launches": n_launch},
+            "safety": ({"ms": float(np.mean([a.elapsed_time(b) for a, b in safety_ev])), "accepted_frac": float(d_accept.float().mean().item())}
+                       if args.safety else None),
             "roofline": {"bound": "hbm", "kernel": "qp_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": measured_traffic(),
                          "algorithmic_bytes_per_replan": bytes_per_replan, "replans_per_launch": launch_replans,

@@ -249,6 +249,21 @@ int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_
  * bend points come from d_committed[j].bend / n_bend.                                          */
 int64_t nep_batch_ent_bytes(const nep_batch_t* h);
 
+/* SURVEY §8(f) rank 1 — post-solve safety check + commit for a bulk-synchronous round
+ * (Neptune::safetyCheckAfterReplan / trajsAndPwpAreInCollision2d, neptune.cpp:719-806;
+ * gjk::collision, gjk.cpp:76-149).  d_prev, d_new: [n_scenes][N] records before / after the round
+ * (d_new = the all-gathered d_commit of nep_batch_replan); every other agent's new trajectory
+ * counts as "received while optimizing".  An agent keeps its new trajectory unless it collides
+ * (either direction) with an accepted lower id; otherwise its previous record is kept
+ * (neptune_ros.cpp:651-663).  d_final [n_scenes][N] receives the records to replan against next,
+ * d_accept [n_scenes][N] (may be NULL) the 1/0 flags.  Asynchronous on `stream`; overwrites the
+ * handle's hull scratch.  d_guess as passed to nep_batch_replan (supplies t_start).           */
+int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new,
+                            const nep_guess* d_guess, nep_traj_rec* d_final, int32_t* d_accept,
+                            void* stream);
+/* Test hook: the conflict matrix [N][N] of one scene from the last safety check. */
+int nep_batch_debug_conflicts(nep_batch_t* h, int32_t scene, uint8_t* conflict_out);
+
 /* Blocks until everything enqueued by this handle on `stream` has finished. */
 int nep_batch_wait(nep_batch_t* h, void* stream);
 

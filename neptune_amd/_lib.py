@@ -18,7 +18,7 @@ EXPORTS = [
     "nep_backend_debug_get_lines", "nep_separator_batch", "nep_hulls_batch", "nep_batch_create", "nep_batch_destroy",
     "nep_batch_replan", "nep_batch_ent_bytes", "nep_batch_wait", "nep_batch_kernel_time", "nep_batch_enable_timing",
     "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
-    "nep_abi_sizeof", "nep_batch_debug_phase_cycles",
+    "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
 ]
 
 
@@ -67,6 +67,8 @@ def lib():
     L.nep_batch_debug_hulls.argtypes = [vp, i, pd, pi]
     L.nep_batch_debug_lines.argtypes = [vp, i, i, pi, pd, pi]
     L.nep_batch_debug_phase_cycles.argtypes = [vp, i, C.POINTER(C.c_int64)]
+    L.nep_batch_safety_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.nep_batch_debug_conflicts.argtypes = [vp, i, C.POINTER(C.c_uint8)]
     _lib = L
     return L
 

@@ -219,6 +219,17 @@ class BatchBackend:
                                      self.d_solution.data_ptr(), self.d_states.data_ptr(),
                                      self.d_commit.data_ptr() if want_commit else None, st.cuda_stream))
 
+    def safety_commit(self, d_prev, d_new, d_guess, d_final, d_accept=None, stream=None):
+        """Post-solve safety check + commit (nep_batch_safety_commit); tensors are device byte/int32 tensors."""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_safety_commit(self._h, d_prev.data_ptr(), d_new.data_ptr(), d_guess.data_ptr(), d_final.data_ptr(),
+                                            d_accept.data_ptr() if d_accept is not None else None, st.cuda_stream))
+
+    def debug_conflicts(self, scene=0):
+        out = np.zeros((self.N, self.N), dtype=np.uint8)
+        check(lib().nep_batch_debug_conflicts(self._h, scene, out.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return out
+
     def solutions(self):
         self.torch.cuda.synchronize(self.device)
         return self.d_solution.cpu().numpy().view(abi.SOLUTION_DTYPE).copy()

@@ -50,6 +50,7 @@ struct Engine {
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_lp_stats;
   DevBuf<long long> d_dbg; bool profile_phases = false;
+  DevBuf<unsigned char> d_conflict;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
@@ -165,7 +166,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release();
-    d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_lp_stats.release();
+    d_conflict.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
   }
@@ -542,6 +543,30 @@ int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_
   ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
   ps.lines_override = 0;
   return E.run(d_committed, h->cfg.num_agents, ps, (hipStream_t)stream);
+}
+
+int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new, const nep_guess* d_guess,
+                            nep_traj_rec* d_final, int32_t* d_accept, void* stream) {
+  if (!h || !d_prev || !d_new || !d_guess || !d_final) return fail(NEP_E_ARG, "null argument");
+  Engine& E = h->eng;
+  const int N = h->cfg.num_agents;
+  if (E.sp.n_hull != N) return fail(NEP_E_STATE, "safety check needs the batched (all-agent) hull layout");
+  if (int e = E.d_conflict.ensure((size_t)h->cfg.n_scenes * N * N)) return e;
+  ProblemSet ps{};
+  E.fill(ps);
+  ps.guess = d_guess;
+  launch_safety(d_prev, d_new, h->cfg.n_scenes, N, E.sp, ps, E.d_conflict.p, d_final, d_accept, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int nep_batch_debug_conflicts(nep_batch_t* h, int32_t scene, uint8_t* conflict_out) {
+  if (!h || !conflict_out || scene < 0 || scene >= h->cfg.n_scenes) return fail(NEP_E_ARG, "bad arguments");
+  const size_t nn = (size_t)h->cfg.num_agents * h->cfg.num_agents;
+  if (h->eng.d_conflict.n < (size_t)h->cfg.n_scenes * nn) return fail(NEP_E_STATE, "no safety check has run");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(conflict_out, h->eng.d_conflict.p + (size_t)scene * nn, nn, hipMemcpyDeviceToHost));
+  return 0;
 }
 
 int nep_batch_wait(nep_batch_t* h, void* stream) { if (!h) return fail(NEP_E_ARG, "null handle"); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }

@@ -502,4 +502,143 @@ void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start,
                      drone_radius, hull_xy, hull_nv, hull0_xy, hull0_nv);
 }
 
+// ---------------------------------------------------------------------------------------------
+// post-solve safety check (neptune.cpp:719-806, gjk.cpp:76-149)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gjk_furthest(int n, const double* __restrict__ V, double dx, double dy) {
+  double mx = dx * V[0] + dy * V[1]; int idx = 0;
+  for (int i = 1; i < n; i++) { const double p = dx * V[2 * i] + dy * V[2 * i + 1]; if (p > mx) { mx = p; idx = i; } }
+  return idx;
+}
+// gjk::collision(vertices1 = V1 [n1][2], vertices2 = the four control points in B)
+__device__ bool gjk_collision(int n1, const double* __restrict__ V1, const Pts4& B) {
+  if (n1 <= 0) return false;
+  double V2[8];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { V2[2 * k] = B.x[k]; V2[2 * k + 1] = B.y[k]; }
+  double p1x = 0, p1y = 0, p2x = 0, p2y = 0;
+  for (int i = 0; i < n1; i++) { p1x += V1[2 * i]; p1y += V1[2 * i + 1]; }
+  for (int i = 0; i < 4; i++) { p2x += V2[2 * i]; p2y += V2[2 * i + 1]; }
+  p1x /= n1; p1y /= n1; p2x /= 4; p2y /= 4;
+  double dx = p1x - p2x, dy = p1y - p2y;
+  if (dx == 0 && dy == 0) dx = 1.0;
+  double s0x, s0y, s1x = 0, s1y = 0;   // simplex columns 0 and 1 (column 2 is always `a`)
+  int i1 = gjk_furthest(n1, V1, dx, dy), i2 = gjk_furthest(4, V2, -dx, -dy);
+  double ax = V1[2 * i1] - V2[2 * i2], ay = V1[2 * i1 + 1] - V2[2 * i2 + 1];
+  s0x = ax; s0y = ay;
+  if (ax * dx + ay * dy <= 0) return false;
+  dx = -ax; dy = -ay;
+  int index = 0;
+  for (int iter = 0; iter < 64; iter++) {
+    ++index;
+    i1 = gjk_furthest(n1, V1, dx, dy); i2 = gjk_furthest(4, V2, -dx, -dy);
+    ax = V1[2 * i1] - V2[2 * i2]; ay = V1[2 * i1 + 1] - V2[2 * i2 + 1];
+    if (index == 1) { s1x = ax; s1y = ay; }
+    if (ax * dx + ay * dy <= 0) return false;
+    const double aox = -ax, aoy = -ay;
+    if (index < 2) {
+      const double abx = s0x - ax, aby = s0y - ay;
+      // tripleProduct(ab, ao, ab) = ao*(ab.ab) - ab*(ao.ab)
+      const double ac_ = abx * abx + aby * aby, bc_ = aox * abx + aoy * aby;
+      dx = aox * ac_ - abx * bc_; dy = aoy * ac_ - aby * bc_;
+      if (sqrt(dx * dx + dy * dy) == 0) { dx = aby; dy = -abx; }
+      continue;
+    }
+    const double bx_ = s1x, by_ = s1y, cx_ = s0x, cy_ = s0y;
+    const double abx = bx_ - ax, aby = by_ - ay, acx = cx_ - ax, acy = cy_ - ay;
+    // acperp = tripleProduct(ab, ac, ac) = ac*(ab.ac) - ab*(ac.ac)
+    double t1 = abx * acx + aby * acy, t2 = acx * acx + acy * acy;
+    const double apx = acx * t1 - abx * t2, apy = acy * t1 - aby * t2;
+    if (apx * aox + apy * aoy >= 0) { dx = apx; dy = apy; }
+    else {
+      // abperp = tripleProduct(ac, ab, ab) = ab*(ac.ab) - ac*(ab.ab)
+      t1 = acx * abx + acy * aby; t2 = abx * abx + aby * aby;
+      const double bpx = abx * t1 - acx * t2, bpy = aby * t1 - acy * t2;
+      if (bpx * aox + bpy * aoy < 0) return true;
+      s0x = s1x; s0y = s1y;
+      dx = bpx; dy = bpy;
+    }
+    s1x = ax; s1y = ay;   // simplex.col(1) = simplex.col(2)
+    --index;
+  }
+  return false;
+}
+
+// conflict[scene][a][j] = agent a's new trajectory hits the interval hulls of agent j's new
+// trajectory (trajsAndPwpAreInCollision2d on the round's interval grid).  One wave per (scene, a);
+// lanes stride over j.  Hulls come from hull_kernel run on the new records.
+__global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec* __restrict__ fresh, int N, int num_pol, double T_span,
+                                                             const double* __restrict__ hull_xy, const int* __restrict__ hull_nv,
+                                                             unsigned char* __restrict__ conflict) {
+  __shared__ double sBx[NEP_MAX_POL * 4], sBy[NEP_MAX_POL * 4];
+  const int lane = threadIdx.x;
+  const int a = blockIdx.x % N, scene = blockIdx.x / N;
+  const nep_traj_rec* ra = fresh + (long)scene * N + a;
+  const int Ka = ra->valid ? (ra->pwp.n_seg < num_pol ? ra->pwp.n_seg : num_pol) : 0;
+  if (lane < 4 * NEP_MAX_POL) {  // my control points, P * A_rest_pos_basis_t_inverse_ (neptune.cpp:789)
+    const int seg = lane >> 2, k = lane & 3;
+    double vx = 0, vy = 0;
+    if (seg < Ka) {
+      const double tp0 = T_span * T_span * T_span, tp1 = T_span * T_span, tp2 = T_span;
+      const double m0 = tp0 * cAPosInv[0][k], m1 = tp1 * cAPosInv[1][k], m2 = tp2 * cAPosInv[2][k], m3 = 1.0 * cAPosInv[3][k];
+      const double* Px = ra->pwp.coeff[0][seg]; const double* Py = ra->pwp.coeff[1][seg];
+      vx = ((Px[0] * m0 + Px[1] * m1) + Px[2] * m2) + Px[3] * m3;
+      vy = ((Py[0] * m0 + Py[1] * m1) + Py[2] * m2) + Py[3] * m3;
+    }
+    sBx[lane] = vx; sBy[lane] = vy;
+  }
+  __syncthreads();
+  for (int j = lane; j < N; j += 64) {
+    bool hit = false;
+    const nep_traj_rec* rj = fresh + (long)scene * N + j;
+    if (j != a && Ka > 0 && rj->valid && rj->is_agent) {
+      for (int i = 0; i < Ka && !hit; i++) {
+        Pts4 B;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { B.x[k] = sBx[i * 4 + k]; B.y[k] = sBy[i * 4 + k]; }
+        const long h = ((long)scene * N + j) * num_pol + i;
+        hit = gjk_collision(hull_nv[h], hull_xy + h * kHullV * 2, B);
+      }
+    }
+    conflict[((long)scene * N + a) * N + j] = hit ? 1 : 0;
+  }
+}
+
+// Agents visited by id; an agent keeps its new trajectory unless it conflicts (either direction)
+// with an already accepted lower id.  One workgroup per scene; then the final records are written.
+__global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec* __restrict__ prev, const nep_traj_rec* __restrict__ fresh, int N,
+                                                             const unsigned char* __restrict__ conflict, nep_traj_rec* __restrict__ final_out,
+                                                             int* __restrict__ accept_out) {
+  extern __shared__ int sAcc[];   // [N] accept flags + [1] vote
+  const int tid = threadIdx.x, scene = blockIdx.x;
+  const unsigned char* Cm = conflict + (long)scene * N * N;
+  int* vote = sAcc + N;
+  for (int a = 0; a < N; a++) {
+    if (tid == 0) *vote = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int j = tid; j < a; j += blockDim.x) bad = bad || (sAcc[j] && (Cm[(long)a * N + j] || Cm[(long)j * N + a]));
+    if (bad) *vote = 1;
+    __syncthreads();
+    if (tid == 0) sAcc[a] = *vote ? 0 : 1;
+    __syncthreads();
+  }
+  const int words = (int)(sizeof(nep_traj_rec) / sizeof(double));
+  for (long e = tid; e < (long)N * words; e += blockDim.x) {
+    const int a = (int)(e / words), w = (int)(e % words);
+    const double* src = (const double*)((sAcc[a] ? fresh : prev) + (long)scene * N + a);
+    ((double*)(final_out + (long)scene * N + a))[w] = src[w];
+  }
+  if (accept_out) for (int a = tid; a < N; a += blockDim.x) accept_out[(long)scene * N + a] = sAcc[a];
+}
+
+void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
+                   unsigned char* conflict, nep_traj_rec* final_out, int* accept_out, hipStream_t st) {
+  if (n_scenes * N <= 0) return;
+  hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, fresh, N, ps.guess, sp.n_local, sp.num_pol, sp.T_span,
+                     sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr);
+  hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
+  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, final_out, accept_out);
+}
+
 }  // namespace nep

@@ -76,5 +76,7 @@ void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy,
 void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 size_t qp_lds_fixed_bytes();
+void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
+                   unsigned char* conflict, nep_traj_rec* final_out, int* accept_out, hipStream_t st);
 
 }  // namespace nep

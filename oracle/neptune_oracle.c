@@ -788,3 +788,120 @@ int orc_replan(const orc_params* par, double drone_radius, int n_rec, const nep_
   free(off); free(xy); free(off0); free(xy0); free(boff); free(bxy);
   return st;
 }
+
+
+/* ------------------------------------------------------------------------------------------ */
+/* post-solve safety check                                                */
+/* ------------------------------------------------------------------------------------------ */
+/* gjk::collision (neptune/src/gjk.cpp:76-149) with its helpers (:17-68), vertices1 = V1, vertices2
+ * = V2.  The reference loops without a bound; a cap of 64 simplex updates returns "no collision"
+ * (never reached on the fixtures). */
+static int gjk_furthest(int n, const double (*V)[2], double dx, double dy) {
+  double mx = dx * V[0][0] + dy * V[0][1]; int idx = 0;
+  for (int i = 1; i < n; i++) { double p = dx * V[i][0] + dy * V[i][1]; if (p > mx) { mx = p; idx = i; } }
+  return idx;
+}
+static void gjk_support(int n1, const double (*V1)[2], int n2, const double (*V2)[2], double dx, double dy, double out[2]) {
+  int i = gjk_furthest(n1, V1, dx, dy), j = gjk_furthest(n2, V2, -dx, -dy);
+  out[0] = V1[i][0] - V2[j][0]; out[1] = V1[i][1] - V2[j][1];
+}
+static void gjk_triple(const double a[2], const double b[2], const double c[2], double out[2]) { /* b*(a.c) - a*(b.c) */
+  double ac = a[0] * c[0] + a[1] * c[1], bc = b[0] * c[0] + b[1] * c[1];
+  out[0] = b[0] * ac - a[0] * bc; out[1] = b[1] * ac - a[1] * bc;
+}
+int orc_gjk_collision(int n1, const double (*V1)[2], int n2, const double (*V2)[2]) {
+  if (n1 <= 0 || n2 <= 0) return 0;
+  double p1[2] = {0, 0}, p2[2] = {0, 0};
+  for (int i = 0; i < n1; i++) { p1[0] += V1[i][0]; p1[1] += V1[i][1]; }
+  for (int i = 0; i < n2; i++) { p2[0] += V2[i][0]; p2[1] += V2[i][1]; }
+  p1[0] /= n1; p1[1] /= n1; p2[0] /= n2; p2[1] /= n2;
+  double d[2] = {p1[0] - p2[0], p1[1] - p2[1]};
+  if (d[0] == 0 && d[1] == 0) d[0] = 1.0;
+  double simplex[3][2], a[2], b[2], c[2], ao[2], ab[2], ac[2], abperp[2], acperp[2];
+  int index = 0;
+  gjk_support(n1, V1, n2, V2, d[0], d[1], simplex[0]);
+  a[0] = simplex[0][0]; a[1] = simplex[0][1];
+  if (a[0] * d[0] + a[1] * d[1] <= 0) return 0;
+  d[0] = -a[0]; d[1] = -a[1];
+  for (int iter = 0; iter < 64; iter++) {
+    ++index;
+    gjk_support(n1, V1, n2, V2, d[0], d[1], simplex[index]);
+    a[0] = simplex[index][0]; a[1] = simplex[index][1];
+    if (a[0] * d[0] + a[1] * d[1] <= 0) return 0;
+    ao[0] = -a[0]; ao[1] = -a[1];
+    if (index < 2) {
+      b[0] = simplex[0][0]; b[1] = simplex[0][1];
+      ab[0] = b[0] - a[0]; ab[1] = b[1] - a[1];
+      gjk_triple(ab, ao, ab, d);
+      if (sqrt(d[0] * d[0] + d[1] * d[1]) == 0) { d[0] = ab[1]; d[1] = -ab[0]; }
+      continue;
+    }
+    b[0] = simplex[1][0]; b[1] = simplex[1][1]; c[0] = simplex[0][0]; c[1] = simplex[0][1];
+    ab[0] = b[0] - a[0]; ab[1] = b[1] - a[1]; ac[0] = c[0] - a[0]; ac[1] = c[1] - a[1];
+    gjk_triple(ab, ac, ac, acperp);
+    if (acperp[0] * ao[0] + acperp[1] * ao[1] >= 0) { d[0] = acperp[0]; d[1] = acperp[1]; }
+    else {
+      gjk_triple(ac, ab, ab, abperp);
+      if (abperp[0] * ao[0] + abperp[1] * ao[1] < 0) return 1;
+      simplex[0][0] = simplex[1][0]; simplex[0][1] = simplex[1][1];
+      d[0] = abperp[0]; d[1] = abperp[1];
+    }
+    simplex[1][0] = simplex[2][0]; simplex[1][1] = simplex[2][1];
+    --index;
+  }
+  return 0;
+}
+
+/* Neptune::trajsAndPwpAreInCollision2d (neptune.cpp:767-806): my new trajectory `mine` against the
+ * inflated interval hulls of `other`. */
+int orc_trajs_and_pwp_in_collision(const nep_traj_rec* other, const nep_pwp* mine, double T_span, double drone_radius) {
+  int n = mine->n_seg;
+  if (n <= 0) return 0;
+  double t_start = mine->times[0], t_end = mine->times[n];
+  double deltaT = (t_end - t_start) / n;
+  if (fabs(deltaT - T_span) > 0.1) return 1; /* :773-781 */
+  double delta[2] = {other->bbox[0] / 2.0 + drone_radius, other->bbox[1] / 2.0 + drone_radius};
+  for (int i = 0; i < n; i++) {
+    double A4[4][2];
+    for (int ax = 0; ax < 2; ax++) { double Q[4]; orc_pos_ctrl_pts(mine->coeff[ax][i], T_span, Q); for (int k = 0; k < 4; k++) A4[k][ax] = Q[k]; } /* :789 */
+    double hull[NEP_HULL_MAX_V][2], hull0[NEP_HULL_MAX_V][2]; int nv, nv0;
+    orc_hull_of_interval(&other->pwp, t_start + deltaT * i, t_start + deltaT * (i + 1), T_span, delta, hull, &nv, hull0, &nv0); /* :792 */
+    if (orc_gjk_collision(nv, (const double(*)[2])hull, 4, (const double(*)[2])A4)) return 1; /* :794 */
+  }
+  return 0;
+}
+
+/* Same test on the bulk-synchronous round's interval grid t_start + i*T_span (the grid the replan
+ * itself used; (t_end - t_start)/n of :770 equals T_span up to rounding, but rounding would move
+ * interval ends across knots and change which segments a hull covers). */
+static int trajs_collide_on_grid(const nep_traj_rec* other, const nep_pwp* mine, double t_start, double T_span, double drone_radius) {
+  int n = mine->n_seg;
+  double delta[2] = {other->bbox[0] / 2.0 + drone_radius, other->bbox[1] / 2.0 + drone_radius};
+  for (int i = 0; i < n; i++) {
+    double A4[4][2];
+    for (int ax = 0; ax < 2; ax++) { double Q[4]; orc_pos_ctrl_pts(mine->coeff[ax][i], T_span, Q); for (int k = 0; k < 4; k++) A4[k][ax] = Q[k]; }
+    double hull[NEP_HULL_MAX_V][2], hull0[NEP_HULL_MAX_V][2]; int nv, nv0;
+    orc_hull_of_interval(&other->pwp, t_start + i * T_span, t_start + (i + 1) * T_span, T_span, delta, hull, &nv, hull0, &nv0);
+    if (orc_gjk_collision(nv, (const double(*)[2])hull, 4, (const double(*)[2])A4)) return 1;
+  }
+  return 0;
+}
+
+/* Bulk-synchronous form of safetyCheckAfterReplan (neptune.cpp:719-765): every other agent's new
+ * trajectory counts as "received while optimizing".  conflict[a][j] = agent a's new trajectory
+ * collides with the hulls of j's new trajectory.  Deterministic resolution (ours; the reference is
+ * asynchronous and simply fails the replan of whoever checks second): agents are visited by id; an
+ * agent keeps its new trajectory unless it conflicts (either direction) with an already accepted
+ * lower id, in which case it keeps executing its previous plan (neptune_ros.cpp:651-663). */
+void orc_safety_resolve(int n, const nep_traj_rec* fresh, double t_start, double T_span, double drone_radius, unsigned char* conflict, int* accept) {
+  for (int a = 0; a < n; a++) for (int j = 0; j < n; j++) {
+    int c = 0;
+    if (a != j && fresh[a].valid && fresh[j].valid && fresh[j].is_agent) c = trajs_collide_on_grid(&fresh[j], &fresh[a].pwp, t_start, T_span, drone_radius);
+    conflict[a * n + j] = (unsigned char)c;
+  }
+  for (int a = 0; a < n; a++) {
+    int ok = 1;
+    for (int j = 0; j < a; j++) if (accept[j] && (conflict[a * n + j] || conflict[j * n + a])) { ok = 0; break; }
+    accept[a] = ok;
+  }
+}

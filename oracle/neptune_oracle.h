@@ -106,6 +106,12 @@ int orc_replan(const orc_params* par, double drone_radius, int n_rec, const nep_
                const nep_guess* guess, const orc_polys* statics, const int* case_id,
                orc_result* out, double* hull_xy_out, int* hull_nv_out);
 
+/* SURVEY §8(f) rank 1 (post-solve safety check): gjk::collision (gjk.cpp:76-149),
+ * Neptune::trajsAndPwpAreInCollision2d (neptune.cpp:767-806) and the bulk-synchronous resolution. */
+int orc_gjk_collision(int n1, const double (*V1)[2], int n2, const double (*V2)[2]);
+int orc_trajs_and_pwp_in_collision(const nep_traj_rec* other, const nep_pwp* mine, double T_span, double drone_radius);
+void orc_safety_resolve(int n, const nep_traj_rec* fresh, double t_start, double T_span, double drone_radius, unsigned char* conflict, int* accept);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,12 @@ def lib():
                                  C.c_void_p, C.POINTER(orc_polys), C.c_void_p,
                                  C.POINTER(orc_result), C.c_void_p, C.c_void_p]
         L.orc_replan.restype = C.c_int
+        L.orc_gjk_collision.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.orc_gjk_collision.restype = C.c_int
+        L.orc_trajs_and_pwp_in_collision.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double]
+        L.orc_trajs_and_pwp_in_collision.restype = C.c_int
+        L.orc_safety_resolve.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_safety_resolve.restype = None
         _LIB = L
     return _LIB
 
@@ -227,3 +233,25 @@ def replan(p, agent_id, recs, guess, statics, case_id=None, want_hulls=False):
     if want_hulls:
         out["hull_xy"] = hx; out["hull_nv"] = hn
     return out
+
+
+def gjk_collision(V1, V2):
+    """gjk::collision(vertices1, vertices2)."""
+    V1 = _c(V1).reshape(-1, 2); V2 = _c(V2).reshape(-1, 2)
+    return bool(lib().orc_gjk_collision(len(V1), V1.ctypes.data, len(V2), V2.ctypes.data))
+
+
+def safety_resolve(fresh, t_start, T_span, drone_radius):
+    """fresh: [N] TRAJ_REC_DTYPE (every agent's new trajectory).  Returns (conflict [N][N] uint8, accept [N] int32)."""
+    fresh = np.ascontiguousarray(fresh)
+    n = len(fresh)
+    conflict = np.zeros((n, n), dtype=np.uint8); accept = np.zeros(n, dtype=np.int32)
+    lib().orc_safety_resolve(n, fresh.ctypes.data, t_start, T_span, drone_radius, conflict.ctypes.data, accept.ctypes.data)
+    return conflict, accept
+
+
+def trajs_and_pwp_in_collision(other_rec, mine_rec, T_span, drone_radius):
+    """Neptune::trajsAndPwpAreInCollision2d(other, mine.pwp, mine.times.front(), mine.times.back())."""
+    o = np.ascontiguousarray(other_rec); m = np.ascontiguousarray(mine_rec)
+    pw = abi.nep_pwp.from_buffer_copy(m["pwp"].tobytes())
+    return bool(lib().orc_trajs_and_pwp_in_collision(o.ctypes.data, C.addressof(pw), T_span, drone_radius))

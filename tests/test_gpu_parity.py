@@ -408,3 +408,33 @@ def test_multi_scene_batch_and_chained_rounds(be, oracle):
         np.testing.assert_allclose(dev_com["pwp"]["times"], new_com["pwp"]["times"], atol=1e-12)
         host_com = dev_com.copy()                        # keep both sides on identical inputs for round 2
     bb.close()
+
+
+def test_safety_check_and_commit(be, oracle):
+    """conflict matrix (GJK on the new trajectories' hulls), id-ordered
+    resolution and the committed records, bit for bit against the oracle."""
+    scenes = [scene.make_scene(8, 0, seed=60 + s) for s in range(2)]
+    p = scenes[0]["par"]
+    prev = np.stack([s["committed"] for s in scenes])
+    fresh = prev.copy()
+    # scene 0: agent 6 and 8 fly copies of agent 2's trajectory next to it; scene 1 untouched
+    for tgt, dx in ((5, 0.5), (7, -0.6)):
+        fresh[0, tgt] = fresh[0, 1]; fresh[0, tgt]["id"] = tgt + 1
+        fresh[0, tgt]["pwp"]["coeff"][0, :, 3] += dx
+    fresh["pos"][:] += 0.01                                      # make new != prev everywhere
+    gue = np.stack([s["guesses"] for s in scenes])
+    bb = be.BatchBackend(p, [], n_scenes=2)
+    d_prev = bb.to_device(prev); d_new = bb.to_device(fresh); d_gue = bb.to_device(gue)
+    d_final = bb.torch.zeros_like(d_prev); d_acc = bb.torch.zeros(2 * 8, dtype=bb.torch.int32, device=bb.device)
+    bb.safety_commit(d_prev, d_new, d_gue, d_final, d_acc)
+    acc = d_acc.cpu().numpy().reshape(2, 8)
+    fin = d_final.cpu().numpy().view(abi.TRAJ_REC_DTYPE).reshape(2, 8)
+    for s_ in range(2):
+        conflict, accept = oracle.safety_resolve(fresh[s_], 0.0, p.T_span, p.drone_radius)
+        np.testing.assert_array_equal(bb.debug_conflicts(s_), conflict)
+        np.testing.assert_array_equal(acc[s_], accept)
+        for a in range(8):
+            want = fresh[s_, a] if accept[a] else prev[s_, a]
+            assert fin[s_, a].tobytes() == want.tobytes()
+    assert list(acc[0]) == [1, 1, 1, 1, 1, 0, 1, 0] and acc[1].all()
+    bb.close()
