@@ -283,8 +283,9 @@ int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* se
 int nep_batch_debug_phase_cycles(nep_batch_t* h, int32_t slot, int64_t* out16);
 
 /* sizeof() of the POD records as compiled (0 nep_pwp, 1 nep_traj_rec, 2 nep_backend_cfg,
- * 3 nep_stats, 4 nep_batch_cfg, 5 nep_guess, 6 nep_solution, 7 nep_ent_view): lets a foreign-
- * language binding verify its struct mirror. */
+ * 3 nep_stats, 4 nep_batch_cfg, 5 nep_guess, 6 nep_solution, 7 nep_ent_view; from neptune_plan.h:
+ * 8 nep_wire_header, 9 nep_plan_cfg, 10 nep_point_a): lets a foreign-language binding verify its
+ * struct mirror. */
 int nep_abi_sizeof(int32_t which);
 
 const char* nep_last_error(void);

@@ -20,6 +20,12 @@ EXPORTS = [
     "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
     "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
 ]
+# every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
+PLAN_EXPORTS = [
+    "nep_pwp_compose", "nep_dyntraj_wire_size", "nep_dyntraj_encode", "nep_dyntraj_decode", "nep_plan_create",
+    "nep_plan_destroy", "nep_plan_reset", "nep_plan_size", "nep_plan_get", "nep_plan_next_goal",
+    "nep_plan_select_a", "nep_plan_splice", "nep_plan_update_delta", "nep_plan_delta",
+]
 
 
 class BackendError(RuntimeError):
@@ -69,6 +75,22 @@ def lib():
     L.nep_batch_debug_phase_cycles.argtypes = [vp, i, C.POINTER(C.c_int64)]
     L.nep_batch_safety_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.nep_batch_debug_conflicts.argtypes = [vp, i, C.POINTER(C.c_uint8)]
+    ppwp, prec, phdr = C.POINTER(abi.nep_pwp), C.POINTER(abi.nep_traj_rec), C.POINTER(abi.nep_wire_header)
+    pu8 = C.POINTER(C.c_uint8)
+    L.nep_pwp_compose.argtypes = [d, d, ppwp, ppwp, ppwp]
+    L.nep_dyntraj_wire_size.argtypes = [prec, phdr]; L.nep_dyntraj_wire_size.restype = C.c_int64
+    L.nep_dyntraj_encode.argtypes = [prec, phdr, pu8, C.c_size_t]; L.nep_dyntraj_encode.restype = C.c_int64
+    L.nep_dyntraj_decode.argtypes = [pu8, C.c_size_t, prec, phdr]; L.nep_dyntraj_decode.restype = C.c_int64
+    L.nep_plan_create.argtypes = [C.POINTER(abi.nep_plan_cfg)]; L.nep_plan_create.restype = vp
+    L.nep_plan_destroy.argtypes = [vp]; L.nep_plan_destroy.restype = None
+    L.nep_plan_reset.argtypes = [vp, pd]
+    L.nep_plan_size.argtypes = [vp]
+    L.nep_plan_get.argtypes = [vp, i, pd]
+    L.nep_plan_next_goal.argtypes = [vp, pd, pi]
+    L.nep_plan_select_a.argtypes = [vp, pd, d, C.POINTER(abi.nep_point_a)]
+    L.nep_plan_splice.argtypes = [vp, i, pd, i]
+    L.nep_plan_update_delta.argtypes = [vp, d]
+    L.nep_plan_delta.argtypes = [vp]
     _lib = L
     return L
 

@@ -80,6 +80,24 @@ class nep_solution(C.Structure):
 
 
 # numpy structured dtypes with identical layout (used for device<->host staging through torch)
+class nep_wire_header(C.Structure):
+    """ROS Header fields of a DynTraj message on the wire (include/neptune_plan.h)."""
+    _fields_ = [("seq", C.c_uint32), ("stamp_sec", C.c_uint32), ("stamp_nsec", C.c_uint32),
+                ("_pad", C.c_uint32), ("frame_id", C.c_char_p)]
+
+
+class nep_plan_cfg(C.Structure):
+    """The yaml parameters replanFull's plan handling reads (neptune.cpp:1366-1425,1713-1720)."""
+    _fields_ = [("dc", C.c_double), ("T_span", C.c_double), ("lower_bound_runtime", C.c_double),
+                ("upper_bound_runtime", C.c_double), ("runtime_opt", C.c_double),
+                ("factor_alpha", C.c_double), ("deltaT0", C.c_int32), ("_pad", C.c_int32)]
+
+
+class nep_point_a(C.Structure):
+    _fields_ = [("A", C.c_double * 12), ("k_index", C.c_int32), ("k_index_end", C.c_int32),
+                ("runtime_search", C.c_double), ("t_start", C.c_double)]
+
+
 def np_dtype(struct):
     return np.dtype(struct)
 

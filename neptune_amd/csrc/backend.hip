@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "nep_device.h"
+#include "../../include/neptune_plan.h"
 
 using namespace nep;
 
@@ -638,6 +639,9 @@ int nep_abi_sizeof(int32_t which) {
     case 5: return (int)sizeof(nep_guess);
     case 6: return (int)sizeof(nep_solution);
     case 7: return (int)sizeof(nep_ent_view);
+    case 8: return (int)sizeof(nep_wire_header);
+    case 9: return (int)sizeof(nep_plan_cfg);
+    case 10: return (int)sizeof(nep_point_a);
     default: return -1;
   }
 }

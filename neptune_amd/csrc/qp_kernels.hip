@@ -12,7 +12,7 @@
 // so the normal matrix  H + G' W G  collapses to  Hax (+) sum_rho D[rho] (x) B[rho]'B[rho]  with
 // 4 weights per base row; rows only ever touch three R x 3 arrays staged in LDS.
 //
-// Work split per iteration (4 row passes, ~15 workgroup barriers):
+// Work split per iteration (3 row passes, 8 workgroup barriers):
 //   * thread t < 3R owns the two box rows of (rho, axis), state in registers;
 //   * every thread owns slice t&7 of the lines of control point (seg,k) = (t>>5, (t>>3)&3): the 8
 //     slices of one control point sit in consecutive lanes, so the scatter onto base rows is three
@@ -94,11 +94,15 @@ __device__ __forceinline__ double wave_max(double v) {
   return fmax(fmax(bcast(v, 0), bcast(v, 16)), fmax(bcast(v, 32), bcast(v, 48)));
 }
 
-// 1/a to ~1 ulp: v_rcp_f64 seed + two Newton steps (the IEEE divide expands to ~3x the work).
+// 1/a: v_rcp_f64 seed + Newton steps (the IEEE divide expands to ~3x the work).  The row passes
+// only use it inside the Newton direction (weights lam/s, ratio tests): one step suffices there,
+// the residuals that decide convergence never go through it.
 __device__ __forceinline__ double frcp(double a) {
   double r = __builtin_amdgcn_rcp(a);
   double e = __builtin_fma(-a, r, 1.0); r = __builtin_fma(r, e, r);
+#ifdef NEP_FRCP_TWO_STEPS
   e = __builtin_fma(-a, r, 1.0); r = __builtin_fma(r, e, r);
+#endif
   return r;
 }
 
@@ -112,17 +116,20 @@ __device__ __forceinline__ double frsqrt(double a) {
   return y;
 }
 
-// Workgroup reductions of one max and up to three sums in two halves, so that the barrier between
+// Workgroup reductions of one max and NS (0..2) sums in two halves, so that the barrier between
 // them can be shared with other hand-offs: reduce_put before the barrier, reduce_get after it.
-__device__ __forceinline__ void reduce_put(double mx, double s0, double s1, double s2, double* red) {
-  mx = wave_max(mx); s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-  if ((threadIdx.x & 63) == 0) { double* o = red + 4 * (threadIdx.x >> 6); o[0] = mx; o[1] = s0; o[2] = s1; o[3] = s2; }
+template <int NS>
+__device__ __forceinline__ void reduce_put(double mx, double s0, double s1, double* red) {
+  mx = wave_max(mx);
+  if (NS > 0) s0 = wave_sum(s0);
+  if (NS > 1) s1 = wave_sum(s1);
+  if ((threadIdx.x & 63) == 0) { double* o = red + 4 * (threadIdx.x >> 6); o[0] = mx; if (NS > 0) o[1] = s0; if (NS > 1) o[2] = s1; }
 }
-__device__ __forceinline__ void reduce_get(double& mx, double& s0, double& s1, double& s2, const double* red) {
+template <int NS>
+__device__ __forceinline__ void reduce_get(double& mx, double& s0, double& s1, const double* red) {
   mx = fmax(fmax(red[0], red[4]), fmax(red[8], red[12]));
-  s0 = (red[1] + red[5]) + (red[9] + red[13]);
-  s1 = (red[2] + red[6]) + (red[10] + red[14]);
-  s2 = (red[3] + red[7]) + (red[11] + red[15]);
+  if (NS > 0) s0 = (red[1] + red[5]) + (red[9] + red[13]);
+  if (NS > 1) s1 = (red[2] + red[6]) + (red[10] + red[14]);
 }
 
 // One max and up to three sums across the workgroup in one round trip.  red: LDS [16].
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       }
       __syncthreads();
 
-      // Eight workgroup barriers per iteration.  Row direction of the previous solve, recomputed by the
+      // Row direction of the previous solve, recomputed by the
       // merged update:  ds = -rp - gd ; dl = -rc/s + w (rp + gd), rc = s lam - sigma mu + dsa dla.
       double alpha_prev = 0.0, sm_prev = 0.0;
       double* redA = sRed; double* redP2 = sRed + 16; double* redP5 = sRed + 32;
@@ -455,7 +462,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         // ---- (A) apply the previous step, then residuals / weights / scatter onto base rows ----
         double bTl = 0, bD = 0, bT1 = 0;
         double lTx = 0, lTy = 0, lDxx = 0, lDxy = 0, lDyy = 0, l1x = 0, l1y = 0;
-        double nrp = 0, sumsl = 0, dummy1 = 0, dummy2 = 0;
+        double nrp = 0, sumsl = 0, dummy1 = 0;
         auto rowA = [&](double& s, double& lam, double a_old, double ga, double gd, double h, double& a_new_out) {
           const double rp0 = a_old + s - h, is = frcp(s), w0 = lam * is;
           const double dsa = -rp0 - ga, dla = -lam + w0 * (rp0 + ga);
@@ -484,9 +491,9 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         lTx = slice_sum(lTx); lTy = slice_sum(lTy); lDxx = slice_sum(lDxx); lDxy = slice_sum(lDxy); lDyy = slice_sum(lDyy); l1x = slice_sum(l1x); l1y = slice_sum(l1y);
         if (slice == 0) { double* o = sAccL + pair * 8; o[0] = lTx; o[1] = lTy; o[2] = lDxx; o[3] = lDxy; o[4] = lDyy; o[5] = l1x; o[6] = l1y; }
         if (has_box) { sTc[brho * 6 + bax] = bTl; sTc[brho * 6 + 3 + bax] = bT1; sDc[brho * 4 + (bax == 0 ? 0 : (bax == 1 ? 2 : 3))] = bD; }
-        reduce_put(nrp, sumsl, dummy1, dummy2, redA);
+        reduce_put<1>(nrp, sumsl, dummy1, redA);
         __syncthreads();                                                                       // barrier 1
-        reduce_get(nrp, sumsl, dummy1, dummy2, redA);
+        reduce_get<1>(nrp, sumsl, dummy1, redA);
         TICK(0);
         if (tid < R) {   // add the line sums onto the position rows (box threads wrote their part above)
           const int rho = tid; const double* al = sAccL + rho * 8;
@@ -602,63 +609,69 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         if (has_box) uab = proj(brho, bax, sDxa);
         if (has_line) { uax = proj(lrho, 0, sDxa); uay = proj(lrho, 1, sDxa); }
         TICK(5);
-        // ---- (P2) affine step: ratio test + the two sums that give mu_aff for any alpha ----------
-        double rmax = 0, c1 = 0, c2 = 0, dmy = 0;
-        auto rowP2 = [&](bool ok, double s, double lam, double a, double ga, double h) {
-          const double rp = a + s - h, is = frcp(s), w = lam * is;
-          const double ds = -rp - ga, dl = -lam + w * (rp + ga);
-          // -dl/lam = 1 - (rp + ga)/s for the affine direction: no second reciprocal
-          rmax = fmax(rmax, ok ? fmax(-ds * is, __builtin_fma(-(rp + ga), is, 1.0)) : 0.0);
-          c1 += ok ? s * dl + lam * ds : 0.0; c2 += ok ? ds * dl : 0.0;
-        };
-        if (has_box) { rowP2(true, bs0, bl0, cpb, uab, bhi); rowP2(true, bs1, bl1, -cpb, -uab, -blo); }
-        for_lines4([&](bool ok, int, double n1, double n2, double h, double s, double lam) { rowP2(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, h); });
+        // ---- (P2) affine step: ratio test, the sum that gives mu_aff for any alpha, and the corrector's
+        // right-hand side split as  va - sigma mu * vb  (sigma is only known after this pass's reduction):
+        //   q = dsa/s;  dla = -lam - w dsa;  rcv/s - w rp = (lam + q dla - w rp) - sigma mu / s.
+        // The first-order term of mu_aff needs no sum: s dla + lam dsa = -s lam for every row.
+        double rmax = 0, c2 = 0, dmy = 0;
+        {
+          double b1a = 0, b1b = 0, vax = 0, vay = 0, vbx = 0, vby = 0;
+          auto rowP2 = [&](bool ok, double s, double lam, double a, double ga, double h, double& va, double& vb) {
+            const double rp = a + s - h, is = frcp(s), w = lam * is;
+            const double dsa = -rp - ga, q = dsa * is, dla = -__builtin_fma(w, dsa, lam);
+            rmax = fmax(rmax, ok ? fmax(-q, 1.0 + q) : 0.0);
+            c2 += ok ? dsa * dla : 0.0;
+            va = __builtin_fma(q, dla, lam) - w * rp; vb = is;
+          };
+          if (has_box) {
+            double va0, vb0, va1, vb1;
+            rowP2(true, bs0, bl0, cpb, uab, bhi, va0, vb0); rowP2(true, bs1, bl1, -cpb, -uab, -blo, va1, vb1);
+            b1a = va0 - va1; b1b = vb0 - vb1;
+          }
+          for_lines4([&](bool ok, int, double n1, double n2, double h, double s, double lam) {
+            double va, vb;
+            rowP2(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, h, va, vb);
+            vax += va * n1; vay += va * n2; vbx += vb * n1; vby += vb * n2;     // (n1 = n2 = 0 on the dummy line)
+          });
+          vax = slice_sum(vax); vay = slice_sum(vay); vbx = slice_sum(vbx); vby = slice_sum(vby);
+          // the T_lambda slots of sAccL / sTc were consumed before barrier 3: they carry vb now
+          if (slice == 0) { double* o = sAccL + pair * 8; o[5] = vax; o[6] = vay; o[0] = vbx; o[1] = vby; }
+          if (has_box) { sTc[brho * 6 + 3 + bax] = b1a; sTc[brho * 6 + bax] = b1b; }
+        }
         if (tid == BS - 1 && has_qc) {
           const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
           double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
           const double dsq = -rpq - gd, dlq = -lq + wq * (rpq + gd);
           sc[sDsqA] = dsq; sc[sDlqA] = dlq;
           rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
-          c1 += sq * dlq + lq * dsq; c2 += dsq * dlq;
+          c2 += dsq * dlq;
         }
-        reduce_put(rmax, c1, c2, dmy, redP2);
+        reduce_put<1>(rmax, c2, dmy, redP2);
         __syncthreads();                                                                       // barrier 5
-        reduce_get(rmax, c1, c2, dmy, redP2);
+        reduce_get<1>(rmax, c2, dmy, redP2);
         double sm;
         {
           const double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
           const double mu = sc[sMu];
-          const double mua = (sc[sSumSl] + aaff * c1 + aaff * aaff * c2) / mt;
+          const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) / mt;
           const double rr = mua / mu;
           sm = rr * rr * rr * mu;                              // sigma * mu, identical in every thread
         }
         TICK(6);
-        // ---- (P4) corrector right-hand side ---------------------------------------------------
-        {
-          double b1 = 0, c1x = 0, c1y = 0;
-          auto rowP4 = [&](double s, double lam, double a, double ga, double h) -> double {
-            const double rp = a + s - h, is = frcp(s), w = lam * is;
-            const double dsa = -rp - ga, dla = -lam + w * (rp + ga);
-            const double rcv = s * lam - sm + dsa * dla;
-            return rcv * is - w * rp;
-          };
-          if (has_box) b1 = rowP4(bs0, bl0, cpb, uab, bhi) - rowP4(bs1, bl1, -cpb, -uab, -blo);
-          for_lines4([&](bool, int, double n1, double n2, double h, double s, double lam) { const double v = rowP4(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, h); c1x += v * n1; c1y += v * n2; });
-          c1x = slice_sum(c1x); c1y = slice_sum(c1y);
-          if (slice == 0) { sAccL[pair * 8 + 5] = c1x; sAccL[pair * 8 + 6] = c1y; }
-          if (has_box) sTc[brho * 6 + 3 + bax] = b1;
-        }
-        __syncthreads();                                                                       // barrier 6
         TICK(7);
         // ---- corrector right-hand side (8 partial sums per entry), then the substitutions -----------
         if (tid < 8 * n) {
           const int o = tid >> 3, sl8 = tid & 7, ax = o / nz, c = o % nz;
           double t1 = 0;
-          for (int rho = sl8; rho < R; rho += 8) { double tt = sTc[rho * 6 + 3 + ax]; if (ax < 2 && rho < 4 * K) tt += sAccL[rho * 8 + 5 + ax]; t1 += sB[rho * SBS + c] * tt; }
+          for (int rho = sl8; rho < R; rho += 8) {
+            double ta = sTc[rho * 6 + 3 + ax], tb2 = sTc[rho * 6 + ax];
+            if (ax < 2 && rho < 4 * K) { ta += sAccL[rho * 8 + 5 + ax]; tb2 += sAccL[rho * 8 + ax]; }
+            t1 += sB[rho * SBS + c] * __builtin_fma(-sm, tb2, ta);
+          }
           t1 = slice_sum(t1);
           if (sl8 == 0) sRhs[o] = t1;
         }
-        __syncthreads();                                                                       // barrier 6b
+        __syncthreads();                                                                       // barrier 6
         if (tid < 128) {
           const bool w0 = tid < 64;
           const int o = w0 ? tid : 2 * nz + (tid - 64);
@@ -676,7 +689,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         if (has_line) { udx = proj(lrho, 0, sDx); udy = proj(lrho, 1, sDx); }
         TICK(8);
         // ---- (P5) step length of the combined direction ------------------------------------------
-        rmax = 0; c1 = 0; c2 = 0; dmy = 0;
+        rmax = 0;
         auto rowP5 = [&](bool ok, double s, double lam, double a, double ga, double gd, double h) {
           const double rp = a + s - h, is = frcp(s), w = lam * is;
           const double dsa = -rp - ga, dla = -lam + w * (rp + ga);
@@ -694,9 +707,9 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           sc[sDsq] = dsq; sc[sDlq] = dlq;
           rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
         }
-        reduce_put(rmax, c1, c2, dmy, redP5);
+        reduce_put<0>(rmax, dmy, dmy, redP5);
         __syncthreads();                                                                       // barrier 8
-        reduce_get(rmax, c1, c2, dmy, redP5);
+        reduce_get<0>(rmax, dmy, dmy, redP5);
         {
           double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
           alpha = fmin(1.0, 0.999 * alpha);

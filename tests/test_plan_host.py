@@ -1,0 +1,344 @@
+"""CPU: the host side of the replan loop (include/neptune_plan.h) against its
+restatement oracle/plan_oracle.py — composition, DynTraj wire format, plan deque.  Host-only
+entry points: no GPU is needed, results must be bit-identical."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from oracle import plan_oracle as po
+
+from neptune_amd import _lib, abi, plan
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def L():
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    return _lib.lib()
+
+
+def rand_pwp(rng, n, t0, uniform=True):
+    dts = np.full(n, 0.5) if uniform else rng.uniform(0.05, 0.7, n)
+    times = t0 + np.concatenate([[0.0], np.cumsum(dts)])
+    coeff = rng.normal(size=(3, n, 4))
+    return times, coeff
+
+
+def to_oracle(times, coeff):
+    return po.Pwp(times, coeff[0], coeff[1], coeff[2])
+
+
+def assert_same_pwp(got, want):
+    t, c = plan.pwp_arrays(got)
+    assert got.n_seg == len(want.cx)
+    if got.n_seg == 0:
+        assert want.times == []
+        return
+    assert t.tolist() == want.times
+    assert c[0].tolist() == want.cx and c[1].tolist() == want.cy and c[2].tolist() == want.cz
+
+
+# ----------------------------------------------------------------------------------------------
+# composePieceWisePol
+# ----------------------------------------------------------------------------------------------
+def compose_both(t, t1, c1, t2, c2):
+    a1, a2 = plan.make_pwp(t1, c1), plan.make_pwp(t2, c2)
+    o1, o2 = to_oracle(t1, c1), to_oracle(t2, c2)
+    got = plan.compose_piecewise_pol(t, 0.05, a1, a2)
+    want = po.compose_piecewise_pol(t, 0.05, o1, o2)
+    assert_same_pwp(got, want)
+    # the in-place knot adjustments of the by-reference arguments
+    assert plan.pwp_arrays(a1)[0].tolist() == o1.times
+    assert plan.pwp_arrays(a2)[0].tolist() == o2.times
+    return got
+
+
+def test_compose_hand_worked():
+    # previous plan: 4 intervals on [10, 12]; new plan starts inside it at 11.0 with 8 intervals
+    rng = np.random.default_rng(0)
+    t1, c1 = rand_pwp(rng, 4, 10.0)
+    t2, c2 = rand_pwp(rng, 8, 11.0)
+    got = compose_both(10.3, t1, c1, t2, c2)
+    t, c = plan.pwp_arrays(got)
+    # knots: t, the p1 knot strictly between (10.5), then every p2 knot
+    assert t.tolist() == [10.3, 10.5] + t2.tolist()
+    # intervals: p1[0] (ending 10.5), p1's LAST interval for the stretch ending at p2.times[0]
+    # (utils.cpp:388-393), then p2's
+    assert np.array_equal(c[:, 0], c1[:, 0]) and np.array_equal(c[:, 1], c1[:, 3])
+    assert np.array_equal(c[:, 2:], c2)
+    assert got.n_seg == 10
+
+
+def test_compose_branches():
+    rng = np.random.default_rng(1)
+    t1, c1 = rand_pwp(rng, 8, 0.0)
+    t2, c2 = rand_pwp(rng, 8, 2.0)
+    # t == start of the new trajectory (|.| < 1e-5): the new one is returned as is
+    got = compose_both(2.0 + 5e-6, t1, c1, t2, c2)
+    assert got.n_seg == 8 and plan.pwp_arrays(got)[0][0] == 2.0
+    # t before p1: p1.times[0] is pulled back to t
+    compose_both(-0.4, t1, c1, t2, c2)
+    # gap between p1 and p2 with t inside the gap: p2 is stretched back, then returned
+    t2g, c2g = rand_pwp(rng, 8, 4.7)
+    compose_both(4.3, t1, c1, t2g, c2g)
+    # gap with t before the end of p1: p2.times[0] is snapped to p1's end
+    compose_both(1.2, t1, c1, t2g, c2g)
+    # t after everything: the empty "dummy"
+    got = compose_both(9.0, t1, c1, t2, c2)
+    assert got.n_seg == 0
+    # t after the start of p2 (late commit): p2's earlier knots are dropped
+    compose_both(2.7, t1, c1, t2, c2)
+
+
+def test_compose_random_against_oracle():
+    rng = np.random.default_rng(2)
+    n_dummy = n_p2 = 0
+    for _ in range(3000):
+        n1, n2 = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        t1, c1 = rand_pwp(rng, n1, float(rng.uniform(0, 3)), uniform=bool(rng.integers(0, 2)))
+        t2, c2 = rand_pwp(rng, n2, float(rng.uniform(t1[0] - 0.5, t1[-1] + 0.6)), uniform=bool(rng.integers(0, 2)))
+        t = float(rng.uniform(t1[0] - 0.3, t2[-1] + 0.3))
+        if rng.integers(0, 8) == 0:
+            t = float(t2[0] + rng.uniform(-2e-5, 2e-5))
+        got = compose_both(t, t1, c1, t2, c2)
+        n_dummy += got.n_seg == 0
+        n_p2 += got.n_seg == n2
+    assert n_dummy > 20 and n_p2 > 100
+
+
+def test_compose_repeated_receding_horizon_fits_the_record():
+    # replanning every 0.35 s with T_span 0.5, 8 intervals: the composed record stays <= 16 intervals
+    rng = np.random.default_rng(3)
+    t1, c1 = rand_pwp(rng, 8, 0.0)
+    prev_a, prev_o = plan.make_pwp(t1, c1), to_oracle(t1, c1)
+    now = 0.0
+    worst = 0
+    for r in range(60):
+        now += float(rng.uniform(0.2, 0.5))
+        k_index = int(rng.integers(4, 12))
+        t2, c2 = rand_pwp(rng, 8, now + 0.05 * k_index)
+        a2, o2 = plan.make_pwp(t2, c2), to_oracle(t2, c2)
+        prev_a = plan.compose_piecewise_pol(now, 0.05, prev_a, a2)
+        prev_o = po.compose_piecewise_pol(now, 0.05, prev_o, o2)
+        assert_same_pwp(prev_a, prev_o)
+        worst = max(worst, prev_a.n_seg)
+    assert 9 <= worst <= abi.NEP_TRAJ_MAX_SEG
+
+
+def test_compose_capacity_and_arguments():
+    rng = np.random.default_rng(4)
+    t1, c1 = rand_pwp(rng, 16, 0.0, uniform=False)
+    t2, c2 = rand_pwp(rng, 16, float(t1[-1]) - 1e-3)
+    a1, a2 = plan.make_pwp(t1, c1), plan.make_pwp(t2, c2)
+    with pytest.raises(plan.PlanError) as e:
+        plan.compose_piecewise_pol(float(t1[0]) + 1e-3, 0.05, a1, a2)
+    assert e.value.code == -4
+    empty = abi.nep_pwp()
+    with pytest.raises(plan.PlanError) as e:
+        plan.compose_piecewise_pol(0.0, 0.05, empty, a2)
+    assert e.value.code == -1
+
+
+# ----------------------------------------------------------------------------------------------
+# DynTraj wire format
+# ----------------------------------------------------------------------------------------------
+def rand_rec(rng, n_seg, n_bend, agent_id):
+    rec = abi.nep_traj_rec()
+    rec.id, rec.is_agent, rec.n_bend, rec.valid = agent_id, 1, n_bend, 1
+    for i in range(3):
+        rec.bbox[i] = 1.2
+        rec.pos[i] = float(rng.normal())
+    bend = rng.normal(size=(n_bend, 2))
+    for i in range(n_bend):
+        rec.bend[i][0], rec.bend[i][1] = bend[i]
+    times, coeff = rand_pwp(rng, n_seg, float(rng.uniform(0, 100))) if n_seg else (np.zeros(0), np.zeros((3, 0, 4)))
+    rec.pwp = plan.make_pwp(times, coeff)
+    msg = po.publish_own_traj(to_oracle(times, coeff), [rec.pos[i] for i in range(3)], agent_id, 0.6,
+                              [tuple(b) for b in bend])
+    return rec, msg
+
+
+def test_wire_matches_the_oracle_serialisation_and_round_trips():
+    rng = np.random.default_rng(5)
+    for k in range(200):
+        n_seg, n_bend = int(rng.integers(0, 17)), int(rng.integers(0, 9))
+        rec, msg = rand_rec(rng, n_seg, n_bend, int(rng.integers(1, 300)))
+        msg.update(seq=k, stamp=(1700000000 + k, 123456789), frame_id=b"world")
+        data = plan.dyntraj_encode(rec, seq=k, stamp=(1700000000 + k, 123456789), frame_id=b"world")
+        assert data == po.dyntraj_encode(msg)
+        back, hdr, used = plan.dyntraj_decode(data)
+        assert used == len(data) and hdr == (k, 1700000000 + k, 123456789)
+        m2, used2 = po.dyntraj_decode(data)
+        assert used2 == len(data)
+        # bbox passes through float32 on the wire, as in the reference
+        assert [back.bbox[i] for i in range(3)] == [float(np.float32(1.2))] * 3 == m2["bbox"]
+        rec.bbox[0] = rec.bbox[1] = rec.bbox[2] = float(np.float32(1.2))
+        a, b = plan.rec_to_numpy(rec), plan.rec_to_numpy(back)
+        for f in ("id", "is_agent", "n_bend", "valid", "bbox", "pos"):
+            assert np.array_equal(a[f], b[f]), f
+        assert np.array_equal(a["bend"][0][:n_bend], b["bend"][0][:n_bend])
+        assert_same_pwp(back.pwp, m2["pwp"])
+        assert_same_pwp(back.pwp, msg["pwp"])
+
+
+def test_wire_golden_bytes():
+    """A message written out field by field from the ROS1 rules, independent of both encoders."""
+    rec = abi.nep_traj_rec()
+    rec.id, rec.is_agent, rec.n_bend, rec.valid = 7, 1, 1, 1
+    rec.bbox[0], rec.bbox[1], rec.bbox[2] = 1.5, 1.5, 1.5
+    rec.pos[0], rec.pos[1], rec.pos[2] = 1.0, -2.0, 0.5
+    rec.bend[0][0], rec.bend[0][1] = 3.0, 4.0
+    rec.pwp = plan.make_pwp([10.0, 10.5], np.array([[[1, 2, 3, 4]], [[5, 6, 7, 8]], [[9, 10, 11, 12]]], dtype=float))
+    want = b"".join([
+        struct.pack("<I", 3), struct.pack("<II", 100, 200), struct.pack("<I", 2), b"ab",       # Header
+        struct.pack("<I", 3), struct.pack("<III", 0, 0, 0),                                    # function
+        struct.pack("<I", 3), struct.pack("<fff", 1.5, 1.5, 1.5),                              # bbox
+        struct.pack("<ddd", 1.0, -2.0, 0.5), struct.pack("<i", 7), b"\x01",                    # pos id is_agent
+        struct.pack("<I", 1), struct.pack("<ddd", 3.0, 4.0, 0.0),                              # bendpt
+        struct.pack("<I", 2), struct.pack("<dd", 10.0, 10.5),                                  # times
+        struct.pack("<I", 1), struct.pack("<dddd", 1, 2, 3, 4),
+        struct.pack("<I", 1), struct.pack("<dddd", 5, 6, 7, 8),
+        struct.pack("<I", 1), struct.pack("<dddd", 9, 10, 11, 12)])
+    got = plan.dyntraj_encode(rec, seq=3, stamp=(100, 200), frame_id=b"ab")
+    assert got == want and len(got) == 235
+    golden = open(os.path.join(ROOT, "tests", "golden", "dyntraj_wire.hex")).read().split()
+    assert got.hex() == golden[0]
+
+
+def test_wire_rejects_malformed_messages():
+    rng = np.random.default_rng(6)
+    rec, msg = rand_rec(rng, 8, 3, 4)
+    data = plan.dyntraj_encode(rec)
+    for cut in (0, 3, 11, 40, len(data) // 2, len(data) - 1):
+        with pytest.raises(plan.PlanError) as e:
+            plan.dyntraj_decode(data[:cut])
+        assert e.value.code == -1
+    # coeff_y shorter than coeff_x: the reference aborts (utils.cpp:231-236)
+    msg["pwp"].cy.pop()
+    with pytest.raises(plan.PlanError) as e:
+        plan.dyntraj_decode(po.dyntraj_encode(msg))
+    assert e.value.code == -1
+    with pytest.raises(ValueError):
+        po.dyntraj_decode(po.dyntraj_encode(msg))
+    # more intervals / bend points than the record holds
+    big = to_oracle(*rand_pwp(rng, 17, 0.0))
+    m = po.publish_own_traj(big, (0, 0, 0), 1, 0.6, [(0.0, 0.0)])
+    with pytest.raises(plan.PlanError) as e:
+        plan.dyntraj_decode(po.dyntraj_encode(m))
+    assert e.value.code == -4
+    m = po.publish_own_traj(to_oracle(*rand_pwp(rng, 2, 0.0)), (0, 0, 0), 1, 0.6, [(0.0, 0.0)] * 9)
+    with pytest.raises(plan.PlanError) as e:
+        plan.dyntraj_decode(po.dyntraj_encode(m))
+    assert e.value.code == -4
+    # a short output buffer
+    buf = (C.c_uint8 * 10)()
+    assert _lib.lib().nep_dyntraj_encode(C.byref(rec), None, buf, 10) == -4
+    # obstacle messages carry non-empty function strings: skipped on decode
+    m = po.publish_own_traj(to_oracle(*rand_pwp(rng, 2, 0.0)), (1, 2, 3), 9, 0.6, [])
+    m["function"] = [b"sin(t)", b"cos(t)", b"1.0"]
+    m["is_agent"] = False
+    back, _, used = plan.dyntraj_decode(po.dyntraj_encode(m))
+    assert back.is_agent == 0 and back.id == 9 and back.pwp.n_seg == 2
+
+
+# ----------------------------------------------------------------------------------------------
+# plan deque
+# ----------------------------------------------------------------------------------------------
+PLAN_ARGS = dict(dc=0.05, T_span=0.5, lower_bound_runtime=0.3, upper_bound_runtime=2.5, runtime_opt=0.08,
+                 factor_alpha=1.5)
+
+
+def both_plans(deltaT0=75):
+    a = plan.CommittedPlan(deltaT0=deltaT0, **PLAN_ARGS)
+    o = po.Plan(PLAN_ARGS["dc"], PLAN_ARGS["T_span"], PLAN_ARGS["lower_bound_runtime"], PLAN_ARGS["upper_bound_runtime"],
+                PLAN_ARGS["runtime_opt"], PLAN_ARGS["factor_alpha"], deltaT0)
+    return a, o
+
+
+def assert_same_plan(a, o):
+    assert len(a) == len(o.content)
+    assert a.to_array().tolist() == [list(map(float, s)) for s in o.content]
+    assert a.deltaT == o.deltaT
+
+
+def test_plan_select_splice_goal_sequence_matches_oracle():
+    rng = np.random.default_rng(7)
+    for trial in range(40):
+        a, o = both_plans(deltaT0=int(rng.integers(1, 120)))
+        s0 = np.concatenate([rng.normal(size=3), np.zeros(9)])
+        a.reset(s0); o.reset(s0)
+        now = 100.0
+        for step in range(60):
+            op = int(rng.integers(0, 3))
+            if op == 0:                                   # control tick: pop the next goal
+                for _ in range(int(rng.integers(1, 12))):
+                    ga, la = a.next_goal()
+                    go, lo = o.next_goal()
+                    assert ga.tolist() == go and la == lo
+                    now += 0.05
+            elif op == 1:                                 # replan: select A, splice a new sample train
+                pos = a.get(0)[:3] + (rng.normal(size=3) * (2.0 if rng.integers(0, 6) == 0 else 0.1))
+                pa = a.select_a(pos, now)
+                pw = o.select_a(list(pos), now)
+                assert [pa.A[i] for i in range(12)] == pw["A"]
+                assert (pa.k_index, pa.k_index_end) == (pw["k_index"], pw["k_index_end"])
+                assert pa.runtime_search == pw["runtime_search"] and pa.t_start == pw["t_start"]
+                traj = rng.normal(size=(int(rng.integers(1, 90)), 12))
+                traj[0] = [pa.A[i] for i in range(12)]
+                a.splice(pa.k_index_end, traj)
+                assert o.splice(pw["k_index_end"], traj.tolist())
+            else:
+                ms = float(rng.uniform(1, 400))
+                a.update_delta(ms); o.update_delta(ms)
+            assert_same_plan(a, o)
+        a.close()
+
+
+def test_plan_point_a_rules():
+    a, o = both_plans(deltaT0=75)
+    s0 = np.zeros(12); s0[:3] = [1, 2, 3]
+    a.reset(s0)
+    # a single state: A is that state, k_index_end 0, full front-end budget (neptune.cpp:1406-1419)
+    pa = a.select_a(s0[:3], 50.0)
+    assert (pa.k_index, pa.k_index_end) == (0, 0) and pa.t_start == 50.0
+    assert pa.runtime_search == PLAN_ARGS["upper_bound_runtime"] - PLAN_ARGS["runtime_opt"]
+    # deltaT saturates to [lower/dc, upper/dc] = [6, 50] with integer truncation
+    assert a.deltaT == 50
+    traj = np.arange(81 * 12, dtype=float).reshape(81, 12)
+    a.splice(pa.k_index_end, traj)
+    assert len(a) == 81
+    pa = a.select_a(traj[0, :3], 50.0)
+    assert pa.k_index_end == 81 - 50 and pa.k_index == 49
+    assert pa.t_start == 49 * 0.05 + 50.0
+    assert [pa.A[i] for i in range(12)] == traj[49].tolist()
+    # measured position > 1 m from the head of the plan: A.pos is replaced (neptune.cpp:1395-1398)
+    pa = a.select_a(traj[0, :3] + [0, 0, 1.5], 50.0)
+    assert [pa.A[i] for i in range(3)] == (traj[0, :3] + [0, 0, 1.5]).tolist()
+    # "Already published the point A"
+    with pytest.raises(plan.PlanError) as e:
+        a.splice(200, traj)
+    assert e.value.code == -2
+    # future_index < 0 (short plan, big deltaT): velocity and acceleration of A are zeroed
+    b, _ = both_plans(deltaT0=40)
+    b.reset(s0)
+    b.splice(0, traj[:20])
+    pb = b.select_a(traj[0, :3], 0.0)
+    assert pb.k_index_end == 0 and pb.k_index == 19
+    assert [pb.A[i] for i in range(3, 9)] == [0.0] * 6 and pb.A[9] == traj[19, 9]
+
+
+def test_plan_exports_and_layouts(L):
+    import re
+    hdr = open(os.path.join(ROOT, "include", "neptune_plan.h")).read()
+    declared = set(re.findall(r"^(?:int|void|int32_t|int64_t|nep_plan_t\*)\s+(nep_[a-z_0-9]+)\(", hdr, re.M))
+    assert declared == set(_lib.PLAN_EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    for k, t in ((8, abi.nep_wire_header), (9, abi.nep_plan_cfg), (10, abi.nep_point_a)):
+        assert C.sizeof(t) == L.nep_abi_sizeof(k), t.__name__
