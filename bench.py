@@ -6,13 +6,18 @@
           --master-port P bench.py --gpus N --steps K --warmup W)
 
 Workload (BASELINE.json north_star / configs[3] scene on the named GPU count): 64 agents + 20
-static polytope obstacles, K = 8 segments, reference yaml parameters, the 32 seeded scenes
-(seeds 0..31) in flight per step.  One step = one bulk-synchronous round: every
-agent of every scene does one full back-end replan (MINVO hulls of the other agents' committed
-trajectories -> separating-line LPs -> spline QP -> sampled states -> committed record), then the
-committed records are exchanged (all-gather over RCCL when N > 1) and become the obstacles of the
-next step.  Inputs are resident in HBM before the timed region.  Agents are block-sharded by id
-across ranks; total work is fixed, so "scaling" is "strong".
+static polytope obstacles, K = 8 segments, reference yaml parameters, 32 seeded scenes (SURVEY.md
+§8d) in flight per GPU per step.  One step = one bulk-synchronous round: every agent of every scene
+does one full back-end replan (MINVO hulls of the other agents' committed trajectories ->
+separating-line LPs -> spline QP -> sampled states -> committed record); the new trajectories are
+the obstacles of the next step.  Inputs are resident in HBM before the timed region.
+
+N > 1: the agents of every scene are block-sharded by id across the ranks (64/N per GPU) and the
+number of scenes grows with N (32 per GPU), so every GPU does 2048 replans per step at any N:
+"scaling" is "weak".  The exchange step is one RCCL all-gather per round of what the other agents'
+replans consume of a committed trajectory — its interval hulls — so hull construction is sharded
+with the agents (--exchange records all-gathers the trajectory records instead and rebuilds every
+hull on every rank).
 """
 import argparse
 import json
@@ -92,7 +97,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--agents", type=int, default=64)
     ap.add_argument("--obstacles", type=int, default=20)
-    ap.add_argument("--scenes", type=int, default=32)
+    ap.add_argument("--scenes", type=int, default=32, help="seeded scenes in flight PER GPU")
+    ap.add_argument("--exchange", choices=["hulls", "records"], default="hulls",
+                    help="N > 1: all-gather the interval hulls of the local agents' committed trajectories (hull work "
+                         "sharded with the agents) or the trajectory records themselves (every rank rebuilds all hulls)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--safety", action="store_true",
                     help="also run the post-solve safety check + commit (SURVEY §8f rank 1) in every step")
@@ -109,6 +117,11 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the back end has no CPU path")
+    # development aid: several ranks on ONE GPU over gloo (the driver's runs use one GPU per rank over RCCL)
+    one_device = os.environ.get("NEP_BENCH_ONE_DEVICE") == "1"
+    dist_backend = os.environ.get("NEP_BENCH_BACKEND", "nccl")
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as tdist
@@ -116,38 +129,83 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        tdist.init_process_group("nccl", device_id=dev)
+        if dist_backend == "nccl":
+            tdist.init_process_group("nccl", device_id=dev)
+        else:
+            tdist.init_process_group(dist_backend)
 
-    N, M, S = args.agents, args.obstacles, args.scenes
-    scenes = [scene.make_scene(N, M, seed=s) for s in range(S)]
-    p = scenes[0]["par"]
-    # one static-obstacle set per handle: scenes share the statics of seed 0 (bases are seed-free)
-    for s in scenes[1:]:
-        s["statics"] = scenes[0]["statics"]
+    # Weak scaling: args.scenes scenes in flight per GPU, so S = scenes * world scenes in total; the
+    # agents of EVERY scene are block-sharded over the ranks (configs[3]: 64 agents, 8 per GPU on 8
+    # GPUs), which keeps scenes * agents replans per GPU per step at any N.
+    N, M, S = args.agents, args.obstacles, args.scenes * world
     first_local, n_local = ndist.shard(N, world, rank)
-    be = BatchBackend(p, scenes[0]["statics"], first_local=first_local, n_local=n_local, n_scenes=S, device=dev)
-    com, gue = ndist.stack_scenes(scenes)
+    # each rank generates its share of the seeded scenes (seeds 0..S-1 overall), then they are shared
+    mine = [scene.make_scene(N, M, seed=s) for s in range(rank * args.scenes, (rank + 1) * args.scenes)]
+    scene0 = mine[0] if rank == 0 else scene.make_scene(N, M, seed=0)
+    p = scene0["par"]
+    statics = scene0["statics"]          # one static-obstacle set per handle: seed 0's (bases are seed-free)
+    com_l, gue_l = ndist.stack_scenes(mine)
+
+    def share(arr):                      # [scenes per GPU][N] per rank -> [S][N] on every rank
+        if world == 1:
+            return arr
+        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy())
+        if dist_backend == "nccl":
+            t = t.to(dev)
+            out = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
+            tdist.all_gather_into_tensor(out, t)
+            out = out.cpu()
+        else:
+            pieces = [torch.empty_like(t) for _ in range(world)]
+            tdist.all_gather(pieces, t)
+            out = torch.cat(pieces)
+        return out.numpy().view(arr.dtype).reshape((S,) + arr.shape[1:])
+    com, gue = share(com_l), share(gue_l)
+
+    be = BatchBackend(p, statics, first_local=first_local, n_local=n_local, n_scenes=S, device=dev)
     d_committed = be.to_device(com)
     d_guess = be.to_device(np.ascontiguousarray(gue[:, first_local:first_local + n_local]))
     ex = ndist.RoundExchange(S, N, world, rank, device=dev)
+    sharded_hulls = world > 1 and args.exchange == "hulls"
+    hx = ndist.HullExchange(be.hull_block_bytes(), world, rank, device=dev) if sharded_hulls else None
+    d_local = be.to_device(np.ascontiguousarray(com[:, first_local:first_local + n_local])) if sharded_hulls else None
     d_committed_next = torch.empty_like(d_committed) if args.safety else None
-
     d_new = torch.empty_like(d_committed) if args.safety else None
     d_accept = torch.zeros(S * N, dtype=torch.int32, device=dev) if args.safety else None
     d_guess_all = be.to_device(np.ascontiguousarray(gue)) if args.safety else None   # t_start source of the safety pass
-    safety_ev = []
+    safety_ev, hull_ev, gather_ev = [], [], []
+    REC = abi.TRAJ_REC_DTYPE.itemsize
+
+    def ev():
+        e = torch.cuda.Event(enable_timing=True); e.record(); return e
 
     def step():
-        be.replan(d_committed, d_guess)
+        if sharded_hulls:
+            # hulls of my agents' committed trajectories -> all-gather of the hull blocks -> separator + QP
+            e0 = ev()
+            be.hulls(d_local, d_guess, hx.local)
+            e1 = ev()
+            blocks = hx.gather()
+            e2 = ev()
+            hull_ev.append((e0, e1)); gather_ev.append((e1, e2))
+            be.replan_hulls(blocks, d_guess)
+        else:
+            be.replan(d_committed, d_guess)
         if not args.safety:
-            ex.gather(be.d_commit, d_committed)
+            if sharded_hulls:
+                d_local.copy_(be.d_commit)                  # my agents' new committed trajectories
+            else:
+                e1 = ev()
+                ex.gather(be.d_commit, d_committed)
+                gather_ev.append((e1, ev()))
             return
         ex.gather(be.d_commit, d_new)                   # everyone's new trajectory
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0 = ev()
         be.safety_commit(d_committed, d_new, d_guess if world == 1 else d_guess_all, d_committed_next, d_accept)
-        e1.record(); safety_ev.append((e0, e1))
+        safety_ev.append((e0, ev()))
         d_committed.copy_(d_committed_next)
+        if sharded_hulls:
+            d_local.view(S, n_local * REC).copy_(d_committed.view(S, N * REC)[:, first_local * REC:(first_local + n_local) * REC])
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -160,7 +218,7 @@ def main():
     barrier()
     be.enable_timing(True)
     be.reset_timing()
-    safety_ev.clear()
+    safety_ev.clear(); hull_ev.clear(); gather_ev.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -170,8 +228,13 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
+
+    def mean_ms(pairs):
+        return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else 0.0
     qp_ms, n_launch = be.kernel_time_ms(2)
     hull_ms, _ = be.kernel_time_ms(0)
+    if sharded_hulls:
+        hull_ms = mean_ms(hull_ev)
     sep_ms, _ = be.kernel_time_ms(1)
     seq_ms, _ = be.kernel_time_ms(3)
     be.enable_timing(False)
@@ -179,29 +242,40 @@ def main():
     sol = be.solutions()
     status = sol["stats"]["status"].astype(int)
     iters = sol["stats"]["iters"].astype(int)
-    hx, hn = be.debug_hulls(0)
     n_states = int(sol[0]["n_states"])
     replans_per_step = S * N
     value = replans_per_step * args.steps / dt
 
     if rank == 0:
-        bytes_per_replan = algorithmic_bytes(p, scenes[0], hn, n_states)
+        from neptune_amd.backend import hulls_batch
+        _, hn, _, _ = hulls_batch(com[0], float(gue[0, 0]["t_start"]), p.num_pol, p.T_span, p.drone_radius)   # vertex counts of scene 0
+        bytes_per_replan = algorithmic_bytes(p, scene0, hn, n_states)
         launch_replans = S * n_local
         achieved = bytes_per_replan * launch_replans / (qp_ms * 1e-3) / 1e9 if qp_ms > 0 else 0.0
+        if world == 1:
+            sharding = "one GPU: all %d agents of every scene" % N
+        elif sharded_hulls:
+            sharding = ("agents of every scene block-sharded by id, %d per GPU; per step one all-gather (RCCL) of the interval hulls of "
+                        "the local agents' committed trajectories (%d B per agent and scene)" % (n_local, be.hull_block_bytes() // (S * n_local)))
+        else:
+            sharding = "agents of every scene block-sharded by id, %d per GPU; per step one all-gather (RCCL) of the committed trajectory records" % n_local
         out = {
             "metric": "backend_replans_per_sec", "value": value, "unit": "replans/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "%d agents + %d static obstacles, K=8, %d seeded scenes in flight per step (seeds 0..%d)" % (N, M, S, S - 1),
-                       "agents": N, "obstacles": M, "scenes_in_flight": S, "replans_per_step": replans_per_step,
-                       "sharding": "agents block-sharded by id, %d per GPU, all-gather of committed records per step" % n_local,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "%d agents + %d static obstacles, K=8, %d seeded scenes in flight per GPU per step (seeds 0..%d over %d GPU%s)"
+                                   % (N, M, args.scenes, S - 1, world, "" if world == 1 else "s"),
+                       "agents": N, "obstacles": M, "scenes_in_flight": S, "scenes_per_gpu": args.scenes,
+                       "replans_per_step": replans_per_step, "replans_per_gpu_per_step": S * n_local,
+                       "sharding": sharding,
                        "params": "reference neptune_mtlp_benchmark.yaml (T_span 0.5, num_pol 8, weight 1000, v 2, a 3)"},
             "solver": {"status_ok": int((status == 0).sum()), "status_relaxed": int((status == 1).sum()),
                        "status_failed": int((status == 2).sum()), "ipm_iters_mean": float(iters.mean()),
                        "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum())},
-            "p50_solve_ms": seq_ms,
-            "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "launches": n_launch},
-            "safety": ({"ms": float(np.mean([a.elapsed_time(b) for a, b in safety_ev])), "accepted_frac": float(d_accept.float().mean().item())}
+            "p50_solve_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),
+            "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange": mean_ms(gather_ev),
+                          "launches": n_launch},
+            "safety": ({"ms": mean_ms(safety_ev), "accepted_frac": float(d_accept.float().mean().item())}
                        if args.safety else None),
             "roofline": {"bound": "hbm", "kernel": "qp_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": measured_traffic(),
@@ -209,8 +283,8 @@ def main():
                          "note": "latency-bound path: ~%d dependent interior-point iterations per replan" % round(float(iters.mean()))},
             "reference_budget": "reference TimeLimit 0.05 s/solve, replan timer 20 Hz/agent => <= %d replans/s for %d agents" % (20 * N, N),
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(p, scenes)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(p, mine)
         print(json.dumps(out))
     if use_dist:
         tdist.barrier()

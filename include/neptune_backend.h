@@ -243,6 +243,20 @@ int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_
                      const void* d_ent, nep_solution* d_solution, double* d_states,
                      nep_traj_rec* d_commit, void* stream);
 
+/* Sharded hulls for multi-GPU rounds.  Instead of every rank rebuilding the hulls of all N
+ * committed trajectories, a rank computes the interval hulls of ITS n_local agents (every scene)
+ * into one block of nep_batch_hull_block_bytes() bytes, the blocks of all ranks are all-gathered
+ * (rank order = agent-id order, dist.shard), and nep_batch_replan_hulls runs the separator and the
+ * QP against the n_blocks = N / n_local gathered blocks.  Bit-identical to nep_batch_replan.
+ *   d_committed_local : device, [n_scenes][n_local] nep_traj_rec of the local agents
+ *   d_block           : device, one block (out);   d_blocks : device, n_blocks consecutive blocks */
+int64_t nep_batch_hull_block_bytes(const nep_batch_t* h);
+int nep_batch_hulls(nep_batch_t* h, const nep_traj_rec* d_committed_local, const nep_guess* d_guess,
+                    void* d_block, void* stream);
+int nep_batch_replan_hulls(nep_batch_t* h, const void* d_blocks, int32_t n_blocks,
+                           const nep_guess* d_guess, const void* d_ent, nep_solution* d_solution,
+                           double* d_states, nep_traj_rec* d_commit, void* stream);
+
 /* Dense per-slot entangle block consumed by nep_batch_replan when enable_entangle != 0:
  *   int32 case_id[NEP_MAX_POL][N]   (0 = no active case for that agent at that segment,
  *                                    else the alphas case id, solver_gurobi_poly.cpp:624-631)

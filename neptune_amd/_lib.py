@@ -19,6 +19,7 @@ EXPORTS = [
     "nep_batch_replan", "nep_batch_ent_bytes", "nep_batch_wait", "nep_batch_kernel_time", "nep_batch_enable_timing",
     "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
     "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
+    "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
@@ -75,6 +76,9 @@ def lib():
     L.nep_batch_debug_phase_cycles.argtypes = [vp, i, C.POINTER(C.c_int64)]
     L.nep_batch_safety_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.nep_batch_debug_conflicts.argtypes = [vp, i, C.POINTER(C.c_uint8)]
+    L.nep_batch_hull_block_bytes.argtypes = [vp]; L.nep_batch_hull_block_bytes.restype = C.c_int64
+    L.nep_batch_hulls.argtypes = [vp, vp, vp, vp, vp]
+    L.nep_batch_replan_hulls.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp]
     ppwp, prec, phdr = C.POINTER(abi.nep_pwp), C.POINTER(abi.nep_traj_rec), C.POINTER(abi.nep_wire_header)
     pu8 = C.POINTER(C.c_uint8)
     L.nep_pwp_compose.argtypes = [d, d, ppwp, ppwp, ppwp]

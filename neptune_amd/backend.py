@@ -219,6 +219,24 @@ class BatchBackend:
                                      self.d_solution.data_ptr(), self.d_states.data_ptr(),
                                      self.d_commit.data_ptr() if want_commit else None, st.cuda_stream))
 
+    # ---- sharded hulls (multi-GPU rounds): hulls of the local agents -> all-gather -> replan -------
+    def hull_block_bytes(self):
+        return int(lib().nep_batch_hull_block_bytes(self._h))
+
+    def hulls(self, d_committed_local, d_guess, d_block, stream=None):
+        """Interval hulls of the local agents' committed trajectories ([S][n_local] records) into d_block."""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_hulls(self._h, d_committed_local.data_ptr(), d_guess.data_ptr(), d_block.data_ptr(), st.cuda_stream))
+
+    def replan_hulls(self, d_blocks, d_guess, d_ent=None, stream=None, want_commit=True):
+        """Separator + QP of every slot against the gathered hull blocks of all ranks."""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        n_blocks = self.N // self.n_local
+        check(lib().nep_batch_replan_hulls(self._h, d_blocks.data_ptr(), n_blocks, d_guess.data_ptr(),
+                                           d_ent.data_ptr() if d_ent is not None else None,
+                                           self.d_solution.data_ptr(), self.d_states.data_ptr(),
+                                           self.d_commit.data_ptr() if want_commit else None, st.cuda_stream))
+
     def safety_commit(self, d_prev, d_new, d_guess, d_final, d_accept=None, stream=None):
         """Post-solve safety check + commit (nep_batch_safety_commit); tensors are device byte/int32 tensors."""
         st = stream if stream is not None else self.torch.cuda.current_stream(self.device)

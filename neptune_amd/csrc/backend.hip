@@ -546,6 +546,65 @@ int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_
   return E.run(d_committed, h->cfg.num_agents, ps, (hipStream_t)stream);
 }
 
+// ---- sharded hulls: a rank computes the interval hulls of its own agents' committed trajectories
+// into one block, the blocks of all ranks are all-gathered, and every rank runs separator + QP
+// against the gathered blocks (kernels address them through hull_ref, nep_device.h) -------------
+namespace {
+struct HullBlock { size_t xy, nv, xy0, nv0, bend, bend_n, bytes; };
+HullBlock hull_block_layout(int n_scenes, int per, int np) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  HullBlock b{};
+  const size_t e = (size_t)n_scenes * per;
+  size_t o = 0;
+  b.xy = o; o = up(o + e * np * kHullV * 2 * sizeof(double));
+  b.nv = o; o = up(o + e * np * sizeof(int));
+  b.xy0 = o; o = up(o + e * np * 2 * sizeof(double));
+  b.nv0 = o; o = up(o + e * np * sizeof(int));
+  b.bend = o; o = up(o + e * kBend * 2 * sizeof(double));
+  b.bend_n = o; o = up(o + e * sizeof(int));
+  b.bytes = o;
+  return b;
+}
+void point_at_block(ProblemSet& ps, const HullBlock& b, void* base) {
+  char* p = (char*)base;
+  ps.hull_xy = (double*)(p + b.xy); ps.hull_nv = (int*)(p + b.nv); ps.hull0_xy = (double*)(p + b.xy0); ps.hull0_nv = (int*)(p + b.nv0);
+  ps.bend_xy = (double*)(p + b.bend); ps.bend_n = (int*)(p + b.bend_n);
+}
+}  // namespace
+
+int64_t nep_batch_hull_block_bytes(const nep_batch_t* h) {
+  return h ? (int64_t)hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol).bytes : 0;
+}
+
+int nep_batch_hulls(nep_batch_t* h, const nep_traj_rec* d_committed_local, const nep_guess* d_guess, void* d_block, void* stream) {
+  if (!h || !d_committed_local || !d_guess || !d_block) return fail(NEP_E_ARG, "null argument");
+  Engine& E = h->eng;
+  const HullBlock b = hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol);
+  ProblemSet ps{};
+  E.fill(ps);
+  point_at_block(ps, b, d_block);
+  ps.guess = d_guess;
+  launch_hulls(d_committed_local, h->cfg.n_scenes, h->cfg.n_local, d_guess, E.sp, ps, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int nep_batch_replan_hulls(nep_batch_t* h, const void* d_blocks, int32_t n_blocks, const nep_guess* d_guess, const void* d_ent,
+                           nep_solution* d_solution, double* d_states, nep_traj_rec* d_commit, void* stream) {
+  if (!h || !d_blocks || !d_guess || !d_solution) return fail(NEP_E_ARG, "null argument");
+  if (n_blocks < 1 || n_blocks * h->cfg.n_local != h->cfg.num_agents) return fail(NEP_E_ARG, "n_blocks * n_local must equal num_agents");
+  Engine& E = h->eng;
+  const HullBlock b = hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol);
+  ProblemSet ps{};
+  E.fill(ps);
+  point_at_block(ps, b, const_cast<void*>(d_blocks));
+  ps.hull_pb = h->cfg.n_local; ps.hull_bstride = (long)b.bytes;
+  ps.guess = d_guess; ps.solution = d_solution; ps.states = d_states; ps.commit = d_commit;
+  ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
+  ps.lines_override = 0;
+  return E.run(nullptr, 0, ps, (hipStream_t)stream);
+}
+
 int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new, const nep_guess* d_guess,
                             nep_traj_rec* d_final, int32_t* d_accept, void* stream) {
   if (!h || !d_prev || !d_new || !d_guess || !d_final) return fail(NEP_E_ARG, "null argument");

@@ -307,11 +307,12 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
   if (c < nH) {
     const int j = c;
     if (sp.skip_own && j == cx.own) return false;
-    const long h = ((long)cx.scene * nH + j) * sp.num_pol + seg;
-    nA = ps.hull_nv[h];
+    const HullRef hr = hull_ref(ps, nH, cx.scene, j);
+    const long h = hr.e * sp.num_pol + seg;
+    nA = blk(ps.hull_nv, hr.boff)[h];
     if (nA <= 0) return false;
     ordered = true;
-    if (stage) { const double2* src = (const double2*)(ps.hull_xy + h * kHullV * 2); for (int v = 0; v < nA; v++) myA[v] = src[v]; }
+    if (stage) { const double2* src = (const double2*)(blk(ps.hull_xy, hr.boff) + h * kHullV * 2); for (int v = 0; v < nA; v++) myA[v] = src[v]; }
     return true;
   } else if (c < nH + N) {
     const int j = c - nH;
@@ -352,14 +353,15 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     const int j = e / kBend, k = e % kBend + 1;
     if (j == cx.own) return false;
     const int case_id = ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * N + j];
-    const int nb = ps.bend_n[(long)cx.scene * N + j];
+    const HullRef hr = hull_ref(ps, N, cx.scene, j);
+    const int nb = blk(ps.bend_n, hr.boff)[hr.e];
     if (!(case_id != 0 && k != case_id && k <= nb)) return false;  // :631-636
-    const double* bp = ps.bend_xy + ((long)cx.scene * N + j) * kBend * 2;
-    const long h0 = ((long)cx.scene * N + j) * sp.num_pol + seg;
+    const double* bp = blk(ps.bend_xy, hr.boff) + hr.e * kBend * 2;
+    const long h0 = hr.e * sp.num_pol + seg;
     double pAx, pAy, pBx, pBy;
     if (k == 1) {  // :719-724
-      if (ps.hull0_nv[h0] <= 0) return false;
-      const double hx0 = ps.hull0_xy[h0 * 2], hy0 = ps.hull0_xy[h0 * 2 + 1];
+      if (blk(ps.hull0_nv, hr.boff)[h0] <= 0) return false;
+      const double hx0 = blk(ps.hull0_xy, hr.boff)[h0 * 2], hy0 = blk(ps.hull0_xy, hr.boff)[h0 * 2 + 1];
       pAx = (1 - sp.long_length) * bp[2 * (nb - 1)] + sp.long_length * hx0;
       pAy = (1 - sp.long_length) * bp[2 * (nb - 1) + 1] + sp.long_length * hy0;
       pBx = hx0; pBy = hy0;

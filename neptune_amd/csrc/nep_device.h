@@ -42,6 +42,11 @@ struct ProblemSet {
   int* hull0_nv;                 // [scenes][N][num_pol]
   double* bend_xy;               // [scenes][N][kBend][2]
   int* bend_n;                   // [scenes][N]
+  // Sharded hulls (nep_batch_replan_hulls): the six arrays above are the first of N / hull_pb
+  // equal blocks, hull_bstride bytes apart, each holding hull_pb agents per scene — the layout an
+  // all-gather of per-rank blocks produces.  hull_pb == 0: one block (everything above as stated).
+  int hull_pb;
+  long hull_bstride;
   // separator output
   double* line_nd;               // [slots][NEP_MAX_POL][lines_cap][3]
   int* line_cnt;                 // [slots][NEP_MAX_POL]
@@ -58,6 +63,15 @@ struct ProblemSet {
   nep_traj_rec* commit;          // [slots] or null
   long long* dbg;                // [slots][16] phase cycle counters (development aid) or null
 };
+
+// entry index (scene-major inside its block) and byte offset of the block of agent j's hull data
+struct HullRef { long e; long boff; };
+__host__ __device__ inline HullRef hull_ref(const ProblemSet& ps, int per_scene, int scene, int j) {
+  if (ps.hull_pb <= 0) return HullRef{(long)scene * per_scene + j, 0L};
+  const int b = j / ps.hull_pb;
+  return HullRef{(long)scene * ps.hull_pb + (j - b * ps.hull_pb), (long)b * ps.hull_bstride};
+}
+template <typename T> __host__ __device__ inline T* blk(T* base, long boff) { return (T*)((char*)base + boff); }
 
 struct SampleSched {             // per K: n, seg[], dt[]
   const int* n;                  // [kMaxK+1]

@@ -46,8 +46,13 @@ class RoundExchange:
             return committed_out
         if self.gathered is None:   # single rank launched under torch.distributed.run: same collective path
             self.gathered = torch.empty(self.piece, dtype=torch.uint8, device=commit_local.device)
-        if hasattr(dist, "all_gather_into_tensor") and commit_local.is_cuda:
+        if commit_local.is_cuda and dist.get_backend(self.group) == "nccl":
             dist.all_gather_into_tensor(self.gathered, commit_local, group=self.group)
+        elif commit_local.is_cuda:   # gloo with device tensors (single-GPU debugging): through host memory
+            mine = commit_local.cpu().contiguous()
+            pieces = [torch.empty_like(mine) for _ in range(W)]
+            dist.all_gather(pieces, mine, group=self.group)
+            self.gathered.copy_(torch.cat(pieces).to(self.gathered.device))
         else:
             pieces = list(self.gathered.view(W, self.piece).unbind(0))
             dist.all_gather(pieces, commit_local.contiguous(), group=self.group)
@@ -55,6 +60,38 @@ class RoundExchange:
         src = self.gathered.view(W, S, nl * REC_BYTES).permute(1, 0, 2)
         committed_out.view(S, W, nl * REC_BYTES).copy_(src)
         return committed_out
+
+
+class HullExchange:
+    """all-gather of per-rank hull blocks (nep_batch_hulls -> nep_batch_replan_hulls): what the
+    separator consumes of the other agents' committed trajectories is their interval hulls, so each
+    rank builds the hulls of its own agents only and the blocks travel instead of the records —
+    the hull work is sharded with the agents.  The gathered buffer is used in place: the kernels
+    address it block by block (rank order = agent-id order), so no permute follows the collective."""
+
+    def __init__(self, block_bytes, world=1, rank=0, group=None, device="cpu"):
+        import torch
+        self.torch = torch
+        self.bb, self.world, self.rank, self.group = block_bytes, world, rank, group
+        self.blocks = torch.zeros(world * block_bytes, dtype=torch.uint8, device=device)
+
+    @property
+    def local(self):
+        """this rank's block inside the gathered buffer (write the hulls here)"""
+        return self.blocks[self.rank * self.bb:(self.rank + 1) * self.bb]
+
+    def gather(self):
+        import torch.distributed as dist
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            return self.blocks
+        if self.blocks.is_cuda and dist.get_backend(self.group) == "nccl":
+            dist.all_gather_into_tensor(self.blocks, self.local, group=self.group)    # in place (NCCL/RCCL allow it)
+        else:   # gloo (CPU tests, single-GPU debugging): through host memory
+            mine = self.local.cpu().contiguous()
+            pieces = [self.torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(pieces, mine, group=self.group)
+            self.blocks.copy_(self.torch.cat(pieces).to(self.blocks.device))
+        return self.blocks
 
 
 def stack_scenes(scenes):

@@ -106,3 +106,43 @@ def test_two_rank_rounds_match_single_process():
     for r in range(world):
         out = np.frombuffer(got[r], dtype=abi.TRAJ_REC_DTYPE).reshape(S, N)
         assert out.tobytes() == expect.tobytes(), "rank %d snapshot differs from the single-process run" % r
+
+
+def _hull_worker(rank, world, port, bb, rounds, result_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    hx = ndist.HullExchange(bb, world, rank, device="cpu")
+    out = []
+    for r in range(rounds):
+        hx.local.copy_(torch.arange(bb, dtype=torch.int64).mul(rank + 3 + r).remainder(251).to(torch.uint8))
+        out.append(hx.gather().numpy().tobytes())
+    result_q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_hull_block_exchange():
+    """Sharded hulls: after the collective every rank holds every rank's block, in rank (= agent id)
+    order, which is the layout nep_batch_replan_hulls addresses."""
+    world, bb, rounds = 2, 4096, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_hull_worker, args=(r, world, port, bb, rounds, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(rounds):
+        want = b"".join((np.arange(bb, dtype=np.int64) * (k + 3 + r) % 251).astype(np.uint8).tobytes() for k in range(world))
+        for k in range(world):
+            assert got[k][r] == want
+
+
+def test_single_rank_hull_exchange_is_in_place():
+    hx = ndist.HullExchange(1024, 1, 0)
+    hx.local.fill_(7)
+    assert hx.gather() is hx.blocks and int(hx.blocks.sum()) == 7 * 1024

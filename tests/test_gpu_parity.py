@@ -410,6 +410,54 @@ def test_multi_scene_batch_and_chained_rounds(be, oracle):
     bb.close()
 
 
+@pytest.mark.parametrize("world,entangle", [(2, False), (4, False), (4, True)])
+def test_sharded_hull_blocks_equal_the_single_rank_replan(be, world, entangle):
+    """Multi-GPU layout on one GPU: every "rank" computes the hull block of its own agents, the
+    blocks are concatenated as the all-gather would, and separator + QP against the blocks must
+    give the single-rank nep_batch_replan results bit for bit (same kernels, same inputs)."""
+    import dataclasses
+    from neptune_amd import dist as ndist
+    N, S = 8, 3
+    scenes = [scene.make_scene(N, 6, seed=70 + s) for s in range(S)]
+    for sc in scenes[1:]:
+        sc["statics"] = scenes[0]["statics"]
+    p = dataclasses.replace(scenes[0]["par"], enable_entangle=entangle)
+    com, gue = ndist.stack_scenes(scenes)
+    case = np.stack([scene.synthetic_entangle(sc, seed=9, frac=0.5) for sc in scenes]) if entangle else None   # [S][N][8][N]
+    full = be.BatchBackend(p, scenes[0]["statics"], n_scenes=S)
+    d_ent = full.torch.from_numpy(case.reshape(-1).copy()).to(full.device) if entangle else None
+    full.replan(full.to_device(com), full.to_device(gue), d_ent=d_ent)
+    want = full.solutions().reshape(S, N)
+    want_commit = full.commits().reshape(S, N)
+    nl = N // world
+    ranks = [be.BatchBackend(p, scenes[0]["statics"], first_local=r * nl, n_local=nl, n_scenes=S) for r in range(world)]
+    bb = ranks[0].hull_block_bytes()
+    assert all(r.hull_block_bytes() == bb for r in ranks) and bb % 256 == 0
+    blocks = full.torch.zeros(world * bb, dtype=full.torch.uint8, device=full.device)
+    g_loc = [ranks[r].to_device(np.ascontiguousarray(gue[:, r * nl:(r + 1) * nl])) for r in range(world)]
+    for r in range(world):
+        ranks[r].hulls(ranks[r].to_device(np.ascontiguousarray(com[:, r * nl:(r + 1) * nl])), g_loc[r], blocks[r * bb:(r + 1) * bb])
+    n_lines = 0
+    for r in range(world):
+        e = None
+        if entangle:
+            e = full.torch.from_numpy(np.ascontiguousarray(case[:, r * nl:(r + 1) * nl]).reshape(-1).copy()).to(full.device)
+        ranks[r].replan_hulls(blocks, g_loc[r], d_ent=e)
+        got = ranks[r].solutions().reshape(S, nl)
+        ref = want[:, r * nl:(r + 1) * nl]
+        np.testing.assert_array_equal(got["coeff"], ref["coeff"])
+        np.testing.assert_array_equal(got["times"], ref["times"])
+        for f in ("status", "iters", "n_lines", "n_lp", "n_lp_failed", "n_rows", "objective"):
+            np.testing.assert_array_equal(got["stats"][f], ref["stats"][f], err_msg=f)
+        gc = ranks[r].commits().reshape(S, nl)
+        np.testing.assert_array_equal(gc["pwp"]["coeff"], want_commit[:, r * nl:(r + 1) * nl]["pwp"]["coeff"])
+        n_lines += int(got["stats"]["n_lines"].sum())
+    assert n_lines > 0
+    for r in ranks:
+        r.close()
+    full.close()
+
+
 def test_safety_check_and_commit(be, oracle):
     """conflict matrix (GJK on the new trajectories' hulls), id-ordered
     resolution and the committed records, bit for bit against the oracle."""
