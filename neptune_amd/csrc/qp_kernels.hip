@@ -182,17 +182,22 @@ __device__ __forceinline__ bool chol_impl(lds_dptr sM, lds_dptr sInvD, int lane)
 template <int N>
 __device__ __forceinline__ double solve_impl(lds_dptr sM, lds_dptr sInvD, int lane, double b) {
   const int row = lane < N ? lane : N - 1;
-  double Lr[N], Uc[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    Lr[j] = sM[row * MS + j];     // row i of L (valid for j < i)
-    Uc[j] = sM[j * MS + row];     // column i of L (valid for j > i)
-  }
   const double dinv = sInvD[row];
+  {
+    double Lr[N];                   // row i of L (valid for j < i)
 #pragma unroll
-  for (int j = 0; j < N; j++) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Lr[j], xj, b); b = lane == j ? xj : (lane > j ? upd : b); }
+    for (int j = 0; j < N; j++) Lr[j] = sM[row * MS + j];
 #pragma unroll
-  for (int j = N - 1; j >= 0; j--) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Uc[j], xj, b); b = lane == j ? xj : (lane < j ? upd : b); }
+    for (int j = 0; j < N; j++) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Lr[j], xj, b); b = lane == j ? xj : (lane > j ? upd : b); }
+  }
+  __builtin_amdgcn_sched_barrier(0);   // the column loads below must not be hoisted over the forward pass (register footprint of the callee)
+  {
+    double Uc[N];                   // column i of L (valid for j > i)
+#pragma unroll
+    for (int j = 0; j < N; j++) Uc[j] = sM[j * MS + row];
+#pragma unroll
+    for (int j = N - 1; j >= 0; j--) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Uc[j], xj, b); b = lane == j ? xj : (lane < j ? upd : b); }
+  }
   return b;
 }
 

@@ -66,7 +66,7 @@ class HullExchange:
     """all-gather of per-rank hull blocks (nep_batch_hulls -> nep_batch_replan_hulls): what the
     separator consumes of the other agents' committed trajectories is their interval hulls, so each
     rank builds the hulls of its own agents only and the blocks travel instead of the records —
-    the hull work is sharded with the agents.  The gathered buffer is used in place: the kernels
+    the hull work is sharded with the agents.  The gathered buffer is used as it arrives: the kernels
     address it block by block (rank order = agent-id order), so no permute follows the collective."""
 
     def __init__(self, block_bytes, world=1, rank=0, group=None, device="cpu"):
@@ -74,18 +74,16 @@ class HullExchange:
         self.torch = torch
         self.bb, self.world, self.rank, self.group = block_bytes, world, rank, group
         self.blocks = torch.zeros(world * block_bytes, dtype=torch.uint8, device=device)
-
-    @property
-    def local(self):
-        """this rank's block inside the gathered buffer (write the hulls here)"""
-        return self.blocks[self.rank * self.bb:(self.rank + 1) * self.bb]
+        # this rank's block (write the hulls here): the gathered buffer itself when there is nothing
+        # to gather, else a separate send buffer (no aliasing between a collective's input and output)
+        self.local = self.blocks if world == 1 else torch.zeros(block_bytes, dtype=torch.uint8, device=device)
 
     def gather(self):
         import torch.distributed as dist
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
             return self.blocks
         if self.blocks.is_cuda and dist.get_backend(self.group) == "nccl":
-            dist.all_gather_into_tensor(self.blocks, self.local, group=self.group)    # in place (NCCL/RCCL allow it)
+            dist.all_gather_into_tensor(self.blocks, self.local, group=self.group)
         else:   # gloo (CPU tests, single-GPU debugging): through host memory
             mine = self.local.cpu().contiguous()
             pieces = [self.torch.empty_like(mine) for _ in range(self.world)]
