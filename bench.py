@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--exchange", choices=["hulls", "records"], default="hulls",
                     help="N > 1: all-gather the interval hulls of the local agents' committed trajectories (hull work "
                          "sharded with the agents) or the trajectory records themselves (every rank rebuilds all hulls)")
+    ap.add_argument("--chunks", type=int, default=2,
+                    help="N > 1 with --exchange hulls: scene chunks pipelined so that one chunk's all-gather overlaps the other's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--safety", action="store_true",
                     help="also run the post-solve safety check + commit (SURVEY §8f rank 1) in every step")
@@ -162,42 +164,63 @@ def main():
         return out.numpy().view(arr.dtype).reshape((S,) + arr.shape[1:])
     com, gue = share(com_l), share(gue_l)
 
-    be = BatchBackend(p, statics, first_local=first_local, n_local=n_local, n_scenes=S, device=dev)
-    d_committed = be.to_device(com)
-    d_guess = be.to_device(np.ascontiguousarray(gue[:, first_local:first_local + n_local]))
-    ex = ndist.RoundExchange(S, N, world, rank, device=dev)
     sharded_hulls = world > 1 and args.exchange == "hulls"
-    hx = ndist.HullExchange(be.hull_block_bytes(), world, rank, device=dev) if sharded_hulls else None
-    d_local = be.to_device(np.ascontiguousarray(com[:, first_local:first_local + n_local])) if sharded_hulls else None
+    C = args.chunks if (sharded_hulls and not args.safety and S % max(args.chunks, 1) == 0) else 1
+    Sc = S // C
+    # one handle per scene chunk (C == 1: all scenes); chunk k holds scenes [k*Sc, (k+1)*Sc)
+    bes = [BatchBackend(p, statics, first_local=first_local, n_local=n_local, n_scenes=Sc, device=dev) for _ in range(C)]
+    be = bes[0]
+    d_committed = be.to_device(com) if C == 1 else None
+    d_guess_c = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)]
+    d_guess = d_guess_c[0]
+    ex = ndist.RoundExchange(S, N, world, rank, device=dev)
+    hxs = [ndist.HullExchange(bes[k].hull_block_bytes(), world, rank, device=dev) for k in range(C)] if sharded_hulls else None
+    d_local_c = [bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)] if sharded_hulls else None
     d_committed_next = torch.empty_like(d_committed) if args.safety else None
     d_new = torch.empty_like(d_committed) if args.safety else None
     d_accept = torch.zeros(S * N, dtype=torch.int32, device=dev) if args.safety else None
     d_guess_all = be.to_device(np.ascontiguousarray(gue)) if args.safety else None   # t_start source of the safety pass
     safety_ev, hull_ev, gather_ev = [], [], []
     REC = abi.TRAJ_REC_DTYPE.itemsize
+    pending = [None] * C
 
     def ev():
         e = torch.cuda.Event(enable_timing=True); e.record(); return e
 
+    def start_exchange(k, src):
+        """hulls of my agents' committed trajectories (chunk k) -> start the all-gather of the hull blocks"""
+        e0 = ev()
+        bes[k].hulls(src, d_guess_c[k], hxs[k].local)
+        hull_ev.append((e0, ev()))
+        pending[k] = hxs[k].gather_async()
+
     def step():
+        if sharded_hulls and not args.safety:
+            # Pipelined over the scene chunks: right after chunk k's replan its next hulls are built and
+            # their all-gather is started, so the collective of one chunk runs under the other chunk's
+            # separator + QP kernels.  One step = every chunk replans once.
+            for k in range(C):
+                if pending[k] is None:
+                    start_exchange(k, d_local_c[k])
+            for k in range(C):
+                e1 = ev()
+                pending[k].wait()
+                gather_ev.append((e1, ev()))                 # what the stream still had to wait for
+                bes[k].replan_hulls(hxs[k].blocks, d_guess_c[k])
+                start_exchange(k, bes[k].d_commit)           # my agents' new committed trajectories
+            return
         if sharded_hulls:
-            # hulls of my agents' committed trajectories -> all-gather of the hull blocks -> separator + QP
-            e0 = ev()
-            be.hulls(d_local, d_guess, hx.local)
+            start_exchange(0, d_local_c[0])
             e1 = ev()
-            blocks = hx.gather()
-            e2 = ev()
-            hull_ev.append((e0, e1)); gather_ev.append((e1, e2))
-            be.replan_hulls(blocks, d_guess)
+            pending[0].wait()
+            gather_ev.append((e1, ev()))
+            be.replan_hulls(hxs[0].blocks, d_guess)
         else:
             be.replan(d_committed, d_guess)
         if not args.safety:
-            if sharded_hulls:
-                d_local.copy_(be.d_commit)                  # my agents' new committed trajectories
-            else:
-                e1 = ev()
-                ex.gather(be.d_commit, d_committed)
-                gather_ev.append((e1, ev()))
+            e1 = ev()
+            ex.gather(be.d_commit, d_committed)
+            gather_ev.append((e1, ev()))
             return
         ex.gather(be.d_commit, d_new)                   # everyone's new trajectory
         e0 = ev()
@@ -205,7 +228,7 @@ def main():
         safety_ev.append((e0, ev()))
         d_committed.copy_(d_committed_next)
         if sharded_hulls:
-            d_local.view(S, n_local * REC).copy_(d_committed.view(S, N * REC)[:, first_local * REC:(first_local + n_local) * REC])
+            d_local_c[0].view(S, n_local * REC).copy_(d_committed.view(S, N * REC)[:, first_local * REC:(first_local + n_local) * REC])
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -216,8 +239,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    be.enable_timing(True)
-    be.reset_timing()
+    for b in bes:
+        b.enable_timing(True)
+        b.reset_timing()
     safety_ev.clear(); hull_ev.clear(); gather_ev.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -231,15 +255,16 @@ def main():
 
     def mean_ms(pairs):
         return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else 0.0
-    qp_ms, n_launch = be.kernel_time_ms(2)
+    qp_ms, n_launch = be.kernel_time_ms(2)           # per launch of one chunk (chunk 0)
     hull_ms, _ = be.kernel_time_ms(0)
     if sharded_hulls:
         hull_ms = mean_ms(hull_ev)
     sep_ms, _ = be.kernel_time_ms(1)
     seq_ms, _ = be.kernel_time_ms(3)
-    be.enable_timing(False)
+    for b in bes:
+        b.enable_timing(False)
 
-    sol = be.solutions()
+    sol = np.concatenate([b.solutions() for b in bes])
     status = sol["stats"]["status"].astype(int)
     iters = sol["stats"]["iters"].astype(int)
     n_states = int(sol[0]["n_states"])
@@ -250,13 +275,14 @@ def main():
         from neptune_amd.backend import hulls_batch
         _, hn, _, _ = hulls_batch(com[0], float(gue[0, 0]["t_start"]), p.num_pol, p.T_span, p.drone_radius)   # vertex counts of scene 0
         bytes_per_replan = algorithmic_bytes(p, scene0, hn, n_states)
-        launch_replans = S * n_local
+        launch_replans = Sc * n_local
         achieved = bytes_per_replan * launch_replans / (qp_ms * 1e-3) / 1e9 if qp_ms > 0 else 0.0
         if world == 1:
             sharding = "one GPU: all %d agents of every scene" % N
         elif sharded_hulls:
-            sharding = ("agents of every scene block-sharded by id, %d per GPU; per step one all-gather (RCCL) of the interval hulls of "
-                        "the local agents' committed trajectories (%d B per agent and scene)" % (n_local, be.hull_block_bytes() // (S * n_local)))
+            sharding = ("agents of every scene block-sharded by id, %d per GPU; per step and scene chunk (%d chunks, pipelined) one all-gather "
+                        "(RCCL) of the interval hulls of the local agents' committed trajectories (%d B per agent and scene)"
+                        % (n_local, C, be.hull_block_bytes() // (Sc * n_local)))
         else:
             sharding = "agents of every scene block-sharded by id, %d per GPU; per step one all-gather (RCCL) of the committed trajectory records" % n_local
         out = {
@@ -273,8 +299,8 @@ def main():
                        "status_failed": int((status == 2).sum()), "ipm_iters_mean": float(iters.mean()),
                        "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum())},
             "p50_solve_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),
-            "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange": mean_ms(gather_ev),
-                          "launches": n_launch},
+            "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange_wait": mean_ms(gather_ev),
+                          "launches": n_launch, "launches_per_step": C},
             "safety": ({"ms": mean_ms(safety_ev), "accepted_frac": float(d_accept.float().mean().item())}
                        if args.safety else None),
             "roofline": {"bound": "hbm", "kernel": "qp_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

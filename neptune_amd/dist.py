@@ -78,6 +78,19 @@ class HullExchange:
         # to gather, else a separate send buffer (no aliasing between a collective's input and output)
         self.local = self.blocks if world == 1 else torch.zeros(block_bytes, dtype=torch.uint8, device=device)
 
+    class _Done:
+        def wait(self):
+            return True
+
+    def gather_async(self):
+        """Starts the collective and returns a handle whose wait() makes the current stream wait for it
+        (RCCL runs on its own stream, so kernels enqueued meanwhile overlap with the exchange)."""
+        import torch.distributed as dist
+        if self.blocks.is_cuda and self.world > 1 and dist.get_backend(self.group) == "nccl":
+            return dist.all_gather_into_tensor(self.blocks, self.local, group=self.group, async_op=True)
+        self.gather()
+        return HullExchange._Done()
+
     def gather(self):
         import torch.distributed as dist
         if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
