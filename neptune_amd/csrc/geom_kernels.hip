@@ -39,9 +39,13 @@ __device__ __forceinline__ bool lex_less(double ax, double ay, double bx, double
 }
 
 // Wave-cooperative convex hull of n <= 64 points held one per lane (px,py valid for lane<n).
-// sxy: LDS [64][2] (sorted points), hxy: LDS [132][2] (hull).  Returns the vertex count (uniform).
-// Rank sort across the lanes, then the monotone chain walked by lane 0 with the top two stack
-// entries cached in registers (one LDS read per pop instead of four per test).
+// sxy: LDS [64][2] (sorted points), hxy: LDS [132][2] (hull + the upper chain's stack).  Returns
+// the vertex count (uniform).  Rank sort and duplicate removal across the lanes, then Andrew's
+// monotone chain with the lower chain on lane 0 and the upper chain on lane 1 at the same time.
+// The two chains never test a triple that spans both (the reference formulation guards the upper
+// chain's pops with k >= lo), so each lane evaluates exactly the cross products the serial walk
+// would, in the same order — the output equals the one-stack walk bit for bit.  The top two stack
+// entries are cached in registers (one LDS read per pop instead of four per test).
 __device__ int wave_hull(int n, double px, double py, double* sxy, double* hxy) {
   const int lane = threadIdx.x & 63;
   // rank sort (lexicographic; ties by lane index so that ranks are a permutation)
@@ -57,37 +61,35 @@ __device__ int wave_hull(int n, double px, double py, double* sxy, double* hxy) 
   __syncthreads();
   if (lane < n) { sxy[2 * rank] = px; sxy[2 * rank + 1] = py; }
   __syncthreads();
-  int k = 0;
-  if (lane == 0 && n > 0) {
-    // unique (in place)
-    int m = 0;
-    double lx = 0, ly = 0;
-    for (int i = 0; i < n; i++) {
-      const double x = sxy[2 * i], y = sxy[2 * i + 1];
-      if (m == 0 || x != lx || y != ly) { sxy[2 * m] = x; sxy[2 * m + 1] = y; lx = x; ly = y; m++; }
-    }
-    if (m == 1) { hxy[0] = sxy[0]; hxy[1] = sxy[1]; k = 1; }
-    else {
-      double ax = 0, ay = 0, bx = 0, by = 0;   // h[k-2], h[k-1]
-      for (int i = 0; i < m; i++) {  // lower hull
-        const double x = sxy[2 * i], y = sxy[2 * i + 1];
-        while (k >= 2 && cross3(ax, ay, bx, by, x, y) <= 0.0) { k--; bx = ax; by = ay; if (k >= 2) { ax = hxy[2 * (k - 2)]; ay = hxy[2 * (k - 2) + 1]; } }
-        hxy[2 * k] = x; hxy[2 * k + 1] = y; k++;
-        ax = bx; ay = by; bx = x; by = y;
-      }
-      const int lo = k + 1;
-      for (int i = m - 2; i >= 0; i--) {  // upper hull
-        const double x = sxy[2 * i], y = sxy[2 * i + 1];
-        while (k >= lo && cross3(ax, ay, bx, by, x, y) <= 0.0) { k--; bx = ax; by = ay; if (k >= 2) { ax = hxy[2 * (k - 2)]; ay = hxy[2 * (k - 2) + 1]; } }
-        hxy[2 * k] = x; hxy[2 * k + 1] = y; k++;
-        ax = bx; ay = by; bx = x; by = y;
-      }
-      k--;
+  // unique: sorted position `lane` survives if it differs from its predecessor; new position = number of survivors before it
+  double ux = 0, uy = 0; bool keep = false;
+  if (lane < n) { ux = sxy[2 * lane]; uy = sxy[2 * lane + 1]; keep = lane == 0 || ux != sxy[2 * lane - 2] || uy != sxy[2 * lane - 1]; }
+  const unsigned long long km = __ballot(keep);
+  const int m = __popcll(km);
+  __syncthreads();
+  if (keep) { const int pos = __popcll(km & ((1ull << lane) - 1ull)); sxy[2 * pos] = ux; sxy[2 * pos + 1] = uy; }
+  __syncthreads();
+  if (m == 0) return 0;
+  if (m == 1) { if (lane == 0) { hxy[0] = sxy[0]; hxy[1] = sxy[1]; } __syncthreads(); return 1; }
+  double* hu = hxy + 132;           // upper chain's stack (the lower chain's is hxy itself)
+  int kc = 0;
+  if (lane < 2) {
+    double* st = lane == 0 ? hxy : hu;
+    double ax = 0, ay = 0, bx = 0, by = 0;   // st[kc-2], st[kc-1]
+    for (int i = 0; i < m; i++) {
+      const int idx = lane == 0 ? i : m - 1 - i;
+      const double x = sxy[2 * idx], y = sxy[2 * idx + 1];
+      while (kc >= 2 && cross3(ax, ay, bx, by, x, y) <= 0.0) { kc--; bx = ax; by = ay; if (kc >= 2) { ax = st[2 * (kc - 2)]; ay = st[2 * (kc - 2) + 1]; } }
+      st[2 * kc] = x; st[2 * kc + 1] = y; kc++;
+      ax = bx; ay = by; bx = x; by = y;
     }
   }
-  k = __shfl(k, 0);
+  const int kl = __shfl(kc, 0), ku = __shfl(kc, 1);
   __syncthreads();
-  return k;
+  // hull = lower chain, then the upper chain without its two end points (they are the lower chain's ends)
+  if (lane >= 1 && lane < ku - 1) { hxy[2 * (kl + lane - 1)] = hu[2 * lane]; hxy[2 * (kl + lane - 1) + 1] = hu[2 * lane + 1]; }
+  __syncthreads();
+  return kl + ku - 2;
 }
 
 // Body shared by the batched and the stand-alone hull kernels: one wave computes the inflated
@@ -95,7 +97,7 @@ __device__ int wave_hull(int n, double px, double py, double* sxy, double* hxy) 
 __device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, double T_span, double drone_radius,
                           long out, bool full0, double* __restrict__ hull_xy, int* __restrict__ hull_nv,
                           double* __restrict__ hull0_xy, int* __restrict__ hull0_nv) {
-  __shared__ __attribute__((aligned(16))) double sxy[128], hxy[264];
+  __shared__ __attribute__((aligned(16))) double sxy[128], hxy[264];   // hxy: hull [66][2] + upper-chain stack [66][2]
   __shared__ double cpx[kHullCP], cpy[kHullCP], stimes[NEP_TRAJ_MAX_SEG + 2];
   const int lane = threadIdx.x;
   if (!(r->valid && r->is_agent) || r->pwp.n_seg <= 0) {   // neptune.cpp:244-262, 332
