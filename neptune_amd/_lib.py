@@ -27,6 +27,8 @@ PLAN_EXPORTS = [
     "nep_plan_destroy", "nep_plan_reset", "nep_plan_size", "nep_plan_get", "nep_plan_next_goal",
     "nep_plan_select_a", "nep_plan_splice", "nep_plan_update_delta", "nep_plan_delta",
 ]
+# every symbol include/neptune_entangle.h declares (host-only)
+ENT_EXPORTS = ["nep_ent_sample_points", "nep_ent_propagate_segment", "nep_ent_propagate_guess", "nep_ent_case_ids"]
 
 
 class BackendError(RuntimeError):
@@ -95,6 +97,11 @@ def lib():
     L.nep_plan_splice.argtypes = [vp, i, pd, i]
     L.nep_plan_update_delta.argtypes = [vp, d]
     L.nep_plan_delta.argtypes = [vp]
+    pcfg, pin, pst = C.POINTER(abi.nep_ent_cfg), C.POINTER(abi.nep_ent_inputs), C.POINTER(abi.nep_ent_state)
+    L.nep_ent_sample_points.argtypes = [ppwp, d, d, i, i, pd]
+    L.nep_ent_propagate_segment.argtypes = [pcfg, pin, pst, pd, pd, pd, i, pd]
+    L.nep_ent_propagate_guess.argtypes = [pcfg, pin, pst, vp, i, pi, pi, pi, pi, pst]
+    L.nep_ent_case_ids.argtypes = [i, i, pi, pi, pi, i, pi]
     _lib = L
     return L
 

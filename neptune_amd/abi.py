@@ -98,6 +98,24 @@ class nep_point_a(C.Structure):
                 ("runtime_search", C.c_double), ("t_start", C.c_double)]
 
 
+class nep_ent_cfg(C.Structure):
+    """include/neptune_entangle.h: what KinodynamicSearch holds for the entangle check."""
+    _fields_ = [("num_agents", C.c_int32), ("id", C.c_int32), ("num_pol", C.c_int32), ("num_samples", C.c_int32),
+                ("T_span", C.c_double), ("cable_length", C.c_double), ("n_static", C.c_int32), ("_pad", C.c_int32),
+                ("pb", C.POINTER(C.c_double)), ("static_rep", C.POINTER(C.c_double)), ("static_longest", C.POINTER(C.c_double))]
+
+
+class nep_ent_inputs(C.Structure):
+    _fields_ = [("sampled", C.POINTER(C.c_double)), ("present", C.POINTER(C.c_int32)),
+                ("bend_off", C.POINTER(C.c_int32)), ("bend_xy", C.POINTER(C.c_double))]
+
+
+class nep_ent_state(C.Structure):
+    _fields_ = [("n_alpha", C.c_int32), ("n_bend", C.c_int32), ("cap", C.c_int32), ("n_active", C.c_int32),
+                ("alphas", C.POINTER(C.c_int32)), ("betas", C.POINTER(C.c_double)), ("bend_idx", C.POINTER(C.c_int32)),
+                ("active_cases", C.POINTER(C.c_int32))]
+
+
 def np_dtype(struct):
     return np.dtype(struct)
 

@@ -306,3 +306,75 @@ def synthetic_entangle(sc, seed, frac=0.1):
             s0 = int(rng.integers(0, abi.NEP_MAX_POL))
             case_id[a, s0:, j] = cid                     # active from some knot on
     return case_id
+
+
+def static_reps(statics):
+    """Two representative points per static obstacle (staticObsRep_) and the longest vertex distance from
+    each (staticObsLongestDist_, neptune_ros.cpp:984-1002).  The reference picks the representatives
+    in its ROS setup from a line through the obstacle; here: the first vertex and the one farthest
+    from it (inputs of the path, not part of it)."""
+    reps, longest = [], []
+    for poly in statics:
+        v = np.asarray(poly, dtype=np.float64).reshape(-1, 2)
+        a = v[0]
+        b = v[int(np.argmax(((v - a) ** 2).sum(axis=1)))]
+        reps.append([a, b])
+        longest.append([float(np.sqrt(((v - a) ** 2).sum(axis=1)).max()), float(np.sqrt(((v - b) ** 2).sum(axis=1)).max())])
+    return np.array(reps).reshape(-1, 2, 2), np.array(longest).reshape(-1, 2)
+
+
+def real_entangle(sc, num_samples=3, cable_length=None, use_statics=True):
+    """Entanglement inputs of every agent's back-end call from the actual geometry:
+    the guess is swept through the other agents' sampled committed trajectories and tether polylines
+    with the host library (neptune_amd.entangle), starting from an empty entangle state.  Returns
+    (case_id [N][NEP_MAX_POL][N], entangled_at [N], per-agent result dicts)."""
+    from . import entangle
+    p = sc["par"]; N = p.num_agents
+    com = sc["committed"]
+    reps, longest = static_reps(sc["statics"]) if (use_statics and len(sc["statics"])) else (np.zeros((0, 2, 2)), np.zeros((0, 2)))
+    cable = cable_length if cable_length is not None else p.tether_length
+    case_id = np.zeros((N, abi.NEP_MAX_POL, N), dtype=np.int32)
+    hit = np.zeros(N, dtype=np.int32)
+    res = []
+    bend = [np.array(com[j]["bend"][: int(com[j]["n_bend"])]) for j in range(N)]
+    for a in range(N):
+        g = sc["guesses"][a]
+        t0 = float(g["t_start"])
+        sampled = np.zeros((N, p.num_pol, num_samples + 1, 2))
+        present = np.zeros(N, dtype=np.int32)
+        for j in range(N):
+            if j == a or not com[j]["valid"]:
+                continue
+            sampled[j] = entangle.sample_points(com[j]["pwp"], t0, t0 + p.num_pol * p.T_span, p.num_pol, num_samples)
+            present[j] = 1
+        chk = entangle.EntangleCheck(N, a + 1, p.num_pol, num_samples, p.T_span, cable, p.pb, reps, longest)
+        chk.set_inputs(sampled, present, bend)
+        r = chk.propagate_guess(chk.new_state(), g)
+        case_id[a] = r["case_id"]; hit[a] = r["entangled_at"]
+        res.append(r)
+    return case_id, hit, res
+
+
+def tether_crossing_scene(num_agents, n_static, seed):
+    """A scene in which tethers actually get crossed between an agent and its base: every other agent
+    hovers just beyond somebody else's guessed path (seen from its own base), with a long tether.
+    Returns the scene with enable_entangle set (inputs for real_entangle / the entangle rows)."""
+    import dataclasses
+    rng = np.random.default_rng(seed)
+    sc = make_scene(num_agents, n_static, seed=seed)
+    p = dataclasses.replace(sc["par"], enable_entangle=True, tether_length=200.0)
+    sc["par"] = p
+    com, gue = sc["committed"], sc["guesses"]
+    N = num_agents
+    for j in range(0, N, 2):
+        a = (j + 3) % N
+        k = int(rng.integers(2, 6))
+        q = np.array([gue[a]["coeff"][0][k][3], gue[a]["coeff"][1][k][3]])
+        d = np.asarray(p.pb[j]) - q
+        d /= np.linalg.norm(d)
+        pos = q - d * rng.uniform(0.3, 0.9) + rng.normal(scale=0.1, size=2)
+        n = int(com[j]["pwp"]["n_seg"])
+        com[j]["pwp"]["coeff"][:, :, :] = 0
+        com[j]["pwp"]["coeff"][0, :n, 3] = pos[0]; com[j]["pwp"]["coeff"][1, :n, 3] = pos[1]; com[j]["pwp"]["coeff"][2, :n, 3] = 1.0
+        com[j]["pos"][:2] = pos
+    return sc

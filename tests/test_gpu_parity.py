@@ -278,6 +278,55 @@ def test_entangle_lines_match_oracle(be, oracle):
     bb.close()
 
 
+def test_real_entangle_states_drive_the_entangle_rows(be, oracle):
+    """SURVEY §8f rank 4 end to end: the entangle states are propagated along the guesses from the actual
+    tether geometry (host library, checked here against its Python restatement), handed to the GPU
+    back end as the dense case block, and lines + QP must match the C oracle fed the same cases."""
+    from oracle import entangle_oracle as eo
+    extra, hits = 0, 0
+    for seed in (60, 56):
+        sc = scene.tether_crossing_scene(8, 6, seed)
+        p = sc["par"]; N = p.num_agents
+        case_id, hit, res = scene.real_entangle(sc)
+        assert int((case_id >= 2).sum()) > 5
+        hits += int((hit > 0).sum())
+        # the same propagation by the restatement
+        reps, longest = scene.static_reps(sc["statics"])
+        com = sc["committed"]
+        for a in range(N):
+            g = sc["guesses"][a]; t0 = float(g["t_start"]); K = int(g["K"])
+            sampled, present = [], []
+            for j in range(N):
+                pw = com[j]["pwp"]; n = int(pw["n_seg"])
+                if j == a:
+                    sampled.append([]); present.append(0); continue
+                sampled.append(eo.sample_points_of_intervals(np.array(pw["times"])[:n + 1].tolist(), np.array(pw["coeff"])[0, :n].tolist(),
+                                                             np.array(pw["coeff"])[1, :n].tolist(), t0, t0 + p.num_pol * p.T_span, p.num_pol, 3))
+                present.append(1)
+            su = eo.Setup(N, a + 1, p.num_pol, 3, p.T_span, p.tether_length, np.asarray(p.pb).tolist(),
+                          [[tuple(r[0]), tuple(r[1])] for r in reps], longest.tolist(), sampled, present,
+                          [[tuple(x) for x in np.array(com[j]["bend"])[: int(com[j]["n_bend"])]] for j in range(N)])
+            states, ohit = eo.propagate_guess(su, eo.EntState(N + len(reps)), np.array(g["coeff"])[0, :K].tolist(), np.array(g["coeff"])[1, :K].tolist())
+            assert ohit == int(hit[a]) and eo.case_ids(states, N) == case_id[a].tolist(), (seed, a)
+        bb = be.BatchBackend(p, sc["statics"])
+        d_ent = bb.torch.from_numpy(case_id.reshape(-1).copy()).to(bb.device)
+        bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]), d_ent=d_ent)
+        sol = bb.solutions()
+        for a in range(N):
+            r = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"], case_id=case_id[a])
+            r0 = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"])
+            extra += r["n_lp"] - r0["n_lp"]
+            seg, nd = bb.debug_lines(a)
+            np.testing.assert_array_equal(seg, r["line_seg"])
+            np.testing.assert_array_equal(nd, r["line_nd"])
+            K = int(sol[a]["K"])
+            assert int(sol[a]["stats"]["status"]) == r["status"]
+            assert np.abs(np.array(sol[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= COEF_TOL
+        bb.close()
+    assert extra >= 3, "no entangle LP came out of the propagated states"
+    assert hits >= 1, "no guess was flagged as entangling"
+
+
 def test_entangle_through_per_agent_api(be, oracle):
     sc = scene.make_scene(4, 0, seed=13)
     case_id = scene.synthetic_entangle(sc, seed=2, frac=1.0)
