@@ -104,6 +104,10 @@ def main():
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1 with --exchange hulls: scene chunks pipelined so that one chunk's all-gather overlaps the other's kernels")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frontend", action="store_true",
+                    help="also run the front-end beam search (SURVEY §8f rank 2) in every step: the guesses are made on the device "
+                         "from point A and the goal instead of being read from the scene (single GPU)")
+    ap.add_argument("--beam", type=int, default=32)
     ap.add_argument("--safety", action="store_true",
                     help="also run the post-solve safety check + commit (SURVEY §8f rank 1) in every step")
     args = ap.parse_args()
@@ -180,8 +184,13 @@ def main():
     d_new = torch.empty_like(d_committed) if args.safety else None
     d_accept = torch.zeros(S * N, dtype=torch.int32, device=dev) if args.safety else None
     d_guess_all = be.to_device(np.ascontiguousarray(gue)) if args.safety else None   # t_start source of the safety pass
-    safety_ev, hull_ev, gather_ev = [], [], []
+    safety_ev, hull_ev, gather_ev, fe_ev = [], [], [], []
     REC = abi.TRAJ_REC_DTYPE.itemsize
+    if args.frontend and world > 1:
+        raise SystemExit("--frontend is a single-GPU option in this round")
+    fe_cfg = scene.frontend_cfg(p, beam_width=args.beam) if args.frontend else None
+    d_fe_start = be.to_device(np.concatenate([scene.frontend_starts(s) for s in mine])) if args.frontend else None
+    d_fe_res = torch.zeros(S * N * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) if args.frontend else None
     pending = [None] * C
 
     def ev():
@@ -215,6 +224,11 @@ def main():
             pending[0].wait()
             gather_ev.append((e1, ev()))
             be.replan_hulls(hxs[0].blocks, d_guess)
+        elif args.frontend:
+            e0 = ev()
+            be.frontend(fe_cfg, d_committed, d_fe_start, d_guess, d_fe_res)     # hulls + beam search -> d_guess
+            fe_ev.append((e0, ev()))
+            be.replan(None, d_guess)                                             # separator + QP on the same hulls
         else:
             be.replan(d_committed, d_guess)
         if not args.safety:
@@ -301,6 +315,11 @@ def main():
             "p50_solve_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),
             "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange_wait": mean_ms(gather_ev),
                           "launches": n_launch, "launches_per_step": C},
+            "frontend": ({"ms": mean_ms(fe_ev), "beam_width": args.beam,
+                          "status_goal_reached": int((d_fe_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)["status"] == 1).sum()),
+                          "status_no_solution": int((d_fe_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)["status"] == 3).sum()),
+                          "children_mean": float(d_fe_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)["n_children"].mean())}
+                         if args.frontend else None),
             "safety": ({"ms": mean_ms(safety_ev), "accepted_frac": float(d_accept.float().mean().item())}
                        if args.safety else None),
             "roofline": {"bound": "hbm", "kernel": "qp_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

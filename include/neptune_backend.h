@@ -181,6 +181,12 @@ int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy
                         const int32_t* b_off, const double* b_xy, double* nd_out,
                         int32_t* solved_out);
 
+/* Batched gjk::collision(vertices1, vertices2) (gjk.cpp:76-149) with vertices1 = polygon p of the CSR
+ * (a_off, a_xy) and vertices2 = the four points b_xy[p][4][2] — the call shape of the safety check
+ * (neptune.cpp:794) and of the front end's collision test (kinodynamic_search.cpp:1514-1553).    */
+int nep_gjk_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy, const double* b_xy,
+                  int32_t* hit_out);
+
 /* Neptune::convexHullsOfCurve2d (neptune.cpp:269-452) for n_traj committed trajectories over
  * num_pol intervals of [t_start, t_start+num_pol*T_span]: inflated hull and uninflated hull per
  * (traj, interval).  hull_xy[(j*num_pol+i)][NEP_HULL_MAX_V][2], hull_nv[(j*num_pol+i)].        */
@@ -232,7 +238,8 @@ void nep_batch_destroy(nep_batch_t* h);
 /* One full back-end replan for every (scene, local agent) slot, enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = default stream), asynchronous.
  *   d_committed : device, [n_scenes][N] nep_traj_rec — snapshot of every agent's committed
- *                 trajectory (own entry ignored)
+ *                 trajectory (own entry ignored); NULL = reuse the interval hulls the handle built
+ *                 in nep_batch_frontend for this round (include/neptune_frontend.h)
  *   d_guess     : device, [n_scenes][n_local] nep_guess
  *   d_ent       : device or NULL, entangle inputs (layout: see nep_batch_ent_bytes)
  *   d_solution  : device, [n_scenes][n_local] nep_solution                        (out)
@@ -298,8 +305,8 @@ int nep_batch_debug_phase_cycles(nep_batch_t* h, int32_t slot, int64_t* out16);
 
 /* sizeof() of the POD records as compiled (0 nep_pwp, 1 nep_traj_rec, 2 nep_backend_cfg,
  * 3 nep_stats, 4 nep_batch_cfg, 5 nep_guess, 6 nep_solution, 7 nep_ent_view; from neptune_plan.h:
- * 8 nep_wire_header, 9 nep_plan_cfg, 10 nep_point_a): lets a foreign-language binding verify its
- * struct mirror. */
+ * 8 nep_wire_header, 9 nep_plan_cfg, 10 nep_point_a; from neptune_frontend.h: 11 nep_fe_cfg,
+ * 12 nep_fe_start, 13 nep_fe_result): lets a foreign-language binding verify its struct mirror. */
 int nep_abi_sizeof(int32_t which);
 
 const char* nep_last_error(void);

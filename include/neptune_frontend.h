@@ -1,0 +1,96 @@
+/* neptune_frontend.h — batched front-end initial-guess generator (SURVEY §8 f, rank 2).
+ *
+ * GPU counterpart of KinodynamicSearch (reference neptune/src/kinodynamic_search.cpp) for the batched
+ * pipeline: every (scene, agent) slot searches the jerk lattice for a kinodynamically feasible,
+ * collision-free K-segment cubic from its point A toward its goal and writes the nep_guess the back
+ * end starts from, so that hulls -> guess -> separator -> QP runs on the device without a host
+ * round trip (Neptune::replanFull, neptune.cpp:1302-1725, between point-A selection and commit).
+ *
+ * What is kept from the reference, rule by rule (kinodynamic_search.cpp):
+ *   motion primitives   constant jerk on a num_samples x num_samples lattice in [-j_max, j_max]^2 over
+ *                       T_span (:1045-1097, :1240-1275); primitive [a b c d] = [j/6, a0/2, v0, p0]
+ *   pruning of a child  |end - start| < 1e-5, acceleration bounds, MINVO position control points in
+ *                       the box and within the tether length of the base, MINVO velocity control points
+ *                       in bounds (not for the first segment, as in the reference's initial overload),
+ *                       the four "cannot brake in time" tests (:1079-1152, :1262-1330)
+ *   collision           gjk::collision of the child's control polygon with the hull of every other
+ *                       agent's committed trajectory over the child's interval (index clamped to
+ *                       num_pol) and with every inflated static obstacle (:1514-1553)
+ *   costs               g = travelled chord length, h = distance to the goal, order by g + bias*h
+ *                       (:1177-1179, CompareCost); one node per voxel of size voxel_size (:1170-1173)
+ *   termination         a node within goal_size of the goal ends the search (:1719-1737); the plan is
+ *                       the first num_pol segments of the path (:521-553); z follows the given height
+ * What differs — this is a level-synchronous BEAM over the same lattice, not the reference's A*:
+ *   the reference's open list is a wall-clock-bounded best-first search whose expansion order is
+ *   shuffled with a time seed (:321-322, :1462-1463) and whose closed-set update toggles with a call
+ *   counter (:1190-1203); it is not reproducible even against itself.  Here depth d keeps the
+ *   beam_width best children (ties by parent rank, then lattice index), a voxel holds one node per
+ *   depth and is closed to later depths, the depth is num_pol, and without reaching the goal the best
+ *   node of the last depth is returned.  The deterministic rule is stated in oracle/ and the kernel
+ *   matches it bit for bit.
+ */
+#ifndef NEPTUNE_FRONTEND_H_
+#define NEPTUNE_FRONTEND_H_
+
+#include <stdint.h>
+
+#include "neptune_backend.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEP_FE_MAX_BEAM 64
+#define NEP_FE_MAX_SAMPLES 5
+
+#define NEP_FE_GOAL_REACHED 1     /* status codes of KinodynamicSearch::run (:1637-1639)          */
+#define NEP_FE_DEPTH_REACHED 0    /* (RUNTIME_REACHED there): best node of the last depth         */
+#define NEP_FE_EMPTY 2            /* the beam died out: best node of the last non-empty depth     */
+#define NEP_FE_NO_SOLUTION 3      /* no feasible first segment: K = 0, nothing to optimise        */
+
+/* setMaxValuesAndSamples / setXYZMinMaxAndRa / setBias / setGoalSize / setTetherLength
+ * (call sites neptune.cpp:92-97); bounds, bases and T_span come from the batch handle.          */
+typedef struct nep_fe_cfg {
+  double j_max;                   /* par_.j_max                                                    */
+  double voxel_size;              /* par_.a_star_fraction_voxel_size                               */
+  double bias;                    /* 1.1 (neptune.cpp:96)                                          */
+  double goal_size;               /* par_.goal_radius                                              */
+  double cable_length;            /* par_.tetherLength                                             */
+  int32_t num_samples;            /* par_.a_star_samp_x, <= NEP_FE_MAX_SAMPLES                     */
+  int32_t beam_width;             /* <= NEP_FE_MAX_BEAM (this build's search width)                */
+} nep_fe_cfg;
+
+/* Point A and the goal of one slot (setUp, kinodynamic_search.cpp:190-227).                      */
+typedef struct nep_fe_start {
+  double pos[3], vel[3], accel[3];   /* A; only x,y enter the search, z is held                     */
+  double goal[3];                    /* G_term.pos                                                  */
+  double t_start;                    /* neptune.cpp:1422-1423                                       */
+} nep_fe_start;
+
+typedef struct nep_fe_result {
+  int32_t status;                 /* NEP_FE_*                                                      */
+  int32_t K;                      /* segments of the guess (<= num_pol)                            */
+  int32_t depth;                  /* depth at which the search stopped                             */
+  int32_t n_children;             /* lattice children generated                                    */
+  int32_t n_feasible;             /* ... that passed the kinodynamic tests                         */
+  int32_t n_collision_free;       /* ... and the collision tests                                   */
+  int32_t goal_occupied;          /* setUp's goal_occupied_ (:210-226)                             */
+  int32_t _pad;
+  double cost;                    /* g + bias*h of the returned node                               */
+  double dist_to_goal;
+} nep_fe_result;
+
+/* Front end of every slot of the batch handle, asynchronous on `stream`.
+ *   d_committed : device, [n_scenes][N] nep_traj_rec (as nep_batch_replan)
+ *   d_start     : device, [n_scenes][n_local] nep_fe_start
+ *   d_guess     : device, [n_scenes][n_local] nep_guess     (out: what nep_batch_replan consumes)
+ *   d_result    : device, [n_scenes][n_local] nep_fe_result (out, may be NULL)
+ * The interval hulls are rebuilt into the handle's scratch exactly as nep_batch_replan does.      */
+int nep_batch_frontend(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed,
+                       const nep_fe_start* d_start, nep_guess* d_guess, nep_fe_result* d_result,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEPTUNE_FRONTEND_H_ */

@@ -19,7 +19,7 @@ EXPORTS = [
     "nep_batch_replan", "nep_batch_ent_bytes", "nep_batch_wait", "nep_batch_kernel_time", "nep_batch_enable_timing",
     "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
     "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
-    "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls",
+    "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_gjk_batch",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
@@ -28,6 +28,8 @@ PLAN_EXPORTS = [
     "nep_plan_select_a", "nep_plan_splice", "nep_plan_update_delta", "nep_plan_delta",
 ]
 # every symbol include/neptune_entangle.h declares (host-only)
+# include/neptune_frontend.h
+FE_EXPORTS = ["nep_batch_frontend"]
 ENT_EXPORTS = ["nep_ent_sample_points", "nep_ent_propagate_segment", "nep_ent_propagate_guess", "nep_ent_case_ids"]
 
 
@@ -64,6 +66,7 @@ def lib():
     L.nep_backend_debug_set_lines.argtypes = [vp, i, pi, pd]
     L.nep_backend_debug_get_lines.argtypes = [vp, i, pi, pd, pi]
     L.nep_separator_batch.argtypes = [i, pi, pd, pi, pd, pd, pi]
+    L.nep_gjk_batch.argtypes = [i, pi, pd, pd, pi]
     L.nep_hulls_batch.argtypes = [i, vp, d, i, d, d, pd, pi, pd, pi]
     L.nep_batch_create.argtypes = [C.POINTER(abi.nep_batch_cfg)]; L.nep_batch_create.restype = vp
     L.nep_batch_destroy.argtypes = [vp]; L.nep_batch_destroy.restype = None
@@ -102,6 +105,7 @@ def lib():
     L.nep_ent_propagate_segment.argtypes = [pcfg, pin, pst, pd, pd, pd, i, pd]
     L.nep_ent_propagate_guess.argtypes = [pcfg, pin, pst, vp, i, pi, pi, pi, pi, pst]
     L.nep_ent_case_ids.argtypes = [i, i, pi, pi, pi, i, pi]
+    L.nep_batch_frontend.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -116,6 +116,23 @@ class nep_ent_state(C.Structure):
                 ("active_cases", C.POINTER(C.c_int32))]
 
 
+class nep_fe_cfg(C.Structure):
+    """include/neptune_frontend.h: the KinodynamicSearch setters the batched front end needs."""
+    _fields_ = [("j_max", C.c_double), ("voxel_size", C.c_double), ("bias", C.c_double), ("goal_size", C.c_double),
+                ("cable_length", C.c_double), ("num_samples", C.c_int32), ("beam_width", C.c_int32)]
+
+
+class nep_fe_start(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("vel", C.c_double * 3), ("accel", C.c_double * 3), ("goal", C.c_double * 3),
+                ("t_start", C.c_double)]
+
+
+class nep_fe_result(C.Structure):
+    _fields_ = [("status", C.c_int32), ("K", C.c_int32), ("depth", C.c_int32), ("n_children", C.c_int32),
+                ("n_feasible", C.c_int32), ("n_collision_free", C.c_int32), ("goal_occupied", C.c_int32), ("_pad", C.c_int32),
+                ("cost", C.c_double), ("dist_to_goal", C.c_double)]
+
+
 def np_dtype(struct):
     return np.dtype(struct)
 
@@ -123,6 +140,8 @@ def np_dtype(struct):
 TRAJ_REC_DTYPE = np.dtype(nep_traj_rec)
 GUESS_DTYPE = np.dtype(nep_guess)
 SOLUTION_DTYPE = np.dtype(nep_solution)
+FE_START_DTYPE = np.dtype(nep_fe_start)
+FE_RESULT_DTYPE = np.dtype(nep_fe_result)
 
 
 def dptr(a):

@@ -161,6 +161,15 @@ def separator_batch(As, Bs):
     return ok.astype(bool), nd
 
 
+def gjk_batch(polys, quads):
+    """Batched gjk::collision(polygon, four points).  polys: list of (n,2); quads: (len(polys), 4, 2)."""
+    aoff, axy = _csr(polys)
+    q = np.ascontiguousarray(quads, dtype=np.float64).reshape(len(polys), 4, 2)
+    hit = np.zeros(len(polys), dtype=np.int32)
+    check(lib().nep_gjk_batch(len(polys), abi.iptr(aoff), abi.dptr(axy), abi.dptr(q), abi.iptr(hit)))
+    return hit.astype(bool)
+
+
 def hulls_batch(recs, t_start, num_pol, T_span, drone_radius):
     """Neptune::convexHullsOfCurve2d for committed-trajectory records (TRAJ_REC_DTYPE array)."""
     recs = np.ascontiguousarray(recs)
@@ -214,7 +223,7 @@ class BatchBackend:
         """Enqueues one replan of every slot; tensors are device byte tensors."""
         torch = self.torch
         st = stream if stream is not None else torch.cuda.current_stream(self.device)
-        check(lib().nep_batch_replan(self._h, d_committed.data_ptr(), d_guess.data_ptr(),
+        check(lib().nep_batch_replan(self._h, d_committed.data_ptr() if d_committed is not None else None, d_guess.data_ptr(),
                                      d_ent.data_ptr() if d_ent is not None else None,
                                      self.d_solution.data_ptr(), self.d_states.data_ptr(),
                                      self.d_commit.data_ptr() if want_commit else None, st.cuda_stream))
@@ -236,6 +245,13 @@ class BatchBackend:
                                            d_ent.data_ptr() if d_ent is not None else None,
                                            self.d_solution.data_ptr(), self.d_states.data_ptr(),
                                            self.d_commit.data_ptr() if want_commit else None, st.cuda_stream))
+
+    # ---- front end: hulls -> beam search over the jerk lattice -> guesses -------------
+    def frontend(self, fe_cfg, d_committed, d_start, d_guess, d_result=None, stream=None):
+        """fe_cfg: abi.nep_fe_cfg; d_start: device bytes of [slots] FE_START_DTYPE; d_guess (out): [slots] GUESS_DTYPE."""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_frontend(self._h, C.byref(fe_cfg), d_committed.data_ptr(), d_start.data_ptr(), d_guess.data_ptr(),
+                                       d_result.data_ptr() if d_result is not None else None, st.cuda_stream))
 
     def safety_commit(self, d_prev, d_new, d_guess, d_final, d_accept=None, stream=None):
         """Post-solve safety check + commit (nep_batch_safety_commit); tensors are device byte/int32 tensors."""

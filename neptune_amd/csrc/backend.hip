@@ -469,6 +469,24 @@ int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy
   return 0;
 }
 
+int nep_gjk_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy, const double* b_xy, int32_t* hit_out) {
+  if (n_prob < 0 || !a_off || !b_xy || !hit_out) return fail(NEP_E_ARG, "bad arguments");
+  if (!have_device()) return fail(NEP_E_HIP, "no HIP device: the back end has no CPU path");
+  if (n_prob == 0) return 0;
+  DevBuf<int> da, dh; DevBuf<double> dax, dbx;
+  const int na = a_off[n_prob];
+  int e = 0;
+  if ((e = da.ensure(n_prob + 1)) || (e = dh.ensure(n_prob)) || (e = dax.ensure((size_t)2 * (na > 0 ? na : 1))) || (e = dbx.ensure((size_t)8 * n_prob))) return e;
+  HIPCHK(hipMemcpy(da.p, a_off, (n_prob + 1) * sizeof(int), hipMemcpyHostToDevice));
+  if (na) HIPCHK(hipMemcpy(dax.p, a_xy, (size_t)2 * na * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dbx.p, b_xy, (size_t)8 * n_prob * sizeof(double), hipMemcpyHostToDevice));
+  launch_gjk_explicit(n_prob, da.p, dax.p, dbx.p, dh.p, nullptr);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpy(hit_out, dh.p, (size_t)n_prob * sizeof(int), hipMemcpyDeviceToHost));
+  da.release(); dh.release(); dax.release(); dbx.release();
+  return 0;
+}
+
 int nep_hulls_batch(int32_t n_traj, const nep_traj_rec* trajs, double t_start, int32_t num_pol, double T_span, double drone_radius,
                     double* hull_xy, int32_t* hull_nv, double* hull0_xy, int32_t* hull0_nv) {
   if (n_traj < 0 || !trajs || !hull_xy || !hull_nv || !hull0_xy || !hull0_nv || num_pol < 1) return fail(NEP_E_ARG, "bad arguments");
@@ -536,13 +554,14 @@ int64_t nep_batch_ent_bytes(const nep_batch_t* h) { return h ? (int64_t)h->slots
 
 int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess, const void* d_ent,
                      nep_solution* d_solution, double* d_states, nep_traj_rec* d_commit, void* stream) {
-  if (!h || !d_committed || !d_guess || !d_solution) return fail(NEP_E_ARG, "null argument");
+  if (!h || !d_guess || !d_solution) return fail(NEP_E_ARG, "null argument");
   Engine& E = h->eng;
   ProblemSet ps{};
   E.fill(ps);
   ps.guess = d_guess; ps.solution = d_solution; ps.states = d_states; ps.commit = d_commit;
   ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
   ps.lines_override = 0;
+  // d_committed == NULL: the interval hulls of this round are already in the handle's scratch (nep_batch_frontend)
   return E.run(d_committed, h->cfg.num_agents, ps, (hipStream_t)stream);
 }
 
@@ -603,6 +622,21 @@ int nep_batch_replan_hulls(nep_batch_t* h, const void* d_blocks, int32_t n_block
   ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
   ps.lines_override = 0;
   return E.run(nullptr, 0, ps, (hipStream_t)stream);
+}
+
+// hulls -> front-end beam search; the guesses land where nep_batch_replan reads them
+int nep_batch_frontend(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed, const nep_fe_start* d_start,
+                       nep_guess* d_guess, nep_fe_result* d_result, void* stream) {
+  if (!h || !cfg || !d_committed || !d_start || !d_guess) return fail(NEP_E_ARG, "null argument");
+  if (cfg->num_samples < 2 || cfg->num_samples > NEP_FE_MAX_SAMPLES || cfg->beam_width < 1 || cfg->beam_width > NEP_FE_MAX_BEAM ||
+      !(cfg->voxel_size > 0.0) || !(cfg->j_max > 0.0)) return fail(NEP_E_ARG, "bad front-end configuration");
+  Engine& E = h->eng;
+  ProblemSet ps{};
+  E.fill(ps);
+  launch_hulls_ts(d_committed, h->cfg.n_scenes, h->cfg.num_agents, &d_start->t_start, (long)sizeof(nep_fe_start), E.sp, ps, (hipStream_t)stream);
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
 }
 
 int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new, const nep_guess* d_guess,
@@ -701,6 +735,9 @@ int nep_abi_sizeof(int32_t which) {
     case 8: return (int)sizeof(nep_wire_header);
     case 9: return (int)sizeof(nep_plan_cfg);
     case 10: return (int)sizeof(nep_point_a);
+    case 11: return (int)sizeof(nep_fe_cfg);
+    case 12: return (int)sizeof(nep_fe_start);
+    case 13: return (int)sizeof(nep_fe_result);
     default: return -1;
   }
 }

@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "nep_device.h"
+#include "../../include/neptune_frontend.h"
 
 namespace nep {
 
@@ -162,7 +163,7 @@ __device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, 
 
 // One block (= one wave) per (scene, committed trajectory, planning interval).
 __global__ __launch_bounds__(64) void hull_kernel(const nep_traj_rec* __restrict__ recs, int n_rec_per_scene,
-                                                  const nep_guess* __restrict__ guess, int n_local,
+                                                  const double* __restrict__ ts0, long ts_scene_stride,
                                                   int num_pol, double T_span, double drone_radius,
                                                   double* __restrict__ hull_xy, int* __restrict__ hull_nv,
                                                   double* __restrict__ hull0_xy, int* __restrict__ hull0_nv,
@@ -177,18 +178,22 @@ __global__ __launch_bounds__(64) void hull_kernel(const nep_traj_rec* __restrict
     bend_n[jt] = (r->valid && r->is_agent) ? nb : 0;
     for (int b = 0; b < nb; b++) { bend_xy[((long)jt * kBend + b) * 2] = r->bend[b][0]; bend_xy[((long)jt * kBend + b) * 2 + 1] = r->bend[b][1]; }
   }
-  // bulk-synchronous round: every agent of a scene replans from the same t_start
-  const double ts = guess[(long)scene * n_local].t_start;
+  // bulk-synchronous round: every agent of a scene replans from the same t_start (that of its first local slot)
+  const double ts = *(const double*)((const char*)ts0 + (long)scene * ts_scene_stride);
   hull_body(r, ts, i, T_span, drone_radius, (long)jt * num_pol + i, false, hull_xy, hull_nv, hull0_xy, hull0_nv);
 }
 
 void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_guess* guess,
                   const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
+  launch_hulls_ts(recs, n_scenes, n_rec, &guess->t_start, (long)sizeof(nep_guess), sp, ps, st);
+}
+void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const double* ts0, long ts_slot_stride,
+                     const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
   int blocks = n_scenes * n_rec * sp.num_pol;
   if (blocks <= 0) return;
   // the uninflated hull is read only by the entangle rows (col(0), solver_gurobi_poly.cpp:722-734)
   const bool need0 = sp.ent_enabled != 0;
-  hipLaunchKernelGGL(hull_kernel, dim3(blocks), dim3(64), 0, st, recs, n_rec, guess, sp.n_local,
+  hipLaunchKernelGGL(hull_kernel, dim3(blocks), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
                      sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
                      need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr);
 }
@@ -639,10 +644,307 @@ __global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec*
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
                    unsigned char* conflict, nep_traj_rec* final_out, int* accept_out, hipStream_t st) {
   if (n_scenes * N <= 0) return;
-  hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, fresh, N, ps.guess, sp.n_local, sp.num_pol, sp.T_span,
+  hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, fresh, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
                      sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr);
   hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
   hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, final_out, accept_out);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// front-end initial guess (include/neptune_frontend.h) — the deterministic
+// beam over KinodynamicSearch's jerk lattice (kinodynamic_search.cpp:1045-1228, :1240-1385, :1514-1553,
+// :1629-1827).  One 256-thread workgroup per (scene, agent): per depth the lattice children of the
+// beam are generated and pruned one per thread, one node per voxel survives, the beam_width best in
+// (g + bias h, parent rank, lattice index) order form the next beam.  Arithmetic is written in the
+// oracle's association order (this file is built -ffp-contract=off): guesses match bit for bit.
+// ---------------------------------------------------------------------------------------------
+__constant__ double cAVelInv[3][3] = {
+    {-0.07735026918962577, 0.16666666666666635, 1.077350269189625},
+    {-0.07735026918962577, 0.49999999999999967, 1.077350269189625},
+    {1.0000000000000002, 1.0000000000000009, 1.0000000000000016}};
+
+struct FeChild { double e[6], cx[4], cy[4], Qx[4], Qy[4], g, dist, f; int vx, vy; };
+
+__device__ __forceinline__ void fe_pos_cps(const double P[4], double T, double Q[4]) {
+  const double tp[4] = {T * T * T, T * T, T, 1.0};
+#pragma unroll
+  for (int k = 0; k < 4; k++) Q[k] = ((P[0] * (tp[0] * cAPosInv[0][k]) + P[1] * (tp[1] * cAPosInv[1][k])) + P[2] * (tp[2] * cAPosInv[2][k])) + P[3] * (tp[3] * cAPosInv[3][k]);
+}
+__device__ __forceinline__ void fe_vel_cps(const double P[4], double T, double Qv[3]) {
+  const double tv[3] = {T * T, T, 1.0}; const double m321[3] = {3.0, 2.0, 1.0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) Qv[k] = (P[0] * (m321[0] * (tv[0] * cAVelInv[0][k])) + P[1] * (m321[1] * (tv[1] * cAVelInv[1][k]))) + P[2] * (m321[2] * (tv[2] * cAVelInv[2][k]));
+}
+
+// one lattice child (expandAndAddToQueue); false when a kinodynamic test prunes it
+__device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const double* __restrict__ pe, double pg, bool first, int jx, int jy,
+                         double gx, double gy, double bx, double by, FeChild& o) {
+  const double tau = sp.T_span, j_min = -fc.j_max, j_max = fc.j_max, v_max = sp.v_max, v_min = -sp.v_max, a_max = sp.a_max, a_min = -sp.a_max;
+  const double delta = (j_max - j_min) / (fc.num_samples - 1);
+  const double ji[2] = {j_min + jx * delta, j_min + jy * delta};
+#pragma unroll
+  for (int ax = 0; ax < 2; ax++) {
+    const double p = pe[ax], v = pe[2 + ax], a = pe[4 + ax], j = ji[ax];
+    o.e[ax] = ((p + v * tau) + ((a * tau) * tau) / 2) + (((j * tau) * tau) * tau) / 6;
+    o.e[2 + ax] = (v + a * tau) + ((j * tau) * tau) / 2;
+    o.e[4 + ax] = a + j * tau;
+  }
+  double n2 = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) n2 += (o.e[i] - pe[i]) * (o.e[i] - pe[i]);
+  if (sqrt(n2) < 0.00001) return false;
+  if (o.e[5] > a_max || o.e[5] < a_min || o.e[4] > a_max || o.e[4] < a_min) return false;
+  o.cx[0] = ji[0] / 6; o.cx[1] = pe[4] / 2; o.cx[2] = pe[2]; o.cx[3] = pe[0];
+  o.cy[0] = ji[1] / 6; o.cy[1] = pe[5] / 2; o.cy[2] = pe[3]; o.cy[3] = pe[1];
+  fe_pos_cps(o.cx, tau, o.Qx); fe_pos_cps(o.cy, tau, o.Qy);
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    if (o.Qx[i] < sp.mins[0] || o.Qx[i] > sp.maxs[0] || o.Qy[i] < sp.mins[1] || o.Qy[i] > sp.maxs[1]) return false;
+    if (sqrt((o.Qx[i] - bx) * (o.Qx[i] - bx) + (o.Qy[i] - by) * (o.Qy[i] - by)) > fc.cable_length) return false;
+  }
+  if (!first) {
+    double Vx[3], Vy[3];
+    fe_vel_cps(o.cx, tau, Vx); fe_vel_cps(o.cy, tau, Vy);
+#pragma unroll
+    for (int i = 0; i < 3; i++) if (Vx[i] < v_min || Vx[i] > v_max || Vy[i] < v_min || Vy[i] > v_max) return false;
+  }
+#pragma unroll
+  for (int ax = 0; ax < 2; ax++) {
+    const double a = o.e[4 + ax], v = o.e[2 + ax];
+    if (a > 0 && v - ((0.5 * a) * a) / j_min > v_max) return false;
+    else if (a < 0 && v - ((0.5 * a) * a) / j_max < v_min) return false;
+  }
+  const double arc = sqrt((o.e[0] - pe[0]) * (o.e[0] - pe[0]) + (o.e[1] - pe[1]) * (o.e[1] - pe[1]));
+  o.g = pg + arc;
+  o.dist = sqrt((o.e[0] - gx) * (o.e[0] - gx) + (o.e[1] - gy) * (o.e[1] - gy));
+  o.f = o.g + fc.bias * o.dist;
+  o.vx = (int)round(o.e[0] / fc.voxel_size); o.vy = (int)round(o.e[1] / fc.voxel_size);
+  return true;
+}
+
+constexpr int kFeCap = NEP_FE_MAX_BEAM * NEP_FE_MAX_SAMPLES * NEP_FE_MAX_SAMPLES;   // 1600
+
+// order-preserving compaction of the ids with flag[id] == want into list; returns the count (uniform)
+__device__ int fe_compact(int n, const unsigned char* flag, int want, unsigned short* list, int* s_cnt) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int base = 0;
+  for (int i0 = 0; i0 < n; i0 += 256) {
+    const int id = i0 + tid;
+    const bool on = id < n && flag[id] == want;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) s_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int off = base;
+    for (int w = 0; w < wave; w++) off += s_cnt[w];
+    if (on) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)id;
+    base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    __syncthreads();
+  }
+  return base;
+}
+
+__global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
+                                                       nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out) {
+  extern __shared__ __attribute__((aligned(16))) double fe_smem[];
+  const int tid = threadIdx.x;
+  const int slot = blockIdx.x, scene = slot / sp.n_local, own = sp.first_local + (slot % sp.n_local);
+  const int N = sp.num_agents, S = sp.n_static, W = fc.beam_width, ns = fc.num_samples, NC = ns * ns, D = sp.num_pol;
+  // ---- LDS carve ----
+  double* s_f = fe_smem;                                   // [kFeCap]
+  double* b_end = s_f + kFeCap;                            // [2][64][6]
+  double* b_g = b_end + 2 * NEP_FE_MAX_BEAM * 6;           // [2][64]
+  double* b_dist = b_g + 2 * NEP_FE_MAX_BEAM;              // [64]
+  double* b_f = b_dist + NEP_FE_MAX_BEAM;                  // [64]
+  double* o_aabb = b_f + NEP_FE_MAX_BEAM;                  // [N+S][4]
+  long long* s_vox = (long long*)(o_aabb + 4 * (N + S));   // [kFeCap]
+  long long* s_vis = s_vox + kFeCap;                       // [64 * NEP_MAX_POL]
+  int* o_nv = (int*)(s_vis + NEP_FE_MAX_BEAM * NEP_MAX_POL);   // [N+S]
+  int* s_i = o_nv + (N + S);                               // [16] scratch / counters
+  unsigned short* s_la = (unsigned short*)(s_i + 16);      // [kFeCap]
+  unsigned short* s_lb = s_la + kFeCap;                    // [kFeCap]
+  unsigned char* s_state = (unsigned char*)(s_lb + kFeCap);   // [kFeCap] 0 dead, 1 alive, 2 lost its voxel
+  signed char* p_parent = (signed char*)(s_state + kFeCap);   // [NEP_MAX_POL + 1][64]
+  signed char* p_comb = p_parent + (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
+
+  const nep_fe_start* st = starts + slot;
+  const double gx = st->goal[0], gy = st->goal[1];
+  const double bx = ps.pb[2 * own], by = ps.pb[2 * own + 1];
+  const double root[6] = {st->pos[0], st->pos[1], st->vel[0], st->vel[1], st->accel[0], st->accel[1]};
+  if (tid < 16) s_i[tid] = 0;     // [4] children, [5] feasible, [6] collision free, [7] goal occupied
+  __syncthreads();
+  // goal_occupied_ (setUp :210-226)
+  {
+    Pts4 G; const double r = 0.5;
+    G.x[0] = gx + r; G.y[0] = gy + r; G.x[1] = gx + r; G.y[1] = gy - r; G.x[2] = gx - r; G.y[2] = gy + r; G.x[3] = gx - r; G.y[3] = gy - r;
+    for (int j = tid; j < N; j += 256) {
+      if (j == own) continue;
+      const HullRef hr = hull_ref(ps, sp.n_hull, scene, j);
+      const long h = hr.e * sp.num_pol + (D - 1);
+      const int nv = blk(ps.hull_nv, hr.boff)[h];
+      if (nv > 0 && gjk_collision(nv, blk(ps.hull_xy, hr.boff) + h * kHullV * 2, G)) s_i[7] = 1;
+    }
+  }
+  int status = NEP_FE_NO_SOLUTION, best_depth = 0, best_rank = -1, n_vis = 0, nb_prev = 1, depth;
+  int my_children = 0, my_feasible = 0, my_free = 0;
+  for (depth = 1; depth <= D; depth++) {
+    const int cur = depth & 1, prv = cur ^ 1;
+    const int idx = (depth > D ? D : depth) - 1;
+    __syncthreads();
+    // ---- obstacle boxes of this interval ----
+    for (int j = tid; j < N + S; j += 256) {
+      int nv = 0; const double* V = nullptr;
+      if (j < N) {
+        if (j != own) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
+      } else { nv = ps.static_nv[j - N]; V = ps.static_xy + (long)(j - N) * kHullV * 2; }
+      o_nv[j] = nv;
+      if (nv > 0) {
+        double x0 = V[0], x1 = V[0], y0 = V[1], y1 = V[1];
+        for (int i = 1; i < nv; i++) { const double x = V[2 * i], y = V[2 * i + 1]; if (x < x0) x0 = x; if (x > x1) x1 = x; if (y < y0) y0 = y; if (y > y1) y1 = y; }
+        o_aabb[4 * j] = x0; o_aabb[4 * j + 1] = x1; o_aabb[4 * j + 2] = y0; o_aabb[4 * j + 3] = y1;
+      }
+    }
+    __syncthreads();
+    // ---- children: one per thread ----
+    const int n_c = nb_prev * NC;
+    for (int id = tid; id < n_c; id += 256) {
+      const int pr = id / NC, cc = id % NC;
+      const double* pe = depth == 1 ? root : b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
+      const double pg = depth == 1 ? 0.0 : b_g[prv * NEP_FE_MAX_BEAM + pr];
+      FeChild ch;
+      unsigned char alive = 0;
+      my_children++;
+      if (fe_child(sp, fc, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch)) {
+        my_feasible++;
+        double qx0 = ch.Qx[0], qx1 = ch.Qx[0], qy0 = ch.Qy[0], qy1 = ch.Qy[0];
+#pragma unroll
+        for (int i = 1; i < 4; i++) { if (ch.Qx[i] < qx0) qx0 = ch.Qx[i]; if (ch.Qx[i] > qx1) qx1 = ch.Qx[i]; if (ch.Qy[i] < qy0) qy0 = ch.Qy[i]; if (ch.Qy[i] > qy1) qy1 = ch.Qy[i]; }
+        Pts4 B;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
+        bool hit = false;
+        for (int j = 0; j < N + S && !hit; j++) {
+          const int nv = o_nv[j];
+          if (nv <= 0) continue;
+          if (o_aabb[4 * j + 1] < qx0 || qx1 < o_aabb[4 * j] || o_aabb[4 * j + 3] < qy0 || qy1 < o_aabb[4 * j + 2]) continue;
+          const double* V;
+          if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); V = blk(ps.hull_xy, hr.boff) + (hr.e * sp.num_pol + idx) * kHullV * 2; }
+          else V = ps.static_xy + (long)(j - N) * kHullV * 2;
+          hit = gjk_collision(nv, V, B);
+        }
+        if (!hit) {
+          my_free++;
+          const long long vox = ((long long)ch.vx << 32) | (unsigned int)ch.vy;
+          bool seen = false;
+          for (int v = 0; v < n_vis && !seen; v++) seen = s_vis[v] == vox;
+          if (!seen) { alive = 1; s_f[id] = ch.f; s_vox[id] = vox; }
+        }
+      }
+      s_state[id] = alive;
+    }
+    __syncthreads();
+    // ---- one node per voxel: the best (f, id) ----
+    const int n_a = fe_compact(n_c, s_state, 1, s_la, s_i);
+    for (int a = tid; a < n_a; a += 256) {
+      const int i = s_la[a];
+      const double fi = s_f[i]; const long long vi = s_vox[i];
+      bool lose = false;
+      for (int b = 0; b < n_a && !lose; b++) {
+        const int k = s_la[b];
+        if (k != i && s_vox[k] == vi) { const double fk = s_f[k]; lose = fk < fi || (fk == fi && k < i); }
+      }
+      if (lose) s_state[i] = 2;
+    }
+    __syncthreads();
+    // ---- the beam: rank among the voxel winners ----
+    const int n_b = fe_compact(n_c, s_state, 1, s_lb, s_i);
+    const int nb = n_b < W ? n_b : W;
+    for (int a = tid; a < n_b; a += 256) {
+      const int i = s_lb[a];
+      const double fi = s_f[i];
+      int rank = 0;
+      for (int b = 0; b < n_b; b++) { const int k = s_lb[b]; const double fk = s_f[k]; if (fk < fi || (fk == fi && k < i)) rank++; }
+      if (rank < W) {   // recompute the child (same arithmetic) and install it
+        const int pr = i / NC, cc = i % NC;
+        const double* pe = depth == 1 ? root : b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
+        const double pg = depth == 1 ? 0.0 : b_g[prv * NEP_FE_MAX_BEAM + pr];
+        FeChild ch;
+        fe_child(sp, fc, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch);
+#pragma unroll
+        for (int q = 0; q < 6; q++) b_end[(cur * NEP_FE_MAX_BEAM + rank) * 6 + q] = ch.e[q];
+        b_g[cur * NEP_FE_MAX_BEAM + rank] = ch.g; b_dist[rank] = ch.dist; b_f[rank] = ch.f;
+        p_parent[depth * NEP_FE_MAX_BEAM + rank] = (signed char)(depth == 1 ? -1 : pr);
+        p_comb[depth * NEP_FE_MAX_BEAM + rank] = (signed char)cc;
+        s_vis[n_vis + rank] = s_vox[i];
+      }
+    }
+    __syncthreads();
+    if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
+    n_vis += nb; nb_prev = nb;
+    best_depth = depth; best_rank = 0;
+    int reached = -1;
+    for (int r = 0; r < nb && reached < 0; r++) if (b_dist[r] < fc.goal_size) reached = r;   // (every thread: uniform)
+    if (reached >= 0) { status = NEP_FE_GOAL_REACHED; best_rank = reached; break; }
+    if (depth == D) { status = NEP_FE_DEPTH_REACHED; break; }
+  }
+  atomicAdd(&s_i[4], my_children); atomicAdd(&s_i[5], my_feasible); atomicAdd(&s_i[6], my_free);
+  __syncthreads();
+  if (tid == 0) {
+    nep_guess* g = guess_out + slot;
+    for (int e = 0; e < 3 * NEP_MAX_POL * 4; e++) (&g->coeff[0][0][0])[e] = 0.0;
+    g->t_start = st->t_start; g->K = best_rank >= 0 ? best_depth : 0; g->n_alpha = 0;
+    if (best_rank >= 0) {
+      signed char combs[NEP_MAX_POL];
+      int r = best_rank;
+      for (int d = best_depth; d >= 1; d--) { combs[d - 1] = p_comb[d * NEP_FE_MAX_BEAM + r]; r = p_parent[d * NEP_FE_MAX_BEAM + r]; }
+      double pe[6]; double pg = 0.0;
+      for (int q = 0; q < 6; q++) pe[q] = root[q];
+      for (int d = 1; d <= best_depth; d++) {   // replay the path from the root with the same arithmetic
+        FeChild ch;
+        fe_child(sp, fc, pe, pg, d == 1, combs[d - 1] / ns, combs[d - 1] % ns, gx, gy, bx, by, ch);
+        for (int k = 0; k < 4; k++) { g->coeff[0][d - 1][k] = ch.cx[k]; g->coeff[1][d - 1][k] = ch.cy[k]; }
+        g->coeff[2][d - 1][3] = st->pos[2];
+        for (int q = 0; q < 6; q++) pe[q] = ch.e[q];
+        pg = ch.g;
+      }
+    }
+    if (res_out) {
+      nep_fe_result* o = res_out + slot;
+      o->status = status; o->K = best_rank >= 0 ? best_depth : 0; o->depth = depth > D ? D : depth;
+      o->n_children = s_i[4]; o->n_feasible = s_i[5]; o->n_collision_free = s_i[6]; o->goal_occupied = s_i[7]; o->_pad = 0;
+      o->cost = best_rank >= 0 ? b_f[best_rank] : 0.0; o->dist_to_goal = best_rank >= 0 ? b_dist[best_rank] : 0.0;
+    }
+  }
+}
+
+// Stand-alone batched gjk::collision (tests / nep_gjk_batch): one lane per (polygon, four points) problem.
+__global__ void gjk_explicit_kernel(int n_prob, const int* __restrict__ a_off, const double* __restrict__ a_xy, const double* __restrict__ b_xy, int* __restrict__ hit) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_prob) return;
+  Pts4 B;
+  for (int i = 0; i < 4; i++) { B.x[i] = b_xy[(p * 4 + i) * 2]; B.y[i] = b_xy[(p * 4 + i) * 2 + 1]; }
+  hit[p] = gjk_collision(a_off[p + 1] - a_off[p], a_xy + 2 * (long)a_off[p], B) ? 1 : 0;
+}
+void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const double* b_xy, int* hit, hipStream_t st) {
+  if (n_prob <= 0) return;
+  hipLaunchKernelGGL(gjk_explicit_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, st, n_prob, a_off, a_xy, b_xy, hit);
+}
+
+size_t frontend_lds_bytes(const SceneParams& sp) {
+  const size_t NS = (size_t)sp.num_agents + sp.n_static;
+  size_t b = sizeof(double) * (kFeCap + 2 * NEP_FE_MAX_BEAM * 6 + 2 * NEP_FE_MAX_BEAM + 2 * NEP_FE_MAX_BEAM + 4 * NS)
+           + sizeof(long long) * (kFeCap + NEP_FE_MAX_BEAM * NEP_MAX_POL) + sizeof(int) * (NS + 16)
+           + sizeof(unsigned short) * 2 * kFeCap + kFeCap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
+  return (b + 15) & ~(size_t)15;
+}
+
+void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
+                     nep_guess* guess_out, nep_fe_result* res_out, hipStream_t st) {
+  if (n_slots <= 0) return;
+  const size_t lds = frontend_lds_bytes(sp);
+  static size_t configured = 0;
+  if (lds > configured) { hipFuncSetAttribute((const void*)frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); configured = lds; }
+  hipLaunchKernelGGL(frontend_kernel, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out);
 }
 
 }  // namespace nep

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include "nep_tables.h"
+#include "../../include/neptune_frontend.h"
 
 namespace nep {
 
@@ -81,6 +82,8 @@ struct SampleSched {             // per K: n, seg[], dt[]
 
 void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_guess* guess,
                   const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
+void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const double* ts0, long ts_slot_stride,
+                     const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
 void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start, int num_pol,
                            double T_span, double drone_radius, double* hull_xy, int* hull_nv,
                            double* hull0_xy, int* hull0_nv, hipStream_t st);
@@ -90,6 +93,9 @@ void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy,
 void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 size_t qp_lds_fixed_bytes();
+void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
+                     nep_guess* guess_out, nep_fe_result* res_out, hipStream_t st);
+void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const double* b_xy, int* hit, hipStream_t st);
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
                    unsigned char* conflict, nep_traj_rec* final_out, int* accept_out, hipStream_t st);
 

@@ -378,3 +378,21 @@ def tether_crossing_scene(num_agents, n_static, seed):
         com[j]["pwp"]["coeff"][0, :n, 3] = pos[0]; com[j]["pwp"]["coeff"][1, :n, 3] = pos[1]; com[j]["pwp"]["coeff"][2, :n, 3] = 1.0
         com[j]["pos"][:2] = pos
     return sc
+
+
+def frontend_cfg(p, beam_width=32, num_samples=5):
+    """The front-end settings Neptune's constructor passes (neptune.cpp:92-97) with the reference yaml values
+    (a_star_samp_x 5, a_star_fraction_voxel_size 0.2, goal_radius 0.2, bias 1.1)."""
+    return abi.nep_fe_cfg(p.j_max, 0.2, 1.1, 0.2, p.tether_length, num_samples, beam_width)
+
+
+def frontend_starts(sc):
+    """Point A of every agent (the state its scene guess starts from) and its goal -> [N] FE_START_DTYPE."""
+    N = sc["par"].num_agents
+    st = np.zeros(N, dtype=abi.FE_START_DTYPE)
+    for a in range(N):
+        co = np.array(sc["guesses"][a]["coeff"])
+        st[a]["pos"] = co[:, 0, 3]; st[a]["vel"] = co[:, 0, 2]; st[a]["accel"] = 2 * co[:, 0, 1]
+        st[a]["goal"] = sc["goals"][a]
+        st[a]["t_start"] = sc["guesses"][a]["t_start"]
+    return st

@@ -905,3 +905,211 @@ void orc_safety_resolve(int n, const nep_traj_rec* fresh, double t_start, double
     accept[a] = ok;
   }
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* front-end initial guess — the deterministic beam rule of               */
+/* include/neptune_frontend.h over KinodynamicSearch's lattice, pruning and cost rules          */
+/* (kinodynamic_search.cpp:190-227 setUp, :1045-1228 / :1240-1385 expansion, :1514-1553          */
+/* collision, :1629-1827 run, :521-553 recoverPwpOut).  The HIP kernel must match bit for bit.   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct fe_node {
+  double end[6];            /* px py vx vy ax ay (:1079-1086) */
+  double cx[4], cy[4];      /* the segment that led here */
+  double g, f, dist;
+  long vx, vy;              /* voxel */
+  int parent;               /* rank in the previous depth's beam, -1 = root */
+} fe_node;
+
+static int fe_aabb_overlap(int n, const double (*V)[2], const double Qx[4], const double Qy[4]) {
+  double ax0 = V[0][0], ax1 = V[0][0], ay0 = V[0][1], ay1 = V[0][1];
+  for (int i = 1; i < n; i++) {
+    if (V[i][0] < ax0) ax0 = V[i][0]; if (V[i][0] > ax1) ax1 = V[i][0];
+    if (V[i][1] < ay0) ay0 = V[i][1]; if (V[i][1] > ay1) ay1 = V[i][1];
+  }
+  double bx0 = Qx[0], bx1 = Qx[0], by0 = Qy[0], by1 = Qy[0];
+  for (int i = 1; i < 4; i++) {
+    if (Qx[i] < bx0) bx0 = Qx[i]; if (Qx[i] > bx1) bx1 = Qx[i];
+    if (Qy[i] < by0) by0 = Qy[i]; if (Qy[i] > by1) by1 = Qy[i];
+  }
+  return !(ax1 < bx0 || bx1 < ax0 || ay1 < by0 || by1 < ay0);
+}
+
+/* one lattice child of `par` (end state, g); returns 0 when a kinodynamic test prunes it */
+static int fe_child(const orc_fe_cfg* c, const double init_end[6], double par_g, int first, int jx, int jy, const double goal[2], fe_node* out) {
+  const double tau = c->T_span, j_min = -c->j_max, j_max = c->j_max, v_max = c->v_max, v_min = -c->v_max, a_max = c->a_max, a_min = -c->a_max;
+  const double delta = (j_max - j_min) / (c->num_samples - 1);
+  const double ji[2] = {j_min + jx * delta, j_min + jy * delta};
+  double e[6];
+  for (int ax = 0; ax < 2; ax++) {
+    const double p = init_end[ax], v = init_end[2 + ax], a = init_end[4 + ax], j = ji[ax];
+    e[ax] = ((p + v * tau) + ((a * tau) * tau) / 2) + (((j * tau) * tau) * tau) / 6;
+    e[2 + ax] = (v + a * tau) + ((j * tau) * tau) / 2;
+    e[4 + ax] = a + j * tau;
+  }
+  double n2 = 0;
+  for (int i = 0; i < 6; i++) n2 += (e[i] - init_end[i]) * (e[i] - init_end[i]);
+  if (sqrt(n2) < 0.00001) return 0;
+  if (e[5] > a_max || e[5] < a_min || e[4] > a_max || e[4] < a_min) return 0;
+  for (int ax = 0; ax < 2; ax++) {
+    double* co = ax == 0 ? out->cx : out->cy;
+    co[0] = ji[ax] / 6; co[1] = init_end[4 + ax] / 2; co[2] = init_end[2 + ax]; co[3] = init_end[ax];
+  }
+  double Qx[4], Qy[4];
+  orc_pos_ctrl_pts(out->cx, tau, Qx); orc_pos_ctrl_pts(out->cy, tau, Qy);
+  const double bx = c->pb[2 * (c->id - 1)], by = c->pb[2 * (c->id - 1) + 1];
+  for (int i = 0; i < 4; i++) {
+    if (Qx[i] < c->mins[0] || Qx[i] > c->maxs[0] || Qy[i] < c->mins[1] || Qy[i] > c->maxs[1]) return 0;
+    if (sqrt((Qx[i] - bx) * (Qx[i] - bx) + (Qy[i] - by) * (Qy[i] - by)) > c->cable_length) return 0;
+  }
+  if (!first) {
+    double Vx[3], Vy[3];
+    orc_vel_ctrl_pts(out->cx, tau, Vx); orc_vel_ctrl_pts(out->cy, tau, Vy);
+    for (int i = 0; i < 3; i++) if (Vx[i] < v_min || Vx[i] > v_max || Vy[i] < v_min || Vy[i] > v_max) return 0;
+  }
+  for (int ax = 0; ax < 2; ax++) {
+    const double a = e[4 + ax], v = e[2 + ax];
+    if (a > 0 && v - ((0.5 * a) * a) / j_min > v_max) return 0;
+    else if (a < 0 && v - ((0.5 * a) * a) / j_max < v_min) return 0;
+  }
+  for (int i = 0; i < 6; i++) out->end[i] = e[i];
+  const double arc = sqrt((e[0] - init_end[0]) * (e[0] - init_end[0]) + (e[1] - init_end[1]) * (e[1] - init_end[1]));
+  out->g = par_g + arc;
+  out->dist = sqrt((e[0] - goal[0]) * (e[0] - goal[0]) + (e[1] - goal[1]) * (e[1] - goal[1]));
+  out->f = out->g + c->bias * out->dist;
+  out->vx = (long)round(e[0] / c->voxel_size); out->vy = (long)round(e[1] / c->voxel_size);
+  return 1;
+}
+
+/* test hook: every feasible child's control polygon and collision verdict, [n][10] = depth, id, Q[4][2] ... */
+static double* g_fe_dump = 0; static int g_fe_dump_cap = 0, g_fe_dump_n = 0;
+void orc_fe_set_dump(double* buf, int cap) { g_fe_dump = buf; g_fe_dump_cap = cap; g_fe_dump_n = 0; }
+int orc_fe_dump_count(void) { return g_fe_dump_n; }
+
+static int fe_collides(const orc_fe_cfg* c, const fe_node* nd, int depth, const double* hull_xy, const int* hull_nv, const orc_polys* statics) {
+  double Qx[4], Qy[4], Q[4][2];
+  orc_pos_ctrl_pts(nd->cx, c->T_span, Qx); orc_pos_ctrl_pts(nd->cy, c->T_span, Qy);
+  for (int i = 0; i < 4; i++) { Q[i][0] = Qx[i]; Q[i][1] = Qy[i]; }
+  int idx = depth > c->num_pol ? c->num_pol : depth;
+  for (int j = 0; j < c->num_agents; j++) {
+    if (j == c->id - 1) continue;
+    const int nv = hull_nv[j * c->num_pol + (idx - 1)];
+    if (nv <= 0) continue;
+    const double(*V)[2] = (const double(*)[2])(hull_xy + ((size_t)(j * c->num_pol + (idx - 1)) * NEP_HULL_MAX_V) * 2);
+    if (!fe_aabb_overlap(nv, V, Qx, Qy)) continue;
+    if (orc_gjk_collision(nv, V, 4, (const double(*)[2])Q)) return 1;
+  }
+  for (int s = 0; statics && s < statics->n; s++) {
+    const int nv = statics->off[s + 1] - statics->off[s];
+    if (nv <= 0) continue;
+    const double(*V)[2] = (const double(*)[2])(statics->xy + 2 * (size_t)statics->off[s]);
+    if (!fe_aabb_overlap(nv, V, Qx, Qy)) continue;
+    if (orc_gjk_collision(nv, V, 4, (const double(*)[2])Q)) return 1;
+  }
+  return 0;
+}
+
+static int fe_before(const fe_node* a, int ia, const fe_node* b, int ib) { return a->f < b->f || (a->f == b->f && ia < ib); }
+
+int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv,
+                      const orc_polys* statics, nep_guess* guess, nep_fe_result* res) {
+  const int W = c->beam_width, ns = c->num_samples, NC = ns * ns, D = c->num_pol;
+  if (W < 1 || W > NEP_FE_MAX_BEAM || ns < 2 || ns > NEP_FE_MAX_SAMPLES || D < 1 || D > NEP_MAX_POL) return -1;
+  static const int CAP = NEP_FE_MAX_BEAM * NEP_FE_MAX_SAMPLES * NEP_FE_MAX_SAMPLES;
+  fe_node* cand = (fe_node*)malloc(sizeof(fe_node) * CAP);
+  int* keep = (int*)malloc(sizeof(int) * CAP);
+  fe_node (*beam)[NEP_FE_MAX_BEAM] = (fe_node(*)[NEP_FE_MAX_BEAM])malloc(sizeof(fe_node) * NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1));
+  int beam_n[NEP_MAX_POL + 2];
+  long (*visited)[2] = (long(*)[2])malloc(sizeof(long) * 2 * NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1));
+  int n_vis = 0;
+  memset(res, 0, sizeof(*res));
+  memset(guess, 0, sizeof(*guess));
+  guess->t_start = st->t_start;
+  const double goal[2] = {st->goal[0], st->goal[1]};
+  /* goal_occupied_ (setUp :210-226); recorded, the beam's ranking does not use it */
+  {
+    const double r = 0.5;
+    const double G[4][2] = {{goal[0] + r, goal[1] + r}, {goal[0] + r, goal[1] - r}, {goal[0] - r, goal[1] + r}, {goal[0] - r, goal[1] - r}};
+    for (int j = 0; j < c->num_agents && !res->goal_occupied; j++) {
+      if (j == c->id - 1) continue;
+      const int nv = hull_nv[j * c->num_pol + (c->num_pol - 1)];
+      if (nv <= 0) continue;
+      if (orc_gjk_collision(nv, (const double(*)[2])(hull_xy + ((size_t)(j * c->num_pol + c->num_pol - 1) * NEP_HULL_MAX_V) * 2), 4, G)) res->goal_occupied = 1;
+    }
+  }
+  const double root[6] = {st->pos[0], st->pos[1], st->vel[0], st->vel[1], st->accel[0], st->accel[1]};
+  int status = NEP_FE_NO_SOLUTION, best_depth = 0, best_rank = -1;
+  beam_n[0] = 1;
+  int depth;
+  for (depth = 1; depth <= D; depth++) {
+    const int n_par = depth == 1 ? 1 : beam_n[depth - 1];
+    int n_c = 0;
+    for (int pr = 0; pr < n_par; pr++)
+      for (int cc = 0; cc < NC; cc++) {
+        const int id = pr * NC + cc;
+        fe_node* nd = &cand[id];
+        keep[id] = 0;
+        res->n_children++;
+        const double* pe = depth == 1 ? root : beam[depth - 1][pr].end;
+        const double pg = depth == 1 ? 0.0 : beam[depth - 1][pr].g;
+        if (!fe_child(c, pe, pg, depth == 1, cc / ns, cc % ns, goal, nd)) continue;
+        nd->parent = depth == 1 ? -1 : pr;
+        res->n_feasible++;
+        {
+          const int col = fe_collides(c, nd, depth, hull_xy, hull_nv, statics);
+          if (g_fe_dump && g_fe_dump_n < g_fe_dump_cap) {
+            double* o = g_fe_dump + 11 * (size_t)g_fe_dump_n++;
+            double Qx[4], Qy[4]; orc_pos_ctrl_pts(nd->cx, c->T_span, Qx); orc_pos_ctrl_pts(nd->cy, c->T_span, Qy);
+            o[0] = depth; o[1] = id; o[2] = col; for (int k = 0; k < 4; k++) { o[3 + 2 * k] = Qx[k]; o[4 + 2 * k] = Qy[k]; }
+          }
+          if (col) continue;
+        }
+        res->n_collision_free++;
+        int seen = 0;
+        for (int v = 0; v < n_vis && !seen; v++) seen = visited[v][0] == nd->vx && visited[v][1] == nd->vy;
+        if (seen) continue;
+        keep[id] = 1;
+      }
+    n_c = n_par * NC;
+    /* one node per voxel: the best (f, id) of the depth */
+    for (int i = 0; i < n_c; i++) {
+      if (!keep[i]) continue;
+      for (int k = 0; k < n_c; k++) {
+        if (k == i || !keep[k] || cand[k].vx != cand[i].vx || cand[k].vy != cand[i].vy) continue;
+        if (fe_before(&cand[k], k, &cand[i], i)) { keep[i] = 2; break; }   /* 2: loses its voxel (still counts for the others' comparisons) */
+      }
+    }
+    /* the beam: the W best survivors in (f, id) order */
+    int nb = 0;
+    for (;;) {
+      int bi = -1;
+      for (int i = 0; i < n_c; i++) if (keep[i] == 1 && (bi < 0 || fe_before(&cand[i], i, &cand[bi], bi))) bi = i;
+      if (bi < 0 || nb == W) break;
+      beam[depth][nb++] = cand[bi];
+      keep[bi] = 3;
+    }
+    beam_n[depth] = nb;
+    if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
+    for (int r = 0; r < nb; r++) { visited[n_vis][0] = beam[depth][r].vx; visited[n_vis][1] = beam[depth][r].vy; n_vis++; }
+    best_depth = depth; best_rank = 0;
+    int reached = -1;
+    for (int r = 0; r < nb && reached < 0; r++) if (beam[depth][r].dist < c->goal_size) reached = r;
+    if (reached >= 0) { status = NEP_FE_GOAL_REACHED; best_rank = reached; break; }
+    if (depth == D) { status = NEP_FE_DEPTH_REACHED; break; }
+  }
+  res->status = status;
+  res->depth = depth > D ? D : depth;
+  if (best_rank >= 0) {
+    const fe_node* nd = &beam[best_depth][best_rank];
+    res->K = best_depth; res->cost = nd->f; res->dist_to_goal = nd->dist;
+    guess->K = best_depth;
+    int r = best_rank;
+    for (int d = best_depth; d >= 1; d--) {
+      const fe_node* q = &beam[d][r];
+      for (int k = 0; k < 4; k++) { guess->coeff[0][d - 1][k] = q->cx[k]; guess->coeff[1][d - 1][k] = q->cy[k]; }
+      guess->coeff[2][d - 1][0] = 0; guess->coeff[2][d - 1][1] = 0; guess->coeff[2][d - 1][2] = 0; guess->coeff[2][d - 1][3] = st->pos[2];
+      r = q->parent;
+    }
+  }
+  free(cand); free(keep); free(beam); free(visited);
+  return 0;
+}

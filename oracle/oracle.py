@@ -235,6 +235,53 @@ def replan(p, agent_id, recs, guess, statics, case_id=None, want_hulls=False):
     return out
 
 
+class orc_fe_cfg(C.Structure):
+    _fields_ = [("num_pol", C.c_int), ("id", C.c_int), ("num_agents", C.c_int), ("num_samples", C.c_int), ("beam_width", C.c_int),
+                ("T_span", C.c_double), ("j_max", C.c_double), ("v_max", C.c_double), ("a_max", C.c_double), ("voxel_size", C.c_double),
+                ("bias", C.c_double), ("goal_size", C.c_double), ("cable_length", C.c_double), ("mins", C.c_double * 2),
+                ("maxs", C.c_double * 2), ("pb", C.POINTER(C.c_double))]
+
+
+def frontend_beam(p, fe, agent_id, start, hull_xy, hull_nv, statics):
+    """The deterministic beam rule of include/neptune_frontend.h for one agent.  fe: abi.nep_fe_cfg; start: one
+    FE_START_DTYPE record; hull_xy/hull_nv as replan(..., want_hulls=True) returns them.  -> (guess record, result dict)."""
+    pb = _c(p.pb)
+    cfg = orc_fe_cfg(p.num_pol, agent_id, p.num_agents, fe.num_samples, fe.beam_width, p.T_span, fe.j_max, p.v_max, p.a_max,
+                     fe.voxel_size, fe.bias, fe.goal_size, fe.cable_length, (C.c_double * 2)(p.x_min, p.y_min),
+                     (C.c_double * 2)(p.x_max, p.y_max), abi.dptr(pb))
+    S = Polys(statics)
+    st = np.ascontiguousarray(start, dtype=abi.FE_START_DTYPE).reshape(1)
+    hx = _c(hull_xy); hn = _c(hull_nv, np.int32)
+    g = np.zeros(1, dtype=abi.GUESS_DTYPE); r = np.zeros(1, dtype=abi.FE_RESULT_DTYPE)
+    f = lib().orc_frontend_beam
+    f.restype = C.c_int
+    rc = f(C.byref(cfg), C.c_void_p(st.ctypes.data), C.c_void_p(hx.ctypes.data), C.c_void_p(hn.ctypes.data), C.byref(S.c),
+           C.c_void_p(g.ctypes.data), C.c_void_p(r.ctypes.data))
+    if rc:
+        raise RuntimeError("orc_frontend_beam: bad configuration")
+    return g[0], {k: r[0][k].item() for k in abi.FE_RESULT_DTYPE.names}
+
+
+def hulls_of_scene(p, agent_id, recs, t_start, statics):
+    """Interval hulls of every record as the oracle builds them for a replan at t_start:
+    (hull_xy [N][num_pol][16][2], hull_nv [N][num_pol])."""
+    g = np.zeros(1, dtype=abi.GUESS_DTYPE)
+    g["K"] = 1; g["t_start"] = t_start
+    out = replan(p, agent_id, recs, g[0], statics, want_hulls=True)
+    # orc_replan lists the hulls in obstacle order (ids 1..N that are present, own id skipped): back to id order
+    N = p.num_agents
+    cx = out["hull_xy"].reshape(-1, p.num_pol, abi.NEP_HULL_MAX_V, 2); cn = out["hull_nv"].reshape(-1, p.num_pol)
+    hx = np.zeros((N, p.num_pol, abi.NEP_HULL_MAX_V, 2)); hn = np.zeros((N, p.num_pol), dtype=np.int32)
+    recs = np.asarray(recs)
+    k = 0
+    for aid in range(1, N + 1):
+        m = [r for r in recs if int(r["id"]) == aid and r["valid"] and r["is_agent"]]
+        if aid == agent_id or not m:
+            continue
+        hx[aid - 1] = cx[k]; hn[aid - 1] = cn[k]; k += 1
+    return hx, hn
+
+
 def gjk_collision(V1, V2):
     """gjk::collision(vertices1, vertices2)."""
     V1 = _c(V1).reshape(-1, 2); V2 = _c(V2).reshape(-1, 2)

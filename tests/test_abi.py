@@ -36,6 +36,11 @@ def test_struct_layouts(L):
     assert abi.TRAJ_REC_DTYPE.itemsize == C.sizeof(abi.nep_traj_rec)
     assert abi.GUESS_DTYPE.itemsize == C.sizeof(abi.nep_guess)
     assert abi.SOLUTION_DTYPE.itemsize == C.sizeof(abi.nep_solution)
+    for k, t in ((11, abi.nep_fe_cfg), (12, abi.nep_fe_start), (13, abi.nep_fe_result)):      # include/neptune_frontend.h
+        assert C.sizeof(t) == L.nep_abi_sizeof(k), t.__name__
+    hdr = open(os.path.join(ROOT, "include", "neptune_frontend.h")).read()
+    declared = set(re.findall(r"^int\s+(nep_[a-z_0-9]+)\(", hdr, re.M))
+    assert declared == set(_lib.FE_EXPORTS) and all(hasattr(L, n) for n in declared)
 
 
 def test_fails_loudly_without_a_gpu(L):

@@ -1,0 +1,96 @@
+"""CPU: the front-end beam rule (include/neptune_frontend.h) as stated by the oracle —
+properties every guess must have, and hand-worked cases.  The GPU kernel is compared with this
+bit for bit in tests/test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+from neptune_amd import abi, scene
+
+T = 0.5
+
+
+def run_agent(oracle, sc, a, fe, starts=None):
+    p = sc["par"]
+    st = (starts if starts is not None else scene.frontend_starts(sc))[a]
+    hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(st["t_start"]), sc["statics"])
+    return oracle.frontend_beam(p, fe, a + 1, st, hx, hn, sc["statics"]), (hx, hn)
+
+
+def check_guess(oracle, sc, a, g, hx, hn, start):
+    """the returned primitives are continuous, inside the bounds and collision free"""
+    p = sc["par"]; K = int(g["K"])
+    co = np.array(g["coeff"])
+    pos, vel, acc = np.array(start["pos"][:2]), np.array(start["vel"][:2]), np.array(start["accel"][:2])
+    for s in range(K):
+        for ax in range(2):
+            c = co[ax, s]
+            assert c[3] == pos[ax] and c[2] == vel[ax] and c[1] == acc[ax] / 2          # starts where the previous one ended
+            assert abs(c[0] * 6) <= p.j_max + 1e-12
+        Q = np.array([oracle.pos_ctrl_pts(co[0, s], T), oracle.pos_ctrl_pts(co[1, s], T)])
+        assert (Q[0] >= p.x_min).all() and (Q[0] <= p.x_max).all() and (Q[1] >= p.y_min).all() and (Q[1] <= p.y_max).all()
+        if s > 0:
+            V = np.array([oracle.vel_ctrl_pts(co[0, s], T), oracle.vel_ctrl_pts(co[1, s], T)])
+            assert (np.abs(V) <= p.v_max).all()
+        for j in range(p.num_agents):
+            if j == a or hn[j, s] <= 0:
+                continue
+            assert not oracle.gjk_collision(hx[j, s, :hn[j, s]], Q.T), (a, s, j)
+        for poly in sc["statics"]:
+            assert not oracle.gjk_collision(poly, Q.T)
+        jerk = 6 * co[:2, s, 0]
+        pos, vel, acc = (pos + vel * T + acc * T * T / 2 + jerk * T ** 3 / 6, vel + acc * T + jerk * T * T / 2, acc + jerk * T)
+        assert (np.abs(acc) <= p.a_max + 1e-9).all()
+
+
+def test_guesses_of_a_scene_are_feasible_and_head_for_the_goal(oracle):
+    sc = scene.make_scene(8, 6, seed=5)
+    fe = scene.frontend_cfg(sc["par"], beam_width=32)
+    starts = scene.frontend_starts(sc)
+    moved = 0
+    for a in range(8):
+        (g, r), (hx, hn) = run_agent(oracle, sc, a, fe, starts)
+        assert r["status"] in (abi_fe("GOAL"), abi_fe("DEPTH")) and r["K"] == int(g["K"]) >= 1
+        assert r["n_children"] >= r["n_feasible"] >= r["n_collision_free"] > 0
+        check_guess(oracle, sc, a, g, hx, hn, starts[a])
+        d0 = np.hypot(*(np.array(starts[a]["pos"][:2]) - np.array(starts[a]["goal"][:2])))
+        assert r["dist_to_goal"] < d0 + 1e-9
+        moved += r["dist_to_goal"] < d0 - 1.0
+    assert moved >= 6
+
+
+def abi_fe(name):
+    return {"GOAL": 1, "DEPTH": 0, "EMPTY": 2, "NONE": 3}[name]
+
+
+def test_goal_next_to_the_start_is_reached_early(oracle):
+    sc = scene.make_scene(3, 0, seed=2)
+    p = sc["par"]
+    fe = scene.frontend_cfg(p, beam_width=16)
+    starts = scene.frontend_starts(sc)
+    starts[0]["vel"] = 0; starts[0]["accel"] = 0
+    starts[0]["goal"][:2] = np.array(starts[0]["pos"][:2]) + [0.10, 0.0]        # inside goal_size after one small step
+    (g, r), _ = run_agent(oracle, sc, 0, fe, starts)
+    assert r["status"] == abi_fe("GOAL") and r["K"] < p.num_pol and r["dist_to_goal"] < fe.goal_size
+
+
+def test_boxed_in_start_has_no_solution(oracle):
+    sc = scene.make_scene(3, 0, seed=2)
+    p = sc["par"]
+    fe = scene.frontend_cfg(p, beam_width=8)
+    fe.cable_length = 0.01                    # every control point is farther than this from the base
+    (g, r), _ = run_agent(oracle, sc, 0, fe)
+    assert r["status"] == abi_fe("NONE") and int(g["K"]) == 0 and r["n_feasible"] == 0
+
+
+def test_beam_width_one_is_greedy_and_wider_beams_do_not_do_worse(oracle):
+    sc = scene.make_scene(8, 10, seed=9)
+    costs = {}
+    for W in (1, 8, 64):
+        fe = scene.frontend_cfg(sc["par"], beam_width=W)
+        tot = 0.0
+        for a in range(8):
+            (g, r), _ = run_agent(oracle, sc, a, fe)
+            assert r["n_children"] <= 25 * (1 + (sc["par"].num_pol - 1) * W)
+            tot += r["cost"] if r["K"] else 1e3
+        costs[W] = tot
+    assert costs[64] <= costs[1] + 1e-9

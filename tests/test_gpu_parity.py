@@ -507,6 +507,66 @@ def test_sharded_hull_blocks_equal_the_single_rank_replan(be, world, entangle):
     full.close()
 
 
+def test_gjk_batch_matches_the_oracle(be, oracle):
+    """gjk::collision on the device (safety check, front end) against the restatement: identical verdicts
+    on control polygons scattered around real interval hulls and inflated statics."""
+    sc = scene.make_scene(8, 6, seed=5)
+    p = sc["par"]
+    hx, hn = oracle.hulls_of_scene(p, 1, sc["committed"], 0.0, sc["statics"])
+    rng = np.random.default_rng(0)
+    polys, quads = [], []
+    shapes = [hx[j, i, :hn[j, i]] for j in range(1, 8) for i in range(8) if hn[j, i] > 0] + [np.asarray(s) for s in sc["statics"]]
+    for V in shapes:
+        c = V.mean(axis=0)
+        for _ in range(150):
+            polys.append(V)
+            quads.append(c + rng.normal(scale=1.5, size=2) + rng.normal(scale=0.6, size=(4, 2)).cumsum(axis=0))
+    got = be.gjk_batch(polys, np.array(quads))
+    want = np.array([oracle.gjk_collision(P, Q) for P, Q in zip(polys, quads)])
+    assert 0.2 < want.mean() < 0.9
+    np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("n_agents,n_static,seed,W", [(8, 6, 5, 32), (8, 10, 9, 64), (5, 0, 3, 1), (16, 8, 4, 16)])
+def test_frontend_beam_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_static, seed, W):
+    """the front-end kernel against the deterministic beam rule of the oracle — the
+    guesses (lattice primitives) must be identical, then the back end runs on the device-made guesses."""
+    sc = scene.make_scene(n_agents, n_static, seed=seed)
+    p = sc["par"]; N = p.num_agents
+    fe = scene.frontend_cfg(p, beam_width=W)
+    starts = scene.frontend_starts(sc)
+    bb = be.BatchBackend(p, sc["statics"])
+    d_com = bb.to_device(sc["committed"])
+    d_start = bb.to_device(starts)
+    d_guess = bb.torch.zeros(N * abi.GUESS_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
+    d_res = bb.torch.zeros(N * abi.FE_RESULT_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
+    bb.frontend(fe, d_com, d_start, d_guess, d_res)
+    bb.torch.cuda.synchronize()
+    got_g = d_guess.cpu().numpy().view(abi.GUESS_DTYPE)
+    got_r = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)
+    n_ok = 0
+    for a in range(N):
+        hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(starts[a]["t_start"]), sc["statics"])
+        g, r = oracle.frontend_beam(p, fe, a + 1, starts[a], hx, hn, sc["statics"])
+        for f in abi.FE_RESULT_DTYPE.names:
+            assert got_r[a][f] == r[f], (a, f, got_r[a][f], r[f])
+        assert int(got_g[a]["K"]) == int(g["K"]) and got_g[a]["t_start"] == g["t_start"]
+        np.testing.assert_array_equal(got_g[a]["coeff"], g["coeff"])
+        n_ok += int(g["K"]) > 0
+    assert n_ok >= N - 1
+    # the back end on the device-made guesses
+    bb.replan(d_com, d_guess)
+    sol = bb.solutions()
+    for a in range(N):
+        K = int(got_g[a]["K"])
+        if K == 0:
+            continue
+        r = oracle.replan(p, a + 1, sc["committed"], got_g[a], sc["statics"])
+        assert int(sol[a]["stats"]["status"]) == r["status"], a
+        assert np.abs(np.array(sol[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= COEF_TOL
+    bb.close()
+
+
 def test_safety_check_and_commit(be, oracle):
     """conflict matrix (GJK on the new trajectories' hulls), id-ordered
     resolution and the committed records, bit for bit against the oracle."""
