@@ -724,26 +724,14 @@ __device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const doub
 }
 
 constexpr int kFeCap = NEP_FE_MAX_BEAM * NEP_FE_MAX_SAMPLES * NEP_FE_MAX_SAMPLES;   // 1600
+constexpr int kFeVis = 1024;    // visited-voxel hash slots (<= 64 * 8 keys)
+constexpr int kFeDd = 2048;     // per-depth voxel -> best candidate hash slots (<= 1600 keys)
+constexpr unsigned long long kFeEmpty = ~0ull;
 
-// order-preserving compaction of the ids with flag[id] == want into list; returns the count (uniform)
-__device__ int fe_compact(int n, const unsigned char* flag, int want, unsigned short* list, int* s_cnt) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int base = 0;
-  for (int i0 = 0; i0 < n; i0 += 256) {
-    const int id = i0 + tid;
-    const bool on = id < n && flag[id] == want;
-    const unsigned long long m = __ballot(on);
-    if (lane == 0) s_cnt[wave] = __popcll(m);
-    __syncthreads();
-    int off = base;
-    for (int w = 0; w < wave; w++) off += s_cnt[w];
-    if (on) list[off + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)id;
-    base += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    __syncthreads();
-  }
-  return base;
-}
+__device__ __forceinline__ unsigned fe_hash(long long vox) { return (unsigned)(((unsigned long long)vox * 0x9E3779B97F4A7C15ull) >> 40); }
 
+// The serial loops of this kernel run out of LDS with every load independent of the previous
+// iteration's result (dense arrays, no early exits): they are latency-bound otherwise.
 __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
                                                        nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out) {
   extern __shared__ __attribute__((aligned(16))) double fe_smem[];
@@ -751,27 +739,35 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
   const int slot = blockIdx.x, scene = slot / sp.n_local, own = sp.first_local + (slot % sp.n_local);
   const int N = sp.num_agents, S = sp.n_static, W = fc.beam_width, ns = fc.num_samples, NC = ns * ns, D = sp.num_pol;
   // ---- LDS carve ----
-  double* s_f = fe_smem;                                   // [kFeCap]
-  double* b_end = s_f + kFeCap;                            // [2][64][6]
+  double* s_f = fe_smem;                                   // [kFeCap] f of candidate id
+  double* r_f = s_f + kFeCap;                              // [kFeCap] f of the voxel winners, dense
+  double* b_end = r_f + kFeCap;                            // [2][64][6]
   double* b_g = b_end + 2 * NEP_FE_MAX_BEAM * 6;           // [2][64]
   double* b_dist = b_g + 2 * NEP_FE_MAX_BEAM;              // [64]
   double* b_f = b_dist + NEP_FE_MAX_BEAM;                  // [64]
-  double* o_aabb = b_f + NEP_FE_MAX_BEAM;                  // [N+S][4]
+  double* p_box = b_f + NEP_FE_MAX_BEAM;                   // [64][4] box of every parent's children
+  double* o_aabb = p_box + NEP_FE_MAX_BEAM * 4;            // [N+S][4] boxes of the shortlisted obstacles, dense
   long long* s_vox = (long long*)(o_aabb + 4 * (N + S));   // [kFeCap]
-  long long* s_vis = s_vox + kFeCap;                       // [64 * NEP_MAX_POL]
-  int* o_nv = (int*)(s_vis + NEP_FE_MAX_BEAM * NEP_MAX_POL);   // [N+S]
-  int* s_i = o_nv + (N + S);                               // [16] scratch / counters
-  unsigned short* s_la = (unsigned short*)(s_i + 16);      // [kFeCap]
-  unsigned short* s_lb = s_la + kFeCap;                    // [kFeCap]
-  unsigned char* s_state = (unsigned char*)(s_lb + kFeCap);   // [kFeCap] 0 dead, 1 alive, 2 lost its voxel
+  unsigned long long* v_key = (unsigned long long*)(s_vox + kFeCap);   // [kFeVis] visited voxels
+  int* d_slot = (int*)(v_key + kFeVis);                    // [kFeDd] voxel -> best candidate of the depth
+  int* o_nv = d_slot + kFeDd;                              // [N+S] dense
+  int* o_id = o_nv + (N + S);                              // [N+S] dense: obstacle index (agent j or N + static)
+  int* s_i = o_id + (N + S);                               // [16] counters
+  unsigned short* r_id = (unsigned short*)(s_i + 16);      // [kFeCap] ids of the voxel winners, dense
+  unsigned char* s_state = (unsigned char*)(r_id + kFeCap);   // [kFeCap] 0 dead, 1 alive, 2 lost its voxel
   signed char* p_parent = (signed char*)(s_state + kFeCap);   // [NEP_MAX_POL + 1][64]
   signed char* p_comb = p_parent + (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
 
   const nep_fe_start* st = starts + slot;
   const double gx = st->goal[0], gy = st->goal[1];
   const double bx = ps.pb[2 * own], by = ps.pb[2 * own + 1];
-  const double root[6] = {st->pos[0], st->pos[1], st->vel[0], st->vel[1], st->accel[0], st->accel[1]};
-  if (tid < 16) s_i[tid] = 0;     // [4] children, [5] feasible, [6] collision free, [7] goal occupied
+  if (tid < 16) s_i[tid] = 0;     // [0] shortlist n, [1] winners n, [4] children, [5] feasible, [6] collision free, [7] goal occupied
+  for (int k = tid; k < kFeVis; k += 256) v_key[k] = kFeEmpty;
+  if (tid < 6) {                  // the root is the one-node beam of depth 0
+    const double v = tid == 0 ? st->pos[0] : tid == 1 ? st->pos[1] : tid == 2 ? st->vel[0] : tid == 3 ? st->vel[1] : tid == 4 ? st->accel[0] : st->accel[1];
+    b_end[tid] = v;               // parity 0
+    if (tid == 0) b_g[0] = 0.0;
+  }
   __syncthreads();
   // goal_occupied_ (setUp :210-226)
   {
@@ -785,32 +781,58 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
       if (nv > 0 && gjk_collision(nv, blk(ps.hull_xy, hr.boff) + h * kHullV * 2, G)) s_i[7] = 1;
     }
   }
-  int status = NEP_FE_NO_SOLUTION, best_depth = 0, best_rank = -1, n_vis = 0, nb_prev = 1, depth;
+  int status = NEP_FE_NO_SOLUTION, best_depth = 0, best_rank = -1, nb_prev = 1, depth;
   int my_children = 0, my_feasible = 0, my_free = 0;
+  const double tau = sp.T_span, delta = (fc.j_max + fc.j_max) / (ns - 1);
   for (depth = 1; depth <= D; depth++) {
     const int cur = depth & 1, prv = cur ^ 1;
     const int idx = (depth > D ? D : depth) - 1;
     __syncthreads();
-    // ---- obstacle boxes of this interval ----
+    // ---- box of every parent's children: the control points are monotone in the jerk, so the four corner
+    //      children bound them all (a superset of every child's own box, feasible or not) ----
+    if (tid < nb_prev) {
+      const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + tid) * 6;
+      double lo[2], hi[2];
+#pragma unroll
+      for (int ax = 0; ax < 2; ax++) {
+        double l = __builtin_huge_val(), h = -__builtin_huge_val();
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+          const double ji = -fc.j_max + (e ? ns - 1 : 0) * delta;
+          const double P[4] = {ji / 6, pe[4 + ax] / 2, pe[2 + ax], pe[ax]};
+          double Q[4];
+          fe_pos_cps(P, tau, Q);
+#pragma unroll
+          for (int k = 0; k < 4; k++) { if (Q[k] < l) l = Q[k]; if (Q[k] > h) h = Q[k]; }
+        }
+        lo[ax] = l; hi[ax] = h;
+      }
+      p_box[4 * tid] = lo[0]; p_box[4 * tid + 1] = hi[0]; p_box[4 * tid + 2] = lo[1]; p_box[4 * tid + 3] = hi[1];
+    }
+    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; }
+    for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
+    __syncthreads();
+    // ---- shortlist: obstacles of this interval whose box meets some parent's box ----
     for (int j = tid; j < N + S; j += 256) {
       int nv = 0; const double* V = nullptr;
       if (j < N) {
         if (j != own) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
       } else { nv = ps.static_nv[j - N]; V = ps.static_xy + (long)(j - N) * kHullV * 2; }
-      o_nv[j] = nv;
-      if (nv > 0) {
-        double x0 = V[0], x1 = V[0], y0 = V[1], y1 = V[1];
-        for (int i = 1; i < nv; i++) { const double x = V[2 * i], y = V[2 * i + 1]; if (x < x0) x0 = x; if (x > x1) x1 = x; if (y < y0) y0 = y; if (y > y1) y1 = y; }
-        o_aabb[4 * j] = x0; o_aabb[4 * j + 1] = x1; o_aabb[4 * j + 2] = y0; o_aabb[4 * j + 3] = y1;
-      }
+      if (nv <= 0) continue;
+      double x0 = V[0], x1 = V[0], y0 = V[1], y1 = V[1];
+      for (int i = 1; i < nv; i++) { const double x = V[2 * i], y = V[2 * i + 1]; if (x < x0) x0 = x; if (x > x1) x1 = x; if (y < y0) y0 = y; if (y > y1) y1 = y; }
+      bool near = false;
+      for (int q = 0; q < nb_prev; q++) near |= !(x1 < p_box[4 * q] || p_box[4 * q + 1] < x0 || y1 < p_box[4 * q + 2] || p_box[4 * q + 3] < y0);
+      if (near) { const int o = atomicAdd(&s_i[0], 1); o_aabb[4 * o] = x0; o_aabb[4 * o + 1] = x1; o_aabb[4 * o + 2] = y0; o_aabb[4 * o + 3] = y1; o_nv[o] = nv; o_id[o] = j; }
     }
     __syncthreads();
+    const int n_obs = s_i[0];
     // ---- children: one per thread ----
     const int n_c = nb_prev * NC;
     for (int id = tid; id < n_c; id += 256) {
       const int pr = id / NC, cc = id % NC;
-      const double* pe = depth == 1 ? root : b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
-      const double pg = depth == 1 ? 0.0 : b_g[prv * NEP_FE_MAX_BEAM + pr];
+      const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
+      const double pg = b_g[prv * NEP_FE_MAX_BEAM + pr];
       FeChild ch;
       unsigned char alive = 0;
       my_children++;
@@ -819,55 +841,69 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
         double qx0 = ch.Qx[0], qx1 = ch.Qx[0], qy0 = ch.Qy[0], qy1 = ch.Qy[0];
 #pragma unroll
         for (int i = 1; i < 4; i++) { if (ch.Qx[i] < qx0) qx0 = ch.Qx[i]; if (ch.Qx[i] > qx1) qx1 = ch.Qx[i]; if (ch.Qy[i] < qy0) qy0 = ch.Qy[i]; if (ch.Qy[i] > qy1) qy1 = ch.Qy[i]; }
-        Pts4 B;
-#pragma unroll
-        for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
+        unsigned long long cand_mask = 0;     // shortlisted obstacles whose box meets this child's (shortlists beyond 64 fall back to a direct test)
         bool hit = false;
-        for (int j = 0; j < N + S && !hit; j++) {
-          const int nv = o_nv[j];
-          if (nv <= 0) continue;
-          if (o_aabb[4 * j + 1] < qx0 || qx1 < o_aabb[4 * j] || o_aabb[4 * j + 3] < qy0 || qy1 < o_aabb[4 * j + 2]) continue;
-          const double* V;
-          if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); V = blk(ps.hull_xy, hr.boff) + (hr.e * sp.num_pol + idx) * kHullV * 2; }
-          else V = ps.static_xy + (long)(j - N) * kHullV * 2;
-          hit = gjk_collision(nv, V, B);
+        for (int o = 0; o < n_obs; o++) {
+          const bool ov = !(o_aabb[4 * o + 1] < qx0 || qx1 < o_aabb[4 * o] || o_aabb[4 * o + 3] < qy0 || qy1 < o_aabb[4 * o + 2]);
+          if (ov) { if (o < 64) cand_mask |= 1ull << o; else if (!hit) {
+            Pts4 B;
+#pragma unroll
+            for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
+            const int j = o_id[o]; const double* V;
+            if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); V = blk(ps.hull_xy, hr.boff) + (hr.e * sp.num_pol + idx) * kHullV * 2; } else V = ps.static_xy + (long)(j - N) * kHullV * 2;
+            hit = gjk_collision(o_nv[o], V, B);
+          } }
+        }
+        while (cand_mask && !hit) {
+          const int o = __ffsll((long long)cand_mask) - 1; cand_mask &= cand_mask - 1;
+          Pts4 B;
+#pragma unroll
+          for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
+          const int j = o_id[o]; const double* V;
+          if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); V = blk(ps.hull_xy, hr.boff) + (hr.e * sp.num_pol + idx) * kHullV * 2; } else V = ps.static_xy + (long)(j - N) * kHullV * 2;
+          hit = gjk_collision(o_nv[o], V, B);
         }
         if (!hit) {
           my_free++;
           const long long vox = ((long long)ch.vx << 32) | (unsigned int)ch.vy;
           bool seen = false;
-          for (int v = 0; v < n_vis && !seen; v++) seen = s_vis[v] == vox;
+          for (unsigned h = fe_hash(vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long k = v_key[h]; if (k == (unsigned long long)vox) { seen = true; break; } if (k == kFeEmpty) break; }
           if (!seen) { alive = 1; s_f[id] = ch.f; s_vox[id] = vox; }
         }
       }
       s_state[id] = alive;
     }
     __syncthreads();
-    // ---- one node per voxel: the best (f, id) ----
-    const int n_a = fe_compact(n_c, s_state, 1, s_la, s_i);
-    for (int a = tid; a < n_a; a += 256) {
-      const int i = s_la[a];
-      const double fi = s_f[i]; const long long vi = s_vox[i];
-      bool lose = false;
-      for (int b = 0; b < n_a && !lose; b++) {
-        const int k = s_la[b];
-        if (k != i && s_vox[k] == vi) { const double fk = s_f[k]; lose = fk < fi || (fk == fi && k < i); }
+    // ---- one node per voxel: the best (f, id) claims the voxel's slot; whoever is displaced or beaten is out ----
+    for (int id = tid; id < n_c; id += 256) {
+      if (s_state[id] != 1) continue;
+      const long long vi = s_vox[id]; const double fi = s_f[id];
+      unsigned h = fe_hash(vi) & (kFeDd - 1);
+      for (;;) {
+        int k = atomicCAS(&d_slot[h], -1, id);
+        if (k == -1) break;                                           // took an empty slot
+        if (s_vox[k] != vi) { h = (h + 1) & (kFeDd - 1); continue; }  // another voxel's slot
+        const double fk = s_f[k];
+        if (fk < fi || (fk == fi && k < id)) { s_state[id] = 2; break; }   // the holder is better
+        if (atomicCAS(&d_slot[h], k, id) == k) { s_state[k] = 2; break; }  // displaced the holder
       }
-      if (lose) s_state[i] = 2;
     }
     __syncthreads();
-    // ---- the beam: rank among the voxel winners ----
-    const int n_b = fe_compact(n_c, s_state, 1, s_lb, s_i);
+    for (int id = tid; id < n_c; id += 256) if (s_state[id] == 1) { const int o = atomicAdd(&s_i[1], 1); r_f[o] = s_f[id]; r_id[o] = (unsigned short)id; }
+    __syncthreads();
+    // ---- the beam: rank among the voxel winners (dense arrays) ----
+    const int n_b = s_i[1];
     const int nb = n_b < W ? n_b : W;
     for (int a = tid; a < n_b; a += 256) {
-      const int i = s_lb[a];
-      const double fi = s_f[i];
+      const int i = r_id[a];
+      const double fi = r_f[a];
       int rank = 0;
-      for (int b = 0; b < n_b; b++) { const int k = s_lb[b]; const double fk = s_f[k]; if (fk < fi || (fk == fi && k < i)) rank++; }
+#pragma unroll 4
+      for (int b = 0; b < n_b; b++) { const int k = r_id[b]; const double fk = r_f[b]; rank += (fk < fi || (fk == fi && k < i)) ? 1 : 0; }
       if (rank < W) {   // recompute the child (same arithmetic) and install it
         const int pr = i / NC, cc = i % NC;
-        const double* pe = depth == 1 ? root : b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
-        const double pg = depth == 1 ? 0.0 : b_g[prv * NEP_FE_MAX_BEAM + pr];
+        const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
+        const double pg = b_g[prv * NEP_FE_MAX_BEAM + pr];
         FeChild ch;
         fe_child(sp, fc, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch);
 #pragma unroll
@@ -875,15 +911,16 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
         b_g[cur * NEP_FE_MAX_BEAM + rank] = ch.g; b_dist[rank] = ch.dist; b_f[rank] = ch.f;
         p_parent[depth * NEP_FE_MAX_BEAM + rank] = (signed char)(depth == 1 ? -1 : pr);
         p_comb[depth * NEP_FE_MAX_BEAM + rank] = (signed char)cc;
-        s_vis[n_vis + rank] = s_vox[i];
+        const unsigned long long vox = (unsigned long long)s_vox[i];      // close the voxel to later depths
+        for (unsigned h = fe_hash((long long)vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long o = atomicCAS(&v_key[h], kFeEmpty, vox); if (o == kFeEmpty || o == vox) break; }
       }
     }
     __syncthreads();
     if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
-    n_vis += nb; nb_prev = nb;
+    nb_prev = nb;
     best_depth = depth; best_rank = 0;
     int reached = -1;
-    for (int r = 0; r < nb && reached < 0; r++) if (b_dist[r] < fc.goal_size) reached = r;   // (every thread: uniform)
+    for (int r = nb - 1; r >= 0; r--) if (b_dist[r] < fc.goal_size) reached = r;   // first in rank order (every thread: uniform)
     if (reached >= 0) { status = NEP_FE_GOAL_REACHED; best_rank = reached; break; }
     if (depth == D) { status = NEP_FE_DEPTH_REACHED; break; }
   }
@@ -894,14 +931,14 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
     for (int e = 0; e < 3 * NEP_MAX_POL * 4; e++) (&g->coeff[0][0][0])[e] = 0.0;
     g->t_start = st->t_start; g->K = best_rank >= 0 ? best_depth : 0; g->n_alpha = 0;
     if (best_rank >= 0) {
-      signed char combs[NEP_MAX_POL];
-      int r = best_rank;
-      for (int d = best_depth; d >= 1; d--) { combs[d - 1] = p_comb[d * NEP_FE_MAX_BEAM + r]; r = p_parent[d * NEP_FE_MAX_BEAM + r]; }
       double pe[6]; double pg = 0.0;
-      for (int q = 0; q < 6; q++) pe[q] = root[q];
+      pe[0] = st->pos[0]; pe[1] = st->pos[1]; pe[2] = st->vel[0]; pe[3] = st->vel[1]; pe[4] = st->accel[0]; pe[5] = st->accel[1];
+      signed char path[NEP_MAX_POL];
+      int r = best_rank;
+      for (int d = best_depth; d >= 1; d--) { path[d - 1] = p_comb[d * NEP_FE_MAX_BEAM + r]; r = p_parent[d * NEP_FE_MAX_BEAM + r]; }
       for (int d = 1; d <= best_depth; d++) {   // replay the path from the root with the same arithmetic
         FeChild ch;
-        fe_child(sp, fc, pe, pg, d == 1, combs[d - 1] / ns, combs[d - 1] % ns, gx, gy, bx, by, ch);
+        fe_child(sp, fc, pe, pg, d == 1, path[d - 1] / ns, path[d - 1] % ns, gx, gy, bx, by, ch);
         for (int k = 0; k < 4; k++) { g->coeff[0][d - 1][k] = ch.cx[k]; g->coeff[1][d - 1][k] = ch.cy[k]; }
         g->coeff[2][d - 1][3] = st->pos[2];
         for (int q = 0; q < 6; q++) pe[q] = ch.e[q];
@@ -932,9 +969,9 @@ void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const
 
 size_t frontend_lds_bytes(const SceneParams& sp) {
   const size_t NS = (size_t)sp.num_agents + sp.n_static;
-  size_t b = sizeof(double) * (kFeCap + 2 * NEP_FE_MAX_BEAM * 6 + 2 * NEP_FE_MAX_BEAM + 2 * NEP_FE_MAX_BEAM + 4 * NS)
-           + sizeof(long long) * (kFeCap + NEP_FE_MAX_BEAM * NEP_MAX_POL) + sizeof(int) * (NS + 16)
-           + sizeof(unsigned short) * 2 * kFeCap + kFeCap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
+  size_t b = sizeof(double) * (2 * kFeCap + 2 * NEP_FE_MAX_BEAM * 6 + 2 * NEP_FE_MAX_BEAM + 2 * NEP_FE_MAX_BEAM + 4 * NEP_FE_MAX_BEAM + 4 * NS)
+           + sizeof(long long) * (kFeCap + kFeVis) + sizeof(int) * (kFeDd + 2 * NS + 16)
+           + sizeof(unsigned short) * kFeCap + kFeCap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
   return (b + 15) & ~(size_t)15;
 }
 
