@@ -567,6 +567,40 @@ def test_frontend_beam_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_st
     bb.close()
 
 
+def test_frontend_multi_scene_and_agent_shard(be, oracle):
+    """The front end with several scenes per launch and on an agent shard (first_local > 0), different
+    t_start per scene: slot -> (scene, agent) bookkeeping, hull interval grid and own-hull skipping."""
+    from neptune_amd import dist as ndist
+    S, N = 3, 6
+    scenes = [scene.make_scene(N, 5, seed=80 + s) for s in range(S)]
+    for k, sc in enumerate(scenes):
+        sc["statics"] = scenes[0]["statics"]
+        sc["guesses"]["t_start"] += 0.35 * k                     # every scene on its own clock
+        sc["committed"]["pwp"]["times"] += 0.35 * k
+    p = scenes[0]["par"]
+    com, _ = ndist.stack_scenes(scenes)
+    fe = scene.frontend_cfg(p, beam_width=24)
+    starts = np.stack([scene.frontend_starts(sc) for sc in scenes])          # [S][N]
+    for first, nl in ((0, 6), (2, 2), (3, 3)):
+        bb = be.BatchBackend(p, scenes[0]["statics"], first_local=first, n_local=nl, n_scenes=S)
+        d_start = bb.to_device(np.ascontiguousarray(starts[:, first:first + nl]))
+        d_guess = bb.torch.zeros(S * nl * abi.GUESS_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
+        d_res = bb.torch.zeros(S * nl * abi.FE_RESULT_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
+        bb.frontend(fe, bb.to_device(com), d_start, d_guess, d_res)
+        bb.torch.cuda.synchronize()
+        got_g = d_guess.cpu().numpy().view(abi.GUESS_DTYPE).reshape(S, nl)
+        got_r = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE).reshape(S, nl)
+        for s_ in range(S):
+            for al in range(nl):
+                a = first + al
+                hx, hn = oracle.hulls_of_scene(p, a + 1, com[s_], float(starts[s_, a]["t_start"]), scenes[0]["statics"])
+                g, r = oracle.frontend_beam(p, fe, a + 1, starts[s_, a], hx, hn, scenes[0]["statics"])
+                assert int(got_r[s_, al]["status"]) == r["status"] and int(got_r[s_, al]["n_collision_free"]) == r["n_collision_free"], (first, s_, a)
+                np.testing.assert_array_equal(got_g[s_, al]["coeff"], g["coeff"])
+                assert got_g[s_, al]["t_start"] == g["t_start"] and int(got_g[s_, al]["K"]) == int(g["K"])
+        bb.close()
+
+
 def test_safety_check_and_commit(be, oracle):
     """conflict matrix (GJK on the new trajectories' hulls), id-ordered
     resolution and the committed records, bit for bit against the oracle."""
