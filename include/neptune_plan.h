@@ -39,6 +39,16 @@ extern "C" {
  * Returns NEP_OK, NEP_E_ARG (null / malformed n_seg), NEP_E_CAP (> NEP_TRAJ_MAX_SEG intervals).  */
 int nep_pwp_compose(double t, double dc, nep_pwp* p1, nep_pwp* p2, nep_pwp* out);
 
+/* Extension (no reference counterpart): the composition that reproduces the flown path.  The reference
+ * routine above gives the stretch that ends at p2.times[0] the coefficients of p1's LAST interval
+ * (utils.cpp:388-393) and leaves the first, partial interval on its source interval's local time, so
+ * between a commit and the next point A a published trajectory can sit metres away from the vehicle.
+ * Here every interval of out carries the coefficients of the source interval that covers it, re-based
+ * (Taylor shift) to its own first knot; past p1's last knot its end point is held.  Knots: t, p1's knots
+ * inside (t, p2.times[0]), p2.times[0], p2's knots.  With t >= p2.times[0] the result is p2 from t on.
+ * Returns NEP_OK, NEP_E_ARG, NEP_E_CAP.                                                          */
+int nep_pwp_compose_exact(double t, const nep_pwp* p1, const nep_pwp* p2, nep_pwp* out);
+
 /* ---------------------------------------------------------------------------------------------
  * mader_msgs/DynTraj in ROS1 serialisation (little endian; every array = uint32 count + items;
  * string = uint32 length + bytes; bool = 1 byte).  Field order:

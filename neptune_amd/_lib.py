@@ -23,7 +23,7 @@ EXPORTS = [
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
-    "nep_pwp_compose", "nep_dyntraj_wire_size", "nep_dyntraj_encode", "nep_dyntraj_decode", "nep_plan_create",
+    "nep_pwp_compose", "nep_pwp_compose_exact", "nep_dyntraj_wire_size", "nep_dyntraj_encode", "nep_dyntraj_decode", "nep_plan_create",
     "nep_plan_destroy", "nep_plan_reset", "nep_plan_size", "nep_plan_get", "nep_plan_next_goal",
     "nep_plan_select_a", "nep_plan_splice", "nep_plan_update_delta", "nep_plan_delta",
 ]
@@ -87,6 +87,7 @@ def lib():
     ppwp, prec, phdr = C.POINTER(abi.nep_pwp), C.POINTER(abi.nep_traj_rec), C.POINTER(abi.nep_wire_header)
     pu8 = C.POINTER(C.c_uint8)
     L.nep_pwp_compose.argtypes = [d, d, ppwp, ppwp, ppwp]
+    L.nep_pwp_compose_exact.argtypes = [d, ppwp, ppwp, ppwp]
     L.nep_dyntraj_wire_size.argtypes = [prec, phdr]; L.nep_dyntraj_wire_size.restype = C.c_int64
     L.nep_dyntraj_encode.argtypes = [prec, phdr, pu8, C.c_size_t]; L.nep_dyntraj_encode.restype = C.c_int64
     L.nep_dyntraj_decode.argtypes = [pu8, C.c_size_t, prec, phdr]; L.nep_dyntraj_decode.restype = C.c_int64

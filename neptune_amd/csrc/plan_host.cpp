@@ -124,6 +124,64 @@ int nep_pwp_compose(double t, double /*dc*/, nep_pwp* p1, nep_pwp* p2, nep_pwp* 
   return NEP_OK;
 }
 
+// Composition that describes the flown path exactly (an extension; see neptune_plan.h): every interval
+// carries the coefficients of the source interval that actually covers it, re-based to its own knot.
+static void rebase(const double c[4], double s, double o[4]) {      // q(w) = p(w + s)
+  o[0] = c[0];
+  o[1] = 3 * c[0] * s + c[1];
+  o[2] = (3 * c[0] * s + 2 * c[1]) * s + c[2];
+  o[3] = ((c[0] * s + c[1]) * s + c[2]) * s + c[3];
+}
+// p restricted to [t0, t1] appended to res (t0 < t1); beyond p's last knot the end point is held
+static bool append_span(nep_pwp* res, const nep_pwp* p, double t0, double t1) {
+  const int n = p->n_seg;
+  double a = t0;
+  while (a < t1) {
+    int k = 0;
+    while (k < n && p->times[k + 1] <= a) k++;
+    if (res->n_seg >= NEP_TRAJ_MAX_SEG) return false;
+    const int o = res->n_seg++;
+    double b;
+    if (k >= n) {                                   // past the end: hold the final point
+      b = t1;
+      const double T = p->times[n] - p->times[n - 1];
+      for (int ax = 0; ax < 3; ax++) {
+        double e[4]; rebase(p->coeff[ax][n - 1], T, e);
+        res->coeff[ax][o][0] = res->coeff[ax][o][1] = res->coeff[ax][o][2] = 0.0; res->coeff[ax][o][3] = e[3];
+      }
+    } else {
+      b = p->times[k + 1] < t1 ? p->times[k + 1] : t1;
+      const double s = a - p->times[k] > 0 ? a - p->times[k] : 0.0;    // (a before p's first knot: p's start is extended backwards)
+      for (int ax = 0; ax < 3; ax++) rebase(p->coeff[ax][k], a - p->times[k] < 0 ? a - p->times[k] : s, res->coeff[ax][o]);
+    }
+    res->times[o + 1] = b;
+    a = b;
+  }
+  return true;
+}
+
+int nep_pwp_compose_exact(double t, const nep_pwp* p1, const nep_pwp* p2, nep_pwp* out) {
+  if (!pwp_ok(p1) || !pwp_ok(p2) || !out || p1->n_seg < 1 || p2->n_seg < 1) return NEP_E_ARG;
+  nep_pwp res;
+  std::memset(&res, 0, sizeof(res));
+  const double t2 = p2->times[0];
+  if (t < t2) {                                       // the old trajectory until the new one takes over
+    res.times[0] = t;
+    if (!append_span(&res, p1, t, t2)) return NEP_E_CAP;
+    for (int i = 0; i < p2->n_seg; i++) {
+      if (res.n_seg >= NEP_TRAJ_MAX_SEG) return NEP_E_CAP;
+      const int o = res.n_seg++;
+      res.times[o + 1] = p2->times[i + 1];
+      for (int ax = 0; ax < 3; ax++) std::memcpy(res.coeff[ax][o], p2->coeff[ax][i], 4 * sizeof(double));
+    }
+  } else {                                            // the new trajectory has already started: its part from t on
+    res.times[0] = t;
+    if (!append_span(&res, p2, t, p2->times[p2->n_seg] > t ? p2->times[p2->n_seg] : t + 1.0)) return NEP_E_CAP;
+  }
+  *out = res;
+  return NEP_OK;
+}
+
 int64_t nep_dyntraj_wire_size(const nep_traj_rec* rec, const nep_wire_header* hdr) {
   Writer w{nullptr, 0, 0, true};
   return write_dyntraj(rec, hdr, w);

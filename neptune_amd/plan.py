@@ -59,6 +59,24 @@ def compose_piecewise_pol(t, dc, p1, p2):
     return out
 
 
+def compose_exact(t, p1, p2):
+    """nep_pwp_compose_exact: the old trajectory from t until p2 starts, then p2, every interval on its own
+    local time (what a closed loop should publish; the reference routine does not reproduce the flown path)."""
+    out = abi.nep_pwp()
+    _ck(lib().nep_pwp_compose_exact(float(t), C.byref(p1), C.byref(p2), C.byref(out)), "nep_pwp_compose_exact")
+    return out
+
+
+def eval_pwp(p, t):
+    """position at time t of a nep_pwp whose intervals run on their own local time (held outside its span)"""
+    times, co = pwp_arrays(p)
+    n = p.n_seg
+    k = int(np.searchsorted(times, t, side="right") - 1)
+    k = min(max(k, 0), n - 1)
+    dt = min(max(t - times[k], 0.0), times[k + 1] - times[k])
+    return np.array([((co[ax, k, 0] * dt + co[ax, k, 1]) * dt + co[ax, k, 2]) * dt + co[ax, k, 3] for ax in range(3)])
+
+
 def dyntraj_encode(rec, seq=0, stamp=(0, 0), frame_id=b""):
     """nep_traj_rec (ctypes struct or 1-element TRAJ_REC_DTYPE array) -> bytes of one mader_msgs/DynTraj."""
     rec = _as_rec(rec)

@@ -54,6 +54,16 @@ def compose_piecewise_pol(t, dc, p1, p2):
     return p
 
 
+def eval_source(p, t):
+    """ground truth of a trajectory whose intervals run on their own local time; end point held after it"""
+    n = len(p.cx)
+    k = 0
+    while k < n - 1 and p.times[k + 1] <= t:
+        k += 1
+    dt = min(t - p.times[k], p.times[k + 1] - p.times[k])
+    return [((c[k][0] * dt + c[k][1]) * dt + c[k][2]) * dt + c[k][3] for c in (p.cx, p.cy, p.cz)]
+
+
 # ---------------------------------------------------------------------------------------------
 # mader_msgs/DynTraj on the ROS1 wire
 # ---------------------------------------------------------------------------------------------

@@ -601,6 +601,23 @@ def test_frontend_multi_scene_and_agent_shard(be, oracle):
         bb.close()
 
 
+@pytest.mark.parametrize("n_agents,n_static,seed,min_reached", [(8, 6, 5, 8), (64, 20, 0, 60)])
+def test_closed_loop_fleet_flies_to_its_goals_without_collisions(be, n_agents, n_static, seed, min_reached):
+    """Everything together (neptune_amd/loop.py): point A from the plan deque -> front-end guess -> separating
+    lines + QP -> safety check -> plan splice + composition -> tracker, in bulk-synchronous rounds until
+    the fleet has arrived.  The planner's contract: centres never closer than the inflation it plans with."""
+    from neptune_amd.loop import FleetLoop
+    sc = scene.make_scene(n_agents, n_static, seed=seed)
+    p = sc["par"]
+    loop = FleetLoop(p, sc["statics"], sc["starts"], sc["goals"], beam_width=32)
+    st = loop.run(max_rounds=400)
+    loop.close()
+    assert st["reached"] >= min_reached, st
+    assert st["min_pair_dist"] >= 2 * p.drone_radius - 0.06, st          # 1.2 m nominal; the tracker runs one tick behind a resting start
+    assert st["min_static_dist"] >= 2 * p.drone_radius + 0.2 - 0.02, st   # inflation of the static obstacles (neptune.cpp:642)
+    assert st["accepted"] > 0.8 * st["replans"] and st["qp_failed"] < 0.01 * st["replans"], st
+
+
 def test_safety_check_and_commit(be, oracle):
     """conflict matrix (GJK on the new trajectories' hulls), id-ordered
     resolution and the committed records, bit for bit against the oracle."""

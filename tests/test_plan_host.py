@@ -342,3 +342,30 @@ def test_plan_exports_and_layouts(L):
         assert hasattr(L, name), name
     for k, t in ((8, abi.nep_wire_header), (9, abi.nep_plan_cfg), (10, abi.nep_point_a)):
         assert C.sizeof(t) == L.nep_abi_sizeof(k), t.__name__
+
+
+def test_compose_exact_reproduces_both_sources():
+    """the extension: the composed trajectory equals the old one until the new one starts, then the new one"""
+    rng = np.random.default_rng(21)
+    for trial in range(300):
+        n1, n2 = int(rng.integers(1, 9)), int(rng.integers(1, 9))
+        t1, c1 = rand_pwp(rng, n1, float(rng.uniform(0, 3)), uniform=bool(rng.integers(0, 2)))
+        t2, c2 = rand_pwp(rng, n2, float(rng.uniform(t1[0] + 0.05, t1[-1] + 0.8)))
+        t = float(rng.uniform(t1[0] - 0.2, t2[0] + (0.3 if rng.integers(0, 5) == 0 else -0.01)))
+        a1, a2 = plan.make_pwp(t1, c1), plan.make_pwp(t2, c2)
+        out = plan.compose_exact(t, a1, a2)
+        o1, o2 = to_oracle(t1, c1), to_oracle(t2, c2)
+        times, _ = plan.pwp_arrays(out)
+        assert times[0] == t and (np.diff(times) > 0).all()
+        for ts in np.linspace(t, t2[-1] - 1e-9, 40):
+            if ts < t2[0]:
+                want = po.eval_source(o1, ts) if ts >= t1[0] else None
+            else:
+                want = po.eval_source(o2, ts)
+            if want is not None:
+                np.testing.assert_allclose(plan.eval_pwp(out, ts), want, rtol=0, atol=1e-9)
+    # hover past the end of the old trajectory until the new one starts
+    t1, c1 = rand_pwp(rng, 2, 0.0); t2, c2 = rand_pwp(rng, 3, 2.0)
+    out = plan.compose_exact(1.5, plan.make_pwp(t1, c1), plan.make_pwp(t2, c2))
+    end = po.eval_source(to_oracle(t1, c1), 1.0)
+    np.testing.assert_allclose(plan.eval_pwp(out, 1.7), end, atol=1e-12)
