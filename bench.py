@@ -186,11 +186,14 @@ def main():
     d_guess_all = be.to_device(np.ascontiguousarray(gue)) if args.safety else None   # t_start source of the safety pass
     safety_ev, hull_ev, gather_ev, fe_ev = [], [], [], []
     REC = abi.TRAJ_REC_DTYPE.itemsize
-    if args.frontend and world > 1:
-        raise SystemExit("--frontend is a single-GPU option in this round")
+    if args.frontend and world > 1 and not (sharded_hulls and not args.safety):
+        raise SystemExit("--frontend with several GPUs needs --exchange hulls and no --safety")
     fe_cfg = scene.frontend_cfg(p, beam_width=args.beam) if args.frontend else None
-    d_fe_start = be.to_device(np.concatenate([scene.frontend_starts(s) for s in mine])) if args.frontend else None
-    d_fe_res = torch.zeros(S * N * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) if args.frontend else None
+    fe_starts = share(np.stack([scene.frontend_starts(s) for s in mine])) if args.frontend else None       # [S][N]
+    d_fe_start_c = [bes[k].to_device(np.ascontiguousarray(fe_starts[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)] if args.frontend else None
+    d_fe_start = d_fe_start_c[0] if args.frontend else None
+    d_fe_res_c = [torch.zeros(Sc * n_local * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(C)] if args.frontend else None
+    d_fe_res = d_fe_res_c[0] if args.frontend else None
     pending = [None] * C
 
     def ev():
@@ -215,6 +218,10 @@ def main():
                 e1 = ev()
                 pending[k].wait()
                 gather_ev.append((e1, ev()))                 # what the stream still had to wait for
+                if args.frontend:
+                    e0 = ev()
+                    bes[k].frontend_hulls(fe_cfg, hxs[k].blocks, d_fe_start_c[k], d_guess_c[k], d_fe_res_c[k])
+                    fe_ev.append((e0, ev()))
                 bes[k].replan_hulls(hxs[k].blocks, d_guess_c[k])
                 start_exchange(k, bes[k].d_commit)           # my agents' new committed trajectories
             return
@@ -286,8 +293,11 @@ def main():
     value = replans_per_step * args.steps / dt
 
     if rank == 0:
-        from neptune_amd.backend import hulls_batch
-        _, hn, _, _ = hulls_batch(com[0], float(gue[0, 0]["t_start"]), p.num_pol, p.T_span, p.drone_radius)   # vertex counts of scene 0
+        if C == 1 and not sharded_hulls and not args.frontend:
+            _, hn = be.debug_hulls(0)          # vertex counts of scene 0 as the last timed launch saw them
+        else:
+            from neptune_amd.backend import hulls_batch
+            _, hn, _, _ = hulls_batch(com[0], float(gue[0, 0]["t_start"]), p.num_pol, p.T_span, p.drone_radius)   # scene 0 at the start
         bytes_per_replan = algorithmic_bytes(p, scene0, hn, n_states)
         launch_replans = Sc * n_local
         achieved = bytes_per_replan * launch_replans / (qp_ms * 1e-3) / 1e9 if qp_ms > 0 else 0.0

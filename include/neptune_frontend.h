@@ -90,6 +90,12 @@ int nep_batch_frontend(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec
                        const nep_fe_start* d_start, nep_guess* d_guess, nep_fe_result* d_result,
                        void* stream);
 
+/* The same against all-gathered hull blocks (multi-GPU rounds, include/neptune_backend.h:
+ * nep_batch_hulls -> all-gather -> nep_batch_frontend_hulls -> nep_batch_replan_hulls).            */
+int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* d_blocks, int32_t n_blocks,
+                             const nep_fe_start* d_start, nep_guess* d_guess, nep_fe_result* d_result,
+                             void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@ PLAN_EXPORTS = [
 ]
 # every symbol include/neptune_entangle.h declares (host-only)
 # include/neptune_frontend.h
-FE_EXPORTS = ["nep_batch_frontend"]
+FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls"]
 ENT_EXPORTS = ["nep_ent_sample_points", "nep_ent_propagate_segment", "nep_ent_propagate_guess", "nep_ent_case_ids"]
 
 
@@ -107,6 +107,7 @@ def lib():
     L.nep_ent_propagate_guess.argtypes = [pcfg, pin, pst, vp, i, pi, pi, pi, pi, pst]
     L.nep_ent_case_ids.argtypes = [i, i, pi, pi, pi, i, pi]
     L.nep_batch_frontend.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, vp, vp, vp, vp]
+    L.nep_batch_frontend_hulls.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, i, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -253,6 +253,12 @@ class BatchBackend:
         check(lib().nep_batch_frontend(self._h, C.byref(fe_cfg), d_committed.data_ptr(), d_start.data_ptr(), d_guess.data_ptr(),
                                        d_result.data_ptr() if d_result is not None else None, st.cuda_stream))
 
+    def frontend_hulls(self, fe_cfg, d_blocks, d_start, d_guess, d_result=None, stream=None):
+        """the front end against all-gathered hull blocks (see hulls / replan_hulls)"""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_frontend_hulls(self._h, C.byref(fe_cfg), d_blocks.data_ptr(), self.N // self.n_local, d_start.data_ptr(),
+                                             d_guess.data_ptr(), d_result.data_ptr() if d_result is not None else None, st.cuda_stream))
+
     def safety_commit(self, d_prev, d_new, d_guess, d_final, d_accept=None, stream=None):
         """Post-solve safety check + commit (nep_batch_safety_commit); tensors are device byte/int32 tensors."""
         st = stream if stream is not None else self.torch.cuda.current_stream(self.device)

@@ -639,6 +639,24 @@ int nep_batch_frontend(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec
   return 0;
 }
 
+// the same against all-gathered hull blocks (multi-GPU rounds: nep_batch_hulls -> all-gather -> this -> nep_batch_replan_hulls)
+int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* d_blocks, int32_t n_blocks, const nep_fe_start* d_start,
+                             nep_guess* d_guess, nep_fe_result* d_result, void* stream) {
+  if (!h || !cfg || !d_blocks || !d_start || !d_guess) return fail(NEP_E_ARG, "null argument");
+  if (n_blocks < 1 || n_blocks * h->cfg.n_local != h->cfg.num_agents) return fail(NEP_E_ARG, "n_blocks * n_local must equal num_agents");
+  if (cfg->num_samples < 2 || cfg->num_samples > NEP_FE_MAX_SAMPLES || cfg->beam_width < 1 || cfg->beam_width > NEP_FE_MAX_BEAM ||
+      !(cfg->voxel_size > 0.0) || !(cfg->j_max > 0.0)) return fail(NEP_E_ARG, "bad front-end configuration");
+  Engine& E = h->eng;
+  const HullBlock b = hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol);
+  ProblemSet ps{};
+  E.fill(ps);
+  point_at_block(ps, b, const_cast<void*>(d_blocks));
+  ps.hull_pb = h->cfg.n_local; ps.hull_bstride = (long)b.bytes;
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new, const nep_guess* d_guess,
                             nep_traj_rec* d_final, int32_t* d_accept, void* stream) {
   if (!h || !d_prev || !d_new || !d_guess || !d_final) return fail(NEP_E_ARG, "null argument");

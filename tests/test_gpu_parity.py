@@ -502,6 +502,21 @@ def test_sharded_hull_blocks_equal_the_single_rank_replan(be, world, entangle):
         np.testing.assert_array_equal(gc["pwp"]["coeff"], want_commit[:, r * nl:(r + 1) * nl]["pwp"]["coeff"])
         n_lines += int(got["stats"]["n_lines"].sum())
     assert n_lines > 0
+    # the front end against the same gathered blocks equals the single-rank front end
+    fe = scene.frontend_cfg(p, beam_width=16)
+    starts = np.stack([scene.frontend_starts(sc) for sc in scenes])
+    T_ = full.torch
+    d_g = T_.zeros(S * N * abi.GUESS_DTYPE.itemsize, dtype=T_.uint8, device=full.device)
+    full.frontend(fe, full.to_device(com), full.to_device(starts), d_g)
+    T_.cuda.synchronize()
+    want_g = d_g.cpu().numpy().view(abi.GUESS_DTYPE).reshape(S, N)
+    for r in range(world):
+        d_gl = T_.zeros(S * nl * abi.GUESS_DTYPE.itemsize, dtype=T_.uint8, device=full.device)
+        ranks[r].frontend_hulls(fe, blocks, ranks[r].to_device(np.ascontiguousarray(starts[:, r * nl:(r + 1) * nl])), d_gl)
+        T_.cuda.synchronize()
+        got_g = d_gl.cpu().numpy().view(abi.GUESS_DTYPE).reshape(S, nl)
+        np.testing.assert_array_equal(got_g["coeff"], want_g[:, r * nl:(r + 1) * nl]["coeff"])
+        np.testing.assert_array_equal(got_g["K"], want_g[:, r * nl:(r + 1) * nl]["K"])
     for r in ranks:
         r.close()
     full.close()
