@@ -283,6 +283,12 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
                             const nep_guess* d_guess, nep_traj_rec* d_final, int32_t* d_accept,
                             void* stream);
 /* Test hook: the conflict matrix [N][N] of one scene from the last safety check. */
+/* on != 0: nep_batch_safety_commit additionally turns down a new trajectory that collides with the
+ * PREVIOUS record of any other agent (its hulls on the round's grid).  The spline QP keeps the two
+ * apart wherever a separating line was found; where the LP had no solution the reference skips the
+ * constraint (solver_gurobi_poly.cpp:483-494) and nothing else certifies the pair — an agent that is
+ * turned down this round keeps flying exactly that previous trajectory.  Off by default.          */
+int nep_batch_set_safety_check_prev(nep_batch_t* h, int32_t on);
 int nep_batch_debug_conflicts(nep_batch_t* h, int32_t scene, uint8_t* conflict_out);
 
 /* Blocks until everything enqueued by this handle on `stream` has finished. */

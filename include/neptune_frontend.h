@@ -58,6 +58,12 @@ typedef struct nep_fe_cfg {
   double cable_length;            /* par_.tetherLength                                             */
   int32_t num_samples;            /* par_.a_star_samp_x, <= NEP_FE_MAX_SAMPLES                     */
   int32_t beam_width;             /* <= NEP_FE_MAX_BEAM (this build's search width)                */
+  int32_t pad_hold;               /* 1: a guess shorter than num_pol (goal reached early, beam died out) is
+                                     extended with segments that hold its end point, so that the back end
+                                     also separates the place where the vehicle will WAIT from everybody's
+                                     committed trajectory (the reference leaves that unchecked,
+                                     kinodynamic_search.cpp:1805-1813)                               */
+  int32_t _pad;
 } nep_fe_cfg;
 
 /* Point A and the goal of one slot (setUp, kinodynamic_search.cpp:190-227).                      */

@@ -119,7 +119,8 @@ class nep_ent_state(C.Structure):
 class nep_fe_cfg(C.Structure):
     """include/neptune_frontend.h: the KinodynamicSearch setters the batched front end needs."""
     _fields_ = [("j_max", C.c_double), ("voxel_size", C.c_double), ("bias", C.c_double), ("goal_size", C.c_double),
-                ("cable_length", C.c_double), ("num_samples", C.c_int32), ("beam_width", C.c_int32)]
+                ("cable_length", C.c_double), ("num_samples", C.c_int32), ("beam_width", C.c_int32),
+                ("pad_hold", C.c_int32), ("_pad", C.c_int32)]
 
 
 class nep_fe_start(C.Structure):

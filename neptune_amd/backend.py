@@ -265,6 +265,10 @@ class BatchBackend:
         check(lib().nep_batch_safety_commit(self._h, d_prev.data_ptr(), d_new.data_ptr(), d_guess.data_ptr(), d_final.data_ptr(),
                                             d_accept.data_ptr() if d_accept is not None else None, st.cuda_stream))
 
+    def set_safety_check_prev(self, on=True):
+        """also turn down new trajectories that collide with another agent's PREVIOUS record (nep_batch_set_safety_check_prev)"""
+        check(lib().nep_batch_set_safety_check_prev(self._h, 1 if on else 0))
+
     def debug_conflicts(self, scene=0):
         out = np.zeros((self.N, self.N), dtype=np.uint8)
         check(lib().nep_batch_debug_conflicts(self._h, scene, out.ctypes.data_as(C.POINTER(C.c_uint8))))

@@ -51,7 +51,8 @@ struct Engine {
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_lp_stats;
   DevBuf<long long> d_dbg; bool profile_phases = false;
-  DevBuf<unsigned char> d_conflict;
+  DevBuf<unsigned char> d_conflict, d_conflict_prev;
+  bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
@@ -167,7 +168,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release();
-    d_conflict.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_lp_stats.release();
+    d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
   }
@@ -667,10 +668,13 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
   ProblemSet ps{};
   E.fill(ps);
   ps.guess = d_guess;
-  launch_safety(d_prev, d_new, h->cfg.n_scenes, N, E.sp, ps, E.d_conflict.p, d_final, d_accept, (hipStream_t)stream);
+  if (E.safety_check_prev) { if (int e = E.d_conflict_prev.ensure((size_t)h->cfg.n_scenes * N * N)) return e; }
+  launch_safety(d_prev, d_new, h->cfg.n_scenes, N, E.sp, ps, E.d_conflict.p, E.safety_check_prev ? E.d_conflict_prev.p : nullptr, d_final, d_accept, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
+
+int nep_batch_set_safety_check_prev(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.safety_check_prev = on != 0; return 0; }
 
 int nep_batch_debug_conflicts(nep_batch_t* h, int32_t scene, uint8_t* conflict_out) {
   if (!h || !conflict_out || scene < 0 || scene >= h->cfg.n_scenes) return fail(NEP_E_ARG, "bad arguments");

@@ -576,7 +576,7 @@ __device__ bool gjk_collision(int n1, const double* __restrict__ V1, const Pts4&
 // conflict[scene][a][j] = agent a's new trajectory hits the interval hulls of agent j's new
 // trajectory (trajsAndPwpAreInCollision2d on the round's interval grid).  One wave per (scene, a);
 // lanes stride over j.  Hulls come from hull_kernel run on the new records.
-__global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec* __restrict__ fresh, int N, int num_pol, double T_span,
+__global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec* __restrict__ fresh, const nep_traj_rec* __restrict__ other, int N, int num_pol, double T_span,
                                                              const double* __restrict__ hull_xy, const int* __restrict__ hull_nv,
                                                              unsigned char* __restrict__ conflict) {
   __shared__ double sBx[NEP_MAX_POL * 4], sBy[NEP_MAX_POL * 4];
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec*
   __syncthreads();
   for (int j = lane; j < N; j += 64) {
     bool hit = false;
-    const nep_traj_rec* rj = fresh + (long)scene * N + j;
+    const nep_traj_rec* rj = other + (long)scene * N + j;     // whose hulls these are (the new or the previous records)
     if (j != a && Ka > 0 && rj->valid && rj->is_agent) {
       for (int i = 0; i < Ka && !hit; i++) {
         Pts4 B;
@@ -616,17 +616,21 @@ __global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec*
 // Agents visited by id; an agent keeps its new trajectory unless it conflicts (either direction)
 // with an already accepted lower id.  One workgroup per scene; then the final records are written.
 __global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec* __restrict__ prev, const nep_traj_rec* __restrict__ fresh, int N,
-                                                             const unsigned char* __restrict__ conflict, nep_traj_rec* __restrict__ final_out,
-                                                             int* __restrict__ accept_out) {
+                                                             const unsigned char* __restrict__ conflict, const unsigned char* __restrict__ conflict_prev,
+                                                             nep_traj_rec* __restrict__ final_out, int* __restrict__ accept_out) {
   extern __shared__ int sAcc[];   // [N] accept flags + [1] vote
   const int tid = threadIdx.x, scene = blockIdx.x;
   const unsigned char* Cm = conflict + (long)scene * N * N;
+  const unsigned char* Cp = conflict_prev ? conflict_prev + (long)scene * N * N : nullptr;
   int* vote = sAcc + N;
   for (int a = 0; a < N; a++) {
     if (tid == 0) *vote = 0;
     __syncthreads();
     bool bad = false;
     for (int j = tid; j < a; j += blockDim.x) bad = bad || (sAcc[j] && (Cm[(long)a * N + j] || Cm[(long)j * N + a]));
+    // (optional) the new trajectory must also clear what everybody else is flying now: whoever is turned
+    // down this round keeps exactly that
+    if (Cp) for (int j = tid; j < N; j += blockDim.x) bad = bad || (j != a && Cp[(long)a * N + j]);
     if (bad) *vote = 1;
     __syncthreads();
     if (tid == 0) sAcc[a] = *vote ? 0 : 1;
@@ -642,12 +646,17 @@ __global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec*
 }
 
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
-                   unsigned char* conflict, nep_traj_rec* final_out, int* accept_out, hipStream_t st) {
+                   unsigned char* conflict, unsigned char* conflict_prev, nep_traj_rec* final_out, int* accept_out, hipStream_t st) {
   if (n_scenes * N <= 0) return;
+  if (conflict_prev) {   // new trajectories against the hulls of the PREVIOUS records on the same grid
+    hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, prev, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
+                       sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr);
+    hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, prev, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict_prev);
+  }
   hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, fresh, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
                      sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr);
-  hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
-  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, final_out, accept_out);
+  hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
+  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, final_out, accept_out);
 }
 
 
@@ -943,6 +952,10 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
         g->coeff[2][d - 1][3] = st->pos[2];
         for (int q = 0; q < 6; q++) pe[q] = ch.e[q];
         pg = ch.g;
+      }
+      if (fc.pad_hold && best_depth < D) {   // hold the end point for the rest of the horizon
+        for (int d = best_depth + 1; d <= D; d++) { g->coeff[0][d - 1][3] = pe[0]; g->coeff[1][d - 1][3] = pe[1]; g->coeff[2][d - 1][3] = st->pos[2]; }
+        g->K = D;
       }
     }
     if (res_out) {

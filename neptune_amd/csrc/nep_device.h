@@ -97,6 +97,6 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
                      nep_guess* guess_out, nep_fe_result* res_out, hipStream_t st);
 void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const double* b_xy, int* hit, hipStream_t st);
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
-                   unsigned char* conflict, nep_traj_rec* final_out, int* accept_out, hipStream_t st);
+                   unsigned char* conflict, unsigned char* conflict_prev, nep_traj_rec* final_out, int* accept_out, hipStream_t st);
 
 }  // namespace nep

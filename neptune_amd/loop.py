@@ -20,7 +20,8 @@ class FleetLoop:
         self.N = N = par.num_agents
         self.goals = np.asarray(goals, dtype=np.float64).reshape(N, 3)
         self.be = BatchBackend(par, statics, n_scenes=1, device=device)
-        self.fe = scene.frontend_cfg(par, beam_width=beam_width)
+        self.be.set_safety_check_prev(True)    # nobody commits a trajectory that crosses what somebody else may keep flying
+        self.fe = scene.frontend_cfg(par, beam_width=beam_width, pad_hold=1)
         self.dc, self.T = par.dc, par.T_span
         self.k_a = delta_t_states - 1          # index of point A in the plan (neptune.cpp:1376-1385 with deltaT_ states ahead)
         self.replan_every = replan_every       # control ticks between rounds (replan timer / dc)
@@ -33,6 +34,7 @@ class FleetLoop:
             self.plans[a].reset(self.state[a])
         self.prev_pwp = [None] * N             # composed committed trajectory (pwp_prev_)
         self.done = np.zeros(N, dtype=bool)
+        self.trace = None                      # set to a list to record (t, agent, outcome, K) of every replan
         self.stats = dict(rounds=0, replans=0, accepted=0, fe_no_solution=0, qp_failed=0, qp_relaxed=0, rejected_by_safety=0,
                           min_pair_dist=np.inf, min_static_dist=np.inf)
         self._static_pts = [np.asarray(s, dtype=np.float64) for s in scene_raw(statics, par)]
@@ -103,17 +105,15 @@ class FleetLoop:
                 continue
             self.stats["replans"] += 1
             K = int(sol[a]["K"]); status = int(sol[a]["stats"]["status"])
-            if int(fres[a]["status"]) == 3 or K == 0:
-                self.stats["fe_no_solution"] += 1
-                continue
-            if status == abi.NEP_FAILED:
-                self.stats["qp_failed"] += 1
-                continue                        # optimize() false: the agent keeps its plan (neptune.cpp:1519-1545)
+            outcome = ("fe_no_solution" if int(fres[a]["status"]) == 3 or K == 0 else
+                       "qp_failed" if status == abi.NEP_FAILED else
+                       "rejected_by_safety" if not acc[a] else "accepted")
+            if self.trace is not None:
+                self.trace.append((t_now, a, outcome, K, int(fres[a]["status"]), status))
+            self.stats[outcome] += 1
+            if outcome != "accepted":
+                continue                        # replanFull() false: the agent keeps its plan (neptune.cpp:1519-1545, neptune_ros.cpp:651-663)
             self.stats["qp_relaxed"] += status == abi.NEP_RELAXED
-            if not acc[a]:
-                self.stats["rejected_by_safety"] += 1
-                continue
-            self.stats["accepted"] += 1
             ns = int(sol[a]["n_states"])
             self.plans[a].splice(int(k_end[a]), states[a, :ns])
             new = plan.make_pwp(np.array(sol[a]["times"])[: K + 1], np.array(sol[a]["coeff"])[:, :K, :])

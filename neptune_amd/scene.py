@@ -380,10 +380,10 @@ def tether_crossing_scene(num_agents, n_static, seed):
     return sc
 
 
-def frontend_cfg(p, beam_width=32, num_samples=5):
+def frontend_cfg(p, beam_width=32, num_samples=5, pad_hold=0):
     """The front-end settings Neptune's constructor passes (neptune.cpp:92-97) with the reference yaml values
     (a_star_samp_x 5, a_star_fraction_voxel_size 0.2, goal_radius 0.2, bias 1.1)."""
-    return abi.nep_fe_cfg(p.j_max, 0.2, 1.1, 0.2, p.tether_length, num_samples, beam_width)
+    return abi.nep_fe_cfg(p.j_max, 0.2, 1.1, 0.2, p.tether_length, num_samples, beam_width, pad_hold, 0)
 
 
 def frontend_starts(sc):
@@ -396,3 +396,24 @@ def frontend_starts(sc):
         st[a]["goal"] = sc["goals"][a]
         st[a]["t_start"] = sc["guesses"][a]["t_start"]
     return st
+
+
+def reachable_goals(sc, margin=0.4):
+    """Goals of a scene with those that fall inside an inflated static obstacle (the scene generator only
+    keeps the first K segments of the way clear) pushed out through the nearest face, `margin` beyond it."""
+    goals = np.array(sc["goals"], dtype=np.float64)
+    for i in range(len(goals)):
+        for _ in range(4):
+            moved = False
+            for s in sc["statics"]:
+                v = np.asarray(s, dtype=np.float64)
+                lo, hi = v.min(axis=0) - margin, v.max(axis=0) + margin
+                g = goals[i, :2]
+                if (g > lo).all() and (g < hi).all():
+                    d = np.array([g[0] - lo[0], hi[0] - g[0], g[1] - lo[1], hi[1] - g[1]])
+                    k = int(np.argmin(d))
+                    goals[i, 0 if k < 2 else 1] = [lo[0], hi[0], lo[1], hi[1]][k]
+                    moved = True
+            if not moved:
+                break
+    return goals

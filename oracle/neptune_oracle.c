@@ -906,6 +906,26 @@ void orc_safety_resolve(int n, const nep_traj_rec* fresh, double t_start, double
   }
 }
 
+/* The same with nep_batch_set_safety_check_prev: a new trajectory that collides with the previous record
+ * of any other agent (on the round's grid) is turned down too. */
+void orc_safety_resolve_prev(int n, const nep_traj_rec* prev, const nep_traj_rec* fresh, double t_start, double T_span, double drone_radius,
+                             unsigned char* conflict, int* accept) {
+  orc_safety_resolve(n, fresh, t_start, T_span, drone_radius, conflict, accept);
+  for (int a = 0; a < n; a++) {
+    int bad = 0;
+    for (int j = 0; j < n && !bad; j++)
+      if (j != a && fresh[a].valid && prev[j].valid && prev[j].is_agent) bad = trajs_collide_on_grid(&prev[j], &fresh[a].pwp, t_start, T_span, drone_radius);
+    if (bad) accept[a] = -1;
+  }
+  /* redo the id-ordered pass with the turned-down agents out of it */
+  for (int a = 0; a < n; a++) {
+    if (accept[a] == -1) { accept[a] = 0; continue; }
+    int ok = 1;
+    for (int j = 0; j < a; j++) if (accept[j] && (conflict[a * n + j] || conflict[j * n + a])) { ok = 0; break; }
+    accept[a] = ok;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* front-end initial guess — the deterministic beam rule of               */
 /* include/neptune_frontend.h over KinodynamicSearch's lattice, pruning and cost rules          */
@@ -1108,6 +1128,13 @@ int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double*
       for (int k = 0; k < 4; k++) { guess->coeff[0][d - 1][k] = q->cx[k]; guess->coeff[1][d - 1][k] = q->cy[k]; }
       guess->coeff[2][d - 1][0] = 0; guess->coeff[2][d - 1][1] = 0; guess->coeff[2][d - 1][2] = 0; guess->coeff[2][d - 1][3] = st->pos[2];
       r = q->parent;
+    }
+    if (c->pad_hold && best_depth < D) {   /* hold the end point for the rest of the horizon */
+      for (int d = best_depth + 1; d <= D; d++) {
+        for (int ax = 0; ax < 3; ax++) for (int k = 0; k < 3; k++) guess->coeff[ax][d - 1][k] = 0;
+        guess->coeff[0][d - 1][3] = nd->end[0]; guess->coeff[1][d - 1][3] = nd->end[1]; guess->coeff[2][d - 1][3] = st->pos[2];
+      }
+      guess->K = D;
     }
   }
   free(cand); free(keep); free(beam); free(visited);

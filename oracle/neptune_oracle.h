@@ -112,12 +112,14 @@ int orc_replan(const orc_params* par, double drone_radius, int n_rec, const nep_
 int orc_gjk_collision(int n1, const double (*V1)[2], int n2, const double (*V2)[2]);
 int orc_trajs_and_pwp_in_collision(const nep_traj_rec* other, const nep_pwp* mine, double T_span, double drone_radius);
 void orc_safety_resolve(int n, const nep_traj_rec* fresh, double t_start, double T_span, double drone_radius, unsigned char* conflict, int* accept);
+void orc_safety_resolve_prev(int n, const nep_traj_rec* prev, const nep_traj_rec* fresh, double t_start, double T_span, double drone_radius,
+                             unsigned char* conflict, int* accept);
 
 /* the deterministic beam rule of include/neptune_frontend.h (front-end initial
  * guess).  hull_xy [num_agents][num_pol][NEP_HULL_MAX_V][2], hull_nv [num_agents][num_pol]: interval
  * hulls of every agent's committed trajectory (own entry ignored), as orc_replan returns them. */
 typedef struct orc_fe_cfg {
-  int num_pol, id, num_agents, num_samples, beam_width;
+  int num_pol, id, num_agents, num_samples, beam_width, pad_hold;
   double T_span, j_max, v_max, a_max, voxel_size, bias, goal_size, cable_length;
   double mins[2], maxs[2];
   const double* pb;

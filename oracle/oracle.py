@@ -89,6 +89,9 @@ def lib():
         L.orc_trajs_and_pwp_in_collision.restype = C.c_int
         L.orc_safety_resolve.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
         L.orc_safety_resolve.restype = None
+        L.orc_safety_resolve_prev.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.orc_safety_resolve_prev.restype = None
+        L.orc_fe_set_dump.argtypes = [C.c_void_p, C.c_int]; L.orc_fe_set_dump.restype = None
         _LIB = L
     return _LIB
 
@@ -236,7 +239,7 @@ def replan(p, agent_id, recs, guess, statics, case_id=None, want_hulls=False):
 
 
 class orc_fe_cfg(C.Structure):
-    _fields_ = [("num_pol", C.c_int), ("id", C.c_int), ("num_agents", C.c_int), ("num_samples", C.c_int), ("beam_width", C.c_int),
+    _fields_ = [("num_pol", C.c_int), ("id", C.c_int), ("num_agents", C.c_int), ("num_samples", C.c_int), ("beam_width", C.c_int), ("pad_hold", C.c_int),
                 ("T_span", C.c_double), ("j_max", C.c_double), ("v_max", C.c_double), ("a_max", C.c_double), ("voxel_size", C.c_double),
                 ("bias", C.c_double), ("goal_size", C.c_double), ("cable_length", C.c_double), ("mins", C.c_double * 2),
                 ("maxs", C.c_double * 2), ("pb", C.POINTER(C.c_double))]
@@ -246,7 +249,7 @@ def frontend_beam(p, fe, agent_id, start, hull_xy, hull_nv, statics):
     """The deterministic beam rule of include/neptune_frontend.h for one agent.  fe: abi.nep_fe_cfg; start: one
     FE_START_DTYPE record; hull_xy/hull_nv as replan(..., want_hulls=True) returns them.  -> (guess record, result dict)."""
     pb = _c(p.pb)
-    cfg = orc_fe_cfg(p.num_pol, agent_id, p.num_agents, fe.num_samples, fe.beam_width, p.T_span, fe.j_max, p.v_max, p.a_max,
+    cfg = orc_fe_cfg(p.num_pol, agent_id, p.num_agents, fe.num_samples, fe.beam_width, fe.pad_hold, p.T_span, fe.j_max, p.v_max, p.a_max,
                      fe.voxel_size, fe.bias, fe.goal_size, fe.cable_length, (C.c_double * 2)(p.x_min, p.y_min),
                      (C.c_double * 2)(p.x_max, p.y_max), abi.dptr(pb))
     S = Polys(statics)
@@ -294,6 +297,15 @@ def safety_resolve(fresh, t_start, T_span, drone_radius):
     n = len(fresh)
     conflict = np.zeros((n, n), dtype=np.uint8); accept = np.zeros(n, dtype=np.int32)
     lib().orc_safety_resolve(n, fresh.ctypes.data, t_start, T_span, drone_radius, conflict.ctypes.data, accept.ctypes.data)
+    return conflict, accept
+
+
+def safety_resolve_prev(prev, fresh, t_start, T_span, drone_radius):
+    """safety_resolve with nep_batch_set_safety_check_prev: new trajectories must also clear the previous records."""
+    prev = np.ascontiguousarray(prev); fresh = np.ascontiguousarray(fresh)
+    n = len(fresh)
+    conflict = np.zeros((n, n), dtype=np.uint8); accept = np.zeros(n, dtype=np.int32)
+    lib().orc_safety_resolve_prev(n, prev.ctypes.data, fresh.ctypes.data, t_start, T_span, drone_radius, conflict.ctypes.data, accept.ctypes.data)
     return conflict, accept
 
 

@@ -14,7 +14,7 @@ ap.add_argument("--seed", type=int, default=0); ap.add_argument("--beam", type=i
 a = ap.parse_args()
 sc = scene.make_scene(a.agents, a.obstacles, seed=a.seed)
 t0 = time.perf_counter()
-loop = FleetLoop(sc["par"], sc["statics"], sc["starts"], sc["goals"], beam_width=a.beam)
+loop = FleetLoop(sc["par"], sc["statics"], sc["starts"], scene.reachable_goals(sc), beam_width=a.beam)
 st = loop.run(a.max_rounds)
 st["wall_s"] = time.perf_counter() - t0
 st["success"] = bool(st["reached"] == a.agents)
