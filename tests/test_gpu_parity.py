@@ -569,6 +569,24 @@ def test_frontend_beam_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_st
         np.testing.assert_array_equal(got_g[a]["coeff"], g["coeff"])
         n_ok += int(g["K"]) > 0
     assert n_ok >= N - 1
+    # pad_hold: short guesses extended with segments holding their end point — same on both sides
+    fe_pad = scene.frontend_cfg(p, beam_width=W, pad_hold=1)
+    starts_near = starts.copy()
+    starts_near["goal"][:, :2] = starts_near["pos"][:, :2] + [0.9, 0.3]          # goals one or two segments away: short searches
+    d_g2 = bb.torch.zeros_like(d_guess)
+    bb.frontend(fe_pad, d_com, bb.to_device(starts_near), d_g2)
+    bb.torch.cuda.synchronize()
+    got2 = d_g2.cpu().numpy().view(abi.GUESS_DTYPE)
+    n_short = 0
+    for a in range(N):
+        hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(starts[a]["t_start"]), sc["statics"])
+        g, r = oracle.frontend_beam(p, fe_pad, a + 1, starts_near[a], hx, hn, sc["statics"])
+        assert int(got2[a]["K"]) == int(g["K"])
+        np.testing.assert_array_equal(got2[a]["coeff"], g["coeff"])
+        if 0 < r["K"] < p.num_pol:
+            n_short += 1
+            assert int(g["K"]) == p.num_pol and (np.array(g["coeff"])[:2, r["K"]:, :3] == 0).all()
+    assert n_short >= 1
     # the back end on the device-made guesses
     bb.replan(d_com, d_guess)
     sol = bb.solutions()
