@@ -130,3 +130,17 @@ def test_ordered_polygon_rule_agrees_with_all_pairs(oracle):
             np.testing.assert_allclose(nd1, nd2, rtol=1e-9, atol=1e-9)
             assert (A @ nd2[:2] + nd2[2]).min() >= 1 - 1e-9 and (B @ nd2[:2] + nd2[2]).max() <= -1 + 1e-9
     assert n_sep > 100
+
+
+def test_hull_matches_qhull(oracle):
+    """cu::convexHullOfPoints2d is CGAL's convex_hull_2 in the reference (absent here): the restatement is
+    pinned against an independent implementation, Qhull (scipy.spatial), on points in general position —
+    same extreme points, same counter-clockwise order, started at the lexicographically smallest."""
+    from scipy.spatial import ConvexHull
+    rng = np.random.default_rng(17)
+    for _ in range(200):
+        n = int(rng.integers(3, 49))
+        pts = rng.normal(size=(n, 2)) * rng.uniform(0.1, 5.0)
+        q = pts[ConvexHull(pts).vertices]                      # counter-clockwise in 2-D
+        k = min(range(len(q)), key=lambda i: tuple(q[i]))
+        np.testing.assert_array_equal(oracle.convex_hull_2d(pts), np.roll(q, -k, axis=0))
