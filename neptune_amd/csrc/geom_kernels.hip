@@ -519,29 +519,37 @@ __device__ __forceinline__ int gjk_furthest(int n, const double* __restrict__ V,
   for (int i = 1; i < n; i++) { const double p = dx * V[2 * i] + dy * V[2 * i + 1]; if (p > mx) { mx = p; idx = i; } }
   return idx;
 }
+// furthest of the four points of B along (dx, dy) — the same first-maximum rule as gjk_furthest, with the points
+// in registers (an indexed private copy would live in scratch memory and turn every support query into
+// memory round trips)
+__device__ __forceinline__ void gjk_furthest4(const Pts4& B, double dx, double dy, double& px, double& py) {
+  double mx = dx * B.x[0] + dy * B.y[0]; px = B.x[0]; py = B.y[0];
+#pragma unroll
+  for (int i = 1; i < 4; i++) { const double p = dx * B.x[i] + dy * B.y[i]; if (p > mx) { mx = p; px = B.x[i]; py = B.y[i]; } }
+}
 // gjk::collision(vertices1 = V1 [n1][2], vertices2 = the four control points in B)
 __device__ bool gjk_collision(int n1, const double* __restrict__ V1, const Pts4& B) {
   if (n1 <= 0) return false;
-  double V2[8];
-#pragma unroll
-  for (int k = 0; k < 4; k++) { V2[2 * k] = B.x[k]; V2[2 * k + 1] = B.y[k]; }
   double p1x = 0, p1y = 0, p2x = 0, p2y = 0;
   for (int i = 0; i < n1; i++) { p1x += V1[2 * i]; p1y += V1[2 * i + 1]; }
-  for (int i = 0; i < 4; i++) { p2x += V2[2 * i]; p2y += V2[2 * i + 1]; }
+#pragma unroll
+  for (int i = 0; i < 4; i++) { p2x += B.x[i]; p2y += B.y[i]; }
   p1x /= n1; p1y /= n1; p2x /= 4; p2y /= 4;
   double dx = p1x - p2x, dy = p1y - p2y;
   if (dx == 0 && dy == 0) dx = 1.0;
   double s0x, s0y, s1x = 0, s1y = 0;   // simplex columns 0 and 1 (column 2 is always `a`)
-  int i1 = gjk_furthest(n1, V1, dx, dy), i2 = gjk_furthest(4, V2, -dx, -dy);
-  double ax = V1[2 * i1] - V2[2 * i2], ay = V1[2 * i1 + 1] - V2[2 * i2 + 1];
+  int i1 = gjk_furthest(n1, V1, dx, dy);
+  double qx, qy;
+  gjk_furthest4(B, -dx, -dy, qx, qy);
+  double ax = V1[2 * i1] - qx, ay = V1[2 * i1 + 1] - qy;
   s0x = ax; s0y = ay;
   if (ax * dx + ay * dy <= 0) return false;
   dx = -ax; dy = -ay;
   int index = 0;
   for (int iter = 0; iter < 64; iter++) {
     ++index;
-    i1 = gjk_furthest(n1, V1, dx, dy); i2 = gjk_furthest(4, V2, -dx, -dy);
-    ax = V1[2 * i1] - V2[2 * i2]; ay = V1[2 * i1 + 1] - V2[2 * i2 + 1];
+    i1 = gjk_furthest(n1, V1, dx, dy); gjk_furthest4(B, -dx, -dy, qx, qy);
+    ax = V1[2 * i1] - qx; ay = V1[2 * i1 + 1] - qy;
     if (index == 1) { s1x = ax; s1y = ay; }
     if (ax * dx + ay * dy <= 0) return false;
     const double aox = -ax, aoy = -ay;
@@ -686,31 +694,41 @@ __device__ __forceinline__ void fe_vel_cps(const double P[4], double T, double Q
   for (int k = 0; k < 3; k++) Qv[k] = (P[0] * (m321[0] * (tv[0] * cAVelInv[0][k])) + P[1] * (m321[1] * (tv[1] * cAVelInv[1][k]))) + P[2] * (m321[2] * (tv[2] * cAVelInv[2][k]));
 }
 
-// one lattice child (expandAndAddToQueue); false when a kinodynamic test prunes it
-__device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const double* __restrict__ pe, double pg, bool first, int jx, int jy,
+// per-lattice-value terms of the primitive (pure functions of the jerk sample: computed once per kernel)
+struct FeLattice { const double* j6; const double* dp; const double* dv; const double* da; };   // LDS tables [num_samples]
+__device__ __forceinline__ void fe_lattice_fill(const SceneParams& sp, const nep_fe_cfg& fc, double* tab, int k) {   // tab: [4][NEP_FE_MAX_SAMPLES]
+  const double tau = sp.T_span, j_min = -fc.j_max, j_max = fc.j_max;
+  const double delta = (j_max - j_min) / (fc.num_samples - 1);
+  const double j = j_min + k * delta;
+  tab[k] = j / 6; tab[NEP_FE_MAX_SAMPLES + k] = (((j * tau) * tau) * tau) / 6; tab[2 * NEP_FE_MAX_SAMPLES + k] = ((j * tau) * tau) / 2; tab[3 * NEP_FE_MAX_SAMPLES + k] = j * tau;
+}
+
+// one lattice child (expandAndAddToQueue); false when a kinodynamic test prunes it.  Norm tests are done on
+// the squares (no square root on the rejection paths); both sides of the parity check state them that way.
+__device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const FeLattice& L, const double* __restrict__ pe, double pg, bool first, int jx, int jy,
                          double gx, double gy, double bx, double by, FeChild& o) {
   const double tau = sp.T_span, j_min = -fc.j_max, j_max = fc.j_max, v_max = sp.v_max, v_min = -sp.v_max, a_max = sp.a_max, a_min = -sp.a_max;
-  const double delta = (j_max - j_min) / (fc.num_samples - 1);
-  const double ji[2] = {j_min + jx * delta, j_min + jy * delta};
+  const int jk[2] = {jx, jy};
 #pragma unroll
   for (int ax = 0; ax < 2; ax++) {
-    const double p = pe[ax], v = pe[2 + ax], a = pe[4 + ax], j = ji[ax];
-    o.e[ax] = ((p + v * tau) + ((a * tau) * tau) / 2) + (((j * tau) * tau) * tau) / 6;
-    o.e[2 + ax] = (v + a * tau) + ((j * tau) * tau) / 2;
-    o.e[4 + ax] = a + j * tau;
+    const double p = pe[ax], v = pe[2 + ax], a = pe[4 + ax];
+    o.e[ax] = ((p + v * tau) + ((a * tau) * tau) / 2) + L.dp[jk[ax]];
+    o.e[2 + ax] = (v + a * tau) + L.dv[jk[ax]];
+    o.e[4 + ax] = a + L.da[jk[ax]];
   }
   double n2 = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) n2 += (o.e[i] - pe[i]) * (o.e[i] - pe[i]);
-  if (sqrt(n2) < 0.00001) return false;
+  if (n2 < 0.00001 * 0.00001) return false;
   if (o.e[5] > a_max || o.e[5] < a_min || o.e[4] > a_max || o.e[4] < a_min) return false;
-  o.cx[0] = ji[0] / 6; o.cx[1] = pe[4] / 2; o.cx[2] = pe[2]; o.cx[3] = pe[0];
-  o.cy[0] = ji[1] / 6; o.cy[1] = pe[5] / 2; o.cy[2] = pe[3]; o.cy[3] = pe[1];
+  o.cx[0] = L.j6[jx]; o.cx[1] = pe[4] / 2; o.cx[2] = pe[2]; o.cx[3] = pe[0];
+  o.cy[0] = L.j6[jy]; o.cy[1] = pe[5] / 2; o.cy[2] = pe[3]; o.cy[3] = pe[1];
   fe_pos_cps(o.cx, tau, o.Qx); fe_pos_cps(o.cy, tau, o.Qy);
+  const double cable2 = fc.cable_length * fc.cable_length;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     if (o.Qx[i] < sp.mins[0] || o.Qx[i] > sp.maxs[0] || o.Qy[i] < sp.mins[1] || o.Qy[i] > sp.maxs[1]) return false;
-    if (sqrt((o.Qx[i] - bx) * (o.Qx[i] - bx) + (o.Qy[i] - by) * (o.Qy[i] - by)) > fc.cable_length) return false;
+    if ((o.Qx[i] - bx) * (o.Qx[i] - bx) + (o.Qy[i] - by) * (o.Qy[i] - by) > cable2) return false;
   }
   if (!first) {
     double Vx[3], Vy[3];
@@ -732,10 +750,18 @@ __device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const doub
   return true;
 }
 
-constexpr int kFeCap = NEP_FE_MAX_BEAM * NEP_FE_MAX_SAMPLES * NEP_FE_MAX_SAMPLES;   // 1600
-constexpr int kFeVis = 1024;    // visited-voxel hash slots (<= 64 * 8 keys)
-constexpr int kFeDd = 2048;     // per-depth voxel -> best candidate hash slots (<= 1600 keys)
+// LDS arrays are sized for the configured beam width (not the maximum), so that narrower beams leave room for
+// more workgroups per CU: cap = beam_width * num_samples^2 candidates per depth, hash tables a power of two above
+// 1.25x (per-depth voxel table) / 2x (visited voxels, beam_width * num_pol keys) their load.
+struct FeSizes { int cap, dd, vis; };
+__host__ __device__ inline FeSizes fe_sizes(int beam_width, int num_samples, int num_pol) {
+  FeSizes z; z.cap = beam_width * num_samples * num_samples; if (z.cap < 64) z.cap = 64;
+  z.dd = 64; while (z.dd * 4 < z.cap * 5) z.dd *= 2;
+  z.vis = 64; while (z.vis < 2 * beam_width * num_pol) z.vis *= 2;
+  return z;
+}
 constexpr unsigned long long kFeEmpty = ~0ull;
+constexpr int kFeObsLds = 24;   // shortlisted obstacles whose vertices are staged in LDS (the rest are read from global memory)
 
 __device__ __forceinline__ unsigned fe_hash(long long vox) { return (unsigned)(((unsigned long long)vox * 0x9E3779B97F4A7C15ull) >> 40); }
 
@@ -747,6 +773,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
   const int tid = threadIdx.x;
   const int slot = blockIdx.x, scene = slot / sp.n_local, own = sp.first_local + (slot % sp.n_local);
   const int N = sp.num_agents, S = sp.n_static, W = fc.beam_width, ns = fc.num_samples, NC = ns * ns, D = sp.num_pol;
+  const FeSizes fz = fe_sizes(W, ns, D);
+  const int kFeCap = fz.cap, kFeDd = fz.dd, kFeVis = fz.vis;
   // ---- LDS carve ----
   double* s_f = fe_smem;                                   // [kFeCap] f of candidate id
   double* r_f = s_f + kFeCap;                              // [kFeCap] f of the voxel winners, dense
@@ -756,7 +784,9 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
   double* b_f = b_dist + NEP_FE_MAX_BEAM;                  // [64]
   double* p_box = b_f + NEP_FE_MAX_BEAM;                   // [64][4] box of every parent's children
   double* o_aabb = p_box + NEP_FE_MAX_BEAM * 4;            // [N+S][4] boxes of the shortlisted obstacles, dense
-  long long* s_vox = (long long*)(o_aabb + 4 * (N + S));   // [kFeCap]
+  double* o_V = o_aabb + 4 * (N + S);                      // [kFeObsLds][16][2] their vertices (GJK walks them several times)
+  double* s_lat = o_V + kFeObsLds * kHullV * 2;            // [4][NEP_FE_MAX_SAMPLES] lattice tables
+  long long* s_vox = (long long*)(s_lat + 4 * NEP_FE_MAX_SAMPLES);   // [kFeCap]
   unsigned long long* v_key = (unsigned long long*)(s_vox + kFeCap);   // [kFeVis] visited voxels
   int* d_slot = (int*)(v_key + kFeVis);                    // [kFeDd] voxel -> best candidate of the depth
   int* o_nv = d_slot + kFeDd;                              // [N+S] dense
@@ -770,8 +800,13 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
   const nep_fe_start* st = starts + slot;
   const double gx = st->goal[0], gy = st->goal[1];
   const double bx = ps.pb[2 * own], by = ps.pb[2 * own + 1];
-  if (tid < 16) s_i[tid] = 0;     // [0] shortlist n, [1] winners n, [4] children, [5] feasible, [6] collision free, [7] goal occupied
+#ifdef NEP_PROFILE_PHASES
+  if (ps.dbg && tid < 16) ps.dbg[(long)slot * 16 + tid] = 0;
+#endif
+  if (tid < 16) s_i[tid] = 0;     // [0] shortlist n, [1] winners n, [2] GJK work list n, [4] children, [5] feasible, [6] collision free, [7] goal occupied
   for (int k = tid; k < kFeVis; k += 256) v_key[k] = kFeEmpty;
+  if (tid < NEP_FE_MAX_SAMPLES) fe_lattice_fill(sp, fc, s_lat, tid);
+  const FeLattice lat{s_lat, s_lat + NEP_FE_MAX_SAMPLES, s_lat + 2 * NEP_FE_MAX_SAMPLES, s_lat + 3 * NEP_FE_MAX_SAMPLES};
   if (tid < 6) {                  // the root is the one-node beam of depth 0
     const double v = tid == 0 ? st->pos[0] : tid == 1 ? st->pos[1] : tid == 2 ? st->vel[0] : tid == 3 ? st->vel[1] : tid == 4 ? st->accel[0] : st->accel[1];
     b_end[tid] = v;               // parity 0
@@ -792,11 +827,18 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
   }
   int status = NEP_FE_NO_SOLUTION, best_depth = 0, best_rank = -1, nb_prev = 1, depth;
   int my_children = 0, my_feasible = 0, my_free = 0;
-  const double tau = sp.T_span, delta = (fc.j_max + fc.j_max) / (ns - 1);
+#ifdef NEP_PROFILE_PHASES
+  long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
+#define FE_TICK(k) do { const long long t_ = clock64(); tph[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define FE_TICK(k) do { } while (0)
+#endif
+  const double tau = sp.T_span;
   for (depth = 1; depth <= D; depth++) {
     const int cur = depth & 1, prv = cur ^ 1;
     const int idx = (depth > D ? D : depth) - 1;
     __syncthreads();
+    FE_TICK(0);
     // ---- box of every parent's children: the control points are monotone in the jerk, so the four corner
     //      children bound them all (a superset of every child's own box, feasible or not) ----
     if (tid < nb_prev) {
@@ -807,8 +849,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
         double l = __builtin_huge_val(), h = -__builtin_huge_val();
 #pragma unroll
         for (int e = 0; e < 2; e++) {
-          const double ji = -fc.j_max + (e ? ns - 1 : 0) * delta;
-          const double P[4] = {ji / 6, pe[4 + ax] / 2, pe[2 + ax], pe[ax]};
+          const double P[4] = {lat.j6[e ? ns - 1 : 0], pe[4 + ax] / 2, pe[2 + ax], pe[ax]};
           double Q[4];
           fe_pos_cps(P, tau, Q);
 #pragma unroll
@@ -818,9 +859,10 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
       }
       p_box[4 * tid] = lo[0]; p_box[4 * tid + 1] = hi[0]; p_box[4 * tid + 2] = lo[1]; p_box[4 * tid + 3] = hi[1];
     }
-    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; }
+    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[2] = 0; }
     for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
     __syncthreads();
+    FE_TICK(1);
     // ---- shortlist: obstacles of this interval whose box meets some parent's box ----
     for (int j = tid; j < N + S; j += 256) {
       int nv = 0; const double* V = nullptr;
@@ -828,61 +870,100 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
         if (j != own) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
       } else { nv = ps.static_nv[j - N]; V = ps.static_xy + (long)(j - N) * kHullV * 2; }
       if (nv <= 0) continue;
-      double x0 = V[0], x1 = V[0], y0 = V[1], y1 = V[1];
-      for (int i = 1; i < nv; i++) { const double x = V[2 * i], y = V[2 * i + 1]; if (x < x0) x0 = x; if (x > x1) x1 = x; if (y < y0) y0 = y; if (y > y1) y1 = y; }
+      // all sixteen vertex slots in one go (the arrays are [16][2]): a loop over nv would pay one memory
+      // round trip per vertex
+      double2 vv[kHullV];
+#pragma unroll
+      for (int i = 0; i < kHullV; i++) vv[i] = ((const double2*)V)[i];
+      double x0 = vv[0].x, x1 = vv[0].x, y0 = vv[0].y, y1 = vv[0].y;
+#pragma unroll
+      for (int i = 1; i < kHullV; i++) if (i < nv) { if (vv[i].x < x0) x0 = vv[i].x; if (vv[i].x > x1) x1 = vv[i].x; if (vv[i].y < y0) y0 = vv[i].y; if (vv[i].y > y1) y1 = vv[i].y; }
       bool near = false;
       for (int q = 0; q < nb_prev; q++) near |= !(x1 < p_box[4 * q] || p_box[4 * q + 1] < x0 || y1 < p_box[4 * q + 2] || p_box[4 * q + 3] < y0);
-      if (near) { const int o = atomicAdd(&s_i[0], 1); o_aabb[4 * o] = x0; o_aabb[4 * o + 1] = x1; o_aabb[4 * o + 2] = y0; o_aabb[4 * o + 3] = y1; o_nv[o] = nv; o_id[o] = j; }
+      if (near) {
+        const int o = atomicAdd(&s_i[0], 1); o_aabb[4 * o] = x0; o_aabb[4 * o + 1] = x1; o_aabb[4 * o + 2] = y0; o_aabb[4 * o + 3] = y1; o_nv[o] = nv; o_id[o] = j;
+        if (o < kFeObsLds) {
+#pragma unroll
+          for (int i = 0; i < kHullV; i++) ((double2*)(o_V + o * kHullV * 2))[i] = vv[i];
+        }
+      }
     }
     __syncthreads();
+    FE_TICK(2);
     const int n_obs = s_i[0];
-    // ---- children: one per thread ----
+    // ---- children: one per thread.  Pass 1 settles everything but the GJK tests: a child whose box meets
+    //      shortlisted obstacles goes on a work list (its obstacle mask parked in s_vox), so that pass 2
+    //      spreads the expensive tests over all threads instead of leaving them with the lanes that
+    //      happened to draw crowded children ----
     const int n_c = nb_prev * NC;
+    auto settle = [&](int id, const FeChild& ch) {       // collision free: closed voxel?  else alive
+      my_free++;
+      const long long vox = ((long long)ch.vx << 32) | (unsigned int)ch.vy;
+      bool seen = false;
+      for (unsigned h = fe_hash(vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long k = v_key[h]; if (k == (unsigned long long)vox) { seen = true; break; } if (k == kFeEmpty) break; }
+      if (!seen) { s_f[id] = ch.f; s_vox[id] = vox; }
+      s_state[id] = seen ? 0 : 1;
+    };
+    auto obstacle_V = [&](int o) -> const double* {
+      if (o < kFeObsLds) return o_V + o * kHullV * 2;
+      const int j = o_id[o];
+      if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); return blk(ps.hull_xy, hr.boff) + (hr.e * sp.num_pol + idx) * kHullV * 2; }
+      return ps.static_xy + (long)(j - N) * kHullV * 2;
+    };
     for (int id = tid; id < n_c; id += 256) {
       const int pr = id / NC, cc = id % NC;
       const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
       const double pg = b_g[prv * NEP_FE_MAX_BEAM + pr];
       FeChild ch;
-      unsigned char alive = 0;
       my_children++;
-      if (fe_child(sp, fc, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch)) {
-        my_feasible++;
-        double qx0 = ch.Qx[0], qx1 = ch.Qx[0], qy0 = ch.Qy[0], qy1 = ch.Qy[0];
+      s_state[id] = 0;
+      if (!fe_child(sp, fc, lat, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch)) continue;
+      my_feasible++;
+      double qx0 = ch.Qx[0], qx1 = ch.Qx[0], qy0 = ch.Qy[0], qy1 = ch.Qy[0];
 #pragma unroll
-        for (int i = 1; i < 4; i++) { if (ch.Qx[i] < qx0) qx0 = ch.Qx[i]; if (ch.Qx[i] > qx1) qx1 = ch.Qx[i]; if (ch.Qy[i] < qy0) qy0 = ch.Qy[i]; if (ch.Qy[i] > qy1) qy1 = ch.Qy[i]; }
-        unsigned long long cand_mask = 0;     // shortlisted obstacles whose box meets this child's (shortlists beyond 64 fall back to a direct test)
-        bool hit = false;
-        for (int o = 0; o < n_obs; o++) {
-          const bool ov = !(o_aabb[4 * o + 1] < qx0 || qx1 < o_aabb[4 * o] || o_aabb[4 * o + 3] < qy0 || qy1 < o_aabb[4 * o + 2]);
-          if (ov) { if (o < 64) cand_mask |= 1ull << o; else if (!hit) {
-            Pts4 B;
-#pragma unroll
-            for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
-            const int j = o_id[o]; const double* V;
-            if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); V = blk(ps.hull_xy, hr.boff) + (hr.e * sp.num_pol + idx) * kHullV * 2; } else V = ps.static_xy + (long)(j - N) * kHullV * 2;
-            hit = gjk_collision(o_nv[o], V, B);
-          } }
-        }
-        while (cand_mask && !hit) {
-          const int o = __ffsll((long long)cand_mask) - 1; cand_mask &= cand_mask - 1;
+      for (int i = 1; i < 4; i++) { if (ch.Qx[i] < qx0) qx0 = ch.Qx[i]; if (ch.Qx[i] > qx1) qx1 = ch.Qx[i]; if (ch.Qy[i] < qy0) qy0 = ch.Qy[i]; if (ch.Qy[i] > qy1) qy1 = ch.Qy[i]; }
+      unsigned long long cand_mask = 0;
+      bool hit = false;
+      for (int o = 0; o < n_obs; o++) {
+        const bool ov = !(o_aabb[4 * o + 1] < qx0 || qx1 < o_aabb[4 * o] || o_aabb[4 * o + 3] < qy0 || qy1 < o_aabb[4 * o + 2]);
+        if (!ov) continue;
+        if (o < 64) cand_mask |= 1ull << o;
+        else if (!hit) {                                  // (shortlists beyond 64: tested on the spot)
           Pts4 B;
 #pragma unroll
           for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
-          const int j = o_id[o]; const double* V;
-          if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); V = blk(ps.hull_xy, hr.boff) + (hr.e * sp.num_pol + idx) * kHullV * 2; } else V = ps.static_xy + (long)(j - N) * kHullV * 2;
-          hit = gjk_collision(o_nv[o], V, B);
-        }
-        if (!hit) {
-          my_free++;
-          const long long vox = ((long long)ch.vx << 32) | (unsigned int)ch.vy;
-          bool seen = false;
-          for (unsigned h = fe_hash(vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long k = v_key[h]; if (k == (unsigned long long)vox) { seen = true; break; } if (k == kFeEmpty) break; }
-          if (!seen) { alive = 1; s_f[id] = ch.f; s_vox[id] = vox; }
+          hit = gjk_collision(o_nv[o], obstacle_V(o), B);
         }
       }
-      s_state[id] = alive;
+      if (hit) continue;
+      if (cand_mask == 0) { settle(id, ch); continue; }
+      s_vox[id] = (long long)cand_mask; s_state[id] = 3;
+      r_id[atomicAdd(&s_i[2], 1)] = (unsigned short)id;    // (r_id is free until the winners are compacted)
+    }
+    FE_TICK(7);
+    __syncthreads();
+    const int n_work = s_i[2];
+#ifdef NEP_PROFILE_PHASES
+    if (tid == 0 && ps.dbg) { ps.dbg[(long)slot * 16 + 9] += n_work; ps.dbg[(long)slot * 16 + 10] += n_obs; ps.dbg[(long)slot * 16 + 11] += n_c; }
+#endif
+    for (int w = tid; w < n_work; w += 256) {
+      const int id = r_id[w];
+      const int pr = id / NC, cc = id % NC;
+      unsigned long long cand_mask = (unsigned long long)s_vox[id];
+      FeChild ch;
+      fe_child(sp, fc, lat, b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6, b_g[prv * NEP_FE_MAX_BEAM + pr], depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch);
+      Pts4 B;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
+      bool hit = false;
+      while (cand_mask && !hit) {
+        const int o = __ffsll((long long)cand_mask) - 1; cand_mask &= cand_mask - 1;
+        hit = gjk_collision(o_nv[o], obstacle_V(o), B);
+      }
+      if (hit) s_state[id] = 0; else settle(id, ch);
     }
     __syncthreads();
+    FE_TICK(3);
     // ---- one node per voxel: the best (f, id) claims the voxel's slot; whoever is displaced or beaten is out ----
     for (int id = tid; id < n_c; id += 256) {
       if (s_state[id] != 1) continue;
@@ -898,8 +979,10 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
       }
     }
     __syncthreads();
+    FE_TICK(4);
     for (int id = tid; id < n_c; id += 256) if (s_state[id] == 1) { const int o = atomicAdd(&s_i[1], 1); r_f[o] = s_f[id]; r_id[o] = (unsigned short)id; }
     __syncthreads();
+    FE_TICK(5);
     // ---- the beam: rank among the voxel winners (dense arrays) ----
     const int n_b = s_i[1];
     const int nb = n_b < W ? n_b : W;
@@ -914,7 +997,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
         const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
         const double pg = b_g[prv * NEP_FE_MAX_BEAM + pr];
         FeChild ch;
-        fe_child(sp, fc, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch);
+        fe_child(sp, fc, lat, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch);
 #pragma unroll
         for (int q = 0; q < 6; q++) b_end[(cur * NEP_FE_MAX_BEAM + rank) * 6 + q] = ch.e[q];
         b_g[cur * NEP_FE_MAX_BEAM + rank] = ch.g; b_dist[rank] = ch.dist; b_f[rank] = ch.f;
@@ -925,6 +1008,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
       }
     }
     __syncthreads();
+    FE_TICK(6);
     if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
     nb_prev = nb;
     best_depth = depth; best_rank = 0;
@@ -935,6 +1019,9 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
   }
   atomicAdd(&s_i[4], my_children); atomicAdd(&s_i[5], my_feasible); atomicAdd(&s_i[6], my_free);
   __syncthreads();
+#ifdef NEP_PROFILE_PHASES
+  if (ps.dbg && tid == 0) { for (int k = 0; k < 8; k++) ps.dbg[(long)slot * 16 + k] = tph[k]; ps.dbg[(long)slot * 16 + 8] = depth; }
+#endif
   if (tid == 0) {
     nep_guess* g = guess_out + slot;
     for (int e = 0; e < 3 * NEP_MAX_POL * 4; e++) (&g->coeff[0][0][0])[e] = 0.0;
@@ -947,7 +1034,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
       for (int d = best_depth; d >= 1; d--) { path[d - 1] = p_comb[d * NEP_FE_MAX_BEAM + r]; r = p_parent[d * NEP_FE_MAX_BEAM + r]; }
       for (int d = 1; d <= best_depth; d++) {   // replay the path from the root with the same arithmetic
         FeChild ch;
-        fe_child(sp, fc, pe, pg, d == 1, path[d - 1] / ns, path[d - 1] % ns, gx, gy, bx, by, ch);
+        fe_child(sp, fc, lat, pe, pg, d == 1, path[d - 1] / ns, path[d - 1] % ns, gx, gy, bx, by, ch);
         for (int k = 0; k < 4; k++) { g->coeff[0][d - 1][k] = ch.cx[k]; g->coeff[1][d - 1][k] = ch.cy[k]; }
         g->coeff[2][d - 1][3] = st->pos[2];
         for (int q = 0; q < 6; q++) pe[q] = ch.e[q];
@@ -980,18 +1067,19 @@ void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const
   hipLaunchKernelGGL(gjk_explicit_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, st, n_prob, a_off, a_xy, b_xy, hit);
 }
 
-size_t frontend_lds_bytes(const SceneParams& sp) {
+size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc) {
   const size_t NS = (size_t)sp.num_agents + sp.n_static;
-  size_t b = sizeof(double) * (2 * kFeCap + 2 * NEP_FE_MAX_BEAM * 6 + 2 * NEP_FE_MAX_BEAM + 2 * NEP_FE_MAX_BEAM + 4 * NEP_FE_MAX_BEAM + 4 * NS)
-           + sizeof(long long) * (kFeCap + kFeVis) + sizeof(int) * (kFeDd + 2 * NS + 16)
-           + sizeof(unsigned short) * kFeCap + kFeCap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
+  const FeSizes z = fe_sizes(fc.beam_width, fc.num_samples, sp.num_pol);
+  size_t b = sizeof(double) * (2 * (size_t)z.cap + 2 * NEP_FE_MAX_BEAM * 6 + 2 * NEP_FE_MAX_BEAM + 2 * NEP_FE_MAX_BEAM + 4 * NEP_FE_MAX_BEAM + 4 * NS + kFeObsLds * kHullV * 2 + 4 * NEP_FE_MAX_SAMPLES)
+           + sizeof(long long) * ((size_t)z.cap + z.vis) + sizeof(int) * (z.dd + 2 * NS + 16)
+           + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
   return (b + 15) & ~(size_t)15;
 }
 
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
                      nep_guess* guess_out, nep_fe_result* res_out, hipStream_t st) {
   if (n_slots <= 0) return;
-  const size_t lds = frontend_lds_bytes(sp);
+  const size_t lds = frontend_lds_bytes(sp, fc);
   static size_t configured = 0;
   if (lds > configured) { hipFuncSetAttribute((const void*)frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); configured = lds; }
   hipLaunchKernelGGL(frontend_kernel, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out);

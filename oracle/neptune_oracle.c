@@ -968,7 +968,7 @@ static int fe_child(const orc_fe_cfg* c, const double init_end[6], double par_g,
   }
   double n2 = 0;
   for (int i = 0; i < 6; i++) n2 += (e[i] - init_end[i]) * (e[i] - init_end[i]);
-  if (sqrt(n2) < 0.00001) return 0;
+  if (n2 < 0.00001 * 0.00001) return 0;   /* |end - start| < 1e-5, on the squares */
   if (e[5] > a_max || e[5] < a_min || e[4] > a_max || e[4] < a_min) return 0;
   for (int ax = 0; ax < 2; ax++) {
     double* co = ax == 0 ? out->cx : out->cy;
@@ -979,7 +979,7 @@ static int fe_child(const orc_fe_cfg* c, const double init_end[6], double par_g,
   const double bx = c->pb[2 * (c->id - 1)], by = c->pb[2 * (c->id - 1) + 1];
   for (int i = 0; i < 4; i++) {
     if (Qx[i] < c->mins[0] || Qx[i] > c->maxs[0] || Qy[i] < c->mins[1] || Qy[i] > c->maxs[1]) return 0;
-    if (sqrt((Qx[i] - bx) * (Qx[i] - bx) + (Qy[i] - by) * (Qy[i] - by)) > c->cable_length) return 0;
+    if ((Qx[i] - bx) * (Qx[i] - bx) + (Qy[i] - by) * (Qy[i] - by) > c->cable_length * c->cable_length) return 0;   /* on the squares */
   }
   if (!first) {
     double Vx[3], Vy[3];
