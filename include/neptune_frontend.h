@@ -19,7 +19,10 @@
  *   costs               g = travelled chord length, h = distance to the goal, order by g + bias*h
  *                       (:1177-1179, CompareCost); one node per voxel of size voxel_size (:1170-1173)
  *   termination         a node within goal_size of the goal ends the search (:1719-1737); the plan is
- *                       the first num_pol segments of the path (:521-553); z follows the given height
+ *                       the first num_pol segments of the path (:521-553); z = Neptune::getInitialZPwp's clamped B-spline
+ *                       ramp from A's height state to the goal height (neptune.cpp:1727-1810; as there,
+ *                       the first three control points are placed for a clamped basis but evaluated with
+ *                       the uniform one, so only a start at rest is reproduced exactly)
  * What differs — this is a level-synchronous BEAM over the same lattice, not the reference's A*:
  *   the reference's open list is a wall-clock-bounded best-first search whose expansion order is
  *   shuffled with a time seed (:321-322, :1462-1463) and whose closed-set update toggles with a call
@@ -68,7 +71,7 @@ typedef struct nep_fe_cfg {
 
 /* Point A and the goal of one slot (setUp, kinodynamic_search.cpp:190-227).                      */
 typedef struct nep_fe_start {
-  double pos[3], vel[3], accel[3];   /* A; only x,y enter the search, z is held                     */
+  double pos[3], vel[3], accel[3];   /* A; x,y enter the search, z the height profile               */
   double goal[3];                    /* G_term.pos                                                  */
   double t_start;                    /* neptune.cpp:1422-1423                                       */
 } nep_fe_start;

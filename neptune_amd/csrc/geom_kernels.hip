@@ -694,6 +694,41 @@ __device__ __forceinline__ void fe_vel_cps(const double P[4], double T, double Q
   for (int k = 0; k < 3; k++) Qv[k] = (P[0] * (m321[0] * (tv[0] * cAVelInv[0][k])) + P[1] * (m321[1] * (tv[1] * cAVelInv[1][k]))) + P[2] * (m321[2] * (tv[2] * cAVelInv[2][k]));
 }
 
+// Neptune::getInitialZPwp (neptune.cpp:1727-1810): the guess's height profile, one thread (same arithmetic as the oracle)
+__device__ void fe_initial_z(double p0, double v0, double a0, double z_final, double T, int np, double v_max_z, double a_max_z, double (*co)[4]) {
+  double q[NEP_MAX_POL + 3], v[NEP_MAX_POL + 2];
+  if (np < 3) { for (int i = 0; i < np; i++) { co[i][0] = co[i][1] = co[i][2] = 0; co[i][3] = p0; } return; }
+  if (v0 < -v_max_z) v0 = -v_max_z; else if (v0 > v_max_z) v0 = v_max_z;
+  if (a0 < -a_max_z) a0 = -a_max_z; else if (a0 > a_max_z) a0 = a_max_z;
+  for (int i = 0; i < np + 2; i++) v[i] = 0;
+  q[0] = p0;
+  q[1] = p0 + T * v0 / 3;
+  q[2] = (3 * 3 * q[1] - 2 * T * (-a0 * T + v0) - 3 * (q[1] + (-2 * T) * v0)) / 6;
+  q[np] = z_final;
+  const double increment = (z_final - q[2]) / (np - 2);
+  for (int i = 3; i <= np - 1; i++) q[i] = q[i - 1] + increment;
+  for (int i = 3; i <= np; i++) {
+    v[i - 1] = (q[i] - q[i - 1]) / T;
+    if (v[i - 1] > v_max_z) { q[i] = q[i - 1] + v_max_z * T; v[i - 1] = v_max_z; }
+    else if (v[i - 1] < -v_max_z) { q[i] = q[i - 1] - v_max_z * T; v[i - 1] = -v_max_z; }
+  }
+  for (int i = 2; i <= np - 1; i++) {
+    const double a_i = (v[i] - v[i - 1]) / T;
+    if (a_i > a_max_z) v[i] = v[i - 1] + a_max_z * T;
+    else if (a_i < -a_max_z) v[i] = v[i - 1] - a_max_z * T;
+    q[i + 1] = q[i] + v[i] * T;
+  }
+  q[np + 1] = q[np]; q[np + 2] = q[np];
+  for (int i = 0; i < np; i++) {
+    const double* s = q + i;
+    const double c0 = (((1.0 / 6.0) * s[0] + (4.0 / 6.0) * s[1]) + (1.0 / 6.0) * s[2]) + (0.0 / 6.0) * s[3];
+    const double c1 = (((-3.0 / 6.0) * s[0] + (0.0 / 6.0) * s[1]) + (3.0 / 6.0) * s[2]) + (0.0 / 6.0) * s[3];
+    const double c2 = (((3.0 / 6.0) * s[0] + (-6.0 / 6.0) * s[1]) + (3.0 / 6.0) * s[2]) + (0.0 / 6.0) * s[3];
+    const double c3 = (((-1.0 / 6.0) * s[0] + (3.0 / 6.0) * s[1]) + (-3.0 / 6.0) * s[2]) + (1.0 / 6.0) * s[3];
+    co[i][3] = 1.0 * c0; co[i][2] = (1 / T) * c1; co[i][1] = (1 / (T * T)) * c2; co[i][0] = (1 / (T * T * T)) * c3;
+  }
+}
+
 // per-lattice-value terms of the primitive (pure functions of the jerk sample: computed once per kernel)
 struct FeLattice { const double* j6; const double* dp; const double* dv; const double* da; };   // LDS tables [num_samples]
 __device__ __forceinline__ void fe_lattice_fill(const SceneParams& sp, const nep_fe_cfg& fc, double* tab, int k) {   // tab: [4][NEP_FE_MAX_SAMPLES]
@@ -1036,14 +1071,15 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
         FeChild ch;
         fe_child(sp, fc, lat, pe, pg, d == 1, path[d - 1] / ns, path[d - 1] % ns, gx, gy, bx, by, ch);
         for (int k = 0; k < 4; k++) { g->coeff[0][d - 1][k] = ch.cx[k]; g->coeff[1][d - 1][k] = ch.cy[k]; }
-        g->coeff[2][d - 1][3] = st->pos[2];
         for (int q = 0; q < 6; q++) pe[q] = ch.e[q];
         pg = ch.g;
       }
       if (fc.pad_hold && best_depth < D) {   // hold the end point for the rest of the horizon
-        for (int d = best_depth + 1; d <= D; d++) { g->coeff[0][d - 1][3] = pe[0]; g->coeff[1][d - 1][3] = pe[1]; g->coeff[2][d - 1][3] = st->pos[2]; }
+        for (int d = best_depth + 1; d <= D; d++) { g->coeff[0][d - 1][3] = pe[0]; g->coeff[1][d - 1][3] = pe[1]; }
         g->K = D;
       }
+      fe_initial_z(st->pos[2], st->vel[2], st->accel[2], st->goal[2], sp.T_span, D, sp.v_max, sp.a_max, g->coeff[2]);   // coeffs_z_ (:540)
+      for (int d = g->K + 1; d <= D; d++) for (int k = 0; k < 4; k++) g->coeff[2][d - 1][k] = 0.0;
     }
     if (res_out) {
       nep_fe_result* o = res_out + slot;

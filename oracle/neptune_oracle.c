@@ -1028,6 +1028,43 @@ static int fe_collides(const orc_fe_cfg* c, const fe_node* nd, int depth, const 
   return 0;
 }
 
+/* Neptune::getInitialZPwp (neptune.cpp:1727-1810): height profile of the guess as a clamped-ramp uniform B-spline,
+ * bspline_basis_[i] = diag(1, 1/T, 1/T^2, 1/T^3) * M/6 (neptune.cpp:67-82), coefficients reversed to [a b c d]. */
+static void fe_initial_z(double p0, double v0, double a0, double z_final, double T, int np, double v_max_z, double a_max_z, double co[NEP_MAX_POL][4]) {
+  double q[NEP_MAX_POL + 3], v[NEP_MAX_POL + 2];
+  if (np < 3) { for (int i = 0; i < np; i++) { co[i][0] = co[i][1] = co[i][2] = 0; co[i][3] = p0; } return; }
+  if (v0 < -v_max_z) v0 = -v_max_z; else if (v0 > v_max_z) v0 = v_max_z;
+  if (a0 < -a_max_z) a0 = -a_max_z; else if (a0 > a_max_z) a0 = a_max_z;
+  for (int i = 0; i < np + 2; i++) v[i] = 0;
+  q[0] = p0;
+  q[1] = p0 + T * v0 / 3;
+  q[2] = (3 * 3 * q[1] - 2 * T * (-a0 * T + v0) - 3 * (q[1] + (-2 * T) * v0)) / 6;
+  q[np] = z_final;
+  const double increment = (z_final - q[2]) / (np - 2);
+  for (int i = 3; i <= np - 1; i++) q[i] = q[i - 1] + increment;
+  for (int i = 3; i <= np; i++) {
+    v[i - 1] = (q[i] - q[i - 1]) / T;
+    if (v[i - 1] > v_max_z) { q[i] = q[i - 1] + v_max_z * T; v[i - 1] = v_max_z; }
+    else if (v[i - 1] < -v_max_z) { q[i] = q[i - 1] - v_max_z * T; v[i - 1] = -v_max_z; }
+  }
+  for (int i = 2; i <= np - 1; i++) {
+    const double a_i = (v[i] - v[i - 1]) / T;
+    if (a_i > a_max_z) v[i] = v[i - 1] + a_max_z * T;
+    else if (a_i < -a_max_z) v[i] = v[i - 1] - a_max_z * T;
+    q[i + 1] = q[i] + v[i] * T;
+  }
+  q[np + 1] = q[np]; q[np + 2] = q[np];
+  for (int i = 0; i < np; i++) {
+    const double* s = q + i;
+    /* M/6 rows, then the interval scaling, lowest power first */
+    const double c0 = (((1.0 / 6.0) * s[0] + (4.0 / 6.0) * s[1]) + (1.0 / 6.0) * s[2]) + (0.0 / 6.0) * s[3];
+    const double c1 = (((-3.0 / 6.0) * s[0] + (0.0 / 6.0) * s[1]) + (3.0 / 6.0) * s[2]) + (0.0 / 6.0) * s[3];
+    const double c2 = (((3.0 / 6.0) * s[0] + (-6.0 / 6.0) * s[1]) + (3.0 / 6.0) * s[2]) + (0.0 / 6.0) * s[3];
+    const double c3 = (((-1.0 / 6.0) * s[0] + (3.0 / 6.0) * s[1]) + (-3.0 / 6.0) * s[2]) + (1.0 / 6.0) * s[3];
+    co[i][3] = 1.0 * c0; co[i][2] = (1 / T) * c1; co[i][1] = (1 / (T * T)) * c2; co[i][0] = (1 / (T * T * T)) * c3;
+  }
+}
+
 static int fe_before(const fe_node* a, int ia, const fe_node* b, int ib) { return a->f < b->f || (a->f == b->f && ia < ib); }
 
 int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv,
@@ -1126,13 +1163,16 @@ int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double*
     for (int d = best_depth; d >= 1; d--) {
       const fe_node* q = &beam[d][r];
       for (int k = 0; k < 4; k++) { guess->coeff[0][d - 1][k] = q->cx[k]; guess->coeff[1][d - 1][k] = q->cy[k]; }
-      guess->coeff[2][d - 1][0] = 0; guess->coeff[2][d - 1][1] = 0; guess->coeff[2][d - 1][2] = 0; guess->coeff[2][d - 1][3] = st->pos[2];
       r = q->parent;
     }
+    double cz[NEP_MAX_POL][4];
+    fe_initial_z(st->pos[2], st->vel[2], st->accel[2], st->goal[2], c->T_span, D, c->v_max, c->a_max, cz);   /* coeffs_z_ (:540) */
+    for (int d = 1; d <= best_depth; d++) for (int k = 0; k < 4; k++) guess->coeff[2][d - 1][k] = cz[d - 1][k];
     if (c->pad_hold && best_depth < D) {   /* hold the end point for the rest of the horizon */
       for (int d = best_depth + 1; d <= D; d++) {
-        for (int ax = 0; ax < 3; ax++) for (int k = 0; k < 3; k++) guess->coeff[ax][d - 1][k] = 0;
-        guess->coeff[0][d - 1][3] = nd->end[0]; guess->coeff[1][d - 1][3] = nd->end[1]; guess->coeff[2][d - 1][3] = st->pos[2];
+        for (int ax = 0; ax < 2; ax++) for (int k = 0; k < 3; k++) guess->coeff[ax][d - 1][k] = 0;
+        guess->coeff[0][d - 1][3] = nd->end[0]; guess->coeff[1][d - 1][3] = nd->end[1];
+        for (int k = 0; k < 4; k++) guess->coeff[2][d - 1][k] = cz[d - 1][k];      /* the height keeps following its profile */
       }
       guess->K = D;
     }

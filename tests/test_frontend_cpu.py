@@ -94,3 +94,28 @@ def test_beam_width_one_is_greedy_and_wider_beams_do_not_do_worse(oracle):
             tot += r["cost"] if r["K"] else 1e3
         costs[W] = tot
     assert costs[64] <= costs[1] + 1e-9
+
+
+def test_height_profile_is_a_c2_spline_from_the_start_state_to_the_goal_height(oracle):
+    """Neptune::getInitialZPwp: the z coefficients of the guess form a C2 cubic spline that starts at A's
+    (clamped) height state; with a reachable goal height it ends there at rest."""
+    sc = scene.make_scene(3, 0, seed=2)
+    p = sc["par"]
+    fe = scene.frontend_cfg(p, beam_width=8, pad_hold=1)
+    starts = scene.frontend_starts(sc)
+    for z0, vz, az, zg in ((1.0, 0.0, 0.0, 2.0), (2.5, 0.8, -1.0, 1.0), (1.0, 5.0, 9.0, 4.0), (1.0, 0.0, 0.0, 30.0)):
+        starts[0]["pos"][2] = z0; starts[0]["vel"][2] = vz; starts[0]["accel"][2] = az; starts[0]["goal"][2] = zg
+        (g, r), _ = run_agent(oracle, sc, 0, fe, starts)
+        K = int(g["K"]); cz = np.array(g["coeff"])[2, :K]
+        assert K == p.num_pol
+        if vz == 0 and az == 0:       # from rest the profile starts exactly at A.  (Otherwise it does not: the reference places
+            # q0..q2 for a clamped basis but evaluates with the uniform matrix, neptune.cpp:67-82,1747-1749 — kept as is.)
+            np.testing.assert_allclose([cz[0, 3], cz[0, 2], 2 * cz[0, 1]], [z0, 0.0, 0.0], atol=1e-12)
+        for s in range(K - 1):                                        # C2 at the knots
+            end = [np.polyval(cz[s], T), np.polyval(np.polyder(cz[s]), T), np.polyval(np.polyder(cz[s], 2), T)]
+            np.testing.assert_allclose(end, [cz[s + 1, 3], cz[s + 1, 2], 2 * cz[s + 1, 1]], atol=1e-9)
+        z_end = np.polyval(cz[-1], T); v_end = np.polyval(np.polyder(cz[-1]), T)
+        if abs(zg - z0) < 5:
+            np.testing.assert_allclose([z_end, v_end], [zg, 0.0], atol=1e-9)
+        else:                                                         # rate limited: climbs at most v_max all the way
+            assert z_end < zg and z_end <= z0 + p.v_max * K * T + 1e-9

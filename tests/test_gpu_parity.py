@@ -614,6 +614,9 @@ def test_frontend_multi_scene_and_agent_shard(be, oracle):
     com, _ = ndist.stack_scenes(scenes)
     fe = scene.frontend_cfg(p, beam_width=24)
     starts = np.stack([scene.frontend_starts(sc) for sc in scenes])          # [S][N]
+    rng = np.random.default_rng(8)                                            # height states and goals: the z profile (getInitialZPwp)
+    starts["pos"][:, :, 2] = rng.uniform(0.5, 3.0, size=(S, N)); starts["vel"][:, :, 2] = rng.normal(scale=1.5, size=(S, N))
+    starts["accel"][:, :, 2] = rng.normal(scale=2.5, size=(S, N)); starts["goal"][:, :, 2] = rng.uniform(0.5, 4.5, size=(S, N))
     for first, nl in ((0, 6), (2, 2), (3, 3)):
         bb = be.BatchBackend(p, scenes[0]["statics"], first_local=first, n_local=nl, n_scenes=S)
         d_start = bb.to_device(np.ascontiguousarray(starts[:, first:first + nl]))
