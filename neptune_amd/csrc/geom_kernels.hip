@@ -297,7 +297,10 @@ __device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ord
   return false;
 }
 
-constexpr int kAStride = 17;  // (x,y) pairs per lane slot: 68 dwords -> 16 lanes of a ds_read_b128 group hit distinct 4-bank slots
+constexpr int kAStride = 13;  // (x,y) pairs per lane slot: 52 dwords (13 odd) -> 16 lanes of a ds_read_b128 group hit distinct 4-bank slots.
+                              // Polygons of up to kAStage vertices are staged here; bigger ones (rare) are read where they lie, so that
+                              // the carve stays at 13 KB and twelve instead of eight workgroups share a CU
+constexpr int kAStage = 12;
 
 // Candidate c of segment seg, in the reference's loop order (solver_gurobi_poly.cpp:477-495 agents,
 // :521-553 bases, :556-593 statics, :620-637 entangle): does the reference call the separator for
@@ -307,7 +310,7 @@ struct SepCtx {
   int slot, scene, own, N, S, nH, total;
 };
 __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, const double* by, double hulldist,
-                          bool stage, double2* myA, int& nA, bool& ordered) {
+                          bool stage, double2* myA, int& nA, bool& ordered, const double2*& Ause) {
   const SceneParams& sp = *cx.sp; const ProblemSet& ps = *cx.ps;
   const int N = cx.N, S = cx.S, nH = cx.nH;
   nA = 0; ordered = false;
@@ -319,7 +322,10 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     nA = blk(ps.hull_nv, hr.boff)[h];
     if (nA <= 0) return false;
     ordered = true;
-    if (stage) { const double2* src = (const double2*)(blk(ps.hull_xy, hr.boff) + h * kHullV * 2); for (int v = 0; v < nA; v++) myA[v] = src[v]; }
+    if (stage) {
+      const double2* src = (const double2*)(blk(ps.hull_xy, hr.boff) + h * kHullV * 2);
+      if (nA <= kAStage) for (int v = 0; v < nA; v++) myA[v] = src[v]; else Ause = src;
+    }
     return true;
   } else if (c < nH + N) {
     const int j = c - nH;
@@ -353,7 +359,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     for (int k = 0; k < nv - 1; k++) { const double ex = src[2 * (k + 1)] - src[2 * k], ey = src[2 * (k + 1) + 1] - src[2 * k + 1]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
     if (!close_s) return false;
     ordered = true; nA = nv;
-    if (stage) for (int v = 0; v < nv; v++) myA[v] = make_double2(src[2 * v], src[2 * v + 1]);
+    if (stage) { if (nv <= kAStage) for (int v = 0; v < nv; v++) myA[v] = make_double2(src[2 * v], src[2 * v + 1]); else Ause = (const double2*)src; }
     return true;
   } else if (c < cx.total) {
     const int e = c - nH - N - S;
@@ -424,7 +430,8 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
   for (int c0 = 0; c0 < total; c0 += 64) {
     const int c = c0 + lane;
     int nA; bool ord;
-    const bool att = c < total && cand_eval(cx, seg, c, bx, by, hulldist, false, nullptr, nA, ord);
+    const double2* unused = nullptr;
+    const bool att = c < total && cand_eval(cx, seg, c, bx, by, hulldist, false, nullptr, nA, ord, unused);
     const unsigned long long mask = __ballot(att);
     if (att) sAtt[n_att + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)c;
     n_att += __popcll(mask);
@@ -440,9 +447,10 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
   for (int a = lane; a < n_att; a += 64) {
     const int c = sAtt[a];
     int nA; bool ord;
-    cand_eval(cx, seg, c, bx, by, hulldist, true, myA, nA, ord);
+    const double2* Ause = myA;
+    cand_eval(cx, seg, c, bx, by, hulldist, true, myA, nA, ord, Ause);
     double nd[3];
-    const bool ok = separator_impl(nA, myA, ord, B4, nd);
+    const bool ok = separator_impl(nA, Ause, ord, B4, nd);
     if (!ok) { n_fail++; nd[0] = nd[1] = nd[2] = 0.0; }
     if (a < sp.lines_cap) { bucket[3 * a] = nd[0]; bucket[3 * a + 1] = nd[1]; bucket[3 * a + 2] = nd[2]; }
   }
