@@ -238,10 +238,10 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   double* sM = smem + oM; double* sHax = smem + oHax;
   double* sZ = smem + oZ; double* sG = smem + oG; double* sRd = smem + oRd; double* sRhs = smem + oRhs;
   double* sDxa = smem + oDxa; double* sDx = smem + oDx; double* sGq = smem + oGq; double* sZl = smem + oZl;
-  double* sInvD = smem + oInvD; double* sEp = smem + oEp; double* sCoef = smem + oCoef; double* sTheta = smem + oTheta;
+  double* sEp = smem + oEp; double* sCoef = smem + oCoef; double* sTheta = smem + oTheta;
   double* sInit = smem + oInit; double* sc = smem + oScal; double* sRed = smem + oRed;
   int* sI = (int*)(smem + kFixedDoubles);      // [0..8] line offsets, [16..] flags
-  double* dyn = smem + kFixedDoubles + 32;     // dynamic part: line coefficients then line-row state
+  // (the dynamic part — line coefficients, then line-row state — starts at smem + kFixedDoubles + 32: ldyn below)
 
   const int tid = threadIdx.x;
   const int slot = blockIdx.x;
