@@ -1180,3 +1180,187 @@ int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double*
   free(cand); free(keep); free(beam); free(visited);
   return 0;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* SURVEY §8(f) rank 2, first half: KinodynamicSearch::run itself (kinodynamic_search.cpp:1629-1827) */
+/* with its two expansion routines (:1045-1228, :1240-1385), CompareCost (kinodynamic_search.hpp:  */
+/* 163-179) on a binary heap with libstdc++'s push_heap / pop_heap mechanics, the (ix, iy) -> first  */
+/* node hash (NodeHashTable::insert does not overwrite), the in-place update of an open node of the  */
+/* same index on every second such event (ran_trigger, :1190-1203), the closest-so-far bookkeeping   */
+/* (:1683-1690) and recoverPwpOut (:521-553).  Entangle check off.  The two things that make the     */
+/* reference irreproducible are parameters here: `order` = all_combinations_ (shuffled with a time   */
+/* seed there, :321-322, :1462-1463) and `max_pops` in place of the wall-clock budget (:1644-1651).   */
+/* Reference material for the beam variant above (quality comparisons in tests); not on any product   */
+/* path.                                                                                             */
+/* ------------------------------------------------------------------------------------------ */
+#define AS_MAX_NODES 20000          /* node_num_max_ (kinodynamic_search.hpp:345) */
+typedef struct as_node { int prev, state, index; double g, h, end[6], cx[4], cy[4], Q[4][2]; long vx, vy; } as_node;
+typedef struct as_ctx {
+  const orc_fe_cfg* c; const double* hull_xy; const int* hull_nv; const orc_polys* statics; const double* goal; const int* order;
+  as_node* pool; int used; int* heap; int heap_n; long (*hkey)[2]; int* hval; int hcap; int ran_trigger;
+} as_ctx;
+static double as_cost(const as_ctx* A, int n) { return A->pool[n].g + A->c->bias * A->pool[n].h; }
+static int as_comp(const as_ctx* A, int l, int r) {     /* CompareCost(left, right) */
+  const double cl = as_cost(A, l), cr = as_cost(A, r);
+  if (fabs(cl - cr) < 1e-5) return A->pool[l].h > A->pool[r].h;
+  return cl > cr;
+}
+static void as_push_heap(as_ctx* A, int hole, int top, int value) {      /* std::__push_heap */
+  int parent = (hole - 1) / 2;
+  while (hole > top && as_comp(A, A->heap[parent], value)) { A->heap[hole] = A->heap[parent]; hole = parent; parent = (hole - 1) / 2; }
+  A->heap[hole] = value;
+}
+static void as_push(as_ctx* A, int n) { A->heap[A->heap_n++] = n; as_push_heap(A, A->heap_n - 1, 0, n); }
+static int as_pop(as_ctx* A) {                                           /* top(); pop(): std::pop_heap + pop_back */
+  const int top = A->heap[0];
+  const int len = A->heap_n - 1;          /* __pop_heap(first, last-1, last-1): value = *(last-1), *(last-1) = *first */
+  const int value = A->heap[len];
+  A->heap[len] = top;
+  int hole = 0, second = 0;
+  while (second < (len - 1) / 2) {        /* std::__adjust_heap(first, 0, len, value) */
+    second = 2 * (second + 1);
+    if (as_comp(A, A->heap[second], A->heap[second - 1])) second--;
+    A->heap[hole] = A->heap[second]; hole = second;
+  }
+  if ((len & 1) == 0 && second == (len - 2) / 2) { second = 2 * (second + 1); A->heap[hole] = A->heap[second - 1]; hole = second - 1; }
+  if (len > 0) as_push_heap(A, hole, 0, value);
+  A->heap_n = len;
+  return top;
+}
+static int as_find(const as_ctx* A, long vx, long vy) {
+  unsigned long h = ((unsigned long)vx * 0x9E3779B97F4A7C15ul) ^ ((unsigned long)vy * 0xC2B2AE3D27D4EB4Ful);
+  for (int k = (int)(h % (unsigned long)A->hcap);; k = (k + 1) % A->hcap) {
+    if (A->hval[k] < 0) return -1 - k;                                   /* empty slot: where it would go */
+    if (A->hkey[k][0] == vx && A->hkey[k][1] == vy) return A->hval[k];
+  }
+}
+static void as_insert(as_ctx* A, long vx, long vy, int n) {               /* unordered_map::insert: keeps the first */
+  const int f = as_find(A, vx, vy);
+  if (f >= 0) return;
+  const int k = -1 - f; A->hkey[k][0] = vx; A->hkey[k][1] = vy; A->hval[k] = n;
+}
+static int as_collides(const as_ctx* A, const as_node* nd) {              /* collidesWithObstacles2dSolve (:1514-1553) */
+  const orc_fe_cfg* c = A->c;
+  int idx = nd->index > c->num_pol ? c->num_pol : nd->index;
+  for (int j = 0; j < c->num_agents; j++) {
+    if (j == c->id - 1) continue;
+    const int nv = A->hull_nv[j * c->num_pol + (idx - 1)];
+    if (nv <= 0) continue;
+    if (orc_gjk_collision(nv, (const double(*)[2])(A->hull_xy + ((size_t)(j * c->num_pol + (idx - 1)) * NEP_HULL_MAX_V) * 2), 4, nd->Q)) return 1;
+  }
+  for (int s = 0; A->statics && s < A->statics->n; s++) {
+    const int nv = A->statics->off[s + 1] - A->statics->off[s];
+    if (nv > 0 && orc_gjk_collision(nv, (const double(*)[2])(A->statics->xy + 2 * (size_t)A->statics->off[s]), 4, nd->Q)) return 1;
+  }
+  return 0;
+}
+/* both expandAndAddToQueue overloads: cur < 0 = from the initial state */
+static void as_expand(as_ctx* A, int cur, const double init[6]) {
+  const orc_fe_cfg* c = A->c;
+  const int ns = c->num_samples;
+  const double* st = cur < 0 ? init : A->pool[cur].end;
+  for (int q = 0; q < ns * ns; q++) {
+    if (cur >= 0 && A->used == AS_MAX_NODES - 1) return;                  /* "run out of memory" (:1061-1065) */
+    if (A->used >= AS_MAX_NODES - 1) return;
+    const int comb = A->order ? A->order[q] : q;
+    as_node* nb = &A->pool[A->used];
+    fe_node tmp;
+    /* the child tests (fe_child above states the two norm tests on the squares) */
+    if (!fe_child(c, st, 0.0, cur < 0, comb / ns, comb % ns, A->goal, &tmp)) continue;
+    nb->index = cur < 0 ? 1 : A->pool[cur].index + 1; nb->prev = cur;
+    for (int i = 0; i < 6; i++) nb->end[i] = tmp.end[i];
+    for (int i = 0; i < 4; i++) { nb->cx[i] = tmp.cx[i]; nb->cy[i] = tmp.cy[i]; }
+    double Qx[4], Qy[4];
+    orc_pos_ctrl_pts(nb->cx, c->T_span, Qx); orc_pos_ctrl_pts(nb->cy, c->T_span, Qy);
+    for (int i = 0; i < 4; i++) { nb->Q[i][0] = Qx[i]; nb->Q[i][1] = Qy[i]; }
+    const double arc = sqrt((nb->end[0] - st[0]) * (nb->end[0] - st[0]) + (nb->end[1] - st[1]) * (nb->end[1] - st[1]));
+    nb->g = (cur < 0 ? 0.0 : A->pool[cur].g) + arc;
+    nb->h = tmp.dist;                                                     /* getH (:401-405) */
+    nb->vx = tmp.vx; nb->vy = tmp.vy;
+    if (cur >= 0) {
+      const int f = as_find(A, nb->vx, nb->vy);
+      if (f >= 0) {
+        as_node* o = &A->pool[f];
+        if (o->state == 1 && o->index == nb->index) {
+          if (nb->g + c->bias * nb->h < o->g + c->bias * o->h && A->ran_trigger % 2 == 0) {   /* update the open node in place */
+            o->prev = cur; o->g = nb->g; o->h = nb->h;
+            for (int i = 0; i < 6; i++) o->end[i] = nb->end[i];
+            for (int i = 0; i < 4; i++) { o->cx[i] = nb->cx[i]; o->cy[i] = nb->cy[i]; o->Q[i][0] = nb->Q[i][0]; o->Q[i][1] = nb->Q[i][1]; }
+          }
+          A->ran_trigger++;
+        }
+        continue;
+      }
+    }
+    nb->state = 1;
+    as_push(A, A->used);
+    as_insert(A, nb->vx, nb->vy, A->used);
+    A->used++;
+  }
+}
+
+int orc_frontend_astar(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv, const orc_polys* statics,
+                       const int* order, int max_pops, nep_guess* guess, nep_fe_result* res) {
+  const int ns = c->num_samples;
+  if (ns < 2 || ns > NEP_FE_MAX_SAMPLES || c->num_pol < 1 || c->num_pol > NEP_MAX_POL) return -1;
+  as_ctx A; memset(&A, 0, sizeof(A));
+  const double goal[2] = {st->goal[0], st->goal[1]};
+  A.c = c; A.hull_xy = hull_xy; A.hull_nv = hull_nv; A.statics = statics; A.goal = goal; A.order = order;
+  A.pool = (as_node*)calloc(AS_MAX_NODES, sizeof(as_node)); A.heap = (int*)malloc(sizeof(int) * AS_MAX_NODES);
+  A.hcap = 4 * AS_MAX_NODES + 7; A.hkey = (long(*)[2])malloc(sizeof(long) * 2 * A.hcap); A.hval = (int*)malloc(sizeof(int) * A.hcap);
+  for (int k = 0; k < A.hcap; k++) A.hval[k] = -1;
+  memset(res, 0, sizeof(*res)); memset(guess, 0, sizeof(*guess)); guess->t_start = st->t_start;
+  {   /* goal_occupied_ (setUp :210-226) */
+    const double r = 0.5;
+    const double G[4][2] = {{goal[0] + r, goal[1] + r}, {goal[0] + r, goal[1] - r}, {goal[0] - r, goal[1] + r}, {goal[0] - r, goal[1] - r}};
+    for (int j = 0; j < c->num_agents && !res->goal_occupied; j++) {
+      if (j == c->id - 1) continue;
+      const int nv = hull_nv[j * c->num_pol + (c->num_pol - 1)];
+      if (nv > 0 && orc_gjk_collision(nv, (const double(*)[2])(hull_xy + ((size_t)(j * c->num_pol + c->num_pol - 1) * NEP_HULL_MAX_V) * 2), 4, G)) res->goal_occupied = 1;
+    }
+  }
+  const double init[6] = {st->pos[0], st->pos[1], st->vel[0], st->vel[1], st->accel[0], st->accel[1]};
+  as_expand(&A, -1, init);
+  int status = NEP_FE_EMPTY, cur = -1, closest = -1, pops = 0;
+  double smallest = 1.7976931348623157e308;
+  while (A.heap_n > 0) {
+    if (pops >= max_pops) { status = NEP_FE_DEPTH_REACHED; break; }       /* RUNTIME_REACHED */
+    cur = as_pop(&A); pops++;
+    as_node* nd = &A.pool[cur];
+    nd->state = -1;
+    const double dist = sqrt((nd->end[0] - goal[0]) * (nd->end[0] - goal[0]) + (nd->end[1] - goal[1]) * (nd->end[1] - goal[1]));
+    const double dfi = sqrt((nd->end[0] - init[0]) * (nd->end[0] - init[0]) + (nd->end[1] - init[1]) * (nd->end[1] - init[1]));
+    if (as_collides(&A, nd)) continue;                                    /* ignore_first_col_ is always false (:1449-1455) */
+    const double dtc = res->goal_occupied ? dist * dist : dfi;
+    const double dti = dtc * (double)nd->index;
+    if (dti < smallest) { smallest = dti; closest = cur; }
+    if (dist < c->goal_size) { status = NEP_FE_GOAL_REACHED; break; }
+    as_expand(&A, cur, init);
+  }
+  int best = -1;
+  if (status == NEP_FE_GOAL_REACHED) best = cur;
+  else best = closest;                                                    /* use_not_reaching_soln */
+  res->n_children = pops; res->n_feasible = A.used; res->depth = best >= 0 ? A.pool[best].index : 0;
+  if (best < 0) status = NEP_FE_NO_SOLUTION;
+  res->status = status;
+  if (best >= 0) {
+    /* recoverPwpOut: the nodes of the path with index <= num_pol */
+    int chain[4096], n = 0;
+    for (int k = best; k >= 0 && n < 4096; k = A.pool[k].prev) chain[n++] = k;
+    int K = 0;
+    for (int i = n - 1; i >= 0; i--) {
+      const as_node* q = &A.pool[chain[i]];
+      if (q->index > c->num_pol) break;
+      for (int k = 0; k < 4; k++) { guess->coeff[0][K][k] = q->cx[k]; guess->coeff[1][K][k] = q->cy[k]; }
+      K++;
+    }
+    double cz[NEP_MAX_POL][4];
+    fe_initial_z(st->pos[2], st->vel[2], st->accel[2], st->goal[2], c->T_span, c->num_pol, c->v_max, c->a_max, cz);
+    for (int d = 0; d < K; d++) for (int k = 0; k < 4; k++) guess->coeff[2][d][k] = cz[d][k];
+    guess->K = K; res->K = K;
+    res->cost = A.pool[best].g + c->bias * A.pool[best].h;
+    res->dist_to_goal = sqrt((A.pool[best].end[0] - goal[0]) * (A.pool[best].end[0] - goal[0]) + (A.pool[best].end[1] - goal[1]) * (A.pool[best].end[1] - goal[1]));
+  }
+  free(A.pool); free(A.heap); free(A.hkey); free(A.hval);
+  return 0;
+}

@@ -124,6 +124,11 @@ typedef struct orc_fe_cfg {
   double mins[2], maxs[2];
   const double* pb;
 } orc_fe_cfg;
+/* KinodynamicSearch::run restated (best-first, unbounded depth) with the lattice order and the pop budget as
+ * parameters; order == NULL: jx-major.  res->n_children = pops, res->n_feasible = nodes created, res->depth = index
+ * of the returned node (may exceed num_pol: the guess keeps the first num_pol segments). */
+int orc_frontend_astar(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv, const orc_polys* statics,
+                       const int* order, int max_pops, nep_guess* guess, nep_fe_result* res);
 int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv,
                       const orc_polys* statics, nep_guess* guess, nep_fe_result* res);
 

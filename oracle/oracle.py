@@ -265,6 +265,26 @@ def frontend_beam(p, fe, agent_id, start, hull_xy, hull_nv, statics):
     return g[0], {k: r[0][k].item() for k in abi.FE_RESULT_DTYPE.names}
 
 
+def frontend_astar(p, fe, agent_id, start, hull_xy, hull_nv, statics, order=None, max_pops=20000):
+    """KinodynamicSearch::run restated (best-first search to the goal, lattice order and pop budget as parameters)."""
+    pb = _c(p.pb)
+    cfg = orc_fe_cfg(p.num_pol, agent_id, p.num_agents, fe.num_samples, fe.beam_width, fe.pad_hold, p.T_span, fe.j_max, p.v_max, p.a_max,
+                     fe.voxel_size, fe.bias, fe.goal_size, fe.cable_length, (C.c_double * 2)(p.x_min, p.y_min),
+                     (C.c_double * 2)(p.x_max, p.y_max), abi.dptr(pb))
+    S = Polys(statics)
+    st = np.ascontiguousarray(start, dtype=abi.FE_START_DTYPE).reshape(1)
+    hx = _c(hull_xy); hn = _c(hull_nv, np.int32)
+    od = _c(order, np.int32) if order is not None else None
+    g = np.zeros(1, dtype=abi.GUESS_DTYPE); r = np.zeros(1, dtype=abi.FE_RESULT_DTYPE)
+    f = lib().orc_frontend_astar
+    f.restype = C.c_int
+    rc = f(C.byref(cfg), C.c_void_p(st.ctypes.data), C.c_void_p(hx.ctypes.data), C.c_void_p(hn.ctypes.data), C.byref(S.c),
+           C.c_void_p(od.ctypes.data) if od is not None else None, C.c_int(max_pops), C.c_void_p(g.ctypes.data), C.c_void_p(r.ctypes.data))
+    if rc:
+        raise RuntimeError("orc_frontend_astar: bad configuration")
+    return g[0], {k: r[0][k].item() for k in abi.FE_RESULT_DTYPE.names}
+
+
 def hulls_of_scene(p, agent_id, recs, t_start, statics):
     """Interval hulls of every record as the oracle builds them for a replan at t_start:
     (hull_xy [N][num_pol][16][2], hull_nv [N][num_pol])."""

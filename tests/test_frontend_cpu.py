@@ -119,3 +119,50 @@ def test_height_profile_is_a_c2_spline_from_the_start_state_to_the_goal_height(o
             np.testing.assert_allclose([z_end, v_end], [zg, 0.0], atol=1e-9)
         else:                                                         # rate limited: climbs at most v_max all the way
             assert z_end < zg and z_end <= z0 + p.v_max * K * T + 1e-9
+
+
+def test_astar_restatement_reaches_a_nearby_goal_and_its_plan_is_feasible(oracle):
+    """KinodynamicSearch::run restated: best-first to the goal; the plan (first num_pol segments) passes the same
+    checks as the beam's guesses; a different lattice order (the reference shuffles it) may change the path but
+    not its validity."""
+    sc = scene.make_scene(8, 6, seed=5)
+    p = sc["par"]
+    fe = scene.frontend_cfg(p, beam_width=32)
+    starts = scene.frontend_starts(sc)
+    rng = np.random.default_rng(4)
+    reached = 0
+    for a in range(8):
+        st = starts[a].copy()
+        d = np.array(st["goal"][:2]) - np.array(st["pos"][:2])
+        st["goal"][:2] = np.array(st["pos"][:2]) + d / np.linalg.norm(d) * min(np.linalg.norm(d), 5.0)      # a goal the search can reach
+        hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(st["t_start"]), sc["statics"])
+        for order in (None, rng.permutation(25)):
+            g, r = oracle.frontend_astar(p, fe, a + 1, st, hx, hn, sc["statics"], order=order, max_pops=6000)
+            assert r["status"] in (0, 1) and 1 <= int(g["K"]) <= p.num_pol
+            check_guess(oracle, sc, a, g, hx, hn, st)
+            reached += r["status"] == 1
+            if r["status"] == 1:
+                assert r["dist_to_goal"] < fe.goal_size and r["depth"] >= int(g["K"])
+    assert reached >= 10
+
+
+def test_beam_guesses_are_competitive_with_the_astar_restatement(oracle):
+    """Same rules, different search strategy: over the first num_pol segments the beam (depth num_pol, width 32) gets
+    about as far towards the goal as the best-first search with a 4000-pop budget."""
+    sc = scene.make_scene(8, 6, seed=5)
+    p = sc["par"]
+    fe = scene.frontend_cfg(p, beam_width=32)
+    starts = scene.frontend_starts(sc)
+
+    def progress(g, st):
+        K = int(g["K"]); co = np.array(g["coeff"])
+        end = np.array([np.polyval(co[ax, K - 1], T) for ax in range(2)])
+        return np.linalg.norm(np.array(st["goal"][:2]) - np.array(st["pos"][:2])) - np.linalg.norm(np.array(st["goal"][:2]) - end)
+    tot_b = tot_a = 0.0
+    for a in range(8):
+        hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(starts[a]["t_start"]), sc["statics"])
+        gb, rb = oracle.frontend_beam(p, fe, a + 1, starts[a], hx, hn, sc["statics"])
+        ga, ra = oracle.frontend_astar(p, fe, a + 1, starts[a], hx, hn, sc["statics"], max_pops=4000)
+        if int(gb["K"]) and int(ga["K"]):
+            tot_b += progress(gb, starts[a]); tot_a += progress(ga, starts[a])
+    assert tot_b > 0 and tot_b >= 0.8 * tot_a, (tot_b, tot_a)
