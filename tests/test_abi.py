@@ -75,3 +75,12 @@ def test_cpp_host_class_compiles_and_links(L):
                            "-L" + os.path.join(ROOT, "neptune_amd"), "-lneptune_backend",
                            "-Wl,-rpath,$ORIGIN/../../neptune_amd", "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe])
     assert os.path.exists(exe)
+
+
+def test_headers_are_plain_c99():
+    """The boundary is a C ABI: every header under include/ (except the C++ class) must compile as strict C99."""
+    import subprocess
+    for h in ("neptune_backend.h", "neptune_plan.h", "neptune_entangle.h", "neptune_frontend.h"):
+        r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                            "-x", "c", "-"], input='#include "%s"\n' % h, text=True, capture_output=True)
+        assert r.returncode == 0, (h, r.stderr)
