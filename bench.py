@@ -103,6 +103,9 @@ def main():
                          "sharded with the agents) or the trajectory records themselves (every rank rebuilds all hulls)")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1 with --exchange hulls: scene chunks pipelined so that one chunk's all-gather overlaps the other's kernels")
+    ap.add_argument("--cull-radius", type=float, default=0.0,
+                    help="presolve of the separating-line rows (nep_batch_set_line_cull): lines farther than this many metres "
+                         "from the guess are left out of the QP and verified after the solve; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frontend", action="store_true",
                     help="also run the front-end beam search (SURVEY §8f rank 2) in every step: the guesses are made on the device "
@@ -174,6 +177,8 @@ def main():
     # one handle per scene chunk (C == 1: all scenes); chunk k holds scenes [k*Sc, (k+1)*Sc)
     bes = [BatchBackend(p, statics, first_local=first_local, n_local=n_local, n_scenes=Sc, device=dev) for _ in range(C)]
     be = bes[0]
+    for b in bes:
+        b.set_line_cull(args.cull_radius)
     d_committed = be.to_device(com) if C == 1 else None
     d_guess_c = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)]
     d_guess = d_guess_c[0]
@@ -321,7 +326,8 @@ def main():
                        "params": "reference neptune_mtlp_benchmark.yaml (T_span 0.5, num_pol 8, weight 1000, v 2, a 3)"},
             "solver": {"status_ok": int((status == 0).sum()), "status_relaxed": int((status == 1).sum()),
                        "status_failed": int((status == 2).sum()), "ipm_iters_mean": float(iters.mean()),
-                       "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum())},
+                       "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum()),
+                       "rows_solved_mean": float(sol["stats"]["n_rows"].mean()), "line_cull_radius": args.cull_radius},
             "p50_solve_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),
             "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange_wait": mean_ms(gather_ev),
                           "launches": n_launch, "launches_per_step": C},

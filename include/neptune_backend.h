@@ -283,6 +283,15 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
                             const nep_guess* d_guess, nep_traj_rec* d_final, int32_t* d_accept,
                             void* stream);
 /* Test hook: the conflict matrix [N][N] of one scene from the last safety check. */
+/* Presolve of the separating-line rows (off by default, radius = 0).  With radius > 0 (metres) a line whose
+ * boundary lies farther than `radius` from all four control points of the guess's segment is left out of the
+ * QP; after the solve every left-out line is checked against the solution's control points and, if one is
+ * violated, the replan is solved again with all lines — the optimum is that of the full problem (what a QP
+ * presolve does with redundant rows; Gurobi runs one inside PolySolverGurobi::optimize).  nep_stats.n_lines
+ * still counts every line, n_rows the rows actually solved for.  The debug line readers see the buckets
+ * reordered (near lines first).                                                                         */
+int nep_batch_set_line_cull(nep_batch_t* h, double radius);
+
 /* on != 0: nep_batch_safety_commit additionally turns down a new trajectory that collides with the
  * PREVIOUS record of any other agent (its hulls on the round's grid).  The spline QP keeps the two
  * apart wherever a separating line was found; where the LP had no solution the reference skips the

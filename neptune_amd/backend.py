@@ -265,6 +265,11 @@ class BatchBackend:
         check(lib().nep_batch_safety_commit(self._h, d_prev.data_ptr(), d_new.data_ptr(), d_guess.data_ptr(), d_final.data_ptr(),
                                             d_accept.data_ptr() if d_accept is not None else None, st.cuda_stream))
 
+    def set_line_cull(self, radius):
+        """presolve: separating lines farther than `radius` metres from the guess are left out of the QP and verified
+        afterwards (nep_batch_set_line_cull); 0 turns it off"""
+        check(lib().nep_batch_set_line_cull(self._h, float(radius)))
+
     def set_safety_check_prev(self, on=True):
         """also turn down new trajectories that collide with another agent's PREVIOUS record (nep_batch_set_safety_check_prev)"""
         check(lib().nep_batch_set_safety_check_prev(self._h, 1 if on else 0))

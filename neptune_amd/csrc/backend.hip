@@ -49,7 +49,7 @@ struct Engine {
   DevBuf<int> d_sched_n, d_sched_seg; DevBuf<double> d_sched_dt;
   DevBuf<double> d_pb, d_static_xy; DevBuf<int> d_static_nv;
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
-  DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_lp_stats;
+  DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
   DevBuf<long long> d_dbg; bool profile_phases = false;
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
@@ -114,6 +114,7 @@ struct Engine {
     if (int e = d_bend_n.ensure((size_t)n_scenes * N)) return e;
     if (int e = d_line_nd.ensure((size_t)slots * lines_total * 3)) return e;
     if (int e = d_line_cnt.ensure((size_t)slots * NEP_MAX_POL)) return e;
+    if (int e = d_line_far.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_lp_stats.ensure((size_t)slots * 2)) return e;
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 16)) return e; }
@@ -126,6 +127,7 @@ struct Engine {
     ps.hull_xy = d_hull_xy.p; ps.hull_nv = d_hull_nv.p; ps.hull0_xy = d_hull0_xy.p; ps.hull0_nv = d_hull0_nv.p;
     ps.bend_xy = d_bend_xy.p; ps.bend_n = d_bend_n.p;
     ps.line_nd = d_line_nd.p; ps.line_cnt = d_line_cnt.p; ps.lp_stats = d_lp_stats.p;
+    ps.line_far = sp.cull_radius > 0.0 ? d_line_far.p : nullptr;
     ps.row_scratch = d_row_scratch.p; ps.rows_cap = rows_cap; ps.lds_rows = lds_rows; ps.lds_lines = lds_lines;
     ps.dbg = profile_phases ? d_dbg.p : nullptr;
   }
@@ -168,7 +170,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release();
-    d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_lp_stats.release();
+    d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
   }
@@ -671,6 +673,12 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
   if (E.safety_check_prev) { if (int e = E.d_conflict_prev.ensure((size_t)h->cfg.n_scenes * N * N)) return e; }
   launch_safety(d_prev, d_new, h->cfg.n_scenes, N, E.sp, ps, E.d_conflict.p, E.safety_check_prev ? E.d_conflict_prev.p : nullptr, d_final, d_accept, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int nep_batch_set_line_cull(nep_batch_t* h, double radius) {
+  if (!h || !(radius >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
+  h->eng.sp.cull_radius = radius;
   return 0;
 }
 

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
   const nep_guess* g = ps.guess + slot;
   const int K = g->K;
   int* cnt_out = ps.line_cnt + (long)slot * NEP_MAX_POL + seg;
-  if (seg >= K || seg >= sp.num_pol) { if (lane == 0) *cnt_out = 0; return; }
+  if (seg >= K || seg >= sp.num_pol) { if (lane == 0) { *cnt_out = 0; if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = 0; } return; }
   const double T = sp.T_span;
   SepCtx cx; cx.sp = &sp; cx.ps = &ps; cx.slot = slot; cx.scene = slot / sp.n_local; cx.own = sp.first_local + (slot % sp.n_local);
   cx.N = sp.num_agents; cx.S = sp.n_static; cx.nH = sp.n_hull;
@@ -444,19 +444,48 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
   for (int k = 0; k < 4; k++) { B4.x[k] = sBx[k]; B4.y[k] = sBy[k]; }
   double* bucket = ps.line_nd + ((long)slot * NEP_MAX_POL + seg) * sp.lines_cap * 3;
   int n_fail = 0;
-  for (int a = lane; a < n_att; a += 64) {
-    const int c = sAtt[a];
-    int nA; bool ord;
-    const double2* Ause = myA;
-    cand_eval(cx, seg, c, bx, by, hulldist, true, myA, nA, ord, Ause);
-    double nd[3];
-    const bool ok = separator_impl(nA, Ause, ord, B4, nd);
-    if (!ok) { n_fail++; nd[0] = nd[1] = nd[2] = 0.0; }
-    if (a < sp.lines_cap) { bucket[3 * a] = nd[0]; bucket[3 * a + 1] = nd[1]; bucket[3 * a + 2] = nd[2]; }
+  // Presolve (sp.cull_radius > 0): a line whose boundary is farther than cull_radius from all four control points of
+  // the guess is parked at the back of the bucket ("far") and left out of the QP; the QP kernel verifies them against
+  // its solution and re-solves with every line if one is violated, so the optimum is unchanged.  Near lines keep
+  // their order at the front; far lines are written from the end of the bucket, in order of appearance.
+  const bool cull = sp.cull_radius > 0.0 && ps.line_far != nullptr;
+  int n_near = 0, n_far = 0;                              // wave-uniform running counts
+  for (int a0 = 0; a0 < n_att; a0 += 64) {
+    const int a = a0 + lane;
+    const bool active = a < n_att;
+    double nd[3] = {0.0, 0.0, 0.0};
+    bool far = false;
+    if (active) {
+      const int c = sAtt[a];
+      int nA; bool ord;
+      const double2* Ause = myA;
+      cand_eval(cx, seg, c, bx, by, hulldist, true, myA, nA, ord, Ause);
+      const bool ok = separator_impl(nA, Ause, ord, B4, nd);
+      if (!ok) { n_fail++; nd[0] = nd[1] = nd[2] = 0.0; }
+      if (cull) {
+        double worst = -NEP_INF;                          // largest n.Q + d - 1 over the guess's control points (<= -2 for a solved LP)
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double v = (nd[0] * B4.x[k] + nd[1] * B4.y[k]) + (nd[2] - 1.0); if (v > worst) worst = v; }
+        const double len = sqrt(nd[0] * nd[0] + nd[1] * nd[1]);
+        far = !ok || -worst > sp.cull_radius * len;       // (a null row constrains nothing)
+      }
+    }
+    if (!cull) {
+      if (active && a < sp.lines_cap) { bucket[3 * a] = nd[0]; bucket[3 * a + 1] = nd[1]; bucket[3 * a + 2] = nd[2]; }
+    } else {
+      const unsigned long long mn = __ballot(active && !far), mf = __ballot(active && far);
+      const unsigned long long below = (1ull << lane) - 1ull;
+      if (active) {
+        const long pos = far ? (long)sp.lines_cap - 1 - (n_far + __popcll(mf & below)) : (long)n_near + __popcll(mn & below);
+        bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2];
+      }
+      n_near += __popcll(mn); n_far += __popcll(mf);
+    }
   }
   for (int o = 32; o > 0; o >>= 1) n_fail += __shfl_xor(n_fail, o);
   if (lane == 0) {
-    *cnt_out = n_att < sp.lines_cap ? n_att : sp.lines_cap;
+    *cnt_out = cull ? n_near : (n_att < sp.lines_cap ? n_att : sp.lines_cap);
+    if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = cull ? n_far : 0;
     atomicAdd(ps.lp_stats + 2 * slot, n_att);
     if (n_fail) atomicAdd(ps.lp_stats + 2 * slot + 1, n_fail);
   }

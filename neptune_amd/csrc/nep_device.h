@@ -26,6 +26,7 @@ struct SceneParams {
   double T_span, weight, dc, drone_radius;
   double mins[3], maxs[3], v_max, a_max;
   double long_length; // solver_gurobi_poly.cpp:173
+  double cull_radius; // > 0: separating lines farther than this from the guess are presolved away (verified after the solve)
 };
 
 // Buffers of one problem set (n_scenes x n_local slots).  All device pointers.
@@ -50,7 +51,8 @@ struct ProblemSet {
   long hull_bstride;
   // separator output
   double* line_nd;               // [slots][NEP_MAX_POL][lines_cap][3]
-  int* line_cnt;                 // [slots][NEP_MAX_POL]
+  int* line_cnt;                 // [slots][NEP_MAX_POL]  lines at the front of the bucket (all of them, or the near ones)
+  int* line_far;                 // [slots][NEP_MAX_POL]  presolved-away lines parked at the back of the bucket, or null
   int* lp_stats;                 // [slots][2]  (attempted, failed)
   int lines_override;            // 1: line buckets were filled by the host (test hook)
   // QP scratch when the row state does not fit LDS

@@ -231,6 +231,9 @@ __device__ __noinline__ double solve_wave(unsigned m_off, unsigned d_off, int n,
 #undef NEP_SOLVE
 }
 
+// CULL: the separator parked far lines at the back of the buckets (nep_batch_set_line_cull) — solve with the near ones,
+// verify the far ones, solve again with all of them if one is violated.  !CULL: every line, one solve.
+template <bool CULL>
 __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sB = smem + oB; double* sOff = smem + oOff; double* sAccL = smem + oAccL;
@@ -252,13 +255,27 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 
   // ---- stage the guess ------------------------------------------------------------------------
   if (tid < 96) sCoef[tid] = (&g->coeff[0][0][0])[tid];
+  // Presolved-away ("far") lines sit at the back of the buckets (separator_kernel); the first attempt solves with the
+  // near lines only and checks the far ones against its solution; a violated one means all lines are solved for.
+  const bool culled = CULL;
+  int status = NEP_FAILED, iters_total = 0, iters_first = 0, L_used = 0, L_all = 0;
+  double objective = 0.0;
+  bool has_qc = false, z_override = false;
+  auto solve_once = [&](const bool use_far) -> bool {   // returns true when the far lines must be added
+  __syncthreads();
   if (tid == 0) {
-    int o = 0;
-    for (int i = 0; i < NEP_MAX_POL; i++) { sI[i] = o; int c = (i < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + i] : 0; o += c; }
-    sI[NEP_MAX_POL] = o;
+    int o = 0, nf = 0, all = 0;
+    for (int i = 0; i < NEP_MAX_POL; i++) {
+      const int cn = (i < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + i] : 0;
+      const int cf = (i < K && culled) ? ps.line_far[(long)slot * NEP_MAX_POL + i] : 0;
+      sI[i] = o; sI[32 + i] = cf; sI[44 + i] = cn;
+      o += cn + (use_far ? cf : 0); nf += cf; all += cn + cf;
+    }
+    sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0;
   }
   __syncthreads();
   const int L = sI[NEP_MAX_POL];
+  L_used = L; L_all = sI[42];
   // Line coefficients and line-row state live in the LDS carve when the replan's L lines fit it
   // (the normal case: ds_read/ds_write through address_space(3) pointers), else in the per-slot
   // global spill; the solver body below is instantiated once per placement.
@@ -278,8 +295,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   }
   __syncthreads();
   const double dix = sCoef[3] - sc[sFinal0], diy = sCoef[32 + 3] - sc[sFinal1], diz = sCoef[64 + 3] - sc[sFinal2];
-  const bool has_qc = sqrt(dix * dix + diy * diy + diz * diz) < 1.0;   // :697-702
-  const bool z_override = sqrt(dix * dix + diy * diy) < 1.0;           // :879-880
+  has_qc = sqrt(dix * dix + diy * diy + diz * diz) < 1.0;   // :697-702
+  z_override = sqrt(dix * dix + diy * diy) < 1.0;           // :879-880
   const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);                    // inequality count (+ball)
 
   // ---- thread roles ---------------------------------------------------------------------------
@@ -303,8 +320,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 #else
 #define TICK(k) do { } while (0)
 #endif
-  int status = NEP_FAILED, iters_total = 0, iters_first = 0;
-  double objective = 0.0;
+  status = NEP_FAILED; iters_total = 0; iters_first = 0; objective = 0.0;
 
   auto run = [&](auto lds_tag) {
   constexpr bool LDSL = decltype(lds_tag)::value;
@@ -315,9 +331,12 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   auto STr = [&](int l, int k, int c) -> double { if constexpr (LDSL) return ldyn[(3 + c * 4 + k) * LL + l]; else return gsp[(3 + c * 4 + k) * GL + l]; };
   auto STw = [&](int l, int k, int c, double v) { if constexpr (LDSL) ldyn[(3 + c * 4 + k) * LL + l] = v; else gsp[(3 + c * 4 + k) * GL + l] = v; };
   for (int i = 0; i < K; i++) {  // gather the separator's buckets into one segment-major list
-    const int beg = sI[i], cnt = sI[i + 1] - beg;
+    const int beg = sI[i], cnt = sI[i + 1] - beg, cn = sI[44 + i];
     const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
-    for (int l = tid; l < cnt; l += BS) { LNw(beg + l, 0, src[3 * l]); LNw(beg + l, 1, src[3 * l + 1]); LNw(beg + l, 2, 1.0 - src[3 * l + 2]); }
+    for (int l = tid; l < cnt; l += BS) {
+      const long e = l < cn ? l : (long)sp.lines_cap - 1 - (l - cn);      // near lines from the front, far ones from the back
+      LNw(beg + l, 0, src[3 * e]); LNw(beg + l, 1, src[3 * e + 1]); LNw(beg + l, 2, 1.0 - src[3 * e + 2]);
+    }
   }
   const int LD = (LDSL ? LL : GL) - 1;   // dummy line: harmless operands for the padded tail of a row group
   if (tid < 4) { STw(LD, tid, 0, 1.0); STw(LD, tid, 1, 1.0); if (tid == 0) { LNw(LD, 0, 0.0); LNw(LD, 1, 0.0); LNw(LD, 2, 1.0); } }
@@ -743,6 +762,36 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   };   // run
   if (L <= ps.lds_lines) run(std::true_type{}); else run(std::false_type{});
   __syncthreads();
+  if (!CULL) return false;
+  if (use_far || sI[41] == 0 || status == NEP_FAILED) return false;
+  {  // the far lines against the solution: position control points from the base rows of the converged mode
+    const QpTable* __restrict__ tbv = tables + status * (kMaxK + 1) + K;
+    const int nzv = tbv->nz;
+    if (tid < 8 * K) {
+      const int rho = tid >> 1, ax = tid & 1;
+      double v = sOff[rho * 3 + ax];
+      for (int c = 0; c < nzv; c++) v = __builtin_fma(sB[rho * SBS + c], sZ[ax * nzv + c], v);
+      sAccL[rho * 2 + ax] = v;
+    }
+    __syncthreads();
+    bool viol = false;
+    for (int i = 0; i < K; i++) {
+      const int cf = sI[32 + i];
+      const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
+      for (int l = tid; l < cf; l += BS) {
+        const long e = (long)sp.lines_cap - 1 - l;
+        const double n1 = src[3 * e], n2 = src[3 * e + 1], dd = src[3 * e + 2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) viol = viol || (n1 * sAccL[(4 * i + k) * 2] + n2 * sAccL[(4 * i + k) * 2 + 1] + dd - 1.0 > 0.0);
+      }
+    }
+    if (viol) sI[21] = 1;
+    __syncthreads();
+    return sI[21] != 0;
+  }
+  };   // solve_once
+  if (solve_once(false)) { if constexpr (CULL) solve_once(true); }
+  __syncthreads();
   // ---- outputs -----------------------------------------------------------------------------------
   if (status == NEP_FAILED) { if (tid < 96) sTheta[tid] = sCoef[tid]; }                    // :856-859
   else if (z_override) { if (tid < 32) sTheta[64 + tid] = sCoef[64 + tid]; }             // :879-880
@@ -755,8 +804,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     sol->stats.status = status; sol->stats.iters = iters_total; sol->stats.iters_first = iters_first;
     // bucket entries of LPs without a separating line are (0,0,0) = null rows (constraint skipped)
     const int n_lp = (ps.lp_stats && !ps.lines_override) ? ps.lp_stats[2 * slot] : 0, n_lpf = (ps.lp_stats && !ps.lines_override) ? ps.lp_stats[2 * slot + 1] : 0;
-    sol->stats.n_lines = L - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
-    sol->stats.n_rows = 48 * K + 4 * (L - n_lpf); sol->stats.qc_active = has_qc ? 1 : 0;
+    sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
+    sol->stats.n_rows = 48 * K + 4 * ((culled && L_used < L_all) ? L_used : L_used - n_lpf); sol->stats.qc_active = has_qc ? 1 : 0;   // rows solved for (null rows of failed LPs excluded)
     sol->stats.objective = objective; sol->stats.solve_us = 0.0;
     sol->K = K; sol->n_states = ns;
   }
@@ -796,12 +845,14 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                const SampleSched& sched, size_t lds_bytes, hipStream_t st) {
   if (n_slots <= 0) return;
-  static size_t configured = 0;
-  if (lds_bytes > configured) {
-    hipFuncSetAttribute((const void*)qp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured = lds_bytes;
+  const bool cull = ps.line_far != nullptr && !ps.lines_override;
+  static size_t configured[2] = {0, 0};
+  if (lds_bytes > configured[cull]) {
+    hipFuncSetAttribute(cull ? (const void*)qp_kernel<true> : (const void*)qp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    configured[cull] = lds_bytes;
   }
-  hipLaunchKernelGGL(qp_kernel, dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
+  if (cull) hipLaunchKernelGGL(qp_kernel<true>, dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
+  else hipLaunchKernelGGL(qp_kernel<false>, dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
 }
 
 }  // namespace nep

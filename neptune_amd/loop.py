@@ -21,6 +21,7 @@ class FleetLoop:
         self.goals = np.asarray(goals, dtype=np.float64).reshape(N, 3)
         self.be = BatchBackend(par, statics, n_scenes=1, device=device)
         self.be.set_safety_check_prev(True)    # nobody commits a trajectory that crosses what somebody else may keep flying
+        self.be.set_line_cull(4.0)             # presolve: far separating lines are verified, not solved for (same optimum)
         self.fe = scene.frontend_cfg(par, beam_width=beam_width, pad_hold=1)
         self.dc, self.T = par.dc, par.T_span
         self.k_a = delta_t_states - 1          # index of point A in the plan (neptune.cpp:1376-1385 with deltaT_ states ahead)

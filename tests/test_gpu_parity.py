@@ -522,6 +522,35 @@ def test_sharded_hull_blocks_equal_the_single_rank_replan(be, world, entangle):
     full.close()
 
 
+@pytest.mark.parametrize("n_agents,n_static,seed,radius", [(8, 10, 3, 3.0), (16, 8, 4, 1.0), (64, 20, 1, 4.0), (64, 20, 2, 0.3)])
+def test_line_presolve_leaves_the_optimum_unchanged(be, oracle, n_agents, n_static, seed, radius):
+    """nep_batch_set_line_cull: separating lines far from the guess are left out of the QP and verified afterwards
+    (re-solve with all lines on a violation) — same statuses and the same trajectories as the full problem, fewer rows."""
+    sc = scene.make_scene(n_agents, n_static, seed=seed)
+    p = sc["par"]; N = p.num_agents
+    bb = be.BatchBackend(p, sc["statics"])
+    d_com = bb.to_device(sc["committed"]); d_gue = bb.to_device(sc["guesses"])
+    bb.replan(d_com, d_gue)
+    full = bb.solutions()
+    bb.set_line_cull(radius)
+    bb.replan(d_com, d_gue)
+    cut = bb.solutions()
+    np.testing.assert_array_equal(cut["stats"]["status"], full["stats"]["status"])
+    np.testing.assert_array_equal(cut["stats"]["n_lines"], full["stats"]["n_lines"])      # still every line is counted
+    np.testing.assert_array_equal(cut["stats"]["n_lp"], full["stats"]["n_lp"])
+    assert (cut["stats"]["n_rows"] <= full["stats"]["n_rows"]).all()
+    if n_agents >= 16:
+        assert cut["stats"]["n_rows"].sum() < 0.6 * full["stats"]["n_rows"].sum()
+    ok = full["stats"]["status"] != abi.NEP_FAILED
+    assert np.abs(np.array(cut["coeff"])[ok] - np.array(full["coeff"])[ok]).max() <= 1e-7
+    for a in range(0, N, max(1, N // 8)):                                                # and against the oracle
+        r = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"])
+        K = int(cut[a]["K"])
+        assert int(cut[a]["stats"]["status"]) == r["status"]
+        assert np.abs(np.array(cut[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= COEF_TOL
+    bb.close()
+
+
 def test_gjk_batch_matches_the_oracle(be, oracle):
     """gjk::collision on the device (safety check, front end) against the restatement: identical verdicts
     on control polygons scattered around real interval hulls and inflated statics."""
