@@ -28,12 +28,18 @@
 
 #include "nep_device.h"
 
+
 namespace nep {
 
 constexpr int BS = 256;
 constexpr int SBS = 9;            // LDS row stride of the base-row table B (8 used; odd -> lanes on consecutive rows hit distinct banks)
 constexpr int MS = 25;            // LDS row stride of the normal matrix (n <= 24; odd -> no bank conflicts)
 constexpr int kMaxIt = 60;
+// offsets (doubles) inside QpTable's tail Gi, ep, ev, ea, up, uv, ua, Nt, Pp, res_u
+constexpr int tGi = 0, tUp = 48, tUv = 51, tUa = 54, tNt = 57, tPp = 121, tResU = 145, kSmallTab = 151;
+static_assert(offsetof(QpTable, up) - offsetof(QpTable, Gi) == tUp * 8 && offsetof(QpTable, Nt) - offsetof(QpTable, Gi) == tNt * 8 &&
+              offsetof(QpTable, Pp) - offsetof(QpTable, Gi) == tPp * 8 && offsetof(QpTable, res_u) - offsetof(QpTable, Gi) == tResU * 8 &&
+              sizeof(QpTable) - offsetof(QpTable, Gi) == kSmallTab * 8, "QpTable tail layout");
 
 // ---- LDS carve (in doubles) -------------------------------------------------------------------
 constexpr int oB = 0;                       // [64][8]
@@ -61,7 +67,7 @@ constexpr int oRed = oScal + 32;            // [3][16] reduction scratch (one sl
 constexpr int oFixedEnd = oRed + 48;
 constexpr int kFixedDoubles = (oFixedEnd + 1) & ~1;
 
-enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu };
+enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2 };
 
 size_t qp_lds_fixed_bytes() { return (size_t)kFixedDoubles * sizeof(double) + 64 * sizeof(int); }
 
@@ -255,20 +261,39 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 
   // ---- stage the guess ------------------------------------------------------------------------
   if (tid < 96) sCoef[tid] = (&g->coeff[0][0][0])[tid];
+  // base rows >= R are never written: start them (and every accumulator) from zero rather than from stale LDS
+  for (int e = tid; e < kMaxR * 6; e += BS) sTc[e] = 0.0;
+  sDc[tid] = 0.0; sAccL[tid] = 0.0;
   // Presolved-away ("far") lines sit at the back of the buckets (separator_kernel); the first attempt solves with the
   // near lines only and checks the far ones against its solution; a violated one means all lines are solved for.
   const bool culled = CULL;
   int status = NEP_FAILED, iters_total = 0, iters_first = 0, L_used = 0, L_all = 0;
   double objective = 0.0;
   bool has_qc = false, z_override = false;
+  // phase cycle counters: compiled in only with -DNEP_PROFILE_PHASES (they hold 26 VGPRs otherwise)
+#ifdef NEP_PROFILE_PHASES
+  long long tph[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; long long tlast = 0;
+  const bool prof = ps.dbg != nullptr;
+  const long long tstart = prof ? clock64() : 0;
+#define TICK(k) do { if (prof) { const long long t_ = clock64(); tph[k] += t_ - tlast; tlast = t_; } } while (0)
+  long long tset[3] = {0, 0, 0}; long long tmark = tstart;
+#define SETUP_TICK(k) do { if (prof) { const long long t_ = clock64(); tset[k] += t_ - tmark; tmark = t_; } } while (0)
+#else
+#define TICK(k) do { } while (0)
+#define SETUP_TICK(k) do { } while (0)
+#endif
   auto solve_once = [&](const bool use_far) -> bool {   // returns true when the far lines must be added
+  __syncthreads();
+  if (tid < NEP_MAX_POL) {   // one load per lane instead of a serial chain of global round trips
+    sI[44 + tid] = (tid < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + tid] : 0;
+    sI[32 + tid] = (tid < K && culled) ? ps.line_far[(long)slot * NEP_MAX_POL + tid] : 0;
+  }
   __syncthreads();
   if (tid == 0) {
     int o = 0, nf = 0, all = 0;
     for (int i = 0; i < NEP_MAX_POL; i++) {
-      const int cn = (i < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + i] : 0;
-      const int cf = (i < K && culled) ? ps.line_far[(long)slot * NEP_MAX_POL + i] : 0;
-      sI[i] = o; sI[32 + i] = cf; sI[44 + i] = cn;
+      const int cn = sI[44 + i], cf = sI[32 + i];
+      sI[i] = o; sI[52 + i] = nf;
       o += cn + (use_far ? cf : 0); nf += cf; all += cn + cf;
     }
     sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0;
@@ -312,14 +337,6 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   // box row state: [0] upper (alpha=+e), [1] lower (alpha=-e)
   double bs0 = 1, bl0 = 0, bs1 = 1, bl1 = 0;
 
-  // phase cycle counters: compiled in only with -DNEP_PROFILE_PHASES (they hold 26 VGPRs otherwise)
-#ifdef NEP_PROFILE_PHASES
-  long long tph[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; long long tlast = 0;
-  const bool prof = ps.dbg != nullptr;
-#define TICK(k) do { if (prof) { const long long t_ = clock64(); tph[k] += t_ - tlast; tlast = t_; } } while (0)
-#else
-#define TICK(k) do { } while (0)
-#endif
   status = NEP_FAILED; iters_total = 0; iters_first = 0; objective = 0.0;
 
   auto run = [&](auto lds_tag) {
@@ -330,13 +347,16 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   // c: 0 s, 1 lambda; k: control point of the segment
   auto STr = [&](int l, int k, int c) -> double { if constexpr (LDSL) return ldyn[(3 + c * 4 + k) * LL + l]; else return gsp[(3 + c * 4 + k) * GL + l]; };
   auto STw = [&](int l, int k, int c, double v) { if constexpr (LDSL) ldyn[(3 + c * 4 + k) * LL + l] = v; else gsp[(3 + c * 4 + k) * GL + l] = v; };
-  for (int i = 0; i < K; i++) {  // gather the separator's buckets into one segment-major list
-    const int beg = sI[i], cnt = sI[i + 1] - beg, cn = sI[44 + i];
+  // gather the separator's buckets into one segment-major list (one flat loop: a loop per segment costs a global
+  // round trip each)
+  for (int e = tid; e < L; e += BS) {
+    int i = 0;
+#pragma unroll
+    for (int j = 1; j < NEP_MAX_POL; j++) i += (e >= sI[j]) ? 1 : 0;
+    const int l = e - sI[i], cn = sI[44 + i];
     const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
-    for (int l = tid; l < cnt; l += BS) {
-      const long e = l < cn ? l : (long)sp.lines_cap - 1 - (l - cn);      // near lines from the front, far ones from the back
-      LNw(beg + l, 0, src[3 * e]); LNw(beg + l, 1, src[3 * e + 1]); LNw(beg + l, 2, 1.0 - src[3 * e + 2]);
-    }
+    const long q = l < cn ? l : (long)sp.lines_cap - 1 - (l - cn);      // near lines from the front, far ones from the back
+    LNw(e, 0, src[3 * q]); LNw(e, 1, src[3 * q + 1]); LNw(e, 2, 1.0 - src[3 * q + 2]);
   }
   const int LD = (LDSL ? LL : GL) - 1;   // dummy line: harmless operands for the padded tail of a row group
   if (tid < 4) { STw(LD, tid, 0, 1.0); STw(LD, tid, 1, 1.0); if (tid == 0) { LNw(LD, 0, 0.0); LNw(LD, 1, 0.0); LNw(LD, 2, 1.0); } }
@@ -356,14 +376,27 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       for (int u = 0; u < 4; u++) body(v[u], l[u], n1[u], n2[u], h[u], s[u], lam[u]);
     }
   };
+  SETUP_TICK(0);
   for (int mode = 0; mode < 2; mode++) {
+#ifdef NEP_PROFILE_PHASES
+    if (prof) tmark = clock64();
+#endif
     const QpTable* __restrict__ tb = tables + mode * (kMaxK + 1) + K;
-    const int nz = tb->nz, n = 3 * nz;
+    const int nz = mode == 1 ? K : (K > 2 ? K - 2 : 0), n = 3 * nz;   // = tb->nz (nep_tables.h), without the round trip
     __syncthreads();
     for (int e = tid; e < kMaxR * kNZ; e += BS) sB[(e / kNZ) * SBS + (e % kNZ)] = (&tb->B[0][0])[e];
     if (tid < 64) sHax[tid] = (&tb->Hax[0][0])[tid];
     if (tid < 8) sEp[tid] = tb->ep[tid];
+    // Gi .. res_u are contiguous in QpTable: one coalesced copy into the normal matrix's space (free until the first
+    // assembly) instead of dependent global loads inside the start-point loops
+    if (tid < kSmallTab) sM[tid] = (&tb->Gi[0][0])[tid];
     if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
+    __syncthreads();
+    const double* tGiP = sM + tGi; const double* tUpP = sM + tUp; const double* tUvP = sM + tUv; const double* tUaP = sM + tUa;
+    const double* tNtP = sM + tNt; const double* tPpP = sM + tPp; const double* tResP = sM + tResU;
+    // a_r of the least-squares point per axis (sRhs is free here) and the init part of the end-position error
+    if (tid < 24) { const int ax = tid >> 3, r = tid & 7; sRhs[tid] = tPpP[r * 3] * sInit[ax * 3] + tPpP[r * 3 + 1] * sInit[ax * 3 + 1] + tPpP[r * 3 + 2] * sInit[ax * 3 + 2]; }
+    else if (tid >= 32 && tid < 35) { const int ax = tid - 32; sc[sPe0 + ax] = tUpP[0] * sInit[ax * 3] + tUpP[1] * sInit[ax * 3 + 1] + tUpP[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; }
     __syncthreads();
     // Normal-matrix entries owned by this thread, decoded once per mode.  Only the blocks that can be
     // non-zero are summed — xx, yx, yy, zz — each entry by a pair of adjacent lanes (even / odd base
@@ -388,6 +421,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     }
     bool converged = false;
     int it = 0;
+    SETUP_TICK(1);
     if (nz == 0) {
       // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
       double viol = 0.0, d0 = 0, d1 = 0, d2 = 0;
@@ -395,11 +429,11 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       { const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; for_lines4([&](bool v, int, double n1, double n2, double h, double, double) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
       if (tid < 6) {  // terminal v = a = 0 must hold at the least-squares point
         const int ax = tid / 2, e = tid % 2;
-        viol = fmax(viol, fabs(tb->res_u[e][0] * sInit[ax * 3] + tb->res_u[e][1] * sInit[ax * 3 + 1] + tb->res_u[e][2] * sInit[ax * 3 + 2]));
+        viol = fmax(viol, fabs(tResP[e * 3] * sInit[ax * 3] + tResP[e * 3 + 1] * sInit[ax * 3 + 1] + tResP[e * 3 + 2] * sInit[ax * 3 + 2]));
       }
       if (tid == 0 && has_qc) {
         double c = -0.10 * 0.10;
-        for (int ax = 0; ax < 3; ax++) { const double pe = tb->up[0] * sInit[ax * 3] + tb->up[1] * sInit[ax * 3 + 1] + tb->up[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; c += pe * pe; }
+        for (int ax = 0; ax < 3; ax++) { const double pe = sc[sPe0 + ax]; c += pe * pe; }
         viol = fmax(viol, c);
       }
       block_reduce4(viol, d0, d1, d2, sRed);
@@ -407,8 +441,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       if (tid == 0) {
         double o = 0;
         for (int ax = 0; ax < 3; ax++) {
-          for (int r = 0; r < K; r++) { const double a = tb->Pp[r][0] * sInit[ax * 3] + tb->Pp[r][1] * sInit[ax * 3 + 1] + tb->Pp[r][2] * sInit[ax * 3 + 2]; o += 36 * T * a * a; }
-          const double pe = tb->up[0] * sInit[ax * 3] + tb->up[1] * sInit[ax * 3 + 1] + tb->up[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax];
+          for (int r = 0; r < K; r++) { const double a = sRhs[ax * 8 + r]; o += 36 * T * a * a; }
+          const double pe = sc[sPe0 + ax];
           o += wgt * pe * pe;
         }
         sc[sObj] = o;
@@ -418,22 +452,19 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       if (tid < n) {
         const int ax = tid / nz, c = tid % nz;
         double z = 0;
-        for (int r = 0; r < K; r++) {
-          const double ap = tb->Pp[r][0] * sInit[ax * 3] + tb->Pp[r][1] * sInit[ax * 3 + 1] + tb->Pp[r][2] * sInit[ax * 3 + 2];
-          z += tb->Nt[c][r] * (sCoef[(ax * 8 + r) * 4] - ap);
-        }
+        for (int r = 0; r < K; r++) z += tNtP[c * kMaxK + r] * (sCoef[(ax * 8 + r) * 4] - sRhs[ax * 8 + r]);
         sZ[tid] = z;
-        sG[tid] = (tb->Gi[c][0] * sInit[ax * 3] + tb->Gi[c][1] * sInit[ax * 3 + 1] + tb->Gi[c][2] * sInit[ax * 3 + 2]) - 2 * wgt * sEp[c] * sc[sFinal0 + ax];
+        sG[tid] = (tGiP[c * 3] * sInit[ax * 3] + tGiP[c * 3 + 1] * sInit[ax * 3 + 1] + tGiP[c * 3 + 2] * sInit[ax * 3 + 2]) - 2 * wgt * sEp[c] * sc[sFinal0 + ax];
       }
       if (tid == 0) {
         double o = 0;
         for (int ax = 0; ax < 3; ax++) {
-          for (int r = 0; r < K; r++) { const double a = tb->Pp[r][0] * sInit[ax * 3] + tb->Pp[r][1] * sInit[ax * 3 + 1] + tb->Pp[r][2] * sInit[ax * 3 + 2]; o += 36 * T * a * a; }
-          const double pe = tb->up[0] * sInit[ax * 3] + tb->up[1] * sInit[ax * 3 + 1] + tb->up[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax];
+          for (int r = 0; r < K; r++) { const double a = sRhs[ax * 8 + r]; o += 36 * T * a * a; }
+          const double pe = sc[sPe0 + ax];
           o += wgt * pe * pe;
           if (mode == 1) {
-            const double ve = tb->uv[0] * sInit[ax * 3] + tb->uv[1] * sInit[ax * 3 + 1] + tb->uv[2] * sInit[ax * 3 + 2];
-            const double ae = tb->ua[0] * sInit[ax * 3] + tb->ua[1] * sInit[ax * 3 + 1] + tb->ua[2] * sInit[ax * 3 + 2];
+            const double ve = tUvP[0] * sInit[ax * 3] + tUvP[1] * sInit[ax * 3 + 1] + tUvP[2] * sInit[ax * 3 + 2];
+            const double ae = tUaP[0] * sInit[ax * 3] + tUaP[1] * sInit[ax * 3 + 1] + tUaP[2] * sInit[ax * 3 + 2];
             o += wgt * (ve * ve + ae * ae);
           }
         }
@@ -443,7 +474,12 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       }
       __syncthreads();
       // each thread keeps the values of its own base rows (and their step projections) in registers
-      auto proj = [&](int rho, int ax, const double* vec) { double v = 0; for (int c = 0; c < nz; c++) v = __builtin_fma(sB[rho * SBS + c], vec[ax * nz + c], v); return v; };
+      auto proj = [&](int rho, int ax, const double* vec) {   // fixed trip (loads in flight together); B's columns >= nz are zero
+        double v = 0;
+#pragma unroll
+        for (int c = 0; c < kNZ; c++) v = __builtin_fma(sB[rho * SBS + c], vec[ax * nz + (c < nz ? c : nz - 1)], v);
+        return v;
+      };
       double cpb = has_box ? sOff[brho * 3 + bax] + proj(brho, bax, sZ) : 0.0, uab = 0.0, udb = 0.0;
       double cpx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sZ) : 0.0, cpy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sZ) : 0.0;
       double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
@@ -465,7 +501,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         sc[sQscale] = qs;
         if (has_qc) {
           double c = -0.10 * 0.10;
-          for (int ax = 0; ax < 3; ax++) { double pe = tb->up[0] * sInit[ax * 3] + tb->up[1] * sInit[ax * 3 + 1] + tb->up[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; for (int e = 0; e < nz; e++) pe += sEp[e] * sZ[ax * nz + e]; c += pe * pe; }
+          for (int ax = 0; ax < 3; ax++) { double pe = sc[sPe0 + ax]; for (int e = 0; e < nz; e++) pe += sEp[e] * sZ[ax * nz + e]; c += pe * pe; }
           const double sq = (-c > 1e-3) ? -c : 1e-3;
           sc[sSq] = sq; sc[sLq] = 1.0 / sq;
         } else { sc[sSq] = 1.0; sc[sLq] = 0.0; }
@@ -479,6 +515,10 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       double* redA = sRed; double* redP2 = sRed + 16; double* redP5 = sRed + 32;
       const int n0 = has_qc ? n : 2 * nz;                       // wave 0 factors this block, wave 1 the z block
       const unsigned zoff_m = lds0 + (oM + 2 * nz * MS + 2 * nz) * 8, zoff_d = lds0 + (oInvD + 2 * nz) * 8;
+      SETUP_TICK(2);
+#ifdef NEP_PROFILE_PHASES
+      if (prof) tph[10] -= clock64();     // [10]: cycles inside the iteration loops
+#endif
       for (it = 0; it < kMaxIt; it++) {
 #ifdef NEP_PROFILE_PHASES
         if (prof) tlast = clock64();
@@ -534,7 +574,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
             sc[sSq] += alpha_prev * sc[sDsq]; sc[sLq] += alpha_prev * sc[sDlq];
             double c = -0.10 * 0.10;
             for (int ax = 0; ax < 3; ax++) {
-              double pe = tb->up[0] * sInit[ax * 3] + tb->up[1] * sInit[ax * 3 + 1] + tb->up[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax];
+              double pe = sc[sPe0 + ax];
               for (int e = 0; e < nz; e++) pe += sEp[e] * sZ[ax * nz + e];
               c += pe * pe;
               for (int e = 0; e < nz; e++) sGq[ax * nz + e] = 2 * pe * sEp[e];
@@ -557,7 +597,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           v = slice_sum(v); t1 = slice_sum(t1);
           if (sl8 == 0) {
             double hz = 0;
-            for (int e = 0; e < nz; e++) hz += sHax[c * kNZ + e] * sZ[ax * nz + e];
+#pragma unroll
+            for (int e = 0; e < kNZ; e++) hz += sHax[c * kNZ + e] * sZ[ax * nz + (e < nz ? e : nz - 1)];   // Hax's columns >= nz are zero
             const double zo = sZ[o], go = sG[o];
             v += go + hz;
             if (has_qc) v += sc[sLq] * sGq[o];
@@ -570,10 +611,14 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           const int ci = me_ci[u], cj = me_cj[u], sel = me_sel[u], half = tid & 1;
           double a0 = 0.0, a1 = 0.0;
           if (me_on[u]) {
-            const int rl = sel == 1 ? 4 * K : R;       // multiples of 4
-            for (int rho = half; rho < rl; rho += 4) {
-              a0 = __builtin_fma(sDc[rho * 4 + sel] * sB[rho * SBS + ci], sB[rho * SBS + cj], a0);
-              a1 = __builtin_fma(sDc[(rho + 2) * 4 + sel] * sB[(rho + 2) * SBS + ci], sB[(rho + 2) * SBS + cj], a1);
+            // (Dxy is zero on the rows >= 4K, so every block can run over all R rows: uniform trip count)
+            for (int q = 0; q < K; q++) {
+              const int rho = half + 8 * q;
+              double d[4], bi[4], bj[4];
+#pragma unroll
+              for (int w = 0; w < 4; w++) { d[w] = sDc[(rho + 2 * w) * 4 + sel]; bi[w] = sB[(rho + 2 * w) * SBS + ci]; bj[w] = sB[(rho + 2 * w) * SBS + cj]; }
+              a0 = __builtin_fma(d[0] * bi[0], bj[0], a0); a1 = __builtin_fma(d[1] * bi[1], bj[1], a1);
+              a0 = __builtin_fma(d[2] * bi[2], bj[2], a0); a1 = __builtin_fma(d[3] * bi[3], bj[3], a1);
             }
           }
           double v = a0 + a1;
@@ -687,9 +732,14 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         if (tid < 8 * n) {
           const int o = tid >> 3, sl8 = tid & 7, ax = o / nz, c = o % nz;
           double t1 = 0;
-          for (int rho = sl8; rho < R; rho += 8) {
+          for (int q = 0; q < K; q++) {
+            const int rho = sl8 + 8 * q;
             double ta = sTc[rho * 6 + 3 + ax], tb2 = sTc[rho * 6 + ax];
-            if (ax < 2 && rho < 4 * K) { ta += sAccL[rho * 8 + 5 + ax]; tb2 += sAccL[rho * 8 + ax]; }
+            if (q < 4) {   // position rows rho < 32 (those >= 4K carry zero line sums: sAccL rows are zeroed / never written)
+              const double la = sAccL[rho * 8 + 5 + (ax & 1)], lb = sAccL[rho * 8 + (ax & 1)];
+              const bool on = ax < 2 && rho < 4 * K;
+              ta += on ? la : 0.0; tb2 += on ? lb : 0.0;
+            }
             t1 += sB[rho * SBS + c] * __builtin_fma(-sm, tb2, ta);
           }
           t1 = slice_sum(t1);
@@ -743,6 +793,9 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         }
         TICK(9);
       }
+#ifdef NEP_PROFILE_PHASES
+      if (prof) tph[10] += clock64();
+#endif
       if (!converged && sI[16]) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
     }
     iters_total = it; if (mode == 0) iters_first = it;
@@ -753,7 +806,11 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       if (tid < 12 * K) {  // theta = Th z + ThU init
         const int ax = tid / (4 * K), r = tid % (4 * K);
         double v = tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2];
-        for (int c = 0; c < nz; c++) v += tb->Th[r][c] * sZ[ax * nz + c];
+        double th[kNZ];
+#pragma unroll
+        for (int c = 0; c < kNZ; c++) th[c] = tb->Th[r][c];   // all loads in flight at once (columns >= nz are zero)
+#pragma unroll
+        for (int c = 0; c < kNZ; c++) v += c < nz ? th[c] * sZ[ax * nz + c] : 0.0;
         sTheta[(ax * 8 + r / 4) * 4 + (r % 4)] = v;
       }
       break;
@@ -775,15 +832,16 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     }
     __syncthreads();
     bool viol = false;
-    for (int i = 0; i < K; i++) {
-      const int cf = sI[32 + i];
-      const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
-      for (int l = tid; l < cf; l += BS) {
-        const long e = (long)sp.lines_cap - 1 - l;
-        const double n1 = src[3 * e], n2 = src[3 * e + 1], dd = src[3 * e + 2];
+    const int F = sI[41];
+    for (int e = tid; e < F; e += BS) {
+      int i = 0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) viol = viol || (n1 * sAccL[(4 * i + k) * 2] + n2 * sAccL[(4 * i + k) * 2 + 1] + dd - 1.0 > 0.0);
-      }
+      for (int j = 1; j < NEP_MAX_POL; j++) i += (e >= sI[52 + j]) ? 1 : 0;
+      const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
+      const long q = (long)sp.lines_cap - 1 - (e - sI[52 + i]);
+      const double n1 = src[3 * q], n2 = src[3 * q + 1], dd = src[3 * q + 2];
+#pragma unroll
+      for (int k = 0; k < 4; k++) viol = viol || (n1 * sAccL[(4 * i + k) * 2] + n2 * sAccL[(4 * i + k) * 2 + 1] + dd - 1.0 > 0.0);
     }
     if (viol) sI[21] = 1;
     __syncthreads();
@@ -823,7 +881,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     }
   }
 #ifdef NEP_PROFILE_PHASES
-  if (prof && tid == 0) { for (int k = 0; k < 12; k++) ps.dbg[(long)slot * 16 + k] = tph[k]; ps.dbg[(long)slot * 16 + 12] = iters_total; }
+  if (prof) tph[11] = clock64() - tstart;   // [11]: workgroup lifetime up to here
+  if (prof && tid == 0) { for (int k = 0; k < 12; k++) ps.dbg[(long)slot * 16 + k] = tph[k]; ps.dbg[(long)slot * 16 + 12] = iters_total; for (int k = 0; k < 3; k++) ps.dbg[(long)slot * 16 + 13 + k] = tset[k]; }
 #endif
   if (ps.commit) {  // the record the agent would publish (neptune_ros.cpp:434-480)
     nep_traj_rec* cr = ps.commit + slot;
