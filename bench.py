@@ -363,6 +363,10 @@ def main():
                        "params": "reference neptune_mtlp_benchmark.yaml (T_span 0.5, num_pol 8, weight 1000, v 2, a 3)"},
             "solver": {"status_ok": int((status == 0).sum()), "status_relaxed": int((status == 1).sum()),
                        "status_failed": int((status == 2).sum()), "ipm_iters_mean": float(iters.mean()),
+                       "ipm_iters_quantiles": {"p50": float(np.percentile(iters, 50)), "p90": float(np.percentile(iters, 90)),
+                                               "p99": float(np.percentile(iters, 99)), "max": int(iters.max())},
+                       "ipm_iters_mean_by_status": {name: (float(iters[status == k].mean()) if (status == k).any() else None)
+                                                    for k, name in ((0, "ok"), (1, "relaxed"), (2, "failed"))},
                        "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum()),
                        "rows_solved_mean": float(sol["stats"]["n_rows"].mean()), "line_cull_radius": args.cull_radius},
             "p50_solve_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),

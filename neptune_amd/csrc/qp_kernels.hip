@@ -471,6 +471,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         sc[sObj0] = o;
         sI[16] = 0;  // loose snapshot present
         sI[17] = 0;  // stall counter
+        sI[22] = -1; // iteration of the first loose hit
       }
       __syncthreads();
       // each thread keeps the values of its own base rows (and their step projections) in registers
@@ -645,7 +646,19 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
           if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
           if (sI[17] >= 3) flag = 3;                           // stalled
+          // Three more iterations after the first loose hit would have reached the strict tolerances if rounding allowed it:
+          // with mu this small the weights lambda/s amplify the rounding of the row activities into the dual residual
+          // (observed floor ~1e-8 |g|), and the iteration would otherwise idle up to kMaxIt.  The current point satisfies
+          // the loose tolerances: take it.
+          if (flag == 2) { if (sI[22] < 0) { if (tid == 0) sI[22] = it; } else if (it - sI[22] >= 3) flag = 1; }
           if (tid == 0) { sc[sObj] = o; if (flag == 2) sc[sObjLoose] = o; sI[18] = flag; }
+#ifdef NEP_QP_ITERDBG
+          if (tid == 0 && ps.dbg && slot == NEP_QP_ITERDBG && it < 60) {   // development aid: convergence history of one slot
+            long long* d = ps.dbg + 16 + it * 8;
+            d[0] = __double_as_longlong(nr); d[1] = __double_as_longlong(nrd); d[2] = __double_as_longlong(qs); d[3] = __double_as_longlong(gap);
+            d[4] = __double_as_longlong(o); d[5] = flag; d[6] = __double_as_longlong(alpha_prev); d[7] = __double_as_longlong(sm_prev);
+          }
+#endif
           TICK(3);
           if (flag != 1 && flag != 3) {                        // (uniform across the wave)
             const bool chol_ok = chol_wave(lds0 + oM * 8, lds0 + oInvD * 8, n0);
@@ -882,7 +895,9 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   }
 #ifdef NEP_PROFILE_PHASES
   if (prof) tph[11] = clock64() - tstart;   // [11]: workgroup lifetime up to here
+#ifndef NEP_QP_ITERDBG
   if (prof && tid == 0) { for (int k = 0; k < 12; k++) ps.dbg[(long)slot * 16 + k] = tph[k]; ps.dbg[(long)slot * 16 + 12] = iters_total; for (int k = 0; k < 3; k++) ps.dbg[(long)slot * 16 + 13 + k] = tset[k]; }
+#endif
 #endif
   if (ps.commit) {  // the record the agent would publish (neptune_ros.cpp:434-480)
     nep_traj_rec* cr = ps.commit + slot;

@@ -14,6 +14,7 @@
 #include "neptune_oracle.h"
 
 #include <math.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -490,7 +491,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   for (int r = 0; r < m; r++) { double a = 0; for (int c = 0; c < ny; c++) a += Gy[(size_t)r * ny + c] * y[c]; double sl = hy[r] - a; s[r] = sl > 1.0 ? sl : 1.0; lam[r] = 1.0 / s[r]; }
   if (qc) { double c; QCY(y, (double*)NULL, c); s[m] = (-c > 1e-3) ? -c : 1e-3; lam[m] = 1.0 / s[m]; }
   double qscale = 1.0; for (int c = 0; c < ny; c++) if (fabs(qy[c]) > qscale) qscale = fabs(qy[c]);
-  int ret = 1, it = 0, loose_ok = 0, stall = 0;
+  int ret = 1, it = 0, loose_ok = 0, stall = 0, first_loose = -1;
   for (it = 0; it < 100; it++) {
     for (int a = 0; a < ny; a++) { double v = qy[a]; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; rd[a] = v; }
     for (int r = 0; r < m; r++) { double a = 0; const double* g = Gy + (size_t)r * ny; for (int c = 0; c < ny; c++) { a += g[c] * y[c]; rd[c] += g[c] * lam[r]; } rp[r] = a + s[r] - hy[r]; }
@@ -502,7 +503,10 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     double obj = obj0; for (int a = 0; a < ny; a++) { double v = 0; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; obj += 0.5 * y[a] * v + qy[a] * y[a]; }
     double gap = mu * mt;
     if (nrp <= 1e-9 && nrd <= 1e-9 * qscale && gap <= 1e-10 * (1.0 + fabs(obj))) { ret = 0; break; }
-    if (nrp <= 1e-6 && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj))) { loose_ok = 1; memcpy(yl, y, sizeof(double) * ny); }
+    if (nrp <= 1e-6 && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj))) { loose_ok = 1; memcpy(yl, y, sizeof(double) * ny);
+      /* three more iterations after the first loose hit reach the strict tolerances unless rounding forbids it (the weights
+         lam/s amplify the rounding of the row activities into rd): stop there with the current, loosely converged point */
+      if (first_loose < 0) first_loose = it; else if (it - first_loose >= 3) { ret = 0; break; } }
     for (int i = 0; i < ny * ny; i++) M[i] = Py[i];
     for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; w[r] = lam[r] / s[r]; for (int a = 0; a < ny; a++) { double wa = w[r] * g[a]; for (int b = 0; b <= a; b++) M[a * ny + b] += wa * g[b]; } }
     for (int a = 0; a < ny; a++) for (int b = a + 1; b < ny; b++) M[a * ny + b] = M[b * ny + a];
@@ -532,6 +536,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       }
     }
     alpha *= 0.999; if (alpha > 1.0) alpha = 1.0;
+    if (getenv("ORC_QP_TRACE")) fprintf(stderr, "it %2d nrp %.3e nrd %.3e (qs %.3e) gap %.3e obj %.9g sigma %.3e alpha %.3e loose %d\n", it, nrp, nrd, qscale, gap, obj, sigma, alpha, loose_ok);
     if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;
     for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];
     for (int r = 0; r < mt; r++) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; }

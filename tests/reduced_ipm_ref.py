@@ -137,7 +137,7 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
         sq = max(-c, 1e-3); lq = 1.0 / sq
     mt = m + (1 if has_qc else 0)
     qscale = max(1.0, np.abs(g).max())
-    loose = None; stall = 0
+    loose = None; stall = 0; first_loose = None
     for it in range(maxit):
         cp = B @ z.T + off
         a = rowvals(cp)
@@ -160,6 +160,10 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
             return True, theta_of(z), obj, it
         if nrp <= 1e-6 and nrd <= 1e-6 * qscale and gap <= 1e-7 * (1 + abs(obj)):
             loose = (z.copy(), obj)
+            if first_loose is None:
+                first_loose = it
+            elif it - first_loose >= 3:       # rounding floor of the dual residual: the loosely converged point is the answer
+                return True, theta_of(z), obj, it
         W = lam / s
         D = np.zeros((R, 3, 3)); np.add.at(D, rho, W[:, None, None] * al[:, :, None] * al[:, None, :])
         n = 3 * nz
