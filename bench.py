@@ -328,6 +328,7 @@ def main():
         presolve = {"value": replans_per_step * args.steps / dt2, "unit": "replans/s", "ms_per_step": dt2 / args.steps * 1e3,
                     "cull_radius_m": args.presolve_radius, "qp_ms": qp2,
                     "rows_solved_mean": float(sol2["stats"]["n_rows"].mean()),
+                    "ipm_iters_mean": float(sol2["stats"]["iters"].mean()), "ipm_iters_max": int(sol2["stats"]["iters"].max()),
                     "status_ok": int((st2 == 0).sum()), "status_relaxed": int((st2 == 1).sum()), "status_failed": int((st2 == 2).sum()),
                     "note": "lines farther than the radius from the guess are parked, checked against the solution and the QP re-solved "
                             "with all of them on a violation: same optimum as the headline run, fewer rows inside the solver"}

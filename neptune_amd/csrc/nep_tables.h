@@ -7,6 +7,7 @@
 // freedom.  Tables below express every quantity the solver needs as an affine map of the reduced
 // variable z (nz = K-2, or K in the relaxed re-solve :838-861) and the initial state.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -47,6 +48,8 @@ struct QpTable {
   double Nt[kNZ][kMaxK];     // z0 = Nt (a_guess - Pp init)
   double Pp[kMaxK][3];
   double res_u[2][3];        // terminal (b_K, c_K) at a = Pp.init: consistency check for K <= 2
+  double Zp[kNZ][4 * kMaxK]; // start point: z0 = Zp (theta_guess - ThU init), the orthogonal projection of the guess's
+                             // coefficients onto the feasible affine set {Th z + ThU init}  (Zp = (Th'Th)^-1 Th')
 };
 
 struct SampleTable {         // generatePwpOut's time walk (solver_gurobi_poly.cpp:911-934)
@@ -156,6 +159,22 @@ inline void build_qp_table(int K, double T, double weight, int mode, QpTable* t)
     for (int r = 0; r < K; r++) { p += ba[2][r] * Pp[r * 3 + u]; v += ba[1][r] * Pp[r * 3 + u]; a += 2 * ba[0][r] * Pp[r * 3 + u]; }
     t->up[u] = p; t->uv[u] = v; t->ua[u] = a;
     t->res_u[0][u] = a / 2; t->res_u[1][u] = v;
+  }
+  if (nz > 0) {  // Zp = (Th'Th)^-1 Th' by Gauss-Jordan with partial pivoting on the nz x nz Gram matrix
+    double G[kNZ][kNZ + 4 * kMaxK];
+    const int nr = 4 * K, w = nz + nr;
+    for (int a = 0; a < nz; a++) {
+      for (int b = 0; b < nz; b++) { double v = 0; for (int r = 0; r < nr; r++) v += t->Th[r][a] * t->Th[r][b]; G[a][b] = v; }
+      for (int r = 0; r < nr; r++) G[a][nz + r] = t->Th[r][a];
+    }
+    for (int c = 0; c < nz; c++) {
+      int piv = c; for (int r = c + 1; r < nz; r++) if (std::fabs(G[r][c]) > std::fabs(G[piv][c])) piv = r;
+      if (piv != c) for (int j = 0; j < w; j++) std::swap(G[c][j], G[piv][j]);
+      const double d = G[c][c];
+      for (int j = 0; j < w; j++) G[c][j] /= d;
+      for (int r = 0; r < nz; r++) if (r != c) { const double f = G[r][c]; if (f != 0.0) for (int j = 0; j < w; j++) G[r][j] -= f * G[c][j]; }
+    }
+    for (int a = 0; a < nz; a++) for (int r = 0; r < nr; r++) t->Zp[a][r] = G[a][nz + r];
   }
   // cost: 36T |a|^2 + w (p_end - f)^2 [+ w v_end^2 + w a_end^2]   (:322-383)
   for (int a = 0; a < nz; a++) {

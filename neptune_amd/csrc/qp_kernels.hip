@@ -35,10 +35,14 @@ constexpr int BS = 256;
 constexpr int SBS = 9;            // LDS row stride of the base-row table B (8 used; odd -> lanes on consecutive rows hit distinct banks)
 constexpr int MS = 25;            // LDS row stride of the normal matrix (n <= 24; odd -> no bank conflicts)
 constexpr int kMaxIt = 60;
-// offsets (doubles) inside QpTable's tail Gi, ep, ev, ea, up, uv, ua, Nt, Pp, res_u
-constexpr int tGi = 0, tUp = 48, tUv = 51, tUa = 54, tNt = 57, tPp = 121, tResU = 145, kSmallTab = 151;
+// start point of the rows: slack = max(h - a.x0, kSlackFloor), lambda = kMu0 / slack.  Chosen on this path's two kinds of
+// guesses (oracle sweep): 1 / 1 needs 11.3 iterations on front-end guesses and 5.8 on near-optimal ones, 0.1 / 2
+// needs 8.6 and 6.1.
+constexpr double kSlackFloor = 0.1, kMu0 = 2.0;
+// offsets (doubles) inside QpTable's tail Gi, ep, ev, ea, up, uv, ua, Nt, Pp, res_u, Zp
+constexpr int tGi = 0, tUp = 48, tUv = 51, tUa = 54, tNt = 57, tPp = 121, tResU = 145, tZp = 151, kSmallTab = 151 + kNZ * 4 * kMaxK;
 static_assert(offsetof(QpTable, up) - offsetof(QpTable, Gi) == tUp * 8 && offsetof(QpTable, Nt) - offsetof(QpTable, Gi) == tNt * 8 &&
-              offsetof(QpTable, Pp) - offsetof(QpTable, Gi) == tPp * 8 && offsetof(QpTable, res_u) - offsetof(QpTable, Gi) == tResU * 8 &&
+              offsetof(QpTable, Pp) - offsetof(QpTable, Gi) == tPp * 8 && offsetof(QpTable, res_u) - offsetof(QpTable, Gi) == tResU * 8 && offsetof(QpTable, Zp) - offsetof(QpTable, Gi) == tZp * 8 &&
               sizeof(QpTable) - offsetof(QpTable, Gi) == kSmallTab * 8, "QpTable tail layout");
 
 // ---- LDS carve (in doubles) -------------------------------------------------------------------
@@ -67,7 +71,7 @@ constexpr int oRed = oScal + 32;            // [3][16] reduction scratch (one sl
 constexpr int oFixedEnd = oRed + 48;
 constexpr int kFixedDoubles = (oFixedEnd + 1) & ~1;
 
-enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2 };
+enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2, sBestMerit };
 
 size_t qp_lds_fixed_bytes() { return (size_t)kFixedDoubles * sizeof(double) + 64 * sizeof(int); }
 
@@ -389,11 +393,13 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     if (tid < 8) sEp[tid] = tb->ep[tid];
     // Gi .. res_u are contiguous in QpTable: one coalesced copy into the normal matrix's space (free until the first
     // assembly) instead of dependent global loads inside the start-point loops
-    if (tid < kSmallTab) sM[tid] = (&tb->Gi[0][0])[tid];
+    for (int e = tid; e < kSmallTab; e += BS) sM[e] = (&tb->Gi[0][0])[e];
+    // guess minus the init part of theta (sTheta is free until the result is written): what the start point projects
+    if (tid < 96) { const int ax = tid >> 5, r = tid & 31; sTheta[tid] = r < 4 * K ? sCoef[tid] - (tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2]) : 0.0; }
     if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
     __syncthreads();
     const double* tGiP = sM + tGi; const double* tUpP = sM + tUp; const double* tUvP = sM + tUv; const double* tUaP = sM + tUa;
-    const double* tNtP = sM + tNt; const double* tPpP = sM + tPp; const double* tResP = sM + tResU;
+    const double* tZpP = sM + tZp; const double* tPpP = sM + tPp; const double* tResP = sM + tResU;
     // a_r of the least-squares point per axis (sRhs is free here) and the init part of the end-position error
     if (tid < 24) { const int ax = tid >> 3, r = tid & 7; sRhs[tid] = tPpP[r * 3] * sInit[ax * 3] + tPpP[r * 3 + 1] * sInit[ax * 3 + 1] + tPpP[r * 3 + 2] * sInit[ax * 3 + 2]; }
     else if (tid >= 32 && tid < 35) { const int ax = tid - 32; sc[sPe0 + ax] = tUpP[0] * sInit[ax * 3] + tUpP[1] * sInit[ax * 3 + 1] + tUpP[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; }
@@ -452,7 +458,9 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       if (tid < n) {
         const int ax = tid / nz, c = tid % nz;
         double z = 0;
-        for (int r = 0; r < K; r++) z += tNtP[c * kMaxK + r] * (sCoef[(ax * 8 + r) * 4] - sRhs[ax * 8 + r]);
+        // orthogonal projection of the guess's coefficients onto {Th z + ThU init} (rows >= 4K of Zp and of the difference are zero)
+#pragma unroll 8
+        for (int r = 0; r < 4 * kMaxK; r++) z = __builtin_fma(tZpP[c * 4 * kMaxK + r], sTheta[ax * 32 + r], z);
         sZ[tid] = z;
         sG[tid] = (tGiP[c * 3] * sInit[ax * 3] + tGiP[c * 3 + 1] * sInit[ax * 3 + 1] + tGiP[c * 3 + 2] * sInit[ax * 3 + 2]) - 2 * wgt * sEp[c] * sc[sFinal0 + ax];
       }
@@ -486,15 +494,15 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
       if (has_box) {
         const double a = cpb;
-        double sl = bhi - a; bs0 = sl > 1.0 ? sl : 1.0; bl0 = 1.0 / bs0;
-        sl = a - blo; bs1 = sl > 1.0 ? sl : 1.0; bl1 = 1.0 / bs1;
+        double sl = bhi - a; bs0 = sl > kSlackFloor ? sl : kSlackFloor; bl0 = kMu0 / bs0;
+        sl = a - blo; bs1 = sl > kSlackFloor ? sl : kSlackFloor; bl1 = kMu0 / bs1;
       }
       {
         const double cx = cpx, cy = cpy;
         for_lines4([&](bool, int l, double n1, double n2, double h, double, double) {
           const double sl = h - (n1 * cx + n2 * cy);
-          const double s = sl > 1.0 ? sl : 1.0;
-          STw(l, lk, 0, s); STw(l, lk, 1, 1.0 / s);
+          const double s = sl > kSlackFloor ? sl : kSlackFloor;
+          STw(l, lk, 0, s); STw(l, lk, 1, kMu0 / s);
         });
       }
       if (tid == 0) {
@@ -646,14 +654,21 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
           if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
           if (sI[17] >= 3) flag = 3;                           // stalled
-          // Three more iterations after the first loose hit would have reached the strict tolerances if rounding allowed it:
-          // with mu this small the weights lambda/s amplify the rounding of the row activities into the dual residual
-          // (observed floor ~1e-8 |g|), and the iteration would otherwise idle up to kMaxIt.  The current point satisfies
-          // the loose tolerances: take it.
-          if (flag == 2) { if (sI[22] < 0) { if (tid == 0) sI[22] = it; } else if (it - sI[22] >= 3) flag = 1; }
+          // Loosely converged iterates: keep the one closest to the strict tolerances (merit <= 1 is the strict test), and
+          // stop three iterations after the first of them.  With mu that small the weights lambda/s amplify the rounding
+          // of the row activities into the dual residual (floor ~1e-8 |g|): an iteration that has not passed the strict
+          // test by then never will, and would idle to kMaxIt while its iterates get noisier.
+          if (flag == 2 || (flag == 0 && sI[22] >= 0)) {
+            const double merit = fmax(fmax(nr * 1e9, nrd / qs * 1e9), gap / (1.0 + fabs(o)) * 1e10);
+            const bool better = flag == 2 && (!sI[16] || merit < sc[sBestMerit]);
+            const bool last = sI[22] >= 0 && it - sI[22] >= 3;
+            if (sI[22] < 0 && tid == 0) sI[22] = it;
+            flag = last ? (better ? 1 : 3) : (better ? 2 : 0);      // 3: leave the loop, the snapshot is the answer
+            if (tid == 0 && flag == 2) sc[sBestMerit] = merit;
+          }
           if (tid == 0) { sc[sObj] = o; if (flag == 2) sc[sObjLoose] = o; sI[18] = flag; }
 #ifdef NEP_QP_ITERDBG
-          if (tid == 0 && ps.dbg && slot == NEP_QP_ITERDBG && it < 60) {   // development aid: convergence history of one slot
+          if (tid == 0 && ps.dbg && slot == NEP_QP_ITERDBG && it < 60 && mode == 0) {   // development aid: convergence history of one slot
             long long* d = ps.dbg + 16 + it * 8;
             d[0] = __double_as_longlong(nr); d[1] = __double_as_longlong(nrd); d[2] = __double_as_longlong(qs); d[3] = __double_as_longlong(gap);
             d[4] = __double_as_longlong(o); d[5] = flag; d[6] = __double_as_longlong(alpha_prev); d[7] = __double_as_longlong(sm_prev);
@@ -686,8 +701,13 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         const int flag = sI[18];
         if (flag == 1) { converged = true; break; }
         if (flag == 3) break;
-        if (!sI[19] || !sI[20]) break;
+        // (the snapshot comes before the factorisation's verdict: a pivot lost to rounding this late must not cost the loosely
+        // converged iterate — the oracle keeps it the same way)
         if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
+#ifdef NEP_QP_ITERDBG
+        if ((!sI[19] || !sI[20]) && tid == 0 && ps.dbg && slot == NEP_QP_ITERDBG && mode == 0 && it < 59) ps.dbg[16 + (it + 1) * 8 + 5] = 100 + sI[19] * 10 + sI[20];
+#endif
+        if (!sI[19] || !sI[20]) break;
         if (has_box) uab = proj(brho, bax, sDxa);
         if (has_line) { uax = proj(lrho, 0, sDxa); uay = proj(lrho, 1, sDxa); }
         TICK(5);
@@ -861,7 +881,10 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     return sI[21] != 0;
   }
   };   // solve_once
-  if (solve_once(false)) { if constexpr (CULL) solve_once(true); }
+  // (one call site: a second inlined copy of the solver body pushes the compiler past its unrolling budget and the
+  // row groups' private arrays into scratch)
+#pragma nounroll
+  for (int attempt = 0; attempt < (CULL ? 2 : 1); attempt++) { if (!solve_once(attempt == 1)) break; }
   __syncthreads();
   // ---- outputs -----------------------------------------------------------------------------------
   if (status == NEP_FAILED) { if (tid < 96) sTheta[tid] = sCoef[tid]; }                    // :856-859

@@ -484,14 +484,18 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   double obj0 = qp_obj(Q, thp);
   /* start at the projection of the guess */
   for (int c = 0; c < ny; c++) { double v = 0; for (int i = 0; i < n; i++) v += Z[i * ny + c] * (th[i] - thp[i]); y[c] = v; }
+  /* start point of the rows (slack floor, mu0): development knobs, defaults = what the kernel uses */
+  const double EXP_FLOOR = getenv("ORC_EXP_FLOOR") ? atof(getenv("ORC_EXP_FLOOR")) : 0.1;
+  const double EXP_MU0 = getenv("ORC_EXP_MU0") ? atof(getenv("ORC_EXP_MU0")) : 2.0;
   double* s = (double*)malloc(sizeof(double) * (mt + 1) * 10);
   double* lam = s + (mt + 1), *ds = lam + (mt + 1), *dl = ds + (mt + 1), *rp = dl + (mt + 1), *rc = rp + (mt + 1),
          *w = rc + (mt + 1), *gdx = w + (mt + 1), *dsa = gdx + (mt + 1), *dla = dsa + (mt + 1);
 #define QCY(yv, grad, out) do { double v_ = ccy; for (int a_ = 0; a_ < ny; a_++) { double r_ = 0; for (int b_ = 0; b_ < ny; b_++) r_ += Cy[a_ * ny + b_] * (yv)[b_]; if (grad) (grad)[a_] = 2.0 * (r_ + cqy[a_]); v_ += (yv)[a_] * r_ + 2.0 * cqy[a_] * (yv)[a_]; } out = v_; } while (0)
-  for (int r = 0; r < m; r++) { double a = 0; for (int c = 0; c < ny; c++) a += Gy[(size_t)r * ny + c] * y[c]; double sl = hy[r] - a; s[r] = sl > 1.0 ? sl : 1.0; lam[r] = 1.0 / s[r]; }
+  for (int r = 0; r < m; r++) { double a = 0; for (int c = 0; c < ny; c++) a += Gy[(size_t)r * ny + c] * y[c]; double sl = hy[r] - a; s[r] = sl > EXP_FLOOR ? sl : EXP_FLOOR; lam[r] = EXP_MU0 / s[r]; }
   if (qc) { double c; QCY(y, (double*)NULL, c); s[m] = (-c > 1e-3) ? -c : 1e-3; lam[m] = 1.0 / s[m]; }
   double qscale = 1.0; for (int c = 0; c < ny; c++) if (fabs(qy[c]) > qscale) qscale = fabs(qy[c]);
   int ret = 1, it = 0, loose_ok = 0, stall = 0, first_loose = -1;
+  double best_merit = 0.0;
   for (it = 0; it < 100; it++) {
     for (int a = 0; a < ny; a++) { double v = qy[a]; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; rd[a] = v; }
     for (int r = 0; r < m; r++) { double a = 0; const double* g = Gy + (size_t)r * ny; for (int c = 0; c < ny; c++) { a += g[c] * y[c]; rd[c] += g[c] * lam[r]; } rp[r] = a + s[r] - hy[r]; }
@@ -503,10 +507,20 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     double obj = obj0; for (int a = 0; a < ny; a++) { double v = 0; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; obj += 0.5 * y[a] * v + qy[a] * y[a]; }
     double gap = mu * mt;
     if (nrp <= 1e-9 && nrd <= 1e-9 * qscale && gap <= 1e-10 * (1.0 + fabs(obj))) { ret = 0; break; }
-    if (nrp <= 1e-6 && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj))) { loose_ok = 1; memcpy(yl, y, sizeof(double) * ny);
-      /* three more iterations after the first loose hit reach the strict tolerances unless rounding forbids it (the weights
-         lam/s amplify the rounding of the row activities into rd): stop there with the current, loosely converged point */
-      if (first_loose < 0) first_loose = it; else if (it - first_loose >= 3) { ret = 0; break; } }
+    /* Loosely converged iterates: keep the one closest to the strict tolerances (merit <= 1 is the strict test) and stop three
+       iterations after the first of them: with mu that small the weights lam/s amplify the rounding of the row activities into
+       rd, so an iteration that has not passed the strict test by then never will */
+    {
+      const int is_loose = nrp <= 1e-6 && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj));
+      if (is_loose || first_loose >= 0) {
+        const double merit = fmax(fmax(nrp * 1e9, nrd / qscale * 1e9), gap / (1.0 + fabs(obj)) * 1e10);
+        const int better = is_loose && (!loose_ok || merit < best_merit);
+        const int last = first_loose >= 0 && it - first_loose >= 3;
+        if (first_loose < 0) first_loose = it;
+        if (better) { loose_ok = 1; best_merit = merit; memcpy(yl, y, sizeof(double) * ny); }
+        if (last) break;          /* the snapshot (possibly this very iterate) is the answer */
+      }
+    }
     for (int i = 0; i < ny * ny; i++) M[i] = Py[i];
     for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; w[r] = lam[r] / s[r]; for (int a = 0; a < ny; a++) { double wa = w[r] * g[a]; for (int b = 0; b <= a; b++) M[a * ny + b] += wa * g[b]; } }
     for (int a = 0; a < ny; a++) for (int b = a + 1; b < ny; b++) M[a * ny + b] = M[b * ny + a];

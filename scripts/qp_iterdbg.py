@@ -28,6 +28,8 @@ hist = np.zeros(16 * 64, dtype=np.int64)
 for s_ in range(64):
     hist[16 * s_:16 * s_ + 16] = be.debug_phase_cycles(s_)
 h = hist[16:16 + 60 * 8].reshape(60, 8)
-for it in range(int(sol["stats"]["iters"][a]) + 1 if sol["stats"]["iters"][a] < 60 else 60):
+for it in range(60):
+    if not h[it].any():
+        continue
     v = h[it].view(np.float64)
     print("it %2d nrp %.3e nrd %.3e (qs %.3e) gap %.3e obj %.9g flag %d alpha_prev %.3e sigmamu_prev %.3e" % (it, v[0], v[1], v[2], v[3], v[4], h[it][5], v[6], v[7]))

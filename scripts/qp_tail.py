@@ -19,15 +19,21 @@ cfg = scene.frontend_cfg(p, beam_width=32)
 d_start = be.to_device(np.stack([scene.frontend_starts(s) for s in scs]))
 d_res = torch.zeros(S * N * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=be.device)
 ex = ndist.RoundExchange(S, N, 1, 0, device=be.device)
+be.enable_timing(True)
 for r in range(rounds):
-    be.frontend(cfg, d_com, d_start, d_gue, d_res)
-    be.replan(None, d_gue)
+    be.reset_timing()
+    if os.environ.get("NEP_NO_FRONTEND"):
+        be.replan(d_com, d_gue)
+    else:
+        be.frontend(cfg, d_com, d_start, d_gue, d_res)
+        be.replan(None, d_gue)
     sol = be.solutions()
+    print("round %d: qp kernel %.3f ms" % (r, be.kernel_time_ms(2)[0]))
     st = sol["stats"]
     it = st["iters"].astype(int); status = st["status"].astype(int)
     print("round %d: iters hist" % r, np.bincount(it, minlength=61)[:61].tolist())
     print("   status counts", np.bincount(status, minlength=3).tolist())
-    order = np.argsort(-it)[:12]
+    order = np.concatenate([np.argsort(-it)[:6], np.nonzero(status == 1)[0][:6], np.argsort(-st["iters_first"].astype(int))[:4]])
     g = d_gue.cpu().numpy().view(abi.GUESS_DTYPE)
     for s_ in order:
         print("   slot %4d  status %d iters %2d first %2d  K %d lines %3d rows %4d qc %d obj %.6g" % (

@@ -123,13 +123,14 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
         ok = np.abs(res).max() <= 1e-6 and (a - h).max() <= 1e-6 and (not has_qc or ((pend - final) ** 2).sum() <= 0.01 + 1e-6)
         return ok, th, full_cost(th, T, w, final, False), 0
     a_guess = coeff_init[:, :, 0]
-    z = np.stack([tb["N"].T @ (a_guess[ax] - tb["Pp"] @ init[ax]) for ax in range(3)])
+    # orthogonal projection of the guess's coefficients onto {Th z + ThU init} (QpTable.Zp in the kernel)
+    z = np.stack([np.linalg.lstsq(tb["Th"], coeff_init[ax, :K].reshape(-1) - tb["ThU"] @ init[ax], rcond=None)[0] for ax in range(3)])
     g = np.stack([tb["Gi"] @ init[ax] - 2 * w * tb["ep"] * final[ax] for ax in range(3)])
     obj0 = full_cost(theta_of(np.zeros((3, nz))), T, w, final, tb["relaxed"])
     Hax = tb["Hax"]
     cp = B @ z.T + off
     a = rowvals(cp)
-    s = np.maximum(h - a, 1.0); lam = 1.0 / s
+    s = np.maximum(h - a, 0.1); lam = 2.0 / s
     sq = lq = 0.0
     if has_qc:
         pend = z @ tb["ep"] + init @ tb["up"]
@@ -137,7 +138,7 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
         sq = max(-c, 1e-3); lq = 1.0 / sq
     mt = m + (1 if has_qc else 0)
     qscale = max(1.0, np.abs(g).max())
-    loose = None; stall = 0; first_loose = None
+    loose = None; stall = 0; first_loose = None; best_merit = 0.0
     for it in range(maxit):
         cp = B @ z.T + off
         a = rowvals(cp)
@@ -158,12 +159,16 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
             print(it, "rp %.2e rd %.2e gap %.2e obj %.9g" % (nrp, nrd, gap, obj))
         if nrp <= 1e-9 and nrd <= 1e-9 * qscale and gap <= 1e-10 * (1 + abs(obj)):
             return True, theta_of(z), obj, it
-        if nrp <= 1e-6 and nrd <= 1e-6 * qscale and gap <= 1e-7 * (1 + abs(obj)):
-            loose = (z.copy(), obj)
+        is_loose = nrp <= 1e-6 and nrd <= 1e-6 * qscale and gap <= 1e-7 * (1 + abs(obj))
+        if is_loose or first_loose is not None:   # keep the loosely converged iterate closest to the strict test, stop 3 after the first
+            merit = max(nrp * 1e9, nrd / qscale * 1e9, gap / (1 + abs(obj)) * 1e10)
+            last = first_loose is not None and it - first_loose >= 3
             if first_loose is None:
                 first_loose = it
-            elif it - first_loose >= 3:       # rounding floor of the dual residual: the loosely converged point is the answer
-                return True, theta_of(z), obj, it
+            if is_loose and (loose is None or merit < best_merit):
+                loose = (z.copy(), obj); best_merit = merit
+            if last:
+                break
         W = lam / s
         D = np.zeros((R, 3, 3)); np.add.at(D, rho, W[:, None, None] * al[:, :, None] * al[:, None, :])
         n = 3 * nz
@@ -227,7 +232,7 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
         if has_qc:
             sq += alpha * dsq; lq += alpha * dlq
     if loose is not None:
-        return True, theta_of(loose[0]), loose[1], maxit
+        return True, theta_of(loose[0]), loose[1], it
     return False, None, None, maxit
 
 
