@@ -56,7 +56,7 @@ def measured_traffic(kernel="nep::qp_kernel"):
     for line in open(path):
         if line.startswith("nep::"):
             cur = line.strip()
-        elif cur == kernel and "mean" in line:
+        elif cur is not None and cur.split("<")[0] == kernel and "mean" in line:
             parts = line.split()
             vals[parts[0]] = float(parts[2])
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:

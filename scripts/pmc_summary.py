@@ -6,6 +6,8 @@ acc = defaultdict(lambda: defaultdict(list))
 for f in sorted(glob.glob(os.path.join(root, "*", "*counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("void "):
+            k = k[5:]            # templated kernels are printed with their return type
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 print("# rocprofv3 --pmc summary (mean per dispatch) of", root)
 for k in sorted(acc):
