@@ -39,6 +39,14 @@ constexpr int kMaxIt = 60;
 // guesses (oracle sweep): 1 / 1 needs 11.3 iterations on front-end guesses and 5.8 on near-optimal ones, 0.1 / 2
 // needs 8.6 and 6.1.
 constexpr double kSlackFloor = 0.1, kMu0 = 2.0;
+// fraction of the step to the boundary: 1 - mu clamped to [0.999, 0.99999].  The late iterations shrink the residuals by
+// (1 - fraction) each, so a fraction closer to one saves one of them (oracle sweep: 6.1 -> 5.2 iterations on the bench
+// guesses); early on, while mu is large, hugging the boundary costs centrality: a fixed 0.99999 left a few front-end-guess
+// replans per thousand iterating to the cap.
+#ifndef NEP_STEPFRAC_MAX
+#define NEP_STEPFRAC_MAX 0.99999
+#endif
+constexpr double kStepFracMin = 0.999, kStepFracMax = NEP_STEPFRAC_MAX;
 // offsets (doubles) inside QpTable's tail Gi, ep, ev, ea, up, uv, ua, Nt, Pp, res_u, Zp
 constexpr int tGi = 0, tUp = 48, tUv = 51, tUa = 54, tNt = 57, tPp = 121, tResU = 145, tZp = 151, kSmallTab = 151 + kNZ * 4 * kMaxK;
 static_assert(offsetof(QpTable, up) - offsetof(QpTable, Gi) == tUp * 8 && offsetof(QpTable, Nt) - offsetof(QpTable, Gi) == tNt * 8 &&
@@ -758,6 +766,10 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) / mt;
           const double rr = mua / mu;
           sm = rr * rr * rr * mu;                              // sigma * mu, identical in every thread
+          // never aim below a tenth of the gap the strict test asks for: with the long steps of kStepFracMax the centring
+          // target would otherwise collapse by 1e5 per iteration, the last iterate would sit at mu ~ 1e-15 with weights
+          // lambda/s ~ 1e17, and the rounding of that last step shows up as 1e-6 in the flat directions of the coefficients
+          sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) / mt);
         }
         TICK(6);
         TICK(7);
@@ -819,7 +831,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         reduce_get<0>(rmax, dmy, dmy, redP5);
         {
           double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
-          alpha = fmin(1.0, 0.999 * alpha);
+          alpha = fmin(1.0, fmin(fmax(1.0 - sc[sMu], kStepFracMin), kStepFracMax) * alpha);
           if (tid == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
           if (tid < n) sZ[tid] += alpha * sDx[tid];
           alpha_prev = alpha; sm_prev = sm;

@@ -487,6 +487,9 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   /* start point of the rows (slack floor, mu0): development knobs, defaults = what the kernel uses */
   const double EXP_FLOOR = getenv("ORC_EXP_FLOOR") ? atof(getenv("ORC_EXP_FLOOR")) : 0.1;
   const double EXP_MU0 = getenv("ORC_EXP_MU0") ? atof(getenv("ORC_EXP_MU0")) : 2.0;
+  const double EXP_TAU = getenv("ORC_EXP_TAU") ? atof(getenv("ORC_EXP_TAU")) : 0.99999;
+  const double EXP_GAPTOL = getenv("ORC_EXP_GAPTOL") ? atof(getenv("ORC_EXP_GAPTOL")) : 1e-10;
+  const double EXP_SIGPOW = getenv("ORC_EXP_SIGPOW") ? atof(getenv("ORC_EXP_SIGPOW")) : 3.0;
   double* s = (double*)malloc(sizeof(double) * (mt + 1) * 10);
   double* lam = s + (mt + 1), *ds = lam + (mt + 1), *dl = ds + (mt + 1), *rp = dl + (mt + 1), *rc = rp + (mt + 1),
          *w = rc + (mt + 1), *gdx = w + (mt + 1), *dsa = gdx + (mt + 1), *dla = dsa + (mt + 1);
@@ -506,21 +509,25 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     for (int a = 0; a < ny; a++) if (fabs(rd[a]) > nrd) nrd = fabs(rd[a]);
     double obj = obj0; for (int a = 0; a < ny; a++) { double v = 0; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; obj += 0.5 * y[a] * v + qy[a] * y[a]; }
     double gap = mu * mt;
-    if (nrp <= 1e-9 && nrd <= 1e-9 * qscale && gap <= 1e-10 * (1.0 + fabs(obj))) { ret = 0; break; }
+    if (nrp <= 1e-9 && nrd <= 1e-9 * qscale && gap <= EXP_GAPTOL * (1.0 + fabs(obj)) && !getenv("ORC_EXP_NOSTOP")) { ret = 0; break; }
     /* Loosely converged iterates: keep the one closest to the strict tolerances (merit <= 1 is the strict test) and stop three
        iterations after the first of them: with mu that small the weights lam/s amplify the rounding of the row activities into
        rd, so an iteration that has not passed the strict test by then never will */
     {
       const int is_loose = nrp <= 1e-6 && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj));
       if (is_loose || first_loose >= 0) {
-        const double merit = fmax(fmax(nrp * 1e9, nrd / qscale * 1e9), gap / (1.0 + fabs(obj)) * 1e10);
+        const double merit = fmax(fmax(nrp * 1e9, nrd / qscale * 1e9), gap / (1.0 + fabs(obj)) / EXP_GAPTOL);
         const int better = is_loose && (!loose_ok || merit < best_merit);
         const int last = first_loose >= 0 && it - first_loose >= 3;
         if (first_loose < 0) first_loose = it;
         if (better) { loose_ok = 1; best_merit = merit; memcpy(yl, y, sizeof(double) * ny); }
-        if (last) break;          /* the snapshot (possibly this very iterate) is the answer */
+        if (last && !getenv("ORC_EXP_NOSTOP")) break;          /* the snapshot (possibly this very iterate) is the answer */
       }
     }
+    /* Primal residuals a tenth of the tolerance or less are taken as zero in the Newton step: recomputed as a + s - h they
+       carry the ~1e-14 cancellation error of activities of tens of metres, which the weights lam/s (1e12 and more near the
+       end) would amplify into the duals and from there into the dual residual */
+    if (nrp <= (getenv("ORC_EXP_RPTHR") ? atof(getenv("ORC_EXP_RPTHR")) : 1e-10)) for (int r = 0; r < mt; r++) rp[r] = 0.0;
     for (int i = 0; i < ny * ny; i++) M[i] = Py[i];
     for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; w[r] = lam[r] / s[r]; for (int a = 0; a < ny; a++) { double wa = w[r] * g[a]; for (int b = 0; b <= a; b++) M[a * ny + b] += wa * g[b]; } }
     for (int a = 0; a < ny; a++) for (int b = a + 1; b < ny; b++) M[a * ny + b] = M[b * ny + a];
@@ -528,7 +535,10 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     if (chol(ny, M)) break;
     double alpha = 1.0, sigma = 0.0;
     for (int pass = 0; pass < 2; pass++) {
-      for (int r = 0; r < mt; r++) rc[r] = (pass == 0) ? s[r] * lam[r] : s[r] * lam[r] - sigma * mu + dsa[r] * dla[r];
+      /* centring target: never below a tenth of the gap the strict test asks for (long steps would otherwise collapse mu to
+         ~1e-15 in the last iteration and the weights lam/s with it to ~1e17) */
+      double smu = sigma * mu; { const double fl = 0.1 * EXP_GAPTOL * (1.0 + fabs(obj)) / (mt > 0 ? mt : 1); if (smu < fl) smu = fl; }
+      for (int r = 0; r < mt; r++) rc[r] = (pass == 0) ? s[r] * lam[r] : s[r] * lam[r] - smu + dsa[r] * dla[r];
       for (int a = 0; a < ny; a++) rhs[a] = -rd[a];
       for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double v = rc[r] / s[r] - w[r] * rp[r]; for (int c = 0; c < ny; c++) rhs[c] += g[c] * v; }
       if (qc) { double v = rc[m] / s[m] - w[m] * rp[m]; for (int a = 0; a < ny; a++) rhs[a] += gq[a] * v; }
@@ -545,11 +555,14 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       if (pass == 0) {
         double mua = 0; for (int r = 0; r < mt; r++) mua += (s[r] + alpha * ds[r]) * (lam[r] + alpha * dl[r]);
         mua /= (mt > 0 ? mt : 1);
-        double rr = mua / mu; sigma = rr * rr * rr;
+        double rr = mua / mu; sigma = pow(rr, EXP_SIGPOW);
         for (int r = 0; r < mt; r++) { dsa[r] = ds[r]; dla[r] = dl[r]; }
       }
     }
-    alpha *= 0.999; if (alpha > 1.0) alpha = 1.0;
+    { double tau = 1.0 - mu;      /* fraction of the step to the boundary: 1 - mu clamped to [0.999, EXP_TAU = 0.99999] */
+      if (tau < 0.999) tau = 0.999;
+      if (tau > EXP_TAU) tau = EXP_TAU;
+      alpha *= tau; if (alpha > 1.0) alpha = 1.0; }
     if (getenv("ORC_QP_TRACE")) fprintf(stderr, "it %2d nrp %.3e nrd %.3e (qs %.3e) gap %.3e obj %.9g sigma %.3e alpha %.3e loose %d\n", it, nrp, nrd, qscale, gap, obj, sigma, alpha, loose_ok);
     if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;
     for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];

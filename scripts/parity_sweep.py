@@ -1,0 +1,63 @@
+"""Parity at scale: every replan of S bench scenes (front-end guesses by default) on the device against the CPU oracle,
+one oracle process per host core.  Prints the distribution of the coefficient and cost differences."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+from concurrent.futures import ProcessPoolExecutor
+
+N, M = 64, 20
+S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+use_fe = not os.environ.get("NEP_NO_FRONTEND")
+
+
+def oracle_one(job):
+    seed, a, g = job
+    from neptune_amd import scene
+    from oracle import oracle
+    sc = scene.make_scene(N, M, seed=seed)
+    statics = scene.make_scene(N, M, seed=0)["statics"]
+    r = oracle.replan(sc["par"], a + 1, sc["committed"], g, statics)
+    return seed, a, r["status"], r["iters"], r["objective"], np.array(r["coeff"])
+
+
+def main():
+    import torch
+    from neptune_amd import abi, dist as ndist, scene
+    from neptune_amd.backend import BatchBackend
+    scs = [scene.make_scene(N, M, seed=s) for s in range(S)]
+    p = scs[0]["par"]
+    com, gue = ndist.stack_scenes(scs)
+    be = BatchBackend(p, scs[0]["statics"], n_scenes=S)
+    d_com = be.to_device(com); d_gue = be.to_device(gue)
+    if use_fe:
+        d_start = be.to_device(np.stack([scene.frontend_starts(s) for s in scs]))
+        be.frontend(scene.frontend_cfg(p, beam_width=32), d_com, d_start, d_gue, None)
+        be.replan(None, d_gue)
+    else:
+        be.replan(d_com, d_gue)
+    sol = be.solutions()
+    g = d_gue.cpu().numpy().view(abi.GUESS_DTYPE).reshape(S, N)
+    jobs = [(s, a, g[s, a].copy()) for s in range(S) for a in range(N) if int(g[s, a]["K"]) > 0]
+    import multiprocessing as mp
+    with ProcessPoolExecutor(max_workers=min(os.cpu_count() or 1, 128), mp_context=mp.get_context("spawn")) as ex:
+        res = list(ex.map(oracle_one, jobs, chunksize=4))
+    dco, dob, st_bad, worst = [], [], 0, None
+    for seed, a, status, iters, obj, coeff in res:
+        so = sol[seed * N + a]
+        if int(so["stats"]["status"]) != status:
+            st_bad += 1
+            continue
+        if status == 2:
+            continue
+        K = coeff.shape[1]
+        d = float(np.abs(np.array(so["coeff"])[:, :K, :] - coeff).max())
+        dco.append(d); dob.append(abs(float(so["stats"]["objective"]) - obj) / (1 + abs(obj)))
+        if worst is None or d > worst[0]:
+            worst = (d, seed, a, int(so["stats"]["iters"]), iters)
+    dco = np.array(dco); dob = np.array(dob)
+    print("replans compared %d (status mismatches %d) | coeff diff: p50 %.2e p99 %.2e max %.2e, > 1e-6: %d, > 1e-5: %d | rel cost diff max %.2e | worst (diff, scene, agent, gpu iters, oracle iters) %s"
+          % (len(dco), st_bad, np.percentile(dco, 50), np.percentile(dco, 99), dco.max(), int((dco > 1e-6).sum()), int((dco > 1e-5).sum()), dob.max(), worst))
+
+
+if __name__ == "__main__":
+    main()

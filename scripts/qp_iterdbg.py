@@ -8,24 +8,25 @@ import numpy as np, torch
 from neptune_amd import abi, dist as ndist, scene
 from neptune_amd.backend import BatchBackend
 from neptune_amd._lib import lib
-N, M = 64, 20
+N, M = int(os.environ.get("NEP_AGENTS", 64)), int(os.environ.get("NEP_STATICS", 20))
+W = int(os.environ.get("NEP_BEAM", 32))
 seed, a = int(sys.argv[1]), int(sys.argv[2])
 sc = scene.make_scene(N, M, seed=seed); p = sc["par"]
-statics = scene.make_scene(N, M, seed=0)["statics"]
+statics = scene.make_scene(N, M, seed=0)["statics"] if N == 64 else sc["statics"]
 be = BatchBackend(p, statics, n_scenes=1)
 if os.environ.get("NEP_CULL"):
     be.set_line_cull(float(os.environ["NEP_CULL"]))
 d_com = be.to_device(sc["committed"]); d_gue = be.to_device(sc["guesses"])
 if not os.environ.get("NEP_NO_FRONTEND"):
     d_start = be.to_device(scene.frontend_starts(sc))
-    be.frontend(scene.frontend_cfg(p, beam_width=32), d_com, d_start, d_gue, None)
+    be.frontend(scene.frontend_cfg(p, beam_width=W), d_com, d_start, d_gue, None)
     be.replan(None, d_gue)
 else:
     be.replan(d_com, d_gue)
 sol = be.solutions()
 print("slot", a, "status", sol["stats"]["status"][a], "iters", sol["stats"]["iters"][a], "obj", sol["stats"]["objective"][a])
-hist = np.zeros(16 * 64, dtype=np.int64)
-for s_ in range(64):
+hist = np.zeros(16 * max(N, 64), dtype=np.int64)
+for s_ in range(N):
     hist[16 * s_:16 * s_ + 16] = be.debug_phase_cycles(s_)
 h = hist[16:16 + 60 * 8].reshape(60, 8)
 for it in range(60):

@@ -191,7 +191,8 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
             if pas == 0:
                 rc = s * lam; rcq = sq * lq
             else:
-                rc = s * lam - sigma * mu + dsa * dla; rcq = sq * lq - sigma * mu + dsqa * dlqa
+                smu = max(sigma * mu, 0.1 * 1e-10 * (1 + abs(obj)) / mt)   # never aim below a tenth of the strict gap
+                rc = s * lam - smu + dsa * dla; rcq = sq * lq - smu + dsqa * dlqa
             v = rc / s - W * rp
             T1 = np.zeros((R, 3)); np.add.at(T1, rho, al * v[:, None])
             rhs = -rd + (B.T @ T1).T
@@ -221,7 +222,7 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
                 dsa, dla = ds, dl
                 if has_qc:
                     dsqa, dlqa = dsq, dlq
-        alpha = min(1.0, 0.999 * alpha)
+        alpha = min(1.0, min(max(1.0 - mu, 0.999), 0.99999) * alpha)
         if alpha < 1e-8:
             stall += 1
             if stall >= 3:
