@@ -502,15 +502,15 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
       if (has_box) {
         const double a = cpb;
-        double sl = bhi - a; bs0 = sl > kSlackFloor ? sl : kSlackFloor; bl0 = kMu0 / bs0;
-        sl = a - blo; bs1 = sl > kSlackFloor ? sl : kSlackFloor; bl1 = kMu0 / bs1;
+        double sl = bhi - a; bs0 = sl > kSlackFloor ? sl : kSlackFloor; bl0 = kMu0 * frcp(bs0);
+        sl = a - blo; bs1 = sl > kSlackFloor ? sl : kSlackFloor; bl1 = kMu0 * frcp(bs1);
       }
       {
         const double cx = cpx, cy = cpy;
         for_lines4([&](bool, int l, double n1, double n2, double h, double, double) {
           const double sl = h - (n1 * cx + n2 * cy);
           const double s = sl > kSlackFloor ? sl : kSlackFloor;
-          STw(l, lk, 0, s); STw(l, lk, 1, kMu0 / s);
+          STw(l, lk, 0, s); STw(l, lk, 1, kMu0 * frcp(s));   // (the start duals need no exact division)
         });
       }
       if (tid == 0) {

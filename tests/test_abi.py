@@ -77,6 +77,16 @@ def test_cpp_host_class_compiles_and_links(L):
     assert os.path.exists(exe)
 
 
+def test_reduced_qp_tables_are_consistent(tmp_path):
+    """nep_tables.h on the host: Zp is the left inverse of Th (start point), theta(z) is C2-continuous, starts at the
+    initial state and (mode 0) ends at rest, and projecting a feasible theta returns its z — for every K and mode."""
+    import subprocess
+    exe = str(tmp_path / "tables_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tests", "cpp", "tables_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok"), out.stdout
+
+
 def test_headers_are_plain_c99():
     """The boundary is a C ABI: every header under include/ (except the C++ class) must compile as strict C99."""
     import subprocess
