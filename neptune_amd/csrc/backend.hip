@@ -47,7 +47,7 @@ struct Engine {
   int n_scenes = 1;
   DevBuf<QpTable> d_tables;
   DevBuf<int> d_sched_n, d_sched_seg; DevBuf<double> d_sched_dt;
-  DevBuf<double> d_pb, d_static_xy; DevBuf<int> d_static_nv;
+  DevBuf<double> d_pb, d_static_xy, d_static_el; DevBuf<int> d_static_nv;
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
   DevBuf<long long> d_dbg; bool profile_phases = false;
@@ -123,7 +123,7 @@ struct Engine {
     return 0;
   }
   void fill(ProblemSet& ps) {
-    ps.pb = d_pb.p; ps.static_xy = d_static_xy.p; ps.static_nv = d_static_nv.p;
+    ps.pb = d_pb.p; ps.static_xy = d_static_xy.p; ps.static_nv = d_static_nv.p; ps.static_el = d_static_el.p;
     ps.hull_xy = d_hull_xy.p; ps.hull_nv = d_hull_nv.p; ps.hull0_xy = d_hull0_xy.p; ps.hull0_nv = d_hull0_nv.p;
     ps.bend_xy = d_bend_xy.p; ps.bend_n = d_bend_n.p;
     ps.line_nd = d_line_nd.p; ps.line_cnt = d_line_cnt.p; ps.lp_stats = d_lp_stats.p;
@@ -139,8 +139,21 @@ struct Engine {
       nv[j] = c;
       for (int v = 0; v < c; v++) { sx[((size_t)j * kHullV + v) * 2] = xy[2 * (off[j] + v)]; sx[((size_t)j * kHullV + v) * 2 + 1] = xy[2 * (off[j] + v) + 1]; }
     }
+    // edge lengths for the proximity cull (solver_gurobi_poly.cpp:566-572), the same IEEE operations the kernel used to
+    // repeat per candidate: squares, one sum, sqrt (no contraction: three separate roundings)
+    std::vector<double> el(sx.size() / 2, 0.0);
+    for (int j = 0; j < n; j++)
+      for (int v = 0; v + 1 < nv[j]; v++) {
+        const double* q = &sx[((size_t)j * kHullV + v) * 2];
+        volatile double ex = q[2] - q[0], ey = q[3] - q[1];
+        volatile double a = ex * ex, b = ey * ey;
+        volatile double c = a + b;
+        el[(size_t)j * kHullV + v] = std::sqrt(c);
+      }
     if (int e = d_static_xy.ensure(sx.size())) return e;
+    if (int e = d_static_el.ensure(el.size())) return e;
     if (int e = d_static_nv.ensure(nv.size())) return e;
+    HIPCHK(hipMemcpy(d_static_el.p, el.data(), el.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_static_xy.p, sx.data(), sx.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_static_nv.p, nv.data(), nv.size() * sizeof(int), hipMemcpyHostToDevice));
     sp.n_static = n;
@@ -169,7 +182,7 @@ struct Engine {
   }
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
-    d_static_nv.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release();
+    d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release();
     d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();

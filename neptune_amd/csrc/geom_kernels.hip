@@ -239,9 +239,12 @@ __device__ __forceinline__ void sep_pair(double px, double py, double qx, double
   const double len2 = nx * nx + ny * ny;
   if (!(len2 > 0.0)) return;
   double minA = NEP_INF, maxA = -NEP_INF, minB = NEP_INF, maxB = -NEP_INF;
-  for (int i = 0; i < nA; i++) { const double2 a = A[i]; const double t = nx * (a.x - px) + ny * (a.y - py); if (t < minA) minA = t; if (t > maxA) maxA = t; }
 #pragma unroll
   for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); if (t < minB) minB = t; if (t > maxB) maxB = t; }
+  // a pair of B with B on both sides of its line supports no candidate (np_ = nm = -inf below): skip the pass over A.
+  // B is the same in every lane of the separator kernel, so this exit is wave-uniform there.
+  if (!from_A && !(maxB <= 0.0) && !(minB >= 0.0)) return;
+  for (int i = 0; i < nA; i++) { const double2 a = A[i]; const double t = nx * (a.x - px) + ny * (a.y - py); if (t < minA) minA = t; if (t > maxA) maxA = t; }
   double np_ = -NEP_INF, nm = -NEP_INF, tAp = 0.0, tAm = 0.0;
   if (from_A) {
     if (minA >= 0.0) { np_ = 0.0 - maxB; tAp = 0.0; }
@@ -308,6 +311,7 @@ constexpr int kAStage = 12;
 struct SepCtx {
   const SceneParams* sp; const ProblemSet* ps;
   int slot, scene, own, N, S, nH, total;
+  double el[3];          // lengths of the control polygon's three edges (the terms of hulldist)
 };
 __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, const double* by, double hulldist,
                           bool stage, double2* myA, int& nA, bool& ordered, const double2*& Ause) {
@@ -331,8 +335,8 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     const int j = c - nH;
     const double base_radius = 0.7;
     const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
-    bool close_to_base = false;
-    for (int k = 0; k < 4; k++) {
+    bool close_to_base = stage;      // (staging is only asked for candidates that passed this test in step 1)
+    for (int k = 0; k < 4 && !stage; k++) {
       const double ddx = bx[k] - pbx, ddy = by[k] - pby;
       // sqrt(ddx^2+ddy^2) >= max(|ddx|,|ddy|): beyond 2.2 on either axis the test below is false; skip its sqrt
       if (fabs(ddx) > 2.2 || fabs(ddy) > 2.2) continue;
@@ -352,12 +356,14 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     const int nv = ps.static_nv[j];
     if (nv <= 0) return false;
     const double* src = ps.static_xy + (long)j * kHullV * 2;
-    bool close_s = false;  // :558-578
-    const double ddx = bx[0] - src[0], ddy = by[0] - src[1];
-    double dist = sqrt(ddx * ddx + ddy * ddy);
-    for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
-    for (int k = 0; k < nv - 1; k++) { const double ex = src[2 * (k + 1)] - src[2 * k], ey = src[2 * (k + 1) + 1] - src[2 * k + 1]; dist -= sqrt(ex * ex + ey * ey); if (dist < 0) { close_s = true; break; } }
-    if (!close_s) return false;
+    if (!stage) {          // :558-578 (staging is only asked for candidates that passed this test in step 1)
+      bool close_s = false;
+      const double ddx = bx[0] - src[0], ddy = by[0] - src[1];
+      double dist = sqrt(ddx * ddx + ddy * ddy);
+      for (int k = 0; k < 3; k++) { dist -= cx.el[k]; if (dist < 0) { close_s = true; break; } }   // (same values as the reference's per-call square roots)
+      for (int k = 0; k < nv - 1 && !close_s; k++) { dist -= ps.static_el[(long)j * kHullV + k]; if (dist < 0) { close_s = true; break; } }
+      if (!close_s) return false;
+    }
     ordered = true; nA = nv;
     if (stage) { if (nv <= kAStage) for (int v = 0; v < nv; v++) myA[v] = make_double2(src[2 * v], src[2 * v + 1]); else Ause = (const double2*)src; }
     return true;
@@ -382,7 +388,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
       pAx = bp[2 * (k - 2)]; pAy = bp[2 * (k - 2) + 1]; pBx = bp[2 * (k - 1)]; pBy = bp[2 * (k - 1) + 1];
     }
     const double ax_ = pAx - bx[0], ay_ = pAy - by[0], bx_ = pBx - bx[0], by_ = pBy - by[0];
-    if (sqrt(ax_ * ax_ + ay_ * ay_) - hulldist > 0 && sqrt(bx_ * bx_ + by_ * by_) - hulldist > 0) return false;  // :743-745
+    if (!stage && sqrt(ax_ * ax_ + ay_ * ay_) - hulldist > 0 && sqrt(bx_ * bx_ + by_ * by_) - hulldist > 0) return false;  // :743-745
     nA = 2;
     if (stage) { myA[0] = make_double2(pAx, pAy); myA[1] = make_double2(pBx, pBy); }
     return true;
@@ -424,7 +430,7 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
   __syncthreads();
   const double* bx = sBx; const double* by = sBy;
   double hulldist = 0;  // :738-742
-  for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; hulldist += sqrt(ex * ex + ey * ey); }
+  for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; cx.el[k] = sqrt(ex * ex + ey * ey); hulldist += cx.el[k]; }
   // ---- step 1: which LPs does the reference call, in order -------------------------------------
   int n_att = 0;
   for (int c0 = 0; c0 < total; c0 += 64) {

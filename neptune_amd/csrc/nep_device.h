@@ -36,6 +36,7 @@ struct ProblemSet {
   const double* pb;              // [N][2]
   const double* static_xy;       // [S][kHullV][2]
   const int* static_nv;          // [S]
+  const double* static_el;       // [S][kHullV] length of edge v -> v+1 (the proximity cull's square roots, taken once at upload)
   const int* case_id;            // [slots][NEP_MAX_POL][N] or null
   // per scene (batch: written by the hull kernel; per-agent: uploaded by setHulls)
   double* hull_xy;               // [scenes][n_hull][num_pol][kHullV][2]
