@@ -5,7 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.ins
 import numpy as np
 from concurrent.futures import ProcessPoolExecutor
 
-N, M = 64, 20
+N, M = int(os.environ.get("NEP_AGENTS", 64)), int(os.environ.get("NEP_STATICS", 20))
+SEED0 = int(os.environ.get("NEP_SEED0", 0))
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 use_fe = not os.environ.get("NEP_NO_FRONTEND")
 
@@ -14,8 +15,8 @@ def oracle_one(job):
     seed, a, g = job
     from neptune_amd import scene
     from oracle import oracle
-    sc = scene.make_scene(N, M, seed=seed)
-    statics = scene.make_scene(N, M, seed=0)["statics"]
+    sc = scene.make_scene(N, M, seed=SEED0 + seed)
+    statics = scene.make_scene(N, M, seed=SEED0)["statics"]
     r = oracle.replan(sc["par"], a + 1, sc["committed"], g, statics)
     return seed, a, r["status"], r["iters"], r["objective"], np.array(r["coeff"])
 
@@ -24,7 +25,7 @@ def main():
     import torch
     from neptune_amd import abi, dist as ndist, scene
     from neptune_amd.backend import BatchBackend
-    scs = [scene.make_scene(N, M, seed=s) for s in range(S)]
+    scs = [scene.make_scene(N, M, seed=SEED0 + s) for s in range(S)]
     p = scs[0]["par"]
     com, gue = ndist.stack_scenes(scs)
     be = BatchBackend(p, scs[0]["statics"], n_scenes=S)
@@ -41,7 +42,7 @@ def main():
     import multiprocessing as mp
     with ProcessPoolExecutor(max_workers=min(os.cpu_count() or 1, 128), mp_context=mp.get_context("spawn")) as ex:
         res = list(ex.map(oracle_one, jobs, chunksize=4))
-    dco, dob, st_bad, worst = [], [], 0, None
+    dco, dob, dpos, st_bad, worst = [], [], [], 0, None
     for seed, a, status, iters, obj, coeff in res:
         so = sol[seed * N + a]
         if int(so["stats"]["status"]) != status:
@@ -52,11 +53,13 @@ def main():
         K = coeff.shape[1]
         d = float(np.abs(np.array(so["coeff"])[:, :K, :] - coeff).max())
         dco.append(d); dob.append(abs(float(so["stats"]["objective"]) - obj) / (1 + abs(obj)))
+        dc = np.array(so["coeff"])[:, :K, :] - coeff                      # position difference along the segments (metres)
+        dpos.append(max(float(np.abs(((dc[..., 0] * t + dc[..., 1]) * t + dc[..., 2]) * t + dc[..., 3]).max()) for t in (0.0, 0.125, 0.25, 0.375, 0.5)))
         if worst is None or d > worst[0]:
             worst = (d, seed, a, int(so["stats"]["iters"]), iters)
-    dco = np.array(dco); dob = np.array(dob)
-    print("replans compared %d (status mismatches %d) | coeff diff: p50 %.2e p99 %.2e max %.2e, > 1e-6: %d, > 1e-5: %d | rel cost diff max %.2e | worst (diff, scene, agent, gpu iters, oracle iters) %s"
-          % (len(dco), st_bad, np.percentile(dco, 50), np.percentile(dco, 99), dco.max(), int((dco > 1e-6).sum()), int((dco > 1e-5).sum()), dob.max(), worst))
+    dco = np.array(dco); dob = np.array(dob); dpos = np.array(dpos)
+    print("replans compared %d (status mismatches %d) | coeff diff: p50 %.2e p99 %.2e max %.2e, > 1e-6: %d, > 1e-5: %d | position diff along the trajectories: p99 %.2e max %.2e m | rel cost diff max %.2e | worst (diff, scene, agent, gpu iters, oracle iters) %s"
+          % (len(dco), st_bad, np.percentile(dco, 50), np.percentile(dco, 99), dco.max(), int((dco > 1e-6).sum()), int((dco > 1e-5).sum()), np.percentile(dpos, 99), dpos.max(), dob.max(), worst))
 
 
 if __name__ == "__main__":
