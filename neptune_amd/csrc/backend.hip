@@ -115,7 +115,7 @@ struct Engine {
     if (int e = d_line_nd.ensure((size_t)slots * lines_total * 3)) return e;
     if (int e = d_line_cnt.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_line_far.ensure((size_t)slots * NEP_MAX_POL)) return e;
-    if (int e = d_lp_stats.ensure((size_t)slots * 2)) return e;
+    if (int e = d_lp_stats.ensure((size_t)slots * NEP_MAX_POL * 2)) return e;   // per (slot, segment): LPs attempted, LPs without a line
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 16)) return e; }
     if (lines_total > lds_lines) { if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e; }
@@ -171,7 +171,6 @@ struct Engine {
     if (d_recs) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st);
     if (timing) hipEventRecord(next_event(), st);
     if (!ps.lines_override) {
-      HIPCHK(hipMemsetAsync(d_lp_stats.p, 0, (size_t)slots * 2 * sizeof(int), st));
       launch_separator(slots, sp, ps, st);
     }
     if (timing) hipEventRecord(next_event(), st);
@@ -394,7 +393,6 @@ int nep_backend_optimize(nep_backend_t* h, double* objective_value) {
     for (int l = 0; l < h->override_n; l++) { int s = h->ov_seg[l]; int c = cnt[s]++; for (int k = 0; k < 3; k++) nd[((size_t)s * E.sp.lines_cap + c) * 3 + k] = h->ov_nd[3 * l + k]; }
     HIPCHK(hipMemcpyAsync(E.d_line_nd.p, nd.data(), nd.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemcpyAsync(E.d_line_cnt.p, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemsetAsync(E.d_lp_stats.p, 0, 2 * sizeof(int), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));  // host vectors go out of scope
     ps.lines_override = 1;
   }

@@ -414,7 +414,8 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
   const nep_guess* g = ps.guess + slot;
   const int K = g->K;
   int* cnt_out = ps.line_cnt + (long)slot * NEP_MAX_POL + seg;
-  if (seg >= K || seg >= sp.num_pol) { if (lane == 0) { *cnt_out = 0; if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = 0; } return; }
+  int* lp_out = ps.lp_stats + ((long)slot * NEP_MAX_POL + seg) * 2;      // every wave writes its own pair: no memset, no atomics
+  if (seg >= K || seg >= sp.num_pol) { if (lane == 0) { *cnt_out = 0; lp_out[0] = 0; lp_out[1] = 0; if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = 0; } return; }
   const double T = sp.T_span;
   SepCtx cx; cx.sp = &sp; cx.ps = &ps; cx.slot = slot; cx.scene = slot / sp.n_local; cx.own = sp.first_local + (slot % sp.n_local);
   cx.N = sp.num_agents; cx.S = sp.n_static; cx.nH = sp.n_hull;
@@ -492,8 +493,7 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
   if (lane == 0) {
     *cnt_out = cull ? n_near : (n_att < sp.lines_cap ? n_att : sp.lines_cap);
     if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = cull ? n_far : 0;
-    atomicAdd(ps.lp_stats + 2 * slot, n_att);
-    if (n_fail) atomicAdd(ps.lp_stats + 2 * slot + 1, n_fail);
+    lp_out[0] = n_att; lp_out[1] = n_fail;
   }
 }
 

@@ -54,7 +54,7 @@ struct ProblemSet {
   double* line_nd;               // [slots][NEP_MAX_POL][lines_cap][3]
   int* line_cnt;                 // [slots][NEP_MAX_POL]  lines at the front of the bucket (all of them, or the near ones)
   int* line_far;                 // [slots][NEP_MAX_POL]  presolved-away lines parked at the back of the bucket, or null
-  int* lp_stats;                 // [slots][2]  (attempted, failed)
+  int* lp_stats;                 // [slots][NEP_MAX_POL][2]  (LPs attempted, LPs without a line) per segment, written by the separator
   int lines_override;            // 1: line buckets were filled by the host (test hook)
   // QP scratch when the row state does not fit LDS
   double* row_scratch;           // [slots][2][rows_cap]

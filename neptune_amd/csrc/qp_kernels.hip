@@ -909,7 +909,14 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   if (tid == 0) {
     sol->stats.status = status; sol->stats.iters = iters_total; sol->stats.iters_first = iters_first;
     // bucket entries of LPs without a separating line are (0,0,0) = null rows (constraint skipped)
-    const int n_lp = (ps.lp_stats && !ps.lines_override) ? ps.lp_stats[2 * slot] : 0, n_lpf = (ps.lp_stats && !ps.lines_override) ? ps.lp_stats[2 * slot + 1] : 0;
+    int n_lp = 0, n_lpf = 0;
+    if (ps.lp_stats && !ps.lines_override) {
+      int v[2 * NEP_MAX_POL];
+#pragma unroll
+      for (int i = 0; i < 2 * NEP_MAX_POL; i++) v[i] = ps.lp_stats[(long)slot * NEP_MAX_POL * 2 + i];   // one round trip
+#pragma unroll
+      for (int i = 0; i < NEP_MAX_POL; i++) { n_lp += v[2 * i]; n_lpf += v[2 * i + 1]; }
+    }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
     sol->stats.n_rows = 48 * K + 4 * ((culled && L_used < L_all) ? L_used : L_used - n_lpf); sol->stats.qc_active = has_qc ? 1 : 0;   // rows solved for (null rows of failed LPs excluded)
     sol->stats.objective = objective; sol->stats.solve_us = 0.0;
