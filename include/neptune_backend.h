@@ -289,7 +289,11 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
  * violated, the replan is solved again with all lines — the optimum is that of the full problem (what a QP
  * presolve does with redundant rows; Gurobi runs one inside PolySolverGurobi::optimize).  nep_stats.n_lines
  * still counts every line, n_rows the rows actually solved for.  The debug line readers see the buckets
- * reordered (near lines first).                                                                         */
+ * reordered (near lines first).
+ * The presolve also tries the minimiser of the cost without any inequality row (one small matrix-vector product
+ * with a host-built inverse): if every box row, every line and the terminal ball hold there, that point with zero
+ * multipliers satisfies the KKT conditions of the full problem and is returned as the optimum without a single
+ * interior-point iteration (nep_stats.iters == 0); otherwise the interior point runs as usual.                */
 int nep_batch_set_line_cull(nep_batch_t* h, double radius);
 
 /* on != 0: nep_batch_safety_commit additionally turns down a new trajectory that collides with the

@@ -267,7 +267,8 @@ class BatchBackend:
 
     def set_line_cull(self, radius):
         """presolve: separating lines farther than `radius` metres from the guess are left out of the QP and verified
-        afterwards (nep_batch_set_line_cull); 0 turns it off"""
+        afterwards, and a replan whose unconstrained minimiser is feasible returns it without iterating
+        (nep_batch_set_line_cull); 0 turns it off"""
         check(lib().nep_batch_set_line_cull(self._h, float(radius)))
 
     def set_safety_check_prev(self, on=True):

@@ -50,6 +50,7 @@ struct QpTable {
   double res_u[2][3];        // terminal (b_K, c_K) at a = Pp.init: consistency check for K <= 2
   double Zp[kNZ][4 * kMaxK]; // start point: z0 = Zp (theta_guess - ThU init), the orthogonal projection of the guess's
                              // coefficients onto the feasible affine set {Th z + ThU init}  (Zp = (Th'Th)^-1 Th')
+  double HaxInv[kNZ][kNZ];   // inverse of the per-axis Hessian: the minimiser without inequality rows is -HaxInv g (presolve)
 };
 
 struct SampleTable {         // generatePwpOut's time walk (solver_gurobi_poly.cpp:911-934)
@@ -190,6 +191,18 @@ inline void build_qp_table(int K, double T, double weight, int mode, QpTable* t)
       if (mode == 1) g += 2 * weight * (t->ev[a] * t->uv[u] + t->ea[a] * t->ua[u]);
       t->Gi[a][u] = g;
     }
+  }
+  if (nz > 0) {  // HaxInv by Gauss-Jordan with partial pivoting (Hax is symmetric positive definite)
+    double G[kNZ][2 * kNZ];
+    for (int a = 0; a < nz; a++) for (int b = 0; b < nz; b++) { G[a][b] = t->Hax[a][b]; G[a][nz + b] = (a == b) ? 1.0 : 0.0; }
+    for (int c = 0; c < nz; c++) {
+      int piv = c; for (int r = c + 1; r < nz; r++) if (std::fabs(G[r][c]) > std::fabs(G[piv][c])) piv = r;
+      if (piv != c) for (int j = 0; j < 2 * nz; j++) std::swap(G[c][j], G[piv][j]);
+      const double d = G[c][c];
+      for (int j = 0; j < 2 * nz; j++) G[c][j] /= d;
+      for (int r = 0; r < nz; r++) if (r != c) { const double f = G[r][c]; if (f != 0.0) for (int j = 0; j < 2 * nz; j++) G[r][j] -= f * G[c][j]; }
+    }
+    for (int a = 0; a < nz; a++) for (int b = 0; b < nz; b++) t->HaxInv[a][b] = G[a][nz + b];
   }
 }
 

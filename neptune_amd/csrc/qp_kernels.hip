@@ -47,10 +47,10 @@ constexpr double kSlackFloor = 0.1, kMu0 = 2.0;
 #define NEP_STEPFRAC_MAX 0.99999
 #endif
 constexpr double kStepFracMin = 0.999, kStepFracMax = NEP_STEPFRAC_MAX;
-// offsets (doubles) inside QpTable's tail Gi, ep, ev, ea, up, uv, ua, Nt, Pp, res_u, Zp
-constexpr int tGi = 0, tUp = 48, tUv = 51, tUa = 54, tNt = 57, tPp = 121, tResU = 145, tZp = 151, kSmallTab = 151 + kNZ * 4 * kMaxK;
+// offsets (doubles) inside QpTable's tail Gi, ep, ev, ea, up, uv, ua, Nt, Pp, res_u, Zp, HaxInv
+constexpr int tGi = 0, tUp = 48, tUv = 51, tUa = 54, tNt = 57, tPp = 121, tResU = 145, tZp = 151, tHi = 151 + kNZ * 4 * kMaxK, kSmallTab = tHi + kNZ * kNZ;
 static_assert(offsetof(QpTable, up) - offsetof(QpTable, Gi) == tUp * 8 && offsetof(QpTable, Nt) - offsetof(QpTable, Gi) == tNt * 8 &&
-              offsetof(QpTable, Pp) - offsetof(QpTable, Gi) == tPp * 8 && offsetof(QpTable, res_u) - offsetof(QpTable, Gi) == tResU * 8 && offsetof(QpTable, Zp) - offsetof(QpTable, Gi) == tZp * 8 &&
+              offsetof(QpTable, Pp) - offsetof(QpTable, Gi) == tPp * 8 && offsetof(QpTable, res_u) - offsetof(QpTable, Gi) == tResU * 8 && offsetof(QpTable, Zp) - offsetof(QpTable, Gi) == tZp * 8 && offsetof(QpTable, HaxInv) - offsetof(QpTable, Gi) == tHi * 8 &&
               sizeof(QpTable) - offsetof(QpTable, Gi) == kSmallTab * 8, "QpTable tail layout");
 
 // ---- LDS carve (in doubles) -------------------------------------------------------------------
@@ -497,6 +497,40 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         for (int c = 0; c < kNZ; c++) v = __builtin_fma(sB[rho * SBS + c], vec[ax * nz + (c < nz ? c : nz - 1)], v);
         return v;
       };
+      // Presolve (only with nep_batch_set_line_cull on): the minimiser of the cost without any inequality row, z* =
+      // -Hax^-1 g per axis.  If every row holds there (and the terminal ball, if present), z* with zero multipliers
+      // satisfies the KKT conditions of the full problem: it IS the optimum and no interior-point iteration is needed.
+      // Far lines are then checked by the usual pass after the solve.  One extra row pass when the test fails.
+      bool uncon = false;
+      if constexpr (CULL) {
+        if (tid < n) {
+          const int ax = tid / nz, c = tid % nz;
+          double v = 0;
+          for (int e = 0; e < nz; e++) v -= sM[tHi + c * kNZ + e] * sG[ax * nz + e];
+          sDx[tid] = v;
+        }
+        __syncthreads();
+        double viol = -1.0, o_share = 0, d1 = 0, d2 = 0;
+        if (has_box) { const double a = sOff[brho * 3 + bax] + proj(brho, bax, sDx); viol = fmax(a - bhi, blo - a); }
+        {
+          const double cx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sDx) : 0.0, cy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sDx) : 0.0;
+          for_lines4([&](bool ok, int, double n1, double n2, double h, double, double) { viol = fmax(viol, ok ? (n1 * cx + n2 * cy) - h : -1.0); });
+        }
+        if (tid == BS - 1 && has_qc) {
+          double c = -0.10 * 0.10;
+          for (int ax = 0; ax < 3; ax++) { double pe = sc[sPe0 + ax]; for (int e = 0; e < nz; e++) pe += sEp[e] * sDx[ax * nz + e]; c += pe * pe; }
+          viol = fmax(viol, c);
+        }
+        if (tid < n) {   // this coordinate's share of the objective at z*
+          const int ax = tid / nz, c = tid % nz;
+          double hz = 0;
+          for (int e = 0; e < nz; e++) hz += sHax[c * kNZ + e] * sDx[ax * nz + e];
+          o_share = sDx[tid] * (0.5 * hz + sG[tid]);
+        }
+        block_reduce4(viol, o_share, d1, d2, sRed);
+        uncon = viol <= 0.0;
+        if (uncon) { if (tid < n) sZ[tid] = sDx[tid]; if (tid == 0) sc[sObj] = sc[sObj0] + o_share; }
+      }
       double cpb = has_box ? sOff[brho * 3 + bax] + proj(brho, bax, sZ) : 0.0, uab = 0.0, udb = 0.0;
       double cpx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sZ) : 0.0, cpy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sZ) : 0.0;
       double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
@@ -536,7 +570,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 #ifdef NEP_PROFILE_PHASES
       if (prof) tph[10] -= clock64();     // [10]: cycles inside the iteration loops
 #endif
-      for (it = 0; it < kMaxIt; it++) {
+      for (it = 0; it < kMaxIt && !uncon; it++) {
 #ifdef NEP_PROFILE_PHASES
         if (prof) tlast = clock64();
 #endif
@@ -841,6 +875,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 #ifdef NEP_PROFILE_PHASES
       if (prof) tph[10] += clock64();
 #endif
+      if (uncon) converged = true;
       if (!converged && sI[16]) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
     }
     iters_total = it; if (mode == 0) iters_first = it;

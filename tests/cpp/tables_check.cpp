@@ -2,6 +2,7 @@
 //   * Zp Th = I            (Zp is the left inverse the start point uses)
 //   * theta = Th z + ThU init is C2-continuous, starts at init and, in mode 0, ends with v = a = 0
 //   * projecting a feasible theta gives its z back
+//   * Hax HaxInv = I
 // Prints "ok" or the first violation; tests/test_abi.py compiles and runs it (no GPU, no HIP).
 #include <cmath>
 #include <cstdio>
@@ -20,6 +21,10 @@ int main() {
       const double e = std::fabs(v - (a == b ? 1.0 : 0.0));
       if (e > worst) worst = e;
       if (e > 1e-9) { std::printf("Zp Th != I at K=%d mode=%d (%d,%d): %g\n", K, mode, a, b, v); return 1; }
+    }
+    for (int a = 0; a < nz; a++) for (int b = 0; b < nz; b++) {   // HaxInv is the inverse of Hax (the presolve's unconstrained minimiser)
+      double v = 0; for (int c = 0; c < nz; c++) v += t.Hax[a][c] * t.HaxInv[c][b];
+      if (std::fabs(v - (a == b ? 1.0 : 0.0)) > 1e-9) { std::printf("Hax HaxInv != I at K=%d mode=%d (%d,%d): %g\n", K, mode, a, b, v); return 1; }
     }
     // a feasible theta from a pseudo-random z and init
     double z[nep::kNZ], init[3] = {0.3, -1.1, 2.0}, th[4 * nep::kMaxK];

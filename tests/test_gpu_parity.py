@@ -543,6 +543,10 @@ def test_line_presolve_leaves_the_optimum_unchanged(be, oracle, n_agents, n_stat
         assert cut["stats"]["n_rows"].sum() < 0.6 * full["stats"]["n_rows"].sum()
     ok = full["stats"]["status"] != abi.NEP_FAILED
     assert np.abs(np.array(cut["coeff"])[ok] - np.array(full["coeff"])[ok]).max() <= 1e-7
+    assert (full["stats"]["iters"][ok] > 0).all()
+    if n_agents == 64:        # the presolve's other half: replans whose unconstrained minimiser is feasible need no iteration
+        assert (cut["stats"]["iters"][ok] == 0).sum() > N // 2
+        assert np.abs(cut["stats"]["objective"][ok] - full["stats"]["objective"][ok]).max() <= 1e-7 * (1 + np.abs(full["stats"]["objective"][ok]).max())
     for a in range(0, N, max(1, N // 8)):                                                # and against the oracle
         r = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"])
         K = int(cut[a]["K"])
