@@ -44,6 +44,17 @@ def algorithmic_bytes(p, sc, hull_nv, n_states):
     return guess + hull + statics + bases + out
 
 
+def algorithmic_flops(K, lines_mean, vertices_mean, iters_mean):
+    """fp64 operations of one replan by SURVEY.md §8d's count: separator L (V+4) 3 2 I_lp with I_lp = 10; QP per
+    interior-point iteration m n^2 + n^3/3 + 4 m n for the (x, y) system (n = 2K, m = 32K + 4L) and the z system
+    (n = K, m = 16K)."""
+    L = lines_mean
+    sep = L * (vertices_mean + 4) * 3 * 2 * 10
+    n_xy, m_xy, n_z, m_z = 2 * K, 32 * K + 4 * L, K, 16 * K
+    per_iter = (m_xy * n_xy ** 2 + n_xy ** 3 / 3 + 4 * m_xy * n_xy) + (m_z * n_z ** 2 + n_z ** 3 / 3 + 4 * m_z * n_z)
+    return sep + iters_mean * per_iter
+
+
 def measured_traffic(kernel="nep::qp_kernel"):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
     same command (profiles/): FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled as
@@ -271,15 +282,18 @@ def main():
         b.enable_timing(True)
         b.reset_timing()
     safety_ev.clear(); hull_ev.clear(); gather_ev.clear()
+    step_ev = [ev()]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        step_ev.append(ev())
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
+    step_ms = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)])   # GPU time of each step (this rank)
 
     def mean_ms(pairs):
         return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else 0.0
@@ -347,6 +361,11 @@ def main():
         bytes_per_replan = algorithmic_bytes(p, scene0, hn, n_states)
         launch_replans = Sc * n_local
         achieved = bytes_per_replan * launch_replans / (qp_ms * 1e-3) / 1e9 if qp_ms > 0 else 0.0
+        K8 = int(sol[0]["K"])
+        flops = algorithmic_flops(K8, float(sol["stats"]["n_lines"].mean()), float(hn[:, :K8][hn[:, :K8] > 0].mean()) if (hn[:, :K8] > 0).any() else 4.0, float(iters.mean()))
+        fp64_ach = flops * launch_replans / (qp_ms * 1e-3) / 1e12 if qp_ms > 0 else 0.0
+        fp64 = {"bound": "fp64 vector (reported next to the HBM roofline, SURVEY 8d)", "achieved": fp64_ach, "peak": 78.6, "unit": "TFLOP/s",
+                "frac": fp64_ach / 78.6, "algorithmic_flops_per_replan": flops}
         if world == 1:
             sharding = "one GPU: all %d agents of every scene" % N
         elif sharded_hulls:
@@ -374,6 +393,8 @@ def main():
                        "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum()),
                        "rows_solved_mean": float(sol["stats"]["n_rows"].mean()), "line_cull_radius": args.cull_radius},
             "p50_solve_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),
+            # every replan of a step completes with its batch: the per-replan solve time is the step's GPU time
+            "step_ms": {"p50": float(np.percentile(step_ms, 50)), "p99": float(np.percentile(step_ms, 99)), "max": float(step_ms.max())},
             "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange_wait": mean_ms(gather_ev),
                           "launches": n_launch, "launches_per_step": C},
             "frontend": ({"ms": mean_ms(fe_ev), "beam_width": args.beam,
@@ -390,6 +411,7 @@ def main():
                          "algorithmic_bytes_per_replan": bytes_per_replan, "replans_per_launch": launch_replans,
                          "note": "latency-bound path: ~%d dependent interior-point iterations per replan" % round(float(iters.mean()))},
             "presolve": presolve,
+            "roofline_fp64": fp64,
             "reference_budget": "reference TimeLimit 0.05 s/solve, replan timer 20 Hz/agent => <= %d replans/s for %d agents" % (20 * N, N),
         }
         if not args.no_cpu_baseline and world == 1:

@@ -11,7 +11,7 @@ if os.environ.get("NEP_CULL"): bb.set_line_cull(float(os.environ["NEP_CULL"]))
 dc = bb.to_device(sc["committed"]); dg = bb.to_device(sc["guesses"])
 for _ in range(3): bb.replan(dc, dg)
 names = ["A rows(update+resid)", "B combine+qc", "C rd+M assembly", "D conv test", "E cholesky", "F pred solve+Ua", "G P2 affine", "H P4 corr rhs", "I corr solve+Ud", "J P5 step+z"]
-for slot in (0, 1):
+for slot in (0, 1, 2, 3):
     c = bb.debug_phase_cycles(slot); it = max(c[12], 1)
     tot = sum(c[:10])
     print("   loop cycles %d, workgroup lifetime %d (outside the loops %d: line gather %d, mode staging+decode %d, start point %d, rest (verify, theta, states) %d)" % (c[10], c[11], c[11] - c[10], c[13], c[14], c[15], c[11] - c[10] - c[13] - c[14] - c[15]))
