@@ -11,11 +11,21 @@ S = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 use_fe = not os.environ.get("NEP_NO_FRONTEND")
 
 
+def tighten(p):
+    """NEP_VMAX / NEP_AMAX: tighter bounds than the scenes were made for (many active rows, relaxed and failed solves)"""
+    if os.environ.get("NEP_VMAX"):
+        p.v_max = float(os.environ["NEP_VMAX"])
+    if os.environ.get("NEP_AMAX"):
+        p.a_max = float(os.environ["NEP_AMAX"])
+    return p
+
+
 def oracle_one(job):
     seed, a, g = job
     from neptune_amd import scene
     from oracle import oracle
     sc = scene.make_scene(N, M, seed=SEED0 + seed)
+    tighten(sc["par"])
     statics = scene.make_scene(N, M, seed=SEED0)["statics"]
     r = oracle.replan(sc["par"], a + 1, sc["committed"], g, statics)
     return seed, a, r["status"], r["iters"], r["objective"], np.array(r["coeff"])
@@ -26,7 +36,7 @@ def main():
     from neptune_amd import abi, dist as ndist, scene
     from neptune_amd.backend import BatchBackend
     scs = [scene.make_scene(N, M, seed=SEED0 + s) for s in range(S)]
-    p = scs[0]["par"]
+    p = tighten(scs[0]["par"])
     com, gue = ndist.stack_scenes(scs)
     be = BatchBackend(p, scs[0]["statics"], n_scenes=S)
     d_com = be.to_device(com); d_gue = be.to_device(gue)
@@ -58,6 +68,10 @@ def main():
         if worst is None or d > worst[0]:
             worst = (d, seed, a, int(so["stats"]["iters"]), iters)
     dco = np.array(dco); dob = np.array(dob); dpos = np.array(dpos)
+    if len(dco) == 0:
+        print("replans compared 0 (status mismatches %d): nothing solved on either side" % st_bad)
+        return
+    print("statuses on the device: ok %d relaxed %d failed %d" % tuple(np.bincount(sol["stats"]["status"].astype(int), minlength=3)[:3]))
     print("replans compared %d (status mismatches %d) | coeff diff: p50 %.2e p99 %.2e max %.2e, > 1e-6: %d, > 1e-5: %d | position diff along the trajectories: p99 %.2e max %.2e m | rel cost diff max %.2e | worst (diff, scene, agent, gpu iters, oracle iters) %s"
           % (len(dco), st_bad, np.percentile(dco, 50), np.percentile(dco, 99), dco.max(), int((dco > 1e-6).sum()), int((dco > 1e-5).sum()), np.percentile(dpos, 99), dpos.max(), dob.max(), worst))
 
