@@ -485,11 +485,12 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   /* start at the projection of the guess */
   for (int c = 0; c < ny; c++) { double v = 0; for (int i = 0; i < n; i++) v += Z[i * ny + c] * (th[i] - thp[i]); y[c] = v; }
   /* start point of the rows (slack floor, mu0): development knobs, defaults = what the kernel uses */
+  /* the solver's constants, overridable for experiments (read per solve, not per iteration) */
   const double EXP_FLOOR = getenv("ORC_EXP_FLOOR") ? atof(getenv("ORC_EXP_FLOOR")) : 0.1;
   const double EXP_MU0 = getenv("ORC_EXP_MU0") ? atof(getenv("ORC_EXP_MU0")) : 2.0;
   const double EXP_TAU = getenv("ORC_EXP_TAU") ? atof(getenv("ORC_EXP_TAU")) : 0.99999;
   const double EXP_GAPTOL = getenv("ORC_EXP_GAPTOL") ? atof(getenv("ORC_EXP_GAPTOL")) : 1e-10;
-  const double EXP_SIGPOW = getenv("ORC_EXP_SIGPOW") ? atof(getenv("ORC_EXP_SIGPOW")) : 3.0;
+  const int trace = getenv("ORC_QP_TRACE") != NULL;
   double* s = (double*)malloc(sizeof(double) * (mt + 1) * 10);
   double* lam = s + (mt + 1), *ds = lam + (mt + 1), *dl = ds + (mt + 1), *rp = dl + (mt + 1), *rc = rp + (mt + 1),
          *w = rc + (mt + 1), *gdx = w + (mt + 1), *dsa = gdx + (mt + 1), *dla = dsa + (mt + 1);
@@ -509,7 +510,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     for (int a = 0; a < ny; a++) if (fabs(rd[a]) > nrd) nrd = fabs(rd[a]);
     double obj = obj0; for (int a = 0; a < ny; a++) { double v = 0; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; obj += 0.5 * y[a] * v + qy[a] * y[a]; }
     double gap = mu * mt;
-    if (nrp <= 1e-9 && nrd <= 1e-9 * qscale && gap <= EXP_GAPTOL * (1.0 + fabs(obj)) && !getenv("ORC_EXP_NOSTOP")) { ret = 0; break; }
+    if (nrp <= 1e-9 && nrd <= 1e-9 * qscale && gap <= EXP_GAPTOL * (1.0 + fabs(obj))) { ret = 0; break; }
     /* Loosely converged iterates: keep the one closest to the strict tolerances (merit <= 1 is the strict test) and stop three
        iterations after the first of them: with mu that small the weights lam/s amplify the rounding of the row activities into
        rd, so an iteration that has not passed the strict test by then never will */
@@ -521,13 +522,9 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
         const int last = first_loose >= 0 && it - first_loose >= 3;
         if (first_loose < 0) first_loose = it;
         if (better) { loose_ok = 1; best_merit = merit; memcpy(yl, y, sizeof(double) * ny); }
-        if (last && !getenv("ORC_EXP_NOSTOP")) break;          /* the snapshot (possibly this very iterate) is the answer */
+        if (last) break;          /* the snapshot (possibly this very iterate) is the answer */
       }
     }
-    /* Primal residuals a tenth of the tolerance or less are taken as zero in the Newton step: recomputed as a + s - h they
-       carry the ~1e-14 cancellation error of activities of tens of metres, which the weights lam/s (1e12 and more near the
-       end) would amplify into the duals and from there into the dual residual */
-    if (nrp <= (getenv("ORC_EXP_RPTHR") ? atof(getenv("ORC_EXP_RPTHR")) : 1e-10)) for (int r = 0; r < mt; r++) rp[r] = 0.0;
     for (int i = 0; i < ny * ny; i++) M[i] = Py[i];
     for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; w[r] = lam[r] / s[r]; for (int a = 0; a < ny; a++) { double wa = w[r] * g[a]; for (int b = 0; b <= a; b++) M[a * ny + b] += wa * g[b]; } }
     for (int a = 0; a < ny; a++) for (int b = a + 1; b < ny; b++) M[a * ny + b] = M[b * ny + a];
@@ -555,7 +552,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       if (pass == 0) {
         double mua = 0; for (int r = 0; r < mt; r++) mua += (s[r] + alpha * ds[r]) * (lam[r] + alpha * dl[r]);
         mua /= (mt > 0 ? mt : 1);
-        double rr = mua / mu; sigma = pow(rr, EXP_SIGPOW);
+        double rr = mua / mu; sigma = rr * rr * rr;
         for (int r = 0; r < mt; r++) { dsa[r] = ds[r]; dla[r] = dl[r]; }
       }
     }
@@ -563,7 +560,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       if (tau < 0.999) tau = 0.999;
       if (tau > EXP_TAU) tau = EXP_TAU;
       alpha *= tau; if (alpha > 1.0) alpha = 1.0; }
-    if (getenv("ORC_QP_TRACE")) fprintf(stderr, "it %2d nrp %.3e nrd %.3e (qs %.3e) gap %.3e obj %.9g sigma %.3e alpha %.3e loose %d\n", it, nrp, nrd, qscale, gap, obj, sigma, alpha, loose_ok);
+    if (trace) fprintf(stderr, "it %2d nrp %.3e nrd %.3e (qs %.3e) gap %.3e obj %.9g sigma %.3e alpha %.3e loose %d\n", it, nrp, nrd, qscale, gap, obj, sigma, alpha, loose_ok);
     if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;
     for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];
     for (int r = 0; r < mt; r++) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; }
