@@ -36,7 +36,7 @@ constexpr int SBS = 9;            // LDS row stride of the base-row table B (8 u
 constexpr int MS = 25;            // LDS row stride of the normal matrix (n <= 24; odd -> no bank conflicts)
 constexpr int kMaxIt = 60;
 // start point of the rows: slack = max(h - a.x0, kSlackFloor), lambda = kMu0 / slack.  Chosen on this path's two kinds of
-// guesses (oracle sweep, DESIGN §6): 1 / 1 needs 11.3 iterations on front-end guesses and 5.8 on near-optimal ones, 0.1 / 2
+// guesses (oracle sweep, DESIGN §4): 1 / 1 needs 11.3 iterations on front-end guesses and 5.8 on near-optimal ones, 0.1 / 2
 // needs 8.6 and 6.1.
 constexpr double kSlackFloor = 0.1, kMu0 = 2.0;
 // fraction of the step to the boundary: 1 - mu clamped to [0.999, 0.99999].  The late iterations shrink the residuals by
