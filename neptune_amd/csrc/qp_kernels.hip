@@ -596,11 +596,13 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         for_lines4([&](bool ok, int l, double n1, double n2, double h, double s, double lam) {
           double an;
           rowA(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, an);
-          STw(l, lk, 0, ok ? s : 1.0); STw(l, lk, 1, ok ? lam : 1.0);   // the dummy line of a padded tail stays (1,1)
+          // The dummy line of a padded tail is (n1, n2, h, s, lambda) = (0, 0, 1, 1, 1): its activity and step are exactly zero,
+          // so its slack stays 1, its residual 0 and everything it adds below is multiplied by n = 0 — only its multiplier
+          // (which would drift) and its s*lambda need masking.
+          STw(l, lk, 0, s); STw(l, lk, 1, ok ? lam : 1.0);
           const double rp = an + s - h, w = lam * frcp(s), v = lam - w * rp;
-          nrp = fmax(nrp, ok ? fabs(rp) : 0.0); sumsl += ok ? s * lam : 0.0;
-          const double lm = ok ? lam : 0.0, wm = ok ? w : 0.0, vm = ok ? v : 0.0;
-          lTx += lm * n1; lTy += lm * n2; lDxx += wm * n1 * n1; lDxy += wm * n1 * n2; lDyy += wm * n2 * n2; l1x += vm * n1; l1y += vm * n2;
+          nrp = fmax(nrp, fabs(rp)); sumsl += ok ? s * lam : 0.0;
+          lTx += lam * n1; lTy += lam * n2; lDxx += w * n1 * n1; lDxy += w * n1 * n2; lDyy += w * n2 * n2; l1x += v * n1; l1y += v * n2;
         });
         cpb = __builtin_fma(alpha_prev, udb, cpb); cpx = __builtin_fma(alpha_prev, udx, cpx); cpy = __builtin_fma(alpha_prev, udy, cpy);   // base rows move with the step
         lTx = slice_sum(lTx); lTy = slice_sum(lTy); lDxx = slice_sum(lDxx); lDxy = slice_sum(lDxy); lDyy = slice_sum(lDyy); l1x = slice_sum(l1x); l1y = slice_sum(l1y);
@@ -763,8 +765,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           auto rowP2 = [&](bool ok, double s, double lam, double a, double ga, double h, double& va, double& vb) {
             const double rp = a + s - h, is = frcp(s), w = lam * is;
             const double dsa = -rp - ga, q = dsa * is, dla = -__builtin_fma(w, dsa, lam);
-            rmax = fmax(rmax, ok ? fmax(-q, 1.0 + q) : 0.0);
-            c2 += ok ? dsa * dla : 0.0;
+            rmax = fmax(rmax, fmax(-q, 1.0 + q));   // (the dummy line gives exactly 1, which the test rmax > 1 ignores, and dsa = 0)
+            c2 += dsa * dla;
             va = __builtin_fma(q, dla, lam) - w * rp; vb = is;
           };
           if (has_box) {
