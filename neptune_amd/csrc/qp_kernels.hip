@@ -82,6 +82,11 @@ constexpr int kFixedDoubles = (oFixedEnd + 1) & ~1;
 enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2, sBestMerit };
 
 size_t qp_lds_fixed_bytes() { return (size_t)kFixedDoubles * sizeof(double) + 64 * sizeof(int); }
+// Line stride of the carve that lets two workgroups share a CU (backend.hip::size_scratch's l_half, rounded the same way):
+// the normal case, instantiated with the stride as a compile-time constant so that the row passes' LDS accesses take
+// immediate offsets instead of one address add each.
+constexpr int kLdsLinesHalf = (int)(((((160 * 1024 / 2) - (kFixedDoubles * 8 + 64 * 4)) / (11 * 8) - 2) + 1) & ~1);
+constexpr int kLLHalf = kLdsLinesHalf + 2;
 
 // Cross-lane primitives on the VALU (DPP) and scalar (v_readlane) paths: HIP's __shfl* go through
 // ds_bpermute (an LDS round trip per 32-bit half), which dominated the first version's reductions
@@ -351,14 +356,16 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 
   status = NEP_FAILED; iters_total = 0; iters_first = 0; objective = 0.0;
 
-  auto run = [&](auto lds_tag) {
+  auto run = [&](auto lds_tag, auto ll_tag) {
   constexpr bool LDSL = decltype(lds_tag)::value;
+  constexpr int LLC = decltype(ll_tag)::value;
+  const int LLe = LLC > 0 ? LLC : LL;         // (a constant in the common instantiation)
   // c: 0 n1, 1 n2, 2 h            (line coefficient)
-  auto LNr = [&](int l, int c) -> double { if constexpr (LDSL) return ldyn[c * LL + l]; else return gsp[c * GL + l]; };
-  auto LNw = [&](int l, int c, double v) { if constexpr (LDSL) ldyn[c * LL + l] = v; else gsp[c * GL + l] = v; };
+  auto LNr = [&](int l, int c) -> double { if constexpr (LDSL) return ldyn[c * LLe + l]; else return gsp[c * GL + l]; };
+  auto LNw = [&](int l, int c, double v) { if constexpr (LDSL) ldyn[c * LLe + l] = v; else gsp[c * GL + l] = v; };
   // c: 0 s, 1 lambda; k: control point of the segment
-  auto STr = [&](int l, int k, int c) -> double { if constexpr (LDSL) return ldyn[(3 + c * 4 + k) * LL + l]; else return gsp[(3 + c * 4 + k) * GL + l]; };
-  auto STw = [&](int l, int k, int c, double v) { if constexpr (LDSL) ldyn[(3 + c * 4 + k) * LL + l] = v; else gsp[(3 + c * 4 + k) * GL + l] = v; };
+  auto STr = [&](int l, int k, int c) -> double { if constexpr (LDSL) return ldyn[(3 + c * 4 + k) * LLe + l]; else return gsp[(3 + c * 4 + k) * GL + l]; };
+  auto STw = [&](int l, int k, int c, double v) { if constexpr (LDSL) ldyn[(3 + c * 4 + k) * LLe + l] = v; else gsp[(3 + c * 4 + k) * GL + l] = v; };
   // gather the separator's buckets into one segment-major list (one flat loop: a loop per segment costs a global
   // round trip each)
   for (int e = tid; e < L; e += BS) {
@@ -370,7 +377,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     const long q = l < cn ? l : (long)sp.lines_cap - 1 - (l - cn);      // near lines from the front, far ones from the back
     LNw(e, 0, src[3 * q]); LNw(e, 1, src[3 * q + 1]); LNw(e, 2, 1.0 - src[3 * q + 2]);
   }
-  const int LD = (LDSL ? LL : GL) - 1;   // dummy line: harmless operands for the padded tail of a row group
+  const int LD = (LDSL ? LLe : GL) - 1;   // dummy line: harmless operands for the padded tail of a row group
   if (tid < 4) { STw(LD, tid, 0, 1.0); STw(LD, tid, 1, 1.0); if (tid == 0) { LNw(LD, 0, 0.0); LNw(LD, 1, 0.0); LNw(LD, 2, 1.0); } }
   __syncthreads();
   // This thread's line rows, four independent rows at a time (loads first, then the four bodies:
@@ -899,7 +906,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     }
   }
   };   // run
-  if (L <= ps.lds_lines) run(std::true_type{}); else run(std::false_type{});
+  if (L <= ps.lds_lines) { if (LL == kLLHalf) run(std::true_type{}, std::integral_constant<int, kLLHalf>{}); else run(std::true_type{}, std::integral_constant<int, 0>{}); }
+  else run(std::false_type{}, std::integral_constant<int, 0>{});
   __syncthreads();
   if (!CULL) return false;
   if (use_far || sI[41] == 0 || status == NEP_FAILED) return false;
