@@ -10,7 +10,12 @@ static polytope obstacles, K = 8 segments, reference yaml parameters, 32 seeded 
 §8d) in flight per GPU per step.  One step = one bulk-synchronous round: every agent of every scene
 does one full back-end replan (MINVO hulls of the other agents' committed trajectories ->
 separating-line LPs -> spline QP -> sampled states -> committed record); the new trajectories are
-the obstacles of the next step.  Inputs are resident in HBM before the timed region.
+the obstacles of the next step.  Inputs are resident in HBM before the timed region.  Every scene carries its
+own static obstacles (nep_batch_set_scene_statics); the CPU baseline solves the same scenes.
+
+Besides the headline the default command reports two more legs, each timed the same way: `presolve` (the
+verified row presolve on) and `chain` (front-end beam search -> separating lines -> QP -> post-solve safety check
+and commit, i.e. the guesses are made on the device instead of being read from the scene).
 
 N > 1: the agents of every scene are block-sharded by id across the ranks (64/N per GPU) and the
 number of scenes grows with N (32 per GPU), so every GPU does 2048 replans per step at any N:
@@ -120,6 +125,8 @@ def main():
                     help="presolve of the separating-line rows (nep_batch_set_line_cull): lines farther than this many metres "
                          "from the guess are left out of the QP and verified after the solve; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-process-group", action="store_true", help="single GPU: do not create the one-rank RCCL process group")
+    ap.add_argument("--no-chain", action="store_true", help="skip the separately reported front end + safety leg")
     ap.add_argument("--frontend", action="store_true",
                     help="also run the front-end beam search (SURVEY §8f rank 2) in every step: the guesses are made on the device "
                          "from point A and the goal instead of being read from the scene (single GPU)")
@@ -148,6 +155,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     import torch.distributed as tdist
     use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
+    rccl_note = None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
@@ -155,6 +163,16 @@ def main():
             tdist.init_process_group("nccl", device_id=dev)
         else:
             tdist.init_process_group(dist_backend)
+    elif not args.no_process_group:
+        # plain `python bench.py`: a one-rank RCCL process group, so that the single-GPU record also shows the collective
+        # library initialising on the box and the round's all-gather call path running (degenerate: one rank)
+        try:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+            tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            use_dist = True
+        except Exception as e:                                 # never lose the measurement to the extra
+            rccl_note = "one-rank process group not created: %r" % (e,)
 
     # Weak scaling: args.scenes scenes in flight per GPU, so S = scenes * world scenes in total; the
     # agents of EVERY scene are block-sharded over the ranks (configs[3]: 64 agents, 8 per GPU on 8
@@ -165,7 +183,10 @@ def main():
     mine = [scene.make_scene(N, M, seed=s) for s in range(rank * args.scenes, (rank + 1) * args.scenes)]
     scene0 = mine[0] if rank == 0 else scene.make_scene(N, M, seed=0)
     p = scene0["par"]
-    statics = scene0["statics"]          # one static-obstacle set per handle: seed 0's (bases are seed-free)
+    # every scene has its own static obstacles (drawn first from its seed, so any rank can rebuild any scene's set)
+    all_statics = [mine[s - rank * args.scenes]["statics"] if rank * args.scenes <= s < (rank + 1) * args.scenes
+                   else scene.scene_statics(N, M, s, par=p) for s in range(S)]
+    statics = all_statics[0]
     com_l, gue_l = ndist.stack_scenes(mine)
 
     def share(arr):                      # [scenes per GPU][N] per rank -> [S][N] on every rank
@@ -190,8 +211,12 @@ def main():
     # one handle per scene chunk (C == 1: all scenes); chunk k holds scenes [k*Sc, (k+1)*Sc)
     bes = [BatchBackend(p, statics, first_local=first_local, n_local=n_local, n_scenes=Sc, device=dev) for _ in range(C)]
     be = bes[0]
-    for b in bes:
+    for k, b in enumerate(bes):
         b.set_line_cull(args.cull_radius)
+        for s_ in range(Sc):
+            if len(all_statics[k * Sc + s_]) != len(statics):
+                raise SystemExit("scene %d drew %d static obstacles instead of %d" % (k * Sc + s_, len(all_statics[k * Sc + s_]), len(statics)))
+            b.set_scene_statics(s_, all_statics[k * Sc + s_])
     d_committed = be.to_device(com) if C == 1 else None
     d_guess_c = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)]
     d_guess = d_guess_c[0]
@@ -201,7 +226,6 @@ def main():
     d_committed_next = torch.empty_like(d_committed) if args.safety else None
     d_new = torch.empty_like(d_committed) if args.safety else None
     d_accept = torch.zeros(S * N, dtype=torch.int32, device=dev) if args.safety else None
-    d_guess_all = be.to_device(np.ascontiguousarray(gue)) if args.safety else None   # t_start source of the safety pass
     safety_ev, hull_ev, gather_ev, fe_ev = [], [], [], []
     REC = abi.TRAJ_REC_DTYPE.itemsize
     if args.frontend and world > 1 and not (sharded_hulls and not args.safety):
@@ -263,7 +287,7 @@ def main():
             return
         ex.gather(be.d_commit, d_new)                   # everyone's new trajectory
         e0 = ev()
-        be.safety_commit(d_committed, d_new, d_guess if world == 1 else d_guess_all, d_committed_next, d_accept)
+        be.safety_commit(d_committed, d_new, d_guess, d_committed_next, d_accept)      # d_guess: [S][n_local], as passed to the replan
         safety_ev.append((e0, ev()))
         d_committed.copy_(d_committed_next)
         if sharded_hulls:
@@ -352,6 +376,49 @@ def main():
         for b in bes:
             b.set_line_cull(0.0)
 
+    # Third leg (single GPU): the whole chain of one round with the guesses made on the device — front-end beam search
+    # from point A and the goal, separating lines + QP on the same hulls, post-solve safety check and commit.
+    chain = None
+    if world == 1 and not args.no_chain and not args.frontend and not args.safety and C == 1:
+        cfg_fe = scene.frontend_cfg(p, beam_width=args.beam)
+        d_st = be.to_device(np.stack([scene.frontend_starts(s_) for s_ in mine]))
+        d_gfe = torch.zeros_like(d_guess)
+        d_res = torch.zeros(S * N * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+        d_com2 = be.to_device(com); d_nxt = torch.empty_like(d_com2); d_acc = torch.zeros(S * N, dtype=torch.int32, device=dev)
+        fe2, sf2 = [], []
+
+        def chain_step():
+            e0 = ev()
+            be.frontend(cfg_fe, d_com2, d_st, d_gfe, d_res)
+            fe2.append((e0, ev()))
+            be.replan(None, d_gfe)                       # (a failed / empty replan's commit slot carries the record of d_com2 over)
+            e1 = ev()
+            be.safety_commit(d_com2, be.d_commit, d_gfe, d_nxt, d_acc)
+            sf2.append((e1, ev()))
+            d_com2.copy_(d_nxt)
+        for _ in range(max(args.warmup, 2)):
+            chain_step()
+        barrier()
+        be.enable_timing(True); be.reset_timing()
+        fe2.clear(); sf2.clear()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            chain_step()
+        barrier()
+        dt3 = time.perf_counter() - t0
+        qp3, _ = be.kernel_time_ms(2); sep3, _ = be.kernel_time_ms(1)
+        be.enable_timing(False)
+        sol3 = be.solutions(); st3 = sol3["stats"]["status"].astype(int)
+        res3 = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)
+        chain = {"value": replans_per_step * args.steps / dt3, "unit": "replans/s", "ms_per_step": dt3 / args.steps * 1e3,
+                 "kernel_ms": {"frontend_with_hulls": mean_ms(fe2), "separator": sep3, "qp": qp3, "safety": mean_ms(sf2)},
+                 "beam_width": args.beam, "frontend_goal_reached": int((res3["status"] == 1).sum()), "frontend_no_solution": int((res3["status"] == 3).sum()),
+                 "ipm_iters_mean": float(sol3["stats"]["iters"].mean()), "ipm_iters_max": int(sol3["stats"]["iters"].max()),
+                 "status_ok": int((st3 == 0).sum()), "status_relaxed": int((st3 == 1).sum()), "status_failed": int((st3 == 2).sum()),
+                 "lp_failed": int(sol3["stats"]["n_lp_failed"].sum()), "accepted_frac": float(d_acc.float().mean().item()),
+                 "note": "front-end beam search -> separating lines -> QP -> safety check + commit, every step; the guesses are the "
+                         "device-made lattice paths (they end at cruise speed and cut corners around obstacles), not the scene's"}
+
     if rank == 0:
         if C == 1 and not sharded_hulls and not args.frontend:
             _, hn = be.debug_hulls(0)          # vertex counts of scene 0 as the last timed launch saw them
@@ -362,6 +429,32 @@ def main():
         launch_replans = Sc * n_local
         achieved = bytes_per_replan * launch_replans / (qp_ms * 1e-3) / 1e9 if qp_ms > 0 else 0.0
         K8 = int(sol[0]["K"])
+        # the same compulsory bytes split by the kernel that moves them (per replan), each over its own duration
+        Kg = int(scene0["guesses"][0]["K"]); L_mean = float(sol["stats"]["n_lines"].mean())
+        b_guess = 8 * (12 * Kg + (Kg + 1)); b_hull_v = 16.0 * hn[:, :Kg].sum() / N          # one agent's hull vertices
+        b_rec = 8 * (13 * Kg + 1)                                                           # one committed trajectory
+        b_static = 16 * sum(len(s_) for s_ in statics); b_out = 8 * (12 * Kg + 1) + 4 + 96 * n_states
+        per_kernel_bytes = {"hull": (b_rec + b_hull_v) * (Sc * (n_local if sharded_hulls else N)) / launch_replans,   # records in, hull vertices out
+                            "separator": b_guess + b_hull_v * (N - 1) + b_static + 16 * N + 24 * L_mean,          # every other agent's hulls in, lines out
+                            "qp": b_guess + 24 * L_mean + b_out}
+        per_kernel = {}
+        for name, ms_k in (("hull", hull_ms), ("separator", sep_ms), ("qp", qp_ms)):
+            gbs = per_kernel_bytes[name] * launch_replans / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
+            per_kernel[name] = {"bytes_per_replan": per_kernel_bytes[name], "ms": ms_k, "GB/s": gbs, "frac": gbs / 8000.0}
+        seq_gbs = bytes_per_replan * launch_replans / (seq_ms * 1e-3) / 1e9 if seq_ms > 0 else 0.0
+        # active inequality rows at the optimum (scene 0 of the last timed step): which replans are constrained at all
+        active = None
+        if C == 1 and not sharded_hulls:
+            nb_a, nl_a, n_con = [], [], 0
+            for a in range(n_local):
+                Ka = int(sol[a]["K"])
+                if Ka < 1:
+                    continue
+                seg_a, nd_a = be.debug_lines(a)
+                nb, nl = scene.active_rows(p, np.array(sol[a]["coeff"]), Ka, seg_a, nd_a)
+                nb_a.append(nb); nl_a.append(nl); n_con += 1 if (nb + nl) > 0 else 0
+            active = {"sample": "scene 0, %d replans of the last timed step" % len(nb_a), "replans_with_active_rows_frac": n_con / max(len(nb_a), 1),
+                      "active_box_rows_mean": float(np.mean(nb_a)), "active_line_rows_mean": float(np.mean(nl_a)), "tol_m": 1e-6}
         flops = algorithmic_flops(K8, float(sol["stats"]["n_lines"].mean()), float(hn[:, :K8][hn[:, :K8] > 0].mean()) if (hn[:, :K8] > 0).any() else 4.0, float(iters.mean()))
         fp64_ach = flops * launch_replans / (qp_ms * 1e-3) / 1e12 if qp_ms > 0 else 0.0
         fp64 = {"bound": "fp64 vector (reported next to the HBM roofline, SURVEY 8d)", "achieved": fp64_ach, "peak": 78.6, "unit": "TFLOP/s",
@@ -391,7 +484,11 @@ def main():
                        "ipm_iters_mean_by_status": {name: (float(iters[status == k].mean()) if (status == k).any() else None)
                                                     for k, name in ((0, "ok"), (1, "relaxed"), (2, "failed"))},
                        "lines_mean": float(sol["stats"]["n_lines"].mean()), "lp_failed": int(sol["stats"]["n_lp_failed"].sum()),
-                       "rows_solved_mean": float(sol["stats"]["n_rows"].mean()), "line_cull_radius": args.cull_radius},
+                       "rows_solved_mean": float(sol["stats"]["n_rows"].mean()), "line_cull_radius": args.cull_radius,
+                       "lp_failed_note": "separator LPs without a separating line: the constraint is skipped as in the reference "
+                                         "(solver_gurobi_poly.cpp:483-494).  Round 0 has none (scenes are sampled so that every LP is feasible); "
+                                         "later rounds replan the same guesses against the others' optimised trajectories, which may cross them",
+                       "active_rows": active},
             "p50_solve_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),
             # every replan of a step completes with its batch: the per-replan solve time is the step's GPU time
             "step_ms": {"p50": float(np.percentile(step_ms, 50)), "p99": float(np.percentile(step_ms, 99)), "max": float(step_ms.max())},
@@ -409,8 +506,17 @@ def main():
                          # the committed PMC summary is of the default single-GPU command (2 048 replans per launch)
                          "traffic": measured_traffic() if launch_replans == 2048 else None,
                          "algorithmic_bytes_per_replan": bytes_per_replan, "replans_per_launch": launch_replans,
-                         "note": "latency-bound path: ~%d dependent interior-point iterations per replan" % round(float(iters.mean()))},
+                         "sequence": {"achieved": seq_gbs, "frac": seq_gbs / 8000.0, "ms": seq_ms,
+                                      "note": "the whole replan's bytes over the whole launch sequence (hull + separator + qp)"},
+                         "per_kernel": per_kernel,
+                         "note": "achieved = the whole replan's algorithmic bytes (SURVEY 8d) x replans per launch / qp_kernel's duration, as the "
+                                 "contract defines it; most of those bytes (other agents' hull vertices) are read by separator_kernel: per_kernel "
+                                 "gives each kernel's own bytes over its own time.  Latency-bound path: ~%d dependent interior-point "
+                                 "iterations per replan" % round(float(iters.mean()))},
             "presolve": presolve,
+            "chain": chain,
+            "rccl": ({"process_group": "nccl (RCCL), world %d" % world, "initialised": True} if (use_dist and dist_backend == "nccl")
+                     else {"initialised": False, "note": rccl_note or dist_backend}),
             "roofline_fp64": fp64,
             "reference_budget": "reference TimeLimit 0.05 s/solve, replan timer 20 Hz/agent => <= %d replans/s for %d agents" % (20 * N, N),
         }

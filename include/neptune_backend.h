@@ -33,8 +33,9 @@ extern "C" {
 #define NEP_TRAJ_MAX_SEG 16 /* committed trajectory = remainder of previous plan + <= 8 new
                                segments (neptune/src/utils.cpp:318-402)                         */
 #define NEP_HULL_MAX_V 16   /* vertices of one interval hull (V <= 16)              */
-#define NEP_HULL_MAX_CP 12  /* MINVO control points feeding one interval hull: <= 3 committed
-                               segments overlap one planning interval x 4 control points       */
+#define NEP_HULL_MAX_CP 16  /* MINVO control points feeding one interval hull: <= 4 committed
+                               segments overlap one planning interval x 4 control points (a
+                               wave holds their 64 inflated corners); more is NEP_E_CAP        */
 #define NEP_MAX_BEND 8      /* tether bend points kept per agent                               */
 #define NEP_STATE_DOUBLES 12 /* mt::state pos,vel,accel,jerk (mader_types.hpp:35-41)           */
 
@@ -235,6 +236,17 @@ typedef struct nep_solution {
 nep_batch_t* nep_batch_create(const nep_batch_cfg* cfg);
 void nep_batch_destroy(nep_batch_t* h);
 
+/* Static obstacles (nep_batch_cfg and nep_backend_set_static_obst_vert alike): each polygon must be convex with
+ * at most NEP_HULL_MAX_V vertices — what Neptune::setStaticObst hands over (neptune.cpp:639-664).  The separator
+ * works on counter-clockwise polygons; clockwise input is reversed at upload (first vertex kept: it feeds the
+ * proximity cull, solver_gurobi_poly.cpp:559), non-convex input is refused with NEP_E_ARG.  The same holds for the
+ * hull lists of nep_backend_set_hulls.
+ *
+ * nep_batch_set_scene_statics gives scene `scene` (0 <= scene < n_scenes) its own set of n_static == cfg.n_static
+ * polygons (host CSR, copied); scenes never set keep the set of nep_batch_cfg.  Blocking (device synchronize).  */
+int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static, const int32_t* static_off,
+                                const double* static_xy);
+
 /* One full back-end replan for every (scene, local agent) slot, enqueued on `stream`
  * (a hipStream_t passed as void*; NULL = default stream), asynchronous.
  *   d_committed : device, [n_scenes][N] nep_traj_rec — snapshot of every agent's committed
@@ -245,7 +257,13 @@ void nep_batch_destroy(nep_batch_t* h);
  *   d_solution  : device, [n_scenes][n_local] nep_solution                        (out)
  *   d_states    : device, [n_scenes][n_local][max_states][12] or NULL             (out)
  *   d_commit    : device or NULL, [n_scenes][n_local] nep_traj_rec: the new trajectory as the
- *                 record the agent would publish (neptune_ros.cpp:434-480)         (out)      */
+ *                 record the agent would publish (neptune_ros.cpp:434-480)         (out)
+ * A replan that fails (status NEP_FAILED: both solves infeasible, or a guess with K < 1 or K > num_pol — a
+ * front-end miss — which is never solved) publishes nothing, as in the reference (neptune_ros.cpp:651-663): its
+ * d_commit slot receives the agent's PREVIOUS record (from d_committed, or from the records nep_batch_frontend
+ * built this round's hulls from); when neither is known (nep_batch_replan_hulls) the slot is left exactly as the
+ * caller passed it, so hand in the buffer that still holds the previous round's records.  d_solution of such a
+ * slot: status NEP_FAILED, coefficients = the guess (all zero and K = 0 for an unusable guess).              */
 int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess,
                      const void* d_ent, nep_solution* d_solution, double* d_states,
                      nep_traj_rec* d_commit, void* stream);
@@ -306,6 +324,12 @@ int nep_batch_debug_conflicts(nep_batch_t* h, int32_t scene, uint8_t* conflict_o
 
 /* Blocks until everything enqueued by this handle on `stream` has finished. */
 int nep_batch_wait(nep_batch_t* h, void* stream);
+
+/* Blocks like nep_batch_wait, then reports (and clears) capacity overflows the kernels met since the last call:
+ * NEP_E_CAP when a planning interval overlapped more than NEP_HULL_MAX_CP / 4 committed segments or an interval hull
+ * had more than NEP_HULL_MAX_V vertices (the reference uses every segment, neptune.cpp:392-449; the kernels flag the
+ * overflow instead of under-covering silently), else 0.  The asynchronous entry points cannot return this themselves. */
+int nep_batch_check(nep_batch_t* h, void* stream);
 
 /* Average device time (ms) of the dominant kernel over the launches since the last call,
  * measured with HIP events on the launch stream; *n_launch = launches averaged.               */

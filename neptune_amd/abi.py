@@ -10,7 +10,7 @@ import numpy as np
 NEP_MAX_POL = 8
 NEP_TRAJ_MAX_SEG = 16
 NEP_HULL_MAX_V = 16
-NEP_HULL_MAX_CP = 12
+NEP_HULL_MAX_CP = 16
 NEP_MAX_BEND = 8
 NEP_STATE_DOUBLES = 12
 

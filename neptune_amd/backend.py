@@ -265,6 +265,16 @@ class BatchBackend:
         check(lib().nep_batch_safety_commit(self._h, d_prev.data_ptr(), d_new.data_ptr(), d_guess.data_ptr(), d_final.data_ptr(),
                                             d_accept.data_ptr() if d_accept is not None else None, st.cuda_stream))
 
+    def set_scene_statics(self, scene, statics):
+        """scene `scene` gets its own static obstacles (same count as the handle's set; nep_batch_set_scene_statics)"""
+        soff, sxy = _csr(statics)
+        check(lib().nep_batch_set_scene_statics(self._h, scene, len(statics), abi.iptr(soff), abi.dptr(sxy)))
+
+    def check(self, stream=None):
+        """waits for the stream and raises on a capacity overflow met by the kernels (nep_batch_check)"""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_check(self._h, st.cuda_stream))
+
     def set_line_cull(self, radius):
         """presolve: separating lines farther than `radius` metres from the guess are left out of the QP and verified
         afterwards, and a replan whose unconstrained minimiser is feasible returns it without iterating

@@ -41,6 +41,29 @@ template <class T> struct DevBuf {
 
 constexpr size_t kLdsBudget = 150 * 1024;  // of the 160 KiB per CU
 
+// The separator treats hull lists and static obstacles as counter-clockwise convex polygons (only their edges are
+// candidate lines and the polygon's own rows hold by convexity, geom_kernels.hip::separator_impl) — the order CGAL's
+// convex_hull_2 and setStaticObst produce.  The reference LP itself is order-independent (separator_glpk.cpp:248-373),
+// so anything a caller may legally pass is brought to that form at upload: clockwise input is reversed (the first
+// vertex stays first: col(0) feeds the proximity cull, solver_gurobi_poly.cpp:559), non-convex input is refused.
+// Returns false for a polygon that is not convex.
+bool normalize_ccw(double* xy, int n) {
+  if (n < 3) return true;
+  double area2 = 0, scale = 0;
+  for (int v = 0; v < n; v++) {
+    const double* a = xy + 2 * v; const double* b = xy + 2 * ((v + 1) % n);
+    area2 += a[0] * b[1] - a[1] * b[0];
+    scale = std::fmax(scale, std::fmax(std::fabs(a[0]), std::fabs(a[1])));
+  }
+  if (area2 < 0) for (int lo = 1, hi = n - 1; lo < hi; lo++, hi--) { std::swap(xy[2 * lo], xy[2 * hi]); std::swap(xy[2 * lo + 1], xy[2 * hi + 1]); }
+  const double tol = 1e-9 * (1.0 + scale) * (1.0 + scale);
+  for (int v = 0; v < n; v++) {
+    const double* o = xy + 2 * v; const double* a = xy + 2 * ((v + 1) % n); const double* b = xy + 2 * ((v + 2) % n);
+    if ((a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0]) < -tol) return false;
+  }
+  return true;
+}
+
 // Everything both handle kinds share: tables, scratch and the launch sequence of one replan.
 struct Engine {
   SceneParams sp{};
@@ -51,6 +74,7 @@ struct Engine {
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
   DevBuf<long long> d_dbg; bool profile_phases = false;
+  DevBuf<int> d_flags;
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
@@ -116,6 +140,7 @@ struct Engine {
     if (int e = d_line_cnt.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_line_far.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_lp_stats.ensure((size_t)slots * NEP_MAX_POL * 2)) return e;   // per (slot, segment): LPs attempted, LPs without a line
+    if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 16)) return e; }
     if (lines_total > lds_lines) { if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e; }
@@ -130,18 +155,22 @@ struct Engine {
     ps.line_far = sp.cull_radius > 0.0 ? d_line_far.p : nullptr;
     ps.row_scratch = d_row_scratch.p; ps.rows_cap = rows_cap; ps.lds_rows = lds_rows; ps.lds_lines = lds_lines;
     ps.dbg = profile_phases ? d_dbg.p : nullptr;
+    ps.flags = d_flags.p;
   }
-  int upload_statics(int n, const int32_t* off, const double* xy) {
-    std::vector<double> sx((size_t)(n > 0 ? n : 1) * kHullV * 2, 0.0); std::vector<int> nv(n > 0 ? n : 1, 0);
+  // packs n polygons into the fixed-stride device layout (vertices, vertex counts, edge lengths)
+  static int pack_statics(int n, const int32_t* off, const double* xy, std::vector<double>& sx, std::vector<int>& nv, std::vector<double>& el) {
+    sx.assign((size_t)(n > 0 ? n : 1) * kHullV * 2, 0.0); nv.assign(n > 0 ? n : 1, 0);
     for (int j = 0; j < n; j++) {
       int c = off[j + 1] - off[j];
       if (c > kHullV) return fail(NEP_E_CAP, "static obstacle with more than NEP_HULL_MAX_V vertices");
+      if (c < 0) return fail(NEP_E_ARG, "static obstacle offsets must not decrease");
       nv[j] = c;
       for (int v = 0; v < c; v++) { sx[((size_t)j * kHullV + v) * 2] = xy[2 * (off[j] + v)]; sx[((size_t)j * kHullV + v) * 2 + 1] = xy[2 * (off[j] + v) + 1]; }
+      if (!normalize_ccw(&sx[(size_t)j * kHullV * 2], c)) return fail(NEP_E_ARG, "static obstacle polygon is not convex");
     }
     // edge lengths for the proximity cull (solver_gurobi_poly.cpp:566-572), the same IEEE operations the kernel used to
     // repeat per candidate: squares, one sum, sqrt (no contraction: three separate roundings)
-    std::vector<double> el(sx.size() / 2, 0.0);
+    el.assign(sx.size() / 2, 0.0);
     for (int j = 0; j < n; j++)
       for (int v = 0; v + 1 < nv[j]; v++) {
         const double* q = &sx[((size_t)j * kHullV + v) * 2];
@@ -150,13 +179,45 @@ struct Engine {
         volatile double c = a + b;
         el[(size_t)j * kHullV + v] = std::sqrt(c);
       }
+    return 0;
+  }
+  int upload_statics(int n, const int32_t* off, const double* xy) {
+    std::vector<double> sx, el; std::vector<int> nv;
+    if (int e = pack_statics(n, off, xy, sx, nv, el)) return e;
     if (int e = d_static_xy.ensure(sx.size())) return e;
     if (int e = d_static_el.ensure(el.size())) return e;
     if (int e = d_static_nv.ensure(nv.size())) return e;
     HIPCHK(hipMemcpy(d_static_el.p, el.data(), el.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_static_xy.p, sx.data(), sx.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_static_nv.p, nv.data(), nv.size() * sizeof(int), hipMemcpyHostToDevice));
-    sp.n_static = n;
+    sp.n_static = n; sp.static_stride = 0;
+    return 0;
+  }
+  // One static-obstacle set per scene (same polygon count S in every scene): the first call replicates the handle's
+  // shared set into [n_scenes][S] arrays, then scene `scene` gets its own polygons.
+  int upload_scene_statics(int scene, int n, const int32_t* off, const double* xy) {
+    const int S = sp.n_static;
+    if (n != S) return fail(NEP_E_ARG, "every scene must have the handle's n_static polygons");
+    if (S == 0) return 0;
+    std::vector<double> sx, el; std::vector<int> nv;
+    if (int e = pack_statics(n, off, xy, sx, nv, el)) return e;
+    if (sp.static_stride == 0) {
+      DevBuf<double> nxy, nel; DevBuf<int> nnv;
+      if (int e = nxy.ensure((size_t)n_scenes * S * kHullV * 2)) return e;
+      if (int e = nel.ensure((size_t)n_scenes * S * kHullV)) return e;
+      if (int e = nnv.ensure((size_t)n_scenes * S)) return e;
+      for (int s = 0; s < n_scenes; s++) {
+        HIPCHK(hipMemcpy(nxy.p + (size_t)s * S * kHullV * 2, d_static_xy.p, (size_t)S * kHullV * 2 * sizeof(double), hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nel.p + (size_t)s * S * kHullV, d_static_el.p, (size_t)S * kHullV * sizeof(double), hipMemcpyDeviceToDevice));
+        HIPCHK(hipMemcpy(nnv.p + (size_t)s * S, d_static_nv.p, (size_t)S * sizeof(int), hipMemcpyDeviceToDevice));
+      }
+      d_static_xy.release(); d_static_el.release(); d_static_nv.release();
+      d_static_xy = nxy; d_static_el = nel; d_static_nv = nnv;
+      sp.static_stride = S;
+    }
+    HIPCHK(hipMemcpy(d_static_xy.p + (size_t)scene * S * kHullV * 2, sx.data(), (size_t)S * kHullV * 2 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_static_el.p + (size_t)scene * S * kHullV, el.data(), (size_t)S * kHullV * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_static_nv.p + (size_t)scene * S, nv.data(), (size_t)S * sizeof(int), hipMemcpyHostToDevice));
     return 0;
   }
   hipEvent_t next_event() {
@@ -182,7 +243,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release();
-    d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
+    d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
   }
@@ -302,6 +363,7 @@ int nep_backend_set_hulls(nep_backend_t* h, int32_t n_obst, const int32_t* off, 
     if (c > kHullV) return fail(NEP_E_CAP, "hull with more than NEP_HULL_MAX_V vertices");
     h->h_hull_nv[p] = c;
     for (int v = 0; v < c; v++) { h->h_hull_xy[((size_t)p * kHullV + v) * 2] = xy[2 * (off[p] + v)]; h->h_hull_xy[((size_t)p * kHullV + v) * 2 + 1] = xy[2 * (off[p] + v) + 1]; }
+    if (!normalize_ccw(&h->h_hull_xy[(size_t)p * kHullV * 2], c)) return fail(NEP_E_ARG, "hull polygon is not convex");
   }
   h->n_obst = n_obst; h->have_hulls = true;
   return 0;
@@ -506,19 +568,23 @@ int nep_hulls_batch(int32_t n_traj, const nep_traj_rec* trajs, double t_start, i
   if (n_traj < 0 || !trajs || !hull_xy || !hull_nv || !hull0_xy || !hull0_nv || num_pol < 1) return fail(NEP_E_ARG, "bad arguments");
   if (!have_device()) return fail(NEP_E_HIP, "no HIP device: the back end has no CPU path");
   if (n_traj == 0) return 0;
-  DevBuf<nep_traj_rec> dr; DevBuf<double> dh, dh0; DevBuf<int> dn, dn0;
+  DevBuf<nep_traj_rec> dr; DevBuf<double> dh, dh0; DevBuf<int> dn, dn0, dfl;
   const size_t np = (size_t)n_traj * num_pol;
   int e = 0;
-  if ((e = dr.ensure(n_traj)) || (e = dh.ensure(np * kHullV * 2)) || (e = dh0.ensure(np * kHullV * 2)) || (e = dn.ensure(np)) || (e = dn0.ensure(np))) return e;
+  if ((e = dr.ensure(n_traj)) || (e = dh.ensure(np * kHullV * 2)) || (e = dh0.ensure(np * kHullV * 2)) || (e = dn.ensure(np)) || (e = dn0.ensure(np)) || (e = dfl.ensure(1))) return e;
+  HIPCHK(hipMemset(dfl.p, 0, sizeof(int)));
   HIPCHK(hipMemcpy(dr.p, trajs, (size_t)n_traj * sizeof(nep_traj_rec), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(dh.p, 0, np * kHullV * 2 * sizeof(double))); HIPCHK(hipMemset(dh0.p, 0, np * kHullV * 2 * sizeof(double)));
-  launch_hulls_explicit(dr.p, n_traj, t_start, num_pol, T_span, drone_radius, dh.p, dn.p, dh0.p, dn0.p, nullptr);
+  launch_hulls_explicit(dr.p, n_traj, t_start, num_pol, T_span, drone_radius, dh.p, dn.p, dh0.p, dn0.p, dfl.p, nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(hull_xy, dh.p, np * kHullV * 2 * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(hull0_xy, dh0.p, np * kHullV * 2 * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(hull_nv, dn.p, np * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(hull0_nv, dn0.p, np * sizeof(int), hipMemcpyDeviceToHost));
-  dr.release(); dh.release(); dh0.release(); dn.release(); dn0.release();
+  int flags = 0;
+  HIPCHK(hipMemcpy(&flags, dfl.p, sizeof(int), hipMemcpyDeviceToHost));
+  dr.release(); dh.release(); dh0.release(); dn.release(); dn0.release(); dfl.release();
+  if (flags & NEP_FLAG_HULL_OVERFLOW) return fail(NEP_E_CAP, "an interval overlaps more than NEP_HULL_MAX_CP/4 committed segments (or its hull has more than NEP_HULL_MAX_V vertices)");
   return 0;
 }
 
@@ -531,6 +597,7 @@ struct nep_batch {
   Engine eng;
   nep_batch_cfg cfg{};
   int slots = 0;
+  const nep_traj_rec* fe_committed = nullptr;   // the records nep_batch_frontend built this round's hulls from
 };
 
 extern "C" {
@@ -573,6 +640,7 @@ int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_
   ProblemSet ps{};
   E.fill(ps);
   ps.guess = d_guess; ps.solution = d_solution; ps.states = d_states; ps.commit = d_commit;
+  ps.prev_commit = d_committed ? d_committed : h->fe_committed;   // (hulls reused from nep_batch_frontend: its records are this round's previous ones)
   ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
   ps.lines_override = 0;
   // d_committed == NULL: the interval hulls of this round are already in the handle's scratch (nep_batch_frontend)
@@ -647,6 +715,7 @@ int nep_batch_frontend(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec
   Engine& E = h->eng;
   ProblemSet ps{};
   E.fill(ps);
+  h->fe_committed = d_committed;
   launch_hulls_ts(d_committed, h->cfg.n_scenes, h->cfg.num_agents, &d_start->t_start, (long)sizeof(nep_fe_start), E.sp, ps, (hipStream_t)stream);
   launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
@@ -666,6 +735,7 @@ int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* 
   E.fill(ps);
   point_at_block(ps, b, const_cast<void*>(d_blocks));
   ps.hull_pb = h->cfg.n_local; ps.hull_bstride = (long)b.bytes;
+  h->fe_committed = nullptr;
   launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
@@ -687,6 +757,12 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
   return 0;
 }
 
+int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static, const int32_t* static_off, const double* static_xy) {
+  if (!h || scene < 0 || scene >= h->cfg.n_scenes || n_static < 0 || (n_static > 0 && (!static_off || !static_xy))) return fail(NEP_E_ARG, "bad arguments");
+  HIPCHK(hipDeviceSynchronize());     // the previous set may still be read by kernels in flight
+  return h->eng.upload_scene_statics(scene, n_static, static_off, static_xy);
+}
+
 int nep_batch_set_line_cull(nep_batch_t* h, double radius) {
   if (!h || !(radius >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
   h->eng.sp.cull_radius = radius;
@@ -705,6 +781,18 @@ int nep_batch_debug_conflicts(nep_batch_t* h, int32_t scene, uint8_t* conflict_o
 }
 
 int nep_batch_wait(nep_batch_t* h, void* stream) { if (!h) return fail(NEP_E_ARG, "null handle"); HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return 0; }
+
+int nep_batch_check(nep_batch_t* h, void* stream) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  int flags = 0;
+  if (h->eng.d_flags.p) {
+    HIPCHK(hipMemcpy(&flags, h->eng.d_flags.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (flags) HIPCHK(hipMemset(h->eng.d_flags.p, 0, sizeof(int)));
+  }
+  if (flags & NEP_FLAG_HULL_OVERFLOW) return fail(NEP_E_CAP, "an interval overlaps more than NEP_HULL_MAX_CP/4 committed segments (or its hull has more than NEP_HULL_MAX_V vertices)");
+  return 0;
+}
 
 int nep_batch_enable_timing(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.timing = on != 0; h->eng.ev_used = 0; return 0; }
 

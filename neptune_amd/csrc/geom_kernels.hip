@@ -97,7 +97,7 @@ __device__ int wave_hull(int n, double px, double py, double* sxy, double* hxy) 
 // and the uninflated hull of trajectory r over [ts + i T, ts + (i+1) T].  neptune.cpp:349-452.
 __device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, double T_span, double drone_radius,
                           long out, bool full0, double* __restrict__ hull_xy, int* __restrict__ hull_nv,
-                          double* __restrict__ hull0_xy, int* __restrict__ hull0_nv) {
+                          double* __restrict__ hull0_xy, int* __restrict__ hull0_nv, int* __restrict__ flags) {
   __shared__ __attribute__((aligned(16))) double sxy[128], hxy[264];   // hxy: hull [66][2] + upper-chain stack [66][2]
   __shared__ double cpx[kHullCP], cpy[kHullCP], stimes[NEP_TRAJ_MAX_SEG + 2];
   const int lane = threadIdx.x;
@@ -115,7 +115,12 @@ __device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, 
   int last = __popcll(__ballot(inr && tk <= t1)) - 1;
   if (first < 0) first = 0; if (first > n - 1) first = n - 1;
   if (last < 0) last = 0; if (last > n - 1) last = n - 1;
-  int nseg = last - first + 1; if (nseg > kHullCP / 4) nseg = kHullCP / 4; if (nseg < 0) nseg = 0;
+  int nseg = last - first + 1; if (nseg < 0) nseg = 0;
+  // The reference takes every committed segment that overlaps the interval (neptune.cpp:392-449); one wave holds the 4 x 4
+  // inflated control points of NEP_HULL_MAX_CP / 4 segments.  More than that (a trajectory composed of several intervals
+  // shorter than T_span) is a capacity overflow: flagged (NEP_E_CAP from nep_batch_check / nep_hulls_batch), never
+  // silently under-covered.
+  if (nseg > kHullCP / 4) { nseg = kHullCP / 4; if (lane == 0 && flags) atomicOr(flags, NEP_FLAG_HULL_OVERFLOW); }
   const int np0 = 4 * nseg;
   __syncthreads();
   if (lane < 2 * np0) {   // one lane per (segment, control point, axis)
@@ -146,7 +151,7 @@ __device__ void hull_body(const nep_traj_rec* __restrict__ r, double ts, int i, 
     } else { px = cpx[lane]; py = cpy[lane]; }
   }
   int k = wave_hull(np, px, py, sxy, hxy);
-  if (k > kHullV) k = kHullV;
+  if (k > kHullV) { k = kHullV; if (lane == 0 && flags) atomicOr(flags, NEP_FLAG_HULL_OVERFLOW); }
   if (lane < k) { hull_xy[(out * kHullV + lane) * 2] = hxy[2 * lane]; hull_xy[(out * kHullV + lane) * 2 + 1] = hxy[2 * lane + 1]; }
   if (lane == 0) hull_nv[out] = k;
   if (hull0_nv) {
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(64) void hull_kernel(const nep_traj_rec* __restrict
                                                   int num_pol, double T_span, double drone_radius,
                                                   double* __restrict__ hull_xy, int* __restrict__ hull_nv,
                                                   double* __restrict__ hull0_xy, int* __restrict__ hull0_nv,
-                                                  double* __restrict__ bend_xy, int* __restrict__ bend_n) {
+                                                  double* __restrict__ bend_xy, int* __restrict__ bend_n, int* __restrict__ flags) {
   const int lane = threadIdx.x;
   const int i = blockIdx.x % num_pol;
   const int jt = blockIdx.x / num_pol;          // scene*n_rec + j
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(64) void hull_kernel(const nep_traj_rec* __restrict
   }
   // bulk-synchronous round: every agent of a scene replans from the same t_start (that of its first local slot)
   const double ts = *(const double*)((const char*)ts0 + (long)scene * ts_scene_stride);
-  hull_body(r, ts, i, T_span, drone_radius, (long)jt * num_pol + i, false, hull_xy, hull_nv, hull0_xy, hull0_nv);
+  hull_body(r, ts, i, T_span, drone_radius, (long)jt * num_pol + i, false, hull_xy, hull_nv, hull0_xy, hull0_nv, flags);
 }
 
 void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_guess* guess,
@@ -195,7 +200,7 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
   const bool need0 = sp.ent_enabled != 0;
   hipLaunchKernelGGL(hull_kernel, dim3(blocks), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
                      sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
-                     need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr);
+                     need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr, ps.flags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -352,16 +357,16 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     }
     return true;
   } else if (c < nH + N + S) {
-    const int j = c - nH - N;
+    const long j = (long)cx.scene * sp.static_stride + (c - nH - N);
     const int nv = ps.static_nv[j];
     if (nv <= 0) return false;
-    const double* src = ps.static_xy + (long)j * kHullV * 2;
+    const double* src = ps.static_xy + j * kHullV * 2;
     if (!stage) {          // :558-578 (staging is only asked for candidates that passed this test in step 1)
       bool close_s = false;
       const double ddx = bx[0] - src[0], ddy = by[0] - src[1];
       double dist = sqrt(ddx * ddx + ddy * ddy);
       for (int k = 0; k < 3; k++) { dist -= cx.el[k]; if (dist < 0) { close_s = true; break; } }   // (same values as the reference's per-call square roots)
-      for (int k = 0; k < nv - 1 && !close_s; k++) { dist -= ps.static_el[(long)j * kHullV + k]; if (dist < 0) { close_s = true; break; } }
+      for (int k = 0; k < nv - 1 && !close_s; k++) { dist -= ps.static_el[j * kHullV + k]; if (dist < 0) { close_s = true; break; } }
       if (!close_s) return false;
     }
     ordered = true; nA = nv;
@@ -506,8 +511,8 @@ size_t separator_lds_bytes(const SceneParams& sp) {
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
   if (n_slots <= 0) return;
   const size_t lds = separator_lds_bytes(sp);
-  static size_t configured = 0;
-  if (lds > configured) { hipFuncSetAttribute((const void*)separator_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); configured = lds; }
+  static DynLdsAttr attr;
+  (void)attr.ensure((const void*)separator_kernel, lds);
   hipLaunchKernelGGL(separator_kernel, dim3(n_slots * NEP_MAX_POL), dim3(64), lds, st, sp, ps);
 }
 
@@ -540,18 +545,18 @@ void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy,
 __global__ __launch_bounds__(64) void hull_explicit_kernel(const nep_traj_rec* __restrict__ recs, double t_start, int num_pol,
                                                            double T_span, double drone_radius,
                                                            double* __restrict__ hull_xy, int* __restrict__ hull_nv,
-                                                           double* __restrict__ hull0_xy, int* __restrict__ hull0_nv) {
+                                                           double* __restrict__ hull0_xy, int* __restrict__ hull0_nv, int* __restrict__ flags) {
   const int i = blockIdx.x % num_pol;
   const int jt = blockIdx.x / num_pol;
-  hull_body(recs + jt, t_start, i, T_span, drone_radius, (long)jt * num_pol + i, true, hull_xy, hull_nv, hull0_xy, hull0_nv);
+  hull_body(recs + jt, t_start, i, T_span, drone_radius, (long)jt * num_pol + i, true, hull_xy, hull_nv, hull0_xy, hull0_nv, flags);
 }
 
 void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start, int num_pol,
                            double T_span, double drone_radius, double* hull_xy, int* hull_nv,
-                           double* hull0_xy, int* hull0_nv, hipStream_t st) {
+                           double* hull0_xy, int* hull0_nv, int* flags, hipStream_t st) {
   if (n_traj * num_pol <= 0) return;
   hipLaunchKernelGGL(hull_explicit_kernel, dim3(n_traj * num_pol), dim3(64), 0, st, recs, t_start, num_pol, T_span,
-                     drone_radius, hull_xy, hull_nv, hull0_xy, hull0_nv);
+                     drone_radius, hull_xy, hull_nv, hull0_xy, hull0_nv, flags);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -701,11 +706,11 @@ void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_sc
   if (n_scenes * N <= 0) return;
   if (conflict_prev) {   // new trajectories against the hulls of the PREVIOUS records on the same grid
     hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, prev, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
-                       sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr);
+                       sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
     hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, prev, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict_prev);
   }
   hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, fresh, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
-                     sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr);
+                     sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
   hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
   hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, final_out, accept_out);
 }
@@ -946,7 +951,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
       int nv = 0; const double* V = nullptr;
       if (j < N) {
         if (j != own) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
-      } else { nv = ps.static_nv[j - N]; V = ps.static_xy + (long)(j - N) * kHullV * 2; }
+      } else { const long js = (long)scene * sp.static_stride + (j - N); nv = ps.static_nv[js]; V = ps.static_xy + js * kHullV * 2; }
       if (nv <= 0) continue;
       // all sixteen vertex slots in one go (the arrays are [16][2]): a loop over nv would pay one memory
       // round trip per vertex
@@ -986,7 +991,7 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
       if (o < kFeObsLds) return o_V + o * kHullV * 2;
       const int j = o_id[o];
       if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); return blk(ps.hull_xy, hr.boff) + (hr.e * sp.num_pol + idx) * kHullV * 2; }
-      return ps.static_xy + (long)(j - N) * kHullV * 2;
+      return ps.static_xy + ((long)scene * sp.static_stride + (j - N)) * kHullV * 2;
     };
     for (int id = tid; id < n_c; id += 256) {
       const int pr = id / NC, cc = id % NC;
@@ -1159,8 +1164,8 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
                      nep_guess* guess_out, nep_fe_result* res_out, hipStream_t st) {
   if (n_slots <= 0) return;
   const size_t lds = frontend_lds_bytes(sp, fc);
-  static size_t configured = 0;
-  if (lds > configured) { hipFuncSetAttribute((const void*)frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); configured = lds; }
+  static DynLdsAttr attr;
+  (void)attr.ensure((const void*)frontend_kernel, lds);
   hipLaunchKernelGGL(frontend_kernel, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out);
 }
 

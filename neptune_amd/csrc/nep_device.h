@@ -2,13 +2,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "nep_tables.h"
 #include "../../include/neptune_frontend.h"
 
 namespace nep {
 
 constexpr int kHullV = NEP_HULL_MAX_V;   // 16
-constexpr int kHullCP = NEP_HULL_MAX_CP; // 12
+constexpr int kHullCP = NEP_HULL_MAX_CP; // 16
 constexpr int kBend = NEP_MAX_BEND;      // 8
 
 // Scene-level constants (setMaxValues, ctor arguments; solver_gurobi_poly.cpp:25-175)
@@ -23,6 +25,7 @@ struct SceneParams {
   int n_local;        // slots per scene
   int first_local;    // index of first local agent (batch); per-agent mode: id-1
   int skip_own;       // 1: hull list is indexed by agent, own entry skipped
+  int static_stride;  // 0: one static-obstacle set for every scene; S: scene s reads polygons [s*S, (s+1)*S) (nep_batch_set_scene_statics)
   double T_span, weight, dc, drone_radius;
   double mins[3], maxs[3], v_max, a_max;
   double long_length; // solver_gurobi_poly.cpp:173
@@ -34,7 +37,7 @@ struct ProblemSet {
   // inputs
   const nep_guess* guess;        // [slots]
   const double* pb;              // [N][2]
-  const double* static_xy;       // [S][kHullV][2]
+  const double* static_xy;       // [S][kHullV][2]   (x n_scenes when sp.static_stride != 0)
   const int* static_nv;          // [S]
   const double* static_el;       // [S][kHullV] length of edge v -> v+1 (the proximity cull's square roots, taken once at upload)
   const int* case_id;            // [slots][NEP_MAX_POL][N] or null
@@ -65,8 +68,11 @@ struct ProblemSet {
   nep_solution* solution;        // [slots]
   double* states;                // [slots][max_states][12] or null
   nep_traj_rec* commit;          // [slots] or null
+  const nep_traj_rec* prev_commit; // [scenes][N] records before this round, or null: what a failed replan's commit slot carries over
   long long* dbg;                // [slots][16] phase cycle counters (development aid) or null
+  int* flags;                    // [1] sticky NEP_FLAG_* bits raised by the kernels (capacity overflows), or null
 };
+constexpr int NEP_FLAG_HULL_OVERFLOW = 1;   // an interval overlapped more committed segments than NEP_HULL_MAX_CP / 4, or its hull has more than NEP_HULL_MAX_V vertices
 
 // entry index (scene-major inside its block) and byte offset of the block of agent j's hull data
 struct HullRef { long e; long boff; };
@@ -76,6 +82,22 @@ __host__ __device__ inline HullRef hull_ref(const ProblemSet& ps, int per_scene,
   return HullRef{(long)scene * ps.hull_pb + (j - b * ps.hull_pb), (long)b * ps.hull_bstride};
 }
 template <typename T> __host__ __device__ inline T* blk(T* base, long boff) { return (T*)((char*)base + boff); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to a (device, function) pair: the size configured so far is kept
+// per device (handles may live on several GPUs of one process) and updated under a lock (handles may be driven from
+// several host threads).
+struct DynLdsAttr {
+  std::mutex mu; size_t configured[64] = {};
+  hipError_t ensure(const void* fn, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    std::lock_guard<std::mutex> lk(mu);
+    if (bytes <= configured[dev]) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) configured[dev] = bytes;
+    return e;
+  }
+};
 
 struct SampleSched {             // per K: n, seg[], dt[]
   const int* n;                  // [kMaxK+1]
@@ -89,7 +111,7 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
                      const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
 void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start, int num_pol,
                            double T_span, double drone_radius, double* hull_xy, int* hull_nv,
-                           double* hull0_xy, int* hull0_nv, hipStream_t st);
+                           double* hull0_xy, int* hull0_nv, int* flags, hipStream_t st);
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
 void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy, const int* b_off,
                                const double* b_xy, double* nd, int* solved, hipStream_t st);

@@ -272,7 +272,11 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   const int tid = threadIdx.x;
   const int slot = blockIdx.x;
   const nep_guess* __restrict__ g = ps.guess + slot;
-  const int K = g->K;
+  // A guess without segments (front-end miss: K = 0) or with more than the handle plans for cannot be solved: such a slot
+  // reports NEP_FAILED with an empty solution and publishes nothing (neptune_ros.cpp:651-663); K_ok guards every use of K.
+  const int K_in = g->K;
+  const bool K_ok = K_in >= 1 && K_in <= NEP_MAX_POL && K_in <= sp.num_pol;
+  const int K = K_ok ? K_in : 1;
   const double T = sp.T_span, wgt = sp.weight;
   nep_solution* __restrict__ sol = ps.solution + slot;
 
@@ -941,15 +945,16 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   // (one call site: a second inlined copy of the solver body pushes the compiler past its unrolling budget and the
   // row groups' private arrays into scratch)
 #pragma nounroll
-  for (int attempt = 0; attempt < (CULL ? 2 : 1); attempt++) { if (!solve_once(attempt == 1)) break; }
+  for (int attempt = 0; attempt < (CULL ? 2 : 1) && K_ok; attempt++) { if (!solve_once(attempt == 1)) break; }
   __syncthreads();
+  const int Ko = K_ok ? K : 0;      // segments of the output
   // ---- outputs -----------------------------------------------------------------------------------
   if (status == NEP_FAILED) { if (tid < 96) sTheta[tid] = sCoef[tid]; }                    // :856-859
   else if (z_override) { if (tid < 32) sTheta[64 + tid] = sCoef[64 + tid]; }             // :879-880
   __syncthreads();
-  if (tid < 96) (&sol->coeff[0][0][0])[tid] = ((tid % 32) / 4 < K) ? sTheta[tid] : 0.0;
-  if (tid <= NEP_MAX_POL) sol->times[tid] = (tid <= K) ? g->t_start + tid * T : 0.0;       // :898 (times = i*T_span + t_start)
-  const int ns_all = sched.n[K];
+  if (tid < 96) (&sol->coeff[0][0][0])[tid] = ((tid % 32) / 4 < Ko) ? sTheta[tid] : 0.0;
+  if (tid <= NEP_MAX_POL) sol->times[tid] = (tid <= Ko) ? g->t_start + tid * T : 0.0;      // :898 (times = i*T_span + t_start)
+  const int ns_all = sched.n[Ko];
   const int ns = ns_all < sp.max_states ? ns_all : sp.max_states;
   if (tid == 0) {
     sol->stats.status = status; sol->stats.iters = iters_total; sol->stats.iters_first = iters_first;
@@ -963,9 +968,9 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       for (int i = 0; i < NEP_MAX_POL; i++) { n_lp += v[2 * i]; n_lpf += v[2 * i + 1]; }
     }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
-    sol->stats.n_rows = 48 * K + 4 * ((culled && L_used < L_all) ? L_used : L_used - n_lpf); sol->stats.qc_active = has_qc ? 1 : 0;   // rows solved for (null rows of failed LPs excluded)
+    sol->stats.n_rows = K_ok ? 48 * K + 4 * ((culled && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;   // rows solved for (null rows of failed LPs excluded)
     sol->stats.objective = objective; sol->stats.solve_us = 0.0;
-    sol->K = K; sol->n_states = ns;
+    sol->K = Ko; sol->n_states = ns;
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)
     for (int s = tid; s < ns; s += BS) {
@@ -989,6 +994,16 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   if (ps.commit) {  // the record the agent would publish (neptune_ros.cpp:434-480)
     nep_traj_rec* cr = ps.commit + slot;
     const int own = sp.first_local + (slot % sp.n_local);
+    if (status == NEP_FAILED) {
+      // A failed replan publishes nothing: the agent keeps flying its committed trajectory (neptune_ros.cpp:651-663).  With
+      // the previous records at hand (nep_batch_replan's d_committed) that record is carried over; otherwise d_commit[slot]
+      // is left as the caller passed it (the usual round loop hands the buffer that holds the previous round's records).
+      if (ps.prev_commit) {
+        const double* src = (const double*)(ps.prev_commit + (long)(slot / sp.n_local) * sp.num_agents + own);
+        for (int e = tid; e < (int)(sizeof(nep_traj_rec) / sizeof(double)); e += BS) ((double*)cr)[e] = src[e];
+      }
+      return;
+    }
     if (tid == 0) {
       cr->id = own + 1; cr->is_agent = 1; cr->n_bend = 1; cr->valid = 1;
       for (int a = 0; a < 3; a++) { cr->bbox[a] = 2 * sp.drone_radius; cr->pos[a] = sTheta[(a * 8) * 4 + 3]; }
@@ -1007,11 +1022,8 @@ void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const Q
                const SampleSched& sched, size_t lds_bytes, hipStream_t st) {
   if (n_slots <= 0) return;
   const bool cull = ps.line_far != nullptr && !ps.lines_override;
-  static size_t configured[2] = {0, 0};
-  if (lds_bytes > configured[cull]) {
-    hipFuncSetAttribute(cull ? (const void*)qp_kernel<true> : (const void*)qp_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    configured[cull] = lds_bytes;
-  }
+  static DynLdsAttr attr[2];
+  (void)attr[cull].ensure(cull ? (const void*)qp_kernel<true> : (const void*)qp_kernel<false>, lds_bytes);   // (a failure surfaces as the launch error)
   if (cull) hipLaunchKernelGGL(qp_kernel<true>, dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
   else hipLaunchKernelGGL(qp_kernel<false>, dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
 }

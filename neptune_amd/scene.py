@@ -185,9 +185,80 @@ def _aabb_sep(lo1, hi1, lo2, hi2):
     return (hi1[0] < lo2[0]) or (hi2[0] < lo1[0]) or (hi1[1] < lo2[1]) or (hi2[1] < lo1[1])
 
 
-def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_jitter=0.0):
+# MINVO velocity basis inverse (mader_types.hpp:159-163 inverted; same literals as csrc/nep_tables.h)
+A_VEL_INV = np.array([
+    [-0.07735026918962577, 0.16666666666666635, 1.077350269189625],
+    [-0.07735026918962577, 0.49999999999999967, 1.077350269189625],
+    [1.0000000000000002, 1.0000000000000009, 1.0000000000000016]])
+
+
+def separable(A, B, margin=1e-6):
+    """Is there a line with the convex hulls of point sets A and B at least `margin` apart on either side
+    (= the separator LP of separator_glpk.cpp:248-373 is feasible)?  Separating-axis test: for two convex
+    polygons one of the edge normals of either separates them if anything does; degenerate hulls (a hovering
+    agent's coincident control points, collinear points) add the axes through pairs of points."""
+    A = np.asarray(A, dtype=np.float64).reshape(-1, 2); B = np.asarray(B, dtype=np.float64).reshape(-1, 2)
+    HA = hull_ccw_lexmin(A); HB = hull_ccw_lexmin(B)
+    axes = []
+    for H in (HA, HB):
+        if len(H) >= 2:
+            e = np.roll(H, -1, 0) - H
+            axes.append(np.stack([-e[:, 1], e[:, 0]], 1))
+    if len(HA) < 3 or len(HB) < 3:
+        d = (HA[:, None, :] - HB[None, :, :]).reshape(-1, 2)
+        axes.append(d); axes.append(np.stack([-d[:, 1], d[:, 0]], 1))
+    ax = np.concatenate(axes)
+    nrm = np.hypot(ax[:, 0], ax[:, 1])
+    ax = ax[nrm > 0] / nrm[nrm > 0, None]
+    if not len(ax):
+        return False
+    pa = ax @ HA.T; pb = ax @ HB.T
+    gap = np.maximum(pa.min(1) - pb.max(1), pb.min(1) - pa.max(1))
+    return bool(gap.max() > margin)
+
+
+def interval_ctrl_pts(times, coeff_xy, t0, t1, T_span):
+    """MINVO control points of the committed segments overlapping [t0, t1] (Neptune::vertexesOfInterval2d,
+    neptune.cpp:379-429): host restatement for scene set-up (which guesses are mutually separable)."""
+    n = len(times) - 1
+    first = int(np.searchsorted(times, t0, side="left")) - 1
+    last = int(np.searchsorted(times, t1, side="right")) - 1
+    first = min(max(first, 0), n - 1); last = min(max(last, 0), n - 1)
+    pts = []
+    for s in range(first, last + 1):
+        if s != last:
+            _t = times[s + 1] - times[s]
+        elif t1 > times[s + 1]:
+            _t = times[s + 1] - times[s]
+        else:
+            _t = t1 - times[s]
+        _t = min(max(_t, 0.0), T_span)
+        M = A_POS_INV * np.array([_t ** 3, _t ** 2, _t, 1.0])[:, None]
+        pts.append(np.stack([coeff_xy[0, s] @ M, coeff_xy[1, s] @ M], 1))
+    return np.concatenate(pts)
+
+
+def interval_hull(times, coeff_xy, t0, t1, T_span, delta):
+    """inflated interval hull (neptune.cpp:436-446 + cu::convexHullOfPoints2d), counter-clockwise"""
+    q = interval_ctrl_pts(times, coeff_xy, t0, t1, T_span)
+    c = np.array([[delta, delta], [delta, -delta], [-delta, -delta], [-delta, delta]])
+    return hull_ccw_lexmin((q[:, None, :] + c[None, :, :]).reshape(-1, 2))
+
+
+def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_jitter=0.0, separation="hull"):
     """Returns dict(par, statics_raw, statics, starts, goals, guesses [N] (GUESS_DTYPE),
-    committed [N] (TRAJ_REC_DTYPE))."""
+    committed [N] (TRAJ_REC_DTYPE)).
+
+    separation: which guesses are accepted ("rejecting guesses ... whose hulls are not separable
+    from every obstacle hull, so every LP is feasible, as after the real front end"):
+      "hull"  every separator LP the back end will pose in round 0 is feasible — each segment's control polygon
+              against every inflated static and against the interval hull of every other agent's guess, both ways
+              (separating-axis test on the actual hulls);
+      "aabb"  the round-1 generator: bounding boxes of the control polygons against inflated, windowed boxes —
+              sufficient for the above but much stricter (agents end up farther apart; kept because the committed
+              golden QP cases of tests/golden/qp_cases.npz were drawn from it)."""
+    if separation not in ("hull", "aabb"):
+        raise ValueError("separation must be 'hull' or 'aabb'")
     rng = np.random.default_rng(seed)
     p = par if par is not None else scaled_params(num_agents, n_static)
     N = p.num_agents
@@ -203,6 +274,8 @@ def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_j
     prev_lo = np.zeros((N, K, 2)); prev_hi = np.zeros((N, K, 2)); prev_n = 0   # windowed control-point boxes of accepted agents
     st_lo_a = np.array(st_lo).reshape(-1, 2); st_hi_a = np.array(st_hi).reshape(-1, 2)
     close_range = 4.0
+    prev_hulls, prev_cps = [], []    # separation == "hull": interval hulls / control polygons of the accepted guesses
+    t_scene = 0.0                    # (hulls are taken on the common grid; with t_jitter the start times differ by < T and the test is approximate)
     for i in range(N):
         accepted = None
         for attempt in range(300):
@@ -230,28 +303,67 @@ def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_j
             # (neptune.cpp:379-389), for it as an obstacle and for the conservative test below
             wlo = np.stack([lo[max(k - 1, 0):min(k + 1, K - 1) + 1].min(0) for k in range(K)])
             whi = np.stack([hi[max(k - 1, 0):min(k + 1, K - 1) + 1].max(0) for k in range(K)])
+            my_hulls = None
+            if separation == "hull":   # base squares (solver_gurobi_poly.cpp:521-553: 0.7 m half-width): LPs against them must be feasible too
+                br = 0.7
+                sepb = ((hi[:, None, 0] < p.pb[None, :, 0] - br - 0.05) | (p.pb[None, :, 0] + br + 0.05 < lo[:, None, 0]) |
+                        (hi[:, None, 1] < p.pb[None, :, 1] - br - 0.05) | (p.pb[None, :, 1] + br + 0.05 < lo[:, None, 1]))
+                ok = True
+                for k, j in zip(*np.nonzero(~sepb)):
+                    sq = p.pb[j] + br * np.array([[1.0, 1.0], [1.0, -1.0], [-1.0, -1.0], [-1.0, 1.0]])
+                    if not separable(sq, np.stack([cx[k], cy[k]], 1), 1e-3):
+                        ok = False
+                        break
+                if not ok:
+                    continue
             if len(st_lo_a):   # static obstacles: [S][2] boxes against every segment's box
                 sep = ((hi[:, None, 0] < st_lo_a[None, :, 0] - 0.05) | (st_hi_a[None, :, 0] + 0.05 < lo[:, None, 0]) |
                        (hi[:, None, 1] < st_lo_a[None, :, 1] - 0.05) | (st_hi_a[None, :, 1] + 0.05 < lo[:, None, 1]))
                 if not sep.all():
-                    continue
+                    if separation == "aabb":
+                        continue
+                    ok = True
+                    for k, j in zip(*np.nonzero(~sep)):      # boxes overlap: the actual polygons decide
+                        if not separable(statics[j], np.stack([cx[k], cy[k]], 1), 1e-3):
+                            ok = False
+                            break
+                    if not ok:
+                        continue
             if prev_n:         # previously accepted agents: [n][K][2] inflated windowed boxes
                 plo = prev_lo[:prev_n] - infl - 0.05; phi = prev_hi[:prev_n] + infl + 0.05
                 sep = ((whi[None, :, 0] < plo[:, :, 0]) | (phi[:, :, 0] < wlo[None, :, 0]) |
                        (whi[None, :, 1] < plo[:, :, 1]) | (phi[:, :, 1] < wlo[None, :, 1]))
                 if not sep.all():
-                    continue
-            accepted = (g, co, lo, hi, wlo, whi)
+                    if separation == "aabb":
+                        continue
+                    # the LPs of both agents for this pair of guesses: my control polygon k against the other's
+                    # interval hull k, and the other's control polygon k against mine
+                    tk = t_scene + np.arange(K + 1) * T
+                    my_hulls = [interval_hull(tk, co[:2], tk[k], tk[k + 1], T, infl) for k in range(K)]
+                    ok = True
+                    for j, k in zip(*np.nonzero(~sep)):
+                        if not separable(prev_hulls[j][k], np.stack([cx[k], cy[k]], 1), 1e-3) or \
+                           not separable(my_hulls[k], prev_cps[j][k], 1e-3):
+                            ok = False
+                            break
+                    if not ok:
+                        continue
+            accepted = (g, co, lo, hi, wlo, whi, my_hulls)
             break
         if accepted is None:  # hover in place
             g = np.array([starts[i][0], starts[i][1], p.goal_height])
             co = np.zeros((3, K, 4)); co[:, :, 3] = g[:, None]
             cx = pos_ctrl_pts(co[0], T); cy = pos_ctrl_pts(co[1], T)
             lo = np.stack([cx.min(1), cy.min(1)], 1); hi = np.stack([cx.max(1), cy.max(1)], 1)
-            accepted = (g, co, lo, hi, lo, hi)
-        g, co, lo, hi, wlo, whi = accepted
+            accepted = (g, co, lo, hi, lo, hi, None)
+        g, co, lo, hi, wlo, whi, my_hulls = accepted
         goals[i] = g
         prev_lo[prev_n] = wlo; prev_hi[prev_n] = whi; prev_n += 1
+        if separation == "hull":
+            tk = t_scene + np.arange(K + 1) * T
+            cx = pos_ctrl_pts(co[0], T); cy = pos_ctrl_pts(co[1], T)
+            prev_hulls.append(my_hulls if my_hulls is not None else [interval_hull(tk, co[:2], tk[k], tk[k + 1], T, infl) for k in range(K)])
+            prev_cps.append([np.stack([cx[k], cy[k]], 1) for k in range(K)])
         t_start = float(rng.uniform(0, t_jitter)) if t_jitter > 0 else 0.0
         guesses[i]["K"] = K
         guesses[i]["t_start"] = t_start
@@ -266,6 +378,32 @@ def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_j
         r["pwp"]["coeff"][:, :K, :] = co
     return dict(par=p, statics_raw=raw, statics=statics, starts=starts, goals=goals,
                 guesses=guesses, committed=committed, seed=seed)
+
+
+def scene_statics(num_agents, n_static, seed, par=None):
+    """The inflated static obstacles make_scene(num_agents, n_static, seed) produces (its first random draws),
+    without building the rest of the scene."""
+    p = par if par is not None else scaled_params(num_agents, n_static)
+    return random_static_obstacles(p, np.random.default_rng(seed))[1]
+
+
+def active_rows(p, coeff, K, line_seg, line_nd, tol=1e-6):
+    """Inequality rows of the spline QP (solver_gurobi_poly.cpp:433-489) that are active (slack < tol) at the
+    trajectory `coeff` [3][K][4]: (box rows, line rows)."""
+    T = p.T_span
+    M4 = A_POS_INV * np.array([T ** 3, T ** 2, T, 1.0])[:, None]
+    V3 = A_VEL_INV * (np.array([3.0, 2.0, 1.0]) * np.array([T ** 2, T, 1.0]))[:, None]
+    mins = [p.x_min, p.y_min, p.z_min]; maxs = [p.x_max, p.y_max, p.z_max]
+    nb = 0
+    for ax in range(3):
+        q = coeff[ax, :K] @ M4; v = coeff[ax, :K, :3] @ V3; a = 6 * T * coeff[ax, :K, 0] + 2 * coeff[ax, :K, 1]
+        nb += int((q > maxs[ax] - tol).sum() + (q < mins[ax] + tol).sum() + (np.abs(v) > p.v_max - tol).sum() + (np.abs(a) > p.a_max - tol).sum())
+    nl = 0
+    if len(line_seg):
+        cx = coeff[0, :K] @ M4; cy = coeff[1, :K] @ M4
+        val = line_nd[:, 0:1] * cx[line_seg] + line_nd[:, 1:2] * cy[line_seg] + line_nd[:, 2:3] - 1.0
+        nl = int((val > -tol).sum())
+    return nb, nl
 
 
 def statics_csr(statics):

@@ -119,10 +119,14 @@ static int upper_bound_d(const double* a, int n, double v) { /* first i with a[i
   return lo;
 }
 
-void orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_span,
-                          const double delta[2], double (*hull)[2], int* nv, double (*hull0)[2],
-                          int* nv0) {
+/* Returns 1 when a capacity of the fixed-size records was exceeded (more than NEP_HULL_MAX_CP / 4 committed segments
+ * overlap the interval, or a hull has more than NEP_HULL_MAX_V vertices): the product reports NEP_E_CAP there, and the
+ * output is then NOT the reference's (which has no such limit), else 0. */
+int orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_span,
+                         const double delta[2], double (*hull)[2], int* nv, double (*hull0)[2],
+                         int* nv0) {
   int n = pwp->n_seg;
+  int overflow = 0;
   double pts[4 * NEP_HULL_MAX_CP][2], pts0[NEP_HULL_MAX_CP][2];
   int np = 0, np0 = 0;
   /* neptune.cpp:379-389 */
@@ -130,6 +134,7 @@ void orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_spa
   int last = upper_bound_d(pwp->times, n + 1, t1) - 1;
   if (first < 0) first = 0; if (first > n - 1) first = n - 1;
   if (last < 0) last = 0; if (last > n - 1) last = n - 1;
+  if (last - first + 1 > NEP_HULL_MAX_CP / 4) overflow = 1;
   for (int i = first; i <= last && np0 + 4 <= NEP_HULL_MAX_CP; i++) {
     double _t; /* neptune.cpp:399-424 */
     if (i != last) _t = pwp->times[i + 1] - pwp->times[i];
@@ -158,13 +163,14 @@ void orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_spa
   }
   double tmp[64][2];
   int k = orc_convex_hull_2d(np, pts, tmp);
-  if (k > NEP_HULL_MAX_V) k = NEP_HULL_MAX_V;
+  if (k > NEP_HULL_MAX_V) { k = NEP_HULL_MAX_V; overflow = 1; }
   for (int i = 0; i < k; i++) { hull[i][0] = tmp[i][0]; hull[i][1] = tmp[i][1]; }
   *nv = k;
   k = orc_convex_hull_2d(np0, pts0, tmp);
   if (k > NEP_HULL_MAX_V) k = NEP_HULL_MAX_V;
   for (int i = 0; i < k; i++) { hull0[i][0] = tmp[i][0]; hull0[i][1] = tmp[i][1]; }
   *nv0 = k;
+  return overflow;
 }
 
 int orc_inflate_static(int nv, const double (*v)[2], double sd, double (*out)[2]) {

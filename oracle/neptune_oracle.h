@@ -65,7 +65,7 @@ int orc_convex_hull_2d(int n, const double (*pts)[2], double (*out)[2]);
 
 /* Neptune::vertexesOfInterval2d + convexHullOfInterval2d (neptune.cpp:288-309, 349-452) for one
  * committed trajectory and one interval.  hull / hull0 receive the inflated / uninflated hulls. */
-void orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_span,
+int orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_span,
                           const double delta[2], double (*hull)[2], int* nv, double (*hull0)[2],
                           int* nv0);
 

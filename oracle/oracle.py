@@ -68,6 +68,7 @@ def lib():
         L.orc_hull_of_interval.argtypes = [C.POINTER(abi.nep_pwp), C.c_double, C.c_double,
                                            C.c_double, C.POINTER(C.c_double), C.c_void_p,
                                            C.POINTER(C.c_int), C.c_void_p, C.POINTER(C.c_int)]
+        L.orc_hull_of_interval.restype = C.c_int
         L.orc_inflate_static.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_void_p]
         L.orc_inflate_static.restype = C.c_int
         for f in (L.orc_separator, L.orc_separator_simplex, L.orc_separator_ordered):
@@ -119,12 +120,14 @@ def convex_hull_2d(pts):
     return out[:k].copy()
 
 
-def hull_of_interval(pwp, t0, t1, T_span, delta):
+def hull_of_interval(pwp, t0, t1, T_span, delta, with_overflow=False):
     d = _c(delta)
     h = np.zeros((abi.NEP_HULL_MAX_V, 2)); h0 = np.zeros((abi.NEP_HULL_MAX_V, 2))
     nv = C.c_int(0); nv0 = C.c_int(0)
-    lib().orc_hull_of_interval(C.byref(pwp), t0, t1, T_span, abi.dptr(d), h.ctypes.data,
-                               C.byref(nv), h0.ctypes.data, C.byref(nv0))
+    ov = lib().orc_hull_of_interval(C.byref(pwp), t0, t1, T_span, abi.dptr(d), h.ctypes.data,
+                                    C.byref(nv), h0.ctypes.data, C.byref(nv0))
+    if with_overflow:
+        return h[:nv.value].copy(), h0[:nv0.value].copy(), bool(ov)
     return h[:nv.value].copy(), h0[:nv0.value].copy()
 
 

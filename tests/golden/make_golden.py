@@ -263,7 +263,7 @@ def qp_cases():
     # (a) scene-derived: lines from the separator on seeded scenes (mostly inactive constraints)
     for (N, S, K, seed, agents) in [(1, 0, 3, 0, [1]), (1, 0, 8, 1, [1]), (5, 0, 8, 2, [1, 3]), (8, 20, 8, 4, [2, 4, 6]),
                                     (8, 20, 5, 6, [1, 2]), (5, 0, 4, 7, [1]), (3, 4, 2, 9, [1, 2]), (3, 4, 1, 10, [1, 2])]:
-        sc = scene.make_scene(N, S, seed=seed, K=K)
+        sc = scene.make_scene(N, S, seed=seed, K=K, separation="aabb")
         p = sc["par"]
         for a in agents:
             g = sc["guesses"][a - 1]
@@ -273,7 +273,7 @@ def qp_cases():
     # (b) binding constraints: random tight lines around the guess
     rng = np.random.default_rng(2024)
     for t, (K, seed) in enumerate([(8, 11), (8, 12), (8, 13), (8, 14), (6, 15), (5, 16), (4, 17), (3, 18), (8, 19), (8, 20)]):
-        sc = scene.make_scene(5, 0, seed=seed, K=K)
+        sc = scene.make_scene(5, 0, seed=seed, K=K, separation="aabb")
         p = sc["par"]; a = int(rng.integers(0, 5))
         ci = np.array(sc["guesses"][a]["coeff"])[:, :K, :]
         seg, nd = tight_lines(ci, p.T_span, rng, per_seg=2 + t % 2)

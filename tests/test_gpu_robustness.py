@@ -1,0 +1,168 @@
+"""GPU tests of the boundary's failure semantics (round-2 advisor findings): what a failed or empty replan
+publishes, polygon orientation at upload, the hull capacity flag, one static-obstacle set per scene."""
+import numpy as np
+import pytest
+
+from neptune_amd import abi, scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from neptune_amd import backend
+    return backend
+
+
+def _infeasible_guess(g, p):
+    """start outside the world box: the position rows of the first control point cannot hold in either solve"""
+    g = g.copy()
+    co = np.array(g["coeff"])
+    co[0, :, 3] += (p.x_max + 5.0) - co[0, 0, 3]
+    g["coeff"] = co
+    return g
+
+
+def test_failed_and_empty_replans_publish_nothing(be, oracle):
+    """neptune_ros.cpp:651-663: a replan that fails publishes nothing, the agent keeps flying its committed
+    trajectory.  Slot 1 fails (both solves infeasible), slot 2 has an empty guess (front-end miss, K = 0):
+    their commit slots carry the previous records over, everything else is the new trajectory."""
+    sc = scene.make_scene(5, 3, seed=4)
+    p = sc["par"]
+    gue = sc["guesses"].copy()
+    gue[1] = _infeasible_guess(gue[1], p)
+    gue[2]["K"] = 0
+    r1 = oracle.replan(p, 2, sc["committed"], gue[1], sc["statics"])
+    assert r1["status"] == 2
+    prev = sc["committed"].copy()
+    prev["pos"][:, 2] = 7.25                     # a marker the new records cannot carry
+    bb = be.BatchBackend(p, sc["statics"])
+    bb.replan(bb.to_device(prev), bb.to_device(gue))
+    sol = bb.solutions(); com = bb.commits()
+    assert [int(s["stats"]["status"]) for s in sol][1:3] == [2, 2] and all(int(sol[a]["stats"]["status"]) != 2 for a in (0, 3, 4))
+    assert int(sol[2]["K"]) == 0 and int(sol[2]["n_states"]) == 0 and not np.array(sol[2]["coeff"]).any()
+    np.testing.assert_array_equal(np.array(sol[1]["coeff"]), np.array(gue[1]["coeff"]))      # output == initial guess (:856-859)
+    for a in (1, 2):
+        assert com[a].tobytes() == prev[a].tobytes()
+    for a in (0, 3, 4):
+        assert int(com[a]["valid"]) == 1 and com[a]["pos"][2] != 7.25
+        np.testing.assert_array_equal(np.array(com[a]["pwp"]["coeff"])[:, :8, :], np.array(sol[a]["coeff"]))
+    # without the previous records (hulls reused: d_committed = None) the slot is left as the caller passed it
+    bb.d_commit.fill_(0xAB)
+    bb.replan(None, bb.to_device(gue))
+    com2 = bb.commits()
+    for a in (1, 2):
+        assert (np.frombuffer(com2[a].tobytes(), dtype=np.uint8) == 0xAB).all()
+    assert int(com2[0]["valid"]) == 1
+    # and the safety pass keeps the previous record of such agents whatever it decides about the others
+    d_final = bb.torch.zeros_like(bb.d_commit); d_acc = bb.torch.zeros(5, dtype=bb.torch.int32, device=bb.device)
+    bb.replan(bb.to_device(prev), bb.to_device(gue))
+    bb.safety_commit(bb.to_device(prev), bb.d_commit, bb.to_device(gue), d_final, d_acc)
+    fin = d_final.cpu().numpy().view(abi.TRAJ_REC_DTYPE)
+    for a in (1, 2):
+        assert fin[a].tobytes() == prev[a].tobytes()
+    bb.close()
+
+
+def test_clockwise_polygons_are_reoriented_and_nonconvex_refused(be, oracle):
+    """The reference LP (separator_glpk.cpp:248-373) does not care about vertex order; the kernel's edge rule
+    does.  Clockwise statics / hull lists give the result of their counter-clockwise form, non-convex input
+    is refused."""
+    from neptune_amd._lib import BackendError
+    sc = scene.make_scene(5, 6, seed=9)
+    p = sc["par"]
+    cw = [np.ascontiguousarray(np.vstack([s[:1], s[1:][::-1]])) for s in sc["statics"]]       # same first vertex, reversed
+    outs = []
+    for statics in (sc["statics"], cw):
+        bb = be.BatchBackend(p, statics)
+        bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]))
+        outs.append((bb.solutions(), [bb.debug_lines(a) for a in range(5)]))
+        bb.close()
+    n_static_lines = 0
+    for a in range(5):
+        np.testing.assert_array_equal(outs[0][1][a][1], outs[1][1][a][1])
+        r = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"])
+        r0 = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], [])
+        n_static_lines += r["n_lp"] - r0["n_lp"]
+        np.testing.assert_array_equal(outs[1][1][a][1], r["line_nd"])
+    assert n_static_lines > 0
+    assert outs[0][0].tobytes() == outs[1][0].tobytes()
+    # a clockwise unit square against points at x >= 3 (the advisor's example): a separating line with A on its >= 1 side
+    sq_cw = np.array([[0.0, 0.0], [0.0, 1.0], [1.0, 1.0], [1.0, 0.0]])
+    s = be.PolySolver(p.num_pol, 3, 1, p.T_span, p.pb, p.weight, 0.5, True)
+    s.setStaticObstVert([sq_cw])
+    with pytest.raises(BackendError):
+        s.setStaticObstVert([np.array([[0.0, 0.0], [2.0, 0.0], [0.5, 0.5], [0.0, 2.0]])])    # reflex vertex
+    s.close()
+    with pytest.raises(BackendError):
+        be.BatchBackend(p, [np.array([[0.0, 0.0], [2.0, 0.0], [0.5, 0.5], [0.0, 2.0]])] * 6)
+
+
+def _short_segment_record(n_short, T=0.5):
+    """a committed trajectory whose first planning interval [0, T] is covered by n_short short segments"""
+    rec = np.zeros(1, dtype=abi.TRAJ_REC_DTYPE)
+    r = rec[0]
+    knots = list(np.linspace(0.0, 0.42, n_short + 1)) + [1.0, 1.5, 2.0, 2.5, 3.0, 3.5, 4.0]
+    n = len(knots) - 1
+    r["id"] = 1; r["is_agent"] = 1; r["valid"] = 1; r["n_bend"] = 1; r["bbox"] = 1.2
+    r["pwp"]["n_seg"] = n
+    r["pwp"]["times"][: n + 1] = knots
+    rng = np.random.default_rng(3)
+    co = rng.normal(size=(3, n, 4)) * np.array([0.05, 0.1, 0.5, 3.0])
+    r["pwp"]["coeff"][:, :n, :] = co
+    return rec
+
+
+def test_hull_capacity_is_flagged_not_truncated(be, oracle):
+    """The reference takes every committed segment overlapping an interval (neptune.cpp:392-449).  Four fit a wave
+    (bit-exact against the oracle); a fifth is NEP_E_CAP, never a silently smaller hull."""
+    from neptune_amd._lib import BackendError
+    p = scene.scaled_params(2, 0)
+    rec4 = _short_segment_record(3)          # interval 0 overlaps segments 0..3
+    pw = abi.nep_pwp.from_buffer_copy(rec4[0]["pwp"].tobytes())
+    d = np.array([0.6 + p.drone_radius, 0.6 + p.drone_radius])
+    h, hu, ov = oracle.hull_of_interval(pw, 0.0, p.T_span, p.T_span, d, with_overflow=True)
+    hx, hn, h0, n0 = be.hulls_batch(rec4, 0.0, p.num_pol, p.T_span, p.drone_radius)
+    if not ov:
+        assert hn[0, 0] == len(h)
+        np.testing.assert_array_equal(hx[0, 0, :len(h)], h)
+    rec6 = _short_segment_record(6)
+    pw6 = abi.nep_pwp.from_buffer_copy(rec6[0]["pwp"].tobytes())
+    assert oracle.hull_of_interval(pw6, 0.0, p.T_span, p.T_span, d, with_overflow=True)[2]
+    with pytest.raises(BackendError, match="NEP_HULL_MAX_CP"):
+        be.hulls_batch(rec6, 0.0, p.num_pol, p.T_span, p.drone_radius)
+    # batched handle: the asynchronous replan cannot return it, nep_batch_check does
+    sc = scene.make_scene(2, 0, seed=1)
+    com = sc["committed"].copy(); com[1] = rec6[0]; com[1]["id"] = 2
+    bb = be.BatchBackend(sc["par"], [])
+    bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]))
+    bb.check()                                # nothing flagged
+    bb.replan(bb.to_device(com), bb.to_device(sc["guesses"]))
+    with pytest.raises(BackendError, match="NEP_HULL_MAX_CP"):
+        bb.check()
+    bb.check()                                # reported once, then cleared
+    bb.close()
+
+
+def test_one_static_set_per_scene(be):
+    """nep_batch_set_scene_statics: two scenes with their own obstacles in one handle equal two handles."""
+    scs = [scene.make_scene(6, 8, seed=s) for s in (30, 31)]
+    p = scs[0]["par"]
+    com = np.stack([s["committed"] for s in scs]); gue = np.stack([s["guesses"] for s in scs])
+    bb = be.BatchBackend(p, scs[0]["statics"], n_scenes=2)
+    bb.set_scene_statics(1, scs[1]["statics"])
+    bb.replan(bb.to_device(com), bb.to_device(gue))
+    both = bb.solutions().reshape(2, 6)
+    lines = [[bb.debug_lines(s * 6 + a)[1] for a in range(6)] for s in range(2)]
+    bb.close()
+    for s in range(2):
+        one = be.BatchBackend(p, scs[s]["statics"])
+        one.replan(one.to_device(scs[s]["committed"]), one.to_device(scs[s]["guesses"]))
+        assert one.solutions().tobytes() == both[s].tobytes()
+        for a in range(6):
+            np.testing.assert_array_equal(one.debug_lines(a)[1], lines[s][a])
+        one.close()
+    assert both[0].tobytes() != both[1].tobytes()

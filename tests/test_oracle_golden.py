@@ -90,13 +90,16 @@ def test_sampling_matches_reference_loop(oracle):
     t = 0.0; i = 0; out = []
     while i < 8:
         dt = t - i * 0.5
-        out.append([co[ax, i] @ np.array([dt ** 3, dt ** 2, dt, 1]) for ax in range(3)])
+        out.append([[co[ax, i] @ np.array([dt ** 3, dt ** 2, dt, 1]) for ax in range(3)],          # pos   (:921-923)
+                    [co[ax, i] @ np.array([3 * dt ** 2, 2 * dt, 1, 0]) for ax in range(3)],       # vel   (:924-926)
+                    [co[ax, i] @ np.array([6 * dt, 2, 0, 0]) for ax in range(3)],                 # accel (:927-929)
+                    [6 * co[ax, i, 0] for ax in range(3)]])                                      # jerk  (:930-932)
         t += 0.05
         if t > (i + 1) * 0.5:
             i += 1
+    out = np.array(out).reshape(len(out), 12)
     assert len(st) == len(out) and 80 <= len(st) <= 90
-    np.testing.assert_allclose(st[:, :3], np.array(out), atol=1e-12)
-    np.testing.assert_allclose(st[:, 9:12], np.tile(6 * co[:, 0, 0], (1, 1)) if False else st[:, 9:12])
+    np.testing.assert_allclose(st, out, atol=1e-12)
 
 
 def test_reduced_model_matches_oracle(oracle):
