@@ -156,20 +156,40 @@ def main():
     import torch.distributed as tdist
     use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
     rccl_note = None
+
+    class _stdout_to_stderr:
+        """RCCL prints a version banner on stdout when its first communicator comes up; stdout carries the one JSON line"""
+        def __enter__(self):
+            sys.stdout.flush()
+            self.saved = os.dup(1); os.dup2(2, 1)
+        def __exit__(self, *a):
+            import ctypes
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except Exception:
+                pass
+            os.dup2(self.saved, 1); os.close(self.saved)
+
+    def init_group(backend, **kw):
+        with _stdout_to_stderr():
+            if backend == "nccl":
+                tdist.init_process_group("nccl", device_id=dev, **kw)
+                t = torch.ones(1, device=dev)
+                tdist.all_reduce(t)                              # brings the communicator up now (and its banner with it)
+                torch.cuda.synchronize(dev)
+            else:
+                tdist.init_process_group(backend, **kw)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
-        if dist_backend == "nccl":
-            tdist.init_process_group("nccl", device_id=dev)
-        else:
-            tdist.init_process_group(dist_backend)
+        init_group(dist_backend)
     elif not args.no_process_group:
         # plain `python bench.py`: a one-rank RCCL process group, so that the single-GPU record also shows the collective
         # library initialising on the box and the round's all-gather call path running (degenerate: one rank)
         try:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
-            tdist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+            init_group("nccl", rank=0, world_size=1)
             use_dist = True
         except Exception as e:                                 # never lose the measurement to the extra
             rccl_note = "one-rank process group not created: %r" % (e,)

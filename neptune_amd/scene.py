@@ -499,7 +499,7 @@ def tether_crossing_scene(num_agents, n_static, seed):
     Returns the scene with enable_entangle set (inputs for real_entangle / the entangle rows)."""
     import dataclasses
     rng = np.random.default_rng(seed)
-    sc = make_scene(num_agents, n_static, seed=seed)
+    sc = make_scene(num_agents, n_static, seed=seed, separation="aabb")   # (the hover positions below were tuned on these guesses)
     p = dataclasses.replace(sc["par"], enable_entangle=True, tether_length=200.0)
     sc["par"] = p
     com, gue = sc["committed"], sc["guesses"]

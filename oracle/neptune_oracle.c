@@ -203,8 +203,33 @@ int orc_inflate_static(int nv, const double (*v)[2], double sd, double (*out)[2]
  * the winning candidate needs a square root and divisions. */
 typedef struct { int have; double num, len2, sg, tA, nx, ny, px, py; } sep_best;
 
+/* ---- which LP vertex is returned: a study knob (scripts/separator_sensitivity.py), NOT part of the restated path ----
+ * GLPK hands back whichever vertex its simplex reaches; the product's rule (policy 0) is the largest gap.  The other
+ * policies return other ADMISSIBLE vertices of the same LP, so that the dependence of the QP optimum on this
+ * solver-defined choice can be measured:
+ *   1 a pseudo-random admissible vertex (seeded)      2 the admissible vertex with the smallest gap
+ *   3 the admissible vertex that leaves the reference control points of the current segment the least room
+ *   4 the vertex a textbook two-phase Bland simplex reaches (orc_separator_simplex)
+ * Thread-local: concurrent callers (bench.py's cpu_baseline) keep the default. */
+#define SEP_MAX_CAND 512
+static __thread int g_policy = 0;
+static __thread unsigned long long g_rng = 1;
+static __thread int g_cur_seg = 0;
+static __thread double g_ref_ctrl[NEP_MAX_POL][4][2];
+static __thread int g_ncand = 0;
+static __thread sep_best g_cand[SEP_MAX_CAND];
+static __thread long g_stat_lps = 0, g_stat_vertices = 0;
+void orc_set_vertex_policy(int policy, unsigned long long seed, const double* ref_ctrl /* [NEP_MAX_POL][4][2] or NULL */) {
+  g_policy = policy; g_rng = seed * 2862933555777941757ULL + 3037000493ULL; g_stat_lps = 0; g_stat_vertices = 0;
+  if (ref_ctrl) memcpy(g_ref_ctrl, ref_ctrl, sizeof(g_ref_ctrl)); else memset(g_ref_ctrl, 0, sizeof(g_ref_ctrl));
+}
+void orc_vertex_policy_stats(long* n_lps, long* n_vertices) { *n_lps = g_stat_lps; *n_vertices = g_stat_vertices; }
+
 static void sep_consider(sep_best* b, double num, double len2, double sg, double tA, double nx, double ny, double px, double py) {
   if (!(num > 0.0)) return;
+  if (g_policy != 0 && (num * num) > (SEP_MIN_GAP * SEP_MIN_GAP) * len2 && g_ncand < SEP_MAX_CAND) {
+    sep_best* c = &g_cand[g_ncand++]; c->have = 1; c->num = num; c->len2 = len2; c->sg = sg; c->tA = tA; c->nx = nx; c->ny = ny; c->px = px; c->py = py;
+  }
   int better;
   if (!b->have) better = (num * num) > (SEP_MIN_GAP * SEP_MIN_GAP) * len2;
   else better = (num * num) * b->len2 > (b->num * b->num) * len2;
@@ -244,8 +269,10 @@ static void sep_edge_ccw(const double p[2], const double q[2], int nB, const dou
   sep_consider(best, 0.0 - maxB, len2, 1.0, 0.0, nx, ny, p[0], p[1]);
 }
 
+int orc_separator_simplex(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]);
 static int separator_impl(int nA, const double (*A)[2], int a_ordered, int nB, const double (*B)[2], double nd[3]) {
   sep_best best; best.have = 0; best.num = 0; best.len2 = 1; best.sg = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
+  g_ncand = 0;
   if (a_ordered && nA >= 3) {
     for (int p = 0; p < nA - 1; p++) {
       sep_edge_ccw(A[p], A[p + 1], nB, B, &best);
@@ -269,6 +296,30 @@ static int separator_impl(int nA, const double (*A)[2], int a_ordered, int nB, c
       for (int i = 0; i < nA; i++) { double t = nx * (A[i][0] - cb[0]) + ny * (A[i][1] - cb[1]); if (t < minA) minA = t; }
       for (int i = 0; i < nB; i++) { double t = nx * (B[i][0] - cb[0]) + ny * (B[i][1] - cb[1]); if (t > maxB) maxB = t; }
       sep_consider(&best, minA - maxB, len2, 1.0, minA, nx, ny, cb[0], cb[1]);
+    }
+  }
+  if (best.have && g_policy != 0) {   /* study knob: another admissible vertex of the same LP (see orc_set_vertex_policy) */
+    g_stat_lps++; g_stat_vertices += g_ncand;
+    if (g_policy == 4) { double t[3]; if (orc_separator_simplex(nA, A, nB, B, t)) { nd[0] = t[0]; nd[1] = t[1]; nd[2] = t[2]; return 1; } }
+    else if (g_ncand > 0) {
+      int pick = 0;
+      if (g_policy == 1) { g_rng = g_rng * 6364136223846793005ULL + 1442695040888963407ULL; pick = (int)((g_rng >> 33) % (unsigned long long)g_ncand); }
+      else {
+        double best_v = INFINITY;
+        for (int c = 0; c < g_ncand; c++) {
+          const sep_best* k = &g_cand[c]; double len = sqrt(k->len2), v;
+          if (g_policy == 2) v = k->num / len;                      /* the gap */
+          else {                                                    /* room left to the reference control points (metres) */
+            v = INFINITY;
+            for (int q = 0; q < 4; q++) {
+              double room = k->sg * k->tA / len - k->sg * (k->nx * (g_ref_ctrl[g_cur_seg][q][0] - k->px) + k->ny * (g_ref_ctrl[g_cur_seg][q][1] - k->py)) / len;
+              if (room < v) v = room;
+            }
+          }
+          if (v < best_v) { best_v = v; pick = c; }
+        }
+      }
+      best = g_cand[pick];
     }
   }
   if (best.have) { /* the winning LP vertex in the reference's epsilon = 1 scaling */
@@ -637,6 +688,7 @@ int orc_optimize(const orc_params* par, int K, const double coeff_init[3][NEP_MA
       continue;
     }
     double B4[4][2]; for (int k = 0; k < 4; k++) { B4[k][0] = ctrl[i][k][0]; B4[k][1] = ctrl[i][k][1]; }
+    g_cur_seg = i;
     /* inter-agent :477-495 */
     for (int j = 0; j < n_obst; j++) {
       int pi = j * par->num_pol + i; int o = hulls->off[pi], nv = hulls->off[pi + 1] - o; double nd[3];

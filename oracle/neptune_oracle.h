@@ -69,6 +69,13 @@ int orc_hull_of_interval(const nep_pwp* pwp, double t0, double t1, double T_span
                           const double delta[2], double (*hull)[2], int* nv, double (*hull0)[2],
                           int* nv0);
 
+/* Study knob (scripts/separator_sensitivity.py), not part of the restated path: which admissible vertex of the
+ * separator LP is returned by the calling thread from now on.  0 (default) largest gap = the product's rule; 1 seeded
+ * pseudo-random; 2 smallest gap; 3 least room for the reference control points ref_ctrl[seg][4][2] of the segment being
+ * built; 4 the vertex of a two-phase Bland simplex. */
+void orc_set_vertex_policy(int policy, unsigned long long seed, const double* ref_ctrl);
+void orc_vertex_policy_stats(long* n_lps, long* n_vertices);
+
 /* Neptune::setStaticObst inflation (neptune.cpp:639-664). */
 int orc_inflate_static(int nv, const double (*v)[2], double safe_dist, double (*out)[2]);
 

@@ -9,8 +9,10 @@ from neptune_amd import scene
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def load_qp_cases():
-    d = np.load(os.path.join(ROOT, "tests", "golden", "qp_cases.npz"), allow_pickle=True)
+def load_qp_cases(name="qp_cases.npz"):
+    """qp_cases.npz: the round-1 set (make_golden.py); qp_cases_r2.npz: BASELINE config-4 / config-5 sizes, K = 7 and
+    front-end guesses (make_golden_r2.py), each accepted on a KKT certificate."""
+    d = np.load(os.path.join(ROOT, "tests", "golden", name), allow_pickle=True)
     out = []
     for i in range(int(d["n"])):
         c = {k[len("c%d_" % i):]: d[k] for k in d.files if k.startswith("c%d_" % i)}

@@ -44,6 +44,26 @@ def test_qp_against_golden(oracle):
     assert seen == {0, 1, 2}
 
 
+def test_qp_against_golden_r2(oracle):
+    """The sizes and inputs the first fixture set did not reach (tests/golden/make_golden_r2.py): BASELINE config 4
+    (~510 lines) and config 5 (~2 050 lines) replans, K = 7, front-end (lattice) guesses.  Every
+    fixture carries a KKT certificate, i.e. it is the optimum to ~1e-9 whatever SciPy's two solvers did."""
+    cases = helpers.load_qp_cases("qp_cases_r2.npz")
+    tags = [c["tag"] for c in cases]
+    assert sum(t.startswith("c4 ") for t in tags) >= 6 and sum(t.startswith("c5 ") for t in tags) >= 2
+    assert sum(t.startswith("fe ") for t in tags) >= 10 and any(c["K"] == 7 for c in cases)
+    worst = 0.0
+    for c in cases:
+        p = helpers.params_of_case(c)
+        r = oracle.optimize(p, 1, c["coeff_init"], [], [], lines=(c["line_seg"], c["line_nd"]))
+        assert r["status"] == c["status"], c["tag"]
+        th = helpers.golden_theta_out(c)
+        err = np.abs(r["coeff"] - th).max(); worst = max(worst, err)
+        assert err <= 1e-6, (c["tag"], err)
+        if c["status"] != 2:
+            assert abs(r["objective"] - c["cost"]) <= 1e-6 * (1 + abs(c["cost"])), c["tag"]
+
+
 def test_separator_feasibility_matches_highs(oracle):
     d = np.load(helpers.ROOT + "/tests/golden/lp_cases.npz")
     n_ok = 0
