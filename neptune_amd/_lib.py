@@ -6,7 +6,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libneptune_backend.so")
+LIB_PATH = os.environ.get("NEP_BACKEND_LIB") or os.path.join(_HERE, "libneptune_backend.so")   # (NEP_BACKEND_LIB: development aid, A/B builds)
 _lib = None
 
 # every symbol include/neptune_backend.h declares

@@ -78,6 +78,7 @@ struct Engine {
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
+  bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
   // timing
@@ -129,6 +130,14 @@ struct Engine {
     lds_lines = (int)((ll + 1) & ~1L);
     lds_rows = 4 * lds_lines;
     lds_bytes = fixed + (size_t)(lds_lines + 2) * per_line;   // + the dummy line of the padded row groups
+    // Placement of the row state.  When the expected lines per segment fit the register slots of qp_reg_kernel (8 per slot;
+    // a few more only cost a trip through the global scratch) and the expected total fits its coefficient carve, the row
+    // state lives in registers and four workgroups share a CU; bigger problems (config 5: ~250 lines per segment) keep
+    // the LDS placement of qp_kernel.  NEP_QP_KERNEL=reg|lds overrides the choice (tests).
+    const long expect_seg = expect / NEP_MAX_POL;
+    use_reg = expect_seg <= 8L * qp_reg_slots() + 8;
+    if (const char* f = getenv("NEP_QP_KERNEL")) { if (!strcmp(f, "reg")) use_reg = true; else if (!strcmp(f, "lds")) use_reg = false; }
+    if (use_reg) { lds_lines = NEP_MAX_POL * 8 * qp_reg_slots(); lds_rows = 4 * lds_lines; lds_bytes = qp_reg_lds_bytes(); }
     rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
     if (int e = d_hull_xy.ensure((size_t)n_scenes * sp.n_hull * np * kHullV * 2)) return e;
     if (int e = d_hull_nv.ensure((size_t)n_scenes * sp.n_hull * np)) return e;
@@ -143,7 +152,7 @@ struct Engine {
     if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 16)) return e; }
-    if (lines_total > lds_lines) { if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e; }
+    if (lines_total > lds_lines || use_reg) { if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e; }
     else d_row_scratch.release();
     return 0;
   }
@@ -235,7 +244,8 @@ struct Engine {
       launch_separator(slots, sp, ps, st);
     }
     if (timing) hipEventRecord(next_event(), st);
-    launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
+    if (use_reg) launch_qp_reg(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
+    else launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     if (timing) hipEventRecord(next_event(), st);
     HIPCHK(hipGetLastError());
     return 0;

@@ -118,6 +118,11 @@ void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy,
 void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 size_t qp_lds_fixed_bytes();
+// the register-resident placement of the same solver (qp_reg_kernel.hip)
+void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
+                   const SampleSched& sched, size_t lds_bytes, hipStream_t st);
+int qp_reg_slots();
+size_t qp_reg_lds_bytes();
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
                      nep_guess* guess_out, nep_fe_result* res_out, hipStream_t st);
 void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const double* b_xy, int* hit, hipStream_t st);

@@ -201,6 +201,113 @@ __device__ __forceinline__ double solve_impl(lds_dptr sM, lds_dptr sInvD, int la
   return b;
 }
 
+// The same two routines for an n x n block inside a fixed size N >= n (the block is extended by the identity on the fly,
+// nothing is written to LDS for it), inlined: qp_reg_kernel keeps its row state in registers across the factorisation and
+// cannot afford an out-of-line call's save/restore.  N is the smallest of a few sizes that holds n (12 and 6 are exact for
+// the usual K = 8 replan).
+template <int N>
+__device__ __forceinline__ bool chol_pad(lds_dptr sM, lds_dptr sInvD, int n, int lane) {
+  const int row = lane < N ? lane : N - 1;
+  const bool rin = row < n;
+  double Lr[N];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < N; j++) { const double v = sM[row * MS + j]; Lr[j] = (rin && j < n) ? v : (row == j ? 1.0 : 0.0); }
+  double dinv = 0.0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const double d = bcast(Lr[j], j);
+    if (!(d > 0.0)) ok = false;
+    const double inv = frsqrt(d);
+    Lr[j] *= inv;
+    dinv = lane == j ? inv : dinv;
+#pragma unroll
+    for (int k = j + 1; k < N; k++) Lr[k] = __builtin_fma(-Lr[j], bcast(Lr[j], k), Lr[k]);
+  }
+  if (lane < n) {
+#pragma unroll
+    for (int j = 0; j < N; j++) if (j < n) sM[lane * MS + j] = Lr[j];
+    sInvD[lane] = dinv;
+  }
+  return ok;
+}
+template <int N>
+__device__ __forceinline__ double solve_pad(lds_dptr sM, lds_dptr sInvD, int n, int lane, double b) {
+  const int row = lane < N ? lane : N - 1;
+  const bool rin = row < n;
+  const double dinv = rin ? sInvD[row] : 1.0;
+  b = lane < n ? b : 0.0;
+  {
+    double Lr[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { const double v = sM[row * MS + j]; Lr[j] = (rin && j < n) ? v : 0.0; }
+#pragma unroll
+    for (int j = 0; j < N; j++) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Lr[j], xj, b); b = lane == j ? xj : (lane > j ? upd : b); }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
+    double Uc[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) { const double v = sM[j * MS + row]; Uc[j] = (rin && j < n) ? v : 0.0; }
+#pragma unroll
+    for (int j = N - 1; j >= 0; j--) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Uc[j], xj, b); b = lane == j ? xj : (lane < j ? upd : b); }
+  }
+  return b;
+}
+// The same two routines for any n <= 24 with the matrix left in LDS (lane i = row i, the pivot column is read back by all
+// lanes: LDS operations of one wave execute in order, so a lane's write is visible to the reads that follow it).  A dozen
+// registers instead of 2 N + ...: qp_reg_kernel uses them for the sizes that are rare (terminal ball active: 3 nz; relaxed
+// re-solve: nz = K), so that the register allocator never has to place a 24-entry row next to the row state.
+__device__ __forceinline__ bool chol_lds(lds_dptr sM, lds_dptr sInvD, int n, int lane) {
+  bool ok = true;
+  const bool rin = lane < n;
+  for (int j = 0; j < n; j++) {
+    const double d = sM[j * MS + j];
+    if (!(d > 0.0)) ok = false;
+    const double inv = frsqrt(d);
+    double lij = 0.0;
+    if (rin && lane >= j) { lij = sM[lane * MS + j] * inv; sM[lane * MS + j] = lij; }
+    if (lane == j) sInvD[j] = inv;
+    for (int k = j + 1; k < n; k++) {
+      const double lkj = sM[k * MS + j];
+      if (rin && lane >= k) sM[lane * MS + k] = __builtin_fma(-lij, lkj, sM[lane * MS + k]);
+    }
+  }
+  return ok;
+}
+__device__ __forceinline__ double solve_lds(lds_dptr sM, lds_dptr sInvD, lds_dptr tmp, int n, int lane, double b) {
+  const bool rin = lane < n;
+  b = rin ? b : 0.0;
+  for (int j = 0; j < n; j++) {               // L y = b
+    if (lane == j) tmp[j] = b * sInvD[j];
+    const double xj = tmp[j];
+    if (rin && lane > j) b = __builtin_fma(-sM[lane * MS + j], xj, b);
+    if (lane == j) b = xj;
+  }
+  for (int j = n - 1; j >= 0; j--) {          // L' x = y
+    if (lane == j) tmp[j] = b * sInvD[j];
+    const double xj = tmp[j];
+    if (lane < j) b = __builtin_fma(-sM[j * MS + lane], xj, b);
+    if (lane == j) b = xj;
+  }
+  return b;
+}
+// wave 0's block (2 nz or 3 nz) / wave 1's block (nz): n is wave-uniform.  tmp: 24 doubles of LDS free during the solve.
+__device__ __forceinline__ bool chol_n(lds_dptr sM, lds_dptr sInvD, int n, int lane) {
+  n = __builtin_amdgcn_readfirstlane(n);
+  if (n <= 6) return chol_pad<6>(sM, sInvD, n, lane);
+  if (n <= 8) return chol_pad<8>(sM, sInvD, n, lane);
+  if (n <= 12) return chol_pad<12>(sM, sInvD, n, lane);
+  return chol_lds(sM, sInvD, n, lane);
+}
+__device__ __forceinline__ double solve_n(lds_dptr sM, lds_dptr sInvD, lds_dptr tmp, int n, int lane, double b) {
+  n = __builtin_amdgcn_readfirstlane(n);
+  if (n <= 6) return solve_pad<6>(sM, sInvD, n, lane, b);
+  if (n <= 8) return solve_pad<8>(sM, sInvD, n, lane, b);
+  if (n <= 12) return solve_pad<12>(sM, sInvD, n, lane, b);
+  return solve_lds(sM, sInvD, tmp, n, lane, b);
+}
+
 // One straight-line instantiation per size (no per-step size tests).  Sizes: 3 nz (ball constraint
 // couples the axes), or the two diagonal blocks 2 nz (x,y) and nz (z) factored by two waves at once.
 #define NEP_SIZE_SWITCH(CALL)                                                                      \

@@ -1,0 +1,788 @@
+// qp_reg_kernel.hip — the interior point of qp_kernels.hip with the line-row state in REGISTERS.
+//
+// Same problem, same iteration, same thread roles as qp_kernel (see its header): one 256-thread workgroup per replan,
+// thread (seg, k, slice) = (tid >> 5, (tid >> 3) & 3, tid & 7) owns the rows of control point k of the lines of segment
+// seg whose index is congruent to slice modulo 8.  What differs is where a row's (s, lambda) lives.  qp_kernel keeps them
+// in LDS (8 doubles per line: 32 KB of the 82 KB carve at config 4) and needs every VGPR it can get (256, and spills):
+// two workgroups per CU by both limits, and the kernel is latency-bound.  The register file of a CU (512 KB) is three times
+// its LDS, so here a thread keeps its first RS rows in RS x 2 doubles of registers — at config 4 a segment has 64-68 lines,
+// i.e. 8 or 9 rows per thread — and only the line coefficients (n1, n2, h: 24 B per line) stay in LDS: 40 KB per
+// workgroup, 128 VGPRs, FOUR workgroups per CU.  Rows beyond RS per thread, and coefficients beyond the LDS carve, go to
+// the per-slot global scratch (correct for any count; config-5 sized problems are given to qp_kernel by the host).
+// The solver body is one straight function whose phases scope their temporaries: no 4-wide row groups (the other three
+// workgroups of the CU hide the latency instead), no out-of-line calls.
+#include <hip/hip_runtime.h>
+
+#include "qp_common.h"
+
+// line rows a thread keeps in registers (8 per segment and slot: 9 slots = 72 lines per segment before the global scratch is used)
+#ifndef NEP_QP_REG_SLOTS
+#define NEP_QP_REG_SLOTS 9
+#endif
+
+// workgroups per CU the register allocation is bounded for (4: 128 VGPRs, 3: 168)
+#ifndef NEP_QP_REG_WGS
+#define NEP_QP_REG_WGS 4
+#endif
+
+namespace nep {
+
+template <bool CULL, int RS>
+__global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sB = smem + oB; double* sOff = smem + oOff; double* sAccL = smem + oAccL;
+  double* sDc = smem + oDc; double* sTc = smem + oTc;
+  double* sM = smem + oM; double* sHax = smem + oHax;
+  double* sZ = smem + oZ; double* sG = smem + oG; double* sRd = smem + oRd; double* sRhs = smem + oRhs;
+  double* sDxa = smem + oDxa; double* sDx = smem + oDx; double* sGq = smem + oGq; double* sZl = smem + oZl;
+  double* sEp = smem + oEp; double* sCoef = smem + oCoef; double* sTheta = smem + oTheta;
+  double* sInit = smem + oInit; double* sc = smem + oScal; double* sRed = smem + oRed;
+  int* sI = (int*)(smem + kFixedDoubles);      // [0..8] line offsets, [16..] flags (same map as qp_kernel)
+
+  const int tid = threadIdx.x;
+  const int slot = blockIdx.x;
+  const nep_guess* __restrict__ g = ps.guess + slot;
+  const int K_in = g->K;
+  const bool K_ok = K_in >= 1 && K_in <= NEP_MAX_POL && K_in <= sp.num_pol;   // (see qp_kernel)
+  const int K = K_ok ? K_in : 1;
+  const double T = sp.T_span, wgt = sp.weight;
+  nep_solution* __restrict__ sol = ps.solution + slot;
+
+  if (tid < 96) sCoef[tid] = (&g->coeff[0][0][0])[tid];
+  for (int e = tid; e < kMaxR * 6; e += BS) sTc[e] = 0.0;
+  sDc[tid] = 0.0; sAccL[tid] = 0.0;
+  int status = NEP_FAILED, iters_total = 0, iters_first = 0, L_used = 0, L_all = 0;
+  double objective = 0.0;
+  bool has_qc = false, z_override = false;
+
+  // Line coefficients in LDS: [n1 | n2 | h][segment][SEGCAP], SEGCAP = 8 RS entries per segment whatever its line count — the
+  // entries past a segment's last line hold the dummy line (0, 0, 1).  A thread's slot u is then a compile-time offset from
+  // one base address (ds_read with an immediate), and a padded slot needs no redirect.  Lines beyond SEGCAP of a segment
+  // (coefficients and row state) live in the per-slot global scratch.
+  typedef __attribute__((address_space(3))) double* lds_ptr;
+  constexpr int SEGCAP = 8 * RS, NS = NEP_MAX_POL * SEGCAP;
+  const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
+  const lds_ptr ldyn = (lds_ptr)(unsigned int)(lds0 + (kFixedDoubles + 32) * sizeof(double));
+  const int GL = ps.rows_cap / 4 + 2;
+  double* __restrict__ gsp = ps.row_scratch + (long)slot * (11L * GL);
+
+  // ---- thread roles ----
+  const int R = 8 * K;
+  const bool has_box = tid < 3 * R;
+  const int bax = has_box ? tid / R : 0, brho = has_box ? tid % R : 0;
+  const double bhi = brho < 4 * K ? sp.maxs[bax] : (brho < 7 * K ? sp.v_max : sp.a_max);
+  const double blo = brho < 4 * K ? sp.mins[bax] : (brho < 7 * K ? -sp.v_max : -sp.a_max);
+  const int pair = tid >> 3, li = pair >> 2, lk = pair & 3, slice = tid & 7;
+  const bool has_line = li < K;
+  const int lrho = 4 * li + lk;
+
+  // row state: box rows [0] upper (alpha = +e), [1] lower; line rows: slot u = line lbeg + slice + 8 u
+  double bs0 = 1, bl0 = 0, bs1 = 1, bl1 = 0;
+  double sl[RS], ll[RS];
+
+#pragma nounroll
+  for (int attempt = 0; attempt < (CULL ? 2 : 1) && K_ok; attempt++) {
+    const bool use_far = attempt == 1;
+    __syncthreads();
+    if (tid < NEP_MAX_POL) {
+      sI[44 + tid] = (tid < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + tid] : 0;
+      sI[32 + tid] = (tid < K && CULL) ? ps.line_far[(long)slot * NEP_MAX_POL + tid] : 0;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int o = 0, nf = 0, all = 0;
+      for (int i = 0; i < NEP_MAX_POL; i++) {
+        const int cn = sI[44 + i], cf = sI[32 + i];
+        sI[i] = o; sI[52 + i] = nf;
+        o += cn + (use_far ? cf : 0); nf += cf; all += cn + cf;
+      }
+      sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0;
+      int over = 0;
+      for (int i = 0; i < NEP_MAX_POL; i++) over |= (sI[i + 1] - sI[i]) > 8 * RS ? 1 : 0;
+      sI[43] = over;
+    }
+    __syncthreads();
+    const int L = sI[NEP_MAX_POL];
+    L_used = L; L_all = sI[42];
+    if (tid < 9) {
+      if (tid < 3) {
+        const double* c = sCoef + (tid * 8 + (K - 1)) * 4;
+        sc[sFinal0 + tid] = ((T * T * T) * c[0] + (T * T) * c[1] + T * c[2]) + c[3];   // final_pos_ (:226-228)
+      }
+      sInit[tid] = sCoef[((tid / 3) * 8 + 0) * 4 + 1 + (tid % 3)];                    // b0,c0,d0 (:390-396)
+    }
+    // the separator's buckets -> the coefficient carve (and the global scratch for what exceeds a segment's SEGCAP entries)
+    for (int e = tid; e < NS; e += BS) {
+      const int i = e / SEGCAP, j = e - i * SEGCAP;
+      const int cn = sI[44 + i], ct = sI[i + 1] - sI[i];     // near lines, lines of this attempt
+      double n1 = 0.0, n2 = 0.0, h = 1.0;
+      if (j < ct) {
+        const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
+        const long q = j < cn ? j : (long)sp.lines_cap - 1 - (j - cn);      // near lines from the front, far ones from the back
+        n1 = src[3 * q]; n2 = src[3 * q + 1]; h = 1.0 - src[3 * q + 2];
+      }
+      ldyn[e] = n1; ldyn[NS + e] = n2; ldyn[2 * NS + e] = h;
+    }
+    if (sI[43]) {                                             // some segment has more than SEGCAP lines (uniform)
+      for (int e = tid; e < L; e += BS) {
+        int i = 0;
+#pragma unroll
+        for (int j = 1; j < NEP_MAX_POL; j++) i += (e >= sI[j]) ? 1 : 0;
+        const int l = e - sI[i], cn = sI[44 + i];
+        if (l < SEGCAP) continue;
+        const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
+        const long q = l < cn ? l : (long)sp.lines_cap - 1 - (l - cn);
+        gsp[e] = src[3 * q]; gsp[GL + e] = src[3 * q + 1]; gsp[2 * GL + e] = 1.0 - src[3 * q + 2];
+      }
+    }
+    __syncthreads();
+    const double dix = sCoef[3] - sc[sFinal0], diy = sCoef[32 + 3] - sc[sFinal1], diz = sCoef[64 + 3] - sc[sFinal2];
+    has_qc = sqrt(dix * dix + diy * diy + diz * diz) < 1.0;   // :697-702
+    z_override = sqrt(dix * dix + diy * diy) < 1.0;           // :879-880
+    const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);
+
+    const int seg_cnt = sI[li + 1] - sI[li];                  // lines of my segment (0 for segments >= K)
+    // slots in use by this wave (it covers segments 2w and 2w + 1): wave-uniform, so the slot loop branches on the scalar unit
+    int n_u;
+    {
+      const int w2 = (tid >> 6) * 2;
+      const int ca = sI[w2 + 1] - sI[w2], cb = sI[w2 + 2] - sI[w2 + 1];
+      const int m = ((ca > cb ? ca : cb) + 7) >> 3;
+      n_u = __builtin_amdgcn_readfirstlane(m < RS ? m : RS);
+    }
+    int my_cnt = seg_cnt - slice; my_cnt = my_cnt > 0 ? (my_cnt + 7) >> 3 : 0;       // my rows (slots u < my_cnt hold real lines)
+    const bool over = sI[43] != 0;
+    const lds_ptr cbase = ldyn + (li * SEGCAP + slice);
+
+    // One pass over this thread's line rows.  body(ok, n1, n2, h, s, lambda); padded slots see the dummy line (0, 0, 1) with
+    // s = lambda = 1: their activity and step are exactly zero (see qp_kernel), `ok` masks what would still matter.
+    auto for_rows = [&](auto&& body) {
+#pragma unroll
+      for (int u = 0; u < RS; u++) {
+        if (u < n_u) {
+          const double n1 = cbase[8 * u], n2 = cbase[NS + 8 * u], h = cbase[2 * NS + 8 * u];
+          body(u < my_cnt, n1, n2, h, sl[u], ll[u]);
+        }
+      }
+      if (over) {   // rows beyond the register slots: coefficients and state in the global scratch
+        for (int j = SEGCAP + slice; j < seg_cnt; j += 8) {
+          const int l = sI[li] + j;
+          const double n1 = gsp[l], n2 = gsp[GL + l], h = gsp[2 * GL + l];
+          double s = gsp[(3 + lk) * GL + l], lam = gsp[(7 + lk) * GL + l];
+          body(true, n1, n2, h, s, lam);
+          gsp[(3 + lk) * GL + l] = s; gsp[(7 + lk) * GL + l] = lam;
+        }
+      }
+    };
+
+    status = NEP_FAILED; iters_total = 0; iters_first = 0; objective = 0.0;
+
+    for (int mode = 0; mode < 2; mode++) {
+      const QpTable* __restrict__ tb = tables + mode * (kMaxK + 1) + K;
+      const int nz = mode == 1 ? K : (K > 2 ? K - 2 : 0), n = 3 * nz;
+      __syncthreads();
+      for (int e = tid; e < kMaxR * kNZ; e += BS) sB[(e / kNZ) * SBS + (e % kNZ)] = (&tb->B[0][0])[e];
+      if (tid < 64) sHax[tid] = (&tb->Hax[0][0])[tid];
+      if (tid < 8) sEp[tid] = tb->ep[tid];
+      for (int e = tid; e < kSmallTab; e += BS) sM[e] = (&tb->Gi[0][0])[e];
+      if (tid < 96) { const int ax = tid >> 5, r = tid & 31; sTheta[tid] = r < 4 * K ? sCoef[tid] - (tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2]) : 0.0; }
+      if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
+      // the iterate and the two directions are read eight entries at a time from an axis' first one (against B's or Hax's zero
+      // columns): what lies beyond the 3 nz entries in use must be finite
+      if (tid >= n && tid < 24) { sZ[tid] = 0.0; sDxa[tid] = 0.0; sDx[tid] = 0.0; }
+      __syncthreads();
+      const double* tGiP = sM + tGi; const double* tUpP = sM + tUp; const double* tUvP = sM + tUv; const double* tUaP = sM + tUa;
+      const double* tZpP = sM + tZp; const double* tPpP = sM + tPp; const double* tResP = sM + tResU;
+      if (tid < 24) { const int ax = tid >> 3, r = tid & 7; sRhs[tid] = tPpP[r * 3] * sInit[ax * 3] + tPpP[r * 3 + 1] * sInit[ax * 3 + 1] + tPpP[r * 3 + 2] * sInit[ax * 3 + 2]; }
+      else if (tid >= 32 && tid < 35) { const int ax = tid - 32; sc[sPe0 + ax] = tUpP[0] * sInit[ax * 3] + tUpP[1] * sInit[ax * 3 + 1] + tUpP[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; }
+      __syncthreads();
+      // normal-matrix entries owned by this thread (xx, yx, yy, zz blocks; a pair of lanes per entry), packed: ci | cj<<4 | sel<<8 | on<<12
+      int me[2];
+      {
+        const int tri_n = nz * (nz + 1) / 2, n_ent = 3 * tri_n + nz * nz;
+        auto tri = [&](int e, int& r, int& c) { r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while ((r + 1) * (r + 2) / 2 <= e) r++; while (r * (r + 1) / 2 > e) r--; c = e - r * (r + 1) / 2; };
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+          const int e = (tid >> 1) + u * (BS / 2);
+          const bool on = e < n_ent && nz > 0;
+          int ci = 0, cj = 0, sel = 0;
+          if (on) {
+            if (e < tri_n) { tri(e, ci, cj); sel = 0; }
+            else if (e < tri_n + nz * nz) { const int f = e - tri_n; ci = f / nz; cj = f % nz; sel = 1; }
+            else if (e < 2 * tri_n + nz * nz) { tri(e - tri_n - nz * nz, ci, cj); sel = 2; }
+            else { tri(e - 2 * tri_n - nz * nz, ci, cj); sel = 3; }
+          }
+          me[u] = ci | (cj << 4) | (sel << 8) | ((on ? 1 : 0) << 12);
+        }
+      }
+      bool converged = false;
+      int it = 0;
+      if (nz == 0) {
+        // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
+        double viol = 0.0, d0 = 0, d1 = 0, d2 = 0;
+        if (has_box) { const double a = sOff[brho * 3 + bax]; viol = fmax(a - bhi, blo - a); }
+        { const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; for_rows([&](bool v, double n1, double n2, double h, double&, double&) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
+        if (tid < 6) {
+          const int ax = tid / 2, e = tid % 2;
+          viol = fmax(viol, fabs(tResP[e * 3] * sInit[ax * 3] + tResP[e * 3 + 1] * sInit[ax * 3 + 1] + tResP[e * 3 + 2] * sInit[ax * 3 + 2]));
+        }
+        if (tid == 0 && has_qc) {
+          double c = -0.10 * 0.10;
+          for (int ax = 0; ax < 3; ax++) { const double pe = sc[sPe0 + ax]; c += pe * pe; }
+          viol = fmax(viol, c);
+        }
+        block_reduce4(viol, d0, d1, d2, sRed);
+        converged = viol <= 1e-6;
+        if (tid == 0) {
+          double o = 0;
+          for (int ax = 0; ax < 3; ax++) {
+            for (int r = 0; r < K; r++) { const double a = sRhs[ax * 8 + r]; o += 36 * T * a * a; }
+            const double pe = sc[sPe0 + ax];
+            o += wgt * pe * pe;
+          }
+          sc[sObj] = o;
+        }
+      } else {
+        // ---- start point: projection of the guess, floored slacks, centred duals ------------------
+        if (tid < n) {
+          const int ax = tid / nz, c = tid % nz;
+          double z = 0;
+#pragma unroll 8
+          for (int r = 0; r < 4 * kMaxK; r++) z = __builtin_fma(tZpP[c * 4 * kMaxK + r], sTheta[ax * 32 + r], z);
+          sZ[tid] = z;
+          sG[tid] = (tGiP[c * 3] * sInit[ax * 3] + tGiP[c * 3 + 1] * sInit[ax * 3 + 1] + tGiP[c * 3 + 2] * sInit[ax * 3 + 2]) - 2 * wgt * sEp[c] * sc[sFinal0 + ax];
+        }
+        if (tid == 0) {
+          double o = 0;
+          for (int ax = 0; ax < 3; ax++) {
+            for (int r = 0; r < K; r++) { const double a = sRhs[ax * 8 + r]; o += 36 * T * a * a; }
+            const double pe = sc[sPe0 + ax];
+            o += wgt * pe * pe;
+            if (mode == 1) {
+              const double ve = tUvP[0] * sInit[ax * 3] + tUvP[1] * sInit[ax * 3 + 1] + tUvP[2] * sInit[ax * 3 + 2];
+              const double ae = tUaP[0] * sInit[ax * 3] + tUaP[1] * sInit[ax * 3 + 1] + tUaP[2] * sInit[ax * 3 + 2];
+              o += wgt * (ve * ve + ae * ae);
+            }
+          }
+          sc[sObj0] = o;
+          sI[16] = 0; sI[17] = 0; sI[22] = -1;
+        }
+        __syncthreads();
+        auto proj = [&](int rho, int ax, const double* vec) {   // B's columns >= nz are zero and the vectors' tails are kept finite (zeroed below)
+          const double* b = sB + rho * SBS; const double* x = vec + ax * nz;
+          double v = 0;
+#pragma unroll
+          for (int c = 0; c < kNZ; c++) v = __builtin_fma(b[c], x[c], v);
+          return v;
+        };
+        bool uncon = false;
+        if constexpr (CULL) {   // presolve: the minimiser without inequality rows, accepted when every row holds there (see qp_kernel)
+          if (tid < n) {
+            const int ax = tid / nz, c = tid % nz;
+            double v = 0;
+            for (int e = 0; e < nz; e++) v -= sM[tHi + c * kNZ + e] * sG[ax * nz + e];
+            sDx[tid] = v;
+          }
+          __syncthreads();
+          double viol = -1.0, o_share = 0, d1 = 0, d2 = 0;
+          if (has_box) { const double a = sOff[brho * 3 + bax] + proj(brho, bax, sDx); viol = fmax(a - bhi, blo - a); }
+          {
+            const double cx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sDx) : 0.0, cy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sDx) : 0.0;
+            for_rows([&](bool ok, double n1, double n2, double h, double&, double&) { viol = fmax(viol, ok ? (n1 * cx + n2 * cy) - h : -1.0); });
+          }
+          if (tid == BS - 1 && has_qc) {
+            double c = -0.10 * 0.10;
+            for (int ax = 0; ax < 3; ax++) { double pe = sc[sPe0 + ax]; for (int e = 0; e < nz; e++) pe += sEp[e] * sDx[ax * nz + e]; c += pe * pe; }
+            viol = fmax(viol, c);
+          }
+          if (tid < n) {
+            const int ax = tid / nz, c = tid % nz;
+            double hz = 0;
+            for (int e = 0; e < nz; e++) hz += sHax[c * kNZ + e] * sDx[ax * nz + e];
+            o_share = sDx[tid] * (0.5 * hz + sG[tid]);
+          }
+          block_reduce4(viol, o_share, d1, d2, sRed);
+          uncon = viol <= 0.0;
+          if (uncon) { if (tid < n) sZ[tid] = sDx[tid]; if (tid == 0) sc[sObj] = sc[sObj0] + o_share; }
+        }
+        // Roles are re-derived from an opaque copy of the thread index in every phase of the iteration: whatever the compiler
+        // could hoist out of the loop (row / entry indices, LDS addresses of four different roles) would otherwise sit in
+        // registers next to the row state for the whole solve.
+        auto otid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+        const int brole = bax | (brho << 2) | ((has_box ? 1 : 0) << 8);
+        auto box_role = [&](int& ax, int& rho, double& hi, double& lo) {
+          int r = brole; asm volatile("" : "+v"(r));
+          ax = r & 3; rho = (r >> 2) & 63;
+          hi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
+          lo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
+          return (r >> 8) != 0;
+        };
+        double cpb = has_box ? sOff[brho * 3 + bax] + proj(brho, bax, sZ) : 0.0, uab = 0.0, udb = 0.0;
+        double cpx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sZ) : 0.0, cpy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sZ) : 0.0;
+        double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
+        if (has_box) {
+          const double a = cpb;
+          double slk = bhi - a; bs0 = slk > kSlackFloor ? slk : kSlackFloor; bl0 = kMu0 * frcp(bs0);
+          slk = a - blo; bs1 = slk > kSlackFloor ? slk : kSlackFloor; bl1 = kMu0 * frcp(bs1);
+        }
+#pragma unroll
+        for (int u = 0; u < RS; u++) { sl[u] = 1.0; ll[u] = 1.0; }
+        for_rows([&](bool ok, double n1, double n2, double h, double& s, double& lam) {
+          const double slk = h - (n1 * cpx + n2 * cpy);
+          s = slk > kSlackFloor ? slk : kSlackFloor; lam = ok ? kMu0 * frcp(s) : 1.0;
+        });
+        if (tid == 0) {
+          double qs = 1.0; for (int e = 0; e < n; e++) qs = fmax(qs, fabs(sG[e]));
+          sc[sQscale] = qs;
+          if (has_qc) {
+            double c = -0.10 * 0.10;
+            for (int ax = 0; ax < 3; ax++) { double pe = sc[sPe0 + ax]; for (int e = 0; e < nz; e++) pe += sEp[e] * sZ[ax * nz + e]; c += pe * pe; }
+            const double sq = (-c > 1e-3) ? -c : 1e-3;
+            sc[sSq] = sq; sc[sLq] = 1.0 / sq;
+          } else { sc[sSq] = 1.0; sc[sLq] = 0.0; }
+          sc[sDsq] = 0.0; sc[sDlq] = 0.0; sc[sDsqA] = 0.0; sc[sDlqA] = 0.0; sc[sRpq] = 0.0; sc[sWq] = 0.0;
+          sc[sAlpha] = 0.0; sc[sSigMu] = 0.0;        // step length and centring target of the previous iteration (read back in pass A)
+        }
+        __syncthreads();
+
+        double* redA = sRed; double* redP2 = sRed + 16; double* redP5 = sRed + 32;
+        const int n0 = has_qc ? n : 2 * nz;                       // wave 0 factors this block, wave 1 the z block
+        for (it = 0; it < kMaxIt && !uncon; it++) {
+          // ---- (A1) apply the previous step to the row state; (A2) residuals / weights / scatter onto base rows.  Two sweeps
+          // over the rows instead of one: the step needs the two direction projections, the scatter seven accumulators — together
+          // they do not fit next to the row state in 128 registers, one after the other they do (the second sweep re-reads three
+          // coefficients per row) ----
+          double nrp = 0, sumsl = 0, dummy1 = 0;
+          {
+            const double alpha_prev = sc[sAlpha], sm_prev = sc[sSigMu];
+            auto rowA1 = [&](double& s, double& lam, double a_old, double ga, double gd, double h) {
+              const double rp0 = a_old + s - h, is = frcp(s), w0 = lam * is;
+              const double dsa = -rp0 - ga, dla = -lam + w0 * (rp0 + ga);
+              const double rcv = s * lam - sm_prev + dsa * dla;
+              const double ds = -rp0 - gd, dl = -rcv * is + w0 * (rp0 + gd);
+              s = __builtin_fma(alpha_prev, ds, s); lam = __builtin_fma(alpha_prev, dl, lam);
+            };
+            {
+              int ax, rho; double hi, lo;
+              if (box_role(ax, rho, hi, lo)) { rowA1(bs0, bl0, cpb, uab, udb, hi); rowA1(bs1, bl1, -cpb, -uab, -udb, -lo); }
+            }
+            for_rows([&](bool ok, double n1, double n2, double h, double& s, double& lam) {
+              rowA1(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h);
+              lam = ok ? lam : 1.0;
+            });
+            cpb = __builtin_fma(alpha_prev, udb, cpb); cpx = __builtin_fma(alpha_prev, udx, cpx); cpy = __builtin_fma(alpha_prev, udy, cpy);   // base rows move with the step
+          }
+          {
+            {
+              int ax, rho; double hi, lo;
+              if (box_role(ax, rho, hi, lo)) {
+                double bTl = 0, bD = 0, bT1 = 0;
+                { const double rp = cpb + bs0 - hi, w = bl0 * frcp(bs0), v = bl0 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs0 * bl0; bTl += bl0; bD += w; bT1 += v; }
+                { const double rp = -cpb + bs1 + lo, w = bl1 * frcp(bs1), v = bl1 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs1 * bl1; bTl -= bl1; bD += w; bT1 -= v; }
+                sTc[rho * 6 + ax] = bTl; sTc[rho * 6 + 3 + ax] = bT1; sDc[rho * 4 + (ax == 0 ? 0 : (ax == 1 ? 2 : 3))] = bD;
+              }
+            }
+            double lTx = 0, lTy = 0, lDxx = 0, lDxy = 0, lDyy = 0, l1x = 0, l1y = 0;
+            for_rows([&](bool ok, double n1, double n2, double h, double& s, double& lam) {
+              const double rp = (n1 * cpx + n2 * cpy) + s - h, w = lam * frcp(s), v = lam - w * rp;
+              nrp = fmax(nrp, fabs(rp)); sumsl += ok ? s * lam : 0.0;
+              lTx += lam * n1; lTy += lam * n2; lDxx += w * n1 * n1; lDxy += w * n1 * n2; lDyy += w * n2 * n2; l1x += v * n1; l1y += v * n2;
+            });
+            lTx = slice_sum(lTx); lTy = slice_sum(lTy); lDxx = slice_sum(lDxx); lDxy = slice_sum(lDxy); lDyy = slice_sum(lDyy); l1x = slice_sum(l1x); l1y = slice_sum(l1y);
+            const int t = otid();
+            if ((t & 7) == 0) { double* o = sAccL + (t >> 3) * 8; o[0] = lTx; o[1] = lTy; o[2] = lDxx; o[3] = lDxy; o[4] = lDyy; o[5] = l1x; o[6] = l1y; }
+          }
+          reduce_put<1>(nrp, sumsl, dummy1, redA);
+          __syncthreads();                                                                       // barrier 1
+          reduce_get<1>(nrp, sumsl, dummy1, redA);
+          {
+            const int t = otid();
+            if (t < R) {
+              const int rho = t; const double* al = sAccL + rho * 8;
+              if (rho < 4 * K) {
+                sDc[rho * 4 + 0] += al[2]; sDc[rho * 4 + 1] = al[3]; sDc[rho * 4 + 2] += al[4];
+                sTc[rho * 6 + 0] += al[0]; sTc[rho * 6 + 1] += al[1]; sTc[rho * 6 + 3] += al[5]; sTc[rho * 6 + 4] += al[6];
+              } else sDc[rho * 4 + 1] = 0.0;
+            }
+            if (t == BS - 1) {   // ball constraint (scalar row)
+              double rpq = 0;
+              if (has_qc) {
+                sc[sSq] += sc[sAlpha] * sc[sDsq]; sc[sLq] += sc[sAlpha] * sc[sDlq];
+                double c = -0.10 * 0.10;
+                for (int ax = 0; ax < 3; ax++) {
+                  double pe = sc[sPe0 + ax];
+                  for (int e = 0; e < nz; e++) pe += sEp[e] * sZ[ax * nz + e];
+                  c += pe * pe;
+                  for (int e = 0; e < nz; e++) sGq[ax * nz + e] = 2 * pe * sEp[e];
+                }
+                rpq = c + sc[sSq];
+                sc[sWq] = sc[sLq] / sc[sSq];
+              }
+              sc[sRpq] = rpq;
+              sc[sSumSl] = sumsl + (has_qc ? sc[sSq] * sc[sLq] : 0.0);
+              sc[sMu] = sc[sSumSl] / mt;
+              sc[sNrp] = fmax(nrp, fabs(rpq));
+            }
+          }
+          __syncthreads();                                                                       // barrier 2
+          // ---- dual residual + predictor rhs (8 partial sums per output), normal matrix -------------
+          {
+            const int t = otid();
+            if (t < 8 * n) {
+              const int o = t >> 3, sl8 = t & 7, ax = o / nz, c = o % nz;
+              double v = 0, t1 = 0;
+              for (int rho = sl8; rho < R; rho += 8) { const double b = sB[rho * SBS + c]; v += b * sTc[rho * 6 + ax]; t1 += b * sTc[rho * 6 + 3 + ax]; }
+              v = slice_sum(v); t1 = slice_sum(t1);
+              if (sl8 == 0) {
+                double hz = 0;
+                { const double* hx = sHax + c * kNZ; const double* zx = sZ + ax * nz;
+#pragma unroll
+                  for (int e = 0; e < kNZ; e++) hz += hx[e] * zx[e]; }
+                const double zo = sZ[o], go = sG[o];
+                v += go + hz;
+                if (has_qc) v += sc[sLq] * sGq[o];
+                sRd[o] = v; sRhs[o] = t1;
+                sDxa[o] = zo * (0.5 * hz + go);
+              }
+            }
+          }
+#pragma unroll 1
+          for (int u = 0; u < 2; u++) {
+            const int t = otid();
+            int mu_ = u == 0 ? me[0] : me[1]; asm volatile("" : "+v"(mu_));
+            const int ci = mu_ & 15, cj = (mu_ >> 4) & 15, sel = (mu_ >> 8) & 3, half = t & 1;
+            const bool on = (mu_ >> 12) != 0;
+            double a0 = 0.0, a1 = 0.0;
+            if (on) {
+              for (int q = 0; q < K; q++) {
+                const int rho = half + 8 * q;
+                double d[4], bi[4], bj[4];
+#pragma unroll
+                for (int w = 0; w < 4; w++) { d[w] = sDc[(rho + 2 * w) * 4 + sel]; bi[w] = sB[(rho + 2 * w) * SBS + ci]; bj[w] = sB[(rho + 2 * w) * SBS + cj]; }
+                a0 = __builtin_fma(d[0] * bi[0], bj[0], a0); a1 = __builtin_fma(d[1] * bi[1], bj[1], a1);
+                a0 = __builtin_fma(d[2] * bi[2], bj[2], a0); a1 = __builtin_fma(d[3] * bi[3], bj[3], a1);
+              }
+            }
+            double v = a0 + a1;
+            v += dpp<DPP_XOR1>(v);
+            if (on && half == 0) {
+              const int bi_ = sel == 0 ? 0 : (sel == 3 ? 2 : 1), bj_ = sel == 0 || sel == 1 ? 0 : (sel == 2 ? 1 : 2);
+              const int mi = bi_ * nz + ci, mj = bj_ * nz + cj;
+              if (sel != 1) v += sHax[ci * kNZ + cj];
+              if (has_qc) { v += sc[sWq] * sGq[mi] * sGq[mj]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
+              sM[mi * MS + mj] = v;
+            }
+          }
+          for (int e = otid(); e < 2 * nz * nz; e += BS) {   // z-x and z-y blocks
+            const int i = 2 * nz + e / (2 * nz), j = e % (2 * nz);
+            sM[i * MS + j] = has_qc ? sc[sWq] * sGq[i] * sGq[j] : 0.0;
+          }
+          __syncthreads();                                                                       // barrier 3
+          // ---- wave 0: convergence test, Cholesky of its block, predictor; wave 1: the z block -------
+          if (tid < 64) {
+            const int t = otid();
+            const double nrd = wave_max(t < n ? fabs(sRd[t]) : 0.0);
+            const double o = sc[sObj0] + wave_sum(t < n ? sDxa[t] : 0.0);
+            const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
+            int flag = 0;
+            if (nr <= 1e-9 && nrd <= 1e-9 * qs && gap <= 1e-10 * (1.0 + fabs(o))) flag = 1;
+            else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
+            if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
+            if (sI[17] >= 3) flag = 3;                           // stalled
+            if (flag == 2 || (flag == 0 && sI[22] >= 0)) {       // loosely converged iterates: see qp_kernel
+              const double merit = fmax(fmax(nr * 1e9, nrd / qs * 1e9), gap / (1.0 + fabs(o)) * 1e10);
+              const bool better = flag == 2 && (!sI[16] || merit < sc[sBestMerit]);
+              const bool last = sI[22] >= 0 && it - sI[22] >= 3;
+              if (sI[22] < 0 && t == 0) sI[22] = it;
+              flag = last ? (better ? 1 : 3) : (better ? 2 : 0);
+              if (t == 0 && flag == 2) sc[sBestMerit] = merit;
+            }
+            if (t == 0) { sc[sObj] = o; if (flag == 2) sc[sObjLoose] = o; sI[18] = flag; }
+            if (flag != 1 && flag != 3) {                        // (uniform across the wave)
+              const lds_dptr sMl = (lds_dptr)(unsigned)(lds0 + oM * 8), sInvDl = (lds_dptr)(unsigned)(lds0 + oInvD * 8);
+              const bool chol_ok = chol_n(sMl, sInvDl, n0, t);
+              if (t == 0) sI[19] = chol_ok ? 1 : 0;
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              double b = 0;
+              if (t < n0) { b = -sRd[t] + sRhs[t]; if (has_qc) b += sGq[t] * (sc[sLq] - sc[sWq] * sc[sRpq]); }
+              b = solve_n(sMl, sInvDl, (lds_dptr)(unsigned)(lds0 + oRed * 8), n0, t, b);
+              if (t < n0) sDxa[t] = b;
+            }
+          } else if (tid < 128) {
+            bool chol_ok = true;
+            const int t = otid();
+            if (!has_qc) {
+              const int l1 = t - 64;
+              const lds_dptr sMz = (lds_dptr)(unsigned)(lds0 + (oM + 2 * nz * MS + 2 * nz) * 8), sInvDz = (lds_dptr)(unsigned)(lds0 + (oInvD + 2 * nz) * 8);
+              chol_ok = chol_n(sMz, sInvDz, nz, l1);
+              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+              double b = l1 < nz ? -sRd[2 * nz + l1] + sRhs[2 * nz + l1] : 0.0;
+              b = solve_n(sMz, sInvDz, (lds_dptr)(unsigned)(lds0 + (oRed + 24) * 8), nz, l1, b);
+              if (l1 < nz) sDxa[2 * nz + l1] = b;
+            }
+            if (t == 64) sI[20] = chol_ok ? 1 : 0;
+          }
+          __syncthreads();                                                                       // barrier 4
+          const int flag = sI[18];
+          if (flag == 1) { converged = true; break; }
+          if (flag == 3) break;
+          if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
+          if (!sI[19] || !sI[20]) break;
+          // ---- (P2) affine step: ratio test, mu_aff, corrector right-hand side split as va - sigma mu vb (see qp_kernel) ----
+          double rmax = 0, c2 = 0, dmy = 0;
+          {
+            auto rowP2 = [&](double s, double lam, double a, double ga, double h, double& va, double& vb) {
+              const double rp = a + s - h, is = frcp(s), w = lam * is;
+              const double dsa = -rp - ga, q = dsa * is, dla = -__builtin_fma(w, dsa, lam);
+              rmax = fmax(rmax, fmax(-q, 1.0 + q));
+              c2 += dsa * dla;
+              va = __builtin_fma(q, dla, lam) - w * rp; vb = is;
+            };
+            {
+              int ax, rho; double hi, lo;
+              if (box_role(ax, rho, hi, lo)) {
+                uab = proj(rho, ax, sDxa);
+                double va0, vb0, va1, vb1;
+                rowP2(bs0, bl0, cpb, uab, hi, va0, vb0); rowP2(bs1, bl1, -cpb, -uab, -lo, va1, vb1);
+                sTc[rho * 6 + 3 + ax] = va0 - va1; sTc[rho * 6 + ax] = vb0 - vb1;
+              }
+            }
+            const int t = otid();
+            { const int rho = t >> 3; uax = proj(rho, 0, sDxa); uay = proj(rho, 1, sDxa); }
+            double vax = 0, vay = 0, vbx = 0, vby = 0;
+            for_rows([&](bool, double n1, double n2, double h, double& s, double& lam) {
+              double va, vb;
+              rowP2(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, h, va, vb);
+              vax += va * n1; vay += va * n2; vbx += vb * n1; vby += vb * n2;
+            });
+            vax = slice_sum(vax); vay = slice_sum(vay); vbx = slice_sum(vbx); vby = slice_sum(vby);
+            if ((t & 7) == 0) { double* o = sAccL + (t >> 3) * 8; o[5] = vax; o[6] = vay; o[0] = vbx; o[1] = vby; }
+            if (t == BS - 1 && has_qc) {
+              const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
+              double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
+              const double dsq = -rpq - gd, dlq = -lq + wq * (rpq + gd);
+              sc[sDsqA] = dsq; sc[sDlqA] = dlq;
+              rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
+              c2 += dsq * dlq;
+            }
+          }
+          reduce_put<1>(rmax, c2, dmy, redP2);
+          __syncthreads();                                                                       // barrier 5
+          reduce_get<1>(rmax, c2, dmy, redP2);
+          double sm;
+          {
+            const double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
+            const double mu = sc[sMu];
+            const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) / mt;
+            const double rr = mua / mu;
+            sm = rr * rr * rr * mu;
+            sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) / mt);
+          }
+          {
+            const int t = otid();
+            if (t < 8 * n) {   // corrector right-hand side
+              const int o = t >> 3, sl8 = t & 7, ax = o / nz, c = o % nz;
+              double t1 = 0;
+              for (int q = 0; q < K; q++) {
+                const int rho = sl8 + 8 * q;
+                double ta = sTc[rho * 6 + 3 + ax], tb2 = sTc[rho * 6 + ax];
+                if (q < 4) {
+                  const double la = sAccL[rho * 8 + 5 + (ax & 1)], lb = sAccL[rho * 8 + (ax & 1)];
+                  const bool on = ax < 2 && rho < 4 * K;
+                  ta += on ? la : 0.0; tb2 += on ? lb : 0.0;
+                }
+                t1 += sB[rho * SBS + c] * __builtin_fma(-sm, tb2, ta);
+              }
+              t1 = slice_sum(t1);
+              if (sl8 == 0) sRhs[o] = t1;
+            }
+          }
+          __syncthreads();                                                                       // barrier 6
+          if (tid < 128) {
+            const int t = otid();
+            const bool w0 = t < 64;
+            const int o = w0 ? t : 2 * nz + (t - 64);
+            const bool mine = w0 ? t < n0 : (!has_qc && t - 64 < nz);
+            double b = 0;
+            if (mine) {
+              b = -sRd[o] + sRhs[o];
+              if (has_qc) { const double sq = sc[sSq], lq = sc[sLq]; const double rcq = sq * lq - sm + sc[sDsqA] * sc[sDlqA]; b += sGq[o] * (rcq / sq - sc[sWq] * sc[sRpq]); }
+            }
+            if (w0) {
+              const lds_dptr sMl = (lds_dptr)(unsigned)(lds0 + oM * 8), sInvDl = (lds_dptr)(unsigned)(lds0 + oInvD * 8);
+              b = solve_n(sMl, sInvDl, (lds_dptr)(unsigned)(lds0 + oRed * 8), n0, t, b); if (mine) sDx[o] = b;
+            } else if (!has_qc) {
+              const lds_dptr sMz = (lds_dptr)(unsigned)(lds0 + (oM + 2 * nz * MS + 2 * nz) * 8), sInvDz = (lds_dptr)(unsigned)(lds0 + (oInvD + 2 * nz) * 8);
+              b = solve_n(sMz, sInvDz, (lds_dptr)(unsigned)(lds0 + (oRed + 24) * 8), nz, t - 64, b); if (mine) sDx[o] = b;
+            }
+          }
+          __syncthreads();                                                                       // barrier 7
+          // ---- (P5) step length of the combined direction ------------------------------------------
+          rmax = 0;
+          {
+            auto rowP5 = [&](bool ok, double s, double lam, double a, double ga, double gd, double h) {
+              const double rp = a + s - h, is = frcp(s), w = lam * is;
+              const double dsa = -rp - ga, dla = -lam + w * (rp + ga);
+              const double rcv = s * lam - sm + dsa * dla;
+              const double ds = -rp - gd, dl = -rcv * is + w * (rp + gd);
+              rmax = fmax(rmax, ok ? fmax(-ds * is, -dl * frcp(lam)) : 0.0);
+            };
+            {
+              int ax, rho; double hi, lo;
+              if (box_role(ax, rho, hi, lo)) { udb = proj(rho, ax, sDx); rowP5(true, bs0, bl0, cpb, uab, udb, hi); rowP5(true, bs1, bl1, -cpb, -uab, -udb, -lo); }
+            }
+            const int t = otid();
+            { const int rho = t >> 3; udx = proj(rho, 0, sDx); udy = proj(rho, 1, sDx); }
+            for_rows([&](bool ok, double n1, double n2, double h, double& s, double& lam) { rowP5(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h); });
+            if (t == BS - 1 && has_qc) {
+              const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
+              double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDx[e];
+              const double rcq = sq * lq - sm + sc[sDsqA] * sc[sDlqA];
+              const double dsq = -rpq - gd, dlq = -rcq / sq + wq * (rpq + gd);
+              sc[sDsq] = dsq; sc[sDlq] = dlq;
+              rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
+            }
+          }
+          reduce_put<0>(rmax, dmy, dmy, redP5);
+          __syncthreads();                                                                       // barrier 8
+          reduce_get<0>(rmax, dmy, dmy, redP5);
+          {
+            double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
+            alpha = fmin(1.0, fmin(fmax(1.0 - sc[sMu], kStepFracMin), kStepFracMax) * alpha);
+            const int t = otid();
+            if (t == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
+            sc[sAlpha] = alpha; sc[sSigMu] = sm;     // (every thread stores the same two values: pass A reads them back without a barrier in between)
+            if (t < n) sZ[t] += alpha * sDx[t];
+          }
+        }
+        if (uncon) converged = true;
+        if (!converged && sI[16]) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
+      }
+      iters_total = it; if (mode == 0) iters_first = it;
+      __syncthreads();
+      if (converged) {
+        status = mode;   // NEP_OK / NEP_RELAXED
+        objective = sc[sObj];
+        if (tid < 12 * K) {  // theta = Th z + ThU init
+          const int ax = tid / (4 * K), r = tid % (4 * K);
+          double v = tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2];
+          double th[kNZ];
+#pragma unroll
+          for (int c = 0; c < kNZ; c++) th[c] = tb->Th[r][c];
+#pragma unroll
+          for (int c = 0; c < kNZ; c++) v += c < nz ? th[c] * sZ[ax * nz + c] : 0.0;
+          sTheta[(ax * 8 + r / 4) * 4 + (r % 4)] = v;
+        }
+        break;
+      }
+    }
+    __syncthreads();
+    if (!CULL) break;
+    if (use_far || sI[41] == 0 || status == NEP_FAILED) break;
+    {  // the far lines against the solution: position control points from the base rows of the converged mode
+      const QpTable* __restrict__ tbv = tables + status * (kMaxK + 1) + K;
+      const int nzv = tbv->nz;
+      if (tid < 8 * K) {
+        const int rho = tid >> 1, ax = tid & 1;
+        double v = sOff[rho * 3 + ax];
+        for (int c = 0; c < nzv; c++) v = __builtin_fma(sB[rho * SBS + c], sZ[ax * nzv + c], v);
+        sAccL[rho * 2 + ax] = v;
+      }
+      __syncthreads();
+      bool viol = false;
+      const int F = sI[41];
+      for (int e = tid; e < F; e += BS) {
+        int i = 0;
+#pragma unroll
+        for (int j = 1; j < NEP_MAX_POL; j++) i += (e >= sI[52 + j]) ? 1 : 0;
+        const double* src = ps.line_nd + ((long)slot * NEP_MAX_POL + i) * sp.lines_cap * 3;
+        const long q = (long)sp.lines_cap - 1 - (e - sI[52 + i]);
+        const double n1 = src[3 * q], n2 = src[3 * q + 1], dd = src[3 * q + 2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) viol = viol || (n1 * sAccL[(4 * i + k) * 2] + n2 * sAccL[(4 * i + k) * 2 + 1] + dd - 1.0 > 0.0);
+      }
+      if (viol) sI[21] = 1;
+      __syncthreads();
+      if (sI[21] == 0) break;
+      for (int e = tid; e < 256; e += BS) sAccL[e] = 0.0;   // (the accumulators were borrowed: the second attempt starts from zeros again)
+    }
+  }
+  __syncthreads();
+  const int Ko = K_ok ? K : 0;
+  // ---- outputs (as qp_kernel) ---------------------------------------------------------------------
+  if (status == NEP_FAILED) { if (tid < 96) sTheta[tid] = sCoef[tid]; }                    // :856-859
+  else if (z_override) { if (tid < 32) sTheta[64 + tid] = sCoef[64 + tid]; }             // :879-880
+  __syncthreads();
+  if (tid < 96) (&sol->coeff[0][0][0])[tid] = ((tid % 32) / 4 < Ko) ? sTheta[tid] : 0.0;
+  if (tid <= NEP_MAX_POL) sol->times[tid] = (tid <= Ko) ? g->t_start + tid * T : 0.0;
+  const int ns_all = sched.n[Ko];
+  const int ns = ns_all < sp.max_states ? ns_all : sp.max_states;
+  if (tid == 0) {
+    sol->stats.status = status; sol->stats.iters = iters_total; sol->stats.iters_first = iters_first;
+    int n_lp = 0, n_lpf = 0;
+    if (ps.lp_stats && !ps.lines_override) {
+      int v[2 * NEP_MAX_POL];
+#pragma unroll
+      for (int i = 0; i < 2 * NEP_MAX_POL; i++) v[i] = ps.lp_stats[(long)slot * NEP_MAX_POL * 2 + i];
+#pragma unroll
+      for (int i = 0; i < NEP_MAX_POL; i++) { n_lp += v[2 * i]; n_lpf += v[2 * i + 1]; }
+    }
+    sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
+    sol->stats.n_rows = K_ok ? 48 * K + 4 * ((CULL && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;
+    sol->stats.objective = objective; sol->stats.solve_us = 0.0;
+    sol->K = Ko; sol->n_states = ns;
+  }
+  if (ps.states) {  // generatePwpOut's samples (:911-934)
+    for (int s = tid; s < ns; s += BS) {
+      const int i = sched.seg[K * sp.max_states + s]; const double dt = sched.dt[K * sp.max_states + s];
+      double* st = ps.states + ((long)slot * sp.max_states + s) * NEP_STATE_DOUBLES;
+      for (int ax = 0; ax < 3; ax++) {
+        const double* c = sTheta + (ax * 8 + i) * 4;
+        st[ax] = ((c[0] * (dt * dt * dt) + c[1] * (dt * dt)) + c[2] * dt) + c[3];
+        st[3 + ax] = (c[0] * (3 * dt * dt) + c[1] * (2 * dt)) + c[2];
+        st[6 + ax] = c[0] * (6 * dt) + c[1] * 2;
+        st[9 + ax] = c[0] * 6;
+      }
+    }
+  }
+  if (ps.commit) {  // the record the agent would publish (neptune_ros.cpp:434-480); a failed replan publishes nothing (see qp_kernel)
+    nep_traj_rec* cr = ps.commit + slot;
+    const int own = sp.first_local + (slot % sp.n_local);
+    if (status == NEP_FAILED) {
+      if (ps.prev_commit) {
+        const double* src = (const double*)(ps.prev_commit + (long)(slot / sp.n_local) * sp.num_agents + own);
+        for (int e = tid; e < (int)(sizeof(nep_traj_rec) / sizeof(double)); e += BS) ((double*)cr)[e] = src[e];
+      }
+      return;
+    }
+    if (tid == 0) {
+      cr->id = own + 1; cr->is_agent = 1; cr->n_bend = 1; cr->valid = 1;
+      for (int a = 0; a < 3; a++) { cr->bbox[a] = 2 * sp.drone_radius; cr->pos[a] = sTheta[(a * 8) * 4 + 3]; }
+      cr->bend[0][0] = ps.pb[2 * own]; cr->bend[0][1] = ps.pb[2 * own + 1];
+      cr->pwp.n_seg = K;
+    }
+    if (tid <= NEP_TRAJ_MAX_SEG) cr->pwp.times[tid] = (tid <= K) ? g->t_start + tid * T : 0.0;
+    for (int e = tid; e < 3 * NEP_TRAJ_MAX_SEG * 4; e += BS) {
+      const int ax = e / (NEP_TRAJ_MAX_SEG * 4), r = e % (NEP_TRAJ_MAX_SEG * 4), seg = r / 4, j = r % 4;
+      (&cr->pwp.coeff[0][0][0])[e] = (seg < K) ? sTheta[(ax * 8 + seg) * 4 + j] : 0.0;
+    }
+  }
+}
+
+constexpr int kRegSlots = NEP_QP_REG_SLOTS;
+
+int qp_reg_slots() { return kRegSlots; }
+// dynamic LDS of the register kernel: the fixed carve + the coefficient carve [3][NEP_MAX_POL][8 slots]
+size_t qp_reg_lds_bytes() { return (size_t)kFixedDoubles * 8 + 64 * 4 + (size_t)3 * NEP_MAX_POL * 8 * kRegSlots * sizeof(double); }
+
+void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
+                   const SampleSched& sched, size_t lds_bytes, hipStream_t st) {
+  if (n_slots <= 0) return;
+  const bool cull = ps.line_far != nullptr && !ps.lines_override;
+  static DynLdsAttr attr[2];
+  (void)attr[cull].ensure(cull ? (const void*)qp_reg_kernel<true, kRegSlots> : (const void*)qp_reg_kernel<false, kRegSlots>, lds_bytes);
+  if (cull) hipLaunchKernelGGL((qp_reg_kernel<true, kRegSlots>), dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
+  else hipLaunchKernelGGL((qp_reg_kernel<false, kRegSlots>), dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
+}
+
+}  // namespace nep
