@@ -125,6 +125,9 @@ def main():
                     help="presolve of the separating-line rows (nep_batch_set_line_cull): lines farther than this many metres "
                          "from the guess are left out of the QP and verified after the solve; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange-native", action="store_true",
+                    help="N > 1 with --exchange hulls: the all-gather through the C ABI's own RCCL binding (nep_batch_exchange_hulls) "
+                         "instead of torch.distributed")
     ap.add_argument("--no-process-group", action="store_true", help="single GPU: do not create the one-rank RCCL process group")
     ap.add_argument("--no-chain", action="store_true", help="skip the separately reported front end + safety leg")
     ap.add_argument("--frontend", action="store_true",
@@ -241,7 +244,7 @@ def main():
     d_guess_c = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)]
     d_guess = d_guess_c[0]
     ex = ndist.RoundExchange(S, N, world, rank, device=dev)
-    hxs = [ndist.HullExchange(bes[k].hull_block_bytes(), world, rank, device=dev) for k in range(C)] if sharded_hulls else None
+    hxs = [ndist.HullExchange(bes[k].hull_block_bytes(), world, rank, device=dev) for k in range(C)] if (sharded_hulls and args.safety) else None
     d_local_c = [bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)] if sharded_hulls else None
     d_committed_next = torch.empty_like(d_committed) if args.safety else None
     d_new = torch.empty_like(d_committed) if args.safety else None
@@ -261,6 +264,18 @@ def main():
     def ev():
         e = torch.cuda.Event(enable_timing=True); e.record(); return e
 
+    class _timed:
+        def __init__(self, lst): self.lst = lst
+        def __enter__(self): self.e0 = ev()
+        def __exit__(self, *a): self.lst.append((self.e0, ev()))
+    _ev_lists = {"hull": hull_ev, "wait": gather_ev, "frontend": fe_ev}
+    rounds = None
+    if sharded_hulls and not args.safety:
+        rounds = ndist.ShardedRounds(bes, d_local_c, d_guess_c, world, rank, native=args.exchange_native,
+                                     fe=(fe_cfg, d_fe_start_c, d_fe_res_c) if args.frontend else None,
+                                     timer=lambda name: _timed(_ev_lists[name]))
+        hxs = rounds.hx
+
     def start_exchange(k, src):
         """hulls of my agents' committed trajectories (chunk k) -> start the all-gather of the hull blocks"""
         e0 = ev()
@@ -269,23 +284,8 @@ def main():
         pending[k] = hxs[k].gather_async()
 
     def step():
-        if sharded_hulls and not args.safety:
-            # Pipelined over the scene chunks: right after chunk k's replan its next hulls are built and
-            # their all-gather is started, so the collective of one chunk runs under the other chunk's
-            # separator + QP kernels.  One step = every chunk replans once.
-            for k in range(C):
-                if pending[k] is None:
-                    start_exchange(k, d_local_c[k])
-            for k in range(C):
-                e1 = ev()
-                pending[k].wait()
-                gather_ev.append((e1, ev()))                 # what the stream still had to wait for
-                if args.frontend:
-                    e0 = ev()
-                    bes[k].frontend_hulls(fe_cfg, hxs[k].blocks, d_fe_start_c[k], d_guess_c[k], d_fe_res_c[k])
-                    fe_ev.append((e0, ev()))
-                bes[k].replan_hulls(hxs[k].blocks, d_guess_c[k])
-                start_exchange(k, bes[k].d_commit)           # my agents' new committed trajectories
+        if rounds is not None:
+            rounds.step()          # chunks pipelined: one chunk's all-gather runs under the other chunk's kernels (dist.ShardedRounds)
             return
         if sharded_hulls:
             start_exchange(0, d_local_c[0])

@@ -282,6 +282,33 @@ int nep_batch_replan_hulls(nep_batch_t* h, const void* d_blocks, int32_t n_block
                            const nep_guess* d_guess, const void* d_ent, nep_solution* d_solution,
                            double* d_states, nep_traj_rec* d_commit, void* stream);
 
+/* ------------------------------------------------------------------------------------------ */
+/* The exchange step of a multi-GPU round (RCCL all-gather over xGMI), for hosts without PyTorch */
+/* ------------------------------------------------------------------------------------------ */
+/* One process per GPU; rank r owns agents [r n_local, (r+1) n_local) of every scene (nep_batch_cfg.first_local).  The
+ * reference exchanges committed trajectories on the /trajs topic (neptune_ros.cpp:434-480 publish, :379-430
+ * receive); here one all-gather per round on the caller's stream does.  RCCL is bound at run time (dlopen of
+ * librccl.so: the copy the process already holds, or the system's); without it these calls return NEP_E_HIP and
+ * nothing else of the library is affected.
+ *   nep_comm_unique_id      rank 0 creates the 128-byte id (ncclGetUniqueId) and ships it to the others by any means
+ *   nep_comm_create         ncclCommInitRank on the calling thread's current HIP device; NULL on failure
+ *   nep_batch_exchange_hulls    d_block (this rank's block from nep_batch_hulls) -> d_blocks (world consecutive
+ *                               blocks, rank order = agent-id order: what nep_batch_replan_hulls reads)
+ *   nep_batch_exchange_records  d_commit_local [n_scenes][n_local] (nep_batch_replan's d_commit) ->
+ *                               d_committed_all [n_scenes][N]: the literal "all-gather of committed trajectories"
+ * Both are asynchronous on `stream`; a round is  nep_batch_hulls -> nep_batch_exchange_hulls ->
+ * nep_batch_replan_hulls  (or  nep_batch_replan -> nep_batch_exchange_records).                                */
+typedef struct nep_comm nep_comm_t;
+int nep_comm_unique_id(uint8_t id_out[128]);
+nep_comm_t* nep_comm_create(const uint8_t id[128], int32_t world, int32_t rank);
+void nep_comm_destroy(nep_comm_t* c);
+int nep_batch_exchange_hulls(nep_batch_t* h, nep_comm_t* c, const void* d_block, void* d_blocks, void* stream);
+int nep_batch_exchange_records(nep_batch_t* h, nep_comm_t* c, const nep_traj_rec* d_commit_local,
+                               nep_traj_rec* d_committed_all, void* stream);
+/* Test hook: the regrouping step of nep_batch_exchange_records ([world][n_scenes][n_local] -> [n_scenes][world n_local]). */
+int nep_debug_regroup_records(const nep_traj_rec* d_src, nep_traj_rec* d_dst, int32_t world, int32_t n_scenes,
+                              int32_t n_local, void* stream);
+
 /* Dense per-slot entangle block consumed by nep_batch_replan when enable_entangle != 0:
  *   int32 case_id[NEP_MAX_POL][N]   (0 = no active case for that agent at that segment,
  *                                    else the alphas case id, solver_gurobi_poly.cpp:624-631)

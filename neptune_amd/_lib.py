@@ -20,7 +20,8 @@ EXPORTS = [
     "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
     "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
     "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_gjk_batch",
-    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics",
+    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy",
+    "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
@@ -86,6 +87,12 @@ def lib():
     L.nep_batch_set_line_cull.argtypes = [vp, d]
     L.nep_batch_set_scene_statics.argtypes = [vp, i, i, pi, pd]
     L.nep_batch_check.argtypes = [vp, vp]
+    L.nep_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
+    L.nep_comm_create.argtypes = [C.POINTER(C.c_uint8), i, i]; L.nep_comm_create.restype = vp
+    L.nep_comm_destroy.argtypes = [vp]; L.nep_comm_destroy.restype = None
+    L.nep_batch_exchange_hulls.argtypes = [vp, vp, vp, vp, vp]
+    L.nep_batch_exchange_records.argtypes = [vp, vp, vp, vp, vp]
+    L.nep_debug_regroup_records.argtypes = [vp, vp, i, i, i, vp]
     L.nep_batch_hull_block_bytes.argtypes = [vp]; L.nep_batch_hull_block_bytes.restype = C.c_int64
     L.nep_batch_hulls.argtypes = [vp, vp, vp, vp, vp]
     L.nep_batch_replan_hulls.argtypes = [vp, vp, i, vp, vp, vp, vp, vp, vp]

@@ -860,6 +860,15 @@ int nep_batch_debug_phase_cycles(nep_batch_t* h, int32_t slot, int64_t* out16) {
   return 0;
 }
 
+}  // extern "C"
+// hooks for exchange.hip (the RCCL step lives in its own translation unit)
+namespace nep {
+void set_last_error(const std::string& msg) { g_err = msg; }
+int64_t batch_hull_block_bytes(const struct ::nep_batch* h) { return nep_batch_hull_block_bytes(h); }
+void batch_dims(const struct ::nep_batch* h, int* n_scenes, int* n_local, int* num_agents) { *n_scenes = h->cfg.n_scenes; *n_local = h->cfg.n_local; *num_agents = h->cfg.num_agents; }
+}
+extern "C" {
+
 // layout self-description for the ctypes mirror (tests/test_abi.py)
 int nep_abi_sizeof(int32_t which) {
   switch (which) {

@@ -1,0 +1,153 @@
+// exchange.hip — the round's exchange step inside the C ABI: RCCL all-gather over xGMI on the caller's HIP stream.
+//
+// The reference exchanges committed trajectories on the /trajs topic (neptune_ros.cpp:434-480 publish, :379-430 receive);
+// here a rank owns a block of agents and one all-gather per round rebuilds what every rank replans against: the interval
+// hulls of everybody's committed trajectories (nep_batch_exchange_hulls, the default) or the records themselves
+// (nep_batch_exchange_records).  RCCL is bound at run time (dlopen of librccl.so, whichever copy the process already
+// holds — PyTorch ships one — or the system's): the library has no link-time dependency on it and a single-GPU user
+// never touches it.  Types and prototypes are RCCL's own (<rccl/rccl.h>).
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <mutex>
+#include <string>
+
+#include "nep_device.h"
+
+namespace nep {
+void set_last_error(const std::string& msg);
+int64_t batch_hull_block_bytes(const struct ::nep_batch* h);
+void batch_dims(const struct ::nep_batch* h, int* n_scenes, int* n_local, int* num_agents);
+}
+
+namespace {
+
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  std::string err;
+  bool load() {
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    if (lib) return true;
+    // RTLD_NOLOAD first: reuse the copy the process already mapped (torch.distributed's), so that one RCCL serves both
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
+    if (!lib) { err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return false; }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) { err = "librccl.so lacks an expected symbol"; lib = nullptr; return false; }
+    return true;
+  }
+};
+Rccl g_rccl;
+
+int fail_nccl(const char* what, ncclResult_t r) {
+  nep::set_last_error(std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error"));
+  return NEP_E_HIP;
+}
+
+// [W][S][nl] records (rank-major, as the all-gather delivers them) -> [S][W * nl] (scene-major, id order)
+__global__ void regroup_records_kernel(const double* __restrict__ src, double* __restrict__ dst, int W, int S, int nl, int words) {
+  const long total = (long)W * S * nl * words;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int w = (int)(e % words); long r = e / words;
+    const int a = (int)(r % nl); r /= nl;
+    const int s = (int)(r % S); const int k = (int)(r / S);
+    dst[(((long)s * W + k) * nl + a) * words + w] = src[e];
+  }
+}
+
+}  // namespace
+
+struct nep_comm {
+  ncclComm_t comm = nullptr;
+  int world = 1, rank = 0;
+  double* staging = nullptr; size_t staging_bytes = 0;
+};
+
+extern "C" {
+
+int nep_comm_unique_id(uint8_t id_out[128]) {
+  if (!id_out) { nep::set_last_error("null argument"); return NEP_E_ARG; }
+  if (!g_rccl.load()) { nep::set_last_error(g_rccl.err); return NEP_E_HIP; }
+  ncclUniqueId id;
+  const ncclResult_t r = g_rccl.GetUniqueId(&id);
+  if (r != ncclSuccess) return fail_nccl("ncclGetUniqueId", r);
+  static_assert(sizeof(id.internal) == 128, "ncclUniqueId size");
+  for (int i = 0; i < 128; i++) id_out[i] = (uint8_t)id.internal[i];
+  return 0;
+}
+
+nep_comm_t* nep_comm_create(const uint8_t id[128], int32_t world, int32_t rank) {
+  if (!id || world < 1 || rank < 0 || rank >= world) { nep::set_last_error("bad communicator arguments"); return nullptr; }
+  if (!g_rccl.load()) { nep::set_last_error(g_rccl.err); return nullptr; }
+  ncclUniqueId uid;
+  for (int i = 0; i < 128; i++) uid.internal[i] = (char)id[i];
+  nep_comm* c = new nep_comm();
+  c->world = world; c->rank = rank;
+  const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);     // on the calling thread's current HIP device
+  if (r != ncclSuccess) { fail_nccl("ncclCommInitRank", r); delete c; return nullptr; }
+  return c;
+}
+
+void nep_comm_destroy(nep_comm_t* c) {
+  if (!c) return;
+  if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  if (c->staging) hipFree(c->staging);
+  delete c;
+}
+
+int nep_batch_exchange_hulls(nep_batch_t* h, nep_comm_t* c, const void* d_block, void* d_blocks, void* stream) {
+  if (!h || !c || !d_block || !d_blocks) { nep::set_last_error("null argument"); return NEP_E_ARG; }
+  const size_t bytes = (size_t)nep::batch_hull_block_bytes(h);
+  const ncclResult_t r = g_rccl.AllGather(d_block, d_blocks, bytes, ncclChar, c->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return fail_nccl("ncclAllGather(hull blocks)", r);
+  return 0;
+}
+
+int nep_batch_exchange_records(nep_batch_t* h, nep_comm_t* c, const nep_traj_rec* d_commit_local, nep_traj_rec* d_committed_all, void* stream) {
+  if (!h || !c || !d_commit_local || !d_committed_all) { nep::set_last_error("null argument"); return NEP_E_ARG; }
+  int S = 0, nl = 0, N = 0;
+  nep::batch_dims(h, &S, &nl, &N);
+  if (nl * c->world != N) { nep::set_last_error("world * n_local must equal num_agents"); return NEP_E_ARG; }
+  const size_t piece = (size_t)S * nl * sizeof(nep_traj_rec);
+  if (c->staging_bytes < piece * c->world) {
+    if (c->staging) hipFree(c->staging);
+    c->staging = nullptr; c->staging_bytes = 0;
+    if (hipMalloc((void**)&c->staging, piece * c->world) != hipSuccess) { nep::set_last_error("hipMalloc(exchange staging)"); return NEP_E_HIP; }
+    c->staging_bytes = piece * c->world;
+  }
+  const ncclResult_t r = g_rccl.AllGather(d_commit_local, c->staging, piece, ncclChar, c->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return fail_nccl("ncclAllGather(records)", r);
+  const int words = (int)(sizeof(nep_traj_rec) / sizeof(double));
+  const long total = (long)c->world * S * nl * words;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(regroup_records_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->staging, (double*)d_committed_all, c->world, S, nl, words);
+  if (hipGetLastError() != hipSuccess) { nep::set_last_error("regroup_records_kernel launch"); return NEP_E_HIP; }
+  return 0;
+}
+
+// Test hook: the regrouping step of nep_batch_exchange_records for any world size, on device buffers
+// (src: [W][S][nl] records as an all-gather delivers them, dst: [S][W * nl]).
+int nep_debug_regroup_records(const nep_traj_rec* d_src, nep_traj_rec* d_dst, int32_t world, int32_t n_scenes, int32_t n_local, void* stream) {
+  if (!d_src || !d_dst || world < 1 || n_scenes < 1 || n_local < 1) { nep::set_last_error("bad arguments"); return NEP_E_ARG; }
+  const int words = (int)(sizeof(nep_traj_rec) / sizeof(double));
+  const long total = (long)world * n_scenes * n_local * words;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(regroup_records_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const double*)d_src, (double*)d_dst, world, n_scenes, n_local, words);
+  if (hipGetLastError() != hipSuccess) { nep::set_last_error("regroup_records_kernel launch"); return NEP_E_HIP; }
+  return 0;
+}
+
+}  // extern "C"

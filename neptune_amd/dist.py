@@ -105,6 +105,98 @@ class HullExchange:
         return self.blocks
 
 
+class NativeExchange:
+    """The same two exchanges through the C ABI's own RCCL binding (nep_comm_* / nep_batch_exchange_*: what a C++ host
+    without PyTorch calls).  The 128-byte communicator id is made by rank 0 and handed to the other ranks through
+    `broadcast_id` (any transport: here torch.distributed's broadcast when a process group exists)."""
+
+    def __init__(self, backend, world=1, rank=0, broadcast_id=None):
+        import ctypes as C
+        from ._lib import lib, check, BackendError
+        self.C, self.lib, self.check = C, lib(), check
+        self.be, self.world, self.rank = backend, world, rank
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            check(self.lib.nep_comm_unique_id(uid))
+        if world > 1:
+            if broadcast_id is None:
+                import torch
+                import torch.distributed as dist
+                t = torch.tensor(list(uid), dtype=torch.uint8)
+                if dist.get_backend() == "nccl":
+                    t = t.to(backend.device)
+                dist.broadcast(t, src=0)
+                uid = (C.c_uint8 * 128)(*t.cpu().tolist())
+            else:
+                uid = (C.c_uint8 * 128)(*broadcast_id(bytes(uid)))
+        with backend.torch.cuda.device(backend.device):
+            self._c = self.lib.nep_comm_create(uid, world, rank)
+        if not self._c:
+            raise BackendError(self.lib.nep_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_c", None):
+            self.lib.nep_comm_destroy(self._c)
+            self._c = None
+
+    __del__ = close
+
+    def hulls(self, d_block, d_blocks, stream=None):
+        st = stream if stream is not None else self.be.torch.cuda.current_stream(self.be.device)
+        self.check(self.lib.nep_batch_exchange_hulls(self.be._h, self._c, d_block.data_ptr(), d_blocks.data_ptr(), st.cuda_stream))
+
+    def records(self, d_commit_local, d_committed_all, stream=None):
+        st = stream if stream is not None else self.be.torch.cuda.current_stream(self.be.device)
+        self.check(self.lib.nep_batch_exchange_records(self.be._h, self._c, d_commit_local.data_ptr(), d_committed_all.data_ptr(), st.cuda_stream))
+
+
+class ShardedRounds:
+    """The multi-GPU round loop of bench.py (and of a deployment): the scenes are split into `chunks` groups, each with its
+    own handle; for a chunk one round is  hulls of MY agents' committed trajectories -> all-gather of the hull blocks ->
+    [front end ->] separating lines + QP against the gathered blocks,  and right after a chunk's replan its next hulls
+    are built and their all-gather is started, so that the collective of one chunk runs under the other chunk's kernels.
+    One step = every chunk replans once.  Results do not depend on `chunks` (tested against chunks = 1)."""
+
+    def __init__(self, backends, d_local, d_guess, world=1, rank=0, group=None, native=False, fe=None, timer=None):
+        """backends: one BatchBackend per chunk; d_local[k]: device bytes [Sc][n_local] committed records of my agents in
+        chunk k; d_guess[k]: [Sc][n_local] guesses; fe: None or (fe_cfg, d_start[k], d_result[k]); native: exchange through
+        the C ABI's own RCCL binding (nep_batch_exchange_hulls, on the current stream) instead of torch.distributed;
+        timer: None or a callable name -> context manager (bench.py records HIP events around the phases)."""
+        import contextlib
+        self.bes, self.d_local, self.d_guess, self.fe = backends, d_local, d_guess, fe
+        self.C = len(backends)
+        dev = backends[0].device
+        self.hx = [HullExchange(b.hull_block_bytes(), world, rank, group=group, device=dev) for b in backends]
+        self.native = NativeExchange(backends[0], world, rank) if native else None
+        self.pending = [None] * self.C
+        self.timer = timer if timer is not None else (lambda name: contextlib.nullcontext())
+
+    def _start(self, k, src):
+        b, hx = self.bes[k], self.hx[k]
+        with self.timer("hull"):
+            b.hulls(src, self.d_guess[k], hx.local)
+        if self.native is not None:
+            self.native.hulls(hx.local, hx.blocks)      # (in place when there is one rank: sendbuff == recvbuff + rank * count)
+            self.pending[k] = HullExchange._Done()
+        else:
+            self.pending[k] = hx.gather_async()
+
+    def step(self):
+        for k in range(self.C):
+            if self.pending[k] is None:
+                self._start(k, self.d_local[k])
+        for k in range(self.C):
+            with self.timer("wait"):
+                self.pending[k].wait()                   # what the stream still has to wait for
+            b = self.bes[k]
+            if self.fe is not None:
+                cfg, d_start, d_res = self.fe
+                with self.timer("frontend"):
+                    b.frontend_hulls(cfg, self.hx[k].blocks, d_start[k], self.d_guess[k], d_res[k])
+            b.replan_hulls(self.hx[k].blocks, self.d_guess[k])
+            self._start(k, b.d_commit)                   # my agents' new committed trajectories
+
+
 def stack_scenes(scenes):
     """[scene dicts] -> (committed [S][N], guesses [S][N]) numpy structured arrays."""
     com = np.stack([s["committed"] for s in scenes])

@@ -1,0 +1,125 @@
+"""GPU tests of the multi-GPU round at the BASELINE layouts, on one GPU: every "rank" is a handle that owns a block of
+agents; what the all-gather would deliver is assembled in device memory (or goes through the C ABI's RCCL binding with
+one rank).  Results must equal the single-rank replan bit for bit."""
+import numpy as np
+import pytest
+
+from neptune_amd import abi, scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from neptune_amd import backend
+    return backend
+
+
+def _emulated_ranks(be, N, M, S, world, seeds):
+    from neptune_amd import dist as ndist
+    scenes = [scene.make_scene(N, M, seed=s) for s in seeds]
+    p = scenes[0]["par"]
+    com, gue = ndist.stack_scenes(scenes)
+    full = be.BatchBackend(p, scenes[0]["statics"], n_scenes=S)
+    for s in range(1, S):
+        full.set_scene_statics(s, scenes[s]["statics"])
+    full.replan(full.to_device(com), full.to_device(gue))
+    want = full.solutions().reshape(S, N); want_commit = full.commits().reshape(S, N)
+    T = full.torch
+    nl = N // world
+    ranks = []
+    for r in range(world):
+        h = be.BatchBackend(p, scenes[0]["statics"], first_local=r * nl, n_local=nl, n_scenes=S)
+        for s in range(1, S):
+            h.set_scene_statics(s, scenes[s]["statics"])
+        ranks.append(h)
+    bb = ranks[0].hull_block_bytes()
+    blocks = T.zeros(world * bb, dtype=T.uint8, device=full.device)
+    g_loc = [ranks[r].to_device(np.ascontiguousarray(gue[:, r * nl:(r + 1) * nl])) for r in range(world)]
+    for r in range(world):
+        ranks[r].hulls(ranks[r].to_device(np.ascontiguousarray(com[:, r * nl:(r + 1) * nl])), g_loc[r], blocks[r * bb:(r + 1) * bb])
+    pieces = []
+    for r in range(world):
+        ranks[r].replan_hulls(blocks, g_loc[r])
+        got = ranks[r].solutions().reshape(S, nl); ref = want[:, r * nl:(r + 1) * nl]
+        assert got.tobytes() == ref.tobytes(), "rank %d of %d" % (r, world)
+        gc = ranks[r].commits().reshape(S, nl)
+        assert gc.tobytes() == want_commit[:, r * nl:(r + 1) * nl].tobytes()
+        pieces.append(ranks[r].d_commit.clone())
+    # the record all-gather's regrouping ([W][S][nl] as delivered -> [S][N]) through the C ABI's kernel
+    from neptune_amd._lib import lib, check
+    gathered = T.cat(pieces)
+    out = T.zeros_like(gathered)
+    check(lib().nep_debug_regroup_records(gathered.data_ptr(), out.data_ptr(), world, S, nl, T.cuda.current_stream().cuda_stream))
+    T.cuda.synchronize()
+    assert out.cpu().numpy().view(abi.TRAJ_REC_DTYPE).reshape(S, N).tobytes() == want_commit.tobytes()
+    assert int(want["stats"]["n_lines"].sum()) > 0
+    for h in ranks:
+        h.close()
+    full.close()
+
+
+def test_config4_layout_64_agents_8_ranks_4_scenes(be):
+    """BASELINE configs[3]: 64 agents + 20 obstacles, 8 ranks x 8 agents, four scenes with their own obstacles."""
+    _emulated_ranks(be, 64, 20, 4, 8, seeds=(40, 41, 42, 43))
+
+
+def test_config5_layout_256_agents_8_ranks(be):
+    """BASELINE configs[4] layout without the entangle rows: 256 agents + 100 obstacles, 8 ranks x 32 agents."""
+    _emulated_ranks(be, 256, 100, 1, 8, seeds=(3,))
+
+
+def test_pipelined_chunks_equal_the_unpipelined_round(be):
+    """bench.py's multi-GPU step (dist.ShardedRounds): two scene chunks whose exchanges overlap the other chunk's kernels
+    must leave exactly the records of the one-chunk loop after several rounds — here with one rank, through
+    torch-free paths (no process group) and through the C ABI's RCCL binding."""
+    from neptune_amd import dist as ndist
+    N, M, S, steps = 16, 8, 4, 3
+    scenes = [scene.make_scene(N, M, seed=80 + s) for s in range(S)]
+    p = scenes[0]["par"]
+    com, gue = ndist.stack_scenes(scenes)
+
+    def run(chunks, native):
+        Sc = S // chunks
+        bes = []
+        for k in range(chunks):
+            h = be.BatchBackend(p, scenes[k * Sc]["statics"], n_scenes=Sc)
+            for s in range(Sc):
+                h.set_scene_statics(s, scenes[k * Sc + s]["statics"])
+            bes.append(h)
+        d_local = [bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc])) for k in range(chunks)]
+        d_guess = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc])) for k in range(chunks)]
+        rounds = ndist.ShardedRounds(bes, d_local, d_guess, world=1, rank=0, native=native)
+        for _ in range(steps):
+            rounds.step()
+        out = np.concatenate([b.commits() for b in bes]); sol = np.concatenate([b.solutions() for b in bes])
+        if rounds.native is not None:
+            rounds.native.close()
+        for b in bes:
+            b.close()
+        return out, sol
+    ref_c, ref_s = run(1, False)
+    for chunks, native in ((2, False), (4, False), (2, True)):
+        c, s_ = run(chunks, native)
+        assert c.tobytes() == ref_c.tobytes(), (chunks, native)
+        assert s_.tobytes() == ref_s.tobytes(), (chunks, native)
+    assert (ref_s["stats"]["status"] != 2).all()
+
+
+def test_native_record_exchange_one_rank(be):
+    """nep_batch_exchange_records with one rank: the all-gather (RCCL) + regrouping is the identity on [S][N] records."""
+    from neptune_amd import dist as ndist
+    scenes = [scene.make_scene(8, 4, seed=90 + s) for s in range(3)]
+    p = scenes[0]["par"]
+    com, gue = ndist.stack_scenes(scenes)
+    h = be.BatchBackend(p, scenes[0]["statics"], n_scenes=3)
+    h.replan(h.to_device(com), h.to_device(gue))
+    nx = ndist.NativeExchange(h, 1, 0)
+    out = h.torch.zeros_like(h.d_commit)
+    nx.records(h.d_commit, out)
+    h.torch.cuda.synchronize()
+    assert out.cpu().numpy().tobytes() == h.d_commit.cpu().numpy().tobytes()
+    nx.close(); h.close()
