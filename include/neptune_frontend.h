@@ -45,6 +45,9 @@ extern "C" {
 
 #define NEP_FE_MAX_BEAM 64
 #define NEP_FE_MAX_SAMPLES 5
+#define NEP_FE_ENT_CAP 24         /* crossings kept per search node with the entangle check on (the reference prunes a
+                                     node at num_agents + statics crossings; one that would exceed this capacity is
+                                     pruned too and reported in nep_fe_result.ent_overflow)                          */
 
 #define NEP_FE_GOAL_REACHED 1     /* status codes of KinodynamicSearch::run (:1637-1639)          */
 #define NEP_FE_DEPTH_REACHED 0    /* (RUNTIME_REACHED there): best node of the last depth         */
@@ -66,8 +69,21 @@ typedef struct nep_fe_cfg {
                                      also separates the place where the vehicle will WAIT from everybody's
                                      committed trajectory (the reference leaves that unchecked,
                                      kinodynamic_search.cpp:1805-1813)                               */
+  int32_t enable_entangle;        /* par_.enable_entangle_check: nep_batch_frontend_ent only                       */
+  int32_t ent_samples;            /* num_sample_per_interval (yaml: 3), 1..8                                       */
   int32_t _pad;
 } nep_fe_cfg;
+
+/* eu::ent_state of one search node / of point A (entangle_utils.hpp:23-29) in a fixed-size record: the crossing list
+ * (agent or static id, case), its betas and the bend-point indices; active_cases[i] is the number of list entries of
+ * agent i and is not stored.                                                                                       */
+typedef struct nep_fe_ent_state {
+  int32_t n_alpha, n_bend;
+  int16_t id[NEP_FE_ENT_CAP];
+  int8_t cs[NEP_FE_ENT_CAP];
+  double beta[NEP_FE_ENT_CAP];
+  int8_t bend[NEP_MAX_BEND];
+} nep_fe_ent_state;
 
 /* Point A and the goal of one slot (setUp, kinodynamic_search.cpp:190-227).                      */
 typedef struct nep_fe_start {
@@ -87,6 +103,8 @@ typedef struct nep_fe_result {
   int32_t _pad;
   double cost;                    /* g + bias*h of the returned node                               */
   double dist_to_goal;
+  int32_t n_entangled;            /* children pruned by entanglesWithOtherAgents (entangle check on)        */
+  int32_t ent_overflow;           /* 1: a node's crossing list would have exceeded NEP_FE_ENT_CAP           */
 } nep_fe_result;
 
 /* Front end of every slot of the batch handle, asynchronous on `stream`.
@@ -104,6 +122,40 @@ int nep_batch_frontend(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec
 int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* d_blocks, int32_t n_blocks,
                              const nep_fe_start* d_start, nep_guess* d_guess, nep_fe_result* d_result,
                              void* stream);
+
+/* ---- enable_entangle_check on ---------------------------------------------------------------------------------
+ * The search node carries the tether's entangle state (eu::ent_state) the way the reference's does:
+ *   pruning     entanglesWithOtherAgents on every child (kinodynamic_search.cpp:1160-1164, :1345-1353, body :707-895):
+ *               crossings of the child's sampled step with every other agent's tether polyline (its committed
+ *               trajectory sampled ent_samples times per interval, Neptune::SamplePointsOfIntervals neptune.cpp:500-565,
+ *               and its bend points from the record) and with the static representatives; cancellation against the
+ *               accumulated list; a second active case for an agent, too many crossings or a tether longer than
+ *               cable_length prune the child
+ *   costs       g = sampled arc length, h = distance to the goal + 0.3 per crossing + 1.0 per bend point (:1177-1182)
+ *   voxel       (ix, iy, getIz(state)) (:1170-1173, :2006-2031)
+ *   collision   additionally the other agents' 0.7 m base squares (collidesWithBases2d, :1583-1628, :1675)
+ *   end point   only a node whose active cases are all <= 1 may end the plan (:1693-1700)
+ * and the states along the returned path give the dense case block nep_batch_replan's d_ent takes (the case of
+ * (segment i, agent j) from the state at the START of segment i, solver_gurobi_poly.cpp:624-631) — guesses AND entangle
+ * cases are then device-made.  Bit-identical to oracle/'s orc_frontend_beam_ent.
+ *
+ * nep_batch_set_static_reps   staticObsRep_ / staticObsLongestDist_ (setStaticObstRep, kinodynamic_search.cpp:385-390):
+ *                             rep [n_static][2][2] (col(0), col(1)), longest [n_static][2]; scene = -1: every scene
+ * nep_batch_frontend_ent      d_ent_init: [slots] state at point A or NULL (empty); d_case_out: [slots][NEP_MAX_POL][N]
+ *                             (out, may be NULL).  Unsharded handle (n_local == num_agents), created with enable_entangle.
+ * nep_batch_safety_commit_ent nep_batch_safety_commit plus KinodynamicSearch::entangleCheckGivenPwp (:897-985) as
+ *                             Neptune::safetyCheckAfterReplan calls it (neptune.cpp:746-754): every new trajectory is
+ *                             re-checked from the state at its start against everybody's NEW trajectories and bend
+ *                             points; as in the reference only its FIRST interval is examined (the loop returns at the
+ *                             end of its first pass, :983), with three times the search's crossing capacity and no
+ *                             tether-length test.  An entangling trajectory is turned down like a colliding one.   */
+int nep_batch_set_static_reps(nep_batch_t* h, int32_t scene, const double* rep, const double* longest);
+int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed, const nep_fe_start* d_start,
+                           const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result,
+                           int32_t* d_case_out, void* stream);
+int nep_batch_safety_commit_ent(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new, const nep_guess* d_guess,
+                                const nep_fe_ent_state* d_ent_init, int32_t ent_samples, double cable_length,
+                                nep_traj_rec* d_final, int32_t* d_accept, void* stream);
 
 #ifdef __cplusplus
 }

@@ -163,7 +163,10 @@ class PolySolver {
 // -------------------------------------------------------------------------------------------------
 // Exact-signature drop-in for the reference tree (needs Eigen + the reference's own type headers).
 // -------------------------------------------------------------------------------------------------
-#if defined(NEPTUNE_AMD_REFERENCE_SHIM) && __has_include(<Eigen/Dense>)
+#if defined(NEPTUNE_AMD_REFERENCE_SHIM)
+#if !__has_include(<Eigen/Dense>)
+#error "NEPTUNE_AMD_REFERENCE_SHIM needs Eigen (<Eigen/Dense>) and the reference's mader_types.hpp / entangle_utils.hpp on the include path"
+#endif
 #include <Eigen/Dense>
 #include "entangle_utils.hpp"   // eu::ent_state
 #include "mader_types.hpp"      // mt::PieceWisePol, mt::state, mt::Polygon_Std, ...

@@ -31,7 +31,7 @@ PLAN_EXPORTS = [
 ]
 # every symbol include/neptune_entangle.h declares (host-only)
 # include/neptune_frontend.h
-FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls"]
+FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_frontend_ent", "nep_batch_safety_commit_ent"]
 ENT_EXPORTS = ["nep_ent_sample_points", "nep_ent_propagate_segment", "nep_ent_propagate_guess", "nep_ent_case_ids"]
 
 
@@ -120,6 +120,9 @@ def lib():
     L.nep_ent_case_ids.argtypes = [i, i, pi, pi, pi, i, pi]
     L.nep_batch_frontend.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, vp, vp, vp, vp]
     L.nep_batch_frontend_hulls.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, i, vp, vp, vp, vp]
+    L.nep_batch_set_static_reps.argtypes = [vp, i, pd, pd]
+    L.nep_batch_frontend_ent.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, vp, vp, vp, vp, vp, vp]
+    L.nep_batch_safety_commit_ent.argtypes = [vp, vp, vp, vp, vp, i, d, vp, vp, vp]
     _lib = L
     return L
 

@@ -120,7 +120,16 @@ class nep_fe_cfg(C.Structure):
     """include/neptune_frontend.h: the KinodynamicSearch setters the batched front end needs."""
     _fields_ = [("j_max", C.c_double), ("voxel_size", C.c_double), ("bias", C.c_double), ("goal_size", C.c_double),
                 ("cable_length", C.c_double), ("num_samples", C.c_int32), ("beam_width", C.c_int32),
-                ("pad_hold", C.c_int32), ("_pad", C.c_int32)]
+                ("pad_hold", C.c_int32), ("enable_entangle", C.c_int32), ("ent_samples", C.c_int32), ("_pad", C.c_int32)]
+
+
+NEP_FE_ENT_CAP = 24
+
+
+class nep_fe_ent_state(C.Structure):
+    """eu::ent_state of a search node / of point A in a fixed-size record (include/neptune_frontend.h)."""
+    _fields_ = [("n_alpha", C.c_int32), ("n_bend", C.c_int32), ("id", C.c_int16 * NEP_FE_ENT_CAP), ("cs", C.c_int8 * NEP_FE_ENT_CAP),
+                ("beta", C.c_double * NEP_FE_ENT_CAP), ("bend", C.c_int8 * 8)]
 
 
 class nep_fe_start(C.Structure):
@@ -131,7 +140,7 @@ class nep_fe_start(C.Structure):
 class nep_fe_result(C.Structure):
     _fields_ = [("status", C.c_int32), ("K", C.c_int32), ("depth", C.c_int32), ("n_children", C.c_int32),
                 ("n_feasible", C.c_int32), ("n_collision_free", C.c_int32), ("goal_occupied", C.c_int32), ("_pad", C.c_int32),
-                ("cost", C.c_double), ("dist_to_goal", C.c_double)]
+                ("cost", C.c_double), ("dist_to_goal", C.c_double), ("n_entangled", C.c_int32), ("ent_overflow", C.c_int32)]
 
 
 def np_dtype(struct):
@@ -143,6 +152,7 @@ GUESS_DTYPE = np.dtype(nep_guess)
 SOLUTION_DTYPE = np.dtype(nep_solution)
 FE_START_DTYPE = np.dtype(nep_fe_start)
 FE_RESULT_DTYPE = np.dtype(nep_fe_result)
+FE_ENT_STATE_DTYPE = np.dtype(nep_fe_ent_state)
 
 
 def dptr(a):

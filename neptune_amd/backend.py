@@ -259,6 +259,30 @@ class BatchBackend:
         check(lib().nep_batch_frontend_hulls(self._h, C.byref(fe_cfg), d_blocks.data_ptr(), self.N // self.n_local, d_start.data_ptr(),
                                              d_guess.data_ptr(), d_result.data_ptr() if d_result is not None else None, st.cuda_stream))
 
+    # ---- entangle check on (include/neptune_frontend.h) ------------------------------------------------------------
+    def set_static_reps(self, reps, longest, scene=-1):
+        """staticObsRep_ [S][2][2] and staticObsLongestDist_ [S][2] (nep_batch_set_static_reps)"""
+        r = np.ascontiguousarray(reps, dtype=np.float64).reshape(-1); l = np.ascontiguousarray(longest, dtype=np.float64).reshape(-1)
+        if r.size == 0:
+            r = np.zeros(4); l = np.zeros(2)
+        check(lib().nep_batch_set_static_reps(self._h, scene, abi.dptr(r), abi.dptr(l)))
+
+    def frontend_ent(self, fe_cfg, d_committed, d_start, d_guess, d_result=None, d_case_out=None, d_ent_init=None, stream=None):
+        """the front end with per-node entangle states: guesses and the dense case block [slots][8][N] (int32) of nep_batch_replan"""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_frontend_ent(self._h, C.byref(fe_cfg), d_committed.data_ptr(), d_start.data_ptr(),
+                                           d_ent_init.data_ptr() if d_ent_init is not None else None, d_guess.data_ptr(),
+                                           d_result.data_ptr() if d_result is not None else None,
+                                           d_case_out.data_ptr() if d_case_out is not None else None, st.cuda_stream))
+
+    def safety_commit_ent(self, d_prev, d_new, d_guess, d_final, d_accept=None, d_ent_init=None, ent_samples=3, cable_length=None, stream=None):
+        """safety_commit plus entangleCheckGivenPwp on every new trajectory (nep_batch_safety_commit_ent)"""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        cable = self.par.tether_length if cable_length is None else cable_length
+        check(lib().nep_batch_safety_commit_ent(self._h, d_prev.data_ptr(), d_new.data_ptr(), d_guess.data_ptr(),
+                                                d_ent_init.data_ptr() if d_ent_init is not None else None, ent_samples, float(cable),
+                                                d_final.data_ptr(), d_accept.data_ptr() if d_accept is not None else None, st.cuda_stream))
+
     def safety_commit(self, d_prev, d_new, d_guess, d_final, d_accept=None, stream=None):
         """Post-solve safety check + commit (nep_batch_safety_commit); tensors are device byte/int32 tensors."""
         st = stream if stream is not None else self.torch.cuda.current_stream(self.device)

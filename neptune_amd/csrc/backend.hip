@@ -75,6 +75,9 @@ struct Engine {
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
   DevBuf<long long> d_dbg; bool profile_phases = false;
   DevBuf<int> d_flags;
+  // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
+  DevBuf<double> d_sampled, d_srep, d_slong; DevBuf<int> d_present, d_entangles;
+  DevBuf<nep_fe_ent_state> d_fe_nodes, d_fe_work; bool have_reps = false;
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
@@ -253,6 +256,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release();
+    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release();
     d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
@@ -727,7 +731,7 @@ int nep_batch_frontend(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec
   E.fill(ps);
   h->fe_committed = d_committed;
   launch_hulls_ts(d_committed, h->cfg.n_scenes, h->cfg.num_agents, &d_start->t_start, (long)sizeof(nep_fe_start), E.sp, ps, (hipStream_t)stream);
-  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, (hipStream_t)stream);
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, nullptr, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -746,7 +750,7 @@ int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* 
   point_at_block(ps, b, const_cast<void*>(d_blocks));
   ps.hull_pb = h->cfg.n_local; ps.hull_bstride = (long)b.bytes;
   h->fe_committed = nullptr;
-  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, (hipStream_t)stream);
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, nullptr, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -762,7 +766,97 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
   E.fill(ps);
   ps.guess = d_guess;
   if (E.safety_check_prev) { if (int e = E.d_conflict_prev.ensure((size_t)h->cfg.n_scenes * N * N)) return e; }
-  launch_safety(d_prev, d_new, h->cfg.n_scenes, N, E.sp, ps, E.d_conflict.p, E.safety_check_prev ? E.d_conflict_prev.p : nullptr, d_final, d_accept, (hipStream_t)stream);
+  launch_safety(d_prev, d_new, h->cfg.n_scenes, N, E.sp, ps, E.d_conflict.p, E.safety_check_prev ? E.d_conflict_prev.p : nullptr, nullptr, d_final, d_accept, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// ---- entangle check on: front end with per-node entangle states, safety pass with entangleCheckGivenPwp ----
+namespace {
+bool fe_cfg_ok(const nep_fe_cfg* cfg) {
+  return cfg->num_samples >= 2 && cfg->num_samples <= NEP_FE_MAX_SAMPLES && cfg->beam_width >= 1 && cfg->beam_width <= NEP_FE_MAX_BEAM &&
+         cfg->voxel_size > 0.0 && cfg->j_max > 0.0;
+}
+int ent_prepare(nep_batch* h, int ns, int beam_width, const nep_traj_rec* d_recs, const double* ts0, long ts_scene_stride, FeEntArgs& ea, hipStream_t st) {
+  Engine& E = h->eng;
+  const int N = h->cfg.num_agents, S = h->cfg.n_scenes, np = h->cfg.num_pol;
+  if (ns < 1 || ns > 8) return fail(NEP_E_ARG, "ent_samples out of range");
+  if (E.sp.n_static > 0 && !E.have_reps) return fail(NEP_E_STATE, "entangle check with static obstacles needs nep_batch_set_static_reps first");
+  if (int e = E.d_sampled.ensure((size_t)S * N * np * (ns + 1) * 2)) return e;
+  if (int e = E.d_present.ensure((size_t)S * N)) return e;
+  if (int e = E.d_fe_work.ensure((size_t)std::max(h->slots * 256, S * N))) return e;
+  if (beam_width > 0) { if (int e = E.d_fe_nodes.ensure((size_t)h->slots * (np + 1) * beam_width)) return e; }
+  if (!E.d_srep.p) { if (int e = E.d_srep.ensure(4)) return e; if (int e2 = E.d_slong.ensure(2)) return e2; }
+  launch_ent_sample(d_recs, S, N, ts0, ts_scene_stride, np, ns, E.sp.T_span, E.d_sampled.p, E.d_present.p, st);
+  ea.sampled = E.d_sampled.p; ea.present = E.d_present.p; ea.srep = E.d_srep.p; ea.slong = E.d_slong.p;
+  ea.nodes = E.d_fe_nodes.p; ea.work = E.d_fe_work.p; ea.ns = ns; ea.init = nullptr; ea.case_out = nullptr;
+  return 0;
+}
+}  // namespace
+
+int nep_batch_set_static_reps(nep_batch_t* h, int32_t scene, const double* rep, const double* longest) {
+  if (!h || !rep || !longest || scene < -1 || scene >= h->cfg.n_scenes) return fail(NEP_E_ARG, "bad arguments");
+  Engine& E = h->eng;
+  const int S = E.sp.n_static;
+  if (S == 0) { E.have_reps = true; return 0; }
+  const int sets = E.sp.static_stride ? h->cfg.n_scenes : 1;
+  HIPCHK(hipDeviceSynchronize());
+  if (E.d_srep.n < (size_t)sets * S * 4) {
+    DevBuf<double> nr, nl;
+    if (int e = nr.ensure((size_t)sets * S * 4)) return e;
+    if (int e = nl.ensure((size_t)sets * S * 2)) return e;
+    HIPCHK(hipMemset(nr.p, 0, (size_t)sets * S * 4 * sizeof(double))); HIPCHK(hipMemset(nl.p, 0, (size_t)sets * S * 2 * sizeof(double)));
+    E.d_srep.release(); E.d_slong.release(); E.d_srep = nr; E.d_slong = nl;
+  }
+  for (int s = 0; s < sets; s++) {
+    if (scene >= 0 && sets > 1 && s != scene) continue;
+    HIPCHK(hipMemcpy(E.d_srep.p + (size_t)s * S * 4, rep, (size_t)S * 4 * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(E.d_slong.p + (size_t)s * S * 2, longest, (size_t)S * 2 * sizeof(double), hipMemcpyHostToDevice));
+  }
+  E.have_reps = true;
+  return 0;
+}
+
+int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed, const nep_fe_start* d_start,
+                           const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result, int32_t* d_case_out, void* stream) {
+  if (!h || !cfg || !d_committed || !d_start || !d_guess) return fail(NEP_E_ARG, "null argument");
+  if (!fe_cfg_ok(cfg)) return fail(NEP_E_ARG, "bad front-end configuration");
+  if (!cfg->enable_entangle || !h->cfg.enable_entangle) return fail(NEP_E_STATE, "nep_batch_frontend_ent needs enable_entangle in the front-end configuration and in the handle");
+  if (h->cfg.n_local != h->cfg.num_agents) return fail(NEP_E_STATE, "the entangle-aware front end runs on an unsharded handle (n_local == num_agents)");
+  Engine& E = h->eng;
+  ProblemSet ps{};
+  E.fill(ps);
+  h->fe_committed = d_committed;
+  launch_hulls_ts(d_committed, h->cfg.n_scenes, h->cfg.num_agents, &d_start->t_start, (long)sizeof(nep_fe_start), E.sp, ps, (hipStream_t)stream);
+  FeEntArgs ea{};
+  if (int e = ent_prepare(h, cfg->ent_samples, cfg->beam_width, d_committed, &d_start->t_start, (long)sizeof(nep_fe_start) * E.sp.n_local, ea, (hipStream_t)stream)) return e;
+  ea.init = d_ent_init; ea.case_out = d_case_out;
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int nep_batch_safety_commit_ent(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new, const nep_guess* d_guess,
+                                const nep_fe_ent_state* d_ent_init, int32_t ent_samples, double cable_length, nep_traj_rec* d_final,
+                                int32_t* d_accept, void* stream) {
+  if (!h || !d_prev || !d_new || !d_guess || !d_final) return fail(NEP_E_ARG, "null argument");
+  Engine& E = h->eng;
+  const int N = h->cfg.num_agents;
+  if (E.sp.n_hull != N || h->cfg.n_local != N) return fail(NEP_E_STATE, "the entangle re-check needs the unsharded batched layout");
+  if (!h->cfg.enable_entangle) return fail(NEP_E_STATE, "handle created without enable_entangle");
+  if (int e = E.d_conflict.ensure((size_t)h->cfg.n_scenes * N * N)) return e;
+  if (int e = E.d_entangles.ensure((size_t)h->cfg.n_scenes * N)) return e;
+  ProblemSet ps{};
+  E.fill(ps);
+  ps.guess = d_guess;
+  if (E.safety_check_prev) { if (int e = E.d_conflict_prev.ensure((size_t)h->cfg.n_scenes * N * N)) return e; }
+  // everybody's NEW trajectory counts as received while optimising: their samples and bend points feed the re-check
+  FeEntArgs ea{};
+  if (int e = ent_prepare(h, ent_samples, 0, d_new, &d_guess->t_start, (long)sizeof(nep_guess) * E.sp.n_local, ea, (hipStream_t)stream)) return e;
+  ea.init = d_ent_init;
+  launch_hulls(d_new, h->cfg.n_scenes, N, d_guess, E.sp, ps, (hipStream_t)stream);     // (with the bend points: ent_enabled)
+  launch_ent_check(E.sp, ps, ea, d_new, h->cfg.n_scenes, cable_length, E.d_entangles.p, (hipStream_t)stream);
+  launch_safety(d_prev, d_new, h->cfg.n_scenes, N, E.sp, ps, E.d_conflict.p, E.safety_check_prev ? E.d_conflict_prev.p : nullptr, E.d_entangles.p, d_final, d_accept, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -886,6 +980,7 @@ int nep_abi_sizeof(int32_t which) {
     case 11: return (int)sizeof(nep_fe_cfg);
     case 12: return (int)sizeof(nep_fe_start);
     case 13: return (int)sizeof(nep_fe_result);
+    case 14: return (int)sizeof(nep_fe_ent_state);
     default: return -1;
   }
 }

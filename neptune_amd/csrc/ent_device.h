@@ -1,0 +1,242 @@
+// ent_device.h — entanglement state of a front-end search node on the device (enable_entangle_check).
+//
+// KinodynamicSearch::entanglesWithOtherAgents (reference neptune/src/kinodynamic_search.cpp:707-895) with
+// eu::entangleHSigToAddAgentInd (entangle_utils.cpp:1129-1228), entangleHSigToAddStatic (:1231-1277), addAlphaBetaToList
+// + breakcondition (:1402-1534, :1608-1647), updateBendPts (:1536-1604), getBendPt2d / calculateBetaForCase /
+// getTetherLength (:1649-1743), getIz / power_int (kinodynamic_search.cpp:2006-2031).  One thread carries one node: the
+// crossing list lives in a fixed-size record (nep_fe_ent_state, NEP_FE_ENT_CAP entries) in global memory; active_cases[i]
+// is the number of list entries of agent i and is derived.  Written in the association order of the CPU checker under
+// oracle/ (this header is only included by geom_kernels.hip, which is built -ffp-contract=off): betas match bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "nep_device.h"
+
+namespace nep {
+
+struct EntCtx {
+  int N, S, own, num_pol, ns;
+  double T_span, cable;
+  const double* pb;          // [N][2]
+  const double* srep;        // [S][2][2] of this scene
+  const double* slong;       // [S][2]
+  const double* sampled;     // [N][num_pol][ns+1][2] of this scene
+  const int* present;        // [N]
+  const ProblemSet* ps; int scene, n_hull;      // bend points come with the hull data (hull_ref)
+};
+struct Ev2 { double x, y; };
+constexpr int kEntAddCap = 32;
+struct EntAdd { short id[kEntAddCap]; signed char cs[kEntAddCap]; int n, overflow; };
+
+__device__ __forceinline__ Ev2 ent_pb(const EntCtx& c, int j) { return Ev2{c.pb[2 * j], c.pb[2 * j + 1]}; }
+__device__ __forceinline__ Ev2 ent_srep(const EntCtx& c, int s, int col) { return Ev2{c.srep[(s * 2 + col) * 2], c.srep[(s * 2 + col) * 2 + 1]}; }
+__device__ __forceinline__ Ev2 ent_sampled(const EntCtx& c, int i, int interval, int col) {
+  const double* q = c.sampled + (((long)i * c.num_pol + interval) * (c.ns + 1) + col) * 2; return Ev2{q[0], q[1]};
+}
+__device__ __forceinline__ double ent_wedge(Ev2 a, Ev2 b, Ev2 cc) { return (b.x - a.x) * (cc.y - a.y) - (cc.x - a.x) * (b.y - a.y); }
+__device__ __forceinline__ double ent_wedge2(Ev2 a, Ev2 b, Ev2 cc, Ev2& ab, Ev2& ac) { ab.x = b.x - a.x; ab.y = b.y - a.y; ac.x = cc.x - a.x; ac.y = cc.y - a.y; return ab.x * ac.y - ac.x * ab.y; }
+__device__ __forceinline__ double ent_ratio(Ev2 u, Ev2 v) { return fabs(u.y * v.y) > fabs(u.x * v.x) ? u.y / v.y : u.x / v.x; }
+__device__ __forceinline__ double ent_dist(Ev2 a, Ev2 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
+__device__ __forceinline__ void ent_push(EntAdd& a, int id, int cs) { if (a.n < kEntAddCap) { a.id[a.n] = (short)id; a.cs[a.n] = (signed char)cs; a.n++; } else a.overflow = 1; }
+
+__device__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id) {
+  bool base_addition = false;
+  for (int k = 0; k < nb; k++) {
+    const bool last = k == nb - 1;
+    const Ev2 bk{bp[2 * k], bp[2 * k + 1]};
+    Ev2 u, v; double c1, c2;
+    if (!last) { const Ev2 bn{bp[2 * (k + 1)], bp[2 * (k + 1) + 1]}; c1 = ent_wedge2(pk, bn, bk, u, v); c2 = ent_wedge(pk1, bn, bk); }
+    else { c1 = ent_wedge2(pk, pik, bk, u, v); c2 = ent_wedge(pk1, pik1, bk); }
+    if (last) {
+      Ev2 ub, vb;
+      const double f1 = ent_wedge2(pb_self, pik, bk, ub, vb), f2 = ent_wedge(pb_self, pik1, bk);
+      if (f1 * f2 < 0) {
+        const double a = ent_ratio(ub, vb);
+        if (a < 0) { }
+        else if (a < 1) ent_push(add, agent_id, 1);
+        else if (k == 0) ent_push(add, agent_id, 0);
+        base_addition = true;
+      }
+    }
+    if (c1 * c2 < 0) {
+      const double a = ent_ratio(u, v);
+      if (a < 0) ent_push(add, agent_id, k + 2);
+      else if (a < 1 && last) ent_push(add, agent_id, 1);
+      else if (a >= 1 && k == 0) ent_push(add, agent_id, 0);
+    }
+  }
+  if (base_addition && add.n >= 2 && add.id[add.n - 1] == add.id[add.n - 2] && add.cs[add.n - 1] == add.cs[add.n - 2]) add.n -= 2;
+}
+__device__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, const EntCtx& c) {
+  for (int s = 0; s < c.S; s++) {
+    const Ev2 pik = ent_srep(c, s, 1), pbi = ent_srep(c, s, 0);
+    Ev2 u, v;
+    const double c1 = ent_wedge2(pk, pik, pbi, u, v), c2 = ent_wedge(pk1, pik, pbi);
+    if (c1 * c2 < 0) {
+      const double a = ent_ratio(u, v);
+      if (a < 0) { }
+      else if (a < 1) ent_push(add, c.N + s + 1, 1);
+      else ent_push(add, c.N + s + 1, 0);
+    }
+  }
+}
+__device__ __forceinline__ Ev2 ent_anchor(int id, int cs, const EntCtx& c) { return id <= c.N ? ent_pb(c, id - 1) : ent_srep(c, id - c.N - 1, cs); }
+__device__ Ev2 ent_cur_bend(const nep_fe_ent_state* st, Ev2 pb_self, const EntCtx& c) {
+  if (st->n_bend == 0) return pb_self;
+  const int b = st->bend[st->n_bend - 1];
+  const int id = st->id[b], cs = st->cs[b];
+  if (id <= c.N && id >= 1) return ent_pb(c, id - 1);
+  if (id > c.N) return ent_srep(c, id - c.N - 1, cs);
+  return Ev2{0, 0};
+}
+__device__ __forceinline__ double ent_beta(int id, int cs, Ev2 pk, Ev2 bp, const EntCtx& c) { return id <= c.N ? 0.0 : ent_wedge(pk, ent_srep(c, id - c.N - 1, cs), bp); }
+__device__ __forceinline__ bool ent_scan_stops(int t_id, int t_cs, int l_id, int j, int last_bend, const EntCtx& c) {
+  if (t_id <= c.N && t_cs >= 2) return j <= last_bend;
+  if (t_id <= c.N) return false;
+  return l_id > c.N || j <= last_bend;
+}
+__device__ void ent_erase(nep_fe_ent_state* st, int j) {
+  for (int k = j; k + 1 < st->n_alpha; k++) { st->id[k] = st->id[k + 1]; st->cs[k] = st->cs[k + 1]; st->beta[k] = st->beta[k + 1]; }
+  st->n_alpha--;
+}
+__device__ int ent_bend_n(const EntCtx& c, int j) { const HullRef hr = hull_ref(*c.ps, c.n_hull, c.scene, j); return blk(c.ps->bend_n, hr.boff)[hr.e]; }
+__device__ bool ent_merge(EntAdd& add, nep_fe_ent_state* st, Ev2 pk, Ev2 pb_self, const EntCtx& c) {
+  bool again = true;
+  while (again) {
+    again = false;
+    const int b = st->n_bend ? st->bend[st->n_bend - 1] : -1;
+    for (int i = 0; i < add.n && !again; i++) {
+      const int t_id = add.id[i], t_cs = add.cs[i];
+      const bool agent = t_id <= c.N;
+      const int t_nb = agent ? ent_bend_n(c, t_id - 1) : 0;
+      for (int j = st->n_alpha - 1; j >= 0; j--) {
+        const int l_id = st->id[j], l_cs = st->cs[j];
+        const bool match = (l_id == t_id && l_cs == t_cs) ||
+                           (agent && l_id == t_id && t_cs >= t_nb + 1 && t_cs < l_cs) ||
+                           (agent && l_id == t_id && l_cs >= 2 && t_cs >= 2 && abs(t_cs - l_cs) == 1 && j > b);
+        if (match) {
+          for (int k = i; k + 1 < add.n; k++) { add.id[k] = add.id[k + 1]; add.cs[k] = add.cs[k + 1]; }
+          add.n--;
+          ent_erase(st, j);
+          if (j == b) {
+            st->n_bend--;
+            const Ev2 bp = ent_cur_bend(st, pb_self, c);
+            for (int k = j; k < st->n_alpha; k++) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk, bp, c);
+          } else if (j < b) {
+            st->bend[st->n_bend - 1] = (signed char)(b - 1);
+            for (int k = st->n_bend - 2; k >= 0; k--) { if (st->bend[k] > j) st->bend[k] -= 1; else break; }
+          }
+          again = true;
+          break;
+        }
+        if (ent_scan_stops(t_id, t_cs, l_id, j, b, c)) break;
+      }
+    }
+  }
+  if (add.n == 0) return false;
+  if (st->n_alpha + add.n > NEP_FE_ENT_CAP) return true;
+  const Ev2 bp = ent_cur_bend(st, pb_self, c);
+  for (int i = 0; i < add.n; i++) {
+    st->id[st->n_alpha] = add.id[i]; st->cs[st->n_alpha] = add.cs[i];
+    st->beta[st->n_alpha] = ent_beta(add.id[i], add.cs[i], pk, bp, c);
+    st->n_alpha++;
+  }
+  return false;
+}
+__device__ bool ent_update_bends(nep_fe_ent_state* st, Ev2 pk1, Ev2 pb_self, const EntCtx& c) {
+  const Ev2 bp = ent_cur_bend(st, pb_self, c);
+  int idx_new = -1;
+  const int start = st->n_bend ? st->bend[st->n_bend - 1] : -1;
+  for (int i = start + 1; i < st->n_alpha; i++) { const double beta = ent_beta(st->id[i], st->cs[i], pk1, bp, c); if (beta * st->beta[i] < -1e-7) idx_new = i; }
+  if (idx_new > -1) {
+    if (st->n_bend >= NEP_MAX_BEND) return true;
+    st->bend[st->n_bend++] = (signed char)idx_new;
+    const Ev2 nb = ent_anchor(st->id[idx_new], st->cs[idx_new], c);
+    for (int i = idx_new + 1; i < st->n_alpha; i++) st->beta[i] = ent_beta(st->id[i], st->cs[i], pk1, nb, c);
+    return false;
+  }
+  while (st->n_bend) {
+    const Ev2 prev = st->n_bend == 1 ? pb_self : ent_anchor(st->id[st->bend[st->n_bend - 2]], st->cs[st->bend[st->n_bend - 2]], c);
+    const int bi = st->bend[st->n_bend - 1];
+    const double beta = ent_beta(st->id[bi], st->cs[bi], pk1, prev, c);
+    if (beta * st->beta[bi] > 1e-7) {
+      for (int k = bi + 1; k < st->n_alpha; k++) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk1, prev, c);
+      st->n_bend--;
+    } else break;
+  }
+  return false;
+}
+__device__ double ent_tether(const nep_fe_ent_state* st, Ev2 from, Ev2 pk1, const EntCtx& c) {
+  double len = 0.0;
+  for (int q = 0; q < st->n_bend; q++) {
+    const int b = st->bend[q]; const int id = st->id[b], cs = st->cs[b];
+    Ev2 bp; double comp;
+    if (id <= c.N) { bp = ent_pb(c, id - 1); comp = 0.0; } else { bp = ent_srep(c, id - c.N - 1, cs); comp = c.slong[(id - c.N - 1) * 2 + cs]; }
+    len += ent_dist(bp, from) + 2 * comp;
+    from = bp;
+  }
+  return len + ent_dist(pk1, from);
+}
+__device__ __forceinline__ int ent_count(const short* ids, int n, int id) { int k = 0; for (int i = 0; i < n; i++) k += ids[i] == id; return k; }
+
+// 0: fine; 1: the reference's function returns true (prune); 2: capacity exceeded (pruned, flagged)
+__device__ int ent_propagate(const EntCtx& c, nep_fe_ent_state* st, const double* cxo, const double* cyo, Ev2 end, int index, double& arc, bool check_tether, int cap_mult) {
+  const int ns = c.ns;
+  const Ev2 pb_self = ent_pb(c, c.own);
+  Ev2 pk{cxo[3], cyo[3]}, pk1 = pk;
+  for (int j = 1; j <= ns; j++) {
+    EntAdd add; add.n = 0; add.overflow = 0;
+    if (j < ns) {
+      const double t = c.T_span * j / ns;
+      const double t3 = t * t * t, t2 = t * t;
+      pk1.x = ((cxo[0] * t3 + cxo[1] * t2) + cxo[2] * t) + cxo[3] * 1.0; pk1.y = ((cyo[0] * t3 + cyo[1] * t2) + cyo[2] * t) + cyo[3] * 1.0;
+    } else pk1 = end;
+    arc += ent_dist(pk1, pk);
+    for (int i = 0; i < c.N; i++) {
+      if (i == c.own || !c.present[i]) continue;
+      Ev2 pik, pik1;
+      if (index > c.num_pol) { pik = ent_sampled(c, i, c.num_pol - 1, ns); pik1 = pik; }
+      else { pik = ent_sampled(c, i, index - 1, j - 1); pik1 = ent_sampled(c, i, index - 1, j); }
+      const HullRef hr = hull_ref(*c.ps, c.n_hull, c.scene, i);
+      ent_cross_agent(add, pk, pk1, pik, pik1, pb_self, blk(c.ps->bend_n, hr.boff)[hr.e], blk(c.ps->bend_xy, hr.boff) + hr.e * kBend * 2, i + 1);
+    }
+    ent_cross_static(add, pk, pk1, c);
+    if (add.overflow) return 2;
+    if (st->n_alpha + add.n > (c.N + c.S) * cap_mult) return 1;
+    short old_id[NEP_FE_ENT_CAP]; const int old_n = st->n_alpha;
+    for (int i = 0; i < old_n; i++) old_id[i] = st->id[i];
+    if (ent_merge(add, st, pk, pb_self, c)) return 2;
+    for (int i = 0; i < st->n_alpha; i++) {
+      const int id = st->id[i];
+      if (id > c.N) continue;
+      const int nw = ent_count(st->id, st->n_alpha, id), od = ent_count(old_id, old_n, id);
+      if (od < 2 && nw >= 2) return 1;
+      if (od >= 2 && nw > od) return 1;
+    }
+    if (ent_update_bends(st, pk1, pb_self, c)) return 2;
+    pk = pk1;
+  }
+  if (check_tether && ent_tether(st, pb_self, pk1, c) > c.cable) return 1;
+  return 0;
+}
+__device__ unsigned ent_iz(const nep_fe_ent_state* st) {
+  unsigned iz = 0;
+  for (int i = 0; i < st->n_alpha; i++) {
+    unsigned base = (unsigned)st->id[i], ex = (unsigned)st->cs[i], r;
+    if (ex == 0) r = 1; else if (base < 2) r = base;
+    else { r = 1; for (unsigned term = base;; term = term * term) { if (ex % 2 != 0) r *= term; ex /= 2; if (ex == 0) break; } }
+    iz += (unsigned)(i + 1) * r;
+  }
+  return iz;
+}
+__device__ bool ent_valid_endpoint(const nep_fe_ent_state* st, int N) {
+  for (int a = 0; a < st->n_alpha; a++) if (st->id[a] <= N && ent_count(st->id, st->n_alpha, st->id[a]) > 1) return false;
+  return true;
+}
+__device__ void ent_copy(nep_fe_ent_state* dst, const nep_fe_ent_state* src) {
+  const long* s = (const long*)src; long* d = (long*)dst;
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) d[i] = s[i];
+}
+
+}  // namespace nep

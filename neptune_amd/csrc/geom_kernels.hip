@@ -17,6 +17,7 @@
 
 #include "nep_device.h"
 #include "../../include/neptune_frontend.h"
+#include "ent_device.h"
 
 namespace nep {
 
@@ -673,7 +674,7 @@ __global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec*
 // with an already accepted lower id.  One workgroup per scene; then the final records are written.
 __global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec* __restrict__ prev, const nep_traj_rec* __restrict__ fresh, int N,
                                                              const unsigned char* __restrict__ conflict, const unsigned char* __restrict__ conflict_prev,
-                                                             nep_traj_rec* __restrict__ final_out, int* __restrict__ accept_out) {
+                                                             const int* __restrict__ entangles, nep_traj_rec* __restrict__ final_out, int* __restrict__ accept_out) {
   extern __shared__ int sAcc[];   // [N] accept flags + [1] vote
   const int tid = threadIdx.x, scene = blockIdx.x;
   const unsigned char* Cm = conflict + (long)scene * N * N;
@@ -687,6 +688,7 @@ __global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec*
     // (optional) the new trajectory must also clear what everybody else is flying now: whoever is turned
     // down this round keeps exactly that
     if (Cp) for (int j = tid; j < N; j += blockDim.x) bad = bad || (j != a && Cp[(long)a * N + j]);
+    if (entangles && tid == 0) bad = bad || entangles[(long)scene * N + a] != 0;     // entangleCheckGivenPwp (neptune.cpp:746-754)
     if (bad) *vote = 1;
     __syncthreads();
     if (tid == 0) sAcc[a] = *vote ? 0 : 1;
@@ -702,7 +704,7 @@ __global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec*
 }
 
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
-                   unsigned char* conflict, unsigned char* conflict_prev, nep_traj_rec* final_out, int* accept_out, hipStream_t st) {
+                   unsigned char* conflict, unsigned char* conflict_prev, const int* entangles, nep_traj_rec* final_out, int* accept_out, hipStream_t st) {
   if (n_scenes * N <= 0) return;
   if (conflict_prev) {   // new trajectories against the hulls of the PREVIOUS records on the same grid
     hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, prev, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
@@ -712,7 +714,7 @@ void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_sc
   hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, fresh, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
                      sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
   hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
-  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, final_out, accept_out);
+  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, entangles, final_out, accept_out);
 }
 
 
@@ -850,8 +852,15 @@ __device__ __forceinline__ unsigned fe_hash(long long vox) { return (unsigned)((
 
 // The serial loops of this kernel run out of LDS with every load independent of the previous
 // iteration's result (dense arrays, no early exits): they are latency-bound otherwise.
+// ENT (fc.enable_entangle): every child additionally carries its parent's entangle state through entanglesWithOtherAgents
+// (ent_device.h; pruned when that returns true), g is the sampled arc length, h gains 0.3 per crossing and 1.0 per bend
+// point (kinodynamic_search.cpp:1177-1182), a voxel is (ix, iy, getIz(state)) (:1170-1173), the other agents' base squares
+// are obstacles (collidesWithBases2d, :1583-1628) and only nodes whose active cases are all <= 1 may end the plan
+// (:1693-1700).  The states of the installed nodes stay in global memory ([depth][rank]); the path's states give the case
+// ids the back end consumes (solver_gurobi_poly.cpp:624-631).
+template <bool ENT>
 __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
-                                                       nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out) {
+                                                       nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out, FeEntArgs ea) {
   extern __shared__ __attribute__((aligned(16))) double fe_smem[];
   const int tid = threadIdx.x;
   const int slot = blockIdx.x, scene = slot / sp.n_local, own = sp.first_local + (slot % sp.n_local);
@@ -874,8 +883,8 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
   int* d_slot = (int*)(v_key + kFeVis);                    // [kFeDd] voxel -> best candidate of the depth
   int* o_nv = d_slot + kFeDd;                              // [N+S] dense
   int* o_id = o_nv + (N + S);                              // [N+S] dense: obstacle index (agent j or N + static)
-  int* s_i = o_id + (N + S);                               // [16] counters
-  unsigned short* r_id = (unsigned short*)(s_i + 16);      // [kFeCap] ids of the voxel winners, dense
+  int* s_i = o_id + (N + S);                               // [32] counters (+ the path's ranks with the entangle check on)
+  unsigned short* r_id = (unsigned short*)(s_i + 32);      // [kFeCap] ids of the voxel winners, dense
   unsigned char* s_state = (unsigned char*)(r_id + kFeCap);   // [kFeCap] 0 dead, 1 alive, 2 lost its voxel
   signed char* p_parent = (signed char*)(s_state + kFeCap);   // [NEP_MAX_POL + 1][64]
   signed char* p_comb = p_parent + (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
@@ -883,10 +892,28 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
   const nep_fe_start* st = starts + slot;
   const double gx = st->goal[0], gy = st->goal[1];
   const double bx = ps.pb[2 * own], by = ps.pb[2 * own + 1];
+  EntCtx ec;
+  nep_fe_ent_state* my_work = nullptr;
+  unsigned char* b_valid = (unsigned char*)(p_comb + (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM);   // [64] may a plan end at this rank
+  auto ent_node = [&](int d, int r) -> nep_fe_ent_state* { return ea.nodes + (((long)slot * (D + 1) + d) * W + r); };
+  if constexpr (ENT) {
+    ec.N = N; ec.S = S; ec.own = own; ec.num_pol = D; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = fc.cable_length;
+    ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
+    ec.sampled = ea.sampled + (long)scene * N * D * (ea.ns + 1) * 2; ec.present = ea.present + (long)scene * N;
+    ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
+    my_work = ea.work + ((long)slot * 256 + tid);
+    if (tid == 0) {
+      nep_fe_ent_state* root = ent_node(0, 0);
+      if (ea.init) ent_copy(root, ea.init + slot);
+      else { long* z = (long*)root; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
+    }
+    if (tid < NEP_FE_MAX_BEAM) b_valid[tid] = 1;
+  }
+  int my_entangled = 0, my_overflow = 0;
 #ifdef NEP_PROFILE_PHASES
   if (ps.dbg && tid < 16) ps.dbg[(long)slot * 16 + tid] = 0;
 #endif
-  if (tid < 16) s_i[tid] = 0;     // [0] shortlist n, [1] winners n, [2] GJK work list n, [4] children, [5] feasible, [6] collision free, [7] goal occupied
+  if (tid < 32) s_i[tid] = 0;     // [0] shortlist n, [1] winners n, [2] GJK work list n, [4] children, [5] feasible, [6] collision free, [7] goal occupied
   for (int k = tid; k < kFeVis; k += 256) v_key[k] = kFeEmpty;
   if (tid < NEP_FE_MAX_SAMPLES) fe_lattice_fill(sp, fc, s_lat, tid);
   const FeLattice lat{s_lat, s_lat + NEP_FE_MAX_SAMPLES, s_lat + 2 * NEP_FE_MAX_SAMPLES, s_lat + 3 * NEP_FE_MAX_SAMPLES};
@@ -979,9 +1006,35 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
     //      spreads the expensive tests over all threads instead of leaving them with the lanes that
     //      happened to draw crowded children ----
     const int n_c = nb_prev * NC;
-    auto settle = [&](int id, const FeChild& ch) {       // collision free: closed voxel?  else alive
-      my_free++;
-      const long long vox = ((long long)ch.vx << 32) | (unsigned int)ch.vy;
+    auto settle = [&](int id, FeChild& ch) {       // collision free: closed voxel?  else alive
+      unsigned iz = 0;
+      if constexpr (ENT) {
+        {   // collidesWithBases2d: the other agents' 0.7 m base squares within 2 T v_max of the first control point
+          const double radius = 0.7, safe_dist = (sp.T_span * sp.v_max) * 2;
+          Pts4 Bq;
+#pragma unroll
+          for (int i = 0; i < 4; i++) { Bq.x[i] = ch.Qx[i]; Bq.y[i] = ch.Qy[i]; }
+          for (int j = 0; j < N; j++) {
+            if (j == own) continue;
+            const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
+            const double d1 = sqrt((ch.Qx[0] - pbx) * (ch.Qx[0] - pbx) + (ch.Qy[0] - pby) * (ch.Qy[0] - pby));
+            if (d1 > safe_dist) continue;
+            const double sq[8] = {pbx + radius, pby + radius, pbx + radius, pby - radius, pbx - radius, pby - radius, pbx - radius, pby + radius};
+            if (gjk_collision(4, sq, Bq)) { s_state[id] = 0; return; }
+          }
+        }
+        my_free++;
+        const int pr_ = id / NC;
+        ent_copy(my_work, ent_node(depth - 1, depth == 1 ? 0 : pr_));
+        double arc = 0.0;
+        const int rc = ent_propagate(ec, my_work, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1);
+        if (rc) { my_entangled++; if (rc == 2) my_overflow = 1; s_state[id] = 0; return; }
+        ch.g = b_g[prv * NEP_FE_MAX_BEAM + pr_] + arc;
+        ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)my_work->n_alpha) + 1.0 * (double)my_work->n_bend);
+        iz = ent_iz(my_work);
+      } else my_free++;
+      const long long vox = ENT ? (long long)(((unsigned long long)(unsigned short)ch.vx << 48) | ((unsigned long long)(unsigned short)ch.vy << 32) | iz)
+                                : (((long long)ch.vx << 32) | (unsigned int)ch.vy);
       bool seen = false;
       for (unsigned h = fe_hash(vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long k = v_key[h]; if (k == (unsigned long long)vox) { seen = true; break; } if (k == kFeEmpty) break; }
       if (!seen) { s_f[id] = ch.f; s_vox[id] = vox; }
@@ -1081,6 +1134,15 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
         const double pg = b_g[prv * NEP_FE_MAX_BEAM + pr];
         FeChild ch;
         fe_child(sp, fc, lat, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch);
+        if constexpr (ENT) {   // the same propagation again, this time into the node's own record
+          nep_fe_ent_state* nd = ent_node(depth, rank);
+          ent_copy(nd, ent_node(depth - 1, depth == 1 ? 0 : pr));
+          double arc = 0.0;
+          ent_propagate(ec, nd, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1);
+          ch.g = pg + arc;
+          ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)nd->n_alpha) + 1.0 * (double)nd->n_bend);
+          b_valid[rank] = ent_valid_endpoint(nd, N) ? 1 : 0;
+        }
 #pragma unroll
         for (int q = 0; q < 6; q++) b_end[(cur * NEP_FE_MAX_BEAM + rank) * 6 + q] = ch.e[q];
         b_g[cur * NEP_FE_MAX_BEAM + rank] = ch.g; b_dist[rank] = ch.dist; b_f[rank] = ch.f;
@@ -1094,13 +1156,15 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
     FE_TICK(6);
     if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
     nb_prev = nb;
-    best_depth = depth; best_rank = 0;
+    if constexpr (ENT) { int fv = -1; for (int r = nb - 1; r >= 0; r--) if (b_valid[r]) fv = r; if (fv >= 0) { best_depth = depth; best_rank = fv; } }
+    else { best_depth = depth; best_rank = 0; }
     int reached = -1;
-    for (int r = nb - 1; r >= 0; r--) if (b_dist[r] < fc.goal_size) reached = r;   // first in rank order (every thread: uniform)
-    if (reached >= 0) { status = NEP_FE_GOAL_REACHED; best_rank = reached; break; }
+    for (int r = nb - 1; r >= 0; r--) if (b_dist[r] < fc.goal_size && (!ENT || b_valid[r])) reached = r;   // first in rank order (every thread: uniform)
+    if (reached >= 0) { status = NEP_FE_GOAL_REACHED; best_depth = depth; best_rank = reached; break; }
     if (depth == D) { status = NEP_FE_DEPTH_REACHED; break; }
   }
   atomicAdd(&s_i[4], my_children); atomicAdd(&s_i[5], my_feasible); atomicAdd(&s_i[6], my_free);
+  if constexpr (ENT) { atomicAdd(&s_i[8], my_entangled); if (my_overflow) s_i[9] = 1; }
   __syncthreads();
 #ifdef NEP_PROFILE_PHASES
   if (ps.dbg && tid == 0) { for (int k = 0; k < 8; k++) ps.dbg[(long)slot * 16 + k] = tph[k]; ps.dbg[(long)slot * 16 + 8] = depth; }
@@ -1134,6 +1198,29 @@ __global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSe
       o->status = status; o->K = best_rank >= 0 ? best_depth : 0; o->depth = depth > D ? D : depth;
       o->n_children = s_i[4]; o->n_feasible = s_i[5]; o->n_collision_free = s_i[6]; o->goal_occupied = s_i[7]; o->_pad = 0;
       o->cost = best_rank >= 0 ? b_f[best_rank] : 0.0; o->dist_to_goal = best_rank >= 0 ? b_dist[best_rank] : 0.0;
+      o->n_entangled = ENT ? s_i[8] : 0; o->ent_overflow = ENT ? s_i[9] : 0;
+    }
+    if constexpr (ENT) {   // ranks of the path's nodes, for the case rows below
+      int r = best_rank;
+      for (int d = best_depth; d >= 1; d--) { s_i[16 + d] = r; r = p_parent[d * NEP_FE_MAX_BEAM + r]; }
+      s_i[16] = 0; s_i[15] = best_rank >= 0 ? best_depth : -1; s_i[14] = best_rank >= 0 ? guess_out[slot].K : 0;
+    }
+  }
+  if constexpr (ENT) {
+    // case id per (knot, agent): the state at the START of segment i is the path's node of depth i (solver_gurobi_poly.cpp:624-631)
+    __syncthreads();
+    if (ea.case_out) {
+      const int bd = s_i[15], Kg = s_i[14];
+      for (int e = tid; e < NEP_MAX_POL * N; e += 256) {
+        const int i = e / N, j = e % N;
+        int cid = 0;
+        if (bd >= 0 && i < Kg) {
+          const int dd = i < bd ? i : bd;
+          const nep_fe_ent_state* sn = ent_node(dd, dd == 0 ? 0 : s_i[16 + dd]);
+          if (ent_count(sn->id, sn->n_alpha, j + 1) == 1) for (int a = 0; a < sn->n_alpha; a++) if (sn->id[a] == j + 1) cid = sn->cs[a];
+        }
+        ea.case_out[((long)slot * NEP_MAX_POL + i) * N + j] = cid;
+      }
     }
   }
 }
@@ -1155,18 +1242,95 @@ size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc) {
   const size_t NS = (size_t)sp.num_agents + sp.n_static;
   const FeSizes z = fe_sizes(fc.beam_width, fc.num_samples, sp.num_pol);
   size_t b = sizeof(double) * (2 * (size_t)z.cap + 2 * NEP_FE_MAX_BEAM * 6 + 2 * NEP_FE_MAX_BEAM + 2 * NEP_FE_MAX_BEAM + 4 * NEP_FE_MAX_BEAM + 4 * NS + kFeObsLds * kHullV * 2 + 4 * NEP_FE_MAX_SAMPLES)
-           + sizeof(long long) * ((size_t)z.cap + z.vis) + sizeof(int) * (z.dd + 2 * NS + 16)
-           + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
+           + sizeof(long long) * ((size_t)z.cap + z.vis) + sizeof(int) * (z.dd + 2 * NS + 32)
+           + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM + NEP_FE_MAX_BEAM;
   return (b + 15) & ~(size_t)15;
 }
 
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
-                     nep_guess* guess_out, nep_fe_result* res_out, hipStream_t st) {
+                     nep_guess* guess_out, nep_fe_result* res_out, const FeEntArgs* ea, hipStream_t st) {
   if (n_slots <= 0) return;
   const size_t lds = frontend_lds_bytes(sp, fc);
-  static DynLdsAttr attr;
-  (void)attr.ensure((const void*)frontend_kernel, lds);
-  hipLaunchKernelGGL(frontend_kernel, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out);
+  static DynLdsAttr attr[2];
+  const bool ent = ea != nullptr;
+  (void)attr[ent].ensure(ent ? (const void*)frontend_kernel<true> : (const void*)frontend_kernel<false>, lds);
+  FeEntArgs none{};
+  if (ent) hipLaunchKernelGGL(frontend_kernel<true>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
+  else hipLaunchKernelGGL(frontend_kernel<false>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
+}
+
+// Neptune::SamplePointsOfIntervals (neptune.cpp:500-565) for every committed trajectory of every scene:
+// sampled[scene][j][interval][0..ns][2] on the round's grid, present[scene][j] = the trajectory exists (trajs_ holds it)
+__global__ void ent_sample_kernel(const nep_traj_rec* __restrict__ recs, int n_scenes, int N, const double* __restrict__ ts0, long ts_scene_stride,
+                                  int num_pol, int ns, double T_span, double* __restrict__ sampled, int* __restrict__ present) {
+  const long per = (long)num_pol * (ns + 1);
+  const long total = (long)n_scenes * N * per;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+    const int col = (int)(e % (ns + 1)); long r = e / (ns + 1);
+    const int i = (int)(r % num_pol); r /= num_pol;
+    const int j = (int)(r % N); const int scene = (int)(r / N);
+    const nep_traj_rec* rec = recs + (long)scene * N + j;
+    const bool ok = rec->valid && rec->is_agent && rec->pwp.n_seg >= 1;
+    if (i == 0 && col == 0) present[(long)scene * N + j] = ok ? 1 : 0;
+    double ox = 0.0, oy = 0.0;
+    if (ok) {
+      const double t_start = *(const double*)((const char*)ts0 + (long)scene * ts_scene_stride), t_end = t_start + num_pol * T_span;
+      const double deltaT = (t_end - t_start) / (1.0 * num_pol);
+      const double ts = t_start + deltaT * i + deltaT / ns * col;
+      const int n = rec->pwp.n_seg;
+      int low = 0;                                 // std::upper_bound: first knot > ts
+      while (low <= n && !(rec->pwp.times[low] > ts)) low++;
+      int seg; double te;
+      if (low <= n) {
+        seg = low - 1;
+        if (seg < 0) seg = 0; else if (seg > n - 1) seg = n - 1;
+        te = ts - rec->pwp.times[seg];
+        if (te < 0) te = 0; else if (te > deltaT) te = deltaT;
+      } else { seg = n - 1; te = rec->pwp.times[n] - rec->pwp.times[n - 1]; }
+      const double t3 = te * te * te, t2 = te * te;
+      const double* cxp = rec->pwp.coeff[0][seg]; const double* cyp = rec->pwp.coeff[1][seg];
+      ox = ((cxp[0] * t3 + cxp[1] * t2) + cxp[2] * te) + cxp[3] * 1.0; oy = ((cyp[0] * t3 + cyp[1] * t2) + cyp[2] * te) + cyp[3] * 1.0;
+    }
+    sampled[e * 2] = ox; sampled[e * 2 + 1] = oy;
+  }
+}
+void launch_ent_sample(const nep_traj_rec* recs, int n_scenes, int N, const double* ts0, long ts_scene_stride, int num_pol, int ns, double T_span,
+                       double* sampled, int* present, hipStream_t st) {
+  const long total = (long)n_scenes * N * num_pol * (ns + 1);
+  if (total <= 0) return;
+  int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(ent_sample_kernel, dim3(blocks), dim3(256), 0, st, recs, n_scenes, N, ts0, ts_scene_stride, num_pol, ns, T_span, sampled, present);
+}
+
+// KinodynamicSearch::entangleCheckGivenPwp for the first interval of every new trajectory (neptune.cpp:746-754): one thread
+// per (scene, agent); entangles[scene][a] = 1 turns the trajectory down in the safety pass.
+__global__ void ent_check_kernel(SceneParams sp, ProblemSet ps, FeEntArgs ea, const nep_traj_rec* __restrict__ fresh, int n_scenes, double cable, int* __restrict__ entangles) {
+  const int N = sp.num_agents;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n_scenes * N) return;
+  const int scene = (int)(idx / N), a = (int)(idx % N);
+  const nep_traj_rec* r = fresh + idx;
+  int hit = 0;
+  if (r->valid && r->pwp.n_seg >= 1) {
+    EntCtx ec;
+    ec.N = N; ec.S = sp.n_static; ec.own = a; ec.num_pol = sp.num_pol; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = cable;
+    ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
+    ec.sampled = ea.sampled + (long)scene * N * sp.num_pol * (ea.ns + 1) * 2; ec.present = ea.present + (long)scene * N;
+    ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
+    nep_fe_ent_state* wk = ea.work + idx;
+    if (ea.init) ent_copy(wk, ea.init + idx); else { long* z = (long*)wk; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
+    const double* cx0 = r->pwp.coeff[0][0]; const double* cy0 = r->pwp.coeff[1][0];
+    const double T = sp.T_span;
+    const Ev2 end{((cx0[0] * (T * T * T) + cx0[1] * (T * T)) + cx0[2] * T) + cx0[3] * 1.0, ((cy0[0] * (T * T * T) + cy0[1] * (T * T)) + cy0[2] * T) + cy0[3] * 1.0};
+    double arc = 0.0;
+    hit = ent_propagate(ec, wk, cx0, cy0, end, 1, arc, false, 3) != 0 ? 1 : 0;
+  }
+  entangles[idx] = hit;
+}
+void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntArgs& ea, const nep_traj_rec* fresh, int n_scenes, double cable, int* entangles, hipStream_t st) {
+  const long total = (long)n_scenes * sp.num_agents;
+  if (total <= 0) return;
+  hipLaunchKernelGGL(ent_check_kernel, dim3((int)((total + 63) / 64)), dim3(64), 0, st, sp, ps, ea, fresh, n_scenes, cable, entangles);
 }
 
 }  // namespace nep

@@ -123,10 +123,25 @@ void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, con
                    const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 int qp_reg_slots();
 size_t qp_reg_lds_bytes();
+// entangle inputs / scratch of the front end and of the safety pass's entangle re-check (device pointers)
+struct FeEntArgs {
+  const double* sampled;         // [scenes][N][num_pol][ns+1][2]   SampledPtsForAll_ (ent_sample_kernel)
+  const int* present;            // [scenes][N]
+  const double* srep;            // [S][2][2] staticObsRep_ (x n_scenes with per-scene statics)
+  const double* slong;           // [S][2]    staticObsLongestDist_
+  const nep_fe_ent_state* init;  // [slots] entangle state at point A, or null (empty)
+  nep_fe_ent_state* nodes;       // [slots][num_pol+1][beam_width] states of the installed nodes
+  nep_fe_ent_state* work;        // [slots][256] one working record per thread
+  int* case_out;                 // [slots][NEP_MAX_POL][N] (out) or null
+  int ns;                        // num_sample_per_interval
+};
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
-                     nep_guess* guess_out, nep_fe_result* res_out, hipStream_t st);
+                     nep_guess* guess_out, nep_fe_result* res_out, const FeEntArgs* ea, hipStream_t st);
+void launch_ent_sample(const nep_traj_rec* recs, int n_scenes, int N, const double* ts0, long ts_scene_stride, int num_pol, int ns, double T_span,
+                       double* sampled, int* present, hipStream_t st);
+void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntArgs& ea, const nep_traj_rec* fresh, int n_scenes, double cable, int* entangles, hipStream_t st);
 void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const double* b_xy, int* hit, hipStream_t st);
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
-                   unsigned char* conflict, unsigned char* conflict_prev, nep_traj_rec* final_out, int* accept_out, hipStream_t st);
+                   unsigned char* conflict, unsigned char* conflict_prev, const int* entangles, nep_traj_rec* final_out, int* accept_out, hipStream_t st);
 
 }  // namespace nep

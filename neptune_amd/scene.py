@@ -518,10 +518,10 @@ def tether_crossing_scene(num_agents, n_static, seed):
     return sc
 
 
-def frontend_cfg(p, beam_width=32, num_samples=5, pad_hold=0):
+def frontend_cfg(p, beam_width=32, num_samples=5, pad_hold=0, entangle=False, ent_samples=3):
     """The front-end settings Neptune's constructor passes (neptune.cpp:92-97) with the reference yaml values
     (a_star_samp_x 5, a_star_fraction_voxel_size 0.2, goal_radius 0.2, bias 1.1)."""
-    return abi.nep_fe_cfg(p.j_max, 0.2, 1.1, 0.2, p.tether_length, num_samples, beam_width, pad_hold, 0)
+    return abi.nep_fe_cfg(p.j_max, 0.2, 1.1, 0.2, p.tether_length, num_samples, beam_width, pad_hold, 1 if entangle else 0, ent_samples, 0)
 
 
 def frontend_starts(sc):

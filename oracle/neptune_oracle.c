@@ -1087,6 +1087,235 @@ static int fe_child(const orc_fe_cfg* c, const double init_end[6], double par_g,
   return 1;
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Entanglement state of a lattice node (enable_entangle_check): KinodynamicSearch::entanglesWithOtherAgents  */
+/* (kinodynamic_search.cpp:707-895) with eu::entangleHSigToAddAgentInd (entangle_utils.cpp:1129-1228),        */
+/* entangleHSigToAddStatic (:1231-1277), addAlphaBetaToList + breakcondition (:1402-1534, :1608-1647),        */
+/* updateBendPts (:1536-1604), getBendPt2d / calculateBetaForCase / getTetherLength (:1649-1743).             */
+/* Fixed capacity: NEP_FE_ENT_CAP crossings per node (the reference prunes at num_agents + statics); a node    */
+/* that would exceed it is pruned and counted in nep_fe_result.ent_overflow.  active_cases[i] is the number of */
+/* list entries of agent i (every append adds one, every cancellation removes one): it is derived, not stored. */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct orc_ent_node { int n_alpha, n_bend; short id[NEP_FE_ENT_CAP]; signed char cs[NEP_FE_ENT_CAP]; double beta[NEP_FE_ENT_CAP]; signed char bend[NEP_MAX_BEND]; } orc_ent_node;
+typedef struct ent_ctx {
+  int N, S, own, num_pol, ns; double T_span, cable;
+  const double* pb; const double* srep; const double* slong; const double* sampled; const int* present; const int* bend_n; const double* bend_xy;
+} ent_ctx;
+typedef struct { double x, y; } ev2;
+#define ENT_ADD_CAP 32
+typedef struct { short id[ENT_ADD_CAP]; signed char cs[ENT_ADD_CAP]; int n, overflow; } ent_add;
+
+static ev2 ent_pb(const ent_ctx* c, int j) { ev2 r = {c->pb[2 * j], c->pb[2 * j + 1]}; return r; }
+static ev2 ent_srep(const ent_ctx* c, int s, int col) { ev2 r = {c->srep[(s * 2 + col) * 2], c->srep[(s * 2 + col) * 2 + 1]}; return r; }
+static ev2 ent_bendpt(const ent_ctx* c, int j, int k) { ev2 r = {c->bend_xy[((size_t)j * NEP_MAX_BEND + k) * 2], c->bend_xy[((size_t)j * NEP_MAX_BEND + k) * 2 + 1]}; return r; }
+static ev2 ent_sampled(const ent_ctx* c, int i, int interval, int col) {
+  const double* q = c->sampled + (((size_t)i * c->num_pol + interval) * (c->ns + 1) + col) * 2; ev2 r = {q[0], q[1]}; return r;
+}
+static double ent_wedge(ev2 a, ev2 b, ev2 cc) { return (b.x - a.x) * (cc.y - a.y) - (cc.x - a.x) * (b.y - a.y); }
+static double ent_wedge2(ev2 a, ev2 b, ev2 cc, ev2* ab, ev2* ac) { ab->x = b.x - a.x; ab->y = b.y - a.y; ac->x = cc.x - a.x; ac->y = cc.y - a.y; return ab->x * ac->y - ac->x * ab->y; }
+static double ent_ratio(ev2 u, ev2 v) { return fabs(u.y * v.y) > fabs(u.x * v.x) ? u.y / v.y : u.x / v.x; }
+static double ent_dist(ev2 a, ev2 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
+static void ent_push(ent_add* a, int id, int cs) { if (a->n < ENT_ADD_CAP) { a->id[a->n] = (short)id; a->cs[a->n] = (signed char)cs; a->n++; } else a->overflow = 1; }
+
+static void ent_cross_agent(ent_add* add, ev2 pk, ev2 pk1, ev2 pik, ev2 pik1, ev2 pb_self, const ent_ctx* c, int i, int agent_id) {
+  const int nb = c->bend_n[i];
+  int base_addition = 0;
+  for (int k = 0; k < nb; k++) {
+    const int last = k == nb - 1;
+    const ev2 bk = ent_bendpt(c, i, k);
+    ev2 u, v; double c1, c2;
+    if (!last) { const ev2 bn = ent_bendpt(c, i, k + 1); c1 = ent_wedge2(pk, bn, bk, &u, &v); c2 = ent_wedge(pk1, bn, bk); }
+    else { c1 = ent_wedge2(pk, pik, bk, &u, &v); c2 = ent_wedge(pk1, pik1, bk); }
+    if (last) {   /* the other agent's last tether piece sweeping over OUR base */
+      ev2 ub, vb;
+      const double f1 = ent_wedge2(pb_self, pik, bk, &ub, &vb), f2 = ent_wedge(pb_self, pik1, bk);
+      if (f1 * f2 < 0) {
+        const double a = ent_ratio(ub, vb);
+        if (a < 0) { }
+        else if (a < 1) ent_push(add, agent_id, 1);
+        else if (k == 0) ent_push(add, agent_id, 0);
+        base_addition = 1;
+      }
+    }
+    if (c1 * c2 < 0) {
+      const double a = ent_ratio(u, v);
+      if (a < 0) ent_push(add, agent_id, k + 2);
+      else if (a < 1 && last) ent_push(add, agent_id, 1);
+      else if (a >= 1 && k == 0) ent_push(add, agent_id, 0);
+    }
+  }
+  if (base_addition && add->n >= 2 && add->id[add->n - 1] == add->id[add->n - 2] && add->cs[add->n - 1] == add->cs[add->n - 2]) add->n -= 2;
+}
+static void ent_cross_static(ent_add* add, ev2 pk, ev2 pk1, const ent_ctx* c) {
+  for (int s = 0; s < c->S; s++) {
+    const ev2 pik = ent_srep(c, s, 1), pbi = ent_srep(c, s, 0);
+    ev2 u, v;
+    const double c1 = ent_wedge2(pk, pik, pbi, &u, &v), c2 = ent_wedge(pk1, pik, pbi);
+    if (c1 * c2 < 0) {
+      const double a = ent_ratio(u, v);
+      if (a < 0) { }
+      else if (a < 1) ent_push(add, c->N + s + 1, 1);
+      else ent_push(add, c->N + s + 1, 0);
+    }
+  }
+}
+static ev2 ent_anchor(int id, int cs, const ent_ctx* c) { return id <= c->N ? ent_pb(c, id - 1) : ent_srep(c, id - c->N - 1, cs); }
+static ev2 ent_cur_bend(const orc_ent_node* st, ev2 pb_self, const ent_ctx* c) {
+  if (st->n_bend == 0) return pb_self;
+  const int b = st->bend[st->n_bend - 1];
+  const int id = st->id[b], cs = st->cs[b];
+  if (id <= c->N && id >= 1) return ent_pb(c, id - 1);
+  if (id > c->N) return ent_srep(c, id - c->N - 1, cs);
+  { ev2 z = {0, 0}; return z; }
+}
+static double ent_beta(int id, int cs, ev2 pk, ev2 bp, const ent_ctx* c) { return id <= c->N ? 0.0 : ent_wedge(pk, ent_srep(c, id - c->N - 1, cs), bp); }
+static int ent_scan_stops(int t_id, int t_cs, int l_id, int j, int last_bend, const ent_ctx* c) {
+  if (t_id <= c->N && t_cs >= 2) return j <= last_bend;
+  if (t_id <= c->N) return 0;
+  return l_id > c->N || j <= last_bend;
+}
+static void ent_erase(orc_ent_node* st, int j) {
+  for (int k = j; k + 1 < st->n_alpha; k++) { st->id[k] = st->id[k + 1]; st->cs[k] = st->cs[k + 1]; st->beta[k] = st->beta[k + 1]; }
+  st->n_alpha--;
+}
+/* returns 1 when the list would exceed its capacity */
+static int ent_merge(ent_add* add, orc_ent_node* st, ev2 pk, ev2 pb_self, const ent_ctx* c) {
+  int again = 1;
+  while (again) {
+    again = 0;
+    const int b = st->n_bend ? st->bend[st->n_bend - 1] : -1;
+    for (int i = 0; i < add->n && !again; i++) {
+      const int t_id = add->id[i], t_cs = add->cs[i];
+      for (int j = st->n_alpha - 1; j >= 0; j--) {
+        const int l_id = st->id[j], l_cs = st->cs[j];
+        const int agent = t_id <= c->N;
+        const int match = (l_id == t_id && l_cs == t_cs) ||
+                          (agent && l_id == t_id && t_cs >= c->bend_n[t_id - 1] + 1 && t_cs < l_cs) ||
+                          (agent && l_id == t_id && l_cs >= 2 && t_cs >= 2 && abs(t_cs - l_cs) == 1 && j > b);
+        if (match) {
+          for (int k = i; k + 1 < add->n; k++) { add->id[k] = add->id[k + 1]; add->cs[k] = add->cs[k + 1]; }
+          add->n--;
+          ent_erase(st, j);
+          if (j == b) {
+            st->n_bend--;
+            const ev2 bp = ent_cur_bend(st, pb_self, c);
+            for (int k = j; k < st->n_alpha; k++) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk, bp, c);
+          } else if (j < b) {
+            st->bend[st->n_bend - 1] = (signed char)(b - 1);
+            for (int k = st->n_bend - 2; k >= 0; k--) { if (st->bend[k] > j) st->bend[k] -= 1; else break; }
+          }
+          again = 1;
+          break;
+        }
+        if (ent_scan_stops(t_id, t_cs, l_id, j, b, c)) break;
+      }
+    }
+  }
+  if (add->n == 0) return 0;
+  if (st->n_alpha + add->n > NEP_FE_ENT_CAP) return 1;
+  const ev2 bp = ent_cur_bend(st, pb_self, c);
+  for (int i = 0; i < add->n; i++) {
+    st->id[st->n_alpha] = add->id[i]; st->cs[st->n_alpha] = add->cs[i];
+    st->beta[st->n_alpha] = ent_beta(add->id[i], add->cs[i], pk, bp, c);
+    st->n_alpha++;
+  }
+  return 0;
+}
+static int ent_update_bends(orc_ent_node* st, ev2 pk1, ev2 pb_self, const ent_ctx* c) {
+  const ev2 bp = ent_cur_bend(st, pb_self, c);
+  int idx_new = -1;
+  const int start = st->n_bend ? st->bend[st->n_bend - 1] : -1;
+  for (int i = start + 1; i < st->n_alpha; i++) { const double beta = ent_beta(st->id[i], st->cs[i], pk1, bp, c); if (beta * st->beta[i] < -1e-7) idx_new = i; }
+  if (idx_new > -1) {
+    if (st->n_bend >= NEP_MAX_BEND) return 1;
+    st->bend[st->n_bend++] = (signed char)idx_new;
+    const ev2 nb = ent_anchor(st->id[idx_new], st->cs[idx_new], c);
+    for (int i = idx_new + 1; i < st->n_alpha; i++) st->beta[i] = ent_beta(st->id[i], st->cs[i], pk1, nb, c);
+    return 0;
+  }
+  while (st->n_bend) {
+    const ev2 prev = st->n_bend == 1 ? pb_self : ent_anchor(st->id[st->bend[st->n_bend - 2]], st->cs[st->bend[st->n_bend - 2]], c);
+    const int bi = st->bend[st->n_bend - 1];
+    const double beta = ent_beta(st->id[bi], st->cs[bi], pk1, prev, c);
+    if (beta * st->beta[bi] > 1e-7) {
+      for (int k = bi + 1; k < st->n_alpha; k++) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk1, prev, c);
+      st->n_bend--;
+    } else break;
+  }
+  return 0;
+}
+static double ent_tether(const orc_ent_node* st, ev2 from, ev2 pk1, const ent_ctx* c) {
+  double len = 0.0;
+  for (int q = 0; q < st->n_bend; q++) {
+    const int b = st->bend[q]; const int id = st->id[b], cs = st->cs[b];
+    ev2 bp; double comp;
+    if (id <= c->N) { bp = ent_pb(c, id - 1); comp = 0.0; } else { bp = ent_srep(c, id - c->N - 1, cs); comp = c->slong[(id - c->N - 1) * 2 + cs]; }
+    len += ent_dist(bp, from) + 2 * comp;
+    from = bp;
+  }
+  return len + ent_dist(pk1, from);
+}
+static int ent_count(const short* ids, int n, int id) { int k = 0; for (int i = 0; i < n; i++) k += ids[i] == id; return k; }
+/* 0: fine; 1: the reference's function returns true (prune); 2: capacity exceeded (pruned, flagged).  check_tether / cap_mult:
+ * entanglesWithOtherAgents (1, 1) and entangleCheckGivenPwp (0, 3: kinodynamic_search.cpp:944-948, 977-983). */
+static int ent_propagate(const ent_ctx* c, orc_ent_node* st, const double cxo[4], const double cyo[4], ev2 end, int index, double* arc, int check_tether, int cap_mult) {
+  const int ns = c->ns;
+  const ev2 pb_self = ent_pb(c, c->own);
+  ev2 pk = {cxo[3], cyo[3]}, pk1 = pk;
+  for (int j = 1; j <= ns; j++) {
+    ent_add add; add.n = 0; add.overflow = 0;
+    if (j < ns) {
+      const double t = c->T_span * j / ns;
+      const double t3 = t * t * t, t2 = t * t;
+      pk1.x = ((cxo[0] * t3 + cxo[1] * t2) + cxo[2] * t) + cxo[3] * 1.0; pk1.y = ((cyo[0] * t3 + cyo[1] * t2) + cyo[2] * t) + cyo[3] * 1.0;
+    } else pk1 = end;
+    *arc += ent_dist(pk1, pk);
+    for (int i = 0; i < c->N; i++) {
+      if (i == c->own || !c->present[i]) continue;
+      ev2 pik, pik1;
+      if (index > c->num_pol) { pik = ent_sampled(c, i, c->num_pol - 1, ns); pik1 = pik; }
+      else { pik = ent_sampled(c, i, index - 1, j - 1); pik1 = ent_sampled(c, i, index - 1, j); }
+      ent_cross_agent(&add, pk, pk1, pik, pik1, pb_self, c, i, i + 1);
+    }
+    ent_cross_static(&add, pk, pk1, c);
+    if (add.overflow) return 2;
+    if (st->n_alpha + add.n > (c->N + c->S) * cap_mult) return 1;
+    short old_id[NEP_FE_ENT_CAP]; const int old_n = st->n_alpha;
+    for (int i = 0; i < old_n; i++) old_id[i] = st->id[i];
+    if (ent_merge(&add, st, pk, pb_self, c)) return 2;
+    for (int i = 0; i < st->n_alpha; i++) {
+      const int id = st->id[i];
+      if (id > c->N) continue;
+      const int nw = ent_count(st->id, st->n_alpha, id), od = ent_count(old_id, old_n, id);
+      if (od < 2 && nw >= 2) return 1;
+      if (od >= 2 && nw > od) return 1;
+    }
+    if (ent_update_bends(st, pk1, pb_self, c)) return 2;
+    pk = pk1;
+  }
+  if (check_tether && ent_tether(st, pb_self, pk1, c) > c->cable) return 1;
+  return 0;
+}
+/* (knot, agent) -> case id of solver_gurobi_poly.cpp:624-631: the last list entry of an agent with exactly one */
+static void ent_case_row(const orc_ent_node* st, int N, int* row) {
+  for (int j = 0; j < N; j++) row[j] = 0;
+  for (int j = 0; j < N; j++) {
+    if (ent_count(st->id, st->n_alpha, j + 1) != 1) continue;
+    for (int a = 0; a < st->n_alpha; a++) if (st->id[a] == j + 1) row[j] = st->cs[a];
+  }
+}
+/* KinodynamicSearch::getIz (:2006-2014) with power_int (:2016-2031), unsigned arithmetic */
+static unsigned ent_iz(const orc_ent_node* st) {
+  unsigned iz = 0;
+  for (int i = 0; i < st->n_alpha; i++) {
+    unsigned base = (unsigned)st->id[i], ex = (unsigned)st->cs[i], r;
+    if (ex == 0) r = 1; else if (base < 2) r = base;
+    else { r = 1; for (unsigned term = base;; term = term * term) { if (ex % 2 != 0) r *= term; ex /= 2; if (ex == 0) break; } }
+    iz += (unsigned)(i + 1) * r;
+  }
+  return iz;
+}
+
 /* test hook: every feasible child's control polygon and collision verdict, [n][10] = depth, id, Q[4][2] ... */
 static double* g_fe_dump = 0; static int g_fe_dump_cap = 0, g_fe_dump_n = 0;
 void orc_fe_set_dump(double* buf, int cap) { g_fe_dump = buf; g_fe_dump_cap = cap; g_fe_dump_n = 0; }
@@ -1154,11 +1383,54 @@ static void fe_initial_z(double p0, double v0, double a0, double z_final, double
 
 static int fe_before(const fe_node* a, int ia, const fe_node* b, int ib) { return a->f < b->f || (a->f == b->f && ia < ib); }
 
+/* collidesWithBases2d (kinodynamic_search.cpp:1583-1628): the control polygon against the 0.7 m squares of the other agents' bases */
+static int fe_collides_bases(const orc_fe_cfg* c, const fe_node* nd) {
+  double Qx[4], Qy[4], Q[4][2];
+  orc_pos_ctrl_pts(nd->cx, c->T_span, Qx); orc_pos_ctrl_pts(nd->cy, c->T_span, Qy);
+  for (int i = 0; i < 4; i++) { Q[i][0] = Qx[i]; Q[i][1] = Qy[i]; }
+  const double radius = 0.7, safe_dist = (c->T_span * c->v_max) * 2;
+  for (int j = 0; j < c->num_agents; j++) {
+    if (j == c->id - 1) continue;
+    const double bx = c->pb[2 * j], by = c->pb[2 * j + 1];
+    const double d1 = sqrt((Q[0][0] - bx) * (Q[0][0] - bx) + (Q[0][1] - by) * (Q[0][1] - by));
+    if (d1 > safe_dist) continue;
+    const double B[4][2] = {{bx + radius, by + radius}, {bx + radius, by - radius}, {bx - radius, by - radius}, {bx - radius, by + radius}};
+    if (orc_gjk_collision(4, B, 4, (const double(*)[2])Q)) return 1;
+  }
+  return 0;
+}
+
+int orc_frontend_beam_ent(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv,
+                          const orc_polys* statics, const orc_fe_ent* E, nep_guess* guess, nep_fe_result* res, int* case_out);
 int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv,
                       const orc_polys* statics, nep_guess* guess, nep_fe_result* res) {
+  return orc_frontend_beam_ent(c, st, hull_xy, hull_nv, statics, 0, guess, res, 0);
+}
+/* E != NULL: enable_entangle_check — every child carries its parent's entangle state through entanglesWithOtherAgents
+ * (pruned when that returns true), g is the sampled arc length, h gains 0.3 per crossing and 1.0 per bend point
+ * (:1177-1182), a voxel is (ix, iy, getIz(state)) (:1170-1173), base squares are obstacles (:1675), and only nodes whose
+ * active_cases are all <= 1 may end the plan (:1693-1700).  case_out [NEP_MAX_POL][N]: the case id per (knot, agent) the
+ * back end consumes (solver_gurobi_poly.cpp:624-631), state at the START of segment i. */
+int orc_frontend_beam_ent(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv,
+                          const orc_polys* statics, const orc_fe_ent* E, nep_guess* guess, nep_fe_result* res, int* case_out) {
   const int W = c->beam_width, ns = c->num_samples, NC = ns * ns, D = c->num_pol;
   if (W < 1 || W > NEP_FE_MAX_BEAM || ns < 2 || ns > NEP_FE_MAX_SAMPLES || D < 1 || D > NEP_MAX_POL) return -1;
   static const int CAP = NEP_FE_MAX_BEAM * NEP_FE_MAX_SAMPLES * NEP_FE_MAX_SAMPLES;
+  ent_ctx ec; memset(&ec, 0, sizeof(ec));
+  orc_ent_node ent_root; memset(&ent_root, 0, sizeof(ent_root));
+  orc_ent_node* cand_ent = 0; orc_ent_node (*beam_ent)[NEP_FE_MAX_BEAM] = 0; unsigned* cand_iz = 0; unsigned (*beam_iz)[NEP_FE_MAX_BEAM] = 0;
+  unsigned* vis_iz = 0;
+  if (E) {
+    if (E->num_samples < 1 || E->num_samples > 8) return -1;
+    ec.N = c->num_agents; ec.S = E->n_static; ec.own = c->id - 1; ec.num_pol = c->num_pol; ec.ns = E->num_samples; ec.T_span = c->T_span; ec.cable = c->cable_length;
+    ec.pb = c->pb; ec.srep = E->static_rep; ec.slong = E->static_longest; ec.sampled = E->sampled; ec.present = E->present; ec.bend_n = E->bend_n; ec.bend_xy = E->bend_xy;
+    if (E->init) memcpy(&ent_root, E->init, sizeof(ent_root));
+    cand_ent = (orc_ent_node*)malloc(sizeof(orc_ent_node) * CAP);
+    beam_ent = (orc_ent_node(*)[NEP_FE_MAX_BEAM])malloc(sizeof(orc_ent_node) * NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1));
+    cand_iz = (unsigned*)calloc(CAP, sizeof(unsigned));
+    beam_iz = (unsigned(*)[NEP_FE_MAX_BEAM])calloc((size_t)NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1), sizeof(unsigned));
+    vis_iz = (unsigned*)calloc((size_t)NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1), sizeof(unsigned));
+  }
   fe_node* cand = (fe_node*)malloc(sizeof(fe_node) * CAP);
   int* keep = (int*)malloc(sizeof(int) * CAP);
   fe_node (*beam)[NEP_FE_MAX_BEAM] = (fe_node(*)[NEP_FE_MAX_BEAM])malloc(sizeof(fe_node) * NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1));
@@ -1207,9 +1479,20 @@ int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double*
           }
           if (col) continue;
         }
+        if (E && fe_collides_bases(c, nd)) continue;
         res->n_collision_free++;
+        if (E) {
+          cand_ent[id] = depth == 1 ? ent_root : beam_ent[depth - 1][pr];
+          double arc = 0.0;
+          const ev2 end = {nd->end[0], nd->end[1]};
+          const int rc = ent_propagate(&ec, &cand_ent[id], nd->cx, nd->cy, end, depth, &arc, 1, 1);
+          if (rc) { res->n_entangled++; if (rc == 2) res->ent_overflow = 1; continue; }
+          nd->g = pg + arc;
+          nd->f = nd->g + c->bias * ((nd->dist + 0.3 * (double)cand_ent[id].n_alpha) + 1.0 * (double)cand_ent[id].n_bend);
+          cand_iz[id] = ent_iz(&cand_ent[id]);
+        }
         int seen = 0;
-        for (int v = 0; v < n_vis && !seen; v++) seen = visited[v][0] == nd->vx && visited[v][1] == nd->vy;
+        for (int v = 0; v < n_vis && !seen; v++) seen = visited[v][0] == nd->vx && visited[v][1] == nd->vy && (!E || vis_iz[v] == cand_iz[id]);
         if (seen) continue;
         keep[id] = 1;
       }
@@ -1218,7 +1501,7 @@ int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double*
     for (int i = 0; i < n_c; i++) {
       if (!keep[i]) continue;
       for (int k = 0; k < n_c; k++) {
-        if (k == i || !keep[k] || cand[k].vx != cand[i].vx || cand[k].vy != cand[i].vy) continue;
+        if (k == i || !keep[k] || cand[k].vx != cand[i].vx || cand[k].vy != cand[i].vy || (E && cand_iz[k] != cand_iz[i])) continue;
         if (fe_before(&cand[k], k, &cand[i], i)) { keep[i] = 2; break; }   /* 2: loses its voxel (still counts for the others' comparisons) */
       }
     }
@@ -1228,16 +1511,24 @@ int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double*
       int bi = -1;
       for (int i = 0; i < n_c; i++) if (keep[i] == 1 && (bi < 0 || fe_before(&cand[i], i, &cand[bi], bi))) bi = i;
       if (bi < 0 || nb == W) break;
+      if (E) { beam_ent[depth][nb] = cand_ent[bi]; beam_iz[depth][nb] = cand_iz[bi]; }
       beam[depth][nb++] = cand[bi];
       keep[bi] = 3;
     }
     beam_n[depth] = nb;
     if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
-    for (int r = 0; r < nb; r++) { visited[n_vis][0] = beam[depth][r].vx; visited[n_vis][1] = beam[depth][r].vy; n_vis++; }
-    best_depth = depth; best_rank = 0;
+    for (int r = 0; r < nb; r++) { visited[n_vis][0] = beam[depth][r].vx; visited[n_vis][1] = beam[depth][r].vy; if (E) vis_iz[n_vis] = beam_iz[depth][r]; n_vis++; }
+    /* a plan may only end at a node none of whose agents has two active cases (:1693-1700): always true without the check */
+    int valid[NEP_FE_MAX_BEAM];
+    for (int r = 0; r < nb; r++) {
+      valid[r] = 1;
+      if (E) for (int a = 0; a < beam_ent[depth][r].n_alpha && valid[r]; a++)
+        if (beam_ent[depth][r].id[a] <= c->num_agents && ent_count(beam_ent[depth][r].id, beam_ent[depth][r].n_alpha, beam_ent[depth][r].id[a]) > 1) valid[r] = 0;
+    }
+    { int fv = -1; for (int r = 0; r < nb && fv < 0; r++) if (valid[r]) fv = r; if (fv >= 0) { best_depth = depth; best_rank = fv; } }
     int reached = -1;
-    for (int r = 0; r < nb && reached < 0; r++) if (beam[depth][r].dist < c->goal_size) reached = r;
-    if (reached >= 0) { status = NEP_FE_GOAL_REACHED; best_rank = reached; break; }
+    for (int r = 0; r < nb && reached < 0; r++) if (beam[depth][r].dist < c->goal_size && valid[r]) reached = r;
+    if (reached >= 0) { status = NEP_FE_GOAL_REACHED; best_depth = depth; best_rank = reached; break; }
     if (depth == D) { status = NEP_FE_DEPTH_REACHED; break; }
   }
   res->status = status;
@@ -1263,9 +1554,64 @@ int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double*
       }
       guess->K = D;
     }
-  }
+    if (E && case_out) {   /* state at the start of segment i = the path's node of depth i (depth 0: the initial state) */
+      int path[NEP_MAX_POL + 1]; int rr = best_rank;
+      for (int d = best_depth; d >= 1; d--) { path[d] = rr; rr = beam[d][rr].parent; }
+      for (int i = 0; i < NEP_MAX_POL; i++) {
+        const int dd = i < best_depth ? i : best_depth;      /* held segments keep the last node's state */
+        const orc_ent_node* sn = dd == 0 ? &ent_root : &beam_ent[dd][path[dd]];
+        if (i < guess->K) ent_case_row(sn, c->num_agents, case_out + (size_t)i * c->num_agents);
+        else for (int j = 0; j < c->num_agents; j++) case_out[(size_t)i * c->num_agents + j] = 0;
+      }
+    }
+  } else if (E && case_out) memset(case_out, 0, sizeof(int) * NEP_MAX_POL * (size_t)c->num_agents);
   free(cand); free(keep); free(beam); free(visited);
+  if (E) { free(cand_ent); free(beam_ent); free(cand_iz); free(beam_iz); free(vis_iz); }
   return 0;
+}
+
+/* Test hook: the states KinodynamicSearch::recoverEntStateVector returns for a GIVEN K-segment path (:582-603), reduced to
+ * the (knot, agent) case ids; *hit_at = first 1-based segment whose update returned true (states repeat from there), 0 if
+ * none.  Lets the C restatement above be compared with oracle/entangle_oracle.py on the same guesses. */
+int orc_ent_propagate_guess(const orc_fe_cfg* c, const orc_fe_ent* E, const nep_guess* g, int* case_out, int* hit_at, int* n_alpha_final) {
+  ent_ctx ec; memset(&ec, 0, sizeof(ec));
+  ec.N = c->num_agents; ec.S = E->n_static; ec.own = c->id - 1; ec.num_pol = c->num_pol; ec.ns = E->num_samples; ec.T_span = c->T_span; ec.cable = c->cable_length;
+  ec.pb = c->pb; ec.srep = E->static_rep; ec.slong = E->static_longest; ec.sampled = E->sampled; ec.present = E->present; ec.bend_n = E->bend_n; ec.bend_xy = E->bend_xy;
+  orc_ent_node stt; memset(&stt, 0, sizeof(stt));
+  if (E->init) memcpy(&stt, E->init, sizeof(stt));
+  const double T = c->T_span;
+  const int K = g->K;
+  *hit_at = 0;
+  for (int s = 1; s <= K; s++) {
+    ent_case_row(&stt, c->num_agents, case_out + (size_t)(s - 1) * c->num_agents);
+    if (*hit_at) continue;
+    const double* cxo = g->coeff[0][s - 1]; const double* cyo = g->coeff[1][s - 1];
+    ev2 end;
+    if (s < K) { end.x = g->coeff[0][s][3]; end.y = g->coeff[1][s][3]; }
+    else { end.x = ((cxo[0] * (T * T * T) + cxo[1] * (T * T)) + cxo[2] * T) + cxo[3]; end.y = ((cyo[0] * (T * T * T) + cyo[1] * (T * T)) + cyo[2] * T) + cyo[3]; }
+    orc_ent_node nx = stt; double arc = 0.0;
+    if (ent_propagate(&ec, &nx, cxo, cyo, end, s, &arc, 1, 1)) *hit_at = s; else stt = nx;
+  }
+  for (int s = K; s < NEP_MAX_POL; s++) for (int j = 0; j < c->num_agents; j++) case_out[(size_t)s * c->num_agents + j] = 0;
+  if (n_alpha_final) *n_alpha_final = stt.n_alpha;
+  return 0;
+}
+
+/* KinodynamicSearch::entangleCheckGivenPwp (kinodynamic_search.cpp:897-985) as called by safetyCheckAfterReplan
+ * (neptune.cpp:746-754): the new trajectory against the entangle state at its start.  As in the reference only the FIRST
+ * interval is examined (the loop returns false at the end of its first pass, :983), the capacity test is three times the
+ * search's (:944-948) and the tether length is not tested (:977-982 commented out).  1 = entangles. */
+int orc_entangle_check_pwp(const orc_fe_cfg* c, const orc_fe_ent* E, const double cx0[4], const double cy0[4]) {
+  ent_ctx ec; memset(&ec, 0, sizeof(ec));
+  ec.N = c->num_agents; ec.S = E->n_static; ec.own = c->id - 1; ec.num_pol = c->num_pol; ec.ns = E->num_samples; ec.T_span = c->T_span; ec.cable = c->cable_length;
+  ec.pb = c->pb; ec.srep = E->static_rep; ec.slong = E->static_longest; ec.sampled = E->sampled; ec.present = E->present; ec.bend_n = E->bend_n; ec.bend_xy = E->bend_xy;
+  orc_ent_node stt; memset(&stt, 0, sizeof(stt));
+  if (E->init) memcpy(&stt, E->init, sizeof(stt));
+  const double T = c->T_span;
+  /* pkplus1 = P * sampled_time_vector_[j] for every j, including the last (:914): the polynomial at T */
+  const ev2 end = {((cx0[0] * (T * T * T) + cx0[1] * (T * T)) + cx0[2] * T) + cx0[3] * 1.0, ((cy0[0] * (T * T * T) + cy0[1] * (T * T)) + cy0[2] * T) + cy0[3] * 1.0};
+  double arc = 0.0;
+  return ent_propagate(&ec, &stt, cx0, cy0, end, 1, &arc, 0, 3) != 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -138,6 +138,26 @@ int orc_frontend_astar(const orc_fe_cfg* c, const nep_fe_start* st, const double
                        const int* order, int max_pops, nep_guess* guess, nep_fe_result* res);
 int orc_frontend_beam(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv,
                       const orc_polys* statics, nep_guess* guess, nep_fe_result* res);
+/* enable_entangle_check: what the search holds besides the hulls (setUp, kinodynamic_search.cpp:190-257; setStaticObstRep
+ * :385-390): the other agents' sampled committed trajectories, their tether bend points, the static representatives,
+ * and the entangle state at point A (NULL = empty). */
+typedef struct orc_fe_ent {
+  int num_samples;                 /* num_sample_per_interval */
+  int n_static;
+  const double* static_rep;        /* [n_static][2][2] */
+  const double* static_longest;    /* [n_static][2] */
+  const double* sampled;           /* [num_agents][num_pol][num_samples+1][2] */
+  const int* present;              /* [num_agents] */
+  const int* bend_n;               /* [num_agents] */
+  const double* bend_xy;           /* [num_agents][NEP_MAX_BEND][2] */
+  const nep_fe_ent_state* init;    /* or NULL */
+} orc_fe_ent;
+int orc_frontend_beam_ent(const orc_fe_cfg* c, const nep_fe_start* st, const double* hull_xy, const int* hull_nv,
+                          const orc_polys* statics, const orc_fe_ent* E, nep_guess* guess, nep_fe_result* res, int* case_out);
+/* test hook: case ids per (knot, agent) along a given guess, as the restatement above accumulates them */
+int orc_ent_propagate_guess(const orc_fe_cfg* c, const orc_fe_ent* E, const nep_guess* g, int* case_out, int* hit_at, int* n_alpha_final);
+/* entangleCheckGivenPwp for the first interval [a b c d] of a new trajectory (1 = entangles) */
+int orc_entangle_check_pwp(const orc_fe_cfg* c, const orc_fe_ent* E, const double cx0[4], const double cy0[4]);
 
 #ifdef __cplusplus
 }

@@ -268,6 +268,72 @@ def frontend_beam(p, fe, agent_id, start, hull_xy, hull_nv, statics):
     return g[0], {k: r[0][k].item() for k in abi.FE_RESULT_DTYPE.names}
 
 
+class orc_fe_ent(C.Structure):
+    _fields_ = [("num_samples", C.c_int), ("n_static", C.c_int), ("static_rep", C.POINTER(C.c_double)), ("static_longest", C.POINTER(C.c_double)),
+                ("sampled", C.POINTER(C.c_double)), ("present", C.POINTER(C.c_int)), ("bend_n", C.POINTER(C.c_int)), ("bend_xy", C.POINTER(C.c_double)),
+                ("init", C.c_void_p)]
+
+
+def _fe_ent(p, ent):
+    """ent: dict(num_samples, reps [S][2][2], longest [S][2], sampled [N][num_pol][ns+1][2], present [N], bend_n [N],
+    bend_xy [N][NEP_MAX_BEND][2], init (one FE_ENT_STATE_DTYPE record or None)) -> (orc_fe_ent, keep-alive list)"""
+    reps = _c(ent["reps"]).reshape(-1); lg = _c(ent["longest"]).reshape(-1)
+    if reps.size == 0:
+        reps = np.zeros(4); lg = np.zeros(2)
+    sm = _c(ent["sampled"]); pr = _c(ent["present"], np.int32); bn = _c(ent["bend_n"], np.int32); bx = _c(ent["bend_xy"])
+    init = np.ascontiguousarray(ent["init"], dtype=abi.FE_ENT_STATE_DTYPE).reshape(1) if ent.get("init") is not None else None
+    E = orc_fe_ent(int(ent["num_samples"]), len(np.asarray(ent["reps"]).reshape(-1, 2, 2)), abi.dptr(reps), abi.dptr(lg), abi.dptr(sm),
+                   pr.ctypes.data_as(C.POINTER(C.c_int)), bn.ctypes.data_as(C.POINTER(C.c_int)), abi.dptr(bx),
+                   init.ctypes.data if init is not None else None)
+    return E, [reps, lg, sm, pr, bn, bx, init]
+
+
+def frontend_beam_ent(p, fe, agent_id, start, hull_xy, hull_nv, statics, ent):
+    """orc_frontend_beam_ent: the beam with the entangle check on -> (guess record, result dict, case_id [NEP_MAX_POL][N])."""
+    pb = _c(p.pb)
+    cfg = orc_fe_cfg(p.num_pol, agent_id, p.num_agents, fe.num_samples, fe.beam_width, fe.pad_hold, p.T_span, fe.j_max, p.v_max, p.a_max,
+                     fe.voxel_size, fe.bias, fe.goal_size, fe.cable_length, (C.c_double * 2)(p.x_min, p.y_min),
+                     (C.c_double * 2)(p.x_max, p.y_max), abi.dptr(pb))
+    S = Polys(statics)
+    st = np.ascontiguousarray(start, dtype=abi.FE_START_DTYPE).reshape(1)
+    hx = _c(hull_xy); hn = _c(hull_nv, np.int32)
+    g = np.zeros(1, dtype=abi.GUESS_DTYPE); r = np.zeros(1, dtype=abi.FE_RESULT_DTYPE)
+    case = np.zeros((abi.NEP_MAX_POL, p.num_agents), dtype=np.int32)
+    E, keep = _fe_ent(p, ent)
+    f = lib().orc_frontend_beam_ent
+    f.restype = C.c_int
+    rc = f(C.byref(cfg), C.c_void_p(st.ctypes.data), C.c_void_p(hx.ctypes.data), C.c_void_p(hn.ctypes.data), C.byref(S.c), C.byref(E),
+           C.c_void_p(g.ctypes.data), C.c_void_p(r.ctypes.data), C.c_void_p(case.ctypes.data))
+    if rc:
+        raise RuntimeError("orc_frontend_beam_ent: bad configuration")
+    return g[0], {k: r[0][k].item() for k in abi.FE_RESULT_DTYPE.names}, case
+
+
+def ent_propagate_guess(p, agent_id, cable_length, guess, ent):
+    """case ids [NEP_MAX_POL][N] and the first entangling segment (0: none) along a given guess (orc_ent_propagate_guess)."""
+    pb = _c(p.pb)
+    cfg = orc_fe_cfg(p.num_pol, agent_id, p.num_agents, 5, 1, 0, p.T_span, p.j_max, p.v_max, p.a_max, 0.2, 1.1, 0.2, cable_length,
+                     (C.c_double * 2)(p.x_min, p.y_min), (C.c_double * 2)(p.x_max, p.y_max), abi.dptr(pb))
+    E, keep = _fe_ent(p, ent)
+    g = np.ascontiguousarray(guess, dtype=abi.GUESS_DTYPE).reshape(1)
+    case = np.zeros((abi.NEP_MAX_POL, p.num_agents), dtype=np.int32)
+    hit = C.c_int(0); na = C.c_int(0)
+    lib().orc_ent_propagate_guess(C.byref(cfg), C.byref(E), C.c_void_p(g.ctypes.data), C.c_void_p(case.ctypes.data), C.byref(hit), C.byref(na))
+    return case, hit.value, na.value
+
+
+def entangle_check_pwp(p, agent_id, cable_length, coeff_x0, coeff_y0, ent):
+    """KinodynamicSearch::entangleCheckGivenPwp on the first interval [a b c d] of a new trajectory."""
+    pb = _c(p.pb)
+    cfg = orc_fe_cfg(p.num_pol, agent_id, p.num_agents, 5, 1, 0, p.T_span, p.j_max, p.v_max, p.a_max, 0.2, 1.1, 0.2, cable_length,
+                     (C.c_double * 2)(p.x_min, p.y_min), (C.c_double * 2)(p.x_max, p.y_max), abi.dptr(pb))
+    E, keep = _fe_ent(p, ent)
+    cx = _c(coeff_x0); cy = _c(coeff_y0)
+    f = lib().orc_entangle_check_pwp
+    f.restype = C.c_int
+    return bool(f(C.byref(cfg), C.byref(E), abi.dptr(cx), abi.dptr(cy)))
+
+
 def frontend_astar(p, fe, agent_id, start, hull_xy, hull_nv, statics, order=None, max_pops=20000):
     """KinodynamicSearch::run restated (best-first search to the goal, lattice order and pop budget as parameters)."""
     pb = _c(p.pb)

@@ -48,3 +48,33 @@ def theta_tol(c):
 
 def load_kat():
     return json.load(open(os.path.join(ROOT, "tests", "golden", "minvo_kat.json")))
+
+
+def ent_inputs(sc, a, num_samples=3, init=None, recs=None, t0=None):
+    """The entangle inputs of agent a's (0-based) search as the reference's setUp assembles them (kinodynamic_search.cpp:
+    190-257): the other agents' committed trajectories sampled on the planning grid (by the Python restatement,
+    oracle/entangle_oracle.py), their tether bend points, the static representatives.  -> dict for oracle.frontend_beam_ent."""
+    from neptune_amd import abi
+    from oracle import entangle_oracle as eo
+    p = sc["par"]; N = p.num_agents
+    com = sc["committed"] if recs is None else recs
+    t0 = float(sc["guesses"][a]["t_start"]) if t0 is None else t0
+    sampled = np.zeros((N, p.num_pol, num_samples + 1, 2)); present = np.zeros(N, dtype=np.int32)
+    bend_n = np.zeros(N, dtype=np.int32); bend_xy = np.zeros((N, abi.NEP_MAX_BEND, 2))
+    for j in range(N):
+        r = com[j]
+        ok = bool(r["valid"]) and bool(r["is_agent"]) and int(r["pwp"]["n_seg"]) >= 1
+        nb = int(r["n_bend"]) if ok else 0
+        bend_n[j] = nb
+        bend_xy[j, :nb] = np.array(r["bend"])[:nb]
+        if j == a or not ok:
+            present[j] = 1 if ok else 0          # (the own entry is skipped by id, not by presence)
+            if not ok:
+                continue
+        pw = r["pwp"]; n = int(pw["n_seg"])
+        pts = eo.sample_points_of_intervals(np.array(pw["times"])[:n + 1].tolist(), np.array(pw["coeff"])[0, :n].tolist(),
+                                            np.array(pw["coeff"])[1, :n].tolist(), t0, t0 + p.num_pol * p.T_span, p.num_pol, num_samples)
+        sampled[j] = np.array(pts).reshape(p.num_pol, num_samples + 1, 2)
+        present[j] = 1
+    reps, longest = scene.static_reps(sc["statics"]) if len(sc["statics"]) else (np.zeros((0, 2, 2)), np.zeros((0, 2)))
+    return dict(num_samples=num_samples, reps=reps, longest=longest, sampled=sampled, present=present, bend_n=bend_n, bend_xy=bend_xy, init=init)

@@ -1,0 +1,143 @@
+"""GPU: the front end with the entangle check on (nep_batch_frontend_ent) against the oracle bit for bit — guesses,
+per-search counters and the case block — then the back end on device-made guesses AND device-made entangle cases, and
+the safety pass's entangle re-check."""
+import dataclasses
+
+import numpy as np
+import pytest
+
+import helpers
+from neptune_amd import abi, scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from neptune_amd import backend
+    return backend
+
+
+def _run_frontend(be, sc, W, inits=None):
+    p = sc["par"]; N = p.num_agents
+    fe = scene.frontend_cfg(p, beam_width=W, entangle=True)
+    bb = be.BatchBackend(p, sc["statics"])
+    reps, longest = scene.static_reps(sc["statics"]) if len(sc["statics"]) else (np.zeros((0, 2, 2)), np.zeros((0, 2)))
+    bb.set_static_reps(reps, longest)
+    T = bb.torch
+    starts = scene.frontend_starts(sc)
+    d_g = T.zeros(N * abi.GUESS_DTYPE.itemsize, dtype=T.uint8, device=bb.device)
+    d_r = T.zeros(N * abi.FE_RESULT_DTYPE.itemsize, dtype=T.uint8, device=bb.device)
+    d_case = T.zeros(N * abi.NEP_MAX_POL * N, dtype=T.int32, device=bb.device)
+    d_init = bb.to_device(inits) if inits is not None else None
+    d_com = bb.to_device(sc["committed"])
+    bb.frontend_ent(fe, d_com, bb.to_device(starts), d_g, d_r, d_case, d_ent_init=d_init)
+    T.cuda.synchronize()
+    return bb, fe, starts, d_com, d_g, d_g.cpu().numpy().view(abi.GUESS_DTYPE), d_r.cpu().numpy().view(abi.FE_RESULT_DTYPE), d_case, d_case.cpu().numpy().reshape(N, abi.NEP_MAX_POL, N)
+
+
+@pytest.mark.parametrize("n_agents,n_static,seed,W", [(8, 6, 60, 16), (8, 6, 56, 32), (16, 8, 61, 16)])
+def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_static, seed, W):
+    sc = scene.tether_crossing_scene(n_agents, n_static, seed)
+    p = sc["par"]; N = n_agents
+    rng = np.random.default_rng(seed)
+    inits = np.zeros(N, dtype=abi.FE_ENT_STATE_DTYPE)           # some searches start with a crossing already on the list
+    for a in range(0, N, 3):
+        j = int((a + 1 + rng.integers(0, N - 1)) % N)
+        if j != a:
+            inits[a]["n_alpha"] = 1; inits[a]["id"][0] = j + 1; inits[a]["cs"][0] = int(rng.integers(0, 3))
+    bb, fe, starts, d_com, d_g, got_g, got_r, d_case, got_case = _run_frontend(be, sc, W, inits)
+    n_cases = n_pruned = 0
+    for a in range(N):
+        hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(starts[a]["t_start"]), sc["statics"])
+        ent = helpers.ent_inputs(sc, a, t0=float(starts[a]["t_start"]), init=inits[a])
+        g, res, case = oracle.frontend_beam_ent(p, fe, a + 1, starts[a], hx, hn, sc["statics"], ent)
+        assert int(got_g[a]["K"]) == int(g["K"]), a
+        np.testing.assert_array_equal(np.array(got_g[a]["coeff"]), np.array(g["coeff"]), err_msg="agent %d" % a)
+        for f in ("status", "K", "n_children", "n_feasible", "n_collision_free", "n_entangled", "ent_overflow"):
+            assert int(got_r[a][f]) == res[f], (a, f, int(got_r[a][f]), res[f])
+        assert float(got_r[a]["cost"]) == res["cost"]
+        np.testing.assert_array_equal(got_case[a], case, err_msg="case block of agent %d" % a)
+        n_cases += int((case != 0).sum()); n_pruned += res["n_entangled"]
+    assert n_cases > 0
+    # the back end on device-made guesses and device-made cases: lines and optimum equal the oracle fed the same
+    bb.replan(None, d_g, d_ent=d_case)
+    sol = bb.solutions()
+    extra = 0
+    for a in range(N):
+        K = int(got_g[a]["K"])
+        if K < 1:
+            assert int(sol[a]["stats"]["status"]) == 2
+            continue
+        r = oracle.replan(p, a + 1, sc["committed"], got_g[a], sc["statics"], case_id=got_case[a])
+        r0 = oracle.replan(p, a + 1, sc["committed"], got_g[a], sc["statics"])
+        extra += r["n_lp"] - r0["n_lp"]
+        seg, nd = bb.debug_lines(a)
+        np.testing.assert_array_equal(nd, r["line_nd"])
+        assert int(sol[a]["stats"]["status"]) == r["status"]
+        assert np.abs(np.array(sol[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= 1e-6
+    assert extra >= 0     # (whether a case yields an LP depends on the bend points' distance cull, solver_gurobi_poly.cpp:738-745:
+    bb.close()            #  tests/test_gpu_parity.py::test_real_entangle_states_drive_the_entangle_rows covers scenes where they do)
+
+
+def test_config5_style_device_made_guesses_and_cases(be):
+    """BASELINE configs[4] ingredients at a size one test can afford (64 agents + 20 obstacles, entangle check on): guesses
+    and entangle cases both made on the device, then separator + QP on them; every returned plan is entangle-free by the
+    host library's own propagation."""
+    sc = scene.make_scene(64, 20, seed=7)
+    sc["par"] = dataclasses.replace(sc["par"], enable_entangle=True)
+    p = sc["par"]
+    bb, fe, starts, d_com, d_g, got_g, got_r, d_case, got_case = _run_frontend(be, sc, 16)
+    assert (got_r["ent_overflow"] == 0).all()
+    K = got_g["K"].astype(int)
+    assert (K >= 1).sum() >= 56
+    bb.replan(None, d_g, d_ent=d_case)
+    sol = bb.solutions()
+    st = sol["stats"]["status"].astype(int)
+    assert ((st != 2) | (K < 1)).mean() > 0.9
+    case_h, hit_h, _ = scene.real_entangle(dict(sc, guesses=got_g))       # host library (neptune_amd/entangle.py) on the device's guesses
+    for a in range(64):
+        if K[a] < 1:
+            continue
+        assert int(hit_h[a]) == 0, a
+        np.testing.assert_array_equal(got_case[a][: K[a]], case_h[a][: K[a]], err_msg="agent %d" % a)
+    bb.close()
+
+
+def test_safety_pass_entangle_recheck(be, oracle):
+    """nep_batch_safety_commit_ent: the flags equal the oracle's entangleCheckGivenPwp on every new trajectory (against
+    everybody's NEW trajectories), and a flagged agent keeps its previous record."""
+    sc = scene.tether_crossing_scene(8, 6, 60)
+    p = sc["par"]; N = 8
+    bb = be.BatchBackend(p, sc["statics"])
+    reps, longest = scene.static_reps(sc["statics"])
+    bb.set_static_reps(reps, longest)
+    T = bb.torch
+    d_prev = bb.to_device(sc["committed"]); d_guess = bb.to_device(sc["guesses"])
+    bb.replan(d_prev, d_guess)
+    fresh = bb.commits()
+    # entangle states at the start that make some re-checks fire: a crossing with a neighbour already on the list
+    inits = np.zeros(N, dtype=abi.FE_ENT_STATE_DTYPE)
+    for a in range(N):
+        j = (a + 3) % N
+        inits[a]["n_alpha"] = 1; inits[a]["id"][0] = j + 1; inits[a]["cs"][0] = 1
+    d_final = T.zeros_like(bb.d_commit); d_acc = T.zeros(N, dtype=T.int32, device=bb.device)
+    bb.safety_commit_ent(d_prev, bb.d_commit, d_guess, d_final, d_acc, d_ent_init=bb.to_device(inits))
+    T.cuda.synchronize()
+    acc = d_acc.cpu().numpy(); fin = d_final.cpu().numpy().view(abi.TRAJ_REC_DTYPE)
+    conflict = bb.debug_conflicts(0)
+    want = []
+    for a in range(N):
+        ent = helpers.ent_inputs(sc, a, recs=fresh, t0=float(sc["guesses"][a]["t_start"]), init=inits[a])
+        want.append(oracle.entangle_check_pwp(p, a + 1, p.tether_length, np.array(fresh[a]["pwp"]["coeff"])[0, 0], np.array(fresh[a]["pwp"]["coeff"])[1, 0], ent))
+    accept = []
+    for a in range(N):
+        bad = want[a] or any(accept[j] and (conflict[a, j] or conflict[j, a]) for j in range(a))
+        accept.append(0 if bad else 1)
+    np.testing.assert_array_equal(acc, accept)
+    for a in range(N):
+        assert fin[a].tobytes() == (fresh[a] if accept[a] else sc["committed"][a]).tobytes()
+    bb.close()
