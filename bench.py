@@ -109,8 +109,8 @@ def cpu_baseline(p, scenes, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--agents", type=int, default=64)
     ap.add_argument("--obstacles", type=int, default=20)
     ap.add_argument("--scenes", type=int, default=32, help="seeded scenes in flight PER GPU")
@@ -321,6 +321,14 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    rccl_one_rank_ok = None
+    if world == 1 and use_dist and dist_backend == "nccl" and not (args.safety or args.frontend) and C == 1:
+        # one rank: the timed steps copy (nothing to exchange); the collective path itself — the all-gather of the committed
+        # records through RCCL — is exercised once here, outside the timed region, and must give the same bytes
+        chk = torch.empty_like(d_committed)
+        ex.gather(be.d_commit, chk, collective=True)
+        torch.cuda.synchronize(dev)
+        rccl_one_rank_ok = bool(torch.equal(chk, be.d_commit.view_as(chk)))
     barrier()
     for b in bes:
         b.enable_timing(True)
@@ -535,7 +543,8 @@ def main():
                                  "iterations per replan" % round(float(iters.mean()))},
             "presolve": presolve,
             "chain": chain,
-            "rccl": ({"process_group": "nccl (RCCL), world %d" % world, "initialised": True} if (use_dist and dist_backend == "nccl")
+            "rccl": ({"process_group": "nccl (RCCL), world %d" % world, "initialised": True, "one_rank_all_gather_matches": rccl_one_rank_ok}
+                     if (use_dist and dist_backend == "nccl")
                      else {"initialised": False, "note": rccl_note or dist_backend}),
             "roofline_fp64": fp64,
             "reference_budget": "reference TimeLimit 0.05 s/solve, replan timer 20 Hz/agent => <= %d replans/s for %d agents" % (20 * N, N),

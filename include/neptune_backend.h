@@ -131,8 +131,11 @@ void nep_backend_destroy(nep_backend_t* h);
 int nep_backend_set_max_values(nep_backend_t* h, double x_min, double x_max, double y_min,
                                double y_max, double z_min, double z_max, double v_max,
                                double a_max, double j_max);
-/* setMaxRuntime (:182-185).  Stored and reported; the batched interior point is iteration-
- * bounded, not wall-clock bounded.                                             */
+/* setMaxRuntime (:182-185) -> Gurobi's TimeLimit (:812): the wall-clock budget of ONE solve (the first and the relaxed
+ * re-solve each get it).  A solve that has not converged when the budget is spent (device wall clock, checked once per
+ * interior-point iteration) counts as "no solution" — the reference accepts a time-limited solve only with an incumbent
+ * (:832-836), which a barrier QP does not have before it converges.  The interior point is also bounded at 60
+ * iterations (tens of microseconds), so the reference's 0.05 s never binds in practice.                        */
 int nep_backend_set_max_runtime(nep_backend_t* h, double seconds);
 /* setTetherLength (:177-180), stored only, as in the reference. */
 int nep_backend_set_tether_length(nep_backend_t* h, double tether_length);
@@ -340,6 +343,9 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
  * multipliers satisfies the KKT conditions of the full problem and is returned as the optimum without a single
  * interior-point iteration (nep_stats.iters == 0); otherwise the interior point runs as usual.                */
 int nep_batch_set_line_cull(nep_batch_t* h, double radius);
+
+/* setMaxRuntime for the batched handle (0 = no wall-clock limit, the default): see nep_backend_set_max_runtime. */
+int nep_batch_set_max_runtime(nep_batch_t* h, double seconds);
 
 /* on != 0: nep_batch_safety_commit additionally turns down a new trajectory that collides with the
  * PREVIOUS record of any other agent (its hulls on the round's grid).  The spline QP keeps the two

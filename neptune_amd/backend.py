@@ -299,6 +299,10 @@ class BatchBackend:
         st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
         check(lib().nep_batch_check(self._h, st.cuda_stream))
 
+    def set_max_runtime(self, seconds):
+        """wall-clock budget of one solve (Gurobi TimeLimit; 0 = off): nep_batch_set_max_runtime"""
+        check(lib().nep_batch_set_max_runtime(self._h, float(seconds)))
+
     def set_line_cull(self, radius):
         """presolve: separating lines farther than `radius` metres from the guess are left out of the QP and verified
         afterwards, and a replan whose unconstrained minimiser is feasible returns it without iterating

@@ -348,7 +348,12 @@ int nep_backend_set_max_values(nep_backend_t* h, double x_min, double x_max, dou
   h->have_bounds = true;
   return 0;
 }
-int nep_backend_set_max_runtime(nep_backend_t* h, double s) { if (!h) return fail(NEP_E_ARG, "null handle"); h->max_runtime = s; return 0; }
+int nep_backend_set_max_runtime(nep_backend_t* h, double s) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  h->max_runtime = s;
+  h->eng.sp.time_limit_ticks = s > 0 ? (long long)(s * 1e8) : 0;      // wall_clock64() counts at 100 MHz on gfx950
+  return 0;
+}
 int nep_backend_set_tether_length(nep_backend_t* h, double t) { if (!h) return fail(NEP_E_ARG, "null handle"); h->tether = t; return 0; }
 
 int nep_backend_set_static_obst_vert(nep_backend_t* h, int32_t n, const int32_t* off, const double* xy) {
@@ -865,6 +870,12 @@ int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static,
   if (!h || scene < 0 || scene >= h->cfg.n_scenes || n_static < 0 || (n_static > 0 && (!static_off || !static_xy))) return fail(NEP_E_ARG, "bad arguments");
   HIPCHK(hipDeviceSynchronize());     // the previous set may still be read by kernels in flight
   return h->eng.upload_scene_statics(scene, n_static, static_off, static_xy);
+}
+
+int nep_batch_set_max_runtime(nep_batch_t* h, double seconds) {
+  if (!h || !(seconds >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
+  h->eng.sp.time_limit_ticks = seconds > 0 ? (long long)(seconds * 1e8) : 0;
+  return 0;
 }
 
 int nep_batch_set_line_cull(nep_batch_t* h, double radius) {

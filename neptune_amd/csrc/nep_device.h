@@ -30,6 +30,7 @@ struct SceneParams {
   double mins[3], maxs[3], v_max, a_max;
   double long_length; // solver_gurobi_poly.cpp:173
   double cull_radius; // > 0: separating lines farther than this from the guess are presolved away (verified after the solve)
+  long long time_limit_ticks;   // > 0: wall-clock budget of ONE solve in 100 MHz ticks (setMaxRuntime -> Gurobi TimeLimit, solver_gurobi_poly.cpp:812)
 };
 
 // Buffers of one problem set (n_scenes x n_local slots).  All device pointers.

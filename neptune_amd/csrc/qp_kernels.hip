@@ -222,6 +222,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     }
     bool converged = false;
     int it = 0;
+    const long long t_solve0 = (long long)wall_clock64();   // m_.optimize() starts here: every solve (first and relaxed) has its own TimeLimit
     SETUP_TICK(1);
     if (nz == 0) {
       // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
@@ -485,6 +486,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
           if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
           if (sI[17] >= 3) flag = 3;                           // stalled
+          if (sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks) flag = 3;   // TimeLimit without an accepted iterate: "no solution" (:832-836)
           // Loosely converged iterates: keep the one closest to the strict tolerances (merit <= 1 is the strict test), and
           // stop three iterations after the first of them.  With mu that small the weights lambda/s amplify the rounding
           // of the row activities into the dual residual (floor ~1e-8 |g|): an iteration that has not passed the strict

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       }
       bool converged = false;
       int it = 0;
+      const long long t_solve0 = (long long)wall_clock64();   // m_.optimize() starts here: every solve (first and relaxed) has its own TimeLimit
       if (nz == 0) {
         // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
         double viol = 0.0, d0 = 0, d1 = 0, d2 = 0;
@@ -489,6 +490,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
             if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
             if (sI[17] >= 3) flag = 3;                           // stalled
+            if (sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks) flag = 3;   // TimeLimit without an accepted iterate: "no solution" (:832-836)
             if (flag == 2 || (flag == 0 && sI[22] >= 0)) {       // loosely converged iterates: see qp_kernel
               const double merit = fmax(fmax(nr * 1e9, nrd / qs * 1e9), gap / (1.0 + fabs(o)) * 1e10);
               const bool better = flag == 2 && (!sI[16] || merit < sc[sBestMerit]);

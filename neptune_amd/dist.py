@@ -36,12 +36,13 @@ class RoundExchange:
         self.piece = n_scenes * self.n_local * REC_BYTES
         self.gathered = torch.empty(world * self.piece, dtype=torch.uint8, device=device) if world > 1 else None
 
-    def gather(self, commit_local, committed_out):
-        """commit_local: uint8 [S][n_local][REC]; committed_out: uint8 [S][N][REC] (overwritten)."""
+    def gather(self, commit_local, committed_out, collective=None):
+        """commit_local: uint8 [S][n_local][REC]; committed_out: uint8 [S][N][REC] (overwritten).  With one rank there is
+        nothing to exchange: a device copy, unless collective=True asks for the (degenerate) all-gather all the same."""
         torch = self.torch
         S, N, nl, W = self.S, self.N, self.n_local, self.world
         import torch.distributed as dist
-        if W == 1 and not (dist.is_available() and dist.is_initialized()):
+        if W == 1 and not (collective and dist.is_available() and dist.is_initialized()):
             committed_out.copy_(commit_local)
             return committed_out
         if self.gathered is None:   # single rank launched under torch.distributed.run: same collective path

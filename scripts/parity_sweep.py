@@ -26,8 +26,7 @@ def oracle_one(job):
     from oracle import oracle
     sc = scene.make_scene(N, M, seed=SEED0 + seed)
     tighten(sc["par"])
-    statics = scene.make_scene(N, M, seed=SEED0)["statics"]
-    r = oracle.replan(sc["par"], a + 1, sc["committed"], g, statics)
+    r = oracle.replan(sc["par"], a + 1, sc["committed"], g, sc["statics"])          # every scene has its own statics, on both sides
     return seed, a, r["status"], r["iters"], r["objective"], np.array(r["coeff"])
 
 
@@ -39,6 +38,8 @@ def main():
     p = tighten(scs[0]["par"])
     com, gue = ndist.stack_scenes(scs)
     be = BatchBackend(p, scs[0]["statics"], n_scenes=S)
+    for s_ in range(1, S):
+        be.set_scene_statics(s_, scs[s_]["statics"])
     d_com = be.to_device(com); d_gue = be.to_device(gue)
     if use_fe:
         d_start = be.to_device(np.stack([scene.frontend_starts(s) for s in scs]))

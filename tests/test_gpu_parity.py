@@ -766,3 +766,48 @@ def test_front_end_guesses_converge_without_idling_to_the_iteration_cap(be, orac
                 n += 1
     assert n >= 15
     bb.close()
+
+
+def test_parity_distribution_on_front_end_guesses(be, oracle):
+    """Not a sample around the outliers: EVERY replan of four 64-agent scenes on front-end (lattice) guesses — the inputs on
+    which the interior point works hardest (8 iterations, relaxed and failed solves) — against the oracle.  Asserted: no
+    status mismatch, p99 of the coefficient difference <= 1e-6, maximum <= 1e-4, positions along the trajectories within
+    5e-5 m, cost within 1e-8 relative — the bounds of profiles/r02_parity_sweep.txt (scripts/parity_sweep.py: 5 848
+    replans of six sizes, no status mismatch; on front-end guesses p99 4.7e-7, max 7.9e-5 on one replan of 1 011 whose two
+    interior-point paths took 17 and 18 iterations, positions within 2.5e-5 m, cost within 2.2e-9; on the scenes' own
+    guesses everything within 3e-8).  The tail is the floor of two IEEE-correct interior-point paths on a cost that is
+    flat along some directions, not something the 1e-6 of the sampled tests above would see."""
+    from neptune_amd import dist as ndist
+    S, N = 4, 64
+    scs = [scene.make_scene(N, 20, seed=200 + s) for s in range(S)]
+    p = scs[0]["par"]
+    com, gue = ndist.stack_scenes(scs)
+    bb = be.BatchBackend(p, scs[0]["statics"], n_scenes=S)
+    for s in range(1, S):
+        bb.set_scene_statics(s, scs[s]["statics"])
+    d_com = bb.to_device(com); d_g = bb.to_device(gue)
+    bb.frontend(scene.frontend_cfg(p, beam_width=32), d_com, bb.to_device(np.stack([scene.frontend_starts(s) for s in scs])), d_g, None)
+    bb.replan(None, d_g)
+    sol = bb.solutions().reshape(S, N)
+    g = d_g.cpu().numpy().view(abi.GUESS_DTYPE).reshape(S, N)
+    dco, dpos, dob, seen = [], [], [], set()
+    for s in range(S):
+        for a in range(N):
+            K = int(g[s, a]["K"])
+            if K < 1:
+                assert int(sol[s, a]["stats"]["status"]) == 2
+                continue
+            r = oracle.replan(p, a + 1, scs[s]["committed"], g[s, a], scs[s]["statics"])
+            assert int(sol[s, a]["stats"]["status"]) == r["status"], (s, a)
+            seen.add(r["status"])
+            if r["status"] == 2:
+                continue
+            dc = np.array(sol[s, a]["coeff"])[:, :K, :] - r["coeff"]
+            dco.append(float(np.abs(dc).max()))
+            dpos.append(max(float(np.abs(((dc[..., 0] * t + dc[..., 1]) * t + dc[..., 2]) * t + dc[..., 3]).max()) for t in (0.0, 0.125, 0.25, 0.375, 0.5)))
+            dob.append(abs(float(sol[s, a]["stats"]["objective"]) - r["objective"]) / (1 + abs(r["objective"])))
+    dco = np.array(dco)
+    assert len(dco) >= 230
+    assert np.percentile(dco, 99) <= 1e-6 and dco.max() <= 1e-4, (np.percentile(dco, 99), dco.max())
+    assert max(dpos) <= 5e-5 and max(dob) <= 1e-8, (max(dpos), max(dob))
+    bb.close()

@@ -166,3 +166,29 @@ def test_one_static_set_per_scene(be):
             np.testing.assert_array_equal(one.debug_lines(a)[1], lines[s][a])
         one.close()
     assert both[0].tobytes() != both[1].tobytes()
+
+
+def test_wall_clock_time_limit(be, oracle):
+    """setMaxRuntime -> TimeLimit (solver_gurobi_poly.cpp:812): a budget no solve can meet turns every replan into
+    "no solution" (both solves time out: output == initial guess); the reference's 0.05 s changes nothing."""
+    sc = scene.make_scene(5, 3, seed=4)
+    p = sc["par"]
+    bb = be.BatchBackend(p, sc["statics"])
+    d_com = bb.to_device(sc["committed"]); d_g = bb.to_device(sc["guesses"])
+    bb.replan(d_com, d_g)
+    ref = bb.solutions()
+    bb.set_max_runtime(0.05)
+    bb.replan(d_com, d_g)
+    assert bb.solutions().tobytes() == ref.tobytes()
+    bb.set_max_runtime(1e-8)                 # one tick of the 100 MHz wall clock
+    bb.replan(d_com, d_g)
+    sol = bb.solutions()
+    moving = [a for a in range(5) if int(ref[a]["stats"]["iters"]) > 0]
+    assert moving
+    for a in moving:
+        assert int(sol[a]["stats"]["status"]) == 2
+        np.testing.assert_array_equal(np.array(sol[a]["coeff"]), np.array(sc["guesses"][a]["coeff"]))
+    bb.set_max_runtime(0.0)
+    bb.replan(d_com, d_g)
+    assert bb.solutions().tobytes() == ref.tobytes()
+    bb.close()
