@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--exchange-native", action="store_true",
                     help="N > 1 with --exchange hulls: the all-gather through the C ABI's own RCCL binding (nep_batch_exchange_hulls) "
                          "instead of torch.distributed")
+    ap.add_argument("--no-graph", action="store_true", help="single GPU: launch every step from the host instead of replaying one captured HIP graph")
     ap.add_argument("--no-process-group", action="store_true", help="single GPU: do not create the one-rank RCCL process group")
     ap.add_argument("--no-chain", action="store_true", help="skip the separately reported front end + safety leg")
     ap.add_argument("--frontend", action="store_true",
@@ -261,7 +262,11 @@ def main():
     d_fe_res = d_fe_res_c[0] if args.frontend else None
     pending = [None] * C
 
+    ev_on = [True]
+
     def ev():
+        if not ev_on[0]:                 # (while a step is being captured into a graph: timing events cannot live inside one)
+            return None
         e = torch.cuda.Event(enable_timing=True); e.record(); return e
 
     class _timed:
@@ -330,14 +335,49 @@ def main():
         torch.cuda.synchronize(dev)
         rccl_one_rank_ok = bool(torch.equal(chk, be.d_commit.view_as(chk)))
     barrier()
+    # One step = a fixed sequence of launches on fixed buffers: on a single GPU it is captured once into a HIP graph and the
+    # timed region replays it (no per-launch host work, no host jitter between the kernels of a step).  The per-kernel HIP
+    # events cannot live inside a graph: they are taken in a short eager section after the timed region.
+    graph, graph_note = None, None
+    can_graph = not args.no_graph and world == 1 and rounds is None
+
+    def capture(fn):
+        """fn() enqueues one step on the current stream -> a captured graph of it, or None (then the host launches)"""
+        nonlocal graph_note
+        if not can_graph:
+            return None
+        try:
+            for b in bes:
+                b.enable_timing(False)
+            torch.cuda.synchronize(dev)
+            g_ = torch.cuda.CUDAGraph()
+            ev_on[0] = False
+            with torch.cuda.graph(g_):
+                fn()
+            ev_on[0] = True
+            g_.replay(); g_.replay()
+            torch.cuda.synchronize(dev)
+            return g_
+        except Exception as e:                       # (falls back to launching from the host)
+            ev_on[0] = True
+            graph_note = "graph capture failed: %r" % (e,)
+            torch.cuda.synchronize(dev)
+            return None
+    if not args.frontend and not args.safety:
+        graph = capture(step)
+    eager_timing = graph is None
     for b in bes:
-        b.enable_timing(True)
+        b.enable_timing(eager_timing)
         b.reset_timing()
     safety_ev.clear(); hull_ev.clear(); gather_ev.clear()
+    barrier()
     step_ev = [ev()]
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        if graph is not None:
+            graph.replay()
+        else:
+            step()
         step_ev.append(ev())
     barrier()
     dt = time.perf_counter() - t0
@@ -346,8 +386,16 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
     step_ms = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)])   # GPU time of each step (this rank)
+    if graph is not None:                            # per-kernel durations: the same steps launched from the host, HIP events on the launch stream
+        for b in bes:
+            b.enable_timing(True)
+            b.reset_timing()
+        for _ in range(min(args.steps, 40)):
+            step()
+        barrier()
 
     def mean_ms(pairs):
+        pairs = [(a, b) for a, b in pairs if a is not None and b is not None]     # (pairs "recorded" while a graph was being captured are placeholders)
         return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else 0.0
     qp_ms, n_launch = be.kernel_time_ms(2)           # per launch of one chunk (chunk 0)
     hull_ms, _ = be.kernel_time_ms(0)
@@ -374,14 +422,26 @@ def main():
         for _ in range(max(args.warmup, 2)):
             step()
         barrier()
+        g2 = capture(step)
         for b in bes:
-            b.enable_timing(True)
+            b.enable_timing(g2 is None)
             b.reset_timing()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step()
+            if g2 is not None:
+                g2.replay()
+            else:
+                step()
         barrier()
         dt2 = time.perf_counter() - t0
+        if g2 is not None:
+            for b in bes:
+                b.enable_timing(True)
+                b.reset_timing()
+            for _ in range(min(args.steps, 40)):
+                step()
+            barrier()
         if use_dist:
             t = torch.tensor([dt2], dtype=torch.float64, device=dev)
             tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
@@ -427,13 +487,24 @@ def main():
         for _ in range(max(args.warmup, 2)):
             chain_step()
         barrier()
-        be.enable_timing(True); be.reset_timing()
+        g3 = capture(chain_step)
+        be.enable_timing(g3 is None); be.reset_timing()
         fe2.clear(); sf2.clear()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            chain_step()
+            if g3 is not None:
+                g3.replay()
+            else:
+                chain_step()
         barrier()
         dt3 = time.perf_counter() - t0
+        if g3 is not None:
+            be.enable_timing(True); be.reset_timing()
+            fe2.clear(); sf2.clear()
+            for _ in range(min(args.steps, 40)):
+                chain_step()
+            barrier()
         qp3, _ = be.kernel_time_ms(2); sep3, _ = be.kernel_time_ms(1)
         be.enable_timing(False)
         sol3 = be.solutions(); st3 = sol3["stats"]["status"].astype(int)
@@ -522,6 +593,8 @@ def main():
             "step_ms": {"p50": float(np.percentile(step_ms, 50)), "p99": float(np.percentile(step_ms, 99)), "max": float(step_ms.max())},
             "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange_wait": mean_ms(gather_ev),
                           "launches": n_launch, "launches_per_step": C},
+            "launch": ("one captured HIP graph per step, replayed (per-kernel events from %d eager steps after the timed region)" % min(args.steps, 40)
+                       if graph is not None else (graph_note or "host launches")),
             "frontend": ({"ms": mean_ms(fe_ev), "beam_width": args.beam,
                           "status_goal_reached": int((d_fe_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)["status"] == 1).sum()),
                           "status_no_solution": int((d_fe_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)["status"] == 3).sum()),

@@ -20,6 +20,12 @@
 #define NEP_QP_REG_SLOTS 9
 #endif
 
+// 1: the normal matrix's weighted Gram blocks  M_sel = sum_rho D_sel[rho] B[rho]' B[rho]  (64 base rows, four weight sets) are
+// formed on the matrix cores as two 16x16 tiles of v_mfma_f64_16x16x4_f64 (K = 64: 16 instructions per tile, one tile per
+// wave) — the one genuine contraction of the path; 0: the VALU version (two entries per thread, 32 base rows per lane pair).
+#ifndef NEP_QP_MFMA
+#define NEP_QP_MFMA 1
+#endif
 // workgroups per CU the register allocation is bounded for (4: 128 VGPRs, 3: 168)
 #ifndef NEP_QP_REG_WGS
 #define NEP_QP_REG_WGS 4
@@ -157,8 +163,19 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     // One pass over this thread's line rows.  body(ok, n1, n2, h, s, lambda); padded slots see the dummy line (0, 0, 1) with
     // s = lambda = 1: their activity and step are exactly zero (see qp_kernel), `ok` masks what would still matter.
     auto for_rows = [&](auto&& body) {
+      // two slots per scalar branch: both rows' coefficient loads are issued before either row's arithmetic (a block per slot
+      // would leave every row waiting for its own three ds_reads)
 #pragma unroll
-      for (int u = 0; u < RS; u++) {
+      for (int u = 0; u + 1 < RS; u += 2) {
+        if (u < n_u) {
+          const double n1a = cbase[8 * u], n2a = cbase[NS + 8 * u], ha = cbase[2 * NS + 8 * u];
+          const double n1b = cbase[8 * u + 8], n2b = cbase[NS + 8 * u + 8], hb = cbase[2 * NS + 8 * u + 8];
+          body(u < my_cnt, n1a, n2a, ha, sl[u], ll[u]);
+          body(u + 1 < my_cnt, n1b, n2b, hb, sl[u + 1], ll[u + 1]);
+        }
+      }
+      if constexpr (RS & 1) {
+        constexpr int u = RS - 1;
         if (u < n_u) {
           const double n1 = cbase[8 * u], n2 = cbase[NS + 8 * u], h = cbase[2 * NS + 8 * u];
           body(u < my_cnt, n1, n2, h, sl[u], ll[u]);
@@ -196,6 +213,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       if (tid < 24) { const int ax = tid >> 3, r = tid & 7; sRhs[tid] = tPpP[r * 3] * sInit[ax * 3] + tPpP[r * 3 + 1] * sInit[ax * 3 + 1] + tPpP[r * 3 + 2] * sInit[ax * 3 + 2]; }
       else if (tid >= 32 && tid < 35) { const int ax = tid - 32; sc[sPe0 + ax] = tUpP[0] * sInit[ax * 3] + tUpP[1] * sInit[ax * 3 + 1] + tUpP[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; }
       __syncthreads();
+#if !NEP_QP_MFMA
       // normal-matrix entries owned by this thread (xx, yx, yy, zz blocks; a pair of lanes per entry), packed: ci | cj<<4 | sel<<8 | on<<12
       int me[2];
       {
@@ -215,6 +233,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           me[u] = ci | (cj << 4) | (sel << 8) | ((on ? 1 : 0) << 12);
         }
       }
+#endif
       bool converged = false;
       int it = 0;
       const long long t_solve0 = (long long)wall_clock64();   // m_.optimize() starts here: every solve (first and relaxed) has its own TimeLimit
@@ -447,6 +466,37 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               }
             }
           }
+#if NEP_QP_MFMA
+          if (tid >= 128) {   // waves 2 and 3: one 16 x 16 output tile each — rows ci, columns (block, cj): tile 0 = xx | yx, tile 1 = yy | zz
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            const int t = otid();
+            const int l = t & 63, i16 = l & 15, kk = l >> 4, cj = l & 7;
+            const int sel = (t >= 192 ? 2 : 0) + (i16 >> 3);           // weight set of this lane's column: 0 xx, 1 yx, 2 yy, 3 zz
+            // A operand: B'[ci][rho] (rows ci >= 8 of the tile are padding); B operand: D_sel[rho] B[rho][cj].  Base rows >= 8 K have zero B and zero weights.
+            const double* pa = sB + kk * SBS + (i16 & 7); const double* pd = sDc + kk * 4 + sel; const double* pb = sB + kk * SBS + cj;
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 2 * NEP_MAX_POL; q += 2) {
+              const double a0 = i16 < 8 ? pa[(4 * q) * SBS] : 0.0, b0 = pd[(4 * q) * 4] * pb[(4 * q) * SBS];
+              const double a1 = i16 < 8 ? pa[(4 * q + 4) * SBS] : 0.0, b1 = pd[(4 * q + 4) * 4] * pb[(4 * q + 4) * SBS];
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
+            }
+            // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 reg
+            const int bi_ = sel == 0 ? 0 : (sel == 3 ? 2 : 1), bj_ = sel == 0 || sel == 1 ? 0 : (sel == 2 ? 1 : 2);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+              const int ci = kk + 4 * r;
+              if (ci < nz && cj < nz) {
+                double v = acc0[r] + acc1[r];
+                const int mi = bi_ * nz + ci, mj = bj_ * nz + cj;
+                if (sel != 1) v += sHax[ci * kNZ + cj];
+                if (has_qc) { v += sc[sWq] * sGq[mi] * sGq[mj]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
+                sM[mi * MS + mj] = v;
+              }
+            }
+          }
+#else
 #pragma unroll 1
           for (int u = 0; u < 2; u++) {
             const int t = otid();
@@ -474,6 +524,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               sM[mi * MS + mj] = v;
             }
           }
+#endif
           for (int e = otid(); e < 2 * nz * nz; e += BS) {   // z-x and z-y blocks
             const int i = 2 * nz + e / (2 * nz), j = e % (2 * nz);
             sM[i * MS + j] = has_qc ? sc[sWq] * sGq[i] * sGq[j] : 0.0;
