@@ -602,10 +602,10 @@ def main():
                          if args.frontend else None),
             "safety": ({"ms": mean_ms(safety_ev), "accepted_frac": float(d_accept.float().mean().item())}
                        if args.safety else None),
-            "roofline": {"bound": "hbm", "kernel": "qp_kernel", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": be.qp_kernel_name(), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
                          # the committed PMC summary is of the default single-GPU command (2 048 replans per launch)
-                         "traffic": measured_traffic() if launch_replans == 2048 else None,
+                         "traffic": measured_traffic("nep::" + be.qp_kernel_name()) if launch_replans == 2048 else None,
                          "algorithmic_bytes_per_replan": bytes_per_replan, "replans_per_launch": launch_replans,
                          "sequence": {"achieved": seq_gbs, "frac": seq_gbs / 8000.0, "ms": seq_ms,
                                       "note": "the whole replan's bytes over the whole launch sequence (hull + separator + qp)"},

@@ -344,6 +344,11 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
  * interior-point iteration (nep_stats.iters == 0); otherwise the interior point runs as usual.                */
 int nep_batch_set_line_cull(nep_batch_t* h, double radius);
 
+/* Which placement of the interior point the handle runs: 1 = qp_reg_kernel (line-row state in registers, four workgroups
+ * per CU: chosen when the expected lines per segment fit its register slots, e.g. BASELINE configs 1-4), 0 = qp_kernel
+ * (row state in LDS with a global spill: config-5 sized problems).  Same solver, same results to rounding.             */
+int nep_batch_qp_placement(nep_batch_t* h);
+
 /* setMaxRuntime for the batched handle (0 = no wall-clock limit, the default): see nep_backend_set_max_runtime. */
 int nep_batch_set_max_runtime(nep_batch_t* h, double seconds);
 

@@ -299,6 +299,10 @@ class BatchBackend:
         st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
         check(lib().nep_batch_check(self._h, st.cuda_stream))
 
+    def qp_kernel_name(self):
+        """the interior-point kernel this handle launches (nep_batch_qp_placement)"""
+        return "qp_reg_kernel" if lib().nep_batch_qp_placement(self._h) == 1 else "qp_kernel"
+
     def set_max_runtime(self, seconds):
         """wall-clock budget of one solve (Gurobi TimeLimit; 0 = off): nep_batch_set_max_runtime"""
         check(lib().nep_batch_set_max_runtime(self._h, float(seconds)))

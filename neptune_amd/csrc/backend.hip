@@ -872,6 +872,8 @@ int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static,
   return h->eng.upload_scene_statics(scene, n_static, static_off, static_xy);
 }
 
+int nep_batch_qp_placement(nep_batch_t* h) { return h ? (h->eng.use_reg ? 1 : 0) : NEP_E_ARG; }
+
 int nep_batch_set_max_runtime(nep_batch_t* h, double seconds) {
   if (!h || !(seconds >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
   h->eng.sp.time_limit_ticks = seconds > 0 ? (long long)(seconds * 1e8) : 0;

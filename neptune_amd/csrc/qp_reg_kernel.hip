@@ -72,15 +72,20 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   const int GL = ps.rows_cap / 4 + 2;
   double* __restrict__ gsp = ps.row_scratch + (long)slot * (11L * GL);
 
-  // ---- thread roles ----
+  // ---- thread roles: derived where they are used (an opaque copy of the thread index keeps the compiler from parking role
+  // indices, bounds and addresses in registers — or scratch — for the whole solve; see the iteration loop) ----
   const int R = 8 * K;
-  const bool has_box = tid < 3 * R;
-  const int bax = has_box ? tid / R : 0, brho = has_box ? tid % R : 0;
-  const double bhi = brho < 4 * K ? sp.maxs[bax] : (brho < 7 * K ? sp.v_max : sp.a_max);
-  const double blo = brho < 4 * K ? sp.mins[bax] : (brho < 7 * K ? -sp.v_max : -sp.a_max);
-  const int pair = tid >> 3, li = pair >> 2, lk = pair & 3, slice = tid & 7;
-  const bool has_line = li < K;
-  const int lrho = 4 * li + lk;
+  auto otid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
+  int brole;                                    // box rows of (base row rho, axis): ax | rho << 2 | owner << 8
+  { const bool hb = tid < 3 * R; const int ax = hb ? tid / R : 0, rho = hb ? tid % R : 0; brole = ax | (rho << 2) | ((hb ? 1 : 0) << 8); }
+  auto box_role = [&](int& ax, int& rho, double& hi, double& lo) {
+    int r = brole; asm volatile("" : "+v"(r));
+    ax = r & 3; rho = (r >> 2) & 63;
+    hi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
+    lo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
+    return (r >> 8) != 0;
+  };
+  // line rows of control point (seg, k) = (t >> 5, (t >> 3) & 3), slice t & 7; base row of that control point: t >> 3
 
   // row state: box rows [0] upper (alpha = +e), [1] lower; line rows: slot u = line lbeg + slice + 8 u
   double bs0 = 1, bl0 = 0, bs1 = 1, bl1 = 0;
@@ -147,6 +152,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     z_override = sqrt(dix * dix + diy * diy) < 1.0;           // :879-880
     const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);
 
+    const int li = tid >> 5, lk = (tid >> 3) & 3, slice = tid & 7;
     const int seg_cnt = sI[li + 1] - sI[li];                  // lines of my segment (0 for segments >= K)
     // slots in use by this wave (it covers segments 2w and 2w + 1): wave-uniform, so the slot loop branches on the scalar unit
     int n_u;
@@ -240,8 +246,8 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       if (nz == 0) {
         // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
         double viol = 0.0, d0 = 0, d1 = 0, d2 = 0;
-        if (has_box) { const double a = sOff[brho * 3 + bax]; viol = fmax(a - bhi, blo - a); }
-        { const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; for_rows([&](bool v, double n1, double n2, double h, double&, double&) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
+        { int ax, rho; double hi, lo; if (box_role(ax, rho, hi, lo)) { const double a = sOff[rho * 3 + ax]; viol = fmax(a - hi, lo - a); } }
+        { const int lrho = otid() >> 3; const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; for_rows([&](bool v, double n1, double n2, double h, double&, double&) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
         if (tid < 6) {
           const int ax = tid / 2, e = tid % 2;
           viol = fmax(viol, fabs(tResP[e * 3] * sInit[ax * 3] + tResP[e * 3 + 1] * sInit[ax * 3 + 1] + tResP[e * 3 + 2] * sInit[ax * 3 + 2]));
@@ -305,8 +311,9 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           }
           __syncthreads();
           double viol = -1.0, o_share = 0, d1 = 0, d2 = 0;
-          if (has_box) { const double a = sOff[brho * 3 + bax] + proj(brho, bax, sDx); viol = fmax(a - bhi, blo - a); }
+          { int ax, rho; double hi, lo; if (box_role(ax, rho, hi, lo)) { const double a = sOff[rho * 3 + ax] + proj(rho, ax, sDx); viol = fmax(a - hi, lo - a); } }
           {
+            const int lrho = otid() >> 3; const bool has_line = (lrho >> 2) < K;
             const double cx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sDx) : 0.0, cy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sDx) : 0.0;
             for_rows([&](bool ok, double n1, double n2, double h, double&, double&) { viol = fmax(viol, ok ? (n1 * cx + n2 * cy) - h : -1.0); });
           }
@@ -325,25 +332,20 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           uncon = viol <= 0.0;
           if (uncon) { if (tid < n) sZ[tid] = sDx[tid]; if (tid == 0) sc[sObj] = sc[sObj0] + o_share; }
         }
-        // Roles are re-derived from an opaque copy of the thread index in every phase of the iteration: whatever the compiler
-        // could hoist out of the loop (row / entry indices, LDS addresses of four different roles) would otherwise sit in
-        // registers next to the row state for the whole solve.
-        auto otid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
-        const int brole = bax | (brho << 2) | ((has_box ? 1 : 0) << 8);
-        auto box_role = [&](int& ax, int& rho, double& hi, double& lo) {
-          int r = brole; asm volatile("" : "+v"(r));
-          ax = r & 3; rho = (r >> 2) & 63;
-          hi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
-          lo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
-          return (r >> 8) != 0;
-        };
-        double cpb = has_box ? sOff[brho * 3 + bax] + proj(brho, bax, sZ) : 0.0, uab = 0.0, udb = 0.0;
-        double cpx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sZ) : 0.0, cpy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sZ) : 0.0;
+        // (roles are re-derived from an opaque copy of the thread index in every phase: whatever the compiler could hoist out of
+        // the iteration loop — row / entry indices, LDS addresses of four different roles — would otherwise sit in registers
+        // next to the row state for the whole solve)
+        double cpb = 0.0, uab = 0.0, udb = 0.0, cpx = 0.0, cpy = 0.0;
         double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
-        if (has_box) {
-          const double a = cpb;
-          double slk = bhi - a; bs0 = slk > kSlackFloor ? slk : kSlackFloor; bl0 = kMu0 * frcp(bs0);
-          slk = a - blo; bs1 = slk > kSlackFloor ? slk : kSlackFloor; bl1 = kMu0 * frcp(bs1);
+        {
+          int ax, rho; double hi, lo;
+          if (box_role(ax, rho, hi, lo)) {
+            cpb = sOff[rho * 3 + ax] + proj(rho, ax, sZ);
+            double slk = hi - cpb; bs0 = slk > kSlackFloor ? slk : kSlackFloor; bl0 = kMu0 * frcp(bs0);
+            slk = cpb - lo; bs1 = slk > kSlackFloor ? slk : kSlackFloor; bl1 = kMu0 * frcp(bs1);
+          }
+          const int lrho = otid() >> 3;
+          if ((lrho >> 2) < K) { cpx = sOff[lrho * 3] + proj(lrho, 0, sZ); cpy = sOff[lrho * 3 + 1] + proj(lrho, 1, sZ); }
         }
 #pragma unroll
         for (int u = 0; u < RS; u++) { sl[u] = 1.0; ll[u] = 1.0; }
