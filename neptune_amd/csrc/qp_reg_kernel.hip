@@ -76,20 +76,18 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   // indices, bounds and addresses in registers — or scratch — for the whole solve; see the iteration loop) ----
   const int R = 8 * K;
   auto otid = [&]() { int t = tid; asm volatile("" : "+v"(t)); return t; };
-  int brole;                                    // box rows of (base row rho, axis): ax | rho << 2 | owner << 8
-  { const bool hb = tid < 3 * R; const int ax = hb ? tid / R : 0, rho = hb ? tid % R : 0; brole = ax | (rho << 2) | ((hb ? 1 : 0) << 8); }
+  // box rows of (axis, base row) = (t / R, t % R) for t < 3 R, R = 8 K: two comparisons instead of a division, so the role costs
+  // nothing to re-derive and nothing to keep
   auto box_role = [&](int& ax, int& rho, double& hi, double& lo) {
-    int r = brole; asm volatile("" : "+v"(r));
-    ax = r & 3; rho = (r >> 2) & 63;
+    const int t = otid(), t8 = t >> 3;
+    ax = (t8 >= K ? 1 : 0) + (t8 >= 2 * K ? 1 : 0);
+    rho = ((t8 - ax * K) << 3) | (t & 7);
     hi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
     lo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
-    return (r >> 8) != 0;
+    return t8 < 3 * K;
   };
   // line rows of control point (seg, k) = (t >> 5, (t >> 3) & 3), slice t & 7; base row of that control point: t >> 3
 
-  // row state: box rows [0] upper (alpha = +e), [1] lower; line rows: slot u = line lbeg + slice + 8 u
-  double bs0 = 1, bl0 = 0, bs1 = 1, bl1 = 0;
-  double sl[RS], ll[RS];
 
 #pragma nounroll
   for (int attempt = 0; attempt < (CULL ? 2 : 1) && K_ok; attempt++) {
@@ -168,7 +166,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
 
     // One pass over this thread's line rows.  body(ok, n1, n2, h, s, lambda); padded slots see the dummy line (0, 0, 1) with
     // s = lambda = 1: their activity and step are exactly zero (see qp_kernel), `ok` masks what would still matter.
-    auto for_rows = [&](auto&& body) {
+    auto for_rows = [&](double (&sl)[RS], double (&ll)[RS], auto&& body) {
       // two slots per scalar branch: both rows' coefficient loads are issued before either row's arithmetic (a block per slot
       // would leave every row waiting for its own three ds_reads)
 #pragma unroll
@@ -203,21 +201,22 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     for (int mode = 0; mode < 2; mode++) {
       const QpTable* __restrict__ tb = tables + mode * (kMaxK + 1) + K;
       const int nz = mode == 1 ? K : (K > 2 ? K - 2 : 0), n = 3 * nz;
+      const int tm = otid();     // (the set-up below runs once per mode: nothing of it is worth hoisting out of the mode loop into registers)
       __syncthreads();
-      for (int e = tid; e < kMaxR * kNZ; e += BS) sB[(e / kNZ) * SBS + (e % kNZ)] = (&tb->B[0][0])[e];
-      if (tid < 64) sHax[tid] = (&tb->Hax[0][0])[tid];
-      if (tid < 8) sEp[tid] = tb->ep[tid];
-      for (int e = tid; e < kSmallTab; e += BS) sM[e] = (&tb->Gi[0][0])[e];
-      if (tid < 96) { const int ax = tid >> 5, r = tid & 31; sTheta[tid] = r < 4 * K ? sCoef[tid] - (tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2]) : 0.0; }
-      if (tid < 3 * R) { const int rho = tid % R, ax = tid / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
+      for (int e = tm; e < kMaxR * kNZ; e += BS) sB[(e / kNZ) * SBS + (e % kNZ)] = (&tb->B[0][0])[e];
+      if (tm < 64) sHax[tm] = (&tb->Hax[0][0])[tm];
+      if (tm < 8) sEp[tm] = tb->ep[tm];
+      for (int e = tm; e < kSmallTab; e += BS) sM[e] = (&tb->Gi[0][0])[e];
+      if (tm < 96) { const int ax = tm >> 5, r = tm & 31; sTheta[tm] = r < 4 * K ? sCoef[tm] - (tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2]) : 0.0; }
+      if (tm < 3 * R) { const int rho = tm % R, ax = tm / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
       // the iterate and the two directions are read eight entries at a time from an axis' first one (against B's or Hax's zero
       // columns): what lies beyond the 3 nz entries in use must be finite
-      if (tid >= n && tid < 24) { sZ[tid] = 0.0; sDxa[tid] = 0.0; sDx[tid] = 0.0; }
+      if (tm >= n && tm < 24) { sZ[tm] = 0.0; sDxa[tm] = 0.0; sDx[tm] = 0.0; }
       __syncthreads();
       const double* tGiP = sM + tGi; const double* tUpP = sM + tUp; const double* tUvP = sM + tUv; const double* tUaP = sM + tUa;
       const double* tZpP = sM + tZp; const double* tPpP = sM + tPp; const double* tResP = sM + tResU;
-      if (tid < 24) { const int ax = tid >> 3, r = tid & 7; sRhs[tid] = tPpP[r * 3] * sInit[ax * 3] + tPpP[r * 3 + 1] * sInit[ax * 3 + 1] + tPpP[r * 3 + 2] * sInit[ax * 3 + 2]; }
-      else if (tid >= 32 && tid < 35) { const int ax = tid - 32; sc[sPe0 + ax] = tUpP[0] * sInit[ax * 3] + tUpP[1] * sInit[ax * 3 + 1] + tUpP[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; }
+      if (tm < 24) { const int ax = tm >> 3, r = tm & 7; sRhs[tm] = tPpP[r * 3] * sInit[ax * 3] + tPpP[r * 3 + 1] * sInit[ax * 3 + 1] + tPpP[r * 3 + 2] * sInit[ax * 3 + 2]; }
+      else if (tm >= 32 && tm < 35) { const int ax = tm - 32; sc[sPe0 + ax] = tUpP[0] * sInit[ax * 3] + tUpP[1] * sInit[ax * 3 + 1] + tUpP[2] * sInit[ax * 3 + 2] - sc[sFinal0 + ax]; }
       __syncthreads();
 #if !NEP_QP_MFMA
       // normal-matrix entries owned by this thread (xx, yx, yy, zz blocks; a pair of lanes per entry), packed: ci | cj<<4 | sel<<8 | on<<12
@@ -227,7 +226,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         auto tri = [&](int e, int& r, int& c) { r = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while ((r + 1) * (r + 2) / 2 <= e) r++; while (r * (r + 1) / 2 > e) r--; c = e - r * (r + 1) / 2; };
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-          const int e = (tid >> 1) + u * (BS / 2);
+          const int e = (tm >> 1) + u * (BS / 2);
           const bool on = e < n_ent && nz > 0;
           int ci = 0, cj = 0, sel = 0;
           if (on) {
@@ -247,19 +246,19 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
         double viol = 0.0, d0 = 0, d1 = 0, d2 = 0;
         { int ax, rho; double hi, lo; if (box_role(ax, rho, hi, lo)) { const double a = sOff[rho * 3 + ax]; viol = fmax(a - hi, lo - a); } }
-        { const int lrho = otid() >> 3; const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; for_rows([&](bool v, double n1, double n2, double h, double&, double&) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
-        if (tid < 6) {
-          const int ax = tid / 2, e = tid % 2;
+        { const int lrho = otid() >> 3; const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; double du_[RS], dv_[RS]; for_rows(du_, dv_, [&](bool v, double n1, double n2, double h, double&, double&) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
+        if (tm < 6) {
+          const int ax = tm / 2, e = tm % 2;
           viol = fmax(viol, fabs(tResP[e * 3] * sInit[ax * 3] + tResP[e * 3 + 1] * sInit[ax * 3 + 1] + tResP[e * 3 + 2] * sInit[ax * 3 + 2]));
         }
-        if (tid == 0 && has_qc) {
+        if (tm == 0 && has_qc) {
           double c = -0.10 * 0.10;
           for (int ax = 0; ax < 3; ax++) { const double pe = sc[sPe0 + ax]; c += pe * pe; }
           viol = fmax(viol, c);
         }
         block_reduce4(viol, d0, d1, d2, sRed);
         converged = viol <= 1e-6;
-        if (tid == 0) {
+        if (tm == 0) {
           double o = 0;
           for (int ax = 0; ax < 3; ax++) {
             for (int r = 0; r < K; r++) { const double a = sRhs[ax * 8 + r]; o += 36 * T * a * a; }
@@ -270,15 +269,15 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         }
       } else {
         // ---- start point: projection of the guess, floored slacks, centred duals ------------------
-        if (tid < n) {
-          const int ax = tid / nz, c = tid % nz;
+        if (tm < n) {
+          const int ax = tm / nz, c = tm % nz;
           double z = 0;
 #pragma unroll 8
           for (int r = 0; r < 4 * kMaxK; r++) z = __builtin_fma(tZpP[c * 4 * kMaxK + r], sTheta[ax * 32 + r], z);
-          sZ[tid] = z;
-          sG[tid] = (tGiP[c * 3] * sInit[ax * 3] + tGiP[c * 3 + 1] * sInit[ax * 3 + 1] + tGiP[c * 3 + 2] * sInit[ax * 3 + 2]) - 2 * wgt * sEp[c] * sc[sFinal0 + ax];
+          sZ[tm] = z;
+          sG[tm] = (tGiP[c * 3] * sInit[ax * 3] + tGiP[c * 3 + 1] * sInit[ax * 3 + 1] + tGiP[c * 3 + 2] * sInit[ax * 3 + 2]) - 2 * wgt * sEp[c] * sc[sFinal0 + ax];
         }
-        if (tid == 0) {
+        if (tm == 0) {
           double o = 0;
           for (int ax = 0; ax < 3; ax++) {
             for (int r = 0; r < K; r++) { const double a = sRhs[ax * 8 + r]; o += 36 * T * a * a; }
@@ -303,11 +302,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         };
         bool uncon = false;
         if constexpr (CULL) {   // presolve: the minimiser without inequality rows, accepted when every row holds there (see qp_kernel)
-          if (tid < n) {
-            const int ax = tid / nz, c = tid % nz;
+          if (tm < n) {
+            const int ax = tm / nz, c = tm % nz;
             double v = 0;
             for (int e = 0; e < nz; e++) v -= sM[tHi + c * kNZ + e] * sG[ax * nz + e];
-            sDx[tid] = v;
+            sDx[tm] = v;
           }
           __syncthreads();
           double viol = -1.0, o_share = 0, d1 = 0, d2 = 0;
@@ -315,26 +314,30 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           {
             const int lrho = otid() >> 3; const bool has_line = (lrho >> 2) < K;
             const double cx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sDx) : 0.0, cy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sDx) : 0.0;
-            for_rows([&](bool ok, double n1, double n2, double h, double&, double&) { viol = fmax(viol, ok ? (n1 * cx + n2 * cy) - h : -1.0); });
+            double du_[RS], dv_[RS];
+            for_rows(du_, dv_, [&](bool ok, double n1, double n2, double h, double&, double&) { viol = fmax(viol, ok ? (n1 * cx + n2 * cy) - h : -1.0); });
           }
-          if (tid == BS - 1 && has_qc) {
+          if (tm == BS - 1 && has_qc) {
             double c = -0.10 * 0.10;
             for (int ax = 0; ax < 3; ax++) { double pe = sc[sPe0 + ax]; for (int e = 0; e < nz; e++) pe += sEp[e] * sDx[ax * nz + e]; c += pe * pe; }
             viol = fmax(viol, c);
           }
-          if (tid < n) {
-            const int ax = tid / nz, c = tid % nz;
+          if (tm < n) {
+            const int ax = tm / nz, c = tm % nz;
             double hz = 0;
             for (int e = 0; e < nz; e++) hz += sHax[c * kNZ + e] * sDx[ax * nz + e];
-            o_share = sDx[tid] * (0.5 * hz + sG[tid]);
+            o_share = sDx[tm] * (0.5 * hz + sG[tm]);
           }
           block_reduce4(viol, o_share, d1, d2, sRed);
           uncon = viol <= 0.0;
-          if (uncon) { if (tid < n) sZ[tid] = sDx[tid]; if (tid == 0) sc[sObj] = sc[sObj0] + o_share; }
+          if (uncon) { if (tm < n) sZ[tm] = sDx[tm]; if (tm == 0) sc[sObj] = sc[sObj0] + o_share; }
         }
         // (roles are re-derived from an opaque copy of the thread index in every phase: whatever the compiler could hoist out of
         // the iteration loop — row / entry indices, LDS addresses of four different roles — would otherwise sit in registers
         // next to the row state for the whole solve)
+        // row state (its lifetime is one solve of one mode): box rows [0] upper (alpha = +e), [1] lower; line rows: slot u = line slice + 8 u of my segment
+        double bs0 = 1, bl0 = 0, bs1 = 1, bl1 = 0;
+        double sl[RS], ll[RS];
         double cpb = 0.0, uab = 0.0, udb = 0.0, cpx = 0.0, cpy = 0.0;
         double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
         {
@@ -349,11 +352,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         }
 #pragma unroll
         for (int u = 0; u < RS; u++) { sl[u] = 1.0; ll[u] = 1.0; }
-        for_rows([&](bool ok, double n1, double n2, double h, double& s, double& lam) {
+        for_rows(sl, ll, [&](bool ok, double n1, double n2, double h, double& s, double& lam) {
           const double slk = h - (n1 * cpx + n2 * cpy);
           s = slk > kSlackFloor ? slk : kSlackFloor; lam = ok ? kMu0 * frcp(s) : 1.0;
         });
-        if (tid == 0) {
+        if (tm == 0) {
           double qs = 1.0; for (int e = 0; e < n; e++) qs = fmax(qs, fabs(sG[e]));
           sc[sQscale] = qs;
           if (has_qc) {
@@ -388,7 +391,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               int ax, rho; double hi, lo;
               if (box_role(ax, rho, hi, lo)) { rowA1(bs0, bl0, cpb, uab, udb, hi); rowA1(bs1, bl1, -cpb, -uab, -udb, -lo); }
             }
-            for_rows([&](bool ok, double n1, double n2, double h, double& s, double& lam) {
+            for_rows(sl, ll, [&](bool ok, double n1, double n2, double h, double& s, double& lam) {
               rowA1(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h);
               lam = ok ? lam : 1.0;
             });
@@ -405,7 +408,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               }
             }
             double lTx = 0, lTy = 0, lDxx = 0, lDxy = 0, lDyy = 0, l1x = 0, l1y = 0;
-            for_rows([&](bool ok, double n1, double n2, double h, double& s, double& lam) {
+            for_rows(sl, ll, [&](bool ok, double n1, double n2, double h, double& s, double& lam) {
               const double rp = (n1 * cpx + n2 * cpy) + s - h, w = lam * frcp(s), v = lam - w * rp;
               nrp = fmax(nrp, fabs(rp)); sumsl += ok ? s * lam : 0.0;
               lTx += lam * n1; lTy += lam * n2; lDxx += w * n1 * n1; lDxy += w * n1 * n2; lDyy += w * n2 * n2; l1x += v * n1; l1y += v * n2;
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const int t = otid();
             { const int rho = t >> 3; uax = proj(rho, 0, sDxa); uay = proj(rho, 1, sDxa); }
             double vax = 0, vay = 0, vbx = 0, vby = 0;
-            for_rows([&](bool, double n1, double n2, double h, double& s, double& lam) {
+            for_rows(sl, ll, [&](bool, double n1, double n2, double h, double& s, double& lam) {
               double va, vb;
               rowP2(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, h, va, vb);
               vax += va * n1; vay += va * n2; vbx += vb * n1; vby += vb * n2;
@@ -688,7 +691,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             }
             const int t = otid();
             { const int rho = t >> 3; udx = proj(rho, 0, sDx); udy = proj(rho, 1, sDx); }
-            for_rows([&](bool ok, double n1, double n2, double h, double& s, double& lam) { rowP5(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h); });
+            for_rows(sl, ll, [&](bool ok, double n1, double n2, double h, double& s, double& lam) { rowP5(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h); });
             if (t == BS - 1 && has_qc) {
               const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
               double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDx[e];
