@@ -6,8 +6,9 @@
           --master-port P bench.py --gpus N --steps K --warmup W)
 
 Workload (BASELINE.json north_star / configs[3] scene on the named GPU count): 64 agents + 20
-static polytope obstacles, K = 8 segments, reference yaml parameters, 32 seeded scenes (SURVEY.md
-§8d) in flight per GPU per step.  One step = one bulk-synchronous round: every agent of every scene
+static polytope obstacles, K = 8 segments, reference yaml parameters, 128 seeded scenes (SURVEY.md
+§8d) in flight per GPU per step (--scenes; rounds 1 and early 2 ran 32: one launch of 2 048 workgroups is two
+waves of the QP kernel over the chip and a third of its time is the second wave draining).  One step = one bulk-synchronous round: every agent of every scene
 does one full back-end replan (MINVO hulls of the other agents' committed trajectories ->
 separating-line LPs -> spline QP -> sampled states -> committed record); the new trajectories are
 the obstacles of the next step.  Inputs are resident in HBM before the timed region.  Every scene carries its
@@ -18,7 +19,7 @@ verified row presolve on) and `chain` (front-end beam search -> separating lines
 and commit, i.e. the guesses are made on the device instead of being read from the scene).
 
 N > 1: the agents of every scene are block-sharded by id across the ranks (64/N per GPU) and the
-number of scenes grows with N (32 per GPU), so every GPU does 2048 replans per step at any N:
+number of scenes grows with N (128 per GPU), so every GPU does 8192 replans per step at any N:
 "scaling" is "weak".  The exchange step is one RCCL all-gather per round of what the other agents'
 replans consume of a committed trajectory — its interval hulls — so hull construction is sharded
 with the agents (--exchange records all-gathers the trajectory records instead and rebuilds every
@@ -113,7 +114,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--agents", type=int, default=64)
     ap.add_argument("--obstacles", type=int, default=20)
-    ap.add_argument("--scenes", type=int, default=32, help="seeded scenes in flight PER GPU")
+    ap.add_argument("--scenes", type=int, default=128, help="seeded scenes in flight PER GPU")
     ap.add_argument("--exchange", choices=["hulls", "records"], default="hulls",
                     help="N > 1: all-gather the interval hulls of the local agents' committed trajectories (hull work "
                          "sharded with the agents) or the trajectory records themselves (every rank rebuilds all hulls)")
@@ -204,7 +205,8 @@ def main():
     N, M, S = args.agents, args.obstacles, args.scenes * world
     first_local, n_local = ndist.shard(N, world, rank)
     # each rank generates its share of the seeded scenes (seeds 0..S-1 overall), then they are shared
-    mine = [scene.make_scene(N, M, seed=s) for s in range(rank * args.scenes, (rank + 1) * args.scenes)]
+    mine = scene.make_scenes(N, M, range(rank * args.scenes, (rank + 1) * args.scenes),
+                             workers=min(args.scenes, max(1, (os.cpu_count() or 1) // (2 * world)), 64))
     scene0 = mine[0] if rank == 0 else scene.make_scene(N, M, seed=0)
     p = scene0["par"]
     # every scene has its own static obstacles (drawn first from its seed, so any rank can rebuild any scene's set)

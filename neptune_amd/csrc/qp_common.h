@@ -181,22 +181,25 @@ __device__ __forceinline__ bool chol_impl(lds_dptr sM, lds_dptr sInvD, int lane)
 }
 template <int N>
 __device__ __forceinline__ double solve_impl(lds_dptr sM, lds_dptr sInvD, int lane, double b) {
+  // (select-free substitution: see solve_pad)
   const int row = lane < N ? lane : N - 1;
   const double dinv = sInvD[row];
   {
-    double Lr[N];                   // row i of L (valid for j < i)
+    double Lr[N];                   // row i of L, zero from the diagonal on
 #pragma unroll
-    for (int j = 0; j < N; j++) Lr[j] = sM[row * MS + j];
+    for (int j = 0; j < N; j++) { const double v = sM[row * MS + j]; Lr[j] = j < lane ? v : 0.0; }
 #pragma unroll
-    for (int j = 0; j < N; j++) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Lr[j], xj, b); b = lane == j ? xj : (lane > j ? upd : b); }
+    for (int j = 0; j < N; j++) b = __builtin_fma(-Lr[j], bcast(b * dinv, j), b);
+    b *= dinv;
   }
   __builtin_amdgcn_sched_barrier(0);   // the column loads below must not be hoisted over the forward pass (register footprint of the callee)
   {
-    double Uc[N];                   // column i of L (valid for j > i)
+    double Uc[N];                   // column i of L, zero down to the diagonal
 #pragma unroll
-    for (int j = 0; j < N; j++) Uc[j] = sM[j * MS + row];
+    for (int j = 0; j < N; j++) { const double v = sM[j * MS + row]; Uc[j] = j > lane ? v : 0.0; }
 #pragma unroll
-    for (int j = N - 1; j >= 0; j--) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Uc[j], xj, b); b = lane == j ? xj : (lane < j ? upd : b); }
+    for (int j = N - 1; j >= 0; j--) b = __builtin_fma(-Uc[j], bcast(b * dinv, j), b);
+    b *= dinv;
   }
   return b;
 }
@@ -233,6 +236,10 @@ __device__ __forceinline__ bool chol_pad(lds_dptr sM, lds_dptr sInvD, int n, int
 }
 template <int N>
 __device__ __forceinline__ double solve_pad(lds_dptr sM, lds_dptr sInvD, int n, int lane, double b) {
+  // Entries a lane must not use are loaded as ZERO (row i of L right of and on the diagonal, column i above and on it), so a
+  // substitution step is one multiply, one broadcast and one fused multiply-add for every lane, with no per-step selects:
+  // lane j's running value stops changing at step j (its later coefficients are zero) and x_j = b_j * dinv_j is taken once
+  // after the loop.  Same operations on the entries that matter as the select form: same bits.
   const int row = lane < N ? lane : N - 1;
   const bool rin = row < n;
   const double dinv = rin ? sInvD[row] : 1.0;
@@ -240,17 +247,19 @@ __device__ __forceinline__ double solve_pad(lds_dptr sM, lds_dptr sInvD, int n, 
   {
     double Lr[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) { const double v = sM[row * MS + j]; Lr[j] = (rin && j < n) ? v : 0.0; }
+    for (int j = 0; j < N; j++) { const double v = sM[row * MS + j]; Lr[j] = (rin && j < n && j < lane) ? v : 0.0; }
 #pragma unroll
-    for (int j = 0; j < N; j++) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Lr[j], xj, b); b = lane == j ? xj : (lane > j ? upd : b); }
+    for (int j = 0; j < N; j++) b = __builtin_fma(-Lr[j], bcast(b * dinv, j), b);
+    b *= dinv;
   }
   __builtin_amdgcn_sched_barrier(0);
   {
     double Uc[N];
 #pragma unroll
-    for (int j = 0; j < N; j++) { const double v = sM[j * MS + row]; Uc[j] = (rin && j < n) ? v : 0.0; }
+    for (int j = 0; j < N; j++) { const double v = sM[j * MS + row]; Uc[j] = (rin && j < n && j > lane) ? v : 0.0; }
 #pragma unroll
-    for (int j = N - 1; j >= 0; j--) { const double xj = bcast(b * dinv, j); const double upd = __builtin_fma(-Uc[j], xj, b); b = lane == j ? xj : (lane < j ? upd : b); }
+    for (int j = N - 1; j >= 0; j--) b = __builtin_fma(-Uc[j], bcast(b * dinv, j), b);
+    b *= dinv;
   }
   return b;
 }

@@ -71,6 +71,17 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   const lds_ptr ldyn = (lds_ptr)(unsigned int)(lds0 + (kFixedDoubles + 32) * sizeof(double));
   const int GL = ps.rows_cap / 4 + 2;
   double* __restrict__ gsp = ps.row_scratch + (long)slot * (11L * GL);
+  // phase cycle counters (make PROFILE=1, scripts/qp_phases.py): thread 0's clock, accumulated in 16 LDS words behind the carve
+#ifdef NEP_PROFILE_PHASES
+  long long* sProf = (long long*)(smem + kFixedDoubles + 32 + 3 * NS);
+  const bool prof = ps.dbg != nullptr;
+  long long tlast = 0;
+  const long long tstart = clock64(), tstart_wall = (long long)wall_clock64();
+  if (tid == 0) { for (int k = 0; k < 16; k++) sProf[k] = 0; tlast = tstart; }
+#define TICK(k) do { if (prof && tid == 0) { const long long t_ = clock64(); sProf[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define TICK(k) do { } while (0)
+#endif
 
   // ---- thread roles: derived where they are used (an opaque copy of the thread index keeps the compiler from parking role
   // indices, bounds and addresses in registers — or scratch — for the whole solve; see the iteration loop) ----
@@ -145,6 +156,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       }
     }
     __syncthreads();
+    TICK(13);
     const double dix = sCoef[3] - sc[sFinal0], diy = sCoef[32 + 3] - sc[sFinal1], diz = sCoef[64 + 3] - sc[sFinal2];
     has_qc = sqrt(dix * dix + diy * diy + diz * diz) < 1.0;   // :697-702
     z_override = sqrt(dix * dix + diy * diy) < 1.0;           // :879-880
@@ -241,6 +253,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
 #endif
       bool converged = false;
       int it = 0;
+      TICK(14);
       const long long t_solve0 = (long long)wall_clock64();   // m_.optimize() starts here: every solve (first and relaxed) has its own TimeLimit
       if (nz == 0) {
         // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
@@ -371,6 +384,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         __syncthreads();
 
         double* redA = sRed; double* redP2 = sRed + 16; double* redP5 = sRed + 32;
+        TICK(15);
         const int n0 = has_qc ? n : 2 * nz;                       // wave 0 factors this block, wave 1 the z block
         for (it = 0; it < kMaxIt && !uncon; it++) {
           // ---- (A1) apply the previous step to the row state; (A2) residuals / weights / scatter onto base rows.  Two sweeps
@@ -419,16 +433,12 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           }
           reduce_put<1>(nrp, sumsl, dummy1, redA);
           __syncthreads();                                                                       // barrier 1
+          TICK(0);
           reduce_get<1>(nrp, sumsl, dummy1, redA);
+          // (the line rows' sums per control point stay in sAccL: what reads the per-base-row weights and right-hand sides below
+          // adds them on the fly — base rows < 32 are the position control points — instead of a combining phase and its barrier)
           {
             const int t = otid();
-            if (t < R) {
-              const int rho = t; const double* al = sAccL + rho * 8;
-              if (rho < 4 * K) {
-                sDc[rho * 4 + 0] += al[2]; sDc[rho * 4 + 1] = al[3]; sDc[rho * 4 + 2] += al[4];
-                sTc[rho * 6 + 0] += al[0]; sTc[rho * 6 + 1] += al[1]; sTc[rho * 6 + 3] += al[5]; sTc[rho * 6 + 4] += al[6];
-              } else sDc[rho * 4 + 1] = 0.0;
-            }
             if (t == BS - 1) {   // ball constraint (scalar row)
               double rpq = 0;
               if (has_qc) {
@@ -449,14 +459,22 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               sc[sNrp] = fmax(nrp, fabs(rpq));
             }
           }
-          __syncthreads();                                                                       // barrier 2
+          if (has_qc) __syncthreads();                                                           // barrier 2 (the ball row's gradient and weight feed the assembly)
+          TICK(1);
           // ---- dual residual + predictor rhs (8 partial sums per output), normal matrix -------------
           {
             const int t = otid();
             if (t < 8 * n) {
               const int o = t >> 3, sl8 = t & 7, ax = o / nz, c = o % nz;
               double v = 0, t1 = 0;
-              for (int rho = sl8; rho < R; rho += 8) { const double b = sB[rho * SBS + c]; v += b * sTc[rho * 6 + ax]; t1 += b * sTc[rho * 6 + 3 + ax]; }
+              const int axl = ax & 1;
+#pragma unroll
+              for (int q = 0; q < NEP_MAX_POL; q++) {     // (base rows >= 8 K: zero B, zero sums)
+                const int rho = sl8 + 8 * q;
+                double tl = sTc[rho * 6 + ax], tv = sTc[rho * 6 + 3 + ax];
+                if (q < 4) { const double la = sAccL[rho * 8 + axl], lv = sAccL[rho * 8 + 5 + axl]; tl += ax < 2 ? la : 0.0; tv += ax < 2 ? lv : 0.0; }
+                const double b = sB[rho * SBS + c]; v += b * tl; t1 += b * tv;
+              }
               v = slice_sum(v); t1 = slice_sum(t1);
               if (sl8 == 0) {
                 double hz = 0;
@@ -467,7 +485,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
                 v += go + hz;
                 if (has_qc) v += sc[sLq] * sGq[o];
                 sRd[o] = v; sRhs[o] = t1;
-                sDxa[o] = zo * (0.5 * hz + go);
+                sDx[o] = zo * (0.5 * hz + go);      // (sDx is free until the corrector solve)
               }
             }
           }
@@ -479,11 +497,14 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const int sel = (t >= 192 ? 2 : 0) + (i16 >> 3);           // weight set of this lane's column: 0 xx, 1 yx, 2 yy, 3 zz
             // A operand: B'[ci][rho] (rows ci >= 8 of the tile are padding); B operand: D_sel[rho] B[rho][cj].  Base rows >= 8 K have zero B and zero weights.
             const double* pa = sB + kk * SBS + (i16 & 7); const double* pd = sDc + kk * 4 + sel; const double* pb = sB + kk * SBS + cj;
+            const double* pl = sAccL + kk * 8 + 2 + (sel < 3 ? sel : 0);      // line rows' share of the weight (xx, yx, yy; none for zz)
             v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 2 * NEP_MAX_POL; q += 2) {
-              const double a0 = i16 < 8 ? pa[(4 * q) * SBS] : 0.0, b0 = pd[(4 * q) * 4] * pb[(4 * q) * SBS];
-              const double a1 = i16 < 8 ? pa[(4 * q + 4) * SBS] : 0.0, b1 = pd[(4 * q + 4) * 4] * pb[(4 * q + 4) * SBS];
+              double d0 = pd[(4 * q) * 4], d1 = pd[(4 * q + 4) * 4];
+              if (q < NEP_MAX_POL) { const double l0 = pl[(4 * q) * 8], l1 = pl[(4 * q + 4) * 8]; d0 += sel < 3 ? l0 : 0.0; d1 += sel < 3 ? l1 : 0.0; }   // base rows < 32
+              const double a0 = i16 < 8 ? pa[(4 * q) * SBS] : 0.0, b0 = d0 * pb[(4 * q) * SBS];
+              const double a1 = i16 < 8 ? pa[(4 * q + 4) * SBS] : 0.0, b1 = d1 * pb[(4 * q + 4) * SBS];
               acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
               acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
             }
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
                 const int rho = half + 8 * q;
                 double d[4], bi[4], bj[4];
 #pragma unroll
-                for (int w = 0; w < 4; w++) { d[w] = sDc[(rho + 2 * w) * 4 + sel]; bi[w] = sB[(rho + 2 * w) * SBS + ci]; bj[w] = sB[(rho + 2 * w) * SBS + cj]; }
+                for (int w = 0; w < 4; w++) { d[w] = sDc[(rho + 2 * w) * 4 + sel] + ((q < 4 && sel < 3) ? sAccL[(rho + 2 * w) * 8 + 2 + sel] : 0.0); bi[w] = sB[(rho + 2 * w) * SBS + ci]; bj[w] = sB[(rho + 2 * w) * SBS + cj]; }
                 a0 = __builtin_fma(d[0] * bi[0], bj[0], a0); a1 = __builtin_fma(d[1] * bi[1], bj[1], a1);
                 a0 = __builtin_fma(d[2] * bi[2], bj[2], a0); a1 = __builtin_fma(d[3] * bi[3], bj[3], a1);
               }
@@ -535,11 +556,25 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             sM[i * MS + j] = has_qc ? sc[sWq] * sGq[i] * sGq[j] : 0.0;
           }
           __syncthreads();                                                                       // barrier 3
-          // ---- wave 0: convergence test, Cholesky of its block, predictor; wave 1: the z block -------
+          TICK(2);
+          // ---- wave 0: Cholesky of its block and the predictor; wave 1: convergence test, then the z block.  Wave 0 does not
+          // wait for the verdict: on the one iteration that ends the solve its factorisation is wasted, on all the others the test
+          // (two wave reductions and a dozen dependent LDS reads) is off the longest chain of the iteration ----
           if (tid < 64) {
             const int t = otid();
-            const double nrd = wave_max(t < n ? fabs(sRd[t]) : 0.0);
-            const double o = sc[sObj0] + wave_sum(t < n ? sDxa[t] : 0.0);
+            const lds_dptr sMl = (lds_dptr)(unsigned)(lds0 + oM * 8), sInvDl = (lds_dptr)(unsigned)(lds0 + oInvD * 8);
+            const bool chol_ok = chol_n(sMl, sInvDl, n0, t);
+            if (t == 0) sI[19] = chol_ok ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            double b = 0;
+            if (t < n0) { b = -sRd[t] + sRhs[t]; if (has_qc) b += sGq[t] * (sc[sLq] - sc[sWq] * sc[sRpq]); }
+            b = solve_n(sMl, sInvDl, (lds_dptr)(unsigned)(lds0 + oRed * 8), n0, t, b);
+            if (t < n0) sDxa[t] = b;
+            TICK(3);
+          } else if (tid < 128) {
+            const int t = otid(), l1 = t - 64;
+            const double nrd = wave_max(l1 < n ? fabs(sRd[l1]) : 0.0);
+            const double o = sc[sObj0] + wave_sum(l1 < n ? sDx[l1] : 0.0);      // (the objective's terms: written next to rd, see above)
             const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
             int flag = 0;
             if (nr <= 1e-9 && nrd <= 1e-9 * qs && gap <= 1e-10 * (1.0 + fabs(o))) flag = 1;
@@ -551,26 +586,13 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               const double merit = fmax(fmax(nr * 1e9, nrd / qs * 1e9), gap / (1.0 + fabs(o)) * 1e10);
               const bool better = flag == 2 && (!sI[16] || merit < sc[sBestMerit]);
               const bool last = sI[22] >= 0 && it - sI[22] >= 3;
-              if (sI[22] < 0 && t == 0) sI[22] = it;
+              if (sI[22] < 0 && l1 == 0) sI[22] = it;
               flag = last ? (better ? 1 : 3) : (better ? 2 : 0);
-              if (t == 0 && flag == 2) sc[sBestMerit] = merit;
+              if (l1 == 0 && flag == 2) sc[sBestMerit] = merit;
             }
-            if (t == 0) { sc[sObj] = o; if (flag == 2) sc[sObjLoose] = o; sI[18] = flag; }
-            if (flag != 1 && flag != 3) {                        // (uniform across the wave)
-              const lds_dptr sMl = (lds_dptr)(unsigned)(lds0 + oM * 8), sInvDl = (lds_dptr)(unsigned)(lds0 + oInvD * 8);
-              const bool chol_ok = chol_n(sMl, sInvDl, n0, t);
-              if (t == 0) sI[19] = chol_ok ? 1 : 0;
-              __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-              double b = 0;
-              if (t < n0) { b = -sRd[t] + sRhs[t]; if (has_qc) b += sGq[t] * (sc[sLq] - sc[sWq] * sc[sRpq]); }
-              b = solve_n(sMl, sInvDl, (lds_dptr)(unsigned)(lds0 + oRed * 8), n0, t, b);
-              if (t < n0) sDxa[t] = b;
-            }
-          } else if (tid < 128) {
+            if (l1 == 0) { sc[sObj] = o; if (flag == 2) sc[sObjLoose] = o; sI[18] = flag; }
             bool chol_ok = true;
-            const int t = otid();
-            if (!has_qc) {
-              const int l1 = t - 64;
+            if (!has_qc && flag != 1 && flag != 3) {             // (uniform across the wave)
               const lds_dptr sMz = (lds_dptr)(unsigned)(lds0 + (oM + 2 * nz * MS + 2 * nz) * 8), sInvDz = (lds_dptr)(unsigned)(lds0 + (oInvD + 2 * nz) * 8);
               chol_ok = chol_n(sMz, sInvDz, nz, l1);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -578,9 +600,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               b = solve_n(sMz, sInvDz, (lds_dptr)(unsigned)(lds0 + (oRed + 24) * 8), nz, l1, b);
               if (l1 < nz) sDxa[2 * nz + l1] = b;
             }
-            if (t == 64) sI[20] = chol_ok ? 1 : 0;
+            if (l1 == 0) sI[20] = chol_ok ? 1 : 0;
           }
           __syncthreads();                                                                       // barrier 4
+          TICK(4);
           const int flag = sI[18];
           if (flag == 1) { converged = true; break; }
           if (flag == 3) break;
@@ -626,6 +649,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           }
           reduce_put<1>(rmax, c2, dmy, redP2);
           __syncthreads();                                                                       // barrier 5
+          TICK(5);
           reduce_get<1>(rmax, c2, dmy, redP2);
           double sm;
           {
@@ -641,7 +665,8 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             if (t < 8 * n) {   // corrector right-hand side
               const int o = t >> 3, sl8 = t & 7, ax = o / nz, c = o % nz;
               double t1 = 0;
-              for (int q = 0; q < K; q++) {
+#pragma unroll
+              for (int q = 0; q < NEP_MAX_POL; q++) {     // (base rows >= 8 K: zero B, zero sums)
                 const int rho = sl8 + 8 * q;
                 double ta = sTc[rho * 6 + 3 + ax], tb2 = sTc[rho * 6 + ax];
                 if (q < 4) {
@@ -656,6 +681,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             }
           }
           __syncthreads();                                                                       // barrier 6
+          TICK(6);
           if (tid < 128) {
             const int t = otid();
             const bool w0 = t < 64;
@@ -675,6 +701,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             }
           }
           __syncthreads();                                                                       // barrier 7
+          TICK(7);
           // ---- (P5) step length of the combined direction ------------------------------------------
           rmax = 0;
           {
@@ -703,6 +730,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           }
           reduce_put<0>(rmax, dmy, dmy, redP5);
           __syncthreads();                                                                       // barrier 8
+          TICK(8);
           reduce_get<0>(rmax, dmy, dmy, redP5);
           {
             double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
@@ -712,6 +740,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             sc[sAlpha] = alpha; sc[sSigMu] = sm;     // (every thread stores the same two values: pass A reads them back without a barrier in between)
             if (t < n) sZ[t] += alpha * sDx[t];
           }
+          TICK(9);
         }
         if (uncon) converged = true;
         if (!converged && sI[16]) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
@@ -803,6 +832,13 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       }
     }
   }
+#ifdef NEP_PROFILE_PHASES
+  if (prof && tid == 0) {   // [0..9] loop phases, [10] workgroup lifetime, [12] iterations, [13] line gather, [14] mode staging, [15] start point
+    for (int k = 0; k < 16; k++) ps.dbg[(long)slot * 16 + k] = sProf[k];
+    ps.dbg[(long)slot * 16 + 10] = clock64() - tstart; ps.dbg[(long)slot * 16 + 12] = iters_total;
+    ps.dbg[(long)slot * 16 + 11] = (tstart_wall << 20) | ((long long)wall_clock64() - tstart_wall);   // start (100 MHz ticks) << 20 | duration
+  }
+#endif
   if (ps.commit) {  // the record the agent would publish (neptune_ros.cpp:434-480); a failed replan publishes nothing (see qp_kernel)
     nep_traj_rec* cr = ps.commit + slot;
     const int own = sp.first_local + (slot % sp.n_local);
@@ -831,7 +867,13 @@ constexpr int kRegSlots = NEP_QP_REG_SLOTS;
 
 int qp_reg_slots() { return kRegSlots; }
 // dynamic LDS of the register kernel: the fixed carve + the coefficient carve [3][NEP_MAX_POL][8 slots]
-size_t qp_reg_lds_bytes() { return (size_t)kFixedDoubles * 8 + 64 * 4 + (size_t)3 * NEP_MAX_POL * 8 * kRegSlots * sizeof(double); }
+size_t qp_reg_lds_bytes() {
+  size_t b = (size_t)kFixedDoubles * 8 + 64 * 4 + (size_t)3 * NEP_MAX_POL * 8 * kRegSlots * sizeof(double);
+#ifdef NEP_PROFILE_PHASES
+  b += 16 * sizeof(long long);
+#endif
+  return b;
+}
 
 void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                    const SampleSched& sched, size_t lds_bytes, hipStream_t st) {

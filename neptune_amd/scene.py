@@ -380,6 +380,27 @@ def make_scene(num_agents, n_static, seed, K=8, warm_fraction=0.5, par=None, t_j
                 guesses=guesses, committed=committed, seed=seed)
 
 
+
+def _make_scene_job(job):
+    num_agents, n_static, seed, kw = job
+    return make_scene(num_agents, n_static, seed=seed, **kw)
+
+
+def make_scenes(num_agents, n_static, seeds, workers=None, **kw):
+    """make_scene for every seed, over a pool of host processes (a 64-agent scene takes about a second of rejection
+    sampling; the bench keeps a hundred of them in flight per GPU).  Same scenes as the serial calls: a scene depends on its
+    seed only."""
+    import os
+    seeds = list(seeds)
+    if workers is None:
+        workers = min(len(seeds), max(1, (os.cpu_count() or 1) // 2), 64)
+    if workers <= 1 or len(seeds) <= 1:
+        return [make_scene(num_agents, n_static, seed=s, **kw) for s in seeds]
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_make_scene_job, [(num_agents, n_static, s, kw) for s in seeds]))
+
 def scene_statics(num_agents, n_static, seed, par=None):
     """The inflated static obstacles make_scene(num_agents, n_static, seed) produces (its first random draws),
     without building the rest of the scene."""
