@@ -439,7 +439,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           // adds them on the fly — base rows < 32 are the position control points — instead of a combining phase and its barrier)
           {
             const int t = otid();
-            if (t == BS - 1) {   // ball constraint (scalar row)
+            if (t == 0) {   // ball constraint (scalar row) and the iteration's scalars
               double rpq = 0;
               if (has_qc) {
                 sc[sSq] += sc[sAlpha] * sc[sDsq]; sc[sLq] += sc[sAlpha] * sc[sDlq];
@@ -461,6 +461,81 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           }
           if (has_qc) __syncthreads();                                                           // barrier 2 (the ball row's gradient and weight feed the assembly)
           TICK(1);
+          // ---- dual residual + predictor rhs, normal matrix: three 16 x 16 tiles of v_mfma_f64_16x16x4_f64 over the 64 base rows
+          // (K = 64: 16 instructions per tile), one tile per wave.  Rows of a tile: ci (B' as the A operand; rows 8..15 repeat rows
+          // 0..7 and are not read back).  Columns: wave 1: Tl(x, y, z), T1(x, y, z) -> B' Tl, B' T1, the two sums the residual and
+          // the predictor's right-hand side need; wave 2: D_xx B | D_yx B; wave 3: D_yy B | D_zz B -> the blocks of M.  An output
+          // entry depends on its own row of A and its own column of B only, so the padding rows / columns carry whatever the loads
+          // return (in-bounds LDS reads) and cost no selects.  C/D layout: column = lane & 15, row = (lane >> 4) + 4 reg. ----
+#if NEP_QP_MFMA
+          if (tid >= 64) {
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            const int t = otid();
+            const int l = t & 63, i16 = l & 15, kk = l >> 4;
+            const double* px = sB + kk * SBS + (i16 & 7);               // B[rho][i16 & 7]: the A operand, and the B operand's factor in the M tiles
+            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            if (t >= 128) {
+              const int cj = l & 7;
+              const int sel = (t >= 192 ? 2 : 0) + (i16 >> 3);         // weight set of this lane's column: 0 xx, 1 yx, 2 yy, 3 zz
+              const double* pd = sDc + kk * 4 + sel;
+              const double* pl = sAccL + kk * 8 + (sel < 3 ? 2 + sel : 7);   // line rows' share of the weight (xx, yx, yy; entry 7 of a row is never written: zero)
+#pragma unroll
+              for (int q = 0; q < 2 * NEP_MAX_POL; q += 2) {
+                double d0 = pd[(4 * q) * 4], d1 = pd[(4 * q + 4) * 4];
+                if (q < NEP_MAX_POL) { d0 += pl[(4 * q) * 8]; d1 += pl[(4 * q + 4) * 8]; }   // base rows < 32: the position control points
+                const double x0 = px[(4 * q) * SBS], x1 = px[(4 * q + 4) * SBS];
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, d0 * x0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, d1 * x1, acc1, 0, 0, 0);
+              }
+              const int bi_ = sel == 0 ? 0 : (sel == 3 ? 2 : 1), bj_ = sel == 0 || sel == 1 ? 0 : (sel == 2 ? 1 : 2);
+#pragma unroll
+              for (int r = 0; r < 2; r++) {
+                const int ci = kk + 4 * r;
+                if (ci < nz && cj < nz) {
+                  double v = acc0[r] + acc1[r];
+                  const int mi = bi_ * nz + ci, mj = bj_ * nz + cj;
+                  if (sel != 1) v += sHax[ci * kNZ + cj];
+                  if (has_qc) { v += sc[sWq] * sGq[mi] * sGq[mj]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
+                  sM[mi * MS + mj] = v;
+                }
+              }
+            } else {
+              // column i16 < 6 of this tile: (Tl | T1)[ax], the box rows' sums from sTc plus, on base rows < 32 and for x and y, the line rows' from sAccL
+              const int ax = i16 < 3 ? i16 : (i16 < 6 ? i16 - 3 : 0);
+              const double* pt = sTc + kk * 6 + (i16 < 6 ? i16 : 0);
+              const double* pl = sAccL + kk * 8 + (i16 < 2 ? i16 : ((i16 == 3 || i16 == 4) ? i16 + 2 : 7));
+#pragma unroll
+              for (int q = 0; q < 2 * NEP_MAX_POL; q += 2) {
+                double t0 = pt[(4 * q) * 6], t1 = pt[(4 * q + 4) * 6];
+                if (q < NEP_MAX_POL) { t0 += pl[(4 * q) * 8]; t1 += pl[(4 * q + 4) * 8]; }
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(px[(4 * q) * SBS], t0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(px[(4 * q + 4) * SBS], t1, acc1, 0, 0, 0);
+              }
+              if (i16 < 6) {
+#pragma unroll 1
+                for (int r = 0; r < 2; r++) {
+                  const int ci = kk + 4 * r;
+                  if (ci < nz) {
+                    const int o = ax * nz + ci;
+                    double v = r == 0 ? acc0[0] + acc1[0] : acc0[1] + acc1[1];
+                    if (i16 >= 3) sRhs[o] = v;
+                    else {
+                      double hz = 0;
+                      { const double* hx = sHax + ci * kNZ; const double* zx = sZ + ax * nz;
+#pragma unroll
+                        for (int e = 0; e < kNZ; e++) hz += hx[e] * zx[e]; }
+                      const double zo = sZ[o], go = sG[o];
+                      v += go + hz;
+                      if (has_qc) v += sc[sLq] * sGq[o];
+                      sRd[o] = v;
+                      sDx[o] = zo * (0.5 * hz + go);      // the objective's terms (sDx is free until the corrector solve)
+                    }
+                  }
+                }
+              }
+            }
+          }
+#else
           // ---- dual residual + predictor rhs (8 partial sums per output), normal matrix -------------
           {
             const int t = otid();
@@ -489,40 +564,6 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               }
             }
           }
-#if NEP_QP_MFMA
-          if (tid >= 128) {   // waves 2 and 3: one 16 x 16 output tile each — rows ci, columns (block, cj): tile 0 = xx | yx, tile 1 = yy | zz
-            typedef double v4d __attribute__((ext_vector_type(4)));
-            const int t = otid();
-            const int l = t & 63, i16 = l & 15, kk = l >> 4, cj = l & 7;
-            const int sel = (t >= 192 ? 2 : 0) + (i16 >> 3);           // weight set of this lane's column: 0 xx, 1 yx, 2 yy, 3 zz
-            // A operand: B'[ci][rho] (rows ci >= 8 of the tile are padding); B operand: D_sel[rho] B[rho][cj].  Base rows >= 8 K have zero B and zero weights.
-            const double* pa = sB + kk * SBS + (i16 & 7); const double* pd = sDc + kk * 4 + sel; const double* pb = sB + kk * SBS + cj;
-            const double* pl = sAccL + kk * 8 + 2 + (sel < 3 ? sel : 0);      // line rows' share of the weight (xx, yx, yy; none for zz)
-            v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int q = 0; q < 2 * NEP_MAX_POL; q += 2) {
-              double d0 = pd[(4 * q) * 4], d1 = pd[(4 * q + 4) * 4];
-              if (q < NEP_MAX_POL) { const double l0 = pl[(4 * q) * 8], l1 = pl[(4 * q + 4) * 8]; d0 += sel < 3 ? l0 : 0.0; d1 += sel < 3 ? l1 : 0.0; }   // base rows < 32
-              const double a0 = i16 < 8 ? pa[(4 * q) * SBS] : 0.0, b0 = d0 * pb[(4 * q) * SBS];
-              const double a1 = i16 < 8 ? pa[(4 * q + 4) * SBS] : 0.0, b1 = d1 * pb[(4 * q + 4) * SBS];
-              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc0, 0, 0, 0);
-              acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc1, 0, 0, 0);
-            }
-            // C/D of the f64 form: column = lane & 15, row = (lane >> 4) + 4 reg
-            const int bi_ = sel == 0 ? 0 : (sel == 3 ? 2 : 1), bj_ = sel == 0 || sel == 1 ? 0 : (sel == 2 ? 1 : 2);
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-              const int ci = kk + 4 * r;
-              if (ci < nz && cj < nz) {
-                double v = acc0[r] + acc1[r];
-                const int mi = bi_ * nz + ci, mj = bj_ * nz + cj;
-                if (sel != 1) v += sHax[ci * kNZ + cj];
-                if (has_qc) { v += sc[sWq] * sGq[mi] * sGq[mj]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
-                sM[mi * MS + mj] = v;
-              }
-            }
-          }
-#else
 #pragma unroll 1
           for (int u = 0; u < 2; u++) {
             const int t = otid();
