@@ -434,12 +434,12 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           reduce_put<1>(nrp, sumsl, dummy1, redA);
           __syncthreads();                                                                       // barrier 1
           TICK(0);
-          reduce_get<1>(nrp, sumsl, dummy1, redA);
           // (the line rows' sums per control point stay in sAccL: what reads the per-base-row weights and right-hand sides below
           // adds them on the fly — base rows < 32 are the position control points — instead of a combining phase and its barrier)
           {
             const int t = otid();
-            if (t == 0) {   // ball constraint (scalar row) and the iteration's scalars
+            if (t == 0) {   // ball constraint (scalar row) and the iteration's scalars (the only reader of this reduction)
+              reduce_get<1>(nrp, sumsl, dummy1, redA);
               double rpq = 0;
               if (has_qc) {
                 sc[sSq] += sc[sAlpha] * sc[sDsq]; sc[sLq] += sc[sAlpha] * sc[sDlq];
@@ -479,13 +479,24 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               const int sel = (t >= 192 ? 2 : 0) + (i16 >> 3);         // weight set of this lane's column: 0 xx, 1 yx, 2 yy, 3 zz
               const double* pd = sDc + kk * 4 + sel;
               const double* pl = sAccL + kk * 8 + (sel < 3 ? 2 + sel : 7);   // line rows' share of the weight (xx, yx, yy; entry 7 of a row is never written: zero)
+              // four base rows' operands are loaded together ahead of their four instructions: one LDS round trip per group
+              // instead of two per pair (the register allocator, at its limit next to the row state, otherwise reuses the same few
+              // registers for every load)
 #pragma unroll
-              for (int q = 0; q < 2 * NEP_MAX_POL; q += 2) {
-                double d0 = pd[(4 * q) * 4], d1 = pd[(4 * q + 4) * 4];
-                if (q < NEP_MAX_POL) { d0 += pl[(4 * q) * 8]; d1 += pl[(4 * q + 4) * 8]; }   // base rows < 32: the position control points
-                const double x0 = px[(4 * q) * SBS], x1 = px[(4 * q + 4) * SBS];
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, d0 * x0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, d1 * x1, acc1, 0, 0, 0);
+              for (int g = 0; g < 4; g++) {
+                double xg[4], dg[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { xg[u] = px[(16 * g + 4 * u) * SBS]; dg[u] = pd[(16 * g + 4 * u) * 4]; }
+                if (g < 2) {
+#pragma unroll
+                  for (int u = 0; u < 4; u++) dg[u] += pl[(16 * g + 4 * u) * 8];     // base rows < 32: the position control points
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                  acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xg[u], dg[u] * xg[u], acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xg[u + 1], dg[u + 1] * xg[u + 1], acc1, 0, 0, 0);
+                }
               }
               const int bi_ = sel == 0 ? 0 : (sel == 3 ? 2 : 1), bj_ = sel == 0 || sel == 1 ? 0 : (sel == 2 ? 1 : 2);
 #pragma unroll
@@ -505,11 +516,20 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               const double* pt = sTc + kk * 6 + (i16 < 6 ? i16 : 0);
               const double* pl = sAccL + kk * 8 + (i16 < 2 ? i16 : ((i16 == 3 || i16 == 4) ? i16 + 2 : 7));
 #pragma unroll
-              for (int q = 0; q < 2 * NEP_MAX_POL; q += 2) {
-                double t0 = pt[(4 * q) * 6], t1 = pt[(4 * q + 4) * 6];
-                if (q < NEP_MAX_POL) { t0 += pl[(4 * q) * 8]; t1 += pl[(4 * q + 4) * 8]; }
-                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(px[(4 * q) * SBS], t0, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(px[(4 * q + 4) * SBS], t1, acc1, 0, 0, 0);
+              for (int g = 0; g < 4; g++) {
+                double xg[4], tg[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { xg[u] = px[(16 * g + 4 * u) * SBS]; tg[u] = pt[(16 * g + 4 * u) * 6]; }
+                if (g < 2) {
+#pragma unroll
+                  for (int u = 0; u < 4; u++) tg[u] += pl[(16 * g + 4 * u) * 8];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 4; u += 2) {
+                  acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xg[u], tg[u], acc0, 0, 0, 0);
+                  acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xg[u + 1], tg[u + 1], acc1, 0, 0, 0);
+                }
               }
               if (i16 < 6) {
 #pragma unroll 1
@@ -592,9 +612,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             }
           }
 #endif
-          for (int e = otid(); e < 2 * nz * nz; e += BS) {   // z-x and z-y blocks
-            const int i = 2 * nz + e / (2 * nz), j = e % (2 * nz);
-            sM[i * MS + j] = has_qc ? sc[sWq] * sGq[i] * sGq[j] : 0.0;
+          if (has_qc) {   // z-x and z-y blocks: only the ball row couples z to x and y (without it the two diagonal blocks are factored apart and these entries are never read)
+            for (int e = otid(); e < 2 * nz * nz; e += BS) {
+              const int i = 2 * nz + e / (2 * nz), j = e % (2 * nz);
+              sM[i * MS + j] = sc[sWq] * sGq[i] * sGq[j];
+            }
           }
           __syncthreads();                                                                       // barrier 3
           TICK(2);
