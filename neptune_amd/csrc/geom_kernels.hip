@@ -15,6 +15,9 @@
 //   compacted in reference loop order with a wave ballot.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+#include <cstring>
+
 #include "nep_device.h"
 #include "../../include/neptune_frontend.h"
 #include "ent_device.h"
@@ -189,6 +192,187 @@ __global__ __launch_bounds__(64) void hull_kernel(const nep_traj_rec* __restrict
   hull_body(r, ts, i, T_span, drone_radius, (long)jt * num_pol + i, false, hull_xy, hull_nv, hull0_xy, hull0_nv, flags);
 }
 
+// ---- the batched hulls, eight to a wave -----------------------------------------------------------
+// hull_kernel above spends most of its instructions with two active lanes (the two monotone chains).  Here one wave takes
+// ALL planning intervals of one committed trajectory: interval i is worked by the eight lanes 8 i .. 8 i + 7, each holding up
+// to eight of the interval's (<= 64) inflated control points.  Same algorithm per hull — rank sort, duplicate removal, the
+// two chains with the same cross products in the same order — so the output is the same bits; per wave the chains of eight
+// hulls advance together and the sort's comparisons are spread over all 64 lanes.
+constexpr int kGrpPts = 8;                         // points per lane
+constexpr int kGrpSxy = 2 * 64;                    // doubles per group: the sorted points
+
+// Hull of the group's n points (point p = sub + 8 j in px[j], py[j]); sxy: this group's LDS.  Every lane of the wave must call
+// it (workgroup barriers inside).  A chain's stack is a subsequence of the sorted points, so it is kept as a 64-bit mask over
+// their indices in the chain lane's registers (push = set a bit, pop = clear the top one, the entry under the top = the next
+// set bit) instead of two coordinate stacks in LDS: a wave of eight hulls needs 10 KB instead of 27, and three times as many
+// waves fit a CU.  Writes the first min(k, cap) vertices to out_xy (lower chain, then the upper chain without its two end
+// points: the lower chain's ends) and returns k.
+__device__ __forceinline__ int group_hull(int n, const double (&px)[kGrpPts], const double (&py)[kGrpPts], double* sxy, int g, int sub,
+                                          bool write, double* __restrict__ out_xy, int cap) {
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kGrpPts; j++) { const int p = sub + 8 * j; if (p < n) { sxy[2 * p] = px[j]; sxy[2 * p + 1] = py[j]; } }
+  __syncthreads();
+  int rank[kGrpPts];
+#pragma unroll
+  for (int j = 0; j < kGrpPts; j++) rank[j] = 0;
+  for (int i = 0; i < n; i++) {                     // (ties by point index so that the ranks are a permutation: as wave_hull)
+    const double qx = sxy[2 * i], qy = sxy[2 * i + 1];
+#pragma unroll
+    for (int j = 0; j < kGrpPts; j++) {
+      if (8 * j >= n) break;
+      if (lex_less(qx, qy, px[j], py[j]) || (qx == px[j] && qy == py[j] && i < sub + 8 * j)) rank[j]++;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kGrpPts; j++) { if (sub + 8 * j < n) { sxy[2 * rank[j]] = px[j]; sxy[2 * rank[j] + 1] = py[j]; } }
+  __syncthreads();
+  // unique: sorted position p survives if it differs from its predecessor; new position = number of survivors before it
+  double ux[kGrpPts], uy[kGrpPts]; int pos[kGrpPts]; bool keep[kGrpPts];
+  int m = 0;
+#pragma unroll
+  for (int j = 0; j < kGrpPts; j++) {
+    const int p = sub + 8 * j;
+    ux[j] = 0; uy[j] = 0; keep[j] = false;
+    if (p < n) { ux[j] = sxy[2 * p]; uy[j] = sxy[2 * p + 1]; keep[j] = p == 0 || ux[j] != sxy[2 * p - 2] || uy[j] != sxy[2 * p - 1]; }
+    const unsigned bits = (unsigned)(__ballot(keep[j]) >> (8 * g)) & 0xffu;
+    pos[j] = m + __popc(bits & ((1u << sub) - 1u));
+    m += __popc(bits);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kGrpPts; j++) { if (keep[j]) { sxy[2 * pos[j]] = ux[j]; sxy[2 * pos[j] + 1] = uy[j]; } }
+  __syncthreads();
+  unsigned long long mask = 0;
+  if (sub < 2 && m >= 2) {          // lane 0 of the group: lower chain (indices ascending); lane 1: upper chain (descending)
+    const bool lower = sub == 0;
+    int kc = 0;
+    double ax = 0, ay = 0, bx = 0, by = 0;   // the two top entries
+    for (int i = 0; i < m; i++) {
+      const int idx = lower ? i : m - 1 - i;
+      const double x = sxy[2 * idx], y = sxy[2 * idx + 1];
+      while (kc >= 2 && cross3(ax, ay, bx, by, x, y) <= 0.0) {
+        const int top = lower ? 63 - __clzll((long long)mask) : __ffsll((long long)mask) - 1;
+        mask &= ~(1ull << top);
+        kc--; bx = ax; by = ay;
+        if (kc >= 2) {
+          const int t1 = lower ? 63 - __clzll((long long)mask) : __ffsll((long long)mask) - 1;
+          const unsigned long long rest = mask & ~(1ull << t1);
+          const int t2 = lower ? 63 - __clzll((long long)rest) : __ffsll((long long)rest) - 1;
+          ax = sxy[2 * t2]; ay = sxy[2 * t2 + 1];
+        }
+      }
+      mask |= 1ull << idx; kc++;
+      ax = bx; ay = by; bx = x; by = y;
+    }
+  }
+  const unsigned long long L = __shfl(mask, 8 * g), U = __shfl(mask, 8 * g + 1);
+  const int kl = __popcll(L), ku = __popcll(U);
+  const int k = m >= 2 ? kl + ku - 2 : m;
+  if (write) {
+    if (m == 1) { if (sub == 0 && cap > 0) { out_xy[0] = sxy[0]; out_xy[1] = sxy[1]; } }
+    else if (m >= 2) {
+#pragma unroll
+      for (int j = 0; j < kGrpPts; j++) {
+        const int p = sub + 8 * j;
+        if (p < m) {
+          const double x = sxy[2 * p], y = sxy[2 * p + 1];
+          if ((L >> p) & 1ull) { const int o = __popcll(L & ((1ull << p) - 1ull)); if (o < cap) { out_xy[2 * o] = x; out_xy[2 * o + 1] = y; } }
+          if (((U >> p) & 1ull) && p != 0 && p != m - 1) {
+            const int o = kl + __popcll(U >> (p + 1)) - 1;      // entries pushed before it that are still on the stack, minus the first
+            if (o < cap) { out_xy[2 * o] = x; out_xy[2 * o + 1] = y; }
+          }
+        }
+      }
+    }
+  }
+  return k;
+}
+
+// One block (= one wave) per (scene, committed trajectory): interval i on lanes 8 i .. 8 i + 7 (num_pol <= 8).
+__global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __restrict__ recs, int n_rec_per_scene,
+                                                        const double* __restrict__ ts0, long ts_scene_stride,
+                                                        int num_pol, double T_span, double drone_radius,
+                                                        double* __restrict__ hull_xy, int* __restrict__ hull_nv,
+                                                        double* __restrict__ hull0_xy, int* __restrict__ hull0_nv,
+                                                        double* __restrict__ bend_xy, int* __restrict__ bend_n, int* __restrict__ flags) {
+  __shared__ __attribute__((aligned(16))) double s_sxy[8][kGrpSxy];
+  __shared__ double s_cpx[8][kHullCP], s_cpy[8][kHullCP], stimes[NEP_TRAJ_MAX_SEG + 2];
+  const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
+  const int jt = blockIdx.x;                      // scene * n_rec + j
+  const int scene = jt / n_rec_per_scene;
+  const nep_traj_rec* r = recs + jt;
+  if (lane == 0 && bend_n) {                      // bend points travel with the record (neptune_ros.cpp:457-476)
+    int nb = r->n_bend; if (nb > kBend) nb = kBend; if (nb < 0) nb = 0;
+    bend_n[jt] = (r->valid && r->is_agent) ? nb : 0;
+    for (int b = 0; b < nb; b++) { bend_xy[((long)jt * kBend + b) * 2] = r->bend[b][0]; bend_xy[((long)jt * kBend + b) * 2 + 1] = r->bend[b][1]; }
+  }
+  const bool act = g < num_pol;                   // this group has an interval
+  const long out = (long)jt * num_pol + g;
+  if (!(r->valid && r->is_agent) || r->pwp.n_seg <= 0) {   // neptune.cpp:244-262, 332
+    if (act && sub == 0) { hull_nv[out] = 0; if (hull0_nv) hull0_nv[out] = 0; }
+    return;
+  }
+  // bulk-synchronous round: every agent of a scene replans from the same t_start (that of its first local slot)
+  const double ts = *(const double*)((const char*)ts0 + (long)scene * ts_scene_stride);
+  const double t0 = ts + g * T_span, t1 = ts + (g + 1) * T_span;   // neptune.cpp:273-280
+  const int n = r->pwp.n_seg;
+  if (lane <= n) stimes[lane] = r->pwp.times[lane];
+  __syncthreads();
+  // std::lower_bound / upper_bound on the sorted knot vector (neptune.cpp:379-389): counts of knots < t0 and <= t1
+  int first = -1, last = -1;
+  for (int k = 0; k <= n; k++) { const double tk = stimes[k]; first += tk < t0 ? 1 : 0; last += tk <= t1 ? 1 : 0; }
+  if (first < 0) first = 0; if (first > n - 1) first = n - 1;
+  if (last < 0) last = 0; if (last > n - 1) last = n - 1;
+  int nseg = last - first + 1; if (nseg < 0) nseg = 0;
+  if (nseg > kHullCP / 4) { nseg = kHullCP / 4; if (act && sub == 0 && flags) atomicOr(flags, NEP_FLAG_HULL_OVERFLOW); }   // (see hull_body)
+  if (!act) nseg = 0;
+  const int np0 = 4 * nseg;
+  double* cpx = s_cpx[g]; double* cpy = s_cpy[g];
+  for (int v = sub; v < 2 * np0; v += 8) {        // one value per (segment, control point, axis)
+    const int sl = v >> 3, k = (v >> 1) & 3, ax = v & 1;
+    const int s = first + sl;
+    double _t;                                                     // neptune.cpp:399-424
+    if (s != last) _t = stimes[s + 1] - stimes[s];
+    else if (t1 > stimes[s + 1]) _t = stimes[s + 1] - stimes[s];
+    else _t = t1 - stimes[s];
+    if (_t > T_span) _t = T_span; else if (_t < 0) _t = 0;
+    const double c0 = _t * _t * _t, c1 = _t * _t, c2 = _t, c3 = 1.0;
+    const double* P = r->pwp.coeff[ax][s];                          // V = (P*C)*A^-1, :426-429
+    const double val = (((P[0] * c0) * cAPosInv[0][k] + (P[1] * c1) * cAPosInv[1][k]) + (P[2] * c2) * cAPosInv[2][k]) + (P[3] * c3) * cAPosInv[3][k];
+    if (ax == 0) cpx[sl * 4 + k] = val; else cpy[sl * 4 + k] = val;
+  }
+  __syncthreads();
+  const double dx = r->bbox[0] / 2.0 + drone_radius, dy = r->bbox[1] / 2.0 + drone_radius;  // neptune.cpp:340
+  const bool inflate = !(sqrt(dx * dx + dy * dy) < 1e-6);
+  const int np = inflate ? 4 * np0 : np0;          // inflated points: 4 corners per control point (:442-445)
+  double px[kGrpPts], py[kGrpPts];
+#pragma unroll
+  for (int j = 0; j < kGrpPts; j++) {
+    const int p = sub + 8 * j;
+    px[j] = 0; py[j] = 0;
+    if (p < np) {
+      if (inflate) {
+        const int c = p >> 2, q = p & 3;
+        const double x = cpx[c], y = cpy[c];
+        px[j] = (q < 2) ? x + dx : x - dx;
+        py[j] = (q == 0 || q == 3) ? y + dy : y - dy;
+      } else { px[j] = cpx[p]; py[j] = cpy[p]; }
+    }
+  }
+  int k = group_hull(np, px, py, s_sxy[g], g, sub, act, hull_xy + out * kHullV * 2, kHullV);
+  if (k > kHullV) { k = kHullV; if (act && sub == 0 && flags) atomicOr(flags, NEP_FLAG_HULL_OVERFLOW); }
+  if (act && sub == 0) hull_nv[out] = k;
+  if (hull0_nv) {
+#pragma unroll
+    for (int j = 0; j < kGrpPts; j++) { const int p = sub + 8 * j; px[j] = p < np0 ? cpx[p] : 0; py[j] = p < np0 ? cpy[p] : 0; }
+    int k0 = group_hull(np0, px, py, s_sxy[g], g, sub, act, hull0_xy + out * 2, 1);      // only col(0) is read (:722-734)
+    if (k0 > kHullV) k0 = kHullV;
+    if (act && sub == 0) hull0_nv[out] = k0;
+  }
+}
+
 void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_guess* guess,
                   const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
   launch_hulls_ts(recs, n_scenes, n_rec, &guess->t_start, (long)sizeof(nep_guess), sp, ps, st);
@@ -199,6 +383,13 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
   if (blocks <= 0) return;
   // the uninflated hull is read only by the entangle rows (col(0), solver_gurobi_poly.cpp:722-734)
   const bool need0 = sp.ent_enabled != 0;
+  static const bool one_per_wave = getenv("NEP_HULL_KERNEL") && !strcmp(getenv("NEP_HULL_KERNEL"), "wave");   // (A/B: the round-1 kernel)
+  if (sp.num_pol <= 8 && !one_per_wave) {
+    hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * n_rec), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
+                       sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
+                       need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr, ps.flags);
+    return;
+  }
   hipLaunchKernelGGL(hull_kernel, dim3(blocks), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
                      sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
                      need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr, ps.flags);
