@@ -349,6 +349,14 @@ int nep_batch_set_line_cull(nep_batch_t* h, double radius);
  * (row state in LDS with a global spill: config-5 sized problems).  Same solver, same results to rounding.             */
 int nep_batch_qp_placement(nep_batch_t* h);
 
+/* Launch order of the interior-point workgroups (a scheduling matter: results do not depend on it).  A batch of more than
+ * 1 024 replans runs as several waves of workgroups over the chip and their durations spread about 1 : 3, so by default the
+ * workgroups of a launch are ordered longest-expected-first, the expectation being the measured device time of the same
+ * slot's previous replan (nep_stats.solve_us; the first replan of a handle runs in slot order).  enable = 0 keeps slot order.
+ * nep_batch_debug_launch_order copies the order of the last replan (n_out = 0 when it ran in slot order).              */
+int nep_batch_set_launch_order(nep_batch_t* h, int32_t enable);
+int nep_batch_debug_launch_order(nep_batch_t* h, int32_t* order, int32_t cap, int32_t* n_out);
+
 /* setMaxRuntime for the batched handle (0 = no wall-clock limit, the default): see nep_backend_set_max_runtime. */
 int nep_batch_set_max_runtime(nep_batch_t* h, double seconds);
 

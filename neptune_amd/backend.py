@@ -303,6 +303,16 @@ class BatchBackend:
         """the interior-point kernel this handle launches (nep_batch_qp_placement)"""
         return "qp_reg_kernel" if lib().nep_batch_qp_placement(self._h) == 1 else "qp_kernel"
 
+    def set_launch_order(self, enable=True):
+        """QP workgroups longest-expected-first (default) or in slot order: nep_batch_set_launch_order"""
+        check(lib().nep_batch_set_launch_order(self._h, 1 if enable else 0))
+
+    def launch_order(self):
+        """the workgroup -> slot order of the last replan, or None when it ran in slot order (nep_batch_debug_launch_order)"""
+        out = np.zeros(self.n_scenes * self.n_local, dtype=np.int32); n = C.c_int32(0)
+        check(lib().nep_batch_debug_launch_order(self._h, abi.iptr(out), len(out), C.byref(n)))
+        return out[:n.value].copy() if n.value else None
+
     def set_max_runtime(self, seconds):
         """wall-clock budget of one solve (Gurobi TimeLimit; 0 = off): nep_batch_set_max_runtime"""
         check(lib().nep_batch_set_max_runtime(self._h, float(seconds)))
@@ -322,9 +332,14 @@ class BatchBackend:
         check(lib().nep_batch_debug_conflicts(self._h, scene, out.ctypes.data_as(C.POINTER(C.c_uint8))))
         return out
 
-    def solutions(self):
+    def solutions(self, timing=False):
+        """the nep_solution records of the last replan.  stats.solve_us (the workgroup's measured device time, which differs
+        from run to run) is zeroed unless timing=True, so that two runs' records can be compared byte for byte."""
         self.torch.cuda.synchronize(self.device)
-        return self.d_solution.cpu().numpy().view(abi.SOLUTION_DTYPE).copy()
+        sol = self.d_solution.cpu().numpy().view(abi.SOLUTION_DTYPE).copy()
+        if not timing:
+            sol["stats"]["solve_us"] = 0.0
+        return sol
 
     def states(self):
         self.torch.cuda.synchronize(self.device)

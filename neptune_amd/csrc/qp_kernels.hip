@@ -46,7 +46,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   // (the dynamic part — line coefficients, then line-row state — starts at smem + kFixedDoubles + 32: ldyn below)
 
   const int tid = threadIdx.x;
-  const int slot = blockIdx.x;
+  const int slot = ps.order ? ps.order[blockIdx.x] : (int)blockIdx.x;   // (launch order: see order_kernel)
+  const long long t_wg0 = (long long)wall_clock64();          // this workgroup's lifetime goes to stats.solve_us (100 MHz ticks)
   const nep_guess* __restrict__ g = ps.guess + slot;
   // A guess without segments (front-end miss: K = 0) or with more than the handle plans for cannot be solved: such a slot
   // reports NEP_FAILED with an empty solution and publishes nothing (neptune_ros.cpp:651-663); K_ok guards every use of K.
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((culled && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;   // rows solved for (null rows of failed LPs excluded)
-    sol->stats.objective = objective; sol->stats.solve_us = 0.0;
+    sol->stats.objective = objective; sol->stats.solve_us = (double)((long long)wall_clock64() - t_wg0) * 0.01;   // the batched handle's per-replan device time (and the next launch's ordering key)
     sol->K = Ko; sol->n_states = ns;
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)
@@ -804,6 +805,33 @@ void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const Q
   (void)attr[cull].ensure(cull ? (const void*)qp_kernel<true> : (const void*)qp_kernel<false>, lds_bytes);   // (a failure surfaces as the launch error)
   if (cull) hipLaunchKernelGGL(qp_kernel<true>, dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
   else hipLaunchKernelGGL(qp_kernel<false>, dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
+}
+
+
+// Launch order of the QP workgroups: longest expected solve first.  A launch is a handful of waves of workgroups over the chip
+// (1 024 at a time at four per CU) whose durations spread 1 : 3 (iteration count; the terminal ball row's 3 nz x 3 nz
+// factorisation); in slot order the long ones that happen to start last set the kernel's end while most CUs idle.  The previous
+// replan of the same slot is the predictor (a receding-horizon replanner re-solves almost the same problem): a counting
+// sort of the slots by its measured device time (stats.solve_us, 8 us bins), descending.  Results do not depend on the order
+// (every workgroup owns its slot).
+__device__ __forceinline__ int order_key(const nep_solution* __restrict__ prev, int i) {
+  const double us = prev[i].stats.solve_us;
+  int k = us > 0.0 ? (int)(us * 0.125) : 0;
+  return k > 63 ? 63 : k;
+}
+__global__ __launch_bounds__(1024) void order_kernel(int n, const nep_solution* __restrict__ prev, int* __restrict__ order) {
+  __shared__ int hist[64], base[64];
+  const int tid = threadIdx.x;
+  if (tid < 64) hist[tid] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[63 - order_key(prev, i)], 1);
+  __syncthreads();
+  if (tid == 0) { int o = 0; for (int b = 0; b < 64; b++) { base[b] = o; o += hist[b]; } }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[63 - order_key(prev, i)], 1)] = i;
+}
+void launch_qp_order(int n_slots, const nep_solution* prev, int* order, hipStream_t st) {
+  if (n_slots > 0) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, n_slots, prev, order);
 }
 
 }  // namespace nep

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   int* sI = (int*)(smem + kFixedDoubles);      // [0..8] line offsets, [16..] flags (same map as qp_kernel)
 
   const int tid = threadIdx.x;
-  const int slot = blockIdx.x;
+  const int slot = ps.order ? ps.order[blockIdx.x] : (int)blockIdx.x;   // (launch order: see order_kernel)
+  const long long t_wg0 = (long long)wall_clock64();          // this workgroup's lifetime goes to stats.solve_us (100 MHz ticks)
   const nep_guess* __restrict__ g = ps.guess + slot;
   const int K_in = g->K;
   const bool K_ok = K_in >= 1 && K_in <= NEP_MAX_POL && K_in <= sp.num_pol;   // (see qp_kernel)
@@ -879,7 +880,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((CULL && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;
-    sol->stats.objective = objective; sol->stats.solve_us = 0.0;
+    sol->stats.objective = objective; sol->stats.solve_us = (double)((long long)wall_clock64() - t_wg0) * 0.01;   // the batched handle's per-replan device time (and the next launch's ordering key)
     sol->K = Ko; sol->n_states = ns;
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)

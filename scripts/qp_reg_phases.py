@@ -38,3 +38,9 @@ print("  finish-time histogram (us):", " ".join("%d:%d" % (int(edges[i + 1]), hi
 busy = np.zeros(int(en.max()) + 2)
 for a, b in zip(st, en): busy[int(a):int(b) + 1] += 1
 print("  resident workgroups over time (every 40 us):", " ".join(str(int(busy[i])) for i in range(0, len(busy), 40)))
+if os.environ.get("NEP_PH_LAST"):
+    idx = np.argsort(-en)[:24]
+    print("  last finishers (slot, iterations, start us, duration us, gather+staging+start cycles):")
+    for i in idx: print("   ", int(i), int(c[i, 12]), "%.1f" % st[i], "%.1f" % (wd[i] / 100.0), int(c[i, 13] + c[i, 14] + c[i, 15]))
+    print("  iterations vs duration (mean us by iteration count):", {int(k): round(float((wd[c[:, 12] == k] / 100.0).mean()), 1) for k in np.unique(c[:, 12])})
+    print("  start time by iteration count (mean us):", {int(k): round(float(st[c[:, 12] == k].mean()), 1) for k in np.unique(c[:, 12])})

@@ -192,3 +192,31 @@ def test_wall_clock_time_limit(be, oracle):
     bb.replan(d_com, d_g)
     assert bb.solutions().tobytes() == ref.tobytes()
     bb.close()
+
+
+def test_launch_order_does_not_change_results(be):
+    """nep_batch_set_launch_order: from a handle's second replan on, the QP workgroups of a batch of more than 1 024 replans are
+    launched longest-expected-first (the previous replan's measured device time is the key).  A scheduling matter: the
+    records of the ordered launch equal those of the slot-order launch byte for byte, and the order is a permutation that
+    starts with the slots that took longest."""
+    scs = [scene.make_scene(64, 20, seed=s) for s in (0, 1, 2)]
+    S = 18                                                        # 1 152 replans: more than one wave of workgroups
+    p = scs[0]["par"]
+    com = np.stack([scs[s % 3]["committed"] for s in range(S)]); gue = np.stack([scs[s % 3]["guesses"] for s in range(S)])
+    bb = be.BatchBackend(p, scs[0]["statics"], n_scenes=S)
+    for s in range(1, S):
+        bb.set_scene_statics(s, scs[s % 3]["statics"])
+    d_com, d_gue = bb.to_device(com), bb.to_device(gue)
+    bb.replan(d_com, d_gue)
+    assert bb.launch_order() is None                              # first replan of the handle: slot order
+    first = bb.solutions(); t_first = bb.solutions(timing=True)["stats"]["solve_us"]
+    assert (t_first > 0).all()
+    bb.replan(d_com, d_gue)
+    order = bb.launch_order()
+    assert order is not None and sorted(order.tolist()) == list(range(S * 64))
+    assert t_first[order[:64]].mean() > t_first[order[-64:]].mean() + 8.0      # (8 us bins)
+    assert bb.solutions().tobytes() == first.tobytes()
+    bb.set_launch_order(False)
+    bb.replan(d_com, d_gue)
+    assert bb.launch_order() is None and bb.solutions().tobytes() == first.tobytes()
+    bb.close()
