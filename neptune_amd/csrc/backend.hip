@@ -81,7 +81,7 @@ struct Engine {
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
-  DevBuf<int> d_order; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
+  DevBuf<int> d_order, d_order_key; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
@@ -141,7 +141,7 @@ struct Engine {
     const long expect_seg = expect / NEP_MAX_POL;
     use_reg = expect_seg <= 8L * qp_reg_slots() + 8;
     if (const char* f = getenv("NEP_QP_LPT")) lpt = atoi(f) != 0;
-    if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; }
+    if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; if (int e = d_order_key.ensure((size_t)slots)) return e; }
     if (const char* f = getenv("NEP_QP_KERNEL")) { if (!strcmp(f, "reg")) use_reg = true; else if (!strcmp(f, "lds")) use_reg = false; }
     if (use_reg) { lds_lines = NEP_MAX_POL * 8 * qp_reg_slots(); lds_rows = 4 * lds_lines; lds_bytes = qp_reg_lds_bytes(); }
     rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
@@ -251,20 +251,21 @@ struct Engine {
     }
     if (timing) hipEventRecord(next_event(), st);
     ps.order = nullptr; last_ordered = false;
-    if (lpt && have_history && slots > 1024 && ps.solution && d_order.n >= (size_t)slots) {   // (more than one wave of workgroups)
-      launch_qp_order(slots, ps.solution, d_order.p, st);
+    ps.order_key = (lpt && d_order_key.n >= (size_t)slots) ? d_order_key.p : nullptr;
+    if (ps.order_key && have_history && slots > 1024 && d_order.n >= (size_t)slots) {   // (more than one wave of workgroups)
+      launch_qp_order(slots, d_order_key.p, d_order.p, st);
       ps.order = d_order.p; last_ordered = true;
     }
     if (use_reg) launch_qp_reg(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     else launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
-    have_history = ps.solution != nullptr;
+    have_history = ps.order_key != nullptr;
     if (timing) hipEventRecord(next_event(), st);
     HIPCHK(hipGetLastError());
     return 0;
   }
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
-    d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release();
+    d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release();
     d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release();
     d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
@@ -885,7 +886,8 @@ int nep_batch_qp_placement(nep_batch_t* h) { return h ? (h->eng.use_reg ? 1 : 0)
 
 int nep_batch_set_launch_order(nep_batch_t* h, int32_t enable) {
   if (!h) return fail(NEP_E_ARG, "null handle");
-  if (enable && !h->eng.d_order.p) { if (int e = h->eng.d_order.ensure((size_t)h->slots)) return e; }
+  if (enable) { if (int e = h->eng.d_order.ensure((size_t)h->slots)) return e; if (int e = h->eng.d_order_key.ensure((size_t)h->slots)) return e; }
+  if (!enable) h->eng.have_history = false;
   h->eng.lpt = enable != 0;
   return 0;
 }

@@ -61,6 +61,7 @@ struct ProblemSet {
   int* lp_stats;                 // [slots][NEP_MAX_POL][2]  (LPs attempted, LPs without a line) per segment, written by the separator
   int lines_override;            // 1: line buckets were filled by the host (test hook)
   const int* order;              // [slots] workgroup -> slot (longest expected solve first, see order_kernel) or null: identity
+  int* order_key;                // [slots] this launch's measured device time in 8 us bins (the next launch's ordering key) or null
   // QP scratch when the row state does not fit LDS
   double* row_scratch;           // [slots][2][rows_cap]
   int rows_cap;
@@ -121,7 +122,7 @@ void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const Q
                const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 size_t qp_lds_fixed_bytes();
 // the register-resident placement of the same solver (qp_reg_kernel.hip)
-void launch_qp_order(int n_slots, const nep_solution* prev, int* order, hipStream_t st);
+void launch_qp_order(int n_slots, const int* key, int* order, hipStream_t st);
 void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                    const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 int qp_reg_slots();

@@ -94,6 +94,13 @@ __device__ __forceinline__ double wave_max(double v) {
   return fmax(fmax(bcast(v, 0), bcast(v, 16)), fmax(bcast(v, 32), bcast(v, 48)));
 }
 
+
+// x / d for 0 <= x < 1024 and a wave-uniform 1 <= d <= 64 as one multiply and a shift (exact in that range; the magic numbers
+// come from constant memory through the scalar unit).  A real integer division expands to a float reciprocal sequence on
+// the VALU which the compiler hoists out of the iteration loops and then has to keep (spill) across them.
+__constant__ unsigned int cDivMagic[65] = {0, 65537, 32769, 21846, 16385, 13108, 10923, 9363, 8193, 7282, 6554, 5958, 5462, 5042, 4682, 4370, 4097, 3856, 3641, 3450, 3277, 3121, 2979, 2850, 2731, 2622, 2521, 2428, 2341, 2260, 2185, 2115, 2049, 1986, 1928, 1873, 1821, 1772, 1725, 1681, 1639, 1599, 1561, 1525, 1490, 1457, 1425, 1395, 1366, 1338, 1311, 1286, 1261, 1237, 1214, 1192, 1171, 1150, 1130, 1111, 1093, 1075, 1058, 1041, 1025};
+__device__ __forceinline__ int div_small(int x, int d) { return (int)(((unsigned)x * cDivMagic[d]) >> 16); }
+
 // 1/a: v_rcp_f64 seed + Newton steps (the IEEE divide expands to ~3x the work).  The row passes
 // only use it inside the Newton direction (weights lam/s, ratio tests): one step suffices there,
 // the residuals that decide convergence never go through it.

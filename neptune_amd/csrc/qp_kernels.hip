@@ -748,7 +748,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
     }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((culled && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;   // rows solved for (null rows of failed LPs excluded)
-    sol->stats.objective = objective; sol->stats.solve_us = (double)((long long)wall_clock64() - t_wg0) * 0.01;   // the batched handle's per-replan device time (and the next launch's ordering key)
+    sol->stats.objective = objective; { const long long dt_ = (long long)wall_clock64() - t_wg0; sol->stats.solve_us = (double)dt_ * 0.01; if (ps.order_key) { const long long k_ = dt_ / 800; ps.order_key[slot] = k_ > 63 ? 63 : (int)k_; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
     sol->K = Ko; sol->n_states = ns;
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)
@@ -812,26 +812,25 @@ void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const Q
 // (1 024 at a time at four per CU) whose durations spread 1 : 3 (iteration count; the terminal ball row's 3 nz x 3 nz
 // factorisation); in slot order the long ones that happen to start last set the kernel's end while most CUs idle.  The previous
 // replan of the same slot is the predictor (a receding-horizon replanner re-solves almost the same problem): a counting
-// sort of the slots by its measured device time (stats.solve_us, 8 us bins), descending.  Results do not depend on the order
+// sort of the slots by its measured device time (stats.solve_us; the kernel leaves it in 8 us bins in ps.order_key), descending.  Results do not depend on the order
 // (every workgroup owns its slot).
-__device__ __forceinline__ int order_key(const nep_solution* __restrict__ prev, int i) {
-  const double us = prev[i].stats.solve_us;
-  int k = us > 0.0 ? (int)(us * 0.125) : 0;
-  return k > 63 ? 63 : k;
+__global__ __launch_bounds__(1024) void order_kernel(int n, const int* __restrict__ key, int* __restrict__ order) {
+  // (sixteen sub-histograms by thread index: most keys fall into two or three bins, and one counter per bin would serialise
+  // the whole launch's atomics on them)
+  __shared__ int hist[64][16], tot[64];
+  const int tid = threadIdx.x, sub = tid & 15;
+  hist[tid >> 4][sub] = 0;
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[63 - (key[i] & 63)][sub], 1);
+  __syncthreads();
+  if (tid < 64) { int o = 0; for (int u = 0; u < 16; u++) { const int c = hist[tid][u]; hist[tid][u] = o; o += c; } tot[tid] = o; }
+  __syncthreads();
+  if (tid == 0) { int o = 0; for (int b = 0; b < 64; b++) { const int c = tot[b]; tot[b] = o; o += c; } }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) { const int b = 63 - (key[i] & 63); order[tot[b] + atomicAdd(&hist[b][sub], 1)] = i; }
 }
-__global__ __launch_bounds__(1024) void order_kernel(int n, const nep_solution* __restrict__ prev, int* __restrict__ order) {
-  __shared__ int hist[64], base[64];
-  const int tid = threadIdx.x;
-  if (tid < 64) hist[tid] = 0;
-  __syncthreads();
-  for (int i = tid; i < n; i += 1024) atomicAdd(&hist[63 - order_key(prev, i)], 1);
-  __syncthreads();
-  if (tid == 0) { int o = 0; for (int b = 0; b < 64; b++) { base[b] = o; o += hist[b]; } }
-  __syncthreads();
-  for (int i = tid; i < n; i += 1024) order[atomicAdd(&base[63 - order_key(prev, i)], 1)] = i;
-}
-void launch_qp_order(int n_slots, const nep_solution* prev, int* order, hipStream_t st) {
-  if (n_slots > 0) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, n_slots, prev, order);
+void launch_qp_order(int n_slots, const int* key, int* order, hipStream_t st) {
+  if (n_slots > 0) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, n_slots, key, order);
 }
 
 }  // namespace nep

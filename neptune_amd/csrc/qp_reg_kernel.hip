@@ -123,8 +123,9 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       sI[43] = over;
     }
     __syncthreads();
-    const int L = sI[NEP_MAX_POL];
-    L_used = L; L_all = sI[42];
+    // (values every thread reads from LDS are wave-uniform: readfirstlane moves them, and what is computed from them, to SGPRs)
+    const int L = __builtin_amdgcn_readfirstlane(sI[NEP_MAX_POL]);
+    L_used = L; L_all = __builtin_amdgcn_readfirstlane(sI[42]);
     if (tid < 9) {
       if (tid < 3) {
         const double* c = sCoef + (tid * 8 + (K - 1)) * 4;
@@ -159,11 +160,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     __syncthreads();
     TICK(13);
     const double dix = sCoef[3] - sc[sFinal0], diy = sCoef[32 + 3] - sc[sFinal1], diz = sCoef[64 + 3] - sc[sFinal2];
-    has_qc = sqrt(dix * dix + diy * diy + diz * diz) < 1.0;   // :697-702
-    z_override = sqrt(dix * dix + diy * diy) < 1.0;           // :879-880
+    has_qc = __builtin_amdgcn_readfirstlane(sqrt(dix * dix + diy * diy + diz * diz) < 1.0 ? 1 : 0) != 0;   // :697-702
+    z_override = __builtin_amdgcn_readfirstlane(sqrt(dix * dix + diy * diy) < 1.0 ? 1 : 0) != 0;           // :879-880
     const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);
 
-    const int li = tid >> 5, lk = (tid >> 3) & 3, slice = tid & 7;
+    const int li = tid >> 5, slice = tid & 7;
     const int seg_cnt = sI[li + 1] - sI[li];                  // lines of my segment (0 for segments >= K)
     // slots in use by this wave (it covers segments 2w and 2w + 1): wave-uniform, so the slot loop branches on the scalar unit
     int n_u;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       n_u = __builtin_amdgcn_readfirstlane(m < RS ? m : RS);
     }
     int my_cnt = seg_cnt - slice; my_cnt = my_cnt > 0 ? (my_cnt + 7) >> 3 : 0;       // my rows (slots u < my_cnt hold real lines)
-    const bool over = sI[43] != 0;
+    const bool over = __builtin_amdgcn_readfirstlane(sI[43]) != 0;
     const lds_ptr cbase = ldyn + (li * SEGCAP + slice);
 
     // One pass over this thread's line rows.  body(ok, n1, n2, h, s, lambda); padded slots see the dummy line (0, 0, 1) with
@@ -198,8 +199,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           body(u < my_cnt, n1, n2, h, sl[u], ll[u]);
         }
       }
-      if (over) {   // rows beyond the register slots: coefficients and state in the global scratch
-        for (int j = SEGCAP + slice; j < seg_cnt; j += 8) {
+      if (over) {   // rows beyond the register slots: coefficients and state in the global scratch (rare: the role is re-derived here rather than kept)
+        const int t_ = otid(), li = t_ >> 5, lk = (t_ >> 3) & 3;
+        const int seg_end = sI[li + 1] - sI[li];
+        for (int j = SEGCAP + (t_ & 7); j < seg_end; j += 8) {
           const int l = sI[li] + j;
           const double n1 = gsp[l], n2 = gsp[GL + l], h = gsp[2 * GL + l];
           double s = gsp[(3 + lk) * GL + l], lam = gsp[(7 + lk) * GL + l];
@@ -221,7 +224,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       if (tm < 8) sEp[tm] = tb->ep[tm];
       for (int e = tm; e < kSmallTab; e += BS) sM[e] = (&tb->Gi[0][0])[e];
       if (tm < 96) { const int ax = tm >> 5, r = tm & 31; sTheta[tm] = r < 4 * K ? sCoef[tm] - (tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2]) : 0.0; }
-      if (tm < 3 * R) { const int rho = tm % R, ax = tm / R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
+      if (tm < 3 * R) { const int ax = div_small(tm, R), rho = tm - ax * R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
       // the iterate and the two directions are read eight entries at a time from an axis' first one (against B's or Hax's zero
       // columns): what lies beyond the 3 nz entries in use must be finite
       if (tm >= n && tm < 24) { sZ[tm] = 0.0; sDxa[tm] = 0.0; sDx[tm] = 0.0; }
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           viol = fmax(viol, c);
         }
         block_reduce4(viol, d0, d1, d2, sRed);
-        converged = viol <= 1e-6;
+        converged = __builtin_amdgcn_readfirstlane(viol <= 1e-6 ? 1 : 0) != 0;
         if (tm == 0) {
           double o = 0;
           for (int ax = 0; ax < 3; ax++) {
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       } else {
         // ---- start point: projection of the guess, floored slacks, centred duals ------------------
         if (tm < n) {
-          const int ax = tm / nz, c = tm % nz;
+          const int ax = div_small(tm, nz), c = tm - ax * nz;
           double z = 0;
 #pragma unroll 8
           for (int r = 0; r < 4 * kMaxK; r++) z = __builtin_fma(tZpP[c * 4 * kMaxK + r], sTheta[ax * 32 + r], z);
@@ -317,7 +320,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         bool uncon = false;
         if constexpr (CULL) {   // presolve: the minimiser without inequality rows, accepted when every row holds there (see qp_kernel)
           if (tm < n) {
-            const int ax = tm / nz, c = tm % nz;
+            const int ax = div_small(tm, nz), c = tm - ax * nz;
             double v = 0;
             for (int e = 0; e < nz; e++) v -= sM[tHi + c * kNZ + e] * sG[ax * nz + e];
             sDx[tm] = v;
@@ -337,13 +340,13 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             viol = fmax(viol, c);
           }
           if (tm < n) {
-            const int ax = tm / nz, c = tm % nz;
+            const int ax = div_small(tm, nz), c = tm - ax * nz;
             double hz = 0;
             for (int e = 0; e < nz; e++) hz += sHax[c * kNZ + e] * sDx[ax * nz + e];
             o_share = sDx[tm] * (0.5 * hz + sG[tm]);
           }
           block_reduce4(viol, o_share, d1, d2, sRed);
-          uncon = viol <= 0.0;
+          uncon = __builtin_amdgcn_readfirstlane(viol <= 0.0 ? 1 : 0) != 0;
           if (uncon) { if (tm < n) sZ[tm] = sDx[tm]; if (tm == 0) sc[sObj] = sc[sObj0] + o_share; }
         }
         // (roles are re-derived from an opaque copy of the thread index in every phase: whatever the compiler could hoist out of
@@ -615,7 +618,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
 #endif
           if (has_qc) {   // z-x and z-y blocks: only the ball row couples z to x and y (without it the two diagonal blocks are factored apart and these entries are never read)
             for (int e = otid(); e < 2 * nz * nz; e += BS) {
-              const int i = 2 * nz + e / (2 * nz), j = e % (2 * nz);
+              const int qi = div_small(e, 2 * nz), i = 2 * nz + qi, j = e - qi * 2 * nz;
               sM[i * MS + j] = sc[sWq] * sGq[i] * sGq[j];
             }
           }
@@ -668,11 +671,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           }
           __syncthreads();                                                                       // barrier 4
           TICK(4);
-          const int flag = sI[18];
+          const int flag = __builtin_amdgcn_readfirstlane(sI[18]);
           if (flag == 1) { converged = true; break; }
           if (flag == 3) break;
           if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
-          if (!sI[19] || !sI[20]) break;
+          if (!__builtin_amdgcn_readfirstlane(sI[19]) || !__builtin_amdgcn_readfirstlane(sI[20])) break;
           // ---- (P2) affine step: ratio test, mu_aff, corrector right-hand side split as va - sigma mu vb (see qp_kernel) ----
           double rmax = 0, c2 = 0, dmy = 0;
           {
@@ -807,15 +810,15 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           TICK(9);
         }
         if (uncon) converged = true;
-        if (!converged && sI[16]) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
+        if (!converged && __builtin_amdgcn_readfirstlane(sI[16])) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
       }
       iters_total = it; if (mode == 0) iters_first = it;
       __syncthreads();
       if (converged) {
         status = mode;   // NEP_OK / NEP_RELAXED
-        objective = sc[sObj];
+        { const double o_ = sc[sObj]; objective = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(o_)), __builtin_amdgcn_readfirstlane(__double2loint(o_))); }
         if (tid < 12 * K) {  // theta = Th z + ThU init
-          const int ax = tid / (4 * K), r = tid % (4 * K);
+          const int ax = div_small(tid, 4 * K), r = tid - ax * 4 * K;
           double v = tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2];
           double th[kNZ];
 #pragma unroll
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     }
     __syncthreads();
     if (!CULL) break;
-    if (use_far || sI[41] == 0 || status == NEP_FAILED) break;
+    if (use_far || __builtin_amdgcn_readfirstlane(sI[41]) == 0 || status == NEP_FAILED) break;
     {  // the far lines against the solution: position control points from the base rows of the converged mode
       const QpTable* __restrict__ tbv = tables + status * (kMaxK + 1) + K;
       const int nzv = tbv->nz;
@@ -854,7 +857,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       }
       if (viol) sI[21] = 1;
       __syncthreads();
-      if (sI[21] == 0) break;
+      if (__builtin_amdgcn_readfirstlane(sI[21]) == 0) break;
       for (int e = tid; e < 256; e += BS) sAccL[e] = 0.0;   // (the accumulators were borrowed: the second attempt starts from zeros again)
     }
   }
@@ -880,7 +883,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((CULL && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;
-    sol->stats.objective = objective; sol->stats.solve_us = (double)((long long)wall_clock64() - t_wg0) * 0.01;   // the batched handle's per-replan device time (and the next launch's ordering key)
+    sol->stats.objective = objective; { const long long dt_ = (long long)wall_clock64() - t_wg0; sol->stats.solve_us = (double)dt_ * 0.01; if (ps.order_key) { const long long k_ = dt_ / 800; ps.order_key[slot] = k_ > 63 ? 63 : (int)k_; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
     sol->K = Ko; sol->n_states = ns;
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)
