@@ -606,8 +606,8 @@ def main():
                        if args.safety else None),
             "roofline": {"bound": "hbm", "kernel": be.qp_kernel_name(), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
-                         # the committed PMC summary is of the default single-GPU command (2 048 replans per launch)
-                         "traffic": measured_traffic("nep::" + be.qp_kernel_name()) if launch_replans == 2048 else None,
+                         # the committed PMC summary is of the default single-GPU command (8 192 replans per launch)
+                         "traffic": measured_traffic("nep::" + be.qp_kernel_name()) if launch_replans == 8192 else None,
                          "algorithmic_bytes_per_replan": bytes_per_replan, "replans_per_launch": launch_replans,
                          "sequence": {"achieved": seq_gbs, "frac": seq_gbs / 8000.0, "ms": seq_ms,
                                       "note": "the whole replan's bytes over the whole launch sequence (hull + separator + qp)"},
