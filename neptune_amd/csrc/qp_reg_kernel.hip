@@ -101,26 +101,31 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   // line rows of control point (seg, k) = (t >> 5, (t >> 3) & 3), slice t & 7; base row of that control point: t >> 3
 
 
+  // the mode's tables -> LDS (B, H of an axis, the end-point row, the small per-K tables in the normal matrix's place)
+  auto stage_tables = [&](const QpTable* __restrict__ tb, int tm) {
+    for (int e = tm; e < kMaxR * kNZ; e += BS) sB[(e / kNZ) * SBS + (e % kNZ)] = (&tb->B[0][0])[e];
+    if (tm < 64) sHax[tm] = (&tb->Hax[0][0])[tm];
+    if (tm < 8) sEp[tm] = tb->ep[tm];
+    for (int e = tm; e < kSmallTab; e += BS) sM[e] = (&tb->Gi[0][0])[e];
+  };
 #pragma nounroll
   for (int attempt = 0; attempt < (CULL ? 2 : 1) && K_ok; attempt++) {
     const bool use_far = attempt == 1;
     __syncthreads();
-    if (tid < NEP_MAX_POL) {
-      sI[44 + tid] = (tid < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + tid] : 0;
-      sI[32 + tid] = (tid < K && CULL) ? ps.line_far[(long)slot * NEP_MAX_POL + tid] : 0;
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int o = 0, nf = 0, all = 0;
+    if (attempt == 0) stage_tables(tables + K, otid());         // the first solve's tables travel together with the line counts and the lines: one global latency instead of two
+    if (tid <= NEP_MAX_POL) {   // line offsets per segment: nine threads read the eight counts (the same two cache lines) and each keeps its own prefix — one round trip and one barrier
+      int o = 0, nf = 0, all = 0, over = 0, my_o = 0, my_nf = 0, my_cn = 0, my_cf = 0;
+#pragma unroll
       for (int i = 0; i < NEP_MAX_POL; i++) {
-        const int cn = sI[44 + i], cf = sI[32 + i];
-        sI[i] = o; sI[52 + i] = nf;
-        o += cn + (use_far ? cf : 0); nf += cf; all += cn + cf;
+        const int cn = (i < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + i] : 0;
+        const int cf = (i < K && CULL) ? ps.line_far[(long)slot * NEP_MAX_POL + i] : 0;
+        if (i == tid) { my_o = o; my_nf = nf; my_cn = cn; my_cf = cf; }
+        const int ct = cn + (use_far ? cf : 0);
+        over |= ct > 8 * RS ? 1 : 0;
+        o += ct; nf += cf; all += cn + cf;
       }
-      sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0;
-      int over = 0;
-      for (int i = 0; i < NEP_MAX_POL; i++) over |= (sI[i + 1] - sI[i]) > 8 * RS ? 1 : 0;
-      sI[43] = over;
+      if (tid < NEP_MAX_POL) { sI[tid] = my_o; sI[52 + tid] = my_nf; sI[44 + tid] = my_cn; sI[32 + tid] = my_cf; }
+      else { sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0; sI[43] = over; }
     }
     __syncthreads();
     // (values every thread reads from LDS are wave-uniform: readfirstlane moves them, and what is computed from them, to SGPRs)
@@ -219,10 +224,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       const int nz = mode == 1 ? K : (K > 2 ? K - 2 : 0), n = 3 * nz;
       const int tm = otid();     // (the set-up below runs once per mode: nothing of it is worth hoisting out of the mode loop into registers)
       __syncthreads();
-      for (int e = tm; e < kMaxR * kNZ; e += BS) sB[(e / kNZ) * SBS + (e % kNZ)] = (&tb->B[0][0])[e];
-      if (tm < 64) sHax[tm] = (&tb->Hax[0][0])[tm];
-      if (tm < 8) sEp[tm] = tb->ep[tm];
-      for (int e = tm; e < kSmallTab; e += BS) sM[e] = (&tb->Gi[0][0])[e];
+      if (mode == 1 || attempt == 1) stage_tables(tb, tm);      // (mode 0 of the first attempt: staged next to the line gather, above)
       if (tm < 96) { const int ax = tm >> 5, r = tm & 31; sTheta[tm] = r < 4 * K ? sCoef[tm] - (tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2]) : 0.0; }
       if (tm < 3 * R) { const int ax = div_small(tm, R), rho = tm - ax * R; sOff[rho * 3 + ax] = tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2]; }
       // the iterate and the two directions are read eight entries at a time from an axis' first one (against B's or Hax's zero
@@ -294,10 +296,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           sZ[tm] = z;
           sG[tm] = (tGiP[c * 3] * sInit[ax * 3] + tGiP[c * 3 + 1] * sInit[ax * 3 + 1] + tGiP[c * 3 + 2] * sInit[ax * 3 + 2]) - 2 * wgt * sEp[c] * sc[sFinal0 + ax];
         }
-        if (tm == 0) {
+        if (tm == 64) {   // (wave 1 has no share of the projection above: the cost's constant term goes there, in the reference's summation order)
           double o = 0;
           for (int ax = 0; ax < 3; ax++) {
-            for (int r = 0; r < K; r++) { const double a = sRhs[ax * 8 + r]; o += 36 * T * a * a; }
+#pragma unroll
+            for (int r = 0; r < NEP_MAX_POL; r++) { const double a = r < K ? sRhs[ax * 8 + r] : 0.0; if (r < K) o += 36 * T * a * a; }
             const double pe = sc[sPe0 + ax];
             o += wgt * pe * pe;
             if (mode == 1) {
@@ -373,9 +376,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           const double slk = h - (n1 * cpx + n2 * cpy);
           s = slk > kSlackFloor ? slk : kSlackFloor; lam = ok ? kMu0 * frcp(s) : 1.0;
         });
+        if (tm >= 64 && tm < 128) {   // the dual residual's scale: a maximum, whatever the order
+          const double qs = fmax(1.0, wave_max(tm - 64 < n ? fabs(sG[tm - 64]) : 0.0));
+          if (tm == 64) sc[sQscale] = qs;
+        }
         if (tm == 0) {
-          double qs = 1.0; for (int e = 0; e < n; e++) qs = fmax(qs, fabs(sG[e]));
-          sc[sQscale] = qs;
           if (has_qc) {
             double c = -0.10 * 0.10;
             for (int ax = 0; ax < 3; ax++) { double pe = sc[sPe0 + ax]; for (int e = 0; e < nz; e++) pe += sEp[e] * sZ[ax * nz + e]; c += pe * pe; }
