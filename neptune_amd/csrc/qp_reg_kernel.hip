@@ -401,7 +401,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           // they do not fit next to the row state in 128 registers, one after the other they do (the second sweep re-reads three
           // coefficients per row) ----
           double nrp = 0, sumsl = 0, dummy1 = 0;
-          {
+          if (it > 0) {     // (the first iteration has no step to apply: alpha = 0 would leave every row as it is)
             const double alpha_prev = sc[sAlpha], sm_prev = sc[sSigMu];
             auto rowA1 = [&](double& s, double& lam, double a_old, double ga, double gd, double h) {
               const double rp0 = a_old + s - h, is = frcp(s), w0 = lam * is;
