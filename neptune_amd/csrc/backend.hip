@@ -729,6 +729,7 @@ int nep_batch_replan_hulls(nep_batch_t* h, const void* d_blocks, int32_t n_block
   E.fill(ps);
   point_at_block(ps, b, const_cast<void*>(d_blocks));
   ps.hull_pb = h->cfg.n_local; ps.hull_bstride = (long)b.bytes;
+  ps.hull_pb_magic = (h->cfg.n_local > 0 && h->cfg.num_agents < 65536) ? (1ull << 32) / (unsigned long long)h->cfg.n_local + 1ull : 0ull;
   ps.guess = d_guess; ps.solution = d_solution; ps.states = d_states; ps.commit = d_commit;
   ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
   ps.lines_override = 0;
@@ -764,6 +765,7 @@ int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* 
   E.fill(ps);
   point_at_block(ps, b, const_cast<void*>(d_blocks));
   ps.hull_pb = h->cfg.n_local; ps.hull_bstride = (long)b.bytes;
+  ps.hull_pb_magic = (h->cfg.n_local > 0 && h->cfg.num_agents < 65536) ? (1ull << 32) / (unsigned long long)h->cfg.n_local + 1ull : 0ull;
   h->fe_committed = nullptr;
   launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, nullptr, (hipStream_t)stream);
   HIPCHK(hipGetLastError());

@@ -53,6 +53,7 @@ struct ProblemSet {
   // equal blocks, hull_bstride bytes apart, each holding hull_pb agents per scene — the layout an
   // all-gather of per-rank blocks produces.  hull_pb == 0: one block (everything above as stated).
   int hull_pb;
+  unsigned long long hull_pb_magic;   // 2^32 / hull_pb + 1 (host): j / hull_pb = (j * magic) >> 32 for j < 65536; 0: divide
   long hull_bstride;
   // separator output
   double* line_nd;               // [slots][NEP_MAX_POL][lines_cap][3]
@@ -81,7 +82,9 @@ constexpr int NEP_FLAG_HULL_OVERFLOW = 1;   // an interval overlapped more commi
 struct HullRef { long e; long boff; };
 __host__ __device__ inline HullRef hull_ref(const ProblemSet& ps, int per_scene, int scene, int j) {
   if (ps.hull_pb <= 0) return HullRef{(long)scene * per_scene + j, 0L};
-  const int b = j / ps.hull_pb;
+  // (j / hull_pb by the host's magic number, exact for j, hull_pb < 65536: an integer division is a forty-instruction float
+  // sequence on the VALU, and the separator takes a hull reference per candidate)
+  const int b = ps.hull_pb_magic ? (int)(((unsigned long long)(unsigned)j * ps.hull_pb_magic) >> 32) : j / ps.hull_pb;
   return HullRef{(long)scene * ps.hull_pb + (j - b * ps.hull_pb), (long)b * ps.hull_bstride};
 }
 template <typename T> __host__ __device__ inline T* blk(T* base, long boff) { return (T*)((char*)base + boff); }
