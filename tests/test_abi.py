@@ -132,3 +132,20 @@ def test_shim_macro_without_eigen_is_an_error(tmp_path):
     src.write_text('#define NEPTUNE_AMD_REFERENCE_SHIM 1\n#include "neptune_poly_solver.hpp"\nint main() { return 0; }\n')
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I" + os.path.join(ROOT, "include"), str(src)], capture_output=True, text=True)
     assert r.returncode != 0 and "needs Eigen" in r.stderr
+
+
+def test_small_divisor_magic_numbers_are_exact():
+    """qp_common.h's cDivMagic (x / d as a multiply and a shift in the QP kernel's set-up) and nep_device.h's hull_pb_magic
+    formula: exact over the ranges the kernels use them on."""
+    import re
+    src = open(os.path.join(ROOT, "neptune_amd", "csrc", "qp_common.h")).read()
+    m = re.search(r"cDivMagic\[65\]\s*=\s*\{([^}]*)\}", src)
+    tab = [int(v) for v in m.group(1).split(",")]
+    assert len(tab) == 65
+    for d in range(1, 65):
+        for x in range(1024):
+            assert (x * tab[d]) >> 16 == x // d, (x, d)
+    for d in list(range(1, 300)) + [512, 1000, 4096, 65535]:
+        magic = (1 << 32) // d + 1
+        for j in list(range(0, 3000, 7)) + [65535]:
+            assert (j * magic) >> 32 == j // d, (j, d)
