@@ -497,11 +497,20 @@ __device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ord
   return false;
 }
 
-constexpr int kAStride = 13;  // (x,y) pairs per lane slot: 52 dwords (13 odd) -> 16 lanes of a ds_read_b128 group hit distinct 4-bank slots.
-                              // Polygons of up to kAStage vertices are staged here; bigger ones (rare) are read where they lie, so that
-                              // the carve stays at 13 KB and twelve instead of eight workgroups share a CU
-constexpr int kAStage = 12;
-
+// waves per SIMD the separator's register allocation is bounded for (3: 168 VGPRs, 4: 128)
+#ifndef NEP_SEP_WAVES
+#define NEP_SEP_WAVES 4
+#endif
+// Point sets A of a batch of 64 LPs are staged in one LDS pool, each lane's polygon at the exclusive prefix sum of the vertex
+// counts (6-12 vertices for an interval hull, 4 for a base or a static): ~590 pairs on average instead of 64 x 13 reserved
+// ones, so that a wave needs 10 KB and SIXTEEN waves share a CU (the allocation is bounded to 128 VGPRs for the same four
+// waves per SIMD).  A polygon that does not fit what is left of the pool is read where it lies (global memory / L2); the
+// computed point sets (base squares, entangle segments) fall back to a private array.  The packed offsets are not
+// bank-conflict-free as the 13-pair stride was; the LDS pipe has the slack (the kernel is bound by VALU issue).
+#ifndef NEP_SEP_LDS
+#define NEP_SEP_LDS (10 * 1024)
+#endif
+constexpr int kSepLdsTarget = NEP_SEP_LDS;
 // Candidate c of segment seg, in the reference's loop order (solver_gurobi_poly.cpp:477-495 agents,
 // :521-553 bases, :556-593 statics, :620-637 entangle): does the reference call the separator for
 // it, and (stage == true) what is point set A.
@@ -511,7 +520,8 @@ struct SepCtx {
   double el[3];          // lengths of the control polygon's three edges (the terms of hulldist)
 };
 __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, const double* by, double hulldist,
-                          bool stage, double2* myA, int& nA, bool& ordered, const double2*& Ause) {
+                          int mode, double2* myA, int& nA, bool& ordered, const double2*& Ause) {
+  const bool stage = mode == 1, cull_tests = mode == 0;   // mode 0: the reference's proximity culls; 1: stage the point set (myA, or in place when null); 2: vertex count only
   const SceneParams& sp = *cx.sp; const ProblemSet& ps = *cx.ps;
   const int N = cx.N, S = cx.S, nH = cx.nH;
   nA = 0; ordered = false;
@@ -525,15 +535,15 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     ordered = true;
     if (stage) {
       const double2* src = (const double2*)(blk(ps.hull_xy, hr.boff) + h * kHullV * 2);
-      if (nA <= kAStage) for (int v = 0; v < nA; v++) myA[v] = src[v]; else Ause = src;
+      if (myA) for (int v = 0; v < nA; v++) myA[v] = src[v]; else Ause = src;
     }
     return true;
   } else if (c < nH + N) {
     const int j = c - nH;
     const double base_radius = 0.7;
     const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
-    bool close_to_base = stage;      // (staging is only asked for candidates that passed this test in step 1)
-    for (int k = 0; k < 4 && !stage; k++) {
+    bool close_to_base = !cull_tests;      // (staging is only asked for candidates that passed this test in step 1)
+    for (int k = 0; k < 4 && cull_tests; k++) {
       const double ddx = bx[k] - pbx, ddy = by[k] - pby;
       // sqrt(ddx^2+ddy^2) >= max(|ddx|,|ddy|): beyond 2.2 on either axis the test below is false; skip its sqrt
       if (fabs(ddx) > 2.2 || fabs(ddy) > 2.2) continue;
@@ -553,7 +563,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     const int nv = ps.static_nv[j];
     if (nv <= 0) return false;
     const double* src = ps.static_xy + j * kHullV * 2;
-    if (!stage) {          // :558-578 (staging is only asked for candidates that passed this test in step 1)
+    if (cull_tests) {          // :558-578 (staging is only asked for candidates that passed this test in step 1)
       bool close_s = false;
       const double ddx = bx[0] - src[0], ddy = by[0] - src[1];
       double dist = sqrt(ddx * ddx + ddy * ddy);
@@ -562,7 +572,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
       if (!close_s) return false;
     }
     ordered = true; nA = nv;
-    if (stage) { if (nv <= kAStage) for (int v = 0; v < nv; v++) myA[v] = make_double2(src[2 * v], src[2 * v + 1]); else Ause = (const double2*)src; }
+    if (stage) { if (myA) for (int v = 0; v < nv; v++) myA[v] = make_double2(src[2 * v], src[2 * v + 1]); else Ause = (const double2*)src; }
     return true;
   } else if (c < cx.total) {
     const int e = c - nH - N - S;
@@ -585,7 +595,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
       pAx = bp[2 * (k - 2)]; pAy = bp[2 * (k - 2) + 1]; pBx = bp[2 * (k - 1)]; pBy = bp[2 * (k - 1) + 1];
     }
     const double ax_ = pAx - bx[0], ay_ = pAy - by[0], bx_ = pBx - bx[0], by_ = pBy - by[0];
-    if (!stage && sqrt(ax_ * ax_ + ay_ * ay_) - hulldist > 0 && sqrt(bx_ * bx_ + by_ * by_) - hulldist > 0) return false;  // :743-745
+    if (cull_tests && sqrt(ax_ * ax_ + ay_ * ay_) - hulldist > 0 && sqrt(bx_ * bx_ + by_ * by_) - hulldist > 0) return false;  // :743-745
     nA = 2;
     if (stage) { myA[0] = make_double2(pAx, pAy); myA[1] = make_double2(pBx, pBy); }
     return true;
@@ -600,10 +610,10 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
 // (with 63 other agents that is one full round plus a short tail instead of three rounds).  Line l
 // lands in bucket (slot, seg) at its call rank; an LP without a separating line leaves (0,0,0)
 // there — the QP kernel reads that as "constraint skipped" (solver_gurobi_poly.cpp:491-494).
-__global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSet ps) {
+__global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParams sp, ProblemSet ps, int pool_pairs) {
   extern __shared__ __attribute__((aligned(16))) double sdyn[];
-  double2* sA = (double2*)sdyn;                      // [64][kAStride] (x,y) pairs
-  double* sBx = sdyn + 2 * 64 * kAStride; double* sBy = sBx + 4;
+  double2* sA = (double2*)sdyn;                      // [pool_pairs] (x,y) pairs: the batch's point sets A, packed
+  double* sBx = sdyn + 2 * pool_pairs; double* sBy = sBx + 4;
   unsigned short* sAtt = (unsigned short*)(sBy + 4);
   const int lane = threadIdx.x;
   const int seg = blockIdx.x % NEP_MAX_POL;
@@ -635,14 +645,13 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
     const int c = c0 + lane;
     int nA; bool ord;
     const double2* unused = nullptr;
-    const bool att = c < total && cand_eval(cx, seg, c, bx, by, hulldist, false, nullptr, nA, ord, unused);
+    const bool att = c < total && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused);
     const unsigned long long mask = __ballot(att);
     if (att) sAtt[n_att + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)c;
     n_att += __popcll(mask);
   }
   __syncthreads();
   // ---- step 2: the LPs ---------------------------------------------------------------------------
-  double2* myA = sA + lane * kAStride;
   Pts4 B4;
 #pragma unroll
   for (int k = 0; k < 4; k++) { B4.x[k] = sBx[k]; B4.y[k] = sBy[k]; }
@@ -659,11 +668,19 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
     const bool active = a < n_att;
     double nd[3] = {0.0, 0.0, 0.0};
     bool far = false;
+    // this batch's pool: every lane's vertex count, its exclusive prefix sum across the wave, then the staging
+    int c = 0, nA = 0; bool ord = false;
+    if (active) { c = sAtt[a]; const double2* u_ = nullptr; cand_eval(cx, seg, c, bx, by, hulldist, 2, nullptr, nA, ord, u_); }
+    int incl = nA;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
     if (active) {
-      const int c = sAtt[a];
-      int nA; bool ord;
+      double2 priv[4];                                       // (base squares / entangle segments when the pool is full: rare)
+      double2* myA = (incl <= pool_pairs) ? sA + (incl - nA) : nullptr;
+      const bool made_here = (c >= cx.nH && c < cx.nH + cx.N) || c >= cx.nH + cx.N + cx.S;
+      if (!myA && made_here) myA = priv;
       const double2* Ause = myA;
-      cand_eval(cx, seg, c, bx, by, hulldist, true, myA, nA, ord, Ause);
+      cand_eval(cx, seg, c, bx, by, hulldist, 1, myA, nA, ord, Ause);
       const bool ok = separator_impl(nA, Ause, ord, B4, nd);
       if (!ok) { n_fail++; nd[0] = nd[1] = nd[2] = 0.0; }
       if (cull) {
@@ -696,8 +713,17 @@ __global__ __launch_bounds__(64) void separator_kernel(SceneParams sp, ProblemSe
 
 size_t separator_lds_bytes(const SceneParams& sp) {
   const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
-  size_t b = (size_t)(2 * 64 * kAStride + 8) * sizeof(double) + (size_t)(total + 8) * sizeof(unsigned short);
-  return (b + 15) & ~(size_t)15;
+  const size_t tail = 8 * sizeof(double) + (((size_t)(total + 8) * sizeof(unsigned short) + 15) & ~(size_t)15);
+  // the pool takes what is left of 10 KB (sixteen waves per CU); with very long candidate lists (config 5 with the entangle rows)
+  // it keeps at least 64 x 8 pairs and the wave gets more LDS
+  size_t pool = tail + 64 * 8 * 16 <= (size_t)kSepLdsTarget ? (size_t)kSepLdsTarget - tail : (size_t)64 * 8 * 16;
+  pool &= ~(size_t)15;
+  return pool + tail;
+}
+static int separator_pool_pairs(const SceneParams& sp) {
+  const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
+  const size_t tail = 8 * sizeof(double) + (((size_t)(total + 8) * sizeof(unsigned short) + 15) & ~(size_t)15);
+  return (int)((separator_lds_bytes(sp) - tail) / 16);
 }
 
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
@@ -705,7 +731,7 @@ void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, 
   const size_t lds = separator_lds_bytes(sp);
   static DynLdsAttr attr;
   (void)attr.ensure((const void*)separator_kernel, lds);
-  hipLaunchKernelGGL(separator_kernel, dim3(n_slots * NEP_MAX_POL), dim3(64), lds, st, sp, ps);
+  hipLaunchKernelGGL(separator_kernel, dim3(n_slots * NEP_MAX_POL), dim3(64), lds, st, sp, ps, separator_pool_pairs(sp));
 }
 
 // Stand-alone batched LP (tests / nep_separator_batch): one lane per problem, A read from global
