@@ -1075,8 +1075,15 @@ __device__ __forceinline__ unsigned fe_hash(long long vox) { return (unsigned)((
 // are obstacles (collidesWithBases2d, :1583-1628) and only nodes whose active cases are all <= 1 may end the plan
 // (:1693-1700).  The states of the installed nodes stay in global memory ([depth][rank]); the path's states give the case
 // ids the back end consumes (solver_gurobi_poly.cpp:624-631).
+// workgroups per CU the front end's register allocation is bounded for (a 256-thread workgroup is one wave per SIMD).  The
+// search is latency-bound (eight depths of ~10 barriers): three workgroups per CU at 168 VGPRs (13 spilled) take 3.06 ms per
+// 8 192 searches against 4.13 ms for two at 187; four at 128 (53 spilled) take 3.78.  The entangle instantiation keeps all
+// its registers (326).
+#ifndef NEP_FE_WAVES
+#define NEP_FE_WAVES 3
+#endif
 template <bool ENT>
-__global__ __launch_bounds__(256) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
+__global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
                                                        nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out, FeEntArgs ea) {
   extern __shared__ __attribute__((aligned(16))) double fe_smem[];
   const int tid = threadIdx.x;
