@@ -923,13 +923,19 @@ __global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec*
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
                    unsigned char* conflict, unsigned char* conflict_prev, const int* entangles, nep_traj_rec* final_out, int* accept_out, hipStream_t st) {
   if (n_scenes * N <= 0) return;
+  auto hulls_of = [&](const nep_traj_rec* recs) {      // interval hulls of one record set on the round's grid (eight per wave, as in the replan)
+    if (sp.num_pol <= 8)
+      hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * N), dim3(64), 0, st, recs, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
+                         sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
+    else
+      hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, recs, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
+                         sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
+  };
   if (conflict_prev) {   // new trajectories against the hulls of the PREVIOUS records on the same grid
-    hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, prev, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
-                       sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
+    hulls_of(prev);
     hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, prev, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict_prev);
   }
-  hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, fresh, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
-                     sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
+  hulls_of(fresh);
   hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
   hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, entangles, final_out, accept_out);
 }
