@@ -400,6 +400,9 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
 // ---------------------------------------------------------------------------------------------
 // Candidate bookkeeping: gaps are compared as num^2/len2 by cross-multiplication, so that only the
 // winning candidate needs a square root and divisions (fp64 sqrt/div expand to ~30 VALU ops each).
+// Running minima / maxima of the projections are fmin / fmax (one v_min_f64 / v_max_f64 each) rather than compare-and-select
+// (three instructions): the inputs are finite, and where the two forms could differ — the sign of a zero — the value is
+// only ever compared with zero or subtracted from it before a strict num > 0 test, so the lines are the same bits.
 struct SepBest { bool have; double num, len2, sg, tA, nx, ny, px, py; };
 
 __device__ __forceinline__ void sep_consider(SepBest& b, double num, double len2, double sg, double tA, double nx, double ny, double px, double py) {
@@ -425,7 +428,7 @@ __device__ __forceinline__ void sep_edge_ccw(double px, double py, double qx, do
   if (!(len2 > 0.0)) return;
   double maxB = -NEP_INF;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); if (t > maxB) maxB = t; }
+  for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); maxB = fmax(maxB, t); }
   sep_consider(best, 0.0 - maxB, len2, 1.0, 0.0, nx, ny, px, py);
 }
 
@@ -437,11 +440,11 @@ __device__ __forceinline__ void sep_pair(double px, double py, double qx, double
   if (!(len2 > 0.0)) return;
   double minA = NEP_INF, maxA = -NEP_INF, minB = NEP_INF, maxB = -NEP_INF;
 #pragma unroll
-  for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); if (t < minB) minB = t; if (t > maxB) maxB = t; }
+  for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); minB = fmin(minB, t); maxB = fmax(maxB, t); }
   // a pair of B with B on both sides of its line supports no candidate (np_ = nm = -inf below): skip the pass over A.
   // B is the same in every lane of the separator kernel, so this exit is wave-uniform there.
   if (!from_A && !(maxB <= 0.0) && !(minB >= 0.0)) return;
-  for (int i = 0; i < nA; i++) { const double2 a = A[i]; const double t = nx * (a.x - px) + ny * (a.y - py); if (t < minA) minA = t; if (t > maxA) maxA = t; }
+  for (int i = 0; i < nA; i++) { const double2 a = A[i]; const double t = nx * (a.x - px) + ny * (a.y - py); minA = fmin(minA, t); maxA = fmax(maxA, t); }
   double np_ = -NEP_INF, nm = -NEP_INF, tAp = 0.0, tAm = 0.0;
   if (from_A) {
     if (minA >= 0.0) { np_ = 0.0 - maxB; tAp = 0.0; }
@@ -479,8 +482,8 @@ __device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ord
     const double len2 = nx * nx + ny * ny;
     if (len2 > 0.0) {
       double minA = NEP_INF, maxB = -NEP_INF;
-      for (int i = 0; i < nA; i++) { const double t = nx * (A[i].x - cbx) + ny * (A[i].y - cby); if (t < minA) minA = t; }
-      for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - cbx) + ny * (B.y[i] - cby); if (t > maxB) maxB = t; }
+      for (int i = 0; i < nA; i++) { const double t = nx * (A[i].x - cbx) + ny * (A[i].y - cby); minA = fmin(minA, t); }
+      for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - cbx) + ny * (B.y[i] - cby); maxB = fmax(maxB, t); }
       sep_consider(best, minA - maxB, len2, 1.0, minA, nx, ny, cbx, cby);
     }
   }
