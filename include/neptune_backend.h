@@ -357,6 +357,10 @@ int nep_batch_qp_placement(nep_batch_t* h);
 int nep_batch_set_launch_order(nep_batch_t* h, int32_t enable);
 int nep_batch_debug_launch_order(nep_batch_t* h, int32_t* order, int32_t cap, int32_t* n_out);
 
+/* Which kernel builds the interval hulls (same hulls, bit for bit): 0 = by batch size (eight hulls per wave from ~2 000
+ * trajectories per launch on, one per wave below: DESIGN.md section 6), 1 = one hull per wave, 2 = eight per wave.       */
+int nep_batch_set_hull_kernel(nep_batch_t* h, int32_t mode);
+
 /* setMaxRuntime for the batched handle (0 = no wall-clock limit, the default): see nep_backend_set_max_runtime. */
 int nep_batch_set_max_runtime(nep_batch_t* h, double seconds);
 

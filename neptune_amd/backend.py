@@ -303,6 +303,10 @@ class BatchBackend:
         """the interior-point kernel this handle launches (nep_batch_qp_placement)"""
         return "qp_reg_kernel" if lib().nep_batch_qp_placement(self._h) == 1 else "qp_kernel"
 
+    def set_hull_kernel(self, mode=0):
+        """0: by batch size, 1: one hull per wave, 2: eight hulls per wave (nep_batch_set_hull_kernel)"""
+        check(lib().nep_batch_set_hull_kernel(self._h, int(mode)))
+
     def set_launch_order(self, enable=True):
         """QP workgroups longest-expected-first (default) or in slot order: nep_batch_set_launch_order"""
         check(lib().nep_batch_set_launch_order(self._h, 1 if enable else 0))

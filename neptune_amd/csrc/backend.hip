@@ -904,6 +904,12 @@ int nep_batch_debug_launch_order(nep_batch_t* h, int32_t* order, int32_t cap, in
   return 0;
 }
 
+int nep_batch_set_hull_kernel(nep_batch_t* h, int32_t mode) {
+  if (!h || mode < 0 || mode > 2) return fail(NEP_E_ARG, "mode: 0 automatic, 1 one hull per wave, 2 eight hulls per wave");
+  h->eng.sp.hull_mode = mode;
+  return 0;
+}
+
 int nep_batch_set_max_runtime(nep_batch_t* h, double seconds) {
   if (!h || !(seconds >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
   h->eng.sp.time_limit_ticks = seconds > 0 ? (long long)(seconds * 1e8) : 0;

@@ -383,8 +383,13 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
   if (blocks <= 0) return;
   // the uninflated hull is read only by the entangle rows (col(0), solver_gurobi_poly.cpp:722-734)
   const bool need0 = sp.ent_enabled != 0;
-  static const bool one_per_wave = getenv("NEP_HULL_KERNEL") && !strcmp(getenv("NEP_HULL_KERNEL"), "wave");   // (A/B: the round-1 kernel)
-  if (sp.num_pol <= 8 && !one_per_wave) {
+  // Eight hulls per wave when there are enough trajectories to fill the chip with such waves (a wave of eight takes ~60 us,
+  // one hull per wave ~26 us: below ~2 000 trajectories the launch is one round of waves either way and the short waves
+  // finish first — 0.026 against 0.058 ms for one 64-agent scene; 0.077 both at 32 scenes; 0.271 against 0.183 ms at 128).
+  // nep_batch_set_hull_kernel / NEP_HULL_KERNEL=wave|group force one (tests, A/B).
+  static const char* force = getenv("NEP_HULL_KERNEL");
+  const bool grouped = sp.hull_mode ? sp.hull_mode == 2 : (force ? strcmp(force, "wave") != 0 : (long)n_scenes * n_rec > 2048);
+  if (sp.num_pol <= 8 && grouped) {
     hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * n_rec), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
                        sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
                        need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr, ps.flags);
@@ -927,7 +932,7 @@ void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_sc
                    unsigned char* conflict, unsigned char* conflict_prev, const int* entangles, nep_traj_rec* final_out, int* accept_out, hipStream_t st) {
   if (n_scenes * N <= 0) return;
   auto hulls_of = [&](const nep_traj_rec* recs) {      // interval hulls of one record set on the round's grid (eight per wave, as in the replan)
-    if (sp.num_pol <= 8)
+    if (sp.num_pol <= 8 && (sp.hull_mode ? sp.hull_mode == 2 : (long)n_scenes * N > 2048))
       hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * N), dim3(64), 0, st, recs, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
                          sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
     else

@@ -20,6 +20,7 @@ struct SceneParams {
   int n_static;       // S
   int n_hull;         // hull lists per scene: N in batch mode, n_obst in per-agent mode
   int ent_enabled;
+  int hull_mode;      // 0: pick the hull kernel by batch size; 1: one hull per wave (hull_kernel); 2: eight per wave (hull_group_kernel)
   int max_states;
   int lines_cap;      // capacity of one (slot, segment) line bucket
   int n_local;        // slots per scene

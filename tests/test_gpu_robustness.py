@@ -220,3 +220,33 @@ def test_launch_order_does_not_change_results(be):
     bb.replan(d_com, d_gue)
     assert bb.launch_order() is None and bb.solutions().tobytes() == first.tobytes()
     bb.close()
+
+
+def test_both_hull_kernels_give_the_oracles_hulls(be, oracle):
+    """nep_batch_set_hull_kernel: one hull per wave (round 1) and eight per wave (interval i on lanes 8i..8i+7, chain stacks as
+    index masks) are the same algorithm; the handle picks by batch size.  Both forced on a 64-agent scene with time-shifted
+    committed trajectories: hull vertices bit for bit equal to each other and to the oracle's, and so are the replans."""
+    sc = scene.make_scene(64, 20, seed=7, t_jitter=0.3)
+    p = sc["par"]
+    outs = []
+    for mode in (1, 2):
+        bb = be.BatchBackend(p, sc["statics"])
+        bb.set_hull_kernel(mode)
+        bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]))
+        hx, hn = bb.debug_hulls(0)
+        outs.append((hx.copy(), hn.copy(), bb.solutions()))
+        bb.close()
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+    for j in range(64):
+        for i in range(p.num_pol):
+            k = outs[0][1][j, i]
+            np.testing.assert_array_equal(outs[0][0][j, i, :k], outs[1][0][j, i, :k])
+    assert outs[0][2].tobytes() == outs[1][2].tobytes()
+    t0 = float(sc["guesses"][0]["t_start"])
+    for j in (0, 17, 63):
+        pw = abi.nep_pwp.from_buffer_copy(sc["committed"][j]["pwp"].tobytes())
+        d = np.array([sc["committed"][j]["bbox"][0] / 2 + p.drone_radius, sc["committed"][j]["bbox"][1] / 2 + p.drone_radius])
+        for i in range(p.num_pol):
+            h, _hu = oracle.hull_of_interval(pw, t0 + i * p.T_span, t0 + (i + 1) * p.T_span, p.T_span, d)
+            assert outs[1][1][j, i] == len(h)
+            np.testing.assert_array_equal(outs[1][0][j, i, :len(h)], h)
