@@ -113,6 +113,16 @@ __device__ __forceinline__ double frcp(double a) {
   return r;
 }
 
+// 1/a to the last bit or two (v_rcp_f64 + two Newton steps: 8 issue slots) for the iteration's SCALARS — the affine step length,
+// mu_aff / mu, the step length — which every thread of the workgroup computes for itself after a reduction: an IEEE division
+// is a ~32-instruction sequence, and four of them on all 256 threads were 8 % of the kernel's VALU instructions.
+__device__ __forceinline__ double frcp2(double a) {
+  double r = __builtin_amdgcn_rcp(a);
+  double e = __builtin_fma(-a, r, 1.0); r = __builtin_fma(r, e, r);
+  e = __builtin_fma(-a, r, 1.0); r = __builtin_fma(r, e, r);
+  return r;
+}
+
 // 1/sqrt(a): v_rsq_f64 seed + two Newton steps (the IEEE sqrt + divide pair costs ~4x more and sits
 // on the Cholesky's critical path once per column).
 __device__ __forceinline__ double frsqrt(double a) {

@@ -173,6 +173,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     has_qc = __builtin_amdgcn_readfirstlane(sqrt(dix * dix + diy * diy + diz * diz) < 1.0 ? 1 : 0) != 0;   // :697-702
     z_override = __builtin_amdgcn_readfirstlane(sqrt(dix * dix + diy * diy) < 1.0 ? 1 : 0) != 0;           // :879-880
     const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);
+    const double inv_mt = 1.0 / (double)mt;                   // (one division per attempt; the per-iteration means multiply by it)
 
     const int li = tid >> 5, slice = tid & 7;
     const int seg_cnt = sI[li + 1] - sI[li];                  // lines of my segment (0 for segments >= K)
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               }
               sc[sRpq] = rpq;
               sc[sSumSl] = sumsl + (has_qc ? sc[sSq] * sc[sLq] : 0.0);
-              sc[sMu] = sc[sSumSl] / mt;
+              sc[sMu] = sc[sSumSl] * inv_mt;
               sc[sNrp] = fmax(nrp, fabs(rpq));
             }
           }
@@ -733,12 +734,12 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           reduce_get<1>(rmax, c2, dmy, redP2);
           double sm;
           {
-            const double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
+            const double aaff = rmax > 1.0 ? frcp2(rmax) : 1.0;
             const double mu = sc[sMu];
-            const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) / mt;
-            const double rr = mua / mu;
+            const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) * inv_mt;
+            const double rr = mua * frcp2(mu);
             sm = rr * rr * rr * mu;
-            sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) / mt);
+            sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) * inv_mt);
           }
           {
             const int t = otid();
@@ -813,7 +814,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           TICK(8);
           reduce_get<0>(rmax, dmy, dmy, redP5);
           {
-            double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
+            double alpha = rmax > 0.0 ? frcp2(rmax) : 1e30;
             alpha = fmin(1.0, fmin(fmax(1.0 - sc[sMu], kStepFracMin), kStepFracMax) * alpha);
             const int t = otid();
             if (t == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
