@@ -121,6 +121,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   has_qc = sqrt(dix * dix + diy * diy + diz * diz) < 1.0;   // :697-702
   z_override = sqrt(dix * dix + diy * diy) < 1.0;           // :879-880
   const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);                    // inequality count (+ball)
+  const double inv_mt = 1.0 / (double)mt;   // (see qp_reg_kernel: the iteration's scalar divisions)
 
   // ---- thread roles ---------------------------------------------------------------------------
   const int R = 8 * K;
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           }
           sc[sRpq] = rpq;
           sc[sSumSl] = sumsl + (has_qc ? sc[sSq] * sc[sLq] : 0.0);
-          sc[sMu] = sc[sSumSl] / mt;
+          sc[sMu] = sc[sSumSl] * inv_mt;
           sc[sNrp] = fmax(nrp, fabs(rpq));
         }
         __syncthreads();                                                                       // barrier 2
@@ -587,15 +588,15 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         reduce_get<1>(rmax, c2, dmy, redP2);
         double sm;
         {
-          const double aaff = rmax > 1.0 ? 1.0 / rmax : 1.0;
+          const double aaff = rmax > 1.0 ? frcp2(rmax) : 1.0;
           const double mu = sc[sMu];
-          const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) / mt;
-          const double rr = mua / mu;
+          const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) * inv_mt;
+          const double rr = mua * frcp2(mu);
           sm = rr * rr * rr * mu;                              // sigma * mu, identical in every thread
           // never aim below a tenth of the gap the strict test asks for: with the long steps of kStepFracMax the centring
           // target would otherwise collapse by 1e5 per iteration, the last iterate would sit at mu ~ 1e-15 with weights
           // lambda/s ~ 1e17, and the rounding of that last step shows up as 1e-6 in the flat directions of the coefficients
-          sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) / mt);
+          sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) * inv_mt);
         }
         TICK(6);
         TICK(7);
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         __syncthreads();                                                                       // barrier 8
         reduce_get<0>(rmax, dmy, dmy, redP5);
         {
-          double alpha = rmax > 0.0 ? 1.0 / rmax : 1e30;
+          double alpha = rmax > 0.0 ? frcp2(rmax) : 1e30;
           alpha = fmin(1.0, fmin(fmax(1.0 - sc[sMu], kStepFracMin), kStepFracMax) * alpha);
           if (tid == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
           if (tid < n) sZ[tid] += alpha * sDx[tid];
