@@ -11,6 +11,21 @@
 // the per-slot global scratch (correct for any count; config-5 sized problems are given to qp_kernel by the host).
 // The solver body is one straight function whose phases scope their temporaries: no 4-wide row groups (the other three
 // workgroups of the CU hide the latency instead), no out-of-line calls.
+//
+// One iteration, seven workgroup barriers (eight with the terminal ball row):
+//   A1 + A2  all threads: apply the previous step to (s, lambda), then residuals / weights and the line rows' sums per
+//            control point (three DPP steps per 8-lane group); the box rows' sums go to sTc / sDc directly            -> b1
+//   assembly wave 1: B' [T_lambda | T1] (dual residual, predictor rhs); waves 2, 3: the blocks of M; one 16 x 16 MFMA
+//            tile each over the 64 base rows, the line sums added as the operands are read; wave 0: the iteration's
+//            scalars (and the ball row: then one more barrier before the tiles)                                       -> b3
+//   factor   wave 0: Cholesky of the (x, y) block in registers + the predictor; wave 1: convergence test, then the z block -> b4
+//   P2       all threads: affine ratio test, corrector right-hand side as  va - sigma mu vb                           -> b5
+//   rhs      144 threads: B' (va - sigma mu vb)                                                                       -> b6
+//   solve    waves 0, 1: the corrector                                                                                -> b7
+//   P5       all threads: step length of the combined direction                                                       -> b8
+// Cycle counts per phase: DESIGN.md section 6 (make PROFILE=1, scripts/qp_reg_phases.py).  The workgroups of a launch are
+// started longest-expected-first (ps.order, order_kernel in qp_kernels.hip); every workgroup leaves its measured duration
+// in nep_stats.solve_us.
 #include <hip/hip_runtime.h>
 
 #include "qp_common.h"
@@ -20,9 +35,10 @@
 #define NEP_QP_REG_SLOTS 9
 #endif
 
-// 1: the normal matrix's weighted Gram blocks  M_sel = sum_rho D_sel[rho] B[rho]' B[rho]  (64 base rows, four weight sets) are
-// formed on the matrix cores as two 16x16 tiles of v_mfma_f64_16x16x4_f64 (K = 64: 16 instructions per tile, one tile per
-// wave) — the one genuine contraction of the path; 0: the VALU version (two entries per thread, 32 base rows per lane pair).
+// 1: the contractions over the 64 base rows — the normal matrix's weighted Gram blocks  M_sel = sum_rho D_sel[rho] B[rho]' B[rho]
+// (four weight sets) and  B' [T_lambda | T1] — are formed on the matrix cores as three 16x16 tiles of v_mfma_f64_16x16x4_f64
+// (K = 64: 16 instructions per tile, one tile per wave); 0: the VALU versions (two matrix entries per thread, 32 base rows per
+// lane pair; eight partial sums per output of the residual), kept for A/B.
 #ifndef NEP_QP_MFMA
 #define NEP_QP_MFMA 1
 #endif
