@@ -205,8 +205,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     const bool over = __builtin_amdgcn_readfirstlane(sI[43]) != 0;
     const lds_ptr cbase = ldyn + (li * SEGCAP + slice);
 
-    // One pass over this thread's line rows.  body(ok, n1, n2, h, s, lambda); padded slots see the dummy line (0, 0, 1) with
-    // s = lambda = 1: their activity and step are exactly zero (see qp_kernel), `ok` masks what would still matter.
+    // One pass over this thread's line rows.  body(ok, n1, n2, h, s, lambda); padded slots see the dummy line (0, 0, 1): their
+    // slack stays exactly 1 (activity and slack step are exactly zero), their multiplier follows lambda <- (1 - alpha) lambda +
+    // alpha sigma mu, positive and finite, and everything it enters is multiplied by the zero normal — `ok` masks the two places
+    // where a padded row would still count: the complementarity sum and the step-length test.
     auto for_rows = [&](double (&sl)[RS], double (&ll)[RS], double (&il)[RS], auto&& body) {
       // two slots per scalar branch: both rows' coefficient loads are issued before either row's arithmetic (a block per slot
       // would leave every row waiting for its own three ds_reads)
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         for (int u = 0; u < RS; u++) { sl[u] = 1.0; ll[u] = 1.0; il[u] = 1.0; }
         for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, double& isv) {
           const double slk = h - (n1 * cpx + n2 * cpy);
-          s = slk > kSlackFloor ? slk : kSlackFloor; isv = frcp(s); lam = ok ? kMu0 * isv : 1.0;
+          s = slk > kSlackFloor ? slk : kSlackFloor; isv = frcp(s); lam = kMu0 * isv;      // (a padded row starts at s = 1, lambda = mu0)
         });
         if (tm >= 64 && tm < 128) {   // the dual residual's scale: a maximum, whatever the order
           const double qs = fmax(1.0, wave_max(tm - 64 < n ? fabs(sG[tm - 64]) : 0.0));
@@ -440,7 +442,6 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             }
             for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, double& isv) {
               rowA1(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, isv);
-              lam = ok ? lam : 1.0;
             });
             cpb = __builtin_fma(alpha_prev, udb, cpb); cpx = __builtin_fma(alpha_prev, udx, cpx); cpy = __builtin_fma(alpha_prev, udy, cpy);   // base rows move with the step
           }
