@@ -505,16 +505,17 @@ __device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ord
   return false;
 }
 
-// waves per SIMD the separator's register allocation is bounded for (3: 168 VGPRs, 4: 128)
+// waves per SIMD the separator's register allocation is bounded for (3: 168 VGPRs, no spills: 0.615 ms per 4.2 M LPs; 4: 128
+// VGPRs, 12 spilled: 0.555 ms; 5: 96 VGPRs, 42 spilled: 0.68 ms — same-box A/B)
 #ifndef NEP_SEP_WAVES
 #define NEP_SEP_WAVES 4
 #endif
 // Point sets A of a batch of 64 LPs are staged in one LDS pool, each lane's polygon at the exclusive prefix sum of the vertex
 // counts (6-12 vertices for an interval hull, 4 for a base or a static): ~590 pairs on average instead of 64 x 13 reserved
 // ones, so that a wave needs 10 KB and SIXTEEN waves share a CU (the allocation is bounded to 128 VGPRs for the same four
-// waves per SIMD).  A polygon that does not fit what is left of the pool is read where it lies (global memory / L2); the
-// computed point sets (base squares, entangle segments) fall back to a private array.  The packed offsets are not
-// bank-conflict-free as the 13-pair stride was; the LDS pipe has the slack (the kernel is bound by VALU issue).
+// waves per SIMD: 11 % faster than three).  A polygon that does not fit what is left of the pool is read where it lies
+// (global memory / L2); the computed point sets (base squares, entangle segments) fall back to a private array.  The packed
+// offsets are not bank-conflict-free as the 13-pair stride was; the LDS pipe has the slack (the kernel is bound by VALU issue).
 #ifndef NEP_SEP_LDS
 #define NEP_SEP_LDS (10 * 1024)
 #endif
