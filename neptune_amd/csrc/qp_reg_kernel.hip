@@ -212,21 +212,23 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     auto for_rows = [&](double (&sl)[RS], double (&ll)[RS], double (&il)[RS], auto&& body) {
       // two slots per scalar branch: both rows' coefficient loads are issued before either row's arithmetic (a block per slot
       // would leave every row waiting for its own three ds_reads)
+      // slots 0..3 and 4..7 four per scalar branch, 8 alone (a wave whose segments have at most 64 lines stops after 7): the rows'
+      // coefficient loads are issued ahead of the rows' arithmetic, group by group
+      static_assert(RS == 9, "slot grouping below");
 #pragma unroll
-      for (int u = 0; u + 1 < RS; u += 2) {
+      for (int u = 0; u < 8; u += 4) {
         if (u < n_u) {
-          const double n1a = cbase[8 * u], n2a = cbase[NS + 8 * u], ha = cbase[2 * NS + 8 * u];
-          const double n1b = cbase[8 * u + 8], n2b = cbase[NS + 8 * u + 8], hb = cbase[2 * NS + 8 * u + 8];
-          body(u < my_cnt, n1a, n2a, ha, sl[u], ll[u], il[u]);
-          body(u + 1 < my_cnt, n1b, n2b, hb, sl[u + 1], ll[u + 1], il[u + 1]);
+          double c1[4], c2[4], c3[4];
+#pragma unroll
+          for (int v = 0; v < 4; v++) { c1[v] = cbase[8 * (u + v)]; c2[v] = cbase[NS + 8 * (u + v)]; c3[v] = cbase[2 * NS + 8 * (u + v)]; }
+#pragma unroll
+          for (int v = 0; v < 4; v++) body(u + v < my_cnt, c1[v], c2[v], c3[v], sl[u + v], ll[u + v], il[u + v]);
         }
       }
-      if constexpr (RS & 1) {
-        constexpr int u = RS - 1;
-        if (u < n_u) {
-          const double n1 = cbase[8 * u], n2 = cbase[NS + 8 * u], h = cbase[2 * NS + 8 * u];
-          body(u < my_cnt, n1, n2, h, sl[u], ll[u], il[u]);
-        }
+      if (8 < n_u) {
+        constexpr int u = 8;
+        const double n1 = cbase[8 * u], n2 = cbase[NS + 8 * u], h = cbase[2 * NS + 8 * u];
+        body(u < my_cnt, n1, n2, h, sl[u], ll[u], il[u]);
       }
       if (over) {   // rows beyond the register slots: coefficients and state in the global scratch (rare: the role is re-derived here rather than kept)
         const int t_ = otid(), li = t_ >> 5, lk = (t_ >> 3) & 3;
