@@ -408,14 +408,14 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
 // Running minima / maxima of the projections are fmin / fmax (one v_min_f64 / v_max_f64 each) rather than compare-and-select
 // (three instructions): the inputs are finite, and where the two forms could differ — the sign of a zero — the value is
 // only ever compared with zero or subtracted from it before a strict num > 0 test, so the lines are the same bits.
-struct SepBest { bool have; double num, len2, sg, tA, nx, ny, px, py; };
+struct SepBest { bool have; double num, len2, tA, nx, ny, px, py; };   // (tA, nx, ny carry the candidate's sign: exact negations)
 
-__device__ __forceinline__ void sep_consider(SepBest& b, double num, double len2, double sg, double tA, double nx, double ny, double px, double py) {
+__device__ __forceinline__ void sep_consider(SepBest& b, double num, double len2, double tA, double nx, double ny, double px, double py) {
   if (!(num > 0.0)) return;
   bool better;
   if (!b.have) better = (num * num) > (SEP_MIN_GAP * SEP_MIN_GAP) * len2;
   else better = (num * num) * b.len2 > (b.num * b.num) * len2;
-  if (better) { b.have = true; b.num = num; b.len2 = len2; b.sg = sg; b.tA = tA; b.nx = nx; b.ny = ny; b.px = px; b.py = py; }
+  if (better) { b.have = true; b.num = num; b.len2 = len2; b.tA = tA; b.nx = nx; b.ny = ny; b.px = px; b.py = py; }
 }
 
 // Point set A: interleaved (x,y) pairs (one ds_read_b128 per point); point set B: the segment's
@@ -434,7 +434,7 @@ __device__ __forceinline__ void sep_edge_ccw(double px, double py, double qx, do
   double maxB = -NEP_INF;
 #pragma unroll
   for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); maxB = fmax(maxB, t); }
-  sep_consider(best, 0.0 - maxB, len2, 1.0, 0.0, nx, ny, px, py);
+  sep_consider(best, 0.0 - maxB, len2, 0.0, nx, ny, px, py);
 }
 
 __device__ __forceinline__ void sep_pair(double px, double py, double qx, double qy, bool from_A,
@@ -458,13 +458,13 @@ __device__ __forceinline__ void sep_pair(double px, double py, double qx, double
     if (maxB <= 0.0) { np_ = minA - 0.0; tAp = minA; }
     if (minB >= 0.0) { nm = 0.0 - maxA; tAm = maxA; }
   }
-  if (np_ >= nm) sep_consider(best, np_, len2, 1.0, tAp, nx, ny, px, py);
-  else sep_consider(best, nm, len2, -1.0, tAm, nx, ny, px, py);
+  const bool plus = np_ >= nm;        // (the side: sign +1 / -1, folded into tA and the normal)
+  sep_consider(best, plus ? np_ : nm, len2, plus ? tAp : -tAm, plus ? nx : -nx, plus ? ny : -ny, px, py);
 }
 
 // nB == 4 in the path (the segment's control points); the stand-alone entry passes general B in A-like storage.
 __device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ordered, const Pts4& B, double nd[3]) {
-  SepBest best; best.have = false; best.num = 0; best.len2 = 1; best.sg = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
+  SepBest best; best.have = false; best.num = 0; best.len2 = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
   if (a_ordered && nA >= 3) {
     for (int p = 0; p < nA - 1; p++) {
       const double2 a0 = A[p], a1 = A[p + 1];
@@ -489,16 +489,16 @@ __device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ord
       double minA = NEP_INF, maxB = -NEP_INF;
       for (int i = 0; i < nA; i++) { const double t = nx * (A[i].x - cbx) + ny * (A[i].y - cby); minA = fmin(minA, t); }
       for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - cbx) + ny * (B.y[i] - cby); maxB = fmax(maxB, t); }
-      sep_consider(best, minA - maxB, len2, 1.0, minA, nx, ny, cbx, cby);
+      sep_consider(best, minA - maxB, len2, minA, nx, ny, cbx, cby);
     }
   }
   if (best.have) {   // the winning LP vertex in the reference's epsilon = 1 scaling
     const double len = sqrt(best.len2);
     const double g = best.num / len;
     const double s = 2.0 / g;
-    const double n1 = s * (best.sg * best.nx / len), n2 = s * (best.sg * best.ny / len);
+    const double n1 = s * (best.nx / len), n2 = s * (best.ny / len);
     nd[0] = n1; nd[1] = n2;
-    nd[2] = (1.0 - s * (best.sg * best.tA / len)) - (n1 * best.px + n2 * best.py);
+    nd[2] = (1.0 - s * (best.tA / len)) - (n1 * best.px + n2 * best.py);
     return true;
   }
   nd[0] = nd[1] = nd[2] = 0.0;
