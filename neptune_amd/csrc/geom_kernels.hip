@@ -412,9 +412,9 @@ struct SepBest { bool have; double num, len2, tA, nx, ny, px, py; };   // (tA, n
 
 __device__ __forceinline__ void sep_consider(SepBest& b, double num, double len2, double tA, double nx, double ny, double px, double py) {
   if (!(num > 0.0)) return;
-  bool better;
-  if (!b.have) better = (num * num) > (SEP_MIN_GAP * SEP_MIN_GAP) * len2;
-  else better = (num * num) * b.len2 > (b.num * b.num) * len2;
+  // (before the first candidate b holds the floor itself, num = SEP_MIN_GAP over len2 = 1: num^2 * 1.0 > (MIN * MIN) * len2 is the
+  // acceptance test of a first candidate, bit for bit, without a second comparison under a divergent branch)
+  const bool better = (num * num) * b.len2 > (b.num * b.num) * len2;
   if (better) { b.have = true; b.num = num; b.len2 = len2; b.tA = tA; b.nx = nx; b.ny = ny; b.px = px; b.py = py; }
 }
 
@@ -464,7 +464,7 @@ __device__ __forceinline__ void sep_pair(double px, double py, double qx, double
 
 // nB == 4 in the path (the segment's control points); the stand-alone entry passes general B in A-like storage.
 __device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ordered, const Pts4& B, double nd[3]) {
-  SepBest best; best.have = false; best.num = 0; best.len2 = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
+  SepBest best; best.have = false; best.num = SEP_MIN_GAP; best.len2 = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
   if (a_ordered && nA >= 3) {
     for (int p = 0; p < nA - 1; p++) {
       const double2 a0 = A[p], a1 = A[p + 1];
