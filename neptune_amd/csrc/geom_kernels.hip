@@ -463,14 +463,34 @@ __device__ __forceinline__ void sep_pair(double px, double py, double qx, double
 }
 
 // nB == 4 in the path (the segment's control points); the stand-alone entry passes general B in A-like storage.
-__device__ bool separator_impl(int nA, const double2* __restrict__ A, bool a_ordered, const Pts4& B, double nd[3]) {
+// kind of point set A: 0 = any points (every pair is a candidate line), 1 = counter-clockwise convex polygon (its edges), 2 = a base
+// square in cand_eval's corner order (+,+) (+,-) (-,+) (-,-)
+__device__ bool separator_impl(int nA, const double2* __restrict__ A, int kind, const Pts4& B, double nd[3]) {
   SepBest best; best.have = false; best.num = SEP_MIN_GAP; best.len2 = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
-  if (a_ordered && nA >= 3) {
+  if (kind == 1 && nA >= 3) {
     for (int p = 0; p < nA - 1; p++) {
       const double2 a0 = A[p], a1 = A[p + 1];
       sep_edge_ccw(a0.x, a0.y, a1.x, a1.y, B, best);
       if (p == 0) { const double2 al = A[nA - 1]; sep_edge_ccw(al.x, al.y, a0.x, a0.y, B, best); }   // closing edge, same orientation
     }
+  } else if (kind == 2) {
+    // The all-pairs enumeration of a square, without its passes over A: of the six pairs the two diagonals have corners on both
+    // sides (no candidate), and for the four edges the side of the other two corners is known — the corners on the edge project
+    // to exactly 0 (their difference to the edge's first point is 0 in one coordinate and multiplies an exactly zero normal
+    // component in the other), the far ones to -+4 r^2.  Same pairs in the same order with the same first points as the general
+    // path: the same candidates, bit for bit, at a third of the instructions (two of five segments meet a base square).
+    auto sq_edge = [&](int ip, int iq, bool plus) {
+      const double2 p = A[ip], q = A[iq];
+      const double ex = q.x - p.x, ey = q.y - p.y;
+      const double nx = -ey, ny = ex;
+      const double len2 = nx * nx + ny * ny;
+      if (!(len2 > 0.0)) return;
+      double minB = NEP_INF, maxB = -NEP_INF;
+#pragma unroll
+      for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - p.x) + ny * (B.y[i] - p.y); minB = fmin(minB, t); maxB = fmax(maxB, t); }
+      sep_consider(best, plus ? 0.0 - maxB : minB - 0.0, len2, plus ? 0.0 : -0.0, plus ? nx : -nx, plus ? ny : -ny, p.x, p.y);
+    };
+    sq_edge(0, 1, false); sq_edge(0, 2, true); sq_edge(1, 3, false); sq_edge(2, 3, true);
   } else {
     for (int p = 0; p < nA; p++) for (int q = p + 1; q < nA; q++) { const double2 a0 = A[p], a1 = A[q]; sep_pair(a0.x, a0.y, a1.x, a1.y, true, nA, A, B, best); }
   }
@@ -529,11 +549,11 @@ struct SepCtx {
   double el[3];          // lengths of the control polygon's three edges (the terms of hulldist)
 };
 __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, const double* by, double hulldist,
-                          int mode, double2* myA, int& nA, bool& ordered, const double2*& Ause) {
+                          int mode, double2* myA, int& nA, int& ordered, const double2*& Ause) {
   const bool stage = mode == 1, cull_tests = mode == 0;   // mode 0: the reference's proximity culls; 1: stage the point set (myA, or in place when null); 2: vertex count only
   const SceneParams& sp = *cx.sp; const ProblemSet& ps = *cx.ps;
   const int N = cx.N, S = cx.S, nH = cx.nH;
-  nA = 0; ordered = false;
+  nA = 0; ordered = 0;       // (the kind of point set: see separator_impl)
   if (c < nH) {
     const int j = c;
     if (sp.skip_own && j == cx.own) return false;
@@ -541,7 +561,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     const long h = hr.e * sp.num_pol + seg;
     nA = blk(ps.hull_nv, hr.boff)[h];
     if (nA <= 0) return false;
-    ordered = true;
+    ordered = 1;
     if (stage) {
       const double2* src = (const double2*)(blk(ps.hull_xy, hr.boff) + h * kHullV * 2);
       if (myA) for (int v = 0; v < nA; v++) myA[v] = src[v]; else Ause = src;
@@ -559,7 +579,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
       if (sqrt(ddx * ddx + ddy * ddy) < base_radius * 3) { close_to_base = true; break; }
     }
     if (!close_to_base) return false;
-    nA = 4;
+    nA = 4; ordered = 2;
     if (stage) {  // :536-540 (column order of base_hull)
       myA[0] = make_double2(pbx + base_radius, pby + base_radius);
       myA[1] = make_double2(pbx + base_radius, pby - base_radius);
@@ -580,7 +600,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
       for (int k = 0; k < nv - 1 && !close_s; k++) { dist -= ps.static_el[j * kHullV + k]; if (dist < 0) { close_s = true; break; } }
       if (!close_s) return false;
     }
-    ordered = true; nA = nv;
+    ordered = 1; nA = nv;
     if (stage) { if (myA) for (int v = 0; v < nv; v++) myA[v] = make_double2(src[2 * v], src[2 * v + 1]); else Ause = (const double2*)src; }
     return true;
   } else if (c < cx.total) {
@@ -652,7 +672,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
   int n_att = 0;
   for (int c0 = 0; c0 < total; c0 += 64) {
     const int c = c0 + lane;
-    int nA; bool ord;
+    int nA; int ord;
     const double2* unused = nullptr;
     const bool att = c < total && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused);
     const unsigned long long mask = __ballot(att);
@@ -678,7 +698,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
     double nd[3] = {0.0, 0.0, 0.0};
     bool far = false;
     // this batch's pool: every lane's vertex count, its exclusive prefix sum across the wave, then the staging
-    int c = 0, nA = 0; bool ord = false;
+    int c = 0, nA = 0; int ord = 0;
     if (active) { c = sAtt[a]; const double2* u_ = nullptr; cand_eval(cx, seg, c, bx, by, hulldist, 2, nullptr, nA, ord, u_); }
     int incl = nA;
 #pragma unroll
@@ -757,7 +777,7 @@ __global__ void separator_explicit_kernel(int n_prob, const int* __restrict__ a_
   for (int i = 0; i < nA; i++) A[i] = make_double2(a_xy[2 * (a_off[p] + i)], a_xy[2 * (a_off[p] + i) + 1]);
   for (int i = 0; i < 4; i++) { B.x[i] = b_xy[2 * (b_off[p] + i)]; B.y[i] = b_xy[2 * (b_off[p] + i) + 1]; }
   double nd[3];
-  const bool ok = separator_impl(nA, A, false, B, nd);
+  const bool ok = separator_impl(nA, A, 0, B, nd);
   nd_out[3 * p] = nd[0]; nd_out[3 * p + 1] = nd[1]; nd_out[3 * p + 2] = nd[2];
   solved[p] = ok ? 1 : 0;
 }
