@@ -210,8 +210,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     // alpha sigma mu, positive and finite, and everything it enters is multiplied by the zero normal — `ok` masks the two places
     // where a padded row would still count: the complementarity sum and the step-length test.
     auto for_rows = [&](double (&sl)[RS], double (&ll)[RS], double (&il)[RS], auto&& body) {
-      // two slots per scalar branch: both rows' coefficient loads are issued before either row's arithmetic (a block per slot
-      // would leave every row waiting for its own three ds_reads)
+      // (a block per slot would leave every row waiting for its own three ds_reads)
       // slots 0..3 and 4..7 four per scalar branch, 8 alone (a wave whose segments have at most 64 lines stops after 7): the rows'
       // coefficient loads are issued ahead of the rows' arithmetic, group by group
       static_assert(RS == 9, "slot grouping below");
