@@ -70,9 +70,10 @@ constexpr int kLLHalf = kLdsLinesHalf + 2;
 // and the register Cholesky.
 template <int CTRL>
 __device__ __forceinline__ double dpp(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  // (mov_dpp, not update_dpp(old = src): the latter first copies the source into the destination — four instructions per double
+  // instead of two; every lane of these permutations has a valid source, so there is no "old" value to keep)
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
 constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
