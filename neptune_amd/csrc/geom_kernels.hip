@@ -216,12 +216,22 @@ __device__ __forceinline__ int group_hull(int n, const double (&px)[kGrpPts], co
   int rank[kGrpPts];
 #pragma unroll
   for (int j = 0; j < kGrpPts; j++) rank[j] = 0;
-  for (int i = 0; i < n; i++) {                     // (ties by point index so that the ranks are a permutation: as wave_hull)
-    const double qx = sxy[2 * i], qy = sxy[2 * i + 1];
+  // (ties by point index so that the ranks are a permutation: as wave_hull.  The point slots in use are bounded for the whole wave
+  // — a scalar branch per slot — and the comparison is written without short circuits: lane-divergent exits cost more here than
+  // the comparisons they skip)
+  int nmax = 0;
+#pragma unroll
+  for (int gg = 0; gg < 8; gg++) { const int ng = __builtin_amdgcn_readlane(n, 8 * gg); nmax = ng > nmax ? ng : nmax; }
+  const int jmax = (nmax + 7) >> 3;
+  for (int i = 0; i < nmax; i++) {
+    const bool live = i < n;
+    const double qx = live ? sxy[2 * i] : 0.0, qy = live ? sxy[2 * i + 1] : 0.0;
 #pragma unroll
     for (int j = 0; j < kGrpPts; j++) {
-      if (8 * j >= n) break;
-      if (lex_less(qx, qy, px[j], py[j]) || (qx == px[j] && qy == py[j] && i < sub + 8 * j)) rank[j]++;
+      if (j < jmax) {
+        const bool lt = (qx < px[j]) | ((qx == px[j]) & ((qy < py[j]) | ((qy == py[j]) & (i < sub + 8 * j))));
+        rank[j] += (live & lt) ? 1 : 0;
+      }
     }
   }
   __syncthreads();
