@@ -262,18 +262,21 @@ __device__ __forceinline__ int group_hull(int n, const double (&px)[kGrpPts], co
     for (int i = 0; i < m; i++) {
       const int idx = lower ? i : m - 1 - i;
       const double x = sxy[2 * idx], y = sxy[2 * idx + 1];
+      // (the mask is kept in PUSH order — bit i = the i-th point this chain visited, i.e. sorted index i for the lower chain and
+      // m - 1 - i for the upper one — so that the top of either stack is the highest set bit)
       while (kc >= 2 && cross3(ax, ay, bx, by, x, y) <= 0.0) {
-        const int top = lower ? 63 - __clzll((long long)mask) : __ffsll((long long)mask) - 1;
+        const int top = 63 - __clzll((long long)mask);
         mask &= ~(1ull << top);
         kc--; bx = ax; by = ay;
         if (kc >= 2) {
-          const int t1 = lower ? 63 - __clzll((long long)mask) : __ffsll((long long)mask) - 1;
+          const int t1 = 63 - __clzll((long long)mask);
           const unsigned long long rest = mask & ~(1ull << t1);
-          const int t2 = lower ? 63 - __clzll((long long)rest) : __ffsll((long long)rest) - 1;
-          ax = sxy[2 * t2]; ay = sxy[2 * t2 + 1];
+          const int t2 = 63 - __clzll((long long)rest);
+          const int p2 = lower ? t2 : m - 1 - t2;
+          ax = sxy[2 * p2]; ay = sxy[2 * p2 + 1];
         }
       }
-      mask |= 1ull << idx; kc++;
+      mask |= 1ull << i; kc++;
       ax = bx; ay = by; bx = x; by = y;
     }
   }
@@ -289,8 +292,9 @@ __device__ __forceinline__ int group_hull(int n, const double (&px)[kGrpPts], co
         if (p < m) {
           const double x = sxy[2 * p], y = sxy[2 * p + 1];
           if ((L >> p) & 1ull) { const int o = __popcll(L & ((1ull << p) - 1ull)); if (o < cap) { out_xy[2 * o] = x; out_xy[2 * o + 1] = y; } }
-          if (((U >> p) & 1ull) && p != 0 && p != m - 1) {
-            const int o = kl + __popcll(U >> (p + 1)) - 1;      // entries pushed before it that are still on the stack, minus the first
+          const int iu = m - 1 - p;                                  // the upper chain's push index of this point
+          if (((U >> iu) & 1ull) && p != 0 && p != m - 1) {
+            const int o = kl + __popcll(U & ((1ull << iu) - 1ull)) - 1;      // entries pushed before it that are still on the stack, minus the first
             if (o < cap) { out_xy[2 * o] = x; out_xy[2 * o + 1] = y; }
           }
         }
