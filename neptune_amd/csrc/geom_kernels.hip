@@ -425,10 +425,10 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
 struct SepBest { bool have; double num, len2, tA, nx, ny, px, py; };   // (tA, nx, ny carry the candidate's sign: exact negations)
 
 __device__ __forceinline__ void sep_consider(SepBest& b, double num, double len2, double tA, double nx, double ny, double px, double py) {
-  if (!(num > 0.0)) return;
   // (before the first candidate b holds the floor itself, num = SEP_MIN_GAP over len2 = 1: num^2 * 1.0 > (MIN * MIN) * len2 is the
-  // acceptance test of a first candidate, bit for bit, without a second comparison under a divergent branch)
-  const bool better = (num * num) * b.len2 > (b.num * b.num) * len2;
+  // acceptance test of a first candidate, bit for bit, without a second comparison under a divergent branch; num > 0 is part of
+  // the predicate rather than an early exit)
+  const bool better = (num > 0.0) & ((num * num) * b.len2 > (b.num * b.num) * len2);
   if (better) { b.have = true; b.num = num; b.len2 = len2; b.tA = tA; b.nx = nx; b.ny = ny; b.px = px; b.py = py; }
 }
 
@@ -444,7 +444,7 @@ __device__ __forceinline__ void sep_edge_ccw(double px, double py, double qx, do
   const double ex = qx - px, ey = qy - py;
   const double nx = -ey, ny = ex;
   const double len2 = nx * nx + ny * ny;
-  if (!(len2 > 0.0)) return;
+  // (a degenerate pair, len2 = 0, needs no exit of its own: every projection is then exactly 0, so is the gap, and a candidate must have num > 0)
   double maxB = -NEP_INF;
 #pragma unroll
   for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); maxB = fmax(maxB, t); }
@@ -456,7 +456,6 @@ __device__ __forceinline__ void sep_pair(double px, double py, double qx, double
   const double ex = qx - px, ey = qy - py;
   const double nx = -ey, ny = ex;
   const double len2 = nx * nx + ny * ny;
-  if (!(len2 > 0.0)) return;
   double minA = NEP_INF, maxA = -NEP_INF, minB = NEP_INF, maxB = -NEP_INF;
 #pragma unroll
   for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - px) + ny * (B.y[i] - py); minB = fmin(minB, t); maxB = fmax(maxB, t); }
@@ -498,7 +497,6 @@ __device__ bool separator_impl(int nA, const double2* __restrict__ A, int kind, 
       const double ex = q.x - p.x, ey = q.y - p.y;
       const double nx = -ey, ny = ex;
       const double len2 = nx * nx + ny * ny;
-      if (!(len2 > 0.0)) return;
       double minB = NEP_INF, maxB = -NEP_INF;
 #pragma unroll
       for (int i = 0; i < 4; i++) { const double t = nx * (B.x[i] - p.x) + ny * (B.y[i] - p.y); minB = fmin(minB, t); maxB = fmax(maxB, t); }
