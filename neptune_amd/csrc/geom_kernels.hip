@@ -584,11 +584,23 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     const double base_radius = 0.7;
     const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
     bool close_to_base = !cull_tests;      // (staging is only asked for candidates that passed this test in step 1)
-    for (int k = 0; k < 4 && cull_tests; k++) {
-      const double ddx = bx[k] - pbx, ddy = by[k] - pby;
-      // sqrt(ddx^2+ddy^2) >= max(|ddx|,|ddy|): beyond 2.2 on either axis the test below is false; skip its sqrt
-      if (fabs(ddx) > 2.2 || fabs(ddy) > 2.2) continue;
-      if (sqrt(ddx * ddx + ddy * ddy) < base_radius * 3) { close_to_base = true; break; }
+    if (cull_tests) {
+      // all four control points, no exits (lanes of a wave leave a loop at different points only to wait for each other); the square
+      // root is taken where the coarse test does not already say "far" (sqrt(ddx^2 + ddy^2) >= max(|ddx|, |ddy|): beyond 2.2 on
+      // either axis the reference's test is false)
+      bool near_any = false; double d2[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double ddx = bx[k] - pbx, ddy = by[k] - pby;
+        d2[k] = ddx * ddx + ddy * ddy;
+        const bool nr = !((fabs(ddx) > 2.2) | (fabs(ddy) > 2.2));
+        if (!nr) d2[k] = 1e30;
+        near_any |= nr;
+      }
+      if (near_any) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) close_to_base |= sqrt(d2[k]) < base_radius * 3;
+      }
     }
     if (!close_to_base) return false;
     nA = 4; ordered = 2;
@@ -608,8 +620,11 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
       bool close_s = false;
       const double ddx = bx[0] - src[0], ddy = by[0] - src[1];
       double dist = sqrt(ddx * ddx + ddy * ddy);
-      for (int k = 0; k < 3; k++) { dist -= cx.el[k]; if (dist < 0) { close_s = true; break; } }   // (same values as the reference's per-call square roots)
-      for (int k = 0; k < nv - 1 && !close_s; k++) { dist -= ps.static_el[j * kHullV + k]; if (dist < 0) { close_s = true; break; } }
+      // (same values as the reference's per-call square roots; the reference leaves at the first negative remainder — the later
+      // subtractions cannot un-set the verdict, so they are done anyway instead of a lane-divergent exit)
+#pragma unroll
+      for (int k = 0; k < 3; k++) { dist -= cx.el[k]; close_s |= dist < 0; }
+      for (int k = 0; k < nv - 1; k++) { dist -= ps.static_el[j * kHullV + k]; close_s |= dist < 0; }
       if (!close_s) return false;
     }
     ordered = 1; nA = nv;
