@@ -48,11 +48,23 @@
 #endif
 // 1: a row's 1 / s is kept next to (s, lambda) from pass A2 to the next iteration's pass A1 (four reciprocals per row and
 // iteration fewer, a third register pair per row: needs the 168-VGPR budget of NEP_QP_REG_WGS = 3)
+// 2: the same as a float (one register per row): the seed of the Newton step that otherwise starts from v_rcp_f64, whose result
+// is no better than a float's 24 bits anyway
 #ifndef NEP_QP_CACHE_IS
 #define NEP_QP_CACHE_IS 0
 #endif
 
 namespace nep {
+#if NEP_QP_CACHE_IS == 2
+typedef float isd_t;
+__device__ __forceinline__ double is_of(double s, isd_t c) { const double r = (double)c, e = __builtin_fma(-s, r, 1.0); return __builtin_fma(r, e, r); }
+#elif NEP_QP_CACHE_IS == 1
+typedef double isd_t;
+__device__ __forceinline__ double is_of(double, isd_t c) { return c; }
+#else
+typedef double isd_t;
+__device__ __forceinline__ double is_of(double s, isd_t) { return frcp(s); }
+#endif
 
 template <bool CULL, int RS>
 __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
@@ -209,7 +221,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     // slack stays exactly 1 (activity and slack step are exactly zero), their multiplier follows lambda <- (1 - alpha) lambda +
     // alpha sigma mu, positive and finite, and everything it enters is multiplied by the zero normal — `ok` masks the two places
     // where a padded row would still count: the complementarity sum and the step-length test.
-    auto for_rows = [&](double (&sl)[RS], double (&ll)[RS], double (&il)[RS], auto&& body) {
+    auto for_rows = [&](double (&sl)[RS], double (&ll)[RS], isd_t (&il)[RS], auto&& body) {
       // (a block per slot would leave every row waiting for its own three ds_reads)
       // slots 0..3 and 4..7 four per scalar branch, 8 alone (a wave whose segments have at most 64 lines stops after 7): the rows'
       // coefficient loads are issued ahead of the rows' arithmetic, group by group
@@ -236,7 +248,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           const int l = sI[li] + j;
           const double n1 = gsp[l], n2 = gsp[GL + l], h = gsp[2 * GL + l];
           double s = gsp[(3 + lk) * GL + l], lam = gsp[(7 + lk) * GL + l];
-          double isg = frcp(s);
+          isd_t isg = (isd_t)frcp(s);
           body(true, n1, n2, h, s, lam, isg);
           gsp[(3 + lk) * GL + l] = s; gsp[(7 + lk) * GL + l] = lam;
         }
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         // ---- K <= 2 with the terminal rows: a single point, feasible or not (tolerance 1e-6) ------
         double viol = 0.0, d0 = 0, d1 = 0, d2 = 0;
         { int ax, rho; double hi, lo; if (box_role(ax, rho, hi, lo)) { const double a = sOff[rho * 3 + ax]; viol = fmax(a - hi, lo - a); } }
-        { const int lrho = otid() >> 3; const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; double du_[RS], dv_[RS], dw_[RS]; for_rows(du_, dv_, dw_, [&](bool v, double n1, double n2, double h, double&, double&, double&) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
+        { const int lrho = otid() >> 3; const double ox = sOff[lrho * 3], oy = sOff[lrho * 3 + 1]; double du_[RS], dv_[RS]; isd_t dw_[RS]; for_rows(du_, dv_, dw_, [&](bool v, double n1, double n2, double h, double&, double&, isd_t&) { viol = fmax(viol, v ? n1 * ox + n2 * oy - h : 0.0); }); }
         if (tm < 6) {
           const int ax = tm / 2, e = tm % 2;
           viol = fmax(viol, fabs(tResP[e * 3] * sInit[ax * 3] + tResP[e * 3 + 1] * sInit[ax * 3 + 1] + tResP[e * 3 + 2] * sInit[ax * 3 + 2]));
@@ -360,8 +372,8 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           {
             const int lrho = otid() >> 3; const bool has_line = (lrho >> 2) < K;
             const double cx = has_line ? sOff[lrho * 3] + proj(lrho, 0, sDx) : 0.0, cy = has_line ? sOff[lrho * 3 + 1] + proj(lrho, 1, sDx) : 0.0;
-            double du_[RS], dv_[RS], dw_[RS];
-            for_rows(du_, dv_, dw_, [&](bool ok, double n1, double n2, double h, double&, double&, double&) { viol = fmax(viol, ok ? (n1 * cx + n2 * cy) - h : -1.0); });
+            double du_[RS], dv_[RS]; isd_t dw_[RS];
+            for_rows(du_, dv_, dw_, [&](bool ok, double n1, double n2, double h, double&, double&, isd_t&) { viol = fmax(viol, ok ? (n1 * cx + n2 * cy) - h : -1.0); });
           }
           if (tm == BS - 1 && has_qc) {
             double c = -0.10 * 0.10;
@@ -383,8 +395,8 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         // next to the row state for the whole solve)
         // row state (its lifetime is one solve of one mode): box rows [0] upper (alpha = +e), [1] lower; line rows: slot u = line slice + 8 u of my segment
         double bs0 = 1, bl0 = 0, bs1 = 1, bl1 = 0;
-        double sl[RS], ll[RS], il[RS];        // (il: 1 / s of the row, kept only with NEP_QP_CACHE_IS)
-        double bi0 = 1, bi1 = 1;
+        double sl[RS], ll[RS]; isd_t il[RS];        // (il: 1 / s of the row, kept only with NEP_QP_CACHE_IS)
+        isd_t bi0 = 1, bi1 = 1;
         double cpb = 0.0, uab = 0.0, udb = 0.0, cpx = 0.0, cpy = 0.0;
         double uax = 0.0, uay = 0.0, udx = 0.0, udy = 0.0;
         {
@@ -398,10 +410,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           if ((lrho >> 2) < K) { cpx = sOff[lrho * 3] + proj(lrho, 0, sZ); cpy = sOff[lrho * 3 + 1] + proj(lrho, 1, sZ); }
         }
 #pragma unroll
-        for (int u = 0; u < RS; u++) { sl[u] = 1.0; ll[u] = 1.0; il[u] = 1.0; }
-        for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, double& isv) {
+        for (int u = 0; u < RS; u++) { sl[u] = 1.0; ll[u] = 1.0; il[u] = (isd_t)1.0; }
+        for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, isd_t& isv) {
           const double slk = h - (n1 * cpx + n2 * cpy);
-          s = slk > kSlackFloor ? slk : kSlackFloor; isv = frcp(s); lam = kMu0 * isv;      // (a padded row starts at s = 1, lambda = mu0)
+          s = slk > kSlackFloor ? slk : kSlackFloor; const double is_ = frcp(s); isv = (isd_t)is_; lam = kMu0 * is_;      // (a padded row starts at s = 1, lambda = mu0)
         });
         if (tm >= 64 && tm < 128) {   // the dual residual's scale: a maximum, whatever the order
           const double qs = fmax(1.0, wave_max(tm - 64 < n ? fabs(sG[tm - 64]) : 0.0));
@@ -430,8 +442,8 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           double nrp = 0, sumsl = 0, dummy1 = 0;
           if (it > 0) {     // (the first iteration has no step to apply: alpha = 0 would leave every row as it is)
             const double alpha_prev = sc[sAlpha], sm_prev = sc[sSigMu];
-            auto rowA1 = [&](double& s, double& lam, double a_old, double ga, double gd, double h, double isc) {
-              const double rp0 = a_old + s - h, is = NEP_QP_CACHE_IS ? isc : frcp(s), w0 = lam * is;
+            auto rowA1 = [&](double& s, double& lam, double a_old, double ga, double gd, double h, isd_t isc) {
+              const double rp0 = a_old + s - h, is = is_of(s, isc), w0 = lam * is;
               const double dsa = -rp0 - ga, dla = -lam + w0 * (rp0 + ga);
               const double rcv = s * lam - sm_prev + dsa * dla;
               const double ds = -rp0 - gd, dl = -rcv * is + w0 * (rp0 + gd);
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               int ax, rho; double hi, lo;
               if (box_role(ax, rho, hi, lo)) { rowA1(bs0, bl0, cpb, uab, udb, hi, bi0); rowA1(bs1, bl1, -cpb, -uab, -udb, -lo, bi1); }
             }
-            for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, double& isv) {
+            for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, isd_t& isv) {
               rowA1(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, isv);
             });
             cpb = __builtin_fma(alpha_prev, udb, cpb); cpx = __builtin_fma(alpha_prev, udx, cpx); cpy = __builtin_fma(alpha_prev, udy, cpy);   // base rows move with the step
@@ -451,15 +463,15 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               int ax, rho; double hi, lo;
               if (box_role(ax, rho, hi, lo)) {
                 double bTl = 0, bD = 0, bT1 = 0;
-                { bi0 = frcp(bs0); const double rp = cpb + bs0 - hi, w = bl0 * bi0, v = bl0 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs0 * bl0; bTl += bl0; bD += w; bT1 += v; }
-                { bi1 = frcp(bs1); const double rp = -cpb + bs1 + lo, w = bl1 * bi1, v = bl1 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs1 * bl1; bTl -= bl1; bD += w; bT1 -= v; }
+                { const double is_ = frcp(bs0); bi0 = (isd_t)is_; const double rp = cpb + bs0 - hi, w = bl0 * is_, v = bl0 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs0 * bl0; bTl += bl0; bD += w; bT1 += v; }
+                { const double is_ = frcp(bs1); bi1 = (isd_t)is_; const double rp = -cpb + bs1 + lo, w = bl1 * is_, v = bl1 - w * rp; nrp = fmax(nrp, fabs(rp)); sumsl += bs1 * bl1; bTl -= bl1; bD += w; bT1 -= v; }
                 sTc[rho * 6 + ax] = bTl; sTc[rho * 6 + 3 + ax] = bT1; sDc[rho * 4 + (ax == 0 ? 0 : (ax == 1 ? 2 : 3))] = bD;
               }
             }
             double lTx = 0, lTy = 0, lDxx = 0, lDxy = 0, lDyy = 0, l1x = 0, l1y = 0;
-            for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, double& isv) {
-              isv = frcp(s);
-              const double rp = (n1 * cpx + n2 * cpy) + s - h, w = lam * isv, v = lam - w * rp;
+            for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, isd_t& isv) {
+              const double is_ = frcp(s); isv = (isd_t)is_;
+              const double rp = (n1 * cpx + n2 * cpy) + s - h, w = lam * is_, v = lam - w * rp;
               nrp = fmax(nrp, fabs(rp)); sumsl += ok ? s * lam : 0.0;
               lTx += lam * n1; lTy += lam * n2; lDxx += w * n1 * n1; lDxy += w * n1 * n2; lDyy += w * n2 * n2; l1x += v * n1; l1y += v * n2;
             });
@@ -711,8 +723,8 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           // ---- (P2) affine step: ratio test, mu_aff, corrector right-hand side split as va - sigma mu vb (see qp_kernel) ----
           double rmax = 0, c2 = 0, dmy = 0;
           {
-            auto rowP2 = [&](double s, double lam, double a, double ga, double h, double& va, double& vb, double isc) {
-              const double rp = a + s - h, is = NEP_QP_CACHE_IS ? isc : frcp(s), w = lam * is;
+            auto rowP2 = [&](double s, double lam, double a, double ga, double h, double& va, double& vb, isd_t isc) {
+              const double rp = a + s - h, is = is_of(s, isc), w = lam * is;
               const double dsa = -rp - ga, q = dsa * is, dla = -__builtin_fma(w, dsa, lam);
               rmax = fmax(rmax, fmax(-q, 1.0 + q));
               c2 += dsa * dla;
@@ -730,7 +742,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const int t = otid();
             { const int rho = t >> 3; uax = proj(rho, 0, sDxa); uay = proj(rho, 1, sDxa); }
             double vax = 0, vay = 0, vbx = 0, vby = 0;
-            for_rows(sl, ll, il, [&](bool, double n1, double n2, double h, double& s, double& lam, double& isv) {
+            for_rows(sl, ll, il, [&](bool, double n1, double n2, double h, double& s, double& lam, isd_t& isv) {
               double va, vb;
               rowP2(s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, h, va, vb, isv);
               vax += va * n1; vay += va * n2; vbx += vb * n1; vby += vb * n2;
@@ -804,8 +816,8 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           // ---- (P5) step length of the combined direction ------------------------------------------
           rmax = 0;
           {
-            auto rowP5 = [&](bool ok, double s, double lam, double a, double ga, double gd, double h, double isc) {
-              const double rp = a + s - h, is = NEP_QP_CACHE_IS ? isc : frcp(s), w = lam * is;
+            auto rowP5 = [&](bool ok, double s, double lam, double a, double ga, double gd, double h, isd_t isc) {
+              const double rp = a + s - h, is = is_of(s, isc), w = lam * is;
               const double dsa = -rp - ga, dla = -lam + w * (rp + ga);
               const double rcv = s * lam - sm + dsa * dla;
               const double ds = -rp - gd, dl = -rcv * is + w * (rp + gd);
@@ -817,7 +829,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             }
             const int t = otid();
             { const int rho = t >> 3; udx = proj(rho, 0, sDx); udy = proj(rho, 1, sDx); }
-            for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, double& isv) { rowP5(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, isv); });
+            for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, isd_t& isv) { rowP5(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, isv); });
             if (t == BS - 1 && has_qc) {
               const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
               double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDx[e];
