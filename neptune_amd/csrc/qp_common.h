@@ -13,6 +13,15 @@ constexpr int BS = 256;
 constexpr int SBS = 9;            // LDS row stride of the base-row table B (8 used; odd -> lanes on consecutive rows hit distinct banks)
 constexpr int MS = 25;            // LDS row stride of the normal matrix (n <= 24; odd -> no bank conflicts)
 constexpr int kMaxIt = 60;
+// Mehrotra's second-order term dsa * dla extrapolates the affine step to its full length.  From iteration kCorrFromIt on (the
+// usual solve has ended by then), whenever less than kCorrMinStep of that step is admissible, the predictor is discarded: the
+// corrector is formed as if the affine direction were zero (dsa = -rp, dla = -lambda + w rp: what is left of the term vanishes
+// with the primal residual), sigma as computed.  With the full term marginally feasible problems cycle (gap down 10x, back up
+// over three short steps, for ever) and infeasible ones blow up to 1e18 and idle to the iteration cap; without it the former
+// converge and the latter stall within a few iterations (oracle: qp_solve).
+constexpr int kCorrFromIt = 10;
+constexpr double kCorrMinStep = 0.1;
+constexpr int kCorrMaxCount = 8;            // a solve that needs this more often is given up (converging ones: at most five times in 16 000)
 // start point of the rows: slack = max(h - a.x0, kSlackFloor), lambda = kMu0 / slack.  Chosen on this path's two kinds of
 // guesses (oracle sweep): 1 / 1 needs 11.3 iterations on front-end guesses and 5.8 on near-optimal ones, 0.1 / 2
 // needs 8.6 and 6.1.
@@ -57,7 +66,7 @@ constexpr int oRed = oScal + 32;            // [3][16] reduction scratch (one sl
 constexpr int oFixedEnd = oRed + 48;
 constexpr int kFixedDoubles = (oFixedEnd + 1) & ~1;
 
-enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigma, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2, sBestMerit };
+enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigKeep, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2, sBestMerit };
 
 // Line stride of the carve that lets two workgroups share a CU (backend.hip::size_scratch's l_half, rounded the same way):
 // the normal case, instantiated with the stride as a compile-time constant so that the row passes' LDS accesses take

@@ -278,6 +278,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         sI[16] = 0;  // loose snapshot present
         sI[17] = 0;  // stall counter
         sI[22] = -1; // iteration of the first loose hit
+        sI[23] = 0;  // this iteration repeats the previous one with its predictor discarded (kCorrMinStep)
       }
       __syncthreads();
       // each thread keeps the values of its own base rows (and their step projections) in registers
@@ -352,7 +353,8 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
 
       // Row direction of the previous solve, recomputed by the
       // merged update:  ds = -rp - gd ; dl = -rc/s + w (rp + gd), rc = s lam - sigma mu + dsa dla.
-      double alpha_prev = 0.0, sm_prev = 0.0;
+      double alpha_prev = 0.0, sm_prev = 0.0, sm_keep = 0.0;
+      int n_nopred = 0;
       double* redA = sRed; double* redP2 = sRed + 16; double* redP5 = sRed + 32;
       const int n0 = has_qc ? n : 2 * nz;                       // wave 0 factors this block, wave 1 the z block
       const unsigned zoff_m = lds0 + (oM + 2 * nz * MS + 2 * nz) * 8, zoff_d = lds0 + (oInvD + 2 * nz) * 8;
@@ -543,8 +545,10 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         if ((!sI[19] || !sI[20]) && tid == 0 && ps.dbg && slot == NEP_QP_ITERDBG && mode == 0 && it < 59) ps.dbg[16 + (it + 1) * 8 + 5] = 100 + sI[19] * 10 + sI[20];
 #endif
         if (!sI[19] || !sI[20]) break;
-        if (has_box) uab = proj(brho, bax, sDxa);
-        if (has_line) { uax = proj(lrho, 0, sDxa); uay = proj(lrho, 1, sDxa); }
+        // (nopred: see kCorrMinStep — every pass that re-derives the second-order term does so from uab / uax / uay)
+        const bool nopred = sI[23] != 0;
+        if (has_box) uab = nopred ? 0.0 : proj(brho, bax, sDxa);
+        if (has_line) { uax = nopred ? 0.0 : proj(lrho, 0, sDxa); uay = nopred ? 0.0 : proj(lrho, 1, sDxa); }
         TICK(5);
         // ---- (P2) affine step: ratio test, the sum that gives mu_aff for any alpha, and the corrector's
         // right-hand side split as  va - sigma mu * vb  (sigma is only known after this pass's reduction):
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         }
         if (tid == BS - 1 && has_qc) {
           const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
-          double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
+          double gd = 0; if (!nopred) for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
           const double dsq = -rpq - gd, dlq = -lq + wq * (rpq + gd);
           sc[sDsqA] = dsq; sc[sDlqA] = dlq;
           rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
@@ -597,6 +601,15 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           // target would otherwise collapse by 1e5 per iteration, the last iterate would sit at mu ~ 1e-15 with weights
           // lambda/s ~ 1e17, and the rounding of that last step shows up as 1e-6 in the flat directions of the coefficients
           sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) * inv_mt);
+          if (nopred) sm = sm_keep;            // (sigma mu of the discarded predictor)
+          else if (it >= kCorrFromIt && aaff < kCorrMinStep) {
+            // the affine step is too short for its second-order term to mean anything: the iteration is repeated from the same
+            // point (a step of length zero) with the predictor discarded — identical in every thread, rare and late
+            if (n_nopred >= kCorrMaxCount) break;             // (not going to end: give this attempt up)
+            alpha_prev = 0.0; sm_keep = sm; sI[23] = 1; n_nopred++;
+            it--;
+            continue;
+          }
         }
         TICK(6);
         TICK(7);
@@ -659,7 +672,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         {
           double alpha = rmax > 0.0 ? frcp2(rmax) : 1e30;
           alpha = fmin(1.0, fmin(fmax(1.0 - sc[sMu], kStepFracMin), kStepFracMax) * alpha);
-          if (tid == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
+          if (tid == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; sI[23] = 0; }
           if (tid < n) sZ[tid] += alpha * sDx[tid];
           alpha_prev = alpha; sm_prev = sm;
         }

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             }
           }
           sc[sObj0] = o;
-          sI[16] = 0; sI[17] = 0; sI[22] = -1;
+          sI[16] = 0; sI[17] = 0; sI[22] = -1; sI[23] = 0; sI[24] = 0;
         }
         __syncthreads();
         auto proj = [&](int rho, int ax, const double* vec) {   // B's columns >= nz are zero and the vectors' tails are kept finite (zeroed below)
@@ -721,6 +721,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
           if (!__builtin_amdgcn_readfirstlane(sI[19]) || !__builtin_amdgcn_readfirstlane(sI[20])) break;
           // ---- (P2) affine step: ratio test, mu_aff, corrector right-hand side split as va - sigma mu vb (see qp_kernel) ----
+          // (nopred: this iteration repeats the previous one with its predictor discarded — kCorrMinStep, below: every pass
+          // that re-derives the second-order term does so from uab / uax / uay, so zeroing the three is all it takes)
+          const bool nopred = __builtin_amdgcn_readfirstlane(sI[23]) != 0;
+          const int n_nopred = __builtin_amdgcn_readfirstlane(sI[24]);      // (how often so far)
           double rmax = 0, c2 = 0, dmy = 0;
           {
             auto rowP2 = [&](double s, double lam, double a, double ga, double h, double& va, double& vb, isd_t isc) {
@@ -733,14 +737,14 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             {
               int ax, rho; double hi, lo;
               if (box_role(ax, rho, hi, lo)) {
-                uab = proj(rho, ax, sDxa);
+                uab = nopred ? 0.0 : proj(rho, ax, sDxa);
                 double va0, vb0, va1, vb1;
                 rowP2(bs0, bl0, cpb, uab, hi, va0, vb0, bi0); rowP2(bs1, bl1, -cpb, -uab, -lo, va1, vb1, bi1);
                 sTc[rho * 6 + 3 + ax] = va0 - va1; sTc[rho * 6 + ax] = vb0 - vb1;
               }
             }
             const int t = otid();
-            { const int rho = t >> 3; uax = proj(rho, 0, sDxa); uay = proj(rho, 1, sDxa); }
+            { const int rho = t >> 3; uax = nopred ? 0.0 : proj(rho, 0, sDxa); uay = nopred ? 0.0 : proj(rho, 1, sDxa); }
             double vax = 0, vay = 0, vbx = 0, vby = 0;
             for_rows(sl, ll, il, [&](bool, double n1, double n2, double h, double& s, double& lam, isd_t& isv) {
               double va, vb;
@@ -751,7 +755,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             if ((t & 7) == 0) { double* o = sAccL + (t >> 3) * 8; o[5] = vax; o[6] = vay; o[0] = vbx; o[1] = vby; }
             if (t == BS - 1 && has_qc) {
               const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
-              double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
+              double gd = 0; if (!nopred) for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
               const double dsq = -rpq - gd, dlq = -lq + wq * (rpq + gd);
               sc[sDsqA] = dsq; sc[sDlqA] = dlq;
               rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
@@ -770,6 +774,15 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const double rr = mua * frcp2(mu);
             sm = rr * rr * rr * mu;
             sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) * inv_mt);
+            if (nopred) sm = sc[sSigKeep];       // (sigma mu of the discarded predictor)
+            else if (__builtin_amdgcn_readfirstlane((int)(it >= kCorrFromIt && aaff < kCorrMinStep))) {
+              // the affine step is too short for its second-order term to mean anything: repeat the iteration from the same point
+              // (a step of length zero) with the predictor discarded.  Rare and late, so the repeated assembly does not matter.
+              if (n_nopred >= kCorrMaxCount) break;                 // (not going to end: give this attempt up)
+              sc[sAlpha] = 0.0; sc[sSigKeep] = sm; sI[23] = 1; sI[24] = n_nopred + 1;      // (every thread stores the same values)
+              it--;
+              continue;
+            }
           }
           {
             const int t = otid();
@@ -847,7 +860,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             double alpha = rmax > 0.0 ? frcp2(rmax) : 1e30;
             alpha = fmin(1.0, fmin(fmax(1.0 - sc[sMu], kStepFracMin), kStepFracMax) * alpha);
             const int t = otid();
-            if (t == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; }
+            if (t == 0) { if (alpha < 1e-8) sI[17]++; else sI[17] = 0; sI[23] = 0; }
             sc[sAlpha] = alpha; sc[sSigMu] = sm;     // (every thread stores the same two values: pass A reads them back without a barrier in between)
             if (t < n) sZ[t] += alpha * sDx[t];
           }

@@ -548,6 +548,17 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   const double EXP_TAU = getenv("ORC_EXP_TAU") ? atof(getenv("ORC_EXP_TAU")) : 0.99999;
   const double EXP_GAPTOL = getenv("ORC_EXP_GAPTOL") ? atof(getenv("ORC_EXP_GAPTOL")) : 1e-10;
   const int trace = getenv("ORC_QP_TRACE") != NULL;
+  /* Mehrotra's second-order term dsa*dla extrapolates the affine step to its full length.  From the tenth iteration on (the
+     usual solve has ended by then), whenever less than a tenth of that step is admissible, the predictor is discarded: the
+     corrector is formed as if the affine direction were zero (dsa = -rp, dla = -lam + w rp: what is left of the term vanishes
+     with the primal residual), sigma as computed.  With the full term marginally feasible problems cycle (gap down 10x, then
+     back up over three short steps, for ever) and infeasible ones blow up to 1e18 and idle to the iteration cap; without it the
+     former converge and the latter stall within a few iterations.  Overridable for experiments. */
+  const double EXP_CORR = getenv("ORC_EXP_CORR") ? atof(getenv("ORC_EXP_CORR")) : 0.1;
+  const int EXP_CORR_IT = getenv("ORC_EXP_CORR_IT") ? atoi(getenv("ORC_EXP_CORR_IT")) : 10;
+  double alpha_aff = 1.0;
+  int ntrig = 0, give_up = 0;
+  const int EXP_CORR_MAX = getenv("ORC_EXP_CORR_MAX") ? atoi(getenv("ORC_EXP_CORR_MAX")) : 8;
   double* s = (double*)malloc(sizeof(double) * (mt + 1) * 10);
   double* lam = s + (mt + 1), *ds = lam + (mt + 1), *dl = ds + (mt + 1), *rp = dl + (mt + 1), *rc = rp + (mt + 1),
          *w = rc + (mt + 1), *gdx = w + (mt + 1), *dsa = gdx + (mt + 1), *dla = dsa + (mt + 1);
@@ -592,6 +603,10 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       /* centring target: never below a tenth of the gap the strict test asks for (long steps would otherwise collapse mu to
          ~1e-15 in the last iteration and the weights lam/s with it to ~1e17) */
       double smu = sigma * mu; { const double fl = 0.1 * EXP_GAPTOL * (1.0 + fabs(obj)) / (mt > 0 ? mt : 1); if (smu < fl) smu = fl; }
+      if (pass == 1 && it >= EXP_CORR_IT && alpha_aff < EXP_CORR) {
+        if (++ntrig > EXP_CORR_MAX) { give_up = 1; break; }     /* a solve that needs this more than eight times is not going to end (converging ones: at most five in 16 000) */
+        for (int r = 0; r < mt; r++) { dsa[r] = -rp[r]; dla[r] = -lam[r] + w[r] * rp[r]; }
+      }
       for (int r = 0; r < mt; r++) rc[r] = (pass == 0) ? s[r] * lam[r] : s[r] * lam[r] - smu + dsa[r] * dla[r];
       for (int a = 0; a < ny; a++) rhs[a] = -rd[a];
       for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double v = rc[r] / s[r] - w[r] * rp[r]; for (int c = 0; c < ny; c++) rhs[c] += g[c] * v; }
@@ -607,12 +622,14 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
         if (dl[r] < 0) { double a = -lam[r] / dl[r]; if (a < alpha) alpha = a; }
       }
       if (pass == 0) {
+        alpha_aff = alpha;
         double mua = 0; for (int r = 0; r < mt; r++) mua += (s[r] + alpha * ds[r]) * (lam[r] + alpha * dl[r]);
         mua /= (mt > 0 ? mt : 1);
         double rr = mua / mu; sigma = rr * rr * rr;
         for (int r = 0; r < mt; r++) { dsa[r] = ds[r]; dla[r] = dl[r]; }
       }
     }
+    if (give_up) break;
     { double tau = 1.0 - mu;      /* fraction of the step to the boundary: 1 - mu clamped to [0.999, EXP_TAU = 0.99999] */
       if (tau < 0.999) tau = 0.999;
       if (tau > EXP_TAU) tau = EXP_TAU;

@@ -138,7 +138,7 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
         sq = max(-c, 1e-3); lq = 1.0 / sq
     mt = m + (1 if has_qc else 0)
     qscale = max(1.0, np.abs(g).max())
-    loose = None; stall = 0; first_loose = None; best_merit = 0.0
+    loose = None; stall = 0; first_loose = None; best_merit = 0.0; ntrig = 0; give_up = False
     for it in range(maxit):
         cp = B @ z.T + off
         a = rowvals(cp)
@@ -192,6 +192,14 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
                 rc = s * lam; rcq = sq * lq
             else:
                 smu = max(sigma * mu, 0.1 * 1e-10 * (1 + abs(obj)) / mt)   # never aim below a tenth of the strict gap
+                if it >= 10 and aaff < 0.1:      # short affine step: the predictor is discarded (see qp_solve in the oracle)
+                    ntrig += 1
+                    if ntrig > 8:
+                        give_up = True
+                        break
+                    dsa, dla = -rp, -lam + W * rp
+                    if has_qc:
+                        dsqa, dlqa = -rpq, -lq + wq * rpq
                 rc = s * lam - smu + dsa * dla; rcq = sq * lq - smu + dsqa * dlqa
             v = rc / s - W * rp
             T1 = np.zeros((R, 3)); np.add.at(T1, rho, al * v[:, None])
@@ -219,9 +227,12 @@ def solve(tb, coeff_init, mins, maxs, v_max, a_max, line_seg, line_nd, maxit=100
             if pas == 0:
                 mua = ((s + alpha * ds) @ (lam + alpha * dl) + ((sq + alpha * dsq) * (lq + alpha * dlq) if has_qc else 0.0)) / mt
                 sigma = (mua / mu) ** 3
+                aaff = alpha
                 dsa, dla = ds, dl
                 if has_qc:
                     dsqa, dlqa = dsq, dlq
+        if give_up:
+            break
         alpha = min(1.0, min(max(1.0 - mu, 0.999), 0.99999) * alpha)
         if alpha < 1e-8:
             stall += 1
