@@ -166,3 +166,20 @@ def test_beam_guesses_are_competitive_with_the_astar_restatement(oracle):
         if int(gb["K"]) and int(ga["K"]):
             tot_b += progress(gb, starts[a]); tot_a += progress(ga, starts[a])
     assert tot_b > 0 and tot_b >= 0.8 * tot_a, (tot_b, tot_a)
+
+
+def test_short_affine_steps_discard_the_predictor(oracle):
+    """The interior point's safeguard (qp_solve in the oracle): two front-end-guess replans found by
+    scanning 128 bench scenes.  (58, 5) is feasible but used to cycle — gap down 13x on one long step, back up over three
+    short ones — to the iteration cap and fall back to the relaxed solve: it converges now.  (30, 53) is infeasible and used
+    to blow up to 1e18 and idle to the cap: it stalls within a few iterations now, same verdict."""
+    fe = None
+    for seed, a, status, obj in ((58, 5, 0, 973.532267), (30, 53, 1, None)):
+        sc = scene.make_scene(64, 20, seed=seed); p = sc["par"]
+        fe = scene.frontend_cfg(p, beam_width=32)
+        (g, r), _ = run_agent(oracle, sc, a, fe)
+        res = oracle.replan(p, a + 1, sc["committed"], g, sc["statics"])
+        assert res["status"] == status, (seed, a, res["status"])
+        assert res["iters_first"] <= 30, (seed, a, res["iters_first"])        # (both ran to the cap of 100 before)
+        if obj is not None:
+            assert abs(res["objective"] - obj) <= 1e-5 * obj

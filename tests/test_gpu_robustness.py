@@ -250,3 +250,33 @@ def test_both_hull_kernels_give_the_oracles_hulls(be, oracle):
             h, _hu = oracle.hull_of_interval(pw, t0 + i * p.T_span, t0 + (i + 1) * p.T_span, p.T_span, d)
             assert outs[1][1][j, i] == len(h)
             np.testing.assert_array_equal(outs[1][0][j, i, :len(h)], h)
+
+
+def test_short_affine_steps_discard_the_predictor(be, oracle):
+    """The interior point's safeguard on the device (qp_common.h kCorrMinStep; CPU side: tests/test_frontend_cpu.py): scene 58's
+    agent 5, feasible, used to cycle to the 60-iteration cap and take the relaxed solve; scene 30's agent 53, infeasible, used
+    to idle to the cap.  Front-end guesses made on the device, every replan of both scenes against the oracle: same
+    statuses, same iteration counts to within one, and nobody near the cap."""
+    for seed, a, status in ((58, 5, 0), (30, 53, 1)):
+        sc = scene.make_scene(64, 20, seed=seed); p = sc["par"]; N = p.num_agents
+        fe = scene.frontend_cfg(p, beam_width=32)
+        starts = scene.frontend_starts(sc)
+        bb = be.BatchBackend(p, sc["statics"])
+        d_com = bb.to_device(sc["committed"]); d_start = bb.to_device(starts)
+        d_guess = bb.torch.zeros(N * abi.GUESS_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
+        bb.frontend(fe, d_com, d_start, d_guess)
+        bb.replan(None, d_guess)
+        sol = bb.solutions(); st = sol["stats"]
+        gue = d_guess.cpu().numpy().view(abi.GUESS_DTYPE)
+        assert int(st["status"][a]) == status and int(st["iters_first"][a]) <= 30
+        assert int(st["iters_first"].max()) <= 40
+        for b in (a, (a + 7) % N, (a + 31) % N):
+            if int(gue[b]["K"]) == 0:
+                continue
+            res = oracle.replan(p, b + 1, sc["committed"], gue[b], sc["statics"])
+            assert int(st["status"][b]) == res["status"], (seed, b)
+            assert abs(int(st["iters_first"][b]) - res["iters_first"]) <= 1, (seed, b, int(st["iters_first"][b]), res["iters_first"])
+            K = int(gue[b]["K"])
+            # (front-end guesses: the bound of the parity sweep, DESIGN.md section 2 — these are its hard cases; observed 1.1e-5)
+            np.testing.assert_allclose(np.array(sol["coeff"][b])[:, :K], np.array(res["coeff"])[:, :K], atol=1e-4, rtol=0)
+        bb.close()
