@@ -1114,6 +1114,34 @@ __device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const FeLa
   return true;
 }
 
+// The same child again for a node that is known to have passed every test of fe_child (the beam's winners are re-derived when
+// they are installed, the children on the GJK work list when their turn comes: there is no room to keep 800 children's states):
+// end state, coefficients, g, distance and f by the same arithmetic, without the kinodynamic tests (whose divisions and branches
+// are most of fe_child); WITH_Q: the position control points and the voxel as well.
+template <bool WITH_Q>
+__device__ __forceinline__ void fe_child_again(const SceneParams& sp, const nep_fe_cfg& fc, const FeLattice& L, const double* __restrict__ pe, double pg, int jx, int jy,
+                                               double gx, double gy, FeChild& o) {
+  const double tau = sp.T_span;
+  const int jk[2] = {jx, jy};
+#pragma unroll
+  for (int ax = 0; ax < 2; ax++) {
+    const double p = pe[ax], v = pe[2 + ax], a = pe[4 + ax];
+    o.e[ax] = ((p + v * tau) + ((a * tau) * tau) / 2) + L.dp[jk[ax]];
+    o.e[2 + ax] = (v + a * tau) + L.dv[jk[ax]];
+    o.e[4 + ax] = a + L.da[jk[ax]];
+  }
+  o.cx[0] = L.j6[jx]; o.cx[1] = pe[4] / 2; o.cx[2] = pe[2]; o.cx[3] = pe[0];
+  o.cy[0] = L.j6[jy]; o.cy[1] = pe[5] / 2; o.cy[2] = pe[3]; o.cy[3] = pe[1];
+  const double arc = sqrt((o.e[0] - pe[0]) * (o.e[0] - pe[0]) + (o.e[1] - pe[1]) * (o.e[1] - pe[1]));
+  o.g = pg + arc;
+  o.dist = sqrt((o.e[0] - gx) * (o.e[0] - gx) + (o.e[1] - gy) * (o.e[1] - gy));
+  o.f = o.g + fc.bias * o.dist;
+  if constexpr (WITH_Q) {
+    fe_pos_cps(o.cx, tau, o.Qx); fe_pos_cps(o.cy, tau, o.Qy);
+    o.vx = (int)round(o.e[0] / fc.voxel_size); o.vy = (int)round(o.e[1] / fc.voxel_size);
+  }
+}
+
 // LDS arrays are sized for the configured beam width (not the maximum), so that narrower beams leave room for
 // more workgroups per CU: cap = beam_width * num_samples^2 candidates per depth, hash tables a power of two above
 // 1.25x (per-depth voxel table) / 2x (visited voxels, beam_width * num_pol keys) their load.
@@ -1373,7 +1401,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
       const int pr = id / NC, cc = id % NC;
       unsigned long long cand_mask = (unsigned long long)s_vox[id];
       FeChild ch;
-      fe_child(sp, fc, lat, b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6, b_g[prv * NEP_FE_MAX_BEAM + pr], depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch);
+      fe_child_again<true>(sp, fc, lat, b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6, b_g[prv * NEP_FE_MAX_BEAM + pr], cc / ns, cc % ns, gx, gy, ch);
       Pts4 B;
 #pragma unroll
       for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
@@ -1419,7 +1447,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
         const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
         const double pg = b_g[prv * NEP_FE_MAX_BEAM + pr];
         FeChild ch;
-        fe_child(sp, fc, lat, pe, pg, depth == 1, cc / ns, cc % ns, gx, gy, bx, by, ch);
+        fe_child_again<false>(sp, fc, lat, pe, pg, cc / ns, cc % ns, gx, gy, ch);
         if constexpr (ENT) {   // the same propagation again, this time into the node's own record
           nep_fe_ent_state* nd = ent_node(depth, rank);
           ent_copy(nd, ent_node(depth - 1, depth == 1 ? 0 : pr));
