@@ -1071,7 +1071,7 @@ __device__ __forceinline__ void fe_lattice_fill(const SceneParams& sp, const nep
 // the squares (no square root on the rejection paths); both sides of the parity check state them that way.
 __device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const FeLattice& L, const double* __restrict__ pe, double pg, bool first, int jx, int jy,
                          double gx, double gy, double bx, double by, FeChild& o) {
-  const double tau = sp.T_span, j_min = -fc.j_max, j_max = fc.j_max, v_max = sp.v_max, v_min = -sp.v_max, a_max = sp.a_max, a_min = -sp.a_max;
+  const double tau = sp.T_span, j_max = fc.j_max, v_max = sp.v_max, v_min = -sp.v_max, a_max = sp.a_max, a_min = -sp.a_max;
   const int jk[2] = {jx, jy};
 #pragma unroll
   for (int ax = 0; ax < 2; ax++) {
@@ -1103,8 +1103,11 @@ __device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const FeLa
 #pragma unroll
   for (int ax = 0; ax < 2; ax++) {
     const double a = o.e[4 + ax], v = o.e[2 + ax];
-    if (a > 0 && v - ((0.5 * a) * a) / j_min > v_max) return false;
-    else if (a < 0 && v - ((0.5 * a) * a) / j_max < v_min) return false;
+    // (the reference divides by j_min = -j_max on one side and by j_max on the other: the quotients are each other's exact
+    // negatives and v - (-q) is the same operation as v + q — one IEEE division per axis instead of two, the same bits)
+    const double q = ((0.5 * a) * a) / j_max;
+    if (a > 0 && v + q > v_max) return false;
+    else if (a < 0 && v - q < v_min) return false;
   }
   const double arc = sqrt((o.e[0] - pe[0]) * (o.e[0] - pe[0]) + (o.e[1] - pe[1]) * (o.e[1] - pe[1]));
   o.g = pg + arc;
