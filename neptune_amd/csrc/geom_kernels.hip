@@ -910,6 +910,8 @@ __global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec*
                                                              const double* __restrict__ hull_xy, const int* __restrict__ hull_nv,
                                                              unsigned char* __restrict__ conflict) {
   __shared__ double sBx[NEP_MAX_POL * 4], sBy[NEP_MAX_POL * 4];
+  __shared__ double2 sV[64][kHullV + 1];
+  __shared__ int sNv[64];
   const int lane = threadIdx.x;
   const int a = blockIdx.x % N, scene = blockIdx.x / N;
   const nep_traj_rec* ra = fresh + (long)scene * N + a;
@@ -927,19 +929,33 @@ __global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec*
     sBx[lane] = vx; sBy[lane] = vy;
   }
   __syncthreads();
-  for (int j = lane; j < N; j += 64) {
+  // One GJK test per lane: the hulls of `ac` agents (all their intervals: contiguous in hull_xy) are brought into LDS with
+  // coalesced loads, lane (jj, i) tests agent j0 + jj's interval i against my interval i, and a ballot gives every agent its
+  // verdict.  (One agent per lane looping over the intervals read each hull with a 2 KB stride between lanes — 64 cache lines
+  // per load instruction: the kernel was bound by that gather.)  Rows are padded to 17 pairs against bank conflicts.
+  const int ac = 64 / num_pol;                                   // agents per round
+  const int jj = lane / num_pol, ii = lane - jj * num_pol;
+  for (int j0 = 0; j0 < N; j0 += ac) {
+    const int na = N - j0 < ac ? N - j0 : ac, cnt = na * num_pol;            // hulls this round
+    const long h0 = ((long)scene * N + j0) * num_pol;
+    const double2* src = (const double2*)hull_xy + h0 * kHullV;
+    for (int e = lane; e < cnt * kHullV; e += 64) sV[e / kHullV][e % kHullV] = src[e];
+    if (lane < cnt) sNv[lane] = hull_nv[h0 + lane];
+    __syncthreads();
     bool hit = false;
-    const nep_traj_rec* rj = other + (long)scene * N + j;     // whose hulls these are (the new or the previous records)
-    if (j != a && Ka > 0 && rj->valid && rj->is_agent) {
-      for (int i = 0; i < Ka && !hit; i++) {
+    const int j = j0 + jj;
+    if (lane < cnt && j != a && ii < Ka) {
+      const nep_traj_rec* rj = other + (long)scene * N + j;     // whose hulls these are (the new or the previous records)
+      if (rj->valid && rj->is_agent) {
         Pts4 B;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { B.x[k] = sBx[i * 4 + k]; B.y[k] = sBy[i * 4 + k]; }
-        const long h = ((long)scene * N + j) * num_pol + i;
-        hit = gjk_collision(hull_nv[h], hull_xy + h * kHullV * 2, B);
+        for (int k = 0; k < 4; k++) { B.x[k] = sBx[ii * 4 + k]; B.y[k] = sBy[ii * 4 + k]; }
+        hit = gjk_collision(sNv[lane], (const double*)&sV[lane][0], B);
       }
     }
-    conflict[((long)scene * N + a) * N + j] = hit ? 1 : 0;
+    const unsigned long long bal = __ballot(hit);
+    if (lane < cnt && ii == 0) conflict[((long)scene * N + a) * N + j] = ((bal >> lane) & ((1ull << num_pol) - 1ull)) ? 1 : 0;
+    __syncthreads();
   }
 }
 
