@@ -1087,6 +1087,10 @@ __device__ __forceinline__ void fe_lattice_fill(const SceneParams& sp, const nep
 // the squares (no square root on the rejection paths); both sides of the parity check state them that way.
 __device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const FeLattice& L, const double* __restrict__ pe, double pg, bool first, int jx, int jy,
                          double gx, double gy, double bx, double by, FeChild& o) {
+  // Branch-free: the tests are gathered in one flag instead of returning at the first failure.  The lanes of a wave run in
+  // lock-step — an early return saves nothing while one lane's child is alive — and a body without exits is one block the
+  // compiler can interleave (the divisions and square roots are long dependent chains).  What a failed child leaves in `o` is
+  // not used.
   const double tau = sp.T_span, j_max = fc.j_max, v_max = sp.v_max, v_min = -sp.v_max, a_max = sp.a_max, a_min = -sp.a_max;
   const int jk[2] = {jx, jy};
 #pragma unroll
@@ -1099,22 +1103,22 @@ __device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const FeLa
   double n2 = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++) n2 += (o.e[i] - pe[i]) * (o.e[i] - pe[i]);
-  if (n2 < 0.00001 * 0.00001) return false;
-  if (o.e[5] > a_max || o.e[5] < a_min || o.e[4] > a_max || o.e[4] < a_min) return false;
+  bool ok = !(n2 < 0.00001 * 0.00001);
+  ok &= !(o.e[5] > a_max || o.e[5] < a_min || o.e[4] > a_max || o.e[4] < a_min);
   o.cx[0] = L.j6[jx]; o.cx[1] = pe[4] / 2; o.cx[2] = pe[2]; o.cx[3] = pe[0];
   o.cy[0] = L.j6[jy]; o.cy[1] = pe[5] / 2; o.cy[2] = pe[3]; o.cy[3] = pe[1];
   fe_pos_cps(o.cx, tau, o.Qx); fe_pos_cps(o.cy, tau, o.Qy);
   const double cable2 = fc.cable_length * fc.cable_length;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    if (o.Qx[i] < sp.mins[0] || o.Qx[i] > sp.maxs[0] || o.Qy[i] < sp.mins[1] || o.Qy[i] > sp.maxs[1]) return false;
-    if ((o.Qx[i] - bx) * (o.Qx[i] - bx) + (o.Qy[i] - by) * (o.Qy[i] - by) > cable2) return false;
+    ok &= !(o.Qx[i] < sp.mins[0] || o.Qx[i] > sp.maxs[0] || o.Qy[i] < sp.mins[1] || o.Qy[i] > sp.maxs[1]);
+    ok &= !((o.Qx[i] - bx) * (o.Qx[i] - bx) + (o.Qy[i] - by) * (o.Qy[i] - by) > cable2);
   }
-  if (!first) {
+  if (!first) {      // (wave-uniform)
     double Vx[3], Vy[3];
     fe_vel_cps(o.cx, tau, Vx); fe_vel_cps(o.cy, tau, Vy);
 #pragma unroll
-    for (int i = 0; i < 3; i++) if (Vx[i] < v_min || Vx[i] > v_max || Vy[i] < v_min || Vy[i] > v_max) return false;
+    for (int i = 0; i < 3; i++) ok &= !(Vx[i] < v_min || Vx[i] > v_max || Vy[i] < v_min || Vy[i] > v_max);
   }
 #pragma unroll
   for (int ax = 0; ax < 2; ax++) {
@@ -1122,15 +1126,14 @@ __device__ bool fe_child(const SceneParams& sp, const nep_fe_cfg& fc, const FeLa
     // (the reference divides by j_min = -j_max on one side and by j_max on the other: the quotients are each other's exact
     // negatives and v - (-q) is the same operation as v + q — one IEEE division per axis instead of two, the same bits)
     const double q = ((0.5 * a) * a) / j_max;
-    if (a > 0 && v + q > v_max) return false;
-    else if (a < 0 && v - q < v_min) return false;
+    ok &= !((a > 0 && v + q > v_max) || (a < 0 && v - q < v_min));
   }
   const double arc = sqrt((o.e[0] - pe[0]) * (o.e[0] - pe[0]) + (o.e[1] - pe[1]) * (o.e[1] - pe[1]));
   o.g = pg + arc;
   o.dist = sqrt((o.e[0] - gx) * (o.e[0] - gx) + (o.e[1] - gy) * (o.e[1] - gy));
   o.f = o.g + fc.bias * o.dist;
   o.vx = (int)round(o.e[0] / fc.voxel_size); o.vy = (int)round(o.e[1] / fc.voxel_size);
-  return true;
+  return ok;
 }
 
 // The same child again for a node that is known to have passed every test of fe_child (the beam's winners are re-derived when
