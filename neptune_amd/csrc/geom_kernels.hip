@@ -1299,7 +1299,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
           double Q[4];
           fe_pos_cps(P, tau, Q);
 #pragma unroll
-          for (int k = 0; k < 4; k++) { if (Q[k] < l) l = Q[k]; if (Q[k] > h) h = Q[k]; }
+          for (int k = 0; k < 4; k++) { l = fmin(l, Q[k]); h = fmax(h, Q[k]); }      // (v_min / v_max_f64: no NaNs here, and a box's zero may have either sign)
         }
         lo[ax] = l; hi[ax] = h;
       }
@@ -1323,7 +1323,10 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
       for (int i = 0; i < kHullV; i++) vv[i] = ((const double2*)V)[i];
       double x0 = vv[0].x, x1 = vv[0].x, y0 = vv[0].y, y1 = vv[0].y;
 #pragma unroll
-      for (int i = 1; i < kHullV; i++) if (i < nv) { if (vv[i].x < x0) x0 = vv[i].x; if (vv[i].x > x1) x1 = vv[i].x; if (vv[i].y < y0) y0 = vv[i].y; if (vv[i].y > y1) y1 = vv[i].y; }
+      for (int i = 1; i < kHullV; i++) {      // (slots beyond nv count as the first vertex again)
+        const double vx = i < nv ? vv[i].x : vv[0].x, vy = i < nv ? vv[i].y : vv[0].y;
+        x0 = fmin(x0, vx); x1 = fmax(x1, vx); y0 = fmin(y0, vy); y1 = fmax(y1, vy);
+      }
       bool near = false;
       for (int q = 0; q < nb_prev; q++) near |= !(x1 < p_box[4 * q] || p_box[4 * q + 1] < x0 || y1 < p_box[4 * q + 2] || p_box[4 * q + 3] < y0);
       if (near) {
@@ -1393,7 +1396,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
       my_feasible++;
       double qx0 = ch.Qx[0], qx1 = ch.Qx[0], qy0 = ch.Qy[0], qy1 = ch.Qy[0];
 #pragma unroll
-      for (int i = 1; i < 4; i++) { if (ch.Qx[i] < qx0) qx0 = ch.Qx[i]; if (ch.Qx[i] > qx1) qx1 = ch.Qx[i]; if (ch.Qy[i] < qy0) qy0 = ch.Qy[i]; if (ch.Qy[i] > qy1) qy1 = ch.Qy[i]; }
+      for (int i = 1; i < 4; i++) { qx0 = fmin(qx0, ch.Qx[i]); qx1 = fmax(qx1, ch.Qx[i]); qy0 = fmin(qy0, ch.Qy[i]); qy1 = fmax(qy1, ch.Qy[i]); }
       unsigned long long cand_mask = 0;
       bool hit = false;
       for (int o = 0; o < n_obs; o++) {
