@@ -1464,9 +1464,11 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
     for (int a = tid; a < n_b; a += 256) {
       const int i = r_id[a];
       const double fi = r_f[a];
-      int rank = 0;
+      // rank = the winners with a smaller f, ties by the lower id: the ids are only looked at when there is a tie (rare)
+      int rank = 0, same = 0;
 #pragma unroll 4
-      for (int b = 0; b < n_b; b++) { const int k = r_id[b]; const double fk = r_f[b]; rank += (fk < fi || (fk == fi && k < i)) ? 1 : 0; }
+      for (int b = 0; b < n_b; b++) { const double fk = r_f[b]; rank += fk < fi ? 1 : 0; same += fk == fi ? 1 : 0; }
+      if (same > 1) { for (int b = 0; b < n_b; b++) rank += (r_f[b] == fi && (int)r_id[b] < i) ? 1 : 0; }
       if (rank < W) {   // recompute the child (same arithmetic) and install it
         const int pr = i / NC, cc = i % NC;
         const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
