@@ -81,6 +81,7 @@ struct Engine {
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
+  DevBuf<double> d_fe_box;          // boxes of the front end's obstacles, made before every search launch
   DevBuf<int> d_order, d_order_key; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
@@ -146,6 +147,7 @@ struct Engine {
     if (use_reg) { lds_lines = NEP_MAX_POL * 8 * qp_reg_slots(); lds_rows = 4 * lds_lines; lds_bytes = qp_reg_lds_bytes(); }
     rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
     if (int e = d_hull_xy.ensure((size_t)n_scenes * sp.n_hull * np * kHullV * 2)) return e;
+    if (int e = d_fe_box.ensure((size_t)n_scenes * (N + (sp.n_static > 0 ? sp.n_static : 0)) * np * 4)) return e;
     if (int e = d_hull_nv.ensure((size_t)n_scenes * sp.n_hull * np)) return e;
     if (int e = d_hull0_xy.ensure((size_t)n_scenes * N * np * 2)) return e;
     if (int e = d_hull0_nv.ensure((size_t)n_scenes * N * np)) return e;
@@ -171,6 +173,7 @@ struct Engine {
     ps.row_scratch = d_row_scratch.p; ps.rows_cap = rows_cap; ps.lds_rows = lds_rows; ps.lds_lines = lds_lines;
     ps.dbg = profile_phases ? d_dbg.p : nullptr;
     ps.flags = d_flags.p;
+    ps.fe_box = d_fe_box.p;
   }
   // packs n polygons into the fixed-stride device layout (vertices, vertex counts, edge lengths)
   static int pack_statics(int n, const int32_t* off, const double* xy, std::vector<double>& sx, std::vector<int>& nv, std::vector<double>& el) {
@@ -206,6 +209,8 @@ struct Engine {
     HIPCHK(hipMemcpy(d_static_xy.p, sx.data(), sx.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_static_nv.p, nv.data(), nv.size() * sizeof(int), hipMemcpyHostToDevice));
     sp.n_static = n; sp.static_stride = 0;
+    if (n_scenes > 0 && sp.num_agents > 0 && sp.num_pol > 0)      // (the front end's obstacle boxes: one per agent or static polygon and interval)
+      if (int e = d_fe_box.ensure((size_t)n_scenes * (sp.num_agents + n) * sp.num_pol * 4)) return e;
     return 0;
   }
   // One static-obstacle set per scene (same polygon count S in every scene): the first call replicates the handle's
@@ -265,7 +270,7 @@ struct Engine {
   }
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
-    d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release();
+    d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_box.release();
     d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release();
     d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);

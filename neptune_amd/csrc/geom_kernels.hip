@@ -1194,6 +1194,34 @@ __device__ __forceinline__ unsigned fe_hash(long long vox) { return (unsigned)((
 #ifndef NEP_FE_WAVES
 #define NEP_FE_WAVES 3
 #endif
+// Boxes of the front end's obstacles — the other agents' interval hulls and the static polygons — once per launch: the 64
+// searches of a scene, eight depths each, used to re-derive them from the sixteen vertex slots every time (a fifth of a search).
+// [scene][num_agents + n_static][num_pol] x (x0, x1, y0, y1); an empty polygon gets a box nothing meets.
+__global__ __launch_bounds__(256) void fe_box_kernel(SceneParams sp, ProblemSet ps, int n_scenes) {
+  const int N = sp.num_agents, S = sp.n_static, D = sp.num_pol;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)n_scenes * (N + S) * D) return;
+  const int idx = (int)(t % D); const long r = t / D;
+  const int j = (int)(r % (N + S)), scene = (int)(r / (N + S));
+  int nv; const double* V;
+  if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
+  else { const long js = (long)scene * sp.static_stride + (j - N); nv = ps.static_nv[js]; V = ps.static_xy + js * kHullV * 2; }
+  double x0 = __builtin_huge_val(), x1 = -__builtin_huge_val(), y0 = __builtin_huge_val(), y1 = -__builtin_huge_val();
+  if (nv > 0) {
+    double2 vv[kHullV];
+#pragma unroll
+    for (int i = 0; i < kHullV; i++) vv[i] = ((const double2*)V)[i];
+    x0 = x1 = vv[0].x; y0 = y1 = vv[0].y;
+#pragma unroll
+    for (int i = 1; i < kHullV; i++) {
+      const double vx = i < nv ? vv[i].x : vv[0].x, vy = i < nv ? vv[i].y : vv[0].y;
+      x0 = fmin(x0, vx); x1 = fmax(x1, vx); y0 = fmin(y0, vy); y1 = fmax(y1, vy);
+    }
+  }
+  double* o = ps.fe_box + t * 4;
+  o[0] = x0; o[1] = x1; o[2] = y0; o[3] = y1;
+}
+
 template <bool ENT>
 __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
                                                        nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out, FeEntArgs ea) {
@@ -1311,25 +1339,18 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
     FE_TICK(1);
     // ---- shortlist: obstacles of this interval whose box meets some parent's box ----
     for (int j = tid; j < N + S; j += 256) {
-      int nv = 0; const double* V = nullptr;
-      if (j < N) {
-        if (j != own) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
-      } else { const long js = (long)scene * sp.static_stride + (j - N); nv = ps.static_nv[js]; V = ps.static_xy + js * kHullV * 2; }
-      if (nv <= 0) continue;
-      // all sixteen vertex slots in one go (the arrays are [16][2]): a loop over nv would pay one memory
-      // round trip per vertex
-      double2 vv[kHullV];
-#pragma unroll
-      for (int i = 0; i < kHullV; i++) vv[i] = ((const double2*)V)[i];
-      double x0 = vv[0].x, x1 = vv[0].x, y0 = vv[0].y, y1 = vv[0].y;
-#pragma unroll
-      for (int i = 1; i < kHullV; i++) {      // (slots beyond nv count as the first vertex again)
-        const double vx = i < nv ? vv[i].x : vv[0].x, vy = i < nv ? vv[i].y : vv[0].y;
-        x0 = fmin(x0, vx); x1 = fmax(x1, vx); y0 = fmin(y0, vy); y1 = fmax(y1, vy);
-      }
+      if (j == own) continue;
+      const double* bxj = ps.fe_box + (((long)scene * (N + S) + j) * sp.num_pol + idx) * 4;      // (fe_box_kernel)
+      const double x0 = bxj[0], x1 = bxj[1], y0 = bxj[2], y1 = bxj[3];
       bool near = false;
       for (int q = 0; q < nb_prev; q++) near |= !(x1 < p_box[4 * q] || p_box[4 * q + 1] < x0 || y1 < p_box[4 * q + 2] || p_box[4 * q + 3] < y0);
-      if (near) {
+      if (near) {      // (rare: now its vertices are worth fetching)
+        int nv; const double* V;
+        if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
+        else { const long js = (long)scene * sp.static_stride + (j - N); nv = ps.static_nv[js]; V = ps.static_xy + js * kHullV * 2; }
+        double2 vv[kHullV];
+#pragma unroll
+        for (int i = 0; i < kHullV; i++) vv[i] = ((const double2*)V)[i];
         const int o = atomicAdd(&s_i[0], 1); o_aabb[4 * o] = x0; o_aabb[4 * o + 1] = x1; o_aabb[4 * o + 2] = y0; o_aabb[4 * o + 3] = y1; o_nv[o] = nv; o_id[o] = j;
         if (o < kFeObsLds) {
 #pragma unroll
@@ -1596,6 +1617,11 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
   const bool ent = ea != nullptr;
   (void)attr[ent].ensure(ent ? (const void*)frontend_kernel<true> : (const void*)frontend_kernel<false>, lds);
   FeEntArgs none{};
+  {
+    const int n_scenes = n_slots / (sp.n_local > 0 ? sp.n_local : 1);
+    const long nb = (long)n_scenes * (sp.num_agents + sp.n_static) * sp.num_pol;
+    hipLaunchKernelGGL(fe_box_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, sp, ps, n_scenes);
+  }
   if (ent) hipLaunchKernelGGL(frontend_kernel<true>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
   else hipLaunchKernelGGL(frontend_kernel<false>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
 }

@@ -76,6 +76,7 @@ struct ProblemSet {
   const nep_traj_rec* prev_commit; // [scenes][N] records before this round, or null: what a failed replan's commit slot carries over
   long long* dbg;                // [slots][16] phase cycle counters (development aid) or null
   int* flags;                    // [1] sticky NEP_FLAG_* bits raised by the kernels (capacity overflows), or null
+  double* fe_box;                // [scenes][num_agents + n_static][num_pol][4] (x0, x1, y0, y1) of the front end's obstacles (fe_box_kernel)
 };
 constexpr int NEP_FLAG_HULL_OVERFLOW = 1;   // an interval overlapped more committed segments than NEP_HULL_MAX_CP / 4, or its hull has more than NEP_HULL_MAX_V vertices
 
