@@ -20,6 +20,8 @@
 //            scalars (and the ball row: then one more barrier before the tiles)                                       -> b3
 //   factor   wave 0: Cholesky of the (x, y) block in registers + the predictor; wave 1: convergence test, then the z block -> b4
 //   P2       all threads: affine ratio test, corrector right-hand side as  va - sigma mu vb                           -> b5
+//            (late in a solve, an affine step shorter than kCorrMinStep sends the iteration back to A1 with a step of length
+//            zero and the predictor discarded: qp_common.h)
 //   rhs      144 threads: B' (va - sigma mu vb)                                                                       -> b6
 //   solve    waves 0, 1: the corrector                                                                                -> b7
 //   P5       all threads: step length of the combined direction                                                       -> b8
