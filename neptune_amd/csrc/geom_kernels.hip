@@ -906,16 +906,20 @@ __device__ bool gjk_collision(int n1, const double* __restrict__ V1, const Pts4&
 // conflict[scene][a][j] = agent a's new trajectory hits the interval hulls of agent j's new
 // trajectory (trajsAndPwpAreInCollision2d on the round's interval grid).  One wave per (scene, a);
 // lanes stride over j.  Hulls come from hull_kernel run on the new records.
-__global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec* __restrict__ fresh, const nep_traj_rec* __restrict__ other, int N, int num_pol, double T_span,
+__global__ __launch_bounds__(256) void safety_conflict_kernel(const nep_traj_rec* __restrict__ fresh, const nep_traj_rec* __restrict__ other, int N, int num_pol, double T_span,
                                                              const double* __restrict__ hull_xy, const int* __restrict__ hull_nv,
                                                              unsigned char* __restrict__ conflict) {
-  __shared__ double sBx[NEP_MAX_POL * 4], sBy[NEP_MAX_POL * 4];
+  // Four agents of a scene per workgroup, one per wave: the other agents' hulls they are tested against are the same, so the
+  // staged copy in LDS is shared (17 KB per workgroup instead of per wave: the register file, not LDS, bounds the occupancy).
+  __shared__ double sBx[4][NEP_MAX_POL * 4], sBy[4][NEP_MAX_POL * 4];
   __shared__ double2 sV[64][kHullV + 1];
   __shared__ int sNv[64];
-  const int lane = threadIdx.x;
-  const int a = blockIdx.x % N, scene = blockIdx.x / N;
-  const nep_traj_rec* ra = fresh + (long)scene * N + a;
-  const int Ka = ra->valid ? (ra->pwp.n_seg < num_pol ? ra->pwp.n_seg : num_pol) : 0;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int groups = (N + 3) >> 2;
+  const int scene = blockIdx.x / groups, a = (blockIdx.x - scene * groups) * 4 + w;
+  const bool mine = a < N;                                      // (a workgroup's last waves may have no agent: they still stage)
+  const nep_traj_rec* ra = fresh + (long)scene * N + (mine ? a : 0);
+  const int Ka = (mine && ra->valid) ? (ra->pwp.n_seg < num_pol ? ra->pwp.n_seg : num_pol) : 0;
   if (lane < 4 * NEP_MAX_POL) {  // my control points, P * A_rest_pos_basis_t_inverse_ (neptune.cpp:789)
     const int seg = lane >> 2, k = lane & 3;
     double vx = 0, vy = 0;
@@ -926,7 +930,7 @@ __global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec*
       vx = ((Px[0] * m0 + Px[1] * m1) + Px[2] * m2) + Px[3] * m3;
       vy = ((Py[0] * m0 + Py[1] * m1) + Py[2] * m2) + Py[3] * m3;
     }
-    sBx[lane] = vx; sBy[lane] = vy;
+    sBx[w][lane] = vx; sBy[w][lane] = vy;
   }
   __syncthreads();
   // One GJK test per lane: the hulls of `ac` agents (all their intervals: contiguous in hull_xy) are brought into LDS with
@@ -939,8 +943,8 @@ __global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec*
     const int na = N - j0 < ac ? N - j0 : ac, cnt = na * num_pol;            // hulls this round
     const long h0 = ((long)scene * N + j0) * num_pol;
     const double2* src = (const double2*)hull_xy + h0 * kHullV;
-    for (int e = lane; e < cnt * kHullV; e += 64) sV[e / kHullV][e % kHullV] = src[e];
-    if (lane < cnt) sNv[lane] = hull_nv[h0 + lane];
+    for (int e = tid; e < cnt * kHullV; e += 256) sV[e / kHullV][e % kHullV] = src[e];
+    if (tid < cnt) sNv[tid] = hull_nv[h0 + tid];
     __syncthreads();
     bool hit = false;
     const int j = j0 + jj;
@@ -949,12 +953,12 @@ __global__ __launch_bounds__(64) void safety_conflict_kernel(const nep_traj_rec*
       if (rj->valid && rj->is_agent) {
         Pts4 B;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { B.x[k] = sBx[ii * 4 + k]; B.y[k] = sBy[ii * 4 + k]; }
+        for (int k = 0; k < 4; k++) { B.x[k] = sBx[w][ii * 4 + k]; B.y[k] = sBy[w][ii * 4 + k]; }
         hit = gjk_collision(sNv[lane], (const double*)&sV[lane][0], B);
       }
     }
     const unsigned long long bal = __ballot(hit);
-    if (lane < cnt && ii == 0) conflict[((long)scene * N + a) * N + j] = ((bal >> lane) & ((1ull << num_pol) - 1ull)) ? 1 : 0;
+    if (mine && lane < cnt && ii == 0) conflict[((long)scene * N + a) * N + j] = ((bal >> lane) & ((1ull << num_pol) - 1ull)) ? 1 : 0;
     __syncthreads();
   }
 }
@@ -1005,10 +1009,10 @@ void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_sc
   };
   if (conflict_prev) {   // new trajectories against the hulls of the PREVIOUS records on the same grid
     hulls_of(prev);
-    hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, prev, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict_prev);
+    hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * ((N + 3) / 4)), dim3(256), 0, st, fresh, prev, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict_prev);
   }
   hulls_of(fresh);
-  hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * N), dim3(64), 0, st, fresh, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
+  hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * ((N + 3) / 4)), dim3(256), 0, st, fresh, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
   hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, entangles, final_out, accept_out);
 }
 
