@@ -266,7 +266,10 @@ int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static,
  * d_commit slot receives the agent's PREVIOUS record (from d_committed, or from the records nep_batch_frontend
  * built this round's hulls from); when neither is known (nep_batch_replan_hulls) the slot is left exactly as the
  * caller passed it, so hand in the buffer that still holds the previous round's records.  d_solution of such a
- * slot: status NEP_FAILED, coefficients = the guess (all zero and K = 0 for an unusable guess).              */
+ * slot: status NEP_FAILED, coefficients = the guess (all zero and K = 0 for an unusable guess).
+ * Lifetime: with d_committed == NULL the handle reads the record buffer that was passed to the preceding
+ * nep_batch_frontend / nep_batch_frontend_ent call (the pointer is kept, nothing is copied): that buffer must stay
+ * allocated and unchanged until this replan has completed on `stream` — do not gather new records into it in between. */
 int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess,
                      const void* d_ent, nep_solution* d_solution, double* d_states,
                      nep_traj_rec* d_commit, void* stream);

@@ -64,6 +64,14 @@ bool normalize_ccw(double* xy, int n) {
   return true;
 }
 
+// wall_clock64() ticks per second of the current device (the constant-rate counter behind nep_stats.solve_us, the launch
+// order's keys and the TimeLimit emulation): 100 MHz on gfx950, asked of the runtime rather than assumed
+double wall_clock_hz() {
+  int dev = 0, khz = 0;
+  if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) return (double)khz * 1e3;
+  return 1e8;
+}
+
 // Everything both handle kinds share: tables, scratch and the launch sequence of one replan.
 struct Engine {
   SceneParams sp{};
@@ -84,6 +92,8 @@ struct Engine {
   DevBuf<double> d_fe_box;          // boxes of the front end's obstacles, made before every search launch
   DevBuf<int> d_order, d_order_key; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
+  double clock_hz = 1e8;       // wall_clock64() rate of the handle's device (set_clock)
+  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; }
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
   // timing
@@ -234,6 +244,18 @@ struct Engine {
       d_static_xy.release(); d_static_el.release(); d_static_nv.release();
       d_static_xy = nxy; d_static_el = nel; d_static_nv = nnv;
       sp.static_stride = S;
+      // the entangle check's representatives (nep_batch_set_static_reps) are indexed like the polygons: one set per scene from
+      // now on.  A set uploaded while the statics were shared is replicated; every scene can then be given its own.
+      if (have_reps && d_srep.p && d_srep.n >= (size_t)S * 4 && d_slong.n >= (size_t)S * 2) {
+        DevBuf<double> nr, nl;
+        if (int e = nr.ensure((size_t)n_scenes * S * 4)) return e;
+        if (int e = nl.ensure((size_t)n_scenes * S * 2)) return e;
+        for (int s = 0; s < n_scenes; s++) {
+          HIPCHK(hipMemcpy(nr.p + (size_t)s * S * 4, d_srep.p, (size_t)S * 4 * sizeof(double), hipMemcpyDeviceToDevice));
+          HIPCHK(hipMemcpy(nl.p + (size_t)s * S * 2, d_slong.p, (size_t)S * 2 * sizeof(double), hipMemcpyDeviceToDevice));
+        }
+        d_srep.release(); d_slong.release(); d_srep = nr; d_slong = nl;
+      } else have_reps = false;
     }
     HIPCHK(hipMemcpy(d_static_xy.p + (size_t)scene * S * kHullV * 2, sx.data(), (size_t)S * kHullV * 2 * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d_static_el.p + (size_t)scene * S * kHullV, el.data(), (size_t)S * kHullV * sizeof(double), hipMemcpyHostToDevice));
@@ -279,6 +301,7 @@ struct Engine {
 };
 
 bool have_device() { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0; }
+
 
 __global__ void sample_kernel(const nep_solution* __restrict__ sol, int K, const int* __restrict__ seg, const double* __restrict__ dt, int ns, double* __restrict__ out) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -335,6 +358,7 @@ nep_backend_t* nep_backend_create(const nep_backend_cfg* cfg) {
   E.sp.num_agents = cfg->num_agents; E.sp.num_pol = cfg->num_pol; E.sp.n_static = 0; E.sp.n_hull = 0; E.sp.ent_enabled = 0;
   E.sp.n_local = 1; E.sp.first_local = cfg->id - 1; E.sp.skip_own = 0; E.sp.T_span = cfg->T_span; E.sp.weight = cfg->weight_term;
   E.sp.drone_radius = 0; E.n_scenes = 1;
+  E.set_clock();
   HIPCHK_NULL(hipStreamCreate(&h->stream));
   HIPCHK_NULL(hipEventCreate(&h->e0)); HIPCHK_NULL(hipEventCreate(&h->e1));
   if (E.d_pb.ensure(h->pb.size())) { delete h; return nullptr; }
@@ -366,7 +390,7 @@ int nep_backend_set_max_values(nep_backend_t* h, double x_min, double x_max, dou
 int nep_backend_set_max_runtime(nep_backend_t* h, double s) {
   if (!h) return fail(NEP_E_ARG, "null handle");
   h->max_runtime = s;
-  h->eng.sp.time_limit_ticks = s > 0 ? (long long)(s * 1e8) : 0;      // wall_clock64() counts at 100 MHz on gfx950
+  h->eng.sp.time_limit_ticks = s > 0 ? (long long)(s * h->eng.clock_hz) : 0;
   return 0;
 }
 int nep_backend_set_tether_length(nep_backend_t* h, double t) { if (!h) return fail(NEP_E_ARG, "null handle"); h->tether = t; return 0; }
@@ -651,6 +675,7 @@ nep_batch_t* nep_batch_create(const nep_batch_cfg* c) {
   sp.v_max = c->v_max; sp.a_max = c->a_max;
   sp.long_length = std::sqrt((c->x_max - c->x_min) * (c->x_max - c->x_min) + (c->y_max - c->y_min) * (c->y_max - c->y_min));
   E.n_scenes = c->n_scenes; h->slots = c->n_scenes * c->n_local;
+  E.set_clock();
   bool ok = true;
   ok = ok && !E.d_pb.ensure((size_t)2 * c->num_agents);
   if (ok) ok = hipMemcpy(E.d_pb.p, c->pb, (size_t)2 * c->num_agents * sizeof(double), hipMemcpyHostToDevice) == hipSuccess;
@@ -804,6 +829,7 @@ int ent_prepare(nep_batch* h, int ns, int beam_width, const nep_traj_rec* d_recs
   const int N = h->cfg.num_agents, S = h->cfg.n_scenes, np = h->cfg.num_pol;
   if (ns < 1 || ns > 8) return fail(NEP_E_ARG, "ent_samples out of range");
   if (E.sp.n_static > 0 && !E.have_reps) return fail(NEP_E_STATE, "entangle check with static obstacles needs nep_batch_set_static_reps first");
+  if (E.sp.n_static > 0 && E.d_srep.n < (size_t)(E.sp.static_stride ? S : 1) * E.sp.n_static * 4) return fail(NEP_E_STATE, "static representatives do not cover every scene's obstacle set: call nep_batch_set_static_reps after nep_batch_set_scene_statics");
   if (int e = E.d_sampled.ensure((size_t)S * N * np * (ns + 1) * 2)) return e;
   if (int e = E.d_present.ensure((size_t)S * N)) return e;
   if (int e = E.d_fe_work.ensure((size_t)std::max(h->slots * 256, S * N))) return e;
@@ -917,7 +943,7 @@ int nep_batch_set_hull_kernel(nep_batch_t* h, int32_t mode) {
 
 int nep_batch_set_max_runtime(nep_batch_t* h, double seconds) {
   if (!h || !(seconds >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
-  h->eng.sp.time_limit_ticks = seconds > 0 ? (long long)(seconds * 1e8) : 0;
+  h->eng.sp.time_limit_ticks = seconds > 0 ? (long long)(seconds * h->eng.clock_hz) : 0;
   return 0;
 }
 

@@ -40,13 +40,13 @@ struct Rccl {
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
     for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL); if (lib) break; }
     if (!lib) for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (lib) break; }
-    if (!lib) { err = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : ""); return false; }
+    if (!lib) { const char* e = dlerror(); err = std::string("librccl.so not found: ") + (e ? e : ""); return false; }
     GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
     AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) { err = "librccl.so lacks an expected symbol"; lib = nullptr; return false; }
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) { err = "librccl.so lacks an expected symbol"; dlclose(lib); lib = nullptr; return false; }
     return true;
   }
 };

@@ -31,7 +31,8 @@ struct SceneParams {
   double mins[3], maxs[3], v_max, a_max;
   double long_length; // solver_gurobi_poly.cpp:173
   double cull_radius; // > 0: separating lines farther than this from the guess are presolved away (verified after the solve)
-  long long time_limit_ticks;   // > 0: wall-clock budget of ONE solve in 100 MHz ticks (setMaxRuntime -> Gurobi TimeLimit, solver_gurobi_poly.cpp:812)
+  long long time_limit_ticks;   // > 0: wall-clock budget of ONE solve in wall_clock64() ticks (setMaxRuntime -> Gurobi TimeLimit, solver_gurobi_poly.cpp:812)
+  double us_per_tick;           // microseconds per wall_clock64() tick of this device (hipDeviceAttributeWallClockRate; 0.01 on gfx950: 100 MHz)
 };
 
 // Buffers of one problem set (n_scenes x n_local slots).  All device pointers.

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
 
   const int tid = threadIdx.x;
   const int slot = ps.order ? ps.order[blockIdx.x] : (int)blockIdx.x;   // (launch order: see order_kernel)
-  const long long t_wg0 = (long long)wall_clock64();          // this workgroup's lifetime goes to stats.solve_us (100 MHz ticks)
+  const long long t_wg0 = (long long)wall_clock64();          // this workgroup's lifetime goes to stats.solve_us (wall-clock ticks: sp.us_per_tick)
   const nep_guess* __restrict__ g = ps.guess + slot;
   const int K_in = g->K;
   const bool K_ok = K_in >= 1 && K_in <= NEP_MAX_POL && K_in <= sp.num_pol;   // (see qp_kernel)
@@ -942,7 +942,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((CULL && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;
-    sol->stats.objective = objective; { const long long dt_ = (long long)wall_clock64() - t_wg0; sol->stats.solve_us = (double)dt_ * 0.01; if (ps.order_key) { const long long k_ = dt_ / 800; ps.order_key[slot] = k_ > 63 ? 63 : (int)k_; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
+    sol->stats.objective = objective; { const long long dt_ = (long long)wall_clock64() - t_wg0; const double us_ = (double)dt_ * sp.us_per_tick; sol->stats.solve_us = us_; if (ps.order_key) { const double k_ = us_ * 0.125; ps.order_key[slot] = k_ > 63.0 ? 63 : (int)k_; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
     sol->K = Ko; sol->n_states = ns;
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)

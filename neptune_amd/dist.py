@@ -171,6 +171,12 @@ class ShardedRounds:
         self.native = NativeExchange(backends[0], world, rank) if native else None
         self.pending = [None] * self.C
         self.timer = timer if timer is not None else (lambda name: contextlib.nullcontext())
+        # A replan that fails publishes nothing: its d_commit slot keeps what it held (nep_batch_replan_hulls knows no previous
+        # records).  The next round's hulls are built from d_commit, so it must hold the agents' committed records from the
+        # start — an agent whose very first replan fails keeps flying (and being avoided on) the trajectory it had
+        # (neptune_ros.cpp:651-663), instead of vanishing from the others' obstacle sets as a valid = 0 record.
+        for b, dl in zip(backends, d_local):
+            b.d_commit.copy_(dl.view_as(b.d_commit))
 
     def _start(self, k, src):
         b, hx = self.bes[k], self.hx[k]

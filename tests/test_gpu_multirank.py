@@ -123,3 +123,32 @@ def test_native_record_exchange_one_rank(be):
     h.torch.cuda.synchronize()
     assert out.cpu().numpy().tobytes() == h.d_commit.cpu().numpy().tobytes()
     nx.close(); h.close()
+
+
+def test_failed_first_replan_keeps_the_agent_in_the_obstacle_sets(be):
+    """An agent whose very first replan fails (here: an unusable guess, K = 0) publishes nothing and keeps its committed
+    trajectory (neptune_ros.cpp:651-663): in the sharded round loop its d_commit slot must carry that record — a valid one —
+    into the next round's hulls, not the zeros the buffer was allocated with (the others would plan through it)."""
+    from neptune_amd import dist as ndist
+    N, M, S = 8, 4, 2
+    scenes = [scene.make_scene(N, M, seed=120 + s) for s in range(S)]
+    p = scenes[0]["par"]
+    com, gue = ndist.stack_scenes(scenes)
+    gue = gue.copy()
+    gue[1, 3]["K"] = 0                                     # scene 1, agent 4: front-end miss in round 0
+    h = be.BatchBackend(p, scenes[0]["statics"], n_scenes=S)
+    for s in range(S):
+        h.set_scene_statics(s, scenes[s]["statics"])
+    rounds = ndist.ShardedRounds([h], [h.to_device(com)], [h.to_device(gue)], world=1, rank=0)
+    rounds.step()
+    sol = h.solutions().reshape(S, N); got = h.commits().reshape(S, N)
+    assert int(sol[1, 3]["stats"]["status"]) == abi.NEP_FAILED
+    assert got[1, 3].tobytes() == com[1, 3].tobytes() and int(got[1, 3]["valid"]) == 1
+    # the next round equals a plain replan against those records (the failed agent's hulls included)
+    rounds.step()
+    ref = be.BatchBackend(p, scenes[0]["statics"], n_scenes=S)
+    for s in range(S):
+        ref.set_scene_statics(s, scenes[s]["statics"])
+    ref.replan(ref.to_device(got), ref.to_device(gue))
+    assert h.solutions().tobytes() == ref.solutions().tobytes()
+    h.close(); ref.close()
