@@ -7,23 +7,33 @@
 
 Workload (BASELINE.json north_star / configs[3] scene on the named GPU count): 64 agents + 20
 static polytope obstacles, K = 8 segments, reference yaml parameters, 128 seeded scenes (SURVEY.md
-§8d) in flight per GPU per step (--scenes; rounds 1 and early 2 ran 32: one launch of 2 048 workgroups is two
-waves of the QP kernel over the chip and a third of its time is the second wave draining).  One step = one bulk-synchronous round: every agent of every scene
+§8d) in flight per GPU per step (--scenes).  One step = one bulk-synchronous round: every agent of every scene
 does one full back-end replan (MINVO hulls of the other agents' committed trajectories ->
 separating-line LPs -> spline QP -> sampled states -> committed record); the new trajectories are
 the obstacles of the next step.  Inputs are resident in HBM before the timed region.  Every scene carries its
 own static obstacles (nep_batch_set_scene_statics); the CPU baseline solves the same scenes.
 
-Besides the headline the default command reports two more legs, each timed the same way: `presolve` (the
-verified row presolve on) and `chain` (front-end beam search -> separating lines -> QP -> post-solve safety check
-and commit, i.e. the guesses are made on the device instead of being read from the scene).
+`value` is that leg, timed over exactly --steps steps.  Because a number means little without what it depends on, the
+same JSON line carries further legs, each timed the same way (barrier + synchronize on both sides; at least 200 steps):
+  long_run          the headline's step over >= 200 steps (the driver's 20 steps are 33 ms)
+  launch_order_off  the same with the QP workgroups in slot order (the headline orders them by the previous replan's
+                    measured time, and re-solves the same problems every step: its predictor is exact)
+  presolve          the verified row presolve on
+  chain             front-end beam search -> lines -> QP -> safety check + commit: device-made guesses
+  moving            the closed loop on the device: chain + point A of the next round from the committed trajectories
+                    (nep_batch_next_starts), goals swapped on arrival — the problems change every step and the
+                    launch-order predictor is the previous replan of the same agent
+  single_scene      ONE fleet of 64 agents (the latency of a round, and the throughput of a single fleet)
+  config5           BASELINE configs[4]: 256 agents + 100 obstacles, enable_entangle_check on
+and `solve_us`: the per-replan device time distribution (p50 / p99) the metric asks for.
 
 N > 1: the agents of every scene are block-sharded by id across the ranks (64/N per GPU) and the
 number of scenes grows with N (128 per GPU), so every GPU does 8192 replans per step at any N:
-"scaling" is "weak".  The exchange step is one RCCL all-gather per round of what the other agents'
-replans consume of a committed trajectory — its interval hulls — so hull construction is sharded
-with the agents (--exchange records all-gathers the trajectory records instead and rebuilds every
-hull on every rank).
+"scaling" is "weak".  The exchange step is one RCCL all-gather per round and scene chunk of what the other agents'
+replans consume of a committed trajectory — its interval hulls — issued through the C ABI's own RCCL binding on a
+side stream inside the step, and the whole per-rank step (hulls, all-gather, separator, order, QP, every chunk) is
+captured into one HIP graph and replayed (--exchange-torch: torch.distributed's collective, launched from the host;
+--exchange records all-gathers the trajectory records instead and rebuilds every hull on every rank).
 """
 import argparse
 import json
@@ -37,9 +47,9 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 
-def algorithmic_bytes(p, sc, hull_nv, n_states):
+def algorithmic_bytes(p, sc, hull_nv, n_states, ent_bytes=0.0):
     """fp64 compulsory traffic of one replan: guess + other agents' hull vertices
-    + statics + bases in; coefficients, cost, status and sampled states out."""
+    + statics + bases (+ entangle inputs) in; coefficients, cost, status and sampled states out."""
     K = int(sc["guesses"][0]["K"])
     guess = 8 * (12 * K + (K + 1))
     N = p.num_agents
@@ -47,7 +57,7 @@ def algorithmic_bytes(p, sc, hull_nv, n_states):
     statics = 16 * sum(len(s) for s in sc["statics"])
     bases = 16 * N
     out = 8 * (12 * K + 1) + 4 + 96 * n_states
-    return guess + hull + statics + bases + out
+    return guess + hull + statics + bases + ent_bytes + out
 
 
 def algorithmic_flops(K, lines_mean, vertices_mean, iters_mean):
@@ -61,12 +71,13 @@ def algorithmic_flops(K, lines_mean, vertices_mean, iters_mean):
     return sep + iters_mean * per_iter
 
 
-def measured_traffic(kernel="nep::qp_kernel"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc summary of this
-    same command (profiles/): FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled as
-    MI355X_MICROARCH.md prescribes for gfx950 (its calibration is for 16 B/lane streams; our 8 B/lane
-    reads are uncalibrated, so this is an upper bound).  None when no summary is committed."""
-    path = os.path.join(ROOT, "profiles", "pmc_summary_latest.txt")
+def measured_traffic(kernel, name="pmc_summary_latest.txt"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 --pmc summary of this same command (profiles/):
+    FETCH_SIZE and WRITE_SIZE are reported in KiB; FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes for gfx950 (its
+    calibration is for 16 B/lane streams; our 8 B/lane reads are uncalibrated, so this is an upper bound).  A replay of a
+    committed file, not a measurement of this run (counters cannot be read from inside the process); None when no
+    summary is committed."""
+    path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return None
     cur, vals = None, {}
@@ -107,6 +118,25 @@ def cpu_baseline(p, scenes, budget_s=12.0):
             "sample": "%d replans of the same scenes (seeds 0..), one oracle thread per core, %.1f s" % (done, dt)}
 
 
+def _config5_scene(job):
+    """pool worker: one BASELINE configs[4] scene with its synthetic entangle inputs"""
+    n_agents, n_static, seed = job
+    from neptune_amd import scene
+    sc = scene.make_scene(n_agents, n_static, seed=seed)
+    case_id = scene.synthetic_entangle(sc, seed=1000 + seed, frac=0.1)
+    return sc, case_id
+
+
+def quantiles(a):
+    a = np.asarray(a, dtype=np.float64)
+    return {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "p99": float(np.percentile(a, 99)), "max": float(a.max()), "mean": float(a.mean())}
+
+
+def status_counts(sol):
+    st = sol["stats"]["status"].astype(int)
+    return {"status_ok": int((st == 0).sum()), "status_relaxed": int((st == 1).sum()), "status_failed": int((st == 2).sum())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -115,6 +145,7 @@ def main():
     ap.add_argument("--agents", type=int, default=64)
     ap.add_argument("--obstacles", type=int, default=20)
     ap.add_argument("--scenes", type=int, default=128, help="seeded scenes in flight PER GPU")
+    ap.add_argument("--aux-steps", type=int, default=200, help="timed steps of the separately reported legs (at least --steps)")
     ap.add_argument("--exchange", choices=["hulls", "records"], default="hulls",
                     help="N > 1: all-gather the interval hulls of the local agents' committed trajectories (hull work "
                          "sharded with the agents) or the trajectory records themselves (every rank rebuilds all hulls)")
@@ -126,12 +157,17 @@ def main():
                     help="presolve of the separating-line rows (nep_batch_set_line_cull): lines farther than this many metres "
                          "from the guess are left out of the QP and verified after the solve; 0 = off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exchange-native", action="store_true",
-                    help="N > 1 with --exchange hulls: the all-gather through the C ABI's own RCCL binding (nep_batch_exchange_hulls) "
-                         "instead of torch.distributed")
-    ap.add_argument("--no-graph", action="store_true", help="single GPU: launch every step from the host instead of replaying one captured HIP graph")
+    ap.add_argument("--exchange-torch", action="store_true",
+                    help="N > 1 with --exchange hulls: the all-gather through torch.distributed (host-launched steps) instead of the "
+                         "C ABI's own RCCL binding inside one captured HIP graph per step")
+    ap.add_argument("--exchange-native", action="store_true", help="(the default now; kept for older command lines)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every step from the host instead of replaying one captured HIP graph")
     ap.add_argument("--no-process-group", action="store_true", help="single GPU: do not create the one-rank RCCL process group")
-    ap.add_argument("--no-chain", action="store_true", help="skip the separately reported front end + safety leg")
+    ap.add_argument("--no-chain", action="store_true", help="skip the separately reported front end + safety legs (chain, moving)")
+    ap.add_argument("--no-config5", action="store_true", help="skip the separately reported BASELINE configs[4] leg")
+    ap.add_argument("--config5-scenes", type=int, default=32, help="scenes in flight of the config-5 leg (x 256 agents = replans per step)")
+    ap.add_argument("--config5-only", action="store_true", help="development aid: only the config-5 leg (profiling)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="only the headline (and what --frontend / --safety ask for)")
     ap.add_argument("--frontend", action="store_true",
                     help="also run the front-end beam search (SURVEY §8f rank 2) in every step: the guesses are made on the device "
                          "from point A and the goal instead of being read from the scene (single GPU)")
@@ -139,6 +175,7 @@ def main():
     ap.add_argument("--safety", action="store_true",
                     help="also run the post-solve safety check + commit (SURVEY §8f rank 1) in every step")
     args = ap.parse_args()
+    aux_steps = max(args.aux_steps, args.steps)
 
     import torch
     from neptune_amd import abi, dist as ndist, scene
@@ -161,6 +198,16 @@ def main():
     import torch.distributed as tdist
     use_dist = world > 1 or "RANK" in os.environ          # launched by torch.distributed.run
     rccl_note = None
+    extra = world == 1 and not args.no_extra_legs and not args.frontend and not args.safety and args.cull_radius == 0.0
+
+    # the config-5 scenes take ~20 s of host time each: a pool makes them while the GPU runs the other legs
+    c5_pool, c5_futs, c5_made, c5_wait = None, None, None, 0.0
+    want_c5 = (extra and not args.no_config5) or args.config5_only
+    if want_c5 and rank == 0:
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        c5_pool = ProcessPoolExecutor(max_workers=min(args.config5_scenes, max(1, (os.cpu_count() or 1) // 2)), mp_context=mp.get_context("spawn"))
+        c5_futs = [c5_pool.submit(_config5_scene, (256, 100, s)) for s in range(args.config5_scenes)]
 
     class _stdout_to_stderr:
         """RCCL prints a version banner on stdout when its first communicator comes up; stdout carries the one JSON line"""
@@ -188,7 +235,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29512")
         init_group(dist_backend)
-    elif not args.no_process_group:
+    elif not args.no_process_group and not args.config5_only:
         # plain `python bench.py`: a one-rank RCCL process group, so that the single-GPU record also shows the collective
         # library initialising on the box and the round's all-gather call path running (degenerate: one rank)
         try:
@@ -199,70 +246,18 @@ def main():
         except Exception as e:                                 # never lose the measurement to the extra
             rccl_note = "one-rank process group not created: %r" % (e,)
 
-    # Weak scaling: args.scenes scenes in flight per GPU, so S = scenes * world scenes in total; the
-    # agents of EVERY scene are block-sharded over the ranks (configs[3]: 64 agents, 8 per GPU on 8
-    # GPUs), which keeps scenes * agents replans per GPU per step at any N.
-    N, M, S = args.agents, args.obstacles, args.scenes * world
-    first_local, n_local = ndist.shard(N, world, rank)
-    # each rank generates its share of the seeded scenes (seeds 0..S-1 overall), then they are shared
-    mine = scene.make_scenes(N, M, range(rank * args.scenes, (rank + 1) * args.scenes),
-                             workers=min(args.scenes, max(1, (os.cpu_count() or 1) // (2 * world)), 64))
-    scene0 = mine[0] if rank == 0 else scene.make_scene(N, M, seed=0)
-    p = scene0["par"]
-    # every scene has its own static obstacles (drawn first from its seed, so any rank can rebuild any scene's set)
-    all_statics = [mine[s - rank * args.scenes]["statics"] if rank * args.scenes <= s < (rank + 1) * args.scenes
-                   else scene.scene_statics(N, M, s, par=p) for s in range(S)]
-    statics = all_statics[0]
-    com_l, gue_l = ndist.stack_scenes(mine)
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if use_dist:
+            tdist.barrier()
+        torch.cuda.synchronize(dev)
 
-    def share(arr):                      # [scenes per GPU][N] per rank -> [S][N] on every rank
-        if world == 1:
-            return arr
-        t = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy())
-        if dist_backend == "nccl":
-            t = t.to(dev)
-            out = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
-            tdist.all_gather_into_tensor(out, t)
-            out = out.cpu()
-        else:
-            pieces = [torch.empty_like(t) for _ in range(world)]
-            tdist.all_gather(pieces, t)
-            out = torch.cat(pieces)
-        return out.numpy().view(arr.dtype).reshape((S,) + arr.shape[1:])
-    com, gue = share(com_l), share(gue_l)
-
-    sharded_hulls = world > 1 and args.exchange == "hulls"
-    C = args.chunks if (sharded_hulls and not args.safety and S % max(args.chunks, 1) == 0) else 1
-    Sc = S // C
-    # one handle per scene chunk (C == 1: all scenes); chunk k holds scenes [k*Sc, (k+1)*Sc)
-    bes = [BatchBackend(p, statics, first_local=first_local, n_local=n_local, n_scenes=Sc, device=dev) for _ in range(C)]
-    be = bes[0]
-    for k, b in enumerate(bes):
-        b.set_line_cull(args.cull_radius)
-        for s_ in range(Sc):
-            if len(all_statics[k * Sc + s_]) != len(statics):
-                raise SystemExit("scene %d drew %d static obstacles instead of %d" % (k * Sc + s_, len(all_statics[k * Sc + s_]), len(statics)))
-            b.set_scene_statics(s_, all_statics[k * Sc + s_])
-    d_committed = be.to_device(com) if C == 1 else None
-    d_guess_c = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)]
-    d_guess = d_guess_c[0]
-    ex = ndist.RoundExchange(S, N, world, rank, device=dev)
-    hxs = [ndist.HullExchange(bes[k].hull_block_bytes(), world, rank, device=dev) for k in range(C)] if (sharded_hulls and args.safety) else None
-    d_local_c = [bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)] if sharded_hulls else None
-    d_committed_next = torch.empty_like(d_committed) if args.safety else None
-    d_new = torch.empty_like(d_committed) if args.safety else None
-    d_accept = torch.zeros(S * N, dtype=torch.int32, device=dev) if args.safety else None
-    safety_ev, hull_ev, gather_ev, fe_ev = [], [], [], []
-    REC = abi.TRAJ_REC_DTYPE.itemsize
-    if args.frontend and world > 1 and not (sharded_hulls and not args.safety):
-        raise SystemExit("--frontend with several GPUs needs --exchange hulls and no --safety")
-    fe_cfg = scene.frontend_cfg(p, beam_width=args.beam) if args.frontend else None
-    fe_starts = share(np.stack([scene.frontend_starts(s) for s in mine])) if args.frontend else None       # [S][N]
-    d_fe_start_c = [bes[k].to_device(np.ascontiguousarray(fe_starts[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)] if args.frontend else None
-    d_fe_start = d_fe_start_c[0] if args.frontend else None
-    d_fe_res_c = [torch.zeros(Sc * n_local * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(C)] if args.frontend else None
-    d_fe_res = d_fe_res_c[0] if args.frontend else None
-    pending = [None] * C
+    def max_over_ranks(dt):
+        if use_dist:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if dist_backend == "nccl" else "cpu")
+            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
 
     ev_on = [True]
 
@@ -275,81 +270,21 @@ def main():
         def __init__(self, lst): self.lst = lst
         def __enter__(self): self.e0 = ev()
         def __exit__(self, *a): self.lst.append((self.e0, ev()))
-    _ev_lists = {"hull": hull_ev, "wait": gather_ev, "frontend": fe_ev}
-    rounds = None
-    if sharded_hulls and not args.safety:
-        rounds = ndist.ShardedRounds(bes, d_local_c, d_guess_c, world, rank, native=args.exchange_native,
-                                     fe=(fe_cfg, d_fe_start_c, d_fe_res_c) if args.frontend else None,
-                                     timer=lambda name: _timed(_ev_lists[name]))
-        hxs = rounds.hx
 
-    def start_exchange(k, src):
-        """hulls of my agents' committed trajectories (chunk k) -> start the all-gather of the hull blocks"""
-        e0 = ev()
-        bes[k].hulls(src, d_guess_c[k], hxs[k].local)
-        hull_ev.append((e0, ev()))
-        pending[k] = hxs[k].gather_async()
+    def mean_ms(pairs):
+        pairs = [(a, b) for a, b in pairs if a is not None and b is not None]     # (pairs "recorded" while a graph was being captured are placeholders)
+        return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else 0.0
 
-    def step():
-        if rounds is not None:
-            rounds.step()          # chunks pipelined: one chunk's all-gather runs under the other chunk's kernels (dist.ShardedRounds)
-            return
-        if sharded_hulls:
-            start_exchange(0, d_local_c[0])
-            e1 = ev()
-            pending[0].wait()
-            gather_ev.append((e1, ev()))
-            be.replan_hulls(hxs[0].blocks, d_guess)
-        elif args.frontend:
-            e0 = ev()
-            be.frontend(fe_cfg, d_committed, d_fe_start, d_guess, d_fe_res)     # hulls + beam search -> d_guess
-            fe_ev.append((e0, ev()))
-            be.replan(None, d_guess)                                             # separator + QP on the same hulls
-        else:
-            be.replan(d_committed, d_guess)
-        if not args.safety:
-            e1 = ev()
-            ex.gather(be.d_commit, d_committed)
-            gather_ev.append((e1, ev()))
-            return
-        ex.gather(be.d_commit, d_new)                   # everyone's new trajectory
-        e0 = ev()
-        be.safety_commit(d_committed, d_new, d_guess, d_committed_next, d_accept)      # d_guess: [S][n_local], as passed to the replan
-        safety_ev.append((e0, ev()))
-        d_committed.copy_(d_committed_next)
-        if sharded_hulls:
-            d_local_c[0].view(S, n_local * REC).copy_(d_committed.view(S, N * REC)[:, first_local * REC:(first_local + n_local) * REC])
+    graph_notes = []
 
-    def barrier():
-        torch.cuda.synchronize(dev)
-        if use_dist:
-            tdist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    rccl_one_rank_ok = None
-    if world == 1 and use_dist and dist_backend == "nccl" and not (args.safety or args.frontend) and C == 1:
-        # one rank: the timed steps copy (nothing to exchange); the collective path itself — the all-gather of the committed
-        # records through RCCL — is exercised once here, outside the timed region, and must give the same bytes
-        chk = torch.empty_like(d_committed)
-        ex.gather(be.d_commit, chk, collective=True)
-        torch.cuda.synchronize(dev)
-        rccl_one_rank_ok = bool(torch.equal(chk, be.d_commit.view_as(chk)))
-    barrier()
-    # One step = a fixed sequence of launches on fixed buffers: on a single GPU it is captured once into a HIP graph and the
-    # timed region replays it (no per-launch host work, no host jitter between the kernels of a step).  The per-kernel HIP
-    # events cannot live inside a graph: they are taken in a short eager section after the timed region.
-    graph, graph_note = None, None
-    can_graph = not args.no_graph and world == 1 and rounds is None
-
-    def capture(fn):
-        """fn() enqueues one step on the current stream -> a captured graph of it, or None (then the host launches)"""
-        nonlocal graph_note
-        if not can_graph:
+    def capture(fn, handles, allow=True):
+        """fn() enqueues one step on the current stream -> a captured graph of it, or None (then the host launches).
+        One step = a fixed sequence of launches on fixed buffers (at N > 1 including the RCCL all-gathers on their side
+        stream): captured once, replayed in the timed region — no per-launch host work, no host jitter between kernels."""
+        if args.no_graph or not allow:
             return None
         try:
-            for b in bes:
+            for b in handles:
                 b.enable_timing(False)
             torch.cuda.synchronize(dev)
             g_ = torch.cuda.CUDAGraph()
@@ -362,165 +297,451 @@ def main():
             return g_
         except Exception as e:                       # (falls back to launching from the host)
             ev_on[0] = True
-            graph_note = "graph capture failed: %r" % (e,)
+            graph_notes.append("graph capture failed: %r" % (e,))
             torch.cuda.synchronize(dev)
             return None
-    if not args.frontend and not args.safety:
-        graph = capture(step)
-    eager_timing = graph is None
-    for b in bes:
-        b.enable_timing(eager_timing)
-        b.reset_timing()
-    safety_ev.clear(); hull_ev.clear(); gather_ev.clear()
-    barrier()
-    step_ev = [ev()]
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if graph is not None:
-            graph.replay()
-        else:
-            step()
-        step_ev.append(ev())
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-        dt = float(t.item())
-    step_ms = np.array([step_ev[i].elapsed_time(step_ev[i + 1]) for i in range(args.steps)])   # GPU time of each step (this rank)
-    if graph is not None:                            # per-kernel durations: the same steps launched from the host, HIP events on the launch stream
-        for b in bes:
-            b.enable_timing(True)
-            b.reset_timing()
-        for _ in range(min(args.steps, 40)):
-            step()
-        barrier()
 
-    def mean_ms(pairs):
-        pairs = [(a, b) for a, b in pairs if a is not None and b is not None]     # (pairs "recorded" while a graph was being captured are placeholders)
-        return float(np.mean([a.elapsed_time(b) for a, b in pairs])) if pairs else 0.0
-    qp_ms, n_launch = be.kernel_time_ms(2)           # per launch of one chunk (chunk 0)
-    hull_ms, _ = be.kernel_time_ms(0)
-    if sharded_hulls:
-        hull_ms = mean_ms(hull_ev)
-    sep_ms, _ = be.kernel_time_ms(1)
-    seq_ms, _ = be.kernel_time_ms(3)
-    for b in bes:
-        b.enable_timing(False)
-
-    sol = np.concatenate([b.solutions() for b in bes])
-    status = sol["stats"]["status"].astype(int)
-    iters = sol["stats"]["iters"].astype(int)
-    n_states = int(sol[0]["n_states"])
-    replans_per_step = S * N
-    value = replans_per_step * args.steps / dt
-
-    # Second, separately reported leg: the same steps with the line presolve on.  The headline `value`
-    # above is always the run that carries every separating-line row through the solver.
-    presolve = None
-    if args.cull_radius == 0.0 and args.presolve_radius > 0.0:
-        for b in bes:
-            b.set_line_cull(args.presolve_radius)
-        for _ in range(max(args.warmup, 2)):
-            step()
+    def run_leg(step_fn, handles, steps, warm, graph_ok=True, eager_after=40, clear=()):
+        """warm untimed steps, then exactly `steps` steps between barriers (max over ranks), replaying one captured graph
+        when possible.  Per-kernel HIP events (handle timing) cannot live inside a graph: with a graph they are taken from
+        `eager_after` host-launched steps after the timed region.  -> (seconds, per-step GPU ms, graph used)"""
+        for _ in range(warm):
+            step_fn()
         barrier()
-        g2 = capture(step)
-        for b in bes:
-            b.enable_timing(g2 is None)
-            b.reset_timing()
+        g_ = capture(step_fn, handles, graph_ok)
+        for b in handles:
+            b.enable_timing(g_ is None); b.reset_timing()
+        for lst in clear:
+            lst.clear()
         barrier()
+        evs = [ev()]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            if g2 is not None:
-                g2.replay()
+        for _ in range(steps):
+            if g_ is not None:
+                g_.replay()
             else:
-                step()
+                step_fn()
+            evs.append(ev())
         barrier()
-        dt2 = time.perf_counter() - t0
-        if g2 is not None:
-            for b in bes:
-                b.enable_timing(True)
-                b.reset_timing()
-            for _ in range(min(args.steps, 40)):
-                step()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        step_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
+        if g_ is not None and eager_after > 0:
+            for b in handles:
+                b.enable_timing(True); b.reset_timing()
+            for lst in clear:
+                lst.clear()
+            for _ in range(min(steps, eager_after)):
+                step_fn()
             barrier()
-        if use_dist:
-            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-            tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
-            dt2 = float(t.item())
-        qp2, _ = be.kernel_time_ms(2)
+        return dt, step_ms, g_
+
+    def solve_us_stats(be_):
+        """per-replan device time of the interior-point workgroup (nep_stats.solve_us) of the last step"""
+        us = be_.solutions(timing=True)["stats"]["solve_us"]
+        return {"p50": float(np.percentile(us, 50)), "p90": float(np.percentile(us, 90)), "p99": float(np.percentile(us, 99)),
+                "max": float(us.max()), "mean": float(us.mean()), "n": int(us.size)}
+
+    out = None
+    if not args.config5_only:
+        # Weak scaling: args.scenes scenes in flight per GPU, so S = scenes * world scenes in total; the
+        # agents of EVERY scene are block-sharded over the ranks (configs[3]: 64 agents, 8 per GPU on 8
+        # GPUs), which keeps scenes * agents replans per GPU per step at any N.
+        N, M, S = args.agents, args.obstacles, args.scenes * world
+        first_local, n_local = ndist.shard(N, world, rank)
+        # each rank generates its share of the seeded scenes (seeds 0..S-1 overall), then they are shared
+        host_cores = os.cpu_count() or 1
+        mine = scene.make_scenes(N, M, range(rank * args.scenes, (rank + 1) * args.scenes),
+                                 workers=min(args.scenes, max(1, (host_cores // (4 if want_c5 else 2)) // world), 64))
+        scene0 = mine[0] if rank == 0 else scene.make_scene(N, M, seed=0)
+        if c5_futs is not None:
+            # the config-5 pool has been running beside this one; nothing is timed while host processes are still busy (a first
+            # version let it run under the timed legs: the GPU time per step was unchanged, the host's share of a 20-step region
+            # went from 1 % to 60 %)
+            t_c5 = time.perf_counter()
+            c5_made = [f.result() for f in c5_futs]
+            c5_pool.shutdown(); c5_pool = None
+            c5_wait = time.perf_counter() - t_c5
+        p = scene0["par"]
+        # every scene has its own static obstacles (drawn first from its seed, so any rank can rebuild any scene's set)
+        all_statics = [mine[s - rank * args.scenes]["statics"] if rank * args.scenes <= s < (rank + 1) * args.scenes
+                       else scene.scene_statics(N, M, s, par=p) for s in range(S)]
+        statics = all_statics[0]
+        com_l, gue_l = ndist.stack_scenes(mine)
+
+        def share(arr):                      # [scenes per GPU][N] per rank -> [S][N] on every rank
+            if world == 1:
+                return arr
+            t = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy())
+            if dist_backend == "nccl":
+                t = t.to(dev)
+                o_ = torch.empty(world * t.numel(), dtype=torch.uint8, device=dev)
+                tdist.all_gather_into_tensor(o_, t)
+                o_ = o_.cpu()
+            else:
+                pieces = [torch.empty_like(t) for _ in range(world)]
+                tdist.all_gather(pieces, t)
+                o_ = torch.cat(pieces)
+            return o_.numpy().view(arr.dtype).reshape((S,) + arr.shape[1:])
+        com, gue = share(com_l), share(gue_l)
+
+        sharded_hulls = world > 1 and args.exchange == "hulls"
+        native = sharded_hulls and not args.exchange_torch and not args.safety and dist_backend == "nccl"
+        C = args.chunks if (sharded_hulls and not args.safety and S % max(args.chunks, 1) == 0) else 1
+        Sc = S // C
+        # one handle per scene chunk (C == 1: all scenes); chunk k holds scenes [k*Sc, (k+1)*Sc)
+        bes = [BatchBackend(p, statics, first_local=first_local, n_local=n_local, n_scenes=Sc, device=dev) for _ in range(C)]
+        be = bes[0]
+        for k, b in enumerate(bes):
+            b.set_line_cull(args.cull_radius)
+            for s_ in range(Sc):
+                if len(all_statics[k * Sc + s_]) != len(statics):
+                    raise SystemExit("scene %d drew %d static obstacles instead of %d" % (k * Sc + s_, len(all_statics[k * Sc + s_]), len(statics)))
+                b.set_scene_statics(s_, all_statics[k * Sc + s_])
+        d_committed = be.to_device(com) if C == 1 else None
+        d_guess_c = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)]
+        d_guess = d_guess_c[0]
+        ex = ndist.RoundExchange(S, N, world, rank, device=dev)
+        hxs = [ndist.HullExchange(bes[k].hull_block_bytes(), world, rank, device=dev) for k in range(C)] if (sharded_hulls and args.safety) else None
+        d_local_c = [bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)] if sharded_hulls else None
+        d_committed_next = torch.empty_like(d_committed) if args.safety else None
+        d_new = torch.empty_like(d_committed) if args.safety else None
+        d_accept = torch.zeros(S * N, dtype=torch.int32, device=dev) if args.safety else None
+        safety_ev, hull_ev, gather_ev, fe_ev = [], [], [], []
+        REC = abi.TRAJ_REC_DTYPE.itemsize
+        if args.frontend and world > 1 and not (sharded_hulls and not args.safety):
+            raise SystemExit("--frontend with several GPUs needs --exchange hulls and no --safety")
+        fe_cfg = scene.frontend_cfg(p, beam_width=args.beam) if args.frontend else None
+        fe_starts = share(np.stack([scene.frontend_starts(s) for s in mine])) if args.frontend else None       # [S][N]
+        d_fe_start_c = [bes[k].to_device(np.ascontiguousarray(fe_starts[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)] if args.frontend else None
+        d_fe_start = d_fe_start_c[0] if args.frontend else None
+        d_fe_res_c = [torch.zeros(Sc * n_local * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(C)] if args.frontend else None
+        d_fe_res = d_fe_res_c[0] if args.frontend else None
+        pending = [None] * C
+        _ev_lists = {"hull": hull_ev, "wait": gather_ev, "frontend": fe_ev}
+        rounds = None
+        nranks = None
+        if sharded_hulls and not args.safety:
+            with _stdout_to_stderr():                      # (a second communicator: RCCL may print again)
+                rounds = ndist.ShardedRounds(bes, d_local_c, d_guess_c, world, rank, native=native,
+                                             fe=(fe_cfg, d_fe_start_c, d_fe_res_c) if args.frontend else None,
+                                             timer=lambda name: _timed(_ev_lists[name]))
+            hxs = rounds.hx
+            if native:
+                mine_n = rounds.native.nranks()
+                t = torch.tensor([mine_n], dtype=torch.int64, device=dev)
+                got = [torch.zeros_like(t) for _ in range(world)]
+                tdist.all_gather(got, t)
+                nranks = [int(x.item()) for x in got]
+                print("[bench] rank %d of %d: native RCCL communicator has %d ranks" % (rank, world, mine_n), file=sys.stderr)
+                if mine_n != world or any(n_ != world for n_ in nranks):
+                    raise SystemExit("native RCCL communicator: ranks joined %r, expected %d on every rank" % (nranks, world))
+        elif world > 1:
+            nranks = [tdist.get_world_size()] * world
+
+        def start_exchange(k, src):
+            """hulls of my agents' committed trajectories (chunk k) -> start the all-gather of the hull blocks"""
+            e0 = ev()
+            bes[k].hulls(src, d_guess_c[k], hxs[k].local)
+            hull_ev.append((e0, ev()))
+            pending[k] = hxs[k].gather_async()
+
+        def step():
+            if rounds is not None:
+                rounds.step()          # chunks pipelined: one chunk's all-gather runs under another chunk's kernels (dist.ShardedRounds)
+                return
+            if sharded_hulls:
+                start_exchange(0, d_local_c[0])
+                e1 = ev()
+                pending[0].wait()
+                gather_ev.append((e1, ev()))
+                be.replan_hulls(hxs[0].blocks, d_guess)
+            elif args.frontend:
+                e0 = ev()
+                be.frontend(fe_cfg, d_committed, d_fe_start, d_guess, d_fe_res)     # hulls + beam search -> d_guess
+                fe_ev.append((e0, ev()))
+                be.replan(None, d_guess)                                             # separator + QP on the same hulls
+            else:
+                be.replan(d_committed, d_guess)
+            if not args.safety:
+                e1 = ev()
+                ex.gather(be.d_commit, d_committed)
+                gather_ev.append((e1, ev()))
+                return
+            ex.gather(be.d_commit, d_new)                   # everyone's new trajectory
+            e0 = ev()
+            be.safety_commit(d_committed, d_new, d_guess, d_committed_next, d_accept)      # d_guess: [S][n_local], as passed to the replan
+            safety_ev.append((e0, ev()))
+            d_committed.copy_(d_committed_next)
+            if sharded_hulls:
+                d_local_c[0].view(S, n_local * REC).copy_(d_committed.view(S, N * REC)[:, first_local * REC:(first_local + n_local) * REC])
+
+        # a step can be captured when it is a fixed launch sequence without host decisions: one GPU, or several with the native
+        # exchange (the torch path's work handles and the gloo / records paths are host-driven)
+        can_graph = (world == 1 and rounds is None) or (rounds is not None and native)
+        graph_plain = can_graph and not args.frontend and not args.safety
+
+        for _ in range(args.warmup):
+            step()
+        rccl_one_rank_ok = None
+        if world == 1 and use_dist and dist_backend == "nccl" and not (args.safety or args.frontend) and C == 1:
+            # one rank: the timed steps copy (nothing to exchange); the collective path itself — the all-gather of the committed
+            # records through RCCL — is exercised once here, outside the timed region, and must give the same bytes
+            chk = torch.empty_like(d_committed)
+            ex.gather(be.d_commit, chk, collective=True)
+            torch.cuda.synchronize(dev)
+            rccl_one_rank_ok = bool(torch.equal(chk, be.d_commit.view_as(chk)))
+        # ---- headline: exactly --steps steps -------------------------------------------------------------------------
+        dt, step_ms, graph = run_leg(step, bes, args.steps, 0, graph_ok=graph_plain, clear=(safety_ev, hull_ev, gather_ev))
+        qp_ms, n_launch = be.kernel_time_ms(2)           # per launch of one chunk (chunk 0)
+        hull_ms, _ = be.kernel_time_ms(0)
+        if sharded_hulls:
+            hull_ms = mean_ms(hull_ev)
+        sep_ms, _ = be.kernel_time_ms(1)
+        seq_ms, _ = be.kernel_time_ms(3)
         for b in bes:
             b.enable_timing(False)
-        sol2 = np.concatenate([b.solutions() for b in bes])
-        st2 = sol2["stats"]["status"].astype(int)
-        presolve = {"value": replans_per_step * args.steps / dt2, "unit": "replans/s", "ms_per_step": dt2 / args.steps * 1e3,
-                    "cull_radius_m": args.presolve_radius, "qp_ms": qp2,
-                    "rows_solved_mean": float(sol2["stats"]["n_rows"].mean()),
-                    "ipm_iters_mean": float(sol2["stats"]["iters"].mean()), "ipm_iters_max": int(sol2["stats"]["iters"].max()),
-                    "status_ok": int((st2 == 0).sum()), "status_relaxed": int((st2 == 1).sum()), "status_failed": int((st2 == 2).sum()),
-                    "solved_without_iteration": int((sol2["stats"]["iters"] == 0).sum()),
-                    "note": "verified shortcuts, same optimum as the headline run: (1) lines farther than the radius from the guess are parked, "
-                            "checked against the solution and the QP re-solved with all of them on a violation; (2) if the minimiser of the "
-                            "cost without inequality rows satisfies every row it is the optimum (KKT with zero multipliers) and no "
-                            "interior-point iteration runs"}
-        for b in bes:
-            b.set_line_cull(0.0)
+        sol = np.concatenate([b.solutions() for b in bes])
+        solve_us = solve_us_stats(be)
+        status = sol["stats"]["status"].astype(int)
+        iters = sol["stats"]["iters"].astype(int)
+        n_states = int(sol[0]["n_states"])
+        replans_per_step = S * N
+        value = replans_per_step * args.steps / dt
 
-    # Third leg (single GPU): the whole chain of one round with the guesses made on the device — front-end beam search
-    # from point A and the goal, separating lines + QP on the same hulls, post-solve safety check and commit.
-    chain = None
-    if world == 1 and not args.no_chain and not args.frontend and not args.safety and C == 1:
-        cfg_fe = scene.frontend_cfg(p, beam_width=args.beam)
-        d_st = be.to_device(np.stack([scene.frontend_starts(s_) for s_ in mine]))
-        d_gfe = torch.zeros_like(d_guess)
-        d_res = torch.zeros(S * N * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
-        d_com2 = be.to_device(com); d_nxt = torch.empty_like(d_com2); d_acc = torch.zeros(S * N, dtype=torch.int32, device=dev)
-        fe2, sf2 = [], []
+        def leg_record(dt_, steps_, step_ms_, **kw):
+            r = {"value": replans_per_step * steps_ / dt_, "unit": "replans/s", "steps": steps_, "ms_per_step": dt_ / steps_ * 1e3,
+                 "step_ms": {"p50": float(np.percentile(step_ms_, 50)), "p99": float(np.percentile(step_ms_, 99)), "max": float(step_ms_.max())}}
+            r.update(kw)
+            return r
 
-        def chain_step():
-            e0 = ev()
-            be.frontend(cfg_fe, d_com2, d_st, d_gfe, d_res)
-            fe2.append((e0, ev()))
-            be.replan(None, d_gfe)                       # (a failed / empty replan's commit slot carries the record of d_com2 over)
-            e1 = ev()
-            be.safety_commit(d_com2, be.d_commit, d_gfe, d_nxt, d_acc)
-            sf2.append((e1, ev()))
-            d_com2.copy_(d_nxt)
-        for _ in range(max(args.warmup, 2)):
-            chain_step()
-        barrier()
-        g3 = capture(chain_step)
-        be.enable_timing(g3 is None); be.reset_timing()
-        fe2.clear(); sf2.clear()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            if g3 is not None:
-                g3.replay()
-            else:
-                chain_step()
-        barrier()
-        dt3 = time.perf_counter() - t0
-        if g3 is not None:
-            be.enable_timing(True); be.reset_timing()
-            fe2.clear(); sf2.clear()
-            for _ in range(min(args.steps, 40)):
-                chain_step()
-            barrier()
-        qp3, _ = be.kernel_time_ms(2); sep3, _ = be.kernel_time_ms(1)
-        be.enable_timing(False)
-        sol3 = be.solutions(); st3 = sol3["stats"]["status"].astype(int)
-        res3 = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)
-        chain = {"value": replans_per_step * args.steps / dt3, "unit": "replans/s", "ms_per_step": dt3 / args.steps * 1e3,
-                 "kernel_ms": {"frontend_with_hulls": mean_ms(fe2), "separator": sep3, "qp": qp3, "safety": mean_ms(sf2)},
-                 "beam_width": args.beam, "frontend_goal_reached": int((res3["status"] == 1).sum()), "frontend_no_solution": int((res3["status"] == 3).sum()),
-                 "ipm_iters_mean": float(sol3["stats"]["iters"].mean()), "ipm_iters_max": int(sol3["stats"]["iters"].max()),
-                 "status_ok": int((st3 == 0).sum()), "status_relaxed": int((st3 == 1).sum()), "status_failed": int((st3 == 2).sum()),
-                 "lp_failed": int(sol3["stats"]["n_lp_failed"].sum()), "accepted_frac": float(d_acc.float().mean().item()),
-                 "note": "front-end beam search -> separating lines -> QP -> safety check + commit, every step; the guesses are the "
-                         "device-made lattice paths (they end at cruise speed and cut corners around obstacles), not the scene's"}
+        # ---- the same step over a longer timed region, and with the launch order off -----------------------------------
+        long_run = order_off = None
+        if not args.no_extra_legs and graph_plain:
+            dt_l, ms_l, _ = run_leg(step, bes, aux_steps, 2, graph_ok=True, eager_after=0)
+            long_run = leg_record(dt_l, aux_steps, ms_l, note="the headline's step, %d steps between the barriers" % aux_steps)
+            for b in bes:
+                b.set_launch_order(False)
+            dt_o, ms_o, _ = run_leg(step, bes, aux_steps, 2, graph_ok=True, eager_after=10)
+            qp_o, _ = be.kernel_time_ms(2)
+            order_off = leg_record(dt_o, aux_steps, ms_o, qp_ms=qp_o, solve_us=solve_us_stats(be),
+                                   note="QP workgroups in slot order (nep_batch_set_launch_order(0)): what the headline gains from ordering "
+                                        "them by each slot's previous measured time — in this leg and in the headline the same problems are "
+                                        "re-solved every step, so that predictor is exact; `moving` has the realistic one")
+            for b in bes:
+                b.enable_timing(False); b.set_launch_order(True)
+            for _ in range(2):
+                step()                                   # (the ordering keys are fresh again for what follows)
 
-    if rank == 0:
+        # ---- presolve: the same steps with the verified line presolve on (DESIGN §6) ------------------------------------
+        presolve = None
+        if args.cull_radius == 0.0 and args.presolve_radius > 0.0 and not args.no_extra_legs:
+            for b in bes:
+                b.set_line_cull(args.presolve_radius)
+            dt2, ms2, _ = run_leg(step, bes, aux_steps, max(args.warmup, 2), graph_ok=graph_plain)
+            qp2, _ = be.kernel_time_ms(2)
+            for b in bes:
+                b.enable_timing(False)
+            sol2 = np.concatenate([b.solutions() for b in bes])
+            presolve = leg_record(dt2, aux_steps, ms2, cull_radius_m=args.presolve_radius, qp_ms=qp2,
+                                  rows_solved_mean=float(sol2["stats"]["n_rows"].mean()),
+                                  ipm_iters_mean=float(sol2["stats"]["iters"].mean()), ipm_iters_max=int(sol2["stats"]["iters"].max()),
+                                  solved_without_iteration=int((sol2["stats"]["iters"] == 0).sum()), solve_us=solve_us_stats(be),
+                                  note="verified shortcuts, same optimum as the headline run: (1) lines farther than the radius from the guess are parked, "
+                                       "checked against the solution and the QP re-solved with all of them on a violation; (2) if the minimiser of the "
+                                       "cost without inequality rows satisfies every row it is the optimum (KKT with zero multipliers) and no "
+                                       "interior-point iteration runs", **status_counts(sol2))
+            for b in bes:
+                b.set_line_cull(0.0)
+
+        # ---- chain (single GPU): front-end beam search from point A and the goal, separating lines + QP on the same hulls,
+        # post-solve safety check and commit — the guesses are device-made -----------------------------------------------
+        chain = moving = None
+        if extra and not args.no_chain and C == 1:
+            cfg_fe = scene.frontend_cfg(p, beam_width=args.beam)
+            starts_np = np.stack([scene.frontend_starts(s_) for s_ in mine])
+            d_st = be.to_device(starts_np)
+            d_gfe = torch.zeros_like(d_guess)
+            d_res = torch.zeros(S * N * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            d_com2 = be.to_device(com); d_nxt = torch.empty_like(d_com2); d_acc = torch.zeros(S * N, dtype=torch.int32, device=dev)
+            fe2, sf2 = [], []
+
+            def chain_step():
+                e0 = ev()
+                be.frontend(cfg_fe, d_com2, d_st, d_gfe, d_res)
+                fe2.append((e0, ev()))
+                be.replan(None, d_gfe)                       # (a failed / empty replan's commit slot carries the record of d_com2 over)
+                e1 = ev()
+                be.safety_commit(d_com2, be.d_commit, d_gfe, d_nxt, d_acc)
+                sf2.append((e1, ev()))
+                d_com2.copy_(d_nxt)
+            dt3, ms3, _ = run_leg(chain_step, [be], aux_steps, max(args.warmup, 2), clear=(fe2, sf2))
+            qp3, _ = be.kernel_time_ms(2); sep3, _ = be.kernel_time_ms(1)
+            be.enable_timing(False)
+            sol3 = be.solutions()
+            res3 = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)
+            chain = leg_record(dt3, aux_steps, ms3,
+                               kernel_ms={"frontend_with_hulls": mean_ms(fe2), "separator": sep3, "qp": qp3, "safety": mean_ms(sf2)},
+                               beam_width=args.beam, frontend_goal_reached=int((res3["status"] == 1).sum()), frontend_no_solution=int((res3["status"] == 3).sum()),
+                               ipm_iters_mean=float(sol3["stats"]["iters"].mean()), ipm_iters_max=int(sol3["stats"]["iters"].max()),
+                               lp_failed=int(sol3["stats"]["n_lp_failed"].sum()), accepted_frac=float(d_acc.float().mean().item()),
+                               solve_us=solve_us_stats(be), terminal_ball_rows=int(sol3["stats"]["qc_active"].sum()),
+                               ipm_iters_quantiles=quantiles(sol3["stats"]["iters"]),
+                               note="front-end beam search -> separating lines -> QP -> safety check + commit, every step; the guesses are the "
+                                    "device-made lattice paths (they end at cruise speed and cut corners around obstacles), not the scene's; "
+                                    "point A stays where it is, so after a few steps every step poses the same problems", **status_counts(sol3))
+
+            # ---- moving: the closed loop on the device.  After the commit, point A of the next round is taken half a second
+            # (T_span: one interval) ahead on every agent's committed trajectory (nep_batch_next_starts) and an agent that has
+            # arrived swaps its goal with its starting point, so the fleets keep flying: every step poses new problems, and the
+            # launch-order key of a slot is the measured time of the SAME AGENT's previous, different replan --------------
+            cfg_mv = scene.frontend_cfg(p, beam_width=args.beam, pad_hold=1)
+            d_st_m = be.to_device(starts_np)
+            alt_np = np.ascontiguousarray(starts_np["pos"].reshape(S * N, 3))          # the way back: where the scene's guess started
+            d_alt = torch.from_numpy(alt_np.copy()).to(dev)
+            d_com3 = be.to_device(com); d_nxt3 = torch.empty_like(d_com3)
+            fe3, sf3 = [], []
+
+            def moving_step():
+                e0 = ev()
+                be.frontend(cfg_mv, d_com3, d_st_m, d_gfe, d_res)
+                fe3.append((e0, ev()))
+                be.replan(None, d_gfe)
+                e1 = ev()
+                be.safety_commit(d_com3, be.d_commit, d_gfe, d_nxt3, d_acc)
+                d_com3.copy_(d_nxt3)
+                be.next_starts(d_com3, p.T_span, d_st_m, d_alt, 0.5)
+                sf3.append((e1, ev()))
+            dt4, ms4, _ = run_leg(moving_step, [be], aux_steps, max(args.warmup, 2), clear=(fe3, sf3))
+            qp4, _ = be.kernel_time_ms(2); sep4, _ = be.kernel_time_ms(1)
+            be.enable_timing(False)
+            sol4 = be.solutions(); res4 = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)
+            st_now = d_st_m.cpu().numpy().view(abi.FE_START_DTYPE)
+            moved = np.hypot(*(st_now["pos"][:, :2] - starts_np.reshape(-1)["pos"][:, :2]).T)
+            swaps = int((np.abs(st_now["goal"] - starts_np.reshape(-1)["goal"]).max(axis=1) > 0).sum())
+            moving = leg_record(dt4, aux_steps, ms4,
+                                kernel_ms={"frontend_with_hulls": mean_ms(fe3), "separator": sep4, "qp": qp4, "safety_commit_next_start": mean_ms(sf3)},
+                                beam_width=args.beam, frontend_goal_reached=int((res4["status"] == 1).sum()), frontend_no_solution=int((res4["status"] == 3).sum()),
+                                ipm_iters_mean=float(sol4["stats"]["iters"].mean()), ipm_iters_max=int(sol4["stats"]["iters"].max()),
+                                lp_failed=int(sol4["stats"]["n_lp_failed"].sum()), accepted_frac=float(d_acc.float().mean().item()),
+                                K_mean=float(sol4["K"].mean()), solve_us=solve_us_stats(be),
+                                terminal_ball_rows=int(sol4["stats"]["qc_active"].sum()), lines_mean=float(sol4["stats"]["n_lines"].mean()),
+                                ipm_iters_quantiles=quantiles(sol4["stats"]["iters"]),
+                                simulated_seconds=float(st_now["t_start"].max() - starts_np["t_start"].max()),
+                                displacement_m_mean=float(moved.mean()), agents_with_swapped_goal=swaps,
+                                note="closed loop on the device, one HIP graph per round: front end -> lines -> QP -> safety check + commit -> point A of "
+                                     "the next round 0.5 s ahead on the committed trajectory; arrived agents turn around.  Every step solves NEW problems; the "
+                                     "launch-order predictor is the same agent's previous replan", **status_counts(sol4))
+
+        # ---- single_scene: ONE fleet -------------------------------------------------------------------------------------
+        single = None
+        if extra:
+            b1 = BatchBackend(p, statics, n_scenes=1, device=dev)
+            d_c1 = b1.to_device(com[0]); d_g1 = b1.to_device(gue[0])
+
+            def single_step():
+                b1.replan(d_c1, d_g1)
+                d_c1.copy_(b1.d_commit)
+            dt5, ms5, _ = run_leg(single_step, [b1], aux_steps, max(args.warmup, 2))
+            k1 = {n_: b1.kernel_time_ms(i_)[0] for i_, n_ in ((0, "hull"), (1, "separator"), (2, "qp"), (3, "sequence"))}
+            b1.enable_timing(False)
+            single = {"value": N * aux_steps / dt5, "unit": "replans/s", "steps": aux_steps, "round_ms": dt5 / aux_steps * 1e3,
+                      "step_ms": {"p50": float(np.percentile(ms5, 50)), "p99": float(np.percentile(ms5, 99)), "max": float(ms5.max())},
+                      "kernel_ms": k1, "solve_us": solve_us_stats(b1),
+                      "note": "one scene of %d agents per launch sequence: the latency of one bulk-synchronous round of a single fleet and that "
+                              "fleet's throughput; `value` at the top keeps %d independent scenes in flight" % (N, S)}
+            b1.close()
+
+    # ---- config5: BASELINE configs[4], 256 agents + 100 obstacles, enable_entangle_check on -------------------------------
+    config5 = None
+    if want_c5 and rank == 0:
+        import dataclasses
+        if c5_pool is not None:                       # (--config5-only)
+            t_c5 = time.perf_counter()
+            c5_made = [f.result() for f in c5_futs]
+            c5_pool.shutdown()
+            c5_wait = time.perf_counter() - t_c5
+        made, t_wait = c5_made, c5_wait
+        S5, N5 = len(made), 256
+        sc5 = [m[0] for m in made]
+        p5 = dataclasses.replace(sc5[0]["par"], enable_entangle=True)
+        b5 = BatchBackend(p5, sc5[0]["statics"], n_scenes=S5, device=dev)
+        for s_ in range(S5):
+            b5.set_scene_statics(s_, sc5[s_]["statics"])
+        com5, gue5 = ndist.stack_scenes(sc5)
+        case5 = np.stack([m[1] for m in made])                       # [S5][N][8][N] int32 (bend points are in the records)
+        d_c5 = b5.to_device(com5); d_g5 = b5.to_device(gue5)
+        d_e5 = torch.from_numpy(np.ascontiguousarray(case5).reshape(-1)).to(dev)
+        bend5 = com5["n_bend"].astype(np.float64)
+
+        # the new trajectories are the next step's obstacles, as in the headline; the tethers' bend points are inputs of the
+        # scene and stay (a committed record as the QP kernel writes it carries the base only): position and polynomial
+        # are copied over, id / flags / bend points are left alone
+        f5 = abi.TRAJ_REC_DTYPE.fields
+        o_pos, o_bend, o_pwp = f5["pos"][1], f5["bend"][1], f5["pwp"][1]
+        REC5 = abi.TRAJ_REC_DTYPE.itemsize
+        v_c5 = d_c5.view(S5 * N5, REC5)
+
+        def c5_step():
+            b5.replan(d_c5, d_g5, d_ent=d_e5)
+            cm = b5.d_commit.view(S5 * N5, REC5)
+            v_c5[:, o_pos:o_bend].copy_(cm[:, o_pos:o_bend])
+            v_c5[:, o_pwp:].copy_(cm[:, o_pwp:])
+
+        def c5_leg(label):
+            dt_, ms_, _ = run_leg(c5_step, [b5], aux_steps if not args.config5_only else args.steps, max(args.warmup, 2), eager_after=10)
+            steps_ = aux_steps if not args.config5_only else args.steps
+            k_ = {n_: b5.kernel_time_ms(i_)[0] for i_, n_ in ((0, "hull"), (1, "separator"), (2, "qp"), (3, "sequence"))}
+            b5.enable_timing(False)
+            s_ = b5.solutions()
+            return dt_, steps_, ms_, k_, s_
+        cull5 = b5.line_cull(); kern5 = b5.qp_kernel_name()
+        dt6, steps6, ms6, k6, sol6 = c5_leg("default")
+        us6 = solve_us_stats(b5)
+        _, hn5 = b5.debug_hulls(0)
+        ns5 = int(sol6[0]["n_states"])
+        ent_b = 4.0 * 8 * N5 + 16.0 * bend5[0].sum()                # the dense case block of one replan + every agent's bend points
+        bytes5 = algorithmic_bytes(p5, sc5[0], hn5, ns5, ent_bytes=ent_b)
+        ach5 = bytes5 * S5 * N5 / (k6["qp"] * 1e-3) / 1e9 if k6["qp"] > 0 else 0.0
+        seq5 = bytes5 * S5 * N5 / (k6["sequence"] * 1e-3) / 1e9 if k6["sequence"] > 0 else 0.0
+        dom = max(("hull", "separator", "qp"), key=lambda n_: k6[n_])
+        dom_name = {"hull": "hull_group_kernel", "separator": "separator_kernel", "qp": kern5}[dom]
+        ach_dom = bytes5 * S5 * N5 / (k6[dom] * 1e-3) / 1e9 if k6[dom] > 0 else 0.0
+        config5 = {"value": S5 * N5 * steps6 / dt6, "unit": "replans/s", "steps": steps6, "ms_per_step": dt6 / steps6 * 1e3,
+                   "step_ms": {"p50": float(np.percentile(ms6, 50)), "p99": float(np.percentile(ms6, 99)), "max": float(ms6.max())},
+                   "workload": "256 agents + 100 static obstacles, enable_entangle_check on (synthetic ent_state: one active case for 10 %% of the agent pairs, "
+                               "2-4 bend points per agent, SURVEY 8d), K=8, %d seeded scenes in flight (seeds 0..%d)" % (S5, S5 - 1),
+                   "replans_per_step": S5 * N5, "qp_kernel": kern5, "line_cull_radius_m": cull5,
+                   "kernel_ms": k6, "solve_us": us6,
+                   "lines_mean": float(sol6["stats"]["n_lines"].mean()), "rows_solved_mean": float(sol6["stats"]["n_rows"].mean()),
+                   "ipm_iters_mean": float(sol6["stats"]["iters"].mean()), "ipm_iters_max": int(sol6["stats"]["iters"].max()),
+                   "solved_without_iteration": int((sol6["stats"]["iters"] == 0).sum()), "lp_failed": int(sol6["stats"]["n_lp_failed"].sum()),
+                   "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach_dom, "peak": 8000.0, "unit": "GB/s", "frac": ach_dom / 8000.0,
+                                "algorithmic_bytes_per_replan": bytes5, "replans_per_launch": S5 * N5, "kernel_ms": k6[dom],
+                                "sequence": {"achieved": seq5, "frac": seq5 / 8000.0, "ms": k6["sequence"]},
+                                "qp_kernel": {"kernel": kern5, "ms": k6["qp"], "achieved": ach5, "frac": ach5 / 8000.0},
+                                "traffic": measured_traffic("nep::" + dom_name, "pmc_summary_config5_latest.txt"),
+                                "traffic_source": "profiles/pmc_summary_config5_latest.txt (committed rocprofv3 --pmc summary of `bench.py --config5-only`)",
+                                "note": "the replan's algorithmic bytes (SURVEY 8d: ~273 KB + the entangle inputs at this size) x replans per launch / the "
+                                        "duration of the DOMINANT kernel of this leg's sequence — here the separator, which reads every other agent's hulls; "
+                                        "`qp_kernel` prices the same bytes against the interior-point kernel as the headline's roofline does"},
+                   "scene_generation_wait_s": t_wait,
+                   "note": "the handle's default for this size: verified line presolve at %.1f m (lines farther from the guess are parked, checked at the "
+                           "solution, re-solved with all rows on a violation), interior point on %s" % (cull5, kern5), **status_counts(sol6)}
+        if not args.config5_only:
+            # every row through the interior point (presolve explicitly off): the LDS placement with its global spill
+            b5.set_line_cull(0.0)
+            kern5f = b5.qp_kernel_name()
+            d_c5.copy_(b5.to_device(com5))
+            dt7, steps7, ms7, k7, sol7 = c5_leg("full_rows")
+            config5["full_rows"] = {"value": S5 * N5 * steps7 / dt7, "unit": "replans/s", "steps": steps7, "ms_per_step": dt7 / steps7 * 1e3,
+                                    "qp_kernel": kern5f, "kernel_ms": k7, "solve_us": solve_us_stats(b5),
+                                    "rows_solved_mean": float(sol7["stats"]["n_rows"].mean()), "ipm_iters_mean": float(sol7["stats"]["iters"].mean()),
+                                    "note": "nep_batch_set_line_cull(0): every separating-line row through the interior point", **status_counts(sol7)}
+        b5.close()
+        if args.config5_only:
+            print(json.dumps({"metric": "backend_replans_per_sec", "config5": config5, "graph_notes": graph_notes}))
+
+    if rank == 0 and not args.config5_only:
         if C == 1 and not sharded_hulls and not args.frontend:
             _, hn = be.debug_hulls(0)          # vertex counts of scene 0 as the last timed launch saw them
         else:
@@ -545,27 +766,30 @@ def main():
         seq_gbs = bytes_per_replan * launch_replans / (seq_ms * 1e-3) / 1e9 if seq_ms > 0 else 0.0
         # active inequality rows at the optimum (scene 0 of the last timed step): which replans are constrained at all
         active = None
-        if C == 1 and not sharded_hulls:
+        if C == 1 and not sharded_hulls and not args.no_extra_legs:
+            be.replan(d_committed, d_guess)            # (the other legs have used the handle's line buckets since)
+            sol_a = be.solutions()
             nb_a, nl_a, n_con = [], [], 0
             for a in range(n_local):
-                Ka = int(sol[a]["K"])
+                Ka = int(sol_a[a]["K"])
                 if Ka < 1:
                     continue
                 seg_a, nd_a = be.debug_lines(a)
-                nb, nl = scene.active_rows(p, np.array(sol[a]["coeff"]), Ka, seg_a, nd_a)
+                nb, nl = scene.active_rows(p, np.array(sol_a[a]["coeff"]), Ka, seg_a, nd_a)
                 nb_a.append(nb); nl_a.append(nl); n_con += 1 if (nb + nl) > 0 else 0
-            active = {"sample": "scene 0, %d replans of the last timed step" % len(nb_a), "replans_with_active_rows_frac": n_con / max(len(nb_a), 1),
+            active = {"sample": "scene 0, %d replans" % len(nb_a), "replans_with_active_rows_frac": n_con / max(len(nb_a), 1),
                       "active_box_rows_mean": float(np.mean(nb_a)), "active_line_rows_mean": float(np.mean(nl_a)), "tol_m": 1e-6}
         flops = algorithmic_flops(K8, float(sol["stats"]["n_lines"].mean()), float(hn[:, :K8][hn[:, :K8] > 0].mean()) if (hn[:, :K8] > 0).any() else 4.0, float(iters.mean()))
         fp64_ach = flops * launch_replans / (qp_ms * 1e-3) / 1e12 if qp_ms > 0 else 0.0
         fp64 = {"bound": "fp64 vector (reported next to the HBM roofline, SURVEY 8d)", "achieved": fp64_ach, "peak": 78.6, "unit": "TFLOP/s",
-                "frac": fp64_ach / 78.6, "algorithmic_flops_per_replan": flops}
+                "frac": fp64_ach / 78.6, "algorithmic_flops_per_replan": flops,
+                "note": "an upper bound: SURVEY 8d's count assumes the dense G'WG product; the kernel's structured assembly over 64 base rows executes fewer"}
         if world == 1:
             sharding = "one GPU: all %d agents of every scene" % N
         elif sharded_hulls:
             sharding = ("agents of every scene block-sharded by id, %d per GPU; per step and scene chunk (%d chunks, pipelined) one all-gather "
-                        "(RCCL) of the interval hulls of the local agents' committed trajectories (%d B per agent and scene)"
-                        % (n_local, C, be.hull_block_bytes() // (Sc * n_local)))
+                        "(RCCL, %s) of the interval hulls of the local agents' committed trajectories (%d B per agent and scene)"
+                        % (n_local, C, "native binding on a side stream inside the captured step" if native else "torch.distributed", be.hull_block_bytes() // (Sc * n_local)))
         else:
             sharding = "agents of every scene block-sharded by id, %d per GPU; per step one all-gather (RCCL) of the committed trajectory records" % n_local
         out = {
@@ -578,6 +802,8 @@ def main():
                        "replans_per_step": replans_per_step, "replans_per_gpu_per_step": S * n_local,
                        "sharding": sharding,
                        "params": "reference neptune_mtlp_benchmark.yaml (T_span 0.5, num_pol 8, weight 1000, v 2, a 3)"},
+            "what_value_is": "throughput of %d INDEPENDENT scenes in flight, every row through the interior point, QP workgroups ordered by the previous "
+                             "step's measured times (exact here: the same problems every step) — see launch_order_off, moving, single_scene" % S,
             "solver": {"status_ok": int((status == 0).sum()), "status_relaxed": int((status == 1).sum()),
                        "status_failed": int((status == 2).sum()), "ipm_iters_mean": float(iters.mean()),
                        "ipm_iters_quantiles": {"p50": float(np.percentile(iters, 50)), "p90": float(np.percentile(iters, 90)),
@@ -590,13 +816,17 @@ def main():
                                          "(solver_gurobi_poly.cpp:483-494).  Round 0 has none (scenes are sampled so that every LP is feasible); "
                                          "later rounds replan the same guesses against the others' optimised trajectories, which may cross them",
                        "active_rows": active},
-            "p50_solve_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),
-            # every replan of a step completes with its batch: the per-replan solve time is the step's GPU time
+            # the per-replan solve time the metric asks for: device time of each replan's interior-point workgroup (nep_stats.solve_us,
+            # last timed step), and the batch view — every replan of a step completes with its batch
+            "solve_us": dict(solve_us, note="device time per replan of the QP workgroup (setup + interior point + outputs); the separator's "
+                                            "%.3f ms per launch is shared by the batch" % sep_ms),
+            "p50_solve_ms": solve_us["p50"] * 1e-3, "p99_solve_ms": solve_us["p99"] * 1e-3,
+            "batch_sequence_ms": seq_ms + (hull_ms if sharded_hulls else 0.0),
             "step_ms": {"p50": float(np.percentile(step_ms, 50)), "p99": float(np.percentile(step_ms, 99)), "max": float(step_ms.max())},
             "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange_wait": mean_ms(gather_ev),
                           "launches": n_launch, "launches_per_step": C},
             "launch": ("one captured HIP graph per step, replayed (per-kernel events from %d eager steps after the timed region)" % min(args.steps, 40)
-                       if graph is not None else (graph_note or "host launches")),
+                       if graph is not None else ("; ".join(graph_notes) or "host launches")),
             "frontend": ({"ms": mean_ms(fe_ev), "beam_width": args.beam,
                           "status_goal_reached": int((d_fe_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)["status"] == 1).sum()),
                           "status_no_solution": int((d_fe_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)["status"] == 3).sum()),
@@ -606,8 +836,9 @@ def main():
                        if args.safety else None),
             "roofline": {"bound": "hbm", "kernel": be.qp_kernel_name(), "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0,
-                         # the committed PMC summary is of the default single-GPU command (8 192 replans per launch)
+                         # the committed PMC summary is of the default single-GPU command (8 192 replans per launch): a replay of that file
                          "traffic": measured_traffic("nep::" + be.qp_kernel_name()) if launch_replans == 8192 else None,
+                         "traffic_source": "profiles/pmc_summary_latest.txt (committed rocprofv3 --pmc summary of this command; counters cannot be read in-process)",
                          "algorithmic_bytes_per_replan": bytes_per_replan, "replans_per_launch": launch_replans,
                          "sequence": {"achieved": seq_gbs, "frac": seq_gbs / 8000.0, "ms": seq_ms,
                                       "note": "the whole replan's bytes over the whole launch sequence (hull + separator + qp)"},
@@ -616,14 +847,23 @@ def main():
                                  "contract defines it; most of those bytes (other agents' hull vertices) are read by separator_kernel: per_kernel "
                                  "gives each kernel's own bytes over its own time.  Latency-bound path: ~%d dependent interior-point "
                                  "iterations per replan" % round(float(iters.mean()))},
+            "long_run": long_run,
+            "launch_order_off": order_off,
             "presolve": presolve,
             "chain": chain,
-            "rccl": ({"process_group": "nccl (RCCL), world %d" % world, "initialised": True, "one_rank_all_gather_matches": rccl_one_rank_ok}
+            "moving": moving,
+            "single_scene": single,
+            "config5": config5,
+            "rccl": ({"process_group": "nccl (RCCL), world %d" % world, "initialised": True, "one_rank_all_gather_matches": rccl_one_rank_ok,
+                      "nranks": nranks, "exchange": ("native (nep_batch_exchange_hulls: ncclAllGather inside the captured step)" if native else
+                                                     ("torch.distributed" if world > 1 else "none (one rank)"))}
                      if (use_dist and dist_backend == "nccl")
                      else {"initialised": False, "note": rccl_note or dist_backend}),
             "roofline_fp64": fp64,
             "reference_budget": "reference TimeLimit 0.05 s/solve, replan timer 20 Hz/agent => <= %d replans/s for %d agents" % (20 * N, N),
         }
+        if graph_notes:
+            out["graph_notes"] = graph_notes
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(p, mine)
         print(json.dumps(out))

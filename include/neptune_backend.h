@@ -176,6 +176,15 @@ int nep_backend_debug_get_lines(nep_backend_t* h, int32_t cap, int32_t* seg, dou
 /* Stand-alone kernels of the path (batched, host buffers): used by the parity tests           */
 /* ------------------------------------------------------------------------------------------ */
 
+/* Neptune::setStaticObst (neptune.cpp:639-664), the one-time host step in front of setStaticObstVert: every vertex of
+ * footprint j (CSR vert_off / xy, as nep_backend_set_static_obst_vert takes them) is pushed out by
+ * safe_dist = 2 drone_radius + 0.2 to four corners and the convex hull of those (cu::convexHullOfPoints2d,
+ * cgal_utils.cpp:157-174: counter-clockwise from the lexicographically smallest point, collinear points dropped) is written
+ * to out_off [n_obst + 1] / out_xy [cap][2] — what nep_backend_set_static_obst_vert / nep_batch_cfg expect.  Host only (no
+ * HIP call, as in the reference).  Returns the number of vertices written, NEP_E_CAP when cap or NEP_HULL_MAX_V is exceeded. */
+int nep_inflate_static(int32_t n_obst, const int32_t* vert_off, const double* xy, double drone_radius,
+                       int32_t* out_off, double* out_xy, int32_t cap);
+
 /* Separator::solveModel 2-D, 2-set (separator_glpk.cpp:248-373), batched: problem p has point
  * set A = a_xy[a_off[p]..a_off[p+1]) and B = b_xy[b_off[p]..b_off[p+1]).  nd_out[p] = (n1,n2,d),
  * solved_out[p] = 1/0.  The 3-set overload (:375-498) is the same LP with A := A u A+.  As at
@@ -184,6 +193,10 @@ int nep_backend_debug_get_lines(nep_backend_t* h, int32_t cap, int32_t* seg, dou
 int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy,
                         const int32_t* b_off, const double* b_xy, double* nd_out,
                         int32_t* solved_out);
+/* The same with the vertex rule named (see nep_batch_set_separator_rule): 0 = nep_separator_batch, 1 = GLPK-class simplex. */
+int nep_separator_batch_rule(int32_t rule, int32_t n_prob, const int32_t* a_off, const double* a_xy,
+                             const int32_t* b_off, const double* b_xy, double* nd_out,
+                             int32_t* solved_out);
 
 /* Batched gjk::collision(vertices1, vertices2) (gjk.cpp:76-149) with vertices1 = polygon p of the CSR
  * (a_off, a_xy) and vertices2 = the four points b_xy[p][4][2] — the call shape of the safety check
@@ -303,11 +316,14 @@ int nep_batch_replan_hulls(nep_batch_t* h, const void* d_blocks, int32_t n_block
  *   nep_batch_exchange_records  d_commit_local [n_scenes][n_local] (nep_batch_replan's d_commit) ->
  *                               d_committed_all [n_scenes][N]: the literal "all-gather of committed trajectories"
  * Both are asynchronous on `stream`; a round is  nep_batch_hulls -> nep_batch_exchange_hulls ->
- * nep_batch_replan_hulls  (or  nep_batch_replan -> nep_batch_exchange_records).                                */
+ * nep_batch_replan_hulls  (or  nep_batch_replan -> nep_batch_exchange_records).  Being plain enqueues on the caller's
+ * stream, they can be captured into a HIP graph together with the kernels around them (RCCL collectives are capturable):
+ * bench.py captures the whole per-rank step, exchange included, and replays it.                                  */
 typedef struct nep_comm nep_comm_t;
 int nep_comm_unique_id(uint8_t id_out[128]);
 nep_comm_t* nep_comm_create(const uint8_t id[128], int32_t world, int32_t rank);
 void nep_comm_destroy(nep_comm_t* c);
+int nep_comm_nranks(nep_comm_t* c);                /* ranks that joined (ncclCommCount), or < 0 */
 int nep_batch_exchange_hulls(nep_batch_t* h, nep_comm_t* c, const void* d_block, void* d_blocks, void* stream);
 int nep_batch_exchange_records(nep_batch_t* h, nep_comm_t* c, const nep_traj_rec* d_commit_local,
                                nep_traj_rec* d_committed_all, void* stream);
@@ -339,17 +355,37 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
  * QP; after the solve every left-out line is checked against the solution's control points and, if one is
  * violated, the replan is solved again with all lines — the optimum is that of the full problem (what a QP
  * presolve does with redundant rows; Gurobi runs one inside PolySolverGurobi::optimize).  nep_stats.n_lines
- * still counts every line, n_rows the rows actually solved for.  The debug line readers see the buckets
- * reordered (near lines first).
+ * still counts every line, n_rows the rows actually solved for.  The debug line readers return, per segment,
+ * the near lines in call order followed by the parked ones in call order.
  * The presolve also tries the minimiser of the cost without any inequality row (one small matrix-vector product
  * with a host-built inverse): if every box row, every line and the terminal ball hold there, that point with zero
  * multipliers satisfies the KKT conditions of the full problem and is returned as the optimum without a single
- * interior-point iteration (nep_stats.iters == 0); otherwise the interior point runs as usual.                */
+ * interior-point iteration (nep_stats.iters == 0); otherwise the interior point runs as usual.
+ * Default: off (radius 0) for scenes whose expected lines per segment fit the register slots of the interior-point kernel
+ * (BASELINE configs 1-4); ON with radius 4 m for bigger scenes (config 5: 256 agents + 100 obstacles, ~260 lines per segment,
+ * of which a few dozen are near) — the near lines then fit the register-resident placement, the parked ones are verified,
+ * and the optimum is still that of the full problem.  An explicit call (any radius, 0 included) overrides the default;
+ * nep_batch_get_line_cull returns the radius in force.                                                             */
 int nep_batch_set_line_cull(nep_batch_t* h, double radius);
+double nep_batch_get_line_cull(nep_batch_t* h);
+
+/* Which vertex of the separating-line LP the separator returns.  The LP (separator_glpk.cpp:248-373) has a zero objective:
+ * the reference gets "whatever vertex glp_simplex reaches", and the spline QP's optimum depends on it.
+ *   0 (default)  the vertex with the largest geometric gap between the two point sets — a rule that depends on the LP only;
+ *   1            the vertex a primal simplex of the class glp_simplex runs by default reaches: standard start basis (row
+ *                variables basic, n1 = n2 = d = 0 non-basic), projected steepest-edge pricing, Harris' two-pass ratio test,
+ *                tol_bnd = tol_dj = 1e-7, no presolve, no scaling (glp_init_smcp defaults, separator_glpk.cpp:39-41, 336).
+ *                GLPK 4.65's source is not in the reference tree, so this is the documented algorithm class, not a clone of
+ *                GLPK's pivot sequence; for callers who want simplex-reached lines.
+ * Both return a point that satisfies every row of the reference LP, or "no line" (the constraint is then skipped,
+ * solver_gurobi_poly.cpp:483-494).  Bit-identical to oracle/'s restatement of either rule.                           */
+int nep_batch_set_separator_rule(nep_batch_t* h, int32_t rule);
+int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule);
 
 /* Which placement of the interior point the handle runs: 1 = qp_reg_kernel (line-row state in registers, four workgroups
- * per CU: chosen when the expected lines per segment fit its register slots, e.g. BASELINE configs 1-4), 0 = qp_kernel
- * (row state in LDS with a global spill: config-5 sized problems).  Same solver, same results to rounding.             */
+ * per CU: chosen when the expected lines per segment fit its register slots, e.g. BASELINE configs 1-4, or when the line
+ * presolve is on — config 5 by default), 0 = qp_kernel (row state in LDS with a global spill: config-5 sized problems
+ * with the presolve explicitly turned off).  Same solver, same results to rounding.                                    */
 int nep_batch_qp_placement(nep_batch_t* h);
 
 /* Launch order of the interior-point workgroups (a scheduling matter: results do not depend on it).  A batch of more than

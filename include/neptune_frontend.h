@@ -157,6 +157,19 @@ int nep_batch_safety_commit_ent(nep_batch_t* h, const nep_traj_rec* d_prev, cons
                                 const nep_fe_ent_state* d_ent_init, int32_t ent_samples, double cable_length,
                                 nep_traj_rec* d_final, int32_t* d_accept, void* stream);
 
+/* Point A of the NEXT round for every slot, on the device: d_start[slot].t_start advances by dt and pos / vel / accel become
+ * the state of the agent's committed trajectory (d_records [n_scenes][N], e.g. nep_batch_safety_commit's d_final) at that
+ * time — Neptune::replanFull's choice of A "deltaT ahead on the committed plan" (neptune.cpp:1366-1399) for a
+ * bulk-synchronous loop in which every agent replans from the same clock.  Evaluated like generatePwpOut's samples
+ * (solver_gurobi_poly.cpp:921-929); beyond the trajectory's last knot the vehicle rests at its end point; an agent without a
+ * valid record keeps its state.  The goal is left alone unless d_alt_goal ([slots][3], may be NULL) is given: then an agent
+ * that has arrived (within switch_radius of its goal, slower than 0.05 m/s) swaps goal and alternate goal, so that a fleet
+ * keeps flying back and forth (what bench.py's `moving` leg runs).  Asynchronous on `stream`; with it a whole round
+ * (front end -> lines + QP -> safety check + commit -> next point A) is a fixed launch sequence on fixed buffers, i.e. one
+ * HIP graph.                                                                                                          */
+int nep_batch_next_starts(nep_batch_t* h, const nep_traj_rec* d_records, double dt, nep_fe_start* d_start,
+                          double* d_alt_goal, double switch_radius, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

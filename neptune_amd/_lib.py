@@ -20,8 +20,8 @@ EXPORTS = [
     "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
     "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
     "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_gjk_batch",
-    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy",
-    "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records", "nep_batch_set_max_runtime", "nep_batch_qp_placement", "nep_batch_set_launch_order", "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel",
+    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks",
+    "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records", "nep_batch_set_max_runtime", "nep_batch_qp_placement", "nep_batch_set_launch_order", "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_get_line_cull", "nep_inflate_static", "nep_separator_batch_rule", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
@@ -31,7 +31,7 @@ PLAN_EXPORTS = [
 ]
 # every symbol include/neptune_entangle.h declares (host-only)
 # include/neptune_frontend.h
-FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_frontend_ent", "nep_batch_safety_commit_ent"]
+FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_frontend_ent", "nep_batch_safety_commit_ent", "nep_batch_next_starts"]
 ENT_EXPORTS = ["nep_ent_sample_points", "nep_ent_propagate_segment", "nep_ent_propagate_guess", "nep_ent_case_ids"]
 
 
@@ -68,6 +68,10 @@ def lib():
     L.nep_backend_debug_set_lines.argtypes = [vp, i, pi, pd]
     L.nep_backend_debug_get_lines.argtypes = [vp, i, pi, pd, pi]
     L.nep_separator_batch.argtypes = [i, pi, pd, pi, pd, pd, pi]
+    L.nep_inflate_static.argtypes = [i, pi, pd, d, pi, pd, i]
+    L.nep_separator_batch_rule.argtypes = [i, i, pi, pd, pi, pd, pd, pi]
+    L.nep_batch_set_separator_rule.argtypes = [vp, i]
+    L.nep_backend_set_separator_rule.argtypes = [vp, i]
     L.nep_gjk_batch.argtypes = [i, pi, pd, pd, pi]
     L.nep_hulls_batch.argtypes = [i, vp, d, i, d, d, pd, pi, pd, pi]
     L.nep_batch_create.argtypes = [C.POINTER(abi.nep_batch_cfg)]; L.nep_batch_create.restype = vp
@@ -85,6 +89,7 @@ def lib():
     L.nep_batch_debug_conflicts.argtypes = [vp, i, C.POINTER(C.c_uint8)]
     L.nep_batch_set_safety_check_prev.argtypes = [vp, i]
     L.nep_batch_set_line_cull.argtypes = [vp, d]
+    L.nep_batch_get_line_cull.argtypes = [vp]; L.nep_batch_get_line_cull.restype = d
     L.nep_batch_set_max_runtime.argtypes = [vp, d]
     L.nep_batch_qp_placement.argtypes = [vp]
     L.nep_batch_set_launch_order.argtypes = [vp, i]
@@ -95,6 +100,7 @@ def lib():
     L.nep_comm_unique_id.argtypes = [C.POINTER(C.c_uint8)]
     L.nep_comm_create.argtypes = [C.POINTER(C.c_uint8), i, i]; L.nep_comm_create.restype = vp
     L.nep_comm_destroy.argtypes = [vp]; L.nep_comm_destroy.restype = None
+    L.nep_comm_nranks.argtypes = [vp]
     L.nep_batch_exchange_hulls.argtypes = [vp, vp, vp, vp, vp]
     L.nep_batch_exchange_records.argtypes = [vp, vp, vp, vp, vp]
     L.nep_debug_regroup_records.argtypes = [vp, vp, i, i, i, vp]
@@ -128,6 +134,7 @@ def lib():
     L.nep_batch_set_static_reps.argtypes = [vp, i, pd, pd]
     L.nep_batch_frontend_ent.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, vp, vp, vp, vp, vp, vp]
     L.nep_batch_safety_commit_ent.argtypes = [vp, vp, vp, vp, vp, i, d, vp, vp, vp]
+    L.nep_batch_next_starts.argtypes = [vp, vp, d, vp, vp, d, vp]
     _lib = L
     return L
 

@@ -60,6 +60,10 @@ class PolySolver:
     def setMaxValues(self, x_min, x_max, y_min, y_max, z_min, z_max, v_max, a_max, j_max):
         check(lib().nep_backend_set_max_values(self._h, x_min, x_max, y_min, y_max, z_min, z_max, v_max, a_max, j_max))
 
+    def setSeparatorRule(self, rule):
+        """not in the reference: which LP vertex the separator returns (nep_backend_set_separator_rule)"""
+        check(lib().nep_backend_set_separator_rule(self._h, int(rule)))
+
     def setMaxRuntime(self, runtime):
         check(lib().nep_backend_set_max_runtime(self._h, runtime))
 
@@ -152,12 +156,13 @@ class PolySolver:
         return seg[:n.value].copy(), nd[:n.value].copy()
 
 
-def separator_batch(As, Bs):
-    """Batched separator::Separator::solveModel (2-D).  As/Bs: lists of (n,2) arrays."""
+def separator_batch(As, Bs, rule=0):
+    """Batched separator::Separator::solveModel (2-D).  As/Bs: lists of (n,2) arrays.  rule: which LP vertex is returned
+    (0 largest gap, 1 GLPK-class simplex: nep_batch_set_separator_rule)."""
     aoff, axy = _csr(As); boff, bxy = _csr(Bs)
     n = len(As)
     nd = np.zeros((n, 3)); ok = np.zeros(n, dtype=np.int32)
-    check(lib().nep_separator_batch(n, abi.iptr(aoff), abi.dptr(axy), abi.iptr(boff), abi.dptr(bxy), abi.dptr(nd), abi.iptr(ok)))
+    check(lib().nep_separator_batch_rule(int(rule), n, abi.iptr(aoff), abi.dptr(axy), abi.iptr(boff), abi.dptr(bxy), abi.dptr(nd), abi.iptr(ok)))
     return ok.astype(bool), nd
 
 
@@ -283,6 +288,14 @@ class BatchBackend:
                                                 d_ent_init.data_ptr() if d_ent_init is not None else None, ent_samples, float(cable),
                                                 d_final.data_ptr(), d_accept.data_ptr() if d_accept is not None else None, st.cuda_stream))
 
+    def next_starts(self, d_records, dt, d_start, d_alt_goal=None, switch_radius=0.0, stream=None):
+        """point A of the next round on the device: d_start's clock advances by dt and its state becomes that of the committed
+        trajectories d_records at the new time; with d_alt_goal ([slots][3] float64) arrived agents swap goals
+        (nep_batch_next_starts)"""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_next_starts(self._h, d_records.data_ptr(), float(dt), d_start.data_ptr(),
+                                          d_alt_goal.data_ptr() if d_alt_goal is not None else None, float(switch_radius), st.cuda_stream))
+
     def safety_commit(self, d_prev, d_new, d_guess, d_final, d_accept=None, stream=None):
         """Post-solve safety check + commit (nep_batch_safety_commit); tensors are device byte/int32 tensors."""
         st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
@@ -326,6 +339,15 @@ class BatchBackend:
         afterwards, and a replan whose unconstrained minimiser is feasible returns it without iterating
         (nep_batch_set_line_cull); 0 turns it off"""
         check(lib().nep_batch_set_line_cull(self._h, float(radius)))
+
+    def line_cull(self):
+        """the presolve radius in force (0: off): nep_batch_get_line_cull — on by default for config-5 sized scenes"""
+        return float(lib().nep_batch_get_line_cull(self._h))
+
+    def set_separator_rule(self, rule):
+        """which vertex of the separating-line LP is returned: 0 largest gap (default), 1 the one a primal simplex of GLPK's
+        default class reaches (nep_batch_set_separator_rule)"""
+        check(lib().nep_batch_set_separator_rule(self._h, int(rule)))
 
     def set_safety_check_prev(self, on=True):
         """also turn down new trajectories that collide with another agent's PREVIOUS record (nep_batch_set_safety_check_prev)"""

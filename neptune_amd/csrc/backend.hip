@@ -122,6 +122,15 @@ struct Engine {
     sched_dc = dc; sched_cap = cap; sp.max_states = cap; sp.dc = dc;
     return 0;
   }
+  // which interior-point kernel the next replan launches, and its LDS carve (see size_scratch)
+  static constexpr double kAutoCullRadius = 4.0;
+  bool fits_reg = true, cull_user_set = false; int lds_lines_lds = 0;
+  void choose_placement() {
+    use_reg = fits_reg || sp.cull_radius > 0.0;
+    if (const char* f = getenv("NEP_QP_KERNEL")) { if (!strcmp(f, "reg")) use_reg = true; else if (!strcmp(f, "lds")) use_reg = false; }
+    if (use_reg) { lds_lines = NEP_MAX_POL * 8 * qp_reg_slots(); lds_rows = 4 * lds_lines; lds_bytes = qp_reg_lds_bytes(); }
+    else { lds_lines = lds_lines_lds; lds_rows = 4 * lds_lines; lds_bytes = qp_lds_fixed_bytes() + (size_t)(lds_lines + 2) * 11 * 8; }   // + the dummy line of the padded row groups
+  }
   // sizes the scratch for (n_scenes x n_local) slots with sp.n_hull hull lists per scene
   int size_scratch() {
     const int N = sp.num_agents, np = sp.num_pol;
@@ -142,19 +151,23 @@ struct Engine {
     const long expect = (long)NEP_MAX_POL * (sp.n_hull + 4 + sp.n_static / 8 + (sp.ent_enabled ? sp.num_agents / 8 : 0));
     long ll = expect <= l_half ? l_half : l_full;
     if (ll > lines_total) ll = lines_total;
-    lds_lines = (int)((ll + 1) & ~1L);
-    lds_rows = 4 * lds_lines;
-    lds_bytes = fixed + (size_t)(lds_lines + 2) * per_line;   // + the dummy line of the padded row groups
+    lds_lines_lds = (int)((ll + 1) & ~1L);
     // Placement of the row state.  When the expected lines per segment fit the register slots of qp_reg_kernel (8 per slot;
-    // a few more only cost a trip through the global scratch) and the expected total fits its coefficient carve, the row
-    // state lives in registers and four workgroups share a CU; bigger problems (config 5: ~250 lines per segment) keep
-    // the LDS placement of qp_kernel.  NEP_QP_KERNEL=reg|lds overrides the choice (tests).
-    const long expect_seg = expect / NEP_MAX_POL;
-    use_reg = expect_seg <= 8L * qp_reg_slots() + 8;
+    // a few more only cost a trip through the global scratch) the row state lives in registers and four workgroups share a
+    // CU.  Bigger problems (config 5: ~260 lines per segment) get the verified line presolve by default (kAutoCullRadius,
+    // nep_batch_set_line_cull): the few dozen near lines fit the register slots, the parked ones are checked at the solution,
+    // and only a replan that violates one is solved again with every row, the rows beyond the slots going through the per-slot
+    // global scratch.  With the presolve turned off (radius 0) such problems keep the LDS placement of qp_kernel.
+    // NEP_QP_KERNEL=reg|lds overrides the choice (tests, A/B).
+    fits_reg = expect / NEP_MAX_POL <= 8L * qp_reg_slots() + 8;
+    if (!cull_user_set) {
+      bool auto_cull = !fits_reg;
+      if (const char* f = getenv("NEP_QP_AUTOCULL")) auto_cull = auto_cull && atoi(f) != 0;
+      sp.cull_radius = auto_cull ? kAutoCullRadius : 0.0;
+    }
     if (const char* f = getenv("NEP_QP_LPT")) lpt = atoi(f) != 0;
     if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; if (int e = d_order_key.ensure((size_t)slots)) return e; }
-    if (const char* f = getenv("NEP_QP_KERNEL")) { if (!strcmp(f, "reg")) use_reg = true; else if (!strcmp(f, "lds")) use_reg = false; }
-    if (use_reg) { lds_lines = NEP_MAX_POL * 8 * qp_reg_slots(); lds_rows = 4 * lds_lines; lds_bytes = qp_reg_lds_bytes(); }
+    choose_placement();
     rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
     if (int e = d_hull_xy.ensure((size_t)n_scenes * sp.n_hull * np * kHullV * 2)) return e;
     if (int e = d_fe_box.ensure((size_t)n_scenes * (N + (sp.n_static > 0 ? sp.n_static : 0)) * np * 4)) return e;
@@ -170,8 +183,7 @@ struct Engine {
     if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 16)) return e; }
-    if (lines_total > lds_lines || use_reg) { if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e; }
-    else d_row_scratch.release();
+    if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e;     // (either placement may end up using it: see choose_placement)
     return 0;
   }
   void fill(ProblemSet& ps) {
@@ -315,6 +327,27 @@ __global__ void sample_kernel(const nep_solution* __restrict__ sol, int K, const
     st[6 + ax] = c[0] * (6 * d) + c[1] * 2;
     st[9 + ax] = c[0] * 6;
   }
+}
+
+// Test hook behind both debug line readers: the lines of one slot in row order — per segment the lines at the front of the
+// bucket (all of them, or with the presolve on the near ones) and then the parked far ones, which the separator writes from
+// the back of the bucket in order of appearance.  LPs without a separating line left (0, 0, 0) and are skipped.
+int read_lines(Engine& E, size_t slot, int n_seg, int32_t cap, int32_t* seg, double* nd, int32_t* n_out) {
+  std::vector<int> cnt(NEP_MAX_POL), far(NEP_MAX_POL, 0); std::vector<double> buf((size_t)NEP_MAX_POL * E.sp.lines_cap * 3);
+  HIPCHK(hipMemcpy(cnt.data(), E.d_line_cnt.p + slot * NEP_MAX_POL, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
+  if (E.sp.cull_radius > 0.0) HIPCHK(hipMemcpy(far.data(), E.d_line_far.p + slot * NEP_MAX_POL, far.size() * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(buf.data(), E.d_line_nd.p + slot * NEP_MAX_POL * E.sp.lines_cap * 3, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  int n = 0;
+  for (int s = 0; s < n_seg && s < NEP_MAX_POL; s++)
+    for (int c = 0; c < cnt[s] + far[s]; c++) {
+      const size_t q = c < cnt[s] ? (size_t)c : (size_t)E.sp.lines_cap - 1 - (size_t)(c - cnt[s]);
+      const double* e = &buf[((size_t)s * E.sp.lines_cap + q) * 3];
+      if (e[0] == 0.0 && e[1] == 0.0 && e[2] == 0.0) continue;   // LP without a separating line
+      if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = e[k]; }
+      n++;
+    }
+  *n_out = n;
+  return 0;
 }
 
 }  // namespace
@@ -562,24 +595,15 @@ int nep_backend_get_stats(nep_backend_t* h, nep_stats* out) { if (!h || !out) re
 
 int nep_backend_debug_get_lines(nep_backend_t* h, int32_t cap, int32_t* seg, double* nd, int32_t* n_out) {
   if (!h || !n_out) return fail(NEP_E_ARG, "null argument");
-  Engine& E = h->eng;
-  std::vector<int> cnt(NEP_MAX_POL); std::vector<double> buf((size_t)NEP_MAX_POL * E.sp.lines_cap * 3);
-  HIPCHK(hipMemcpy(cnt.data(), E.d_line_cnt.p, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(buf.data(), E.d_line_nd.p, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
-  int n = 0;
-  for (int s = 0; s < h->guess.K; s++) for (int c = 0; c < cnt[s]; c++) {
-    const double* e = &buf[((size_t)s * E.sp.lines_cap + c) * 3];
-    if (e[0] == 0.0 && e[1] == 0.0 && e[2] == 0.0) continue;   // LP without a separating line
-    if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
-  *n_out = n;
-  return 0;
+  return read_lines(h->eng, 0, h->guess.K, cap, seg, nd, n_out);
 }
 
 // =================================================================================================
 // stand-alone kernels
 // =================================================================================================
-int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy, const int32_t* b_off, const double* b_xy,
-                        double* nd_out, int32_t* solved_out) {
+int nep_separator_batch_rule(int32_t rule, int32_t n_prob, const int32_t* a_off, const double* a_xy, const int32_t* b_off, const double* b_xy,
+                             double* nd_out, int32_t* solved_out) {
+  if (rule != 0 && rule != 1) return fail(NEP_E_ARG, "separator rule: 0 largest gap, 1 GLPK-class simplex");
   if (n_prob < 0 || !a_off || !b_off || !nd_out || !solved_out) return fail(NEP_E_ARG, "bad arguments");
   if (!have_device()) return fail(NEP_E_HIP, "no HIP device: the back end has no CPU path");
   if (n_prob == 0) return 0;
@@ -595,12 +619,17 @@ int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy
   HIPCHK(hipMemcpy(db.p, b_off, (n_prob + 1) * sizeof(int), hipMemcpyHostToDevice));
   if (na) HIPCHK(hipMemcpy(dax.p, a_xy, (size_t)2 * na * sizeof(double), hipMemcpyHostToDevice));
   if (nb) HIPCHK(hipMemcpy(dbx.p, b_xy, (size_t)2 * nb * sizeof(double), hipMemcpyHostToDevice));
-  launch_separator_explicit(n_prob, da.p, dax.p, db.p, dbx.p, dnd.p, ds.p, nullptr);
+  launch_separator_explicit(n_prob, da.p, dax.p, db.p, dbx.p, dnd.p, ds.p, rule, nullptr);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(nd_out, dnd.p, (size_t)3 * n_prob * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(solved_out, ds.p, (size_t)n_prob * sizeof(int), hipMemcpyDeviceToHost));
   da.release(); db.release(); ds.release(); dax.release(); dbx.release(); dnd.release();
   return 0;
+}
+
+int nep_separator_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy, const int32_t* b_off, const double* b_xy,
+                        double* nd_out, int32_t* solved_out) {
+  return nep_separator_batch_rule(0, n_prob, a_off, a_xy, b_off, b_xy, nd_out, solved_out);
 }
 
 int nep_gjk_batch(int32_t n_prob, const int32_t* a_off, const double* a_xy, const double* b_xy, int32_t* hit_out) {
@@ -909,6 +938,14 @@ int nep_batch_safety_commit_ent(nep_batch_t* h, const nep_traj_rec* d_prev, cons
   return 0;
 }
 
+int nep_batch_next_starts(nep_batch_t* h, const nep_traj_rec* d_records, double dt, nep_fe_start* d_start, double* d_alt_goal,
+                          double switch_radius, void* stream) {
+  if (!h || !d_records || !d_start || !(dt >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
+  launch_next_starts(d_records, h->cfg.n_scenes, h->cfg.num_agents, h->cfg.first_local, h->cfg.n_local, dt, d_start, d_alt_goal, switch_radius, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static, const int32_t* static_off, const double* static_xy) {
   if (!h || scene < 0 || scene >= h->cfg.n_scenes || n_static < 0 || (n_static > 0 && (!static_off || !static_xy))) return fail(NEP_E_ARG, "bad arguments");
   HIPCHK(hipDeviceSynchronize());     // the previous set may still be read by kernels in flight
@@ -949,7 +986,20 @@ int nep_batch_set_max_runtime(nep_batch_t* h, double seconds) {
 
 int nep_batch_set_line_cull(nep_batch_t* h, double radius) {
   if (!h || !(radius >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
-  h->eng.sp.cull_radius = radius;
+  h->eng.sp.cull_radius = radius; h->eng.cull_user_set = true;
+  h->eng.choose_placement();      // (a culled problem's near lines fit the register kernel whatever the scene size)
+  return 0;
+}
+double nep_batch_get_line_cull(nep_batch_t* h) { return h ? h->eng.sp.cull_radius : -1.0; }
+
+int nep_batch_set_separator_rule(nep_batch_t* h, int32_t rule) {
+  if (!h || (rule != 0 && rule != 1)) return fail(NEP_E_ARG, "separator rule: 0 largest gap, 1 GLPK-class simplex");
+  h->eng.sp.sep_rule = rule;
+  return 0;
+}
+int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule) {
+  if (!h || (rule != 0 && rule != 1)) return fail(NEP_E_ARG, "separator rule: 0 largest gap, 1 GLPK-class simplex");
+  h->eng.sp.sep_rule = rule;
   return 0;
 }
 
@@ -1012,17 +1062,8 @@ int nep_batch_debug_hulls(nep_batch_t* h, int32_t scene, double* hull_xy, int32_
 int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* seg, double* nd, int32_t* n_out) {
   if (!h || !n_out || slot < 0 || slot >= h->slots) return fail(NEP_E_ARG, "bad arguments");
   Engine& E = h->eng;
-  std::vector<int> cnt(NEP_MAX_POL); std::vector<double> buf((size_t)NEP_MAX_POL * E.sp.lines_cap * 3);
   HIPCHK(hipDeviceSynchronize());
-  HIPCHK(hipMemcpy(cnt.data(), E.d_line_cnt.p + (size_t)slot * NEP_MAX_POL, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(buf.data(), E.d_line_nd.p + (size_t)slot * NEP_MAX_POL * E.sp.lines_cap * 3, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
-  int n = 0;
-  for (int s = 0; s < NEP_MAX_POL; s++) for (int c = 0; c < cnt[s]; c++) {
-    const double* e = &buf[((size_t)s * E.sp.lines_cap + c) * 3];
-    if (e[0] == 0.0 && e[1] == 0.0 && e[2] == 0.0) continue;   // LP without a separating line
-    if (n < cap) { seg[n] = s; for (int k = 0; k < 3; k++) nd[3 * n + k] = buf[((size_t)s * E.sp.lines_cap + c) * 3 + k]; } n++; }
-  *n_out = n;
-  return 0;
+  return read_lines(E, (size_t)slot, NEP_MAX_POL, cap, seg, nd, n_out);
 }
 
 // development aid: per-phase shader cycles of the QP kernel (only with NEP_QP_PROFILE set at create)

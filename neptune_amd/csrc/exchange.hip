@@ -30,6 +30,7 @@ struct Rccl {
   decltype(&ncclCommInitRank) CommInitRank = nullptr;
   decltype(&ncclCommDestroy) CommDestroy = nullptr;
   decltype(&ncclAllGather) AllGather = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
   std::string err;
   bool load() {
@@ -45,8 +46,9 @@ struct Rccl {
     CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
     AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
+    CommCount = (decltype(CommCount))dlsym(lib, "ncclCommCount");
     GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !GetErrorString) { err = "librccl.so lacks an expected symbol"; dlclose(lib); lib = nullptr; return false; }
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather || !CommCount || !GetErrorString) { err = "librccl.so lacks an expected symbol"; dlclose(lib); lib = nullptr; return false; }
     return true;
   }
 };
@@ -99,6 +101,14 @@ nep_comm_t* nep_comm_create(const uint8_t id[128], int32_t world, int32_t rank) 
   const ncclResult_t r = g_rccl.CommInitRank(&c->comm, world, uid, rank);     // on the calling thread's current HIP device
   if (r != ncclSuccess) { fail_nccl("ncclCommInitRank", r); delete c; return nullptr; }
   return c;
+}
+
+int nep_comm_nranks(nep_comm_t* c) {
+  if (!c || !c->comm) { nep::set_last_error("null communicator"); return NEP_E_ARG; }
+  int n = 0;
+  const ncclResult_t r = g_rccl.CommCount(c->comm, &n);
+  if (r != ncclSuccess) return fail_nccl("ncclCommCount", r);
+  return n;
 }
 
 void nep_comm_destroy(nep_comm_t* c) {

@@ -555,6 +555,115 @@ constexpr int kSepLdsTarget = NEP_SEP_LDS;
 // Candidate c of segment seg, in the reference's loop order (solver_gurobi_poly.cpp:477-495 agents,
 // :521-553 bases, :556-593 statics, :620-637 entangle): does the reference call the separator for
 // it, and (stage == true) what is point set A.
+
+// ---- separator rule 1: a primal simplex of the class GLPK's glp_simplex runs by default (nep_batch_set_separator_rule) ----
+// The reference's separator hands its LP to glp_simplex with glp_init_smcp's defaults (separator_glpk.cpp:39-41, 336): primal
+// simplex, projected steepest-edge pricing, Harris' two-pass ratio test, tol_bnd = tol_dj = 1e-7, no presolve, no scaling,
+// from the standard basis (every row variable basic, the free structurals n1, n2, d non-basic at zero).  This is that
+// documented algorithm class — stated line by line in oracle/neptune_oracle.c::orc_separator_glpk_class, which this function
+// follows operation for operation (same loop orders, same association, no contraction): the two return the same bits.
+// A basis leaves three variables non-basic; x = W v with W = G^-1 (G: gradients of the non-basics, by cofactors), the tableau
+// is [A 1; B 1] W.  Rows 0 .. nA-1 are A's (r >= 1), rows nA .. nA+3 the four points of B (r <= -1).
+__device__ __forceinline__ bool spx_inv3(const double (&G)[3][3], double (&W)[3][3]) {
+  const double c00 = G[1][1] * G[2][2] - G[1][2] * G[2][1], c01 = G[1][2] * G[2][0] - G[1][0] * G[2][2], c02 = G[1][0] * G[2][1] - G[1][1] * G[2][0];
+  const double det = (G[0][0] * c00 + G[0][1] * c01) + G[0][2] * c02;
+  if (!(fabs(det) > 1e-300)) return false;
+  const double id = 1.0 / det;
+  W[0][0] = c00 * id; W[1][0] = c01 * id; W[2][0] = c02 * id;
+  W[0][1] = (G[0][2] * G[2][1] - G[0][1] * G[2][2]) * id; W[1][1] = (G[0][0] * G[2][2] - G[0][2] * G[2][0]) * id; W[2][1] = (G[0][1] * G[2][0] - G[0][0] * G[2][1]) * id;
+  W[0][2] = (G[0][1] * G[1][2] - G[0][2] * G[1][1]) * id; W[1][2] = (G[0][2] * G[1][0] - G[0][0] * G[1][2]) * id; W[2][2] = (G[0][0] * G[1][1] - G[0][1] * G[1][0]) * id;
+  return true;
+}
+__device__ bool separator_glpk_class(int nA, const double2* A, const Pts4& B, double nd[3]) {
+  constexpr int kMaxIt = 60;
+  constexpr double kTolBnd = 1e-7, kTolDj = 1e-7, kTolPiv = 1e-9;
+  nd[0] = nd[1] = nd[2] = 0.0;
+  if (nA <= 0) return false;
+  auto point = [&](int i, double& px, double& py) {     // row i's point (B's four live in registers: selected, not indexed)
+    if (i < nA) { const double2 a = A[i]; px = a.x; py = a.y; }
+    else { const int k = i - nA; px = k == 0 ? B.x[0] : (k == 1 ? B.x[1] : (k == 2 ? B.x[2] : B.x[3])); py = k == 0 ? B.y[0] : (k == 1 ? B.y[1] : (k == 2 ? B.y[2] : B.y[3])); }
+  };
+  int slot[3] = {-1, -2, -3};
+  unsigned nb_rows = 0;
+  for (int it = 0; it <= kMaxIt; it++) {
+    double G[3][3], W[3][3], v[3], x[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      if (slot[j] < 0) { const int k = -slot[j] - 1; G[j][0] = k == 0; G[j][1] = k == 1; G[j][2] = k == 2; v[j] = 0.0; }
+      else { double px, py; point(slot[j], px, py); G[j][0] = px; G[j][1] = py; G[j][2] = 1.0; v[j] = slot[j] < nA ? 1.0 : -1.0; }
+    }
+    if (!spx_inv3(G, W)) return false;
+#pragma unroll
+    for (int k = 0; k < 3; k++) x[k] = (W[k][0] * v[0] + W[k][1] * v[1]) + W[k][2] * v[2];
+    double d[3] = {0.0, 0.0, 0.0}; int n_inf = 0;
+    auto cost_row = [&](int i, double px, double py, bool isA) {
+      if ((nb_rows >> i) & 1u) return;
+      const double r = (px * x[0] + py * x[1]) + x[2];
+      const double bnd = isA ? 1.0 : -1.0, delta = kTolBnd * (1.0 + 1e-3 * fabs(bnd));
+      double c = 0.0;
+      if (isA) { if (r < bnd - delta) c = -1.0; } else { if (r > bnd + delta) c = 1.0; }
+      if (c != 0.0) {
+        n_inf++;
+#pragma unroll
+        for (int j = 0; j < 3; j++) d[j] += c * ((px * W[0][j] + py * W[1][j]) + W[2][j]);
+      }
+    };
+    for (int i = 0; i < nA; i++) { const double2 a = A[i]; cost_row(i, a.x, a.y, true); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) cost_row(nA + k, B.x[k], B.y[k], false);
+    if (n_inf == 0) { nd[0] = x[0]; nd[1] = x[1]; nd[2] = x[2]; return true; }
+    if (it == kMaxIt) break;
+    int q = -1; double best = 0.0, sdir = 0.0;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      double s_ = 0.0; bool elig = false;
+      if (slot[j] < 0) { if (d[j] < -kTolDj) { s_ = 1.0; elig = true; } else if (d[j] > kTolDj) { s_ = -1.0; elig = true; } }
+      else if (slot[j] < nA) { if (d[j] < -kTolDj) { s_ = 1.0; elig = true; } }
+      else { if (d[j] > kTolDj) { s_ = -1.0; elig = true; } }
+      if (elig) {
+        double gamma = slot[j] < 0 ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+          const bool basic = slot[0] != -(k + 1) && slot[1] != -(k + 1) && slot[2] != -(k + 1);
+          if (basic) gamma += W[k][j] * W[k][j];
+        }
+        if (!(gamma > 1e-300)) gamma = 1e-300;
+        const double score = d[j] * d[j] / gamma;
+        if (score > best) { best = score; q = j; sdir = s_; }
+      }
+    }
+    if (q < 0) return false;
+    const double wq0 = q == 0 ? W[0][0] : (q == 1 ? W[0][1] : W[0][2]), wq1 = q == 0 ? W[1][0] : (q == 1 ? W[1][1] : W[1][2]), wq2 = q == 0 ? W[2][0] : (q == 1 ? W[2][1] : W[2][2]);
+    double tmax = NEP_INF;
+    int p = -1;
+    for (int pass = 0; pass < 2; pass++) {
+      double piv = 0.0;
+      auto ratio_row = [&](int i, double px, double py, bool isA) {
+        if ((nb_rows >> i) & 1u) return;
+        const double r = (px * x[0] + py * x[1]) + x[2];
+        const double rho = sdir * ((px * wq0 + py * wq1) + wq2);
+        if (!(fabs(rho) > kTolPiv)) return;
+        const double bnd = isA ? 1.0 : -1.0, delta = kTolBnd * (1.0 + 1e-3 * fabs(bnd));
+        double dist;
+        if (isA) { const bool inf = r < bnd - delta; if (inf ? rho > 0 : rho < 0) dist = inf ? bnd - r : r - bnd; else return; }
+        else { const bool inf = r > bnd + delta; if (inf ? rho < 0 : rho > 0) dist = inf ? r - bnd : bnd - r; else return; }
+        const double arho = fabs(rho);
+        if (pass == 0) { const double t = (dist + delta) / arho; if (t < tmax) tmax = t; }
+        else { const double t = dist / arho; if (t <= tmax && arho > piv) { piv = arho; p = i; } }
+      };
+      for (int i = 0; i < nA; i++) { const double2 a = A[i]; ratio_row(i, a.x, a.y, true); }
+#pragma unroll
+      for (int k = 0; k < 4; k++) ratio_row(nA + k, B.x[k], B.y[k], false);
+    }
+    if (p < 0) return false;
+    nb_rows |= 1u << p;
+    const int old = q == 0 ? slot[0] : (q == 1 ? slot[1] : slot[2]);
+    if (old >= 0) nb_rows &= ~(1u << old);
+    if (q == 0) slot[0] = p; else if (q == 1) slot[1] = p; else slot[2] = p;
+  }
+  return false;
+}
+
 struct SepCtx {
   const SceneParams* sp; const ProblemSet* ps;
   int slot, scene, own, N, S, nH, total;
@@ -666,6 +775,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
 // (with 63 other agents that is one full round plus a short tail instead of three rounds).  Line l
 // lands in bucket (slot, seg) at its call rank; an LP without a separating line leaves (0,0,0)
 // there — the QP kernel reads that as "constraint skipped" (solver_gurobi_poly.cpp:491-494).
+template <int RULE>
 __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParams sp, ProblemSet ps, int pool_pairs) {
   extern __shared__ __attribute__((aligned(16))) double sdyn[];
   double2* sA = (double2*)sdyn;                      // [pool_pairs] (x,y) pairs: the batch's point sets A, packed
@@ -737,7 +847,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
       if (!myA && made_here) myA = priv;
       const double2* Ause = myA;
       cand_eval(cx, seg, c, bx, by, hulldist, 1, myA, nA, ord, Ause);
-      const bool ok = separator_impl(nA, Ause, ord, B4, nd);
+      const bool ok = RULE == 1 ? separator_glpk_class(nA, Ause, B4, nd) : separator_impl(nA, Ause, ord, B4, nd);   // (the LP vertex rule: sp.sep_rule)
       if (!ok) { n_fail++; nd[0] = nd[1] = nd[2] = 0.0; }
       if (cull) {
         double worst = -NEP_INF;                          // largest n.Q + d - 1 over the guess's control points (<= -2 for a solved LP)
@@ -785,16 +895,21 @@ static int separator_pool_pairs(const SceneParams& sp) {
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
   if (n_slots <= 0) return;
   const size_t lds = separator_lds_bytes(sp);
-  static DynLdsAttr attr;
-  (void)attr.ensure((const void*)separator_kernel, lds);
-  hipLaunchKernelGGL(separator_kernel, dim3(n_slots * NEP_MAX_POL), dim3(64), lds, st, sp, ps, separator_pool_pairs(sp));
+  static DynLdsAttr attr[2];
+  if (sp.sep_rule == 1) {
+    (void)attr[1].ensure((const void*)separator_kernel<1>, lds);
+    hipLaunchKernelGGL(separator_kernel<1>, dim3(n_slots * NEP_MAX_POL), dim3(64), lds, st, sp, ps, separator_pool_pairs(sp));
+  } else {
+    (void)attr[0].ensure((const void*)separator_kernel<0>, lds);
+    hipLaunchKernelGGL(separator_kernel<0>, dim3(n_slots * NEP_MAX_POL), dim3(64), lds, st, sp, ps, separator_pool_pairs(sp));
+  }
 }
 
 // Stand-alone batched LP (tests / nep_separator_batch): one lane per problem, A read from global
 // memory into a private array, B = four points (what every call site of the path passes).
 __global__ void separator_explicit_kernel(int n_prob, const int* __restrict__ a_off, const double* __restrict__ a_xy,
                                           const int* __restrict__ b_off, const double* __restrict__ b_xy,
-                                          double* __restrict__ nd_out, int* __restrict__ solved) {
+                                          double* __restrict__ nd_out, int* __restrict__ solved, int rule) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n_prob) return;
   double2 A[kHullV];
@@ -804,15 +919,15 @@ __global__ void separator_explicit_kernel(int n_prob, const int* __restrict__ a_
   for (int i = 0; i < nA; i++) A[i] = make_double2(a_xy[2 * (a_off[p] + i)], a_xy[2 * (a_off[p] + i) + 1]);
   for (int i = 0; i < 4; i++) { B.x[i] = b_xy[2 * (b_off[p] + i)]; B.y[i] = b_xy[2 * (b_off[p] + i) + 1]; }
   double nd[3];
-  const bool ok = separator_impl(nA, A, 0, B, nd);
+  const bool ok = rule == 1 ? separator_glpk_class(nA, A, B, nd) : separator_impl(nA, A, 0, B, nd);
   nd_out[3 * p] = nd[0]; nd_out[3 * p + 1] = nd[1]; nd_out[3 * p + 2] = nd[2];
   solved[p] = ok ? 1 : 0;
 }
 
 void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy, const int* b_off,
-                               const double* b_xy, double* nd, int* solved, hipStream_t st) {
+                               const double* b_xy, double* nd, int* solved, int rule, hipStream_t st) {
   if (n_prob <= 0) return;
-  hipLaunchKernelGGL(separator_explicit_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, st, n_prob, a_off, a_xy, b_off, b_xy, nd, solved);
+  hipLaunchKernelGGL(separator_explicit_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, st, n_prob, a_off, a_xy, b_off, b_xy, nd, solved, rule);
 }
 
 // Stand-alone hulls (tests / nep_hulls_batch): full vertex lists of both hulls.
@@ -1702,6 +1817,50 @@ void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntAr
   const long total = (long)n_scenes * sp.num_agents;
   if (total <= 0) return;
   hipLaunchKernelGGL(ent_check_kernel, dim3((int)((total + 63) / 64)), dim3(64), 0, st, sp, ps, ea, fresh, n_scenes, cable, entangles);
+}
+
+// Point A of the next round for every slot (include/neptune_frontend.h: nep_batch_next_starts): the agent's committed
+// trajectory evaluated at t = previous t_start + dt — in a bulk-synchronous loop every agent replans from the same clock,
+// so "deltaT states ahead on the plan" (neptune.cpp:1366-1399) is one evaluation of the committed polynomial; the
+// polynomial is evaluated the way generatePwpOut samples it (solver_gurobi_poly.cpp:921-929), beyond its last knot the
+// vehicle rests at the end point.  With alt != null an agent that has arrived (within r_switch of its goal, slower than
+// 0.05 m/s) swaps its goal with alt[slot]: fleets that keep flying (bench.py's `moving` leg).
+__global__ void next_starts_kernel(const nep_traj_rec* __restrict__ recs, int slots, int N, int first_local, int n_local, double dt,
+                                   nep_fe_start* __restrict__ starts, double* __restrict__ alt, double r_switch) {
+  const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+  if (slot >= slots) return;
+  const int scene = slot / n_local, a = first_local + (slot - scene * n_local);
+  const nep_traj_rec* r = recs + (long)scene * N + a;
+  nep_fe_start* s = starts + slot;
+  const double t = s->t_start + dt;
+  s->t_start = t;
+  const int n = r->pwp.n_seg;
+  if (r->valid && n >= 1) {
+    int i = 0;
+    for (int k = 1; k < n && k < NEP_TRAJ_MAX_SEG; k++) if (t >= r->pwp.times[k]) i = k;
+    const bool past = t >= r->pwp.times[n];
+    double u = t - r->pwp.times[i];
+    if (u < 0.0) u = 0.0;
+    if (past) u = r->pwp.times[n] - r->pwp.times[n - 1];
+    for (int ax = 0; ax < 3; ax++) {
+      const double* c = r->pwp.coeff[ax][i];
+      s->pos[ax] = ((c[0] * (u * u * u) + c[1] * (u * u)) + c[2] * u) + c[3];
+      s->vel[ax] = past ? 0.0 : (c[0] * (3 * u * u) + c[1] * (2 * u)) + c[2];
+      s->accel[ax] = past ? 0.0 : c[0] * (6 * u) + c[1] * 2;
+    }
+  }
+  if (alt) {
+    const double dx = s->pos[0] - s->goal[0], dy = s->pos[1] - s->goal[1];
+    if (sqrt(dx * dx + dy * dy) < r_switch && sqrt(s->vel[0] * s->vel[0] + s->vel[1] * s->vel[1]) < 0.05) {
+      for (int ax = 0; ax < 3; ax++) { const double g = s->goal[ax]; s->goal[ax] = alt[(long)slot * 3 + ax]; alt[(long)slot * 3 + ax] = g; }
+    }
+  }
+}
+void launch_next_starts(const nep_traj_rec* recs, int n_scenes, int N, int first_local, int n_local, double dt, nep_fe_start* starts,
+                        double* alt, double r_switch, hipStream_t st) {
+  const int slots = n_scenes * n_local;
+  if (slots <= 0) return;
+  hipLaunchKernelGGL(next_starts_kernel, dim3((slots + 255) / 256), dim3(256), 0, st, recs, slots, N, first_local, n_local, dt, starts, alt, r_switch);
 }
 
 }  // namespace nep

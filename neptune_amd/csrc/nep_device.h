@@ -32,6 +32,7 @@ struct SceneParams {
   double long_length; // solver_gurobi_poly.cpp:173
   double cull_radius; // > 0: separating lines farther than this from the guess are presolved away (verified after the solve)
   long long time_limit_ticks;   // > 0: wall-clock budget of ONE solve in wall_clock64() ticks (setMaxRuntime -> Gurobi TimeLimit, solver_gurobi_poly.cpp:812)
+  int sep_rule;                 // which vertex of the separator LP is returned: 0 the largest-gap one (default), 1 the one a primal simplex of GLPK's default class reaches (nep_batch_set_separator_rule)
   double us_per_tick;           // microseconds per wall_clock64() tick of this device (hipDeviceAttributeWallClockRate; 0.01 on gfx950: 100 MHz)
 };
 
@@ -123,7 +124,7 @@ void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start,
                            double* hull0_xy, int* hull0_nv, int* flags, hipStream_t st);
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
 void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy, const int* b_off,
-                               const double* b_xy, double* nd, int* solved, hipStream_t st);
+                               const double* b_xy, double* nd, int* solved, int rule, hipStream_t st);
 void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 size_t qp_lds_fixed_bytes();
@@ -150,6 +151,8 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
 void launch_ent_sample(const nep_traj_rec* recs, int n_scenes, int N, const double* ts0, long ts_scene_stride, int num_pol, int ns, double T_span,
                        double* sampled, int* present, hipStream_t st);
 void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntArgs& ea, const nep_traj_rec* fresh, int n_scenes, double cable, int* entangles, hipStream_t st);
+void launch_next_starts(const nep_traj_rec* recs, int n_scenes, int N, int first_local, int n_local, double dt, nep_fe_start* starts,
+                        double* alt, double r_switch, hipStream_t st);
 void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const double* b_xy, int* hit, hipStream_t st);
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
                    unsigned char* conflict, unsigned char* conflict_prev, const int* entangles, nep_traj_rec* final_out, int* accept_out, hipStream_t st);

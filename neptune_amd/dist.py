@@ -142,6 +142,10 @@ class NativeExchange:
 
     __del__ = close
 
+    def nranks(self):
+        """ranks that joined the communicator (ncclCommCount) — nep_comm_nranks"""
+        return int(self.check(self.lib.nep_comm_nranks(self._c)))
+
     def hulls(self, d_block, d_blocks, stream=None):
         st = stream if stream is not None else self.be.torch.cuda.current_stream(self.be.device)
         self.check(self.lib.nep_batch_exchange_hulls(self.be._h, self._c, d_block.data_ptr(), d_blocks.data_ptr(), st.cuda_stream))
@@ -154,19 +158,26 @@ class NativeExchange:
 class ShardedRounds:
     """The multi-GPU round loop of bench.py (and of a deployment): the scenes are split into `chunks` groups, each with its
     own handle; for a chunk one round is  hulls of MY agents' committed trajectories -> all-gather of the hull blocks ->
-    [front end ->] separating lines + QP against the gathered blocks,  and right after a chunk's replan its next hulls
-    are built and their all-gather is started, so that the collective of one chunk runs under the other chunk's kernels.
-    One step = every chunk replans once.  Results do not depend on `chunks` (tested against chunks = 1)."""
+    [front end ->] separating lines + QP against the gathered blocks.  One step = every chunk replans once, and the exchange
+    of one chunk runs under another chunk's kernels.  Results do not depend on `chunks` (tested against chunks = 1).
+
+    native=True (bench.py's default at N > 1): the all-gather goes through the C ABI's own RCCL binding
+    (nep_batch_exchange_hulls) on a side stream that forks from and joins the compute stream inside the step — phase k of a
+    step runs  exchange of chunk k+1 (mod C)  beside  replan of chunk k  — so a step is a fixed launch sequence with
+    explicit stream dependencies and no host decision in it: it can be captured whole into one HIP graph (RCCL collectives
+    are capturable) and replayed without Python between the kernels.
+    native=False: torch.distributed's all_gather_into_tensor with async work handles (RCCL's own stream); right after a
+    chunk's replan its next hulls are built and their all-gather is started."""
 
     def __init__(self, backends, d_local, d_guess, world=1, rank=0, group=None, native=False, fe=None, timer=None):
         """backends: one BatchBackend per chunk; d_local[k]: device bytes [Sc][n_local] committed records of my agents in
-        chunk k; d_guess[k]: [Sc][n_local] guesses; fe: None or (fe_cfg, d_start[k], d_result[k]); native: exchange through
-        the C ABI's own RCCL binding (nep_batch_exchange_hulls, on the current stream) instead of torch.distributed;
-        timer: None or a callable name -> context manager (bench.py records HIP events around the phases)."""
+        chunk k; d_guess[k]: [Sc][n_local] guesses; fe: None or (fe_cfg, d_start[k], d_result[k]); timer: None or a callable
+        name -> context manager (bench.py records HIP events around the phases)."""
         import contextlib
         self.bes, self.d_local, self.d_guess, self.fe = backends, d_local, d_guess, fe
         self.C = len(backends)
         dev = backends[0].device
+        self.torch = backends[0].torch
         self.hx = [HullExchange(b.hull_block_bytes(), world, rank, group=group, device=dev) for b in backends]
         self.native = NativeExchange(backends[0], world, rank) if native else None
         self.pending = [None] * self.C
@@ -177,6 +188,8 @@ class ShardedRounds:
         # (neptune_ros.cpp:651-663), instead of vanishing from the others' obstacle sets as a valid = 0 record.
         for b, dl in zip(backends, d_local):
             b.d_commit.copy_(dl.view_as(b.d_commit))
+        self.side = self.torch.cuda.Stream(device=dev) if (native and self.torch.cuda.is_available()) else None
+        self.primed = False
 
     def _start(self, k, src):
         b, hx = self.bes[k], self.hx[k]
@@ -188,20 +201,45 @@ class ShardedRounds:
         else:
             self.pending[k] = hx.gather_async()
 
+    def _replan(self, k):
+        b = self.bes[k]
+        if self.fe is not None:
+            cfg, d_start, d_res = self.fe
+            with self.timer("frontend"):
+                b.frontend_hulls(cfg, self.hx[k].blocks, d_start[k], self.d_guess[k], d_res[k])
+        b.replan_hulls(self.hx[k].blocks, self.d_guess[k])
+
+    def prime(self):
+        """native mode: the hull blocks chunk 0 replans against in the first step (the other chunks' are exchanged inside it)"""
+        if self.native is not None and not self.primed:
+            self._start(0, self.d_local[0])
+            self.primed = True
+
     def step(self):
+        if self.native is not None:
+            torch = self.torch
+            self.prime()
+            main = torch.cuda.current_stream(self.bes[0].device)
+            if self.C == 1:                               # nothing to overlap with: replan, then the exchange for the next step
+                self._replan(0)
+                self._start(0, self.bes[0].d_commit)
+                return
+            for k in range(self.C):
+                j = (k + 1) % self.C
+                self.side.wait_stream(main)               # fork: chunk j's commit records (previous step, or this one for j = 0) are complete
+                with torch.cuda.stream(self.side):
+                    self._start(j, self.bes[j].d_commit)
+                self._replan(k)                           # reads blocks of chunk k, exchanged one phase ago
+                main.wait_stream(self.side)               # join
+            return
         for k in range(self.C):
             if self.pending[k] is None:
                 self._start(k, self.d_local[k])
         for k in range(self.C):
             with self.timer("wait"):
                 self.pending[k].wait()                   # what the stream still has to wait for
-            b = self.bes[k]
-            if self.fe is not None:
-                cfg, d_start, d_res = self.fe
-                with self.timer("frontend"):
-                    b.frontend_hulls(cfg, self.hx[k].blocks, d_start[k], self.d_guess[k], d_res[k])
-            b.replan_hulls(self.hx[k].blocks, self.d_guess[k])
-            self._start(k, b.d_commit)                   # my agents' new committed trajectories
+            self._replan(k)
+            self._start(k, self.bes[k].d_commit)         # my agents' new committed trajectories
 
 
 def stack_scenes(scenes):

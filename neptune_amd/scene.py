@@ -104,13 +104,22 @@ def hull_ccw_lexmin(pts):
 
 
 def inflate_static(verts, drone_radius):
-    """Neptune::setStaticObst, neptune.cpp:639-664: every vertex +-(2*drone_radius+0.2), hull."""
-    sd = 2 * drone_radius + 0.2
-    v = np.asarray(verts, dtype=np.float64).reshape(-1, 2)
-    pts = []
-    for x, y in v:
-        pts += [(x + sd, y + sd), (x + sd, y - sd), (x - sd, y - sd), (x - sd, y + sd)]
-    return hull_ccw_lexmin(pts)
+    """Neptune::setStaticObst, neptune.cpp:639-664: every vertex +-(2*drone_radius+0.2), hull — through the C ABI
+    (nep_inflate_static, host-only set-up step of the library)."""
+    return inflate_statics([verts], drone_radius)[0]
+
+
+def inflate_statics(footprints, drone_radius):
+    """nep_inflate_static for a list of (n,2) footprints -> list of inflated counter-clockwise polygons."""
+    import ctypes as C
+    from ._lib import check, lib
+    fp = [np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 2) for v in footprints]
+    off = np.zeros(len(fp) + 1, dtype=np.int32)
+    off[1:] = np.cumsum([len(v) for v in fp])
+    xy = np.ascontiguousarray(np.concatenate(fp)) if len(fp) and off[-1] else np.zeros((0, 2))
+    out_off = np.zeros(len(fp) + 1, dtype=np.int32); cap = max(4 * int(off[-1]), 1); out = np.zeros((cap, 2))
+    check(lib().nep_inflate_static(len(fp), abi.iptr(off), abi.dptr(xy), float(drone_radius), abi.iptr(out_off), abi.dptr(out), cap))
+    return [out[out_off[j]:out_off[j + 1]].copy() for j in range(len(fp))]
 
 
 def random_static_obstacles(p, rng, voxel=0.2):
@@ -132,7 +141,7 @@ def random_static_obstacles(p, rng, voxel=0.2):
             pts.append((x, y))
     raw = [np.array([[x + .25, y + .25], [x + .25, y - .25], [x - .25, y - .25], [x - .25, y + .25]])
            for x, y in pts]
-    return raw, [inflate_static(v, p.drone_radius) for v in raw]
+    return raw, inflate_statics(raw, p.drone_radius)
 
 
 LATTICE = np.array([-5.0, -2.5, 0.0, 2.5, 5.0])

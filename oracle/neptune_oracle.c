@@ -210,16 +210,22 @@ typedef struct { int have; double num, len2, sg, tA, nx, ny, px, py; } sep_best;
  *   1 a pseudo-random admissible vertex (seeded)      2 the admissible vertex with the smallest gap
  *   3 the admissible vertex that leaves the reference control points of the current segment the least room
  *   4 the vertex a textbook two-phase Bland simplex reaches (orc_separator_simplex)
+ *   5 the vertex a primal simplex of GLPK's default class reaches (orc_separator_glpk_class): standard start basis, projected
+ *     steepest-edge pricing, Harris ratio test — also selectable in the product (nep_batch_set_separator_rule)
  * Thread-local: concurrent callers (bench.py's cpu_baseline) keep the default. */
 #define SEP_MAX_CAND 512
 static __thread int g_policy = 0;
+static __thread int g_sep_rule = 0;       /* 0: the largest-gap vertex (default), 1: the GLPK-class simplex's (nep_batch_set_separator_rule) */
 static __thread unsigned long long g_rng = 1;
 static __thread int g_cur_seg = 0;
 static __thread double g_ref_ctrl[NEP_MAX_POL][4][2];
 static __thread int g_ncand = 0;
 static __thread sep_best g_cand[SEP_MAX_CAND];
 static __thread long g_stat_lps = 0, g_stat_vertices = 0;
+void orc_set_separator_rule(int rule) { g_sep_rule = rule; }
 void orc_set_vertex_policy(int policy, unsigned long long seed, const double* ref_ctrl /* [NEP_MAX_POL][4][2] or NULL */) {
+  g_sep_rule = policy == 5 ? 1 : 0;        /* policy 5 IS the product's second rule */
+  if (policy == 5) policy = 0;
   g_policy = policy; g_rng = seed * 2862933555777941757ULL + 3037000493ULL; g_stat_lps = 0; g_stat_vertices = 0;
   if (ref_ctrl) memcpy(g_ref_ctrl, ref_ctrl, sizeof(g_ref_ctrl)); else memset(g_ref_ctrl, 0, sizeof(g_ref_ctrl));
 }
@@ -270,7 +276,9 @@ static void sep_edge_ccw(const double p[2], const double q[2], int nB, const dou
 }
 
 int orc_separator_simplex(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3]);
+int orc_separator_glpk_class(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3], int* n_pivots);
 static int separator_impl(int nA, const double (*A)[2], int a_ordered, int nB, const double (*B)[2], double nd[3]) {
+  if (g_sep_rule == 1) return orc_separator_glpk_class(nA, A, nB, B, nd, NULL);      /* (the point sets' order plays no role for it) */
   sep_best best; best.have = 0; best.num = 0; best.len2 = 1; best.sg = 1; best.tA = 0; best.nx = best.ny = best.px = best.py = 0;
   g_ncand = 0;
   if (a_ordered && nA >= 3) {
@@ -301,6 +309,7 @@ static int separator_impl(int nA, const double (*A)[2], int a_ordered, int nB, c
   if (best.have && g_policy != 0) {   /* study knob: another admissible vertex of the same LP (see orc_set_vertex_policy) */
     g_stat_lps++; g_stat_vertices += g_ncand;
     if (g_policy == 4) { double t[3]; if (orc_separator_simplex(nA, A, nB, B, t)) { nd[0] = t[0]; nd[1] = t[1]; nd[2] = t[2]; return 1; } }
+
     else if (g_ncand > 0) {
       int pick = 0;
       if (g_policy == 1) { g_rng = g_rng * 6364136223846793005ULL + 1442695040888963407ULL; pick = (int)((g_rng >> 33) % (unsigned long long)g_ncand); }
@@ -393,6 +402,116 @@ int orc_separator_simplex(int nA, const double (*A)[2], int nB, const double (*B
 #undef TB
   free(T); free(basis);
   return ok;
+}
+
+/* ---- vertex policy 5 / separator rule 1: a primal simplex of the class GLPK's glp_simplex runs by default -------------
+ * The reference calls glp_simplex with glp_init_smcp's defaults (separator_glpk.cpp:39-41, 336): primal simplex, projected
+ * steepest-edge pricing (GLP_PT_PSE), Harris' two-pass ratio test (GLP_RT_HAR), tol_bnd = tol_dj = 1e-7, tol_piv = 1e-9, no
+ * presolve, no scaling, started from the standard basis glp_create_prob leaves behind: every auxiliary (row) variable
+ * basic, the three free structurals (n1, n2, d) non-basic at zero.  GLPK 4.65's source is not in the tree (downloaded at
+ * build time, submodules/separator/cmake/glpk.cmake.in:6), so this is that documented algorithm CLASS, not a clone of its
+ * pivot sequence: ties and loop orders are this file's (stated below), and GLPK's internals that the documentation does not
+ * pin (its phase-1 bookkeeping, periodic refactorisation, reference-space resets) are not imitated.
+ *
+ * LP in GLPK's standard form: r = [A 1; B 1] x, rows of A bounded r >= 1, rows of B bounded r <= -1, x free, objective 0.
+ * A basis leaves exactly three variables non-basic; the structurals are expressed through them, x = W v with W = G^-1, G's
+ * rows the gradients of the non-basic variables (e_k for a structural, (a_x, a_y, 1) for a row) and v their values (0 for a
+ * structural, the bound for a row): the whole tableau is A W, recomputed from G every iteration (3 x 3 by cofactors).
+ * Phase 1 minimises the sum of infeasibilities of the basic rows (cost -1 on a row below its lower bound, +1 above its upper
+ * bound; an infeasible row blocks where it becomes feasible); with the zero objective the first feasible vertex is optimal.
+ * Pricing: largest d_j^2 / gamma_j among the eligible non-basics (free structural: |d_j| > tol_dj; row at its lower bound:
+ * d_j < -tol_dj; at its upper bound: d_j > tol_dj), gamma_j the projected steepest-edge weight for the reference space of
+ * the initial non-basics, gamma_j = [j in R] + sum over basic structurals k of W[k][j]^2 (evaluated from its definition).
+ * Ratio test: Harris — pass 1 the largest step with every bound relaxed by delta = tol_bnd (1 + 1e-3 |bound|) — pass 2 among
+ * the rows that block within it the one with the largest |pivot|; ties to the lowest row index, non-basic slots in order
+ * 0, 1, 2; the leaving row takes the entering variable's slot.  Returns 1 with the vertex (n1, n2, d), 0 when phase 1 ends
+ * with an infeasible row (no separating line) or after SPX_MAX_IT pivots. */
+#define SPX_MAX_IT 60
+#define SPX_TOL_BND 1e-7
+#define SPX_TOL_DJ 1e-7
+#define SPX_TOL_PIV 1e-9
+static int spx_inv3(const double G[3][3], double W[3][3]) {
+  const double c00 = G[1][1] * G[2][2] - G[1][2] * G[2][1], c01 = G[1][2] * G[2][0] - G[1][0] * G[2][2], c02 = G[1][0] * G[2][1] - G[1][1] * G[2][0];
+  const double det = (G[0][0] * c00 + G[0][1] * c01) + G[0][2] * c02;
+  if (!(fabs(det) > 1e-300)) return 0;
+  const double id = 1.0 / det;
+  W[0][0] = c00 * id; W[1][0] = c01 * id; W[2][0] = c02 * id;
+  W[0][1] = (G[0][2] * G[2][1] - G[0][1] * G[2][2]) * id; W[1][1] = (G[0][0] * G[2][2] - G[0][2] * G[2][0]) * id; W[2][1] = (G[0][1] * G[2][0] - G[0][0] * G[2][1]) * id;
+  W[0][2] = (G[0][1] * G[1][2] - G[0][2] * G[1][1]) * id; W[1][2] = (G[0][2] * G[1][0] - G[0][0] * G[1][2]) * id; W[2][2] = (G[0][0] * G[1][1] - G[0][1] * G[1][0]) * id;
+  return 1;
+}
+int orc_separator_glpk_class(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3], int* n_pivots) {
+  const int m = nA + nB;
+  nd[0] = nd[1] = nd[2] = 0.0;
+  if (n_pivots) *n_pivots = 0;
+  if (nA <= 0 || nB <= 0 || m > 64) return 0;
+  int slot[3] = {-1, -2, -3};                 /* non-basic slots: -(k+1) structural k, i >= 0 row i */
+  unsigned long long nb_rows = 0;             /* rows that are non-basic (sitting at their bound) */
+  for (int it = 0; it <= SPX_MAX_IT; it++) {
+    double G[3][3], W[3][3], v[3], x[3];
+    for (int j = 0; j < 3; j++) {
+      if (slot[j] < 0) { const int k = -slot[j] - 1; G[j][0] = k == 0; G[j][1] = k == 1; G[j][2] = k == 2; v[j] = 0.0; }
+      else { const int i = slot[j]; const double* pt = i < nA ? A[i] : B[i - nA]; G[j][0] = pt[0]; G[j][1] = pt[1]; G[j][2] = 1.0; v[j] = i < nA ? 1.0 : -1.0; }
+    }
+    if (!spx_inv3(G, W)) return 0;
+    for (int k = 0; k < 3; k++) x[k] = (W[k][0] * v[0] + W[k][1] * v[1]) + W[k][2] * v[2];
+    /* reduced costs of the phase-1 objective over the basic rows, and whether any is infeasible */
+    double d[3] = {0, 0, 0}; int n_inf = 0;
+    for (int i = 0; i < m; i++) {
+      if ((nb_rows >> i) & 1ULL) continue;
+      const double* pt = i < nA ? A[i] : B[i - nA];
+      const double r = (pt[0] * x[0] + pt[1] * x[1]) + x[2];
+      const double bnd = i < nA ? 1.0 : -1.0, delta = SPX_TOL_BND * (1.0 + 1e-3 * fabs(bnd));
+      double c = 0.0;
+      if (i < nA) { if (r < bnd - delta) c = -1.0; } else { if (r > bnd + delta) c = 1.0; }
+      if (c != 0.0) { n_inf++; for (int j = 0; j < 3; j++) d[j] += c * ((pt[0] * W[0][j] + pt[1] * W[1][j]) + W[2][j]); }
+    }
+    if (n_inf == 0) { nd[0] = x[0]; nd[1] = x[1]; nd[2] = x[2]; if (n_pivots) *n_pivots = it; return 1; }
+    if (it == SPX_MAX_IT) break;
+    /* pricing */
+    int q = -1; double best = 0.0, sdir = 0.0;
+    for (int j = 0; j < 3; j++) {
+      double s_;
+      if (slot[j] < 0) { if (d[j] < -SPX_TOL_DJ) s_ = 1.0; else if (d[j] > SPX_TOL_DJ) s_ = -1.0; else continue; }
+      else if (slot[j] < nA) { if (d[j] < -SPX_TOL_DJ) s_ = 1.0; else continue; }       /* at its lower bound: may only increase */
+      else { if (d[j] > SPX_TOL_DJ) s_ = -1.0; else continue; }                          /* at its upper bound: may only decrease */
+      double gamma = slot[j] < 0 ? 1.0 : 0.0;
+      for (int k = 0; k < 3; k++) { int basic = 1; for (int jj = 0; jj < 3; jj++) if (slot[jj] == -(k + 1)) basic = 0; if (basic) gamma += W[k][j] * W[k][j]; }
+      if (!(gamma > 1e-300)) gamma = 1e-300;
+      const double score = d[j] * d[j] / gamma;
+      if (score > best) { best = score; q = j; sdir = s_; }
+    }
+    if (q < 0) return 0;                        /* no improving direction with infeasible rows left: the LP has no solution */
+    /* Harris ratio test over the basic rows */
+    double tmax = INFINITY;
+    for (int pass = 0; pass < 2; pass++) {
+      int p = -1; double piv = 0.0, step = 0.0;
+      for (int i = 0; i < m; i++) {
+        if ((nb_rows >> i) & 1ULL) continue;
+        const double* pt = i < nA ? A[i] : B[i - nA];
+        const double r = (pt[0] * x[0] + pt[1] * x[1]) + x[2];
+        const double rho = sdir * ((pt[0] * W[0][q] + pt[1] * W[1][q]) + W[2][q]);
+        if (!(fabs(rho) > SPX_TOL_PIV)) continue;
+        const double bnd = i < nA ? 1.0 : -1.0, delta = SPX_TOL_BND * (1.0 + 1e-3 * fabs(bnd));
+        /* the bound the row meets in this direction: an infeasible row where it becomes feasible, a feasible one where it
+         * would stop being so */
+        double dist;
+        if (i < nA) { const int inf = r < bnd - delta; if (inf ? rho > 0 : rho < 0) dist = inf ? bnd - r : r - bnd; else continue; }
+        else { const int inf = r > bnd + delta; if (inf ? rho < 0 : rho > 0) dist = inf ? r - bnd : bnd - r; else continue; }
+        const double arho = fabs(rho);
+        if (pass == 0) { const double t = (dist + delta) / arho; if (t < tmax) tmax = t; }
+        else { const double t = dist / arho; if (t <= tmax && arho > piv) { piv = arho; p = i; step = t > 0.0 ? t : 0.0; } }
+      }
+      if (pass == 1) {
+        if (p < 0) return 0;                    /* nothing blocks: cannot happen while the infeasibility decreases */
+        (void)step;
+        nb_rows |= 1ULL << p;
+        if (slot[q] >= 0) nb_rows &= ~(1ULL << slot[q]);
+        slot[q] = p;
+      }
+    }
+  }
+  return 0;
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -92,6 +92,10 @@ int orc_separator_ordered(int nA, const double (*A)[2], int nB, const double (*B
  * source).  Used only to cross-check feasibility in tests. */
 int orc_separator_simplex(int nA, const double (*A)[2], int nB, const double (*B)[2],
                           double nd[3]);
+/* the vertex a primal simplex of GLPK's default class reaches (see neptune_oracle.c); n_pivots may be NULL */
+int orc_separator_glpk_class(int nA, const double (*A)[2], int nB, const double (*B)[2], double nd[3], int* n_pivots);
+/* which separator rule the restated path uses from now on (thread-local): 0 largest gap, 1 GLPK-class simplex */
+void orc_set_separator_rule(int rule);
 
 /* PolySolverGurobi::optimize (solver_gurobi_poly.cpp:804-887) for one agent.
  *   K, coeff_init: setInitTrajectory (:187-244)

@@ -74,6 +74,9 @@ def lib():
         for f in (L.orc_separator, L.orc_separator_simplex, L.orc_separator_ordered):
             f.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
             f.restype = C.c_int
+        L.orc_separator_glpk_class.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        L.orc_separator_glpk_class.restype = C.c_int
+        L.orc_set_separator_rule.argtypes = [C.c_int]; L.orc_set_separator_rule.restype = None
         L.orc_optimize.argtypes = [C.POINTER(orc_params), C.c_int, C.c_void_p, C.c_int,
                                    C.POINTER(orc_polys), C.POINTER(orc_polys), C.POINTER(orc_ent),
                                    C.c_int, C.c_void_p, C.c_void_p, C.POINTER(orc_result)]
@@ -144,6 +147,20 @@ def separator(A, B, simplex=False, ordered=False):
     f = lib().orc_separator_simplex if simplex else (lib().orc_separator_ordered if ordered else lib().orc_separator)
     ok = f(len(A), A.ctypes.data, len(B), B.ctypes.data, abi.dptr(nd))
     return bool(ok), nd
+
+
+def separator_glpk_class(A, B):
+    """the vertex a primal simplex of GLPK's default class reaches (orc_separator_glpk_class) -> (ok, nd, pivots)"""
+    A = _c(A).reshape(-1, 2); B = _c(B).reshape(-1, 2)
+    nd = np.zeros(3); n = C.c_int(0)
+    ok = lib().orc_separator_glpk_class(len(A), A.ctypes.data, len(B), B.ctypes.data, abi.dptr(nd), C.byref(n))
+    return bool(ok), nd, n.value
+
+
+def set_separator_rule(rule):
+    """0: the largest-gap vertex (default); 1: the GLPK-class simplex's vertex — for every separator call of the restated path
+    made from this thread afterwards (checker of nep_batch_set_separator_rule)"""
+    lib().orc_set_separator_rule(int(rule))
 
 
 class Polys:

@@ -196,3 +196,37 @@ class Plan:
     def update_delta(self, elapsed_ms):                      # neptune.cpp:1713-1720
         states_last_replan = math.ceil(elapsed_ms / (self.dc * 1000))
         self.deltaT = int(max(self.factor_alpha * states_last_replan, 1.0))
+
+
+def next_start(times, coeff, valid, start, dt, alt_goal=None, r_switch=0.0):
+    """Point A of the next bulk-synchronous round (checker of nep_batch_next_starts, include/neptune_frontend.h): the state
+    of a committed trajectory — times [n+1], coeff [3][n][4] — at t = start['t_start'] + dt, evaluated like generatePwpOut's
+    samples (solver_gurobi_poly.cpp:921-929); at rest at the end point beyond the last knot (Neptune::replanFull takes A
+    on the committed plan, neptune.cpp:1366-1399).  start: dict pos/vel/accel/goal (lists of 3) + t_start; returns the new
+    dict and the (possibly swapped) alternate goal."""
+    out = {k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in start.items()}
+    t = start["t_start"] + dt
+    out["t_start"] = t
+    n = len(times) - 1
+    if valid and n >= 1:
+        i = 0
+        for k in range(1, n):
+            if t >= times[k]:
+                i = k
+        past = t >= times[n]
+        u = t - times[i]
+        if u < 0.0:
+            u = 0.0
+        if past:
+            u = times[n] - times[n - 1]
+        for ax in range(3):
+            c = coeff[ax][i]
+            out["pos"][ax] = ((c[0] * (u * u * u) + c[1] * (u * u)) + c[2] * u) + c[3]
+            out["vel"][ax] = 0.0 if past else (c[0] * (3 * u * u) + c[1] * (2 * u)) + c[2]
+            out["accel"][ax] = 0.0 if past else c[0] * (6 * u) + c[1] * 2
+    alt = None if alt_goal is None else list(alt_goal)
+    if alt is not None:
+        dx = out["pos"][0] - out["goal"][0]; dy = out["pos"][1] - out["goal"][1]
+        if math.sqrt(dx * dx + dy * dy) < r_switch and math.sqrt(out["vel"][0] * out["vel"][0] + out["vel"][1] * out["vel"][1]) < 0.05:
+            out["goal"], alt = alt, list(out["goal"])
+    return out, alt

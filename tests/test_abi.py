@@ -22,7 +22,7 @@ def L():
 
 def test_exports_every_declared_symbol(L):
     hdr = open(os.path.join(ROOT, "include", "neptune_backend.h")).read()
-    declared = set(re.findall(r"^(?:int|void|int64_t|const char\*|nep_backend_t\*|nep_batch_t\*|nep_comm_t\*)\s+(nep_[a-z_0-9]+)\(", hdr, re.M))
+    declared = set(re.findall(r"^(?:int|void|double|int64_t|const char\*|nep_backend_t\*|nep_batch_t\*|nep_comm_t\*)\s+(nep_[a-z_0-9]+)\(", hdr, re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.EXPORTS)
     for name in declared:

@@ -66,6 +66,77 @@ def test_separator_bit_exact_on_golden_lps(be, oracle):
     assert n_ok > 200
 
 
+def test_separator_rule_glpk_class_bit_exact(be, oracle):
+    """nep_separator_batch_rule(1): the vertex a primal simplex of GLPK's default class reaches — device == oracle bit for bit
+    on the golden LPs (feasibility as HiGHS) and on random point sets of every size the path poses."""
+    d = np.load(helpers.ROOT + "/tests/golden/lp_cases.npz")
+    As = [A[~np.isnan(A[:, 0])] for A in d["A"]]; Bs = list(d["B"])
+    rng = np.random.default_rng(11)
+    for k in range(400):                       # two clouds a random distance apart (some overlap: infeasible), 1..16 against 4 points
+        nA = int(rng.integers(1, 17))
+        c = rng.uniform(-3, 3, 2)
+        As.append(rng.normal(size=(nA, 2)) * rng.uniform(0.1, 1.5)); Bs.append(c + rng.normal(size=(4, 2)) * rng.uniform(0.05, 1.0))
+    As.append(np.zeros((3, 2))); Bs.append(np.ones((4, 2)))                          # coincident points
+    ok, nd = be.separator_batch(As, Bs, rule=1)
+    n_ok = 0
+    for k in range(len(As)):
+        o, n, _ = oracle.separator_glpk_class(As[k], Bs[k])
+        assert bool(ok[k]) == o, k
+        assert nd[k].tobytes() == n.tobytes(), (k, nd[k], n)
+        n_ok += o
+    assert np.array_equal(ok[:300], d["feasible"].astype(bool))
+    assert n_ok > 300
+    ok0, nd0 = be.separator_batch(As[:300], Bs[:300])                                # (rule 0 is what nep_separator_batch runs)
+    assert np.array_equal(ok0, ok[:300]) or (ok0 <= ok[:300]).all()
+    assert not np.array_equal(nd0, nd[:300])
+
+
+def test_replan_with_the_glpk_class_separator_rule(be, oracle):
+    """nep_batch_set_separator_rule(1): every line of a replan comes from the simplex rule — bit-identical to the oracle
+    running the same rule — and the QP on those lines agrees as for the default rule; through the per-agent handle too."""
+    sc = scene.make_scene(8, 20, seed=3)
+    p = sc["par"]
+    oracle.set_separator_rule(1)
+    try:
+        bb = be.BatchBackend(p, sc["statics"])
+        bb.set_separator_rule(1)
+        bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]))
+        sol = bb.solutions()
+        n_diff = 0
+        for a in range(p.num_agents):
+            r = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"])
+            seg, nd = bb.debug_lines(a)
+            np.testing.assert_array_equal(seg, r["line_seg"]); np.testing.assert_array_equal(nd, r["line_nd"])
+            st = sol[a]["stats"]; K = int(sol[a]["K"])
+            assert int(st["status"]) == r["status"] and int(st["n_lp"]) == r["n_lp"] and int(st["n_lp_failed"]) == r["n_lp_failed"]
+            assert np.abs(np.array(sol[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= COEF_TOL
+            oracle.set_separator_rule(0)
+            r0 = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"])
+            oracle.set_separator_rule(1)
+            assert r0["n_lp"] == r["n_lp"] and r0["n_lp_failed"] == r["n_lp_failed"]           # same LPs, same feasibility
+            n_diff += not np.array_equal(r0["line_nd"], r["line_nd"])
+        assert n_diff > 0
+        bb.set_separator_rule(0)
+        bb.close()
+        # per-agent handle
+        aid = 3
+        hx, hn, h0, n0 = be.hulls_batch(sc["committed"], 0.0, p.num_pol, p.T_span, p.drone_radius)
+        others = [j for j in range(p.num_agents) if j != aid - 1]
+        s = _solver(be, p, aid)
+        s.setSeparatorRule(1)
+        s.setStaticObstVert(sc["statics"])
+        g = sc["guesses"][aid - 1]; K = int(g["K"])
+        s.setInitTrajectory(np.arange(K + 1) * p.T_span, np.array(g["coeff"])[:, :K, :])
+        s.setHulls([[hx[j, i, :hn[j, i]] for i in range(p.num_pol)] for j in others])
+        s.optimize()
+        r = oracle.replan(p, aid, sc["committed"], g, sc["statics"])
+        seg, nd = s.debugGetLines()
+        np.testing.assert_array_equal(nd, r["line_nd"])
+        s.close()
+    finally:
+        oracle.set_separator_rule(0)
+
+
 def test_separator_edge_cases(be, oracle):
     sq = np.array([[1.0, 1.0], [1.0, -1.0], [-1.0, 1.0], [-1.0, -1.0]])
     cases = [(sq, np.tile([[3.0, 0.5]], (4, 1))),                       # hovering agent (coincident control points)
@@ -389,30 +460,48 @@ def test_cpp_host_class_reference_call_sequence(be, oracle):
             assert abs(float(obj) - r["objective"]) <= COST_RTOL * (1 + abs(r["objective"]))
 
 
-def test_config5_size_256_agents_entangle_spill_path(be, oracle):
-    """BASELINE config 5 size on one GPU: 256 agents + 100 obstacles, entangle check on.  The ~2000
-    lines per agent exceed the LDS carve, so this exercises the global-spill placement of the QP
-    rows; a few agents are compared with the oracle, all of them through size-independent checks."""
+@pytest.mark.parametrize("placement", ["default", "full_rows_lds", "full_rows_reg"])
+def test_config5_size_256_agents_entangle(be, oracle, placement, monkeypatch):
+    """BASELINE config 5 size on one GPU: 256 agents + 100 obstacles, entangle check on, ~2 000 lines per agent.
+    default: the handle turns the verified line presolve on by itself (4 m) and runs the register-resident kernel — the
+    few dozen near lines fit its slots; full_rows_lds: presolve explicitly off, every row through qp_kernel (LDS carve +
+    global spill); full_rows_reg: every row through qp_reg_kernel (rows beyond its slots in the global scratch).  A few
+    agents are compared with the oracle, all of them through size-independent checks."""
     import dataclasses
+    if placement == "full_rows_reg":
+        monkeypatch.setenv("NEP_QP_KERNEL", "reg")
     sc = scene.make_scene(256, 100, seed=1)
     case_id = scene.synthetic_entangle(sc, seed=3, frac=0.1)
     p = dataclasses.replace(sc["par"], enable_entangle=True)
     bb = be.BatchBackend(p, sc["statics"])
+    if placement == "default":
+        assert bb.line_cull() == 4.0 and bb.qp_kernel_name() == "qp_reg_kernel"
+    else:
+        bb.set_line_cull(0.0)
+        assert bb.line_cull() == 0.0 and bb.qp_kernel_name() == ("qp_kernel" if placement == "full_rows_lds" else "qp_reg_kernel")
     d_ent = bb.torch.from_numpy(case_id.reshape(-1).copy()).to(bb.device)
     bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]), d_ent=d_ent)
     sol = bb.solutions()
     st = sol["stats"]
     assert (st["n_lines"] > 1500).all() and (st["status"] <= 2).all()
     assert (st["status"] == 0).sum() >= 240
+    if placement == "default":
+        assert st["n_rows"].mean() < 0.2 * (48 * 8 + 4 * st["n_lines"].mean())       # most rows are presolved away
     T = p.T_span
     M4 = scene.A_POS_INV * np.array([T ** 3, T ** 2, T, 1.0])[:, None]
     for a in (0, 17, 101, 255):
         r = oracle.replan(p, a + 1, sc["committed"], sc["guesses"][a], sc["statics"], case_id=case_id[a])
         K = int(sol[a]["K"])
         seg, nd = bb.debug_lines(a, cap=20000)
-        np.testing.assert_array_equal(nd, r["line_nd"])
-        assert int(st[a]["status"]) == r["status"] and int(st[a]["n_lp"]) == r["n_lp"]
+        if placement == "default":        # (near lines first, then the parked ones: the same lines per segment)
+            key = lambda sg, l: sorted(map(tuple, np.column_stack([sg, l])))
+            assert key(seg, nd) == key(r["line_seg"], r["line_nd"])
+        else:
+            np.testing.assert_array_equal(nd, r["line_nd"])
+        assert int(st[a]["status"]) == r["status"] and int(st[a]["n_lp"]) == r["n_lp"] and int(st[a]["n_lines"]) == r["n_lines"]
         assert np.abs(np.array(sol[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= COEF_TOL
+        if r["status"] != 2:
+            assert abs(float(st[a]["objective"]) - r["objective"]) <= COST_RTOL * (1 + abs(r["objective"]))
     for a in range(0, 256, 16):
         if int(st[a]["status"]) == 2:
             continue

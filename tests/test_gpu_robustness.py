@@ -280,3 +280,50 @@ def test_short_affine_steps_discard_the_predictor(be, oracle):
             # (front-end guesses: the bound of the parity sweep, DESIGN.md section 2 — these are its hard cases; observed 1.1e-5)
             np.testing.assert_allclose(np.array(sol["coeff"][b])[:, :K], np.array(res["coeff"])[:, :K], atol=1e-4, rtol=0)
         bb.close()
+
+
+def test_next_starts_equals_the_restatement_bit_for_bit(be):
+    """nep_batch_next_starts (point A of the next bulk-synchronous round, on the device) against oracle/plan_oracle.next_start:
+    inside the trajectory, on a knot, beyond its end (at rest), an invalid record (state kept), and the goal swap of an
+    agent that has arrived; sharded handle (first_local > 0) and two scenes."""
+    from oracle import plan_oracle as po
+    N, S = 8, 2
+    scs = [scene.make_scene(N, 3, seed=70 + s) for s in range(S)]
+    p = scs[0]["par"]
+    first, nl = 2, 4
+    bb = be.BatchBackend(p, scs[0]["statics"], first_local=first, n_local=nl, n_scenes=S)
+    com = np.stack([s["committed"] for s in scs]).copy()
+    com[1, 3]["valid"] = 0
+    starts = np.stack([scene.frontend_starts(s) for s in scs])[:, first:first + nl].copy()
+    rng = np.random.default_rng(3)
+    dts = [0.0, 0.25, 0.5, 1.3, 3.999, 4.0, 7.5]
+    alt = rng.uniform(-5, 5, (S, nl, 3))
+    # one agent sits on its goal at the end of its trajectory: it must swap goals once t passes the end
+    K = int(com[0, first]["pwp"]["n_seg"]); T = p.T_span
+    c = np.array(com[0, first]["pwp"]["coeff"])[:, K - 1]
+    starts[0, 0]["goal"] = c[:, 0] * T ** 3 + c[:, 1] * T ** 2 + c[:, 2] * T + c[:, 3]
+    d_com = bb.to_device(com); d_st = bb.to_device(starts); d_alt = bb.torch.from_numpy(alt.copy()).to(bb.device)
+    want = [[{k: (list(map(float, starts[s, a][k])) if k != "t_start" else float(starts[s, a][k])) for k in ("pos", "vel", "accel", "goal", "t_start")}
+             for a in range(nl)] for s in range(S)]
+    want_alt = alt.copy()
+    swapped = 0
+    for dt in dts:
+        bb.next_starts(d_com, dt, d_st, d_alt, 0.3)
+        got = d_st.cpu().numpy().view(abi.FE_START_DTYPE).reshape(S, nl); got_alt = d_alt.cpu().numpy()
+        for s in range(S):
+            for a in range(nl):
+                r = com[s, first + a]; n = int(r["pwp"]["n_seg"])
+                w, al = po.next_start(list(map(float, r["pwp"]["times"][:n + 1])), np.array(r["pwp"]["coeff"])[:, :n].tolist(), bool(r["valid"]),
+                                      want[s][a], dt, list(want_alt[s, a]), 0.3)
+                swapped += al != list(want_alt[s, a])
+                want[s][a] = w; want_alt[s, a] = al
+                for k in ("pos", "vel", "accel", "goal"):
+                    assert np.array(got[s, a][k]).tobytes() == np.array(w[k], dtype=np.float64).tobytes(), (dt, s, a, k)
+                assert float(got[s, a]["t_start"]) == w["t_start"]
+        assert got_alt.tobytes() == want_alt.tobytes()
+    assert swapped >= 1
+    # without the alternate goals nothing is swapped
+    g0 = d_st.cpu().numpy().view(abi.FE_START_DTYPE)["goal"].copy()
+    bb.next_starts(d_com, 0.5, d_st)
+    assert d_st.cpu().numpy().view(abi.FE_START_DTYPE)["goal"].tobytes() == g0.tobytes()
+    bb.close()

@@ -86,6 +86,43 @@ def test_separator_feasibility_matches_highs(oracle):
     assert n_ok > 200
 
 
+def test_glpk_class_simplex_on_golden_lps(oracle):
+    """Separator rule 1 (orc_separator_glpk_class: primal simplex from the standard basis, projected steepest-edge pricing,
+    Harris ratio test — the algorithm class glp_simplex runs with its defaults, separator_glpk.cpp:39-41, 336): feasibility
+    equals HiGHS' on every golden LP, the returned point satisfies every row of the reference LP and is a vertex of it in
+    GLPK's standard form (three non-basic variables: tight rows, or structurals left at zero)."""
+    d = np.load(helpers.ROOT + "/tests/golden/lp_cases.npz")
+    n_ok = n_same = 0
+    pivots = []
+    for A, B, feas in zip(d["A"], d["B"], d["feasible"]):
+        A = A[~np.isnan(A[:, 0])]
+        ok, nd, npiv = oracle.separator_glpk_class(A, B)
+        assert ok == bool(feas)
+        if not ok:
+            assert (nd == 0).all()
+            continue
+        ra = A @ nd[:2] + nd[2]; rb = B @ nd[:2] + nd[2]
+        assert ra.min() >= 1 - 3e-7 and rb.max() <= -1 + 3e-7                      # (tol_bnd = 1e-7, relative to the bound)
+        tight = (np.abs(ra - 1) < 1e-9).sum() + (np.abs(rb + 1) < 1e-9).sum() + (nd == 0).sum()
+        assert tight >= 3
+        n_ok += 1; pivots.append(npiv)
+        ok0, nd0 = oracle.separator(A, B)
+        if ok0:
+            l = np.array([nd[0], nd[1], nd[2] - 1]) / np.hypot(*nd[:2]); l0 = np.array([nd0[0], nd0[1], nd0[2] - 1]) / np.hypot(*nd0[:2])
+            n_same += np.abs(l - l0).max() < 1e-9
+    assert n_ok > 200 and max(pivots) <= 20
+    assert 0 < n_same < n_ok           # a different rule: it meets the largest-gap line on some LPs, not on all
+    # the rule switch of the restated path: orc_separator* follow it
+    A = d["A"][0]; A = A[~np.isnan(A[:, 0])]; B = d["B"][0]
+    oracle.set_separator_rule(1)
+    try:
+        ok1, nd1 = oracle.separator(A, B)
+    finally:
+        oracle.set_separator_rule(0)
+    ok2, nd2, _ = oracle.separator_glpk_class(A, B)
+    assert ok1 == ok2 and nd1.tobytes() == nd2.tobytes()
+
+
 def test_hull_properties(oracle):
     rng = np.random.default_rng(3)
     for _ in range(100):
