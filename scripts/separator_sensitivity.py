@@ -11,11 +11,14 @@ enumerates them all (oracle/neptune_oracle.c::orc_set_vertex_policy), and each r
   mingap   the admissible vertex with the smallest gap (the opposite extreme of the product's rule)
   worst    per LP the admissible vertex that leaves the max-gap optimum's own control points the least room
   bland    the vertex a textbook two-phase simplex with Bland's rule reaches
+  glpk     the vertex a primal simplex of the class glp_simplex runs by default reaches (standard start basis, projected
+           steepest-edge pricing, Harris ratio test: oracle policy 5 = the product's separator rule 1,
+           nep_batch_set_separator_rule) — the closest stand-in for the reference's own lines this image allows
 
 against the product's rule (largest gap).  A replan is PROVABLY separator-independent when the optimum of its QP without
 any line row satisfies the rows of the worst admissible vertex of every LP: then every choice yields that same point.
 
-  python scripts/separator_sensitivity.py [--replans 200] [--out profiles/r02_separator_sensitivity.txt]
+  python scripts/separator_sensitivity.py [--replans 200] [--out profiles/r03_separator_sensitivity.txt]
 """
 import argparse
 import json
@@ -80,7 +83,7 @@ def study_replan(oracle, scene, sc, a, guess=None):
         indep = rw["n_lp_failed"] == r0["n_lp_failed"] and rows_hold(p, rf["coeff"], K, rw["line_seg"], rw["line_nd"])
     out["provably_independent"] = bool(indep)
     pos0 = oracle.sample(r0["coeff"], T, p.dc)[:, :3]
-    variants = [("random1", 1, 11), ("random2", 1, 22), ("random3", 1, 33), ("mingap", 2, 0), ("worst", 3, 0), ("bland", 4, 0)]
+    variants = [("random1", 1, 11), ("random2", 1, 22), ("random3", 1, 33), ("mingap", 2, 0), ("worst", 3, 0), ("bland", 4, 0), ("glpk", 5, 0)]
     n_lp = n_vert = 0
     for name, pol, seed in variants:
         set_policy(oracle, pol, seed, ref=ctrl_of(r0["coeff"], K, T) if pol == 3 else None)
@@ -88,6 +91,14 @@ def study_replan(oracle, scene, sc, a, guess=None):
         if pol == 1 and seed == 11:
             n_lp, n_vert = policy_stats(oracle)
         rec = {"status": r["status"]}
+        if pol == 5:     # how many of its lines ARE the largest-gap lines (same supporting half-plane of the obstacle side)
+            same = tot = 0
+            if len(r["line_nd"]) == len(r0["line_nd"]) and len(r0["line_nd"]):
+                a_, b_ = r["line_nd"], r0["line_nd"]
+                la = np.column_stack([a_[:, 0], a_[:, 1], a_[:, 2] - 1.0]) / np.hypot(a_[:, 0], a_[:, 1])[:, None]
+                lb = np.column_stack([b_[:, 0], b_[:, 1], b_[:, 2] - 1.0]) / np.hypot(b_[:, 0], b_[:, 1])[:, None]
+                same = int((np.abs(la - lb).max(axis=1) < 1e-9).sum()); tot = len(a_)
+            rec["same_lines"] = same; rec["lines"] = tot
         if r["status"] != 2 and r0["status"] != 2:
             rec["dcost"] = (r["objective"] - r0["objective"]) / (1.0 + abs(r0["objective"]))
             rec["dpos"] = float(np.abs(oracle.sample(r["coeff"], T, p.dc)[:, :3] - pos0).max())
@@ -108,7 +119,7 @@ def summarise(name, recs, lines):
                  % (indep, 100.0 * indep / n, noact, 100.0 * noact / n))
     lines.append("  %-8s %8s %12s %12s %12s %12s %12s %12s" % ("variant", "status!=", "dcost p50", "dcost p99", "dcost max", "dpos p50 m", "dpos p99 m", "dpos max m"))
     worst = {"dcost": 0.0, "dpos": 0.0, "status_changes": 0}
-    for v in ("random1", "random2", "random3", "mingap", "worst", "bland"):
+    for v in ("random1", "random2", "random3", "mingap", "worst", "bland", "glpk"):
         dep = [r for r in recs if not r["provably_independent"]]
         st = sum(r[v]["status"] != r["status0"] for r in recs)
         dc = np.array([abs(r[v]["dcost"]) for r in dep if "dcost" in r[v]]); dp = np.array([r[v]["dpos"] for r in dep if "dpos" in r[v]])
@@ -120,6 +131,11 @@ def summarise(name, recs, lines):
         di = [r[v].get("dpos", 0.0) for r in recs if r["provably_independent"]]
         if di:
             worst.setdefault("indep_dpos", 0.0); worst["indep_dpos"] = max(worst["indep_dpos"], float(max(di)))
+    sl = sum(r["glpk"].get("same_lines", 0) for r in recs); tl = sum(r["glpk"].get("lines", 0) for r in recs)
+    unmoved = sum(1 for r in recs if r["glpk"].get("dpos", 1.0) < 1e-6)
+    lines.append("  glpk: %d of %d lines (%.1f %%) are the largest-gap line; %d of %d replans (%.1f %%) end within 1e-6 m of the max-gap trajectory"
+                 % (sl, tl, 100.0 * sl / max(tl, 1), unmoved, n, 100.0 * unmoved / n))
+    worst["glpk_same_line_frac"] = sl / max(tl, 1); worst["glpk_unmoved_frac"] = unmoved / n
     lines.append("  (the %d provably independent replans moved by at most %.1e m under any variant; statistics above are over the other %d)"
                  % (indep, worst.get("indep_dpos", 0.0), n - indep))
     return worst
@@ -128,8 +144,8 @@ def summarise(name, recs, lines):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--replans", type=int, default=200)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r02_separator_sensitivity.txt"))
-    ap.add_argument("--json", default=os.path.join(ROOT, "profiles", "r02_separator_sensitivity.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03_separator_sensitivity.txt"))
+    ap.add_argument("--json", default=os.path.join(ROOT, "profiles", "r03_separator_sensitivity.json"))
     args = ap.parse_args()
     from neptune_amd import scene
     from oracle import oracle

@@ -152,3 +152,54 @@ def test_failed_first_replan_keeps_the_agent_in_the_obstacle_sets(be):
     ref.replan(ref.to_device(got), ref.to_device(gue))
     assert h.solutions().tobytes() == ref.solutions().tobytes()
     h.close(); ref.close()
+
+
+def test_captured_native_step_equals_the_eager_one(be):
+    """The N > 1 step of bench.py — hulls of my agents, ncclAllGather through the C ABI's binding on a side stream, separator,
+    launch order, QP, for every scene chunk — captured into ONE HIP graph (no Python between the kernels) and replayed must
+    leave exactly the records and solutions of the same steps launched from the host.  One rank here (the collective is
+    degenerate but it is RCCL's kernel that is captured); nep_comm_nranks reports the communicator's size."""
+    from neptune_amd import dist as ndist
+    N, M, S, chunks, steps = 16, 8, 4, 2, 4
+    scenes = [scene.make_scene(N, M, seed=140 + s) for s in range(S)]
+    p = scenes[0]["par"]
+    com, gue = ndist.stack_scenes(scenes)
+    Sc = S // chunks
+
+    def build():
+        bes = []
+        for k in range(chunks):
+            h = be.BatchBackend(p, scenes[k * Sc]["statics"], n_scenes=Sc)
+            for s in range(Sc):
+                h.set_scene_statics(s, scenes[k * Sc + s]["statics"])
+            bes.append(h)
+        d_local = [bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc])) for k in range(chunks)]
+        d_guess = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc])) for k in range(chunks)]
+        return bes, ndist.ShardedRounds(bes, d_local, d_guess, world=1, rank=0, native=True)
+
+    def result(bes, rounds):
+        out = np.concatenate([b.commits() for b in bes]); sol = np.concatenate([b.solutions() for b in bes])
+        rounds.native.close()
+        for b in bes:
+            b.close()
+        return out, sol
+    bes, rounds = build()
+    assert rounds.native.nranks() == 1
+    for _ in range(steps):
+        rounds.step()
+    want_c, want_s = result(bes, rounds)
+
+    bes, rounds = build()
+    T = bes[0].torch
+    rounds.step()                                   # (primes the first chunk's blocks; RCCL's first call sets itself up outside the capture)
+    T.cuda.synchronize()
+    g = T.cuda.CUDAGraph()
+    with T.cuda.graph(g):
+        rounds.step()
+    for _ in range(steps - 1):
+        g.replay()
+    T.cuda.synchronize()
+    got_c, got_s = result(bes, rounds)
+    assert got_c.tobytes() == want_c.tobytes()
+    assert got_s.tobytes() == want_s.tobytes()
+    assert (want_s["stats"]["status"] != 2).all()
