@@ -706,6 +706,7 @@ def main():
         cull5 = b5.line_cull(); kern5 = b5.qp_kernel_name()
         dt6, steps6, ms6, k6, sol6 = c5_leg("default")
         us6 = solve_us_stats(b5)
+        redo6 = {"replans": b5.redo_count(), **b5.redo_reasons}
         _, hn5 = b5.debug_hulls(0)
         ns5 = int(sol6[0]["n_states"])
         ent_b = 4.0 * 8 * N5 + 16.0 * bend5[0].sum()                # the dense case block of one replan + every agent's bend points
@@ -720,7 +721,7 @@ def main():
                    "workload": "256 agents + 100 static obstacles, enable_entangle_check on (synthetic ent_state: one active case for 10 %% of the agent pairs, "
                                "2-4 bend points per agent, SURVEY 8d), K=8, %d seeded scenes in flight (seeds 0..%d)" % (S5, S5 - 1),
                    "replans_per_step": S5 * N5, "qp_kernel": kern5, "line_cull_radius_m": cull5,
-                   "kernel_ms": k6, "solve_us": us6,
+                   "kernel_ms": k6, "solve_us": us6, "presolve_redo_last_step": redo6,
                    "lines_mean": float(sol6["stats"]["n_lines"].mean()), "rows_solved_mean": float(sol6["stats"]["n_rows"].mean()),
                    "ipm_iters_mean": float(sol6["stats"]["iters"].mean()), "ipm_iters_max": int(sol6["stats"]["iters"].max()),
                    "solved_without_iteration": int((sol6["stats"]["iters"] == 0).sum()), "lp_failed": int(sol6["stats"]["n_lp_failed"].sum()),
@@ -746,6 +747,43 @@ def main():
                                     "qp_kernel": kern5f, "kernel_ms": k7, "solve_us": solve_us_stats(b5),
                                     "rows_solved_mean": float(sol7["stats"]["n_rows"].mean()), "ipm_iters_mean": float(sol7["stats"]["iters"].mean()),
                                     "note": "nep_batch_set_line_cull(0): every separating-line row through the interior point", **status_counts(sol7)}
+        if not args.no_chain and not args.config5_only:
+            # the whole chain at this size with the entangle check on: front end with per-node entangle states (guesses AND the
+            # entangle cases are device-made) -> lines + QP -> safety check with the entangle re-check + commit
+            b5.set_line_cull(cull5)
+            cfg5 = scene.frontend_cfg(p5, beam_width=args.beam, entangle=True)
+            for s_ in range(S5):
+                reps_, long_ = scene.static_reps(sc5[s_]["statics"])
+                b5.set_static_reps(reps_, long_, scene=s_)
+            d_st5 = b5.to_device(np.stack([scene.frontend_starts(s_) for s_ in sc5]))
+            d_gf5 = torch.zeros_like(d_g5); d_res5 = torch.zeros(S5 * N5 * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev)
+            d_case5 = torch.zeros(S5 * N5 * abi.NEP_MAX_POL * N5, dtype=torch.int32, device=dev)
+            d_cc5 = b5.to_device(com5); d_nx5 = torch.empty_like(d_cc5); d_ac5 = torch.zeros(S5 * N5, dtype=torch.int32, device=dev)
+            fe5, sf5 = [], []
+
+            def c5_chain_step():
+                e0 = ev()
+                b5.frontend_ent(cfg5, d_cc5, d_st5, d_gf5, d_res5, d_case5)
+                fe5.append((e0, ev()))
+                b5.replan(None, d_gf5, d_ent=d_case5)
+                e1 = ev()
+                b5.safety_commit_ent(d_cc5, b5.d_commit, d_gf5, d_nx5, d_ac5)
+                sf5.append((e1, ev()))
+                d_cc5.copy_(d_nx5)
+            steps8 = max(20, aux_steps // 10)
+            dt8, ms8, _ = run_leg(c5_chain_step, [b5], steps8, 2, eager_after=5, clear=(fe5, sf5))
+            k8 = {n_: b5.kernel_time_ms(i_)[0] for i_, n_ in ((1, "separator"), (2, "qp"))}
+            b5.enable_timing(False)
+            sol8 = b5.solutions(); res8 = d_res5.cpu().numpy().view(abi.FE_RESULT_DTYPE)
+            config5["chain"] = {"value": S5 * N5 * steps8 / dt8, "unit": "replans/s", "steps": steps8, "ms_per_step": dt8 / steps8 * 1e3,
+                                "kernel_ms": {"frontend_ent_with_hulls": mean_ms(fe5), "separator": k8["separator"], "qp": k8["qp"], "safety_ent": mean_ms(sf5)},
+                                "beam_width": args.beam, "frontend_goal_reached": int((res8["status"] == 1).sum()), "frontend_no_solution": int((res8["status"] == 3).sum()),
+                                "children_pruned_by_the_entangle_check": int(res8["n_entangled"].sum()), "ent_overflow": int(res8["ent_overflow"].sum()),
+                                "active_entangle_cases": int((d_case5 != 0).sum().item()),
+                                "ipm_iters_mean": float(sol8["stats"]["iters"].mean()), "accepted_frac": float(d_ac5.float().mean().item()),
+                                "solve_us": solve_us_stats(b5),
+                                "note": "frontend_kernel<true> (entangle states per search node) -> separator + QP on device-made guesses and device-made "
+                                        "entangle cases -> safety check with entangleCheckGivenPwp + commit", **status_counts(sol8)}
         b5.close()
         if args.config5_only:
             print(json.dumps({"metric": "backend_replans_per_sec", "config5": config5, "graph_notes": graph_notes}))

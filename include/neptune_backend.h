@@ -368,6 +368,15 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
  * nep_batch_get_line_cull returns the radius in force.                                                             */
 int nep_batch_set_line_cull(nep_batch_t* h, double radius);
 double nep_batch_get_line_cull(nep_batch_t* h);
+/* With the presolve on (largest-gap rule, batched handle) the separator does not even SOLVE the LPs whose line must be far: a
+ * hull or inflated static whose bounding box is farther than the radius from the box of the guess's control points along x or
+ * y (the sides of those boxes are edges of the polygons, so the largest-gap line lies at least that far away).  Such LPs are
+ * counted as attempted and solved (n_lp, n_lines: sets that far apart are separable) and verified through the distance the
+ * solution's control points moved from the guess's; a replan that does not verify is solved again by a redo pass with every
+ * LP and every row.  The debug line readers do not see lines that were never made.  nep_batch_debug_redo_count: replans
+ * the last call sent through the redo pass (test hook); by_reason (may be NULL) receives how many of them had a parked line
+ * violated [0] and how many moved farther than the radius [1].                                                       */
+int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason);
 
 /* Which vertex of the separating-line LP the separator returns.  The LP (separator_glpk.cpp:248-373) has a zero objective:
  * the reference gets "whatever vertex glp_simplex reaches", and the spline QP's optimum depends on it.

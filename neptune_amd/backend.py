@@ -344,6 +344,13 @@ class BatchBackend:
         """the presolve radius in force (0: off): nep_batch_get_line_cull — on by default for config-5 sized scenes"""
         return float(lib().nep_batch_get_line_cull(self._h))
 
+    def redo_count(self):
+        """replans the last replan sent through the presolve's redo pass (nep_batch_debug_redo_count)"""
+        r = np.zeros(2, dtype=np.int32)
+        n = int(check(lib().nep_batch_debug_redo_count(self._h, abi.iptr(r))))
+        self.redo_reasons = {"parked_line_violated": int(r[0]), "moved_beyond_radius": int(r[1])}
+        return n
+
     def set_separator_rule(self, rule):
         """which vertex of the separating-line LP is returned: 0 largest gap (default), 1 the one a primal simplex of GLPK's
         default class reaches (nep_batch_set_separator_rule)"""

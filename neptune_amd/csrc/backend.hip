@@ -81,6 +81,7 @@ struct Engine {
   DevBuf<double> d_pb, d_static_xy, d_static_el; DevBuf<int> d_static_nv;
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
+  DevBuf<int> d_line_skip, d_redo_list, d_redo_count;   // spatial presolve: skipped LPs per segment, replans listed for the redo pass
   DevBuf<long long> d_dbg; bool profile_phases = false;
   DevBuf<int> d_flags;
   // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
@@ -124,7 +125,7 @@ struct Engine {
   }
   // which interior-point kernel the next replan launches, and its LDS carve (see size_scratch)
   static constexpr double kAutoCullRadius = 4.0;
-  bool fits_reg = true, cull_user_set = false; int lds_lines_lds = 0;
+  bool fits_reg = true, cull_user_set = false, skip_lps = true; int lds_lines_lds = 0;
   void choose_placement() {
     use_reg = fits_reg || sp.cull_radius > 0.0;
     if (const char* f = getenv("NEP_QP_KERNEL")) { if (!strcmp(f, "reg")) use_reg = true; else if (!strcmp(f, "lds")) use_reg = false; }
@@ -165,6 +166,7 @@ struct Engine {
       if (const char* f = getenv("NEP_QP_AUTOCULL")) auto_cull = auto_cull && atoi(f) != 0;
       sp.cull_radius = auto_cull ? kAutoCullRadius : 0.0;
     }
+    if (const char* f = getenv("NEP_SEP_SKIP")) skip_lps = atoi(f) != 0;      // (A/B: 0 solves every LP of a presolved replan too)
     if (const char* f = getenv("NEP_QP_LPT")) lpt = atoi(f) != 0;
     if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; if (int e = d_order_key.ensure((size_t)slots)) return e; }
     choose_placement();
@@ -180,6 +182,9 @@ struct Engine {
     if (int e = d_line_cnt.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_line_far.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_lp_stats.ensure((size_t)slots * NEP_MAX_POL * 2)) return e;   // per (slot, segment): LPs attempted, LPs without a line
+    if (int e = d_line_skip.ensure((size_t)slots * NEP_MAX_POL)) return e;
+    if (int e = d_redo_list.ensure((size_t)slots)) return e;
+    if (!d_redo_count.p) { if (int e = d_redo_count.ensure(4)) return e; HIPCHK(hipMemset(d_redo_count.p, 0, 4 * sizeof(int))); }
     if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 16)) return e; }
@@ -192,6 +197,12 @@ struct Engine {
     ps.bend_xy = d_bend_xy.p; ps.bend_n = d_bend_n.p;
     ps.line_nd = d_line_nd.p; ps.line_cnt = d_line_cnt.p; ps.lp_stats = d_lp_stats.p;
     ps.line_far = sp.cull_radius > 0.0 ? d_line_far.p : nullptr;
+    // LPs whose line is known to be far without solving them are skipped when the presolve is on, the rule is the largest gap
+    // (box far => line far holds for that vertex only), the hull lists are the batch's (one per agent: the boxes are indexed
+    // by agent) and the interior point is the register kernel (the one that verifies them): see separator_body / qp_reg_kernel
+    const bool skip = sp.cull_radius > 0.0 && use_reg && sp.sep_rule == 0 && sp.skip_own == 1 && sp.n_hull == sp.num_agents && skip_lps;
+    ps.skip_box = skip ? d_fe_box.p : nullptr; ps.line_skip = skip ? d_line_skip.p : nullptr;
+    ps.redo_list = skip ? d_redo_list.p : nullptr; ps.redo_count = skip ? d_redo_count.p : nullptr; ps.order_count = nullptr;
     ps.row_scratch = d_row_scratch.p; ps.rows_cap = rows_cap; ps.lds_rows = lds_rows; ps.lds_lines = lds_lines;
     ps.dbg = profile_phases ? d_dbg.p : nullptr;
     ps.flags = d_flags.p;
@@ -285,7 +296,10 @@ struct Engine {
     if (timing) hipEventRecord(next_event(), st);
     if (d_recs) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st);
     if (timing) hipEventRecord(next_event(), st);
+    if (ps.lines_override) { ps.skip_box = nullptr; ps.line_skip = nullptr; ps.redo_list = nullptr; ps.redo_count = nullptr; }
+    const bool skip = ps.skip_box != nullptr;
     if (!ps.lines_override) {
+      if (skip) { launch_boxes(n_scenes, sp, ps, st); HIPCHK(hipMemsetAsync(d_redo_count.p, 0, 4 * sizeof(int), st)); }
       launch_separator(slots, sp, ps, st);
     }
     if (timing) hipEventRecord(next_event(), st);
@@ -297,6 +311,14 @@ struct Engine {
     }
     if (use_reg) launch_qp_reg(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     else launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
+    if (skip) {
+      // the presolve's redo pass: replans whose solution did not verify the skipped / parked lines (listed by the kernel above; the
+      // list is empty nearly always) get every LP solved and every row through the interior point
+      launch_separator_redo(slots, sp, ps, st);
+      ProblemSet pr = ps;
+      pr.line_far = nullptr; pr.line_skip = nullptr; pr.order = d_redo_list.p; pr.order_count = d_redo_count.p;
+      launch_qp_reg(slots, sp, pr, d_tables.p, sc, lds_bytes, st);
+    }
     have_history = ps.order_key != nullptr;
     if (timing) hipEventRecord(next_event(), st);
     HIPCHK(hipGetLastError());
@@ -306,7 +328,7 @@ struct Engine {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_box.release();
     d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release();
-    d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
+    d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
   }
@@ -950,6 +972,16 @@ int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static,
   if (!h || scene < 0 || scene >= h->cfg.n_scenes || n_static < 0 || (n_static > 0 && (!static_off || !static_xy))) return fail(NEP_E_ARG, "bad arguments");
   HIPCHK(hipDeviceSynchronize());     // the previous set may still be read by kernels in flight
   return h->eng.upload_scene_statics(scene, n_static, static_off, static_xy);
+}
+
+// Test hook: replans the last nep_batch_replan* sent through the presolve's redo pass (0 when LP skipping is off).
+int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  int n[4] = {0, 0, 0, 0};
+  HIPCHK(hipDeviceSynchronize());
+  if (h->eng.d_redo_count.p) HIPCHK(hipMemcpy(n, h->eng.d_redo_count.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+  if (by_reason) { by_reason[0] = n[1]; by_reason[1] = n[2]; }
+  return n[0];
 }
 
 int nep_batch_qp_placement(nep_batch_t* h) { return h ? (h->eng.use_reg ? 1 : 0) : NEP_E_ARG; }

@@ -668,9 +668,21 @@ struct SepCtx {
   const SceneParams* sp; const ProblemSet* ps;
   int slot, scene, own, N, S, nH, total;
   double el[3];          // lengths of the control polygon's three edges (the terms of hulldist)
+  double bb[4];          // box of the segment's four control points (x0, x1, y0, y1): the spatial presolve's far test
+  const double* skip_box; // boxes of the hulls / statics (fe_box_kernel) when far LPs may be skipped, else null
+  double skip_r;
 };
+// Spatial presolve (cx.skip_box != null): is polygon j's box farther than skip_r from the box of the segment's control points along
+// x or along y?  Hulls and inflated statics are hulls of axis-aligned squares, so the sides of their boxes are EDGES of the
+// polygon: the largest-gap line of such a pair has a gap of at least the box distance, i.e. it lies farther than skip_r from
+// every control point of the guess — the LP need not be solved to know that its line is "far" (separator_body).
+__device__ __forceinline__ bool box_far(const SepCtx& cx, int seg, int jbox) {
+  const double* b = cx.skip_box + (((long)cx.scene * (cx.N + cx.S) + jbox) * cx.sp->num_pol + seg) * 4;
+  const double x0 = b[0], x1 = b[1], y0 = b[2], y1 = b[3];
+  return (x0 - cx.bb[1] > cx.skip_r) | (cx.bb[0] - x1 > cx.skip_r) | (y0 - cx.bb[3] > cx.skip_r) | (cx.bb[2] - y1 > cx.skip_r);
+}
 __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, const double* by, double hulldist,
-                          int mode, double2* myA, int& nA, int& ordered, const double2*& Ause) {
+                          int mode, double2* myA, int& nA, int& ordered, const double2*& Ause, bool* skip = nullptr) {
   const bool stage = mode == 1, cull_tests = mode == 0;   // mode 0: the reference's proximity culls; 1: stage the point set (myA, or in place when null); 2: vertex count only
   const SceneParams& sp = *cx.sp; const ProblemSet& ps = *cx.ps;
   const int N = cx.N, S = cx.S, nH = cx.nH;
@@ -683,6 +695,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     nA = blk(ps.hull_nv, hr.boff)[h];
     if (nA <= 0) return false;
     ordered = 1;
+    if (skip && cx.skip_box) *skip = box_far(cx, seg, j);
     if (stage) {
       const double2* src = (const double2*)(blk(ps.hull_xy, hr.boff) + h * kHullV * 2);
       if (myA) for (int v = 0; v < nA; v++) myA[v] = src[v]; else Ause = src;
@@ -737,6 +750,7 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
       if (!close_s) return false;
     }
     ordered = 1; nA = nv;
+    if (skip && cx.skip_box) *skip = box_far(cx, seg, N + (c - nH - N));
     if (stage) { if (myA) for (int v = 0; v < nv; v++) myA[v] = make_double2(src[2 * v], src[2 * v + 1]); else Ause = (const double2*)src; }
     return true;
   } else if (c < cx.total) {
@@ -775,20 +789,23 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
 // (with 63 other agents that is one full round plus a short tail instead of three rounds).  Line l
 // lands in bucket (slot, seg) at its call rank; an LP without a separating line leaves (0,0,0)
 // there — the QP kernel reads that as "constraint skipped" (solver_gurobi_poly.cpp:491-494).
+// presolve: the handle's line presolve is on for this launch (sp.cull_radius > 0): lines far from the guess are parked, and LPs
+// whose line is known to be far without solving them (box_far) are not solved at all — they are counted as attempted and
+// solved (two point sets more than skip_r apart are separable), their number goes to ps.line_skip, and the QP kernel verifies
+// them through the distance its solution moved from the guess (qp_reg_kernel).  presolve = false: every LP, every line in call
+// order — the reference's loop, and what the redo pass runs for a replan whose presolve did not verify.
 template <int RULE>
-__global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParams sp, ProblemSet ps, int pool_pairs) {
+__device__ __forceinline__ void separator_body(const SceneParams& sp, const ProblemSet& ps, int pool_pairs, int slot, int seg, bool presolve) {
   extern __shared__ __attribute__((aligned(16))) double sdyn[];
   double2* sA = (double2*)sdyn;                      // [pool_pairs] (x,y) pairs: the batch's point sets A, packed
   double* sBx = sdyn + 2 * pool_pairs; double* sBy = sBx + 4;
   unsigned short* sAtt = (unsigned short*)(sBy + 4);
   const int lane = threadIdx.x;
-  const int seg = blockIdx.x % NEP_MAX_POL;
-  const int slot = blockIdx.x / NEP_MAX_POL;
   const nep_guess* g = ps.guess + slot;
   const int K = g->K;
   int* cnt_out = ps.line_cnt + (long)slot * NEP_MAX_POL + seg;
   int* lp_out = ps.lp_stats + ((long)slot * NEP_MAX_POL + seg) * 2;      // every wave writes its own pair: no memset, no atomics
-  if (seg >= K || seg >= sp.num_pol) { if (lane == 0) { *cnt_out = 0; lp_out[0] = 0; lp_out[1] = 0; if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = 0; } return; }
+  if (seg >= K || seg >= sp.num_pol) { if (lane == 0) { *cnt_out = 0; lp_out[0] = 0; lp_out[1] = 0; if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = 0; if (ps.line_skip) ps.line_skip[(long)slot * NEP_MAX_POL + seg] = 0; } return; }
   const double T = sp.T_span;
   SepCtx cx; cx.sp = &sp; cx.ps = &ps; cx.slot = slot; cx.scene = slot / sp.n_local; cx.own = sp.first_local + (slot % sp.n_local);
   cx.N = sp.num_agents; cx.S = sp.n_static; cx.nH = sp.n_hull;
@@ -805,16 +822,43 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
   const double* bx = sBx; const double* by = sBy;
   double hulldist = 0;  // :738-742
   for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; cx.el[k] = sqrt(ex * ex + ey * ey); hulldist += cx.el[k]; }
+  cx.bb[0] = fmin(fmin(bx[0], bx[1]), fmin(bx[2], bx[3])); cx.bb[1] = fmax(fmax(bx[0], bx[1]), fmax(bx[2], bx[3]));
+  cx.bb[2] = fmin(fmin(by[0], by[1]), fmin(by[2], by[3])); cx.bb[3] = fmax(fmax(by[0], by[1]), fmax(by[2], by[3]));
+  // (the largest-gap rule is what guarantees "box far => line far"; a simplex-reached vertex may lie anywhere between the sets)
+  cx.skip_box = (presolve && RULE == 0 && sp.cull_radius > 0.0 && ps.line_far != nullptr) ? ps.skip_box : nullptr; cx.skip_r = sp.cull_radius;
   // ---- step 1: which LPs does the reference call, in order -------------------------------------
-  int n_att = 0;
-  for (int c0 = 0; c0 < total; c0 += 64) {
+  int n_att = 0, n_skip = 0;                              // LPs to solve (listed), LPs known to give a far line (counted only)
+  const int n_plain = cx.nH + cx.N + cx.S;                // hulls, bases, statics: one candidate per lane and round
+  for (int c0 = 0; c0 < n_plain; c0 += 64) {
     const int c = c0 + lane;
-    int nA; int ord;
+    int nA; int ord; bool skp = false;
     const double2* unused = nullptr;
-    const bool att = c < total && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused);
-    const unsigned long long mask = __ballot(att);
-    if (att) sAtt[n_att + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)c;
+    const bool att = c < n_plain && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused, &skp);
+    const unsigned long long mask = __ballot(att && !skp);
+    if (att && !skp) sAtt[n_att + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)c;
     n_att += __popcll(mask);
+    n_skip += __popcll(__ballot(att && skp));
+  }
+  // Entangle candidates (agent j, bend segment k), the reference's double loop (:624-636): one lane per AGENT — nine in ten
+  // have no active case and are done after one load — instead of one lane per (j, k) pair, which at config 5 was 32 of a
+  // segment's 42 rounds.  A lane collects the k it would call as a bit mask; a prefix sum over the wave appends them in (j, k)
+  // order, the order of the one-pair-per-lane enumeration.
+  for (int j0 = 0; n_plain < total && j0 < cx.N; j0 += 64) {
+    const int j = j0 + lane;
+    unsigned m = 0;
+    if (j < cx.N && j != cx.own && ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * cx.N + j] != 0) {
+      for (int k = 0; k < kBend; k++) {
+        int nA; int ord; const double2* unused = nullptr;
+        if (cand_eval(cx, seg, n_plain + j * kBend + k, bx, by, hulldist, 0, nullptr, nA, ord, unused)) m |= 1u << k;
+      }
+    }
+    const int cnt = __popc(m);
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+    int pos = n_att + incl - cnt;
+    for (unsigned mm = m; mm; mm &= mm - 1) sAtt[pos++] = (unsigned short)(n_plain + j * kBend + (__ffs(mm) - 1));
+    n_att += __shfl(incl, 63);
   }
   __syncthreads();
   // ---- step 2: the LPs ---------------------------------------------------------------------------
@@ -827,7 +871,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
   // the guess is parked at the back of the bucket ("far") and left out of the QP; the QP kernel verifies them against
   // its solution and re-solves with every line if one is violated, so the optimum is unchanged.  Near lines keep
   // their order at the front; far lines are written from the end of the bucket, in order of appearance.
-  const bool cull = sp.cull_radius > 0.0 && ps.line_far != nullptr;
+  const bool cull = presolve && sp.cull_radius > 0.0 && ps.line_far != nullptr;
   int n_near = 0, n_far = 0;                              // wave-uniform running counts
   for (int a0 = 0; a0 < n_att; a0 += 64) {
     const int a = a0 + lane;
@@ -873,7 +917,23 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
   if (lane == 0) {
     *cnt_out = cull ? n_near : (n_att < sp.lines_cap ? n_att : sp.lines_cap);
     if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = cull ? n_far : 0;
-    lp_out[0] = n_att; lp_out[1] = n_fail;
+    if (ps.line_skip) ps.line_skip[(long)slot * NEP_MAX_POL + seg] = n_skip;
+    lp_out[0] = n_att + n_skip; lp_out[1] = n_fail;
+  }
+}
+template <int RULE>
+__global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParams sp, ProblemSet ps, int pool_pairs) {
+  separator_body<RULE>(sp, ps, pool_pairs, blockIdx.x / NEP_MAX_POL, blockIdx.x % NEP_MAX_POL, true);
+}
+// The redo pass of the presolve: every segment of the replans the QP kernel listed (ps.redo_list / ps.redo_count: a parked
+// line violated, or the solution moved farther from the guess than the skipped LPs allow) with every LP solved and every line
+// in call order, for the full re-solve that follows.  A fixed small grid walks the list (it is empty nearly always).
+template <int RULE>
+__global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_redo_kernel(SceneParams sp, ProblemSet ps, int pool_pairs) {
+  const int n = *ps.redo_count * NEP_MAX_POL;
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    separator_body<RULE>(sp, ps, pool_pairs, ps.redo_list[i / NEP_MAX_POL], i % NEP_MAX_POL, false);
+    __syncthreads();
   }
 }
 
@@ -902,6 +962,19 @@ void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, 
   } else {
     (void)attr[0].ensure((const void*)separator_kernel<0>, lds);
     hipLaunchKernelGGL(separator_kernel<0>, dim3(n_slots * NEP_MAX_POL), dim3(64), lds, st, sp, ps, separator_pool_pairs(sp));
+  }
+}
+void launch_separator_redo(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
+  if (n_slots <= 0 || !ps.redo_count || !ps.redo_list) return;
+  const size_t lds = separator_lds_bytes(sp);
+  static DynLdsAttr attr[2];
+  const int grid = n_slots * NEP_MAX_POL < 1024 ? n_slots * NEP_MAX_POL : 1024;
+  if (sp.sep_rule == 1) {
+    (void)attr[1].ensure((const void*)separator_redo_kernel<1>, lds);
+    hipLaunchKernelGGL(separator_redo_kernel<1>, dim3(grid), dim3(64), lds, st, sp, ps, separator_pool_pairs(sp));
+  } else {
+    (void)attr[0].ensure((const void*)separator_redo_kernel<0>, lds);
+    hipLaunchKernelGGL(separator_redo_kernel<0>, dim3(grid), dim3(64), lds, st, sp, ps, separator_pool_pairs(sp));
   }
 }
 
@@ -1340,6 +1413,11 @@ __global__ __launch_bounds__(256) void fe_box_kernel(SceneParams sp, ProblemSet 
   double* o = ps.fe_box + t * 4;
   o[0] = x0; o[1] = x1; o[2] = y0; o[3] = y1;
 }
+// (also what the separator's spatial presolve reads: ps.skip_box)
+void launch_boxes(int n_scenes, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
+  const long nb = (long)n_scenes * (sp.num_agents + sp.n_static) * sp.num_pol;
+  if (nb > 0) hipLaunchKernelGGL(fe_box_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, sp, ps, n_scenes);
+}
 
 template <bool ENT>
 __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
@@ -1736,11 +1814,7 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
   const bool ent = ea != nullptr;
   (void)attr[ent].ensure(ent ? (const void*)frontend_kernel<true> : (const void*)frontend_kernel<false>, lds);
   FeEntArgs none{};
-  {
-    const int n_scenes = n_slots / (sp.n_local > 0 ? sp.n_local : 1);
-    const long nb = (long)n_scenes * (sp.num_agents + sp.n_static) * sp.num_pol;
-    hipLaunchKernelGGL(fe_box_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, sp, ps, n_scenes);
-  }
+  launch_boxes(n_slots / (sp.n_local > 0 ? sp.n_local : 1), sp, ps, st);
   if (ent) hipLaunchKernelGGL(frontend_kernel<true>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
   else hipLaunchKernelGGL(frontend_kernel<false>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
 }

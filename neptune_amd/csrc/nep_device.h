@@ -63,6 +63,13 @@ struct ProblemSet {
   int* line_cnt;                 // [slots][NEP_MAX_POL]  lines at the front of the bucket (all of them, or the near ones)
   int* line_far;                 // [slots][NEP_MAX_POL]  presolved-away lines parked at the back of the bucket, or null
   int* lp_stats;                 // [slots][NEP_MAX_POL][2]  (LPs attempted, LPs without a line) per segment, written by the separator
+  // spatial presolve (line presolve on, largest-gap rule, batched hull layout): LPs whose line is known to be far from the guess
+  // without solving them are skipped; a replan whose solution does not verify them is listed for the redo pass
+  const double* skip_box;        // = fe_box when LPs may be skipped, else null
+  int* line_skip;                // [slots][NEP_MAX_POL] LPs skipped per segment, or null
+  int* redo_list;                // [slots] replans to solve again with every LP and every row, or null
+  int* redo_count;               // [1]
+  const int* order_count;        // [1] or null: only the first *order_count workgroups of the QP launch have work (the redo pass)
   int lines_override;            // 1: line buckets were filled by the host (test hook)
   const int* order;              // [slots] workgroup -> slot (longest expected solve first, see order_kernel) or null: identity
   int* order_key;                // [slots] this launch's measured device time in 8 us bins (the next launch's ordering key) or null
@@ -123,6 +130,8 @@ void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start,
                            double T_span, double drone_radius, double* hull_xy, int* hull_nv,
                            double* hull0_xy, int* hull0_nv, int* flags, hipStream_t st);
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
+void launch_separator_redo(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
+void launch_boxes(int n_scenes, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
 void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy, const int* b_off,
                                const double* b_xy, double* nd, int* solved, int rule, hipStream_t st);
 void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,

@@ -63,7 +63,8 @@ constexpr int oTheta = oCoef + 96;          // [3][8][4] result
 constexpr int oInit = oTheta + 96;          // [3][3] b0,c0,d0 per axis
 constexpr int oScal = oInit + 9;            // scalars, see enum
 constexpr int oRed = oScal + 32;            // [3][16] reduction scratch (one slot per reduction of an iteration)
-constexpr int oFixedEnd = oRed + 48;
+constexpr int oU = oRed + 48;               // [24] D^-1 g of the terminal ball row (Sherman-Morrison, qp_reg_kernel) + [8] its dot products
+constexpr int oFixedEnd = oU + 32;
 constexpr int kFixedDoubles = (oFixedEnd + 1) & ~1;
 
 enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigKeep, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2, sBestMerit };
@@ -104,6 +105,14 @@ __device__ __forceinline__ double wave_max(double v) {
   return fmax(fmax(bcast(v, 0), bcast(v, 16)), fmax(bcast(v, 32), bcast(v, 48)));
 }
 
+
+// MINVO position basis inverse on [0, 1] (mader_types.hpp:152-157 inverted; the literals of nep_tables.h::kAPosInv): the guess's
+// control points, for the presolve's movement test
+__constant__ double cQpAPosInv[4][4] = {
+    {-0.03203276669713047, -0.09273093424558249, 0.3420572455666699, 1.1023313949144335},
+    {-0.05111494245568798, -0.046272612998418894, 0.5458234872124772, 1.0979806946005568},
+    {-0.07454781852812224, 0.203951949894552, 0.796048050105448, 1.0745478185281223},
+    {1.0, 1.0, 0.9999999999999996, 0.9999999999999993}};
 
 // x / d for 0 <= x < 1024 and a wave-uniform 1 <= d <= 64 as one multiply and a shift (exact in that range; the magic numbers
 // come from constant memory through the scalar unit).  A real integer division expands to a float reciprocal sequence on

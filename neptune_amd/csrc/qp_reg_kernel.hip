@@ -55,6 +55,15 @@
 #ifndef NEP_QP_CACHE_IS
 #define NEP_QP_CACHE_IS 0
 #endif
+// 1: the terminal ball row (a rank-one term w g g' that couples the three axes) is taken out of the normal matrix and put back
+// by the Sherman-Morrison formula: with D = M - w g g' block diagonal (x, y | z), x = y - u (w g'y) / (1 + w g'u), y = D^-1 b,
+// u = D^-1 g — the two blocks are factored in registers on two waves as for a replan without the row (sizes 12 and 6 at
+// K = 8), one more substitution per iteration for u, one barrier more per solve.  0: the coupled 3 nz x 3 nz matrix, which
+// at K = 8 (18 x 18, relaxed solve 24 x 24) is factored out of LDS at 1.5-3 x the iteration's duration.  Replans near their
+// goal all have the row: a fifth of a closed loop's replans and its stragglers (bench.py's `moving` leg).
+#ifndef NEP_QP_BALL_SM
+#define NEP_QP_BALL_SM 1
+#endif
 
 namespace nep {
 #if NEP_QP_CACHE_IS == 2
@@ -81,6 +90,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   int* sI = (int*)(smem + kFixedDoubles);      // [0..8] line offsets, [16..] flags (same map as qp_kernel)
 
   const int tid = threadIdx.x;
+  if (ps.order_count && (int)blockIdx.x >= *ps.order_count) return;     // (the presolve's redo pass: a list that is empty nearly always)
   const int slot = ps.order ? ps.order[blockIdx.x] : (int)blockIdx.x;   // (launch order: see order_kernel)
   const long long t_wg0 = (long long)wall_clock64();          // this workgroup's lifetime goes to stats.solve_us (wall-clock ticks: sp.us_per_tick)
   const nep_guess* __restrict__ g = ps.guess + slot;
@@ -149,18 +159,19 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     __syncthreads();
     if (attempt == 0) stage_tables(tables + K, otid());         // the first solve's tables travel together with the line counts and the lines: one global latency instead of two
     if (tid <= NEP_MAX_POL) {   // line offsets per segment: nine threads read the eight counts (the same two cache lines) and each keeps its own prefix — one round trip and one barrier
-      int o = 0, nf = 0, all = 0, over = 0, my_o = 0, my_nf = 0, my_cn = 0, my_cf = 0;
+      int o = 0, nf = 0, all = 0, over = 0, my_o = 0, my_nf = 0, my_cn = 0, my_cf = 0, nsk = 0;
 #pragma unroll
       for (int i = 0; i < NEP_MAX_POL; i++) {
         const int cn = (i < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + i] : 0;
         const int cf = (i < K && CULL) ? ps.line_far[(long)slot * NEP_MAX_POL + i] : 0;
+        const int cs = (i < K && CULL && ps.line_skip) ? ps.line_skip[(long)slot * NEP_MAX_POL + i] : 0;   // LPs the separator did not solve: their lines are known to be far (spatial presolve)
         if (i == tid) { my_o = o; my_nf = nf; my_cn = cn; my_cf = cf; }
         const int ct = cn + (use_far ? cf : 0);
         over |= ct > 8 * RS ? 1 : 0;
-        o += ct; nf += cf; all += cn + cf;
+        o += ct; nf += cf; all += cn + cf + cs; nsk += cs;
       }
       if (tid < NEP_MAX_POL) { sI[tid] = my_o; sI[52 + tid] = my_nf; sI[44 + tid] = my_cn; sI[32 + tid] = my_cf; }
-      else { sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0; sI[43] = over; }
+      else { sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0; sI[43] = over; sI[40] = nsk; sI[25] = 0; }
     }
     __syncthreads();
     // (values every thread reads from LDS are wave-uniform: readfirstlane moves them, and what is computed from them, to SGPRs)
@@ -435,7 +446,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
 
         double* redA = sRed; double* redP2 = sRed + 16; double* redP5 = sRed + 32;
         TICK(15);
-        const int n0 = has_qc ? n : 2 * nz;                       // wave 0 factors this block, wave 1 the z block
+        const int n0 = (has_qc && !NEP_QP_BALL_SM) ? n : 2 * nz;  // wave 0 factors this block, wave 1 the z block
+        const bool qc_full = has_qc && !NEP_QP_BALL_SM;           // the ball row inside the matrix (coupled system on wave 0)
+        const bool qc_sm = has_qc && NEP_QP_BALL_SM;              // ... or put back after the block solves
+        double* sU = smem + oU; double* sUd = smem + oU + 24;     // D^-1 g; [0..1] g'u (xy, z), [2..3] g'y of the predictor, [4..5] of the corrector
         for (it = 0; it < kMaxIt && !uncon; it++) {
           // ---- (A1) apply the previous step to the row state; (A2) residuals / weights / scatter onto base rows.  Two sweeps
           // over the rows instead of one: the step needs the two direction projections, the scatter seven accumulators — together
@@ -556,7 +570,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
                   double v = acc0[r] + acc1[r];
                   const int mi = bi_ * nz + ci, mj = bj_ * nz + cj;
                   if (sel != 1) v += sHax[ci * kNZ + cj];
-                  if (has_qc) { v += sc[sWq] * sGq[mi] * sGq[mj]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
+                  if (has_qc) { if (qc_full) v += sc[sWq] * sGq[mi] * sGq[mj]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
                   sM[mi * MS + mj] = v;
                 }
               }
@@ -657,12 +671,12 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               const int bi_ = sel == 0 ? 0 : (sel == 3 ? 2 : 1), bj_ = sel == 0 || sel == 1 ? 0 : (sel == 2 ? 1 : 2);
               const int mi = bi_ * nz + ci, mj = bj_ * nz + cj;
               if (sel != 1) v += sHax[ci * kNZ + cj];
-              if (has_qc) { v += sc[sWq] * sGq[mi] * sGq[mj]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
+              if (has_qc) { if (qc_full) v += sc[sWq] * sGq[mi] * sGq[mj]; if (sel != 1) v += sc[sLq] * 2 * sEp[ci] * sEp[cj]; }
               sM[mi * MS + mj] = v;
             }
           }
 #endif
-          if (has_qc) {   // z-x and z-y blocks: only the ball row couples z to x and y (without it the two diagonal blocks are factored apart and these entries are never read)
+          if (qc_full) {   // z-x and z-y blocks: only the ball row couples z to x and y (without it the two diagonal blocks are factored apart and these entries are never read)
             for (int e = otid(); e < 2 * nz * nz; e += BS) {
               const int qi = div_small(e, 2 * nz), i = 2 * nz + qi, j = e - qi * 2 * nz;
               sM[i * MS + j] = sc[sWq] * sGq[i] * sGq[j];
@@ -683,6 +697,13 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             if (t < n0) { b = -sRd[t] + sRhs[t]; if (has_qc) b += sGq[t] * (sc[sLq] - sc[sWq] * sc[sRpq]); }
             b = solve_n(sMl, sInvDl, (lds_dptr)(unsigned)(lds0 + oRed * 8), n0, t, b);
             if (t < n0) sDxa[t] = b;
+            if (qc_sm) {   // u = D^-1 g on this block, and the two dot products the rank-one correction needs
+              const double gt = t < n0 ? sGq[t] : 0.0;
+              const double u = solve_n(sMl, sInvDl, (lds_dptr)(unsigned)(lds0 + oRed * 8), n0, t, gt);
+              if (t < n0) sU[t] = u;
+              const double gu = wave_sum(t < n0 ? gt * u : 0.0), gy = wave_sum(t < n0 ? gt * b : 0.0);
+              if (t == 0) { sUd[0] = gu; sUd[2] = gy; }
+            }
             TICK(3);
           } else if (tid < 128) {
             const int t = otid(), l1 = t - 64;
@@ -705,13 +726,21 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             }
             if (l1 == 0) { sc[sObj] = o; if (flag == 2) sc[sObjLoose] = o; sI[18] = flag; }
             bool chol_ok = true;
-            if (!has_qc && flag != 1 && flag != 3) {             // (uniform across the wave)
+            if (!qc_full && flag != 1 && flag != 3) {             // (uniform across the wave)
               const lds_dptr sMz = (lds_dptr)(unsigned)(lds0 + (oM + 2 * nz * MS + 2 * nz) * 8), sInvDz = (lds_dptr)(unsigned)(lds0 + (oInvD + 2 * nz) * 8);
               chol_ok = chol_n(sMz, sInvDz, nz, l1);
               __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
               double b = l1 < nz ? -sRd[2 * nz + l1] + sRhs[2 * nz + l1] : 0.0;
+              if (qc_sm && l1 < nz) b += sGq[2 * nz + l1] * (sc[sLq] - sc[sWq] * sc[sRpq]);
               b = solve_n(sMz, sInvDz, (lds_dptr)(unsigned)(lds0 + (oRed + 24) * 8), nz, l1, b);
               if (l1 < nz) sDxa[2 * nz + l1] = b;
+              if (qc_sm) {
+                const double gt = l1 < nz ? sGq[2 * nz + l1] : 0.0;
+                const double u = solve_n(sMz, sInvDz, (lds_dptr)(unsigned)(lds0 + (oRed + 24) * 8), nz, l1, gt);
+                if (l1 < nz) sU[2 * nz + l1] = u;
+                const double gu = wave_sum(l1 < nz ? gt * u : 0.0), gy = wave_sum(l1 < nz ? gt * b : 0.0);
+                if (l1 == 0) { sUd[1] = gu; sUd[3] = gy; }
+              }
             }
             if (l1 == 0) sI[20] = chol_ok ? 1 : 0;
           }
@@ -722,6 +751,12 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           if (flag == 3) break;
           if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
           if (!__builtin_amdgcn_readfirstlane(sI[19]) || !__builtin_amdgcn_readfirstlane(sI[20])) break;
+          if (qc_sm) {   // the rank-one term back in: x = y - u (w g'y) / (1 + w g'u)
+            const double wq = sc[sWq];
+            const double cA = wq * (sUd[2] + sUd[3]) / (1.0 + wq * (sUd[0] + sUd[1]));
+            if (tid < n) sDxa[tid] = __builtin_fma(-cA, sU[tid], sDxa[tid]);
+            __syncthreads();
+          }
           // ---- (P2) affine step: ratio test, mu_aff, corrector right-hand side split as va - sigma mu vb (see qp_kernel) ----
           // (nopred: this iteration repeats the previous one with its predictor discarded — kCorrMinStep, below: every pass
           // that re-derives the second-order term does so from uab / uax / uay, so zeroing the three is all it takes)
@@ -757,7 +792,13 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             if ((t & 7) == 0) { double* o = sAccL + (t >> 3) * 8; o[5] = vax; o[6] = vay; o[0] = vbx; o[1] = vby; }
             if (t == BS - 1 && has_qc) {
               const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
-              double gd = 0; if (!nopred) for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
+              double gd = 0;
+              if (!nopred) {
+                // (with the rank-one term put back by the Sherman-Morrison formula g'x is known in closed form, g'y / (1 + w g'u):
+                // summed from the corrected vector it would be the small difference of two large dot products)
+                if (qc_sm) gd = (sUd[2] + sUd[3]) / (1.0 + wq * (sUd[0] + sUd[1]));
+                else for (int e = 0; e < n; e++) gd += sGq[e] * sDxa[e];
+              }
               const double dsq = -rpq - gd, dlq = -lq + wq * (rpq + gd);
               sc[sDsqA] = dsq; sc[sDlqA] = dlq;
               rmax = fmax(rmax, fmax(-dsq / sq, -dlq / lq));
@@ -812,7 +853,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const int t = otid();
             const bool w0 = t < 64;
             const int o = w0 ? t : 2 * nz + (t - 64);
-            const bool mine = w0 ? t < n0 : (!has_qc && t - 64 < nz);
+            const bool mine = w0 ? t < n0 : (!qc_full && t - 64 < nz);
             double b = 0;
             if (mine) {
               b = -sRd[o] + sRhs[o];
@@ -821,12 +862,19 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             if (w0) {
               const lds_dptr sMl = (lds_dptr)(unsigned)(lds0 + oM * 8), sInvDl = (lds_dptr)(unsigned)(lds0 + oInvD * 8);
               b = solve_n(sMl, sInvDl, (lds_dptr)(unsigned)(lds0 + oRed * 8), n0, t, b); if (mine) sDx[o] = b;
-            } else if (!has_qc) {
+            } else if (!qc_full) {
               const lds_dptr sMz = (lds_dptr)(unsigned)(lds0 + (oM + 2 * nz * MS + 2 * nz) * 8), sInvDz = (lds_dptr)(unsigned)(lds0 + (oInvD + 2 * nz) * 8);
               b = solve_n(sMz, sInvDz, (lds_dptr)(unsigned)(lds0 + (oRed + 24) * 8), nz, t - 64, b); if (mine) sDx[o] = b;
             }
+            if (qc_sm) { const double gy = wave_sum(mine ? sGq[o] * b : 0.0); if ((t & 63) == 0) sUd[4 + (t >> 6)] = gy; }
           }
           __syncthreads();                                                                       // barrier 7
+          if (qc_sm) {
+            const double wq = sc[sWq];
+            const double cB = wq * (sUd[4] + sUd[5]) / (1.0 + wq * (sUd[0] + sUd[1]));
+            if (tid < n) sDx[tid] = __builtin_fma(-cB, sU[tid], sDx[tid]);
+            __syncthreads();
+          }
           TICK(7);
           // ---- (P5) step length of the combined direction ------------------------------------------
           rmax = 0;
@@ -847,7 +895,9 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             for_rows(sl, ll, il, [&](bool ok, double n1, double n2, double h, double& s, double& lam, isd_t& isv) { rowP5(ok, s, lam, n1 * cpx + n2 * cpy, n1 * uax + n2 * uay, n1 * udx + n2 * udy, h, isv); });
             if (t == BS - 1 && has_qc) {
               const double sq = sc[sSq], lq = sc[sLq], wq = sc[sWq], rpq = sc[sRpq];
-              double gd = 0; for (int e = 0; e < n; e++) gd += sGq[e] * sDx[e];
+              double gd = 0;
+              if (qc_sm) gd = (sUd[4] + sUd[5]) / (1.0 + wq * (sUd[0] + sUd[1]));
+              else for (int e = 0; e < n; e++) gd += sGq[e] * sDx[e];
               const double rcq = sq * lq - sm + sc[sDsqA] * sc[sDlqA];
               const double dsq = -rpq - gd, dlq = -rcq / sq + wq * (rpq + gd);
               sc[sDsq] = dsq; sc[sDlq] = dlq;
@@ -891,7 +941,9 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     }
     __syncthreads();
     if (!CULL) break;
-    if (use_far || __builtin_amdgcn_readfirstlane(sI[41]) == 0 || status == NEP_FAILED) break;
+    if (use_far || status == NEP_FAILED) break;
+    const int n_skip = __builtin_amdgcn_readfirstlane(sI[40]);
+    if (__builtin_amdgcn_readfirstlane(sI[41]) == 0 && n_skip == 0) break;
     {  // the far lines against the solution: position control points from the base rows of the converged mode
       const QpTable* __restrict__ tbv = tables + status * (kMaxK + 1) + K;
       const int nzv = tbv->nz;
@@ -900,6 +952,18 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         double v = sOff[rho * 3 + ax];
         for (int c = 0; c < nzv; c++) v = __builtin_fma(sB[rho * SBS + c], sZ[ax * nzv + c], v);
         sAccL[rho * 2 + ax] = v;
+        if (n_skip > 0) {
+          // The LPs the separator skipped have lines farther than cull_radius from every control point of the GUESS (their
+          // point sets' boxes are that far apart and the box sides are polygon edges: separator_body).  A solution control point
+          // that stays within cull_radius of the guess's — a point of the guess's control polygon — is therefore on the right
+          // side of every one of them: nothing to evaluate.  One that moved farther sends the replan to the redo pass.
+          const int sg = rho >> 2, k = rho & 3;
+          const double* P = sCoef + (ax * 8 + sg) * 4;
+          const double gq = ((P[0] * ((T * T * T) * cQpAPosInv[0][k]) + P[1] * ((T * T) * cQpAPosInv[1][k])) + P[2] * (T * cQpAPosInv[2][k])) + P[3] * cQpAPosInv[3][k];
+          double d2 = (v - gq) * (v - gq);
+          d2 += dpp<DPP_XOR1>(d2);                        // (x and y of a control point sit on neighbouring lanes)
+          if (d2 > sp.cull_radius * sp.cull_radius) sI[25] = 1;
+        }
       }
       __syncthreads();
       bool viol = false;
@@ -916,7 +980,14 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       }
       if (viol) sI[21] = 1;
       __syncthreads();
-      if (__builtin_amdgcn_readfirstlane(sI[21]) == 0) break;
+      const bool v_far = __builtin_amdgcn_readfirstlane(sI[21]) != 0, v_move = __builtin_amdgcn_readfirstlane(sI[25]) != 0;
+      if (!v_far && !v_move) break;
+      if (n_skip > 0) {
+        // lines are missing from the buckets, so the full problem cannot be posed here: the redo pass solves every LP of this
+        // replan and every row (separator_redo_kernel, then this kernel without the presolve); what is written below is overwritten
+        if (tid == 0 && ps.redo_count) { const int idx = atomicAdd(ps.redo_count, 1); ps.redo_list[idx] = slot; if (v_far) atomicAdd(ps.redo_count + 1, 1); if (v_move) atomicAdd(ps.redo_count + 2, 1); }   // ([1], [2]: by reason, for the test hook)
+        break;
+      }
       for (int e = tid; e < 256; e += BS) sAccL[e] = 0.0;   // (the accumulators were borrowed: the second attempt starts from zeros again)
     }
   }

@@ -20,4 +20,4 @@ run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT S
 python scripts/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary_config5.txt"
 rm -rf "$OUT/kt" "$OUT/pmc"
 head -12 "$OUT/config5_kernel_stats.txt"; python -c "
-import json,sys; d=json.load(open('$OUT/config5_line.json'))['config5']; print({k:d[k] for k in ('value','ms_per_step','kernel_ms','qp_kernel','line_cull_radius_m')})"
+import json,sys; d=json.load(open('$OUT/config5_line.json'))['config5']; print({k:d[k] for k in ('value','ms_per_step','kernel_ms','qp_kernel','line_cull_radius_m','presolve_redo_last_step')})"
