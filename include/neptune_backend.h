@@ -295,6 +295,11 @@ int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_
  *   d_committed_local : device, [n_scenes][n_local] nep_traj_rec of the local agents
  *   d_block           : device, one block (out);   d_blocks : device, n_blocks consecutive blocks */
 int64_t nep_batch_hull_block_bytes(const nep_batch_t* h);
+/* Handles created with enable_entangle: the block also carries what the entangle check reads of a committed trajectory — its
+ * samples (Neptune::SamplePointsOfIntervals, neptune.cpp:500-565: ns + 1 points per interval) and whether it exists — so
+ * that nep_batch_frontend_ent_hulls and nep_batch_safety_commit_ent work on sharded handles.  ns = num_sample_per_interval,
+ * 3 by default (the reference's yaml); set it before the first nep_batch_hull_block_bytes / nep_batch_hulls call.     */
+int nep_batch_set_ent_samples(nep_batch_t* h, int32_t ns);
 int nep_batch_hulls(nep_batch_t* h, const nep_traj_rec* d_committed_local, const nep_guess* d_guess,
                     void* d_block, void* stream);
 int nep_batch_replan_hulls(nep_batch_t* h, const void* d_blocks, int32_t n_blocks,
@@ -327,6 +332,10 @@ int nep_comm_nranks(nep_comm_t* c);                /* ranks that joined (ncclCom
 int nep_batch_exchange_hulls(nep_batch_t* h, nep_comm_t* c, const void* d_block, void* d_blocks, void* stream);
 int nep_batch_exchange_records(nep_batch_t* h, nep_comm_t* c, const nep_traj_rec* d_commit_local,
                                nep_traj_rec* d_committed_all, void* stream);
+/* The same all-gather + regrouping for ANY per-slot array: d_local [n_scenes][n_local][bytes_per_slot] of every rank ->
+ * d_all [n_scenes][N][bytes_per_slot] (bytes_per_slot a positive multiple of 8) — e.g. the entangle states at point A that
+ * nep_batch_safety_commit_ent reads of every agent.                                                               */
+int nep_batch_exchange_slots(nep_batch_t* h, nep_comm_t* c, const void* d_local, void* d_all, int64_t bytes_per_slot, void* stream);
 /* Test hook: the regrouping step of nep_batch_exchange_records ([world][n_scenes][n_local] -> [n_scenes][world n_local]). */
 int nep_debug_regroup_records(const nep_traj_rec* d_src, nep_traj_rec* d_dst, int32_t world, int32_t n_scenes,
                               int32_t n_local, void* stream);

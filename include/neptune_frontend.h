@@ -142,7 +142,8 @@ int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* 
  * nep_batch_set_static_reps   staticObsRep_ / staticObsLongestDist_ (setStaticObstRep, kinodynamic_search.cpp:385-390):
  *                             rep [n_static][2][2] (col(0), col(1)), longest [n_static][2]; scene = -1: every scene
  * nep_batch_frontend_ent      d_ent_init: [slots] state at point A or NULL (empty); d_case_out: [slots][NEP_MAX_POL][N]
- *                             (out, may be NULL).  Unsharded handle (n_local == num_agents), created with enable_entangle.
+ *                             (out, may be NULL).  Unsharded handle (n_local == num_agents), created with enable_entangle;
+ *                             sharded handles: nep_batch_frontend_ent_hulls below.
  * nep_batch_safety_commit_ent nep_batch_safety_commit plus KinodynamicSearch::entangleCheckGivenPwp (:897-985) as
  *                             Neptune::safetyCheckAfterReplan calls it (neptune.cpp:746-754): every new trajectory is
  *                             re-checked from the state at its start against everybody's NEW trajectories and bend
@@ -153,6 +154,16 @@ int nep_batch_set_static_reps(nep_batch_t* h, int32_t scene, const double* rep, 
 int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed, const nep_fe_start* d_start,
                            const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result,
                            int32_t* d_case_out, void* stream);
+/* nep_batch_frontend_ent against all-gathered hull blocks (multi-GPU rounds: the blocks of a handle created with
+ * enable_entangle carry every agent's samples and presence flag next to its hulls and bend points, nep_batch_hulls);
+ * cfg->ent_samples must equal the handle's nep_batch_set_ent_samples value (3 by default).  Bit-identical to
+ * nep_batch_frontend_ent on an unsharded handle.                                                                      */
+int nep_batch_frontend_ent_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* d_blocks, int32_t n_blocks, const nep_fe_start* d_start,
+                                 const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result,
+                                 int32_t* d_case_out, void* stream);
+/* On a sharded handle nep_batch_safety_commit_ent takes, like the records, the entangle states of ALL agents:
+ * d_ent_init [n_scenes][N] (gather them with nep_batch_exchange_slots); d_guess stays [n_scenes][n_local] (it supplies the
+ * round's clock).  Every rank then computes the same accept vector.                                                   */
 int nep_batch_safety_commit_ent(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new, const nep_guess* d_guess,
                                 const nep_fe_ent_state* d_ent_init, int32_t ent_samples, double cable_length,
                                 nep_traj_rec* d_final, int32_t* d_accept, void* stream);

@@ -20,7 +20,7 @@ EXPORTS = [
     "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
     "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
     "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_gjk_batch",
-    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks",
+    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks", "nep_batch_exchange_slots", "nep_batch_set_ent_samples",
     "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records", "nep_batch_set_max_runtime", "nep_batch_qp_placement", "nep_batch_set_launch_order", "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_get_line_cull", "nep_inflate_static", "nep_batch_debug_redo_count", "nep_separator_batch_rule", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
@@ -31,7 +31,7 @@ PLAN_EXPORTS = [
 ]
 # every symbol include/neptune_entangle.h declares (host-only)
 # include/neptune_frontend.h
-FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_frontend_ent", "nep_batch_safety_commit_ent", "nep_batch_next_starts"]
+FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_frontend_ent", "nep_batch_safety_commit_ent", "nep_batch_next_starts", "nep_batch_frontend_ent_hulls"]
 ENT_EXPORTS = ["nep_ent_sample_points", "nep_ent_propagate_segment", "nep_ent_propagate_guess", "nep_ent_case_ids"]
 
 
@@ -136,6 +136,9 @@ def lib():
     L.nep_batch_frontend_ent.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, vp, vp, vp, vp, vp, vp]
     L.nep_batch_safety_commit_ent.argtypes = [vp, vp, vp, vp, vp, i, d, vp, vp, vp]
     L.nep_batch_next_starts.argtypes = [vp, vp, d, vp, vp, d, vp]
+    L.nep_batch_frontend_ent_hulls.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, i, vp, vp, vp, vp, vp, vp]
+    L.nep_batch_exchange_slots.argtypes = [vp, vp, vp, vp, C.c_int64, vp]
+    L.nep_batch_set_ent_samples.argtypes = [vp, i]
     _lib = L
     return L
 

@@ -280,6 +280,18 @@ class BatchBackend:
                                            d_result.data_ptr() if d_result is not None else None,
                                            d_case_out.data_ptr() if d_case_out is not None else None, st.cuda_stream))
 
+    def frontend_ent_hulls(self, fe_cfg, d_blocks, d_start, d_guess, d_result=None, d_case_out=None, d_ent_init=None, stream=None):
+        """frontend_ent against all-gathered hull blocks (sharded handle created with enable_entangle): nep_batch_frontend_ent_hulls"""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_frontend_ent_hulls(self._h, C.byref(fe_cfg), d_blocks.data_ptr(), self.N // self.n_local, d_start.data_ptr(),
+                                                 d_ent_init.data_ptr() if d_ent_init is not None else None, d_guess.data_ptr(),
+                                                 d_result.data_ptr() if d_result is not None else None,
+                                                 d_case_out.data_ptr() if d_case_out is not None else None, st.cuda_stream))
+
+    def set_ent_samples(self, ns):
+        """num_sample_per_interval the hull blocks reserve room for (nep_batch_set_ent_samples)"""
+        check(lib().nep_batch_set_ent_samples(self._h, int(ns)))
+
     def safety_commit_ent(self, d_prev, d_new, d_guess, d_final, d_accept=None, d_ent_init=None, ent_samples=3, cable_length=None, stream=None):
         """safety_commit plus entangleCheckGivenPwp on every new trajectory (nep_batch_safety_commit_ent)"""
         st = stream if stream is not None else self.torch.cuda.current_stream(self.device)

@@ -707,6 +707,7 @@ struct nep_batch {
   nep_batch_cfg cfg{};
   int slots = 0;
   const nep_traj_rec* fe_committed = nullptr;   // the records nep_batch_frontend built this round's hulls from
+  int ent_ns = 3;                               // num_sample_per_interval the hull blocks reserve room for (nep_batch_set_ent_samples; yaml: 3)
 };
 
 extern "C" {
@@ -761,8 +762,11 @@ int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_
 // into one block, the blocks of all ranks are all-gathered, and every rank runs separator + QP
 // against the gathered blocks (kernels address them through hull_ref, nep_device.h) -------------
 namespace {
-struct HullBlock { size_t xy, nv, xy0, nv0, bend, bend_n, bytes; };
-HullBlock hull_block_layout(int n_scenes, int per, int np) {
+struct HullBlock { size_t xy, nv, xy0, nv0, bend, bend_n, samp, present, bytes; };
+// ent_ns > 0 (handle created with enable_entangle): the block also carries what the entangle check reads of a committed
+// trajectory — its ent_ns + 1 samples per interval (Neptune::SamplePointsOfIntervals) and whether it exists — so that the
+// entangle-aware front end and the safety pass's re-check run against gathered blocks like everything else
+HullBlock hull_block_layout(int n_scenes, int per, int np, int ent_ns = 0) {
   auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
   HullBlock b{};
   const size_t e = (size_t)n_scenes * per;
@@ -773,9 +777,12 @@ HullBlock hull_block_layout(int n_scenes, int per, int np) {
   b.nv0 = o; o = up(o + e * np * sizeof(int));
   b.bend = o; o = up(o + e * kBend * 2 * sizeof(double));
   b.bend_n = o; o = up(o + e * sizeof(int));
+  b.samp = o; b.present = o;
+  if (ent_ns > 0) { o = up(o + e * np * (ent_ns + 1) * 2 * sizeof(double)); b.present = o; o = up(o + e * sizeof(int)); }
   b.bytes = o;
   return b;
 }
+HullBlock block_of(const nep_batch* h);
 void point_at_block(ProblemSet& ps, const HullBlock& b, void* base) {
   char* p = (char*)base;
   ps.hull_xy = (double*)(p + b.xy); ps.hull_nv = (int*)(p + b.nv); ps.hull0_xy = (double*)(p + b.xy0); ps.hull0_nv = (int*)(p + b.nv0);
@@ -783,20 +790,31 @@ void point_at_block(ProblemSet& ps, const HullBlock& b, void* base) {
 }
 }  // namespace
 
+namespace { HullBlock block_of(const nep_batch* h) { return hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol, h->cfg.enable_entangle ? h->ent_ns : 0); } }
+
 int64_t nep_batch_hull_block_bytes(const nep_batch_t* h) {
-  return h ? (int64_t)hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol).bytes : 0;
+  return h ? (int64_t)block_of(h).bytes : 0;
 }
 
 int nep_batch_hulls(nep_batch_t* h, const nep_traj_rec* d_committed_local, const nep_guess* d_guess, void* d_block, void* stream) {
   if (!h || !d_committed_local || !d_guess || !d_block) return fail(NEP_E_ARG, "null argument");
   Engine& E = h->eng;
-  const HullBlock b = hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol);
+  const HullBlock b = block_of(h);
   ProblemSet ps{};
   E.fill(ps);
   point_at_block(ps, b, d_block);
   ps.guess = d_guess;
   launch_hulls(d_committed_local, h->cfg.n_scenes, h->cfg.n_local, d_guess, E.sp, ps, (hipStream_t)stream);
+  if (h->cfg.enable_entangle)      // what the entangle check reads of my agents' trajectories travels in the same block
+    launch_ent_sample(d_committed_local, h->cfg.n_scenes, h->cfg.n_local, &d_guess->t_start, (long)sizeof(nep_guess) * h->cfg.n_local, h->cfg.num_pol, h->ent_ns,
+                      E.sp.T_span, (double*)((char*)d_block + b.samp), (int*)((char*)d_block + b.present), (hipStream_t)stream);
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int nep_batch_set_ent_samples(nep_batch_t* h, int32_t ns) {
+  if (!h || ns < 1 || ns > 8) return fail(NEP_E_ARG, "ent_samples out of range (1..8)");
+  h->ent_ns = ns;
   return 0;
 }
 
@@ -805,7 +823,7 @@ int nep_batch_replan_hulls(nep_batch_t* h, const void* d_blocks, int32_t n_block
   if (!h || !d_blocks || !d_guess || !d_solution) return fail(NEP_E_ARG, "null argument");
   if (n_blocks < 1 || n_blocks * h->cfg.n_local != h->cfg.num_agents) return fail(NEP_E_ARG, "n_blocks * n_local must equal num_agents");
   Engine& E = h->eng;
-  const HullBlock b = hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol);
+  const HullBlock b = block_of(h);
   ProblemSet ps{};
   E.fill(ps);
   point_at_block(ps, b, const_cast<void*>(d_blocks));
@@ -841,7 +859,7 @@ int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* 
   if (cfg->num_samples < 2 || cfg->num_samples > NEP_FE_MAX_SAMPLES || cfg->beam_width < 1 || cfg->beam_width > NEP_FE_MAX_BEAM ||
       !(cfg->voxel_size > 0.0) || !(cfg->j_max > 0.0)) return fail(NEP_E_ARG, "bad front-end configuration");
   Engine& E = h->eng;
-  const HullBlock b = hull_block_layout(h->cfg.n_scenes, h->cfg.n_local, h->cfg.num_pol);
+  const HullBlock b = block_of(h);
   ProblemSet ps{};
   E.fill(ps);
   point_at_block(ps, b, const_cast<void*>(d_blocks));
@@ -935,13 +953,43 @@ int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj
   return 0;
 }
 
+// the same against all-gathered hull blocks (which carry the samples and the presence flags of every agent's trajectory when the
+// handle was created with enable_entangle: nep_batch_hulls): the entangle-aware front end of a sharded handle
+int nep_batch_frontend_ent_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* d_blocks, int32_t n_blocks, const nep_fe_start* d_start,
+                                 const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result, int32_t* d_case_out, void* stream) {
+  if (!h || !cfg || !d_blocks || !d_start || !d_guess) return fail(NEP_E_ARG, "null argument");
+  if (n_blocks < 1 || n_blocks * h->cfg.n_local != h->cfg.num_agents) return fail(NEP_E_ARG, "n_blocks * n_local must equal num_agents");
+  if (!fe_cfg_ok(cfg)) return fail(NEP_E_ARG, "bad front-end configuration");
+  if (!cfg->enable_entangle || !h->cfg.enable_entangle) return fail(NEP_E_STATE, "nep_batch_frontend_ent_hulls needs enable_entangle in the front-end configuration and in the handle");
+  if (cfg->ent_samples != h->ent_ns) return fail(NEP_E_ARG, "ent_samples differs from what the hull blocks were made with (nep_batch_set_ent_samples)");
+  Engine& E = h->eng;
+  if (E.sp.n_static > 0 && !E.have_reps) return fail(NEP_E_STATE, "entangle check with static obstacles needs nep_batch_set_static_reps first");
+  const HullBlock b = block_of(h);
+  ProblemSet ps{};
+  E.fill(ps);
+  point_at_block(ps, b, const_cast<void*>(d_blocks));
+  ps.hull_pb = h->cfg.n_local; ps.hull_bstride = (long)b.bytes;
+  ps.hull_pb_magic = (h->cfg.n_local > 0 && h->cfg.num_agents < 65536) ? (1ull << 32) / (unsigned long long)h->cfg.n_local + 1ull : 0ull;
+  h->fe_committed = nullptr;
+  if (int e = E.d_fe_work.ensure((size_t)std::max(h->slots * 256, h->cfg.n_scenes * h->cfg.num_agents))) return e;
+  if (int e = E.d_fe_nodes.ensure((size_t)h->slots * (h->cfg.num_pol + 1) * cfg->beam_width)) return e;
+  if (!E.d_srep.p) { if (int e = E.d_srep.ensure(4)) return e; if (int e2 = E.d_slong.ensure(2)) return e2; }
+  FeEntArgs ea{};
+  ea.sampled = (const double*)((const char*)d_blocks + b.samp); ea.present = (const int*)((const char*)d_blocks + b.present);
+  ea.srep = E.d_srep.p; ea.slong = E.d_slong.p; ea.nodes = E.d_fe_nodes.p; ea.work = E.d_fe_work.p; ea.ns = h->ent_ns;
+  ea.init = d_ent_init; ea.case_out = d_case_out;
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 int nep_batch_safety_commit_ent(nep_batch_t* h, const nep_traj_rec* d_prev, const nep_traj_rec* d_new, const nep_guess* d_guess,
                                 const nep_fe_ent_state* d_ent_init, int32_t ent_samples, double cable_length, nep_traj_rec* d_final,
                                 int32_t* d_accept, void* stream) {
   if (!h || !d_prev || !d_new || !d_guess || !d_final) return fail(NEP_E_ARG, "null argument");
   Engine& E = h->eng;
   const int N = h->cfg.num_agents;
-  if (E.sp.n_hull != N || h->cfg.n_local != N) return fail(NEP_E_STATE, "the entangle re-check needs the unsharded batched layout");
+  if (E.sp.n_hull != N) return fail(NEP_E_STATE, "the entangle re-check needs the batched (all-agent) hull layout");
   if (!h->cfg.enable_entangle) return fail(NEP_E_STATE, "handle created without enable_entangle");
   if (int e = E.d_conflict.ensure((size_t)h->cfg.n_scenes * N * N)) return e;
   if (int e = E.d_entangles.ensure((size_t)h->cfg.n_scenes * N)) return e;

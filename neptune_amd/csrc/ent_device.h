@@ -20,8 +20,8 @@ struct EntCtx {
   const double* pb;          // [N][2]
   const double* srep;        // [S][2][2] of this scene
   const double* slong;       // [S][2]
-  const double* sampled;     // [N][num_pol][ns+1][2] of this scene
-  const int* present;        // [N]
+  const double* sampled;     // [scenes][N][num_pol][ns+1][2] (scene 0's / block 0's base: indexed through hull_ref like the hulls)
+  const int* present;        // [scenes][N]
   const ProblemSet* ps; int scene, n_hull;      // bend points come with the hull data (hull_ref)
 };
 struct Ev2 { double x, y; };
@@ -30,8 +30,9 @@ struct EntAdd { short id[kEntAddCap]; signed char cs[kEntAddCap]; int n, overflo
 
 __device__ __forceinline__ Ev2 ent_pb(const EntCtx& c, int j) { return Ev2{c.pb[2 * j], c.pb[2 * j + 1]}; }
 __device__ __forceinline__ Ev2 ent_srep(const EntCtx& c, int s, int col) { return Ev2{c.srep[(s * 2 + col) * 2], c.srep[(s * 2 + col) * 2 + 1]}; }
-__device__ __forceinline__ Ev2 ent_sampled(const EntCtx& c, int i, int interval, int col) {
-  const double* q = c.sampled + (((long)i * c.num_pol + interval) * (c.ns + 1) + col) * 2; return Ev2{q[0], q[1]};
+// (hr: hull_ref of agent i — the samples and the presence flags travel with the hull data, in one array or in all-gathered blocks)
+__device__ __forceinline__ Ev2 ent_sampled(const EntCtx& c, const HullRef& hr, int interval, int col) {
+  const double* q = blk(c.sampled, hr.boff) + ((hr.e * c.num_pol + interval) * (c.ns + 1) + col) * 2; return Ev2{q[0], q[1]};
 }
 __device__ __forceinline__ double ent_wedge(Ev2 a, Ev2 b, Ev2 cc) { return (b.x - a.x) * (cc.y - a.y) - (cc.x - a.x) * (b.y - a.y); }
 __device__ __forceinline__ double ent_wedge2(Ev2 a, Ev2 b, Ev2 cc, Ev2& ab, Ev2& ac) { ab.x = b.x - a.x; ab.y = b.y - a.y; ac.x = cc.x - a.x; ac.y = cc.y - a.y; return ab.x * ac.y - ac.x * ab.y; }
@@ -193,11 +194,12 @@ __device__ int ent_propagate(const EntCtx& c, nep_fe_ent_state* st, const double
     } else pk1 = end;
     arc += ent_dist(pk1, pk);
     for (int i = 0; i < c.N; i++) {
-      if (i == c.own || !c.present[i]) continue;
-      Ev2 pik, pik1;
-      if (index > c.num_pol) { pik = ent_sampled(c, i, c.num_pol - 1, ns); pik1 = pik; }
-      else { pik = ent_sampled(c, i, index - 1, j - 1); pik1 = ent_sampled(c, i, index - 1, j); }
+      if (i == c.own) continue;
       const HullRef hr = hull_ref(*c.ps, c.n_hull, c.scene, i);
+      if (!blk(c.present, hr.boff)[hr.e]) continue;
+      Ev2 pik, pik1;
+      if (index > c.num_pol) { pik = ent_sampled(c, hr, c.num_pol - 1, ns); pik1 = pik; }
+      else { pik = ent_sampled(c, hr, index - 1, j - 1); pik1 = ent_sampled(c, hr, index - 1, j); }
       ent_cross_agent(add, pk, pk1, pik, pik1, pb_self, blk(c.ps->bend_n, hr.boff)[hr.e], blk(c.ps->bend_xy, hr.boff) + hr.e * kBend * 2, i + 1);
     }
     ent_cross_static(add, pk, pk1, c);

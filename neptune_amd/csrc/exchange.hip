@@ -148,6 +148,30 @@ int nep_batch_exchange_records(nep_batch_t* h, nep_comm_t* c, const nep_traj_rec
   return 0;
 }
 
+// Any per-slot array [n_scenes][n_local][bytes_per_slot] of every rank -> [n_scenes][N][bytes_per_slot] on every rank (all-gather +
+// regrouping; bytes_per_slot a multiple of 8): e.g. the entangle states at point A the safety pass's re-check reads of every agent.
+int nep_batch_exchange_slots(nep_batch_t* h, nep_comm_t* c, const void* d_local, void* d_all, int64_t bytes_per_slot, void* stream) {
+  if (!h || !c || !d_local || !d_all || bytes_per_slot <= 0 || bytes_per_slot % 8) { nep::set_last_error("bad arguments (bytes_per_slot must be a positive multiple of 8)"); return NEP_E_ARG; }
+  int S = 0, nl = 0, N = 0;
+  nep::batch_dims(h, &S, &nl, &N);
+  if (nl * c->world != N) { nep::set_last_error("world * n_local must equal num_agents"); return NEP_E_ARG; }
+  const size_t piece = (size_t)S * nl * (size_t)bytes_per_slot;
+  if (c->staging_bytes < piece * c->world) {
+    if (c->staging) hipFree(c->staging);
+    c->staging = nullptr; c->staging_bytes = 0;
+    if (hipMalloc((void**)&c->staging, piece * c->world) != hipSuccess) { nep::set_last_error("hipMalloc(exchange staging)"); return NEP_E_HIP; }
+    c->staging_bytes = piece * c->world;
+  }
+  const ncclResult_t r = g_rccl.AllGather(d_local, c->staging, piece, ncclChar, c->comm, (hipStream_t)stream);
+  if (r != ncclSuccess) return fail_nccl("ncclAllGather(slots)", r);
+  const int words = (int)(bytes_per_slot / 8);
+  const long total = (long)c->world * S * nl * words;
+  int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(regroup_records_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->staging, (double*)d_all, c->world, S, nl, words);
+  if (hipGetLastError() != hipSuccess) { nep::set_last_error("regroup kernel launch"); return NEP_E_HIP; }
+  return 0;
+}
+
 // Test hook: the regrouping step of nep_batch_exchange_records for any world size, on device buffers
 // (src: [W][S][nl] records as an all-gather delivers them, dst: [S][W * nl]).
 int nep_debug_regroup_records(const nep_traj_rec* d_src, nep_traj_rec* d_dst, int32_t world, int32_t n_scenes, int32_t n_local, void* stream) {

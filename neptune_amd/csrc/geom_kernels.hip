@@ -1460,7 +1460,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
   if constexpr (ENT) {
     ec.N = N; ec.S = S; ec.own = own; ec.num_pol = D; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = fc.cable_length;
     ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
-    ec.sampled = ea.sampled + (long)scene * N * D * (ea.ns + 1) * 2; ec.present = ea.present + (long)scene * N;
+    ec.sampled = ea.sampled; ec.present = ea.present;
     ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
     my_work = ea.work + ((long)slot * 256 + tid);
     if (tid == 0) {
@@ -1875,7 +1875,7 @@ __global__ void ent_check_kernel(SceneParams sp, ProblemSet ps, FeEntArgs ea, co
     EntCtx ec;
     ec.N = N; ec.S = sp.n_static; ec.own = a; ec.num_pol = sp.num_pol; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = cable;
     ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
-    ec.sampled = ea.sampled + (long)scene * N * sp.num_pol * (ea.ns + 1) * 2; ec.present = ea.present + (long)scene * N;
+    ec.sampled = ea.sampled; ec.present = ea.present;
     ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
     nep_fe_ent_state* wk = ea.work + idx;
     if (ea.init) ent_copy(wk, ea.init + idx); else { long* z = (long*)wk; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }

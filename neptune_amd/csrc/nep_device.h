@@ -145,8 +145,8 @@ int qp_reg_slots();
 size_t qp_reg_lds_bytes();
 // entangle inputs / scratch of the front end and of the safety pass's entangle re-check (device pointers)
 struct FeEntArgs {
-  const double* sampled;         // [scenes][N][num_pol][ns+1][2]   SampledPtsForAll_ (ent_sample_kernel)
-  const int* present;            // [scenes][N]
+  const double* sampled;         // [scenes][N][num_pol][ns+1][2]   SampledPtsForAll_ (ent_sample_kernel); with sharded hulls: block 0's
+  const int* present;            // [scenes][N]                     (both indexed through hull_ref: they travel in the hull blocks)
   const double* srep;            // [S][2][2] staticObsRep_ (x n_scenes with per-scene statics)
   const double* slong;           // [S][2]    staticObsLongestDist_
   const nep_fe_ent_state* init;  // [slots] entangle state at point A, or null (empty)

@@ -150,6 +150,11 @@ class NativeExchange:
         st = stream if stream is not None else self.be.torch.cuda.current_stream(self.be.device)
         self.check(self.lib.nep_batch_exchange_hulls(self.be._h, self._c, d_block.data_ptr(), d_blocks.data_ptr(), st.cuda_stream))
 
+    def slots(self, d_local, d_all, bytes_per_slot, stream=None):
+        """any per-slot array [S][n_local][bytes] of every rank -> [S][N][bytes] (nep_batch_exchange_slots)"""
+        st = stream if stream is not None else self.be.torch.cuda.current_stream(self.be.device)
+        self.check(self.lib.nep_batch_exchange_slots(self.be._h, self._c, d_local.data_ptr(), d_all.data_ptr(), int(bytes_per_slot), st.cuda_stream))
+
     def records(self, d_commit_local, d_committed_all, stream=None):
         st = stream if stream is not None else self.be.torch.cuda.current_stream(self.be.device)
         self.check(self.lib.nep_batch_exchange_records(self.be._h, self._c, d_commit_local.data_ptr(), d_committed_all.data_ptr(), st.cuda_stream))

@@ -203,3 +203,81 @@ def test_captured_native_step_equals_the_eager_one(be):
     assert got_c.tobytes() == want_c.tobytes()
     assert got_s.tobytes() == want_s.tobytes()
     assert (want_s["stats"]["status"] != 2).all()
+
+
+@pytest.mark.parametrize("n_agents,n_static,world,seed", [(16, 8, 4, 61), (64, 20, 8, 7)])
+def test_entangle_front_end_and_recheck_on_sharded_handles(be, n_agents, n_static, world, seed):
+    """enable_entangle_check on sharded handles: the hull blocks carry every agent's trajectory samples and presence flag
+    (nep_batch_hulls), so the entangle-aware front end runs against gathered blocks (nep_batch_frontend_ent_hulls) — guesses,
+    search counters and the case block equal the single handle's bit for bit — the back end consumes the device-made cases,
+    and the safety pass's entangle re-check on a sharded handle (all agents' states at point A gathered) gives the single
+    handle's accept vector and records."""
+    import dataclasses
+    N, W = n_agents, 16
+    if n_agents == 16:
+        sc = scene.tether_crossing_scene(N, n_static, seed)
+    else:
+        sc = scene.make_scene(N, n_static, seed=seed); sc["par"] = dataclasses.replace(sc["par"], enable_entangle=True)
+    p = sc["par"]
+    fe = scene.frontend_cfg(p, beam_width=W, entangle=True)
+    reps, longest = scene.static_reps(sc["statics"])
+    starts = scene.frontend_starts(sc)
+    rng = np.random.default_rng(seed)
+    inits = np.zeros(N, dtype=abi.FE_ENT_STATE_DTYPE)
+    for a in range(0, N, 3):
+        j = int((a + 1 + rng.integers(0, N - 1)) % N)
+        if j != a:
+            inits[a]["n_alpha"] = 1; inits[a]["id"][0] = j + 1; inits[a]["cs"][0] = int(rng.integers(0, 3))
+    full = be.BatchBackend(p, sc["statics"])
+    full.set_static_reps(reps, longest)
+    T = full.torch
+    dev = full.device
+
+    def bufs(n):
+        return (T.zeros(n * abi.GUESS_DTYPE.itemsize, dtype=T.uint8, device=dev), T.zeros(n * abi.FE_RESULT_DTYPE.itemsize, dtype=T.uint8, device=dev),
+                T.zeros(n * abi.NEP_MAX_POL * N, dtype=T.int32, device=dev))
+    d_g, d_r, d_case = bufs(N)
+    d_com = full.to_device(sc["committed"])
+    full.frontend_ent(fe, d_com, full.to_device(starts), d_g, d_r, d_case, d_ent_init=full.to_device(inits))
+    full.replan(None, d_g, d_ent=d_case)
+    want_sol = full.solutions(); want_commit = full.commits()
+    want_g = d_g.cpu().numpy().view(abi.GUESS_DTYPE); want_r = d_r.cpu().numpy().view(abi.FE_RESULT_DTYPE); want_case = d_case.cpu().numpy().reshape(N, abi.NEP_MAX_POL, N)
+    assert (want_case != 0).sum() > 0 or n_agents != 16
+    d_final = T.zeros_like(full.d_commit); d_acc = T.zeros(N, dtype=T.int32, device=dev)
+    full.safety_commit_ent(d_com, full.d_commit, d_g, d_final, d_acc, d_ent_init=full.to_device(inits))
+    want_final = d_final.cpu().numpy().tobytes(); want_acc = d_acc.cpu().numpy().copy()
+
+    nl = N // world
+    ranks = []
+    for r in range(world):
+        h = be.BatchBackend(p, sc["statics"], first_local=r * nl, n_local=nl)
+        h.set_static_reps(reps, longest)
+        ranks.append(h)
+    bb = ranks[0].hull_block_bytes()
+    blocks = T.zeros(world * bb, dtype=T.uint8, device=dev)
+    clock = np.zeros(N, dtype=abi.GUESS_DTYPE); clock["t_start"] = starts["t_start"]            # (nep_batch_hulls reads the round's clock from the guess records)
+    for r in range(world):
+        sl = slice(r * nl, (r + 1) * nl)
+        ranks[r].hulls(ranks[r].to_device(sc["committed"][sl]), ranks[r].to_device(clock[sl]), blocks[r * bb:(r + 1) * bb])
+    new_commits = []
+    for r in range(world):
+        sl = slice(r * nl, (r + 1) * nl)
+        g_l, r_l, c_l = bufs(nl)
+        ranks[r].frontend_ent_hulls(fe, blocks, ranks[r].to_device(starts[sl]), g_l, r_l, c_l, d_ent_init=ranks[r].to_device(inits[sl]))
+        assert g_l.cpu().numpy().tobytes() == want_g[sl].tobytes(), "guesses of rank %d" % r
+        assert r_l.cpu().numpy().tobytes() == want_r[sl].tobytes(), "search results of rank %d" % r
+        assert np.array_equal(c_l.cpu().numpy().reshape(nl, abi.NEP_MAX_POL, N), want_case[sl]), "case block of rank %d" % r
+        ranks[r].replan_hulls(blocks, g_l, d_ent=c_l)
+        assert ranks[r].solutions().tobytes() == want_sol[sl].tobytes(), "solutions of rank %d" % r
+        assert ranks[r].commits().tobytes() == want_commit[sl].tobytes()
+        new_commits.append(ranks[r].d_commit.clone())
+        if r == world - 1:
+            # the safety pass with the entangle re-check on this (sharded) handle: everybody's records and states gathered
+            d_new_all = T.cat(new_commits)
+            f_l = T.zeros_like(d_new_all); a_l = T.zeros(N, dtype=T.int32, device=dev)
+            ranks[r].safety_commit_ent(d_com, d_new_all, g_l, f_l, a_l, d_ent_init=full.to_device(inits))
+            assert np.array_equal(a_l.cpu().numpy(), want_acc)
+            assert f_l.cpu().numpy().tobytes() == want_final
+    for h in ranks:
+        h.close()
+    full.close()
