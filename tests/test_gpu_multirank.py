@@ -267,6 +267,7 @@ def test_entangle_front_end_and_recheck_on_sharded_handles(be, n_agents, n_stati
         assert g_l.cpu().numpy().tobytes() == want_g[sl].tobytes(), "guesses of rank %d" % r
         assert r_l.cpu().numpy().tobytes() == want_r[sl].tobytes(), "search results of rank %d" % r
         assert np.array_equal(c_l.cpu().numpy().reshape(nl, abi.NEP_MAX_POL, N), want_case[sl]), "case block of rank %d" % r
+        ranks[r].d_commit.copy_(ranks[r].to_device(sc["committed"][sl]))      # (a failed replan publishes nothing: its slot keeps the record it holds)
         ranks[r].replan_hulls(blocks, g_l, d_ent=c_l)
         assert ranks[r].solutions().tobytes() == want_sol[sl].tobytes(), "solutions of rank %d" % r
         assert ranks[r].commits().tobytes() == want_commit[sl].tobytes()
