@@ -1505,53 +1505,65 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
 #define FE_TICK(k) do { } while (0)
 #endif
   const double tau = sp.T_span;
+  // box of a node's children: the control points are monotone in the jerk, so the four corner children bound them all (a
+  // superset of every child's own box, feasible or not).  Made by whoever installs the node (the root: thread 0, here), so that a
+  // depth starts with the shortlist at once: no serial phase on beam_width threads and no barrier in front of it.
+  auto children_box = [&](const double* pe, int r) {
+    double lo[2], hi[2];
+#pragma unroll
+    for (int ax = 0; ax < 2; ax++) {
+      double l = __builtin_huge_val(), h = -__builtin_huge_val();
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const double P[4] = {lat.j6[e ? ns - 1 : 0], pe[4 + ax] / 2, pe[2 + ax], pe[ax]};
+        double Q[4];
+        fe_pos_cps(P, tau, Q);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { l = fmin(l, Q[k]); h = fmax(h, Q[k]); }      // (v_min / v_max_f64: no NaNs here, and a box's zero may have either sign)
+      }
+      lo[ax] = l; hi[ax] = h;
+    }
+    p_box[4 * r] = lo[0]; p_box[4 * r + 1] = hi[0]; p_box[4 * r + 2] = lo[1]; p_box[4 * r + 3] = hi[1];
+  };
+  if (tid == 0) children_box(b_end, 0);
+  for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
+  __syncthreads();
   for (depth = 1; depth <= D; depth++) {
     const int cur = depth & 1, prv = cur ^ 1;
     const int idx = (depth > D ? D : depth) - 1;
-    __syncthreads();
     FE_TICK(0);
-    // ---- box of every parent's children: the control points are monotone in the jerk, so the four corner
-    //      children bound them all (a superset of every child's own box, feasible or not) ----
-    if (tid < nb_prev) {
-      const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + tid) * 6;
-      double lo[2], hi[2];
-#pragma unroll
-      for (int ax = 0; ax < 2; ax++) {
-        double l = __builtin_huge_val(), h = -__builtin_huge_val();
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-          const double P[4] = {lat.j6[e ? ns - 1 : 0], pe[4 + ax] / 2, pe[2 + ax], pe[ax]};
-          double Q[4];
-          fe_pos_cps(P, tau, Q);
-#pragma unroll
-          for (int k = 0; k < 4; k++) { l = fmin(l, Q[k]); h = fmax(h, Q[k]); }      // (v_min / v_max_f64: no NaNs here, and a box's zero may have either sign)
-        }
-        lo[ax] = l; hi[ax] = h;
-      }
-      p_box[4 * tid] = lo[0]; p_box[4 * tid + 1] = hi[0]; p_box[4 * tid + 2] = lo[1]; p_box[4 * tid + 3] = hi[1];
-    }
-    if (tid == 0) { s_i[0] = 0; s_i[1] = 0; s_i[2] = 0; }
-    for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
-    __syncthreads();
     FE_TICK(1);
-    // ---- shortlist: obstacles of this interval whose box meets some parent's box ----
-    for (int j = tid; j < N + S; j += 256) {
-      if (j == own) continue;
-      const double* bxj = ps.fe_box + (((long)scene * (N + S) + j) * sp.num_pol + idx) * 4;      // (fe_box_kernel)
-      const double x0 = bxj[0], x1 = bxj[1], y0 = bxj[2], y1 = bxj[3];
-      bool near = false;
-      for (int q = 0; q < nb_prev; q++) near |= !(x1 < p_box[4 * q] || p_box[4 * q + 1] < x0 || y1 < p_box[4 * q + 2] || p_box[4 * q + 3] < y0);
-      if (near) {      // (rare: now its vertices are worth fetching)
-        int nv; const double* V;
-        if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
-        else { const long js = (long)scene * sp.static_stride + (j - N); nv = ps.static_nv[js]; V = ps.static_xy + js * kHullV * 2; }
-        double2 vv[kHullV];
+    // ---- shortlist: obstacles of this interval whose box meets some parent's box.  G lanes share an obstacle's pass over the
+    //      parents (G = 2 at 64 agents + 20 statics: this loop over up to 64 parents on a third of the threads was a quarter of a
+    //      search), each parent's box is one 32-byte LDS read, the four comparisons are combined without branches, and the
+    //      lanes of a group exchange their verdicts inside the wave ----
+    {
+      int G = 1; while (2 * G * (N + S) <= 256 && G < 8) G *= 2;
+      const int part = tid & (G - 1);
+      for (int j0 = 0; j0 < N + S; j0 += 256 / G) {
+        const int j = j0 + tid / G;
+        const bool mine = j < N + S && j != own;
+        double x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+        if (mine) { const double* bxj = ps.fe_box + (((long)scene * (N + S) + j) * sp.num_pol + idx) * 4; x0 = bxj[0]; x1 = bxj[1]; y0 = bxj[2]; y1 = bxj[3]; }      // (fe_box_kernel)
+        bool near = false;
+        for (int q = part; q < nb_prev; q += G) {
+          const double2 pa = ((const double2*)p_box)[2 * q], pb = ((const double2*)p_box)[2 * q + 1];
+          near |= (x1 >= pa.x) & (pa.y >= x0) & (y1 >= pb.x) & (pb.y >= y0);
+        }
+        int nr = (mine && near) ? 1 : 0;
+        for (int o = 1; o < G; o <<= 1) nr |= __shfl_xor(nr, o);
+        if (nr && part == 0 && mine) {      // (rare: now its vertices are worth fetching)
+          int nv; const double* V;
+          if (j < N) { const HullRef hr = hull_ref(ps, sp.n_hull, scene, j); const long h = hr.e * sp.num_pol + idx; nv = blk(ps.hull_nv, hr.boff)[h]; V = blk(ps.hull_xy, hr.boff) + h * kHullV * 2; }
+          else { const long js = (long)scene * sp.static_stride + (j - N); nv = ps.static_nv[js]; V = ps.static_xy + js * kHullV * 2; }
+          double2 vv[kHullV];
 #pragma unroll
-        for (int i = 0; i < kHullV; i++) vv[i] = ((const double2*)V)[i];
-        const int o = atomicAdd(&s_i[0], 1); o_aabb[4 * o] = x0; o_aabb[4 * o + 1] = x1; o_aabb[4 * o + 2] = y0; o_aabb[4 * o + 3] = y1; o_nv[o] = nv; o_id[o] = j;
-        if (o < kFeObsLds) {
+          for (int i = 0; i < kHullV; i++) vv[i] = ((const double2*)V)[i];
+          const int o = atomicAdd(&s_i[0], 1); o_aabb[4 * o] = x0; o_aabb[4 * o + 1] = x1; o_aabb[4 * o + 2] = y0; o_aabb[4 * o + 3] = y1; o_nv[o] = nv; o_id[o] = j;
+          if (o < kFeObsLds) {
 #pragma unroll
-          for (int i = 0; i < kHullV; i++) ((double2*)(o_V + o * kHullV * 2))[i] = vv[i];
+            for (int i = 0; i < kHullV; i++) ((double2*)(o_V + o * kHullV * 2))[i] = vv[i];
+          }
         }
       }
     }
@@ -1563,6 +1575,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
     //      spreads the expensive tests over all threads instead of leaving them with the lanes that
     //      happened to draw crowded children ----
     const int n_c = nb_prev * NC;
+    if (tid == 0) s_i[1] = 0;                              // (the winners' counter: last read in the previous depth's rank phase)
     auto settle = [&](int id, FeChild& ch) {       // collision free: closed voxel?  else alive
       unsigned iz = 0;
       if constexpr (ENT) {
@@ -1704,6 +1717,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) b_end[(cur * NEP_FE_MAX_BEAM + rank) * 6 + q] = ch.e[q];
+        children_box(ch.e, rank);                         // (what the next depth's shortlist tests the obstacles against)
         b_g[cur * NEP_FE_MAX_BEAM + rank] = ch.g; b_dist[rank] = ch.dist; b_f[rank] = ch.f;
         p_parent[depth * NEP_FE_MAX_BEAM + rank] = (signed char)(depth == 1 ? -1 : pr);
         p_comb[depth * NEP_FE_MAX_BEAM + rank] = (signed char)cc;
@@ -1711,6 +1725,9 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
         for (unsigned h = fe_hash((long long)vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long o = atomicCAS(&v_key[h], kFeEmpty, vox); if (o == kFeEmpty || o == vox) break; }
       }
     }
+    // (the next depth's counters and voxel table: nobody reads them any more in this one)
+    if (tid == 0) { s_i[0] = 0; s_i[2] = 0; }
+    for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
     __syncthreads();
     FE_TICK(6);
     if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
