@@ -386,6 +386,7 @@ double nep_batch_get_line_cull(nep_batch_t* h);
  * the last call sent through the redo pass (test hook); by_reason (may be NULL) receives how many of them had a parked line
  * violated [0] and how many moved farther than the radius [1].                                                       */
 int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason);
+int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap);    /* the listed slots (test hook) */
 
 /* Which vertex of the separating-line LP the separator returns.  The LP (separator_glpk.cpp:248-373) has a zero objective:
  * the reference gets "whatever vertex glp_simplex reaches", and the spline QP's optimum depends on it.

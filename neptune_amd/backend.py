@@ -363,6 +363,11 @@ class BatchBackend:
         self.redo_reasons = {"parked_line_violated": int(r[0]), "moved_beyond_radius": int(r[1])}
         return n
 
+    def redo_list(self, cap=4096):
+        out = np.zeros(cap, dtype=np.int32)
+        n = int(check(lib().nep_batch_debug_redo_list(self._h, abi.iptr(out), cap)))
+        return out[:n].copy()
+
     def set_separator_rule(self, rule):
         """which vertex of the separating-line LP is returned: 0 largest gap (default), 1 the one a primal simplex of GLPK's
         default class reaches (nep_batch_set_separator_rule)"""

@@ -311,7 +311,7 @@ struct Engine {
     }
     if (use_reg) launch_qp_reg(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     else launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
-    if (skip) {
+    if (skip && !getenv("NEP_SEP_NO_REDO")) {      // (NEP_SEP_NO_REDO: development aid — the flagged replans keep their presolved result for inspection)
       // the presolve's redo pass: replans whose solution did not verify the skipped / parked lines (listed by the kernel above; the
       // list is empty nearly always) get every LP solved and every row through the interior point
       launch_separator_redo(slots, sp, ps, st);
@@ -1030,6 +1030,18 @@ int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason) {
   if (h->eng.d_redo_count.p) HIPCHK(hipMemcpy(n, h->eng.d_redo_count.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
   if (by_reason) { by_reason[0] = n[1]; by_reason[1] = n[2]; }
   return n[0];
+}
+
+// Test hook: the slots on the redo list of the last replan (at most cap).
+int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap) {
+  if (!h || !slots_out || cap < 0) return fail(NEP_E_ARG, "bad arguments");
+  int n = 0;
+  HIPCHK(hipDeviceSynchronize());
+  if (!h->eng.d_redo_count.p) return 0;
+  HIPCHK(hipMemcpy(&n, h->eng.d_redo_count.p, sizeof(int), hipMemcpyDeviceToHost));
+  if (n > cap) n = cap;
+  if (n > 0) HIPCHK(hipMemcpy(slots_out, h->eng.d_redo_list.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  return n;
 }
 
 int nep_batch_qp_placement(nep_batch_t* h) { return h ? (h->eng.use_reg ? 1 : 0) : NEP_E_ARG; }

@@ -829,7 +829,33 @@ __device__ __forceinline__ void separator_body(const SceneParams& sp, const Prob
   // ---- step 1: which LPs does the reference call, in order -------------------------------------
   int n_att = 0, n_skip = 0;                              // LPs to solve (listed), LPs known to give a far line (counted only)
   const int n_plain = cx.nH + cx.N + cx.S;                // hulls, bases, statics: one candidate per lane and round
-  for (int c0 = 0; c0 < n_plain; c0 += 64) {
+  int c_first = 0;
+  if (cx.skip_box) {
+    // Spatial presolve: a hull candidate is decided by its box alone — empty (fe_box_kernel marks it with x0 = +inf: never called),
+    // far (counted, not solved) or to be solved — one 32-byte load per candidate, fetched a round ahead of its use, instead
+    // of the vertex count followed by the box; at config 5 these are 4 of a segment's rounds and nearly all of them are far.
+    const double* bx0 = cx.skip_box + ((long)cx.scene * (cx.N + cx.S) * sp.num_pol + seg) * 4;
+    auto load_box = [&](int j, double2& a, double2& b) {
+      const bool v = j < cx.nH;
+      const double2* q = (const double2*)(bx0 + (long)(v ? j : 0) * sp.num_pol * 4);
+      a = q[0]; b = q[1];
+    };
+    double2 ca, cb, na, nb2;
+    load_box(lane, ca, cb);
+    for (int c0 = 0; c0 < cx.nH; c0 += 64) {
+      const int j = c0 + lane;
+      load_box(j + 64, na, nb2);
+      const bool valid = j < cx.nH && !(sp.skip_own && j == cx.own) && ca.x < NEP_INF;
+      const bool far = (ca.x - cx.bb[1] > cx.skip_r) | (cx.bb[0] - ca.y > cx.skip_r) | (cb.x - cx.bb[3] > cx.skip_r) | (cx.bb[2] - cb.y > cx.skip_r);
+      const unsigned long long mask = __ballot(valid && !far);
+      if (valid && !far) sAtt[n_att + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
+      n_att += __popcll(mask);
+      n_skip += __popcll(__ballot(valid && far));
+      ca = na; cb = nb2;
+    }
+    c_first = cx.nH;
+  }
+  for (int c0 = c_first; c0 < n_plain; c0 += 64) {
     const int c = c0 + lane;
     int nA; int ord; bool skp = false;
     const double2* unused = nullptr;

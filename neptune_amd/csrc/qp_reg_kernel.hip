@@ -944,22 +944,21 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     if (use_far || status == NEP_FAILED) break;
     const int n_skip = __builtin_amdgcn_readfirstlane(sI[40]);
     if (__builtin_amdgcn_readfirstlane(sI[41]) == 0 && n_skip == 0) break;
-    {  // the far lines against the solution: position control points from the base rows of the converged mode
-      const QpTable* __restrict__ tbv = tables + status * (kMaxK + 1) + K;
-      const int nzv = tbv->nz;
+    {  // the far lines against the solution: its position control points, from the coefficients it returns (the MINVO matrix applied
+       // to sTheta: what a caller evaluating the returned trajectory sees)
       if (tid < 8 * K) {
-        const int rho = tid >> 1, ax = tid & 1;
-        double v = sOff[rho * 3 + ax];
-        for (int c = 0; c < nzv; c++) v = __builtin_fma(sB[rho * SBS + c], sZ[ax * nzv + c], v);
+        const int rho = tid >> 1, ax = tid & 1, sg = rho >> 2, k = rho & 3;
+        const double c0 = (T * T * T) * cQpAPosInv[0][k], c1 = (T * T) * cQpAPosInv[1][k], c2 = T * cQpAPosInv[2][k], c3 = cQpAPosInv[3][k];
+        const double* Q = sTheta + (ax * 8 + sg) * 4;
+        const double v = ((Q[0] * c0 + Q[1] * c1) + Q[2] * c2) + Q[3] * c3;
         sAccL[rho * 2 + ax] = v;
         if (n_skip > 0) {
           // The LPs the separator skipped have lines farther than cull_radius from every control point of the GUESS (their
           // point sets' boxes are that far apart and the box sides are polygon edges: separator_body).  A solution control point
           // that stays within cull_radius of the guess's — a point of the guess's control polygon — is therefore on the right
           // side of every one of them: nothing to evaluate.  One that moved farther sends the replan to the redo pass.
-          const int sg = rho >> 2, k = rho & 3;
           const double* P = sCoef + (ax * 8 + sg) * 4;
-          const double gq = ((P[0] * ((T * T * T) * cQpAPosInv[0][k]) + P[1] * ((T * T) * cQpAPosInv[1][k])) + P[2] * (T * cQpAPosInv[2][k])) + P[3] * cQpAPosInv[3][k];
+          const double gq = ((P[0] * c0 + P[1] * c1) + P[2] * c2) + P[3] * c3;
           double d2 = (v - gq) * (v - gq);
           d2 += dpp<DPP_XOR1>(d2);                        // (x and y of a control point sit on neighbouring lanes)
           if (d2 > sp.cull_radius * sp.cull_radius) sI[25] = 1;
