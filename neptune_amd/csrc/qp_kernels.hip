@@ -222,7 +222,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         me_ci[u] = ci; me_cj[u] = cj; me_i[u] = bi * nz + ci; me_j[u] = bj * nz + cj; me_sel[u] = sel;
       }
     }
-    bool converged = false;
+    bool converged = false, have_loose = false;      // (have_loose: see the snapshot below)
     int it = 0;
     const long long t_solve0 = (long long)wall_clock64();   // m_.optimize() starts here: every solve (first and relaxed) has its own TimeLimit
     SETUP_TICK(1);
@@ -540,7 +540,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
         if (flag == 3) break;
         // (the snapshot comes before the factorisation's verdict: a pivot lost to rounding this late must not cost the loosely
         // converged iterate — the oracle keeps it the same way)
-        if (flag == 2) { if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }
+        if (flag == 2) { have_loose = true; if (tid < n) sZl[tid] = sZ[tid]; if (tid == 0) sI[16] = 1; }      // (every thread notes it for itself: sI[16] is read back below without a barrier in between, see qp_reg_kernel)
 #ifdef NEP_QP_ITERDBG
         if ((!sI[19] || !sI[20]) && tid == 0 && ps.dbg && slot == NEP_QP_ITERDBG && mode == 0 && it < 59) ps.dbg[16 + (it + 1) * 8 + 5] = 100 + sI[19] * 10 + sI[20];
 #endif
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
       if (prof) tph[10] += clock64();
 #endif
       if (uncon) converged = true;
-      if (!converged && sI[16]) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
+      if (!converged && have_loose) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
     }
     iters_total = it; if (mode == 0) iters_first = it;
     __syncthreads();

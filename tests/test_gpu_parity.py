@@ -485,6 +485,10 @@ def test_config5_size_256_agents_entangle(be, oracle, placement, monkeypatch):
     st = sol["stats"]
     assert (st["n_lines"] > 1500).all() and (st["status"] <= 2).all()
     assert (st["status"] == 0).sum() >= 240
+    # the same launch again gives the same bytes (a workgroup whose waves disagreed on "converged" — a flag word read back without a
+    # barrier, found in round 3 — showed up as run-to-run differences at this size)
+    bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]), d_ent=d_ent)
+    assert bb.solutions().tobytes() == sol.tobytes()
     if placement == "default":
         assert st["n_rows"].mean() < 0.2 * (48 * 8 + 4 * st["n_lines"].mean())       # most rows are presolved away
     T = p.T_span
