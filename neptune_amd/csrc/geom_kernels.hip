@@ -865,26 +865,30 @@ __device__ __forceinline__ void separator_body(const SceneParams& sp, const Prob
     n_att += __popcll(mask);
     n_skip += __popcll(__ballot(att && skp));
   }
-  // Entangle candidates (agent j, bend segment k), the reference's double loop (:624-636): one lane per AGENT — nine in ten
-  // have no active case and are done after one load — instead of one lane per (j, k) pair, which at config 5 was 32 of a
-  // segment's 42 rounds.  A lane collects the k it would call as a bit mask; a prefix sum over the wave appends them in (j, k)
-  // order, the order of the one-pair-per-lane enumeration.
-  for (int j0 = 0; n_plain < total && j0 < cx.N; j0 += 64) {
-    const int j = j0 + lane;
-    unsigned m = 0;
-    if (j < cx.N && j != cx.own && ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * cx.N + j] != 0) {
-      for (int k = 0; k < kBend; k++) {
-        int nA; int ord; const double2* unused = nullptr;
-        if (cand_eval(cx, seg, n_plain + j * kBend + k, bx, by, hulldist, 0, nullptr, nA, ord, unused)) m |= 1u << k;
-      }
+  // Entangle candidates (agent j, bend segment k), the reference's double loop (:624-636).  Nine agents in ten have no active
+  // case: the agents that do are first gathered (one load per agent, ballot order = id order), then their (j, k) pairs are
+  // handed out densely, one per lane — a few rounds instead of one per 64 (j, k) slots (32 of a config-5 segment's 42 rounds,
+  // and still 0.6 of the kernel's 1.0 ms when every lane with a case walked its own eight k).  Pair order = (j, k) order.
+  if (n_plain < total) {
+    unsigned short* sAct = sAtt + (total + 8);
+    int n_act = 0;
+    for (int j0 = 0; j0 < cx.N; j0 += 64) {
+      const int j = j0 + lane;
+      const bool act = j < cx.N && j != cx.own && ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * cx.N + j] != 0;
+      const unsigned long long mask = __ballot(act);
+      if (act) sAct[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
+      n_act += __popcll(mask);
     }
-    const int cnt = __popc(m);
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
-    int pos = n_att + incl - cnt;
-    for (unsigned mm = m; mm; mm &= mm - 1) sAtt[pos++] = (unsigned short)(n_plain + j * kBend + (__ffs(mm) - 1));
-    n_att += __shfl(incl, 63);
+    __syncthreads();
+    for (int p0 = 0; p0 < n_act * kBend; p0 += 64) {
+      const int pp = p0 + lane;
+      int nA; int ord; const double2* unused = nullptr;
+      const int c = pp < n_act * kBend ? n_plain + (int)sAct[pp / kBend] * kBend + (pp % kBend) : 0;
+      const bool att = pp < n_act * kBend && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused);
+      const unsigned long long mask = __ballot(att);
+      if (att) sAtt[n_att + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)c;
+      n_att += __popcll(mask);
+    }
   }
   __syncthreads();
   // ---- step 2: the LPs ---------------------------------------------------------------------------
@@ -965,7 +969,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_redo_kernel(Scene
 
 size_t separator_lds_bytes(const SceneParams& sp) {
   const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
-  const size_t tail = 8 * sizeof(double) + (((size_t)(total + 8) * sizeof(unsigned short) + 15) & ~(size_t)15);
+  const size_t tail = 8 * sizeof(double) + (((size_t)(total + 8 + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short) + 15) & ~(size_t)15);   // (+ the agents with an active entangle case)
   // the pool takes what is left of 10 KB (sixteen waves per CU); with very long candidate lists (config 5 with the entangle rows)
   // it keeps at least 64 x 8 pairs and the wave gets more LDS
   size_t pool = tail + 64 * 8 * 16 <= (size_t)kSepLdsTarget ? (size_t)kSepLdsTarget - tail : (size_t)64 * 8 * 16;
@@ -974,7 +978,7 @@ size_t separator_lds_bytes(const SceneParams& sp) {
 }
 static int separator_pool_pairs(const SceneParams& sp) {
   const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
-  const size_t tail = 8 * sizeof(double) + (((size_t)(total + 8) * sizeof(unsigned short) + 15) & ~(size_t)15);
+  const size_t tail = 8 * sizeof(double) + (((size_t)(total + 8 + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short) + 15) & ~(size_t)15);
   return (int)((separator_lds_bytes(sp) - tail) / 16);
 }
 
