@@ -156,6 +156,8 @@ def main():
     ap.add_argument("--cull-radius", type=float, default=0.0,
                     help="presolve of the separating-line rows (nep_batch_set_line_cull): lines farther than this many metres "
                          "from the guess are left out of the QP and verified after the solve; 0 = off")
+    ap.add_argument("--chain-cull-radius", type=float, default=0.0,
+                    help="line presolve radius of the chain and moving legs (0: every row through the interior point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange-torch", action="store_true",
                     help="N > 1 with --exchange hulls: the all-gather through torch.distributed (host-launched steps) instead of the "
@@ -564,6 +566,7 @@ def main():
         chain = moving = None
         if extra and not args.no_chain and C == 1:
             cfg_fe = scene.frontend_cfg(p, beam_width=args.beam)
+            be.set_line_cull(args.chain_cull_radius)
             starts_np = np.stack([scene.frontend_starts(s_) for s_ in mine])
             d_st = be.to_device(starts_np)
             d_gfe = torch.zeros_like(d_guess)
@@ -591,7 +594,8 @@ def main():
                                ipm_iters_mean=float(sol3["stats"]["iters"].mean()), ipm_iters_max=int(sol3["stats"]["iters"].max()),
                                lp_failed=int(sol3["stats"]["n_lp_failed"].sum()), accepted_frac=float(d_acc.float().mean().item()),
                                solve_us=solve_us_stats(be), terminal_ball_rows=int(sol3["stats"]["qc_active"].sum()),
-                               ipm_iters_quantiles=quantiles(sol3["stats"]["iters"]),
+                               ipm_iters_quantiles=quantiles(sol3["stats"]["iters"]), line_cull_radius_m=args.chain_cull_radius,
+                               rows_solved_mean=float(sol3["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(),
                                note="front-end beam search -> separating lines -> QP -> safety check + commit, every step; the guesses are the "
                                     "device-made lattice paths (they end at cruise speed and cut corners around obstacles), not the scene's; "
                                     "point A stays where it is, so after a few steps every step poses the same problems", **status_counts(sol3))
@@ -631,12 +635,14 @@ def main():
                                 lp_failed=int(sol4["stats"]["n_lp_failed"].sum()), accepted_frac=float(d_acc.float().mean().item()),
                                 K_mean=float(sol4["K"].mean()), solve_us=solve_us_stats(be),
                                 terminal_ball_rows=int(sol4["stats"]["qc_active"].sum()), lines_mean=float(sol4["stats"]["n_lines"].mean()),
-                                ipm_iters_quantiles=quantiles(sol4["stats"]["iters"]),
+                                ipm_iters_quantiles=quantiles(sol4["stats"]["iters"]), line_cull_radius_m=args.chain_cull_radius,
+                                rows_solved_mean=float(sol4["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(),
                                 simulated_seconds=float(st_now["t_start"].max() - starts_np["t_start"].max()),
                                 displacement_m_mean=float(moved.mean()), agents_with_swapped_goal=swaps,
                                 note="closed loop on the device, one HIP graph per round: front end -> lines -> QP -> safety check + commit -> point A of "
                                      "the next round 0.5 s ahead on the committed trajectory; arrived agents turn around.  Every step solves NEW problems; the "
                                      "launch-order predictor is the same agent's previous replan", **status_counts(sol4))
+            be.set_line_cull(0.0)
 
         # ---- single_scene: ONE fleet -------------------------------------------------------------------------------------
         single = None

@@ -667,6 +667,8 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   const double EXP_TAU = getenv("ORC_EXP_TAU") ? atof(getenv("ORC_EXP_TAU")) : 0.99999;
   const double EXP_GAPTOL = getenv("ORC_EXP_GAPTOL") ? atof(getenv("ORC_EXP_GAPTOL")) : 1e-10;
   const int trace = getenv("ORC_QP_TRACE") != NULL;
+  const int EXP_REFINE = getenv("ORC_EXP_REFINE") ? atoi(getenv("ORC_EXP_REFINE")) : 0;   /* experiment: refinement steps per Newton solve (0 = what the kernel does) */
+  double* M0 = (double*)malloc(sizeof(double) * ((size_t)ny * ny + ny)); double* res = M0 + (size_t)ny * ny;
   /* Mehrotra's second-order term dsa*dla extrapolates the affine step to its full length.  From the tenth iteration on (the
      usual solve has ended by then), whenever less than a tenth of that step is admissible, the predictor is discarded: the
      corrector is formed as if the affine direction were zero (dsa = -rp, dla = -lam + w rp: what is left of the term vanishes
@@ -716,6 +718,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; w[r] = lam[r] / s[r]; for (int a = 0; a < ny; a++) { double wa = w[r] * g[a]; for (int b = 0; b <= a; b++) M[a * ny + b] += wa * g[b]; } }
     for (int a = 0; a < ny; a++) for (int b = a + 1; b < ny; b++) M[a * ny + b] = M[b * ny + a];
     if (qc) { w[m] = lam[m] / s[m]; for (int a = 0; a < ny; a++) for (int b = 0; b < ny; b++) M[a * ny + b] += lam[m] * 2.0 * Cy[a * ny + b] + w[m] * gq[a] * gq[b]; }
+    if (EXP_REFINE) memcpy(M0, M, sizeof(double) * ny * ny);
     if (chol(ny, M)) break;
     double alpha = 1.0, sigma = 0.0;
     for (int pass = 0; pass < 2; pass++) {
@@ -732,6 +735,10 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       if (qc) { double v = rc[m] / s[m] - w[m] * rp[m]; for (int a = 0; a < ny; a++) rhs[a] += gq[a] * v; }
       for (int a = 0; a < ny; a++) dy[a] = rhs[a];
       chol_solve(ny, M, dy);
+      for (int k = 0; k < EXP_REFINE; k++) {      /* experiment only (scripts/parity_floor.py): iterative refinement of the Newton solve */
+        for (int a = 0; a < ny; a++) { double v = rhs[a]; for (int b = 0; b < ny; b++) v -= M0[a * ny + b] * dy[b]; res[a] = v; }
+        chol_solve(ny, M, res); for (int a = 0; a < ny; a++) dy[a] += res[a];
+      }
       for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = 0; for (int c = 0; c < ny; c++) a += g[c] * dy[c]; gdx[r] = a; }
       if (qc) { double a = 0; for (int c = 0; c < ny; c++) a += gq[c] * dy[c]; gdx[m] = a; }
       for (int r = 0; r < mt; r++) { ds[r] = -rp[r] - gdx[r]; dl[r] = -rc[r] / s[r] + w[r] * (rp[r] + gdx[r]); }
@@ -762,7 +769,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   if (ret != 0 && loose_ok) { memcpy(y, yl, sizeof(double) * ny); ret = 0; }
   if (ret == 0) for (int i = 0; i < n; i++) { double v = thp[i]; for (int c = 0; c < ny; c++) v += Z[i * ny + c] * y[c]; th[i] = v; }
   *iters_out = it;
-  free(s); free(Py); free(Gy); free(Z); free(Et); free(perm);
+  free(s); free(Py); free(Gy); free(Z); free(Et); free(perm); free(M0);
   return ret;
 }
 

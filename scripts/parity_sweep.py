@@ -27,7 +27,15 @@ def oracle_one(job):
     sc = scene.make_scene(N, M, seed=SEED0 + seed)
     tighten(sc["par"])
     r = oracle.replan(sc["par"], a + 1, sc["committed"], g, sc["statics"])          # every scene has its own statics, on both sides
-    return seed, a, r["status"], r["iters"], r["objective"], np.array(r["coeff"])
+    strict = None
+    if os.environ.get("NEP_SWEEP_STRICT"):
+        # the same oracle pushed to its limit (gap tolerance 1e-13 and two refinement steps per Newton solve; read per solve
+        # by the C library): tells which of the two sides a difference belongs to
+        os.environ["ORC_EXP_GAPTOL"] = "1e-13"; os.environ["ORC_EXP_REFINE"] = "2"
+        r2 = oracle.replan(sc["par"], a + 1, sc["committed"], g, sc["statics"])
+        del os.environ["ORC_EXP_GAPTOL"], os.environ["ORC_EXP_REFINE"]
+        strict = (r2["status"], r2["iters"], np.array(r2["coeff"]))
+    return seed, a, r["status"], r["iters"], r["objective"], np.array(r["coeff"]), strict
 
 
 def main():
@@ -54,7 +62,8 @@ def main():
     with ProcessPoolExecutor(max_workers=min(os.cpu_count() or 1, 128), mp_context=mp.get_context("spawn")) as ex:
         res = list(ex.map(oracle_one, jobs, chunksize=4))
     dco, dob, dpos, st_bad, worst = [], [], [], 0, None
-    for seed, a, status, iters, obj, coeff in res:
+    d_gs, d_os, tail = [], [], []
+    for seed, a, status, iters, obj, coeff, strict in res:
         so = sol[seed * N + a]
         if int(so["stats"]["status"]) != status:
             st_bad += 1
@@ -68,6 +77,10 @@ def main():
         dpos.append(max(float(np.abs(((dc[..., 0] * t + dc[..., 1]) * t + dc[..., 2]) * t + dc[..., 3]).max()) for t in (0.0, 0.125, 0.25, 0.375, 0.5)))
         if worst is None or d > worst[0]:
             worst = (d, seed, a, int(so["stats"]["iters"]), iters)
+        if strict is not None and strict[0] == status:
+            d_gs.append(float(np.abs(np.array(so["coeff"])[:, :K, :] - strict[2]).max())); d_os.append(float(np.abs(coeff - strict[2]).max()))
+            if d > 1e-6:
+                tail.append((seed, a, int(so["stats"]["status"]), int(so["stats"]["iters"]), iters, strict[1], d, d_gs[-1], d_os[-1]))
     dco = np.array(dco); dob = np.array(dob); dpos = np.array(dpos)
     if len(dco) == 0:
         print("replans compared 0 (status mismatches %d): nothing solved on either side" % st_bad)
@@ -75,6 +88,12 @@ def main():
     print("statuses on the device: ok %d relaxed %d failed %d" % tuple(np.bincount(sol["stats"]["status"].astype(int), minlength=3)[:3]))
     print("replans compared %d (status mismatches %d) | coeff diff: p50 %.2e p99 %.2e max %.2e, > 1e-6: %d, > 1e-5: %d | position diff along the trajectories: p99 %.2e max %.2e m | rel cost diff max %.2e | worst (diff, scene, agent, gpu iters, oracle iters) %s"
           % (len(dco), st_bad, np.percentile(dco, 50), np.percentile(dco, 99), dco.max(), int((dco > 1e-6).sum()), int((dco > 1e-5).sum()), np.percentile(dpos, 99), dpos.max(), dob.max(), worst))
+    if d_gs:
+        d_gs = np.array(d_gs); d_os = np.array(d_os)
+        print("against the oracle at its limit (gap tolerance 1e-13, two refinement steps per Newton solve), %d replans: device p99 %.2e max %.2e | oracle (as shipped) p99 %.2e max %.2e"
+              % (len(d_gs), np.percentile(d_gs, 99), d_gs.max(), np.percentile(d_os, 99), d_os.max()))
+        for t in tail:
+            print("   tail: scene %d agent %d status %d iterations device %d oracle %d strict %d | device-oracle %.2e device-strict %.2e oracle-strict %.2e" % t)
 
 
 if __name__ == "__main__":
