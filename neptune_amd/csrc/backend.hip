@@ -86,7 +86,7 @@ struct Engine {
   DevBuf<int> d_flags;
   // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
   DevBuf<double> d_sampled, d_srep, d_slong; DevBuf<int> d_present, d_entangles;
-  DevBuf<nep_fe_ent_state> d_fe_nodes, d_fe_work; bool have_reps = false;
+  DevBuf<nep_fe_ent_state> d_fe_nodes, d_fe_work, d_fe_saved; DevBuf<double> d_fe_arc; bool have_reps = false;
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
@@ -187,7 +187,7 @@ struct Engine {
     if (!d_redo_count.p) { if (int e = d_redo_count.ensure(64)) return e; HIPCHK(hipMemset(d_redo_count.p, 0, 64 * sizeof(int))); }
     if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
-    if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 16)) return e; }
+    if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 32)) return e; }      // (the QP kernels use 16 per slot, the front end 32)
     if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e;     // (either placement may end up using it: see choose_placement)
     return 0;
   }
@@ -327,7 +327,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_box.release();
-    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release();
+    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release();
     d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
@@ -906,7 +906,7 @@ int ent_prepare(nep_batch* h, int ns, int beam_width, const nep_traj_rec* d_recs
   if (!E.d_srep.p) { if (int e = E.d_srep.ensure(4)) return e; if (int e2 = E.d_slong.ensure(2)) return e2; }
   launch_ent_sample(d_recs, S, N, ts0, ts_scene_stride, np, ns, E.sp.T_span, E.d_sampled.p, E.d_present.p, st);
   ea.sampled = E.d_sampled.p; ea.present = E.d_present.p; ea.srep = E.d_srep.p; ea.slong = E.d_slong.p;
-  ea.nodes = E.d_fe_nodes.p; ea.work = E.d_fe_work.p; ea.ns = ns; ea.init = nullptr; ea.case_out = nullptr;
+  ea.nodes = E.d_fe_nodes.p; ea.work = E.d_fe_work.p; ea.ns = ns; ea.init = nullptr; ea.case_out = nullptr; ea.saved = nullptr; ea.saved_arc = nullptr;
   return 0;
 }
 }  // namespace
@@ -948,6 +948,12 @@ int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj
   FeEntArgs ea{};
   if (int e = ent_prepare(h, cfg->ent_samples, cfg->beam_width, d_committed, &d_start->t_start, (long)sizeof(nep_fe_start) * E.sp.n_local, ea, (hipStream_t)stream)) return e;
   ea.init = d_ent_init; ea.case_out = d_case_out;
+  {   // what every surviving child arrived with, kept for the depth's installs (the winners are not propagated twice)
+    const size_t cap = frontend_children_cap(*cfg, h->cfg.num_pol);
+    if (int e = E.d_fe_saved.ensure((size_t)h->slots * cap)) return e;
+    if (int e = E.d_fe_arc.ensure((size_t)h->slots * cap)) return e;
+    ea.saved = E.d_fe_saved.p; ea.saved_arc = E.d_fe_arc.p;
+  }
   launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
@@ -978,6 +984,12 @@ int nep_batch_frontend_ent_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const vo
   ea.sampled = (const double*)((const char*)d_blocks + b.samp); ea.present = (const int*)((const char*)d_blocks + b.present);
   ea.srep = E.d_srep.p; ea.slong = E.d_slong.p; ea.nodes = E.d_fe_nodes.p; ea.work = E.d_fe_work.p; ea.ns = h->ent_ns;
   ea.init = d_ent_init; ea.case_out = d_case_out;
+  {   // what every surviving child arrived with, kept for the depth's installs (the winners are not propagated twice)
+    const size_t cap = frontend_children_cap(*cfg, h->cfg.num_pol);
+    if (int e = E.d_fe_saved.ensure((size_t)h->slots * cap)) return e;
+    if (int e = E.d_fe_arc.ensure((size_t)h->slots * cap)) return e;
+    ea.saved = E.d_fe_saved.p; ea.saved_arc = E.d_fe_arc.p;
+  }
   launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1161,7 +1173,7 @@ int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* se
 
 // development aid: per-phase shader cycles of the QP kernel (only with NEP_QP_PROFILE set at create)
 int nep_batch_debug_phase_cycles(nep_batch_t* h, int32_t slot, int64_t* out16) {
-  if (!h || !out16 || slot < 0 || slot >= h->slots) return fail(NEP_E_ARG, "bad arguments");
+  if (!h || !out16 || slot < 0 || slot >= 2 * h->slots) return fail(NEP_E_ARG, "bad arguments");      // (the front end keeps 32 values per slot: rows 2 slot and 2 slot + 1)
   if (!h->eng.profile_phases) return fail(NEP_E_STATE, "NEP_QP_PROFILE was not set when the handle was created");
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out16, h->eng.d_dbg.p + (size_t)slot * 16, 16 * sizeof(long long), hipMemcpyDeviceToHost));

@@ -23,10 +23,14 @@ struct EntCtx {
   const double* sampled;     // [scenes][N][num_pol][ns+1][2] (scene 0's / block 0's base: indexed through hull_ref like the hulls)
   const int* present;        // [scenes][N]
   const ProblemSet* ps; int scene, n_hull;      // bend points come with the hull data (hull_ref)
+  // Optional (front end): bit i set = agent i / static i MAY add a crossing for the step at hand; a clear bit is a proof that it
+  // cannot (frontend_kernel's per-parent masks).  nullptr: everybody is examined.
+  const unsigned* m_agent = nullptr; const unsigned* m_static = nullptr;
+  long long* prof = nullptr;      // (NEP_PROFILE_PHASES builds: seven per-search accumulators, see scripts/fe_ent_phases.py)
 };
 struct Ev2 { double x, y; };
 constexpr int kEntAddCap = 32;
-struct EntAdd { short id[kEntAddCap]; signed char cs[kEntAddCap]; int n, overflow; };
+struct EntAdd { short id[kEntAddCap]; signed char cs[kEntAddCap]; signed char nb[kEntAddCap]; int n, overflow; };      // (nb: the crossed agent's bend-point count, known where the crossing is found — the merge needs it)
 
 __device__ __forceinline__ Ev2 ent_pb(const EntCtx& c, int j) { return Ev2{c.pb[2 * j], c.pb[2 * j + 1]}; }
 __device__ __forceinline__ Ev2 ent_srep(const EntCtx& c, int s, int col) { return Ev2{c.srep[(s * 2 + col) * 2], c.srep[(s * 2 + col) * 2 + 1]}; }
@@ -38,7 +42,7 @@ __device__ __forceinline__ double ent_wedge(Ev2 a, Ev2 b, Ev2 cc) { return (b.x 
 __device__ __forceinline__ double ent_wedge2(Ev2 a, Ev2 b, Ev2 cc, Ev2& ab, Ev2& ac) { ab.x = b.x - a.x; ab.y = b.y - a.y; ac.x = cc.x - a.x; ac.y = cc.y - a.y; return ab.x * ac.y - ac.x * ab.y; }
 __device__ __forceinline__ double ent_ratio(Ev2 u, Ev2 v) { return fabs(u.y * v.y) > fabs(u.x * v.x) ? u.y / v.y : u.x / v.x; }
 __device__ __forceinline__ double ent_dist(Ev2 a, Ev2 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
-__device__ __forceinline__ void ent_push(EntAdd& a, int id, int cs) { if (a.n < kEntAddCap) { a.id[a.n] = (short)id; a.cs[a.n] = (signed char)cs; a.n++; } else a.overflow = 1; }
+__device__ __forceinline__ void ent_push(EntAdd& a, int id, int cs, int nb = 0) { if (a.n < kEntAddCap) { a.id[a.n] = (short)id; a.cs[a.n] = (signed char)cs; a.nb[a.n] = (signed char)nb; a.n++; } else a.overflow = 1; }
 
 __device__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id) {
   bool base_addition = false;
@@ -54,22 +58,23 @@ __device__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1,
       if (f1 * f2 < 0) {
         const double a = ent_ratio(ub, vb);
         if (a < 0) { }
-        else if (a < 1) ent_push(add, agent_id, 1);
-        else if (k == 0) ent_push(add, agent_id, 0);
+        else if (a < 1) ent_push(add, agent_id, 1, nb);
+        else if (k == 0) ent_push(add, agent_id, 0, nb);
         base_addition = true;
       }
     }
     if (c1 * c2 < 0) {
       const double a = ent_ratio(u, v);
-      if (a < 0) ent_push(add, agent_id, k + 2);
-      else if (a < 1 && last) ent_push(add, agent_id, 1);
-      else if (a >= 1 && k == 0) ent_push(add, agent_id, 0);
+      if (a < 0) ent_push(add, agent_id, k + 2, nb);
+      else if (a < 1 && last) ent_push(add, agent_id, 1, nb);
+      else if (a >= 1 && k == 0) ent_push(add, agent_id, 0, nb);
     }
   }
   if (base_addition && add.n >= 2 && add.id[add.n - 1] == add.id[add.n - 2] && add.cs[add.n - 1] == add.cs[add.n - 2]) add.n -= 2;
 }
 __device__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, const EntCtx& c) {
   for (int s = 0; s < c.S; s++) {
+    if (c.m_static && !((c.m_static[s >> 5] >> (s & 31)) & 1u)) { s |= 31 * !c.m_static[s >> 5]; continue; }   // (an empty word is skipped whole)
     const Ev2 pik = ent_srep(c, s, 1), pbi = ent_srep(c, s, 0);
     Ev2 u, v;
     const double c1 = ent_wedge2(pk, pik, pbi, u, v), c2 = ent_wedge(pk1, pik, pbi);
@@ -109,14 +114,14 @@ __device__ bool ent_merge(EntAdd& add, nep_fe_ent_state* st, Ev2 pk, Ev2 pb_self
     for (int i = 0; i < add.n && !again; i++) {
       const int t_id = add.id[i], t_cs = add.cs[i];
       const bool agent = t_id <= c.N;
-      const int t_nb = agent ? ent_bend_n(c, t_id - 1) : 0;
+      const int t_nb = agent ? add.nb[i] : 0;
       for (int j = st->n_alpha - 1; j >= 0; j--) {
         const int l_id = st->id[j], l_cs = st->cs[j];
         const bool match = (l_id == t_id && l_cs == t_cs) ||
                            (agent && l_id == t_id && t_cs >= t_nb + 1 && t_cs < l_cs) ||
                            (agent && l_id == t_id && l_cs >= 2 && t_cs >= 2 && abs(t_cs - l_cs) == 1 && j > b);
         if (match) {
-          for (int k = i; k + 1 < add.n; k++) { add.id[k] = add.id[k + 1]; add.cs[k] = add.cs[k + 1]; }
+          for (int k = i; k + 1 < add.n; k++) { add.id[k] = add.id[k + 1]; add.cs[k] = add.cs[k + 1]; add.nb[k] = add.nb[k + 1]; }
           add.n--;
           ent_erase(st, j);
           if (j == b) {
@@ -185,8 +190,15 @@ __device__ int ent_propagate(const EntCtx& c, nep_fe_ent_state* st, const double
   const int ns = c.ns;
   const Ev2 pb_self = ent_pb(c, c.own);
   Ev2 pk{cxo[3], cyo[3]}, pk1 = pk;
+#ifdef NEP_PROFILE_PHASES
+  long long pt[5] = {0, 0, 0, 0, 0}; long long pl = clock64(); int p_add = 0;
+#define ENT_PT(k) do { const long long t_ = clock64(); pt[k] += t_ - pl; pl = t_; } while (0)
+#else
+#define ENT_PT(k) do { } while (0)
+#endif
   for (int j = 1; j <= ns; j++) {
     EntAdd add; add.n = 0; add.overflow = 0;
+    ENT_PT(4);
     if (j < ns) {
       const double t = c.T_span * j / ns;
       const double t3 = t * t * t, t2 = t * t;
@@ -194,6 +206,7 @@ __device__ int ent_propagate(const EntCtx& c, nep_fe_ent_state* st, const double
     } else pk1 = end;
     arc += ent_dist(pk1, pk);
     for (int i = 0; i < c.N; i++) {
+      if (c.m_agent && !((c.m_agent[i >> 5] >> (i & 31)) & 1u)) { i |= 31 * !c.m_agent[i >> 5]; continue; }      // (an empty word is skipped whole)
       if (i == c.own) continue;
       const HullRef hr = hull_ref(*c.ps, c.n_hull, c.scene, i);
       if (!blk(c.present, hr.boff)[hr.e]) continue;
@@ -202,23 +215,40 @@ __device__ int ent_propagate(const EntCtx& c, nep_fe_ent_state* st, const double
       else { pik = ent_sampled(c, hr, index - 1, j - 1); pik1 = ent_sampled(c, hr, index - 1, j); }
       ent_cross_agent(add, pk, pk1, pik, pik1, pb_self, blk(c.ps->bend_n, hr.boff)[hr.e], blk(c.ps->bend_xy, hr.boff) + hr.e * kBend * 2, i + 1);
     }
+    ENT_PT(0);
     ent_cross_static(add, pk, pk1, c);
+    ENT_PT(1);
+#ifdef NEP_PROFILE_PHASES
+    p_add += add.n > 0;
+#endif
     if (add.overflow) return 2;
     if (st->n_alpha + add.n > (c.N + c.S) * cap_mult) return 1;
-    short old_id[NEP_FE_ENT_CAP]; const int old_n = st->n_alpha;
-    for (int i = 0; i < old_n; i++) old_id[i] = st->id[i];
-    if (ent_merge(add, st, pk, pb_self, c)) return 2;
-    for (int i = 0; i < st->n_alpha; i++) {
-      const int id = st->id[i];
-      if (id > c.N) continue;
-      const int nw = ent_count(st->id, st->n_alpha, id), od = ent_count(old_id, old_n, id);
-      if (od < 2 && nw >= 2) return 1;
-      if (od >= 2 && nw > od) return 1;
+    if (add.n > 0) {     // (no crossing in this step: the list, and with it every count below, is what it was)
+      // entanglesWithOtherAgents compares, for every agent in the new list, its number of entries before and after the merge
+      // (:870-887: a second entry where there was at most one, or one more where there were two, prunes the child).  The merge
+      // only ever touches entries of the agents in `add`, so theirs are the only counts that can differ: the old ones are
+      // taken before the merge, for those agents only — no copy of the old list, no pass over every pair of entries.
+      short a_id[kEntAddCap]; signed char a_od[kEntAddCap]; const int a_n = add.n;
+      for (int e = 0; e < a_n; e++) { a_id[e] = add.id[e]; a_od[e] = (signed char)(add.id[e] <= c.N ? ent_count(st->id, st->n_alpha, add.id[e]) : 0); }
+      if (ent_merge(add, st, pk, pb_self, c)) return 2;
+      for (int e = 0; e < a_n; e++) {
+        if (a_id[e] > c.N) continue;
+        const int nw = ent_count(st->id, st->n_alpha, a_id[e]), od = a_od[e];
+        if (od < 2 && nw >= 2) return 1;
+        if (od >= 2 && nw > od) return 1;
+      }
     }
+    ENT_PT(2);
     if (ent_update_bends(st, pk1, pb_self, c)) return 2;
+    ENT_PT(3);
     pk = pk1;
   }
-  if (check_tether && ent_tether(st, pb_self, pk1, c) > c.cable) return 1;
+  const bool too_long = check_tether && ent_tether(st, pb_self, pk1, c) > c.cable;
+  ENT_PT(4);
+#ifdef NEP_PROFILE_PHASES
+  if (c.prof) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)c.prof + k, (unsigned long long)pt[k]); atomicAdd((unsigned long long*)c.prof + 5, 1ull); atomicAdd((unsigned long long*)c.prof + 6, (unsigned long long)p_add); }
+#endif
+  if (too_long) return 1;
   return 0;
 }
 __device__ unsigned ent_iz(const nep_fe_ent_state* st) {

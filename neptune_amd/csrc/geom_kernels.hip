@@ -1449,8 +1449,11 @@ void launch_boxes(int n_scenes, const SceneParams& sp, const ProblemSet& ps, hip
   if (nb > 0) hipLaunchKernelGGL(fe_box_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, sp, ps, n_scenes);
 }
 
+#ifndef NEP_FE_ENT_WGS
+#define NEP_FE_ENT_WGS 2      // workgroups per CU of the entangle instantiation: 2 = working records in global memory, registers bounded to 256 (19.9 ms per 2 048 config-5 searches); 1 = working records in LDS, 139 KB (27.4 ms: the list surgery is latency-bound, a second workgroup hides more than LDS saves)
+#endif
 template <bool ENT>
-__global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
+__global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
                                                        nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out, FeEntArgs ea) {
   extern __shared__ __attribute__((aligned(16))) double fe_smem[];
   const int tid = threadIdx.x;
@@ -1487,12 +1490,21 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
   nep_fe_ent_state* my_work = nullptr;
   unsigned char* b_valid = (unsigned char*)(p_comb + (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM);   // [64] may a plan end at this rank
   auto ent_node = [&](int d, int r) -> nep_fe_ent_state* { return ea.nodes + (((long)slot * (D + 1) + d) * W + r); };
+  // ENT: per parent of the depth at hand, who can matter to ANY of its children (bit sets over the agents / statics; filled next
+  // to the shortlist from the parent's children box, see there)
+  const int MW = (N + 31) >> 5, SW = (S + 31) >> 5;
+  unsigned* m_ent = (unsigned*)(b_valid + NEP_FE_MAX_BEAM + ((4 - ((3 * kFeCap) & 3)) & 3));      // [64][MW] agents whose tether a child's step may cross (aligned: every array before r_id is a multiple of four bytes)
+  unsigned* m_base = m_ent + NEP_FE_MAX_BEAM * MW;               // [64][MW] agents whose base square a child may be near
+  unsigned* m_stat = m_base + NEP_FE_MAX_BEAM * MW;              // [64][SW] static representatives a child's step may cross
   if constexpr (ENT) {
     ec.N = N; ec.S = S; ec.own = own; ec.num_pol = D; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = fc.cable_length;
     ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
     ec.sampled = ea.sampled; ec.present = ea.present;
     ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
-    my_work = ea.work + ((long)slot * 256 + tid);
+#ifdef NEP_PROFILE_PHASES
+    ec.prof = ps.dbg ? ps.dbg + (long)slot * 32 + 16 : nullptr;
+#endif
+    my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(m_stat + NEP_FE_MAX_BEAM * SW) + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
     if (tid == 0) {
       nep_fe_ent_state* root = ent_node(0, 0);
       if (ea.init) ent_copy(root, ea.init + slot);
@@ -1502,7 +1514,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
   }
   int my_entangled = 0, my_overflow = 0;
 #ifdef NEP_PROFILE_PHASES
-  if (ps.dbg && tid < 16) ps.dbg[(long)slot * 16 + tid] = 0;
+  if (ps.dbg && tid < 32) ps.dbg[(long)slot * 32 + tid] = 0;
 #endif
   if (tid < 32) s_i[tid] = 0;     // [0] shortlist n, [1] winners n, [2] GJK work list n, [4] children, [5] feasible, [6] collision free, [7] goal occupied
   for (int k = tid; k < kFeVis; k += 256) v_key[k] = kFeEmpty;
@@ -1530,9 +1542,14 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
   int my_children = 0, my_feasible = 0, my_free = 0;
 #ifdef NEP_PROFILE_PHASES
   long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = clock64();
+  long long tent[4] = {0, 0, 0, 0};      // ENT, this thread: base squares, state copy, propagation, mask fill
+#define FE_ENT_T0() const long long te0_ = clock64()
+#define FE_ENT_T(k) tent[k] += clock64() - te0_
 #define FE_TICK(k) do { const long long t_ = clock64(); tph[k] += t_ - tlast; tlast = t_; } while (0)
 #else
 #define FE_TICK(k) do { } while (0)
+#define FE_ENT_T0() do { } while (0)
+#define FE_ENT_T(k) do { } while (0)
 #endif
   const double tau = sp.T_span;
   // box of a node's children: the control points are monotone in the jerk, so the four corner children bound them all (a
@@ -1557,6 +1574,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
   };
   if (tid == 0) children_box(b_end, 0);
   for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
+  if constexpr (ENT) { for (int k = tid; k < NEP_FE_MAX_BEAM * (2 * MW + SW); k += 256) m_ent[k] = 0u; }
   __syncthreads();
   for (depth = 1; depth <= D; depth++) {
     const int cur = depth & 1, prv = cur ^ 1;
@@ -1597,6 +1615,64 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
         }
       }
     }
+    if constexpr (ENT) {
+      // ---- who can matter to a parent's children.  A child's sampled step p_k -> p_k1 adds a crossing with a tether segment
+      //      only if the two points lie on strictly opposite sides of the segment's line (ent_cross_agent: c1 c2 < 0); every
+      //      sample of every child lies in the parent's children box (control-point box of the corner children), and the
+      //      wedge is affine in the point: if all four box corners are on one side by a margin far above the wedge's rounding
+      //      (1e-6 m^2 against < 1e-10), so is every sample, in exact and in floating-point arithmetic, and the agent adds
+      //      nothing — for the last tether segment, whose far end moves with the agent, the same side of all ns + 1 sampled
+      //      lines.  The one test that does not involve the child (the agent's tether sweeping over OUR base) is evaluated as
+      //      is.  Base squares: an agent farther than the cull distance from the whole box is farther from any first control
+      //      point.  A clear bit is a proof; a set bit only means "run the reference's test".  255 agents x 3 steps per child
+      //      -> a dozen. ----
+      FE_ENT_T0();
+      const double kEps = 1e-6, kPad = 1e-9;
+      const double safe_dist = (sp.T_span * sp.v_max) * 2;
+      const int ens = ea.ns;
+      const Ev2 pb_self{ps.pb[2 * own], ps.pb[2 * own + 1]};
+      for (int e = tid; e < nb_prev * (N + S); e += 256) {
+        const int q = e / (N + S), j = e - q * (N + S);
+        const double x0 = p_box[4 * q] - kPad, x1 = p_box[4 * q + 1] + kPad, y0 = p_box[4 * q + 2] - kPad, y1 = p_box[4 * q + 3] + kPad;
+        auto side = [&](Ev2 b, Ev2 cc) -> int {      // +1 / -1: every corner strictly on that side of the line (as ent_wedge(p, b, cc) sees it); 0: undecided
+          const double w0 = ent_wedge(Ev2{x0, y0}, b, cc), w1 = ent_wedge(Ev2{x1, y0}, b, cc), w2 = ent_wedge(Ev2{x0, y1}, b, cc), w3 = ent_wedge(Ev2{x1, y1}, b, cc);
+          const double lo = fmin(fmin(w0, w1), fmin(w2, w3)), hi = fmax(fmax(w0, w1), fmax(w2, w3));
+          return lo > kEps ? 1 : (hi < -kEps ? -1 : 0);
+        };
+        if (j < N) {
+          if (j == own) continue;
+          const HullRef hr = hull_ref(ps, sp.n_hull, scene, j);
+          {   // collidesWithBases2d's distance cull, from the box
+            const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
+            const double dx = fmax(fmax(x0 - pbx, pbx - x1), 0.0), dy = fmax(fmax(y0 - pby, pby - y1), 0.0);
+            if (sqrt(dx * dx + dy * dy) <= safe_dist + 1e-6) atomicOr(&m_base[q * MW + (j >> 5)], 1u << (j & 31));
+          }
+          if (!blk(ec.present, hr.boff)[hr.e]) continue;
+          const int nbj = blk(ps.bend_n, hr.boff)[hr.e];
+          const double* bp = blk(ps.bend_xy, hr.boff) + hr.e * kBend * 2;
+          bool maybe = false;
+          for (int k = 0; k + 1 < nbj; k++) maybe |= side(Ev2{bp[2 * (k + 1)], bp[2 * (k + 1) + 1]}, Ev2{bp[2 * k], bp[2 * k + 1]}) == 0;
+          if (nbj >= 1) {
+            const Ev2 bk{bp[2 * (nbj - 1)], bp[2 * (nbj - 1) + 1]};
+            Ev2 pik = ent_sampled(ec, hr, idx, 0);
+            const int s0 = side(pik, bk);
+            maybe |= s0 == 0;
+            for (int jj = 1; jj <= ens; jj++) {
+              const Ev2 pik1 = ent_sampled(ec, hr, idx, jj);
+              maybe |= side(pik1, bk) != s0;
+              const double f1 = ent_wedge(pb_self, pik, bk), f2 = ent_wedge(pb_self, pik1, bk);
+              maybe |= f1 * f2 < 0;
+              pik = pik1;
+            }
+          }
+          if (maybe) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
+        } else {
+          const int sj = j - N;
+          if (side(ent_srep(ec, sj, 1), ent_srep(ec, sj, 0)) == 0) atomicOr(&m_stat[q * SW + (sj >> 5)], 1u << (sj & 31));
+        }
+      }
+      FE_ENT_T(3);
+    }
     __syncthreads();
     FE_TICK(2);
     const int n_obs = s_i[0];
@@ -1610,11 +1686,14 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
       unsigned iz = 0;
       if constexpr (ENT) {
         {   // collidesWithBases2d: the other agents' 0.7 m base squares within 2 T v_max of the first control point
+          FE_ENT_T0();
           const double radius = 0.7, safe_dist = (sp.T_span * sp.v_max) * 2;
           Pts4 Bq;
 #pragma unroll
           for (int i = 0; i < 4; i++) { Bq.x[i] = ch.Qx[i]; Bq.y[i] = ch.Qy[i]; }
+          const unsigned* mb = m_base + (id / NC) * MW;
           for (int j = 0; j < N; j++) {
+            if (!((mb[j >> 5] >> (j & 31)) & 1u)) { j |= 31 * !mb[j >> 5]; continue; }      // (farther than the cull distance from every child of this parent)
             if (j == own) continue;
             const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
             const double d1 = sqrt((ch.Qx[0] - pbx) * (ch.Qx[0] - pbx) + (ch.Qy[0] - pby) * (ch.Qy[0] - pby));
@@ -1622,13 +1701,17 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
             const double sq[8] = {pbx + radius, pby + radius, pbx + radius, pby - radius, pbx - radius, pby - radius, pbx - radius, pby + radius};
             if (gjk_collision(4, sq, Bq)) { s_state[id] = 0; return; }
           }
+          FE_ENT_T(0);
         }
         my_free++;
         const int pr_ = id / NC;
-        ent_copy(my_work, ent_node(depth - 1, depth == 1 ? 0 : pr_));
+        { FE_ENT_T0(); ent_copy(my_work, ent_node(depth - 1, depth == 1 ? 0 : pr_)); FE_ENT_T(1); }
         double arc = 0.0;
-        const int rc = ent_propagate(ec, my_work, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1);
+        ec.m_agent = m_ent + pr_ * MW; ec.m_static = m_stat + pr_ * SW;
+        int rc;
+        { FE_ENT_T0(); rc = ent_propagate(ec, my_work, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
         if (rc) { my_entangled++; if (rc == 2) my_overflow = 1; s_state[id] = 0; return; }
+        ent_copy(ea.saved + ((long)slot * kFeCap + id), my_work); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
         ch.g = b_g[prv * NEP_FE_MAX_BEAM + pr_] + arc;
         ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)my_work->n_alpha) + 1.0 * (double)my_work->n_bend);
         iz = ent_iz(my_work);
@@ -1680,7 +1763,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
     __syncthreads();
     const int n_work = s_i[2];
 #ifdef NEP_PROFILE_PHASES
-    if (tid == 0 && ps.dbg) { ps.dbg[(long)slot * 16 + 9] += n_work; ps.dbg[(long)slot * 16 + 10] += n_obs; ps.dbg[(long)slot * 16 + 11] += n_c; }
+    if (tid == 0 && ps.dbg) { ps.dbg[(long)slot * 32 + 9] += n_work; ps.dbg[(long)slot * 32 + 10] += n_obs; ps.dbg[(long)slot * 32 + 11] += n_c; }
 #endif
     for (int w = tid; w < n_work; w += 256) {
       const int id = r_id[w];
@@ -1737,10 +1820,11 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
         FeChild ch;
         fe_child_again<false>(sp, fc, lat, pe, pg, cc / ns, cc % ns, gx, gy, ch);
         if constexpr (ENT) {   // the same propagation again, this time into the node's own record
-          nep_fe_ent_state* nd = ent_node(depth, rank);
-          ent_copy(nd, ent_node(depth - 1, depth == 1 ? 0 : pr));
-          double arc = 0.0;
-          ent_propagate(ec, nd, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1);
+          // the state and the arc length this child arrived with were kept by whoever examined it (a second propagation here, by
+          // up to beam_width threads while the others wait, was a quarter of the search)
+          const nep_fe_ent_state* nd = ea.saved + ((long)slot * kFeCap + i);
+          ent_copy(ent_node(depth, rank), nd);
+          const double arc = ea.saved_arc[(long)slot * kFeCap + i];
           ch.g = pg + arc;
           ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)nd->n_alpha) + 1.0 * (double)nd->n_bend);
           b_valid[rank] = ent_valid_endpoint(nd, N) ? 1 : 0;
@@ -1759,6 +1843,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
     if (tid == 0) { s_i[0] = 0; s_i[2] = 0; }
     for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
     __syncthreads();
+    if constexpr (ENT) { for (int k = tid; k < NEP_FE_MAX_BEAM * (2 * MW + SW); k += 256) m_ent[k] = 0u; __syncthreads(); }      // (read by the installs above, filled again by the next depth)
     FE_TICK(6);
     if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
     nb_prev = nb;
@@ -1773,7 +1858,7 @@ __global__ __launch_bounds__(256, ENT ? 1 : NEP_FE_WAVES) void frontend_kernel(S
   if constexpr (ENT) { atomicAdd(&s_i[8], my_entangled); if (my_overflow) s_i[9] = 1; }
   __syncthreads();
 #ifdef NEP_PROFILE_PHASES
-  if (ps.dbg && tid == 0) { for (int k = 0; k < 8; k++) ps.dbg[(long)slot * 16 + k] = tph[k]; ps.dbg[(long)slot * 16 + 8] = depth; }
+  if (ps.dbg && tid == 0) { for (int k = 0; k < 8; k++) ps.dbg[(long)slot * 32 + k] = tph[k]; ps.dbg[(long)slot * 32 + 8] = depth; for (int k = 0; k < 4; k++) ps.dbg[(long)slot * 32 + 12 + k] = tent[k]; }
 #endif
   if (tid == 0) {
     nep_guess* g = guess_out + slot;
@@ -1844,21 +1929,23 @@ void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const
   hipLaunchKernelGGL(gjk_explicit_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, st, n_prob, a_off, a_xy, b_xy, hit);
 }
 
-size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc) {
+size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol) { return (size_t)fe_sizes(fc.beam_width, fc.num_samples, num_pol).cap; }
+size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc, bool ent) {
   const size_t NS = (size_t)sp.num_agents + sp.n_static;
   const FeSizes z = fe_sizes(fc.beam_width, fc.num_samples, sp.num_pol);
   size_t b = sizeof(double) * (2 * (size_t)z.cap + 2 * NEP_FE_MAX_BEAM * 6 + 2 * NEP_FE_MAX_BEAM + 2 * NEP_FE_MAX_BEAM + 4 * NEP_FE_MAX_BEAM + 4 * NS + kFeObsLds * kHullV * 2 + 4 * NEP_FE_MAX_SAMPLES)
            + sizeof(long long) * ((size_t)z.cap + z.vis) + sizeof(int) * (z.dd + 2 * NS + 32)
            + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM + NEP_FE_MAX_BEAM;
+  if (ent) b = ((b + 3) & ~(size_t)3) + sizeof(unsigned) * NEP_FE_MAX_BEAM * (2 * (size_t)((sp.num_agents + 31) >> 5) + (size_t)((sp.n_static + 31) >> 5)) + (NEP_FE_ENT_WGS == 1 ? 256 * sizeof(nep_fe_ent_state) + 8 : 0);
   return (b + 15) & ~(size_t)15;
 }
 
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
                      nep_guess* guess_out, nep_fe_result* res_out, const FeEntArgs* ea, hipStream_t st) {
   if (n_slots <= 0) return;
-  const size_t lds = frontend_lds_bytes(sp, fc);
-  static DynLdsAttr attr[2];
   const bool ent = ea != nullptr;
+  const size_t lds = frontend_lds_bytes(sp, fc, ent);
+  static DynLdsAttr attr[2];
   (void)attr[ent].ensure(ent ? (const void*)frontend_kernel<true> : (const void*)frontend_kernel<false>, lds);
   FeEntArgs none{};
   launch_boxes(n_slots / (sp.n_local > 0 ? sp.n_local : 1), sp, ps, st);

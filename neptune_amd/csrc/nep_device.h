@@ -151,10 +151,13 @@ struct FeEntArgs {
   const double* slong;           // [S][2]    staticObsLongestDist_
   const nep_fe_ent_state* init;  // [slots] entangle state at point A, or null (empty)
   nep_fe_ent_state* nodes;       // [slots][num_pol+1][beam_width] states of the installed nodes
-  nep_fe_ent_state* work;        // [slots][256] one working record per thread
+  nep_fe_ent_state* work;        // [scenes * N] one working record per thread of ent_check_kernel
+  nep_fe_ent_state* saved;       // [slots][children cap] the state every surviving child of the depth at hand arrived with (frontend_children_cap)
+  double* saved_arc;             // [slots][children cap] and its sampled arc length
   int* case_out;                 // [slots][NEP_MAX_POL][N] (out) or null
   int ns;                        // num_sample_per_interval
 };
+size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol);      // children per depth of one search (beam_width x lattice)
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
                      nep_guess* guess_out, nep_fe_result* res_out, const FeEntArgs* ea, hipStream_t st);
 void launch_ent_sample(const nep_traj_rec* recs, int n_scenes, int N, const double* ts0, long ts_scene_stride, int num_pol, int ns, double T_span,

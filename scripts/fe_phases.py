@@ -1,6 +1,7 @@
 """Per-phase shader cycles of the front-end kernel for two slots (build with make PROFILE=1, NEP_QP_PROFILE=1)."""
 import os, sys
 os.environ["NEP_QP_PROFILE"] = "1"
+os.environ.setdefault("NEP_BACKEND_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "neptune_amd", "libneptune_backend_prof.so"))
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from neptune_amd import scene, backend, abi
@@ -16,7 +17,7 @@ for _ in range(3): bb.frontend(fe, bb.to_device(com), bb.to_device(st), d_g)
 torch.cuda.synchronize()
 names = ["loop top/barrier", "parent boxes + clear", "shortlist", "children pass 2 (GJK)", "voxel dedup", "compact", "rank + install", "children pass 1"]
 for slot in (0, 100):
-    c = bb.debug_phase_cycles(slot); tot = sum(c[:8]); d = max(c[8], 1)
+    c = bb.debug_phase_cycles(2 * slot); tot = sum(c[:8]); d = max(c[8], 1)
     print("slot %d: depths %d total %d" % (slot, d, tot))
     print('   per depth: GJK work list %d, shortlist %d, children %d' % (c[9] // d, c[10] // d, c[11] // d))
     for k, n in enumerate(names[:8]): print("   %-22s %9d  per-depth %7d  %5.1f%%" % (n, c[k], c[k] // d, 100.0 * c[k] / max(tot, 1)))
