@@ -44,6 +44,45 @@ __device__ __forceinline__ double ent_ratio(Ev2 u, Ev2 v) { return fabs(u.y * v.
 __device__ __forceinline__ double ent_dist(Ev2 a, Ev2 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
 __device__ __forceinline__ void ent_push(EntAdd& a, int id, int cs, int nb = 0) { if (a.n < kEntAddCap) { a.id[a.n] = (short)id; a.cs[a.n] = (signed char)cs; a.nb[a.n] = (signed char)nb; a.n++; } else a.overflow = 1; }
 
+// ---- proofs that an obstacle adds no crossing for ANY sampled step inside a box (frontend_kernel's per-parent masks,
+// ent_check_kernel's per-trajectory mask).  A step p_k -> p_k1 adds a crossing with a tether segment only if the two points lie
+// on strictly opposite sides of the segment's line (ent_cross_agent: c1 c2 < 0), and the wedge is affine in the point: if all
+// four corners of a box that holds every sample are on one side by a margin far above the wedge's rounding (1e-6 m^2 against
+// < 1e-10), so is every sample, in exact and in floating-point arithmetic.  For the last tether segment, whose far end moves
+// with the agent, the same side of all ns + 1 sampled lines.  The one test that does not involve the step (the agent's tether
+// sweeping over OUR base) is evaluated as is.  false is a proof; true only means "run the reference's test".
+struct EntBox { double x0, x1, y0, y1; };
+__device__ __forceinline__ int ent_side(const EntBox& q, Ev2 b, Ev2 cc) {      // +1 / -1: every corner strictly on that side of the line (as ent_wedge(p, b, cc) sees it); 0: undecided
+  const double kEps = 1e-6;
+  const double w0 = ent_wedge(Ev2{q.x0, q.y0}, b, cc), w1 = ent_wedge(Ev2{q.x1, q.y0}, b, cc), w2 = ent_wedge(Ev2{q.x0, q.y1}, b, cc), w3 = ent_wedge(Ev2{q.x1, q.y1}, b, cc);
+  const double lo = fmin(fmin(w0, w1), fmin(w2, w3)), hi = fmax(fmax(w0, w1), fmax(w2, w3));
+  return lo > kEps ? 1 : (hi < -kEps ? -1 : 0);
+}
+__device__ bool ent_agent_may_cross(const EntCtx& c, const EntBox& q, int j, int interval) {      // (j != own)
+  const HullRef hr = hull_ref(*c.ps, c.n_hull, c.scene, j);
+  if (!blk(c.present, hr.boff)[hr.e]) return false;
+  const int nbj = blk(c.ps->bend_n, hr.boff)[hr.e];
+  const double* bp = blk(c.ps->bend_xy, hr.boff) + hr.e * kBend * 2;
+  const Ev2 pb_self = ent_pb(c, c.own);
+  bool maybe = false;
+  for (int k = 0; k + 1 < nbj; k++) maybe |= ent_side(q, Ev2{bp[2 * (k + 1)], bp[2 * (k + 1) + 1]}, Ev2{bp[2 * k], bp[2 * k + 1]}) == 0;
+  if (nbj >= 1) {
+    const Ev2 bk{bp[2 * (nbj - 1)], bp[2 * (nbj - 1) + 1]};
+    Ev2 pik = ent_sampled(c, hr, interval, 0);
+    const int s0 = ent_side(q, pik, bk);
+    maybe |= s0 == 0;
+    for (int jj = 1; jj <= c.ns; jj++) {
+      const Ev2 pik1 = ent_sampled(c, hr, interval, jj);
+      maybe |= ent_side(q, pik1, bk) != s0;
+      const double f1 = ent_wedge(pb_self, pik, bk), f2 = ent_wedge(pb_self, pik1, bk);
+      maybe |= f1 * f2 < 0;
+      pik = pik1;
+    }
+  }
+  return maybe;
+}
+__device__ __forceinline__ bool ent_static_may_cross(const EntCtx& c, const EntBox& q, int s) { return ent_side(q, ent_srep(c, s, 1), ent_srep(c, s, 0)) == 0; }
+
 __device__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id) {
   bool base_addition = false;
   for (int k = 0; k < nb; k++) {

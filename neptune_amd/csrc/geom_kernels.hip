@@ -1616,59 +1616,27 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
       }
     }
     if constexpr (ENT) {
-      // ---- who can matter to a parent's children.  A child's sampled step p_k -> p_k1 adds a crossing with a tether segment
-      //      only if the two points lie on strictly opposite sides of the segment's line (ent_cross_agent: c1 c2 < 0); every
-      //      sample of every child lies in the parent's children box (control-point box of the corner children), and the
-      //      wedge is affine in the point: if all four box corners are on one side by a margin far above the wedge's rounding
-      //      (1e-6 m^2 against < 1e-10), so is every sample, in exact and in floating-point arithmetic, and the agent adds
-      //      nothing — for the last tether segment, whose far end moves with the agent, the same side of all ns + 1 sampled
-      //      lines.  The one test that does not involve the child (the agent's tether sweeping over OUR base) is evaluated as
-      //      is.  Base squares: an agent farther than the cull distance from the whole box is farther from any first control
-      //      point.  A clear bit is a proof; a set bit only means "run the reference's test".  255 agents x 3 steps per child
-      //      -> a dozen. ----
+      // ---- who can matter to a parent's children (ent_agent_may_cross, ent_device.h): every sample of every child lies in the
+      //      parent's children box (control-point box of the corner children).  Base squares: an agent farther than the cull
+      //      distance from the whole box is farther from any first control point.  A clear bit is a proof; a set bit only means
+      //      "run the reference's test".  255 agents x 3 steps per child -> a few dozen. ----
       FE_ENT_T0();
-      const double kEps = 1e-6, kPad = 1e-9;
+      const double kPad = 1e-9;
       const double safe_dist = (sp.T_span * sp.v_max) * 2;
-      const int ens = ea.ns;
-      const Ev2 pb_self{ps.pb[2 * own], ps.pb[2 * own + 1]};
       for (int e = tid; e < nb_prev * (N + S); e += 256) {
         const int q = e / (N + S), j = e - q * (N + S);
-        const double x0 = p_box[4 * q] - kPad, x1 = p_box[4 * q + 1] + kPad, y0 = p_box[4 * q + 2] - kPad, y1 = p_box[4 * q + 3] + kPad;
-        auto side = [&](Ev2 b, Ev2 cc) -> int {      // +1 / -1: every corner strictly on that side of the line (as ent_wedge(p, b, cc) sees it); 0: undecided
-          const double w0 = ent_wedge(Ev2{x0, y0}, b, cc), w1 = ent_wedge(Ev2{x1, y0}, b, cc), w2 = ent_wedge(Ev2{x0, y1}, b, cc), w3 = ent_wedge(Ev2{x1, y1}, b, cc);
-          const double lo = fmin(fmin(w0, w1), fmin(w2, w3)), hi = fmax(fmax(w0, w1), fmax(w2, w3));
-          return lo > kEps ? 1 : (hi < -kEps ? -1 : 0);
-        };
+        const EntBox bx{p_box[4 * q] - kPad, p_box[4 * q + 1] + kPad, p_box[4 * q + 2] - kPad, p_box[4 * q + 3] + kPad};
         if (j < N) {
           if (j == own) continue;
-          const HullRef hr = hull_ref(ps, sp.n_hull, scene, j);
           {   // collidesWithBases2d's distance cull, from the box
             const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
-            const double dx = fmax(fmax(x0 - pbx, pbx - x1), 0.0), dy = fmax(fmax(y0 - pby, pby - y1), 0.0);
+            const double dx = fmax(fmax(bx.x0 - pbx, pbx - bx.x1), 0.0), dy = fmax(fmax(bx.y0 - pby, pby - bx.y1), 0.0);
             if (sqrt(dx * dx + dy * dy) <= safe_dist + 1e-6) atomicOr(&m_base[q * MW + (j >> 5)], 1u << (j & 31));
           }
-          if (!blk(ec.present, hr.boff)[hr.e]) continue;
-          const int nbj = blk(ps.bend_n, hr.boff)[hr.e];
-          const double* bp = blk(ps.bend_xy, hr.boff) + hr.e * kBend * 2;
-          bool maybe = false;
-          for (int k = 0; k + 1 < nbj; k++) maybe |= side(Ev2{bp[2 * (k + 1)], bp[2 * (k + 1) + 1]}, Ev2{bp[2 * k], bp[2 * k + 1]}) == 0;
-          if (nbj >= 1) {
-            const Ev2 bk{bp[2 * (nbj - 1)], bp[2 * (nbj - 1) + 1]};
-            Ev2 pik = ent_sampled(ec, hr, idx, 0);
-            const int s0 = side(pik, bk);
-            maybe |= s0 == 0;
-            for (int jj = 1; jj <= ens; jj++) {
-              const Ev2 pik1 = ent_sampled(ec, hr, idx, jj);
-              maybe |= side(pik1, bk) != s0;
-              const double f1 = ent_wedge(pb_self, pik, bk), f2 = ent_wedge(pb_self, pik1, bk);
-              maybe |= f1 * f2 < 0;
-              pik = pik1;
-            }
-          }
-          if (maybe) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
+          if (ent_agent_may_cross(ec, bx, j, idx)) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
         } else {
           const int sj = j - N;
-          if (side(ent_srep(ec, sj, 1), ent_srep(ec, sj, 0)) == 0) atomicOr(&m_stat[q * SW + (sj >> 5)], 1u << (sj & 31));
+          if (ent_static_may_cross(ec, bx, sj)) atomicOr(&m_stat[q * SW + (sj >> 5)], 1u << (sj & 31));
         }
       }
       FE_ENT_T(3);
@@ -1998,33 +1966,57 @@ void launch_ent_sample(const nep_traj_rec* recs, int n_scenes, int N, const doub
 
 // KinodynamicSearch::entangleCheckGivenPwp for the first interval of every new trajectory (neptune.cpp:746-754): one thread
 // per (scene, agent); entangles[scene][a] = 1 turns the trajectory down in the safety pass.
-__global__ void ent_check_kernel(SceneParams sp, ProblemSet ps, FeEntArgs ea, const nep_traj_rec* __restrict__ fresh, int n_scenes, double cable, int* __restrict__ entangles) {
-  const int N = sp.num_agents;
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)n_scenes * N) return;
+__global__ __launch_bounds__(64) void ent_check_kernel(SceneParams sp, ProblemSet ps, FeEntArgs ea, const nep_traj_rec* __restrict__ fresh, int n_scenes, double cable, int* __restrict__ entangles) {
+  // one wave per trajectory: the lanes first prove, 64 obstacles at a time, who cannot add a crossing anywhere along the sampled
+  // interval (ent_agent_may_cross against the box of the samples), then lane 0 walks the reference's test over the rest
+  extern __shared__ unsigned m_ec[];
+  const int N = sp.num_agents, S = sp.n_static, lane = threadIdx.x;
+  unsigned* m_agent = m_ec; unsigned* m_static = m_ec + ((N + 63) >> 6) * 2;
+  const long idx = blockIdx.x;
   const int scene = (int)(idx / N), a = (int)(idx % N);
   const nep_traj_rec* r = fresh + idx;
-  int hit = 0;
-  if (r->valid && r->pwp.n_seg >= 1) {
-    EntCtx ec;
-    ec.N = N; ec.S = sp.n_static; ec.own = a; ec.num_pol = sp.num_pol; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = cable;
-    ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
-    ec.sampled = ea.sampled; ec.present = ea.present;
-    ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
+  if (!(r->valid && r->pwp.n_seg >= 1)) { if (lane == 0) entangles[idx] = 0; return; }
+  EntCtx ec;
+  ec.N = N; ec.S = S; ec.own = a; ec.num_pol = sp.num_pol; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = cable;
+  ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
+  ec.sampled = ea.sampled; ec.present = ea.present;
+  ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
+  const double* cx0 = r->pwp.coeff[0][0]; const double* cy0 = r->pwp.coeff[1][0];
+  const double T = sp.T_span;
+  const Ev2 end{((cx0[0] * (T * T * T) + cx0[1] * (T * T)) + cx0[2] * T) + cx0[3] * 1.0, ((cy0[0] * (T * T * T) + cy0[1] * (T * T)) + cy0[2] * T) + cy0[3] * 1.0};
+  EntBox bx{fmin(cx0[3], end.x), fmax(cx0[3], end.x), fmin(cy0[3], end.y), fmax(cy0[3], end.y)};      // the samples, exactly as ent_propagate takes them
+  for (int j = 1; j < ea.ns; j++) {
+    const double t = sp.T_span * j / ea.ns, t3 = t * t * t, t2 = t * t;
+    const double x = ((cx0[0] * t3 + cx0[1] * t2) + cx0[2] * t) + cx0[3] * 1.0, y = ((cy0[0] * t3 + cy0[1] * t2) + cy0[2] * t) + cy0[3] * 1.0;
+    bx.x0 = fmin(bx.x0, x); bx.x1 = fmax(bx.x1, x); bx.y0 = fmin(bx.y0, y); bx.y1 = fmax(bx.y1, y);
+  }
+  bx.x0 -= 1e-9; bx.x1 += 1e-9; bx.y0 -= 1e-9; bx.y1 += 1e-9;
+  for (int j0 = 0; j0 < N; j0 += 64) {
+    const int j = j0 + lane;
+    const bool may = j < N && j != a && ent_agent_may_cross(ec, bx, j, 0);
+    const unsigned long long bal = __ballot(may);
+    if (lane == 0) { m_agent[j0 >> 5] = (unsigned)bal; if (j0 + 32 < N) m_agent[(j0 >> 5) + 1] = (unsigned)(bal >> 32); }
+  }
+  for (int s0 = 0; s0 < S; s0 += 64) {
+    const int s_ = s0 + lane;
+    const bool may = s_ < S && ent_static_may_cross(ec, bx, s_);
+    const unsigned long long bal = __ballot(may);
+    if (lane == 0) { m_static[s0 >> 5] = (unsigned)bal; if (s0 + 32 < S) m_static[(s0 >> 5) + 1] = (unsigned)(bal >> 32); }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    ec.m_agent = m_agent; ec.m_static = m_static;
     nep_fe_ent_state* wk = ea.work + idx;
     if (ea.init) ent_copy(wk, ea.init + idx); else { long* z = (long*)wk; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
-    const double* cx0 = r->pwp.coeff[0][0]; const double* cy0 = r->pwp.coeff[1][0];
-    const double T = sp.T_span;
-    const Ev2 end{((cx0[0] * (T * T * T) + cx0[1] * (T * T)) + cx0[2] * T) + cx0[3] * 1.0, ((cy0[0] * (T * T * T) + cy0[1] * (T * T)) + cy0[2] * T) + cy0[3] * 1.0};
     double arc = 0.0;
-    hit = ent_propagate(ec, wk, cx0, cy0, end, 1, arc, false, 3) != 0 ? 1 : 0;
+    entangles[idx] = ent_propagate(ec, wk, cx0, cy0, end, 1, arc, false, 3) != 0 ? 1 : 0;
   }
-  entangles[idx] = hit;
 }
 void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntArgs& ea, const nep_traj_rec* fresh, int n_scenes, double cable, int* entangles, hipStream_t st) {
   const long total = (long)n_scenes * sp.num_agents;
   if (total <= 0) return;
-  hipLaunchKernelGGL(ent_check_kernel, dim3((int)((total + 63) / 64)), dim3(64), 0, st, sp, ps, ea, fresh, n_scenes, cable, entangles);
+  const size_t lds = sizeof(unsigned) * 2 * (size_t)(((sp.num_agents + 63) >> 6) + ((sp.n_static + 63) >> 6) + 1);
+  hipLaunchKernelGGL(ent_check_kernel, dim3((int)total), dim3(64), lds, st, sp, ps, ea, fresh, n_scenes, cable, entangles);
 }
 
 // Point A of the next round for every slot (include/neptune_frontend.h: nep_batch_next_starts): the agent's committed

@@ -39,8 +39,9 @@ def _run_frontend(be, sc, W, inits=None):
     return bb, fe, starts, d_com, d_g, d_g.cpu().numpy().view(abi.GUESS_DTYPE), d_r.cpu().numpy().view(abi.FE_RESULT_DTYPE), d_case, d_case.cpu().numpy().reshape(N, abi.NEP_MAX_POL, N)
 
 
-@pytest.mark.parametrize("n_agents,n_static,seed,W", [(8, 6, 60, 16), (8, 6, 56, 32), (16, 8, 61, 16)])
-def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_static, seed, W):
+@pytest.mark.parametrize("n_agents,n_static,seed,W,stride", [(8, 6, 60, 16, 1), (8, 6, 56, 32, 1), (16, 8, 61, 16, 1),
+                                                             (72, 40, 63, 16, 6)])      # (more than one 32-bit word of agents and of statics in the kernel's per-parent masks; every sixth agent against the oracle)
+def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_static, seed, W, stride):
     sc = scene.tether_crossing_scene(n_agents, n_static, seed)
     p = sc["par"]; N = n_agents
     rng = np.random.default_rng(seed)
@@ -51,7 +52,7 @@ def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents,
             inits[a]["n_alpha"] = 1; inits[a]["id"][0] = j + 1; inits[a]["cs"][0] = int(rng.integers(0, 3))
     bb, fe, starts, d_com, d_g, got_g, got_r, d_case, got_case = _run_frontend(be, sc, W, inits)
     n_cases = n_pruned = 0
-    for a in range(N):
+    for a in range(0, N, stride):
         hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(starts[a]["t_start"]), sc["statics"])
         ent = helpers.ent_inputs(sc, a, t0=float(starts[a]["t_start"]), init=inits[a])
         g, res, case = oracle.frontend_beam_ent(p, fe, a + 1, starts[a], hx, hn, sc["statics"], ent)
@@ -64,10 +65,11 @@ def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents,
         n_cases += int((case != 0).sum()); n_pruned += res["n_entangled"]
     assert n_cases > 0
     # the back end on device-made guesses and device-made cases: lines and optimum equal the oracle fed the same
+    bb.set_line_cull(0.0)        # (the larger case would get the presolve by default: the lines are compared in the oracle's order here)
     bb.replan(None, d_g, d_ent=d_case)
     sol = bb.solutions()
     extra = 0
-    for a in range(N):
+    for a in range(0, N, stride):
         K = int(got_g[a]["K"])
         if K < 1:
             assert int(sol[a]["stats"]["status"]) == 2
