@@ -529,7 +529,7 @@ def main():
             return r
 
         # ---- the same step over a longer timed region, and with the launch order off -----------------------------------
-        long_run = order_off = None
+        long_run = order_off = ref_tol = None
         if not args.no_extra_legs and graph_plain:
             dt_l, ms_l, _ = run_leg(step, bes, aux_steps, 2, graph_ok=True, eager_after=0)
             long_run = leg_record(dt_l, aux_steps, ms_l, note="the headline's step, %d steps between the barriers" % aux_steps)
@@ -545,6 +545,21 @@ def main():
                 b.enable_timing(False); b.set_launch_order(True)
             for _ in range(2):
                 step()                                   # (the ordering keys are fresh again for what follows)
+            # ---- the same step stopped where the reference's solver stops: Gurobi's default barrier tolerances ---------
+            for b in bes:
+                b.set_tolerances(1e-6, 1e-8)
+            dt_t, ms_t, _ = run_leg(step, bes, aux_steps, 3, graph_ok=True, eager_after=10)
+            qp_t, _ = be.kernel_time_ms(2)
+            sol_t = be.solutions()
+            ref_tol = leg_record(dt_t, aux_steps, ms_t, qp_ms=qp_t, solve_us=solve_us_stats(be), ipm_iters_mean=float(sol_t["stats"]["iters"].mean()),
+                                 residual_tol=1e-6, gap_tol=1e-8,
+                                 note="nep_batch_set_tolerances(1e-6, 1e-8): the strict tests at Gurobi's defaults (FeasibilityTol = OptimalityTol = "
+                                      "1e-6, BarConvTol = 1e-8), which is where the reference's solver stops (PolySolverGurobi sets OutputFlag and "
+                                      "TimeLimit only, solver_gurobi_poly.cpp:811-812); the headline and every other leg use 1e-9 / 1e-10", **status_counts(sol_t))
+            for b in bes:
+                b.enable_timing(False); b.set_tolerances(1e-9, 1e-10)
+            for _ in range(2):
+                step()
 
         # ---- presolve: the same steps with the verified line presolve on ------------------------------------
         presolve = None
@@ -908,6 +923,7 @@ def main():
                                  "iterations per replan" % round(float(iters.mean()))},
             "long_run": long_run,
             "launch_order_off": order_off,
+            "reference_tolerances": ref_tol,
             "presolve": presolve,
             "chain": chain,
             "moving": moving,

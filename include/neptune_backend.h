@@ -401,6 +401,16 @@ int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap); 
 int nep_batch_set_separator_rule(nep_batch_t* h, int32_t rule);
 int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule);
 
+/* The interior point's stopping tests.  Default: primal residual <= 1e-9, dual residual <= 1e-9 x the cost's scale, duality
+ * gap <= 1e-10 (1 + |objective|) — two orders tighter than the solver the reference calls: PolySolverGurobi never touches
+ * Gurobi's parameters beyond OutputFlag and TimeLimit (solver_gurobi_poly.cpp:811-812), so its barrier stops at Gurobi's
+ * defaults, BarConvTol = 1e-8 (relative gap) with FeasibilityTol = OptimalityTol = 1e-6.  nep_*_set_tolerances(h, 1e-6, 1e-8)
+ * stops where the reference's solver does: about half an iteration less per replan (the last iteration of a solve shrinks the
+ * gap by 1e4 or more), answers within the reference's own accuracy instead of 1e-8 of the optimum.  The loose-snapshot rule
+ *  keeps its thresholds (1e-6, 1e-6, 1e-7).  Same knob in oracle/ (orc_set_qp_tolerances).           */
+int nep_batch_set_tolerances(nep_batch_t* h, double residual_tol, double gap_tol);
+int nep_backend_set_tolerances(nep_backend_t* h, double residual_tol, double gap_tol);
+
 /* Which placement of the interior point the handle runs: 1 = qp_reg_kernel (line-row state in registers, four workgroups
  * per CU: chosen when the expected lines per segment fit its register slots, e.g. BASELINE configs 1-4, or when the line
  * presolve is on — config 5 by default), 0 = qp_kernel (row state in LDS with a global spill: config-5 sized problems

@@ -64,6 +64,10 @@ class PolySolver:
         """not in the reference: which LP vertex the separator returns (nep_backend_set_separator_rule)"""
         check(lib().nep_backend_set_separator_rule(self._h, int(rule)))
 
+    def setTolerances(self, residual_tol=1e-9, gap_tol=1e-10):
+        """not in the reference (which leaves Gurobi's defaults, 1e-6 / 1e-8): the interior point's strict tests (nep_backend_set_tolerances)"""
+        check(lib().nep_backend_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
+
     def setMaxRuntime(self, runtime):
         check(lib().nep_backend_set_max_runtime(self._h, runtime))
 
@@ -372,6 +376,10 @@ class BatchBackend:
         """which vertex of the separating-line LP is returned: 0 largest gap (default), 1 the one a primal simplex of GLPK's
         default class reaches (nep_batch_set_separator_rule)"""
         check(lib().nep_batch_set_separator_rule(self._h, int(rule)))
+
+    def set_tolerances(self, residual_tol=1e-9, gap_tol=1e-10):
+        """the interior point's strict tests (nep_batch_set_tolerances); (1e-6, 1e-8) = Gurobi's defaults, what the reference's solver stops at"""
+        check(lib().nep_batch_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
 
     def set_safety_check_prev(self, on=True):
         """also turn down new trajectories that collide with another agent's PREVIOUS record (nep_batch_set_safety_check_prev)"""

@@ -486,7 +486,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           const double o = sc[sObj0] + wave_sum(tid < n ? sDxa[tid] : 0.0);
           const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
           int flag = 0;
-          if (nr <= 1e-9 && nrd <= 1e-9 * qs && gap <= 1e-10 * (1.0 + fabs(o))) flag = 1;
+          if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-9, 1e-9, 1e-10 unless nep_batch_set_tolerances says otherwise)
           else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
           if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
           if (sI[17] >= 3) flag = 3;                           // stalled
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           // of the row activities into the dual residual (floor ~1e-8 |g|): an iteration that has not passed the strict
           // test by then never will, and would idle to kMaxIt while its iterates get noisier.
           if (flag == 2 || (flag == 0 && sI[22] >= 0)) {
-            const double merit = fmax(fmax(nr * 1e9, nrd / qs * 1e9), gap / (1.0 + fabs(o)) * 1e10);
+            const double merit = fmax(fmax(nr * sp.tol_res_inv, nrd / qs * sp.tol_res_inv), gap / (1.0 + fabs(o)) * sp.tol_gap_inv);
             const bool better = flag == 2 && (!sI[16] || merit < sc[sBestMerit]);
             const bool last = sI[22] >= 0 && it - sI[22] >= 3;
             if (sI[22] < 0 && tid == 0) sI[22] = it;
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           // never aim below a tenth of the gap the strict test asks for: with the long steps of kStepFracMax the centring
           // target would otherwise collapse by 1e5 per iteration, the last iterate would sit at mu ~ 1e-15 with weights
           // lambda/s ~ 1e17, and the rounding of that last step shows up as 1e-6 in the flat directions of the coefficients
-          sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) * inv_mt);
+          sm = fmax(sm, 0.1 * sp.tol_gap * (1.0 + fabs(sc[sObj])) * inv_mt);
           if (nopred) sm = sm_keep;            // (sigma mu of the discarded predictor)
           else if (it >= kCorrFromIt && aaff < kCorrMinStep) {
             // the affine step is too short for its second-order term to mean anything: the iteration is repeated from the same

@@ -717,13 +717,13 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const double o = sc[sObj0] + wave_sum(l1 < n ? sDx[l1] : 0.0);      // (the objective's terms: written next to rd, see above)
             const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
             int flag = 0;
-            if (nr <= 1e-9 && nrd <= 1e-9 * qs && gap <= 1e-10 * (1.0 + fabs(o))) flag = 1;
+            if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-9, 1e-9, 1e-10 unless nep_batch_set_tolerances says otherwise)
             else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
             if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
             if (sI[17] >= 3) flag = 3;                           // stalled
             if (sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks) flag = 3;   // TimeLimit without an accepted iterate: "no solution" (:832-836)
             if (flag == 2 || (flag == 0 && sI[22] >= 0)) {       // loosely converged iterates: see qp_kernel
-              const double merit = fmax(fmax(nr * 1e9, nrd / qs * 1e9), gap / (1.0 + fabs(o)) * 1e10);
+              const double merit = fmax(fmax(nr * sp.tol_res_inv, nrd / qs * sp.tol_res_inv), gap / (1.0 + fabs(o)) * sp.tol_gap_inv);
               const bool better = flag == 2 && (!sI[16] || merit < sc[sBestMerit]);
               const bool last = sI[22] >= 0 && it - sI[22] >= 3;
               if (sI[22] < 0 && l1 == 0) sI[22] = it;
@@ -827,7 +827,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) * inv_mt;
             const double rr = mua * frcp2(mu);
             sm = rr * rr * rr * mu;
-            sm = fmax(sm, 0.1 * 1e-10 * (1.0 + fabs(sc[sObj])) * inv_mt);
+            sm = fmax(sm, 0.1 * sp.tol_gap * (1.0 + fabs(sc[sObj])) * inv_mt);
             if (nopred) sm = sc[sSigKeep];       // (sigma mu of the discarded predictor)
             else if (__builtin_amdgcn_readfirstlane((int)(it >= kCorrFromIt && aaff < kCorrMinStep))) {
               // the affine step is too short for its second-order term to mean anything: repeat the iteration from the same point

@@ -223,6 +223,8 @@ static __thread int g_ncand = 0;
 static __thread sep_best g_cand[SEP_MAX_CAND];
 static __thread long g_stat_lps = 0, g_stat_vertices = 0;
 void orc_set_separator_rule(int rule) { g_sep_rule = rule; }
+static __thread double g_tol_res = 1e-9, g_tol_gap = 1e-10, g_tol_res_inv = 1e9;     /* nep_batch_set_tolerances */
+void orc_set_qp_tolerances(double residual_tol, double gap_tol) { g_tol_res = residual_tol; g_tol_gap = gap_tol; g_tol_res_inv = residual_tol == 1e-9 ? 1e9 : 1.0 / residual_tol; }
 void orc_set_vertex_policy(int policy, unsigned long long seed, const double* ref_ctrl /* [NEP_MAX_POL][4][2] or NULL */) {
   g_sep_rule = policy == 5 ? 1 : 0;        /* policy 5 IS the product's second rule */
   if (policy == 5) policy = 0;
@@ -665,7 +667,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   const double EXP_FLOOR = getenv("ORC_EXP_FLOOR") ? atof(getenv("ORC_EXP_FLOOR")) : 0.1;
   const double EXP_MU0 = getenv("ORC_EXP_MU0") ? atof(getenv("ORC_EXP_MU0")) : 2.0;
   const double EXP_TAU = getenv("ORC_EXP_TAU") ? atof(getenv("ORC_EXP_TAU")) : 0.99999;
-  const double EXP_GAPTOL = getenv("ORC_EXP_GAPTOL") ? atof(getenv("ORC_EXP_GAPTOL")) : 1e-10;
+  const double EXP_GAPTOL = getenv("ORC_EXP_GAPTOL") ? atof(getenv("ORC_EXP_GAPTOL")) : g_tol_gap;
   const int trace = getenv("ORC_QP_TRACE") != NULL;
   const int EXP_REFINE = getenv("ORC_EXP_REFINE") ? atoi(getenv("ORC_EXP_REFINE")) : 0;   /* experiment: refinement steps per Newton solve (0 = what the kernel does) */
   double* M0 = (double*)malloc(sizeof(double) * ((size_t)ny * ny + ny)); double* res = M0 + (size_t)ny * ny;
@@ -699,14 +701,14 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     for (int a = 0; a < ny; a++) if (fabs(rd[a]) > nrd) nrd = fabs(rd[a]);
     double obj = obj0; for (int a = 0; a < ny; a++) { double v = 0; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; obj += 0.5 * y[a] * v + qy[a] * y[a]; }
     double gap = mu * mt;
-    if (nrp <= 1e-9 && nrd <= 1e-9 * qscale && gap <= EXP_GAPTOL * (1.0 + fabs(obj))) { ret = 0; break; }
+    if (nrp <= g_tol_res && nrd <= g_tol_res * qscale && gap <= EXP_GAPTOL * (1.0 + fabs(obj))) { ret = 0; break; }
     /* Loosely converged iterates: keep the one closest to the strict tolerances (merit <= 1 is the strict test) and stop three
        iterations after the first of them: with mu that small the weights lam/s amplify the rounding of the row activities into
        rd, so an iteration that has not passed the strict test by then never will */
     {
       const int is_loose = nrp <= 1e-6 && nrd <= 1e-6 * qscale && gap <= 1e-7 * (1.0 + fabs(obj));
       if (is_loose || first_loose >= 0) {
-        const double merit = fmax(fmax(nrp * 1e9, nrd / qscale * 1e9), gap / (1.0 + fabs(obj)) / EXP_GAPTOL);
+        const double merit = fmax(fmax(nrp * g_tol_res_inv, nrd / qscale * g_tol_res_inv), gap / (1.0 + fabs(obj)) / EXP_GAPTOL);
         const int better = is_loose && (!loose_ok || merit < best_merit);
         const int last = first_loose >= 0 && it - first_loose >= 3;
         if (first_loose < 0) first_loose = it;

@@ -97,6 +97,9 @@ int orc_separator_glpk_class(int nA, const double (*A)[2], int nB, const double 
 /* which separator rule the restated path uses from now on (thread-local): 0 largest gap, 1 GLPK-class simplex */
 void orc_set_separator_rule(int rule);
 
+/* the interior point's strict tests (thread-local; defaults 1e-9 / 1e-10; checker of nep_batch_set_tolerances) */
+void orc_set_qp_tolerances(double residual_tol, double gap_tol);
+
 /* PolySolverGurobi::optimize (solver_gurobi_poly.cpp:804-887) for one agent.
  *   K, coeff_init: setInitTrajectory (:187-244)
  *   hulls: setHulls, polygons j*num_pol+i (:246-281)

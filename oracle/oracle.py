@@ -77,6 +77,7 @@ def lib():
         L.orc_separator_glpk_class.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
         L.orc_separator_glpk_class.restype = C.c_int
         L.orc_set_separator_rule.argtypes = [C.c_int]; L.orc_set_separator_rule.restype = None
+        L.orc_set_qp_tolerances.argtypes = [C.c_double, C.c_double]; L.orc_set_qp_tolerances.restype = None
         L.orc_optimize.argtypes = [C.POINTER(orc_params), C.c_int, C.c_void_p, C.c_int,
                                    C.POINTER(orc_polys), C.POINTER(orc_polys), C.POINTER(orc_ent),
                                    C.c_int, C.c_void_p, C.c_void_p, C.POINTER(orc_result)]
@@ -161,6 +162,11 @@ def set_separator_rule(rule):
     """0: the largest-gap vertex (default); 1: the GLPK-class simplex's vertex — for every separator call of the restated path
     made from this thread afterwards (checker of nep_batch_set_separator_rule)"""
     lib().orc_set_separator_rule(int(rule))
+
+
+def set_qp_tolerances(residual_tol=1e-9, gap_tol=1e-10):
+    """the interior point's strict tests, for every solve made from this thread afterwards (checker of nep_batch_set_tolerances)"""
+    lib().orc_set_qp_tolerances(float(residual_tol), float(gap_tol))
 
 
 class Polys:
