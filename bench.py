@@ -499,10 +499,10 @@ def main():
             ex.gather(be.d_commit, chk, collective=True)
             torch.cuda.synchronize(dev)
             rccl_one_rank_ok = bool(torch.equal(chk, be.d_commit.view_as(chk)))
-            if own_group and not os.environ.get("NEP_BENCH_KEEP_PG"):
-                # the one-rank group has done its job.  It is torn down before anything is timed: with a live RCCL
-                # communicator in the process, replays of the config-5 step's graph take 1.55 instead of 1.28 ms (same kernels,
-                # same kernel times; eager launches and the headline's graph are unaffected — measured)
+            if own_group and os.environ.get("NEP_BENCH_PG_TEARDOWN"):
+                # development aid.  With a live RCCL communicator in the process a hipMemsetAsync node in a replayed graph costs
+                # ~0.27 ms (found on the config-5 step: 1.55 instead of 1.28 ms with identical kernel times; the presolve's redo
+                # counters are now zeroed by a kernel and the step has no memset node): this tears the one-rank group down early
                 tdist.destroy_process_group(); use_dist = False; rccl_torn_down = True
         # ---- headline: exactly --steps steps -------------------------------------------------------------------------
         dt, step_ms, graph = run_leg(step, bes, args.steps, 0, graph_ok=graph_plain, clear=(safety_ev, hull_ev, gather_ev))

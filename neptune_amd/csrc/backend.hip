@@ -299,7 +299,7 @@ struct Engine {
     if (ps.lines_override) { ps.skip_box = nullptr; ps.line_skip = nullptr; ps.redo_list = nullptr; ps.redo_count = nullptr; }
     const bool skip = ps.skip_box != nullptr;
     if (!ps.lines_override) {
-      if (skip) { launch_boxes(n_scenes, sp, ps, st); HIPCHK(hipMemsetAsync(d_redo_count.p, 0, 64 * sizeof(int), st)); }
+      if (skip) launch_boxes(n_scenes, sp, ps, st);      // (zeroes the redo counters as well)
       launch_separator(slots, sp, ps, st);
     }
     if (timing) hipEventRecord(next_event(), st);
