@@ -1,7 +1,7 @@
 #!/bin/bash
 # One call on the GPU box: BASELINE configs[4] (256 agents + 100 obstacles, entangle check on) through `bench.py --config5-only`:
 # its JSON leg, the rocprofv3 kernel trace of the same command and the PMC passes (one counter group per pass).
-# Usage: bash scripts/profile_config5.sh <tag> [extra bench args]   ->  gpurun_out/<tag>/{config5_line.json,config5_kernel_stats.txt,pmc_summary_config5.txt}
+# Usage: bash scripts/profile_config5.sh <tag> [extra bench args]   ->  gpurun_out/<tag>/{config5_line.json,config5_kernel_stats.txt,pmc_summary_config5.txt,config5_chain_kernel_stats.txt}
 set -u
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -18,6 +18,9 @@ run write WRITE_SIZE
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY
 run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 python scripts/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary_config5.txt"
-rm -rf "$OUT/kt" "$OUT/pmc"
+# the config-5 chain (frontend_kernel<true>, ent_check_kernel, ...): kernel trace of the default command with short legs
+rocprofv3 --kernel-trace --stats -d "$OUT/ktf" -o kt --output-format rocpd -- python bench.py --steps 5 --warmup 2 --aux-steps 10 --presolve-radius 0 --no-cpu-baseline --no-graph > "$OUT/ktf.log" 2>&1
+python scripts/rocpd_summary.py "$(find "$OUT/ktf" -name "*.db" | head -1)" > "$OUT/config5_chain_kernel_stats.txt" 2>> "$OUT/ktf.log"
+rm -rf "$OUT/kt" "$OUT/pmc" "$OUT/ktf"
 head -12 "$OUT/config5_kernel_stats.txt"; python -c "
 import json,sys; d=json.load(open('$OUT/config5_line.json'))['config5']; print({k:d[k] for k in ('value','ms_per_step','kernel_ms','qp_kernel','line_cull_radius_m','presolve_redo_last_step')})"
