@@ -184,7 +184,7 @@ struct Engine {
     if (int e = d_lp_stats.ensure((size_t)slots * NEP_MAX_POL * 2)) return e;   // per (slot, segment): LPs attempted, LPs without a line
     if (int e = d_line_skip.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_redo_list.ensure((size_t)slots)) return e;
-    if (!d_redo_count.p) { if (int e = d_redo_count.ensure(64)) return e; HIPCHK(hipMemset(d_redo_count.p, 0, 64 * sizeof(int))); }
+    if (!d_redo_count.p) { if (int e = d_redo_count.ensure(4)) return e; HIPCHK(hipMemset(d_redo_count.p, 0, 4 * sizeof(int))); }      // [0] listed replans, [1] parked line violated, [2] moved beyond the radius
     if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 32)) return e; }      // (the QP kernels use 16 per slot, the front end 32)
@@ -1037,11 +1037,10 @@ int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static,
 // Test hook: replans the last nep_batch_replan* sent through the presolve's redo pass (0 when LP skipping is off).
 int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason) {
   if (!h) return fail(NEP_E_ARG, "null handle");
-  int n[4] = {0, 0, 0, 0};
+  int n[3] = {0, 0, 0};
   HIPCHK(hipDeviceSynchronize());
-  if (h->eng.d_redo_count.p) HIPCHK(hipMemcpy(n, h->eng.d_redo_count.p, 4 * sizeof(int), hipMemcpyDeviceToHost));
+  if (h->eng.d_redo_count.p) HIPCHK(hipMemcpy(n, h->eng.d_redo_count.p, 3 * sizeof(int), hipMemcpyDeviceToHost));
   if (by_reason) { by_reason[0] = n[1]; by_reason[1] = n[2]; }
-  if (getenv("NEP_SEP_DEBUG") && n[3] > 0) { double dbg[18]; HIPCHK(hipMemcpy(dbg, h->eng.d_redo_count.p + 4, sizeof(dbg), hipMemcpyDeviceToHost)); fprintf(stderr, "[base rows != theta] %d lanes; slot %.0f tid %.0f vb %.9g v %.9g iters %.0f loose %.0f first_loose %.0f qc %.0f status %.0f uncon %.0f | sB-table %.3g sOff-table %.3g sInit-guess %.3g %.3g %.3g |z|1 %.6g chol %.0f %.0f\n", n[3], dbg[0], dbg[1], dbg[2], dbg[3], dbg[4], dbg[5], dbg[6], dbg[7], dbg[8], dbg[9], dbg[10], dbg[11], dbg[12], dbg[13], dbg[14], dbg[15], dbg[16], dbg[17]); }
   return n[0];
 }
 

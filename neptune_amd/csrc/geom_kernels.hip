@@ -1422,7 +1422,7 @@ __device__ __forceinline__ unsigned fe_hash(long long vox) { return (unsigned)((
 __global__ __launch_bounds__(256) void fe_box_kernel(SceneParams sp, ProblemSet ps, int n_scenes) {
   const int N = sp.num_agents, S = sp.n_static, D = sp.num_pol;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
-  if (ps.redo_count && t < 64) ps.redo_count[t] = 0;      // (the presolve's redo list starts empty: this kernel runs before the separator — no memset node in the step's graph)
+  if (ps.redo_count && t < 4) ps.redo_count[t] = 0;      // (the presolve's redo list starts empty: this kernel runs before the separator — no memset node in the step's graph)
   if (t >= (long)n_scenes * (N + S) * D) return;
   const int idx = (int)(t % D); const long r = t / D;
   const int j = (int)(r % (N + S)), scene = (int)(r / (N + S));

@@ -106,9 +106,6 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   int status = NEP_FAILED, iters_total = 0, iters_first = 0, L_used = 0, L_all = 0;
   double objective = 0.0;
   bool has_qc = false, z_override = false;
-#ifdef NEP_DEBUG_BASEROWS
-  double uncon_dbg = 0.0;
-#endif
 
   // Line coefficients in LDS: [n1 | n2 | h][segment][SEGCAP], SEGCAP = 8 RS entries per segment whatever its line count — the
   // entries past a segment's last line hold the dummy line (0, 0, 1).  A thread's slot u is then a compile-time offset from
@@ -405,9 +402,6 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           block_reduce4(viol, o_share, d1, d2, sRed);
           uncon = __builtin_amdgcn_readfirstlane(viol <= 0.0 ? 1 : 0) != 0;
           if (uncon) { if (tm < n) sZ[tm] = sDx[tm]; if (tm == 0) sc[sObj] = sc[sObj0] + o_share; }
-#ifdef NEP_DEBUG_BASEROWS
-          uncon_dbg = uncon ? 1.0 : 0.0;
-#endif
         }
         // (roles are re-derived from an opaque copy of the thread index in every phase: whatever the compiler could hoist out of
         // the iteration loop — row / entry indices, LDS addresses of four different roles — would otherwise sit in registers
@@ -963,19 +957,6 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         const double* Q = sTheta + (ax * 8 + sg) * 4;
         const double v = ((Q[0] * c0 + Q[1] * c1) + Q[2] * c2) + Q[3] * c3;
         sAccL[rho * 2 + ax] = v;
-#ifdef NEP_DEBUG_BASEROWS
-        {   // development aid: the same control point from the base rows of the converged mode, B z + U init
-          const QpTable* __restrict__ tbv = tables + status * (kMaxK + 1) + K;
-          const int nzv = tbv->nz;
-          double vb = sOff[rho * 3 + ax];
-          for (int c = 0; c < nzv; c++) vb = __builtin_fma(sB[rho * SBS + c], sZ[ax * nzv + c], vb);
-          if (fabs(vb - v) > 1e-6 && ps.redo_count) { atomicAdd(ps.redo_count + 3, 1); double* dbg = (double*)(ps.redo_count + 4); dbg[0] = (double)slot; dbg[1] = (double)tid; dbg[2] = vb; dbg[3] = v; dbg[4] = (double)iters_total; dbg[5] = (double)sI[16]; dbg[6] = (double)sI[22]; dbg[7] = (double)(has_qc ? 1 : 0); dbg[8] = (double)status; dbg[9] = uncon_dbg;
-            double bd = 0; for (int c = 0; c < kNZ; c++) bd = fmax(bd, fabs(sB[rho * SBS + c] - tbv->B[rho][c]));
-            const double og = tbv->U[rho][0] * sInit[ax * 3] + tbv->U[rho][1] * sInit[ax * 3 + 1] + tbv->U[rho][2] * sInit[ax * 3 + 2];
-            dbg[10] = bd; dbg[11] = sOff[rho * 3 + ax] - og; dbg[12] = sInit[ax * 3] - sCoef[(ax * 8) * 4 + 1]; dbg[13] = sInit[ax * 3 + 1] - sCoef[(ax * 8) * 4 + 2]; dbg[14] = sInit[ax * 3 + 2] - sCoef[(ax * 8) * 4 + 3];
-            double zs = 0; for (int c = 0; c < 24; c++) zs += fabs(sZ[c]); dbg[15] = zs; dbg[16] = (double)sI[19]; dbg[17] = (double)sI[20]; }
-        }
-#endif
         if (n_skip > 0) {
           // The LPs the separator skipped have lines farther than cull_radius from every control point of the GUESS (their
           // point sets' boxes are that far apart and the box sides are polygon edges: separator_body).  A solution control point
