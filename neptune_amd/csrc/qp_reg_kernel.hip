@@ -103,8 +103,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   if (tid < 96) sCoef[tid] = (&g->coeff[0][0][0])[tid];
   for (int e = tid; e < kMaxR * 6; e += BS) sTc[e] = 0.0;
   sDc[tid] = 0.0; sAccL[tid] = 0.0;
-  int status = NEP_FAILED, iters_total = 0, iters_first = 0, L_used = 0, L_all = 0;
-  double objective = 0.0;
+  int status = NEP_FAILED, L_used = 0, L_all = 0;
+  // (what only the last lines need — iteration counts, the objective, 1 / rows — waits in LDS, not in registers that would be
+  // spilled to scratch for the whole solve: sI[31] iterations of the last solve, sI[32] of the first, sc[sObjOut], sc[sInvMt])
+  if (tid == 0) { sI[31] = 0; sI[32] = 0; sc[sObjOut] = 0.0; }      // (written and read back by thread 0 only; a replan that never reaches a solve — K = 0 — reports zeros)
   bool has_qc = false, z_override = false;
 
   // Line coefficients in LDS: [n1 | n2 | h][segment][SEGCAP], SEGCAP = 8 RS entries per segment whatever its line count — the
@@ -214,7 +216,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     has_qc = __builtin_amdgcn_readfirstlane(sqrt(dix * dix + diy * diy + diz * diz) < 1.0 ? 1 : 0) != 0;   // :697-702
     z_override = __builtin_amdgcn_readfirstlane(sqrt(dix * dix + diy * diy) < 1.0 ? 1 : 0) != 0;           // :879-880
     const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);
-    const double inv_mt = 1.0 / (double)mt;                   // (one division per attempt; the per-iteration means multiply by it)
+    if (tid == 0) sc[sInvMt] = 1.0 / (double)mt;               // (one division per attempt; the per-iteration means multiply by it)
 
     const int li = tid >> 5, slice = tid & 7;
     const int seg_cnt = sI[li + 1] - sI[li];                  // lines of my segment (0 for segments >= K)
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       }
     };
 
-    status = NEP_FAILED; iters_total = 0; iters_first = 0; objective = 0.0;
+    status = NEP_FAILED; if (tid == 0) { sI[31] = 0; sI[32] = 0; sc[sObjOut] = 0.0; }
 
     for (int mode = 0; mode < 2; mode++) {
       const QpTable* __restrict__ tb = tables + mode * (kMaxK + 1) + K;
@@ -519,7 +521,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
               }
               sc[sRpq] = rpq;
               sc[sSumSl] = sumsl + (has_qc ? sc[sSq] * sc[sLq] : 0.0);
-              sc[sMu] = sc[sSumSl] * inv_mt;
+              sc[sMu] = sc[sSumSl] * sc[sInvMt];
               sc[sNrp] = fmax(nrp, fabs(rpq));
             }
           }
@@ -818,6 +820,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           {
             const double aaff = rmax > 1.0 ? frcp2(rmax) : 1.0;
             const double mu = sc[sMu];
+            const double inv_mt = sc[sInvMt];
             const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) * inv_mt;
             const double rr = mua * frcp2(mu);
             sm = rr * rr * rr * mu;
@@ -926,11 +929,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         if (uncon) converged = true;
         if (!converged && have_loose) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
       }
-      iters_total = it; if (mode == 0) iters_first = it;
+      if (tid == 0) { sI[31] = it; if (mode == 0) sI[32] = it; }
       __syncthreads();
       if (converged) {
         status = mode;   // NEP_OK / NEP_RELAXED
-        { const double o_ = sc[sObj]; objective = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(o_)), __builtin_amdgcn_readfirstlane(__double2loint(o_))); }
+        if (tid == 0) sc[sObjOut] = sc[sObj];
         if (tid < 12 * K) {  // theta = Th z + ThU init
           const int ax = div_small(tid, 4 * K), r = tid - ax * 4 * K;
           double v = tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2];
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   const int ns_all = sched.n[Ko];
   const int ns = ns_all < sp.max_states ? ns_all : sp.max_states;
   if (tid == 0) {
-    sol->stats.status = status; sol->stats.iters = iters_total; sol->stats.iters_first = iters_first;
+    sol->stats.status = status; sol->stats.iters = sI[31]; sol->stats.iters_first = sI[32];
     int n_lp = 0, n_lpf = 0;
     if (ps.lp_stats && !ps.lines_override) {
       int v[2 * NEP_MAX_POL];
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((CULL && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;
-    sol->stats.objective = objective; { const long long dt_ = (long long)wall_clock64() - t_wg0; const double us_ = (double)dt_ * sp.us_per_tick; sol->stats.solve_us = us_; if (ps.order_key) { const double k_ = us_ * 0.125; ps.order_key[slot] = k_ > 63.0 ? 63 : (int)k_; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
+    sol->stats.objective = sc[sObjOut]; { const long long dt_ = (long long)wall_clock64() - t_wg0; const double us_ = (double)dt_ * sp.us_per_tick; sol->stats.solve_us = us_; if (ps.order_key) { const double k_ = us_ * 0.125; ps.order_key[slot] = k_ > 63.0 ? 63 : (int)k_; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
     sol->K = Ko; sol->n_states = ns;
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)
@@ -1036,7 +1039,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
 #ifdef NEP_PROFILE_PHASES
   if (prof && tid == 0) {   // [0..9] loop phases, [10] workgroup lifetime, [12] iterations, [13] line gather, [14] mode staging, [15] start point
     for (int k = 0; k < 16; k++) ps.dbg[(long)slot * 16 + k] = sProf[k];
-    ps.dbg[(long)slot * 16 + 10] = clock64() - tstart; ps.dbg[(long)slot * 16 + 12] = iters_total;
+    ps.dbg[(long)slot * 16 + 10] = clock64() - tstart; ps.dbg[(long)slot * 16 + 12] = sI[31];
     ps.dbg[(long)slot * 16 + 11] = (tstart_wall << 20) | ((long long)wall_clock64() - tstart_wall);   // start (100 MHz ticks) << 20 | duration
   }
 #endif

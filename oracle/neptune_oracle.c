@@ -762,7 +762,13 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       if (tau < 0.999) tau = 0.999;
       if (tau > EXP_TAU) tau = EXP_TAU;
       alpha *= tau; if (alpha > 1.0) alpha = 1.0; }
-    if (trace) fprintf(stderr, "it %2d nrp %.3e nrd %.3e (qs %.3e) gap %.3e obj %.9g sigma %.3e alpha %.3e loose %d\n", it, nrp, nrd, qscale, gap, obj, sigma, alpha, loose_ok);
+    if (trace) {
+      /* (trace only) how close lam / |lam|_1 is to a Farkas ray: G'lam -> 0 with h'lam < 0 proves the rows infeasible */
+      double l1 = 0, hl = 0, gl[64]; for (int c = 0; c < ny && c < 64; c++) gl[c] = 0;
+      for (int r = 0; r < m; r++) { l1 += lam[r]; hl += hy[r] * lam[r]; const double* g = Gy + (size_t)r * ny; for (int c = 0; c < ny && c < 64; c++) gl[c] += g[c] * lam[r]; }
+      double gmax = 0, g1 = 0; for (int c = 0; c < ny && c < 64; c++) { if (fabs(gl[c]) > gmax) gmax = fabs(gl[c]); g1 += fabs(gl[c]); }
+      fprintf(stderr, "it %2d nrp %.3e nrd %.3e (qs %.3e) gap %.3e obj %.9g sigma %.3e alpha %.3e loose %d | farkas: |G'l|_1/|l|_1 %.3e  h'l/|l|_1 %.3e  ratio %.3e\n", it, nrp, nrd, qscale, gap, obj, sigma, alpha, loose_ok, g1 / l1, hl / l1, g1 / fmax(-hl, 1e-300));
+    }
     if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;
     for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];
     for (int r = 0; r < mt; r++) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; }
