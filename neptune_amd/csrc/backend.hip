@@ -94,7 +94,7 @@ struct Engine {
   DevBuf<int> d_order, d_order_key; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double clock_hz = 1e8;       // wall_clock64() rate of the handle's device (set_clock)
-  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; if (!(sp.tol_res > 0.0)) { sp.tol_res = 1e-9; sp.tol_gap = 1e-10; sp.tol_res_inv = 1e9; sp.tol_gap_inv = 1e10; } }      // (called by both create paths: the strict tests' defaults with it)
+  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; if (!(sp.tol_res > 0.0)) { sp.tol_res = 1e-9; sp.tol_gap = 1e-10; sp.tol_res_inv = 1e9; sp.tol_gap_inv = 1e10; sp.tol_gap_floor = 0.1 * 1e-10; } }      // (called by both create paths: the strict tests' defaults with it)
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
   // timing
@@ -1110,7 +1110,7 @@ int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule) {
 namespace { int set_tol(Engine& E, double res, double gap) {
   if (!(res >= 1e-12 && res <= 1e-6) || !(gap >= 1e-13 && gap <= 1e-7)) return fail(NEP_E_ARG, "tolerances: residuals in [1e-12, 1e-6], relative gap in [1e-13, 1e-7]");
   E.sp.tol_res = res; E.sp.tol_gap = gap;
-  E.sp.tol_res_inv = res == 1e-9 ? 1e9 : 1.0 / res; E.sp.tol_gap_inv = gap == 1e-10 ? 1e10 : 1.0 / gap;      // (the defaults' reciprocals as the literals the kernels were validated with)
+  E.sp.tol_res_inv = res == 1e-9 ? 1e9 : 1.0 / res; E.sp.tol_gap_inv = gap == 1e-10 ? 1e10 : 1.0 / gap; E.sp.tol_gap_floor = 0.1 * gap;      // (the defaults' reciprocals as the literals the kernels were validated with)
   return 0;
 } }
 int nep_batch_set_tolerances(nep_batch_t* h, double residual_tol, double gap_tol) { if (!h) return fail(NEP_E_ARG, "null handle"); return set_tol(h->eng, residual_tol, gap_tol); }

@@ -67,7 +67,7 @@ constexpr int oU = oRed + 48;               // [24] D^-1 g of the terminal ball 
 constexpr int oFixedEnd = oU + 32;
 constexpr int kFixedDoubles = (oFixedEnd + 1) & ~1;
 
-enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigKeep, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2, sBestMerit, sInvMt, sObjOut };      // (32 slots)
+enum { sFinal0 = 0, sFinal1, sFinal2, sMu, sSigKeep, sAlpha, sObj0, sObj, sSq, sLq, sRpq, sWq, sDsqA, sDlqA, sDsq, sDlq, sQscale, sNrp, sSumSl, sObjLoose, sSigMu, sPe0, sPe1, sPe2, sBestMerit, sInvMt, sObjOut, sMtD };      // (32 slots)
 
 // Line stride of the carve that lets two workgroups share a CU (backend.hip::size_scratch's l_half, rounded the same way):
 // the normal case, instantiated with the stride as a compile-time constant so that the row passes' LDS accesses take

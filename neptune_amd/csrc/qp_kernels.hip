@@ -600,7 +600,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           // never aim below a tenth of the gap the strict test asks for: with the long steps of kStepFracMax the centring
           // target would otherwise collapse by 1e5 per iteration, the last iterate would sit at mu ~ 1e-15 with weights
           // lambda/s ~ 1e17, and the rounding of that last step shows up as 1e-6 in the flat directions of the coefficients
-          sm = fmax(sm, 0.1 * sp.tol_gap * (1.0 + fabs(sc[sObj])) * inv_mt);
+          sm = fmax(sm, sp.tol_gap_floor * (1.0 + fabs(sc[sObj])) * inv_mt);
           if (nopred) sm = sm_keep;            // (sigma mu of the discarded predictor)
           else if (it >= kCorrFromIt && aaff < kCorrMinStep) {
             // the affine step is too short for its second-order term to mean anything: the iteration is repeated from the same

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     has_qc = __builtin_amdgcn_readfirstlane(sqrt(dix * dix + diy * diy + diz * diz) < 1.0 ? 1 : 0) != 0;   // :697-702
     z_override = __builtin_amdgcn_readfirstlane(sqrt(dix * dix + diy * diy) < 1.0 ? 1 : 0) != 0;           // :879-880
     const int mt = 48 * K + 4 * L + (has_qc ? 1 : 0);
-    if (tid == 0) sc[sInvMt] = 1.0 / (double)mt;               // (one division per attempt; the per-iteration means multiply by it)
+    if (tid == 0) { sc[sInvMt] = 1.0 / (double)mt; sc[sMtD] = (double)mt; }               // (one division per attempt; the per-iteration means multiply by it)
 
     const int li = tid >> 5, slice = tid & 7;
     const int seg_cnt = sI[li + 1] - sI[li];                  // lines of my segment (0 for segments >= K)
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const int t = otid(), l1 = t - 64;
             const double nrd = wave_max(l1 < n ? fabs(sRd[l1]) : 0.0);
             const double o = sc[sObj0] + wave_sum(l1 < n ? sDx[l1] : 0.0);      // (the objective's terms: written next to rd, see above)
-            const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
+            const double gap = sc[sMu] * sc[sMtD], nr = sc[sNrp], qs = sc[sQscale];
             int flag = 0;
             if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-9, 1e-9, 1e-10 unless nep_batch_set_tolerances says otherwise)
             else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const double mua = ((1.0 - aaff) * sc[sSumSl] + aaff * aaff * c2) * inv_mt;
             const double rr = mua * frcp2(mu);
             sm = rr * rr * rr * mu;
-            sm = fmax(sm, 0.1 * sp.tol_gap * (1.0 + fabs(sc[sObj])) * inv_mt);
+            sm = fmax(sm, sp.tol_gap_floor * (1.0 + fabs(sc[sObj])) * inv_mt);
             if (nopred) sm = sc[sSigKeep];       // (sigma mu of the discarded predictor)
             else if (__builtin_amdgcn_readfirstlane((int)(it >= kCorrFromIt && aaff < kCorrMinStep))) {
               // the affine step is too short for its second-order term to mean anything: repeat the iteration from the same point
