@@ -706,7 +706,9 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     const double base_radius = 0.7;
     const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
     bool close_to_base = !cull_tests;      // (staging is only asked for candidates that passed this test in step 1)
-    if (cull_tests) {
+    // (a base farther than 2.2 m from the box of the four control points along x or y is farther than that from each of them: the
+    // per-point test below is false for all four — a round of 64 far bases skips it as a whole)
+    if (cull_tests && !((pbx < cx.bb[0] - 2.2) | (pbx > cx.bb[1] + 2.2) | (pby < cx.bb[2] - 2.2) | (pby > cx.bb[3] + 2.2))) {
       // all four control points, no exits (lanes of a wave leave a loop at different points only to wait for each other); the square
       // root is taken where the coarse test does not already say "far" (sqrt(ddx^2 + ddy^2) >= max(|ddx|, |ddy|): beyond 2.2 on
       // either axis the reference's test is false)
@@ -955,6 +957,180 @@ template <int RULE>
 __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParams sp, ProblemSet ps, int pool_pairs) {
   separator_body<RULE>(sp, ps, pool_pairs, blockIdx.x / NEP_MAX_POL, blockIdx.x % NEP_MAX_POL, true);
 }
+// The spatial presolve's separator (launched instead of separator_kernel<0> when LPs may be skipped, ps.skip_box != null): one wave
+// takes kSepPack consecutive segments of a slot (all eight in a large launch).  With the skipping a segment is left with a dozen or two LPs (17 on average at
+// config 5) — a quarter of a wave's lanes, and an LP batch costs the same whatever its fill — so step 1 runs for the wave's
+// segments one after the other, appending (segment, candidate) entries to ONE list, and the LPs are then solved 64 to a batch
+// across the segments: three batches per slot instead of eight.  Same candidates, same culls, same per-LP arithmetic and the same
+// order within every segment as separator_body (lines and counts are bit-identical: the presolve tests compare them); a lane's
+// segment only enters through its control points (LDS) and the hull interval.  The list has the unpacked kernel's capacity: when
+// a round of candidates might not fit, what has been gathered is solved first.
+// (segments per wave, chosen by the host from the launch's size — 2: 0.555, 3: 0.511, 4: 0.497, 8: 0.488 ms per 8 192 config-5
+// replans against 0.639 unpacked; small launches keep more, shorter waves)
+__global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(SceneParams sp, ProblemSet ps, int pool_pairs, int kSepPack) {
+  const int kSepGroups = (NEP_MAX_POL + kSepPack - 1) / kSepPack;
+  extern __shared__ __attribute__((aligned(16))) double sdyn[];
+  double2* sA = (double2*)sdyn;                      // [pool_pairs] the batch's point sets A, packed
+  double* sBx = sdyn + 2 * pool_pairs; double* sBy = sBx + 4 * NEP_MAX_POL;      // [segment][4] control points
+  int* sCnt = (int*)(sBy + 4 * NEP_MAX_POL);          // [segment][6]: near, far, failed, attempted, skipped (running)
+  unsigned short* sAtt = (unsigned short*)(sCnt + 6 * NEP_MAX_POL);      // entries (segment << 13 | candidate)
+  const int lane = threadIdx.x;
+  const int slot = blockIdx.x / kSepGroups, grp = blockIdx.x % kSepGroups;
+  const int seg_lo = grp * kSepPack, seg_hi = seg_lo + kSepPack < NEP_MAX_POL ? seg_lo + kSepPack : NEP_MAX_POL;
+  const nep_guess* g = ps.guess + slot;
+  const int K = g->K;
+  const double T = sp.T_span;
+  SepCtx cx; cx.sp = &sp; cx.ps = &ps; cx.slot = slot; cx.scene = slot / sp.n_local; cx.own = sp.first_local + (slot % sp.n_local);
+  cx.N = sp.num_agents; cx.S = sp.n_static; cx.nH = sp.n_hull;
+  cx.total = cx.nH + cx.N + cx.S + ((sp.ent_enabled && ps.case_id) ? cx.N * kBend : 0);
+  cx.skip_box = ps.skip_box; cx.skip_r = sp.cull_radius;
+  const int total = cx.total, cap = total + 8;
+  if (lane < 6 * NEP_MAX_POL) sCnt[lane] = 0;
+  if (lane < 4 * (seg_hi - seg_lo)) {  // ctrlPtsInit_[seg] (solver_gurobi_poly.cpp:232-243)
+    const int seg = seg_lo + (lane >> 2), k = lane & 3;
+    if (seg < K && seg < sp.num_pol) {
+      const double tp0 = T * T * T, tp1 = T * T, tp2 = T;
+      const double m0 = tp0 * cAPosInv[0][k], m1 = tp1 * cAPosInv[1][k], m2 = tp2 * cAPosInv[2][k], m3 = 1.0 * cAPosInv[3][k];
+      const double* Px = g->coeff[0][seg]; const double* Py = g->coeff[1][seg];
+      sBx[seg * 4 + k] = ((Px[0] * m0 + Px[1] * m1) + Px[2] * m2) + Px[3] * m3;
+      sBy[seg * 4 + k] = ((Py[0] * m0 + Py[1] * m1) + Py[2] * m2) + Py[3] * m3;
+    }
+  }
+  __syncthreads();
+  int n_list = 0;
+  // ---- the LPs gathered so far, 64 to a batch across the segments ----
+  auto flush = [&]() {
+    __syncthreads();
+    for (int a0 = 0; a0 < n_list; a0 += 64) {
+      const int a = a0 + lane;
+      const bool active = a < n_list;
+      const int e = active ? (int)sAtt[a] : 0;
+      const int sl = e >> 13, c = e & 8191;
+      Pts4 B4;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { B4.x[k] = sBx[sl * 4 + k]; B4.y[k] = sBy[sl * 4 + k]; }
+      double nd[3] = {0.0, 0.0, 0.0};
+      bool far = false, ok = true;
+      int nA = 0; int ord = 0;
+      if (active) { const double2* u_ = nullptr; cand_eval(cx, sl, c, sBx, sBy, 0.0, 2, nullptr, nA, ord, u_); }
+      int incl = nA;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+      if (active) {
+        double2 priv[4];
+        double2* myA = (incl <= pool_pairs) ? sA + (incl - nA) : nullptr;
+        const bool made_here = (c >= cx.nH && c < cx.nH + cx.N) || c >= cx.nH + cx.N + cx.S;
+        if (!myA && made_here) myA = priv;
+        const double2* Ause = myA;
+        cand_eval(cx, sl, c, sBx, sBy, 0.0, 1, myA, nA, ord, Ause);
+        ok = separator_impl(nA, Ause, ord, B4, nd);
+        if (!ok) { nd[0] = nd[1] = nd[2] = 0.0; }
+        double worst = -NEP_INF;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const double v = (nd[0] * B4.x[k] + nd[1] * B4.y[k]) + (nd[2] - 1.0); if (v > worst) worst = v; }
+        const double len = sqrt(nd[0] * nd[0] + nd[1] * nd[1]);
+        far = !ok || -worst > sp.cull_radius * len;
+      }
+      const unsigned long long below = (1ull << lane) - 1ull;
+      for (int s_ = seg_lo; s_ < seg_hi; s_++) {           // (near lines keep their call order at the front of their segment's bucket, far ones from its end)
+        const bool mine = active && sl == s_;
+        const unsigned long long mS = __ballot(mine);
+        if (mS == 0ull) continue;
+        const unsigned long long mn = __ballot(mine && !far), mf = __ballot(mine && far), mx = __ballot(mine && !ok);
+        const int base_n = sCnt[s_ * 6], base_f = sCnt[s_ * 6 + 1];
+        if (mine) {
+          double* bucket = ps.line_nd + ((long)slot * NEP_MAX_POL + s_) * sp.lines_cap * 3;
+          const long pos = far ? (long)sp.lines_cap - 1 - (base_f + __popcll(mf & below)) : (long)base_n + __popcll(mn & below);
+          bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2];
+        }
+        __syncthreads();
+        if (lane == 0) { sCnt[s_ * 6] = base_n + __popcll(mn); sCnt[s_ * 6 + 1] = base_f + __popcll(mf); sCnt[s_ * 6 + 2] += __popcll(mx); }
+        __syncthreads();
+      }
+    }
+    n_list = 0;
+  };
+  // ---- step 1, segment by segment: which LPs does the reference call, in order (as separator_body with the spatial presolve) ----
+  for (int seg = seg_lo; seg < seg_hi; seg++) {
+    if (seg >= K || seg >= sp.num_pol) continue;
+    const double* bx = sBx + seg * 4; const double* by = sBy + seg * 4;
+    const int tag = seg << 13;
+    double hulldist = 0;  // :738-742
+    for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; cx.el[k] = sqrt(ex * ex + ey * ey); hulldist += cx.el[k]; }
+    cx.bb[0] = fmin(fmin(bx[0], bx[1]), fmin(bx[2], bx[3])); cx.bb[1] = fmax(fmax(bx[0], bx[1]), fmax(bx[2], bx[3]));
+    cx.bb[2] = fmin(fmin(by[0], by[1]), fmin(by[2], by[3])); cx.bb[3] = fmax(fmax(by[0], by[1]), fmax(by[2], by[3]));
+    int n_att = 0, n_skip = 0;
+    const int n_plain = cx.nH + cx.N + cx.S;
+    {
+      const double* bx0 = cx.skip_box + ((long)cx.scene * (cx.N + cx.S) * sp.num_pol + seg) * 4;
+      auto load_box = [&](int j, double2& a, double2& b) {
+        const bool v = j < cx.nH;
+        const double2* q = (const double2*)(bx0 + (long)(v ? j : 0) * sp.num_pol * 4);
+        a = q[0]; b = q[1];
+      };
+      double2 ca, cb, na, nb2;
+      load_box(lane, ca, cb);
+      for (int c0 = 0; c0 < cx.nH; c0 += 64) {
+        if (n_list + 64 > cap) flush();
+        const int j = c0 + lane;
+        load_box(j + 64, na, nb2);
+        const bool valid = j < cx.nH && !(sp.skip_own && j == cx.own) && ca.x < NEP_INF;
+        const bool far = (ca.x - cx.bb[1] > cx.skip_r) | (cx.bb[0] - ca.y > cx.skip_r) | (cb.x - cx.bb[3] > cx.skip_r) | (cx.bb[2] - cb.y > cx.skip_r);
+        const unsigned long long mask = __ballot(valid && !far);
+        if (valid && !far) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | j);
+        n_list += __popcll(mask); n_att += __popcll(mask);
+        n_skip += __popcll(__ballot(valid && far));
+        ca = na; cb = nb2;
+      }
+    }
+    for (int c0 = cx.nH; c0 < n_plain; c0 += 64) {
+      if (n_list + 64 > cap) flush();
+      const int c = c0 + lane;
+      int nA; int ord; bool skp = false;
+      const double2* unused = nullptr;
+      const bool att = c < n_plain && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused, &skp);
+      const unsigned long long mask = __ballot(att && !skp);
+      if (att && !skp) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | c);
+      n_list += __popcll(mask); n_att += __popcll(mask);
+      n_skip += __popcll(__ballot(att && skp));
+    }
+    if (n_plain < total) {      // entangle candidates (agent j, bend segment k): the agents with an active case first, then their pairs densely
+      unsigned short* sAct = sAtt + cap;
+      int n_act = 0;
+      __syncthreads();
+      for (int j0 = 0; j0 < cx.N; j0 += 64) {
+        const int j = j0 + lane;
+        const bool act = j < cx.N && j != cx.own && ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * cx.N + j] != 0;
+        const unsigned long long mask = __ballot(act);
+        if (act) sAct[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
+        n_act += __popcll(mask);
+      }
+      __syncthreads();
+      for (int p0 = 0; p0 < n_act * kBend; p0 += 64) {
+        if (n_list + 64 > cap) flush();
+        const int pp = p0 + lane;
+        int nA; int ord; const double2* unused = nullptr;
+        const int c = pp < n_act * kBend ? n_plain + (int)sAct[pp / kBend] * kBend + (pp % kBend) : 0;
+        const bool att = pp < n_act * kBend && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused);
+        const unsigned long long mask = __ballot(att);
+        if (att) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | c);
+        n_list += __popcll(mask); n_att += __popcll(mask);
+      }
+    }
+    if (lane == 0) { sCnt[seg * 6 + 3] = n_att; sCnt[seg * 6 + 4] = n_skip; }
+  }
+  flush();
+  __syncthreads();
+  if (lane < seg_hi - seg_lo) {
+    const int seg = seg_lo + lane;
+    const long o = (long)slot * NEP_MAX_POL + seg;
+    ps.line_cnt[o] = sCnt[seg * 6];
+    ps.line_far[o] = sCnt[seg * 6 + 1];
+    if (ps.line_skip) ps.line_skip[o] = sCnt[seg * 6 + 4];
+    ps.lp_stats[o * 2] = sCnt[seg * 6 + 3] + sCnt[seg * 6 + 4]; ps.lp_stats[o * 2 + 1] = sCnt[seg * 6 + 2];
+  }
+}
+
 // The redo pass of the presolve: every segment of the replans the QP kernel listed (ps.redo_list / ps.redo_count: a parked
 // line violated, or the solution moved farther from the guess than the skipped LPs allow) with every LP solved and every line
 // in call order, for the full re-solve that follows.  A fixed small grid walks the list (it is empty nearly always).
@@ -984,6 +1160,19 @@ static int separator_pool_pairs(const SceneParams& sp) {
 
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
   if (n_slots <= 0) return;
+  if (ps.skip_box && ps.line_far && sp.sep_rule == 0 && sp.cull_radius > 0.0 && !getenv("NEP_SEP_UNPACKED")) {      // the spatial presolve: segments packed three to a wave
+    const int pairs = separator_pool_pairs(sp);
+    const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
+    const size_t lds_p = ((size_t)pairs * 16 + 8 * NEP_MAX_POL * sizeof(double) + 6 * NEP_MAX_POL * sizeof(int)
+                          + (size_t)(total + 8 + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short) + 15) & ~(size_t)15;
+    static DynLdsAttr attr_p;
+    (void)attr_p.ensure((const void*)separator_packed_kernel, lds_p);
+    int pack = 1; while (pack < NEP_MAX_POL && (long)n_slots * (NEP_MAX_POL / (pack * 2)) >= 4096) pack *= 2;      // (at least ~4 000 waves while the launch allows it)
+    if (const char* e = getenv("NEP_SEP_PACK")) { const int v = atoi(e); if (v >= 1 && v <= NEP_MAX_POL) pack = v; }
+    const int groups = (NEP_MAX_POL + pack - 1) / pack;
+    hipLaunchKernelGGL(separator_packed_kernel, dim3(n_slots * groups), dim3(64), lds_p, st, sp, ps, pairs, pack);
+    return;
+  }
   const size_t lds = separator_lds_bytes(sp);
   static DynLdsAttr attr[2];
   if (sp.sep_rule == 1) {
