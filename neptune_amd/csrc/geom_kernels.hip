@@ -983,7 +983,8 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   SepCtx cx; cx.sp = &sp; cx.ps = &ps; cx.slot = slot; cx.scene = slot / sp.n_local; cx.own = sp.first_local + (slot % sp.n_local);
   cx.N = sp.num_agents; cx.S = sp.n_static; cx.nH = sp.n_hull;
   cx.total = cx.nH + cx.N + cx.S + ((sp.ent_enabled && ps.case_id) ? cx.N * kBend : 0);
-  cx.skip_box = ps.skip_box; cx.skip_r = sp.cull_radius;
+  const bool cull = sp.cull_radius > 0.0 && ps.line_far != nullptr;      // (the line presolve: far lines parked at the back of the bucket)
+  cx.skip_box = cull ? ps.skip_box : nullptr; cx.skip_r = sp.cull_radius;      // (the spatial presolve on top: LPs known to give a far line are not solved)
   const int total = cx.total, cap = total + 8;
   if (lane < 6 * NEP_MAX_POL) sCnt[lane] = 0;
   if (lane < 4 * (seg_hi - seg_lo)) {  // ctrlPtsInit_[seg] (solver_gurobi_poly.cpp:232-243)
@@ -1025,11 +1026,13 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         cand_eval(cx, sl, c, sBx, sBy, 0.0, 1, myA, nA, ord, Ause);
         ok = separator_impl(nA, Ause, ord, B4, nd);
         if (!ok) { nd[0] = nd[1] = nd[2] = 0.0; }
-        double worst = -NEP_INF;
+        if (cull) {
+          double worst = -NEP_INF;
 #pragma unroll
-        for (int k = 0; k < 4; k++) { const double v = (nd[0] * B4.x[k] + nd[1] * B4.y[k]) + (nd[2] - 1.0); if (v > worst) worst = v; }
-        const double len = sqrt(nd[0] * nd[0] + nd[1] * nd[1]);
-        far = !ok || -worst > sp.cull_radius * len;
+          for (int k = 0; k < 4; k++) { const double v = (nd[0] * B4.x[k] + nd[1] * B4.y[k]) + (nd[2] - 1.0); if (v > worst) worst = v; }
+          const double len = sqrt(nd[0] * nd[0] + nd[1] * nd[1]);
+          far = !ok || -worst > sp.cull_radius * len;
+        }
       }
       const unsigned long long below = (1ull << lane) - 1ull;
       for (int s_ = seg_lo; s_ < seg_hi; s_++) {           // (near lines keep their call order at the front of their segment's bucket, far ones from its end)
@@ -1061,7 +1064,8 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     cx.bb[2] = fmin(fmin(by[0], by[1]), fmin(by[2], by[3])); cx.bb[3] = fmax(fmax(by[0], by[1]), fmax(by[2], by[3]));
     int n_att = 0, n_skip = 0;
     const int n_plain = cx.nH + cx.N + cx.S;
-    {
+    int c_first = 0;
+    if (cx.skip_box) {
       const double* bx0 = cx.skip_box + ((long)cx.scene * (cx.N + cx.S) * sp.num_pol + seg) * 4;
       auto load_box = [&](int j, double2& a, double2& b) {
         const bool v = j < cx.nH;
@@ -1082,8 +1086,9 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         n_skip += __popcll(__ballot(valid && far));
         ca = na; cb = nb2;
       }
+      c_first = cx.nH;
     }
-    for (int c0 = cx.nH; c0 < n_plain; c0 += 64) {
+    for (int c0 = c_first; c0 < n_plain; c0 += 64) {
       if (n_list + 64 > cap) flush();
       const int c = c0 + lane;
       int nA; int ord; bool skp = false;
@@ -1125,7 +1130,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     const int seg = seg_lo + lane;
     const long o = (long)slot * NEP_MAX_POL + seg;
     ps.line_cnt[o] = sCnt[seg * 6];
-    ps.line_far[o] = sCnt[seg * 6 + 1];
+    if (ps.line_far) ps.line_far[o] = sCnt[seg * 6 + 1];
     if (ps.line_skip) ps.line_skip[o] = sCnt[seg * 6 + 4];
     ps.lp_stats[o * 2] = sCnt[seg * 6 + 3] + sCnt[seg * 6 + 4]; ps.lp_stats[o * 2 + 1] = sCnt[seg * 6 + 2];
   }
@@ -1160,7 +1165,9 @@ static int separator_pool_pairs(const SceneParams& sp) {
 
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
   if (n_slots <= 0) return;
-  if (ps.skip_box && ps.line_far && sp.sep_rule == 0 && sp.cull_radius > 0.0 && !getenv("NEP_SEP_UNPACKED")) {      // the spatial presolve: segments packed three to a wave
+  // (only with the spatial presolve: with every LP to solve a segment fills its wave by itself — 64 to 68 LPs — and the packed form is
+  // slower, 0.53 against 0.41 ms per 4.2 M LPs: its step 1 is serial over the segments and its lanes hold different control points)
+  if (ps.skip_box && ps.line_far && sp.sep_rule == 0 && sp.cull_radius > 0.0 && !getenv("NEP_SEP_UNPACKED")) {
     const int pairs = separator_pool_pairs(sp);
     const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
     const size_t lds_p = ((size_t)pairs * 16 + 8 * NEP_MAX_POL * sizeof(double) + 6 * NEP_MAX_POL * sizeof(int)
