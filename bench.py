@@ -741,7 +741,7 @@ def main():
         ach5 = bytes5 * S5 * N5 / (k6["qp"] * 1e-3) / 1e9 if k6["qp"] > 0 else 0.0
         seq5 = bytes5 * S5 * N5 / (k6["sequence"] * 1e-3) / 1e9 if k6["sequence"] > 0 else 0.0
         dom = max(("hull", "separator", "qp"), key=lambda n_: k6[n_])
-        dom_name = {"hull": "hull_group_kernel", "separator": "separator_kernel", "qp": kern5}[dom]
+        dom_name = {"hull": "hull_group_kernel", "separator": "separator_packed_kernel" if cull5 > 0.0 else "separator_kernel", "qp": kern5}[dom]
         ach_dom = bytes5 * S5 * N5 / (k6[dom] * 1e-3) / 1e9 if k6[dom] > 0 else 0.0
         config5 = {"value": S5 * N5 * steps6 / dt6, "unit": "replans/s", "steps": steps6, "ms_per_step": dt6 / steps6 * 1e3,
                    "step_ms": {"p50": float(np.percentile(ms6, 50)), "p99": float(np.percentile(ms6, 99)), "max": float(ms6.max())},
@@ -760,7 +760,9 @@ def main():
                                 "traffic_source": "profiles/pmc_summary_config5_latest.txt (committed rocprofv3 --pmc summary of `bench.py --config5-only`)",
                                 "note": "the replan's algorithmic bytes (SURVEY 8d: ~273 KB + the entangle inputs at this size) x replans per launch / the "
                                         "duration of the DOMINANT kernel of this leg's sequence — here the separator, which reads every other agent's hulls; "
-                                        "`qp_kernel` prices the same bytes against the interior-point kernel as the headline's roofline does"},
+                                        "`qp_kernel` prices the same bytes against the interior-point kernel as the headline's roofline does.  With the presolve the "
+                                        "separator reads a 32-byte box instead of the hull for every obstacle it skips, so the measured `traffic` is far BELOW "
+                                        "the algorithmic bytes and this fraction overstates how close the kernel is to the memory roof: it is VALU-issue bound"},
                    "scene_generation_wait_s": t_wait,
                    "note": "the handle's default for this size: verified line presolve at %.1f m (lines farther from the guess are parked, checked at the "
                            "solution, re-solved with all rows on a violation), interior point on %s" % (cull5, kern5), **status_counts(sol6)}
