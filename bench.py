@@ -663,6 +663,27 @@ def main():
                                 note="closed loop on the device, one HIP graph per round: front end -> lines -> QP -> safety check + commit -> point A of "
                                      "the next round 0.5 s ahead on the committed trajectory; arrived agents turn around.  Every step solves NEW problems; the "
                                      "launch-order predictor is the same agent's previous replan", **status_counts(sol4))
+            # ---- both again with the verified presolve (what a deployment runs, and the handle's default at config-5 size) ----
+            if args.chain_cull_radius == 0.0 and args.presolve_radius > 0.0:
+                be.set_line_cull(args.presolve_radius)
+                d_com2.copy_(be.to_device(com))
+                dt3p, ms3p, _ = run_leg(chain_step, [be], aux_steps, max(args.warmup, 2), clear=(fe2, sf2))
+                qp3p, _ = be.kernel_time_ms(2); sep3p, _ = be.kernel_time_ms(1)
+                be.enable_timing(False)
+                sol3p = be.solutions()
+                chain["with_presolve"] = leg_record(dt3p, aux_steps, ms3p, cull_radius_m=args.presolve_radius,
+                                                    kernel_ms={"frontend_with_hulls": mean_ms(fe2), "separator": sep3p, "qp": qp3p, "safety": mean_ms(sf2)},
+                                                    rows_solved_mean=float(sol3p["stats"]["n_rows"].mean()), ipm_iters_mean=float(sol3p["stats"]["iters"].mean()),
+                                                    presolve_redo_last_step=be.redo_count(), **status_counts(sol3p))
+                d_st_m.copy_(be.to_device(starts_np)); d_alt.copy_(torch.from_numpy(alt_np.copy()).to(dev)); d_com3.copy_(be.to_device(com))
+                dt4p, ms4p, _ = run_leg(moving_step, [be], aux_steps, max(args.warmup, 2), clear=(fe3, sf3))
+                qp4p, _ = be.kernel_time_ms(2); sep4p, _ = be.kernel_time_ms(1)
+                be.enable_timing(False)
+                sol4p = be.solutions()
+                moving["with_presolve"] = leg_record(dt4p, aux_steps, ms4p, cull_radius_m=args.presolve_radius,
+                                                     kernel_ms={"frontend_with_hulls": mean_ms(fe3), "separator": sep4p, "qp": qp4p, "safety_commit_next_start": mean_ms(sf3)},
+                                                     rows_solved_mean=float(sol4p["stats"]["n_rows"].mean()), ipm_iters_mean=float(sol4p["stats"]["iters"].mean()),
+                                                     presolve_redo_last_step=be.redo_count(), **status_counts(sol4p))
             be.set_line_cull(0.0)
 
         # ---- single_scene: ONE fleet -------------------------------------------------------------------------------------
