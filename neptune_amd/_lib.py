@@ -46,6 +46,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise BackendError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(or make -C neptune_amd/csrc); there is no CPU fallback" % LIB_PATH)
+    # The library links the HIP runtime; PyTorch ships its own copy of it.  Whichever is loaded first serves both, and it has to
+    # be PyTorch's (device memory and streams come from there): a host-only entry point called before `import torch` — the scene
+    # helpers inflate static obstacles through nep_inflate_static — would otherwise bind the system's copy, and the handle
+    # created later would see no device.  (A C++ host has one runtime and no such order.)
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     d, i, vp = C.c_double, C.c_int32, C.c_void_p
     pd, pi = C.POINTER(C.c_double), C.POINTER(C.c_int32)
