@@ -895,7 +895,7 @@ def test_parity_distribution_on_front_end_guesses(be, oracle):
     """Not a sample around the outliers: EVERY replan of four 64-agent scenes on front-end (lattice) guesses — the inputs on
     which the interior point works hardest (8 iterations, relaxed and failed solves) — against the oracle.  Asserted: no
     status mismatch, p99 of the coefficient difference <= 1e-6, maximum <= 1e-4, positions along the trajectories within
-    5e-5 m, cost within 1e-8 relative — the bounds of profiles/r03_parity_sweep.txt (scripts/parity_sweep.py: 5 800
+    5e-5 m, cost within 1e-8 relative — the bounds of profiles/r03_parity_sweep.txt (scripts/parity_sweep.py: 5 041
     replans of six sizes, no status mismatch; on front-end guesses p99 5.8e-7, max 7.7e-5 on one replan of 1 011 whose two
     interior-point paths took 17 and 18 iterations, positions within 2.5e-5 m, cost within 2.2e-9; on the scenes' own
     guesses everything within 1.5e-8).  Why the maximum is not 1e-6: the tail consists of replans that never pass the strict
