@@ -1379,35 +1379,63 @@ __global__ __launch_bounds__(256) void safety_conflict_kernel(const nep_traj_rec
 
 // Agents visited by id; an agent keeps its new trajectory unless it conflicts (either direction)
 // with an already accepted lower id.  One workgroup per scene; then the final records are written.
+// The conflict matrix is first folded into one symmetric bit row per agent in LDS (all threads, coalesced passes over the
+// two byte matrices), then one thread walks the ids — accepted(a) = !forced_bad(a) && (row(a) & accepted) == 0, a few words per
+// agent — instead of three workgroup barriers and two strided byte gathers per agent (63 -> 8 us per launch of 128 scenes).
+constexpr int kResolveParts = 8;
 __global__ __launch_bounds__(256) void safety_resolve_kernel(const nep_traj_rec* __restrict__ prev, const nep_traj_rec* __restrict__ fresh, int N,
                                                              const unsigned char* __restrict__ conflict, const unsigned char* __restrict__ conflict_prev,
                                                              const int* __restrict__ entangles, nep_traj_rec* __restrict__ final_out, int* __restrict__ accept_out) {
-  extern __shared__ int sAcc[];   // [N] accept flags + [1] vote
-  const int tid = threadIdx.x, scene = blockIdx.x;
+  extern __shared__ int sAcc[];   // [N] accept flags, [N] forced-bad flags, [N][W] symmetric conflict rows (32-bit words), [W] accepted ids
+  // (kResolveParts workgroups per scene: each works out the accept flags — a few thousand bytes — and writes its share of the final
+  // records: the copy, 120 KB per 64-agent scene, is what takes time, and one workgroup per scene left half of the chip idle)
+  const int tid = threadIdx.x, scene = blockIdx.x / kResolveParts, part = blockIdx.x % kResolveParts;
+  const int W = (N + 31) >> 5;
+  int* sBad = sAcc + N;
+  unsigned* sRow = (unsigned*)(sBad + N);
+  unsigned* sBits = sRow + N * W;      // [W] accepted ids so far, when they do not fit eight registers (N > 256)
   const unsigned char* Cm = conflict + (long)scene * N * N;
   const unsigned char* Cp = conflict_prev ? conflict_prev + (long)scene * N * N : nullptr;
-  int* vote = sAcc + N;
-  for (int a = 0; a < N; a++) {
-    if (tid == 0) *vote = 0;
-    __syncthreads();
-    bool bad = false;
-    for (int j = tid; j < a; j += blockDim.x) bad = bad || (sAcc[j] && (Cm[(long)a * N + j] || Cm[(long)j * N + a]));
-    // (optional) the new trajectory must also clear what everybody else is flying now: whoever is turned
-    // down this round keeps exactly that
-    if (Cp) for (int j = tid; j < N; j += blockDim.x) bad = bad || (j != a && Cp[(long)a * N + j]);
-    if (entangles && tid == 0) bad = bad || entangles[(long)scene * N + a] != 0;     // entangleCheckGivenPwp (neptune.cpp:746-754)
-    if (bad) *vote = 1;
-    __syncthreads();
-    if (tid == 0) sAcc[a] = *vote ? 0 : 1;
-    __syncthreads();
+  for (int e = tid; e < N * W + W; e += blockDim.x) sRow[e] = 0u;
+  for (int a = tid; a < N; a += blockDim.x) sBad[a] = (entangles && entangles[(long)scene * N + a] != 0) ? 1 : 0;      // entangleCheckGivenPwp (neptune.cpp:746-754)
+  __syncthreads();
+  for (long e = tid; e < (long)N * N; e += blockDim.x) {
+    const int a = (int)(e / N), j = (int)(e % N);
+    if (Cm[e] && a != j) { atomicOr(&sRow[a * W + (j >> 5)], 1u << (j & 31)); atomicOr(&sRow[j * W + (a >> 5)], 1u << (a & 31)); }
+    // (optional) the new trajectory must also clear what everybody else is flying now: whoever is turned down this round keeps
+    // exactly that
+    if (Cp && Cp[e] && a != j) sBad[a] = 1;
   }
+  __syncthreads();
+  if (tid == 0) {
+    unsigned acc[8];                                  // accepted ids so far (N <= 256: the path's sizes; beyond that the words live in LDS)
+#pragma unroll
+    for (int w = 0; w < 8; w++) acc[w] = 0u;
+    for (int a = 0; a < N; a++) {
+      bool bad = sBad[a] != 0;
+      if (W <= 8) {
+#pragma unroll
+        for (int w = 0; w < 8; w++) if (w < W) bad |= (sRow[a * W + w] & acc[w]) != 0u;
+      } else {
+        for (int w = 0; w < W; w++) bad |= (sRow[a * W + w] & sBits[w]) != 0u;
+      }
+      sAcc[a] = bad ? 0 : 1;
+      if (!bad) {
+        if (W <= 8) {
+#pragma unroll
+          for (int w = 0; w < 8; w++) if (w == (a >> 5)) acc[w] |= 1u << (a & 31);
+        } else sBits[a >> 5] |= 1u << (a & 31);
+      }
+    }
+  }
+  __syncthreads();
   const int words = (int)(sizeof(nep_traj_rec) / sizeof(double));
-  for (long e = tid; e < (long)N * words; e += blockDim.x) {
+  for (long e = (long)part * blockDim.x + tid; e < (long)N * words; e += (long)blockDim.x * kResolveParts) {
     const int a = (int)(e / words), w = (int)(e % words);
     const double* src = (const double*)((sAcc[a] ? fresh : prev) + (long)scene * N + a);
     ((double*)(final_out + (long)scene * N + a))[w] = src[w];
   }
-  if (accept_out) for (int a = tid; a < N; a += blockDim.x) accept_out[(long)scene * N + a] = sAcc[a];
+  if (accept_out && part == 0) for (int a = tid; a < N; a += blockDim.x) accept_out[(long)scene * N + a] = sAcc[a];
 }
 
 void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_scenes, int N, const SceneParams& sp, const ProblemSet& ps,
@@ -1427,7 +1455,7 @@ void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_sc
   }
   hulls_of(fresh);
   hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * ((N + 3) / 4)), dim3(256), 0, st, fresh, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
-  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes), dim3(256), (size_t)(N + 2) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, entangles, final_out, accept_out);
+  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes * kResolveParts), dim3(256), (size_t)(2 * N + (N + 1) * ((N + 31) / 32)) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, entangles, final_out, accept_out);
 }
 
 
