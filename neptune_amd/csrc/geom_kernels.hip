@@ -2040,10 +2040,14 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     FE_TICK(6);
     if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
     nb_prev = nb;
-    if constexpr (ENT) { int fv = -1; for (int r = nb - 1; r >= 0; r--) if (b_valid[r]) fv = r; if (fv >= 0) { best_depth = depth; best_rank = fv; } }
+    // (first rank in order that may end a plan / that is inside the goal radius: one LDS read per lane and a ballot in every wave — the
+    // beam holds at most 64 nodes — instead of every thread walking the ranks, which was 8 % of a depth)
+    const int rl = tid & 63;
+    const bool r_in = rl < nb, r_ok = r_in && (!ENT || b_valid[rl] != 0);
+    if constexpr (ENT) { const unsigned long long mv = __ballot(r_ok); if (mv) { best_depth = depth; best_rank = __builtin_ctzll(mv); } }
     else { best_depth = depth; best_rank = 0; }
-    int reached = -1;
-    for (int r = nb - 1; r >= 0; r--) if (b_dist[r] < fc.goal_size && (!ENT || b_valid[r])) reached = r;   // first in rank order (every thread: uniform)
+    const unsigned long long mr = __ballot(r_ok && b_dist[rl] < fc.goal_size);
+    const int reached = mr ? __builtin_ctzll(mr) : -1;   // first in rank order (every wave finds the same: uniform)
     if (reached >= 0) { status = NEP_FE_GOAL_REACHED; best_depth = depth; best_rank = reached; break; }
     if (depth == D) { status = NEP_FE_DEPTH_REACHED; break; }
   }
