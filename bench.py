@@ -179,6 +179,21 @@ def main():
     args = ap.parse_args()
     aux_steps = max(args.aux_steps, args.steps)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N` (the shape of the driver's single-GPU command): launch the N ranks ourselves, one
+        # process per GPU under torch.distributed.run, rendezvous on 127.0.0.1; rank 0's JSON line is the only thing on stdout
+        import socket
+        import subprocess
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if env.get("NEP_BENCH_ONE_DEVICE") == "1":
+            env.setdefault("NEP_BENCH_BACKEND", "gloo")        # several ranks on one GPU: RCCL refuses duplicate devices
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     import torch
     from neptune_amd import abi, dist as ndist, scene
     from neptune_amd.backend import BatchBackend
@@ -190,6 +205,9 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the back end has no CPU path")
+    if world > 1 and os.environ.get("NEP_BENCH_ONE_DEVICE") != "1" and torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d: this box shows %d GPU(s) (development aid: NEP_BENCH_ONE_DEVICE=1 runs the ranks on one device over gloo)"
+                         % (world, torch.cuda.device_count()))
     # development aid: several ranks on ONE GPU over gloo (the driver's runs use one GPU per rank over RCCL)
     one_device = os.environ.get("NEP_BENCH_ONE_DEVICE") == "1"
     dist_backend = os.environ.get("NEP_BENCH_BACKEND", "nccl")
@@ -310,6 +328,8 @@ def main():
             torch.cuda.synchronize(dev)
             return None
 
+    last_wall = [0.0]
+
     def run_leg(step_fn, handles, steps, warm, graph_ok=True, eager_after=40, clear=()):
         """warm untimed steps, then exactly `steps` steps between barriers (max over ranks), replaying one captured graph
         when possible.  Per-kernel HIP events (handle timing) cannot live inside a graph: with a graph they are taken from
@@ -332,7 +352,8 @@ def main():
                 step_fn()
             evs.append(ev())
         barrier()
-        dt = max_over_ranks(time.perf_counter() - t0)
+        last_wall[0] = time.perf_counter() - t0
+        dt = max_over_ranks(last_wall[0])
         step_ms = np.array([evs[i].elapsed_time(evs[i + 1]) for i in range(steps)])
         if g_ is not None and eager_after > 0:
             for b in handles:
@@ -506,6 +527,7 @@ def main():
                 tdist.destroy_process_group(); use_dist = False; rccl_torn_down = True
         # ---- headline: exactly --steps steps -------------------------------------------------------------------------
         dt, step_ms, graph = run_leg(step, bes, args.steps, 0, graph_ok=graph_plain, clear=(safety_ev, hull_ev, gather_ev))
+        dt_local = last_wall[0]
         qp_ms, n_launch = be.kernel_time_ms(2)           # per launch of one chunk (chunk 0)
         hull_ms, _ = be.kernel_time_ms(0)
         if sharded_hulls:
@@ -838,6 +860,14 @@ def main():
         if args.config5_only:
             print(json.dumps({"metric": "backend_replans_per_sec", "config5": config5, "graph_notes": graph_notes}))
 
+    per_rank = None
+    if world > 1 and not args.config5_only:
+        # every rank's own view of the step (the line's kernel_ms is rank 0's): kernel times and what its stream waited for
+        mine_rec = {"rank": rank, "device": torch.cuda.get_device_name(dev), "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms,
+                                                                                             "exchange_wait": mean_ms(gather_ev)},
+                    "step_ms_p50": float(np.percentile(step_ms, 50)), "step_ms_max": float(step_ms.max()), "wall_s": dt_local}
+        per_rank = [None] * world
+        tdist.all_gather_object(per_rank, mine_rec)
     if rank == 0 and not args.config5_only:
         if C == 1 and not sharded_hulls and not args.frontend:
             _, hn = be.debug_hulls(0)          # vertex counts of scene 0 as the last timed launch saw them
@@ -952,6 +982,8 @@ def main():
             "moving": moving,
             "single_scene": single,
             "config5": config5,
+            "per_gpu_value": value / world,
+            "per_rank": per_rank,
             "rccl": ({"process_group": "nccl (RCCL), world %d" % world, "initialised": True, "one_rank_all_gather_matches": rccl_one_rank_ok,
                       "nranks": nranks, "exchange": ("native (nep_batch_exchange_hulls: ncclAllGather inside the captured step)" if native else
                                                      ("torch.distributed" if world > 1 else "none (one rank)")),

@@ -336,6 +336,12 @@ int nep_batch_exchange_records(nep_batch_t* h, nep_comm_t* c, const nep_traj_rec
  * d_all [n_scenes][N][bytes_per_slot] (bytes_per_slot a positive multiple of 8) — e.g. the entangle states at point A that
  * nep_batch_safety_commit_ent reads of every agent.                                                               */
 int nep_batch_exchange_slots(nep_batch_t* h, nep_comm_t* c, const void* d_local, void* d_all, int64_t bytes_per_slot, void* stream);
+/* nep_batch_exchange_records and nep_batch_exchange_slots regroup through a staging buffer owned by the communicator (one per
+ * kind of exchange, so a records exchange and a slots exchange may be in flight on different streams; two exchanges of the SAME
+ * kind must be ordered on one stream).  A buffer grows on demand — but never while `stream` is capturing (the call then returns
+ * NEP_E_ARG): reserve the gathered sizes (world x one rank's piece, in bytes; 0 = leave as is) before capturing a graph, or run
+ * the exchange once eagerly.  A graph captured earlier holds the pointer it was captured with: do not grow a buffer afterwards. */
+int nep_comm_reserve(nep_comm_t* c, int64_t records_bytes, int64_t slots_bytes);
 /* Test hook: the regrouping step of nep_batch_exchange_records ([world][n_scenes][n_local] -> [n_scenes][world n_local]). */
 int nep_debug_regroup_records(const nep_traj_rec* d_src, nep_traj_rec* d_dst, int32_t world, int32_t n_scenes,
                               int32_t n_local, void* stream);
@@ -382,11 +388,19 @@ double nep_batch_get_line_cull(nep_batch_t* h);
  * y (the sides of those boxes are edges of the polygons, so the largest-gap line lies at least that far away).  Such LPs are
  * counted as attempted and solved (n_lp, n_lines: sets that far apart are separable) and verified through the distance the
  * solution's control points moved from the guess's; a replan that does not verify is solved again by a redo pass with every
- * LP and every row.  The debug line readers do not see lines that were never made.  nep_batch_debug_redo_count: replans
+ * LP and every row.  Precondition of the box test, checked at upload: every static polygon has an edge on each side of its
+ * bounding box (true of the inflated statics nep_inflate_static makes and of the interval hulls: hulls of axis-aligned squares);
+ * a handle that is given any other convex polygon (a diamond, say) solves every LP — parked lines and the zero-iteration test
+ * still apply, they evaluate real lines.  The debug line readers do not see lines that were never made.  nep_batch_debug_redo_count: replans
  * the last call sent through the redo pass (test hook); by_reason (may be NULL) receives how many of them had a parked line
  * violated [0] and how many moved farther than the radius [1].                                                       */
 int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason);
 int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap);    /* the listed slots (test hook) */
+/* Test hook: which form of the presolve's separator the next replans launch — 0 (default) segments per wave picked from the
+ * launch size, -1 the unpacked kernel (one segment per wave), 1..NEP_MAX_POL that many segments per wave.  The packed form's
+ * list entries hold 8 191 candidates per segment (n_hull + N + S + 8 N with the entangle rows); larger scenes take the unpacked
+ * kernel whatever is asked here.  Results do not depend on the form (GPU test).                                          */
+int nep_batch_debug_set_separator_pack(nep_batch_t* h, int32_t pack);
 
 /* Which vertex of the separating-line LP the separator returns.  The LP (separator_glpk.cpp:248-373) has a zero objective:
  * the reference gets "whatever vertex glp_simplex reaches", and the spline QP's optimum depends on it.

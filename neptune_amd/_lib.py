@@ -20,8 +20,8 @@ EXPORTS = [
     "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
     "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
     "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_gjk_batch",
-    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks", "nep_batch_exchange_slots", "nep_batch_set_ent_samples",
-    "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records", "nep_batch_set_max_runtime", "nep_batch_qp_placement", "nep_batch_set_launch_order", "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_get_line_cull", "nep_inflate_static", "nep_batch_debug_redo_count", "nep_batch_debug_redo_list", "nep_separator_batch_rule", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule", "nep_batch_set_tolerances", "nep_backend_set_tolerances",
+    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks", "nep_comm_reserve", "nep_batch_exchange_slots", "nep_batch_set_ent_samples",
+    "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records", "nep_batch_set_max_runtime", "nep_batch_qp_placement", "nep_batch_set_launch_order", "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_get_line_cull", "nep_inflate_static", "nep_batch_debug_redo_count", "nep_batch_debug_redo_list", "nep_batch_debug_set_separator_pack", "nep_separator_batch_rule", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule", "nep_batch_set_tolerances", "nep_backend_set_tolerances",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
@@ -102,6 +102,7 @@ def lib():
     L.nep_batch_get_line_cull.argtypes = [vp]; L.nep_batch_get_line_cull.restype = d
     L.nep_batch_debug_redo_count.argtypes = [vp, pi]
     L.nep_batch_debug_redo_list.argtypes = [vp, pi, i]
+    L.nep_batch_debug_set_separator_pack.argtypes = [vp, i]
     L.nep_batch_set_max_runtime.argtypes = [vp, d]
     L.nep_batch_qp_placement.argtypes = [vp]
     L.nep_batch_set_launch_order.argtypes = [vp, i]
@@ -113,6 +114,7 @@ def lib():
     L.nep_comm_create.argtypes = [C.POINTER(C.c_uint8), i, i]; L.nep_comm_create.restype = vp
     L.nep_comm_destroy.argtypes = [vp]; L.nep_comm_destroy.restype = None
     L.nep_comm_nranks.argtypes = [vp]
+    L.nep_comm_reserve.argtypes = [vp, C.c_int64, C.c_int64]
     L.nep_batch_exchange_hulls.argtypes = [vp, vp, vp, vp, vp]
     L.nep_batch_exchange_records.argtypes = [vp, vp, vp, vp, vp]
     L.nep_debug_regroup_records.argtypes = [vp, vp, i, i, i, vp]

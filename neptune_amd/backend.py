@@ -367,6 +367,10 @@ class BatchBackend:
         self.redo_reasons = {"parked_line_violated": int(r[0]), "moved_beyond_radius": int(r[1])}
         return n
 
+    def set_separator_pack(self, pack):
+        """test hook: 0 segments per wave by launch size, -1 the unpacked separator, 1..8 forced (nep_batch_debug_set_separator_pack)"""
+        check(lib().nep_batch_debug_set_separator_pack(self._h, int(pack)))
+
     def redo_list(self, cap=4096):
         out = np.zeros(cap, dtype=np.int32)
         n = int(check(lib().nep_batch_debug_redo_list(self._h, abi.iptr(out), cap)))

@@ -125,7 +125,7 @@ struct Engine {
   }
   // which interior-point kernel the next replan launches, and its LDS carve (see size_scratch)
   static constexpr double kAutoCullRadius = 4.0;
-  bool fits_reg = true, cull_user_set = false, skip_lps = true; int lds_lines_lds = 0;
+  bool fits_reg = true, cull_user_set = false, skip_lps = true, no_redo = false; int lds_lines_lds = 0, sep_pack = 0;
   void choose_placement() {
     use_reg = fits_reg || sp.cull_radius > 0.0;
     if (const char* f = getenv("NEP_QP_KERNEL")) { if (!strcmp(f, "reg")) use_reg = true; else if (!strcmp(f, "lds")) use_reg = false; }
@@ -168,6 +168,10 @@ struct Engine {
     }
     if (const char* f = getenv("NEP_SEP_SKIP")) skip_lps = atoi(f) != 0;      // (A/B: 0 solves every LP of a presolved replan too)
     if (const char* f = getenv("NEP_QP_LPT")) lpt = atoi(f) != 0;
+    no_redo = getenv("NEP_SEP_NO_REDO") != nullptr;
+    // (development aids, read here once and not per replan: NEP_SEP_UNPACKED, NEP_SEP_PACK=n — see nep_batch_debug_set_separator_pack)
+    if (getenv("NEP_SEP_UNPACKED")) sep_pack = -1;
+    else if (const char* f = getenv("NEP_SEP_PACK")) { const int v = atoi(f); if (v >= 1 && v <= NEP_MAX_POL) sep_pack = v; }
     if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; if (int e = d_order_key.ensure((size_t)slots)) return e; }
     choose_placement();
     rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
@@ -200,16 +204,18 @@ struct Engine {
     // LPs whose line is known to be far without solving them are skipped when the presolve is on, the rule is the largest gap
     // (box far => line far holds for that vertex only), the hull lists are the batch's (one per agent: the boxes are indexed
     // by agent) and the interior point is the register kernel (the one that verifies them): see separator_body / qp_reg_kernel
-    const bool skip = sp.cull_radius > 0.0 && use_reg && sp.sep_rule == 0 && sp.skip_own == 1 && sp.n_hull == sp.num_agents && skip_lps;
+    const bool skip = sp.cull_radius > 0.0 && use_reg && sp.sep_rule == 0 && sp.skip_own == 1 && sp.n_hull == sp.num_agents && skip_lps && statics_boxy;
     ps.skip_box = skip ? d_fe_box.p : nullptr; ps.line_skip = skip ? d_line_skip.p : nullptr;
     ps.redo_list = skip ? d_redo_list.p : nullptr; ps.redo_count = skip ? d_redo_count.p : nullptr; ps.order_count = nullptr;
+    ps.sep_pack = sep_pack;
     ps.row_scratch = d_row_scratch.p; ps.rows_cap = rows_cap; ps.lds_rows = lds_rows; ps.lds_lines = lds_lines;
     ps.dbg = profile_phases ? d_dbg.p : nullptr;
     ps.flags = d_flags.p;
     ps.fe_box = d_fe_box.p;
   }
   // packs n polygons into the fixed-stride device layout (vertices, vertex counts, edge lengths)
-  static int pack_statics(int n, const int32_t* off, const double* xy, std::vector<double>& sx, std::vector<int>& nv, std::vector<double>& el) {
+  bool statics_boxy = true;      // every static polygon uploaded so far has an edge on each side of its bounding box (see pack_statics)
+  int pack_statics(int n, const int32_t* off, const double* xy, std::vector<double>& sx, std::vector<int>& nv, std::vector<double>& el) {
     sx.assign((size_t)(n > 0 ? n : 1) * kHullV * 2, 0.0); nv.assign(n > 0 ? n : 1, 0);
     for (int j = 0; j < n; j++) {
       int c = off[j + 1] - off[j];
@@ -218,6 +224,21 @@ struct Engine {
       nv[j] = c;
       for (int v = 0; v < c; v++) { sx[((size_t)j * kHullV + v) * 2] = xy[2 * (off[j] + v)]; sx[((size_t)j * kHullV + v) * 2 + 1] = xy[2 * (off[j] + v) + 1]; }
       if (!normalize_ccw(&sx[(size_t)j * kHullV * 2], c)) return fail(NEP_E_ARG, "static obstacle polygon is not convex");
+      // The spatial presolve skips the LP of an obstacle whose BOX is far (box_far, geom_kernels.hip): sound only when every side of
+      // the box carries an edge of the polygon — true of inflated statics and interval hulls (hulls of axis-aligned squares), not of
+      // an arbitrary convex polygon (a diamond's nearest edge line can lie at 0.71 of the box distance).  One polygon without that
+      // property turns LP skipping off for the handle (parked lines and the zero-iteration test stay: they evaluate real lines).
+      if (c > 0) {
+        const double* q = &sx[(size_t)j * kHullV * 2];
+        double lo[2] = {q[0], q[1]}, hi[2] = {q[0], q[1]};
+        for (int v = 1; v < c; v++) for (int a = 0; a < 2; a++) { lo[a] = std::min(lo[a], q[2 * v + a]); hi[a] = std::max(hi[a], q[2 * v + a]); }
+        const double tol = 1e-9 * (1.0 + (hi[0] - lo[0]) + (hi[1] - lo[1]));
+        for (int a = 0; a < 2; a++) {
+          int n_lo = 0, n_hi = 0;
+          for (int v = 0; v < c; v++) { n_lo += q[2 * v + a] - lo[a] <= tol; n_hi += hi[a] - q[2 * v + a] <= tol; }
+          if (n_lo < 2 || n_hi < 2) statics_boxy = false;
+        }
+      }
     }
     // edge lengths for the proximity cull (solver_gurobi_poly.cpp:566-572), the same IEEE operations the kernel used to
     // repeat per candidate: squares, one sum, sqrt (no contraction: three separate roundings)
@@ -234,6 +255,7 @@ struct Engine {
   }
   int upload_statics(int n, const int32_t* off, const double* xy) {
     std::vector<double> sx, el; std::vector<int> nv;
+    statics_boxy = true;       // (a new shared set replaces every earlier polygon)
     if (int e = pack_statics(n, off, xy, sx, nv, el)) return e;
     if (int e = d_static_xy.ensure(sx.size())) return e;
     if (int e = d_static_el.ensure(el.size())) return e;
@@ -311,7 +333,7 @@ struct Engine {
     }
     if (use_reg) launch_qp_reg(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     else launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
-    if (skip && !getenv("NEP_SEP_NO_REDO")) {      // (NEP_SEP_NO_REDO: development aid — the flagged replans keep their presolved result for inspection)
+    if (skip && !no_redo) {      // (NEP_SEP_NO_REDO, read in size_scratch: development aid — the flagged replans keep their presolved result for inspection)
       // the presolve's redo pass: replans whose solution did not verify the skipped / parked lines (listed by the kernel above; the
       // list is empty nearly always) get every LP solved and every row through the interior point
       launch_separator_redo(slots, sp, ps, st);
@@ -1054,6 +1076,13 @@ int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap) {
   if (n > cap) n = cap;
   if (n > 0) HIPCHK(hipMemcpy(slots_out, h->eng.d_redo_list.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
   return n;
+}
+
+// Test hook: segments per wave of the presolve's separator (0: by launch size, -1: the unpacked kernel, 1..NEP_MAX_POL: forced)
+int nep_batch_debug_set_separator_pack(nep_batch_t* h, int32_t pack) {
+  if (!h || pack < -1 || pack > NEP_MAX_POL) return fail(NEP_E_ARG, "pack must be -1, 0 or 1..NEP_MAX_POL");
+  h->eng.sep_pack = pack;
+  return 0;
 }
 
 int nep_batch_qp_placement(nep_batch_t* h) { return h ? (h->eng.use_reg ? 1 : 0) : NEP_E_ARG; }

@@ -75,7 +75,24 @@ __global__ void regroup_records_kernel(const double* __restrict__ src, double* _
 struct nep_comm {
   ncclComm_t comm = nullptr;
   int world = 1, rank = 0;
-  double* staging = nullptr; size_t staging_bytes = 0;
+  // one staging buffer per kind of exchange ([0] records, [1] slots): the two may be in flight on different streams, and a
+  // captured graph keeps the pointer it was captured with
+  double* staging[2] = {nullptr, nullptr}; size_t staging_bytes[2] = {0, 0};
+  // grows staging[k] to `bytes`.  Never while `stream` is capturing: hipMalloc / hipFree are not capturable and a graph captured
+  // earlier holds the old pointer — the caller reserves first (nep_comm_reserve, or one eager call of the exchange).
+  int ensure(int k, size_t bytes, hipStream_t stream) {
+    if (staging_bytes[k] >= bytes) return 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) {
+      nep::set_last_error("exchange staging buffer must grow while the stream is capturing: call nep_comm_reserve (or run the exchange once eagerly) before the capture");
+      return NEP_E_ARG;
+    }
+    if (staging[k]) { (void)hipDeviceSynchronize(); (void)hipFree(staging[k]); }      // (a kernel of an earlier exchange may still read it)
+    staging[k] = nullptr; staging_bytes[k] = 0;
+    if (hipMalloc((void**)&staging[k], bytes) != hipSuccess) { nep::set_last_error("hipMalloc(exchange staging)"); return NEP_E_HIP; }
+    staging_bytes[k] = bytes;
+    return 0;
+  }
 };
 
 extern "C" {
@@ -114,8 +131,18 @@ int nep_comm_nranks(nep_comm_t* c) {
 void nep_comm_destroy(nep_comm_t* c) {
   if (!c) return;
   if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-  if (c->staging) hipFree(c->staging);
+  for (int k = 0; k < 2; k++) if (c->staging[k]) hipFree(c->staging[k]);
   delete c;
+}
+
+// Sizes the staging buffers of the two regrouping exchanges ahead of a graph capture: records_bytes / slots_bytes = the gathered
+// size (world x one rank's piece) the largest nep_batch_exchange_records / nep_batch_exchange_slots call will need; 0 leaves a
+// buffer as it is.  Synchronises the device when a buffer has to be replaced.
+int nep_comm_reserve(nep_comm_t* c, int64_t records_bytes, int64_t slots_bytes) {
+  if (!c || records_bytes < 0 || slots_bytes < 0) { nep::set_last_error("bad arguments"); return NEP_E_ARG; }
+  if (records_bytes > 0) if (int e = c->ensure(0, (size_t)records_bytes, nullptr)) return e;
+  if (slots_bytes > 0) if (int e = c->ensure(1, (size_t)slots_bytes, nullptr)) return e;
+  return 0;
 }
 
 int nep_batch_exchange_hulls(nep_batch_t* h, nep_comm_t* c, const void* d_block, void* d_blocks, void* stream) {
@@ -132,18 +159,13 @@ int nep_batch_exchange_records(nep_batch_t* h, nep_comm_t* c, const nep_traj_rec
   nep::batch_dims(h, &S, &nl, &N);
   if (nl * c->world != N) { nep::set_last_error("world * n_local must equal num_agents"); return NEP_E_ARG; }
   const size_t piece = (size_t)S * nl * sizeof(nep_traj_rec);
-  if (c->staging_bytes < piece * c->world) {
-    if (c->staging) hipFree(c->staging);
-    c->staging = nullptr; c->staging_bytes = 0;
-    if (hipMalloc((void**)&c->staging, piece * c->world) != hipSuccess) { nep::set_last_error("hipMalloc(exchange staging)"); return NEP_E_HIP; }
-    c->staging_bytes = piece * c->world;
-  }
-  const ncclResult_t r = g_rccl.AllGather(d_commit_local, c->staging, piece, ncclChar, c->comm, (hipStream_t)stream);
+  if (int e = c->ensure(0, piece * c->world, (hipStream_t)stream)) return e;
+  const ncclResult_t r = g_rccl.AllGather(d_commit_local, c->staging[0], piece, ncclChar, c->comm, (hipStream_t)stream);
   if (r != ncclSuccess) return fail_nccl("ncclAllGather(records)", r);
   const int words = (int)(sizeof(nep_traj_rec) / sizeof(double));
   const long total = (long)c->world * S * nl * words;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(regroup_records_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->staging, (double*)d_committed_all, c->world, S, nl, words);
+  hipLaunchKernelGGL(regroup_records_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->staging[0], (double*)d_committed_all, c->world, S, nl, words);
   if (hipGetLastError() != hipSuccess) { nep::set_last_error("regroup_records_kernel launch"); return NEP_E_HIP; }
   return 0;
 }
@@ -156,18 +178,13 @@ int nep_batch_exchange_slots(nep_batch_t* h, nep_comm_t* c, const void* d_local,
   nep::batch_dims(h, &S, &nl, &N);
   if (nl * c->world != N) { nep::set_last_error("world * n_local must equal num_agents"); return NEP_E_ARG; }
   const size_t piece = (size_t)S * nl * (size_t)bytes_per_slot;
-  if (c->staging_bytes < piece * c->world) {
-    if (c->staging) hipFree(c->staging);
-    c->staging = nullptr; c->staging_bytes = 0;
-    if (hipMalloc((void**)&c->staging, piece * c->world) != hipSuccess) { nep::set_last_error("hipMalloc(exchange staging)"); return NEP_E_HIP; }
-    c->staging_bytes = piece * c->world;
-  }
-  const ncclResult_t r = g_rccl.AllGather(d_local, c->staging, piece, ncclChar, c->comm, (hipStream_t)stream);
+  if (int e = c->ensure(1, piece * c->world, (hipStream_t)stream)) return e;
+  const ncclResult_t r = g_rccl.AllGather(d_local, c->staging[1], piece, ncclChar, c->comm, (hipStream_t)stream);
   if (r != ncclSuccess) return fail_nccl("ncclAllGather(slots)", r);
   const int words = (int)(bytes_per_slot / 8);
   const long total = (long)c->world * S * nl * words;
   int blocks = (int)((total + 255) / 256); if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(regroup_records_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->staging, (double*)d_all, c->world, S, nl, words);
+  hipLaunchKernelGGL(regroup_records_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, c->staging[1], (double*)d_all, c->world, S, nl, words);
   if (hipGetLastError() != hipSuccess) { nep::set_last_error("regroup kernel launch"); return NEP_E_HIP; }
   return 0;
 }

@@ -1167,15 +1167,17 @@ void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, 
   if (n_slots <= 0) return;
   // (only with the spatial presolve: with every LP to solve a segment fills its wave by itself — 64 to 68 LPs — and the packed form is
   // slower, 0.53 against 0.41 ms per 4.2 M LPs: its step 1 is serial over the segments and its lanes hold different control points)
-  if (ps.skip_box && ps.line_far && sp.sep_rule == 0 && sp.cull_radius > 0.0 && !getenv("NEP_SEP_UNPACKED")) {
+  const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
+  // the packed kernel's list entries are (segment << 13 | candidate) in 16 bits: candidates beyond 8 191 (about 800 agents with the
+  // entangle rows, 4 000 without) take the unpacked kernel, whose entries hold 65 535 (size_scratch refuses more)
+  if (ps.skip_box && ps.line_far && sp.sep_rule == 0 && sp.cull_radius > 0.0 && ps.sep_pack >= 0 && total <= 8191) {
     const int pairs = separator_pool_pairs(sp);
-    const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
     const size_t lds_p = ((size_t)pairs * 16 + 8 * NEP_MAX_POL * sizeof(double) + 6 * NEP_MAX_POL * sizeof(int)
                           + (size_t)(total + 8 + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short) + 15) & ~(size_t)15;
     static DynLdsAttr attr_p;
     (void)attr_p.ensure((const void*)separator_packed_kernel, lds_p);
     int pack = 1; while (pack < NEP_MAX_POL && (long)n_slots * (NEP_MAX_POL / (pack * 2)) >= 4096) pack *= 2;      // (at least ~4 000 waves while the launch allows it)
-    if (const char* e = getenv("NEP_SEP_PACK")) { const int v = atoi(e); if (v >= 1 && v <= NEP_MAX_POL) pack = v; }
+    if (ps.sep_pack >= 1 && ps.sep_pack <= NEP_MAX_POL) pack = ps.sep_pack;
     const int groups = (NEP_MAX_POL + pack - 1) / pack;
     hipLaunchKernelGGL(separator_packed_kernel, dim3(n_slots * groups), dim3(64), lds_p, st, sp, ps, pairs, pack);
     return;
@@ -1455,7 +1457,12 @@ void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_sc
   }
   hulls_of(fresh);
   hipLaunchKernelGGL(safety_conflict_kernel, dim3(n_scenes * ((N + 3) / 4)), dim3(256), 0, st, fresh, fresh, N, sp.num_pol, sp.T_span, ps.hull_xy, ps.hull_nv, conflict);
-  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes * kResolveParts), dim3(256), (size_t)(2 * N + (N + 1) * ((N + 31) / 32)) * sizeof(int), st, prev, fresh, N, conflict, conflict_prev, entangles, final_out, accept_out);
+  // (2 N + (N + 1) ceil(N / 32)) ints of dynamic LDS: quadratic in N — above the 64 KB default from N ~ 690 on, so the limit is
+  // raised explicitly (160 KB per CU: N up to ~1 100; beyond that the launch fails and HIPCHK(hipGetLastError()) reports it)
+  const size_t resolve_lds = (size_t)(2 * N + (N + 1) * ((N + 31) / 32)) * sizeof(int);
+  static DynLdsAttr resolve_attr;
+  (void)resolve_attr.ensure((const void*)safety_resolve_kernel, resolve_lds);
+  hipLaunchKernelGGL(safety_resolve_kernel, dim3(n_scenes * kResolveParts), dim3(256), resolve_lds, st, prev, fresh, N, conflict, conflict_prev, entangles, final_out, accept_out);
 }
 
 

@@ -72,6 +72,7 @@ struct ProblemSet {
   int* redo_count;               // [1]
   const int* order_count;        // [1] or null: only the first *order_count workgroups of the QP launch have work (the redo pass)
   int lines_override;            // 1: line buckets were filled by the host (test hook)
+  int sep_pack;                  // host only: segments per wave of the presolve's separator — 0 picked by launch size, -1 the unpacked kernel, 1..NEP_MAX_POL forced (nep_batch_debug_set_separator_pack; NEP_SEP_PACK / NEP_SEP_UNPACKED at create)
   const int* order;              // [slots] workgroup -> slot (longest expected solve first, see order_kernel) or null: identity
   int* order_key;                // [slots] this launch's measured device time in 8 us bins (the next launch's ordering key) or null
   // QP scratch when the row state does not fit LDS

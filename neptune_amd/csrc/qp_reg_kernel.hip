@@ -106,7 +106,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   int status = NEP_FAILED, L_used = 0, L_all = 0;
   // (what only the last lines need — iteration counts, the objective, 1 / rows — waits in LDS, not in registers that would be
   // spilled to scratch for the whole solve: sI[31] iterations of the last solve, sI[32] of the first, sc[sObjOut], sc[sInvMt])
-  if (tid == 0) { sI[31] = 0; sI[32] = 0; sc[sObjOut] = 0.0; }      // (written and read back by thread 0 only; a replan that never reaches a solve — K = 0 — reports zeros)
+  if (tid == 0) { sI[31] = 0; sI[32] = 0; sI[26] = 0; sc[sObjOut] = 0.0; }      // (written and read back by thread 0 only; a replan that never reaches a solve — K = 0 — reports zeros; sI[26]: sent to the redo pass)
   bool has_qc = false, z_override = false;
 
   // Line coefficients in LDS: [n1 | n2 | h][segment][SEGCAP], SEGCAP = 8 RS entries per segment whatever its line count — the
@@ -991,8 +991,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       if (!v_far && !v_move) break;
       if (n_skip > 0) {
         // lines are missing from the buckets, so the full problem cannot be posed here: the redo pass solves every LP of this
-        // replan and every row (separator_redo_kernel, then this kernel without the presolve); what is written below is overwritten
-        if (tid == 0 && ps.redo_count) { const int idx = atomicAdd(ps.redo_count, 1); ps.redo_list[idx] = slot; if (v_far) atomicAdd(ps.redo_count + 1, 1); if (v_move) atomicAdd(ps.redo_count + 2, 1); }   // ([1], [2]: by reason, for the test hook)
+        // replan and every row (separator_redo_kernel, then this kernel without the presolve); the solution written below is
+        // overwritten by that pass whatever its outcome, but the COMMIT record is not written here at all (sI[26]): if the redo
+        // solve fails the slot must keep the record it held, not this unverified trajectory marked valid
+        if (tid == 0 && ps.redo_count) { sI[26] = 1; const int idx = atomicAdd(ps.redo_count, 1); ps.redo_list[idx] = slot; if (v_far) atomicAdd(ps.redo_count + 1, 1); if (v_move) atomicAdd(ps.redo_count + 2, 1); }   // ([1], [2]: by reason, for the test hook)
         break;
       }
       for (int e = tid; e < 256; e += BS) sAccL[e] = 0.0;   // (the accumulators were borrowed: the second attempt starts from zeros again)
@@ -1046,7 +1048,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   if (ps.commit) {  // the record the agent would publish (neptune_ros.cpp:434-480); a failed replan publishes nothing (see qp_kernel)
     nep_traj_rec* cr = ps.commit + slot;
     const int own = sp.first_local + (slot % sp.n_local);
-    if (status == NEP_FAILED) {
+    if (status == NEP_FAILED || (CULL && __builtin_amdgcn_readfirstlane(sI[26]) != 0)) {
       if (ps.prev_commit) {
         const double* src = (const double*)(ps.prev_commit + (long)(slot / sp.n_local) * sp.num_agents + own);
         for (int e = tid; e < (int)(sizeof(nep_traj_rec) / sizeof(double)); e += BS) ((double*)cr)[e] = src[e];

@@ -146,6 +146,10 @@ class NativeExchange:
         """ranks that joined the communicator (ncclCommCount) — nep_comm_nranks"""
         return int(self.check(self.lib.nep_comm_nranks(self._c)))
 
+    def reserve(self, records_bytes=0, slots_bytes=0):
+        """sizes the regrouping exchanges' staging buffers ahead of a graph capture (nep_comm_reserve)"""
+        self.check(self.lib.nep_comm_reserve(self._c, int(records_bytes), int(slots_bytes)))
+
     def hulls(self, d_block, d_blocks, stream=None):
         st = stream if stream is not None else self.be.torch.cuda.current_stream(self.be.device)
         self.check(self.lib.nep_batch_exchange_hulls(self.be._h, self._c, d_block.data_ptr(), d_blocks.data_ptr(), st.cuda_stream))

@@ -999,7 +999,7 @@ def test_packed_separator_gives_the_unpacked_kernels_lines(be, n_agents, n_stati
     """separator_packed_kernel (the spatial presolve's separator: several segments of a slot per wave, LPs solved 64 to a batch
     across the segments) against separator_kernel<0> on the same launch: every line bucket (near lines in call order, parked lines
     from the end), every count and every solution byte for byte — with 1, 3 and 8 segments per wave (the host picks by launch
-    size; NEP_SEP_PACK forces one), with a candidate list far shorter than a wave (5 agents) and with entangle candidates."""
+    size; nep_batch_debug_set_separator_pack forces one), with a candidate list far shorter than a wave (5 agents) and with entangle candidates."""
     import dataclasses, os
     sc = scene.make_scene(n_agents, n_static, seed=seed)
     p = dataclasses.replace(sc["par"], enable_entangle=True) if ent else sc["par"]
@@ -1010,22 +1010,16 @@ def test_packed_separator_gives_the_unpacked_kernels_lines(be, n_agents, n_stati
     d_com = bb.to_device(sc["committed"]); d_gue = bb.to_device(sc["guesses"])
     d_ent = bb.torch.from_numpy(np.ascontiguousarray(case).reshape(-1)).to(bb.device) if ent else None
 
-    def run(env):
-        for k in ("NEP_SEP_PACK", "NEP_SEP_UNPACKED"):
-            os.environ.pop(k, None)
-        os.environ.update(env)
-        try:
-            bb.replan(d_com, d_gue, d_ent=d_ent)
-            sol = bb.solutions().copy()
-            lines = [bb.debug_lines(a, cap=4096) for a in range(N)]
-            return sol, lines, bb.redo_count()
-        finally:
-            for k in env:
-                os.environ.pop(k, None)
-    ref_sol, ref_lines, ref_redo = run({"NEP_SEP_UNPACKED": "1"})
+    def run(pack):
+        bb.set_separator_pack(pack)
+        bb.replan(d_com, d_gue, d_ent=d_ent)
+        sol = bb.solutions().copy()
+        lines = [bb.debug_lines(a, cap=4096) for a in range(N)]
+        return sol, lines, bb.redo_count()
+    ref_sol, ref_lines, ref_redo = run(-1)
     assert int(ref_sol["stats"]["n_lines"].sum()) > 0
-    for pack in ("1", "3", "8"):
-        sol, lines, redo = run({"NEP_SEP_PACK": pack})
+    for pack in (1, 3, 8):
+        sol, lines, redo = run(pack)
         assert sol.tobytes() == ref_sol.tobytes(), pack
         assert redo == ref_redo
         for a in range(N):

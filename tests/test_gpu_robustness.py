@@ -327,3 +327,67 @@ def test_next_starts_equals_the_restatement_bit_for_bit(be):
     bb.next_starts(d_com, 0.5, d_st)
     assert d_st.cpu().numpy().view(abi.FE_START_DTYPE)["goal"].tobytes() == g0.tobytes()
     bb.close()
+
+
+def test_redo_pass_that_fails_publishes_nothing(be):
+    """Round-3 advisor finding (qp_reg_kernel.hip, the presolve's redo list).  A replan the presolve cannot verify goes on the redo
+    list; its first-pass trajectory (unverified: it crosses a parked line or left the radius the skipped LPs were proven for) used
+    to be written into the commit slot as valid before the redo pass ran, and stayed there when the redo's full solve FAILED and
+    there were no previous records to copy back (nep_batch_replan with d_committed = NULL; the sharded nep_batch_replan_hulls).
+    Forced here: a 5 cm radius sends most replans to the redo list without an iteration (their unconstrained minimiser is
+    feasible for the few near rows), and a 0.1 us TimeLimit makes every solve that has to iterate fail.  A failed redo must leave
+    the commit slot exactly as the caller passed it (neptune_ros.cpp:651-663: a failed replan publishes nothing)."""
+    sc = scene.make_scene(64, 20, seed=3)
+    p = sc["par"]
+    bb = be.BatchBackend(p, sc["statics"])
+    bb.set_line_cull(0.05)
+    d_com = bb.to_device(sc["committed"]); d_gue = bb.to_device(sc["guesses"])
+    bb.replan(d_com, d_gue)                         # hulls + a first round (everything converges: no time limit yet)
+    assert bb.redo_count() > 0
+    assert (bb.solutions()["stats"]["status"] != 2).all()
+    bb.set_max_runtime(1e-7)
+    bb.d_commit.fill_(0xAB)
+    bb.replan(None, d_gue)                          # hulls reused, no previous records: prev_commit == NULL in the kernels
+    listed = set(int(s) for s in bb.redo_list())
+    sol = bb.solutions(); com = bb.commits()
+    failed_redo = [a for a in listed if int(sol[a]["stats"]["status"]) == 2]
+    assert failed_redo, "no listed replan failed its redo solve: the case this test is for did not occur"
+    for a in range(p.num_agents):
+        raw = np.frombuffer(com[a].tobytes(), dtype=np.uint8)
+        if int(sol[a]["stats"]["status"]) == 2:
+            assert (raw == 0xAB).all(), "agent %d failed (listed for redo: %s) but its commit slot was written" % (a, a in listed)
+            np.testing.assert_array_equal(np.array(sol[a]["coeff"]), np.array(sc["guesses"][a]["coeff"]))      # :856-859
+        else:
+            assert int(com[a]["valid"]) == 1
+            np.testing.assert_array_equal(np.array(com[a]["pwp"]["coeff"])[:, :8, :], np.array(sol[a]["coeff"]))
+    bb.close()
+
+
+def test_lp_skipping_is_off_for_statics_that_are_not_box_edged(be):
+    """Round-3 advisor finding (box_far, geom_kernels.hip): the spatial presolve skips the LP of an obstacle whose bounding box is
+    far, which is sound only if the box's sides are edges of the polygon (inflated statics, interval hulls).  A diamond is not:
+    its nearest edge line lies at 0.71 of the box distance.  Such a handle must solve every LP: with the presolve on, every
+    line exists (near or parked) and the optimum is the unculled one; with box-edged statics of the same scene LPs ARE skipped."""
+    sc = scene.make_scene(16, 12, seed=21)
+    p = sc["par"]
+    diamonds = []
+    for s in sc["statics"]:
+        c = s.mean(axis=0); r = np.abs(s - c).max()
+        diamonds.append(np.array([[c[0] + r, c[1]], [c[0], c[1] + r], [c[0] - r, c[1]], [c[0], c[1] - r]]))
+    n_lines = {}
+    for name, statics in (("squares", sc["statics"]), ("diamonds", diamonds)):
+        bb = be.BatchBackend(p, statics)
+        d_com = bb.to_device(sc["committed"]); d_gue = bb.to_device(sc["guesses"])
+        bb.set_line_cull(0.0)
+        bb.replan(d_com, d_gue)
+        full = bb.solutions().copy()
+        full_lines = [len(bb.debug_lines(a)[0]) for a in range(p.num_agents)]
+        bb.set_line_cull(1.0)
+        bb.replan(d_com, d_gue)
+        cul = bb.solutions().copy()
+        n_lines[name] = (sum(full_lines), sum(len(bb.debug_lines(a)[0]) for a in range(p.num_agents)))
+        np.testing.assert_array_equal(cul["stats"]["status"], full["stats"]["status"])
+        assert np.abs(np.array(cul["coeff"]) - np.array(full["coeff"])).max() < 1e-7
+        bb.close()
+    assert n_lines["diamonds"][1] == n_lines["diamonds"][0]          # nothing skipped: every line was made
+    assert n_lines["squares"][1] < n_lines["squares"][0]             # box-edged statics: far LPs never solved
