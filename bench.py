@@ -114,8 +114,19 @@ def cpu_baseline(p, scenes, budget_s=12.0):
             if time.perf_counter() - t0 > budget_s:
                 break
     dt = time.perf_counter() - t0
-    return {"value": done / dt, "unit": "replans/s", "cores": cores, "kind": "port",
-            "sample": "%d replans of the same scenes (seeds 0..), one oracle thread per core, %.1f s" % (done, dt)}
+    out = {"value": done / dt, "unit": "replans/s", "cores": cores, "kind": "port",
+           "sample": "%d replans of the same scenes (seeds 0..), one oracle thread per core, %.1f s" % (done, dt)}
+    # the reference's own solvers, where a box has them (neither is in this image: then the line says so)
+    from oracle import reference_solvers as rs
+    out["reference_solvers"] = rs.probe()
+    if rs.glpk_lib() is not None:
+        rng = np.random.default_rng(0)
+        A = rng.uniform(-1, 1, (200, 8, 2)); B = rng.uniform(-1, 1, (200, 4, 2)) + np.array([3.0, 0.0])
+        t1 = time.perf_counter()
+        for a_, b_ in zip(A, B):
+            rs.glpk_separator(a_, b_)
+        out["reference_solvers"]["glpk_us_per_lp"] = (time.perf_counter() - t1) / 200 * 1e6
+    return out
 
 
 def _config5_scene(job):
@@ -997,6 +1008,7 @@ def main():
             out["graph_notes"] = graph_notes
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(p, mine)
+            out["reference_solvers"] = out["cpu_baseline"]["reference_solvers"]
         print(json.dumps(out))
     if use_dist:
         tdist.barrier()
