@@ -143,6 +143,16 @@ def quantiles(a):
     return {"p50": float(np.percentile(a, 50)), "p90": float(np.percentile(a, 90)), "p99": float(np.percentile(a, 99)), "max": float(a.max()), "mean": float(a.mean())}
 
 
+def active_summary(be_, tol=1e-6):
+    """which replans are constrained at all: inequality rows with slack < tol at the optimum, over EVERY replan of the leg's last step
+    (nep_batch_active_rows: box rows = position / velocity / acceleration bounds, line rows = separating lines)"""
+    ar = be_.active_rows(tol)
+    nb, nl = ar[:, 0], ar[:, 1]
+    return {"sample": "every replan of the last step (%d)" % len(ar), "replans_with_active_rows_frac": float(((nb + nl) > 0).mean()),
+            "replans_with_active_line_rows_frac": float((nl > 0).mean()), "replans_with_active_box_rows_frac": float((nb > 0).mean()),
+            "active_box_rows_mean": float(nb.mean()), "active_line_rows_mean": float(nl.mean()), "tol_m": tol}
+
+
 def status_counts(sol):
     st = sol["stats"]["status"].astype(int)
     return {"status_ok": int((st == 0).sum()), "status_relaxed": int((st == 1).sum()), "status_failed": int((st == 2).sum())}
@@ -548,6 +558,7 @@ def main():
         for b in bes:
             b.enable_timing(False)
         sol = np.concatenate([b.solutions() for b in bes])
+        active = active_summary(be) if C == 1 else None          # (chunk 0's handle when the scenes are chunked: see sharding)
         solve_us = solve_us_stats(be)
         status = sol["stats"]["status"].astype(int)
         iters = sol["stats"]["iters"].astype(int)
@@ -902,21 +913,6 @@ def main():
             gbs = per_kernel_bytes[name] * launch_replans / (ms_k * 1e-3) / 1e9 if ms_k > 0 else 0.0
             per_kernel[name] = {"bytes_per_replan": per_kernel_bytes[name], "ms": ms_k, "GB/s": gbs, "frac": gbs / 8000.0}
         seq_gbs = bytes_per_replan * launch_replans / (seq_ms * 1e-3) / 1e9 if seq_ms > 0 else 0.0
-        # active inequality rows at the optimum (scene 0 of the last timed step): which replans are constrained at all
-        active = None
-        if C == 1 and not sharded_hulls and not args.no_extra_legs:
-            be.replan(d_committed, d_guess)            # (the other legs have used the handle's line buckets since)
-            sol_a = be.solutions()
-            nb_a, nl_a, n_con = [], [], 0
-            for a in range(n_local):
-                Ka = int(sol_a[a]["K"])
-                if Ka < 1:
-                    continue
-                seg_a, nd_a = be.debug_lines(a)
-                nb, nl = scene.active_rows(p, np.array(sol_a[a]["coeff"]), Ka, seg_a, nd_a)
-                nb_a.append(nb); nl_a.append(nl); n_con += 1 if (nb + nl) > 0 else 0
-            active = {"sample": "scene 0, %d replans" % len(nb_a), "replans_with_active_rows_frac": n_con / max(len(nb_a), 1),
-                      "active_box_rows_mean": float(np.mean(nb_a)), "active_line_rows_mean": float(np.mean(nl_a)), "tol_m": 1e-6}
         flops = algorithmic_flops(K8, float(sol["stats"]["n_lines"].mean()), float(hn[:, :K8][hn[:, :K8] > 0].mean()) if (hn[:, :K8] > 0).any() else 4.0, float(iters.mean()))
         fp64_ach = flops * launch_replans / (qp_ms * 1e-3) / 1e12 if qp_ms > 0 else 0.0
         fp64 = {"bound": "fp64 vector (reported next to the HBM roofline, SURVEY 8d)", "achieved": fp64_ach, "peak": 78.6, "unit": "TFLOP/s",

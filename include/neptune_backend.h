@@ -396,6 +396,10 @@ double nep_batch_get_line_cull(nep_batch_t* h);
  * violated [0] and how many moved farther than the radius [1].                                                       */
 int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason);
 int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap);    /* the listed slots (test hook) */
+/* Diagnostic ("how hard are these problems"): inequality rows of the QP (solver_gurobi_poly.cpp:433-489) whose slack at the
+ * solutions of the last nep_batch_replan* is below tol: d_out [slots][2] int32 = (box rows, separating-line rows) per slot.
+ * d_solution is what that replan wrote; the lines are the handle's own (parked ones included).  Asynchronous on `stream`.  */
+int nep_batch_active_rows(nep_batch_t* h, const nep_solution* d_solution, double tol, int32_t* d_out, void* stream);
 /* Test hook: which form of the presolve's separator the next replans launch — 0 (default) segments per wave picked from the
  * launch size, -1 the unpacked kernel (one segment per wave), 1..NEP_MAX_POL that many segments per wave.  The packed form's
  * list entries hold 8 191 candidates per segment (n_hull + N + S + 8 N with the entangle rows); larger scenes take the unpacked

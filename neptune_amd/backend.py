@@ -403,6 +403,13 @@ class BatchBackend:
             sol["stats"]["solve_us"] = 0.0
         return sol
 
+    def active_rows(self, tol=1e-6):
+        """(box rows, line rows) [slots][2] whose slack at the last replan's solutions is below tol (nep_batch_active_rows)"""
+        out = self.torch.zeros(self.slots * 2, dtype=self.torch.int32, device=self.device)
+        check(lib().nep_batch_active_rows(self._h, self.d_solution.data_ptr(), float(tol), out.data_ptr(), self.torch.cuda.current_stream(self.device).cuda_stream))
+        self.torch.cuda.synchronize(self.device)
+        return out.cpu().numpy().reshape(self.slots, 2)
+
     def states(self):
         self.torch.cuda.synchronize(self.device)
         return self.d_states.cpu().numpy().reshape(self.slots, self.par.max_states, abi.NEP_STATE_DOUBLES).copy()

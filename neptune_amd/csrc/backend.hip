@@ -1208,6 +1208,19 @@ int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* se
   return read_lines(E, (size_t)slot, NEP_MAX_POL, cap, seg, nd, n_out);
 }
 
+// Diagnostic: active inequality rows (slack < tol) at the solutions of the last nep_batch_replan*, per slot: d_out [slots][2] =
+// (box rows, separating-line rows).  Reads the handle's line buckets as that replan left them and d_solution as the caller got it.
+int nep_batch_active_rows(nep_batch_t* h, const nep_solution* d_solution, double tol, int32_t* d_out, void* stream) {
+  if (!h || !d_solution || !d_out || !(tol >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
+  Engine& E = h->eng;
+  ProblemSet ps{};
+  E.fill(ps);
+  ps.solution = const_cast<nep_solution*>(d_solution);
+  launch_active_rows(h->slots, E.sp, ps, tol, d_out, (hipStream_t)stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // development aid: per-phase shader cycles of the QP kernel (only with NEP_QP_PROFILE set at create)
 int nep_batch_debug_phase_cycles(nep_batch_t* h, int32_t slot, int64_t* out16) {
   if (!h || !out16 || slot < 0 || slot >= 2 * h->slots) return fail(NEP_E_ARG, "bad arguments");      // (the front end keeps 32 values per slot: rows 2 slot and 2 slot + 1)

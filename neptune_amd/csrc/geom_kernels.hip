@@ -2120,6 +2120,46 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
   }
 }
 
+// Diagnostic (bench.py's "how hard are these problems"): inequality rows of the spline QP (solver_gurobi_poly.cpp:433-489) whose
+// slack at the returned trajectory is below tol, per slot: out[slot] = (box rows, line rows).  One wave per slot; the lines are
+// the ones the separator left in the buckets (near ones from the front, parked ones from the back; an LP the spatial presolve
+// skipped has no line — it is farther than the radius from where the solution was verified to be).
+__global__ __launch_bounds__(64) void active_rows_kernel(SceneParams sp, ProblemSet ps, double tol, int* __restrict__ out) {
+  const int slot = blockIdx.x, lane = threadIdx.x;
+  const nep_solution* sol = ps.solution + slot;
+  const int K = sol->K;
+  __shared__ double sQ[2][NEP_MAX_POL][4];
+  int nb = 0, nl = 0;
+  if (lane < 3 * NEP_MAX_POL) {
+    const int ax = lane / NEP_MAX_POL, i = lane % NEP_MAX_POL;
+    if (i < K) {
+      const double* P = sol->coeff[ax][i];
+      double Q[4], V[3];
+      fe_pos_cps(P, sp.T_span, Q); fe_vel_cps(P, sp.T_span, V);
+      for (int k = 0; k < 4; k++) { nb += (Q[k] > sp.maxs[ax] - tol) + (Q[k] < sp.mins[ax] + tol); if (ax < 2) sQ[ax][i][k] = Q[k]; }
+      for (int k = 0; k < 3; k++) nb += fabs(V[k]) > sp.v_max - tol;
+      nb += fabs(6 * sp.T_span * P[0] + 2 * P[1]) > sp.a_max - tol;
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < K && i < NEP_MAX_POL; i++) {
+    const long o = (long)slot * NEP_MAX_POL + i;
+    const int cn = ps.line_cnt[o], cf = ps.line_far ? ps.line_far[o] : 0;
+    const double* bucket = ps.line_nd + o * sp.lines_cap * 3;
+    for (int c = lane; c < cn + cf; c += 64) {
+      const long q = c < cn ? (long)c : (long)sp.lines_cap - 1 - (c - cn);
+      const double n1 = bucket[3 * q], n2 = bucket[3 * q + 1], d = bucket[3 * q + 2];
+      if (n1 == 0.0 && n2 == 0.0 && d == 0.0) continue;      // (LP without a separating line: no rows)
+      for (int k = 0; k < 4; k++) nl += (n1 * sQ[0][i][k] + n2 * sQ[1][i][k] + d - 1.0) > -tol;
+    }
+  }
+  for (int o = 32; o; o >>= 1) { nb += __shfl_xor(nb, o); nl += __shfl_xor(nl, o); }
+  if (lane == 0) { out[2 * slot] = nb; out[2 * slot + 1] = nl; }
+}
+void launch_active_rows(int n_slots, const SceneParams& sp, const ProblemSet& ps, double tol, int* out, hipStream_t st) {
+  if (n_slots > 0) hipLaunchKernelGGL(active_rows_kernel, dim3(n_slots), dim3(64), 0, st, sp, ps, tol, out);
+}
+
 // Stand-alone batched gjk::collision (tests / nep_gjk_batch): one lane per (polygon, four points) problem.
 __global__ void gjk_explicit_kernel(int n_prob, const int* __restrict__ a_off, const double* __restrict__ a_xy, const double* __restrict__ b_xy, int* __restrict__ hit) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;

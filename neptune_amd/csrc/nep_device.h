@@ -134,6 +134,7 @@ void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start,
 void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
 void launch_separator_redo(int n_slots, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
 void launch_boxes(int n_scenes, const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
+void launch_active_rows(int n_slots, const SceneParams& sp, const ProblemSet& ps, double tol, int* out, hipStream_t st);
 void launch_separator_explicit(int n_prob, const int* a_off, const double* a_xy, const int* b_off,
                                const double* b_xy, double* nd, int* solved, int rule, hipStream_t st);
 void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
