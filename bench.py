@@ -619,6 +619,7 @@ def main():
                                   rows_solved_mean=float(sol2["stats"]["n_rows"].mean()),
                                   ipm_iters_mean=float(sol2["stats"]["iters"].mean()), ipm_iters_max=int(sol2["stats"]["iters"].max()),
                                   solved_without_iteration=int((sol2["stats"]["iters"] == 0).sum()), solve_us=solve_us_stats(be),
+                                  active_rows=active_summary(be),
                                   note="verified shortcuts, same optimum as the headline run: (1) lines farther than the radius from the guess are parked, "
                                        "checked against the solution and the QP re-solved with all of them on a violation; (2) if the minimiser of the "
                                        "cost without inequality rows satisfies every row it is the optimum (KKT with zero multipliers) and no "
@@ -628,7 +629,7 @@ def main():
 
         # ---- chain (single GPU): front-end beam search from point A and the goal, separating lines + QP on the same hulls,
         # post-solve safety check and commit — the guesses are device-made -----------------------------------------------
-        chain = moving = None
+        chain = moving = crossing = None
         if extra and not args.no_chain and C == 1:
             cfg_fe = scene.frontend_cfg(p, beam_width=args.beam)
             be.set_line_cull(args.chain_cull_radius)
@@ -661,6 +662,7 @@ def main():
                                solve_us=solve_us_stats(be), terminal_ball_rows=int(sol3["stats"]["qc_active"].sum()),
                                ipm_iters_quantiles=quantiles(sol3["stats"]["iters"]), line_cull_radius_m=args.chain_cull_radius,
                                rows_solved_mean=float(sol3["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(),
+                               active_rows=active_summary(be),
                                note="front-end beam search -> separating lines -> QP -> safety check + commit, every step; the guesses are the "
                                     "device-made lattice paths (they end at cruise speed and cut corners around obstacles), not the scene's; "
                                     "point A stays where it is, so after a few steps every step poses the same problems", **status_counts(sol3))
@@ -670,43 +672,63 @@ def main():
             # arrived swaps its goal with its starting point, so the fleets keep flying: every step poses new problems, and the
             # launch-order key of a slot is the measured time of the SAME AGENT's previous, different replan --------------
             cfg_mv = scene.frontend_cfg(p, beam_width=args.beam, pad_hold=1)
-            d_st_m = be.to_device(starts_np)
-            alt_np = np.ascontiguousarray(starts_np["pos"].reshape(S * N, 3))          # the way back: where the scene's guess started
-            d_alt = torch.from_numpy(alt_np.copy()).to(dev)
-            d_com3 = be.to_device(com); d_nxt3 = torch.empty_like(d_com3)
-            fe3, sf3 = [], []
 
-            def moving_step():
-                e0 = ev()
-                be.frontend(cfg_mv, d_com3, d_st_m, d_gfe, d_res)
-                fe3.append((e0, ev()))
-                be.replan(None, d_gfe)
-                e1 = ev()
-                be.safety_commit(d_com3, be.d_commit, d_gfe, d_nxt3, d_acc)
-                d_com3.copy_(d_nxt3)
-                be.next_starts(d_com3, p.T_span, d_st_m, d_alt, 0.5)
-                sf3.append((e1, ev()))
-            dt4, ms4, _ = run_leg(moving_step, [be], aux_steps, max(args.warmup, 2), clear=(fe3, sf3))
-            qp4, _ = be.kernel_time_ms(2); sep4, _ = be.kernel_time_ms(1)
-            be.enable_timing(False)
-            sol4 = be.solutions(); res4 = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)
-            st_now = d_st_m.cpu().numpy().view(abi.FE_START_DTYPE)
-            moved = np.hypot(*(st_now["pos"][:, :2] - starts_np.reshape(-1)["pos"][:, :2]).T)
-            swaps = int((np.abs(st_now["goal"] - starts_np.reshape(-1)["goal"]).max(axis=1) > 0).sum())
-            moving = leg_record(dt4, aux_steps, ms4,
-                                kernel_ms={"frontend_with_hulls": mean_ms(fe3), "separator": sep4, "qp": qp4, "safety_commit_next_start": mean_ms(sf3)},
-                                beam_width=args.beam, frontend_goal_reached=int((res4["status"] == 1).sum()), frontend_no_solution=int((res4["status"] == 3).sum()),
-                                ipm_iters_mean=float(sol4["stats"]["iters"].mean()), ipm_iters_max=int(sol4["stats"]["iters"].max()),
-                                lp_failed=int(sol4["stats"]["n_lp_failed"].sum()), accepted_frac=float(d_acc.float().mean().item()),
-                                K_mean=float(sol4["K"].mean()), solve_us=solve_us_stats(be),
-                                terminal_ball_rows=int(sol4["stats"]["qc_active"].sum()), lines_mean=float(sol4["stats"]["n_lines"].mean()),
-                                ipm_iters_quantiles=quantiles(sol4["stats"]["iters"]), line_cull_radius_m=args.chain_cull_radius,
-                                rows_solved_mean=float(sol4["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(),
-                                simulated_seconds=float(st_now["t_start"].max() - starts_np["t_start"].max()),
-                                displacement_m_mean=float(moved.mean()), agents_with_swapped_goal=swaps,
-                                note="closed loop on the device, one HIP graph per round: front end -> lines -> QP -> safety check + commit -> point A of "
+            def closed_loop(starts_in, com_in, note):
+                """one closed-loop leg from the given points A / goals and committed records -> (record, rerun(cull) -> record)"""
+                d_st_m = be.to_device(starts_in)
+                alt_np = np.ascontiguousarray(starts_in["pos"].reshape(S * N, 3))          # the way back: where the agent started
+                d_alt = torch.from_numpy(alt_np.copy()).to(dev)
+                d_com3 = be.to_device(com_in); d_nxt3 = torch.empty_like(d_com3)
+                fe3, sf3 = [], []
+
+                def moving_step():
+                    e0 = ev()
+                    be.frontend(cfg_mv, d_com3, d_st_m, d_gfe, d_res)
+                    fe3.append((e0, ev()))
+                    be.replan(None, d_gfe)
+                    e1 = ev()
+                    be.safety_commit(d_com3, be.d_commit, d_gfe, d_nxt3, d_acc)
+                    d_com3.copy_(d_nxt3)
+                    be.next_starts(d_com3, p.T_span, d_st_m, d_alt, 0.5)
+                    sf3.append((e1, ev()))
+
+                def run(cull):
+                    be.set_line_cull(cull)
+                    d_st_m.copy_(be.to_device(starts_in)); d_alt.copy_(torch.from_numpy(alt_np.copy()).to(dev)); d_com3.copy_(be.to_device(com_in))
+                    dt4, ms4, _ = run_leg(moving_step, [be], aux_steps, max(args.warmup, 2), clear=(fe3, sf3))
+                    qp4, _ = be.kernel_time_ms(2); sep4, _ = be.kernel_time_ms(1)
+                    be.enable_timing(False)
+                    sol4 = be.solutions(); res4 = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)
+                    st_now = d_st_m.cpu().numpy().view(abi.FE_START_DTYPE)
+                    moved = np.hypot(*(st_now["pos"][:, :2] - starts_in.reshape(-1)["pos"][:, :2]).T)
+                    swaps = int((np.abs(st_now["goal"] - starts_in.reshape(-1)["goal"]).max(axis=1) > 0).sum())
+                    return leg_record(dt4, aux_steps, ms4,
+                                      kernel_ms={"frontend_with_hulls": mean_ms(fe3), "separator": sep4, "qp": qp4, "safety_commit_next_start": mean_ms(sf3)},
+                                      beam_width=args.beam, frontend_goal_reached=int((res4["status"] == 1).sum()), frontend_no_solution=int((res4["status"] == 3).sum()),
+                                      ipm_iters_mean=float(sol4["stats"]["iters"].mean()), ipm_iters_max=int(sol4["stats"]["iters"].max()),
+                                      lp_failed=int(sol4["stats"]["n_lp_failed"].sum()), accepted_frac=float(d_acc.float().mean().item()),
+                                      K_mean=float(sol4["K"].mean()), solve_us=solve_us_stats(be),
+                                      terminal_ball_rows=int(sol4["stats"]["qc_active"].sum()), lines_mean=float(sol4["stats"]["n_lines"].mean()),
+                                      ipm_iters_quantiles=quantiles(sol4["stats"]["iters"]), line_cull_radius_m=cull,
+                                      rows_solved_mean=float(sol4["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(),
+                                      simulated_seconds=float(st_now["t_start"].max() - starts_in["t_start"].max()),
+                                      displacement_m_mean=float(moved.mean()), agents_with_swapped_goal=swaps,
+                                      failed_frac=float((sol4["stats"]["status"] == 2).mean()), active_rows=active_summary(be),
+                                      note=note, **status_counts(sol4))
+                return run
+            run_moving = closed_loop(starts_np, com,
+                                     "closed loop on the device, one HIP graph per round: front end -> lines -> QP -> safety check + commit -> point A of "
                                      "the next round 0.5 s ahead on the committed trajectory; arrived agents turn around.  Every step solves NEW problems; the "
-                                     "launch-order predictor is the same agent's previous replan", **status_counts(sol4))
+                                     "launch-order predictor is the same agent's previous replan")
+            moving = run_moving(args.chain_cull_radius)
+            # ---- crossing: the same closed loop on the hard variant of every scene — all 64 agents start at rest on the base circle
+            # and fly to the antipodal point, so the whole fleet meets in the middle (and turns around on arrival) --------------
+            cross = [scene.crossing_scene(s_) for s_ in mine]
+            run_cross = closed_loop(np.stack([c_[0] for c_ in cross]), np.stack([c_[1] for c_ in cross]),
+                                    "the closed loop of `moving` on the circle-swap variant of the same scenes: every agent starts at rest on the base circle, "
+                                    "its goal is the antipodal point (the start of the agent opposite), arrived agents turn around — the fleet crosses the middle of "
+                                    "the world together, against the scene's static obstacles.  The hard leg: see active_rows, failed_frac, ipm_iters")
+            crossing = run_cross(args.chain_cull_radius)
             # ---- both again with the verified presolve (what a deployment runs, and the handle's default at config-5 size) ----
             if args.chain_cull_radius == 0.0 and args.presolve_radius > 0.0:
                 be.set_line_cull(args.presolve_radius)
@@ -719,15 +741,8 @@ def main():
                                                     kernel_ms={"frontend_with_hulls": mean_ms(fe2), "separator": sep3p, "qp": qp3p, "safety": mean_ms(sf2)},
                                                     rows_solved_mean=float(sol3p["stats"]["n_rows"].mean()), ipm_iters_mean=float(sol3p["stats"]["iters"].mean()),
                                                     presolve_redo_last_step=be.redo_count(), **status_counts(sol3p))
-                d_st_m.copy_(be.to_device(starts_np)); d_alt.copy_(torch.from_numpy(alt_np.copy()).to(dev)); d_com3.copy_(be.to_device(com))
-                dt4p, ms4p, _ = run_leg(moving_step, [be], aux_steps, max(args.warmup, 2), clear=(fe3, sf3))
-                qp4p, _ = be.kernel_time_ms(2); sep4p, _ = be.kernel_time_ms(1)
-                be.enable_timing(False)
-                sol4p = be.solutions()
-                moving["with_presolve"] = leg_record(dt4p, aux_steps, ms4p, cull_radius_m=args.presolve_radius,
-                                                     kernel_ms={"frontend_with_hulls": mean_ms(fe3), "separator": sep4p, "qp": qp4p, "safety_commit_next_start": mean_ms(sf3)},
-                                                     rows_solved_mean=float(sol4p["stats"]["n_rows"].mean()), ipm_iters_mean=float(sol4p["stats"]["iters"].mean()),
-                                                     presolve_redo_last_step=be.redo_count(), **status_counts(sol4p))
+                moving["with_presolve"] = run_moving(args.presolve_radius)
+                crossing["with_presolve"] = run_cross(args.presolve_radius)
             be.set_line_cull(0.0)
 
         # ---- single_scene: ONE fleet -------------------------------------------------------------------------------------
@@ -748,6 +763,62 @@ def main():
                       "note": "one scene of %d agents per launch sequence: the latency of one bulk-synchronous round of a single fleet and that "
                               "fleet's throughput; `value` at the top keeps %d independent scenes in flight" % (N, S)}
             b1.close()
+
+    # ---- the other single-GPU configs of BASELINE.json (configs[1]: 5 agents obstacle-free; configs[2]: 8 agents + 20 obstacles):
+    # the batched step at those sizes, and the DROP-IN call — the per-agent handle behind include/neptune_poly_solver.hpp, what
+    # Neptune::replanCB would call once per replan (neptune.cpp:1504-1528) — timed inside the library ------------------------
+    small_configs = per_agent = None
+    if extra and rank == 0 and not args.config5_only:
+        from neptune_amd.backend import PolySolver, hulls_batch as hulls_of
+        small_configs = {}
+        for name, n_a, n_o, n_sc in (("config2_5_agents", 5, 0, 1024), ("config3_8_agents_20_obstacles", 8, 20, 512)):
+            scs = scene.make_scenes(n_a, n_o, range(n_sc), workers=min(n_sc, max(1, host_cores // 2), 64))
+            pc = scs[0]["par"]
+            bc = BatchBackend(pc, scs[0]["statics"], n_scenes=n_sc, device=dev)
+            for s_ in range(n_sc):
+                if len(scs[s_]["statics"]) != len(scs[0]["statics"]):
+                    raise SystemExit("%s: scene %d drew another number of static obstacles" % (name, s_))
+                bc.set_scene_statics(s_, scs[s_]["statics"])
+            com_c, gue_c = ndist.stack_scenes(scs)
+            d_cc = bc.to_device(com_c); d_gc = bc.to_device(gue_c)
+
+            def small_step():
+                bc.replan(d_cc, d_gc)
+                d_cc.copy_(bc.d_commit)
+            dtc, msc, _ = run_leg(small_step, [bc], aux_steps, max(args.warmup, 2))
+            kc = {n_: bc.kernel_time_ms(i_)[0] for i_, n_ in ((0, "hull"), (1, "separator"), (2, "qp"), (3, "sequence"))}
+            bc.enable_timing(False)
+            solc = bc.solutions()
+            small_configs[name] = {"value": n_a * n_sc * aux_steps / dtc, "unit": "replans/s", "steps": aux_steps, "ms_per_step": dtc / aux_steps * 1e3,
+                                   "scenes_in_flight": n_sc, "replans_per_step": n_a * n_sc, "kernel_ms": kc, "solve_us": solve_us_stats(bc),
+                                   "ipm_iters_mean": float(solc["stats"]["iters"].mean()), "lines_mean": float(solc["stats"]["n_lines"].mean()),
+                                   "active_rows": active_summary(bc), **status_counts(solc)}
+            bc.close()
+        per_agent = {"note": "the six-call drop-in sequence of ONE replan (setInitTrajectory -> setHulls -> setHullsNoInflation -> setEntStateVector -> optimize "
+                             "-> generatePwpOut, neptune.cpp:1514-1527) through the per-agent C ABI with host buffers, blocking, as a C++ caller's clock sees it "
+                             "(nep_backend_debug_time_sequence: no Python between the calls): one host-to-device copy, separator + QP kernels, one device-to-host "
+                             "copy.  The reference's budget for the same call is TimeLimit 0.05 s",
+                     "iterations_per_agent": 200}
+        for name, n_a, n_o in (("config2_5_agents", 5, 0), ("config3_8_agents_20_obstacles", 8, 20), ("config4_64_agents_20_obstacles", N, M)):
+            sc_ = scene.make_scene(n_a, n_o, seed=0) if (n_a, n_o) != (N, M) else scene0
+            pp = sc_["par"]
+            hx_, hn_, h0_, n0_ = hulls_of(sc_["committed"], 0.0, pp.num_pol, pp.T_span, pp.drone_radius)
+            us_all, uo_all, st_all = [], [], []
+            for aid in range(1, min(n_a, 4) + 1):
+                ps_ = PolySolver(pp.num_pol, 3, aid, pp.T_span, pp.pb, pp.weight, 0.5, True)
+                ps_.setMaxValues(pp.x_min, pp.x_max, pp.y_min, pp.y_max, pp.z_min, pp.z_max, pp.v_max, pp.a_max, pp.j_max)
+                ps_.setMaxRuntime(0.05); ps_.setTetherLength(pp.tether_length); ps_.setStaticObstVert(sc_["statics"])
+                g_ = sc_["guesses"][aid - 1]; K_ = int(g_["K"])
+                hl_ = [[hx_[j, i, :hn_[j, i]] for i in range(pp.num_pol)] for j in range(n_a) if j != aid - 1]
+                h0l_ = [[h0_[j, i, :n0_[j, i]] for i in range(pp.num_pol)] if j != aid - 1 else [] for j in range(n_a)]
+                ps_.timeSequence(np.arange(K_ + 1) * pp.T_span, np.array(g_["coeff"])[:, :K_, :], hl_, h0l_, dc=pp.dc, n_iter=20)      # warm
+                st_, us_, uo_ = ps_.timeSequence(np.arange(K_ + 1) * pp.T_span, np.array(g_["coeff"])[:, :K_, :], hl_, h0l_, dc=pp.dc, n_iter=200)
+                us_all.append(us_); uo_all.append(uo_); st_all.append(int(st_))
+                ps_.close()
+            us_all = np.concatenate(us_all); uo_all = np.concatenate(uo_all)
+            per_agent[name] = {"sequence_ms": {"p50": float(np.percentile(us_all, 50)) * 1e-3, "p99": float(np.percentile(us_all, 99)) * 1e-3, "max": float(us_all.max()) * 1e-3},
+                               "optimize_ms": {"p50": float(np.percentile(uo_all, 50)) * 1e-3, "p99": float(np.percentile(uo_all, 99)) * 1e-3},
+                               "agents_timed": len(st_all), "status": st_all, "hull_lists": n_a - 1}
 
     # ---- config5: BASELINE configs[4], 256 agents + 100 obstacles, enable_entangle_check on -------------------------------
     config5 = None
@@ -803,11 +874,10 @@ def main():
         ns5 = int(sol6[0]["n_states"])
         ent_b = 4.0 * 8 * N5 + 16.0 * bend5[0].sum()                # the dense case block of one replan + every agent's bend points
         bytes5 = algorithmic_bytes(p5, sc5[0], hn5, ns5, ent_bytes=ent_b)
-        ach5 = bytes5 * S5 * N5 / (k6["qp"] * 1e-3) / 1e9 if k6["qp"] > 0 else 0.0
-        seq5 = bytes5 * S5 * N5 / (k6["sequence"] * 1e-3) / 1e9 if k6["sequence"] > 0 else 0.0
         dom = max(("hull", "separator", "qp"), key=lambda n_: k6[n_])
         dom_name = {"hull": "hull_group_kernel", "separator": "separator_packed_kernel" if cull5 > 0.0 else "separator_kernel", "qp": kern5}[dom]
         ach_dom = bytes5 * S5 * N5 / (k6[dom] * 1e-3) / 1e9 if k6[dom] > 0 else 0.0
+        traffic5 = measured_traffic("nep::" + dom_name, "pmc_summary_config5_latest.txt")
         config5 = {"value": S5 * N5 * steps6 / dt6, "unit": "replans/s", "steps": steps6, "ms_per_step": dt6 / steps6 * 1e3,
                    "step_ms": {"p50": float(np.percentile(ms6, 50)), "p99": float(np.percentile(ms6, 99)), "max": float(ms6.max())},
                    "workload": "256 agents + 100 static obstacles, enable_entangle_check on (synthetic ent_state: one active case for 10 %% of the agent pairs, "
@@ -817,17 +887,16 @@ def main():
                    "lines_mean": float(sol6["stats"]["n_lines"].mean()), "rows_solved_mean": float(sol6["stats"]["n_rows"].mean()),
                    "ipm_iters_mean": float(sol6["stats"]["iters"].mean()), "ipm_iters_max": int(sol6["stats"]["iters"].max()),
                    "solved_without_iteration": int((sol6["stats"]["iters"] == 0).sum()), "lp_failed": int(sol6["stats"]["n_lp_failed"].sum()),
-                   "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": ach_dom, "peak": 8000.0, "unit": "GB/s", "frac": ach_dom / 8000.0,
-                                "algorithmic_bytes_per_replan": bytes5, "replans_per_launch": S5 * N5, "kernel_ms": k6[dom],
-                                "sequence": {"achieved": seq5, "frac": seq5 / 8000.0, "ms": k6["sequence"]},
-                                "qp_kernel": {"kernel": kern5, "ms": k6["qp"], "achieved": ach5, "frac": ach5 / 8000.0},
-                                "traffic": measured_traffic("nep::" + dom_name, "pmc_summary_config5_latest.txt"),
-                                "traffic_source": "profiles/pmc_summary_config5_latest.txt (committed rocprofv3 --pmc summary of `bench.py --config5-only`)",
-                                "note": "the replan's algorithmic bytes (SURVEY 8d: ~273 KB + the entangle inputs at this size) x replans per launch / the "
-                                        "duration of the DOMINANT kernel of this leg's sequence — here the separator, which reads every other agent's hulls; "
-                                        "`qp_kernel` prices the same bytes against the interior-point kernel as the headline's roofline does.  With the presolve the "
-                                        "separator reads a 32-byte box instead of the hull for every obstacle it skips, so the measured `traffic` is far BELOW "
-                                        "the algorithmic bytes and this fraction overstates how close the kernel is to the memory roof: it is VALU-issue bound"},
+                   "roofline": ({"bound": "hbm", "kernel": dom_name, "kernel_ms": k6[dom], "frac": None, "achieved": None, "peak": 8000.0, "unit": "GB/s",
+                                 "algorithmic_bytes_per_replan": bytes5, "replans_per_launch": S5 * N5,
+                                 "traffic": traffic5, "traffic_over_algorithmic": (traffic5 / (bytes5 * S5 * N5)) if traffic5 else None,
+                                 "traffic_source": "profiles/pmc_summary_config5_latest.txt (committed rocprofv3 --pmc summary of `bench.py --config5-only`)",
+                                 "note": "no fraction is printed for this leg: with the presolve the separator reads a 32-byte box instead of the hull of every obstacle "
+                                         "it skips, so the kernel moves a small part of the bytes SURVEY 8d prices (traffic_over_algorithmic) and bytes / time would "
+                                         "say nothing about the memory system — the kernels are VALU-issue bound.  The fractions of this size are `full_rows.roofline`"}
+                                if cull5 > 0.0 else
+                                {"bound": "hbm", "kernel": dom_name, "achieved": ach_dom, "peak": 8000.0, "unit": "GB/s", "frac": ach_dom / 8000.0,
+                                 "algorithmic_bytes_per_replan": bytes5, "replans_per_launch": S5 * N5, "kernel_ms": k6[dom]}),
                    "scene_generation_wait_s": t_wait,
                    "note": "the handle's default for this size: verified line presolve at %.1f m (lines farther from the guess are parked, checked at the "
                            "solution, re-solved with all rows on a violation), interior point on %s" % (cull5, kern5), **status_counts(sol6)}
@@ -840,6 +909,11 @@ def main():
             config5["full_rows"] = {"value": S5 * N5 * steps7 / dt7, "unit": "replans/s", "steps": steps7, "ms_per_step": dt7 / steps7 * 1e3,
                                     "qp_kernel": kern5f, "kernel_ms": k7, "solve_us": solve_us_stats(b5),
                                     "rows_solved_mean": float(sol7["stats"]["n_rows"].mean()), "ipm_iters_mean": float(sol7["stats"]["iters"].mean()),
+                                    "active_rows": active_summary(b5),
+                                    "roofline": {"bound": "hbm", "peak": 8000.0, "unit": "GB/s", "algorithmic_bytes_per_replan": bytes5, "replans_per_launch": S5 * N5,
+                                                 **{kn: {"ms": k7[kk], "achieved": bytes5 * S5 * N5 / (k7[kk] * 1e-3) / 1e9 if k7[kk] > 0 else 0.0,
+                                                         "frac": bytes5 * S5 * N5 / (k7[kk] * 1e-3) / 1e9 / 8000.0 if k7[kk] > 0 else 0.0}
+                                                    for kn, kk in (("separator_kernel", "separator"), (kern5f, "qp"))}},
                                     "note": "nep_batch_set_line_cull(0): every separating-line row through the interior point", **status_counts(sol7)}
         if not args.no_chain and not args.config5_only:
             # the whole chain at this size with the entangle check on: front end with per-node entangle states (guesses AND the
@@ -937,7 +1011,9 @@ def main():
                        "sharding": sharding,
                        "params": "reference neptune_mtlp_benchmark.yaml (T_span 0.5, num_pol 8, weight 1000, v 2, a 3)"},
             "what_value_is": "throughput of %d INDEPENDENT scenes in flight, every row through the interior point, QP workgroups ordered by the previous "
-                             "step's measured times (exact here: the same problems every step) — see launch_order_off, moving, single_scene" % S,
+                             "step's measured times (exact here: the same problems every step).  The representative figures are the closed-loop legs, "
+                             "where every step poses new problems from device-made guesses: moving %s replans/s, crossing (the whole fleet through the middle) %s "
+                             "replans/s — see also launch_order_off, single_scene, active_rows" % (S, ("%.3g" % moving["value"]) if moving else "n/a", ("%.3g" % crossing["value"]) if crossing else "n/a"),
             "solver": {"status_ok": int((status == 0).sum()), "status_relaxed": int((status == 1).sum()),
                        "status_failed": int((status == 2).sum()), "ipm_iters_mean": float(iters.mean()),
                        "ipm_iters_quantiles": {"p50": float(np.percentile(iters, 50)), "p90": float(np.percentile(iters, 90)),
@@ -987,7 +1063,10 @@ def main():
             "presolve": presolve,
             "chain": chain,
             "moving": moving,
+            "crossing": crossing,
             "single_scene": single,
+            "small_configs": small_configs,
+            "per_agent_api": per_agent,
             "config5": config5,
             "per_gpu_value": value / world,
             "per_rank": per_rank,

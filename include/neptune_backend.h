@@ -115,7 +115,8 @@ typedef struct nep_stats {
   int32_t n_rows;                 /* inequality rows of the QP                                  */
   int32_t qc_active;              /* terminal ball constraint present (solver_gurobi_poly.cpp:699) */
   double objective;               /* objective_value (solver_gurobi_poly.cpp:882)               */
-  double solve_us;                /* device time of the last optimize, microseconds             */
+  double solve_us;                /* batched handle: device time of the replan's QP workgroup; per-agent handle: wall time of
+                                     optimize() as the caller's clock sees it (neptune.cpp:1504,1528), microseconds */
 } nep_stats;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -162,6 +163,13 @@ int nep_backend_generate_pwp_out(nep_backend_t* h, double t_start, double dc, ne
                                  double* states_out, int32_t states_cap, int32_t* n_states_out);
 /* Neptune::getPlanningStats side channel (neptune.cpp:1812-1819) + solver counters.            */
 int nep_backend_get_stats(nep_backend_t* h, nep_stats* out);
+/* Measurement aid: the drop-in call sequence of one replan (neptune.cpp:1514-1527: setInitTrajectory -> setHulls ->
+ * setHullsNoInflation -> setEntStateVector -> optimize -> generatePwpOut) n_iter times from the calling thread;
+ * us_out[n_iter] = wall microseconds of each iteration, us_optimize_out (may be NULL) = of optimize() alone.  h0_off / ent may
+ * be NULL (entangle check off).  Returns the last optimize's status or < 0.                                           */
+int nep_backend_debug_time_sequence(nep_backend_t* h, const nep_pwp* init, int32_t n_obst, const int32_t* hull_off,
+                                    const double* hull_xy, const int32_t* h0_off, const double* h0_xy, const nep_ent_view* ent,
+                                    double t_start, double dc, int32_t n_iter, double* us_out, double* us_optimize_out);
 
 /* Test hook: bypass the separator and use these lines for the next optimize():
  * seg[i] in [0,K), nd[i] = (n1,n2,d) in the reference's scaling (row: n.q + d - 1 <= 0).

@@ -146,6 +146,24 @@ class PolySolver:
         check(lib().nep_backend_get_stats(self._h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in abi.nep_stats._fields_}
 
+    def timeSequence(self, times, coeff, hulls, hulls_no_inflation=None, t_start=0.0, dc=0.05, n_iter=100):
+        """measurement aid (nep_backend_debug_time_sequence): the six-call drop-in sequence of one replan n_iter times inside the
+        library, no Python between the calls -> (status, wall us per sequence [n_iter], wall us of optimize() alone [n_iter])"""
+        pw = make_pwp(times, np.asarray(coeff, dtype=np.float64))
+        off, xy = _csr([h for obs in hulls for h in obs])
+        if hulls_no_inflation is not None:
+            flat = []
+            for obs in hulls_no_inflation:
+                obs = list(obs) + [np.zeros((0, 2))] * (self.num_pol - len(obs))
+                flat += obs[:self.num_pol]
+            off0, xy0 = _csr(flat)
+        us = np.zeros(n_iter); uo = np.zeros(n_iter)
+        st = check(lib().nep_backend_debug_time_sequence(self._h, C.byref(pw), len(hulls), abi.iptr(off), abi.dptr(xy),
+                                                         abi.iptr(off0) if hulls_no_inflation is not None else None,
+                                                         abi.dptr(xy0) if hulls_no_inflation is not None else None, None,
+                                                         float(t_start), float(dc), int(n_iter), abi.dptr(us), abi.dptr(uo)))
+        return st, us, uo
+
     # ---- test hooks ----------------------------------------------------------------------------
     def debugSetLines(self, seg, nd):
         if seg is None:

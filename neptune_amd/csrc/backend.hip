@@ -5,6 +5,7 @@
 // every compute entry point returns NEP_E_HIP.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -37,6 +38,22 @@ template <class T> struct DevBuf {
     return 0;
   }
   void release() { if (p) hipFree(p); p = nullptr; n = 0; }
+};
+
+// Page-locked host memory (the per-agent handle's staging arenas: one DMA in, one out per replan).  Growth keeps the contents.
+struct PinnedArena {
+  char* p = nullptr; size_t n = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= n && p) return 0;
+    char* q = nullptr;
+    hipError_t e = hipHostMalloc((void**)&q, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { g_err = std::string("hipHostMalloc: ") + hipGetErrorString(e); return NEP_E_HIP; }
+    if (p) { std::memcpy(q, p, n); hipHostFree(p); }
+    if (bytes > n) std::memset(q + n, 0, bytes - n);
+    p = q; n = bytes;
+    return 0;
+  }
+  void release() { if (p) hipHostFree(p); p = nullptr; n = 0; }
 };
 
 constexpr size_t kLdsBudget = 150 * 1024;  // of the 160 KiB per CU
@@ -399,6 +416,27 @@ int read_lines(Engine& E, size_t slot, int n_seg, int32_t cap, int32_t* seg, dou
 // =================================================================================================
 // per-agent handle
 // =================================================================================================
+// One replan through this handle is ONE host-to-device copy, two kernels (separator, QP with generatePwpOut's samples in its
+// tail) and ONE device-to-host copy: the setters write straight into a page-locked arena whose layout the device mirrors,
+//   [guess][hull vertex counts: cap x num_pol][entangle block: cases, col(0) of the uninflated hulls, bend points][hull vertices: used],
+// (the copy ends with the vertices of the hull lists actually set; the entangle block travels only after setEntStateVector),
+// and the solution comes back together with its sampled states.  neptune.cpp:1504-1528 is the call sequence this serves.
+struct InLayout { size_t guess, nv, cas, h0xy, h0nv, bend, bendn, xy, cap_end; };
+static InLayout in_layout(int N, int np, int cap) {
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  InLayout L{};
+  size_t o = 0;
+  L.guess = o; o = up(o + sizeof(nep_guess));
+  L.nv = o; o = up(o + (size_t)cap * np * sizeof(int));
+  L.cas = o; o = up(o + (size_t)NEP_MAX_POL * N * sizeof(int));
+  L.h0xy = o; o = up(o + (size_t)N * np * 2 * sizeof(double));
+  L.h0nv = o; o = up(o + (size_t)N * np * sizeof(int));
+  L.bend = o; o = up(o + (size_t)N * kBend * 2 * sizeof(double));
+  L.bendn = o; o = up(o + (size_t)N * sizeof(int));
+  L.xy = o; o = up(o + (size_t)cap * np * kHullV * 2 * sizeof(double));
+  L.cap_end = o;
+  return L;
+}
 struct nep_backend {
   Engine eng;
   nep_backend_cfg cfg{};
@@ -407,14 +445,32 @@ struct nep_backend {
   bool have_bounds = false, have_init = false, have_hulls = false, solved = false;
   nep_guess guess{}; std::vector<double> guess_times;
   int n_obst = 0;
-  std::vector<double> h_hull_xy; std::vector<int> h_hull_nv;      // [n_obst][num_pol][16][2]
-  std::vector<double> h_hull0_xy; std::vector<int> h_hull0_nv;    // [N][num_pol][2]
-  std::vector<int> h_case; std::vector<double> h_bend; std::vector<int> h_bend_n; bool have_ent = false;
+  PinnedArena hin, hout; DevBuf<char> d_in, d_out;
+  int in_cap = 0; InLayout L{};                 // hull lists the arenas are laid out for
+  bool have_h0 = false, have_ent = false, states_fresh = false;
   int override_n = -1; std::vector<int> ov_seg; std::vector<double> ov_nd;
-  DevBuf<nep_guess> d_guess; DevBuf<nep_solution> d_sol; DevBuf<int> d_case; DevBuf<double> d_states;
   nep_solution h_sol{}; nep_stats stats{};
   hipStream_t stream = nullptr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
+  // (re)lays the input arena out for `cap` hull lists, keeping what the setters have written
+  int lay_out(int cap) {
+    const int N = cfg.num_agents, np = cfg.num_pol;
+    if (cap <= in_cap && hin.p) return 0;
+    if (cap < 8) cap = 8;
+    const InLayout nl = in_layout(N, np, cap);
+    PinnedArena fresh;
+    if (int e = fresh.ensure(nl.cap_end)) return e;
+    std::memset(fresh.p, 0, nl.cap_end);
+    if (hin.p) {
+      std::memcpy(fresh.p + nl.guess, hin.p + L.guess, sizeof(nep_guess));
+      std::memcpy(fresh.p + nl.nv, hin.p + L.nv, (size_t)in_cap * np * sizeof(int));
+      std::memcpy(fresh.p + nl.cas, hin.p + L.cas, L.xy - L.cas);                    // the whole entangle block (same sizes: they depend on N only)
+      std::memcpy(fresh.p + nl.xy, hin.p + L.xy, (size_t)in_cap * np * kHullV * 2 * sizeof(double));
+      hin.release();
+    }
+    hin = fresh; L = nl; in_cap = cap;
+    return d_in.ensure(nl.cap_end);
+  }
+  template <class T> T* in(size_t off) { return (T*)(hin.p + off); }
 };
 
 extern "C" {
@@ -437,7 +493,7 @@ nep_backend_t* nep_backend_create(const nep_backend_cfg* cfg) {
   E.sp.drone_radius = 0; E.n_scenes = 1;
   E.set_clock();
   HIPCHK_NULL(hipStreamCreate(&h->stream));
-  HIPCHK_NULL(hipEventCreate(&h->e0)); HIPCHK_NULL(hipEventCreate(&h->e1));
+  if (h->lay_out(cfg->num_agents > 8 ? cfg->num_agents : 8)) { delete h; return nullptr; }
   if (E.d_pb.ensure(h->pb.size())) { delete h; return nullptr; }
   HIPCHK_NULL(hipMemcpy(E.d_pb.p, h->pb.data(), h->pb.size() * sizeof(double), hipMemcpyHostToDevice));
   int32_t off0[1] = {0};
@@ -448,8 +504,7 @@ nep_backend_t* nep_backend_create(const nep_backend_cfg* cfg) {
 
 void nep_backend_destroy(nep_backend_t* h) {
   if (!h) return;
-  h->eng.release(); h->d_guess.release(); h->d_sol.release(); h->d_case.release(); h->d_states.release();
-  if (h->e0) hipEventDestroy(h->e0); if (h->e1) hipEventDestroy(h->e1);
+  h->eng.release(); h->d_in.release(); h->d_out.release(); h->hin.release(); h->hout.release();
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -485,20 +540,25 @@ int nep_backend_set_init_trajectory(nep_backend_t* h, const nep_pwp* p) {
   h->guess.K = p->n_seg; h->guess.t_start = 0.0;
   for (int ax = 0; ax < 3; ax++) for (int i = 0; i < p->n_seg; i++) for (int j = 0; j < 4; j++) h->guess.coeff[ax][i][j] = p->coeff[ax][i][j];
   h->guess_times.assign(p->times, p->times + p->n_seg + 1);
-  h->have_init = true; h->solved = false;
+  *h->in<nep_guess>(h->L.guess) = h->guess;
+  h->have_init = true; h->solved = false; h->states_fresh = false;
   return 0;
 }
 
 int nep_backend_set_hulls(nep_backend_t* h, int32_t n_obst, const int32_t* off, const double* xy) {
   if (!h || n_obst < 0 || (n_obst > 0 && (!off || !xy))) return fail(NEP_E_ARG, "bad hull arguments");
   const int np = h->cfg.num_pol;
-  h->h_hull_xy.assign((size_t)(n_obst > 0 ? n_obst : 1) * np * kHullV * 2, 0.0); h->h_hull_nv.assign((size_t)(n_obst > 0 ? n_obst : 1) * np, 0);
+  if (int e = h->lay_out(n_obst)) return e;
+  int* nv = h->in<int>(h->L.nv); double* hx = h->in<double>(h->L.xy);
   for (int p = 0; p < n_obst * np; p++) {
-    int c = off[p + 1] - off[p];
+    const int c = off[p + 1] - off[p];
     if (c > kHullV) return fail(NEP_E_CAP, "hull with more than NEP_HULL_MAX_V vertices");
-    h->h_hull_nv[p] = c;
-    for (int v = 0; v < c; v++) { h->h_hull_xy[((size_t)p * kHullV + v) * 2] = xy[2 * (off[p] + v)]; h->h_hull_xy[((size_t)p * kHullV + v) * 2 + 1] = xy[2 * (off[p] + v) + 1]; }
-    if (!normalize_ccw(&h->h_hull_xy[(size_t)p * kHullV * 2], c)) return fail(NEP_E_ARG, "hull polygon is not convex");
+    if (c < 0) return fail(NEP_E_ARG, "hull offsets must not decrease");
+    nv[p] = c;
+    double* q = hx + (size_t)p * kHullV * 2;
+    std::memcpy(q, xy + 2 * (size_t)off[p], (size_t)c * 2 * sizeof(double));
+    if (c < kHullV) std::memset(q + 2 * c, 0, (size_t)(kHullV - c) * 2 * sizeof(double));
+    if (!normalize_ccw(q, c)) return fail(NEP_E_ARG, "hull polygon is not convex");
   }
   h->n_obst = n_obst; h->have_hulls = true;
   return 0;
@@ -507,12 +567,14 @@ int nep_backend_set_hulls(nep_backend_t* h, int32_t n_obst, const int32_t* off, 
 int nep_backend_set_hulls_no_inflation(nep_backend_t* h, int32_t n_agents, const int32_t* off, const double* xy) {
   if (!h || n_agents != h->cfg.num_agents || !off) return fail(NEP_E_ARG, "hullsNoInflation must be indexed by agent id (num_agents lists)");
   const int np = h->cfg.num_pol;
-  h->h_hull0_xy.assign((size_t)n_agents * np * 2, 0.0); h->h_hull0_nv.assign((size_t)n_agents * np, 0);
+  double* x0 = h->in<double>(h->L.h0xy); int* n0 = h->in<int>(h->L.h0nv);
   for (int p = 0; p < n_agents * np; p++) {
-    int c = off[p + 1] - off[p];
-    h->h_hull0_nv[p] = c;
-    if (c > 0) { h->h_hull0_xy[(size_t)p * 2] = xy[2 * off[p]]; h->h_hull0_xy[(size_t)p * 2 + 1] = xy[2 * off[p] + 1]; }  // only col(0) is read (:722-734)
+    const int c = off[p + 1] - off[p];
+    n0[p] = c;
+    if (c > 0) { x0[(size_t)p * 2] = xy[2 * off[p]]; x0[(size_t)p * 2 + 1] = xy[2 * off[p] + 1]; }  // only col(0) is read (:722-734)
+    else { x0[(size_t)p * 2] = 0.0; x0[(size_t)p * 2 + 1] = 0.0; }
   }
+  h->have_h0 = true;
   return 0;
 }
 
@@ -521,21 +583,23 @@ int nep_backend_set_ent_state_vector(nep_backend_t* h, const nep_ent_view* e) {
   if (!e) { h->have_ent = false; return 0; }
   const int N = h->cfg.num_agents;
   if (e->n_active < N) return fail(NEP_E_ARG, "active_cases rows shorter than num_agents");
-  h->h_case.assign((size_t)NEP_MAX_POL * N, 0);
+  int* cas = h->in<int>(h->L.cas);
+  std::memset(cas, 0, (size_t)NEP_MAX_POL * N * sizeof(int));
   // case id of (knot i, agent j): solver_gurobi_poly.cpp:624-631 (last matching alpha wins)
   for (int i = 0; i < e->n_states && i < NEP_MAX_POL; i++)
     for (int j = 0; j < N; j++) {
       if (e->active_cases[(size_t)i * e->n_active + j] != 1) continue;
       int cid = 0;
       for (int a = e->alpha_off[i]; a < e->alpha_off[i + 1]; a++) if (e->alphas[2 * a] == j + 1) cid = e->alphas[2 * a + 1];
-      h->h_case[(size_t)i * N + j] = cid;
+      cas[(size_t)i * N + j] = cid;
     }
-  h->h_bend.assign((size_t)N * kBend * 2, 0.0); h->h_bend_n.assign(N, 0);
+  double* bend = h->in<double>(h->L.bend); int* bend_n = h->in<int>(h->L.bendn);
+  std::memset(bend, 0, (size_t)N * kBend * 2 * sizeof(double));
   for (int j = 0; j < N; j++) {
-    int nb = e->bend_off[j + 1] - e->bend_off[j];
+    const int nb = e->bend_off[j + 1] - e->bend_off[j];
     if (nb > kBend) return fail(NEP_E_CAP, "more than NEP_MAX_BEND bend points");
-    h->h_bend_n[j] = nb;
-    for (int b = 0; b < nb; b++) { h->h_bend[((size_t)j * kBend + b) * 2] = e->bend_xy[2 * (e->bend_off[j] + b)]; h->h_bend[((size_t)j * kBend + b) * 2 + 1] = e->bend_xy[2 * (e->bend_off[j] + b) + 1]; }
+    bend_n[j] = nb;
+    for (int b = 0; b < nb; b++) { bend[((size_t)j * kBend + b) * 2] = e->bend_xy[2 * (e->bend_off[j] + b)]; bend[((size_t)j * kBend + b) * 2 + 1] = e->bend_xy[2 * (e->bend_off[j] + b) + 1]; }
   }
   h->have_ent = true;
   return 0;
@@ -564,25 +628,33 @@ int nep_backend_optimize(nep_backend_t* h, double* objective_value) {
   }
   if (int e = E.size_scratch()) return e;
   if (h->override_n >= 0) E.sp.n_hull = 0;
+  const auto t_host0 = std::chrono::steady_clock::now();
   ProblemSet ps{};
   E.fill(ps);
-  if (int e = h->d_guess.ensure(1)) return e;
-  if (int e = h->d_sol.ensure(1)) return e;
-  HIPCHK(hipMemcpyAsync(h->d_guess.p, &h->guess, sizeof(nep_guess), hipMemcpyHostToDevice, h->stream));
-  ps.guess = h->d_guess.p; ps.solution = h->d_sol.p; ps.states = nullptr; ps.commit = nullptr; ps.case_id = nullptr;
-  if (h->have_hulls && h->n_obst > 0 && h->override_n < 0) {
-    HIPCHK(hipMemcpyAsync(E.d_hull_xy.p, h->h_hull_xy.data(), (size_t)h->n_obst * np * kHullV * 2 * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(E.d_hull_nv.p, h->h_hull_nv.data(), (size_t)h->n_obst * np * sizeof(int), hipMemcpyHostToDevice, h->stream));
-  }
+  const InLayout& L = h->L;
+  const bool with_hulls = h->have_hulls && h->n_obst > 0 && h->override_n < 0;
+  // one copy in: the guess, the vertex counts and — the arena's tail — the vertices of the hull lists in use; with the entangle
+  // rows the block between them goes along (one contiguous range from the start), without them the two ends travel separately
+  // only when the block in between is bigger than what it would cost to carry it
+  const size_t xy_used = with_hulls ? (size_t)h->n_obst * np * kHullV * 2 * sizeof(double) : 0;
   if (h->have_ent) {
-    if (h->h_hull0_nv.size() != (size_t)N * np) return fail(NEP_E_STATE, "setEntStateVector without setHullsNoInflation");
-    if (int e = h->d_case.ensure(h->h_case.size())) return e;
-    HIPCHK(hipMemcpyAsync(h->d_case.p, h->h_case.data(), h->h_case.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(E.d_hull0_xy.p, h->h_hull0_xy.data(), h->h_hull0_xy.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(E.d_hull0_nv.p, h->h_hull0_nv.data(), h->h_hull0_nv.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(E.d_bend_xy.p, h->h_bend.data(), h->h_bend.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(hipMemcpyAsync(E.d_bend_n.p, h->h_bend_n.data(), h->h_bend_n.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    ps.case_id = h->d_case.p;
+    if (!h->have_h0) return fail(NEP_E_STATE, "setEntStateVector without setHullsNoInflation");
+    HIPCHK(hipMemcpyAsync(h->d_in.p, h->hin.p, L.xy + xy_used, hipMemcpyHostToDevice, h->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(h->d_in.p, h->hin.p, L.cas, hipMemcpyHostToDevice, h->stream));
+    if (xy_used) HIPCHK(hipMemcpyAsync(h->d_in.p + L.xy, h->hin.p + L.xy, xy_used, hipMemcpyHostToDevice, h->stream));
+  }
+  const size_t out_states = (sizeof(nep_solution) + 255) & ~(size_t)255;
+  const size_t out_bytes = out_states + (size_t)E.sp.max_states * NEP_STATE_DOUBLES * sizeof(double);
+  if (int e = h->d_out.ensure(out_bytes)) return e;
+  if (int e = h->hout.ensure(out_bytes)) return e;
+  ps.guess = (const nep_guess*)(h->d_in.p + L.guess); ps.solution = (nep_solution*)h->d_out.p;
+  ps.states = (double*)(h->d_out.p + out_states); ps.commit = nullptr; ps.case_id = nullptr;
+  if (with_hulls) { ps.hull_xy = (double*)(h->d_in.p + L.xy); ps.hull_nv = (int*)(h->d_in.p + L.nv); }
+  if (h->have_ent) {
+    ps.case_id = (const int*)(h->d_in.p + L.cas);
+    ps.hull0_xy = (double*)(h->d_in.p + L.h0xy); ps.hull0_nv = (int*)(h->d_in.p + L.h0nv);
+    ps.bend_xy = (double*)(h->d_in.p + L.bend); ps.bend_n = (int*)(h->d_in.p + L.bendn);
   }
   ps.lines_override = 0;
   if (h->override_n >= 0) {
@@ -593,14 +665,14 @@ int nep_backend_optimize(nep_backend_t* h, double* objective_value) {
     HIPCHK(hipStreamSynchronize(h->stream));  // host vectors go out of scope
     ps.lines_override = 1;
   }
-  HIPCHK(hipEventRecord(h->e0, h->stream));
   if (int e = E.run(nullptr, 0, ps, h->stream)) return e;
-  HIPCHK(hipEventRecord(h->e1, h->stream));
-  HIPCHK(hipMemcpyAsync(&h->h_sol, h->d_sol.p, sizeof(nep_solution), hipMemcpyDeviceToHost, h->stream));
+  // one copy out: the solution and generatePwpOut's samples at the schedule's dc (the QP kernel's tail wrote them)
+  HIPCHK(hipMemcpyAsync(h->hout.p, h->d_out.p, out_bytes, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  float ms = 0; hipEventElapsedTime(&ms, h->e0, h->e1);
-  h->stats = h->h_sol.stats; h->stats.solve_us = ms * 1000.0;
-  h->solved = true;
+  h->h_sol = *(const nep_solution*)h->hout.p;
+  h->stats = h->h_sol.stats;
+  h->stats.solve_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count();   // what the caller's clock around optimize() sees (neptune.cpp:1504,1528), set-up checks excluded
+  h->solved = true; h->states_fresh = true;
   if (h->stats.status != NEP_FAILED && objective_value) *objective_value = h->stats.objective;  // :882 (untouched on failure)
   return h->stats.status;
 }
@@ -616,23 +688,65 @@ int nep_backend_generate_pwp_out(nep_backend_t* h, double t_start, double dc, ne
   const double (*co)[NEP_MAX_POL][4] = h->solved ? h->h_sol.coeff : h->guess.coeff;   // pwp_out_ = pwp_init_ until solved
   for (int ax = 0; ax < 3; ax++) for (int i = 0; i < K; i++) for (int j = 0; j < 4; j++) pwp_out->coeff[ax][i][j] = co[ax][i][j];
   if (n_states_out) *n_states_out = 0;
+  if (states_out && states_cap > 0 && h->solved && h->states_fresh && dc == h->eng.sched_dc) {
+    // the samples came back with the solution (the QP kernel's tail made them at this dc): no device work here
+    int ns = h->h_sol.n_states; if (ns > states_cap) ns = states_cap;
+    const size_t out_states = (sizeof(nep_solution) + 255) & ~(size_t)255;
+    std::memcpy(states_out, h->hout.p + out_states, (size_t)ns * NEP_STATE_DOUBLES * sizeof(double));
+    if (n_states_out) *n_states_out = ns;
+    return 0;
+  }
   if (states_out && states_cap > 0) {
     Engine& E = h->eng;
-    if (!h->solved) {  // sample the guess: stage it as the solution
-      nep_solution s{}; s.K = K; std::memcpy(s.coeff, h->guess.coeff, sizeof(s.coeff));
-      if (int e = h->d_sol.ensure(1)) return e;
-      HIPCHK(hipMemcpy(h->d_sol.p, &s, sizeof(s), hipMemcpyHostToDevice));
+    DevBuf<nep_solution> d_sol_tmp; DevBuf<double> d_states_tmp;
+    struct Rel { DevBuf<nep_solution>& a; DevBuf<double>& b; ~Rel() { a.release(); b.release(); } } rel{d_sol_tmp, d_states_tmp};
+    if (int e = d_sol_tmp.ensure(1)) return e;
+    {  // another dc than the schedule's, or no solve yet: stage the trajectory to sample (the solution, else the guess)
+      nep_solution s{}; s.K = K; std::memcpy(s.coeff, h->solved ? h->h_sol.coeff : h->guess.coeff, sizeof(s.coeff));
+      HIPCHK(hipMemcpy(d_sol_tmp.p, &s, sizeof(s), hipMemcpyHostToDevice));
     }
     int cap = (int)std::ceil(h->cfg.num_pol * h->cfg.T_span / dc) + 3;
     if (int e = E.build_schedule(dc, cap)) return e;
     int ns = E.h_sched_n[K]; if (ns > states_cap) ns = states_cap;
-    if (int e = h->d_states.ensure((size_t)cap * NEP_STATE_DOUBLES)) return e;
-    hipLaunchKernelGGL(sample_kernel, dim3((ns + 63) / 64), dim3(64), 0, h->stream, h->d_sol.p, K, E.d_sched_seg.p + (size_t)K * cap, E.d_sched_dt.p + (size_t)K * cap, ns, h->d_states.p);
-    HIPCHK(hipMemcpyAsync(states_out, h->d_states.p, (size_t)ns * NEP_STATE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (int e = d_states_tmp.ensure((size_t)cap * NEP_STATE_DOUBLES)) return e;
+    hipLaunchKernelGGL(sample_kernel, dim3((ns + 63) / 64), dim3(64), 0, h->stream, d_sol_tmp.p, K, E.d_sched_seg.p + (size_t)K * cap, E.d_sched_dt.p + (size_t)K * cap, ns, d_states_tmp.p);
+    HIPCHK(hipMemcpyAsync(states_out, d_states_tmp.p, (size_t)ns * NEP_STATE_DOUBLES * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    h->states_fresh = false;      // (the schedule now belongs to this dc: the next optimize samples at it)
     if (n_states_out) *n_states_out = ns;
   }
   return 0;
+}
+
+// Measurement aid (bench.py's per_agent_api leg): the drop-in call sequence of one replan, as Neptune::replanFull issues it
+// (neptune.cpp:1514-1527: setInitTrajectory -> setHulls -> setHullsNoInflation -> setEntStateVector -> optimize ->
+// generatePwpOut), n_iter times from one host thread with the caller's buffers; us_out[i] = wall time of iteration i as a C++
+// caller's clock around the six calls sees it, us_optimize_out[i] (may be NULL) = of optimize() alone.  h0_off / ent may be
+// NULL (entangle check off).  Returns the status of the last optimize, or < 0.
+int nep_backend_debug_time_sequence(nep_backend_t* h, const nep_pwp* init, int32_t n_obst, const int32_t* hull_off, const double* hull_xy,
+                                    const int32_t* h0_off, const double* h0_xy, const nep_ent_view* ent, double t_start, double dc,
+                                    int32_t n_iter, double* us_out, double* us_optimize_out) {
+  if (!h || !init || n_iter < 1 || !us_out) return fail(NEP_E_ARG, "bad arguments");
+  const int cap = (int)std::ceil(h->cfg.num_pol * h->cfg.T_span / dc) + 3;
+  std::vector<double> states((size_t)cap * NEP_STATE_DOUBLES);
+  nep_pwp out; int32_t ns = 0; int status = 0;
+  for (int it = 0; it < n_iter; it++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (int e = nep_backend_set_init_trajectory(h, init)) return e;
+    if (int e = nep_backend_set_hulls(h, n_obst, hull_off, hull_xy)) return e;
+    if (h0_off) if (int e = nep_backend_set_hulls_no_inflation(h, h->cfg.num_agents, h0_off, h0_xy)) return e;
+    if (int e = nep_backend_set_ent_state_vector(h, ent)) return e;
+    const auto t1 = std::chrono::steady_clock::now();
+    double obj = 0.0;
+    status = nep_backend_optimize(h, &obj);
+    if (status < 0) return status;
+    const auto t2 = std::chrono::steady_clock::now();
+    if (int e = nep_backend_generate_pwp_out(h, t_start, dc, &out, states.data(), cap, &ns)) return e;
+    const auto t3 = std::chrono::steady_clock::now();
+    us_out[it] = std::chrono::duration<double, std::micro>(t3 - t0).count();
+    if (us_optimize_out) us_optimize_out[it] = std::chrono::duration<double, std::micro>(t2 - t1).count();
+  }
+  return status;
 }
 
 int nep_backend_get_stats(nep_backend_t* h, nep_stats* out) { if (!h || !out) return fail(NEP_E_ARG, "null argument"); *out = h->stats; return 0; }

@@ -566,6 +566,28 @@ def frontend_starts(sc):
     return st
 
 
+def crossing_scene(sc, K=8):
+    """The hard variant of a scene for the closed-loop legs ("circle swap"): every agent starts at rest on the base circle
+    (neptune_ros.cpp:138-151) and its goal is the antipodal point — the start of the agent opposite — so the whole fleet
+    crosses the middle of the world at once, against the scene's own static obstacles.  -> (starts [N] FE_START_DTYPE,
+    committed [N] TRAJ_REC_DTYPE: everybody hovering at its start)."""
+    p = sc["par"]; N = p.num_agents; T = p.T_span
+    st = np.zeros(N, dtype=abi.FE_START_DTYPE)
+    com = np.zeros(N, dtype=abi.TRAJ_REC_DTYPE)
+    for a in range(N):
+        pos = np.array([sc["starts"][a][0], sc["starts"][a][1], p.goal_height])
+        st[a]["pos"] = pos; st[a]["goal"] = np.array([-pos[0], -pos[1], p.goal_height]); st[a]["t_start"] = 0.0
+        r = com[a]
+        r["id"] = a + 1; r["is_agent"] = 1; r["valid"] = 1; r["n_bend"] = 1
+        r["bbox"] = 2 * p.drone_radius
+        r["pos"] = pos
+        r["bend"][0] = p.pb[a]
+        r["pwp"]["n_seg"] = K
+        r["pwp"]["times"][:K + 1] = np.arange(K + 1) * T
+        r["pwp"]["coeff"][:, :K, 3] = pos[:, None]
+    return st, com
+
+
 def reachable_goals(sc, margin=0.4):
     """Goals of a scene with those that fall inside an inflated static obstacle (the scene generator only
     keeps the first K segments of the way clear) pushed out through the nearest face, `margin` beyond it."""

@@ -275,6 +275,46 @@ def test_per_agent_api_matches_batch(be, oracle):
     s.close()
 
 
+def test_per_agent_one_copy_in_one_copy_out(be, oracle):
+    """The per-agent handle stages its inputs in one page-locked arena (one host-to-device copy per replan) and gets the sampled
+    states back with the solution (generatePwpOut at the schedule's dc does no device work).  Checked: the samples of either path
+    equal the oracle's on the returned coefficients; a dc other than the schedule's takes the sampling kernel and the NEXT replan
+    samples at it; hull lists beyond the arena's capacity re-lay it out without losing what the other setters wrote; the measured
+    sequence (nep_backend_debug_time_sequence) returns the same status."""
+    sc = scene.make_scene(5, 3, seed=7)
+    p = sc["par"]
+    aid = 2
+    hx, hn, h0, n0 = be.hulls_batch(sc["committed"], 0.0, p.num_pol, p.T_span, p.drone_radius)
+    others = [j for j in range(5) if j != aid - 1]
+    g = sc["guesses"][aid - 1]; K = int(g["K"])
+    hulls = [[hx[j, i, :hn[j, i]] for i in range(p.num_pol)] for j in others]
+    hulls0 = [[h0[j, i, :n0[j, i]] for i in range(p.num_pol)] if j != aid - 1 else [] for j in range(5)]
+    r = oracle.replan(p, aid, sc["committed"], g, sc["statics"])
+    s = _solver(be, p, aid)
+    s.setStaticObstVert(sc["statics"])
+    times0 = np.arange(K + 1) * p.T_span; co0 = np.array(g["coeff"])[:, :K, :]
+
+    def replan(hl, dc):
+        s.setInitTrajectory(times0, co0); s.setHulls(hl); s.setHullsNoInflation(hulls0)
+        ok, _ = s.optimize()
+        return ok, s.generatePwpOut(0.0, dc)
+    ok, (_, coeff, traj) = replan(hulls, p.dc)                       # states came back with the solution
+    assert ok and np.abs(coeff - r["coeff"]).max() <= COEF_TOL
+    np.testing.assert_allclose(traj, oracle.sample(coeff, p.T_span, p.dc), rtol=0, atol=1e-12)
+    _, _, traj_b = s.generatePwpOut(0.0, 0.1)                         # another dc: the sampling kernel
+    np.testing.assert_allclose(traj_b, oracle.sample(coeff, p.T_span, 0.1), rtol=0, atol=1e-12)
+    ok, (_, coeff_c, traj_c) = replan(hulls, 0.1)                     # the next replan samples at the new dc by itself
+    np.testing.assert_array_equal(coeff_c, coeff)
+    np.testing.assert_allclose(traj_c, traj_b, rtol=0, atol=1e-12)
+    # twelve hull lists (more than the arena was laid out for): the first four as before, the rest copies far away
+    far = [[h + np.array([500.0, 500.0]) for h in hulls[k % 4]] for k in range(8)]
+    ok, (_, coeff_d, _) = replan(hulls + far, p.dc)
+    assert ok and np.abs(coeff_d - coeff).max() <= 1e-9
+    st, us, uo = s.timeSequence(times0, co0, hulls, hulls0, dc=p.dc, n_iter=20)
+    assert st == 0 and (us > 0).all() and (uo <= us).all()
+    s.close()
+
+
 def test_call_sequence_errors(be):
     from neptune_amd._lib import BackendError
     p = scene.scaled_params(2, 0)
