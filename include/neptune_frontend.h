@@ -45,7 +45,9 @@ extern "C" {
 
 #define NEP_FE_MAX_BEAM 64
 #define NEP_FE_MAX_SAMPLES 5
-#define NEP_FE_ENT_CAP 24         /* crossings kept per search node with the entangle check on (the reference prunes a
+#ifndef NEP_FE_ENT_CAP
+#define NEP_FE_ENT_CAP 24
+#endif                            /* crossings kept per search node with the entangle check on (the reference prunes a
                                      node at num_agents + statics crossings; one that would exceed this capacity is
                                      pruned too and reported in nep_fe_result.ent_overflow)                          */
 

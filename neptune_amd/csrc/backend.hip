@@ -103,7 +103,7 @@ struct Engine {
   DevBuf<int> d_flags;
   // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
   DevBuf<double> d_sampled, d_srep, d_slong; DevBuf<int> d_present, d_entangles;
-  DevBuf<nep_fe_ent_state> d_fe_nodes, d_fe_work, d_fe_saved; DevBuf<double> d_fe_arc; bool have_reps = false;
+  DevBuf<nep_fe_ent_state> d_fe_nodes, d_fe_work, d_fe_saved; DevBuf<double> d_fe_arc, d_fe_packed; bool have_reps = false;
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
@@ -366,7 +366,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_box.release();
-    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release();
+    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release();
     d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
@@ -1070,6 +1070,20 @@ int nep_batch_set_static_reps(nep_batch_t* h, int32_t scene, const double* rep, 
   return 0;
 }
 
+// scratch of the entangle-aware front end: what every surviving child arrived with (kept for the depth's installs: the winners are
+// not propagated twice) and the packed per-(agent, interval) records of the entangle check
+static int fe_ent_scratch(nep_batch* h, const nep_fe_cfg& cfg, FeEntArgs& ea) {
+  Engine& E = h->eng;
+  const size_t cap = frontend_children_cap(cfg, h->cfg.num_pol);
+  if (int e = E.d_fe_saved.ensure((size_t)h->slots * cap)) return e;
+  if (int e = E.d_fe_arc.ensure((size_t)h->slots * cap)) return e;
+  ea.saved = E.d_fe_saved.p; ea.saved_arc = E.d_fe_arc.p;
+  ea.pk_stride = 2 + 2 * kBend + 2 * (ea.ns + 1);      // (kEntPkHead + the samples: an even number of doubles)
+  if (int e = E.d_fe_packed.ensure((size_t)h->cfg.n_scenes * h->cfg.num_agents * h->cfg.num_pol * ea.pk_stride)) return e;
+  ea.packed = E.d_fe_packed.p;
+  return 0;
+}
+
 int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed, const nep_fe_start* d_start,
                            const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result, int32_t* d_case_out, void* stream) {
   if (!h || !cfg || !d_committed || !d_start || !d_guess) return fail(NEP_E_ARG, "null argument");
@@ -1084,12 +1098,7 @@ int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj
   FeEntArgs ea{};
   if (int e = ent_prepare(h, cfg->ent_samples, cfg->beam_width, d_committed, &d_start->t_start, (long)sizeof(nep_fe_start) * E.sp.n_local, ea, (hipStream_t)stream)) return e;
   ea.init = d_ent_init; ea.case_out = d_case_out;
-  {   // what every surviving child arrived with, kept for the depth's installs (the winners are not propagated twice)
-    const size_t cap = frontend_children_cap(*cfg, h->cfg.num_pol);
-    if (int e = E.d_fe_saved.ensure((size_t)h->slots * cap)) return e;
-    if (int e = E.d_fe_arc.ensure((size_t)h->slots * cap)) return e;
-    ea.saved = E.d_fe_saved.p; ea.saved_arc = E.d_fe_arc.p;
-  }
+  if (int e = fe_ent_scratch(h, *cfg, ea)) return e;
   launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;
@@ -1120,12 +1129,7 @@ int nep_batch_frontend_ent_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const vo
   ea.sampled = (const double*)((const char*)d_blocks + b.samp); ea.present = (const int*)((const char*)d_blocks + b.present);
   ea.srep = E.d_srep.p; ea.slong = E.d_slong.p; ea.nodes = E.d_fe_nodes.p; ea.work = E.d_fe_work.p; ea.ns = h->ent_ns;
   ea.init = d_ent_init; ea.case_out = d_case_out;
-  {   // what every surviving child arrived with, kept for the depth's installs (the winners are not propagated twice)
-    const size_t cap = frontend_children_cap(*cfg, h->cfg.num_pol);
-    if (int e = E.d_fe_saved.ensure((size_t)h->slots * cap)) return e;
-    if (int e = E.d_fe_arc.ensure((size_t)h->slots * cap)) return e;
-    ea.saved = E.d_fe_saved.p; ea.saved_arc = E.d_fe_arc.p;
-  }
+  if (int e = fe_ent_scratch(h, *cfg, ea)) return e;
   launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream);
   HIPCHK(hipGetLastError());
   return 0;

@@ -26,11 +26,17 @@ struct EntCtx {
   // Optional (front end): bit i set = agent i / static i MAY add a crossing for the step at hand; a clear bit is a proof that it
   // cannot (frontend_kernel's per-parent masks).  nullptr: everybody is examined.
   const unsigned* m_agent = nullptr; const unsigned* m_static = nullptr;
+  // Optional (front end): what the entangle check reads of agent j in interval i, packed into one record (ent_pack_kernel):
+  // [present, bend count | 8 bend points | ns + 1 samples], pk_stride doubles apart — one round trip instead of a chain of four
+  const double* packed = nullptr; int pk_stride = 0;
   long long* prof = nullptr;      // (NEP_PROFILE_PHASES builds: seven per-search accumulators, see scripts/fe_ent_phases.py)
 };
 struct Ev2 { double x, y; };
 constexpr int kEntAddCap = 32;
-struct EntAdd { short id[kEntAddCap]; signed char cs[kEntAddCap]; signed char nb[kEntAddCap]; int n, overflow; };      // (nb: the crossed agent's bend-point count, known where the crossing is found — the merge needs it)
+template <int CAP> struct EntAddT { static constexpr int cap = CAP; short id[CAP]; signed char cs[CAP]; signed char nb[CAP]; int n, overflow; };      // (nb: the crossed agent's bend-point count, known where the crossing is found — the merge needs it)
+typedef EntAddT<kEntAddCap> EntAdd;
+constexpr int kEntPkHead = 2 + 2 * kBend;      // doubles of a packed record before the samples: [present, bend count | pad] [8 bend points] (everything 16-byte aligned)
+constexpr int kEntPkBend = 2;
 
 __device__ __forceinline__ Ev2 ent_pb(const EntCtx& c, int j) { return Ev2{c.pb[2 * j], c.pb[2 * j + 1]}; }
 __device__ __forceinline__ Ev2 ent_srep(const EntCtx& c, int s, int col) { return Ev2{c.srep[(s * 2 + col) * 2], c.srep[(s * 2 + col) * 2 + 1]}; }
@@ -42,7 +48,7 @@ __device__ __forceinline__ double ent_wedge(Ev2 a, Ev2 b, Ev2 cc) { return (b.x 
 __device__ __forceinline__ double ent_wedge2(Ev2 a, Ev2 b, Ev2 cc, Ev2& ab, Ev2& ac) { ab.x = b.x - a.x; ab.y = b.y - a.y; ac.x = cc.x - a.x; ac.y = cc.y - a.y; return ab.x * ac.y - ac.x * ab.y; }
 __device__ __forceinline__ double ent_ratio(Ev2 u, Ev2 v) { return fabs(u.y * v.y) > fabs(u.x * v.x) ? u.y / v.y : u.x / v.x; }
 __device__ __forceinline__ double ent_dist(Ev2 a, Ev2 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
-__device__ __forceinline__ void ent_push(EntAdd& a, int id, int cs, int nb = 0) { if (a.n < kEntAddCap) { a.id[a.n] = (short)id; a.cs[a.n] = (signed char)cs; a.nb[a.n] = (signed char)nb; a.n++; } else a.overflow = 1; }
+template <class A> __device__ __forceinline__ void ent_push(A& a, int id, int cs, int nb = 0) { if (a.n < A::cap) { a.id[a.n] = (short)id; a.cs[a.n] = (signed char)cs; a.nb[a.n] = (signed char)nb; a.n++; } else a.overflow = 1; }
 
 // ---- proofs that an obstacle adds no crossing for ANY sampled step inside a box (frontend_kernel's per-parent masks,
 // ent_check_kernel's per-trajectory mask).  A step p_k -> p_k1 adds a crossing with a tether segment only if the two points lie
@@ -81,9 +87,35 @@ __device__ bool ent_agent_may_cross(const EntCtx& c, const EntBox& q, int j, int
   }
   return maybe;
 }
+// the same proof from the packed record (front end): every load is independent of the others
+__device__ __forceinline__ const double* ent_rec(const EntCtx& c, int j, int interval) { return c.packed + (((long)c.scene * c.N + j) * c.num_pol + interval) * c.pk_stride; }
+__device__ bool ent_agent_may_cross_pk(const EntCtx& c, const EntBox& q, int j, int interval) {      // (j != own)
+  const double* r = ent_rec(c, j, interval);
+  const int2 hd = *(const int2*)r;
+  if (!hd.x) return false;
+  const int nbj = hd.y;
+  const double* bp = r + kEntPkBend; const double* sm = r + kEntPkHead;
+  const Ev2 pb_self = ent_pb(c, c.own);
+  bool maybe = false;
+  for (int k = 0; k + 1 < nbj; k++) maybe |= ent_side(q, Ev2{bp[2 * (k + 1)], bp[2 * (k + 1) + 1]}, Ev2{bp[2 * k], bp[2 * k + 1]}) == 0;
+  if (nbj >= 1) {
+    const Ev2 bk{bp[2 * (nbj - 1)], bp[2 * (nbj - 1) + 1]};
+    Ev2 pik{sm[0], sm[1]};
+    const int s0 = ent_side(q, pik, bk);
+    maybe |= s0 == 0;
+    for (int jj = 1; jj <= c.ns; jj++) {
+      const Ev2 pik1{sm[2 * jj], sm[2 * jj + 1]};
+      maybe |= ent_side(q, pik1, bk) != s0;
+      const double f1 = ent_wedge(pb_self, pik, bk), f2 = ent_wedge(pb_self, pik1, bk);
+      maybe |= f1 * f2 < 0;
+      pik = pik1;
+    }
+  }
+  return maybe;
+}
 __device__ __forceinline__ bool ent_static_may_cross(const EntCtx& c, const EntBox& q, int s) { return ent_side(q, ent_srep(c, s, 1), ent_srep(c, s, 0)) == 0; }
 
-__device__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id) {
+template <class A> __device__ void ent_cross_agent(A& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id) {
   bool base_addition = false;
   for (int k = 0; k < nb; k++) {
     const bool last = k == nb - 1;
@@ -126,7 +158,7 @@ __device__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, const EntCtx& c) 
   }
 }
 __device__ __forceinline__ Ev2 ent_anchor(int id, int cs, const EntCtx& c) { return id <= c.N ? ent_pb(c, id - 1) : ent_srep(c, id - c.N - 1, cs); }
-__device__ Ev2 ent_cur_bend(const nep_fe_ent_state* st, Ev2 pb_self, const EntCtx& c) {
+template <class ST> __device__ Ev2 ent_cur_bend(const ST* st, Ev2 pb_self, const EntCtx& c) {
   if (st->n_bend == 0) return pb_self;
   const int b = st->bend[st->n_bend - 1];
   const int id = st->id[b], cs = st->cs[b];
@@ -140,12 +172,12 @@ __device__ __forceinline__ bool ent_scan_stops(int t_id, int t_cs, int l_id, int
   if (t_id <= c.N) return false;
   return l_id > c.N || j <= last_bend;
 }
-__device__ void ent_erase(nep_fe_ent_state* st, int j) {
+template <class ST> __device__ void ent_erase(ST* st, int j) {
   for (int k = j; k + 1 < st->n_alpha; k++) { st->id[k] = st->id[k + 1]; st->cs[k] = st->cs[k + 1]; st->beta[k] = st->beta[k + 1]; }
   st->n_alpha--;
 }
 __device__ int ent_bend_n(const EntCtx& c, int j) { const HullRef hr = hull_ref(*c.ps, c.n_hull, c.scene, j); return blk(c.ps->bend_n, hr.boff)[hr.e]; }
-__device__ bool ent_merge(EntAdd& add, nep_fe_ent_state* st, Ev2 pk, Ev2 pb_self, const EntCtx& c) {
+template <class ST> __device__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 pb_self, const EntCtx& c) {
   bool again = true;
   while (again) {
     again = false;
@@ -188,7 +220,7 @@ __device__ bool ent_merge(EntAdd& add, nep_fe_ent_state* st, Ev2 pk, Ev2 pb_self
   }
   return false;
 }
-__device__ bool ent_update_bends(nep_fe_ent_state* st, Ev2 pk1, Ev2 pb_self, const EntCtx& c) {
+template <class ST> __device__ bool ent_update_bends(ST* st, Ev2 pk1, Ev2 pb_self, const EntCtx& c) {
   const Ev2 bp = ent_cur_bend(st, pb_self, c);
   int idx_new = -1;
   const int start = st->n_bend ? st->bend[st->n_bend - 1] : -1;
@@ -211,7 +243,7 @@ __device__ bool ent_update_bends(nep_fe_ent_state* st, Ev2 pk1, Ev2 pb_self, con
   }
   return false;
 }
-__device__ double ent_tether(const nep_fe_ent_state* st, Ev2 from, Ev2 pk1, const EntCtx& c) {
+template <class ST> __device__ double ent_tether(const ST* st, Ev2 from, Ev2 pk1, const EntCtx& c) {
   double len = 0.0;
   for (int q = 0; q < st->n_bend; q++) {
     const int b = st->bend[q]; const int id = st->id[b], cs = st->cs[b];
@@ -222,15 +254,15 @@ __device__ double ent_tether(const nep_fe_ent_state* st, Ev2 from, Ev2 pk1, cons
   }
   return len + ent_dist(pk1, from);
 }
-__device__ __forceinline__ int ent_count(const short* ids, int n, int id) { int k = 0; for (int i = 0; i < n; i++) k += ids[i] == id; return k; }
+template <class P> __device__ __forceinline__ int ent_count(P ids, int n, int id) { int k = 0; for (int i = 0; i < n; i++) k += ids[i] == id; return k; }
 
 // 0: fine; 1: the reference's function returns true (prune); 2: capacity exceeded (pruned, flagged)
-__device__ int ent_propagate(const EntCtx& c, nep_fe_ent_state* st, const double* cxo, const double* cyo, Ev2 end, int index, double& arc, bool check_tether, int cap_mult) {
+template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const double* cxo, const double* cyo, Ev2 end, int index, double& arc, bool check_tether, int cap_mult) {
   const int ns = c.ns;
   const Ev2 pb_self = ent_pb(c, c.own);
   Ev2 pk{cxo[3], cyo[3]}, pk1 = pk;
 #ifdef NEP_PROFILE_PHASES
-  long long pt[5] = {0, 0, 0, 0, 0}; long long pl = clock64(); int p_add = 0;
+  long long pt[5] = {0, 0, 0, 0, 0}; long long pl = clock64(); int p_add = 0, p_chg = 0;
 #define ENT_PT(k) do { const long long t_ = clock64(); pt[k] += t_ - pl; pl = t_; } while (0)
 #else
 #define ENT_PT(k) do { } while (0)
@@ -244,6 +276,32 @@ __device__ int ent_propagate(const EntCtx& c, nep_fe_ent_state* st, const double
       pk1.x = ((cxo[0] * t3 + cxo[1] * t2) + cxo[2] * t) + cxo[3] * 1.0; pk1.y = ((cyo[0] * t3 + cyo[1] * t2) + cyo[2] * t) + cyo[3] * 1.0;
     } else pk1 = end;
     arc += ent_dist(pk1, pk);
+    if (c.packed) {
+      // front end: the candidates of this parent in index order (set bits of its mask), one packed record per (agent, interval);
+      // the NEXT candidate's header and samples are requested before the current one is worked on (the loop is bound by that
+      // round trip, not by the four wedges of a crossing test)
+      const int itv = index > c.num_pol ? c.num_pol - 1 : index - 1;
+      const int jl = index > c.num_pol ? ns : j - 1, jr = index > c.num_pol ? ns : j;
+      const int MWn = (c.N + 31) >> 5;
+      auto next_cand = [&](int from) -> int {
+        for (int w = from >> 5; w < MWn; w++) {
+          unsigned m = c.m_agent ? c.m_agent[w] : ~0u;
+          if (w == (from >> 5)) m &= ~0u << (from & 31);
+          if (m) { const int i = (w << 5) + __ffs(m) - 1; return i < c.N ? i : c.N; }
+        }
+        return c.N;
+      };
+      int i = next_cand(0);
+      const double* r = ent_rec(c, i < c.N ? i : 0, itv);
+      int2 hd = *(const int2*)r; double2 sa = *(const double2*)(r + kEntPkHead + 2 * jl), sb = *(const double2*)(r + kEntPkHead + 2 * jr);
+      while (i < c.N) {
+        const int in = next_cand(i + 1);
+        const double* rn = ent_rec(c, in < c.N ? in : 0, itv);
+        const int2 hdn = *(const int2*)rn; const double2 san = *(const double2*)(rn + kEntPkHead + 2 * jl), sbn = *(const double2*)(rn + kEntPkHead + 2 * jr);
+        if (i != c.own && hd.x) ent_cross_agent(add, pk, pk1, Ev2{sa.x, sa.y}, Ev2{sb.x, sb.y}, pb_self, hd.y, r + kEntPkBend, i + 1);
+        i = in; r = rn; hd = hdn; sa = san; sb = sbn;
+      }
+    } else
     for (int i = 0; i < c.N; i++) {
       if (c.m_agent && !((c.m_agent[i >> 5] >> (i & 31)) & 1u)) { i |= 31 * !c.m_agent[i >> 5]; continue; }      // (an empty word is skipped whole)
       if (i == c.own) continue;
@@ -278,19 +336,51 @@ __device__ int ent_propagate(const EntCtx& c, nep_fe_ent_state* st, const double
       }
     }
     ENT_PT(2);
+#ifdef NEP_PROFILE_PHASES
+    const int nb_before_ = st->n_bend, lb_before_ = st->n_bend ? st->bend[st->n_bend - 1] : -1;
+#endif
     if (ent_update_bends(st, pk1, pb_self, c)) return 2;
+#ifdef NEP_PROFILE_PHASES
+    p_chg |= (add.n > 0) | (st->n_bend != nb_before_) | ((st->n_bend ? st->bend[st->n_bend - 1] : -1) != lb_before_);
+#endif
     ENT_PT(3);
     pk = pk1;
   }
   const bool too_long = check_tether && ent_tether(st, pb_self, pk1, c) > c.cable;
   ENT_PT(4);
 #ifdef NEP_PROFILE_PHASES
-  if (c.prof) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)c.prof + k, (unsigned long long)pt[k]); atomicAdd((unsigned long long*)c.prof + 5, 1ull); atomicAdd((unsigned long long*)c.prof + 6, (unsigned long long)p_add); }
+  if (c.prof) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)c.prof + k, (unsigned long long)pt[k]); atomicAdd((unsigned long long*)c.prof + 5, 1ull); atomicAdd((unsigned long long*)c.prof + 6, (unsigned long long)p_add);
+    atomicAdd((unsigned long long*)c.prof + 7, (unsigned long long)(p_chg != 0)); atomicMax((unsigned long long*)c.prof + 8, (unsigned long long)st->n_alpha); atomicAdd((unsigned long long*)c.prof + 9, (unsigned long long)st->n_alpha); }
 #endif
   if (too_long) return 1;
   return 0;
 }
-__device__ unsigned ent_iz(const nep_fe_ent_state* st) {
+// A search node's state while its child is being merged (front end, phase two): the crossing list's ids and cases and the bend
+// indices in LDS (the list surgery scans and shifts them: a chain of dependent reads), the betas — written when an entry is
+// added or re-anchored, read once per step — in the thread's global working record.  Same member names as nep_fe_ent_state: the
+// surgery code is a template over the two.
+typedef __attribute__((address_space(3))) short* ent_lds_short;
+typedef __attribute__((address_space(3))) signed char* ent_lds_char;
+struct EntLds { int n_alpha, n_bend; ent_lds_short id; ent_lds_char cs; double* beta; ent_lds_char bend; };
+constexpr int kEntLdsBytes = ((NEP_FE_ENT_CAP * 3 + NEP_MAX_BEND + 3) & ~3) | 4;      // per thread; an odd number of dwords, so that the threads' lists fall into different banks
+__device__ __forceinline__ void ent_lds_load(EntLds& L, const nep_fe_ent_state* __restrict__ src) {
+  L.n_alpha = src->n_alpha; L.n_bend = src->n_bend;
+#pragma unroll
+  for (int i = 0; i < NEP_FE_ENT_CAP; i++) { L.id[i] = src->id[i]; L.cs[i] = src->cs[i]; }
+#pragma unroll
+  for (int i = 0; i < NEP_MAX_BEND; i++) L.bend[i] = src->bend[i];
+  for (int i = 0; i < L.n_alpha; i++) L.beta[i] = src->beta[i];
+}
+__device__ __forceinline__ void ent_lds_store(nep_fe_ent_state* __restrict__ dst, const EntLds& L) {
+  dst->n_alpha = L.n_alpha; dst->n_bend = L.n_bend;
+#pragma unroll
+  for (int i = 0; i < NEP_FE_ENT_CAP; i++) { dst->id[i] = L.id[i]; dst->cs[i] = L.cs[i]; }
+#pragma unroll
+  for (int i = 0; i < NEP_MAX_BEND; i++) dst->bend[i] = L.bend[i];
+  for (int i = 0; i < L.n_alpha; i++) dst->beta[i] = L.beta[i];
+}
+
+template <class ST> __device__ unsigned ent_iz(const ST* st) {
   unsigned iz = 0;
   for (int i = 0; i < st->n_alpha; i++) {
     unsigned base = (unsigned)st->id[i], ex = (unsigned)st->cs[i], r;

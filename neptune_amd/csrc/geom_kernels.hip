@@ -1681,6 +1681,26 @@ void launch_boxes(int n_scenes, const SceneParams& sp, const ProblemSet& ps, hip
   if (nb > 0) hipLaunchKernelGGL(fe_box_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, st, sp, ps, n_scenes);
 }
 
+// What the entangle check reads of agent j in interval i — does its trajectory exist, its tether's bend points, its ns + 1 samples of
+// the interval — gathered from the hull data (one array or all-gathered blocks: hull_ref) into ONE record per (scene, agent,
+// interval): the front end's proofs and its crossing detection visit an agent with a single round trip, every load independent.
+__global__ __launch_bounds__(256) void ent_pack_kernel(SceneParams sp, ProblemSet ps, FeEntArgs ea, int n_scenes) {
+  const int N = sp.num_agents, D = sp.num_pol, ns = ea.ns;
+  const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (long)n_scenes * N * D) return;
+  const int i = (int)(t % D); const long r = t / D;
+  const int j = (int)(r % N), scene = (int)(r / N);
+  const HullRef hr = hull_ref(ps, sp.n_hull, scene, j);
+  double* o = ea.packed + t * ea.pk_stride;
+  const int present = blk(ea.present, hr.boff)[hr.e], nb = blk(ps.bend_n, hr.boff)[hr.e];
+  *(int2*)o = int2{present, nb};
+  const double* bp = blk(ps.bend_xy, hr.boff) + hr.e * kBend * 2;
+  o[1] = 0.0;
+  for (int k = 0; k < 2 * kBend; k++) o[kEntPkBend + k] = k < 2 * nb ? bp[k] : 0.0;
+  const double* sm = blk(ea.sampled, hr.boff) + ((hr.e * D + i) * (ns + 1)) * 2;
+  for (int k = 0; k < 2 * (ns + 1); k++) o[kEntPkHead + k] = sm[k];
+}
+
 #ifndef NEP_FE_ENT_WGS
 #define NEP_FE_ENT_WGS 2      // workgroups per CU of the entangle instantiation: 2 = working records in global memory, registers bounded to 256 (19.9 ms per 2 048 config-5 searches); 1 = working records in LDS, 139 KB (27.4 ms: the list surgery is latency-bound, a second workgroup hides more than LDS saves)
 #endif
@@ -1720,6 +1740,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
   const double bx = ps.pb[2 * own], by = ps.pb[2 * own + 1];
   EntCtx ec;
   nep_fe_ent_state* my_work = nullptr;
+  unsigned char* ent_lists = nullptr;
   unsigned char* b_valid = (unsigned char*)(p_comb + (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM);   // [64] may a plan end at this rank
   auto ent_node = [&](int d, int r) -> nep_fe_ent_state* { return ea.nodes + (((long)slot * (D + 1) + d) * W + r); };
   // ENT: per parent of the depth at hand, who can matter to ANY of its children (bit sets over the agents / statics; filled next
@@ -1733,9 +1754,13 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
     ec.sampled = ea.sampled; ec.present = ea.present;
     ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
+    ec.packed = ea.packed; ec.pk_stride = ea.pk_stride;
 #ifdef NEP_PROFILE_PHASES
     ec.prof = ps.dbg ? ps.dbg + (long)slot * 32 + 16 : nullptr;
 #endif
+    // the crossing lists of the children being merged (phase two of the propagation pass) live where the shortlist's boxes and
+    // vertices are: those are dead between a depth's GJK pass and the next depth's shortlist
+    ent_lists = (unsigned char*)o_aabb;      // [n_merge][kEntLdsBytes]
     my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(m_stat + NEP_FE_MAX_BEAM * SW) + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
     if (tid == 0) {
       nep_fe_ent_state* root = ent_node(0, 0);
@@ -1865,7 +1890,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
             const double dx = fmax(fmax(bx.x0 - pbx, pbx - bx.x1), 0.0), dy = fmax(fmax(bx.y0 - pby, pby - bx.y1), 0.0);
             if (sqrt(dx * dx + dy * dy) <= safe_dist + 1e-6) atomicOr(&m_base[q * MW + (j >> 5)], 1u << (j & 31));
           }
-          if (ent_agent_may_cross(ec, bx, j, idx)) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
+          if (ent_agent_may_cross_pk(ec, bx, j, idx)) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
         } else {
           const int sj = j - N;
           if (ent_static_may_cross(ec, bx, sj)) atomicOr(&m_stat[q * SW + (sj >> 5)], 1u << (sj & 31));
@@ -1882,8 +1907,22 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     //      happened to draw crowded children ----
     const int n_c = nb_prev * NC;
     if (tid == 0) s_i[1] = 0;                              // (the winners' counter: last read in the previous depth's rank phase)
+    // ENT: settling a collision-free child is split in two.  Part one (here, by whoever examined the child) is the base-square test;
+    // a survivor goes on the propagation list (p_list, in r_f's storage: free until the winners are compacted).  Part two — copy
+    // of the parent's entangle state, entanglesWithOtherAgents, the voxel — runs after a barrier over that DENSE list, one
+    // survivor per thread: the propagation is two orders of magnitude dearer than anything else a child costs and only a fifth of
+    // the children reach it, so examined in place the threads that drew two or three survivors kept the others waiting (pass 1 was
+    // 65 % of a config-5 search, its critical path three propagations per depth instead of one).
+    unsigned short* p_list = (unsigned short*)r_f;
+    auto settle_voxel = [&](int id, FeChild& ch, unsigned iz) {
+      const long long vox = ENT ? (long long)(((unsigned long long)(unsigned short)ch.vx << 48) | ((unsigned long long)(unsigned short)ch.vy << 32) | iz)
+                                : (((long long)ch.vx << 32) | (unsigned int)ch.vy);
+      bool seen = false;
+      for (unsigned h = fe_hash(vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long k = v_key[h]; if (k == (unsigned long long)vox) { seen = true; break; } if (k == kFeEmpty) break; }
+      if (!seen) { s_f[id] = ch.f; s_vox[id] = vox; }
+      s_state[id] = seen ? 0 : 1;
+    };
     auto settle = [&](int id, FeChild& ch) {       // collision free: closed voxel?  else alive
-      unsigned iz = 0;
       if constexpr (ENT) {
         {   // collidesWithBases2d: the other agents' 0.7 m base squares within 2 T v_max of the first control point
           FE_ENT_T0();
@@ -1904,24 +1943,33 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
           FE_ENT_T(0);
         }
         my_free++;
-        const int pr_ = id / NC;
-        { FE_ENT_T0(); ent_copy(my_work, ent_node(depth - 1, depth == 1 ? 0 : pr_)); FE_ENT_T(1); }
-        double arc = 0.0;
-        ec.m_agent = m_ent + pr_ * MW; ec.m_static = m_stat + pr_ * SW;
-        int rc;
-        { FE_ENT_T0(); rc = ent_propagate(ec, my_work, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
-        if (rc) { my_entangled++; if (rc == 2) my_overflow = 1; s_state[id] = 0; return; }
-        ent_copy(ea.saved + ((long)slot * kFeCap + id), my_work); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
-        ch.g = b_g[prv * NEP_FE_MAX_BEAM + pr_] + arc;
-        ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)my_work->n_alpha) + 1.0 * (double)my_work->n_bend);
-        iz = ent_iz(my_work);
-      } else my_free++;
-      const long long vox = ENT ? (long long)(((unsigned long long)(unsigned short)ch.vx << 48) | ((unsigned long long)(unsigned short)ch.vy << 32) | iz)
-                                : (((long long)ch.vx << 32) | (unsigned int)ch.vy);
-      bool seen = false;
-      for (unsigned h = fe_hash(vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long k = v_key[h]; if (k == (unsigned long long)vox) { seen = true; break; } if (k == kFeEmpty) break; }
-      if (!seen) { s_f[id] = ch.f; s_vox[id] = vox; }
-      s_state[id] = seen ? 0 : 1;
+        s_state[id] = 4;                                        // (awaiting its propagation)
+        p_list[atomicAdd(&s_i[3], 1)] = (unsigned short)id;
+      } else {
+        my_free++;
+        settle_voxel(id, ch, 0u);
+      }
+    };
+    auto propagate = [&](int id) {      // ENT, part two (see above)
+      const int pr_ = id / NC, cc = id % NC;
+      FeChild ch;
+      fe_child_again<true>(sp, fc, lat, b_end + (prv * NEP_FE_MAX_BEAM + pr_) * 6, b_g[prv * NEP_FE_MAX_BEAM + pr_], cc / ns, cc % ns, gx, gy, ch);
+      EntLds L;
+      {
+        typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
+        const lds_bytes base = (lds_bytes)(unsigned)(size_t)(ent_lists + tid * kEntLdsBytes);      // (the low 32 bits of a generic LDS address are the LDS offset)
+        L.id = (ent_lds_short)base; L.cs = (ent_lds_char)(base + 2 * NEP_FE_ENT_CAP); L.bend = (ent_lds_char)(base + 3 * NEP_FE_ENT_CAP); L.beta = my_work->beta;
+      }
+      { FE_ENT_T0(); ent_lds_load(L, ent_node(depth - 1, depth == 1 ? 0 : pr_)); FE_ENT_T(1); }
+      double arc = 0.0;
+      int rc;
+      ec.m_agent = m_ent + pr_ * MW; ec.m_static = m_stat + pr_ * SW;
+      { FE_ENT_T0(); rc = ent_propagate(ec, &L, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
+      if (rc) { my_entangled++; if (rc == 2) my_overflow = 1; s_state[id] = 0; return; }
+      ent_lds_store(ea.saved + ((long)slot * kFeCap + id), L); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
+      ch.g = b_g[prv * NEP_FE_MAX_BEAM + pr_] + arc;
+      ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)L.n_alpha) + 1.0 * (double)L.n_bend);
+      settle_voxel(id, ch, ent_iz(&L));
     };
     auto obstacle_V = [&](int o) -> const double* {
       if (o < kFeObsLds) return o_V + o * kHullV * 2;
@@ -1983,6 +2031,16 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     }
     __syncthreads();
     FE_TICK(3);
+    if constexpr (ENT) {
+      const int n_prop = s_i[3];
+      int n_merge = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2)) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS
+      if (n_merge > 256) n_merge = 256;
+      for (int b0 = 0; b0 < n_prop; b0 += n_merge) {             // that many survivors at a time, one per thread
+        if (tid < n_merge && b0 + tid < n_prop) propagate(p_list[b0 + tid]);
+        __syncthreads();
+      }
+      FE_TICK(1);
+    }
     // ---- one node per voxel: the best (f, id) claims the voxel's slot; whoever is displaced or beaten is out ----
     for (int id = tid; id < n_c; id += 256) {
       if (s_state[id] != 1) continue;
@@ -2040,7 +2098,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
       }
     }
     // (the next depth's counters and voxel table: nobody reads them any more in this one)
-    if (tid == 0) { s_i[0] = 0; s_i[2] = 0; }
+    if (tid == 0) { s_i[0] = 0; s_i[2] = 0; s_i[3] = 0; }
     for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
     __syncthreads();
     if constexpr (ENT) { for (int k = tid; k < NEP_FE_MAX_BEAM * (2 * MW + SW); k += 256) m_ent[k] = 0u; __syncthreads(); }      // (read by the installs above, filled again by the next depth)
@@ -2193,6 +2251,11 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
   (void)attr[ent].ensure(ent ? (const void*)frontend_kernel<true> : (const void*)frontend_kernel<false>, lds);
   FeEntArgs none{};
   launch_boxes(n_slots / (sp.n_local > 0 ? sp.n_local : 1), sp, ps, st);
+  if (ent && ea->packed) {
+    const int n_scenes = n_slots / (sp.n_local > 0 ? sp.n_local : 1);
+    const long np_ = (long)n_scenes * sp.num_agents * sp.num_pol;
+    hipLaunchKernelGGL(ent_pack_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, st, sp, ps, *ea, n_scenes);
+  }
   if (ent) hipLaunchKernelGGL(frontend_kernel<true>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
   else hipLaunchKernelGGL(frontend_kernel<false>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
 }

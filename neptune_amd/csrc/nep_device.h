@@ -159,6 +159,8 @@ struct FeEntArgs {
   double* saved_arc;             // [slots][children cap] and its sampled arc length
   int* case_out;                 // [slots][NEP_MAX_POL][N] (out) or null
   int ns;                        // num_sample_per_interval
+  double* packed;                // [scenes][N][num_pol][pk_stride] one record per (agent, interval) of what the check reads (ent_pack_kernel), or null
+  int pk_stride;
 };
 size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol);      // children per depth of one search (beam_width x lattice)
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
