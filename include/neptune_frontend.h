@@ -46,7 +46,7 @@ extern "C" {
 #define NEP_FE_MAX_BEAM 64
 #define NEP_FE_MAX_SAMPLES 5
 #ifndef NEP_FE_ENT_CAP
-#define NEP_FE_ENT_CAP 24
+#define NEP_FE_ENT_CAP 40
 #endif                            /* crossings kept per search node with the entangle check on (the reference prunes a
                                      node at num_agents + statics crossings; one that would exceed this capacity is
                                      pruned too and reported in nep_fe_result.ent_overflow)                          */
@@ -78,7 +78,9 @@ typedef struct nep_fe_cfg {
 
 /* eu::ent_state of one search node / of point A (entangle_utils.hpp:23-29) in a fixed-size record: the crossing list
  * (agent or static id, case), its betas and the bend-point indices; active_cases[i] is the number of list entries of
- * agent i and is not stored.                                                                                       */
+ * agent i and is not stored.  beta of an AGENT crossing (id <= num_agents) is 0.0, as the reference's calculateBetaForCase
+ * returns it (entangle_utils.cpp:1713-1719); only static crossings carry one.  States made by nep_ent_propagate_* honour that;
+ * a state that does not is flagged by nep_batch_check (the search does not read such betas).                              */
 typedef struct nep_fe_ent_state {
   int32_t n_alpha, n_bend;
   int16_t id[NEP_FE_ENT_CAP];

@@ -123,7 +123,7 @@ class nep_fe_cfg(C.Structure):
                 ("pad_hold", C.c_int32), ("enable_entangle", C.c_int32), ("ent_samples", C.c_int32), ("_pad", C.c_int32)]
 
 
-NEP_FE_ENT_CAP = 24
+NEP_FE_ENT_CAP = 40
 
 
 class nep_fe_ent_state(C.Structure):

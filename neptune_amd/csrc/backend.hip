@@ -1284,6 +1284,7 @@ int nep_batch_check(nep_batch_t* h, void* stream) {
     HIPCHK(hipMemcpy(&flags, h->eng.d_flags.p, sizeof(int), hipMemcpyDeviceToHost));
     if (flags) HIPCHK(hipMemset(h->eng.d_flags.p, 0, sizeof(int)));
   }
+  if (flags & NEP_FLAG_ENT_BETA) return fail(NEP_E_ARG, "an entangle state passed to the front end has a non-zero beta for an agent crossing (the reference's calculateBetaForCase makes it 0.0)");
   if (flags & NEP_FLAG_HULL_OVERFLOW) return fail(NEP_E_CAP, "an interval overlaps more than NEP_HULL_MAX_CP/4 committed segments (or its hull has more than NEP_HULL_MAX_V vertices)");
   return 0;
 }

@@ -33,8 +33,20 @@ struct EntCtx {
 };
 struct Ev2 { double x, y; };
 constexpr int kEntAddCap = 32;
-template <int CAP> struct EntAddT { static constexpr int cap = CAP; short id[CAP]; signed char cs[CAP]; signed char nb[CAP]; int n, overflow; };      // (nb: the crossed agent's bend-point count, known where the crossing is found — the merge needs it)
-typedef EntAddT<kEntAddCap> EntAdd;
+// The crossings one sampled step adds, in the reference's order (at most kEntAddCap; more: flagged).  An entry is one word —
+// id | case << 16 | nb << 24 (nb: the crossed agent's bend-point count, known where the crossing is found; the merge needs it) —
+// and the first four entries are plain members, so that they stay in registers: a step adds two or three crossings, and every
+// read of a list in scratch memory is a round trip the list surgery waits for (the merge was 57 % of a propagation).
+struct EntAdd {
+  static constexpr int cap = kEntAddCap;
+  unsigned r0, r1, r2, r3; unsigned rest[kEntAddCap - 4]; int n, overflow;
+  __device__ __forceinline__ unsigned get(int i) const { return i == 0 ? r0 : i == 1 ? r1 : i == 2 ? r2 : i == 3 ? r3 : rest[i - 4]; }
+  __device__ __forceinline__ void set(int i, unsigned v) { if (i == 0) r0 = v; else if (i == 1) r1 = v; else if (i == 2) r2 = v; else if (i == 3) r3 = v; else rest[i - 4] = v; }
+  __device__ __forceinline__ int id(int i) const { return (int)(get(i) & 0xffffu); }
+  __device__ __forceinline__ int cs(int i) const { return (int)((get(i) >> 16) & 0xffu); }
+  __device__ __forceinline__ int nb(int i) const { return (int)(get(i) >> 24); }
+  __device__ __forceinline__ void remove(int i) { for (int k = i; k + 1 < n; k++) set(k, get(k + 1)); n--; }
+};
 constexpr int kEntPkHead = 2 + 2 * kBend;      // doubles of a packed record before the samples: [present, bend count | pad] [8 bend points] (everything 16-byte aligned)
 constexpr int kEntPkBend = 2;
 
@@ -48,7 +60,7 @@ __device__ __forceinline__ double ent_wedge(Ev2 a, Ev2 b, Ev2 cc) { return (b.x 
 __device__ __forceinline__ double ent_wedge2(Ev2 a, Ev2 b, Ev2 cc, Ev2& ab, Ev2& ac) { ab.x = b.x - a.x; ab.y = b.y - a.y; ac.x = cc.x - a.x; ac.y = cc.y - a.y; return ab.x * ac.y - ac.x * ab.y; }
 __device__ __forceinline__ double ent_ratio(Ev2 u, Ev2 v) { return fabs(u.y * v.y) > fabs(u.x * v.x) ? u.y / v.y : u.x / v.x; }
 __device__ __forceinline__ double ent_dist(Ev2 a, Ev2 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
-template <class A> __device__ __forceinline__ void ent_push(A& a, int id, int cs, int nb = 0) { if (a.n < A::cap) { a.id[a.n] = (short)id; a.cs[a.n] = (signed char)cs; a.nb[a.n] = (signed char)nb; a.n++; } else a.overflow = 1; }
+__device__ __forceinline__ void ent_push(EntAdd& a, int id, int cs, int nb = 0) { if (a.n < EntAdd::cap) { a.set(a.n, (unsigned)(id & 0xffff) | ((unsigned)(cs & 0xff) << 16) | ((unsigned)(nb & 0xff) << 24)); a.n++; } else a.overflow = 1; }
 
 // ---- proofs that an obstacle adds no crossing for ANY sampled step inside a box (frontend_kernel's per-parent masks,
 // ent_check_kernel's per-trajectory mask).  A step p_k -> p_k1 adds a crossing with a tether segment only if the two points lie
@@ -115,7 +127,7 @@ __device__ bool ent_agent_may_cross_pk(const EntCtx& c, const EntBox& q, int j, 
 }
 __device__ __forceinline__ bool ent_static_may_cross(const EntCtx& c, const EntBox& q, int s) { return ent_side(q, ent_srep(c, s, 1), ent_srep(c, s, 0)) == 0; }
 
-template <class A> __device__ void ent_cross_agent(A& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id) {
+__device__ __forceinline__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id) {
   bool base_addition = false;
   for (int k = 0; k < nb; k++) {
     const bool last = k == nb - 1;
@@ -141,7 +153,7 @@ template <class A> __device__ void ent_cross_agent(A& add, Ev2 pk, Ev2 pk1, Ev2 
       else if (a >= 1 && k == 0) ent_push(add, agent_id, 0, nb);
     }
   }
-  if (base_addition && add.n >= 2 && add.id[add.n - 1] == add.id[add.n - 2] && add.cs[add.n - 1] == add.cs[add.n - 2]) add.n -= 2;
+  if (base_addition && add.n >= 2 && ((add.get(add.n - 1) ^ add.get(add.n - 2)) & 0xffffffu) == 0u) add.n -= 2;      // (same id, same case)
 }
 __device__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, const EntCtx& c) {
   for (int s = 0; s < c.S; s++) {
@@ -172,8 +184,21 @@ __device__ __forceinline__ bool ent_scan_stops(int t_id, int t_cs, int l_id, int
   if (t_id <= c.N) return false;
   return l_id > c.N || j <= last_bend;
 }
-template <class ST> __device__ void ent_erase(ST* st, int j) {
-  for (int k = j; k + 1 < st->n_alpha; k++) { st->id[k] = st->id[k + 1]; st->cs[k] = st->cs[k + 1]; st->beta[k] = st->beta[k + 1]; }
+// The beta of an AGENT crossing is 0.0 by the reference's own rule (calculateBetaForCase, entangle_utils.cpp:1713-1719: only static
+// obstacles carry one).  The LDS-resident view (EntLds, below) keeps its betas in global memory and relies on that: it neither
+// reads nor rewrites the beta of an agent entry — reads are round trips the list surgery would wait for, and nearly every entry is
+// an agent's.  nep_fe_ent_state itself is handled as written (every beta moved and compared as stored).
+struct EntLds;
+template <class ST> struct ent_lazy_beta { static constexpr bool v = false; };
+template <> struct ent_lazy_beta<EntLds> { static constexpr bool v = true; };
+template <class ST> __device__ void ent_erase(ST* st, int j, int N) {
+  constexpr bool lazy = ent_lazy_beta<ST>::v;
+  for (int k = j; k + 1 < st->n_alpha; k++) {
+    const int id_new = st->id[k + 1];
+    if (!lazy) st->beta[k] = st->beta[k + 1];
+    else if (id_new > N) st->beta[k] = st->beta[k + 1];      // (an agent entry's beta is never looked at: nothing to move)
+    st->id[k] = (short)id_new; st->cs[k] = st->cs[k + 1];
+  }
   st->n_alpha--;
 }
 __device__ int ent_bend_n(const EntCtx& c, int j) { const HullRef hr = hull_ref(*c.ps, c.n_hull, c.scene, j); return blk(c.ps->bend_n, hr.boff)[hr.e]; }
@@ -183,22 +208,22 @@ template <class ST> __device__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 p
     again = false;
     const int b = st->n_bend ? st->bend[st->n_bend - 1] : -1;
     for (int i = 0; i < add.n && !again; i++) {
-      const int t_id = add.id[i], t_cs = add.cs[i];
+      const unsigned t_w = add.get(i);
+      const int t_id = (int)(t_w & 0xffffu), t_cs = (int)((t_w >> 16) & 0xffu);
       const bool agent = t_id <= c.N;
-      const int t_nb = agent ? add.nb[i] : 0;
+      const int t_nb = agent ? (int)(t_w >> 24) : 0;
       for (int j = st->n_alpha - 1; j >= 0; j--) {
         const int l_id = st->id[j], l_cs = st->cs[j];
         const bool match = (l_id == t_id && l_cs == t_cs) ||
                            (agent && l_id == t_id && t_cs >= t_nb + 1 && t_cs < l_cs) ||
                            (agent && l_id == t_id && l_cs >= 2 && t_cs >= 2 && abs(t_cs - l_cs) == 1 && j > b);
         if (match) {
-          for (int k = i; k + 1 < add.n; k++) { add.id[k] = add.id[k + 1]; add.cs[k] = add.cs[k + 1]; add.nb[k] = add.nb[k + 1]; }
-          add.n--;
-          ent_erase(st, j);
+          add.remove(i);
+          ent_erase(st, j, c.N);
           if (j == b) {
             st->n_bend--;
             const Ev2 bp = ent_cur_bend(st, pb_self, c);
-            for (int k = j; k < st->n_alpha; k++) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk, bp, c);
+            for (int k = j; k < st->n_alpha; k++) if (!ent_lazy_beta<ST>::v || st->id[k] > c.N) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk, bp, c);
           } else if (j < b) {
             st->bend[st->n_bend - 1] = (signed char)(b - 1);
             for (int k = st->n_bend - 2; k >= 0; k--) { if (st->bend[k] > j) st->bend[k] -= 1; else break; }
@@ -214,8 +239,8 @@ template <class ST> __device__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 p
   if (st->n_alpha + add.n > NEP_FE_ENT_CAP) return true;
   const Ev2 bp = ent_cur_bend(st, pb_self, c);
   for (int i = 0; i < add.n; i++) {
-    st->id[st->n_alpha] = add.id[i]; st->cs[st->n_alpha] = add.cs[i];
-    st->beta[st->n_alpha] = ent_beta(add.id[i], add.cs[i], pk, bp, c);
+    st->id[st->n_alpha] = (short)add.id(i); st->cs[st->n_alpha] = (signed char)add.cs(i);
+    if (!ent_lazy_beta<ST>::v || add.id(i) > c.N) st->beta[st->n_alpha] = ent_beta(add.id(i), add.cs(i), pk, bp, c);
     st->n_alpha++;
   }
   return false;
@@ -224,20 +249,24 @@ template <class ST> __device__ bool ent_update_bends(ST* st, Ev2 pk1, Ev2 pb_sel
   const Ev2 bp = ent_cur_bend(st, pb_self, c);
   int idx_new = -1;
   const int start = st->n_bend ? st->bend[st->n_bend - 1] : -1;
-  for (int i = start + 1; i < st->n_alpha; i++) { const double beta = ent_beta(st->id[i], st->cs[i], pk1, bp, c); if (beta * st->beta[i] < -1e-7) idx_new = i; }
+  for (int i = start + 1; i < st->n_alpha; i++) {
+    if (ent_lazy_beta<ST>::v && st->id[i] <= c.N) continue;      // (0.0 times the stored 0.0)
+    const double beta = ent_beta(st->id[i], st->cs[i], pk1, bp, c); if (beta * st->beta[i] < -1e-7) idx_new = i;
+  }
   if (idx_new > -1) {
     if (st->n_bend >= NEP_MAX_BEND) return true;
     st->bend[st->n_bend++] = (signed char)idx_new;
     const Ev2 nb = ent_anchor(st->id[idx_new], st->cs[idx_new], c);
-    for (int i = idx_new + 1; i < st->n_alpha; i++) st->beta[i] = ent_beta(st->id[i], st->cs[i], pk1, nb, c);
+    for (int i = idx_new + 1; i < st->n_alpha; i++) if (!ent_lazy_beta<ST>::v || st->id[i] > c.N) st->beta[i] = ent_beta(st->id[i], st->cs[i], pk1, nb, c);
     return false;
   }
   while (st->n_bend) {
     const Ev2 prev = st->n_bend == 1 ? pb_self : ent_anchor(st->id[st->bend[st->n_bend - 2]], st->cs[st->bend[st->n_bend - 2]], c);
     const int bi = st->bend[st->n_bend - 1];
     const double beta = ent_beta(st->id[bi], st->cs[bi], pk1, prev, c);
-    if (beta * st->beta[bi] > 1e-7) {
-      for (int k = bi + 1; k < st->n_alpha; k++) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk1, prev, c);
+    const double stored = (ent_lazy_beta<ST>::v && st->id[bi] <= c.N) ? 0.0 : st->beta[bi];
+    if (beta * stored > 1e-7) {
+      for (int k = bi + 1; k < st->n_alpha; k++) if (!ent_lazy_beta<ST>::v || st->id[k] > c.N) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk1, prev, c);
       st->n_bend--;
     } else break;
   }
@@ -325,12 +354,13 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
       // (:870-887: a second entry where there was at most one, or one more where there were two, prunes the child).  The merge
       // only ever touches entries of the agents in `add`, so theirs are the only counts that can differ: the old ones are
       // taken before the merge, for those agents only — no copy of the old list, no pass over every pair of entries.
-      short a_id[kEntAddCap]; signed char a_od[kEntAddCap]; const int a_n = add.n;
-      for (int e = 0; e < a_n; e++) { a_id[e] = add.id[e]; a_od[e] = (signed char)(add.id[e] <= c.N ? ent_count(st->id, st->n_alpha, add.id[e]) : 0); }
+      EntAdd chk; chk.n = 0; chk.overflow = 0; const int a_n = add.n;      // (id, entries of that agent before the merge)
+      for (int e = 0; e < a_n; e++) { const int id_ = add.id(e); ent_push(chk, id_, id_ <= c.N ? ent_count(st->id, st->n_alpha, id_) : 0); }
       if (ent_merge(add, st, pk, pb_self, c)) return 2;
       for (int e = 0; e < a_n; e++) {
-        if (a_id[e] > c.N) continue;
-        const int nw = ent_count(st->id, st->n_alpha, a_id[e]), od = a_od[e];
+        const int id_ = chk.id(e);
+        if (id_ > c.N) continue;
+        const int nw = ent_count(st->id, st->n_alpha, id_), od = chk.cs(e);
         if (od < 2 && nw >= 2) return 1;
         if (od >= 2 && nw > od) return 1;
       }
@@ -363,21 +393,17 @@ typedef __attribute__((address_space(3))) short* ent_lds_short;
 typedef __attribute__((address_space(3))) signed char* ent_lds_char;
 struct EntLds { int n_alpha, n_bend; ent_lds_short id; ent_lds_char cs; double* beta; ent_lds_char bend; };
 constexpr int kEntLdsBytes = ((NEP_FE_ENT_CAP * 3 + NEP_MAX_BEND + 3) & ~3) | 4;      // per thread; an odd number of dwords, so that the threads' lists fall into different banks
-__device__ __forceinline__ void ent_lds_load(EntLds& L, const nep_fe_ent_state* __restrict__ src) {
+__device__ __forceinline__ void ent_lds_load(EntLds& L, const nep_fe_ent_state* __restrict__ src, int N) {
   L.n_alpha = src->n_alpha; L.n_bend = src->n_bend;
-#pragma unroll
-  for (int i = 0; i < NEP_FE_ENT_CAP; i++) { L.id[i] = src->id[i]; L.cs[i] = src->cs[i]; }
-#pragma unroll
-  for (int i = 0; i < NEP_MAX_BEND; i++) L.bend[i] = src->bend[i];
-  for (int i = 0; i < L.n_alpha; i++) L.beta[i] = src->beta[i];
+  for (int i = 0; i < L.n_alpha; i++) { L.id[i] = src->id[i]; L.cs[i] = src->cs[i]; }
+  for (int i = 0; i < L.n_bend; i++) L.bend[i] = src->bend[i];
+  for (int i = 0; i < L.n_alpha; i++) if (src->id[i] > N) L.beta[i] = src->beta[i];      // (statics only: see ent_lazy_beta)
 }
-__device__ __forceinline__ void ent_lds_store(nep_fe_ent_state* __restrict__ dst, const EntLds& L) {
+__device__ __forceinline__ void ent_lds_store(nep_fe_ent_state* __restrict__ dst, const EntLds& L, int N) {
   dst->n_alpha = L.n_alpha; dst->n_bend = L.n_bend;
-#pragma unroll
-  for (int i = 0; i < NEP_FE_ENT_CAP; i++) { dst->id[i] = L.id[i]; dst->cs[i] = L.cs[i]; }
-#pragma unroll
-  for (int i = 0; i < NEP_MAX_BEND; i++) dst->bend[i] = L.bend[i];
-  for (int i = 0; i < L.n_alpha; i++) dst->beta[i] = L.beta[i];
+  for (int i = 0; i < L.n_alpha; i++) { dst->id[i] = L.id[i]; dst->cs[i] = L.cs[i]; }
+  for (int i = 0; i < L.n_bend; i++) dst->bend[i] = L.bend[i];
+  for (int i = 0; i < L.n_alpha; i++) dst->beta[i] = L.id[i] > N ? L.beta[i] : 0.0;
 }
 
 template <class ST> __device__ unsigned ent_iz(const ST* st) {

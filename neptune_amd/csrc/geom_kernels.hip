@@ -1715,15 +1715,15 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
   const int kFeCap = fz.cap, kFeDd = fz.dd, kFeVis = fz.vis;
   // ---- LDS carve ----
   double* s_f = fe_smem;                                   // [kFeCap] f of candidate id
-  double* r_f = s_f + kFeCap;                              // [kFeCap] f of the voxel winners, dense
-  double* b_end = r_f + kFeCap;                            // [2][64][6]
+  double* b_end = s_f + kFeCap;                            // [2][64][6]
   double* b_g = b_end + 2 * NEP_FE_MAX_BEAM * 6;           // [2][64]
   double* b_dist = b_g + 2 * NEP_FE_MAX_BEAM;              // [64]
   double* b_f = b_dist + NEP_FE_MAX_BEAM;                  // [64]
   double* p_box = b_f + NEP_FE_MAX_BEAM;                   // [64][4] box of every parent's children
   double* o_aabb = p_box + NEP_FE_MAX_BEAM * 4;            // [N+S][4] boxes of the shortlisted obstacles, dense
   double* o_V = o_aabb + 4 * (N + S);                      // [kFeObsLds][16][2] their vertices (GJK walks them several times)
-  double* s_lat = o_V + kFeObsLds * kHullV * 2;            // [4][NEP_FE_MAX_SAMPLES] lattice tables
+  double* r_f = o_V + kFeObsLds * kHullV * 2;              // [kFeCap] f of the voxel winners, dense (ENT: behind o_aabb and o_V, with which its head is lent to the crossing lists)
+  double* s_lat = r_f + kFeCap;                            // [4][NEP_FE_MAX_SAMPLES] lattice tables
   long long* s_vox = (long long*)(s_lat + 4 * NEP_FE_MAX_SAMPLES);   // [kFeCap]
   unsigned long long* v_key = (unsigned long long*)(s_vox + kFeCap);   // [kFeVis] visited voxels
   int* d_slot = (int*)(v_key + kFeVis);                    // [kFeDd] voxel -> best candidate of the depth
@@ -1759,13 +1759,17 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     ec.prof = ps.dbg ? ps.dbg + (long)slot * 32 + 16 : nullptr;
 #endif
     // the crossing lists of the children being merged (phase two of the propagation pass) live where the shortlist's boxes and
-    // vertices are: those are dead between a depth's GJK pass and the next depth's shortlist
+    // vertices and the winners' f values are: dead between a depth's GJK pass and its compaction / the next depth's shortlist
     ent_lists = (unsigned char*)o_aabb;      // [n_merge][kEntLdsBytes]
     my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(m_stat + NEP_FE_MAX_BEAM * SW) + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
     if (tid == 0) {
       nep_fe_ent_state* root = ent_node(0, 0);
-      if (ea.init) ent_copy(root, ea.init + slot);
-      else { long* z = (long*)root; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
+      if (ea.init) {
+        ent_copy(root, ea.init + slot);
+        // an agent crossing's beta is 0.0 (calculateBetaForCase, entangle_utils.cpp:1713-1719): a state that says otherwise was not
+        // made by the reference's rules — flagged (nep_batch_check), since the propagation does not look at such betas
+        for (int i = 0; i < root->n_alpha && i < NEP_FE_ENT_CAP; i++) if (root->id[i] <= N && root->beta[i] != 0.0 && ps.flags) atomicOr(ps.flags, NEP_FLAG_ENT_BETA);
+      } else { long* z = (long*)root; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
     }
     if (tid < NEP_FE_MAX_BEAM) b_valid[tid] = 1;
   }
@@ -1880,20 +1884,23 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
       FE_ENT_T0();
       const double kPad = 1e-9;
       const double safe_dist = (sp.T_span * sp.v_max) * 2;
-      for (int e = tid; e < nb_prev * (N + S); e += 256) {
-        const int q = e / (N + S), j = e - q * (N + S);
-        const EntBox bx{p_box[4 * q] - kPad, p_box[4 * q + 1] + kPad, p_box[4 * q + 2] - kPad, p_box[4 * q + 3] + kPad};
-        if (j < N) {
-          if (j == own) continue;
-          {   // collidesWithBases2d's distance cull, from the box
-            const double pbx = ps.pb[2 * j], pby = ps.pb[2 * j + 1];
-            const double dx = fmax(fmax(bx.x0 - pbx, pbx - bx.x1), 0.0), dy = fmax(fmax(bx.y0 - pby, pby - bx.y1), 0.0);
-            if (sqrt(dx * dx + dy * dy) <= safe_dist + 1e-6) atomicOr(&m_base[q * MW + (j >> 5)], 1u << (j & 31));
+      // (an obstacle per thread, the parents in the inner loop: its packed record is fetched once and then read from the L1 for
+      // every parent, instead of once per (parent, obstacle) pair from wherever it was)
+      for (int j = tid; j < N + S; j += 256) {
+        if (j == own) continue;
+        const double pbx = j < N ? ps.pb[2 * j] : 0.0, pby = j < N ? ps.pb[2 * j + 1] : 0.0;
+        for (int q = 0; q < nb_prev; q++) {
+          const EntBox bx{p_box[4 * q] - kPad, p_box[4 * q + 1] + kPad, p_box[4 * q + 2] - kPad, p_box[4 * q + 3] + kPad};
+          if (j < N) {
+            {   // collidesWithBases2d's distance cull, from the box
+              const double dx = fmax(fmax(bx.x0 - pbx, pbx - bx.x1), 0.0), dy = fmax(fmax(bx.y0 - pby, pby - bx.y1), 0.0);
+              if (sqrt(dx * dx + dy * dy) <= safe_dist + 1e-6) atomicOr(&m_base[q * MW + (j >> 5)], 1u << (j & 31));
+            }
+            if (ent_agent_may_cross_pk(ec, bx, j, idx)) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
+          } else {
+            const int sj = j - N;
+            if (ent_static_may_cross(ec, bx, sj)) atomicOr(&m_stat[q * SW + (sj >> 5)], 1u << (sj & 31));
           }
-          if (ent_agent_may_cross_pk(ec, bx, j, idx)) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
-        } else {
-          const int sj = j - N;
-          if (ent_static_may_cross(ec, bx, sj)) atomicOr(&m_stat[q * SW + (sj >> 5)], 1u << (sj & 31));
         }
       }
       FE_ENT_T(3);
@@ -1908,12 +1915,12 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     const int n_c = nb_prev * NC;
     if (tid == 0) s_i[1] = 0;                              // (the winners' counter: last read in the previous depth's rank phase)
     // ENT: settling a collision-free child is split in two.  Part one (here, by whoever examined the child) is the base-square test;
-    // a survivor goes on the propagation list (p_list, in r_f's storage: free until the winners are compacted).  Part two — copy
+    // a survivor goes on the propagation list (p_list, in the tail of r_f's storage: free until the winners are compacted).  Part two — copy
     // of the parent's entangle state, entanglesWithOtherAgents, the voxel — runs after a barrier over that DENSE list, one
     // survivor per thread: the propagation is two orders of magnitude dearer than anything else a child costs and only a fifth of
     // the children reach it, so examined in place the threads that drew two or three survivors kept the others waiting (pass 1 was
     // 65 % of a config-5 search, its critical path three propagations per depth instead of one).
-    unsigned short* p_list = (unsigned short*)r_f;
+    unsigned short* p_list = (unsigned short*)(r_f + kFeCap) - kFeCap;      // (the LAST kFeCap shorts of r_f: its head is lent to the crossing lists)
     auto settle_voxel = [&](int id, FeChild& ch, unsigned iz) {
       const long long vox = ENT ? (long long)(((unsigned long long)(unsigned short)ch.vx << 48) | ((unsigned long long)(unsigned short)ch.vy << 32) | iz)
                                 : (((long long)ch.vx << 32) | (unsigned int)ch.vy);
@@ -1960,13 +1967,13 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
         const lds_bytes base = (lds_bytes)(unsigned)(size_t)(ent_lists + tid * kEntLdsBytes);      // (the low 32 bits of a generic LDS address are the LDS offset)
         L.id = (ent_lds_short)base; L.cs = (ent_lds_char)(base + 2 * NEP_FE_ENT_CAP); L.bend = (ent_lds_char)(base + 3 * NEP_FE_ENT_CAP); L.beta = my_work->beta;
       }
-      { FE_ENT_T0(); ent_lds_load(L, ent_node(depth - 1, depth == 1 ? 0 : pr_)); FE_ENT_T(1); }
+      { FE_ENT_T0(); ent_lds_load(L, ent_node(depth - 1, depth == 1 ? 0 : pr_), N); FE_ENT_T(1); }
       double arc = 0.0;
       int rc;
       ec.m_agent = m_ent + pr_ * MW; ec.m_static = m_stat + pr_ * SW;
       { FE_ENT_T0(); rc = ent_propagate(ec, &L, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
       if (rc) { my_entangled++; if (rc == 2) my_overflow = 1; s_state[id] = 0; return; }
-      ent_lds_store(ea.saved + ((long)slot * kFeCap + id), L); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
+      ent_lds_store(ea.saved + ((long)slot * kFeCap + id), L, N); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
       ch.g = b_g[prv * NEP_FE_MAX_BEAM + pr_] + arc;
       ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)L.n_alpha) + 1.0 * (double)L.n_bend);
       settle_voxel(id, ch, ent_iz(&L));
@@ -2033,7 +2040,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     FE_TICK(3);
     if constexpr (ENT) {
       const int n_prop = s_i[3];
-      int n_merge = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2)) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS
+      int n_merge = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2 + kFeCap) - sizeof(unsigned short) * kFeCap) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS (o_aabb, o_V, r_f without p_list)
       if (n_merge > 256) n_merge = 256;
       for (int b0 = 0; b0 < n_prop; b0 += n_merge) {             // that many survivors at a time, one per thread
         if (tid < n_merge && b0 + tid < n_prop) propagate(p_list[b0 + tid]);
