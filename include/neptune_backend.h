@@ -404,6 +404,15 @@ double nep_batch_get_line_cull(nep_batch_t* h);
  * violated [0] and how many moved farther than the radius [1].                                                       */
 int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason);
 int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap);    /* the listed slots (test hook) */
+/* Row scratch (rows and coefficients of a replan beyond the interior-point kernel's register slots or LDS carve).  In general one
+ * worst-case area per slot.  With the presolve's redo pass (line presolve on, largest-gap rule, batched hull layout, box-edged
+ * statics) the first pass never needs one — a replan whose near lines exceed the slots goes to the redo pass unsolved — so a
+ * handle of more than 1 024 slots keeps a pool of 1 024 areas for that pass (config 5, 32 scenes: 1.9 GB instead of 15.3).  A
+ * launch that lists more such replans than the pool holds fails them and raises a sticky flag: nep_batch_check returns
+ * NEP_E_CAP; nep_batch_reserve_row_scratch switches the handle to one area per slot for good.  Setters that change the mode
+ * (nep_batch_set_line_cull, nep_batch_set_separator_rule) re-size the scratch: never call them inside a graph capture.        */
+int nep_batch_reserve_row_scratch(nep_batch_t* h);
+int64_t nep_batch_row_scratch_bytes(nep_batch_t* h);
 /* Diagnostic ("how hard are these problems"): inequality rows of the QP (solver_gurobi_poly.cpp:433-489) whose slack at the
  * solutions of the last nep_batch_replan* is below tol: d_out [slots][2] int32 = (box rows, separating-line rows) per slot.
  * d_solution is what that replan wrote; the lines are the handle's own (parked ones included).  Asynchronous on `stream`.  */

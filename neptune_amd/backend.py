@@ -385,6 +385,13 @@ class BatchBackend:
         self.redo_reasons = {"parked_line_violated": int(r[0]), "moved_beyond_radius": int(r[1])}
         return n
 
+    def reserve_row_scratch(self):
+        """one worst-case row-scratch area per slot instead of the redo pass's pool (nep_batch_reserve_row_scratch)"""
+        check(lib().nep_batch_reserve_row_scratch(self._h))
+
+    def row_scratch_bytes(self):
+        return int(lib().nep_batch_row_scratch_bytes(self._h))
+
     def set_separator_pack(self, pack):
         """test hook: 0 segments per wave by launch size, -1 the unpacked separator, 1..8 forced (nep_batch_debug_set_separator_pack)"""
         check(lib().nep_batch_debug_set_separator_pack(self._h, int(pack)))

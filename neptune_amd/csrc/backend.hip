@@ -143,6 +143,19 @@ struct Engine {
   // which interior-point kernel the next replan launches, and its LDS carve (see size_scratch)
   static constexpr double kAutoCullRadius = 4.0;
   bool fits_reg = true, cull_user_set = false, skip_lps = true, no_redo = false; int lds_lines_lds = 0, sep_pack = 0;
+  // Row scratch (rows and coefficients beyond the register slots / the LDS carve): one area per slot in general.  With the presolve's
+  // redo pass (skip_mode()) the first pass never needs one — a replan whose near lines exceed the slots is sent to the redo pass —
+  // so the handle keeps a pool of kScratchPool areas for that pass (config 5: 1.9 GB instead of 15.3 per 32 scenes);
+  // nep_batch_reserve_row_scratch asks for the worst case.
+  static constexpr int kScratchPool = 1024;
+  bool scratch_full = false; int scratch_chunks = 0;
+  bool skip_mode() const { return sp.cull_radius > 0.0 && use_reg && sp.sep_rule == 0 && sp.skip_own == 1 && sp.n_hull == sp.num_agents && skip_lps && statics_boxy && !no_redo; }
+  int size_row_scratch() {
+    const long slots = (long)n_scenes * sp.n_local;
+    const bool pooled = skip_mode() && !scratch_full && slots > kScratchPool;
+    scratch_chunks = pooled ? kScratchPool : 0;
+    return d_row_scratch.ensure((size_t)(pooled ? kScratchPool : slots) * (11L * (rows_cap / 4 + 2)));
+  }
   void choose_placement() {
     use_reg = fits_reg || sp.cull_radius > 0.0;
     if (const char* f = getenv("NEP_QP_KERNEL")) { if (!strcmp(f, "reg")) use_reg = true; else if (!strcmp(f, "lds")) use_reg = false; }
@@ -209,7 +222,7 @@ struct Engine {
     if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 32)) return e; }      // (the QP kernels use 16 per slot, the front end 32)
-    if (int e = d_row_scratch.ensure((size_t)slots * (11L * (rows_cap / 4 + 2)))) return e;     // (either placement may end up using it: see choose_placement)
+    if (int e = size_row_scratch()) return e;
     return 0;
   }
   void fill(ProblemSet& ps) {
@@ -222,6 +235,7 @@ struct Engine {
     // (box far => line far holds for that vertex only), the hull lists are the batch's (one per agent: the boxes are indexed
     // by agent) and the interior point is the register kernel (the one that verifies them): see separator_body / qp_reg_kernel
     const bool skip = sp.cull_radius > 0.0 && use_reg && sp.sep_rule == 0 && sp.skip_own == 1 && sp.n_hull == sp.num_agents && skip_lps && statics_boxy;
+    ps.scratch_chunks = (skip && !no_redo) ? scratch_chunks : 0; ps.scratch_by_block = 0;
     ps.skip_box = skip ? d_fe_box.p : nullptr; ps.line_skip = skip ? d_line_skip.p : nullptr;
     ps.redo_list = skip ? d_redo_list.p : nullptr; ps.redo_count = skip ? d_redo_count.p : nullptr; ps.order_count = nullptr;
     ps.sep_pack = sep_pack;
@@ -336,6 +350,12 @@ struct Engine {
     if (d_recs) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st);
     if (timing) hipEventRecord(next_event(), st);
     if (ps.lines_override) { ps.skip_box = nullptr; ps.line_skip = nullptr; ps.redo_list = nullptr; ps.redo_count = nullptr; }
+    if (scratch_chunks > 0 && ps.scratch_chunks == 0) {      // (a pooled handle asked for a replan without the redo pass — lines from the host, a rule or hull layout that cannot skip LPs: one area per slot after all)
+      scratch_full = true;
+      HIPCHK(hipStreamSynchronize(st));
+      if (int e = size_row_scratch()) return e;
+      ps.row_scratch = d_row_scratch.p;
+    }
     const bool skip = ps.skip_box != nullptr;
     if (!ps.lines_override) {
       if (skip) launch_boxes(n_scenes, sp, ps, st);      // (zeroes the redo counters as well)
@@ -356,6 +376,7 @@ struct Engine {
       launch_separator_redo(slots, sp, ps, st);
       ProblemSet pr = ps;
       pr.line_far = nullptr; pr.line_skip = nullptr; pr.order = d_redo_list.p; pr.order_count = d_redo_count.p;
+      pr.scratch_by_block = ps.scratch_chunks > 0 ? 1 : 0;
       launch_qp_reg(slots, sp, pr, d_tables.p, sc, lds_bytes, st);
     }
     have_history = ps.order_key != nullptr;
@@ -1239,15 +1260,26 @@ int nep_batch_set_line_cull(nep_batch_t* h, double radius) {
   if (!h || !(radius >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
   h->eng.sp.cull_radius = radius; h->eng.cull_user_set = true;
   h->eng.choose_placement();      // (a culled problem's near lines fit the register kernel whatever the scene size)
-  return 0;
+  HIPCHK(hipDeviceSynchronize());
+  return h->eng.size_row_scratch();      // (the row scratch follows the mode: a pool with the redo pass, one area per slot without — never inside a capture)
 }
 double nep_batch_get_line_cull(nep_batch_t* h) { return h ? h->eng.sp.cull_radius : -1.0; }
 
 int nep_batch_set_separator_rule(nep_batch_t* h, int32_t rule) {
   if (!h || (rule != 0 && rule != 1)) return fail(NEP_E_ARG, "separator rule: 0 largest gap, 1 GLPK-class simplex");
   h->eng.sp.sep_rule = rule;
-  return 0;
+  HIPCHK(hipDeviceSynchronize());
+  return h->eng.size_row_scratch();
 }
+// Row scratch for the worst case (one area per slot) whatever the mode: nep_batch_check reports NEP_E_CAP when the pool of the
+// presolve's redo pass ran out (more than 1 024 replans of one launch listed with rows beyond the register slots).
+int nep_batch_reserve_row_scratch(nep_batch_t* h) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  h->eng.scratch_full = true;
+  HIPCHK(hipDeviceSynchronize());
+  return h->eng.size_row_scratch();
+}
+int64_t nep_batch_row_scratch_bytes(nep_batch_t* h) { return h ? (int64_t)(h->eng.d_row_scratch.n * sizeof(double)) : 0; }
 int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule) {
   if (!h || (rule != 0 && rule != 1)) return fail(NEP_E_ARG, "separator rule: 0 largest gap, 1 GLPK-class simplex");
   h->eng.sp.sep_rule = rule;
@@ -1284,6 +1316,7 @@ int nep_batch_check(nep_batch_t* h, void* stream) {
     HIPCHK(hipMemcpy(&flags, h->eng.d_flags.p, sizeof(int), hipMemcpyDeviceToHost));
     if (flags) HIPCHK(hipMemset(h->eng.d_flags.p, 0, sizeof(int)));
   }
+  if (flags & NEP_FLAG_SCRATCH) return fail(NEP_E_CAP, "the presolve's redo pass listed more replans with rows beyond the register slots than the handle has scratch areas for: nep_batch_reserve_row_scratch");
   if (flags & NEP_FLAG_ENT_BETA) return fail(NEP_E_ARG, "an entangle state passed to the front end has a non-zero beta for an agent crossing (the reference's calculateBetaForCase makes it 0.0)");
   if (flags & NEP_FLAG_HULL_OVERFLOW) return fail(NEP_E_CAP, "an interval overlaps more than NEP_HULL_MAX_CP/4 committed segments (or its hull has more than NEP_HULL_MAX_V vertices)");
   return 0;

@@ -76,7 +76,9 @@ struct ProblemSet {
   const int* order;              // [slots] workgroup -> slot (longest expected solve first, see order_kernel) or null: identity
   int* order_key;                // [slots] this launch's measured device time in 8 us bins (the next launch's ordering key) or null
   // QP scratch when the row state does not fit LDS
-  double* row_scratch;           // [slots][2][rows_cap]
+  double* row_scratch;           // [slots or scratch_chunks][11][rows_cap / 4 + 2]
+  int scratch_chunks;            // 0: one scratch area per slot.  > 0 (presolve with the redo pass): that many areas, used by the redo pass only, by launch index
+  int scratch_by_block;          // 1: this launch addresses the scratch by blockIdx.x (the redo pass)
   int rows_cap;
   int lds_rows;                  // rows that fit the dynamic LDS carve
   int lds_lines;
@@ -89,6 +91,7 @@ struct ProblemSet {
   int* flags;                    // [1] sticky NEP_FLAG_* bits raised by the kernels (capacity overflows), or null
   double* fe_box;                // [scenes][num_agents + n_static][num_pol][4] (x0, x1, y0, y1) of the front end's obstacles (fe_box_kernel)
 };
+constexpr int NEP_FLAG_SCRATCH = 4;         // more replans went through the presolve's redo pass with rows beyond the register slots than the handle has scratch areas for (nep_batch_reserve_row_scratch)
 constexpr int NEP_FLAG_ENT_BETA = 2;        // an entangle state handed to the front end carries a non-zero beta for an agent crossing (the reference's rule makes it 0.0)
 constexpr int NEP_FLAG_HULL_OVERFLOW = 1;   // an interval overlapped more committed segments than NEP_HULL_MAX_CP / 4, or its hull has more than NEP_HULL_MAX_V vertices
 

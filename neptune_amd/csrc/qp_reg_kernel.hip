@@ -118,7 +118,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   const unsigned lds0 = __builtin_amdgcn_groupstaticsize();
   const lds_ptr ldyn = (lds_ptr)(unsigned int)(lds0 + (kFixedDoubles + 32) * sizeof(double));
   const int GL = ps.rows_cap / 4 + 2;
-  double* __restrict__ gsp = ps.row_scratch + (long)slot * (11L * GL);
+  double* __restrict__ gsp = ps.row_scratch + (long)(ps.scratch_by_block ? (int)blockIdx.x : slot) * (11L * GL);      // (the redo pass of a handle with pooled scratch: one area per listed replan)
   // phase cycle counters (make PROFILE=1, scripts/qp_phases.py): thread 0's clock, accumulated in 16 LDS words behind the carve
 #ifdef NEP_PROFILE_PHASES
   long long* sProf = (long long*)(smem + kFixedDoubles + 32 + 3 * NS);
@@ -176,6 +176,19 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       else { sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0; sI[43] = over; sI[40] = nsk; sI[25] = 0; }
     }
     __syncthreads();
+    if (ps.scratch_chunks > 0 && __builtin_amdgcn_readfirstlane(sI[43]) != 0) {
+      // rows beyond the register slots, on a handle whose row scratch is a small pool for the redo pass (the presolve's default: the
+      // near lines of a replan fit the slots nearly always).  First pass: the replan goes to the redo pass as it is, unsolved;
+      // redo pass: its area is the one of its place on the list — a list longer than the pool is flagged, those replans fail.
+      if (CULL && ps.redo_count) {
+        if (tid == 0) { sI[26] = 1; const int idx = atomicAdd(ps.redo_count, 1); ps.redo_list[idx] = slot; atomicAdd(ps.redo_count + 3, 1); }      // ([3]: listed unsolved, for the test hook)
+        break;
+      }
+      if (!ps.scratch_by_block || (int)blockIdx.x >= ps.scratch_chunks) {
+        if (tid == 0 && ps.flags) atomicOr(ps.flags, NEP_FLAG_SCRATCH);
+        break;
+      }
+    }
     // (values every thread reads from LDS are wave-uniform: readfirstlane moves them, and what is computed from them, to SGPRs)
     const int L = __builtin_amdgcn_readfirstlane(sI[NEP_MAX_POL]);
     L_used = L; L_all = __builtin_amdgcn_readfirstlane(sI[42]);
@@ -989,7 +1002,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       __syncthreads();
       const bool v_far = __builtin_amdgcn_readfirstlane(sI[21]) != 0, v_move = __builtin_amdgcn_readfirstlane(sI[25]) != 0;
       if (!v_far && !v_move) break;
-      if (n_skip > 0) {
+      if (n_skip > 0 || (ps.scratch_chunks > 0 && ps.redo_count)) {      // (pooled scratch: the second attempt's rows would not fit the slots — the redo pass has the room)
         // lines are missing from the buckets, so the full problem cannot be posed here: the redo pass solves every LP of this
         // replan and every row (separator_redo_kernel, then this kernel without the presolve); the solution written below is
         // overwritten by that pass whatever its outcome, but the COMMIT record is not written here at all (sI[26]): if the redo

@@ -44,7 +44,16 @@ def main():
     print("  K histogram", np.bincount(sol["K"].astype(int), minlength=9).tolist(), " front-end status", np.bincount(res["status"].astype(int), minlength=4).tolist())
     print("  share of the launch's workgroup time: ball rows %.1f %%, relaxed + failed %.1f %%" % (100 * us[(qc == 1)].sum() / us.sum(), 100 * us[status > 0].sum() / us.sum()))
     for s_ in np.argsort(-us)[:12]:
-        print("   slot %5d  %7.1f us  status %d iters %2d first %2d  K %d lines %3d rows %4d qc %d" % (s_, us[s_], status[s_], it[s_], itf[s_], sol["K"][s_], st["n_lines"][s_], st["n_rows"][s_], qc[s_]))
+        print("   slot %5d  %7.1f us  status %d iters %2d first %2d  K %d lines %3d rows %4d qc %d  fe status %d feK %d dist %.2f" % (s_, us[s_], status[s_], it[s_], itf[s_], sol["K"][s_], st["n_lines"][s_], st["n_rows"][s_], qc[s_], res["status"][s_], res["K"][s_], res["dist_to_goal"][s_]))
+    slow = us > 400
+    print("  workgroups above 400 us: %d; by front-end status %s; by front-end K %s" % (slow.sum(), np.bincount(res["status"][slow].astype(int), minlength=4).tolist(), np.bincount(res["K"][slow].astype(int), minlength=9).tolist()))
+    print("  all: front-end K histogram %s" % np.bincount(res["K"].astype(int), minlength=9).tolist())
+    g = d_g.cpu().numpy().view(abi.GUESS_DTYPE); co = np.array(g["coeff"])
+    T = p.T_span
+    v_end = np.hypot(3 * co[:, 0, 7, 0] * T * T + 2 * co[:, 0, 7, 1] * T + co[:, 0, 7, 2], 3 * co[:, 1, 7, 0] * T * T + 2 * co[:, 1, 7, 1] * T + co[:, 1, 7, 2])
+    v0 = np.hypot(co[:, 0, 0, 2], co[:, 1, 0, 2]); a0 = 2 * np.hypot(co[:, 0, 0, 1], co[:, 1, 0, 1])
+    for nm, arr in (("end speed of the guess", v_end), ("start speed", v0), ("start accel", a0)):
+        print("  %-24s slow: mean %.2f p10 %.2f p90 %.2f | all: mean %.2f p10 %.2f p90 %.2f" % (nm, arr[slow].mean(), np.percentile(arr[slow], 10), np.percentile(arr[slow], 90), arr.mean(), np.percentile(arr, 10), np.percentile(arr, 90)))
 
 
 

@@ -391,3 +391,50 @@ def test_lp_skipping_is_off_for_statics_that_are_not_box_edged(be):
         bb.close()
     assert n_lines["diamonds"][1] == n_lines["diamonds"][0]          # nothing skipped: every line was made
     assert n_lines["squares"][1] < n_lines["squares"][0]             # box-edged statics: far LPs never solved
+
+
+def test_row_scratch_is_a_pool_with_the_redo_pass(be):
+    """Round-3 review (memory worst-case sized): with the presolve's redo pass the row scratch is a pool of 1 024 areas used by that
+    pass only — a replan whose near lines exceed the register slots goes there unsolved.  96 agents + 20 obstacles, 16 scenes
+    (1 536 slots, ~97 lines per segment): (a) the default presolve gives the unculled optimum from a pool a fraction of the
+    per-slot size; (b) with a 60 m radius every line is "near": all 1 536 replans are listed, more than the pool holds — the
+    overflow is flagged by nep_batch_check (NEP_E_CAP), never silent; (c) after nep_batch_reserve_row_scratch the same launch
+    solves them all."""
+    from neptune_amd._lib import BackendError
+    from neptune_amd import dist as ndist
+    S = 16
+    scs = scene.make_scenes(96, 20, range(40, 40 + S), workers=16)
+    p = scs[0]["par"]
+    com, gue = ndist.stack_scenes(scs)
+
+    def handle():
+        b = be.BatchBackend(p, scs[0]["statics"], n_scenes=S)
+        for s_ in range(S):
+            b.set_scene_statics(s_, scs[s_]["statics"])
+        return b
+    bf = handle(); bf.set_line_cull(0.0)
+    bf.replan(bf.to_device(com), bf.to_device(gue))
+    full = bf.solutions().copy(); full_bytes = bf.row_scratch_bytes(); bf.close()
+    bb = handle(); bb.set_line_cull(4.0)
+    assert bb.row_scratch_bytes() * 1536 == full_bytes * 1024          # 1 024 areas instead of one per slot
+    d_com = bb.to_device(com); d_gue = bb.to_device(gue)
+    bb.replan(d_com, d_gue)
+    bb.check()
+    cul = bb.solutions().copy()
+    np.testing.assert_array_equal(cul["stats"]["status"], full["stats"]["status"])
+    assert np.abs(np.array(cul["coeff"]) - np.array(full["coeff"])).max() < 1e-7
+    bb.set_line_cull(60.0)
+    bb.replan(d_com, d_gue)
+    assert bb.redo_count() == S * 96
+    with pytest.raises(BackendError):
+        bb.check()
+    st = bb.solutions()["stats"]["status"]
+    assert (st == 2).sum() >= S * 96 - 1024 and (st != 2).sum() >= 1000          # the listed replans beyond the pool failed, the pool's were solved
+    bb.reserve_row_scratch()
+    assert bb.row_scratch_bytes() == full_bytes
+    bb.replan(d_com, d_gue)
+    bb.check()
+    sol = bb.solutions()
+    np.testing.assert_array_equal(sol["stats"]["status"], full["stats"]["status"])
+    assert np.abs(np.array(sol["coeff"]) - np.array(full["coeff"])).max() < 1e-7
+    bb.close()
