@@ -1950,8 +1950,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
           FE_ENT_T(0);
         }
         my_free++;
-        s_state[id] = 4;                                        // (awaiting its propagation)
-        p_list[atomicAdd(&s_i[3], 1)] = (unsigned short)id;
+        s_state[id] = 4;                                        // (awaiting its propagation: listed in id order after the barrier)
       } else {
         my_free++;
         settle_voxel(id, ch, 0u);
@@ -2039,6 +2038,24 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     __syncthreads();
     FE_TICK(3);
     if constexpr (ENT) {
+      // the survivors in id order (a block-wide prefix sum over the marks): neighbouring threads then propagate children of the SAME
+      // parent — the same starting list, the same candidate agents, nearly the same crossings — so a wave's lanes follow one path
+      // through the list surgery instead of 64, and their record loads fall on the same lines
+      {
+        const int per = (n_c + 255) >> 8;
+        int cnt = 0;
+        for (int k = 0; k < per; k++) { const int id = tid * per + k; cnt += (id < n_c && s_state[id] == 4) ? 1 : 0; }
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(incl, o); if ((tid & 63) >= o) incl += y; }
+        if ((tid & 63) == 63) s_i[20 + (tid >> 6)] = incl;
+        __syncthreads();
+        int off = incl - cnt;
+        for (int w = 0; w < (tid >> 6); w++) off += s_i[20 + w];
+        for (int k = 0; k < per; k++) { const int id = tid * per + k; if (id < n_c && s_state[id] == 4) p_list[off++] = (unsigned short)id; }
+        if (tid == 255) s_i[3] = off;
+        __syncthreads();
+      }
       const int n_prop = s_i[3];
       int n_merge = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2 + kFeCap) - sizeof(unsigned short) * kFeCap) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS (o_aabb, o_V, r_f without p_list)
       if (n_merge > 256) n_merge = 256;

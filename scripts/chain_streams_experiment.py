@@ -14,7 +14,8 @@ if __name__ == "__main__":
     p = scs[0]["par"]
     com, gue = ndist.stack_scenes(scs)
     starts = np.stack([scene.frontend_starts(s) for s in scs])
-    cfg = scene.frontend_cfg(p, beam_width=32)
+    MOVING = os.environ.get("NEP_MOVING") == "1"        # the closed loop (bench.py's `moving` leg) instead of the chain
+    cfg = scene.frontend_cfg(p, beam_width=32, pad_hold=1 if MOVING else 0)
     dev = torch.device("cuda", 0)
     STAGGER = len(sys.argv) > 2 and sys.argv[2] == "stagger"
     for G in (1, 2, 4, 8):
@@ -33,6 +34,7 @@ if __name__ == "__main__":
         d_nxt = [torch.empty_like(d_com[k]) for k in range(G)]
         d_acc = [torch.zeros(Sg * N, dtype=torch.int32, device=dev) for k in range(G)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
+        d_alt = [torch.from_numpy(np.ascontiguousarray(starts[sl[k]]["pos"].reshape(Sg * N, 3)).copy()).to(dev) for k in range(G)]
 
         def step():
             cur = torch.cuda.current_stream(dev)
@@ -47,6 +49,8 @@ if __name__ == "__main__":
                     bes[k].replan(None, d_gfe[k])
                     bes[k].safety_commit(d_com[k], bes[k].d_commit, d_gfe[k], d_nxt[k], d_acc[k])
                     d_com[k].copy_(d_nxt[k])
+                    if MOVING:
+                        bes[k].next_starts(d_com[k], p.T_span, d_st[k], d_alt[k], 0.5)
             for k in range(G):
                 cur.wait_stream(streams[k])
         for _ in range(3):
