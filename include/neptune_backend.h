@@ -412,6 +412,13 @@ int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap); 
  * NEP_E_CAP; nep_batch_reserve_row_scratch switches the handle to one area per slot for good.  Setters that change the mode
  * (nep_batch_set_line_cull, nep_batch_set_separator_rule) re-size the scratch: never call them inside a graph capture.        */
 int nep_batch_reserve_row_scratch(nep_batch_t* h);
+/* Separating lines a (replan, segment) bucket holds.  The reference's worst case is n_hull + N + S + 8 N (one line per hull, base,
+ * static and (agent, bend segment) pair of the entangle rows); by default the buckets budget 2 N entangle lines per segment instead
+ * of 8 N (an entangle line needs an active case for that agent and segment).  A segment that gets more raises a sticky flag —
+ * nep_batch_check returns NEP_E_CAP, nothing is written past a bucket — and (h, -1) sizes for the worst case; (h, n) sets n; (h, 0)
+ * the default.  Re-sizes buffers: never inside a graph capture.                                                              */
+int nep_batch_set_line_capacity(nep_batch_t* h, int32_t lines_per_segment);
+int64_t nep_batch_line_bucket_bytes(nep_batch_t* h);
 int64_t nep_batch_row_scratch_bytes(nep_batch_t* h);
 /* Diagnostic ("how hard are these problems"): inequality rows of the QP (solver_gurobi_poly.cpp:433-489) whose slack at the
  * solutions of the last nep_batch_replan* is below tol: d_out [slots][2] int32 = (box rows, separating-line rows) per slot.

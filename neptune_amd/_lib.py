@@ -21,7 +21,7 @@ EXPORTS = [
     "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
     "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_gjk_batch",
     "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks", "nep_comm_reserve", "nep_batch_exchange_slots", "nep_batch_set_ent_samples",
-    "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records", "nep_batch_set_max_runtime", "nep_batch_qp_placement", "nep_batch_set_launch_order", "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_get_line_cull", "nep_inflate_static", "nep_batch_debug_redo_count", "nep_batch_debug_redo_list", "nep_batch_debug_set_separator_pack", "nep_batch_active_rows", "nep_batch_reserve_row_scratch", "nep_batch_row_scratch_bytes", "nep_backend_debug_time_sequence", "nep_separator_batch_rule", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule", "nep_batch_set_tolerances", "nep_backend_set_tolerances",
+    "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records", "nep_batch_set_max_runtime", "nep_batch_qp_placement", "nep_batch_set_launch_order", "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_get_line_cull", "nep_inflate_static", "nep_batch_debug_redo_count", "nep_batch_debug_redo_list", "nep_batch_debug_set_separator_pack", "nep_batch_active_rows", "nep_batch_reserve_row_scratch", "nep_batch_set_line_capacity", "nep_batch_line_bucket_bytes", "nep_batch_row_scratch_bytes", "nep_backend_debug_time_sequence", "nep_separator_batch_rule", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule", "nep_batch_set_tolerances", "nep_backend_set_tolerances",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
@@ -105,6 +105,8 @@ def lib():
     L.nep_batch_debug_set_separator_pack.argtypes = [vp, i]
     L.nep_batch_active_rows.argtypes = [vp, vp, d, vp, vp]
     L.nep_batch_reserve_row_scratch.argtypes = [vp]
+    L.nep_batch_set_line_capacity.argtypes = [vp, i]
+    L.nep_batch_line_bucket_bytes.argtypes = [vp]; L.nep_batch_line_bucket_bytes.restype = C.c_int64
     L.nep_batch_row_scratch_bytes.argtypes = [vp]; L.nep_batch_row_scratch_bytes.restype = C.c_int64
     L.nep_backend_debug_time_sequence.argtypes = [vp, vp, i, pi, pd, pi, pd, vp, d, d, i, pd, pd]
     L.nep_batch_set_max_runtime.argtypes = [vp, d]

@@ -389,6 +389,13 @@ class BatchBackend:
         """one worst-case row-scratch area per slot instead of the redo pass's pool (nep_batch_reserve_row_scratch)"""
         check(lib().nep_batch_reserve_row_scratch(self._h))
 
+    def set_line_capacity(self, lines_per_segment):
+        """lines a (replan, segment) bucket holds: 0 default budget, -1 the reference's worst case, n > 0 (nep_batch_set_line_capacity)"""
+        check(lib().nep_batch_set_line_capacity(self._h, int(lines_per_segment)))
+
+    def line_bucket_bytes(self):
+        return int(lib().nep_batch_line_bucket_bytes(self._h))
+
     def row_scratch_bytes(self):
         return int(lib().nep_batch_row_scratch_bytes(self._h))
 

@@ -149,6 +149,7 @@ struct Engine {
   // nep_batch_reserve_row_scratch asks for the worst case.
   static constexpr int kScratchPool = 1024;
   bool scratch_full = false; int scratch_chunks = 0;
+  int lines_cap_user = 0;      // 0: the default budget; -1: the reference's worst case; n > 0: n lines per segment (nep_batch_set_line_capacity)
   bool skip_mode() const { return sp.cull_radius > 0.0 && use_reg && sp.sep_rule == 0 && sp.skip_own == 1 && sp.n_hull == sp.num_agents && skip_lps && statics_boxy && !no_redo; }
   int size_row_scratch() {
     const long slots = (long)n_scenes * sp.n_local;
@@ -166,9 +167,17 @@ struct Engine {
   int size_scratch() {
     const int N = sp.num_agents, np = sp.num_pol;
     const long slots = (long)n_scenes * sp.n_local;
-    sp.lines_cap = sp.n_hull + N + sp.n_static + (sp.ent_enabled ? N * kBend : 0);
+    // Lines a segment's bucket holds.  The reference's worst case is one line per other agent's hull, per base, per static and per
+    // (agent, bend segment) pair of the entangle rows — n_hull + N + S + 8 N.  The last term is by far the largest (2 048 of 2 660 at
+    // config 5) and an entangle line needs an ACTIVE case for that agent and segment, which a tenth of the pairs have in the
+    // survey's scenes: by default the buckets budget 2 N entangle lines per segment (config 5: 1 124 instead of 2 660, 1.8 GB
+    // instead of 4.2 per 32 scenes).  A segment that gets more is flagged (nep_batch_check: NEP_E_CAP), never written past its
+    // bucket; nep_batch_set_line_capacity(h, -1) restores the worst case, (h, n) sets n.
+    const int worst_lines = sp.n_hull + N + sp.n_static + (sp.ent_enabled ? N * kBend : 0);
+    if ((long)NEP_MAX_POL * worst_lines > 65535) return fail(NEP_E_CAP, "more than 65535 separator candidates per agent");
+    sp.lines_cap = lines_cap_user < 0 ? worst_lines : (lines_cap_user > 0 ? lines_cap_user : sp.n_hull + N + sp.n_static + (sp.ent_enabled ? std::min(N * kBend, std::max(2 * N, 64)) : 0));
+    if (sp.lines_cap > worst_lines) sp.lines_cap = worst_lines;
     if (sp.lines_cap < 8) sp.lines_cap = 8;
-    if ((long)NEP_MAX_POL * sp.lines_cap > 65535) return fail(NEP_E_CAP, "more than 65535 separator candidates per agent");
     const long lines_total = (long)NEP_MAX_POL * sp.lines_cap;
     // LDS carve of the QP kernel: 11 doubles per line (n1, n2, h + 4 x (s, lambda)).  The worst case
     // (every base and every obstacle close to every segment) almost never happens, so the carve is
@@ -512,6 +521,7 @@ nep_backend_t* nep_backend_create(const nep_backend_cfg* cfg) {
   E.sp.num_agents = cfg->num_agents; E.sp.num_pol = cfg->num_pol; E.sp.n_static = 0; E.sp.n_hull = 0; E.sp.ent_enabled = 0;
   E.sp.n_local = 1; E.sp.first_local = cfg->id - 1; E.sp.skip_own = 0; E.sp.T_span = cfg->T_span; E.sp.weight = cfg->weight_term;
   E.sp.drone_radius = 0; E.n_scenes = 1;
+  E.lines_cap_user = -1;      // (one replan at a time: the buckets are sized for the reference's worst case, there is no flag to poll)
   E.set_clock();
   HIPCHK_NULL(hipStreamCreate(&h->stream));
   if (h->lay_out(cfg->num_agents > 8 ? cfg->num_agents : 8)) { delete h; return nullptr; }
@@ -1279,6 +1289,15 @@ int nep_batch_reserve_row_scratch(nep_batch_t* h) {
   HIPCHK(hipDeviceSynchronize());
   return h->eng.size_row_scratch();
 }
+// Lines per (replan, segment) the line buckets hold: 0 the default budget, -1 the reference's worst case, n > 0 that many (see
+// size_scratch).  Re-sizes the buffers: not inside a graph capture.
+int nep_batch_set_line_capacity(nep_batch_t* h, int32_t lines_per_segment) {
+  if (!h || lines_per_segment < -1) return fail(NEP_E_ARG, "bad arguments");
+  HIPCHK(hipDeviceSynchronize());
+  h->eng.lines_cap_user = lines_per_segment;
+  return h->eng.size_scratch();
+}
+int64_t nep_batch_line_bucket_bytes(nep_batch_t* h) { return h ? (int64_t)h->slots * NEP_MAX_POL * h->eng.sp.lines_cap * 3 * (int64_t)sizeof(double) : 0; }
 int64_t nep_batch_row_scratch_bytes(nep_batch_t* h) { return h ? (int64_t)(h->eng.d_row_scratch.n * sizeof(double)) : 0; }
 int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule) {
   if (!h || (rule != 0 && rule != 1)) return fail(NEP_E_ARG, "separator rule: 0 largest gap, 1 GLPK-class simplex");
@@ -1316,6 +1335,7 @@ int nep_batch_check(nep_batch_t* h, void* stream) {
     HIPCHK(hipMemcpy(&flags, h->eng.d_flags.p, sizeof(int), hipMemcpyDeviceToHost));
     if (flags) HIPCHK(hipMemset(h->eng.d_flags.p, 0, sizeof(int)));
   }
+  if (flags & NEP_FLAG_LINES) return fail(NEP_E_CAP, "a segment got more separating lines than its bucket holds: nep_batch_set_line_capacity(h, -1) sizes the buckets for the reference's worst case");
   if (flags & NEP_FLAG_SCRATCH) return fail(NEP_E_CAP, "the presolve's redo pass listed more replans with rows beyond the register slots than the handle has scratch areas for: nep_batch_reserve_row_scratch");
   if (flags & NEP_FLAG_ENT_BETA) return fail(NEP_E_ARG, "an entangle state passed to the front end has a non-zero beta for an agent crossing (the reference's calculateBetaForCase makes it 0.0)");
   if (flags & NEP_FLAG_HULL_OVERFLOW) return fail(NEP_E_CAP, "an interval overlaps more than NEP_HULL_MAX_CP/4 committed segments (or its hull has more than NEP_HULL_MAX_V vertices)");

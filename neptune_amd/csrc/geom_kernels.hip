@@ -940,13 +940,15 @@ __device__ __forceinline__ void separator_body(const SceneParams& sp, const Prob
       const unsigned long long below = (1ull << lane) - 1ull;
       if (active) {
         const long pos = far ? (long)sp.lines_cap - 1 - (n_far + __popcll(mf & below)) : (long)n_near + __popcll(mn & below);
-        bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2];
+        if (pos >= 0 && pos < sp.lines_cap) { bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2]; }      // (a bucket smaller than the worst case: an overflow is flagged below, never written past the bucket)
       }
       n_near += __popcll(mn); n_far += __popcll(mf);
     }
   }
   for (int o = 32; o > 0; o >>= 1) n_fail += __shfl_xor(n_fail, o);
   if (lane == 0) {
+    const bool spill = cull ? n_near + n_far > sp.lines_cap : n_att > sp.lines_cap;
+    if (spill) { if (ps.flags) atomicOr(ps.flags, NEP_FLAG_LINES); if (n_near > sp.lines_cap) n_near = sp.lines_cap; if (n_far > sp.lines_cap - n_near) n_far = sp.lines_cap - n_near; }
     *cnt_out = cull ? n_near : (n_att < sp.lines_cap ? n_att : sp.lines_cap);
     if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = cull ? n_far : 0;
     if (ps.line_skip) ps.line_skip[(long)slot * NEP_MAX_POL + seg] = n_skip;
@@ -1044,7 +1046,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         if (mine) {
           double* bucket = ps.line_nd + ((long)slot * NEP_MAX_POL + s_) * sp.lines_cap * 3;
           const long pos = far ? (long)sp.lines_cap - 1 - (base_f + __popcll(mf & below)) : (long)base_n + __popcll(mn & below);
-          bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2];
+          if (pos >= 0 && pos < sp.lines_cap) { bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2]; }
         }
         __syncthreads();
         if (lane == 0) { sCnt[s_ * 6] = base_n + __popcll(mn); sCnt[s_ * 6 + 1] = base_f + __popcll(mf); sCnt[s_ * 6 + 2] += __popcll(mx); }
@@ -1129,8 +1131,10 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   if (lane < seg_hi - seg_lo) {
     const int seg = seg_lo + lane;
     const long o = (long)slot * NEP_MAX_POL + seg;
-    ps.line_cnt[o] = sCnt[seg * 6];
-    if (ps.line_far) ps.line_far[o] = sCnt[seg * 6 + 1];
+    int cn_ = sCnt[seg * 6], cf_ = sCnt[seg * 6 + 1];
+    if (cn_ + cf_ > sp.lines_cap) { if (ps.flags) atomicOr(ps.flags, NEP_FLAG_LINES); if (cn_ > sp.lines_cap) cn_ = sp.lines_cap; if (cf_ > sp.lines_cap - cn_) cf_ = sp.lines_cap - cn_; }      // (bucket smaller than the worst case: flagged)
+    ps.line_cnt[o] = cn_;
+    if (ps.line_far) ps.line_far[o] = cf_;
     if (ps.line_skip) ps.line_skip[o] = sCnt[seg * 6 + 4];
     ps.lp_stats[o * 2] = sCnt[seg * 6 + 3] + sCnt[seg * 6 + 4]; ps.lp_stats[o * 2 + 1] = sCnt[seg * 6 + 2];
   }

@@ -91,6 +91,7 @@ struct ProblemSet {
   int* flags;                    // [1] sticky NEP_FLAG_* bits raised by the kernels (capacity overflows), or null
   double* fe_box;                // [scenes][num_agents + n_static][num_pol][4] (x0, x1, y0, y1) of the front end's obstacles (fe_box_kernel)
 };
+constexpr int NEP_FLAG_LINES = 8;           // a segment got more separating lines than its bucket holds (nep_batch_set_line_capacity)
 constexpr int NEP_FLAG_SCRATCH = 4;         // more replans went through the presolve's redo pass with rows beyond the register slots than the handle has scratch areas for (nep_batch_reserve_row_scratch)
 constexpr int NEP_FLAG_ENT_BETA = 2;        // an entangle state handed to the front end carries a non-zero beta for an agent crossing (the reference's rule makes it 0.0)
 constexpr int NEP_FLAG_HULL_OVERFLOW = 1;   // an interval overlapped more committed segments than NEP_HULL_MAX_CP / 4, or its hull has more than NEP_HULL_MAX_V vertices

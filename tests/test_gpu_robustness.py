@@ -438,3 +438,37 @@ def test_row_scratch_is_a_pool_with_the_redo_pass(be):
     np.testing.assert_array_equal(sol["stats"]["status"], full["stats"]["status"])
     assert np.abs(np.array(sol["coeff"]) - np.array(full["coeff"])).max() < 1e-6
     bb.close()
+
+
+def test_line_buckets_smaller_than_the_worst_case_flag_an_overflow(be):
+    """The line buckets budget 2 N entangle lines per segment instead of the worst case's 8 N (nep_batch_set_line_capacity).  A
+    segment that gets more lines than its bucket holds is flagged by nep_batch_check and nothing is written past a bucket; the
+    default budget gives the worst-case sizing's result bit for bit on a scene with entangle rows."""
+    import dataclasses
+    from neptune_amd._lib import BackendError
+    sc = scene.make_scene(24, 12, seed=33)
+    case = scene.synthetic_entangle(sc, seed=733, frac=0.3)
+    p = dataclasses.replace(sc["par"], enable_entangle=True)
+    bb = be.BatchBackend(p, sc["statics"])
+    d_com = bb.to_device(sc["committed"]); d_gue = bb.to_device(sc["guesses"])
+    d_ent = bb.torch.from_numpy(np.ascontiguousarray(case).reshape(-1)).to(bb.device)
+    worst = 24 + 24 + 12 + 8 * 24
+    assert bb.line_bucket_bytes() == 24 * 8 * (24 + 24 + 12 + 64) * 24          # default: 2 N -> max(2 N, 64) entangle lines
+    for cull in (0.0, 2.0):
+        bb.set_line_cull(cull)
+        bb.set_line_capacity(0)
+        bb.replan(d_com, d_gue, d_ent=d_ent); bb.check()
+        ref = bb.solutions().copy()
+        bb.set_line_capacity(-1)
+        assert bb.line_bucket_bytes() == 24 * 8 * worst * 24
+        bb.replan(d_com, d_gue, d_ent=d_ent); bb.check()
+        assert bb.solutions().tobytes() == ref.tobytes()
+        if cull == 0.0:                                            # (with the presolve the far LPs are not even solved: few lines are made)
+            bb.set_line_capacity(8)                                # far too small: ~30 lines per segment
+            bb.replan(d_com, d_gue, d_ent=d_ent)
+            with pytest.raises(BackendError):
+                bb.check()
+            bb.replan(d_com, d_gue, d_ent=d_ent)                   # (sticky until read; a second launch raises it again)
+            with pytest.raises(BackendError):
+                bb.check()
+    bb.close()
