@@ -486,8 +486,8 @@ def main():
                 print("[bench] rank %d of %d: native RCCL communicator has %d ranks" % (rank, world, mine_n), file=sys.stderr)
                 if mine_n != world or any(n_ != world for n_ in nranks):
                     raise SystemExit("native RCCL communicator: ranks joined %r, expected %d on every rank" % (nranks, world))
-        elif world > 1:
-            nranks = [tdist.get_world_size()] * world
+        elif use_dist and dist_backend == "nccl":
+            nranks = [tdist.get_world_size()] * world      # (N = 1: the one-rank process group this run created)
 
         def start_exchange(k, src):
             """hulls of my agents' committed trajectories (chunk k) -> start the all-gather of the hull blocks"""
@@ -729,6 +729,46 @@ def main():
                                     "its goal is the antipodal point (the start of the agent opposite), arrived agents turn around — the fleet crosses the middle of "
                                     "the world together, against the scene's static obstacles.  The hard leg: see active_rows, failed_frac, ipm_iters")
             crossing = run_cross(args.chain_cull_radius)
+            # ---- moving, as two scene groups on two streams inside the one captured step: the tail of one group's kernels (the QP
+            # launch ends with a handful of failing solves of ~1.2 ms each on an otherwise empty GPU) runs beside the other group's
+            # kernels.  Same scenes, same results; what a deployment that keeps several fleets in flight does ------------------
+            if S % 2 == 0 and not args.no_graph:
+                Sg = S // 2
+                gb = []
+                for k_ in range(2):
+                    b_ = BatchBackend(p, statics, n_scenes=Sg, device=dev)
+                    for s_ in range(Sg):
+                        b_.set_scene_statics(s_, all_statics[k_ * Sg + s_])
+                    b_.set_line_cull(args.chain_cull_radius)
+                    gb.append(b_)
+                g_st = [gb[k_].to_device(np.ascontiguousarray(starts_np[k_ * Sg:(k_ + 1) * Sg])) for k_ in range(2)]
+                g_alt = [torch.from_numpy(np.ascontiguousarray(starts_np[k_ * Sg:(k_ + 1) * Sg]["pos"].reshape(Sg * N, 3)).copy()).to(dev) for k_ in range(2)]
+                g_com = [gb[k_].to_device(np.ascontiguousarray(com[k_ * Sg:(k_ + 1) * Sg])) for k_ in range(2)]
+                g_nxt = [torch.empty_like(g_com[k_]) for k_ in range(2)]
+                g_gfe = [torch.zeros(Sg * N * abi.GUESS_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
+                g_res = [torch.zeros(Sg * N * abi.FE_RESULT_DTYPE.itemsize, dtype=torch.uint8, device=dev) for _ in range(2)]
+                g_acc = [torch.zeros(Sg * N, dtype=torch.int32, device=dev) for _ in range(2)]
+                g_streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+                def two_group_step():
+                    cur_ = torch.cuda.current_stream(dev)
+                    for k_ in range(2):
+                        g_streams[k_].wait_stream(cur_)
+                        with torch.cuda.stream(g_streams[k_]):
+                            gb[k_].frontend(cfg_mv, g_com[k_], g_st[k_], g_gfe[k_], g_res[k_])
+                            gb[k_].replan(None, g_gfe[k_])
+                            gb[k_].safety_commit(g_com[k_], gb[k_].d_commit, g_gfe[k_], g_nxt[k_], g_acc[k_])
+                            g_com[k_].copy_(g_nxt[k_])
+                            gb[k_].next_starts(g_com[k_], p.T_span, g_st[k_], g_alt[k_], 0.5)
+                    for k_ in range(2):
+                        cur_.wait_stream(g_streams[k_])
+                dtg, msg, gg = run_leg(two_group_step, gb, aux_steps, max(args.warmup, 2), eager_after=0)
+                solg = np.concatenate([b_.solutions() for b_ in gb])
+                moving["two_groups"] = leg_record(dtg, aux_steps, msg, graph=gg is not None, ipm_iters_mean=float(solg["stats"]["iters"].mean()),
+                                                  note="the moving leg's step with the scenes in two groups of %d on two streams inside one captured graph" % Sg,
+                                                  **status_counts(solg))
+                for b_ in gb:
+                    b_.close()
             # ---- both again with the verified presolve (what a deployment runs, and the handle's default at config-5 size) ----
             if args.chain_cull_radius == 0.0 and args.presolve_radius > 0.0:
                 be.set_line_cull(args.presolve_radius)

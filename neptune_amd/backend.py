@@ -236,7 +236,10 @@ class BatchBackend:
 
     def close(self):
         if getattr(self, "_h", None):
-            lib().nep_batch_destroy(self._h)
+            try:
+                lib().nep_batch_destroy(self._h)
+            except TypeError:          # (interpreter shutdown: the module globals are gone)
+                pass
             self._h = None
 
     __del__ = close
