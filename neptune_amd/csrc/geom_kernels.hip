@@ -1624,11 +1624,12 @@ __device__ __forceinline__ void fe_child_again(const SceneParams& sp, const nep_
 // LDS arrays are sized for the configured beam width (not the maximum), so that narrower beams leave room for
 // more workgroups per CU: cap = beam_width * num_samples^2 candidates per depth, hash tables a power of two above
 // 1.25x (per-depth voxel table) / 2x (visited voxels, beam_width * num_pol keys) their load.
-struct FeSizes { int cap, dd, vis; };
+struct FeSizes { int cap, dd, vis, mb; };
 __host__ __device__ inline FeSizes fe_sizes(int beam_width, int num_samples, int num_pol) {
   FeSizes z; z.cap = beam_width * num_samples * num_samples; if (z.cap < 64) z.cap = 64;
   z.dd = 64; while (z.dd * 4 < z.cap * 5) z.dd *= 2;
   z.vis = 64; while (z.vis < 2 * beam_width * num_pol) z.vis *= 2;
+  z.mb = beam_width <= 32 ? 32 : NEP_FE_MAX_BEAM;      // stride of the per-rank arrays (the beam's width rounded up: a width-32 beam does not pay for 64 ranks of LDS)
   return z;
 }
 constexpr unsigned long long kFeEmpty = ~0ull;
@@ -1708,26 +1709,31 @@ __global__ __launch_bounds__(256) void ent_pack_kernel(SceneParams sp, ProblemSe
 #ifndef NEP_FE_ENT_WGS
 #define NEP_FE_ENT_WGS 2      // workgroups per CU of the entangle instantiation: 2 = working records in global memory, registers bounded to 256 (19.9 ms per 2 048 config-5 searches); 1 = working records in LDS, 139 KB (27.4 ms: the list surgery is latency-bound, a second workgroup hides more than LDS saves)
 #endif
-template <bool ENT>
-__global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
+template <bool ENT, int WGS>
+__global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
                                                        nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out, FeEntArgs ea) {
   extern __shared__ __attribute__((aligned(16))) double fe_smem[];
   const int tid = threadIdx.x;
   const int slot = blockIdx.x, scene = slot / sp.n_local, own = sp.first_local + (slot % sp.n_local);
   const int N = sp.num_agents, S = sp.n_static, W = fc.beam_width, ns = fc.num_samples, NC = ns * ns, D = sp.num_pol;
   const FeSizes fz = fe_sizes(W, ns, D);
-  const int kFeCap = fz.cap, kFeDd = fz.dd, kFeVis = fz.vis;
+  const int kFeCap = fz.cap, kFeDd = fz.dd, kFeVis = fz.vis, MB = fz.mb;
   // ---- LDS carve ----
   double* s_f = fe_smem;                                   // [kFeCap] f of candidate id
   double* b_end = s_f + kFeCap;                            // [2][64][6]
-  double* b_g = b_end + 2 * NEP_FE_MAX_BEAM * 6;           // [2][64]
-  double* b_dist = b_g + 2 * NEP_FE_MAX_BEAM;              // [64]
-  double* b_f = b_dist + NEP_FE_MAX_BEAM;                  // [64]
-  double* p_box = b_f + NEP_FE_MAX_BEAM;                   // [64][4] box of every parent's children
-  double* o_aabb = p_box + NEP_FE_MAX_BEAM * 4;            // [N+S][4] boxes of the shortlisted obstacles, dense
+  double* b_g = b_end + 2 * MB * 6;           // [2][64]
+  double* b_dist = b_g + 2 * MB;              // [64]
+  double* b_f = b_dist + MB;                  // [64]
+  double* p_box = b_f + MB;                   // [64][4] box of every parent's children
+  double* o_aabb = p_box + MB * 4;            // [N+S][4] boxes of the shortlisted obstacles, dense
   double* o_V = o_aabb + 4 * (N + S);                      // [kFeObsLds][16][2] their vertices (GJK walks them several times)
-  double* r_f = o_V + kFeObsLds * kHullV * 2;              // [kFeCap] f of the voxel winners, dense (ENT: behind o_aabb and o_V, with which its head is lent to the crossing lists)
-  double* s_lat = r_f + kFeCap;                            // [4][NEP_FE_MAX_SAMPLES] lattice tables
+  // [kFeCap] f of the voxel winners, dense: written by the compaction and read by the rank count, when the shortlist's boxes and
+  // vertices are dead — without the entangle check it lives in their storage when they are big enough (6.4 KB of the 51 a search
+  // held: with the per-rank arrays at the beam's width the carve drops below 40 KB, four workgroups per CU instead of three); with
+  // it behind them, its head lent together with them to the crossing lists
+  const bool rf_alias = !ENT && 4 * (N + S) + kFeObsLds * kHullV * 2 >= kFeCap;
+  double* r_f = rf_alias ? o_aabb : o_V + kFeObsLds * kHullV * 2;
+  double* s_lat = o_V + kFeObsLds * kHullV * 2 + (rf_alias ? 0 : kFeCap);   // [4][NEP_FE_MAX_SAMPLES] lattice tables
   long long* s_vox = (long long*)(s_lat + 4 * NEP_FE_MAX_SAMPLES);   // [kFeCap]
   unsigned long long* v_key = (unsigned long long*)(s_vox + kFeCap);   // [kFeVis] visited voxels
   int* d_slot = (int*)(v_key + kFeVis);                    // [kFeDd] voxel -> best candidate of the depth
@@ -1737,7 +1743,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
   unsigned short* r_id = (unsigned short*)(s_i + 32);      // [kFeCap] ids of the voxel winners, dense
   unsigned char* s_state = (unsigned char*)(r_id + kFeCap);   // [kFeCap] 0 dead, 1 alive, 2 lost its voxel
   signed char* p_parent = (signed char*)(s_state + kFeCap);   // [NEP_MAX_POL + 1][64]
-  signed char* p_comb = p_parent + (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM;
+  signed char* p_comb = p_parent + (NEP_MAX_POL + 1) * MB;
 
   const nep_fe_start* st = starts + slot;
   const double gx = st->goal[0], gy = st->goal[1];
@@ -1745,14 +1751,14 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
   EntCtx ec;
   nep_fe_ent_state* my_work = nullptr;
   unsigned char* ent_lists = nullptr;
-  unsigned char* b_valid = (unsigned char*)(p_comb + (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM);   // [64] may a plan end at this rank
+  unsigned char* b_valid = (unsigned char*)(p_comb + (NEP_MAX_POL + 1) * MB);   // [64] may a plan end at this rank
   auto ent_node = [&](int d, int r) -> nep_fe_ent_state* { return ea.nodes + (((long)slot * (D + 1) + d) * W + r); };
   // ENT: per parent of the depth at hand, who can matter to ANY of its children (bit sets over the agents / statics; filled next
   // to the shortlist from the parent's children box, see there)
   const int MW = (N + 31) >> 5, SW = (S + 31) >> 5;
-  unsigned* m_ent = (unsigned*)(b_valid + NEP_FE_MAX_BEAM + ((4 - ((3 * kFeCap) & 3)) & 3));      // [64][MW] agents whose tether a child's step may cross (aligned: every array before r_id is a multiple of four bytes)
-  unsigned* m_base = m_ent + NEP_FE_MAX_BEAM * MW;               // [64][MW] agents whose base square a child may be near
-  unsigned* m_stat = m_base + NEP_FE_MAX_BEAM * MW;              // [64][SW] static representatives a child's step may cross
+  unsigned* m_ent = (unsigned*)(b_valid + MB + ((4 - ((3 * kFeCap) & 3)) & 3));      // [64][MW] agents whose tether a child's step may cross (aligned: every array before r_id is a multiple of four bytes)
+  unsigned* m_base = m_ent + MB * MW;               // [64][MW] agents whose base square a child may be near
+  unsigned* m_stat = m_base + MB * MW;              // [64][SW] static representatives a child's step may cross
   if constexpr (ENT) {
     ec.N = N; ec.S = S; ec.own = own; ec.num_pol = D; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = fc.cable_length;
     ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
@@ -1765,7 +1771,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     // the crossing lists of the children being merged (phase two of the propagation pass) live where the shortlist's boxes and
     // vertices and the winners' f values are: dead between a depth's GJK pass and its compaction / the next depth's shortlist
     ent_lists = (unsigned char*)o_aabb;      // [n_merge][kEntLdsBytes]
-    my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(m_stat + NEP_FE_MAX_BEAM * SW) + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
+    my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(m_stat + MB * SW) + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
     if (tid == 0) {
       nep_fe_ent_state* root = ent_node(0, 0);
       if (ea.init) {
@@ -1775,7 +1781,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
         for (int i = 0; i < root->n_alpha && i < NEP_FE_ENT_CAP; i++) if (root->id[i] <= N && root->beta[i] != 0.0 && ps.flags) atomicOr(ps.flags, NEP_FLAG_ENT_BETA);
       } else { long* z = (long*)root; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
     }
-    if (tid < NEP_FE_MAX_BEAM) b_valid[tid] = 1;
+    if (tid < MB) b_valid[tid] = 1;
   }
   int my_entangled = 0, my_overflow = 0;
 #ifdef NEP_PROFILE_PHASES
@@ -1839,7 +1845,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
   };
   if (tid == 0) children_box(b_end, 0);
   for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
-  if constexpr (ENT) { for (int k = tid; k < NEP_FE_MAX_BEAM * (2 * MW + SW); k += 256) m_ent[k] = 0u; }
+  if constexpr (ENT) { for (int k = tid; k < MB * (2 * MW + SW); k += 256) m_ent[k] = 0u; }
   __syncthreads();
   for (depth = 1; depth <= D; depth++) {
     const int cur = depth & 1, prv = cur ^ 1;
@@ -1963,7 +1969,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     auto propagate = [&](int id) {      // ENT, part two (see above)
       const int pr_ = id / NC, cc = id % NC;
       FeChild ch;
-      fe_child_again<true>(sp, fc, lat, b_end + (prv * NEP_FE_MAX_BEAM + pr_) * 6, b_g[prv * NEP_FE_MAX_BEAM + pr_], cc / ns, cc % ns, gx, gy, ch);
+      fe_child_again<true>(sp, fc, lat, b_end + (prv * MB + pr_) * 6, b_g[prv * MB + pr_], cc / ns, cc % ns, gx, gy, ch);
       EntLds L;
       {
         typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
@@ -1977,7 +1983,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
       { FE_ENT_T0(); rc = ent_propagate(ec, &L, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
       if (rc) { my_entangled++; if (rc == 2) my_overflow = 1; s_state[id] = 0; return; }
       ent_lds_store(ea.saved + ((long)slot * kFeCap + id), L, N); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
-      ch.g = b_g[prv * NEP_FE_MAX_BEAM + pr_] + arc;
+      ch.g = b_g[prv * MB + pr_] + arc;
       ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)L.n_alpha) + 1.0 * (double)L.n_bend);
       settle_voxel(id, ch, ent_iz(&L));
     };
@@ -1989,8 +1995,8 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     };
     for (int id = tid; id < n_c; id += 256) {
       const int pr = id / NC, cc = id % NC;
-      const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
-      const double pg = b_g[prv * NEP_FE_MAX_BEAM + pr];
+      const double* pe = b_end + (prv * MB + pr) * 6;
+      const double pg = b_g[prv * MB + pr];
       FeChild ch;
       my_children++;
       s_state[id] = 0;
@@ -2028,7 +2034,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
       const int pr = id / NC, cc = id % NC;
       unsigned long long cand_mask = (unsigned long long)s_vox[id];
       FeChild ch;
-      fe_child_again<true>(sp, fc, lat, b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6, b_g[prv * NEP_FE_MAX_BEAM + pr], cc / ns, cc % ns, gx, gy, ch);
+      fe_child_again<true>(sp, fc, lat, b_end + (prv * MB + pr) * 6, b_g[prv * MB + pr], cc / ns, cc % ns, gx, gy, ch);
       Pts4 B;
 #pragma unroll
       for (int i = 0; i < 4; i++) { B.x[i] = ch.Qx[i]; B.y[i] = ch.Qy[i]; }
@@ -2101,8 +2107,8 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
       if (same > 1) { for (int b = 0; b < n_b; b++) rank += (r_f[b] == fi && (int)r_id[b] < i) ? 1 : 0; }
       if (rank < W) {   // recompute the child (same arithmetic) and install it
         const int pr = i / NC, cc = i % NC;
-        const double* pe = b_end + (prv * NEP_FE_MAX_BEAM + pr) * 6;
-        const double pg = b_g[prv * NEP_FE_MAX_BEAM + pr];
+        const double* pe = b_end + (prv * MB + pr) * 6;
+        const double pg = b_g[prv * MB + pr];
         FeChild ch;
         fe_child_again<false>(sp, fc, lat, pe, pg, cc / ns, cc % ns, gx, gy, ch);
         if constexpr (ENT) {   // the same propagation again, this time into the node's own record
@@ -2116,11 +2122,11 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
           b_valid[rank] = ent_valid_endpoint(nd, N) ? 1 : 0;
         }
 #pragma unroll
-        for (int q = 0; q < 6; q++) b_end[(cur * NEP_FE_MAX_BEAM + rank) * 6 + q] = ch.e[q];
+        for (int q = 0; q < 6; q++) b_end[(cur * MB + rank) * 6 + q] = ch.e[q];
         children_box(ch.e, rank);                         // (what the next depth's shortlist tests the obstacles against)
-        b_g[cur * NEP_FE_MAX_BEAM + rank] = ch.g; b_dist[rank] = ch.dist; b_f[rank] = ch.f;
-        p_parent[depth * NEP_FE_MAX_BEAM + rank] = (signed char)(depth == 1 ? -1 : pr);
-        p_comb[depth * NEP_FE_MAX_BEAM + rank] = (signed char)cc;
+        b_g[cur * MB + rank] = ch.g; b_dist[rank] = ch.dist; b_f[rank] = ch.f;
+        p_parent[depth * MB + rank] = (signed char)(depth == 1 ? -1 : pr);
+        p_comb[depth * MB + rank] = (signed char)cc;
         const unsigned long long vox = (unsigned long long)s_vox[i];      // close the voxel to later depths
         for (unsigned h = fe_hash((long long)vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long o = atomicCAS(&v_key[h], kFeEmpty, vox); if (o == kFeEmpty || o == vox) break; }
       }
@@ -2129,7 +2135,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     if (tid == 0) { s_i[0] = 0; s_i[2] = 0; s_i[3] = 0; }
     for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
     __syncthreads();
-    if constexpr (ENT) { for (int k = tid; k < NEP_FE_MAX_BEAM * (2 * MW + SW); k += 256) m_ent[k] = 0u; __syncthreads(); }      // (read by the installs above, filled again by the next depth)
+    if constexpr (ENT) { for (int k = tid; k < MB * (2 * MW + SW); k += 256) m_ent[k] = 0u; __syncthreads(); }      // (read by the installs above, filled again by the next depth)
     FE_TICK(6);
     if (nb == 0) { status = depth == 1 ? NEP_FE_NO_SOLUTION : NEP_FE_EMPTY; break; }
     nb_prev = nb;
@@ -2159,7 +2165,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
       pe[0] = st->pos[0]; pe[1] = st->pos[1]; pe[2] = st->vel[0]; pe[3] = st->vel[1]; pe[4] = st->accel[0]; pe[5] = st->accel[1];
       signed char path[NEP_MAX_POL];
       int r = best_rank;
-      for (int d = best_depth; d >= 1; d--) { path[d - 1] = p_comb[d * NEP_FE_MAX_BEAM + r]; r = p_parent[d * NEP_FE_MAX_BEAM + r]; }
+      for (int d = best_depth; d >= 1; d--) { path[d - 1] = p_comb[d * MB + r]; r = p_parent[d * MB + r]; }
       for (int d = 1; d <= best_depth; d++) {   // replay the path from the root with the same arithmetic
         FeChild ch;
         fe_child(sp, fc, lat, pe, pg, d == 1, path[d - 1] / ns, path[d - 1] % ns, gx, gy, bx, by, ch);
@@ -2183,7 +2189,7 @@ __global__ __launch_bounds__(256, ENT ? NEP_FE_ENT_WGS : NEP_FE_WAVES) void fron
     }
     if constexpr (ENT) {   // ranks of the path's nodes, for the case rows below
       int r = best_rank;
-      for (int d = best_depth; d >= 1; d--) { s_i[16 + d] = r; r = p_parent[d * NEP_FE_MAX_BEAM + r]; }
+      for (int d = best_depth; d >= 1; d--) { s_i[16 + d] = r; r = p_parent[d * MB + r]; }
       s_i[16] = 0; s_i[15] = best_rank >= 0 ? best_depth : -1; s_i[14] = best_rank >= 0 ? guess_out[slot].K : 0;
     }
   }
@@ -2259,14 +2265,17 @@ void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const
   hipLaunchKernelGGL(gjk_explicit_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, st, n_prob, a_off, a_xy, b_xy, hit);
 }
 
+static bool getenv_fe_three() { static const bool v = getenv("NEP_FE_THREE") != nullptr; return v; }      // (A/B: keep the three-workgroup instantiation)
 size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol) { return (size_t)fe_sizes(fc.beam_width, fc.num_samples, num_pol).cap; }
 size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc, bool ent) {
   const size_t NS = (size_t)sp.num_agents + sp.n_static;
   const FeSizes z = fe_sizes(fc.beam_width, fc.num_samples, sp.num_pol);
-  size_t b = sizeof(double) * (2 * (size_t)z.cap + 2 * NEP_FE_MAX_BEAM * 6 + 2 * NEP_FE_MAX_BEAM + 2 * NEP_FE_MAX_BEAM + 4 * NEP_FE_MAX_BEAM + 4 * NS + kFeObsLds * kHullV * 2 + 4 * NEP_FE_MAX_SAMPLES)
+  const size_t MB = (size_t)z.mb;
+  const bool rf_alias = !ent && 4 * NS + kFeObsLds * kHullV * 2 >= (size_t)z.cap;      // (as in the kernel's carve)
+  size_t b = sizeof(double) * ((size_t)z.cap * (rf_alias ? 1 : 2) + 2 * MB * 6 + 2 * MB + 2 * MB + 4 * MB + 4 * NS + kFeObsLds * kHullV * 2 + 4 * NEP_FE_MAX_SAMPLES)
            + sizeof(long long) * ((size_t)z.cap + z.vis) + sizeof(int) * (z.dd + 2 * NS + 32)
-           + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * NEP_FE_MAX_BEAM + NEP_FE_MAX_BEAM;
-  if (ent) b = ((b + 3) & ~(size_t)3) + sizeof(unsigned) * NEP_FE_MAX_BEAM * (2 * (size_t)((sp.num_agents + 31) >> 5) + (size_t)((sp.n_static + 31) >> 5)) + (NEP_FE_ENT_WGS == 1 ? 256 * sizeof(nep_fe_ent_state) + 8 : 0);
+           + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * MB + MB;
+  if (ent) b = ((b + 3) & ~(size_t)3) + sizeof(unsigned) * MB * (2 * (size_t)((sp.num_agents + 31) >> 5) + (size_t)((sp.n_static + 31) >> 5)) + (NEP_FE_ENT_WGS == 1 ? 256 * sizeof(nep_fe_ent_state) + 8 : 0);
   return (b + 15) & ~(size_t)15;
 }
 
@@ -2275,8 +2284,12 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
   if (n_slots <= 0) return;
   const bool ent = ea != nullptr;
   const size_t lds = frontend_lds_bytes(sp, fc, ent);
-  static DynLdsAttr attr[2];
-  (void)attr[ent].ensure(ent ? (const void*)frontend_kernel<true> : (const void*)frontend_kernel<false>, lds);
+  // a search whose LDS leaves room for four workgroups on a CU (160 KB / 4) runs the instantiation bounded to 128 registers
+  // (11 spilled); larger ones — more obstacles, a wider beam — the one bounded for three
+  const bool four = !ent && lds <= (size_t)40 * 1024 && !getenv_fe_three();
+  static DynLdsAttr attr[3];
+  const void* fn = ent ? (const void*)frontend_kernel<true, NEP_FE_ENT_WGS> : four ? (const void*)frontend_kernel<false, 4> : (const void*)frontend_kernel<false, NEP_FE_WAVES>;
+  (void)attr[ent ? 0 : four ? 1 : 2].ensure(fn, lds);
   FeEntArgs none{};
   launch_boxes(n_slots / (sp.n_local > 0 ? sp.n_local : 1), sp, ps, st);
   if (ent && ea->packed) {
@@ -2284,8 +2297,9 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
     const long np_ = (long)n_scenes * sp.num_agents * sp.num_pol;
     hipLaunchKernelGGL(ent_pack_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, st, sp, ps, *ea, n_scenes);
   }
-  if (ent) hipLaunchKernelGGL(frontend_kernel<true>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
-  else hipLaunchKernelGGL(frontend_kernel<false>, dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
+  if (ent) hipLaunchKernelGGL((frontend_kernel<true, NEP_FE_ENT_WGS>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
+  else if (four) hipLaunchKernelGGL((frontend_kernel<false, 4>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
+  else hipLaunchKernelGGL((frontend_kernel<false, NEP_FE_WAVES>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
 }
 
 // Neptune::SamplePointsOfIntervals (neptune.cpp:500-565) for every committed trajectory of every scene:
