@@ -1707,7 +1707,7 @@ __global__ __launch_bounds__(256) void ent_pack_kernel(SceneParams sp, ProblemSe
 }
 
 #ifndef NEP_FE_ENT_WGS
-#define NEP_FE_ENT_WGS 2      // workgroups per CU of the entangle instantiation: 2 = working records in global memory, registers bounded to 256 (19.9 ms per 2 048 config-5 searches); 1 = working records in LDS, 139 KB (27.4 ms: the list surgery is latency-bound, a second workgroup hides more than LDS saves)
+#define NEP_FE_ENT_WGS 3      // (round 4: 3 = 168 registers, 48 spilled, 52 KB of LDS at config 5) // workgroups per CU of the entangle instantiation: 2 = working records in global memory, registers bounded to 256 (19.9 ms per 2 048 config-5 searches); 1 = working records in LDS, 139 KB (27.4 ms: the list surgery is latency-bound, a second workgroup hides more than LDS saves)
 #endif
 template <bool ENT, int WGS>
 __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
@@ -1728,10 +1728,10 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
   double* o_aabb = p_box + MB * 4;            // [N+S][4] boxes of the shortlisted obstacles, dense
   double* o_V = o_aabb + 4 * (N + S);                      // [kFeObsLds][16][2] their vertices (GJK walks them several times)
   // [kFeCap] f of the voxel winners, dense: written by the compaction and read by the rank count, when the shortlist's boxes and
-  // vertices are dead — without the entangle check it lives in their storage when they are big enough (6.4 KB of the 51 a search
-  // held: with the per-rank arrays at the beam's width the carve drops below 40 KB, four workgroups per CU instead of three); with
-  // it behind them, its head lent together with them to the crossing lists
-  const bool rf_alias = !ENT && 4 * (N + S) + kFeObsLds * kHullV * 2 >= kFeCap;
+  // vertices are dead — it lives in their storage when they are big enough (6.4 KB of the 51 a search held: with the per-rank arrays
+  // at the beam's width the carve drops below 40 KB, four workgroups per CU instead of three; with the entangle check, where the same
+  // storage is lent to the crossing lists in between, below 53 KB at config 5: three instead of two)
+  const bool rf_alias = 4 * (N + S) + kFeObsLds * kHullV * 2 >= kFeCap;
   double* r_f = rf_alias ? o_aabb : o_V + kFeObsLds * kHullV * 2;
   double* s_lat = o_V + kFeObsLds * kHullV * 2 + (rf_alias ? 0 : kFeCap);   // [4][NEP_FE_MAX_SAMPLES] lattice tables
   long long* s_vox = (long long*)(s_lat + 4 * NEP_FE_MAX_SAMPLES);   // [kFeCap]
@@ -1925,12 +1925,12 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
     const int n_c = nb_prev * NC;
     if (tid == 0) s_i[1] = 0;                              // (the winners' counter: last read in the previous depth's rank phase)
     // ENT: settling a collision-free child is split in two.  Part one (here, by whoever examined the child) is the base-square test;
-    // a survivor goes on the propagation list (p_list, in the tail of r_f's storage: free until the winners are compacted).  Part two — copy
+    // a survivor is marked and, after the barrier, listed (p_list, in r_id's storage: free until the winners are compacted).  Part two — copy
     // of the parent's entangle state, entanglesWithOtherAgents, the voxel — runs after a barrier over that DENSE list, one
     // survivor per thread: the propagation is two orders of magnitude dearer than anything else a child costs and only a fifth of
     // the children reach it, so examined in place the threads that drew two or three survivors kept the others waiting (pass 1 was
     // 65 % of a config-5 search, its critical path three propagations per depth instead of one).
-    unsigned short* p_list = (unsigned short*)(r_f + kFeCap) - kFeCap;      // (the LAST kFeCap shorts of r_f: its head is lent to the crossing lists)
+    unsigned short* p_list = r_id;      // (the GJK work list has been consumed when the survivors are listed; the winners are compacted after the propagation)
     auto settle_voxel = [&](int id, FeChild& ch, unsigned iz) {
       const long long vox = ENT ? (long long)(((unsigned long long)(unsigned short)ch.vx << 48) | ((unsigned long long)(unsigned short)ch.vy << 32) | iz)
                                 : (((long long)ch.vx << 32) | (unsigned int)ch.vy);
@@ -2067,8 +2067,9 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         __syncthreads();
       }
       const int n_prop = s_i[3];
-      int n_merge = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2 + kFeCap) - sizeof(unsigned short) * kFeCap) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS (o_aabb, o_V, r_f without p_list)
+      int n_merge = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2 + (rf_alias ? 0 : kFeCap))) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS (o_aabb, o_V and, when it has storage of its own, r_f)
       if (n_merge > 256) n_merge = 256;
+      { const int rounds = (n_prop + n_merge - 1) / n_merge; if (rounds > 1) n_merge = (n_prop + rounds - 1) / rounds; }      // (even rounds: 178 survivors are 89 + 89, not 131 + 47)
       for (int b0 = 0; b0 < n_prop; b0 += n_merge) {             // that many survivors at a time, one per thread
         if (tid < n_merge && b0 + tid < n_prop) propagate(p_list[b0 + tid]);
         __syncthreads();
@@ -2271,7 +2272,7 @@ size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc, bool ent)
   const size_t NS = (size_t)sp.num_agents + sp.n_static;
   const FeSizes z = fe_sizes(fc.beam_width, fc.num_samples, sp.num_pol);
   const size_t MB = (size_t)z.mb;
-  const bool rf_alias = !ent && 4 * NS + kFeObsLds * kHullV * 2 >= (size_t)z.cap;      // (as in the kernel's carve)
+  const bool rf_alias = 4 * NS + kFeObsLds * kHullV * 2 >= (size_t)z.cap;      // (as in the kernel's carve)
   size_t b = sizeof(double) * ((size_t)z.cap * (rf_alias ? 1 : 2) + 2 * MB * 6 + 2 * MB + 2 * MB + 4 * MB + 4 * NS + kFeObsLds * kHullV * 2 + 4 * NEP_FE_MAX_SAMPLES)
            + sizeof(long long) * ((size_t)z.cap + z.vis) + sizeof(int) * (z.dd + 2 * NS + 32)
            + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * MB + MB;
