@@ -36,6 +36,8 @@ if __name__ == "__main__":
         streams = [torch.cuda.Stream(device=dev) for _ in range(G)]
         d_alt = [torch.from_numpy(np.ascontiguousarray(starts[sl[k]]["pos"].reshape(Sg * N, 3)).copy()).to(dev) for k in range(G)]
 
+        R = int(os.environ.get("NEP_ROUNDS", "1"))       # rounds of every group inside one captured graph (the groups drift apart: one's QP tail beside another's front end)
+
         def step():
             cur = torch.cuda.current_stream(dev)
             fe_done = None
@@ -44,13 +46,15 @@ if __name__ == "__main__":
                 if STAGGER and fe_done is not None:
                     streams[k].wait_event(fe_done)          # the front ends one after the other: each back end runs next to the following group's front end
                 with torch.cuda.stream(streams[k]):
-                    bes[k].frontend(cfg, d_com[k], d_st[k], d_gfe[k], d_res[k])
-                    fe_done = torch.cuda.Event(); fe_done.record(streams[k])
-                    bes[k].replan(None, d_gfe[k])
-                    bes[k].safety_commit(d_com[k], bes[k].d_commit, d_gfe[k], d_nxt[k], d_acc[k])
-                    d_com[k].copy_(d_nxt[k])
-                    if MOVING:
-                        bes[k].next_starts(d_com[k], p.T_span, d_st[k], d_alt[k], 0.5)
+                    for r_ in range(R):
+                        bes[k].frontend(cfg, d_com[k], d_st[k], d_gfe[k], d_res[k])
+                        if r_ == 0:
+                            fe_done = torch.cuda.Event(); fe_done.record(streams[k])
+                        bes[k].replan(None, d_gfe[k])
+                        bes[k].safety_commit(d_com[k], bes[k].d_commit, d_gfe[k], d_nxt[k], d_acc[k])
+                        d_com[k].copy_(d_nxt[k])
+                        if MOVING:
+                            bes[k].next_starts(d_com[k], p.T_span, d_st[k], d_alt[k], 0.5)
             for k in range(G):
                 cur.wait_stream(streams[k])
         for _ in range(3):
@@ -66,6 +70,6 @@ if __name__ == "__main__":
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         st = np.concatenate([b.solutions()["stats"]["status"] for b in bes]).astype(int)
-        print("groups %d: %.4f ms/step, %.0f replans/s (status %s)" % (G, dt / 40 * 1e3, S * N * 40 / dt, np.bincount(st, minlength=3).tolist()), flush=True)
+        print("groups %d, %d rounds per graph%s: %.4f ms/round, %.0f replans/s (status %s)" % (G, R, " staggered" if STAGGER else "", dt / 40 / R * 1e3, S * N * 40 * R / dt, np.bincount(st, minlength=3).tolist()), flush=True)
         for b in bes:
             b.close()
