@@ -191,6 +191,12 @@ __device__ __forceinline__ bool ent_scan_stops(int t_id, int t_cs, int l_id, int
 struct EntLds;
 template <class ST> struct ent_lazy_beta { static constexpr bool v = false; };
 template <> struct ent_lazy_beta<EntLds> { static constexpr bool v = true; };
+// A 64-bit signature of the ids on a list (bit id mod 64): the cancellation scan of a new crossing and the per-agent counts walk the
+// whole list looking for entries of ONE id, and nearly always there is none (a crossing with somebody not crossed before is the
+// common case) — a clear bit proves that without the walk.  Kept by the LDS view only (set on append, rebuilt on erase).
+template <class ST> __device__ __forceinline__ bool ent_sig_may_have(const ST*, int) { return true; }
+template <class ST> __device__ __forceinline__ void ent_sig_add(ST*, int) { }
+template <class ST> __device__ __forceinline__ void ent_sig_rebuild(ST*) { }
 template <class ST> __device__ void ent_erase(ST* st, int j, int N) {
   constexpr bool lazy = ent_lazy_beta<ST>::v;
   for (int k = j; k + 1 < st->n_alpha; k++) {
@@ -212,6 +218,7 @@ template <class ST> __device__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 p
       const int t_id = (int)(t_w & 0xffffu), t_cs = (int)((t_w >> 16) & 0xffu);
       const bool agent = t_id <= c.N;
       const int t_nb = agent ? (int)(t_w >> 24) : 0;
+      if (!ent_sig_may_have(st, t_id)) continue;      // (every match needs an entry of the same id: there is none)
       for (int j = st->n_alpha - 1; j >= 0; j--) {
         const int l_id = st->id[j], l_cs = st->cs[j];
         const bool match = (l_id == t_id && l_cs == t_cs) ||
@@ -220,6 +227,7 @@ template <class ST> __device__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 p
         if (match) {
           add.remove(i);
           ent_erase(st, j, c.N);
+          ent_sig_rebuild(st);
           if (j == b) {
             st->n_bend--;
             const Ev2 bp = ent_cur_bend(st, pb_self, c);
@@ -239,7 +247,7 @@ template <class ST> __device__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 p
   if (st->n_alpha + add.n > NEP_FE_ENT_CAP) return true;
   const Ev2 bp = ent_cur_bend(st, pb_self, c);
   for (int i = 0; i < add.n; i++) {
-    st->id[st->n_alpha] = (short)add.id(i); st->cs[st->n_alpha] = (signed char)add.cs(i);
+    st->id[st->n_alpha] = (short)add.id(i); st->cs[st->n_alpha] = (signed char)add.cs(i); ent_sig_add(st, add.id(i));
     if (!ent_lazy_beta<ST>::v || add.id(i) > c.N) st->beta[st->n_alpha] = ent_beta(add.id(i), add.cs(i), pk, bp, c);
     st->n_alpha++;
   }
@@ -355,7 +363,7 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
       // only ever touches entries of the agents in `add`, so theirs are the only counts that can differ: the old ones are
       // taken before the merge, for those agents only — no copy of the old list, no pass over every pair of entries.
       EntAdd chk; chk.n = 0; chk.overflow = 0; const int a_n = add.n;      // (id, entries of that agent before the merge)
-      for (int e = 0; e < a_n; e++) { const int id_ = add.id(e); ent_push(chk, id_, id_ <= c.N ? ent_count(st->id, st->n_alpha, id_) : 0); }
+      for (int e = 0; e < a_n; e++) { const int id_ = add.id(e); ent_push(chk, id_, (id_ <= c.N && ent_sig_may_have(st, id_)) ? ent_count(st->id, st->n_alpha, id_) : 0); }
       if (ent_merge(add, st, pk, pb_self, c)) return 2;
       for (int e = 0; e < a_n; e++) {
         const int id_ = chk.id(e);
@@ -391,13 +399,17 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
 // surgery code is a template over the two.
 typedef __attribute__((address_space(3))) short* ent_lds_short;
 typedef __attribute__((address_space(3))) signed char* ent_lds_char;
-struct EntLds { int n_alpha, n_bend; ent_lds_short id; ent_lds_char cs; double* beta; ent_lds_char bend; };
+struct EntLds { int n_alpha, n_bend; ent_lds_short id; ent_lds_char cs; double* beta; ent_lds_char bend; unsigned long long sig; };
+template <> __device__ __forceinline__ bool ent_sig_may_have<EntLds>(const EntLds* st, int id) { return (st->sig >> (id & 63)) & 1ull; }
+template <> __device__ __forceinline__ void ent_sig_add<EntLds>(EntLds* st, int id) { st->sig |= 1ull << (id & 63); }
+template <> __device__ __forceinline__ void ent_sig_rebuild<EntLds>(EntLds* st) { unsigned long long g = 0ull; for (int i = 0; i < st->n_alpha; i++) g |= 1ull << (st->id[i] & 63); st->sig = g; }
 constexpr int kEntLdsBytes = ((NEP_FE_ENT_CAP * 3 + NEP_MAX_BEND + 3) & ~3) | 4;      // per thread; an odd number of dwords, so that the threads' lists fall into different banks
 __device__ __forceinline__ void ent_lds_load(EntLds& L, const nep_fe_ent_state* __restrict__ src, int N) {
   L.n_alpha = src->n_alpha; L.n_bend = src->n_bend;
-  for (int i = 0; i < L.n_alpha; i++) { L.id[i] = src->id[i]; L.cs[i] = src->cs[i]; }
+  unsigned long long g = 0ull;
+  for (int i = 0; i < L.n_alpha; i++) { const int id_ = src->id[i]; L.id[i] = (short)id_; L.cs[i] = src->cs[i]; g |= 1ull << (id_ & 63); if (id_ > N) L.beta[i] = src->beta[i]; }      // (betas of statics only: see ent_lazy_beta)
+  L.sig = g;
   for (int i = 0; i < L.n_bend; i++) L.bend[i] = src->bend[i];
-  for (int i = 0; i < L.n_alpha; i++) if (src->id[i] > N) L.beta[i] = src->beta[i];      // (statics only: see ent_lazy_beta)
 }
 __device__ __forceinline__ void ent_lds_store(nep_fe_ent_state* __restrict__ dst, const EntLds& L, int N) {
   dst->n_alpha = L.n_alpha; dst->n_bend = L.n_bend;
