@@ -156,8 +156,39 @@ __device__ __forceinline__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev
   if (base_addition && add.n >= 2 && ((add.get(add.n - 1) ^ add.get(add.n - 2)) & 0xffffffu) == 0u) add.n -= 2;      // (same id, same case)
 }
 __device__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, const EntCtx& c) {
+  if (c.m_static) {
+    // (front end: the candidates of this parent in index order, the NEXT one's representative requested before the current one's
+    // wedges are evaluated — as for the agents, ent_propagate)
+    const int SWn = (c.S + 31) >> 5;
+    auto next_cand = [&](int from) -> int {
+      for (int w = from >> 5; w < SWn; w++) {
+        unsigned m = c.m_static[w];
+        if (w == (from >> 5)) m &= ~0u << (from & 31);
+        if (m) { const int i = (w << 5) + __ffs(m) - 1; return i < c.S ? i : c.S; }
+      }
+      return c.S;
+    };
+    int s = next_cand(0);
+    const double2* r = (const double2*)(c.srep + (long)(s < c.S ? s : 0) * 4);
+    double2 q0 = r[0], q1 = r[1];
+    while (s < c.S) {
+      const int sn = next_cand(s + 1);
+      const double2* rn = (const double2*)(c.srep + (long)(sn < c.S ? sn : 0) * 4);
+      const double2 n0 = rn[0], n1 = rn[1];
+      const Ev2 pik{q1.x, q1.y}, pbi{q0.x, q0.y};
+      Ev2 u, v;
+      const double c1 = ent_wedge2(pk, pik, pbi, u, v), c2 = ent_wedge(pk1, pik, pbi);
+      if (c1 * c2 < 0) {
+        const double a = ent_ratio(u, v);
+        if (a < 0) { }
+        else if (a < 1) ent_push(add, c.N + s + 1, 1);
+        else ent_push(add, c.N + s + 1, 0);
+      }
+      s = sn; q0 = n0; q1 = n1;
+    }
+    return;
+  }
   for (int s = 0; s < c.S; s++) {
-    if (c.m_static && !((c.m_static[s >> 5] >> (s & 31)) & 1u)) { s |= 31 * !c.m_static[s >> 5]; continue; }   // (an empty word is skipped whole)
     const Ev2 pik = ent_srep(c, s, 1), pbi = ent_srep(c, s, 0);
     Ev2 u, v;
     const double c1 = ent_wedge2(pk, pik, pbi, u, v), c2 = ent_wedge(pk1, pik, pbi);
