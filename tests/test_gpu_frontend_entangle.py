@@ -40,7 +40,9 @@ def _run_frontend(be, sc, W, inits=None):
 
 
 @pytest.mark.parametrize("n_agents,n_static,seed,W,stride", [(8, 6, 60, 16, 1), (8, 6, 56, 32, 1), (16, 8, 61, 16, 1),
-                                                             (72, 40, 63, 16, 6)])      # (more than one 32-bit word of agents and of statics in the kernel's per-parent masks; every sixth agent against the oracle)
+                                                             (72, 40, 63, 16, 6),       # (more than one 32-bit word of agents and of statics in the kernel's per-parent masks; every sixth agent against the oracle)
+                                                             (5, 0, 64, 64, 1),         # (round 4: the widest beam — per-rank arrays at 64 — in a scene too small for the LDS aliasing of the winners' f values)
+                                                             (16, 8, 65, 48, 2)])
 def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_static, seed, W, stride):
     sc = scene.tether_crossing_scene(n_agents, n_static, seed)
     p = sc["par"]; N = n_agents

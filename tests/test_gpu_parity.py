@@ -869,6 +869,31 @@ def test_frontend_multi_scene_and_agent_shard(be, oracle):
         bb.close()
 
 
+@pytest.mark.parametrize("n_agents,n_static,seed,W", [(5, 0, 3, 64), (5, 0, 4, 8), (64, 20, 2, 48), (24, 12, 9, 33)])
+def test_frontend_beam_widths_and_small_scenes(be, oracle, n_agents, n_static, seed, W):
+    """The front end's LDS carve depends on the beam's width (per-rank arrays at 32 or 64) and on the scene's size (the winners'
+    f values live in the shortlist's storage when that is big enough; four or three workgroups per CU): widths either side of
+    32, the widest, and a scene too small for the aliasing — guesses, cost and status against the oracle, bit for bit."""
+    sc = scene.make_scene(n_agents, n_static, seed=seed)
+    p = sc["par"]; N = n_agents
+    fe = scene.frontend_cfg(p, beam_width=W)
+    starts = scene.frontend_starts(sc)
+    bb = be.BatchBackend(p, sc["statics"])
+    d_guess = bb.torch.zeros(N * abi.GUESS_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
+    d_res = bb.torch.zeros(N * abi.FE_RESULT_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
+    bb.frontend(fe, bb.to_device(sc["committed"]), bb.to_device(starts), d_guess, d_res)
+    bb.torch.cuda.synchronize()
+    got_g = d_guess.cpu().numpy().view(abi.GUESS_DTYPE); got_r = d_res.cpu().numpy().view(abi.FE_RESULT_DTYPE)
+    for a in range(0, N, max(1, N // 8)):
+        hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(starts[a]["t_start"]), sc["statics"])
+        g, r = oracle.frontend_beam(p, fe, a + 1, starts[a], hx, hn, sc["statics"])
+        for f in ("status", "K", "n_children", "n_feasible", "n_collision_free"):
+            assert int(got_r[a][f]) == r[f], (a, f)
+        assert float(got_r[a]["cost"]) == r["cost"]
+        np.testing.assert_array_equal(np.array(got_g[a]["coeff"]), np.array(g["coeff"]), err_msg="agent %d" % a)
+    bb.close()
+
+
 @pytest.mark.parametrize("n_agents,n_static,seed,min_reached", [(8, 6, 5, 8), (16, 8, 1, 16), (64, 20, 0, 64)])
 def test_closed_loop_fleet_flies_to_its_goals_without_collisions(be, n_agents, n_static, seed, min_reached):
     """Everything together (neptune_amd/loop.py): point A from the plan deque -> front-end guess -> separating
