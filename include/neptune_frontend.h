@@ -104,7 +104,9 @@ typedef struct nep_fe_result {
   int32_t n_feasible;             /* ... that passed the kinodynamic tests                         */
   int32_t n_collision_free;       /* ... and the collision tests                                   */
   int32_t goal_occupied;          /* setUp's goal_occupied_ (:210-226)                             */
-  int32_t _pad;
+  int32_t _pad;                   /* entangle check on: WHICH capacity a search flagged ent_overflow ran into — bit 0 the
+                                     crossing list (NEP_FE_ENT_CAP), bit 1 more than 32 new crossings in one sampled step,
+                                     bit 2 more than NEP_MAX_BEND bend points; else 0                              */
   double cost;                    /* g + bias*h of the returned node                               */
   double dist_to_goal;
   int32_t n_entangled;            /* children pruned by entanglesWithOtherAgents (entangle check on)        */

@@ -324,7 +324,7 @@ template <class ST> __device__ double ent_tether(const ST* st, Ev2 from, Ev2 pk1
 }
 template <class P> __device__ __forceinline__ int ent_count(P ids, int n, int id) { int k = 0; for (int i = 0; i < n; i++) k += ids[i] == id; return k; }
 
-// 0: fine; 1: the reference's function returns true (prune); 2: capacity exceeded (pruned, flagged)
+// 0: fine; 1: the reference's function returns true (prune); 2, 3, 4: a capacity exceeded (pruned, flagged; which one: see the returns)
 template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const double* cxo, const double* cyo, Ev2 end, int index, double& arc, bool check_tether, int cap_mult) {
   const int ns = c.ns;
   const Ev2 pb_self = ent_pb(c, c.own);
@@ -386,7 +386,7 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
 #ifdef NEP_PROFILE_PHASES
     p_add += add.n > 0;
 #endif
-    if (add.overflow) return 2;
+    if (add.overflow) return 3;      // (2: the list's capacity, 3: more than kEntAddCap new crossings in one step, 4: more than NEP_MAX_BEND bend points)
     if (st->n_alpha + add.n > (c.N + c.S) * cap_mult) return 1;
     if (add.n > 0) {     // (no crossing in this step: the list, and with it every count below, is what it was)
       // entanglesWithOtherAgents compares, for every agent in the new list, its number of entries before and after the merge
@@ -408,7 +408,7 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
 #ifdef NEP_PROFILE_PHASES
     const int nb_before_ = st->n_bend, lb_before_ = st->n_bend ? st->bend[st->n_bend - 1] : -1;
 #endif
-    if (ent_update_bends(st, pk1, pb_self, c)) return 2;
+    if (ent_update_bends(st, pk1, pb_self, c)) return 4;
 #ifdef NEP_PROFILE_PHASES
     p_chg |= (add.n > 0) | (st->n_bend != nb_before_) | ((st->n_bend ? st->bend[st->n_bend - 1] : -1) != lb_before_);
 #endif

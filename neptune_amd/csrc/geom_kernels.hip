@@ -1981,7 +1981,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       int rc;
       ec.m_agent = m_ent + pr_ * MW; ec.m_static = m_stat + pr_ * SW;
       { FE_ENT_T0(); rc = ent_propagate(ec, &L, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
-      if (rc) { my_entangled++; if (rc == 2) my_overflow = 1; s_state[id] = 0; return; }
+      if (rc) { my_entangled++; if (rc >= 2) my_overflow |= 1 << (rc - 2); s_state[id] = 0; return; }
       ent_lds_store(ea.saved + ((long)slot * kFeCap + id), L, N); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
       ch.g = b_g[prv * MB + pr_] + arc;
       ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)L.n_alpha) + 1.0 * (double)L.n_bend);
@@ -2152,7 +2152,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
     if (depth == D) { status = NEP_FE_DEPTH_REACHED; break; }
   }
   atomicAdd(&s_i[4], my_children); atomicAdd(&s_i[5], my_feasible); atomicAdd(&s_i[6], my_free);
-  if constexpr (ENT) { atomicAdd(&s_i[8], my_entangled); if (my_overflow) s_i[9] = 1; }
+  if constexpr (ENT) { atomicAdd(&s_i[8], my_entangled); if (my_overflow) atomicOr(&s_i[9], my_overflow); }
   __syncthreads();
 #ifdef NEP_PROFILE_PHASES
   if (ps.dbg && tid == 0) { for (int k = 0; k < 8; k++) ps.dbg[(long)slot * 32 + k] = tph[k]; ps.dbg[(long)slot * 32 + 8] = depth; for (int k = 0; k < 4; k++) ps.dbg[(long)slot * 32 + 12 + k] = tent[k]; }
@@ -2186,7 +2186,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       o->status = status; o->K = best_rank >= 0 ? best_depth : 0; o->depth = depth > D ? D : depth;
       o->n_children = s_i[4]; o->n_feasible = s_i[5]; o->n_collision_free = s_i[6]; o->goal_occupied = s_i[7]; o->_pad = 0;
       o->cost = best_rank >= 0 ? b_f[best_rank] : 0.0; o->dist_to_goal = best_rank >= 0 ? b_dist[best_rank] : 0.0;
-      o->n_entangled = ENT ? s_i[8] : 0; o->ent_overflow = ENT ? s_i[9] : 0;
+      o->n_entangled = ENT ? s_i[8] : 0; o->ent_overflow = ENT ? (s_i[9] != 0 ? 1 : 0) : 0; o->_pad = ENT ? s_i[9] : 0;      // (_pad: which capacity, bit 0 the list's, 1 a step's new crossings, 2 the bend points)
     }
     if constexpr (ENT) {   // ranks of the path's nodes, for the case rows below
       int r = best_rank;
