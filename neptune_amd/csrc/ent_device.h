@@ -35,17 +35,30 @@ struct Ev2 { double x, y; };
 constexpr int kEntAddCap = 32;
 // The crossings one sampled step adds, in the reference's order (at most kEntAddCap; more: flagged).  An entry is one word —
 // id | case << 16 | nb << 24 (nb: the crossed agent's bend-point count, known where the crossing is found; the merge needs it) —
-// and the first four entries are plain members, so that they stay in registers: a step adds two or three crossings, and every
-// read of a list in scratch memory is a round trip the list surgery waits for (the merge was 57 % of a propagation).
+// and the first four entries are plain members that stay in registers (a step adds two or three crossings).  The tail is a
+// SEPARATE array behind a pointer: an array member indexed by a variable keeps the whole struct in scratch memory (the compiler
+// splits a local struct into registers only if every access to it has a constant offset) — every push was a 32-byte load and
+// store of the "register" entries, and every read in the list surgery a round trip.  (Eight register entries instead of four:
+// the same time — the kernel is short of registers as it is.)  An entry the merge cancels is flagged in
+// `gone` and stays where it is: no shifting, and the ids of the step's crossings remain readable after the merge.
 struct EntAdd {
-  static constexpr int cap = kEntAddCap;
-  unsigned r0, r1, r2, r3; unsigned rest[kEntAddCap - 4]; int n, overflow;
-  __device__ __forceinline__ unsigned get(int i) const { return i == 0 ? r0 : i == 1 ? r1 : i == 2 ? r2 : i == 3 ? r3 : rest[i - 4]; }
-  __device__ __forceinline__ void set(int i, unsigned v) { if (i == 0) r0 = v; else if (i == 1) r1 = v; else if (i == 2) r2 = v; else if (i == 3) r3 = v; else rest[i - 4] = v; }
+  static constexpr int cap = kEntAddCap, reg = 4;
+  unsigned r0, r1, r2, r3; unsigned* rest; int n, overflow; unsigned gone;      // rest: kEntAddCap - reg words of the caller's
+  __device__ __forceinline__ unsigned get(int i) const {
+    if (__builtin_expect(i >= reg, 0)) return rest[i - reg];
+    const unsigned a = (i & 1) ? r1 : r0, b = (i & 1) ? r3 : r2;
+    return (i & 2) ? b : a;
+  }
+  __device__ __forceinline__ void set(int i, unsigned v) {
+    if (__builtin_expect(i >= reg, 0)) { rest[i - reg] = v; return; }
+    r0 = i == 0 ? v : r0; r1 = i == 1 ? v : r1; r2 = i == 2 ? v : r2; r3 = i == 3 ? v : r3;
+  }
+  __device__ __forceinline__ void clear() { n = 0; overflow = 0; gone = 0u; }
+  __device__ __forceinline__ bool alive(int i) const { return !((gone >> i) & 1u); }
+  __device__ __forceinline__ int n_alive() const { return n - __popc(gone); }
   __device__ __forceinline__ int id(int i) const { return (int)(get(i) & 0xffffu); }
   __device__ __forceinline__ int cs(int i) const { return (int)((get(i) >> 16) & 0xffu); }
   __device__ __forceinline__ int nb(int i) const { return (int)(get(i) >> 24); }
-  __device__ __forceinline__ void remove(int i) { for (int k = i; k + 1 < n; k++) set(k, get(k + 1)); n--; }
 };
 constexpr int kEntPkHead = 2 + 2 * kBend;      // doubles of a packed record before the samples: [present, bend count | pad] [8 bend points] (everything 16-byte aligned)
 constexpr int kEntPkBend = 2;
@@ -155,7 +168,7 @@ __device__ __forceinline__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev
   }
   if (base_addition && add.n >= 2 && ((add.get(add.n - 1) ^ add.get(add.n - 2)) & 0xffffffu) == 0u) add.n -= 2;      // (same id, same case)
 }
-__device__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, const EntCtx& c) {
+__device__ __forceinline__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, const EntCtx& c) {
   if (c.m_static) {
     // (front end: the candidates of this parent in index order, the NEXT one's representative requested before the current one's
     // wedges are evaluated — as for the agents, ent_propagate)
@@ -210,11 +223,9 @@ template <class ST> __device__ Ev2 ent_cur_bend(const ST* st, Ev2 pb_self, const
   return Ev2{0, 0};
 }
 __device__ __forceinline__ double ent_beta(int id, int cs, Ev2 pk, Ev2 bp, const EntCtx& c) { return id <= c.N ? 0.0 : ent_wedge(pk, ent_srep(c, id - c.N - 1, cs), bp); }
-__device__ __forceinline__ bool ent_scan_stops(int t_id, int t_cs, int l_id, int j, int last_bend, const EntCtx& c) {
-  if (t_id <= c.N && t_cs >= 2) return j <= last_bend;
-  if (t_id <= c.N) return false;
-  return l_id > c.N || j <= last_bend;
-}
+// breakcondition (entangle_utils.cpp:1608-1647), where ent_merge's walk over the list ends after an entry that did not cancel: a
+// crossing of an agent's tether segment (case >= 2) is looked for down to the last bend point; of an agent otherwise, in the whole
+// list; of an obstacle, down to the last bend point or the first obstacle entry, whichever comes first.
 // The beta of an AGENT crossing is 0.0 by the reference's own rule (calculateBetaForCase, entangle_utils.cpp:1713-1719: only static
 // obstacles carry one).  The LDS-resident view (EntLds, below) keeps its betas in global memory and relies on that: it neither
 // reads nor rewrites the beta of an agent entry — reads are round trips the list surgery would wait for, and nearly every entry is
@@ -224,10 +235,11 @@ template <class ST> struct ent_lazy_beta { static constexpr bool v = false; };
 template <> struct ent_lazy_beta<EntLds> { static constexpr bool v = true; };
 // A 64-bit signature of the ids on a list (bit id mod 64): the cancellation scan of a new crossing and the per-agent counts walk the
 // whole list looking for entries of ONE id, and nearly always there is none (a crossing with somebody not crossed before is the
-// common case) — a clear bit proves that without the walk.  Kept by the LDS view only (set on append, rebuilt on erase).
+// common case) — a clear bit proves that without the walk.  Kept by the LDS view only (set on append, never cleared: a stale bit
+// costs a walk, not a wrong answer).
 template <class ST> __device__ __forceinline__ bool ent_sig_may_have(const ST*, int) { return true; }
 template <class ST> __device__ __forceinline__ void ent_sig_add(ST*, int) { }
-template <class ST> __device__ __forceinline__ void ent_sig_rebuild(ST*) { }
+template <class ST> __device__ __forceinline__ unsigned long long ent_sig_of(const ST*) { return ~0ull; }
 template <class ST> __device__ void ent_erase(ST* st, int j, int N) {
   constexpr bool lazy = ent_lazy_beta<ST>::v;
   for (int k = j; k + 1 < st->n_alpha; k++) {
@@ -239,26 +251,39 @@ template <class ST> __device__ void ent_erase(ST* st, int j, int N) {
   st->n_alpha--;
 }
 __device__ int ent_bend_n(const EntCtx& c, int j) { const HullRef hr = hull_ref(*c.ps, c.n_hull, c.scene, j); return blk(c.ps->bend_n, hr.boff)[hr.e]; }
-template <class ST> __device__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 pb_self, const EntCtx& c) {
+#ifdef NEP_PROFILE_PHASES
+#define ENT_MT(k) do { if (mt) { const long long t_ = clock64(); mt[k] += t_ - *ml; *ml = t_; } } while (0)
+#else
+#define ENT_MT(k) do { } while (0)
+#endif
+template <class ST> __device__ __forceinline__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 pb_self, const EntCtx& c, long long* mt = nullptr, long long* ml = nullptr) {
   bool again = true;
   while (again) {
     again = false;
     const int b = st->n_bend ? st->bend[st->n_bend - 1] : -1;
     for (int i = 0; i < add.n && !again; i++) {
+      if (!add.alive(i)) continue;
       const unsigned t_w = add.get(i);
       const int t_id = (int)(t_w & 0xffffu), t_cs = (int)((t_w >> 16) & 0xffu);
       const bool agent = t_id <= c.N;
       const int t_nb = agent ? (int)(t_w >> 24) : 0;
       if (!ent_sig_may_have(st, t_id)) continue;      // (every match needs an entry of the same id: there is none)
-      for (int j = st->n_alpha - 1; j >= 0; j--) {
-        const int l_id = st->id[j], l_cs = st->cs[j];
-        const bool match = (l_id == t_id && l_cs == t_cs) ||
-                           (agent && l_id == t_id && t_cs >= t_nb + 1 && t_cs < l_cs) ||
-                           (agent && l_id == t_id && l_cs >= 2 && t_cs >= 2 && abs(t_cs - l_cs) == 1 && j > b);
+      // (the three ways an entry cancels against the new crossing and the rule that ends the walk — breakcondition, above — as flag
+      // arithmetic: evaluated with short-circuit branches, an iteration of this walk was a dozen jumps)
+      const bool t_deep = agent & (t_cs >= t_nb + 1), t_bend = agent & (t_cs >= 2);
+      const bool stop_at_bend = !agent | t_bend, stop_at_static = !agent;
+      // (the walk is a chain of list reads: the entry below is requested before this one's tests)
+      int j = st->n_alpha - 1, l_id = 0, l_cs = 0;
+      if (j >= 0) { l_id = st->id[j]; l_cs = st->cs[j]; }
+      for (; j >= 0; j--) {
+        int n_id = 0, n_cs = 0;
+        if (j > 0) { n_id = st->id[j - 1]; n_cs = st->cs[j - 1]; }
+        const int dcs = t_cs - l_cs;
+        const bool match = (l_id == t_id) & ((dcs == 0) | (t_deep & (dcs < 0)) | (t_bend & (l_cs >= 2) & ((dcs == 1) | (dcs == -1)) & (j > b)));
         if (match) {
-          add.remove(i);
-          ent_erase(st, j, c.N);
-          ent_sig_rebuild(st);
+          add.gone |= 1u << i;
+          ENT_MT(1);
+          ent_erase(st, j, c.N);      // (the id signature keeps the erased entry's bit: a set bit only ever costs a walk)
           if (j == b) {
             st->n_bend--;
             const Ev2 bp = ent_cur_bend(st, pb_self, c);
@@ -268,20 +293,26 @@ template <class ST> __device__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 p
             for (int k = st->n_bend - 2; k >= 0; k--) { if (st->bend[k] > j) st->bend[k] -= 1; else break; }
           }
           again = true;
+          ENT_MT(2);
           break;
         }
-        if (ent_scan_stops(t_id, t_cs, l_id, j, b, c)) break;
+        if ((stop_at_bend & (j <= b)) | (stop_at_static & (l_id > c.N))) break;
+        l_id = n_id; l_cs = n_cs;
       }
     }
   }
-  if (add.n == 0) return false;
-  if (st->n_alpha + add.n > NEP_FE_ENT_CAP) return true;
+  ENT_MT(1);
+  const int n_new = add.n_alive();
+  if (n_new == 0) return false;
+  if (st->n_alpha + n_new > NEP_FE_ENT_CAP) return true;
   const Ev2 bp = ent_cur_bend(st, pb_self, c);
   for (int i = 0; i < add.n; i++) {
+    if (!add.alive(i)) continue;
     st->id[st->n_alpha] = (short)add.id(i); st->cs[st->n_alpha] = (signed char)add.cs(i); ent_sig_add(st, add.id(i));
     if (!ent_lazy_beta<ST>::v || add.id(i) > c.N) st->beta[st->n_alpha] = ent_beta(add.id(i), add.cs(i), pk, bp, c);
     st->n_alpha++;
   }
+  ENT_MT(3);
   return false;
 }
 template <class ST> __device__ bool ent_update_bends(ST* st, Ev2 pk1, Ev2 pb_self, const EntCtx& c) {
@@ -330,13 +361,14 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
   const Ev2 pb_self = ent_pb(c, c.own);
   Ev2 pk{cxo[3], cyo[3]}, pk1 = pk;
 #ifdef NEP_PROFILE_PHASES
-  long long pt[5] = {0, 0, 0, 0, 0}; long long pl = clock64(); int p_add = 0, p_chg = 0;
+  long long pt[5] = {0, 0, 0, 0, 0}; long long pl = clock64(); int p_add = 0, p_chg = 0; long long mt[5] = {0, 0, 0, 0, 0}, ml = 0;
 #define ENT_PT(k) do { const long long t_ = clock64(); pt[k] += t_ - pl; pl = t_; } while (0)
 #else
 #define ENT_PT(k) do { } while (0)
 #endif
+  unsigned add_tail[kEntAddCap - EntAdd::reg];
   for (int j = 1; j <= ns; j++) {
-    EntAdd add; add.n = 0; add.overflow = 0;
+    EntAdd add; add.rest = add_tail; add.clear();
     ENT_PT(4);
     if (j < ns) {
       const double t = c.T_span * j / ns;
@@ -393,16 +425,32 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
       // (:870-887: a second entry where there was at most one, or one more where there were two, prunes the child).  The merge
       // only ever touches entries of the agents in `add`, so theirs are the only counts that can differ: the old ones are
       // taken before the merge, for those agents only — no copy of the old list, no pass over every pair of entries.
-      EntAdd chk; chk.n = 0; chk.overflow = 0; const int a_n = add.n;      // (id, entries of that agent before the merge)
-      for (int e = 0; e < a_n; e++) { const int id_ = add.id(e); ent_push(chk, id_, (id_ <= c.N && ent_sig_may_have(st, id_)) ? ent_count(st->id, st->n_alpha, id_) : 0); }
+      // With m matches of an agent in the merge (each removes one entry of the new list and one of the old), its count moves from
+      // od to od - m + rem, rem = init - m its entries left in the new list: by d = 2 rem - init, known without looking at the old
+      // list at all.  d <= 0 never prunes; d >= 2 always does; d = 1 prunes iff the agent had an entry before (od >= 1, i.e. two
+      // entries now) — and the list's id signature, taken BEFORE the merge, answers that with "no" for the common case of an agent
+      // crossed for the first time.  (Entries of one id are adjacent in both lists: the loops over obstacles run in index order.)
+      const unsigned long long sig_before = ent_sig_of(st);
+#ifdef NEP_PROFILE_PHASES
+      ml = pl; { const long long t_ = clock64(); mt[0] += t_ - ml; ml = t_; }
+      if (ent_merge(add, st, pk, pb_self, c, mt, &ml)) return 2;
+#else
       if (ent_merge(add, st, pk, pb_self, c)) return 2;
-      for (int e = 0; e < a_n; e++) {
-        const int id_ = chk.id(e);
+#endif
+      for (int e = 0; e < add.n;) {
+        const int id_ = add.id(e);
+        int init = 0, rem = 0;
+        do { rem += add.alive(e) ? 1 : 0; init++; e++; } while (e < add.n && add.id(e) == id_);
         if (id_ > c.N) continue;
-        const int nw = ent_count(st->id, st->n_alpha, id_), od = chk.cs(e);
-        if (od < 2 && nw >= 2) return 1;
-        if (od >= 2 && nw > od) return 1;
+        const int d = 2 * rem - init;
+        if (d <= 0) continue;
+        if (d >= 2) return 1;
+        if (!((sig_before >> (id_ & 63)) & 1ull)) continue;
+        if (ent_count(st->id, st->n_alpha, id_) >= 2) return 1;
       }
+#ifdef NEP_PROFILE_PHASES
+      { const long long t_ = clock64(); mt[4] += t_ - ml; }
+#endif
     }
     ENT_PT(2);
 #ifdef NEP_PROFILE_PHASES
@@ -410,7 +458,7 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
 #endif
     if (ent_update_bends(st, pk1, pb_self, c)) return 4;
 #ifdef NEP_PROFILE_PHASES
-    p_chg |= (add.n > 0) | (st->n_bend != nb_before_) | ((st->n_bend ? st->bend[st->n_bend - 1] : -1) != lb_before_);
+    p_chg |= (add.n_alive() > 0) | (st->n_bend != nb_before_) | ((st->n_bend ? st->bend[st->n_bend - 1] : -1) != lb_before_);
 #endif
     ENT_PT(3);
     pk = pk1;
@@ -419,7 +467,8 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
   ENT_PT(4);
 #ifdef NEP_PROFILE_PHASES
   if (c.prof) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)c.prof + k, (unsigned long long)pt[k]); atomicAdd((unsigned long long*)c.prof + 5, 1ull); atomicAdd((unsigned long long*)c.prof + 6, (unsigned long long)p_add);
-    atomicAdd((unsigned long long*)c.prof + 7, (unsigned long long)(p_chg != 0)); atomicMax((unsigned long long*)c.prof + 8, (unsigned long long)st->n_alpha); atomicAdd((unsigned long long*)c.prof + 9, (unsigned long long)st->n_alpha); }
+    atomicAdd((unsigned long long*)c.prof + 7, (unsigned long long)(p_chg != 0)); atomicMax((unsigned long long*)c.prof + 8, (unsigned long long)st->n_alpha); atomicAdd((unsigned long long*)c.prof + 9, (unsigned long long)st->n_alpha);
+    for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)c.prof + 10 + k, (unsigned long long)mt[k]); }
 #endif
   if (too_long) return 1;
   return 0;
@@ -433,7 +482,7 @@ typedef __attribute__((address_space(3))) signed char* ent_lds_char;
 struct EntLds { int n_alpha, n_bend; ent_lds_short id; ent_lds_char cs; double* beta; ent_lds_char bend; unsigned long long sig; };
 template <> __device__ __forceinline__ bool ent_sig_may_have<EntLds>(const EntLds* st, int id) { return (st->sig >> (id & 63)) & 1ull; }
 template <> __device__ __forceinline__ void ent_sig_add<EntLds>(EntLds* st, int id) { st->sig |= 1ull << (id & 63); }
-template <> __device__ __forceinline__ void ent_sig_rebuild<EntLds>(EntLds* st) { unsigned long long g = 0ull; for (int i = 0; i < st->n_alpha; i++) g |= 1ull << (st->id[i] & 63); st->sig = g; }
+template <> __device__ __forceinline__ unsigned long long ent_sig_of<EntLds>(const EntLds* st) { return st->sig; }
 constexpr int kEntLdsBytes = ((NEP_FE_ENT_CAP * 3 + NEP_MAX_BEND + 3) & ~3) | 4;      // per thread; an odd number of dwords, so that the threads' lists fall into different banks
 __device__ __forceinline__ void ent_lds_load(EntLds& L, const nep_fe_ent_state* __restrict__ src, int N) {
   L.n_alpha = src->n_alpha; L.n_bend = src->n_bend;

@@ -43,6 +43,8 @@ def main():
     print("propagations per search %.0f (%.1f %% of them with a crossing in some step); cycles per propagation %.0f (summed over all threads)" % (rows[:, 21].mean(), 100.0 * rows[:, 22].sum() / max(npr, 1), tp / max(npr, 1)))
     for k, n in enumerate(pn):
         print("   %-24s %10.0f per propagation  %5.1f %%" % (n, rows[:, 16 + k].sum() / max(npr, 1), 100.0 * rows[:, 16 + k].sum() / max(tp, 1)))
+    for k, n in enumerate(["merge: ids of the new list", "merge: scans", "merge: erase + re-anchor", "merge: append", "merge: counts"]):
+        print("      %-28s %10.0f per propagation" % (n, rows[:, 26 + k].sum() / max(npr, 1)))
     print("propagations whose state differs from the parent's: %.2f %%; crossing-list length at the end of a propagation: mean %.2f, max over the searches: p50 %d p90 %d p99 %d max %d; searches flagged ent_overflow %d"
           % (100.0 * rows[:, 23].sum() / max(npr, 1), rows[:, 25].sum() / max(npr, 1), np.percentile(rows[:, 24], 50), np.percentile(rows[:, 24], 90), np.percentile(rows[:, 24], 99), rows[:, 24].max(), int(res["ent_overflow"].sum())))
     i = int(np.argmax(tot)); print("slowest search: slot %d total %.0f (%.1fx the mean)" % (i, tot[i], tot[i] / tot.mean()), rows[i, :8].astype(int).tolist(), rows[i, 12:].astype(int).tolist())
