@@ -29,6 +29,10 @@ struct EntCtx {
   // Optional (front end): what the entangle check reads of agent j in interval i, packed into one record (ent_pack_kernel):
   // [present, bend count | 8 bend points | ns + 1 samples], pk_stride doubles apart — one round trip instead of a chain of four
   const double* packed = nullptr; int pk_stride = 0;
+  // Optional (front end, with `packed`): per agent, bit jj - 1 = the agent's moving tether segment sweeps over OUR base in sampled step jj
+  // (f1 f2 < 0 in ent_cross_agent) — the same for every child of every parent of a depth, so it is evaluated once per depth
+  // (ent_agent_fbits_pk, next to the masks) instead of once per child, obstacle and step
+  const unsigned char* f_bits = nullptr;
   long long* prof = nullptr;      // (NEP_PROFILE_PHASES builds: seven per-search accumulators, see scripts/fe_ent_phases.py)
 };
 struct Ev2 { double x, y; };
@@ -114,44 +118,59 @@ __device__ bool ent_agent_may_cross(const EntCtx& c, const EntBox& q, int j, int
 }
 // the same proof from the packed record (front end): every load is independent of the others
 __device__ __forceinline__ const double* ent_rec(const EntCtx& c, int j, int interval) { return c.packed + (((long)c.scene * c.N + j) * c.num_pol + interval) * c.pk_stride; }
+__device__ __forceinline__ unsigned ent_agent_fbits_pk(const EntCtx& c, int j, int interval) {      // (j != own; ns <= 8)
+  const double* r = ent_rec(c, j, interval);
+  const int2 hd = *(const int2*)r;
+  if (!hd.x || hd.y < 1) return 0u;
+  const double* bp = r + kEntPkBend; const double* sm = r + kEntPkHead;
+  const Ev2 pb_self = ent_pb(c, c.own);
+  const Ev2 bk{bp[2 * (hd.y - 1)], bp[2 * (hd.y - 1) + 1]};
+  Ev2 pik{sm[0], sm[1]};
+  unsigned fb = 0u;
+  for (int jj = 1; jj <= c.ns; jj++) {
+    const Ev2 pik1{sm[2 * jj], sm[2 * jj + 1]};
+    const double f1 = ent_wedge(pb_self, pik, bk), f2 = ent_wedge(pb_self, pik1, bk);
+    fb |= (f1 * f2 < 0 ? 1u : 0u) << (jj - 1);
+    pik = pik1;
+  }
+  return fb;
+}
+// (the box part of the proof: the caller has looked at ent_agent_fbits_pk — any bit set means "maybe" for every box)
 __device__ bool ent_agent_may_cross_pk(const EntCtx& c, const EntBox& q, int j, int interval) {      // (j != own)
   const double* r = ent_rec(c, j, interval);
   const int2 hd = *(const int2*)r;
   if (!hd.x) return false;
   const int nbj = hd.y;
   const double* bp = r + kEntPkBend; const double* sm = r + kEntPkHead;
-  const Ev2 pb_self = ent_pb(c, c.own);
   bool maybe = false;
   for (int k = 0; k + 1 < nbj; k++) maybe |= ent_side(q, Ev2{bp[2 * (k + 1)], bp[2 * (k + 1) + 1]}, Ev2{bp[2 * k], bp[2 * k + 1]}) == 0;
   if (nbj >= 1) {
     const Ev2 bk{bp[2 * (nbj - 1)], bp[2 * (nbj - 1) + 1]};
-    Ev2 pik{sm[0], sm[1]};
-    const int s0 = ent_side(q, pik, bk);
+    const int s0 = ent_side(q, Ev2{sm[0], sm[1]}, bk);
     maybe |= s0 == 0;
-    for (int jj = 1; jj <= c.ns; jj++) {
-      const Ev2 pik1{sm[2 * jj], sm[2 * jj + 1]};
-      maybe |= ent_side(q, pik1, bk) != s0;
-      const double f1 = ent_wedge(pb_self, pik, bk), f2 = ent_wedge(pb_self, pik1, bk);
-      maybe |= f1 * f2 < 0;
-      pik = pik1;
-    }
+    for (int jj = 1; jj <= c.ns; jj++) maybe |= ent_side(q, Ev2{sm[2 * jj], sm[2 * jj + 1]}, bk) != s0;
   }
   return maybe;
 }
 __device__ __forceinline__ bool ent_static_may_cross(const EntCtx& c, const EntBox& q, int s) { return ent_side(q, ent_srep(c, s, 1), ent_srep(c, s, 0)) == 0; }
 
-__device__ __forceinline__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id) {
+// (f_known: -1 = evaluate the base-sweep test here; 0 / 1 = its outcome, from EntCtx::f_bits)
+// (b0: bend point 0 in registers, where the caller has fetched it with the record's header — most tethers have no other, and a load
+// issued here waits for everything the caller has requested ahead, i.e. for the NEXT obstacle's record)
+__device__ __forceinline__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id, int f_known = -1, bool have_b0 = false, Ev2 b0 = Ev2{0, 0}) {
   bool base_addition = false;
   for (int k = 0; k < nb; k++) {
     const bool last = k == nb - 1;
-    const Ev2 bk{bp[2 * k], bp[2 * k + 1]};
+    Ev2 bk = b0;
+    if (!(have_b0 && k == 0)) { bk.x = bp[2 * k]; bk.y = bp[2 * k + 1]; }
     Ev2 u, v; double c1, c2;
     if (!last) { const Ev2 bn{bp[2 * (k + 1)], bp[2 * (k + 1) + 1]}; c1 = ent_wedge2(pk, bn, bk, u, v); c2 = ent_wedge(pk1, bn, bk); }
     else { c1 = ent_wedge2(pk, pik, bk, u, v); c2 = ent_wedge(pk1, pik1, bk); }
     if (last) {
-      Ev2 ub, vb;
-      const double f1 = ent_wedge2(pb_self, pik, bk, ub, vb), f2 = ent_wedge(pb_self, pik1, bk);
-      if (f1 * f2 < 0) {
+      Ev2 ub, vb; bool sweeps;
+      if (f_known < 0) { const double f1 = ent_wedge2(pb_self, pik, bk, ub, vb), f2 = ent_wedge(pb_self, pik1, bk); sweeps = f1 * f2 < 0; }
+      else { sweeps = f_known != 0; ub.x = pik.x - pb_self.x; ub.y = pik.y - pb_self.y; vb.x = bk.x - pb_self.x; vb.y = bk.y - pb_self.y; }
+      if (sweeps) {
         const double a = ent_ratio(ub, vb);
         if (a < 0) { }
         else if (a < 1) ent_push(add, agent_id, 1, nb);
@@ -393,13 +412,14 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
       };
       int i = next_cand(0);
       const double* r = ent_rec(c, i < c.N ? i : 0, itv);
-      int2 hd = *(const int2*)r; double2 sa = *(const double2*)(r + kEntPkHead + 2 * jl), sb = *(const double2*)(r + kEntPkHead + 2 * jr);
+      int2 hd = *(const int2*)r; double2 sa = *(const double2*)(r + kEntPkHead + 2 * jl), sb = *(const double2*)(r + kEntPkHead + 2 * jr), b0 = *(const double2*)(r + kEntPkBend);
       while (i < c.N) {
         const int in = next_cand(i + 1);
         const double* rn = ent_rec(c, in < c.N ? in : 0, itv);
-        const int2 hdn = *(const int2*)rn; const double2 san = *(const double2*)(rn + kEntPkHead + 2 * jl), sbn = *(const double2*)(rn + kEntPkHead + 2 * jr);
-        if (i != c.own && hd.x) ent_cross_agent(add, pk, pk1, Ev2{sa.x, sa.y}, Ev2{sb.x, sb.y}, pb_self, hd.y, r + kEntPkBend, i + 1);
-        i = in; r = rn; hd = hdn; sa = san; sb = sbn;
+        const int fk = !c.f_bits ? -1 : (index > c.num_pol ? 0 : (int)((c.f_bits[i] >> (j - 1)) & 1u));      // (holding at the end: pik = pik1, f1 f2 = f1^2)
+        const int2 hdn = *(const int2*)rn; const double2 san = *(const double2*)(rn + kEntPkHead + 2 * jl), sbn = *(const double2*)(rn + kEntPkHead + 2 * jr), b0n = *(const double2*)(rn + kEntPkBend);
+        if (i != c.own && hd.x) ent_cross_agent(add, pk, pk1, Ev2{sa.x, sa.y}, Ev2{sb.x, sb.y}, pb_self, hd.y, r + kEntPkBend, i + 1, fk, true, Ev2{b0.x, b0.y});
+        i = in; r = rn; hd = hdn; sa = san; sb = sbn; b0 = b0n;
       }
     } else
     for (int i = 0; i < c.N; i++) {

@@ -1759,19 +1759,21 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
   unsigned* m_ent = (unsigned*)(b_valid + MB + ((4 - ((3 * kFeCap) & 3)) & 3));      // [64][MW] agents whose tether a child's step may cross (aligned: every array before r_id is a multiple of four bytes)
   unsigned* m_base = m_ent + MB * MW;               // [64][MW] agents whose base square a child may be near
   unsigned* m_stat = m_base + MB * MW;              // [64][SW] static representatives a child's step may cross
+  unsigned char* f_bits = (unsigned char*)(m_stat + MB * SW);      // [N] ENT: per agent, the sampled steps in which its moving tether segment sweeps over our base (EntCtx::f_bits)
   if constexpr (ENT) {
     ec.N = N; ec.S = S; ec.own = own; ec.num_pol = D; ec.ns = ea.ns; ec.T_span = sp.T_span; ec.cable = fc.cable_length;
     ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
     ec.sampled = ea.sampled; ec.present = ea.present;
     ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
     ec.packed = ea.packed; ec.pk_stride = ea.pk_stride;
+    ec.f_bits = (ea.packed && ea.ns <= 8) ? f_bits : nullptr;
 #ifdef NEP_PROFILE_PHASES
     ec.prof = ps.dbg ? ps.dbg + (long)slot * 32 + 16 : nullptr;
 #endif
     // the crossing lists of the children being merged (phase two of the propagation pass) live where the shortlist's boxes and
     // vertices and the winners' f values are: dead between a depth's GJK pass and its compaction / the next depth's shortlist
     ent_lists = (unsigned char*)o_aabb;      // [n_merge][kEntLdsBytes]
-    my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(m_stat + MB * SW) + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
+    my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(f_bits + N) + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
     if (tid == 0) {
       nep_fe_ent_state* root = ent_node(0, 0);
       if (ea.init) {
@@ -1899,6 +1901,10 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       for (int j = tid; j < N + S; j += 256) {
         if (j == own) continue;
         const double pbx = j < N ? ps.pb[2 * j] : 0.0, pby = j < N ? ps.pb[2 * j + 1] : 0.0;
+        // the part of the proof that does not involve the box (the agent's moving tether segment sweeping over OUR base, per step):
+        // once per obstacle — and kept for the children's crossing tests, which would evaluate it once per child and step
+        unsigned fb_j = 0u;
+        if (j < N) { fb_j = ec.ns <= 8 ? ent_agent_fbits_pk(ec, j, idx) : 0xffu; f_bits[j] = (unsigned char)fb_j; }
         for (int q = 0; q < nb_prev; q++) {
           const EntBox bx{p_box[4 * q] - kPad, p_box[4 * q + 1] + kPad, p_box[4 * q + 2] - kPad, p_box[4 * q + 3] + kPad};
           if (j < N) {
@@ -1906,7 +1912,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
               const double dx = fmax(fmax(bx.x0 - pbx, pbx - bx.x1), 0.0), dy = fmax(fmax(bx.y0 - pby, pby - bx.y1), 0.0);
               if (sqrt(dx * dx + dy * dy) <= safe_dist + 1e-6) atomicOr(&m_base[q * MW + (j >> 5)], 1u << (j & 31));
             }
-            if (ent_agent_may_cross_pk(ec, bx, j, idx)) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
+            if (fb_j || ent_agent_may_cross_pk(ec, bx, j, idx)) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
           } else {
             const int sj = j - N;
             if (ent_static_may_cross(ec, bx, sj)) atomicOr(&m_stat[q * SW + (sj >> 5)], 1u << (sj & 31));
@@ -2276,7 +2282,7 @@ size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc, bool ent)
   size_t b = sizeof(double) * ((size_t)z.cap * (rf_alias ? 1 : 2) + 2 * MB * 6 + 2 * MB + 2 * MB + 4 * MB + 4 * NS + kFeObsLds * kHullV * 2 + 4 * NEP_FE_MAX_SAMPLES)
            + sizeof(long long) * ((size_t)z.cap + z.vis) + sizeof(int) * (z.dd + 2 * NS + 32)
            + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * MB + MB;
-  if (ent) b = ((b + 3) & ~(size_t)3) + sizeof(unsigned) * MB * (2 * (size_t)((sp.num_agents + 31) >> 5) + (size_t)((sp.n_static + 31) >> 5)) + (NEP_FE_ENT_WGS == 1 ? 256 * sizeof(nep_fe_ent_state) + 8 : 0);
+  if (ent) b = ((b + 3) & ~(size_t)3) + sizeof(unsigned) * MB * (2 * (size_t)((sp.num_agents + 31) >> 5) + (size_t)((sp.n_static + 31) >> 5)) + (size_t)sp.num_agents + (NEP_FE_ENT_WGS == 1 ? 256 * sizeof(nep_fe_ent_state) + 8 : 0);
   return (b + 15) & ~(size_t)15;
 }
 
