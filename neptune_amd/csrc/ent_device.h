@@ -192,19 +192,18 @@ __device__ __forceinline__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, c
     // (front end: the candidates of this parent in index order, the NEXT one's representative requested before the current one's
     // wedges are evaluated — as for the agents, ent_propagate)
     const int SWn = (c.S + 31) >> 5;
-    auto next_cand = [&](int from) -> int {
-      for (int w = from >> 5; w < SWn; w++) {
-        unsigned m = c.m_static[w];
-        if (w == (from >> 5)) m &= ~0u << (from & 31);
-        if (m) { const int i = (w << 5) + __ffs(m) - 1; return i < c.S ? i : c.S; }
-      }
-      return c.S;
+    int mw = -1; unsigned cw = 0u;      // (the mask word at hand in a register, as for the agents)
+    auto next_cand = [&]() -> int {
+      while (cw == 0u) { if (++mw >= SWn) return c.S; cw = c.m_static[mw]; }
+      const int i = (mw << 5) + __ffs(cw) - 1; cw &= cw - 1u;
+      if (i >= c.S) { cw = 0u; mw = SWn; return c.S; }
+      return i;
     };
-    int s = next_cand(0);
+    int s = next_cand();
     const double2* r = (const double2*)(c.srep + (long)(s < c.S ? s : 0) * 4);
     double2 q0 = r[0], q1 = r[1];
     while (s < c.S) {
-      const int sn = next_cand(s + 1);
+      const int sn = next_cand();
       const double2* rn = (const double2*)(c.srep + (long)(sn < c.S ? sn : 0) * 4);
       const double2 n0 = rn[0], n1 = rn[1];
       const Ev2 pik{q1.x, q1.y}, pbi{q0.x, q0.y};
@@ -402,19 +401,20 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
       const int itv = index > c.num_pol ? c.num_pol - 1 : index - 1;
       const int jl = index > c.num_pol ? ns : j - 1, jr = index > c.num_pol ? ns : j;
       const int MWn = (c.N + 31) >> 5;
-      auto next_cand = [&](int from) -> int {
-        for (int w = from >> 5; w < MWn; w++) {
-          unsigned m = c.m_agent ? c.m_agent[w] : ~0u;
-          if (w == (from >> 5)) m &= ~0u << (from & 31);
-          if (m) { const int i = (w << 5) + __ffs(m) - 1; return i < c.N ? i : c.N; }
-        }
-        return c.N;
+      // (the mask word at hand is kept in a register and consumed bit by bit: a read of the LDS word per candidate sat on the path
+      // from one candidate's index to the request for the next one's record)
+      int mw = -1; unsigned cw = 0u;
+      auto next_cand = [&]() -> int {
+        while (cw == 0u) { if (++mw >= MWn) return c.N; cw = c.m_agent ? c.m_agent[mw] : ~0u; }
+        const int i = (mw << 5) + __ffs(cw) - 1; cw &= cw - 1u;
+        if (i >= c.N) { cw = 0u; mw = MWn; return c.N; }
+        return i;
       };
-      int i = next_cand(0);
+      int i = next_cand();
       const double* r = ent_rec(c, i < c.N ? i : 0, itv);
       int2 hd = *(const int2*)r; double2 sa = *(const double2*)(r + kEntPkHead + 2 * jl), sb = *(const double2*)(r + kEntPkHead + 2 * jr), b0 = *(const double2*)(r + kEntPkBend);
       while (i < c.N) {
-        const int in = next_cand(i + 1);
+        const int in = next_cand();
         const double* rn = ent_rec(c, in < c.N ? in : 0, itv);
         const int fk = !c.f_bits ? -1 : (index > c.num_pol ? 0 : (int)((c.f_bits[i] >> (j - 1)) & 1u));      // (holding at the end: pik = pik1, f1 f2 = f1^2)
         const int2 hdn = *(const int2*)rn; const double2 san = *(const double2*)(rn + kEntPkHead + 2 * jl), sbn = *(const double2*)(rn + kEntPkHead + 2 * jr), b0n = *(const double2*)(rn + kEntPkBend);

@@ -1905,6 +1905,19 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         // once per obstacle — and kept for the children's crossing tests, which would evaluate it once per child and step
         unsigned fb_j = 0u;
         if (j < N) { fb_j = ec.ns <= 8 ? ent_agent_fbits_pk(ec, j, idx) : 0xffu; f_bits[j] = (unsigned char)fb_j; }
+        // (three samples per interval, a tether without bend points besides its base: what the box test reads of the record — the
+        // base and the four samples — is fetched once here, not once per parent)
+        bool plain = false, absent = false; Ev2 bk{0, 0}, sm0{0, 0}, sm1{0, 0}, sm2{0, 0}, sm3{0, 0};
+        if (j < N && !fb_j && ec.ns == 3) {
+          const double* r = ent_rec(ec, j, idx);
+          const int2 hd = *(const int2*)r;
+          absent = !hd.x;                                   // (no trajectory: nothing to cross — its base square stays)
+          if (hd.x && hd.y == 1) {
+            plain = true;
+            const double2 b = *(const double2*)(r + kEntPkBend), a0 = *(const double2*)(r + kEntPkHead), a1 = *(const double2*)(r + kEntPkHead + 2), a2 = *(const double2*)(r + kEntPkHead + 4), a3 = *(const double2*)(r + kEntPkHead + 6);
+            bk = Ev2{b.x, b.y}; sm0 = Ev2{a0.x, a0.y}; sm1 = Ev2{a1.x, a1.y}; sm2 = Ev2{a2.x, a2.y}; sm3 = Ev2{a3.x, a3.y};
+          }
+        }
         for (int q = 0; q < nb_prev; q++) {
           const EntBox bx{p_box[4 * q] - kPad, p_box[4 * q + 1] + kPad, p_box[4 * q + 2] - kPad, p_box[4 * q + 3] + kPad};
           if (j < N) {
@@ -1912,7 +1925,14 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
               const double dx = fmax(fmax(bx.x0 - pbx, pbx - bx.x1), 0.0), dy = fmax(fmax(bx.y0 - pby, pby - bx.y1), 0.0);
               if (sqrt(dx * dx + dy * dy) <= safe_dist + 1e-6) atomicOr(&m_base[q * MW + (j >> 5)], 1u << (j & 31));
             }
-            if (fb_j || ent_agent_may_cross_pk(ec, bx, j, idx)) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
+            bool may;
+            if (fb_j) may = true;
+            else if (absent) may = false;
+            else if (plain) {      // ent_agent_may_cross_pk for nb = 1, from registers
+              const int s0 = ent_side(bx, sm0, bk);
+              may = (s0 == 0) | (ent_side(bx, sm1, bk) != s0) | (ent_side(bx, sm2, bk) != s0) | (ent_side(bx, sm3, bk) != s0);
+            } else may = ent_agent_may_cross_pk(ec, bx, j, idx);
+            if (may) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
           } else {
             const int sj = j - N;
             if (ent_static_may_cross(ec, bx, sj)) atomicOr(&m_stat[q * SW + (sj >> 5)], 1u << (sj & 31));
