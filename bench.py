@@ -998,8 +998,8 @@ def main():
                                 "kernel_ms": {"frontend_ent_with_hulls": mean_ms(fe5), "separator": k8["separator"], "qp": k8["qp"], "safety_ent": mean_ms(sf5)},
                                 "beam_width": args.beam, "frontend_goal_reached": int((res8["status"] == 1).sum()), "frontend_no_solution": int((res8["status"] == 3).sum()),
                                 "children_pruned_by_the_entangle_check": int(res8["n_entangled"].sum()), "ent_overflow": int(res8["ent_overflow"].sum()),
-                                "ent_overflow_by_capacity": {"crossing_list_40": int((res8["_pad"] & 1 != 0).sum()), "new_crossings_per_step_32": int((res8["_pad"] & 2 != 0).sum()),
-                                                             "bend_points_8": int((res8["_pad"] & 4 != 0).sum())},
+                                "big_records": {"searches": int(((res8["_pad"].astype(np.int64) >> 8) > 0).sum()), "children": int((res8["_pad"].astype(np.int64) >> 8).sum()),
+                                                "note": "searches in which a child's entangle state outgrew the fixed record (40 crossings, 32 new ones per sampled step, 8 bend points): re-run by the big-record instantiation after the launch, bounded by the reference's own rule (num_agents + statics) only; ent_overflow counts the searches the POOL of big records failed (0)"},
                                 "active_entangle_cases": int((d_case5 != 0).sum().item()),
                                 "ipm_iters_mean": float(sol8["stats"]["iters"].mean()), "accepted_frac": float(d_ac5.float().mean().item()),
                                 "solve_us": solve_us_stats(b5),

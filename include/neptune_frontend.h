@@ -47,9 +47,15 @@ extern "C" {
 #define NEP_FE_MAX_SAMPLES 5
 #ifndef NEP_FE_ENT_CAP
 #define NEP_FE_ENT_CAP 40
-#endif                            /* crossings kept per search node with the entangle check on (the reference prunes a
-                                     node at num_agents + statics crossings; one that would exceed this capacity is
-                                     pruned too and reported in nep_fe_result.ent_overflow)                          */
+#endif                            /* crossings of the FIXED entangle-state record (nep_fe_ent_state: the state at point A
+                                     the caller passes in, and a search node's state on the fast path).  It is not a
+                                     limit of the search: the reference prunes a node at num_agents + statics crossings
+                                     (kinodynamic_search.cpp:850-854) and so does the front end — a node whose list, new
+                                     crossings of one sampled step (more than 32) or bend points (more than NEP_MAX_BEND)
+                                     outgrow the fixed record is carried, with all its descendants, in a "big record" of
+                                     a per-handle pool in device memory that is sized by that very bound (round 4; before,
+                                     such a node was pruned and flagged).  nep_fe_result.ent_overflow now only says that
+                                     the POOL ran out (nep_batch_set_fe_ent_big_records)                              */
 
 #define NEP_FE_GOAL_REACHED 1     /* status codes of KinodynamicSearch::run (:1637-1639)          */
 #define NEP_FE_DEPTH_REACHED 0    /* (RUNTIME_REACHED there): best node of the last depth         */
@@ -104,13 +110,13 @@ typedef struct nep_fe_result {
   int32_t n_feasible;             /* ... that passed the kinodynamic tests                         */
   int32_t n_collision_free;       /* ... and the collision tests                                   */
   int32_t goal_occupied;          /* setUp's goal_occupied_ (:210-226)                             */
-  int32_t _pad;                   /* entangle check on: WHICH capacity a search flagged ent_overflow ran into — bit 0 the
-                                     crossing list (NEP_FE_ENT_CAP), bit 1 more than 32 new crossings in one sampled step,
-                                     bit 2 more than NEP_MAX_BEND bend points; else 0                              */
+  int32_t _pad;                   /* entangle check on: bit 3 = the pool of big records ran out (ent_overflow); bits 8
+                                     and up = children of this search that were carried in big records; else 0       */
   double cost;                    /* g + bias*h of the returned node                               */
   double dist_to_goal;
   int32_t n_entangled;            /* children pruned by entanglesWithOtherAgents (entangle check on)        */
-  int32_t ent_overflow;           /* 1: a node's crossing list would have exceeded NEP_FE_ENT_CAP           */
+  int32_t ent_overflow;           /* 1: a child needed a big record and the handle's pool had none left: pruned (a
+                                     deviation from the reference's rule; 0 in every test and bench leg)             */
 } nep_fe_result;
 
 /* Front end of every slot of the batch handle, asynchronous on `stream`.
@@ -157,6 +163,20 @@ int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* 
  *                             end of its first pass, :983), with three times the search's crossing capacity and no
  *                             tether-length test.  An entangling trajectory is turned down like a colliding one.   */
 int nep_batch_set_static_reps(nep_batch_t* h, int32_t scene, const double* rep, const double* longest);
+/* Big records of the entangle-aware front end (see NEP_FE_ENT_CAP above).
+ * nep_batch_set_fe_ent_big_records   records in the handle's pool (0: the default, 4 per slot and at least 4 096); a record
+ *                                    holds num_agents + statics crossings (13 bytes each) and the scratch of one sampled
+ *                                    step; takes effect at the next front-end call (not while a stream is capturing).
+ * nep_batch_set_fe_ent_fast_caps     what the fixed record's path accepts before a child goes to a big record: list
+ *                                    entries (<= NEP_FE_ENT_CAP), new crossings per sampled step (<= 32), bend points
+ *                                    (<= NEP_MAX_BEND).  The results do not depend on these — the tests set them to
+ *                                    0 / 1 / 2 to drive ordinary scenes through the big records.                      */
+/* Device time of the last search of every slot, microseconds (what nep_stats.solve_us is for the QP): us [slots], host.  The
+ * searches of a launch are started longest-expected-first — the previous search of the same slot is the predictor, as for the
+ * QP's workgroups (nep_batch_set_launch_order switches both); the results do not depend on the order.               */
+int nep_batch_fe_search_us(nep_batch_t* h, float* us, int32_t cap);
+int nep_batch_set_fe_ent_big_records(nep_batch_t* h, int64_t records);
+int nep_batch_set_fe_ent_fast_caps(nep_batch_t* h, int32_t list_cap, int32_t add_cap, int32_t bend_cap);
 int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed, const nep_fe_start* d_start,
                            const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result,
                            int32_t* d_case_out, void* stream);

@@ -31,7 +31,7 @@ PLAN_EXPORTS = [
 ]
 # every symbol include/neptune_entangle.h declares (host-only)
 # include/neptune_frontend.h
-FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_frontend_ent", "nep_batch_safety_commit_ent", "nep_batch_next_starts", "nep_batch_frontend_ent_hulls"]
+FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_frontend_ent", "nep_batch_safety_commit_ent", "nep_batch_next_starts", "nep_batch_frontend_ent_hulls", "nep_batch_set_fe_ent_big_records", "nep_batch_set_fe_ent_fast_caps", "nep_batch_fe_search_us"]
 ENT_EXPORTS = ["nep_ent_sample_points", "nep_ent_propagate_segment", "nep_ent_propagate_guess", "nep_ent_case_ids"]
 
 
@@ -106,6 +106,9 @@ def lib():
     L.nep_batch_active_rows.argtypes = [vp, vp, d, vp, vp]
     L.nep_batch_reserve_row_scratch.argtypes = [vp]
     L.nep_batch_set_line_capacity.argtypes = [vp, i]
+    L.nep_batch_set_fe_ent_big_records.argtypes = [vp, C.c_int64]
+    L.nep_batch_set_fe_ent_fast_caps.argtypes = [vp, i, i, i]
+    L.nep_batch_fe_search_us.argtypes = [vp, C.POINTER(C.c_float), i]
     L.nep_batch_line_bucket_bytes.argtypes = [vp]; L.nep_batch_line_bucket_bytes.restype = C.c_int64
     L.nep_batch_row_scratch_bytes.argtypes = [vp]; L.nep_batch_row_scratch_bytes.restype = C.c_int64
     L.nep_backend_debug_time_sequence.argtypes = [vp, vp, i, pi, pd, pi, pd, vp, d, d, i, pd, pd]

@@ -392,6 +392,20 @@ class BatchBackend:
         """one worst-case row-scratch area per slot instead of the redo pass's pool (nep_batch_reserve_row_scratch)"""
         check(lib().nep_batch_reserve_row_scratch(self._h))
 
+    def fe_search_us(self):
+        """device time of the last front-end search of every slot, microseconds (nep_batch_fe_search_us)"""
+        out = np.zeros(self.slots, dtype=np.float32)
+        check(lib().nep_batch_fe_search_us(self._h, out.ctypes.data_as(C.POINTER(C.c_float)), int(self.slots)))
+        return out
+
+    def set_fe_ent_big_records(self, records):
+        """records in the pool of big entangle-state records of the front end (0: default; nep_batch_set_fe_ent_big_records)"""
+        check(lib().nep_batch_set_fe_ent_big_records(self._h, int(records)))
+
+    def set_fe_ent_fast_caps(self, list_cap=40, add_cap=32, bend_cap=8):
+        """what the fixed entangle-state record's path accepts before a child goes to a big record (results do not depend on it)"""
+        check(lib().nep_batch_set_fe_ent_fast_caps(self._h, int(list_cap), int(add_cap), int(bend_cap)))
+
     def set_line_capacity(self, lines_per_segment):
         """lines a (replan, segment) bucket holds: 0 default budget, -1 the reference's worst case, n > 0 (nep_batch_set_line_capacity)"""
         check(lib().nep_batch_set_line_capacity(self._h, int(lines_per_segment)))

@@ -104,10 +104,14 @@ struct Engine {
   // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
   DevBuf<double> d_sampled, d_srep, d_slong; DevBuf<int> d_present, d_entangles;
   DevBuf<nep_fe_ent_state> d_fe_nodes, d_fe_work, d_fe_saved; DevBuf<double> d_fe_arc, d_fe_packed; bool have_reps = false;
+  // big records of the entangle-aware front end (ent_device.h): a pool per handle, 0 = the default budget (4 per slot, at least 4 096)
+  DevBuf<unsigned char> d_fe_big, d_fe_big_check; DevBuf<int> d_fe_big_count, d_fe_big_check_count; long fe_big_records = 0;
+  int fe_fast_cap = NEP_FE_ENT_CAP, fe_fast_add = 32, fe_fast_bend = NEP_MAX_BEND;
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
   DevBuf<double> d_fe_box;          // boxes of the front end's obstacles, made before every search launch
+  DevBuf<int> d_fe_order, d_fe_order_key; DevBuf<float> d_fe_us; bool fe_history = false;      // the same for the front end's searches (frontend_kernel)
   DevBuf<int> d_order, d_order_key; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double clock_hz = 1e8;       // wall_clock64() rate of the handle's device (set_clock)
@@ -212,6 +216,8 @@ struct Engine {
     if (getenv("NEP_SEP_UNPACKED")) sep_pack = -1;
     else if (const char* f = getenv("NEP_SEP_PACK")) { const int v = atoi(f); if (v >= 1 && v <= NEP_MAX_POL) sep_pack = v; }
     if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; if (int e = d_order_key.ensure((size_t)slots)) return e; }
+    if (lpt) { if (int e = d_fe_order.ensure((size_t)slots)) return e; if (int e = d_fe_order_key.ensure((size_t)slots)) return e; }
+    if (int e = d_fe_us.ensure((size_t)slots)) return e;
     choose_placement();
     rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
     if (int e = d_hull_xy.ensure((size_t)n_scenes * sp.n_hull * np * kHullV * 2)) return e;
@@ -238,6 +244,7 @@ struct Engine {
     ps.pb = d_pb.p; ps.static_xy = d_static_xy.p; ps.static_nv = d_static_nv.p; ps.static_el = d_static_el.p;
     ps.hull_xy = d_hull_xy.p; ps.hull_nv = d_hull_nv.p; ps.hull0_xy = d_hull0_xy.p; ps.hull0_nv = d_hull0_nv.p;
     ps.bend_xy = d_bend_xy.p; ps.bend_n = d_bend_n.p;
+    ps.fe_order = nullptr; ps.fe_order_key = (lpt && d_fe_order_key.n >= (size_t)n_scenes * (size_t)sp.n_local) ? d_fe_order_key.p : nullptr; ps.fe_us = d_fe_us.p;
     ps.line_nd = d_line_nd.p; ps.line_cnt = d_line_cnt.p; ps.lp_stats = d_lp_stats.p;
     ps.line_far = sp.cull_radius > 0.0 ? d_line_far.p : nullptr;
     // LPs whose line is known to be far without solving them are skipped when the presolve is on, the rule is the largest gap
@@ -395,8 +402,8 @@ struct Engine {
   }
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
-    d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_box.release();
-    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release();
+    d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_order.release(); d_fe_order_key.release(); d_fe_us.release(); d_fe_box.release();
+    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release(); d_fe_big.release(); d_fe_big_count.release(); d_fe_big_check.release(); d_fe_big_check_count.release();
     d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
@@ -1013,7 +1020,8 @@ int nep_batch_frontend(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec
   E.fill(ps);
   h->fe_committed = d_committed;
   launch_hulls_ts(d_committed, h->cfg.n_scenes, h->cfg.num_agents, &d_start->t_start, (long)sizeof(nep_fe_start), E.sp, ps, (hipStream_t)stream);
-  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, nullptr, (hipStream_t)stream);
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, nullptr, (hipStream_t)stream, E.lpt ? E.d_fe_order.p : nullptr, E.fe_history);
+  E.fe_history = true;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1033,7 +1041,8 @@ int nep_batch_frontend_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const void* 
   ps.hull_pb = h->cfg.n_local; ps.hull_bstride = (long)b.bytes;
   ps.hull_pb_magic = (h->cfg.n_local > 0 && h->cfg.num_agents < 65536) ? (1ull << 32) / (unsigned long long)h->cfg.n_local + 1ull : 0ull;
   h->fe_committed = nullptr;
-  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, nullptr, (hipStream_t)stream);
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, nullptr, (hipStream_t)stream, E.lpt ? E.d_fe_order.p : nullptr, E.fe_history);
+  E.fe_history = true;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1071,9 +1080,17 @@ int ent_prepare(nep_batch* h, int ns, int beam_width, const nep_traj_rec* d_recs
   if (int e = E.d_fe_work.ensure((size_t)std::max(h->slots * 256, S * N))) return e;
   if (beam_width > 0) { if (int e = E.d_fe_nodes.ensure((size_t)h->slots * (np + 1) * beam_width)) return e; }
   if (!E.d_srep.p) { if (int e = E.d_srep.ensure(4)) return e; if (int e2 = E.d_slong.ensure(2)) return e2; }
-  launch_ent_sample(d_recs, S, N, ts0, ts_scene_stride, np, ns, E.sp.T_span, E.d_sampled.p, E.d_present.p, st);
+  {   // the re-check's big records (three times the search's bound: entangleCheckGivenPwp); a sixteenth of the search's pool, at least 256
+    const long n_rec = std::max(256L, (E.fe_big_records > 0 ? E.fe_big_records : std::max(4096L, 4L * h->slots)) / 16);
+    const size_t rec = (size_t)ent_big_rec_bytes(N, E.sp.n_static, 3);
+    if (int e = E.d_fe_big_check.ensure(rec * (size_t)n_rec)) return e;
+    if (int e = E.d_fe_big_check_count.ensure(1)) return e;
+    ea.big_check = EntBigPool{E.d_fe_big_check.p, E.d_fe_big_check_count.p, (int)n_rec, (int)rec, ent_big_cap(N, E.sp.n_static, 3), ent_big_add_lim(N, E.sp.n_static, 3)};
+  }
+  launch_ent_sample(d_recs, S, N, ts0, ts_scene_stride, np, ns, E.sp.T_span, E.d_sampled.p, E.d_present.p, st, E.d_fe_big_check_count.p);
   ea.sampled = E.d_sampled.p; ea.present = E.d_present.p; ea.srep = E.d_srep.p; ea.slong = E.d_slong.p;
   ea.nodes = E.d_fe_nodes.p; ea.work = E.d_fe_work.p; ea.ns = ns; ea.init = nullptr; ea.case_out = nullptr; ea.saved = nullptr; ea.saved_arc = nullptr;
+  ea.fast_cap = E.fe_fast_cap; ea.fast_add = E.fe_fast_add; ea.fast_bend = E.fe_fast_bend;
   return 0;
 }
 }  // namespace
@@ -1112,6 +1129,26 @@ static int fe_ent_scratch(nep_batch* h, const nep_fe_cfg& cfg, FeEntArgs& ea) {
   ea.pk_stride = 2 + 2 * kBend + 2 * (ea.ns + 1);      // (kEntPkHead + the samples: an even number of doubles)
   if (int e = E.d_fe_packed.ensure((size_t)h->cfg.n_scenes * h->cfg.num_agents * h->cfg.num_pol * ea.pk_stride)) return e;
   ea.packed = E.d_fe_packed.p;
+  // the pool of big records: states beyond the fixed record's capacities (rare: a handful of children in a few of 8 192 config-5
+  // searches), sized by the reference's own bound on a list (num_agents + statics)
+  const int N = h->cfg.num_agents, S = E.sp.n_static;
+  const long n_rec = E.fe_big_records > 0 ? E.fe_big_records : std::max(4096L, 4L * h->slots);
+  const size_t rec = (size_t)ent_big_rec_bytes(N, S);
+  if (int e = E.d_fe_big.ensure(rec * (size_t)n_rec)) return e;
+  if (int e = E.d_fe_big_count.ensure(2 + 1024)) return e;      // [0] records claimed, [1] searches listed for the big-record instantiation, [2..] the list
+  ea.redo_count = E.d_fe_big_count.p + 1; ea.redo_list = E.d_fe_big_count.p + 2; ea.redo_cap = 1024;
+  ea.big = EntBigPool{E.d_fe_big.p, E.d_fe_big_count.p, (int)n_rec, (int)rec, ent_big_cap(N, S), ent_big_add_lim(N, S)};
+  ea.fast_cap = E.fe_fast_cap; ea.fast_add = E.fe_fast_add; ea.fast_bend = E.fe_fast_bend;
+  return 0;
+}
+int nep_batch_set_fe_ent_big_records(nep_batch_t* h, int64_t records) {
+  if (!h || records < 0) return fail(NEP_E_ARG, "bad arguments");
+  h->eng.fe_big_records = (long)records;
+  return 0;
+}
+int nep_batch_set_fe_ent_fast_caps(nep_batch_t* h, int32_t list_cap, int32_t add_cap, int32_t bend_cap) {
+  if (!h || list_cap < 0 || list_cap > NEP_FE_ENT_CAP || add_cap < 0 || add_cap > 32 || bend_cap < 0 || bend_cap > NEP_MAX_BEND) return fail(NEP_E_ARG, "fast-path capacities out of range");
+  h->eng.fe_fast_cap = list_cap; h->eng.fe_fast_add = add_cap; h->eng.fe_fast_bend = bend_cap;
   return 0;
 }
 
@@ -1130,7 +1167,8 @@ int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj
   if (int e = ent_prepare(h, cfg->ent_samples, cfg->beam_width, d_committed, &d_start->t_start, (long)sizeof(nep_fe_start) * E.sp.n_local, ea, (hipStream_t)stream)) return e;
   ea.init = d_ent_init; ea.case_out = d_case_out;
   if (int e = fe_ent_scratch(h, *cfg, ea)) return e;
-  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream);
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream, E.lpt ? E.d_fe_order.p : nullptr, E.fe_history);
+  E.fe_history = true;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1161,7 +1199,8 @@ int nep_batch_frontend_ent_hulls(nep_batch_t* h, const nep_fe_cfg* cfg, const vo
   ea.srep = E.d_srep.p; ea.slong = E.d_slong.p; ea.nodes = E.d_fe_nodes.p; ea.work = E.d_fe_work.p; ea.ns = h->ent_ns;
   ea.init = d_ent_init; ea.case_out = d_case_out;
   if (int e = fe_ent_scratch(h, *cfg, ea)) return e;
-  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream);
+  launch_frontend(h->slots, E.sp, ps, *cfg, d_start, d_guess, d_result, &ea, (hipStream_t)stream, E.lpt ? E.d_fe_order.p : nullptr, E.fe_history);
+  E.fe_history = true;
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -1239,8 +1278,15 @@ int nep_batch_qp_placement(nep_batch_t* h) { return h ? (h->eng.use_reg ? 1 : 0)
 int nep_batch_set_launch_order(nep_batch_t* h, int32_t enable) {
   if (!h) return fail(NEP_E_ARG, "null handle");
   if (enable) { if (int e = h->eng.d_order.ensure((size_t)h->slots)) return e; if (int e = h->eng.d_order_key.ensure((size_t)h->slots)) return e; }
-  if (!enable) h->eng.have_history = false;
+  if (enable) { if (int e = h->eng.d_fe_order.ensure((size_t)h->slots)) return e; if (int e = h->eng.d_fe_order_key.ensure((size_t)h->slots)) return e; }
+  if (!enable) { h->eng.have_history = false; h->eng.fe_history = false; }
   h->eng.lpt = enable != 0;
+  return 0;
+}
+int nep_batch_fe_search_us(nep_batch_t* h, float* us, int32_t cap) {
+  if (!h || !us || cap < h->slots) return fail(NEP_E_ARG, "bad arguments");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(us, h->eng.d_fe_us.p, (size_t)h->slots * sizeof(float), hipMemcpyDeviceToHost));
   return 0;
 }
 int nep_batch_debug_launch_order(nep_batch_t* h, int32_t* order, int32_t cap, int32_t* n_out) {
@@ -1337,6 +1383,7 @@ int nep_batch_check(nep_batch_t* h, void* stream) {
   }
   if (flags & NEP_FLAG_LINES) return fail(NEP_E_CAP, "a segment got more separating lines than its bucket holds: nep_batch_set_line_capacity(h, -1) sizes the buckets for the reference's worst case");
   if (flags & NEP_FLAG_SCRATCH) return fail(NEP_E_CAP, "the presolve's redo pass listed more replans with rows beyond the register slots than the handle has scratch areas for: nep_batch_reserve_row_scratch");
+  if (flags & NEP_FLAG_ENT_POOL) return fail(NEP_E_CAP, "the entangle re-check of the safety pass ran out of big records (a trajectory was turned down for it): nep_batch_set_fe_ent_big_records");
   if (flags & NEP_FLAG_ENT_BETA) return fail(NEP_E_ARG, "an entangle state passed to the front end has a non-zero beta for an agent crossing (the reference's calculateBetaForCase makes it 0.0)");
   if (flags & NEP_FLAG_HULL_OVERFLOW) return fail(NEP_E_CAP, "an interval overlaps more than NEP_HULL_MAX_CP/4 committed segments (or its hull has more than NEP_HULL_MAX_V vertices)");
   return 0;

@@ -47,7 +47,10 @@ constexpr int kEntAddCap = 32;
 // `gone` and stays where it is: no shifting, and the ids of the step's crossings remain readable after the merge.
 struct EntAdd {
   static constexpr int cap = kEntAddCap, reg = 4;
-  unsigned r0, r1, r2, r3; unsigned* rest; int n, overflow; unsigned gone;      // rest: kEntAddCap - reg words of the caller's
+  static constexpr bool exact = false;      // (a full list is a capacity: the caller retries on the global-memory form below)
+  unsigned r0, r1, r2, r3; unsigned* rest; int n, overflow; unsigned gone; int lim;      // rest: kEntAddCap - reg words of the caller's; lim <= cap: entries accepted
+  struct Store { unsigned* rest; int lim; };      // (what outlives a sampled step: the list itself is made anew for every step, so that nothing of it is live across steps)
+  __device__ __forceinline__ void attach(const Store& s) { rest = s.rest; lim = s.lim; }
   __device__ __forceinline__ unsigned get(int i) const {
     if (__builtin_expect(i >= reg, 0)) return rest[i - reg];
     const unsigned a = (i & 1) ? r1 : r0, b = (i & 1) ? r3 : r2;
@@ -59,7 +62,28 @@ struct EntAdd {
   }
   __device__ __forceinline__ void clear() { n = 0; overflow = 0; gone = 0u; }
   __device__ __forceinline__ bool alive(int i) const { return !((gone >> i) & 1u); }
+  __device__ __forceinline__ void kill(int i) { gone |= 1u << i; }
   __device__ __forceinline__ int n_alive() const { return n - __popc(gone); }
+  __device__ __forceinline__ int id(int i) const { return (int)(get(i) & 0xffffu); }
+  __device__ __forceinline__ int cs(int i) const { return (int)((get(i) >> 16) & 0xffu); }
+  __device__ __forceinline__ int nb(int i) const { return (int)(get(i) >> 24); }
+};
+// The same list without a capacity of its own: words and cancellation bits in global memory (a big record's tail, below), room for
+// num_agents + statics + 2 entries.  That is exact for the reference's rule: entanglesWithOtherAgents prunes the child when the
+// node's list plus the step's new crossings exceed num_agents + statics (kinodynamic_search.cpp:850-854), an agent's own pushes are
+// the only ones its base-addition pop removes (entangle_utils.cpp:1129-1228: the last TWO entries, same id), so a step that fills
+// this list has at least lim - 1 > num_agents + statics crossings when the agent loop ends — pruned whatever the list holds.
+struct EntAddBig {
+  static constexpr bool exact = true;
+  unsigned* w; unsigned* gone_w; int n, overflow, n_gone, lim;
+  struct Store { unsigned* w; unsigned* gone_w; int lim; };
+  __device__ __forceinline__ void attach(const Store& s) { w = s.w; gone_w = s.gone_w; lim = s.lim; }
+  __device__ __forceinline__ unsigned get(int i) const { return w[i]; }
+  __device__ __forceinline__ void set(int i, unsigned v) { w[i] = v; }
+  __device__ __forceinline__ void clear() { n = 0; overflow = 0; n_gone = 0; for (int i = 0; i < (lim + 31) >> 5; i++) gone_w[i] = 0u; }
+  __device__ __forceinline__ bool alive(int i) const { return !((gone_w[i >> 5] >> (i & 31)) & 1u); }
+  __device__ __forceinline__ void kill(int i) { gone_w[i >> 5] |= 1u << (i & 31); n_gone++; }
+  __device__ __forceinline__ int n_alive() const { return n - n_gone; }
   __device__ __forceinline__ int id(int i) const { return (int)(get(i) & 0xffffu); }
   __device__ __forceinline__ int cs(int i) const { return (int)((get(i) >> 16) & 0xffu); }
   __device__ __forceinline__ int nb(int i) const { return (int)(get(i) >> 24); }
@@ -77,7 +101,7 @@ __device__ __forceinline__ double ent_wedge(Ev2 a, Ev2 b, Ev2 cc) { return (b.x 
 __device__ __forceinline__ double ent_wedge2(Ev2 a, Ev2 b, Ev2 cc, Ev2& ab, Ev2& ac) { ab.x = b.x - a.x; ab.y = b.y - a.y; ac.x = cc.x - a.x; ac.y = cc.y - a.y; return ab.x * ac.y - ac.x * ab.y; }
 __device__ __forceinline__ double ent_ratio(Ev2 u, Ev2 v) { return fabs(u.y * v.y) > fabs(u.x * v.x) ? u.y / v.y : u.x / v.x; }
 __device__ __forceinline__ double ent_dist(Ev2 a, Ev2 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
-__device__ __forceinline__ void ent_push(EntAdd& a, int id, int cs, int nb = 0) { if (a.n < EntAdd::cap) { a.set(a.n, (unsigned)(id & 0xffff) | ((unsigned)(cs & 0xff) << 16) | ((unsigned)(nb & 0xff) << 24)); a.n++; } else a.overflow = 1; }
+template <class ADD> __device__ __forceinline__ void ent_push(ADD& a, int id, int cs, int nb = 0) { if (a.n < a.lim) { a.set(a.n, (unsigned)(id & 0xffff) | ((unsigned)(cs & 0xff) << 16) | ((unsigned)(nb & 0xff) << 24)); a.n++; } else a.overflow = 1; }
 
 // ---- proofs that an obstacle adds no crossing for ANY sampled step inside a box (frontend_kernel's per-parent masks,
 // ent_check_kernel's per-trajectory mask).  A step p_k -> p_k1 adds a crossing with a tether segment only if the two points lie
@@ -157,7 +181,7 @@ __device__ __forceinline__ bool ent_static_may_cross(const EntCtx& c, const EntB
 // (f_known: -1 = evaluate the base-sweep test here; 0 / 1 = its outcome, from EntCtx::f_bits)
 // (b0: bend point 0 in registers, where the caller has fetched it with the record's header — most tethers have no other, and a load
 // issued here waits for everything the caller has requested ahead, i.e. for the NEXT obstacle's record)
-__device__ __forceinline__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id, int f_known = -1, bool have_b0 = false, Ev2 b0 = Ev2{0, 0}) {
+template <class ADD> __device__ __forceinline__ void ent_cross_agent(ADD& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id, int f_known = -1, bool have_b0 = false, Ev2 b0 = Ev2{0, 0}) {
   bool base_addition = false;
   for (int k = 0; k < nb; k++) {
     const bool last = k == nb - 1;
@@ -187,7 +211,7 @@ __device__ __forceinline__ void ent_cross_agent(EntAdd& add, Ev2 pk, Ev2 pk1, Ev
   }
   if (base_addition && add.n >= 2 && ((add.get(add.n - 1) ^ add.get(add.n - 2)) & 0xffffffu) == 0u) add.n -= 2;      // (same id, same case)
 }
-__device__ __forceinline__ void ent_cross_static(EntAdd& add, Ev2 pk, Ev2 pk1, const EntCtx& c) {
+template <class ADD> __device__ __forceinline__ void ent_cross_static(ADD& add, Ev2 pk, Ev2 pk1, const EntCtx& c) {
   if (c.m_static) {
     // (front end: the candidates of this parent in index order, the NEXT one's representative requested before the current one's
     // wedges are evaluated — as for the agents, ent_propagate)
@@ -248,9 +272,17 @@ __device__ __forceinline__ double ent_beta(int id, int cs, Ev2 pk, Ev2 bp, const
 // obstacles carry one).  The LDS-resident view (EntLds, below) keeps its betas in global memory and relies on that: it neither
 // reads nor rewrites the beta of an agent entry — reads are round trips the list surgery would wait for, and nearly every entry is
 // an agent's.  nep_fe_ent_state itself is handled as written (every beta moved and compared as stored).
-struct EntLds;
+struct EntLds; struct EntBig;
 template <class ST> struct ent_lazy_beta { static constexpr bool v = false; };
 template <> struct ent_lazy_beta<EntLds> { static constexpr bool v = true; };
+template <> struct ent_lazy_beta<EntBig> { static constexpr bool v = true; };
+// capacities of a state's form and the type of its bend indices (the fixed record and its LDS view: NEP_FE_ENT_CAP entries at most,
+// NEP_MAX_BEND bend points, byte indices; the big record: as many as the reference's rule can ever leave on a list, 16-bit indices)
+template <class ST> struct ent_tr {
+  typedef signed char bend_t;
+  static __device__ __forceinline__ int cap(const ST*) { return NEP_FE_ENT_CAP; }
+  static __device__ __forceinline__ int bend_cap(const ST*) { return NEP_MAX_BEND; }
+};
 // A 64-bit signature of the ids on a list (bit id mod 64): the cancellation scan of a new crossing and the per-agent counts walk the
 // whole list looking for entries of ONE id, and nearly always there is none (a crossing with somebody not crossed before is the
 // common case) — a clear bit proves that without the walk.  Kept by the LDS view only (set on append, never cleared: a stale bit
@@ -274,7 +306,7 @@ __device__ int ent_bend_n(const EntCtx& c, int j) { const HullRef hr = hull_ref(
 #else
 #define ENT_MT(k) do { } while (0)
 #endif
-template <class ST> __device__ __forceinline__ bool ent_merge(EntAdd& add, ST* st, Ev2 pk, Ev2 pb_self, const EntCtx& c, long long* mt = nullptr, long long* ml = nullptr) {
+template <class ST, class ADD> __device__ __forceinline__ bool ent_merge(ADD& add, ST* st, Ev2 pk, Ev2 pb_self, const EntCtx& c, long long* mt = nullptr, long long* ml = nullptr) {
   bool again = true;
   while (again) {
     again = false;
@@ -299,7 +331,7 @@ template <class ST> __device__ __forceinline__ bool ent_merge(EntAdd& add, ST* s
         const int dcs = t_cs - l_cs;
         const bool match = (l_id == t_id) & ((dcs == 0) | (t_deep & (dcs < 0)) | (t_bend & (l_cs >= 2) & ((dcs == 1) | (dcs == -1)) & (j > b)));
         if (match) {
-          add.gone |= 1u << i;
+          add.kill(i);
           ENT_MT(1);
           ent_erase(st, j, c.N);      // (the id signature keeps the erased entry's bit: a set bit only ever costs a walk)
           if (j == b) {
@@ -307,7 +339,7 @@ template <class ST> __device__ __forceinline__ bool ent_merge(EntAdd& add, ST* s
             const Ev2 bp = ent_cur_bend(st, pb_self, c);
             for (int k = j; k < st->n_alpha; k++) if (!ent_lazy_beta<ST>::v || st->id[k] > c.N) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk, bp, c);
           } else if (j < b) {
-            st->bend[st->n_bend - 1] = (signed char)(b - 1);
+            st->bend[st->n_bend - 1] = (typename ent_tr<ST>::bend_t)(b - 1);
             for (int k = st->n_bend - 2; k >= 0; k--) { if (st->bend[k] > j) st->bend[k] -= 1; else break; }
           }
           again = true;
@@ -322,7 +354,7 @@ template <class ST> __device__ __forceinline__ bool ent_merge(EntAdd& add, ST* s
   ENT_MT(1);
   const int n_new = add.n_alive();
   if (n_new == 0) return false;
-  if (st->n_alpha + n_new > NEP_FE_ENT_CAP) return true;
+  if (st->n_alpha + n_new > ent_tr<ST>::cap(st)) return true;
   const Ev2 bp = ent_cur_bend(st, pb_self, c);
   for (int i = 0; i < add.n; i++) {
     if (!add.alive(i)) continue;
@@ -342,8 +374,8 @@ template <class ST> __device__ bool ent_update_bends(ST* st, Ev2 pk1, Ev2 pb_sel
     const double beta = ent_beta(st->id[i], st->cs[i], pk1, bp, c); if (beta * st->beta[i] < -1e-7) idx_new = i;
   }
   if (idx_new > -1) {
-    if (st->n_bend >= NEP_MAX_BEND) return true;
-    st->bend[st->n_bend++] = (signed char)idx_new;
+    if (st->n_bend >= ent_tr<ST>::bend_cap(st)) return true;
+    st->bend[st->n_bend++] = (typename ent_tr<ST>::bend_t)idx_new;
     const Ev2 nb = ent_anchor(st->id[idx_new], st->cs[idx_new], c);
     for (int i = idx_new + 1; i < st->n_alpha; i++) if (!ent_lazy_beta<ST>::v || st->id[i] > c.N) st->beta[i] = ent_beta(st->id[i], st->cs[i], pk1, nb, c);
     return false;
@@ -374,7 +406,8 @@ template <class ST> __device__ double ent_tether(const ST* st, Ev2 from, Ev2 pk1
 template <class P> __device__ __forceinline__ int ent_count(P ids, int n, int id) { int k = 0; for (int i = 0; i < n; i++) k += ids[i] == id; return k; }
 
 // 0: fine; 1: the reference's function returns true (prune); 2, 3, 4: a capacity exceeded (pruned, flagged; which one: see the returns)
-template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const double* cxo, const double* cyo, Ev2 end, int index, double& arc, bool check_tether, int cap_mult) {
+// (ADD, store: the form of the list of a step's new crossings and its storage — EntAdd with its tail, or EntAddBig on a big record)
+template <class ADD, class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const typename ADD::Store& store, const double* cxo, const double* cyo, Ev2 end, int index, double& arc, bool check_tether, int cap_mult) {
   const int ns = c.ns;
   const Ev2 pb_self = ent_pb(c, c.own);
   Ev2 pk{cxo[3], cyo[3]}, pk1 = pk;
@@ -384,9 +417,8 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
 #else
 #define ENT_PT(k) do { } while (0)
 #endif
-  unsigned add_tail[kEntAddCap - EntAdd::reg];
   for (int j = 1; j <= ns; j++) {
-    EntAdd add; add.rest = add_tail; add.clear();
+    ADD add; add.attach(store); add.clear();
     ENT_PT(4);
     if (j < ns) {
       const double t = c.T_span * j / ns;
@@ -438,7 +470,7 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
 #ifdef NEP_PROFILE_PHASES
     p_add += add.n > 0;
 #endif
-    if (add.overflow) return 3;      // (2: the list's capacity, 3: more than kEntAddCap new crossings in one step, 4: more than NEP_MAX_BEND bend points)
+    if (add.overflow) return ADD::exact ? 1 : 3;      // (EntAddBig: see there; 2: the list's capacity, 3: more than kEntAddCap new crossings in one step, 4: more than NEP_MAX_BEND bend points)
     if (st->n_alpha + add.n > (c.N + c.S) * cap_mult) return 1;
     if (add.n > 0) {     // (no crossing in this step: the list, and with it every count below, is what it was)
       // entanglesWithOtherAgents compares, for every agent in the new list, its number of entries before and after the merge
@@ -499,17 +531,25 @@ template <class ST> __device__ int ent_propagate(const EntCtx& c, ST* st, const 
 // surgery code is a template over the two.
 typedef __attribute__((address_space(3))) short* ent_lds_short;
 typedef __attribute__((address_space(3))) signed char* ent_lds_char;
-struct EntLds { int n_alpha, n_bend; ent_lds_short id; ent_lds_char cs; double* beta; ent_lds_char bend; unsigned long long sig; };
+struct EntLds { int n_alpha, n_bend; ent_lds_short id; ent_lds_char cs; double* beta; ent_lds_char bend; unsigned long long sig; int cap, bend_cap; };      // cap <= NEP_FE_ENT_CAP, bend_cap <= NEP_MAX_BEND: what the view accepts (the handle's fast-path limits)
+template <> struct ent_tr<EntLds> {
+  typedef signed char bend_t;
+  static __device__ __forceinline__ int cap(const EntLds* st) { return st->cap; }
+  static __device__ __forceinline__ int bend_cap(const EntLds* st) { return st->bend_cap; }
+};
 template <> __device__ __forceinline__ bool ent_sig_may_have<EntLds>(const EntLds* st, int id) { return (st->sig >> (id & 63)) & 1ull; }
 template <> __device__ __forceinline__ void ent_sig_add<EntLds>(EntLds* st, int id) { st->sig |= 1ull << (id & 63); }
 template <> __device__ __forceinline__ unsigned long long ent_sig_of<EntLds>(const EntLds* st) { return st->sig; }
 constexpr int kEntLdsBytes = ((NEP_FE_ENT_CAP * 3 + NEP_MAX_BEND + 3) & ~3) | 4;      // per thread; an odd number of dwords, so that the threads' lists fall into different banks
-__device__ __forceinline__ void ent_lds_load(EntLds& L, const nep_fe_ent_state* __restrict__ src, int N) {
+// (false: the record is a big record's marker, or holds more than the view takes — the caller goes to the big form)
+__device__ __forceinline__ bool ent_lds_load(EntLds& L, const nep_fe_ent_state* __restrict__ src, int N) {
   L.n_alpha = src->n_alpha; L.n_bend = src->n_bend;
+  if (__builtin_expect((L.n_alpha < 0) | (L.n_alpha > L.cap) | (L.n_bend > L.bend_cap), 0)) return false;
   unsigned long long g = 0ull;
   for (int i = 0; i < L.n_alpha; i++) { const int id_ = src->id[i]; L.id[i] = (short)id_; L.cs[i] = src->cs[i]; g |= 1ull << (id_ & 63); if (id_ > N) L.beta[i] = src->beta[i]; }      // (betas of statics only: see ent_lazy_beta)
   L.sig = g;
   for (int i = 0; i < L.n_bend; i++) L.bend[i] = src->bend[i];
+  return true;
 }
 __device__ __forceinline__ void ent_lds_store(nep_fe_ent_state* __restrict__ dst, const EntLds& L, int N) {
   dst->n_alpha = L.n_alpha; dst->n_bend = L.n_bend;
@@ -517,6 +557,39 @@ __device__ __forceinline__ void ent_lds_store(nep_fe_ent_state* __restrict__ dst
   for (int i = 0; i < L.n_bend; i++) dst->bend[i] = L.bend[i];
   for (int i = 0; i < L.n_alpha; i++) dst->beta[i] = L.id[i] > N ? L.beta[i] : 0.0;
 }
+
+// ---- A state without a capacity of its own: the big record.  A child whose step adds more crossings than EntAdd holds, whose list
+// outgrows NEP_FE_ENT_CAP or whose tether bends more than NEP_MAX_BEND times — and every child of such a node — is carried in a record
+// of the launch's pool in global memory, sized by the reference's own bound: entanglesWithOtherAgents prunes a child whose list plus
+// new crossings exceed num_agents + statics (kinodynamic_search.cpp:850-854), so no list — and no set of bend points, which are list
+// entries — is ever longer than that.  The fixed record that stands for such a node (saved[], nodes[]) holds n_alpha = -(k + 1), k
+// the pool index; a record is written once and never changed (its children copy it).  Layout of record k (rec_bytes apart):
+//   [n_alpha, n_bend | beta[cap] | id[cap] (16 bit) | bend[cap] (16 bit) | cs[cap] | pad | add words[add_lim] | add cancel bits]
+struct EntBig { int n_alpha, n_bend; short* id; signed char* cs; double* beta; short* bend; int cap; unsigned long long sig; };      // (sig: as EntLds'; betas of agent entries neither read nor written, as there)
+template <> __device__ __forceinline__ bool ent_sig_may_have<EntBig>(const EntBig* st, int id) { return (st->sig >> (id & 63)) & 1ull; }
+template <> __device__ __forceinline__ void ent_sig_add<EntBig>(EntBig* st, int id) { st->sig |= 1ull << (id & 63); }
+template <> __device__ __forceinline__ unsigned long long ent_sig_of<EntBig>(const EntBig* st) { return st->sig; }
+template <> struct ent_tr<EntBig> {
+  typedef short bend_t;
+  static __device__ __forceinline__ int cap(const EntBig* st) { return st->cap; }
+  static __device__ __forceinline__ int bend_cap(const EntBig* st) { return st->cap; }
+};
+__device__ __forceinline__ EntBig ent_big_view(const EntBigPool& P, int k) {
+  unsigned char* r = P.base + (size_t)k * P.rec_bytes;
+  EntBig B; B.cap = P.cap; B.sig = ~0ull; B.n_alpha = ((const int*)r)[0]; B.n_bend = ((const int*)r)[1];
+  B.beta = (double*)(r + 8); B.id = (short*)(r + 8 + 8 * P.cap); B.bend = (short*)(r + 8 + 10 * P.cap); B.cs = (signed char*)(r + 8 + 12 * P.cap);
+  return B;
+}
+__device__ __forceinline__ EntAddBig::Store ent_big_add(const EntBigPool& P, int k) {
+  unsigned char* r = P.base + (size_t)k * P.rec_bytes + ((8 + 13 * P.cap + 3) & ~3);
+  return EntAddBig::Store{(unsigned*)r, (unsigned*)(r + 4 * P.add_lim), P.add_lim};
+}
+__device__ __forceinline__ void ent_big_close(const EntBigPool& P, int k, const EntBig& B) { int* h = (int*)(P.base + (size_t)k * P.rec_bytes); h[0] = B.n_alpha; h[1] = B.n_bend; }
+// One child in the big form (frontend_kernel<true>: a child of a big node, or one whose fast-path propagation ran into a capacity):
+// claim a record, copy the parent's state into it (fixed or big), propagate.  Returns ent_propagate's verdict (0 / 1) or 5 = the pool
+// is exhausted (pruned and flagged: nep_fe_result.ent_overflow).  The callers keep it out of their hot loops (a pass of its own behind
+// a flag): as a called function its frame and the registers saved around the call cost the fixed record's path a third of its speed.
+struct EntBigOut { int rc, k, n_alpha, n_bend; unsigned iz; double arc; };
 
 template <class ST> __device__ unsigned ent_iz(const ST* st) {
   unsigned iz = 0;
@@ -528,7 +601,7 @@ template <class ST> __device__ unsigned ent_iz(const ST* st) {
   }
   return iz;
 }
-__device__ bool ent_valid_endpoint(const nep_fe_ent_state* st, int N) {
+template <class ST> __device__ bool ent_valid_endpoint(const ST* st, int N) {
   for (int a = 0; a < st->n_alpha; a++) if (st->id[a] <= N && ent_count(st->id, st->n_alpha, st->id[a]) > 1) return false;
   return true;
 }
@@ -536,6 +609,33 @@ __device__ void ent_copy(nep_fe_ent_state* dst, const nep_fe_ent_state* src) {
   const long* s = (const long*)src; long* d = (long*)dst;
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) d[i] = s[i];
+}
+
+__device__ __forceinline__ EntBigOut ent_big_child(const EntCtx& c, const EntBigPool& P, const nep_fe_ent_state* par, const double* cxo, const double* cyo, Ev2 end, int index, bool check_tether, int cap_mult) {
+  EntBigOut o; o.rc = 5; o.k = -1; o.n_alpha = 0; o.n_bend = 0; o.iz = 0u; o.arc = 0.0;
+  if (!P.base) return o;
+  const int k = atomicAdd(P.count, 1);
+  if (k >= P.n_rec) return o;
+  EntBig B = ent_big_view(P, k);
+  if (par->n_alpha < 0) {
+    const EntBig Q = ent_big_view(P, -par->n_alpha - 1);
+    B.n_alpha = Q.n_alpha; B.n_bend = Q.n_bend;
+    unsigned long long g = 0ull;
+    for (int i = 0; i < Q.n_alpha; i++) { const int id_ = Q.id[i]; B.id[i] = (short)id_; B.cs[i] = Q.cs[i]; g |= 1ull << (id_ & 63); if (id_ > c.N) B.beta[i] = Q.beta[i]; }
+    B.sig = g;
+    for (int i = 0; i < Q.n_bend; i++) B.bend[i] = Q.bend[i];
+  } else {
+    B.n_alpha = par->n_alpha; B.n_bend = par->n_bend;
+    unsigned long long g = 0ull;
+    for (int i = 0; i < par->n_alpha; i++) { const int id_ = par->id[i]; B.id[i] = (short)id_; B.cs[i] = par->cs[i]; g |= 1ull << (id_ & 63); if (id_ > c.N) B.beta[i] = par->beta[i]; }
+    B.sig = g;
+    for (int i = 0; i < par->n_bend; i++) B.bend[i] = par->bend[i];
+  }
+  double arc = 0.0;
+  o.rc = ent_propagate<EntAddBig>(c, &B, ent_big_add(P, k), cxo, cyo, end, index, arc, check_tether, cap_mult);
+  ent_big_close(P, k, B);
+  o.arc = arc; o.k = k; o.n_alpha = B.n_alpha; o.n_bend = B.n_bend; o.iz = ent_iz(&B);
+  return o;
 }
 
 }  // namespace nep

@@ -1692,6 +1692,7 @@ void launch_boxes(int n_scenes, const SceneParams& sp, const ProblemSet& ps, hip
 __global__ __launch_bounds__(256) void ent_pack_kernel(SceneParams sp, ProblemSet ps, FeEntArgs ea, int n_scenes) {
   const int N = sp.num_agents, D = sp.num_pol, ns = ea.ns;
   const long t = (long)blockIdx.x * 256 + threadIdx.x;
+  if (t == 0 && ea.big.count) { *ea.big.count = 0; if (ea.redo_count) *ea.redo_count = 0; }      // (the big-record pool and the list of searches that need it start empty: this kernel runs before the search — no memset node in a captured step)
   if (t >= (long)n_scenes * N * D) return;
   const int i = (int)(t % D); const long r = t / D;
   const int j = (int)(r % N), scene = (int)(r / N);
@@ -1709,12 +1710,22 @@ __global__ __launch_bounds__(256) void ent_pack_kernel(SceneParams sp, ProblemSe
 #ifndef NEP_FE_ENT_WGS
 #define NEP_FE_ENT_WGS 3      // (round 4: 3 = 168 registers, 48 spilled, 52 KB of LDS at config 5) // workgroups per CU of the entangle instantiation: 2 = working records in global memory, registers bounded to 256 (19.9 ms per 2 048 config-5 searches); 1 = working records in LDS, 139 KB (27.4 ms: the list surgery is latency-bound, a second workgroup hides more than LDS saves)
 #endif
-template <bool ENT, int WGS>
+// BIG (with ENT): the instantiation that re-runs, after the launch proper, the few searches in which a child's entangle state outgrew
+// the fixed record (ea.redo_list): such a child — pruned and listed by the plain instantiation — is carried in a big record here
+// (ent_device.h), bounded by the reference's own rule only.  A kernel of its own because the big-record pass compiled into the
+// search every slot runs costs that search 40 % (1.43 -> 1.98 ms per search at config 5: its 372 spilled registers and 1.8 KB of
+// scratch per lane weigh on the fixed record's path although a launch executes it for a dozen searches in 8 192).
+template <bool ENT, int WGS, bool BIG = false>
 __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, ProblemSet ps, nep_fe_cfg fc, const nep_fe_start* __restrict__ starts,
                                                        nep_guess* __restrict__ guess_out, nep_fe_result* __restrict__ res_out, FeEntArgs ea) {
   extern __shared__ __attribute__((aligned(16))) double fe_smem[];
   const int tid = threadIdx.x;
-  const int slot = blockIdx.x, scene = slot / sp.n_local, own = sp.first_local + (slot % sp.n_local);
+  // (launch order: longest expected search first — the previous search of the same slot is the predictor, as for the QP's
+  // workgroups, order_kernel; a search's time spreads 1 : 4 with the depth it ends at, and with the entangle check a search that
+  // carries its nodes in big records takes several times the others': started last it would set the kernel's end by itself)
+  const long long t_wg0 = (long long)wall_clock64();
+  if constexpr (BIG) { if ((int)blockIdx.x >= *ea.redo_count) return; }      // (the list holds at most gridDim.x = ea.redo_cap entries)
+  const int slot = BIG ? ea.redo_list[blockIdx.x] : (ps.fe_order ? ps.fe_order[blockIdx.x] : (int)blockIdx.x), scene = slot / sp.n_local, own = sp.first_local + (slot % sp.n_local);
   const int N = sp.num_agents, S = sp.n_static, W = fc.beam_width, ns = fc.num_samples, NC = ns * ns, D = sp.num_pol;
   const FeSizes fz = fe_sizes(W, ns, D);
   const int kFeCap = fz.cap, kFeDd = fz.dd, kFeVis = fz.vis, MB = fz.mb;
@@ -1785,7 +1796,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
     }
     if (tid < MB) b_valid[tid] = 1;
   }
-  int my_entangled = 0, my_overflow = 0;
+  int my_entangled = 0, my_overflow = 0, my_big = 0;
 #ifdef NEP_PROFILE_PHASES
   if (ps.dbg && tid < 32) ps.dbg[(long)slot * 32 + tid] = 0;
 #endif
@@ -2001,17 +2012,45 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
         const lds_bytes base = (lds_bytes)(unsigned)(size_t)(ent_lists + tid * kEntLdsBytes);      // (the low 32 bits of a generic LDS address are the LDS offset)
         L.id = (ent_lds_short)base; L.cs = (ent_lds_char)(base + 2 * NEP_FE_ENT_CAP); L.bend = (ent_lds_char)(base + 3 * NEP_FE_ENT_CAP); L.beta = my_work->beta;
+        L.cap = ea.fast_cap; L.bend_cap = ea.fast_bend;
       }
-      { FE_ENT_T0(); ent_lds_load(L, ent_node(depth - 1, depth == 1 ? 0 : pr_), N); FE_ENT_T(1); }
       double arc = 0.0;
-      int rc;
+      int rc = 2;
       ec.m_agent = m_ent + pr_ * MW; ec.m_static = m_stat + pr_ * SW;
-      { FE_ENT_T0(); rc = ent_propagate(ec, &L, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
-      if (rc) { my_entangled++; if (rc >= 2) my_overflow |= 1 << (rc - 2); s_state[id] = 0; return; }
+      // the fixed record's path — unless the parent is a big record already (n_alpha < 0, ent_device.h) or holds more than this
+      // handle's fast path takes
+      bool loaded;
+      { FE_ENT_T0(); loaded = ent_lds_load(L, ent_node(depth - 1, depth == 1 ? 0 : pr_), N); FE_ENT_T(1); }
+      if (loaded) {
+        unsigned add_tail[kEntAddCap - EntAdd::reg];
+        { FE_ENT_T0(); rc = ent_propagate<EntAdd>(ec, &L, EntAdd::Store{add_tail, ea.fast_add}, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
+      }
+      // a capacity of the fixed record (its list, a step's new crossings, the bend points) or a big parent: the child is left for the
+      // big-record pass below (rare: the flag keeps that pass out of every other depth's way)
+      if (__builtin_expect(rc >= 2, 0)) {
+        if constexpr (BIG) { s_state[id] = 5; s_i[11] = 1; }
+        else { my_entangled++; my_overflow |= 1 << (rc - 2); s_state[id] = 0; }      // (pruned for now: the search is listed for the big-record instantiation)
+        return;
+      }
+      if (rc) { my_entangled++; s_state[id] = 0; return; }
       ent_lds_store(ea.saved + ((long)slot * kFeCap + id), L, N); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
       ch.g = b_g[prv * MB + pr_] + arc;
       ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)L.n_alpha) + 1.0 * (double)L.n_bend);
       settle_voxel(id, ch, ent_iz(&L));
+    };
+    auto propagate_big = [&](int id) {      // ENT: the same child in a big record, which has the reference's own bound and no other (ent_device.h)
+      const int pr_ = id / NC, cc = id % NC;
+      FeChild ch;
+      fe_child_again<true>(sp, fc, lat, b_end + (prv * MB + pr_) * 6, b_g[prv * MB + pr_], cc / ns, cc % ns, gx, gy, ch);
+      ec.m_agent = m_ent + pr_ * MW; ec.m_static = m_stat + pr_ * SW;
+      const EntBigOut bo = ent_big_child(ec, ea.big, ent_node(depth - 1, depth == 1 ? 0 : pr_), ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, true, 1);
+      my_big++;
+      if (bo.rc) { my_entangled++; if (bo.rc >= 2) my_overflow |= 8; s_state[id] = 0; return; }
+      nep_fe_ent_state* sv = ea.saved + ((long)slot * kFeCap + id);
+      sv->n_alpha = -(bo.k + 1); sv->n_bend = 0; ea.saved_arc[(long)slot * kFeCap + id] = bo.arc;
+      ch.g = b_g[prv * MB + pr_] + bo.arc;
+      ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)bo.n_alpha) + 1.0 * (double)bo.n_bend);
+      settle_voxel(id, ch, bo.iz);
     };
     auto obstacle_V = [&](int o) -> const double* {
       if (o < kFeObsLds) return o_V + o * kHullV * 2;
@@ -2100,6 +2139,12 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         if (tid < n_merge && b0 + tid < n_prop) propagate(p_list[b0 + tid]);
         __syncthreads();
       }
+      if constexpr (BIG) {
+        if (s_i[11] != 0) {                                      // children the fixed record could not carry
+          for (int w = tid; w < n_prop; w += 256) { const int id = p_list[w]; if (s_state[id] == 5) propagate_big(id); }
+          __syncthreads();
+        }
+      }
       FE_TICK(1);
     }
     // ---- one node per voxel: the best (f, id) claims the voxel's slot; whoever is displaced or beaten is out ----
@@ -2142,11 +2187,16 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
           // the state and the arc length this child arrived with were kept by whoever examined it (a second propagation here, by
           // up to beam_width threads while the others wait, was a quarter of the search)
           const nep_fe_ent_state* nd = ea.saved + ((long)slot * kFeCap + i);
-          ent_copy(ent_node(depth, rank), nd);
           const double arc = ea.saved_arc[(long)slot * kFeCap + i];
           ch.g = pg + arc;
-          ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)nd->n_alpha) + 1.0 * (double)nd->n_bend);
-          b_valid[rank] = ent_valid_endpoint(nd, N) ? 1 : 0;
+          int nA = nd->n_alpha, nB = nd->n_bend; bool valid;
+          if (BIG && nA < 0) {      // a big record (ent_device.h): the node is its marker
+            nep_fe_ent_state* dn = ent_node(depth, rank); dn->n_alpha = nA; dn->n_bend = 0;
+            const EntBig B = ent_big_view(ea.big, -nA - 1);
+            nA = B.n_alpha; nB = B.n_bend; valid = ent_valid_endpoint(&B, N);
+          } else { ent_copy(ent_node(depth, rank), nd); valid = ent_valid_endpoint(nd, N); }
+          ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)nA) + 1.0 * (double)nB);
+          b_valid[rank] = valid ? 1 : 0;
         }
 #pragma unroll
         for (int q = 0; q < 6; q++) b_end[(cur * MB + rank) * 6 + q] = ch.e[q];
@@ -2159,7 +2209,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       }
     }
     // (the next depth's counters and voxel table: nobody reads them any more in this one)
-    if (tid == 0) { s_i[0] = 0; s_i[2] = 0; s_i[3] = 0; }
+    if (tid == 0) { s_i[0] = 0; s_i[2] = 0; s_i[3] = 0; s_i[11] = 0; }
     for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;
     __syncthreads();
     if constexpr (ENT) { for (int k = tid; k < MB * (2 * MW + SW); k += 256) m_ent[k] = 0u; __syncthreads(); }      // (read by the installs above, filled again by the next depth)
@@ -2178,12 +2228,20 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
     if (depth == D) { status = NEP_FE_DEPTH_REACHED; break; }
   }
   atomicAdd(&s_i[4], my_children); atomicAdd(&s_i[5], my_feasible); atomicAdd(&s_i[6], my_free);
-  if constexpr (ENT) { atomicAdd(&s_i[8], my_entangled); if (my_overflow) atomicOr(&s_i[9], my_overflow); }
+  if constexpr (ENT) { atomicAdd(&s_i[8], my_entangled); if (my_overflow) atomicOr(&s_i[9], my_overflow); if (my_big) atomicAdd(&s_i[10], my_big); }
   __syncthreads();
 #ifdef NEP_PROFILE_PHASES
   if (ps.dbg && tid == 0) { for (int k = 0; k < 8; k++) ps.dbg[(long)slot * 32 + k] = tph[k]; ps.dbg[(long)slot * 32 + 8] = depth; for (int k = 0; k < 4; k++) ps.dbg[(long)slot * 32 + 12 + k] = tent[k]; }
 #endif
   if (tid == 0) {
+    if constexpr (!BIG) {   // this search's device time: a statistic, and the next launch's ordering key
+      const double us_ = (double)((long long)wall_clock64() - t_wg0) * sp.us_per_tick;
+      if (ps.fe_us) ps.fe_us[slot] = (float)us_;
+      if (ps.fe_order_key) { const double k_ = us_ * (ENT ? 1.0 / 256.0 : 1.0 / 8.0); ps.fe_order_key[slot] = k_ > 63.0 ? 63 : (int)k_; }
+      if constexpr (ENT) {   // a child outgrew the fixed record: the search is run again by the big-record instantiation (launch_frontend)
+        if (s_i[9] != 0 && ea.redo_list) { const int k_ = atomicAdd(ea.redo_count, 1); if (k_ < ea.redo_cap) ea.redo_list[k_] = slot; }      // (beyond the list: the search stays flagged)
+      }
+    }
     nep_guess* g = guess_out + slot;
     for (int e = 0; e < 3 * NEP_MAX_POL * 4; e++) (&g->coeff[0][0][0])[e] = 0.0;
     g->t_start = st->t_start; g->K = best_rank >= 0 ? best_depth : 0; g->n_alpha = 0;
@@ -2212,7 +2270,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       o->status = status; o->K = best_rank >= 0 ? best_depth : 0; o->depth = depth > D ? D : depth;
       o->n_children = s_i[4]; o->n_feasible = s_i[5]; o->n_collision_free = s_i[6]; o->goal_occupied = s_i[7]; o->_pad = 0;
       o->cost = best_rank >= 0 ? b_f[best_rank] : 0.0; o->dist_to_goal = best_rank >= 0 ? b_dist[best_rank] : 0.0;
-      o->n_entangled = ENT ? s_i[8] : 0; o->ent_overflow = ENT ? (s_i[9] != 0 ? 1 : 0) : 0; o->_pad = ENT ? s_i[9] : 0;      // (_pad: which capacity, bit 0 the list's, 1 a step's new crossings, 2 the bend points)
+      o->n_entangled = ENT ? s_i[8] : 0; o->ent_overflow = ENT ? (s_i[9] != 0 ? 1 : 0) : 0; o->_pad = ENT ? (s_i[9] | (s_i[10] << 8)) : 0;      // (_pad: bit 3 = the big-record pool ran out; from bit 8 up: children carried in big records)
     }
     if constexpr (ENT) {   // ranks of the path's nodes, for the case rows below
       int r = best_rank;
@@ -2231,7 +2289,8 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         if (bd >= 0 && i < Kg) {
           const int dd = i < bd ? i : bd;
           const nep_fe_ent_state* sn = ent_node(dd, dd == 0 ? 0 : s_i[16 + dd]);
-          if (ent_count(sn->id, sn->n_alpha, j + 1) == 1) for (int a = 0; a < sn->n_alpha; a++) if (sn->id[a] == j + 1) cid = sn->cs[a];
+          if (BIG && sn->n_alpha < 0) { const EntBig B = ent_big_view(ea.big, -sn->n_alpha - 1); if (ent_count(B.id, B.n_alpha, j + 1) == 1) for (int a = 0; a < B.n_alpha; a++) if (B.id[a] == j + 1) cid = B.cs[a]; }
+          else if (ent_count(sn->id, sn->n_alpha, j + 1) == 1) for (int a = 0; a < sn->n_alpha; a++) if (sn->id[a] == j + 1) cid = sn->cs[a];
         }
         ea.case_out[((long)slot * NEP_MAX_POL + i) * N + j] = cid;
       }
@@ -2306,9 +2365,15 @@ size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc, bool ent)
   return (b + 15) & ~(size_t)15;
 }
 
-void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
-                     nep_guess* guess_out, nep_fe_result* res_out, const FeEntArgs* ea, hipStream_t st) {
+void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps_in, const nep_fe_cfg& fc, const nep_fe_start* starts,
+                     nep_guess* guess_out, nep_fe_result* res_out, const FeEntArgs* ea, hipStream_t st, int* order_buf, bool have_history) {
   if (n_slots <= 0) return;
+  ProblemSet ps = ps_in;
+  ps.fe_order = nullptr;
+  if (ps.fe_order_key && order_buf && have_history && n_slots > 1024) {      // (more than one wave of workgroups)
+    launch_qp_order(n_slots, ps.fe_order_key, order_buf, st);
+    ps.fe_order = order_buf;
+  }
   const bool ent = ea != nullptr;
   const size_t lds = frontend_lds_bytes(sp, fc, ent);
   // a search whose LDS leaves room for four workgroups on a CU (160 KB / 4) runs the instantiation bounded to 128 registers
@@ -2324,7 +2389,14 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
     const long np_ = (long)n_scenes * sp.num_agents * sp.num_pol;
     hipLaunchKernelGGL(ent_pack_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, st, sp, ps, *ea, n_scenes);
   }
-  if (ent) hipLaunchKernelGGL((frontend_kernel<true, NEP_FE_ENT_WGS>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
+  if (ent) {
+    hipLaunchKernelGGL((frontend_kernel<true, NEP_FE_ENT_WGS>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
+    if (ea->redo_list && ea->big.base && ea->redo_cap > 0) {      // the searches listed by that launch, again, with big records (nearly always none: the workgroups return at once)
+      static DynLdsAttr attr_big;
+      (void)attr_big.ensure((const void*)frontend_kernel<true, 1, true>, lds);
+      hipLaunchKernelGGL((frontend_kernel<true, 1, true>), dim3(ea->redo_cap < n_slots ? ea->redo_cap : n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
+    }
+  }
   else if (four) hipLaunchKernelGGL((frontend_kernel<false, 4>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
   else hipLaunchKernelGGL((frontend_kernel<false, NEP_FE_WAVES>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);
 }
@@ -2332,7 +2404,8 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, c
 // Neptune::SamplePointsOfIntervals (neptune.cpp:500-565) for every committed trajectory of every scene:
 // sampled[scene][j][interval][0..ns][2] on the round's grid, present[scene][j] = the trajectory exists (trajs_ holds it)
 __global__ void ent_sample_kernel(const nep_traj_rec* __restrict__ recs, int n_scenes, int N, const double* __restrict__ ts0, long ts_scene_stride,
-                                  int num_pol, int ns, double T_span, double* __restrict__ sampled, int* __restrict__ present) {
+                                  int num_pol, int ns, double T_span, double* __restrict__ sampled, int* __restrict__ present, int* __restrict__ zero_this) {
+  if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0;      // (the re-check's pool of big records starts empty)
   const long per = (long)num_pol * (ns + 1);
   const long total = (long)n_scenes * N * per;
   for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
@@ -2365,11 +2438,11 @@ __global__ void ent_sample_kernel(const nep_traj_rec* __restrict__ recs, int n_s
   }
 }
 void launch_ent_sample(const nep_traj_rec* recs, int n_scenes, int N, const double* ts0, long ts_scene_stride, int num_pol, int ns, double T_span,
-                       double* sampled, int* present, hipStream_t st) {
+                       double* sampled, int* present, hipStream_t st, int* zero_this) {
   const long total = (long)n_scenes * N * num_pol * (ns + 1);
   if (total <= 0) return;
   int blocks = (int)((total + 255) / 256); if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(ent_sample_kernel, dim3(blocks), dim3(256), 0, st, recs, n_scenes, N, ts0, ts_scene_stride, num_pol, ns, T_span, sampled, present);
+  hipLaunchKernelGGL(ent_sample_kernel, dim3(blocks), dim3(256), 0, st, recs, n_scenes, N, ts0, ts_scene_stride, num_pol, ns, T_span, sampled, present, zero_this);
 }
 
 // KinodynamicSearch::entangleCheckGivenPwp for the first interval of every new trajectory (neptune.cpp:746-754): one thread
@@ -2417,7 +2490,17 @@ __global__ __launch_bounds__(64) void ent_check_kernel(SceneParams sp, ProblemSe
     nep_fe_ent_state* wk = ea.work + idx;
     if (ea.init) ent_copy(wk, ea.init + idx); else { long* z = (long*)wk; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
     double arc = 0.0;
-    entangles[idx] = ent_propagate(ec, wk, cx0, cy0, end, 1, arc, false, 3) != 0 ? 1 : 0;
+    unsigned add_tail[kEntAddCap - EntAdd::reg];
+    int rc = ent_propagate<EntAdd>(ec, wk, EntAdd::Store{add_tail, ea.fast_add}, cx0, cy0, end, 1, arc, false, 3);      // (fast_add: 32 unless a test shrinks it)
+    if (__builtin_expect(rc >= 2, 0)) {
+      // a capacity of the fixed record, not the reference's verdict: the same interval in a big record, bounded by the reference's
+      // rule only (three times the search's bound here).  An exhausted pool turns the trajectory down and raises NEP_FLAG_ENT_POOL.
+      if (ea.init) ent_copy(wk, ea.init + idx); else { long* z = (long*)wk; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
+      const EntBigOut bo = ent_big_child(ec, ea.big_check, wk, cx0, cy0, end, 1, false, 3);
+      rc = bo.rc;
+      if (rc >= 2 && ps.flags) atomicOr(ps.flags, NEP_FLAG_ENT_POOL);
+    }
+    entangles[idx] = rc != 0 ? 1 : 0;
   }
 }
 void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntArgs& ea, const nep_traj_rec* fresh, int n_scenes, double cable, int* entangles, hipStream_t st) {

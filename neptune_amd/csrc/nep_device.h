@@ -75,6 +75,10 @@ struct ProblemSet {
   int sep_pack;                  // host only: segments per wave of the presolve's separator — 0 picked by launch size, -1 the unpacked kernel, 1..NEP_MAX_POL forced (nep_batch_debug_set_separator_pack; NEP_SEP_PACK / NEP_SEP_UNPACKED at create)
   const int* order;              // [slots] workgroup -> slot (longest expected solve first, see order_kernel) or null: identity
   int* order_key;                // [slots] this launch's measured device time in 8 us bins (the next launch's ordering key) or null
+  // front end: the same for the searches (frontend_kernel: longest expected search first; key bins of 8 us, 256 us with the entangle check)
+  const int* fe_order;           // [slots] workgroup -> slot or null: identity
+  int* fe_order_key;             // [slots] or null
+  float* fe_us;                  // [slots] device time of the last search of every slot, microseconds, or null
   // QP scratch when the row state does not fit LDS
   double* row_scratch;           // [slots or scratch_chunks][11][rows_cap / 4 + 2]
   int scratch_chunks;            // 0: one scratch area per slot.  > 0 (presolve with the redo pass): that many areas, used by the redo pass only, by launch index
@@ -91,6 +95,7 @@ struct ProblemSet {
   int* flags;                    // [1] sticky NEP_FLAG_* bits raised by the kernels (capacity overflows), or null
   double* fe_box;                // [scenes][num_agents + n_static][num_pol][4] (x0, x1, y0, y1) of the front end's obstacles (fe_box_kernel)
 };
+constexpr int NEP_FLAG_ENT_POOL = 16;       // the safety pass's entangle re-check needed a big record and the pool had none left (nep_batch_set_fe_ent_big_records): the trajectory was turned down
 constexpr int NEP_FLAG_LINES = 8;           // a segment got more separating lines than its bucket holds (nep_batch_set_line_capacity)
 constexpr int NEP_FLAG_SCRATCH = 4;         // more replans went through the presolve's redo pass with rows beyond the register slots than the handle has scratch areas for (nep_batch_reserve_row_scratch)
 constexpr int NEP_FLAG_ENT_BETA = 2;        // an entangle state handed to the front end carries a non-zero beta for an agent crossing (the reference's rule makes it 0.0)
@@ -151,6 +156,13 @@ void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, con
                    const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 int qp_reg_slots();
 size_t qp_reg_lds_bytes();
+// pool of big records (ent_device.h: a search node's entangle state beyond the fixed record's capacities), claimed by atomic
+// increments of *count during a launch; the launch's first kernel zeroes the counter
+struct EntBigPool { unsigned char* base; int* count; int n_rec; int rec_bytes; int cap; int add_lim; };
+// (mult: 1 for the search, 3 for the safety pass's re-check — entangleCheckGivenPwp prunes at three times the search's bound, kinodynamic_search.cpp:944-948)
+__host__ __device__ inline int ent_big_cap(int N, int S, int mult = 1) { int c = (N + S) * mult; if (c < NEP_FE_ENT_CAP) c = NEP_FE_ENT_CAP; return (c + 3) & ~3; }      // (any fixed record can be copied into one)
+__host__ __device__ inline int ent_big_add_lim(int N, int S, int mult = 1) { return ((N + S) * mult + 2 + 31) & ~31; }
+__host__ __device__ inline int ent_big_rec_bytes(int N, int S, int mult = 1) { const int c = ent_big_cap(N, S, mult), a = ent_big_add_lim(N, S, mult); return (((8 + 13 * c + 3) & ~3) + 4 * a + a / 8 + 7) & ~7; }
 // entangle inputs / scratch of the front end and of the safety pass's entangle re-check (device pointers)
 struct FeEntArgs {
   const double* sampled;         // [scenes][N][num_pol][ns+1][2]   SampledPtsForAll_ (ent_sample_kernel); with sharded hulls: block 0's
@@ -166,12 +178,18 @@ struct FeEntArgs {
   int ns;                        // num_sample_per_interval
   double* packed;                // [scenes][N][num_pol][pk_stride] one record per (agent, interval) of what the check reads (ent_pack_kernel), or null
   int pk_stride;
+  EntBigPool big;                // front end: where states beyond the fixed record go (base == null: such children are pruned and flagged)
+  EntBigPool big_check;          // the same for the safety pass's re-check (records of three times the bound; its counter is zeroed by ent_sample_kernel)
+  int* redo_list; int* redo_count; int redo_cap;      // front end: searches in which a child outgrew the fixed record, listed by frontend_kernel<true, W> for frontend_kernel<true, 2, true> (beyond redo_cap: they stay flagged)
+  int fast_cap, fast_add, fast_bend;      // front end: what the fixed record's path accepts (<= NEP_FE_ENT_CAP, 32, NEP_MAX_BEND; nep_batch_set_fe_ent_fast_caps — the tests shrink them to drive ordinary scenes through the big records)
 };
 size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol);      // children per depth of one search (beam_width x lattice)
+// (order_buf: [slots] scratch for the launch order, used when the previous launch left its keys — have_history — and the launch is
+// more than one wave of workgroups; null: slot order)
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
-                     nep_guess* guess_out, nep_fe_result* res_out, const FeEntArgs* ea, hipStream_t st);
+                     nep_guess* guess_out, nep_fe_result* res_out, const FeEntArgs* ea, hipStream_t st, int* order_buf = nullptr, bool have_history = false);
 void launch_ent_sample(const nep_traj_rec* recs, int n_scenes, int N, const double* ts0, long ts_scene_stride, int num_pol, int ns, double T_span,
-                       double* sampled, int* present, hipStream_t st);
+                       double* sampled, int* present, hipStream_t st, int* zero_this = nullptr);
 void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntArgs& ea, const nep_traj_rec* fresh, int n_scenes, double cable, int* entangles, hipStream_t st);
 void launch_next_starts(const nep_traj_rec* recs, int n_scenes, int N, int first_local, int n_local, double dt, nep_fe_start* starts,
                         double* alt, double r_switch, hipStream_t st);

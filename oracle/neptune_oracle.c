@@ -1243,18 +1243,45 @@ static int fe_child(const orc_fe_cfg* c, const double init_end[6], double par_g,
 /* (kinodynamic_search.cpp:707-895) with eu::entangleHSigToAddAgentInd (entangle_utils.cpp:1129-1228),        */
 /* entangleHSigToAddStatic (:1231-1277), addAlphaBetaToList + breakcondition (:1402-1534, :1608-1647),        */
 /* updateBendPts (:1536-1604), getBendPt2d / calculateBetaForCase / getTetherLength (:1649-1743).             */
-/* Fixed capacity: NEP_FE_ENT_CAP crossings per node (the reference prunes at num_agents + statics); a node    */
-/* that would exceed it is pruned and counted in nep_fe_result.ent_overflow.  active_cases[i] is the number of */
-/* list entries of agent i (every append adds one, every cancellation removes one): it is derived, not stored. */
+/* No capacity of its own: like the reference's vectors, a node's list is bounded by the reference's rule only   */
+/* (a child is pruned when its list plus the new crossings of a step exceed cap_mult * (num_agents + statics),  */
+/* kinodynamic_search.cpp:850-854, :944-948), its bend points by its list, a step's new crossings by what the   */
+/* agents' tethers can give.  nep_fe_result.ent_overflow stays 0.  active_cases[i] is the number of list entries */
+/* of agent i (every append adds one, every cancellation removes one): it is derived, not stored.               */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct orc_ent_node { int n_alpha, n_bend; short id[NEP_FE_ENT_CAP]; signed char cs[NEP_FE_ENT_CAP]; double beta[NEP_FE_ENT_CAP]; signed char bend[NEP_MAX_BEND]; } orc_ent_node;
+typedef struct orc_ent_node { int n_alpha, n_bend; short* id; signed char* cs; double* beta; short* bend; } orc_ent_node;
+/* `count` nodes of `cap` entries each in one allocation (free(nodes) releases everything) */
+static orc_ent_node* ent_nodes_alloc(size_t count, int cap) {
+  const size_t per = ((size_t)cap * (sizeof(double) + 2 * sizeof(short) + 1) + 7) & ~(size_t)7;
+  char* m = (char*)calloc(1, count * (sizeof(orc_ent_node) + per) + 16);
+  orc_ent_node* nd = (orc_ent_node*)m;
+  char* slab = m + ((count * sizeof(orc_ent_node) + 7) & ~(size_t)7);
+  for (size_t i = 0; i < count; i++) {
+    char* q = slab + i * per;
+    nd[i].beta = (double*)q; nd[i].id = (short*)(q + (size_t)cap * 8); nd[i].bend = (short*)(q + (size_t)cap * 10); nd[i].cs = (signed char*)(q + (size_t)cap * 12);
+  }
+  return nd;
+}
+static void ent_node_copy(orc_ent_node* d, const orc_ent_node* s) {
+  d->n_alpha = s->n_alpha; d->n_bend = s->n_bend;
+  for (int i = 0; i < s->n_alpha; i++) { d->id[i] = s->id[i]; d->cs[i] = s->cs[i]; d->beta[i] = s->beta[i]; }
+  for (int i = 0; i < s->n_bend; i++) d->bend[i] = s->bend[i];
+}
+static void ent_node_from_fixed(orc_ent_node* d, const nep_fe_ent_state* s) {      /* the state at point A, as the C ABI carries it */
+  d->n_alpha = s->n_alpha; d->n_bend = s->n_bend;
+  for (int i = 0; i < s->n_alpha && i < NEP_FE_ENT_CAP; i++) { d->id[i] = s->id[i]; d->cs[i] = s->cs[i]; d->beta[i] = s->beta[i]; }
+  for (int i = 0; i < s->n_bend && i < NEP_MAX_BEND; i++) d->bend[i] = s->bend[i];
+}
+
 typedef struct ent_ctx {
   int N, S, own, num_pol, ns; double T_span, cable;
   const double* pb; const double* srep; const double* slong; const double* sampled; const int* present; const int* bend_n; const double* bend_xy;
 } ent_ctx;
 typedef struct { double x, y; } ev2;
-#define ENT_ADD_CAP 32
-typedef struct { short id[ENT_ADD_CAP]; signed char cs[ENT_ADD_CAP]; int n, overflow; } ent_add;
+typedef struct { short* id; signed char* cs; int n, cap, overflow; } ent_add;      /* (overflow: cannot happen, ent_add_cap) */
+/* entries a node of this problem can ever hold (cap_mult = 3 for entangleCheckGivenPwp), and new crossings one step can add */
+static int ent_node_cap(const ent_ctx* c, int cap_mult) { int k = (c->N + c->S) * cap_mult; if (k < NEP_FE_ENT_CAP) k = NEP_FE_ENT_CAP; return k + 4; }
+static int ent_add_cap(const ent_ctx* c) { return c->N * (2 * NEP_MAX_BEND + 2) + c->S + 4; }      /* every tether segment of every agent twice (crossing + base sweep), every static once */
 
 static ev2 ent_pb(const ent_ctx* c, int j) { ev2 r = {c->pb[2 * j], c->pb[2 * j + 1]}; return r; }
 static ev2 ent_srep(const ent_ctx* c, int s, int col) { ev2 r = {c->srep[(s * 2 + col) * 2], c->srep[(s * 2 + col) * 2 + 1]}; return r; }
@@ -1266,7 +1293,7 @@ static double ent_wedge(ev2 a, ev2 b, ev2 cc) { return (b.x - a.x) * (cc.y - a.y
 static double ent_wedge2(ev2 a, ev2 b, ev2 cc, ev2* ab, ev2* ac) { ab->x = b.x - a.x; ab->y = b.y - a.y; ac->x = cc.x - a.x; ac->y = cc.y - a.y; return ab->x * ac->y - ac->x * ab->y; }
 static double ent_ratio(ev2 u, ev2 v) { return fabs(u.y * v.y) > fabs(u.x * v.x) ? u.y / v.y : u.x / v.x; }
 static double ent_dist(ev2 a, ev2 b) { return sqrt((a.x - b.x) * (a.x - b.x) + (a.y - b.y) * (a.y - b.y)); }
-static void ent_push(ent_add* a, int id, int cs) { if (a->n < ENT_ADD_CAP) { a->id[a->n] = (short)id; a->cs[a->n] = (signed char)cs; a->n++; } else a->overflow = 1; }
+static void ent_push(ent_add* a, int id, int cs) { if (a->n < a->cap) { a->id[a->n] = (short)id; a->cs[a->n] = (signed char)cs; a->n++; } else a->overflow = 1; }
 
 static void ent_cross_agent(ent_add* add, ev2 pk, ev2 pk1, ev2 pik, ev2 pik1, ev2 pb_self, const ent_ctx* c, int i, int agent_id) {
   const int nb = c->bend_n[i];
@@ -1329,7 +1356,6 @@ static void ent_erase(orc_ent_node* st, int j) {
   for (int k = j; k + 1 < st->n_alpha; k++) { st->id[k] = st->id[k + 1]; st->cs[k] = st->cs[k + 1]; st->beta[k] = st->beta[k + 1]; }
   st->n_alpha--;
 }
-/* returns 1 when the list would exceed its capacity */
 static int ent_merge(ent_add* add, orc_ent_node* st, ev2 pk, ev2 pb_self, const ent_ctx* c) {
   int again = 1;
   while (again) {
@@ -1352,7 +1378,7 @@ static int ent_merge(ent_add* add, orc_ent_node* st, ev2 pk, ev2 pb_self, const 
             const ev2 bp = ent_cur_bend(st, pb_self, c);
             for (int k = j; k < st->n_alpha; k++) st->beta[k] = ent_beta(st->id[k], st->cs[k], pk, bp, c);
           } else if (j < b) {
-            st->bend[st->n_bend - 1] = (signed char)(b - 1);
+            st->bend[st->n_bend - 1] = (short)(b - 1);
             for (int k = st->n_bend - 2; k >= 0; k--) { if (st->bend[k] > j) st->bend[k] -= 1; else break; }
           }
           again = 1;
@@ -1363,7 +1389,6 @@ static int ent_merge(ent_add* add, orc_ent_node* st, ev2 pk, ev2 pb_self, const 
     }
   }
   if (add->n == 0) return 0;
-  if (st->n_alpha + add->n > NEP_FE_ENT_CAP) return 1;
   const ev2 bp = ent_cur_bend(st, pb_self, c);
   for (int i = 0; i < add->n; i++) {
     st->id[st->n_alpha] = add->id[i]; st->cs[st->n_alpha] = add->cs[i];
@@ -1378,8 +1403,7 @@ static int ent_update_bends(orc_ent_node* st, ev2 pk1, ev2 pb_self, const ent_ct
   const int start = st->n_bend ? st->bend[st->n_bend - 1] : -1;
   for (int i = start + 1; i < st->n_alpha; i++) { const double beta = ent_beta(st->id[i], st->cs[i], pk1, bp, c); if (beta * st->beta[i] < -1e-7) idx_new = i; }
   if (idx_new > -1) {
-    if (st->n_bend >= NEP_MAX_BEND) return 1;
-    st->bend[st->n_bend++] = (signed char)idx_new;
+    st->bend[st->n_bend++] = (short)idx_new;
     const ev2 nb = ent_anchor(st->id[idx_new], st->cs[idx_new], c);
     for (int i = idx_new + 1; i < st->n_alpha; i++) st->beta[i] = ent_beta(st->id[i], st->cs[i], pk1, nb, c);
     return 0;
@@ -1413,8 +1437,12 @@ static int ent_propagate(const ent_ctx* c, orc_ent_node* st, const double cxo[4]
   const int ns = c->ns;
   const ev2 pb_self = ent_pb(c, c->own);
   ev2 pk = {cxo[3], cyo[3]}, pk1 = pk;
-  for (int j = 1; j <= ns; j++) {
-    ent_add add; add.n = 0; add.overflow = 0;
+  const int acap = ent_add_cap(c), ncap = ent_node_cap(c, cap_mult);
+  short* abuf = (short*)malloc((size_t)acap * 3 + (size_t)ncap * 2 + 16);
+  short* old_id = abuf + acap + ((acap + 1) >> 1) + 2;
+  int verdict = 0;
+  for (int j = 1; j <= ns && !verdict; j++) {
+    ent_add add; add.id = abuf; add.cs = (signed char*)(abuf + acap); add.cap = acap; add.n = 0; add.overflow = 0;
     if (j < ns) {
       const double t = c->T_span * j / ns;
       const double t3 = t * t * t, t2 = t * t;
@@ -1429,21 +1457,24 @@ static int ent_propagate(const ent_ctx* c, orc_ent_node* st, const double cxo[4]
       ent_cross_agent(&add, pk, pk1, pik, pik1, pb_self, c, i, i + 1);
     }
     ent_cross_static(&add, pk, pk1, c);
-    if (add.overflow) return 2;
-    if (st->n_alpha + add.n > (c->N + c->S) * cap_mult) return 1;
-    short old_id[NEP_FE_ENT_CAP]; const int old_n = st->n_alpha;
+    if (add.overflow) { verdict = 2; break; }      /* (not reachable: ent_add_cap) */
+    if (st->n_alpha + add.n > (c->N + c->S) * cap_mult) { verdict = 1; break; }
+    const int old_n = st->n_alpha;
     for (int i = 0; i < old_n; i++) old_id[i] = st->id[i];
-    if (ent_merge(&add, st, pk, pb_self, c)) return 2;
-    for (int i = 0; i < st->n_alpha; i++) {
+    ent_merge(&add, st, pk, pb_self, c);
+    for (int i = 0; i < st->n_alpha && !verdict; i++) {
       const int id = st->id[i];
       if (id > c->N) continue;
       const int nw = ent_count(st->id, st->n_alpha, id), od = ent_count(old_id, old_n, id);
-      if (od < 2 && nw >= 2) return 1;
-      if (od >= 2 && nw > od) return 1;
+      if (od < 2 && nw >= 2) verdict = 1;
+      if (od >= 2 && nw > od) verdict = 1;
     }
-    if (ent_update_bends(st, pk1, pb_self, c)) return 2;
+    if (verdict) break;
+    ent_update_bends(st, pk1, pb_self, c);
     pk = pk1;
   }
+  free(abuf);
+  if (verdict) return verdict;
   if (check_tether && ent_tether(st, pb_self, pk1, c) > c->cable) return 1;
   return 0;
 }
@@ -1568,16 +1599,18 @@ int orc_frontend_beam_ent(const orc_fe_cfg* c, const nep_fe_start* st, const dou
   if (W < 1 || W > NEP_FE_MAX_BEAM || ns < 2 || ns > NEP_FE_MAX_SAMPLES || D < 1 || D > NEP_MAX_POL) return -1;
   static const int CAP = NEP_FE_MAX_BEAM * NEP_FE_MAX_SAMPLES * NEP_FE_MAX_SAMPLES;
   ent_ctx ec; memset(&ec, 0, sizeof(ec));
-  orc_ent_node ent_root; memset(&ent_root, 0, sizeof(ent_root));
+  orc_ent_node* ent_root_p = 0;
   orc_ent_node* cand_ent = 0; orc_ent_node (*beam_ent)[NEP_FE_MAX_BEAM] = 0; unsigned* cand_iz = 0; unsigned (*beam_iz)[NEP_FE_MAX_BEAM] = 0;
   unsigned* vis_iz = 0;
   if (E) {
     if (E->num_samples < 1 || E->num_samples > 8) return -1;
     ec.N = c->num_agents; ec.S = E->n_static; ec.own = c->id - 1; ec.num_pol = c->num_pol; ec.ns = E->num_samples; ec.T_span = c->T_span; ec.cable = c->cable_length;
     ec.pb = c->pb; ec.srep = E->static_rep; ec.slong = E->static_longest; ec.sampled = E->sampled; ec.present = E->present; ec.bend_n = E->bend_n; ec.bend_xy = E->bend_xy;
-    if (E->init) memcpy(&ent_root, E->init, sizeof(ent_root));
-    cand_ent = (orc_ent_node*)malloc(sizeof(orc_ent_node) * CAP);
-    beam_ent = (orc_ent_node(*)[NEP_FE_MAX_BEAM])malloc(sizeof(orc_ent_node) * NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1));
+    const int ncap = ent_node_cap(&ec, 1);
+    ent_root_p = ent_nodes_alloc(1, ncap);
+    if (E->init) ent_node_from_fixed(ent_root_p, E->init);
+    cand_ent = ent_nodes_alloc((size_t)W * NC, ncap);
+    beam_ent = (orc_ent_node(*)[NEP_FE_MAX_BEAM])ent_nodes_alloc((size_t)NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1), ncap);
     cand_iz = (unsigned*)calloc(CAP, sizeof(unsigned));
     beam_iz = (unsigned(*)[NEP_FE_MAX_BEAM])calloc((size_t)NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1), sizeof(unsigned));
     vis_iz = (unsigned*)calloc((size_t)NEP_FE_MAX_BEAM * (NEP_MAX_POL + 1), sizeof(unsigned));
@@ -1633,7 +1666,7 @@ int orc_frontend_beam_ent(const orc_fe_cfg* c, const nep_fe_start* st, const dou
         if (E && fe_collides_bases(c, nd)) continue;
         res->n_collision_free++;
         if (E) {
-          cand_ent[id] = depth == 1 ? ent_root : beam_ent[depth - 1][pr];
+          ent_node_copy(&cand_ent[id], depth == 1 ? ent_root_p : &beam_ent[depth - 1][pr]);
           double arc = 0.0;
           const ev2 end = {nd->end[0], nd->end[1]};
           const int rc = ent_propagate(&ec, &cand_ent[id], nd->cx, nd->cy, end, depth, &arc, 1, 1);
@@ -1662,7 +1695,7 @@ int orc_frontend_beam_ent(const orc_fe_cfg* c, const nep_fe_start* st, const dou
       int bi = -1;
       for (int i = 0; i < n_c; i++) if (keep[i] == 1 && (bi < 0 || fe_before(&cand[i], i, &cand[bi], bi))) bi = i;
       if (bi < 0 || nb == W) break;
-      if (E) { beam_ent[depth][nb] = cand_ent[bi]; beam_iz[depth][nb] = cand_iz[bi]; }
+      if (E) { ent_node_copy(&beam_ent[depth][nb], &cand_ent[bi]); beam_iz[depth][nb] = cand_iz[bi]; }
       beam[depth][nb++] = cand[bi];
       keep[bi] = 3;
     }
@@ -1710,14 +1743,14 @@ int orc_frontend_beam_ent(const orc_fe_cfg* c, const nep_fe_start* st, const dou
       for (int d = best_depth; d >= 1; d--) { path[d] = rr; rr = beam[d][rr].parent; }
       for (int i = 0; i < NEP_MAX_POL; i++) {
         const int dd = i < best_depth ? i : best_depth;      /* held segments keep the last node's state */
-        const orc_ent_node* sn = dd == 0 ? &ent_root : &beam_ent[dd][path[dd]];
+        const orc_ent_node* sn = dd == 0 ? ent_root_p : &beam_ent[dd][path[dd]];
         if (i < guess->K) ent_case_row(sn, c->num_agents, case_out + (size_t)i * c->num_agents);
         else for (int j = 0; j < c->num_agents; j++) case_out[(size_t)i * c->num_agents + j] = 0;
       }
     }
   } else if (E && case_out) memset(case_out, 0, sizeof(int) * NEP_MAX_POL * (size_t)c->num_agents);
   free(cand); free(keep); free(beam); free(visited);
-  if (E) { free(cand_ent); free(beam_ent); free(cand_iz); free(beam_iz); free(vis_iz); }
+  if (E) { free(cand_ent); free(beam_ent); free(ent_root_p); free(cand_iz); free(beam_iz); free(vis_iz); }
   return 0;
 }
 
@@ -1728,23 +1761,26 @@ int orc_ent_propagate_guess(const orc_fe_cfg* c, const orc_fe_ent* E, const nep_
   ent_ctx ec; memset(&ec, 0, sizeof(ec));
   ec.N = c->num_agents; ec.S = E->n_static; ec.own = c->id - 1; ec.num_pol = c->num_pol; ec.ns = E->num_samples; ec.T_span = c->T_span; ec.cable = c->cable_length;
   ec.pb = c->pb; ec.srep = E->static_rep; ec.slong = E->static_longest; ec.sampled = E->sampled; ec.present = E->present; ec.bend_n = E->bend_n; ec.bend_xy = E->bend_xy;
-  orc_ent_node stt; memset(&stt, 0, sizeof(stt));
-  if (E->init) memcpy(&stt, E->init, sizeof(stt));
+  orc_ent_node* two = ent_nodes_alloc(2, ent_node_cap(&ec, 1));
+  orc_ent_node* stt = &two[0]; orc_ent_node* nx = &two[1];
+  if (E->init) ent_node_from_fixed(stt, E->init);
   const double T = c->T_span;
   const int K = g->K;
   *hit_at = 0;
   for (int s = 1; s <= K; s++) {
-    ent_case_row(&stt, c->num_agents, case_out + (size_t)(s - 1) * c->num_agents);
+    ent_case_row(stt, c->num_agents, case_out + (size_t)(s - 1) * c->num_agents);
     if (*hit_at) continue;
     const double* cxo = g->coeff[0][s - 1]; const double* cyo = g->coeff[1][s - 1];
     ev2 end;
     if (s < K) { end.x = g->coeff[0][s][3]; end.y = g->coeff[1][s][3]; }
     else { end.x = ((cxo[0] * (T * T * T) + cxo[1] * (T * T)) + cxo[2] * T) + cxo[3]; end.y = ((cyo[0] * (T * T * T) + cyo[1] * (T * T)) + cyo[2] * T) + cyo[3]; }
-    orc_ent_node nx = stt; double arc = 0.0;
-    if (ent_propagate(&ec, &nx, cxo, cyo, end, s, &arc, 1, 1)) *hit_at = s; else stt = nx;
+    double arc = 0.0;
+    ent_node_copy(nx, stt);
+    if (ent_propagate(&ec, nx, cxo, cyo, end, s, &arc, 1, 1)) *hit_at = s; else ent_node_copy(stt, nx);
   }
   for (int s = K; s < NEP_MAX_POL; s++) for (int j = 0; j < c->num_agents; j++) case_out[(size_t)s * c->num_agents + j] = 0;
-  if (n_alpha_final) *n_alpha_final = stt.n_alpha;
+  if (n_alpha_final) *n_alpha_final = stt->n_alpha;
+  free(two);
   return 0;
 }
 
@@ -1756,13 +1792,15 @@ int orc_entangle_check_pwp(const orc_fe_cfg* c, const orc_fe_ent* E, const doubl
   ent_ctx ec; memset(&ec, 0, sizeof(ec));
   ec.N = c->num_agents; ec.S = E->n_static; ec.own = c->id - 1; ec.num_pol = c->num_pol; ec.ns = E->num_samples; ec.T_span = c->T_span; ec.cable = c->cable_length;
   ec.pb = c->pb; ec.srep = E->static_rep; ec.slong = E->static_longest; ec.sampled = E->sampled; ec.present = E->present; ec.bend_n = E->bend_n; ec.bend_xy = E->bend_xy;
-  orc_ent_node stt; memset(&stt, 0, sizeof(stt));
-  if (E->init) memcpy(&stt, E->init, sizeof(stt));
+  orc_ent_node* stt = ent_nodes_alloc(1, ent_node_cap(&ec, 3));
+  if (E->init) ent_node_from_fixed(stt, E->init);
   const double T = c->T_span;
   /* pkplus1 = P * sampled_time_vector_[j] for every j, including the last (:914): the polynomial at T */
   const ev2 end = {((cx0[0] * (T * T * T) + cx0[1] * (T * T)) + cx0[2] * T) + cx0[3] * 1.0, ((cy0[0] * (T * T * T) + cy0[1] * (T * T)) + cy0[2] * T) + cy0[3] * 1.0};
   double arc = 0.0;
-  return ent_propagate(&ec, &stt, cx0, cy0, end, 1, &arc, 0, 3) != 0;
+  const int rc = ent_propagate(&ec, stt, cx0, cy0, end, 1, &arc, 0, 3) != 0;
+  free(stt);
+  return rc;
 }
 
 /* ------------------------------------------------------------------------------------------ */

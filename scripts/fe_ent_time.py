@@ -31,6 +31,9 @@ def main():
         print("round %d: frontend_ent of %d searches %.2f ms; entangled %d overflow %d; guesses checksum %d" % (
             r, S * N, e0.elapsed_time(e1), int(res["n_entangled"].sum()), int(res["ent_overflow"].sum()),
             int(d_g.view(torch.int64).sum().item() & 0xffffffffffff)), flush=True)
+        us = be.fe_search_us(); big = res["_pad"].astype(np.int64) >> 8
+        print("         search time us: mean %.0f p50 %.0f p99 %.0f max %.0f; searches with big records %d (children %d), their times %s" % (
+            us.mean(), np.percentile(us, 50), np.percentile(us, 99), us.max(), int((big > 0).sum()), int(big.sum()), np.sort(us[big > 0]).astype(int).tolist()), flush=True)
         be.replan(None, d_g, d_ent=d_case)
         be.safety_commit_ent(d_c, be.d_commit, d_g, d_nx, d_ac)
         d_c.copy_(d_nx)

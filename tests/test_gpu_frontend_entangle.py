@@ -21,10 +21,14 @@ def be():
     return backend
 
 
-def _run_frontend(be, sc, W, inits=None):
+def _run_frontend(be, sc, W, inits=None, fast_caps=None, big_records=None):
     p = sc["par"]; N = p.num_agents
     fe = scene.frontend_cfg(p, beam_width=W, entangle=True)
     bb = be.BatchBackend(p, sc["statics"])
+    if fast_caps is not None:
+        bb.set_fe_ent_fast_caps(*fast_caps)
+    if big_records is not None:
+        bb.set_fe_ent_big_records(big_records)
     reps, longest = scene.static_reps(sc["statics"]) if len(sc["statics"]) else (np.zeros((0, 2, 2)), np.zeros((0, 2)))
     bb.set_static_reps(reps, longest)
     T = bb.torch
@@ -87,6 +91,53 @@ def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents,
     bb.close()            #  tests/test_gpu_parity.py::test_real_entangle_states_drive_the_entangle_rows covers scenes where they do)
 
 
+@pytest.mark.parametrize("fast_caps", [(0, 32, 8), (2, 32, 8), (40, 1, 8), (40, 32, 0), (1, 0, 0)])
+def test_big_records_carry_what_the_fixed_record_cannot(be, oracle, fast_caps):
+    """A search node whose crossing list, new crossings of one sampled step or bend points outgrow the fixed record
+    (NEP_FE_ENT_CAP / 32 / NEP_MAX_BEND) is carried in a big record of the handle's pool, bounded by the reference's own
+    rule only (kinodynamic_search.cpp:850-854).  With the fixed record's limits shrunk (list entries, new crossings per
+    step, bend points) an ordinary scene runs through the big records: every output is the default run's, bit for bit —
+    and the oracle's, which has no capacity at all."""
+    sc = scene.tether_crossing_scene(16, 8, 61)
+    p = sc["par"]; N = 16
+    rng = np.random.default_rng(5)
+    inits = np.zeros(N, dtype=abi.FE_ENT_STATE_DTYPE)
+    for a in range(0, N, 2):
+        j = int((a + 1 + rng.integers(0, N - 1)) % N)
+        if j != a:
+            inits[a]["n_alpha"] = 1; inits[a]["id"][0] = j + 1; inits[a]["cs"][0] = int(rng.integers(0, 3))
+    ref = _run_frontend(be, sc, 16, inits)
+    got = _run_frontend(be, sc, 16, inits, fast_caps=fast_caps, big_records=1 << 16)
+    ref[0].close(); got[0].close()
+    assert (got[6]["ent_overflow"] == 0).all() and (ref[6]["ent_overflow"] == 0).all()
+    big = got[6]["_pad"].astype(np.int64) >> 8
+    assert (ref[6]["_pad"] == 0).all()                       # (this scene needs no big record at the default limits)
+    assert big.sum() > 50, big                                # (and many with the shrunk ones)
+    assert got[5].tobytes() == ref[5].tobytes()               # guesses
+    np.testing.assert_array_equal(got[8], ref[8])             # case blocks
+    for f in ("status", "K", "depth", "n_children", "n_feasible", "n_collision_free", "n_entangled", "cost", "dist_to_goal"):
+        np.testing.assert_array_equal(got[6][f], ref[6][f], err_msg=f)
+    starts = got[2]
+    for a in (0, 5, 10):
+        hx, hn = oracle.hulls_of_scene(p, a + 1, sc["committed"], float(starts[a]["t_start"]), sc["statics"])
+        ent = helpers.ent_inputs(sc, a, t0=float(starts[a]["t_start"]), init=inits[a])
+        g, res, case = oracle.frontend_beam_ent(p, got[1], a + 1, starts[a], hx, hn, sc["statics"], ent)
+        np.testing.assert_array_equal(np.array(got[5][a]["coeff"]), np.array(g["coeff"]))
+        np.testing.assert_array_equal(got[8][a], case)
+        assert int(got[6][a]["n_entangled"]) == res["n_entangled"] and res["ent_overflow"] == 0
+
+
+def test_an_exhausted_pool_of_big_records_is_flagged(be):
+    """nep_fe_result.ent_overflow: the only capacity left is the pool itself — a child that finds it empty is pruned and
+    the search says so (bit 3 of _pad)."""
+    sc = scene.tether_crossing_scene(16, 8, 61)
+    got = _run_frontend(be, sc, 16, fast_caps=(0, 32, 8), big_records=3)
+    got[0].close()
+    r = got[6]
+    assert r["ent_overflow"].sum() > 0
+    assert ((r["_pad"][r["ent_overflow"] != 0] & 8) != 0).all()
+
+
 def test_config5_style_device_made_guesses_and_cases(be):
     """BASELINE configs[4] ingredients at a size one test can afford (64 agents + 20 obstacles, entangle check on): guesses
     and entangle cases both made on the device, then separator + QP on them; every returned plan is entangle-free by the
@@ -111,12 +162,15 @@ def test_config5_style_device_made_guesses_and_cases(be):
     bb.close()
 
 
-def test_safety_pass_entangle_recheck(be, oracle):
+@pytest.mark.parametrize("fast_add", [32, 0])
+def test_safety_pass_entangle_recheck(be, oracle, fast_add):
     """nep_batch_safety_commit_ent: the flags equal the oracle's entangleCheckGivenPwp on every new trajectory (against
-    everybody's NEW trajectories), and a flagged agent keeps its previous record."""
+    everybody's NEW trajectories), and a flagged agent keeps its previous record.  fast_add = 0: every interval with a
+    crossing goes through the re-check's big records (what a step of more than 32 new crossings does)."""
     sc = scene.tether_crossing_scene(8, 6, 60)
     p = sc["par"]; N = 8
     bb = be.BatchBackend(p, sc["statics"])
+    bb.set_fe_ent_fast_caps(40, fast_add, 8)
     reps, longest = scene.static_reps(sc["statics"])
     bb.set_static_reps(reps, longest)
     T = bb.torch
