@@ -105,6 +105,7 @@ struct Engine {
   DevBuf<double> d_sampled, d_srep, d_slong; DevBuf<int> d_present, d_entangles;
   DevBuf<nep_fe_ent_state> d_fe_nodes, d_fe_work, d_fe_saved; DevBuf<double> d_fe_arc, d_fe_packed; bool have_reps = false;
   // big records of the entangle-aware front end (ent_device.h): a pool per handle, 0 = the default budget (4 per slot, at least 4 096)
+  DevBuf<double> d_fe_big_beta;
   DevBuf<unsigned char> d_fe_big, d_fe_big_check; DevBuf<int> d_fe_big_count, d_fe_big_check_count; long fe_big_records = 0;
   int fe_fast_cap = NEP_FE_ENT_CAP, fe_fast_add = 32, fe_fast_bend = NEP_MAX_BEND;
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
@@ -403,7 +404,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_order.release(); d_fe_order_key.release(); d_fe_us.release(); d_fe_box.release();
-    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release(); d_fe_big.release(); d_fe_big_count.release(); d_fe_big_check.release(); d_fe_big_check_count.release();
+    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release(); d_fe_big.release(); d_fe_big_beta.release(); d_fe_big_count.release(); d_fe_big_check.release(); d_fe_big_check_count.release();
     d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
@@ -1135,8 +1136,10 @@ static int fe_ent_scratch(nep_batch* h, const nep_fe_cfg& cfg, FeEntArgs& ea) {
   const long n_rec = E.fe_big_records > 0 ? E.fe_big_records : std::max(4096L, 4L * h->slots);
   const size_t rec = (size_t)ent_big_rec_bytes(N, S);
   if (int e = E.d_fe_big.ensure(rec * (size_t)n_rec)) return e;
-  if (int e = E.d_fe_big_count.ensure(2 + 1024)) return e;      // [0] records claimed, [1] searches listed for the big-record instantiation, [2..] the list
-  ea.redo_count = E.d_fe_big_count.p + 1; ea.redo_list = E.d_fe_big_count.p + 2; ea.redo_cap = 1024;
+  if (int e = E.d_fe_big_count.ensure(2 + 256)) return e;      // [0] records claimed, [1] searches listed for the big-record instantiation, [2..] the list
+  ea.redo_count = E.d_fe_big_count.p + 1; ea.redo_list = E.d_fe_big_count.p + 2; ea.redo_cap = 256;
+  if (int e = E.d_fe_big_beta.ensure((size_t)ea.redo_cap * 256 * 120)) return e;      // (kEntBigLdsCap betas per thread of the big-record instantiation: 63 MB)
+  ea.big_beta = E.d_fe_big_beta.p;
   ea.big = EntBigPool{E.d_fe_big.p, E.d_fe_big_count.p, (int)n_rec, (int)rec, ent_big_cap(N, S), ent_big_add_lim(N, S)};
   ea.fast_cap = E.fe_fast_cap; ea.fast_add = E.fe_fast_add; ea.fast_bend = E.fe_fast_bend;
   return 0;

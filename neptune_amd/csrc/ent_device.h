@@ -611,6 +611,27 @@ __device__ void ent_copy(nep_fe_ent_state* dst, const nep_fe_ent_state* src) {
   for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) d[i] = s[i];
 }
 
+// the same from / into a big record (the big-record instantiation keeps lists of up to kEntBigLdsCap entries in LDS: a list in a
+// big record's global memory makes every step of the surgery a round trip of its own — a search that runs on big records took
+// 3.4 ms against 0.8 for one that does not)
+constexpr int kEntBigLdsCap = 120, kEntBigLdsBend = 16;
+constexpr int kEntBigLdsBytes = ((kEntBigLdsCap * 3 + kEntBigLdsBend + 3) & ~3) | 4;      // per thread; an odd number of dwords
+__device__ __forceinline__ bool ent_lds_load_big(EntLds& L, const EntBig& Q, int N) {
+  L.n_alpha = Q.n_alpha; L.n_bend = Q.n_bend;
+  if ((L.n_alpha > L.cap) | (L.n_bend > L.bend_cap)) return false;
+  unsigned long long g = 0ull;
+  for (int i = 0; i < L.n_alpha; i++) { const int id_ = Q.id[i]; L.id[i] = (short)id_; L.cs[i] = Q.cs[i]; g |= 1ull << (id_ & 63); if (id_ > N) L.beta[i] = Q.beta[i]; }
+  L.sig = g;
+  for (int i = 0; i < L.n_bend; i++) L.bend[i] = (signed char)Q.bend[i];
+  return true;
+}
+__device__ __forceinline__ void ent_lds_store_big(const EntBigPool& P, int k, const EntLds& L, int N) {
+  EntBig B = ent_big_view(P, k);
+  for (int i = 0; i < L.n_alpha; i++) { const int id_ = L.id[i]; B.id[i] = (short)id_; B.cs[i] = L.cs[i]; if (id_ > N) B.beta[i] = L.beta[i]; }
+  for (int i = 0; i < L.n_bend; i++) B.bend[i] = L.bend[i];
+  B.n_alpha = L.n_alpha; B.n_bend = L.n_bend;
+  ent_big_close(P, k, B);
+}
 __device__ __forceinline__ EntBigOut ent_big_child(const EntCtx& c, const EntBigPool& P, const nep_fe_ent_state* par, const double* cxo, const double* cyo, Ev2 end, int index, bool check_tether, int cap_mult) {
   EntBigOut o; o.rc = 5; o.k = -1; o.n_alpha = 0; o.n_bend = 0; o.iz = 0u; o.arc = 0.0;
   if (!P.base) return o;

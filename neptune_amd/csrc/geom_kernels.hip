@@ -2013,6 +2013,14 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         const lds_bytes base = (lds_bytes)(unsigned)(size_t)(ent_lists + tid * kEntLdsBytes);      // (the low 32 bits of a generic LDS address are the LDS offset)
         L.id = (ent_lds_short)base; L.cs = (ent_lds_char)(base + 2 * NEP_FE_ENT_CAP); L.bend = (ent_lds_char)(base + 3 * NEP_FE_ENT_CAP); L.beta = my_work->beta;
         L.cap = ea.fast_cap; L.bend_cap = ea.fast_bend;
+        if constexpr (BIG) {
+          if (ea.big_lds_off) {      // lists of up to kEntBigLdsCap entries in LDS of their own (one workgroup per CU: there is room), their betas in global memory
+            const lds_bytes bb = (lds_bytes)(unsigned)(size_t)((unsigned char*)fe_smem + ea.big_lds_off + tid * kEntBigLdsBytes);
+            L.id = (ent_lds_short)bb; L.cs = (ent_lds_char)(bb + 2 * kEntBigLdsCap); L.bend = (ent_lds_char)(bb + 3 * kEntBigLdsCap);
+            L.beta = ea.big_beta + ((long)blockIdx.x * 256 + tid) * kEntBigLdsCap;
+            L.cap = ea.big.cap < kEntBigLdsCap ? ea.big.cap : kEntBigLdsCap; L.bend_cap = kEntBigLdsBend;
+          }
+        }
       }
       double arc = 0.0;
       int rc = 2;
@@ -2020,7 +2028,13 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       // the fixed record's path — unless the parent is a big record already (n_alpha < 0, ent_device.h) or holds more than this
       // handle's fast path takes
       bool loaded;
-      { FE_ENT_T0(); loaded = ent_lds_load(L, ent_node(depth - 1, depth == 1 ? 0 : pr_), N); FE_ENT_T(1); }
+      {
+        FE_ENT_T0();
+        const nep_fe_ent_state* par = ent_node(depth - 1, depth == 1 ? 0 : pr_);
+        if constexpr (BIG) { const int pn = par->n_alpha; loaded = pn < 0 ? (ea.big_lds_off != 0 && ent_lds_load_big(L, ent_big_view(ea.big, -pn - 1), N)) : ent_lds_load(L, par, N); }
+        else loaded = ent_lds_load(L, par, N);
+        FE_ENT_T(1);
+      }
       if (loaded) {
         unsigned add_tail[kEntAddCap - EntAdd::reg];
         { FE_ENT_T0(); rc = ent_propagate<EntAdd>(ec, &L, EntAdd::Store{add_tail, ea.fast_add}, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
@@ -2033,7 +2047,17 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         return;
       }
       if (rc) { my_entangled++; s_state[id] = 0; return; }
-      ent_lds_store(ea.saved + ((long)slot * kFeCap + id), L, N); ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
+      if (BIG && (L.n_alpha > ea.fast_cap || L.n_alpha > NEP_FE_ENT_CAP || L.n_bend > ea.fast_bend || L.n_bend > NEP_MAX_BEND)) {
+        // more than the fixed record holds (the LDS lists of this instantiation do): into a big record
+        const int k = ea.big.base ? atomicAdd(ea.big.count, 1) : ea.big.n_rec;
+        my_big++;
+        if (k >= ea.big.n_rec) { my_entangled++; my_overflow |= 8; s_state[id] = 0; return; }
+        ent_lds_store_big(ea.big, k, L, N);
+        nep_fe_ent_state* sv = ea.saved + ((long)slot * kFeCap + id);
+        sv->n_alpha = -(k + 1); sv->n_bend = 0;
+      } else
+      ent_lds_store(ea.saved + ((long)slot * kFeCap + id), L, N);
+      ea.saved_arc[(long)slot * kFeCap + id] = arc;      // (for the install, should this child win its voxel and a rank)
       ch.g = b_g[prv * MB + pr_] + arc;
       ch.f = ch.g + fc.bias * ((ch.dist + 0.3 * (double)L.n_alpha) + 1.0 * (double)L.n_bend);
       settle_voxel(id, ch, ent_iz(&L));
@@ -2134,6 +2158,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       const int n_prop = s_i[3];
       int n_merge = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2 + (rf_alias ? 0 : kFeCap))) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS (o_aabb, o_V and, when it has storage of its own, r_f)
       if (n_merge > 256) n_merge = 256;
+      if constexpr (BIG) { if (ea.big_lds_off) n_merge = 256; }      // (lists of their own)
       { const int rounds = (n_prop + n_merge - 1) / n_merge; if (rounds > 1) n_merge = (n_prop + rounds - 1) / rounds; }      // (even rounds: 178 survivors are 89 + 89, not 131 + 47)
       for (int b0 = 0; b0 < n_prop; b0 += n_merge) {             // that many survivors at a time, one per thread
         if (tid < n_merge && b0 + tid < n_prop) propagate(p_list[b0 + tid]);
@@ -2393,8 +2418,11 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps_in
     hipLaunchKernelGGL((frontend_kernel<true, NEP_FE_ENT_WGS>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
     if (ea->redo_list && ea->big.base && ea->redo_cap > 0) {      // the searches listed by that launch, again, with big records (nearly always none: the workgroups return at once)
       static DynLdsAttr attr_big;
-      (void)attr_big.ensure((const void*)frontend_kernel<true, 1, true>, lds);
-      hipLaunchKernelGGL((frontend_kernel<true, 1, true>), dim3(ea->redo_cap < n_slots ? ea->redo_cap : n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, *ea);
+      FeEntArgs eb = *ea;
+      size_t lds_b = lds;
+      if (eb.big_beta && lds + 256 * (size_t)kEntBigLdsBytes <= (size_t)160 * 1024) { eb.big_lds_off = (int)lds; lds_b = lds + 256 * (size_t)kEntBigLdsBytes; } else eb.big_lds_off = 0;
+      (void)attr_big.ensure((const void*)frontend_kernel<true, 1, true>, lds_b);
+      hipLaunchKernelGGL((frontend_kernel<true, 1, true>), dim3(ea->redo_cap < n_slots ? ea->redo_cap : n_slots), dim3(256), lds_b, st, sp, ps, fc, starts, guess_out, res_out, eb);
     }
   }
   else if (four) hipLaunchKernelGGL((frontend_kernel<false, 4>), dim3(n_slots), dim3(256), lds, st, sp, ps, fc, starts, guess_out, res_out, none);

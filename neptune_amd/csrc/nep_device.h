@@ -180,6 +180,8 @@ struct FeEntArgs {
   int pk_stride;
   EntBigPool big;                // front end: where states beyond the fixed record go (base == null: such children are pruned and flagged)
   EntBigPool big_check;          // the same for the safety pass's re-check (records of three times the bound; its counter is zeroed by ent_sample_kernel)
+  int big_lds_off;               // big-record instantiation: byte offset, in the dynamic LDS, of its per-thread lists (kEntBigLdsBytes each), or 0: none (the launch's LDS would not hold them)
+  double* big_beta;              // [redo_cap][256][kEntBigLdsCap] betas of those lists
   int* redo_list; int* redo_count; int redo_cap;      // front end: searches in which a child outgrew the fixed record, listed by frontend_kernel<true, W> for frontend_kernel<true, 2, true> (beyond redo_cap: they stay flagged)
   int fast_cap, fast_add, fast_bend;      // front end: what the fixed record's path accepts (<= NEP_FE_ENT_CAP, 32, NEP_MAX_BEND; nep_batch_set_fe_ent_fast_caps — the tests shrink them to drive ordinary scenes through the big records)
 };
