@@ -112,7 +112,7 @@ struct Engine {
   bool safety_check_prev = false;
   int lds_lines = 0, lds_rows = 0, rows_cap = 0; size_t lds_bytes = 0;
   DevBuf<double> d_fe_box;          // boxes of the front end's obstacles, made before every search launch
-  DevBuf<int> d_fe_order, d_fe_order_key; DevBuf<float> d_fe_us; bool fe_history = false;      // the same for the front end's searches (frontend_kernel)
+  DevBuf<int> d_fe_order, d_fe_order_key; DevBuf<float> d_fe_us; bool fe_history = false, fe_lpt = true;      // the same for the front end's searches (frontend_kernel)
   DevBuf<int> d_order, d_order_key; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double clock_hz = 1e8;       // wall_clock64() rate of the handle's device (set_clock)
@@ -212,6 +212,7 @@ struct Engine {
     }
     if (const char* f = getenv("NEP_SEP_SKIP")) skip_lps = atoi(f) != 0;      // (A/B: 0 solves every LP of a presolved replan too)
     if (const char* f = getenv("NEP_QP_LPT")) lpt = atoi(f) != 0;
+    if (const char* f = getenv("NEP_FE_LPT")) fe_lpt = atoi(f) != 0;      // (A/B: the front end's launch order alone)
     no_redo = getenv("NEP_SEP_NO_REDO") != nullptr;
     // (development aids, read here once and not per replan: NEP_SEP_UNPACKED, NEP_SEP_PACK=n — see nep_batch_debug_set_separator_pack)
     if (getenv("NEP_SEP_UNPACKED")) sep_pack = -1;
@@ -245,7 +246,7 @@ struct Engine {
     ps.pb = d_pb.p; ps.static_xy = d_static_xy.p; ps.static_nv = d_static_nv.p; ps.static_el = d_static_el.p;
     ps.hull_xy = d_hull_xy.p; ps.hull_nv = d_hull_nv.p; ps.hull0_xy = d_hull0_xy.p; ps.hull0_nv = d_hull0_nv.p;
     ps.bend_xy = d_bend_xy.p; ps.bend_n = d_bend_n.p;
-    ps.fe_order = nullptr; ps.fe_order_key = (lpt && d_fe_order_key.n >= (size_t)n_scenes * (size_t)sp.n_local) ? d_fe_order_key.p : nullptr; ps.fe_us = d_fe_us.p;
+    ps.fe_order = nullptr; ps.fe_order_key = (lpt && fe_lpt && d_fe_order_key.n >= (size_t)n_scenes * (size_t)sp.n_local) ? d_fe_order_key.p : nullptr; ps.fe_us = d_fe_us.p;
     ps.line_nd = d_line_nd.p; ps.line_cnt = d_line_cnt.p; ps.lp_stats = d_lp_stats.p;
     ps.line_far = sp.cull_radius > 0.0 ? d_line_far.p : nullptr;
     // LPs whose line is known to be far without solving them are skipped when the presolve is on, the rule is the largest gap
