@@ -115,8 +115,10 @@ typedef struct nep_fe_result {
   double cost;                    /* g + bias*h of the returned node                               */
   double dist_to_goal;
   int32_t n_entangled;            /* children pruned by entanglesWithOtherAgents (entangle check on)        */
-  int32_t ent_overflow;           /* 1: a child needed a big record and the handle's pool had none left: pruned (a
-                                     deviation from the reference's rule; 0 in every test and bench leg)             */
+  int32_t ent_overflow;           /* 1: a child needed a big record and the handle's pool had none left (pruned), or
+                                     more than 256 searches of one launch needed big records (the ones beyond keep
+                                     the fixed record's limits: _pad bits 0-2 say which) — deviations from the
+                                     reference's rule; 0 in every test and bench leg                                */
 } nep_fe_result;
 
 /* Front end of every slot of the batch handle, asynchronous on `stream`.
