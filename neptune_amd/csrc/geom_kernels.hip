@@ -2262,7 +2262,12 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
     if constexpr (!BIG) {   // this search's device time: a statistic, and the next launch's ordering key
       const double us_ = (double)((long long)wall_clock64() - t_wg0) * sp.us_per_tick;
       if (ps.fe_us) ps.fe_us[slot] = (float)us_;
-      if (ps.fe_order_key) { const double k_ = us_ * (ENT ? 1.0 / 256.0 : 1.0 / 8.0); ps.fe_order_key[slot] = k_ > 63.0 ? 63 : (int)k_; }
+      // (the key remembers: the maximum of this search's bin and the previous key less fe_key_decay — a slot whose searches alternate
+      // between short and long ones, e.g. no first primitive in one round and a full search in the next, is started with the long
+      // ones; started last, a long search sets the kernel's end.  Simulated on the measured times of the config-5 chain, 768
+      // workgroup slots: 17.5 ms with the previous round's time as the key, 16.8 with the maximum over the rounds so far, 16.0
+      // with a perfect predictor, 15.5 = sum / 768)
+      if (ps.fe_order_key) { const double k_ = us_ * (ENT ? 1.0 / 256.0 : 1.0 / 8.0); const int kn = k_ > 63.0 ? 63 : (int)k_, ko = ps.fe_order_key[slot] - sp.fe_key_decay; ps.fe_order_key[slot] = (sp.fe_key_decay > 0 && ko > kn) ? ko : kn; }
       if constexpr (ENT) {   // a child outgrew the fixed record: the search is run again by the big-record instantiation (launch_frontend)
         if (s_i[9] != 0 && ea.redo_list) { const int k_ = atomicAdd(ea.redo_count, 1); if (k_ < ea.redo_cap) ea.redo_list[k_] = slot; }      // (beyond the list: the search stays flagged)
       }

@@ -34,6 +34,23 @@ def main():
         us = be.fe_search_us(); big = res["_pad"].astype(np.int64) >> 8
         print("         search time us: mean %.0f p50 %.0f p99 %.0f max %.0f; searches with big records %d (children %d), their times %s" % (
             us.mean(), np.percentile(us, 50), np.percentile(us, 99), us.max(), int((big > 0).sum()), int(big.sum()), np.sort(us[big > 0]).astype(int).tolist()), flush=True)
+        if r == 0: us_prev2 = us.copy(); us_max = us.copy()
+        if r > 0:      # what the launch order is worth: list scheduling of this round's measured times on 768 workgroup slots
+            import heapq
+            def makespan(order):
+                h = [0.0] * 768; heapq.heapify(h)
+                end = 0.0
+                for i in order:
+                    t = heapq.heappop(h) + us[i]; end = max(end, t); heapq.heappush(h, t)
+                return end
+            n = len(us)
+            for name, order in (("slot order", np.arange(n)), ("previous round's time in 256 us bins (what the kernel does)", np.argsort(-np.minimum(63, (us_prev / 256).astype(int)), kind="stable")),
+                                ("previous round's time in 64 us bins", np.argsort(-np.minimum(63, (us_prev / 64).astype(int)), kind="stable")), ("previous round's time, exact", np.argsort(-us_prev, kind="stable")),
+                                ("max of the two previous rounds' times", np.argsort(-np.maximum(us_prev, us_prev2), kind="stable")),
+                                ("max of the previous rounds' times, all", np.argsort(-us_max, kind="stable")),
+                                ("this round's time (perfect predictor)", np.argsort(-us, kind="stable"))):
+                print("         simulated makespan on 768 slots, %s: %.2f ms (sum / 768 = %.2f ms)" % (name, makespan(order) / 1e3, us.sum() / 768e3))
+        us_prev2 = us_prev.copy() if r > 0 else us.copy(); us_prev = us.copy(); us_max = np.maximum(us_max, us) if r > 0 else us.copy()
         be.replan(None, d_g, d_ent=d_case)
         be.safety_commit_ent(d_c, be.d_commit, d_g, d_nx, d_ac)
         d_c.copy_(d_nx)
