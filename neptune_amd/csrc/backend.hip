@@ -213,13 +213,14 @@ struct Engine {
     if (const char* f = getenv("NEP_SEP_SKIP")) skip_lps = atoi(f) != 0;      // (A/B: 0 solves every LP of a presolved replan too)
     if (const char* f = getenv("NEP_QP_LPT")) lpt = atoi(f) != 0;
     if (const char* f = getenv("NEP_FE_LPT")) fe_lpt = atoi(f) != 0;      // (A/B: the front end's launch order alone)
-    sp.fe_key_decay = 1;
+    sp.fe_key_decay = 1; sp.qp_key_decay = 2;
+    if (const char* f = getenv("NEP_QP_KEY_DECAY")) sp.qp_key_decay = atoi(f);      // (A/B)
     if (const char* f = getenv("NEP_FE_KEY_DECAY")) sp.fe_key_decay = atoi(f);      // (A/B)
     no_redo = getenv("NEP_SEP_NO_REDO") != nullptr;
     // (development aids, read here once and not per replan: NEP_SEP_UNPACKED, NEP_SEP_PACK=n — see nep_batch_debug_set_separator_pack)
     if (getenv("NEP_SEP_UNPACKED")) sep_pack = -1;
     else if (const char* f = getenv("NEP_SEP_PACK")) { const int v = atoi(f); if (v >= 1 && v <= NEP_MAX_POL) sep_pack = v; }
-    if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; if (int e = d_order_key.ensure((size_t)slots)) return e; }
+    if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; if (int e = d_order_key.ensure((size_t)slots)) return e; hipMemset(d_order_key.p, 0, (size_t)slots * sizeof(int)); }
     if (lpt) { if (int e = d_fe_order.ensure((size_t)slots)) return e; if (int e = d_fe_order_key.ensure((size_t)slots)) return e; hipMemset(d_fe_order_key.p, 0, (size_t)slots * sizeof(int)); }
     if (int e = d_fe_us.ensure((size_t)slots)) return e;
     choose_placement();

@@ -34,6 +34,7 @@ struct SceneParams {
   long long time_limit_ticks;   // > 0: wall-clock budget of ONE solve in wall_clock64() ticks (setMaxRuntime -> Gurobi TimeLimit, solver_gurobi_poly.cpp:812)
   double tol_res, tol_gap, tol_res_inv, tol_gap_inv, tol_gap_floor;      // (tol_gap_floor = 0.1 tol_gap: the centring target's floor)      // the interior point's strict tests: residuals (absolute, the dual one scaled), relative gap; their reciprocals for the merit (nep_batch_set_tolerances)
   int sep_rule;                 // which vertex of the separator LP is returned: 0 the largest-gap one (default), 1 the one a primal simplex of GLPK's default class reaches (nep_batch_set_separator_rule)
+  int qp_key_decay;             // the same for the QP workgroups' key (8 us bins; 2: chain QP launch 1.63 -> 1.55 ms, crossing 2.29 -> 2.26; NEP_QP_KEY_DECAY for A/Bs, 0 = the last solve's bin)
   int fe_key_decay;             // front end's launch-order key: bins an old key loses per launch (0: the key is the last search's bin)
   double us_per_tick;           // microseconds per wall_clock64() tick of this device (hipDeviceAttributeWallClockRate; 0.01 on gfx950: 100 MHz)
 };

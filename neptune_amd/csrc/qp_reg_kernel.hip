@@ -1035,7 +1035,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     }
     sol->stats.n_lines = L_all - n_lpf; sol->stats.n_lp = n_lp; sol->stats.n_lp_failed = n_lpf;
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((CULL && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;
-    sol->stats.objective = sc[sObjOut]; { const long long dt_ = (long long)wall_clock64() - t_wg0; const double us_ = (double)dt_ * sp.us_per_tick; sol->stats.solve_us = us_; if (ps.order_key) { const double k_ = us_ * 0.125; ps.order_key[slot] = k_ > 63.0 ? 63 : (int)k_; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
+    sol->stats.objective = sc[sObjOut]; { const long long dt_ = (long long)wall_clock64() - t_wg0; const double us_ = (double)dt_ * sp.us_per_tick; sol->stats.solve_us = us_; if (ps.order_key) { const double k_ = us_ * 0.125; const int kn = k_ > 63.0 ? 63 : (int)k_, ko = ps.order_key[slot] - sp.qp_key_decay; ps.order_key[slot] = (sp.qp_key_decay > 0 && ko > kn) ? ko : kn; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
     sol->K = Ko; sol->n_states = ns;
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)
