@@ -181,14 +181,17 @@ __device__ __forceinline__ bool ent_static_may_cross(const EntCtx& c, const EntB
 // (f_known: -1 = evaluate the base-sweep test here; 0 / 1 = its outcome, from EntCtx::f_bits)
 // (b0: bend point 0 in registers, where the caller has fetched it with the record's header — most tethers have no other, and a load
 // issued here waits for everything the caller has requested ahead, i.e. for the NEXT obstacle's record)
-template <class ADD> __device__ __forceinline__ void ent_cross_agent(ADD& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id, int f_known = -1, bool have_b0 = false, Ev2 b0 = Ev2{0, 0}) {
+template <class ADD> __device__ __forceinline__ void ent_cross_agent(ADD& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id, int f_known = -1, bool have_b0 = false, Ev2 b0 = Ev2{0, 0}, Ev2 b1 = Ev2{0, 0}) {
   bool base_addition = false;
+  // (have_b0: bend points 0 AND 1 are in registers, fetched by the caller with the record's header; a segment's far end is kept for
+  // the next segment's near end.  Read where they are used, a tether of two to four bend points — the bench's config-5 tethers — cost
+  // two to four round trips per visit; now none, one or two)
+  Ev2 bk = b0;
+  if (!have_b0 && nb > 0) { bk.x = bp[0]; bk.y = bp[1]; }
   for (int k = 0; k < nb; k++) {
     const bool last = k == nb - 1;
-    Ev2 bk = b0;
-    if (!(have_b0 && k == 0)) { bk.x = bp[2 * k]; bk.y = bp[2 * k + 1]; }
-    Ev2 u, v; double c1, c2;
-    if (!last) { const Ev2 bn{bp[2 * (k + 1)], bp[2 * (k + 1) + 1]}; c1 = ent_wedge2(pk, bn, bk, u, v); c2 = ent_wedge(pk1, bn, bk); }
+    Ev2 u, v, bn = bk; double c1, c2;
+    if (!last) { if (have_b0 && k == 0) bn = b1; else { bn.x = bp[2 * (k + 1)]; bn.y = bp[2 * (k + 1) + 1]; } c1 = ent_wedge2(pk, bn, bk, u, v); c2 = ent_wedge(pk1, bn, bk); }
     else { c1 = ent_wedge2(pk, pik, bk, u, v); c2 = ent_wedge(pk1, pik1, bk); }
     if (last) {
       Ev2 ub, vb; bool sweeps;
@@ -208,6 +211,7 @@ template <class ADD> __device__ __forceinline__ void ent_cross_agent(ADD& add, E
       else if (a < 1 && last) ent_push(add, agent_id, 1, nb);
       else if (a >= 1 && k == 0) ent_push(add, agent_id, 0, nb);
     }
+    bk = bn;
   }
   if (base_addition && add.n >= 2 && ((add.get(add.n - 1) ^ add.get(add.n - 2)) & 0xffffffu) == 0u) add.n -= 2;      // (same id, same case)
 }
@@ -412,7 +416,7 @@ template <class ADD, class ST> __device__ int ent_propagate(const EntCtx& c, ST*
   const Ev2 pb_self = ent_pb(c, c.own);
   Ev2 pk{cxo[3], cyo[3]}, pk1 = pk;
 #ifdef NEP_PROFILE_PHASES
-  long long pt[5] = {0, 0, 0, 0, 0}; long long pl = clock64(); int p_add = 0, p_chg = 0; long long mt[5] = {0, 0, 0, 0, 0}, ml = 0;
+  long long pt[5] = {0, 0, 0, 0, 0}; long long pl = clock64(); int p_add = 0, p_chg = 0, p_visit = 0; long long mt[5] = {0, 0, 0, 0, 0}, ml = 0;
 #define ENT_PT(k) do { const long long t_ = clock64(); pt[k] += t_ - pl; pl = t_; } while (0)
 #else
 #define ENT_PT(k) do { } while (0)
@@ -444,14 +448,17 @@ template <class ADD, class ST> __device__ int ent_propagate(const EntCtx& c, ST*
       };
       int i = next_cand();
       const double* r = ent_rec(c, i < c.N ? i : 0, itv);
-      int2 hd = *(const int2*)r; double2 sa = *(const double2*)(r + kEntPkHead + 2 * jl), sb = *(const double2*)(r + kEntPkHead + 2 * jr), b0 = *(const double2*)(r + kEntPkBend);
+      int2 hd = *(const int2*)r; double2 sa = *(const double2*)(r + kEntPkHead + 2 * jl), sb = *(const double2*)(r + kEntPkHead + 2 * jr), b0 = *(const double2*)(r + kEntPkBend), b1 = *(const double2*)(r + kEntPkBend + 2);
       while (i < c.N) {
         const int in = next_cand();
         const double* rn = ent_rec(c, in < c.N ? in : 0, itv);
         const int fk = !c.f_bits ? -1 : (index > c.num_pol ? 0 : (int)((c.f_bits[i] >> (j - 1)) & 1u));      // (holding at the end: pik = pik1, f1 f2 = f1^2)
-        const int2 hdn = *(const int2*)rn; const double2 san = *(const double2*)(rn + kEntPkHead + 2 * jl), sbn = *(const double2*)(rn + kEntPkHead + 2 * jr), b0n = *(const double2*)(rn + kEntPkBend);
-        if (i != c.own && hd.x) ent_cross_agent(add, pk, pk1, Ev2{sa.x, sa.y}, Ev2{sb.x, sb.y}, pb_self, hd.y, r + kEntPkBend, i + 1, fk, true, Ev2{b0.x, b0.y});
-        i = in; r = rn; hd = hdn; sa = san; sb = sbn; b0 = b0n;
+        const int2 hdn = *(const int2*)rn; const double2 san = *(const double2*)(rn + kEntPkHead + 2 * jl), sbn = *(const double2*)(rn + kEntPkHead + 2 * jr), b0n = *(const double2*)(rn + kEntPkBend), b1n = *(const double2*)(rn + kEntPkBend + 2);
+        if (i != c.own && hd.x) ent_cross_agent(add, pk, pk1, Ev2{sa.x, sa.y}, Ev2{sb.x, sb.y}, pb_self, hd.y, r + kEntPkBend, i + 1, fk, true, Ev2{b0.x, b0.y}, Ev2{b1.x, b1.y});
+#ifdef NEP_PROFILE_PHASES
+        p_visit++;
+#endif
+        i = in; r = rn; hd = hdn; sa = san; sb = sbn; b0 = b0n; b1 = b1n;
       }
     } else
     for (int i = 0; i < c.N; i++) {
@@ -520,7 +527,7 @@ template <class ADD, class ST> __device__ int ent_propagate(const EntCtx& c, ST*
 #ifdef NEP_PROFILE_PHASES
   if (c.prof) { for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)c.prof + k, (unsigned long long)pt[k]); atomicAdd((unsigned long long*)c.prof + 5, 1ull); atomicAdd((unsigned long long*)c.prof + 6, (unsigned long long)p_add);
     atomicAdd((unsigned long long*)c.prof + 7, (unsigned long long)(p_chg != 0)); atomicMax((unsigned long long*)c.prof + 8, (unsigned long long)st->n_alpha); atomicAdd((unsigned long long*)c.prof + 9, (unsigned long long)st->n_alpha);
-    for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)c.prof + 10 + k, (unsigned long long)mt[k]); }
+    for (int k = 0; k < 5; k++) atomicAdd((unsigned long long*)c.prof + 10 + k, (unsigned long long)mt[k]); atomicAdd((unsigned long long*)c.prof + 15, (unsigned long long)p_visit); }
 #endif
   if (too_long) return 1;
   return 0;

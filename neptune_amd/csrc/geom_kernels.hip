@@ -1918,17 +1918,23 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         if (j < N) { fb_j = ec.ns <= 8 ? ent_agent_fbits_pk(ec, j, idx) : 0xffu; f_bits[j] = (unsigned char)fb_j; }
         // (three samples per interval, a tether without bend points besides its base: what the box test reads of the record — the
         // base and the four samples — is fetched once here, not once per parent)
-        bool plain = false, absent = false; Ev2 bk{0, 0}, sm0{0, 0}, sm1{0, 0}, sm2{0, 0}, sm3{0, 0};
+        // (up to four bend points — the bench's config-5 tethers have two to four: every value of the record the test reads is in
+        // registers before the loop over the parents; read inside it, one bend point at a time, the proof was a chain of round trips
+        // per (obstacle, parent) and 16 % of a search)
+        int nreg = 0; bool absent = false; Ev2 bq0{0, 0}, bq1{0, 0}, bq2{0, 0}, bq3{0, 0}, sm0{0, 0}, sm1{0, 0}, sm2{0, 0}, sm3{0, 0};
         if (j < N && !fb_j && ec.ns == 3) {
           const double* r = ent_rec(ec, j, idx);
           const int2 hd = *(const int2*)r;
           absent = !hd.x;                                   // (no trajectory: nothing to cross — its base square stays)
-          if (hd.x && hd.y == 1) {
-            plain = true;
-            const double2 b = *(const double2*)(r + kEntPkBend), a0 = *(const double2*)(r + kEntPkHead), a1 = *(const double2*)(r + kEntPkHead + 2), a2 = *(const double2*)(r + kEntPkHead + 4), a3 = *(const double2*)(r + kEntPkHead + 6);
-            bk = Ev2{b.x, b.y}; sm0 = Ev2{a0.x, a0.y}; sm1 = Ev2{a1.x, a1.y}; sm2 = Ev2{a2.x, a2.y}; sm3 = Ev2{a3.x, a3.y};
+          if (hd.x && hd.y >= 1 && hd.y <= 4) {
+            nreg = hd.y;
+            const double2 b = *(const double2*)(r + kEntPkBend), b1 = *(const double2*)(r + kEntPkBend + 2), b2 = *(const double2*)(r + kEntPkBend + 4), b3 = *(const double2*)(r + kEntPkBend + 6);
+            const double2 a0 = *(const double2*)(r + kEntPkHead), a1 = *(const double2*)(r + kEntPkHead + 2), a2 = *(const double2*)(r + kEntPkHead + 4), a3 = *(const double2*)(r + kEntPkHead + 6);
+            bq0 = Ev2{b.x, b.y}; bq1 = Ev2{b1.x, b1.y}; bq2 = Ev2{b2.x, b2.y}; bq3 = Ev2{b3.x, b3.y};
+            sm0 = Ev2{a0.x, a0.y}; sm1 = Ev2{a1.x, a1.y}; sm2 = Ev2{a2.x, a2.y}; sm3 = Ev2{a3.x, a3.y};
           }
         }
+        const Ev2 bk = nreg <= 1 ? bq0 : nreg == 2 ? bq1 : nreg == 3 ? bq2 : bq3;      // the last bend point: where the moving segment starts
         for (int q = 0; q < nb_prev; q++) {
           const EntBox bx{p_box[4 * q] - kPad, p_box[4 * q + 1] + kPad, p_box[4 * q + 2] - kPad, p_box[4 * q + 3] + kPad};
           if (j < N) {
@@ -1939,9 +1945,12 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
             bool may;
             if (fb_j) may = true;
             else if (absent) may = false;
-            else if (plain) {      // ent_agent_may_cross_pk for nb = 1, from registers
+            else if (nreg) {      // ent_agent_may_cross_pk for nb <= 4, from registers
               const int s0 = ent_side(bx, sm0, bk);
               may = (s0 == 0) | (ent_side(bx, sm1, bk) != s0) | (ent_side(bx, sm2, bk) != s0) | (ent_side(bx, sm3, bk) != s0);
+              if (nreg > 1) may |= ent_side(bx, bq1, bq0) == 0;
+              if (nreg > 2) may |= ent_side(bx, bq2, bq1) == 0;
+              if (nreg > 3) may |= ent_side(bx, bq3, bq2) == 0;
             } else may = ent_agent_may_cross_pk(ec, bx, j, idx);
             if (may) atomicOr(&m_ent[q * MW + (j >> 5)], 1u << (j & 31));
           } else {
@@ -2400,7 +2409,11 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps_in
   if (n_slots <= 0) return;
   ProblemSet ps = ps_in;
   ps.fe_order = nullptr;
-  if (ps.fe_order_key && order_buf && have_history && n_slots > 1024) {      // (more than one wave of workgroups)
+  static const int xcd_mode = getenv("NEP_FE_XCD") ? atoi(getenv("NEP_FE_XCD")) : 1;      // (A/B: 0 = the launch order without the XCD placement)
+  if (order_buf && n_slots > 1024 && n_slots % 8 == 0 && xcd_mode) {      // a few whole scenes per XCD, the longest expected searches first within each (order_xcd_kernel)
+    launch_order_xcd(n_slots, (ps.fe_order_key && have_history) ? ps.fe_order_key : nullptr, order_buf, st);
+    ps.fe_order = order_buf;
+  } else if (ps.fe_order_key && order_buf && have_history && n_slots > 1024) {      // (more than one wave of workgroups)
     launch_qp_order(n_slots, ps.fe_order_key, order_buf, st);
     ps.fe_order = order_buf;
   }

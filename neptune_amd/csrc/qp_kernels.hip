@@ -843,6 +843,30 @@ __global__ __launch_bounds__(1024) void order_kernel(int n, const int* __restric
   __syncthreads();
   for (int i = tid; i < n; i += 1024) { const int b = 63 - (key[i] & 63); order[tot[b] + atomicAdd(&hist[b][sub], 1)] = i; }
 }
+// The same for launches whose neighbouring slots share data (the front end: the 64 or 256 searches of a scene read the same hulls,
+// boxes and packed records): the dispatcher is observed to run block b on XCD b % 8 (MI355X_MICROARCH.md, a speed matter only), so
+// in slot order every XCD's L2 sees every scene's data — 32 MB of it at config 5 against 4 MB of L2 — and a record read costs a
+// trip to the Infinity Cache (measured: ~4 000 cycles per visited record in the entangle check's agent loop).  Here XCD x gets the
+// x-th eighth of the slots — a few whole scenes — and, within it, the longest expected first: order[8 p + x] = the p-th slot of
+// eighth x by descending key (key == null: in slot order).  n must be a multiple of 8.
+__global__ __launch_bounds__(1024) void order_xcd_kernel(int n, const int* __restrict__ key, int* __restrict__ order) {
+  __shared__ int hist[8][64];
+  const int tid = threadIdx.x, chunk = n >> 3;
+  if (tid < 512) hist[tid >> 6][tid & 63] = 0;
+  __syncthreads();
+  if (key) for (int i = tid; i < n; i += 1024) atomicAdd(&hist[i / chunk][63 - (key[i] & 63)], 1);
+  __syncthreads();
+  if (tid < 8 && key) { int o = 0; for (int b = 0; b < 64; b++) { const int c = hist[tid][b]; hist[tid][b] = o; o += c; } }
+  __syncthreads();
+  for (int i = tid; i < n; i += 1024) {
+    const int c = i / chunk;
+    const int pos = key ? atomicAdd(&hist[c][63 - (key[i] & 63)], 1) : i - c * chunk;
+    order[pos * 8 + c] = i;
+  }
+}
+void launch_order_xcd(int n_slots, const int* key, int* order, hipStream_t st) {
+  if (n_slots > 0) hipLaunchKernelGGL(order_xcd_kernel, dim3(1), dim3(1024), 0, st, n_slots, key, order);
+}
 void launch_qp_order(int n_slots, const int* key, int* order, hipStream_t st) {
   if (n_slots > 0) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, n_slots, key, order);
 }

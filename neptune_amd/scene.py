@@ -444,7 +444,7 @@ def statics_csr(statics):
     return off, np.ascontiguousarray(xy)
 
 
-def synthetic_entangle(sc, seed, frac=0.1):
+def synthetic_entangle(sc, seed, frac=0.1, nb_range=(2, 5)):
     """Synthetic entanglement inputs for a scene: for ~frac of the agent
     pairs one active case, 2-4 bend points per agent (bend[0] is the base, neptune_ros.cpp:453-457).
     Returns case_id [N][NEP_MAX_POL][N] (row a = the block agent a+1 hands to the back end: the
@@ -454,7 +454,7 @@ def synthetic_entangle(sc, seed, frac=0.1):
     p = sc["par"]; N = p.num_agents
     com = sc["committed"]
     for j in range(N):
-        nb = int(rng.integers(2, 5))
+        nb = int(rng.integers(nb_range[0], nb_range[1]))
         com[j]["n_bend"] = nb
         com[j]["bend"][0] = p.pb[j]
         for b in range(1, nb):

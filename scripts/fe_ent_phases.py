@@ -13,6 +13,8 @@ from neptune_amd.backend import BatchBackend
 def main():
     S = int(sys.argv[1]) if len(sys.argv) > 1 else 2
     scs = [scene.make_scene(256, 100, seed=s) for s in range(S)]
+    if os.environ.get("NEP_SCRIPT_BENDS"):      # the bench's config-5 inputs: 2-4 bend points per tether (scene.synthetic_entangle)
+        for k_, m_ in enumerate(scs): scene.synthetic_entangle(m_, seed=1000 + k_, frac=0.1)
     p = dataclasses.replace(scs[0]["par"], enable_entangle=True)
     be = BatchBackend(p, scs[0]["statics"], n_scenes=S)
     for s in range(S):
@@ -41,6 +43,7 @@ def main():
     pn = ["agent loop", "static loop", "merge + counts", "update bends", "tether + rest"]
     npr = rows[:, 21].sum(); tp = rows[:, 16:21].sum()
     print("propagations per search %.0f (%.1f %% of them with a crossing in some step); cycles per propagation %.0f (summed over all threads)" % (rows[:, 21].mean(), 100.0 * rows[:, 22].sum() / max(npr, 1), tp / max(npr, 1)))
+    print("   agents visited per propagation (all sampled steps): %.1f; cycles of the agent loop per visit: %.0f" % (rows[:, 31].sum() / max(npr, 1), rows[:, 16].sum() / max(rows[:, 31].sum(), 1)))
     for k, n in enumerate(pn):
         print("   %-24s %10.0f per propagation  %5.1f %%" % (n, rows[:, 16 + k].sum() / max(npr, 1), 100.0 * rows[:, 16 + k].sum() / max(tp, 1)))
     for k, n in enumerate(["merge: ids of the new list", "merge: scans", "merge: erase + re-anchor", "merge: append", "merge: counts"]):

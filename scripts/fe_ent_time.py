@@ -12,6 +12,8 @@ def main():
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
     N = 256
     made = scene.make_scenes(N, 100, range(S), workers=min(S, 32))
+    if os.environ.get("NEP_SCRIPT_BENDS"):      # the bench's config-5 inputs: 2-4 bend points per tether (scene.synthetic_entangle)
+        for k_, m_ in enumerate(made): scene.synthetic_entangle(m_, seed=1000 + k_, frac=0.1)
     p = dataclasses.replace(made[0]["par"], enable_entangle=True)
     be = BatchBackend(p, made[0]["statics"], n_scenes=S)
     for s in range(S):

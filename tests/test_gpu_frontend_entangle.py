@@ -43,12 +43,16 @@ def _run_frontend(be, sc, W, inits=None, fast_caps=None, big_records=None):
     return bb, fe, starts, d_com, d_g, d_g.cpu().numpy().view(abi.GUESS_DTYPE), d_r.cpu().numpy().view(abi.FE_RESULT_DTYPE), d_case, d_case.cpu().numpy().reshape(N, abi.NEP_MAX_POL, N)
 
 
-@pytest.mark.parametrize("n_agents,n_static,seed,W,stride", [(8, 6, 60, 16, 1), (8, 6, 56, 32, 1), (16, 8, 61, 16, 1),
-                                                             (72, 40, 63, 16, 6),       # (more than one 32-bit word of agents and of statics in the kernel's per-parent masks; every sixth agent against the oracle)
-                                                             (5, 0, 64, 64, 1),         # (round 4: the widest beam — per-rank arrays at 64 — in a scene too small for the LDS aliasing of the winners' f values)
-                                                             (16, 8, 65, 48, 2)])
-def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_static, seed, W, stride):
+@pytest.mark.parametrize("n_agents,n_static,seed,W,stride,bends", [(8, 6, 60, 16, 1, 0), (8, 6, 56, 32, 1, 0), (16, 8, 61, 16, 1, 0),
+                                                                   (72, 40, 63, 16, 6, 0),       # (more than one 32-bit word of agents and of statics in the kernel's per-parent masks; every sixth agent against the oracle)
+                                                                   (5, 0, 64, 64, 1, 0),         # (round 4: the widest beam — per-rank arrays at 64 — in a scene too small for the LDS aliasing of the winners' f values)
+                                                                   (16, 8, 65, 48, 2, 0),
+                                                                   (16, 8, 66, 16, 1, 1), (24, 10, 67, 32, 2, 1),      # (tethers with 2-4 bend points, as the bench's config-5 inputs have them: the multi-segment paths of the masks and of the crossing test)
+                                                                   (12, 4, 68, 16, 1, 2)])                             # (5-8 bend points: beyond what those paths keep in registers)
+def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents, n_static, seed, W, stride, bends):
     sc = scene.tether_crossing_scene(n_agents, n_static, seed)
+    if bends:
+        scene.synthetic_entangle(sc, seed=900 + seed, frac=0.1, nb_range=(2, 5) if bends == 1 else (5, 9))
     p = sc["par"]; N = n_agents
     rng = np.random.default_rng(seed)
     inits = np.zeros(N, dtype=abi.FE_ENT_STATE_DTYPE)           # some searches start with a crossing already on the list
