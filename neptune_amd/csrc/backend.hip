@@ -220,8 +220,10 @@ struct Engine {
     // (development aids, read here once and not per replan: NEP_SEP_UNPACKED, NEP_SEP_PACK=n — see nep_batch_debug_set_separator_pack)
     if (getenv("NEP_SEP_UNPACKED")) sep_pack = -1;
     else if (const char* f = getenv("NEP_SEP_PACK")) { const int v = atoi(f); if (v >= 1 && v <= NEP_MAX_POL) sep_pack = v; }
-    if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; if (int e = d_order_key.ensure((size_t)slots)) return e; hipMemset(d_order_key.p, 0, (size_t)slots * sizeof(int)); }
-    if (lpt) { if (int e = d_fe_order.ensure((size_t)slots)) return e; if (int e = d_fe_order_key.ensure((size_t)slots)) return e; hipMemset(d_fe_order_key.p, 0, (size_t)slots * sizeof(int)); }
+    // (the keys remember — a new key is the maximum of the measured bin and the old key less a decay — so a fresh buffer starts at zero;
+    // only a fresh one: the per-agent handle sizes its scratch on every replan and a memset there was 30 us of its 100)
+    if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; const int* was = d_order_key.p; if (int e = d_order_key.ensure((size_t)slots)) return e; if (d_order_key.p != was) hipMemset(d_order_key.p, 0, d_order_key.n * sizeof(int)); }
+    if (lpt) { if (int e = d_fe_order.ensure((size_t)slots)) return e; const int* was = d_fe_order_key.p; if (int e = d_fe_order_key.ensure((size_t)slots)) return e; if (d_fe_order_key.p != was) hipMemset(d_fe_order_key.p, 0, d_fe_order_key.n * sizeof(int)); }
     if (int e = d_fe_us.ensure((size_t)slots)) return e;
     choose_placement();
     rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
@@ -1287,6 +1289,11 @@ int nep_batch_set_launch_order(nep_batch_t* h, int32_t enable) {
   if (enable) { if (int e = h->eng.d_order.ensure((size_t)h->slots)) return e; if (int e = h->eng.d_order_key.ensure((size_t)h->slots)) return e; }
   if (enable) { if (int e = h->eng.d_fe_order.ensure((size_t)h->slots)) return e; if (int e = h->eng.d_fe_order_key.ensure((size_t)h->slots)) return e; }
   if (!enable) { h->eng.have_history = false; h->eng.fe_history = false; }
+  if (enable && !h->eng.lpt) {      // (the keys remember: switched on, they start from zero)
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemset(h->eng.d_order_key.p, 0, h->eng.d_order_key.n * sizeof(int))); HIPCHK(hipMemset(h->eng.d_fe_order_key.p, 0, h->eng.d_fe_order_key.n * sizeof(int)));
+    h->eng.have_history = false; h->eng.fe_history = false;
+  }
   h->eng.lpt = enable != 0;
   return 0;
 }

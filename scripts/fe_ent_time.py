@@ -54,7 +54,9 @@ def main():
                 print("         simulated makespan on 768 slots, %s: %.2f ms (sum / 768 = %.2f ms)" % (name, makespan(order) / 1e3, us.sum() / 768e3))
         us_prev2 = us_prev.copy() if r > 0 else us.copy(); us_prev = us.copy(); us_max = np.maximum(us_max, us) if r > 0 else us.copy()
         be.replan(None, d_g, d_ent=d_case)
-        be.safety_commit_ent(d_c, be.d_commit, d_g, d_nx, d_ac)
+        e2 = torch.cuda.Event(enable_timing=True); e3 = torch.cuda.Event(enable_timing=True)
+        e2.record(); be.safety_commit_ent(d_c, be.d_commit, d_g, d_nx, d_ac); e3.record(); torch.cuda.synchronize()
+        print("         safety pass with the entangle re-check: %.3f ms; accepted %d" % (e2.elapsed_time(e3), int(d_ac.sum().item())), flush=True)
         d_c.copy_(d_nx)
 
 
