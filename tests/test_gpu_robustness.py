@@ -194,6 +194,34 @@ def test_wall_clock_time_limit(be, oracle):
     bb.close()
 
 
+def test_front_end_launch_order_does_not_change_results(be):
+    """The front end's searches are started longest-expected-first, a few whole scenes per XCD (order_xcd_kernel; the key remembers
+    the slot's earlier search times): a scheduling matter — guesses and results of the ordered launches (first: XCD placement alone,
+    then with the keys) equal those of the slot-order launch byte for byte, and every search reports its device time."""
+    scs = [scene.make_scene(64, 20, seed=s) for s in (0, 1, 2)]
+    S = 24                                                        # 1 536 searches: more than one wave of workgroups, a multiple of 8
+    p = scs[0]["par"]
+    bb = be.BatchBackend(p, scs[0]["statics"], n_scenes=S)
+    for s in range(1, S):
+        bb.set_scene_statics(s, scs[s % 3]["statics"])
+    T = bb.torch
+    d_com = bb.to_device(np.stack([scs[s % 3]["committed"] for s in range(S)])); d_st = bb.to_device(np.stack([scene.frontend_starts(scs[s % 3]) for s in range(S)]))
+    fe = scene.frontend_cfg(p, beam_width=32, pad_hold=1)
+    d_g = T.zeros(S * 64 * abi.GUESS_DTYPE.itemsize, dtype=T.uint8, device=bb.device); d_r = T.zeros(S * 64 * abi.FE_RESULT_DTYPE.itemsize, dtype=T.uint8, device=bb.device)
+    outs = []
+    for k in range(4):
+        if k == 3:
+            bb.set_launch_order(False)
+        d_g.zero_(); d_r.zero_()
+        bb.frontend(fe, d_com, d_st, d_g, d_r); T.cuda.synchronize()
+        outs.append((d_g.cpu().numpy().tobytes(), d_r.cpu().numpy().tobytes()))
+        if k < 3:
+            us = bb.fe_search_us()
+            assert (us > 0).all() and us.max() < 1e5
+    assert outs[0] == outs[3] and outs[1] == outs[3] and outs[2] == outs[3]
+    bb.close()
+
+
 def test_launch_order_does_not_change_results(be):
     """nep_batch_set_launch_order: from a handle's second replan on, the QP workgroups of a batch of more than 1 024 replans are
     launched longest-expected-first (the previous replan's measured device time is the key).  A scheduling matter: the
