@@ -2496,9 +2496,10 @@ void launch_ent_sample(const nep_traj_rec* recs, int n_scenes, int N, const doub
 __global__ __launch_bounds__(64) void ent_check_kernel(SceneParams sp, ProblemSet ps, FeEntArgs ea, const nep_traj_rec* __restrict__ fresh, int n_scenes, double cable, int* __restrict__ entangles) {
   // one wave per trajectory: the lanes first prove, 64 obstacles at a time, who cannot add a crossing anywhere along the sampled
   // interval (ent_agent_may_cross against the box of the samples), then lane 0 walks the reference's test over the rest
-  extern __shared__ unsigned m_ec[];
+  extern __shared__ __attribute__((aligned(16))) unsigned m_ec[];
   const int N = sp.num_agents, S = sp.n_static, lane = threadIdx.x;
   unsigned* m_agent = m_ec; unsigned* m_static = m_ec + ((N + 63) >> 6) * 2;
+  const int ec_lds_words = 2 * (((N + 63) >> 6) + ((S + 63) >> 6) + 1);      // (the masks: launch_ent_check sizes the same; an even number of words, so that the record behind them is 8-byte aligned)
   const long idx = blockIdx.x;
   const int scene = (int)(idx / N), a = (int)(idx % N);
   const nep_traj_rec* r = fresh + idx;
@@ -2533,7 +2534,9 @@ __global__ __launch_bounds__(64) void ent_check_kernel(SceneParams sp, ProblemSe
   __syncthreads();
   if (lane == 0) {
     ec.m_agent = m_agent; ec.m_static = m_static;
-    nep_fe_ent_state* wk = ea.work + idx;
+    // (the working record in LDS: lane 0's list surgery is a chain of dependent reads and writes of this record — in global memory
+    // every one of them was a round trip)
+    nep_fe_ent_state* wk = (nep_fe_ent_state*)(m_ec + ec_lds_words);
     if (ea.init) ent_copy(wk, ea.init + idx); else { long* z = (long*)wk; for (int i = 0; i < (int)(sizeof(nep_fe_ent_state) / 8); i++) z[i] = 0; }
     double arc = 0.0;
     unsigned add_tail[kEntAddCap - EntAdd::reg];
@@ -2552,7 +2555,7 @@ __global__ __launch_bounds__(64) void ent_check_kernel(SceneParams sp, ProblemSe
 void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntArgs& ea, const nep_traj_rec* fresh, int n_scenes, double cable, int* entangles, hipStream_t st) {
   const long total = (long)n_scenes * sp.num_agents;
   if (total <= 0) return;
-  const size_t lds = sizeof(unsigned) * 2 * (size_t)(((sp.num_agents + 63) >> 6) + ((sp.n_static + 63) >> 6) + 1);
+  const size_t lds = sizeof(unsigned) * 2 * (size_t)(((sp.num_agents + 63) >> 6) + ((sp.n_static + 63) >> 6) + 1) + sizeof(nep_fe_ent_state);
   hipLaunchKernelGGL(ent_check_kernel, dim3((int)total), dim3(64), lds, st, sp, ps, ea, fresh, n_scenes, cable, entangles);
 }
 
