@@ -1232,6 +1232,9 @@ int nep_batch_safety_commit_ent(nep_batch_t* h, const nep_traj_rec* d_prev, cons
   FeEntArgs ea{};
   if (int e = ent_prepare(h, ent_samples, 0, d_new, &d_guess->t_start, (long)sizeof(nep_guess) * E.sp.n_local, ea, (hipStream_t)stream)) return e;
   ea.init = d_ent_init;
+  ea.pk_stride = 2 + 2 * kBend + 2 * (ea.ns + 1);
+  if (int e = E.d_fe_packed.ensure((size_t)h->cfg.n_scenes * N * h->cfg.num_pol * ea.pk_stride)) return e;
+  ea.packed = E.d_fe_packed.p;
   launch_hulls(d_new, h->cfg.n_scenes, N, d_guess, E.sp, ps, (hipStream_t)stream);     // (with the bend points: ent_enabled)
   launch_ent_check(E.sp, ps, ea, d_new, h->cfg.n_scenes, cable_length, E.d_entangles.p, (hipStream_t)stream);
   launch_safety(d_prev, d_new, h->cfg.n_scenes, N, E.sp, ps, E.d_conflict.p, E.safety_check_prev ? E.d_conflict_prev.p : nullptr, E.d_entangles.p, d_final, d_accept, (hipStream_t)stream);

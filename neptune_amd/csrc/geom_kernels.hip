@@ -2509,6 +2509,7 @@ __global__ __launch_bounds__(64) void ent_check_kernel(SceneParams sp, ProblemSe
   ec.pb = ps.pb; ec.srep = ea.srep + (long)scene * sp.static_stride * 4; ec.slong = ea.slong + (long)scene * sp.static_stride * 2;
   ec.sampled = ea.sampled; ec.present = ea.present;
   ec.ps = &ps; ec.scene = scene; ec.n_hull = sp.n_hull;
+  ec.packed = ea.packed; ec.pk_stride = ea.pk_stride;      // (one record per (agent, interval), launch_ent_check: every visit one round trip instead of a chain through the hull tables)
   const double* cx0 = r->pwp.coeff[0][0]; const double* cy0 = r->pwp.coeff[1][0];
   const double T = sp.T_span;
   const Ev2 end{((cx0[0] * (T * T * T) + cx0[1] * (T * T)) + cx0[2] * T) + cx0[3] * 1.0, ((cy0[0] * (T * T * T) + cy0[1] * (T * T)) + cy0[2] * T) + cy0[3] * 1.0};
@@ -2521,7 +2522,7 @@ __global__ __launch_bounds__(64) void ent_check_kernel(SceneParams sp, ProblemSe
   bx.x0 -= 1e-9; bx.x1 += 1e-9; bx.y0 -= 1e-9; bx.y1 += 1e-9;
   for (int j0 = 0; j0 < N; j0 += 64) {
     const int j = j0 + lane;
-    const bool may = j < N && j != a && ent_agent_may_cross(ec, bx, j, 0);
+    const bool may = j < N && j != a && (ec.packed ? (ent_agent_fbits_pk(ec, j, 0) != 0u || ent_agent_may_cross_pk(ec, bx, j, 0)) : ent_agent_may_cross(ec, bx, j, 0));
     const unsigned long long bal = __ballot(may);
     if (lane == 0) { m_agent[j0 >> 5] = (unsigned)bal; if (j0 + 32 < N) m_agent[(j0 >> 5) + 1] = (unsigned)(bal >> 32); }
   }
@@ -2556,6 +2557,10 @@ void launch_ent_check(const SceneParams& sp, const ProblemSet& ps, const FeEntAr
   const long total = (long)n_scenes * sp.num_agents;
   if (total <= 0) return;
   const size_t lds = sizeof(unsigned) * 2 * (size_t)(((sp.num_agents + 63) >> 6) + ((sp.n_static + 63) >> 6) + 1) + sizeof(nep_fe_ent_state);
+  if (ea.packed && ea.ns <= 8) {      // the packed records of the NEW trajectories (the re-check reads interval 0 only; the kernel packs them all: 10 us)
+    const long np_ = (long)n_scenes * sp.num_agents * sp.num_pol;
+    hipLaunchKernelGGL(ent_pack_kernel, dim3((unsigned)((np_ + 255) / 256)), dim3(256), 0, st, sp, ps, ea, n_scenes);
+  }
   hipLaunchKernelGGL(ent_check_kernel, dim3((int)total), dim3(64), lds, st, sp, ps, ea, fresh, n_scenes, cable, entangles);
 }
 
