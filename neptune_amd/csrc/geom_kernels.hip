@@ -1977,6 +1977,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
     // the children reach it, so examined in place the threads that drew two or three survivors kept the others waiting (pass 1 was
     // 65 % of a config-5 search, its critical path three propagations per depth instead of one).
     unsigned short* p_list = r_id;      // (the GJK work list has been consumed when the survivors are listed; the winners are compacted after the propagation)
+    const int n_lists_a = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2 + (rf_alias ? 0 : kFeCap))) / kEntLdsBytes);      // crossing lists the borrowed storage holds (o_aabb, o_V, r_f when it has storage of its own)
     auto settle_voxel = [&](int id, FeChild& ch, unsigned iz) {
       const long long vox = ENT ? (long long)(((unsigned long long)(unsigned short)ch.vx << 48) | ((unsigned long long)(unsigned short)ch.vy << 32) | iz)
                                 : (((long long)ch.vx << 32) | (unsigned int)ch.vy);
@@ -2019,7 +2020,10 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       EntLds L;
       {
         typedef __attribute__((address_space(3))) unsigned char* lds_bytes;
-        const lds_bytes base = (lds_bytes)(unsigned)(size_t)(ent_lists + tid * kEntLdsBytes);      // (the low 32 bits of a generic LDS address are the LDS offset)
+        // (threads beyond the borrowed storage's n_lists_a lists keep theirs in the depth's voxel table, which is dead — all -1 — until the
+        // voxel pass after the propagation and is cleared again before it: 163 instead of 132 survivors per round at config 5, and a
+        // depth's ~140 survivors are one round instead of two)
+        const lds_bytes base = (lds_bytes)(unsigned)(size_t)(tid < n_lists_a ? ent_lists + tid * kEntLdsBytes : (unsigned char*)d_slot + (tid - n_lists_a) * kEntLdsBytes);      // (the low 32 bits of a generic LDS address are the LDS offset)
         L.id = (ent_lds_short)base; L.cs = (ent_lds_char)(base + 2 * NEP_FE_ENT_CAP); L.bend = (ent_lds_char)(base + 3 * NEP_FE_ENT_CAP); L.beta = my_work->beta;
         L.cap = ea.fast_cap; L.bend_cap = ea.fast_bend;
         if constexpr (BIG) {
@@ -2165,7 +2169,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         __syncthreads();
       }
       const int n_prop = s_i[3];
-      int n_merge = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2 + (rf_alias ? 0 : kFeCap))) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS (o_aabb, o_V and, when it has storage of its own, r_f)
+      int n_merge = n_lists_a + (int)((sizeof(int) * (size_t)kFeDd) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS (o_aabb, o_V and, when it has storage of its own, r_f; the voxel table)
       if (n_merge > 256) n_merge = 256;
       if constexpr (BIG) { if (ea.big_lds_off) n_merge = 256; }      // (lists of their own)
       { const int rounds = (n_prop + n_merge - 1) / n_merge; if (rounds > 1) n_merge = (n_prop + rounds - 1) / rounds; }      // (even rounds: 178 survivors are 89 + 89, not 131 + 47)
@@ -2173,6 +2177,8 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         if (tid < n_merge && b0 + tid < n_prop) propagate(p_list[b0 + tid]);
         __syncthreads();
       }
+      for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;     // (lent to the lists above)
+      __syncthreads();
       if constexpr (BIG) {
         if (s_i[11] != 0) {                                      // children the fixed record could not carry
           for (int w = tid; w < n_prop; w += 256) { const int id = p_list[w]; if (s_state[id] == 5) propagate_big(id); }
