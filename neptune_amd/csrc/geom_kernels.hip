@@ -1978,12 +1978,14 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
     // 65 % of a config-5 search, its critical path three propagations per depth instead of one).
     unsigned short* p_list = r_id;      // (the GJK work list has been consumed when the survivors are listed; the winners are compacted after the propagation)
     const int n_lists_a = (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2 + (rf_alias ? 0 : kFeCap))) / kEntLdsBytes);      // crossing lists the borrowed storage holds (o_aabb, o_V, r_f when it has storage of its own)
+    const int n_lists_b = (int)((sizeof(int) * (size_t)kFeDd) / kEntLdsBytes), n_lists_c = (int)((sizeof(double) * (size_t)kFeCap) / kEntLdsBytes);      // ... the voxel table; s_f, and s_vox as many again
     auto settle_voxel = [&](int id, FeChild& ch, unsigned iz) {
       const long long vox = ENT ? (long long)(((unsigned long long)(unsigned short)ch.vx << 48) | ((unsigned long long)(unsigned short)ch.vy << 32) | iz)
                                 : (((long long)ch.vx << 32) | (unsigned int)ch.vy);
       bool seen = false;
       for (unsigned h = fe_hash(vox) & (kFeVis - 1);; h = (h + 1) & (kFeVis - 1)) { const unsigned long long k = v_key[h]; if (k == (unsigned long long)vox) { seen = true; break; } if (k == kFeEmpty) break; }
-      if (!seen) { s_f[id] = ch.f; s_vox[id] = vox; }
+      if constexpr (ENT) { if (!seen) { ea.st_f[(long)slot * kFeCap + id] = ch.f; ea.st_vox[(long)slot * kFeCap + id] = vox; } }      // (parked in global memory: s_f and s_vox are lent to the crossing lists during the propagation pass and filled after it)
+      else { if (!seen) { s_f[id] = ch.f; s_vox[id] = vox; } }
       s_state[id] = seen ? 0 : 1;
     };
     auto settle = [&](int id, FeChild& ch) {       // collision free: closed voxel?  else alive
@@ -2023,7 +2025,12 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         // (threads beyond the borrowed storage's n_lists_a lists keep theirs in the depth's voxel table, which is dead — all -1 — until the
         // voxel pass after the propagation and is cleared again before it: 163 instead of 132 survivors per round at config 5, and a
         // depth's ~140 survivors are one round instead of two)
-        const lds_bytes base = (lds_bytes)(unsigned)(size_t)(tid < n_lists_a ? ent_lists + tid * kEntLdsBytes : (unsigned char*)d_slot + (tid - n_lists_a) * kEntLdsBytes);      // (the low 32 bits of a generic LDS address are the LDS offset)
+        // (and then in s_f and s_vox, whose contents — f and voxel of the children that survive this pass — are parked in global memory
+        // until the pass is over: 259 lists at config 5, every depth one round)
+        const lds_bytes base = (lds_bytes)(unsigned)(size_t)(tid < n_lists_a ? ent_lists + tid * kEntLdsBytes
+                                                            : tid < n_lists_a + n_lists_b ? (unsigned char*)d_slot + (tid - n_lists_a) * kEntLdsBytes
+                                                            : tid < n_lists_a + n_lists_b + n_lists_c ? (unsigned char*)s_f + (tid - n_lists_a - n_lists_b) * kEntLdsBytes
+                                                            : (unsigned char*)s_vox + (tid - n_lists_a - n_lists_b - n_lists_c) * kEntLdsBytes);      // (the low 32 bits of a generic LDS address are the LDS offset)
         L.id = (ent_lds_short)base; L.cs = (ent_lds_char)(base + 2 * NEP_FE_ENT_CAP); L.bend = (ent_lds_char)(base + 3 * NEP_FE_ENT_CAP); L.beta = my_work->beta;
         L.cap = ea.fast_cap; L.bend_cap = ea.fast_bend;
         if constexpr (BIG) {
@@ -2169,7 +2176,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         __syncthreads();
       }
       const int n_prop = s_i[3];
-      int n_merge = n_lists_a + (int)((sizeof(int) * (size_t)kFeDd) / kEntLdsBytes);      // threads whose lists fit the borrowed LDS (o_aabb, o_V and, when it has storage of its own, r_f; the voxel table)
+      int n_merge = n_lists_a + n_lists_b + 2 * n_lists_c;      // threads whose lists fit the borrowed LDS (o_aabb, o_V and, when it has storage of its own, r_f; the voxel table; s_f and s_vox)
       if (n_merge > 256) n_merge = 256;
       if constexpr (BIG) { if (ea.big_lds_off) n_merge = 256; }      // (lists of their own)
       { const int rounds = (n_prop + n_merge - 1) / n_merge; if (rounds > 1) n_merge = (n_prop + rounds - 1) / rounds; }      // (even rounds: 178 survivors are 89 + 89, not 131 + 47)
@@ -2178,13 +2185,15 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         __syncthreads();
       }
       for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;     // (lent to the lists above)
-      __syncthreads();
+      __syncthreads();                                           // (nobody reads a list any more)
       if constexpr (BIG) {
         if (s_i[11] != 0) {                                      // children the fixed record could not carry
           for (int w = tid; w < n_prop; w += 256) { const int id = p_list[w]; if (s_state[id] == 5) propagate_big(id); }
           __syncthreads();
         }
       }
+      for (int id = tid; id < n_c; id += 256) if (s_state[id] == 1) { s_f[id] = ea.st_f[(long)slot * kFeCap + id]; s_vox[id] = ea.st_vox[(long)slot * kFeCap + id]; }      // (back from where settle_voxel parked them)
+      __syncthreads();
       FE_TICK(1);
     }
     // ---- one node per voxel: the best (f, id) claims the voxel's slot; whoever is displaced or beaten is out ----

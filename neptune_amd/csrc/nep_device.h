@@ -177,6 +177,7 @@ struct FeEntArgs {
   nep_fe_ent_state* work;        // [scenes * N] one working record per thread of ent_check_kernel
   nep_fe_ent_state* saved;       // [slots][children cap] the state every surviving child of the depth at hand arrived with (frontend_children_cap)
   double* saved_arc;             // [slots][children cap] and its sampled arc length
+  double* st_f; long long* st_vox;      // [slots][children cap] f and voxel key of the children that survive the propagation pass: parked here while the LDS arrays that hold them (s_f, s_vox) are lent to the crossing lists
   int* case_out;                 // [slots][NEP_MAX_POL][N] (out) or null
   int ns;                        // num_sample_per_interval
   double* packed;                // [scenes][N][num_pol][pk_stride] one record per (agent, interval) of what the check reads (ent_pack_kernel), or null
