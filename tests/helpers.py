@@ -78,3 +78,31 @@ def ent_inputs(sc, a, num_samples=3, init=None, recs=None, t0=None):
         present[j] = 1
     reps, longest = scene.static_reps(sc["statics"]) if len(sc["statics"]) else (np.zeros((0, 2, 2)), np.zeros((0, 2)))
     return dict(num_samples=num_samples, reps=reps, longest=longest, sampled=sampled, present=present, bend_n=bend_n, bend_xy=bend_xy, init=init)
+
+
+def bundle_scene(n_agents, a, t_range, P=(-20.0, -1.0), Q=(20.0, 1.0)):
+    """Every other agent hovers where its tether (base -> hover point) crosses agent a's straight path P -> Q at a point of its own,
+    the crossing points spread over the fraction t_range of the path: a bundle of n_agents - 1 tethers to fly through (sc["bundle"] = P, Q)."""
+    from neptune_amd import abi, scene
+    import dataclasses
+    sc = scene.make_scene(n_agents, 0, seed=77, separation="aabb")
+    p = dataclasses.replace(sc["par"], enable_entangle=True, tether_length=1000.0)
+    sc["par"] = p
+    P = np.array(P, dtype=np.float64); Q = np.array(Q, dtype=np.float64); K = abi.NEP_MAX_POL; T = p.T_span
+    g = sc["guesses"][a]
+    g["K"] = K; g["coeff"][:, :, :] = 0
+    v = (Q - P) / (K * T)
+    for i in range(K):
+        for ax in range(2):
+            g["coeff"][ax][i][2] = v[ax]; g["coeff"][ax][i][3] = P[ax] + v[ax] * i * T
+    others = [j for j in range(n_agents) if j != a]
+    for k, j in enumerate(others):
+        t = t_range[0] + (t_range[1] - t_range[0]) * k / len(others)      # (a sampled step of the guess covers 1/24 of the path)
+        M = P + t * (Q - P)
+        pos = 2 * M - np.asarray(p.pb[j])
+        com = sc["committed"][j]; n = int(com["pwp"]["n_seg"])
+        com["pwp"]["coeff"][:, :, :] = 0
+        com["pwp"]["coeff"][0, :n, 3] = pos[0]; com["pwp"]["coeff"][1, :n, 3] = pos[1]; com["pwp"]["coeff"][2, :n, 3] = 1.0
+        com["pos"][:2] = pos
+    sc["bundle"] = (P, Q)
+    return sc

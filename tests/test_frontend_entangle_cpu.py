@@ -105,39 +105,13 @@ def test_entangle_check_of_a_new_trajectory(oracle):
     assert hits >= 0
 
 
-def _bundle_scene(n_agents, a, spread):
-    """Every other agent hovers where its tether (base -> hover point) crosses agent a's straight path at a point of its own:
-    a bundle of n_agents - 1 tethers to fly through — spread over the whole path, or all of them inside the first sampled step."""
-    import dataclasses
-    sc = scene.make_scene(n_agents, 0, seed=77, separation="aabb")
-    p = dataclasses.replace(sc["par"], enable_entangle=True, tether_length=1000.0)
-    sc["par"] = p
-    P = np.array([-20.0, -1.0]); Q = np.array([20.0, 1.0]); K = abi.NEP_MAX_POL; T = p.T_span
-    g = sc["guesses"][a]
-    g["K"] = K; g["coeff"][:, :, :] = 0
-    v = (Q - P) / (K * T)
-    for i in range(K):
-        for ax in range(2):
-            g["coeff"][ax][i][2] = v[ax]; g["coeff"][ax][i][3] = P[ax] + v[ax] * i * T
-    others = [j for j in range(n_agents) if j != a]
-    for k, j in enumerate(others):
-        t = (0.05 + 0.9 * k / len(others)) if spread else (0.002 + 0.03 * k / len(others))      # (the first sampled step covers 1/24 of the path)
-        M = P + t * (Q - P)
-        pos = 2 * M - np.asarray(p.pb[j])
-        com = sc["committed"][j]; n = int(com["pwp"]["n_seg"])
-        com["pwp"]["coeff"][:, :, :] = 0
-        com["pwp"]["coeff"][0, :n, 3] = pos[0]; com["pwp"]["coeff"][1, :n, 3] = pos[1]; com["pwp"]["coeff"][2, :n, 3] = 1.0
-        com["pos"][:2] = pos
-    return sc
-
-
 def test_no_capacity_but_the_references_rule(oracle):
     """The oracle's entangle state has no capacity of its own (round 4; the device's fixed record of 40 crossings / 32 new ones per
     sampled step is backed by big records): flying through a bundle of 59 tethers leaves 59 crossings on the list — spread over the
     path, or 59 of them in ONE sampled step — exactly as the Python restatement of the same reference lines has them; one tether
     more than num_agents + statics allows is the reference's own pruning rule (kinodynamic_search.cpp:850-854)."""
     for spread in (True, False):
-        sc = _bundle_scene(60, 7, spread)
+        sc = helpers.bundle_scene(60, 7, (0.05, 0.95) if spread else (0.002, 0.032))
         p = sc["par"]; g = sc["guesses"][7]
         ent = helpers.ent_inputs(sc, 7)
         case_c, hit_c, n_alpha = oracle.ent_propagate_guess(p, 8, p.tether_length, g, ent)

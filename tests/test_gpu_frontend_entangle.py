@@ -131,6 +131,41 @@ def test_big_records_carry_what_the_fixed_record_cannot(be, oracle, fast_caps):
         assert int(got[6][a]["n_entangled"]) == res["n_entangled"] and res["ent_overflow"] == 0
 
 
+def test_a_bundle_of_tethers_needs_big_records_at_the_default_limits(be, oracle):
+    """No test knob: agent 7 starts in front of a bundle of 59 tethers that cross its way within a third of a metre, so its first
+    sampled steps add more than 32 crossings at once and its nodes carry more than 40 — the fixed record's limits.  The search is
+    listed, run again on big records, and equals the oracle (which has no capacity) bit for bit; nothing is flagged."""
+    a = 7
+    sc = helpers.bundle_scene(60, a, (0.004, 0.03), P=(-6.0, -0.5), Q=(6.0, 0.5))
+    p = sc["par"]; N = 60
+    P, Q = sc["bundle"]
+    fe = scene.frontend_cfg(p, beam_width=16, entangle=True)
+    bb = be.BatchBackend(p, sc["statics"])
+    bb.set_static_reps(np.zeros((0, 2, 2)), np.zeros((0, 2)))
+    T = bb.torch
+    starts = scene.frontend_starts(sc)
+    d = (Q - P) / np.linalg.norm(Q - P)
+    starts[a]["pos"][:2] = P; starts[a]["vel"][:2] = 1.5 * d; starts[a]["accel"][:2] = 0.0; starts[a]["goal"][:2] = Q
+    d_g = T.zeros(N * abi.GUESS_DTYPE.itemsize, dtype=T.uint8, device=bb.device)
+    d_r = T.zeros(N * abi.FE_RESULT_DTYPE.itemsize, dtype=T.uint8, device=bb.device)
+    d_case = T.zeros(N * abi.NEP_MAX_POL * N, dtype=T.int32, device=bb.device)
+    bb.frontend_ent(fe, bb.to_device(sc["committed"]), bb.to_device(starts), d_g, d_r, d_case)
+    T.cuda.synchronize()
+    got_g = d_g.cpu().numpy().view(abi.GUESS_DTYPE); got_r = d_r.cpu().numpy().view(abi.FE_RESULT_DTYPE); got_case = d_case.cpu().numpy().reshape(N, abi.NEP_MAX_POL, N)
+    bb.close()
+    assert (got_r["ent_overflow"] == 0).all()
+    assert int(got_r[a]["_pad"]) >> 8 > 0, "agent 7's search was expected to need big records"
+    for b in (a, 0, 30):
+        hx, hn = oracle.hulls_of_scene(p, b + 1, sc["committed"], float(starts[b]["t_start"]), sc["statics"])
+        ent = helpers.ent_inputs(sc, b, t0=float(starts[b]["t_start"]))
+        g, res, case = oracle.frontend_beam_ent(p, fe, b + 1, starts[b], hx, hn, sc["statics"], ent)
+        np.testing.assert_array_equal(np.array(got_g[b]["coeff"]), np.array(g["coeff"]), err_msg="agent %d" % b)
+        for f in ("status", "K", "n_children", "n_feasible", "n_collision_free", "n_entangled", "ent_overflow"):
+            assert int(got_r[b][f]) == res[f], (b, f, int(got_r[b][f]), res[f])
+        np.testing.assert_array_equal(got_case[b], case)
+    assert int((got_case[a] != 0).sum()) > 40 * 2       # (more than 40 active cases along agent 7's plan)
+
+
 def test_an_exhausted_pool_of_big_records_is_flagged(be):
     """nep_fe_result.ent_overflow: the only capacity left is the pool itself — a child that finds it empty is pruned and
     the search says so (bit 3 of _pad)."""
