@@ -592,10 +592,11 @@ __device__ __forceinline__ EntAddBig::Store ent_big_add(const EntBigPool& P, int
   return EntAddBig::Store{(unsigned*)r, (unsigned*)(r + 4 * P.add_lim), P.add_lim};
 }
 __device__ __forceinline__ void ent_big_close(const EntBigPool& P, int k, const EntBig& B) { int* h = (int*)(P.base + (size_t)k * P.rec_bytes); h[0] = B.n_alpha; h[1] = B.n_bend; }
-// One child in the big form (frontend_kernel<true>: a child of a big node, or one whose fast-path propagation ran into a capacity):
-// claim a record, copy the parent's state into it (fixed or big), propagate.  Returns ent_propagate's verdict (0 / 1) or 5 = the pool
-// is exhausted (pruned and flagged: nep_fe_result.ent_overflow).  The callers keep it out of their hot loops (a pass of its own behind
-// a flag): as a called function its frame and the registers saved around the call cost the fixed record's path a third of its speed.
+// One child in the big form (ent_big_child, at the end of this header; used by frontend_kernel<true, 1, true> — the instantiation that
+// re-runs the searches the plain one lists — and by ent_check_kernel): claim a record, copy the parent's state into it (fixed or big),
+// propagate.  rc = ent_propagate's verdict (0 / 1), or 5 = the pool is exhausted (pruned and flagged: nep_fe_result.ent_overflow,
+// NEP_FLAG_ENT_POOL).  It is kept out of the search every slot runs: compiled into it — inlined as a pass of its own behind a flag, or
+// as a called function — it cost that search's fixed-record path a third of its speed (geom_kernels.hip, frontend_kernel).
 struct EntBigOut { int rc, k, n_alpha, n_bend; unsigned iz; double arc; };
 
 template <class ST> __device__ unsigned ent_iz(const ST* st) {
