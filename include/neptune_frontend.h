@@ -111,7 +111,7 @@ typedef struct nep_fe_result {
   int32_t n_collision_free;       /* ... and the collision tests                                   */
   int32_t goal_occupied;          /* setUp's goal_occupied_ (:210-226)                             */
   int32_t _pad;                   /* entangle check on: bit 3 = the pool of big records ran out (ent_overflow); bits 8
-                                     and up = children of this search that were carried in big records; else 0       */
+                                     and up = children of this search whose state went into a big record; else 0    */
   double cost;                    /* g + bias*h of the returned node                               */
   double dist_to_goal;
   int32_t n_entangled;            /* children pruned by entanglesWithOtherAgents (entangle check on)        */
