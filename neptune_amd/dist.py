@@ -178,12 +178,18 @@ class ShardedRounds:
     native=False: torch.distributed's all_gather_into_tensor with async work handles (RCCL's own stream); right after a
     chunk's replan its next hulls are built and their all-gather is started."""
 
-    def __init__(self, backends, d_local, d_guess, world=1, rank=0, group=None, native=False, fe=None, timer=None):
+    def __init__(self, backends, d_local, d_guess, world=1, rank=0, group=None, native=False, fe=None, timer=None, d_ent=None, carry=None):
         """backends: one BatchBackend per chunk; d_local[k]: device bytes [Sc][n_local] committed records of my agents in
         chunk k; d_guess[k]: [Sc][n_local] guesses; fe: None or (fe_cfg, d_start[k], d_result[k]); timer: None or a callable
-        name -> context manager (bench.py records HIP events around the phases)."""
+        name -> context manager (bench.py records HIP events around the phases); d_ent: None or per chunk the dense entangle
+        case block [Sc][n_local][8][N] (int32) of nep_batch_replan_hulls (enable_entangle_check handles).
+        carry: None — the next round's hulls are built from the commit slots as the QP kernel wrote them — or a tuple of byte
+        ranges (lo, hi) of a record: after a chunk's replan those ranges of every commit slot are copied into d_local[k] and the
+        hulls are built from d_local[k] — what a caller does whose records carry fields the back end does not write (the
+        tethers' bend points of a config-5 scene: a commit slot holds the base only)."""
         import contextlib
         self.bes, self.d_local, self.d_guess, self.fe = backends, d_local, d_guess, fe
+        self.d_ent, self.carry = d_ent, carry
         self.C = len(backends)
         dev = backends[0].device
         self.torch = backends[0].torch
@@ -216,7 +222,15 @@ class ShardedRounds:
             cfg, d_start, d_res = self.fe
             with self.timer("frontend"):
                 b.frontend_hulls(cfg, self.hx[k].blocks, d_start[k], self.d_guess[k], d_res[k])
-        b.replan_hulls(self.hx[k].blocks, self.d_guess[k])
+        b.replan_hulls(self.hx[k].blocks, self.d_guess[k], d_ent=self.d_ent[k] if self.d_ent is not None else None)
+        if self.carry is not None:
+            src = b.d_commit.view(-1, REC_BYTES); dst = self.d_local[k].view(-1, REC_BYTES)
+            for lo, hi in self.carry:
+                dst[:, lo:hi].copy_(src[:, lo:hi])
+
+    def _next_src(self, k):
+        """the records chunk k's next hulls are built from"""
+        return self.d_local[k] if self.carry is not None else self.bes[k].d_commit
 
     def prime(self):
         """native mode: the hull blocks chunk 0 replans against in the first step (the other chunks' are exchanged inside it)"""
@@ -231,13 +245,13 @@ class ShardedRounds:
             main = torch.cuda.current_stream(self.bes[0].device)
             if self.C == 1:                               # nothing to overlap with: replan, then the exchange for the next step
                 self._replan(0)
-                self._start(0, self.bes[0].d_commit)
+                self._start(0, self._next_src(0))
                 return
             for k in range(self.C):
                 j = (k + 1) % self.C
                 self.side.wait_stream(main)               # fork: chunk j's commit records (previous step, or this one for j = 0) are complete
                 with torch.cuda.stream(self.side):
-                    self._start(j, self.bes[j].d_commit)
+                    self._start(j, self._next_src(j))
                 self._replan(k)                           # reads blocks of chunk k, exchanged one phase ago
                 main.wait_stream(self.side)               # join
             return
@@ -248,7 +262,7 @@ class ShardedRounds:
             with self.timer("wait"):
                 self.pending[k].wait()                   # what the stream still has to wait for
             self._replan(k)
-            self._start(k, self.bes[k].d_commit)         # my agents' new committed trajectories
+            self._start(k, self._next_src(k))            # my agents' new committed trajectories
 
 
 def stack_scenes(scenes):

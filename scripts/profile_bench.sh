@@ -1,12 +1,12 @@
 #!/bin/bash
 # One call on the GPU box: the default bench line, the rocprofv3 kernel traces of the headline leg and of the chain / moving legs,
 # and the PMC passes of both (one counter group per pass; never combined with sys/hip traces).
-# Usage: bash scripts/profile_bench.sh <tag>  ->  gpurun_out/<tag>/{bench_line.json,bench_kernel_stats.txt,bench_chain_kernel_stats.txt,pmc_summary.txt,pmc_summary_chain.txt}
+# Usage: bash scripts/profile_bench.sh <tag>  ->  gpurun_out/<tag>/{bench_line.json,bench_detail.json,bench_kernel_stats.txt,bench_chain_kernel_stats.txt,pmc_summary.txt,pmc_summary_chain.txt}
 set -u
 TAG=$1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
-python bench.py --steps 20 --warmup 5 > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"
+python bench.py --gpus 1 --steps 20 --warmup 5 --detail "$OUT/bench_detail.json" > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"      # the driver's command; bench_line.json = the short line it parses
 HEAD="--steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs --no-graph"
 CHAIN="--steps 10 --warmup 3 --no-cpu-baseline --no-config5 --no-graph --presolve-radius 0 --aux-steps 10"
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format rocpd -- python bench.py $HEAD > "$OUT/kt.log" 2>&1
@@ -24,4 +24,4 @@ done
 python scripts/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary.txt"
 python scripts/pmc_summary.py "$OUT/pmcc" > "$OUT/pmc_summary_chain.txt"
 rm -rf "$OUT/kt" "$OUT/ktc" "$OUT/pmc" "$OUT/pmcc"
-python scripts/bench_brief.py "$OUT/bench_line.json"; head -8 "$OUT/bench_kernel_stats.txt"; head -14 "$OUT/bench_chain_kernel_stats.txt"
+python scripts/bench_brief.py "$OUT/bench_detail.json"; head -8 "$OUT/bench_kernel_stats.txt"; head -14 "$OUT/bench_chain_kernel_stats.txt"

@@ -8,7 +8,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 export NEP_BENCH_SCENE_CACHE=/tmp/nep_c5_scenes.pkl
 ARGS="--config5-only --no-cpu-baseline --no-graph $*"
-python bench.py --config5-only --steps 100 --warmup 5 "$@" > "$OUT/config5_line.json" 2> "$OUT/config5_line.err"
+python bench.py --config5-only --steps 100 --warmup 5 --detail "$OUT/config5_line.json" "$@" > "$OUT/config5_short.json" 2> "$OUT/config5_line.err"      # config5_line.json: the leg's full record
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format rocpd -- python bench.py $ARGS --steps 20 --warmup 3 > "$OUT/kt.log" 2>&1
 DB=$(find "$OUT/kt" -name "*.db" | head -1)
 python scripts/rocpd_summary.py "$DB" > "$OUT/config5_kernel_stats.txt" 2>> "$OUT/kt.log"

@@ -149,3 +149,21 @@ def test_small_divisor_magic_numbers_are_exact():
         magic = (1 << 32) // d + 1
         for j in list(range(0, 3000, 7)) + [65535]:
             assert (j * magic) >> 32 == j // d, (j, d)
+
+
+def test_bench_line_stays_short():
+    """bench.py's last stdout line is what the driver parses out of an 8 KB tail: the compact form of a full record (here: round 4's
+    27 KB line, which the driver could not read) must stay below 4 KB and keep the contract's fields"""
+    import json
+    from bench_legs import compact
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_v53_bench_line.json")))
+    line = json.dumps(compact.compact_line(full, "bench_detail.json"))
+    assert len(line) < 4096
+    out = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert out[k] == full[k] or abs(out[k] - full[k]) <= 1e-5 * abs(full[k]), k
+    assert out["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4) and out["cpu_baseline"]["kind"] == "port"
+    assert out["config"]["workload"] == full["config"]["workload"]
+    # a record with 64 ranks' entries still fits (the optional parts are shed, largest first)
+    full["per_rank"] = [{"rank": r, "kernel_ms": {"hull": 0.1, "separator": 0.4, "qp": 1.0, "exchange_wait": 0.01}, "step_ms_p50": 1.6, "wall_s": 0.03} for r in range(64)]
+    assert len(json.dumps(compact.compact_line(full))) <= compact.LIMIT
