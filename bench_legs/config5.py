@@ -249,7 +249,7 @@ def workload(ctx):
     # the all-gather through the C ABI's own RCCL binding inside the captured step (one rank: the same call, degenerate); gloo
     # (NEP_BENCH_ONE_DEVICE, a development aid) and --exchange-torch go through torch.distributed, launched from the host
     native = not args.exchange_torch and (world == 1 or ctx.dist_backend == "nccl")
-    C = args.chunks if S % max(args.chunks, 1) == 0 and S >= args.chunks else 1
+    C = args.chunks if (world > 1 and S % max(args.chunks, 1) == 0 and S >= args.chunks) else 1      # (one rank: nothing to overlap a chunk's kernels with)
     Sc = S // C
     bes = []
     for k in range(C):

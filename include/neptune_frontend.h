@@ -45,9 +45,8 @@ extern "C" {
 
 #define NEP_FE_MAX_BEAM 64
 #define NEP_FE_MAX_SAMPLES 5
-#ifndef NEP_FE_ENT_CAP
-#define NEP_FE_ENT_CAP 40
-#endif                            /* crossings of the FIXED entangle-state record (nep_fe_ent_state: the state at point A
+#define NEP_FE_ENT_CAP 40        /* (a fixed ABI constant: nep_fe_ent_state's layout depends on it; nep_abi_sizeof(14) lets a client verify)
+                                     crossings of the FIXED entangle-state record (nep_fe_ent_state: the state at point A
                                      the caller passes in, and a search node's state on the fast path).  It is not a
                                      limit of the search: the reference prunes a node at num_agents + statics crossings
                                      (kinodynamic_search.cpp:850-854) and so does the front end — a node whose list, new

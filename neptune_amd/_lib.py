@@ -161,6 +161,14 @@ def lib():
     L.nep_batch_frontend_ent_hulls.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, i, vp, vp, vp, vp, vp, vp]
     L.nep_batch_exchange_slots.argtypes = [vp, vp, vp, vp, C.c_int64, vp]
     L.nep_batch_set_ent_samples.argtypes = [vp, i]
+    # the records this mirror builds with ctypes must have the library's layout (a library compiled from other headers would read
+    # them at another stride): fail loudly at load, not as wrong numbers later
+    L.nep_abi_sizeof.argtypes = [i]; L.nep_abi_sizeof.restype = i
+    for which, struct in ((1, abi.nep_traj_rec), (5, abi.nep_guess), (6, abi.nep_solution), (11, abi.nep_fe_cfg), (12, abi.nep_fe_start),
+                          (13, abi.nep_fe_result), (14, abi.nep_fe_ent_state)):
+        if L.nep_abi_sizeof(which) != C.sizeof(struct):
+            raise BackendError("%s: sizeof(%s) is %d in the library, %d in neptune_amd/abi.py — rebuild the library from this tree's headers"
+                               % (LIB_PATH, struct.__name__, L.nep_abi_sizeof(which), C.sizeof(struct)))
     _lib = L
     return L
 

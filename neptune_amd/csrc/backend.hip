@@ -442,6 +442,7 @@ int read_lines(Engine& E, size_t slot, int n_seg, int32_t cap, int32_t* seg, dou
   HIPCHK(hipMemcpy(cnt.data(), E.d_line_cnt.p + slot * NEP_MAX_POL, cnt.size() * sizeof(int), hipMemcpyDeviceToHost));
   if (E.sp.cull_radius > 0.0) HIPCHK(hipMemcpy(far.data(), E.d_line_far.p + slot * NEP_MAX_POL, far.size() * sizeof(int), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(buf.data(), E.d_line_nd.p + slot * NEP_MAX_POL * E.sp.lines_cap * 3, buf.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int& c : cnt) c = line_count(c);      // (an overflowed bucket's count is stored as -1 - n)
   int n = 0;
   for (int s = 0; s < n_seg && s < NEP_MAX_POL; s++)
     for (int c = 0; c < cnt[s] + far[s]; c++) {
@@ -665,7 +666,14 @@ int nep_backend_optimize(nep_backend_t* h, double* objective_value) {
   const int N = h->cfg.num_agents, np = h->cfg.num_pol;
   E.sp.n_hull = h->have_hulls ? h->n_obst : 0;
   E.sp.ent_enabled = h->have_ent ? 1 : 0;
-  if (int e = E.build_schedule(E.sched_dc > 0 ? E.sched_dc : 0.05, E.sched_cap > 0 ? E.sched_cap : 128)) return e;
+  {
+    // the samples generatePwpOut returns are made by the QP kernel's tail at the schedule's dc: the schedule must hold every state of the
+    // horizon (ceil(num_pol T_span / dc) + 1, as generatePwpOut's own path sizes it) — a fixed cap of 128 cut trajectories longer than
+    // 6.3 s short of what the reference's time walk returns (solver_gurobi_poly.cpp:911-934)
+    const double dc0 = E.sched_dc > 0 ? E.sched_dc : 0.05;
+    const int need = (int)std::ceil(np * E.sp.T_span / dc0) + 3;
+    if (int e = E.build_schedule(dc0, need)) return e;
+  }
   if (h->override_n >= 0) {  // line buckets sized for the override
     int per_seg[NEP_MAX_POL] = {0}; for (int l = 0; l < h->override_n; l++) { int s = h->ov_seg[l]; if (s < 0 || s >= NEP_MAX_POL) return fail(NEP_E_ARG, "override line segment out of range"); per_seg[s]++; }
     int mx = 8; for (int s = 0; s < NEP_MAX_POL; s++) if (per_seg[s] > mx) mx = per_seg[s];
@@ -1403,7 +1411,7 @@ int nep_batch_check(nep_batch_t* h, void* stream) {
   }
   if (flags & NEP_FLAG_LINES) return fail(NEP_E_CAP, "a segment got more separating lines than its bucket holds: nep_batch_set_line_capacity(h, -1) sizes the buckets for the reference's worst case");
   if (flags & NEP_FLAG_SCRATCH) return fail(NEP_E_CAP, "the presolve's redo pass listed more replans with rows beyond the register slots than the handle has scratch areas for: nep_batch_reserve_row_scratch");
-  if (flags & NEP_FLAG_ENT_POOL) return fail(NEP_E_CAP, "the entangle re-check of the safety pass ran out of big records (a trajectory was turned down for it): nep_batch_set_fe_ent_big_records");
+  if (flags & NEP_FLAG_ENT_POOL) return fail(NEP_E_CAP, "the pool of big entangle-state records ran out (front end: children of a search were pruned for it, by claim order; safety re-check: a trajectory was turned down): nep_batch_set_fe_ent_big_records");
   if (flags & NEP_FLAG_ENT_BETA) return fail(NEP_E_ARG, "an entangle state passed to the front end has a non-zero beta for an agent crossing (the reference's calculateBetaForCase makes it 0.0)");
   if (flags & NEP_FLAG_HULL_OVERFLOW) return fail(NEP_E_CAP, "an interval overlaps more than NEP_HULL_MAX_CP/4 committed segments (or its hull has more than NEP_HULL_MAX_V vertices)");
   return 0;

@@ -949,7 +949,10 @@ __device__ __forceinline__ void separator_body(const SceneParams& sp, const Prob
   if (lane == 0) {
     const bool spill = cull ? n_near + n_far > sp.lines_cap : n_att > sp.lines_cap;
     if (spill) { if (ps.flags) atomicOr(ps.flags, NEP_FLAG_LINES); if (n_near > sp.lines_cap) n_near = sp.lines_cap; if (n_far > sp.lines_cap - n_near) n_far = sp.lines_cap - n_near; }
-    *cnt_out = cull ? n_near : (n_att < sp.lines_cap ? n_att : sp.lines_cap);
+    // (a bucket that could not hold every line of its segment: the count goes out as -1 - n, and the QP kernels fail that replan — it
+    // keeps its previous trajectory — instead of solving without the rows that did not fit; line_count() reads either form)
+    const int n_out = cull ? n_near : (n_att < sp.lines_cap ? n_att : sp.lines_cap);
+    *cnt_out = spill ? -1 - n_out : n_out;
     if (ps.line_far) ps.line_far[(long)slot * NEP_MAX_POL + seg] = cull ? n_far : 0;
     if (ps.line_skip) ps.line_skip[(long)slot * NEP_MAX_POL + seg] = n_skip;
     lp_out[0] = n_att + n_skip; lp_out[1] = n_fail;
@@ -1132,8 +1135,9 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     const int seg = seg_lo + lane;
     const long o = (long)slot * NEP_MAX_POL + seg;
     int cn_ = sCnt[seg * 6], cf_ = sCnt[seg * 6 + 1];
-    if (cn_ + cf_ > sp.lines_cap) { if (ps.flags) atomicOr(ps.flags, NEP_FLAG_LINES); if (cn_ > sp.lines_cap) cn_ = sp.lines_cap; if (cf_ > sp.lines_cap - cn_) cf_ = sp.lines_cap - cn_; }      // (bucket smaller than the worst case: flagged)
-    ps.line_cnt[o] = cn_;
+    bool spill_ = false;
+    if (cn_ + cf_ > sp.lines_cap) { spill_ = true; if (ps.flags) atomicOr(ps.flags, NEP_FLAG_LINES); if (cn_ > sp.lines_cap) cn_ = sp.lines_cap; if (cf_ > sp.lines_cap - cn_) cf_ = sp.lines_cap - cn_; }      // (bucket smaller than the worst case: flagged, and the replan fails — see separator_body)
+    ps.line_cnt[o] = spill_ ? -1 - cn_ : cn_;
     if (ps.line_far) ps.line_far[o] = cf_;
     if (ps.line_skip) ps.line_skip[o] = sCnt[seg * 6 + 4];
     ps.lp_stats[o * 2] = sCnt[seg * 6 + 3] + sCnt[seg * 6 + 4]; ps.lp_stats[o * 2 + 1] = sCnt[seg * 6 + 2];
@@ -2319,6 +2323,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       fe_initial_z(st->pos[2], st->vel[2], st->accel[2], st->goal[2], sp.T_span, D, sp.v_max, sp.a_max, g->coeff[2]);   // coeffs_z_ (:540)
       for (int d = g->K + 1; d <= D; d++) for (int k = 0; k < 4; k++) g->coeff[2][d - 1][k] = 0.0;
     }
+    if (ENT && (s_i[9] & 8) != 0 && ps.flags) atomicOr(ps.flags, NEP_FLAG_ENT_POOL);      // the pool of big records ran out: WHICH children were pruned depends on the claim order — sticky, nep_batch_check reports it
     if (res_out) {
       nep_fe_result* o = res_out + slot;
       o->status = status; o->K = best_rank >= 0 ? best_depth : 0; o->depth = depth > D ? D : depth;
@@ -2376,7 +2381,7 @@ __global__ __launch_bounds__(64) void active_rows_kernel(SceneParams sp, Problem
   __syncthreads();
   for (int i = 0; i < K && i < NEP_MAX_POL; i++) {
     const long o = (long)slot * NEP_MAX_POL + i;
-    const int cn = ps.line_cnt[o], cf = ps.line_far ? ps.line_far[o] : 0;
+    const int cn = line_count(ps.line_cnt[o]), cf = ps.line_far ? ps.line_far[o] : 0;
     const double* bucket = ps.line_nd + o * sp.lines_cap * 3;
     for (int c = lane; c < cn + cf; c += 64) {
       const long q = c < cn ? (long)c : (long)sp.lines_cap - 1 - (c - cn);

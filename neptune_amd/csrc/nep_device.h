@@ -63,7 +63,7 @@ struct ProblemSet {
   long hull_bstride;
   // separator output
   double* line_nd;               // [slots][NEP_MAX_POL][lines_cap][3]
-  int* line_cnt;                 // [slots][NEP_MAX_POL]  lines at the front of the bucket (all of them, or the near ones)
+  int* line_cnt;                 // [slots][NEP_MAX_POL]  lines at the front of the bucket (all of them, or the near ones); -1 - n: the bucket overflowed (line_count())
   int* line_far;                 // [slots][NEP_MAX_POL]  presolved-away lines parked at the back of the bucket, or null
   int* lp_stats;                 // [slots][NEP_MAX_POL][2]  (LPs attempted, LPs without a line) per segment, written by the separator
   // spatial presolve (line presolve on, largest-gap rule, batched hull layout): LPs whose line is known to be far from the guess
@@ -103,6 +103,8 @@ constexpr int NEP_FLAG_SCRATCH = 4;         // more replans went through the pre
 constexpr int NEP_FLAG_ENT_BETA = 2;        // an entangle state handed to the front end carries a non-zero beta for an agent crossing (the reference's rule makes it 0.0)
 constexpr int NEP_FLAG_HULL_OVERFLOW = 1;   // an interval overlapped more committed segments than NEP_HULL_MAX_CP / 4, or its hull has more than NEP_HULL_MAX_V vertices
 
+// a (slot, segment) line count as the separator stores it: n, or -1 - n when the bucket overflowed (the replan then fails)
+__host__ __device__ inline int line_count(int stored) { return stored < 0 ? -1 - stored : stored; }
 // entry index (scene-major inside its block) and byte offset of the block of agent j's hull data
 struct HullRef { long e; long boff; };
 __host__ __device__ inline HullRef hull_ref(const ProblemSet& ps, int per_scene, int scene, int j) {

@@ -88,15 +88,19 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
   }
   __syncthreads();
   if (tid == 0) {
-    int o = 0, nf = 0, all = 0;
+    int o = 0, nf = 0, all = 0, ovf = 0;
     for (int i = 0; i < NEP_MAX_POL; i++) {
-      const int cn = sI[44 + i], cf = sI[32 + i];
+      const int cn_raw = sI[44 + i], cf = sI[32 + i];
+      ovf |= cn_raw < 0 ? 1 : 0;                                    // the segment's bucket overflowed: lines are missing (separator_body)
+      const int cn = cn_raw < 0 ? -1 - cn_raw : cn_raw;
+      sI[44 + i] = cn;
       sI[i] = o; sI[52 + i] = nf;
       o += cn + (use_far ? cf : 0); nf += cf; all += cn + cf;
     }
-    sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0;
+    sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0; sI[27] = ovf;
   }
   __syncthreads();
+  if (sI[27] != 0) return false;      // (a replan whose line bucket overflowed is not solved: it fails and keeps its previous trajectory — see qp_reg_kernel)
   const int L = sI[NEP_MAX_POL];
   L_used = L; L_all = sI[42];
   // Line coefficients and line-row state live in the LDS carve when the replan's L lines fit it

@@ -161,10 +161,12 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     __syncthreads();
     if (attempt == 0) stage_tables(tables + K, otid());         // the first solve's tables travel together with the line counts and the lines: one global latency instead of two
     if (tid <= NEP_MAX_POL) {   // line offsets per segment: nine threads read the eight counts (the same two cache lines) and each keeps its own prefix — one round trip and one barrier
-      int o = 0, nf = 0, all = 0, over = 0, my_o = 0, my_nf = 0, my_cn = 0, my_cf = 0, nsk = 0;
+      int o = 0, nf = 0, all = 0, over = 0, my_o = 0, my_nf = 0, my_cn = 0, my_cf = 0, nsk = 0, ovf = 0;
 #pragma unroll
       for (int i = 0; i < NEP_MAX_POL; i++) {
-        const int cn = (i < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + i] : 0;
+        const int cn_raw = (i < K) ? ps.line_cnt[(long)slot * NEP_MAX_POL + i] : 0;
+        ovf |= cn_raw < 0 ? 1 : 0;                                  // the segment's bucket overflowed: lines are missing (separator_body)
+        const int cn = cn_raw < 0 ? -1 - cn_raw : cn_raw;
         const int cf = (i < K && CULL) ? ps.line_far[(long)slot * NEP_MAX_POL + i] : 0;
         const int cs = (i < K && CULL && ps.line_skip) ? ps.line_skip[(long)slot * NEP_MAX_POL + i] : 0;   // LPs the separator did not solve: their lines are known to be far (spatial presolve)
         if (i == tid) { my_o = o; my_nf = nf; my_cn = cn; my_cf = cf; }
@@ -173,9 +175,13 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         o += ct; nf += cf; all += cn + cf + cs; nsk += cs;
       }
       if (tid < NEP_MAX_POL) { sI[tid] = my_o; sI[52 + tid] = my_nf; sI[44 + tid] = my_cn; sI[32 + tid] = my_cf; }
-      else { sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0; sI[43] = over; sI[40] = nsk; sI[25] = 0; }
+      else { sI[NEP_MAX_POL] = o; sI[41] = nf; sI[42] = all; sI[21] = 0; sI[43] = over; sI[40] = nsk; sI[25] = 0; sI[27] = ovf; }
     }
     __syncthreads();
+    // A replan with a segment whose line bucket overflowed (NEP_FLAG_LINES is raised) is not solved: rows of the reference's problem are
+    // missing, and a trajectory optimised without them must not be published.  It fails (status NEP_FAILED, output = the guess, the commit
+    // slot keeps the previous record) — solver_gurobi_poly.cpp poses every line (:473-656).
+    if (__builtin_amdgcn_readfirstlane(sI[27]) != 0) break;
     if (ps.scratch_chunks > 0 && __builtin_amdgcn_readfirstlane(sI[43]) != 0) {
       // rows beyond the register slots, on a handle whose row scratch is a small pool for the redo pass (the presolve's default: the
       // near lines of a replan fit the slots nearly always).  First pass: the replan goes to the redo pass as it is, unsolved;

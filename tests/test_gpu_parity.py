@@ -317,6 +317,18 @@ def test_per_agent_one_copy_in_one_copy_out(be, oracle):
     st, us, uo = s.timeSequence(times0, co0, hulls, hulls0, dc=p.dc, n_iter=20)
     assert st == 0 and (us > 0).all() and (uo <= us).all()
     s.close()
+    # a horizon of more than 128 states at the default dc (num_pol T_span / 0.05 + 1 = 161 at T_span = 1 s): the states that come back
+    # with the solution must be ALL of generatePwpOut's time walk (solver_gurobi_poly.cpp:911-934), not the first 128
+    s2 = be.PolySolver(p.num_pol, 3, aid, 1.0, p.pb, p.weight, 0.5, True)
+    s2.setMaxValues(*_bounds(p)); s2.setMaxRuntime(0.05); s2.setTetherLength(p.tether_length); s2.setStaticObstVert([])
+    co2 = co0 * np.array([0.125, 0.25, 0.5, 1.0])                     # the same path flown at half the speed: p2(t) = p(t / 2)
+    s2.setInitTrajectory(times0 * 2.0, co2); s2.setHulls([])
+    ok2, _ = s2.optimize()
+    _, coeff2, traj2 = s2.generatePwpOut(0.0, 0.05)
+    want2 = oracle.sample(coeff2, 1.0, 0.05)
+    assert ok2 and K == 8 and len(want2) == 161 and traj2.shape == want2.shape
+    np.testing.assert_allclose(traj2, want2, rtol=0, atol=1e-12)
+    s2.close()
 
 
 def test_call_sequence_errors(be):

@@ -499,4 +499,18 @@ def test_line_buckets_smaller_than_the_worst_case_flag_an_overflow(be):
             bb.replan(d_com, d_gue, d_ent=d_ent)                   # (sticky until read; a second launch raises it again)
             with pytest.raises(BackendError):
                 bb.check()
+            # ... and it fails SAFE per replan, whether or not the caller polls nep_batch_check: a replan with a segment whose lines did
+            # not all fit is not solved without them (the reference poses every line, solver_gurobi_poly.cpp:473-656) — status
+            # NEP_FAILED, output = the guess, and its commit slot keeps the previous record; the others are untouched
+            sol = bb.solutions(); com = bb.commits()
+            segs, _ = zip(*[bb.debug_lines(a) for a in range(24)])
+            per_seg = np.array([[int((np.asarray(sg) == i).sum()) for i in range(8)] for sg in segs])
+            failed = sol["stats"]["status"] == abi.NEP_FAILED
+            assert failed.sum() > 0 and (per_seg[~failed] <= 8).all()           # (whoever was solved had every line in its buckets)
+            for a in np.nonzero(failed)[0]:
+                K = int(sc["guesses"][a]["K"])
+                assert np.array_equal(np.array(sol[a]["coeff"])[:, :K], np.array(sc["guesses"][a]["coeff"])[:, :K])
+                assert com[a].tobytes() == sc["committed"][a].tobytes()
+            for a in np.nonzero(~failed)[0]:
+                assert sol[a].tobytes() == ref[a].tobytes()
     bb.close()
