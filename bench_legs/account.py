@@ -1,5 +1,4 @@
 """What one replan moves and computes, and the committed counter summaries the line quotes."""
-import json
 import os
 
 import numpy as np
@@ -58,18 +57,20 @@ def measured_traffic(kernel, name="pmc_summary_latest.txt"):
     return None
 
 
-def executed_flops(kernel="qp_reg_kernel"):
-    """fp64 operations a launch of `kernel` EXECUTES, from the committed instruction-mix file (profiles/isa_flops_latest.json:
-    scripts/isa_mix.py's static count of fp64 VALU / MFMA instructions per loop region x the iteration counters the same run
-    measured), or None when that file is not committed.  -> dict(flops_per_launch, source, ...)"""
-    path = os.path.join(ROOT, "profiles", "isa_flops_latest.json")
-    if not os.path.exists(path):
+def executed_flops(kernel, name="pmc_summary_latest.txt"):
+    """fp64 operations one launch of `kernel` EXECUTES, from the committed rocprofv3 --pmc summary of this command (its own pass:
+    SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 count wave instructions, SQ_INSTS_VALU_MFMA_MOPS_F64 counts MFMA operations / 512):
+    64 lanes x (ADD + MUL + TRANS + 2 FMA) + 512 x MFMA_MOPS.  Wave instructions are priced at 64 lanes whatever their EXEC mask, so
+    this is the work ISSUED (an upper bound of the useful lane operations); compares, min / max, moves and conversions are not flops.
+    A replay of a committed file like `traffic`; None when the summary has no such pass."""
+    v = pmc_means(kernel, name)
+    need = ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MFMA_MOPS_F64")
+    if not all(k in v for k in need):
         return None
-    try:
-        d = json.load(open(path))
-    except Exception:
-        return None
-    return d.get(kernel)
+    valu = 64.0 * (v["SQ_INSTS_VALU_ADD_F64"] + v["SQ_INSTS_VALU_MUL_F64"] + v.get("SQ_INSTS_VALU_TRANS_F64", 0.0) + 2.0 * v["SQ_INSTS_VALU_FMA_F64"])
+    mfma = 512.0 * v["SQ_INSTS_VALU_MFMA_MOPS_F64"]
+    return {"flops_per_launch": valu + mfma, "valu_flops_per_launch": valu, "mfma_flops_per_launch": mfma,
+            "source": "profiles/%s: 64 x (ADD + MUL + TRANS + 2 FMA)_F64 wave instructions + 512 x MFMA_MOPS_F64" % name}
 
 
 def quantiles(a):

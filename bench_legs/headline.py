@@ -304,14 +304,15 @@ def record(ctx, H):
             "frac": fp64_ach / 78.6, "algorithmic_flops_per_replan": flops,
             "note": "an upper bound: SURVEY 8d's count assumes the dense G'WG product; the kernel's structured assembly over 64 base rows executes fewer "
                     "(executed_*: the instructions the kernel issues, profiles/isa_flops_latest.json)"}
-    ex_f = acc.executed_flops(be.qp_kernel_name())
-    if ex_f and launch_replans == int(ex_f.get("replans_per_launch", 0)) and qp_ms > 0:
-        # executed fp64 work of a launch (committed instruction-mix file: static fp64 VALU / MFMA counts per loop region of the ISA
-        # x the iteration and row counters of the same workload) over THIS run's kernel duration
+    ex_f = acc.executed_flops("nep::" + be.qp_kernel_name()) if launch_replans == 8192 else None
+    if ex_f and qp_ms > 0:
+        # the fp64 work the kernel ISSUES per launch (hardware instruction counters of the committed PMC summary of this command,
+        # 8 192 replans per launch) over THIS run's kernel duration — next to the SURVEY-count figure above, which prices a dense product
         fp64["executed_flops_per_replan"] = ex_f["flops_per_launch"] / launch_replans
         fp64["executed_achieved"] = ex_f["flops_per_launch"] / (qp_ms * 1e-3) / 1e12
         fp64["executed_frac"] = fp64["executed_achieved"] / 78.6
-        fp64["executed_source"] = ex_f.get("source")
+        fp64["executed_mfma_share"] = ex_f["mfma_flops_per_launch"] / ex_f["flops_per_launch"] if ex_f["flops_per_launch"] > 0 else None
+        fp64["executed_source"] = ex_f["source"]
     if world == 1:
         sharding = "one GPU: all %d agents of every scene" % N
     elif H.sharded_hulls:

@@ -163,22 +163,6 @@ int nep_backend_generate_pwp_out(nep_backend_t* h, double t_start, double dc, ne
                                  double* states_out, int32_t states_cap, int32_t* n_states_out);
 /* Neptune::getPlanningStats side channel (neptune.cpp:1812-1819) + solver counters.            */
 int nep_backend_get_stats(nep_backend_t* h, nep_stats* out);
-/* Measurement aid: the drop-in call sequence of one replan (neptune.cpp:1514-1527: setInitTrajectory -> setHulls ->
- * setHullsNoInflation -> setEntStateVector -> optimize -> generatePwpOut) n_iter times from the calling thread;
- * us_out[n_iter] = wall microseconds of each iteration, us_optimize_out (may be NULL) = of optimize() alone.  h0_off / ent may
- * be NULL (entangle check off).  Returns the last optimize's status or < 0.                                           */
-int nep_backend_debug_time_sequence(nep_backend_t* h, const nep_pwp* init, int32_t n_obst, const int32_t* hull_off,
-                                    const double* hull_xy, const int32_t* h0_off, const double* h0_xy, const nep_ent_view* ent,
-                                    double t_start, double dc, int32_t n_iter, double* us_out, double* us_optimize_out);
-
-/* Test hook: bypass the separator and use these lines for the next optimize():
- * seg[i] in [0,K), nd[i] = (n1,n2,d) in the reference's scaling (row: n.q + d - 1 <= 0).
- * n_lines < 0 restores the built-in separator.                                                 */
-int nep_backend_debug_set_lines(nep_backend_t* h, int32_t n_lines, const int32_t* seg,
-                                const double* nd);
-/* Test hook: copy out the lines used by the last optimize() (order = row order).              */
-int nep_backend_debug_get_lines(nep_backend_t* h, int32_t cap, int32_t* seg, double* nd,
-                                int32_t* n_out);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Stand-alone kernels of the path (batched, host buffers): used by the parity tests           */
@@ -350,9 +334,6 @@ int nep_batch_exchange_slots(nep_batch_t* h, nep_comm_t* c, const void* d_local,
  * NEP_E_ARG): reserve the gathered sizes (world x one rank's piece, in bytes; 0 = leave as is) before capturing a graph, or run
  * the exchange once eagerly.  A graph captured earlier holds the pointer it was captured with: do not grow a buffer afterwards. */
 int nep_comm_reserve(nep_comm_t* c, int64_t records_bytes, int64_t slots_bytes);
-/* Test hook: the regrouping step of nep_batch_exchange_records ([world][n_scenes][n_local] -> [n_scenes][world n_local]). */
-int nep_debug_regroup_records(const nep_traj_rec* d_src, nep_traj_rec* d_dst, int32_t world, int32_t n_scenes,
-                              int32_t n_local, void* stream);
 
 /* Dense per-slot entangle block consumed by nep_batch_replan when enable_entangle != 0:
  *   int32 case_id[NEP_MAX_POL][N]   (0 = no active case for that agent at that segment,
@@ -399,11 +380,7 @@ double nep_batch_get_line_cull(nep_batch_t* h);
  * LP and every row.  Precondition of the box test, checked at upload: every static polygon has an edge on each side of its
  * bounding box (true of the inflated statics nep_inflate_static makes and of the interval hulls: hulls of axis-aligned squares);
  * a handle that is given any other convex polygon (a diamond, say) solves every LP — parked lines and the zero-iteration test
- * still apply, they evaluate real lines.  The debug line readers do not see lines that were never made.  nep_batch_debug_redo_count: replans
- * the last call sent through the redo pass (test hook); by_reason (may be NULL) receives how many of them had a parked line
- * violated [0] and how many moved farther than the radius [1].                                                       */
-int nep_batch_debug_redo_count(nep_batch_t* h, int32_t* by_reason);
-int nep_batch_debug_redo_list(nep_batch_t* h, int32_t* slots_out, int32_t cap);    /* the listed slots (test hook) */
+ * still apply, they evaluate real lines.  The debug line readers (neptune_backend_debug.h) do not see lines that were never made.       */
 /* Row scratch (rows and coefficients of a replan beyond the interior-point kernel's register slots or LDS carve).  In general one
  * worst-case area per slot.  With the presolve's redo pass (line presolve on, largest-gap rule, batched hull layout, box-edged
  * statics) the first pass never needs one — a replan whose near lines exceed the slots goes to the redo pass unsolved — so a
@@ -418,17 +395,6 @@ int nep_batch_reserve_row_scratch(nep_batch_t* h);
  * nep_batch_check returns NEP_E_CAP, nothing is written past a bucket — and (h, -1) sizes for the worst case; (h, n) sets n; (h, 0)
  * the default.  Re-sizes buffers: never inside a graph capture.                                                              */
 int nep_batch_set_line_capacity(nep_batch_t* h, int32_t lines_per_segment);
-int64_t nep_batch_line_bucket_bytes(nep_batch_t* h);
-int64_t nep_batch_row_scratch_bytes(nep_batch_t* h);
-/* Diagnostic ("how hard are these problems"): inequality rows of the QP (solver_gurobi_poly.cpp:433-489) whose slack at the
- * solutions of the last nep_batch_replan* is below tol: d_out [slots][2] int32 = (box rows, separating-line rows) per slot.
- * d_solution is what that replan wrote; the lines are the handle's own (parked ones included).  Asynchronous on `stream`.  */
-int nep_batch_active_rows(nep_batch_t* h, const nep_solution* d_solution, double tol, int32_t* d_out, void* stream);
-/* Test hook: which form of the presolve's separator the next replans launch — 0 (default) segments per wave picked from the
- * launch size, -1 the unpacked kernel (one segment per wave), 1..NEP_MAX_POL that many segments per wave.  The packed form's
- * list entries hold 8 191 candidates per segment (n_hull + N + S + 8 N with the entangle rows); larger scenes take the unpacked
- * kernel whatever is asked here.  Results do not depend on the form (GPU test).                                          */
-int nep_batch_debug_set_separator_pack(nep_batch_t* h, int32_t pack);
 
 /* Which vertex of the separating-line LP the separator returns.  The LP (separator_glpk.cpp:248-373) has a zero objective:
  * the reference gets "whatever vertex glp_simplex reaches", and the spline QP's optimum depends on it.
@@ -453,24 +419,6 @@ int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule);
 int nep_batch_set_tolerances(nep_batch_t* h, double residual_tol, double gap_tol);
 int nep_backend_set_tolerances(nep_backend_t* h, double residual_tol, double gap_tol);
 
-/* Which placement of the interior point the handle runs: 1 = qp_reg_kernel (line-row state in registers, four workgroups
- * per CU: chosen when the expected lines per segment fit its register slots, e.g. BASELINE configs 1-4, or when the line
- * presolve is on — config 5 by default), 0 = qp_kernel (row state in LDS with a global spill: config-5 sized problems
- * with the presolve explicitly turned off).  Same solver, same results to rounding.                                    */
-int nep_batch_qp_placement(nep_batch_t* h);
-
-/* Launch order of the interior-point workgroups (a scheduling matter: results do not depend on it).  A batch of more than
- * 1 024 replans runs as several waves of workgroups over the chip and their durations spread about 1 : 3, so by default the
- * workgroups of a launch are ordered longest-expected-first, the expectation being the measured device time of the same
- * slot's previous replan (nep_stats.solve_us; the first replan of a handle runs in slot order).  enable = 0 keeps slot order.
- * nep_batch_debug_launch_order copies the order of the last replan (n_out = 0 when it ran in slot order).              */
-int nep_batch_set_launch_order(nep_batch_t* h, int32_t enable);
-int nep_batch_debug_launch_order(nep_batch_t* h, int32_t* order, int32_t cap, int32_t* n_out);
-
-/* Which kernel builds the interval hulls (same hulls, bit for bit): 0 = by batch size (eight hulls per wave from ~2 000
- * trajectories per launch on, one per wave below: DESIGN.md section 6), 1 = one hull per wave, 2 = eight per wave.       */
-int nep_batch_set_hull_kernel(nep_batch_t* h, int32_t mode);
-
 /* setMaxRuntime for the batched handle (0 = no wall-clock limit, the default): see nep_backend_set_max_runtime. */
 int nep_batch_set_max_runtime(nep_batch_t* h, double seconds);
 
@@ -480,7 +428,6 @@ int nep_batch_set_max_runtime(nep_batch_t* h, double seconds);
  * constraint (solver_gurobi_poly.cpp:483-494) and nothing else certifies the pair — an agent that is
  * turned down this round keeps flying exactly that previous trajectory.  Off by default.          */
 int nep_batch_set_safety_check_prev(nep_batch_t* h, int32_t on);
-int nep_batch_debug_conflicts(nep_batch_t* h, int32_t scene, uint8_t* conflict_out);
 
 /* Blocks until everything enqueued by this handle on `stream` has finished. */
 int nep_batch_wait(nep_batch_t* h, void* stream);
@@ -490,21 +437,6 @@ int nep_batch_wait(nep_batch_t* h, void* stream);
  * had more than NEP_HULL_MAX_V vertices (the reference uses every segment, neptune.cpp:392-449; the kernels flag the
  * overflow instead of under-covering silently), else 0.  The asynchronous entry points cannot return this themselves. */
 int nep_batch_check(nep_batch_t* h, void* stream);
-
-/* Average device time (ms) of the dominant kernel over the launches since the last call,
- * measured with HIP events on the launch stream; *n_launch = launches averaged.               */
-int nep_batch_kernel_time(nep_batch_t* h, int32_t which, double* avg_ms, int32_t* n_launch);
-int nep_batch_enable_timing(nep_batch_t* h, int32_t on);
-int nep_batch_reset_timing(nep_batch_t* h);
-
-/* Test hooks: fetch intermediates of the last replan to host.                                 */
-int nep_batch_debug_hulls(nep_batch_t* h, int32_t scene, double* hull_xy, int32_t* hull_nv);
-int nep_batch_debug_lines(nep_batch_t* h, int32_t slot, int32_t cap, int32_t* seg, double* nd,
-                          int32_t* n_out);
-
-/* Development aid: shader-cycle counters of the QP kernel's phases for one slot (handle must be
- * created with NEP_QP_PROFILE set in the environment). */
-int nep_batch_debug_phase_cycles(nep_batch_t* h, int32_t slot, int64_t* out16);
 
 /* sizeof() of the POD records as compiled (0 nep_pwp, 1 nep_traj_rec, 2 nep_backend_cfg,
  * 3 nep_stats, 4 nep_batch_cfg, 5 nep_guess, 6 nep_solution, 7 nep_ent_view; from neptune_plan.h:

@@ -168,16 +168,11 @@ int nep_batch_set_static_reps(nep_batch_t* h, int32_t scene, const double* rep, 
  * nep_batch_set_fe_ent_big_records   records in the handle's pool (0: the default, 4 per slot and at least 4 096); a record
  *                                    holds num_agents + statics crossings (13 bytes each) and the scratch of one sampled
  *                                    step; takes effect at the next front-end call (not while a stream is capturing).
- * nep_batch_set_fe_ent_fast_caps     what the fixed record's path accepts before a child goes to a big record: list
+ * nep_batch_set_fe_ent_fast_caps     (neptune_backend_debug.h) what the fixed record's path accepts before a child goes to a big record: list
  *                                    entries (<= NEP_FE_ENT_CAP), new crossings per sampled step (<= 32), bend points
  *                                    (<= NEP_MAX_BEND).  The results do not depend on these — the tests set them to
  *                                    0 / 1 / 2 to drive ordinary scenes through the big records.                      */
-/* Device time of the last search of every slot, microseconds (what nep_stats.solve_us is for the QP): us [slots], host.  The
- * searches of a launch are started longest-expected-first — the previous search of the same slot is the predictor, as for the
- * QP's workgroups (nep_batch_set_launch_order switches both); the results do not depend on the order.               */
-int nep_batch_fe_search_us(nep_batch_t* h, float* us, int32_t cap);
 int nep_batch_set_fe_ent_big_records(nep_batch_t* h, int64_t records);
-int nep_batch_set_fe_ent_fast_caps(nep_batch_t* h, int32_t list_cap, int32_t add_cap, int32_t bend_cap);
 int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed, const nep_fe_start* d_start,
                            const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result,
                            int32_t* d_case_out, void* stream);

@@ -9,19 +9,33 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NEP_BACKEND_LIB") or os.path.join(_HERE, "libneptune_backend.so")   # (NEP_BACKEND_LIB: development aid, A/B builds)
 _lib = None
 
-# every symbol include/neptune_backend.h declares
+# every symbol include/neptune_backend.h declares (the drop-in surface + the batched handle)
 EXPORTS = [
     "nep_backend_create", "nep_backend_destroy", "nep_backend_set_max_values", "nep_backend_set_max_runtime",
     "nep_backend_set_tether_length", "nep_backend_set_static_obst_vert", "nep_backend_set_init_trajectory",
     "nep_backend_set_hulls", "nep_backend_set_hulls_no_inflation", "nep_backend_set_ent_state_vector",
-    "nep_backend_optimize", "nep_backend_generate_pwp_out", "nep_backend_get_stats", "nep_backend_debug_set_lines",
-    "nep_backend_debug_get_lines", "nep_separator_batch", "nep_hulls_batch", "nep_batch_create", "nep_batch_destroy",
-    "nep_batch_replan", "nep_batch_ent_bytes", "nep_batch_wait", "nep_batch_kernel_time", "nep_batch_enable_timing",
-    "nep_batch_reset_timing", "nep_batch_debug_hulls", "nep_batch_debug_lines", "nep_last_error", "nep_version",
-    "nep_abi_sizeof", "nep_batch_debug_phase_cycles", "nep_batch_safety_commit", "nep_batch_debug_conflicts",
-    "nep_batch_hull_block_bytes", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_gjk_batch",
-    "nep_batch_set_safety_check_prev", "nep_batch_set_line_cull", "nep_batch_check", "nep_batch_set_scene_statics", "nep_comm_unique_id", "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks", "nep_comm_reserve", "nep_batch_exchange_slots", "nep_batch_set_ent_samples",
-    "nep_batch_exchange_hulls", "nep_batch_exchange_records", "nep_debug_regroup_records", "nep_batch_set_max_runtime", "nep_batch_qp_placement", "nep_batch_set_launch_order", "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_get_line_cull", "nep_inflate_static", "nep_batch_debug_redo_count", "nep_batch_debug_redo_list", "nep_batch_debug_set_separator_pack", "nep_batch_active_rows", "nep_batch_reserve_row_scratch", "nep_batch_set_line_capacity", "nep_batch_line_bucket_bytes", "nep_batch_row_scratch_bytes", "nep_backend_debug_time_sequence", "nep_separator_batch_rule", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule", "nep_batch_set_tolerances", "nep_backend_set_tolerances",
+    "nep_backend_optimize", "nep_backend_generate_pwp_out", "nep_backend_get_stats", "nep_inflate_static",
+    "nep_separator_batch", "nep_separator_batch_rule", "nep_gjk_batch", "nep_hulls_batch", "nep_batch_create",
+    "nep_batch_destroy", "nep_batch_set_scene_statics", "nep_batch_replan", "nep_batch_hull_block_bytes",
+    "nep_batch_set_ent_samples", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_comm_unique_id",
+    "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks", "nep_batch_exchange_hulls",
+    "nep_batch_exchange_records", "nep_batch_exchange_slots", "nep_comm_reserve", "nep_batch_ent_bytes",
+    "nep_batch_safety_commit", "nep_batch_set_line_cull", "nep_batch_get_line_cull", "nep_batch_reserve_row_scratch",
+    "nep_batch_set_line_capacity", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule",
+    "nep_batch_set_tolerances", "nep_backend_set_tolerances", "nep_batch_set_max_runtime",
+    "nep_batch_set_safety_check_prev", "nep_batch_wait", "nep_batch_check", "nep_abi_sizeof", "nep_last_error",
+    "nep_version",
+]
+# every symbol include/neptune_backend_debug.h declares (test hooks, measurement aids, A/B knobs)
+DEBUG_EXPORTS = [
+    "nep_backend_debug_time_sequence", "nep_backend_debug_set_lines", "nep_backend_debug_get_lines",
+    "nep_debug_regroup_records", "nep_batch_debug_redo_count", "nep_batch_debug_redo_list",
+    "nep_batch_line_bucket_bytes", "nep_batch_row_scratch_bytes", "nep_batch_active_rows",
+    "nep_batch_debug_set_separator_pack", "nep_batch_qp_placement", "nep_batch_set_launch_order",
+    "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_debug_conflicts",
+    "nep_batch_kernel_time", "nep_batch_enable_timing", "nep_batch_reset_timing", "nep_batch_debug_hulls",
+    "nep_batch_debug_lines", "nep_batch_debug_phase_cycles", "nep_batch_fe_search_us",
+    "nep_batch_set_fe_ent_fast_caps",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
@@ -31,7 +45,7 @@ PLAN_EXPORTS = [
 ]
 # every symbol include/neptune_entangle.h declares (host-only)
 # include/neptune_frontend.h
-FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_frontend_ent", "nep_batch_safety_commit_ent", "nep_batch_next_starts", "nep_batch_frontend_ent_hulls", "nep_batch_set_fe_ent_big_records", "nep_batch_set_fe_ent_fast_caps", "nep_batch_fe_search_us"]
+FE_EXPORTS = ["nep_batch_frontend", "nep_batch_frontend_hulls", "nep_batch_set_static_reps", "nep_batch_set_fe_ent_big_records", "nep_batch_frontend_ent", "nep_batch_frontend_ent_hulls", "nep_batch_safety_commit_ent", "nep_batch_next_starts"]
 ENT_EXPORTS = ["nep_ent_sample_points", "nep_ent_propagate_segment", "nep_ent_propagate_guess", "nep_ent_case_ids"]
 
 

@@ -6,6 +6,7 @@
 
 #include "nep_tables.h"
 #include "../../include/neptune_frontend.h"
+#include "../../include/neptune_backend_debug.h"
 
 namespace nep {
 

@@ -668,6 +668,8 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   const double EXP_MU0 = getenv("ORC_EXP_MU0") ? atof(getenv("ORC_EXP_MU0")) : 2.0;
   const double EXP_TAU = getenv("ORC_EXP_TAU") ? atof(getenv("ORC_EXP_TAU")) : 0.99999;
   const double EXP_GAPTOL = getenv("ORC_EXP_GAPTOL") ? atof(getenv("ORC_EXP_GAPTOL")) : g_tol_gap;
+  const double EXP_TAU2 = getenv("ORC_EXP_TAU2") ? atof(getenv("ORC_EXP_TAU2")) : 1.0;
+  const int EXP_TAU2_AFTER = getenv("ORC_EXP_TAU2_AFTER") ? atoi(getenv("ORC_EXP_TAU2_AFTER")) : 1;
   const int trace = getenv("ORC_QP_TRACE") != NULL;
   const int EXP_REFINE = getenv("ORC_EXP_REFINE") ? atoi(getenv("ORC_EXP_REFINE")) : 0;   /* experiment: refinement steps per Newton solve (0 = what the kernel does) */
   double* M0 = (double*)malloc(sizeof(double) * ((size_t)ny * ny + ny)); double* res = M0 + (size_t)ny * ny;
@@ -761,12 +763,15 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     { double tau = 1.0 - mu;      /* fraction of the step to the boundary: 1 - mu clamped to [0.999, EXP_TAU = 0.99999] */
       if (tau < 0.999) tau = 0.999;
       if (tau > EXP_TAU) tau = EXP_TAU;
+      if (ntrig >= EXP_TAU2_AFTER && tau > EXP_TAU2) tau = EXP_TAU2;
       alpha *= tau; if (alpha > 1.0) alpha = 1.0; }
     if (trace) {
       /* (trace only) how close lam / |lam|_1 is to a Farkas ray: G'lam -> 0 with h'lam < 0 proves the rows infeasible */
       double l1 = 0, hl = 0, gl[64]; for (int c = 0; c < ny && c < 64; c++) gl[c] = 0;
       for (int r = 0; r < m; r++) { l1 += lam[r]; hl += hy[r] * lam[r]; const double* g = Gy + (size_t)r * ny; for (int c = 0; c < ny && c < 64; c++) gl[c] += g[c] * lam[r]; }
       double gmax = 0, g1 = 0; for (int c = 0; c < ny && c < 64; c++) { if (fabs(gl[c]) > gmax) gmax = fabs(gl[c]); g1 += fabs(gl[c]); }
+      { double cmin = 1e300, cmax = 0; int nsm = 0; for (int r = 0; r < mt; r++) { const double c_ = s[r] * lam[r] / mu; if (c_ < cmin) cmin = c_; if (c_ > cmax) cmax = c_; if (c_ < 1e-3) nsm++; }
+        fprintf(stderr, "   alpha_aff %.3e  centrality min %.3e max %.3e  pairs below 1e-3 mu: %d  ntrig %d\n", alpha_aff, cmin, cmax, nsm, ntrig); }
       fprintf(stderr, "it %2d nrp %.3e nrd %.3e (qs %.3e) gap %.3e obj %.9g sigma %.3e alpha %.3e loose %d | farkas: |G'l|_1/|l|_1 %.3e  h'l/|l|_1 %.3e  ratio %.3e\n", it, nrp, nrd, qscale, gap, obj, sigma, alpha, loose_ok, g1 / l1, hl / l1, g1 / fmax(-hl, 1e-300));
     }
     if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;

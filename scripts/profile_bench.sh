@@ -19,6 +19,7 @@ for leg in "pmc|--steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs --no-grap
   pmc $dir "$args" fetch FETCH_SIZE
   pmc $dir "$args" write WRITE_SIZE
   pmc $dir "$args" sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY
+  pmc $dir "$args" f64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA
   pmc $dir "$args" sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 done
 python scripts/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary.txt"

@@ -6,6 +6,7 @@
 #include <iostream>
 
 #include "neptune_poly_solver.hpp"
+#include "neptune_backend_debug.h"      // (the test hook below: lines as input)
 
 int main() {
   int K; double T, w, b[8];

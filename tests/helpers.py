@@ -106,3 +106,22 @@ def bundle_scene(n_agents, a, t_range, P=(-20.0, -1.0), Q=(20.0, 1.0)):
         com["pos"][:2] = pos
     sc["bundle"] = (P, Q)
     return sc
+
+
+def load_moving_hard_cases():
+    """tests/golden/moving_hard_cases.npz (make_moving_hard_cases.py): the hard replans of the closed loop as stand-alone QPs —
+    guess, separating lines, HiGHS feasibility margins of the reference's linear rows and the status they imply
+    -> (Params, list of dicts)"""
+    d = np.load(os.path.join(ROOT, "tests", "golden", "moving_hard_cases.npz"))
+    b = d["bounds"]
+    p = scene.Params(num_agents=1, pb=np.full((1, 2), 1e6))
+    p.x_min, p.x_max, p.y_min, p.y_max, p.z_min, p.z_max = [float(x) for x in b[:6]]
+    p.v_max, p.a_max, p.T_span, p.weight = float(b[6]), float(b[7]), float(b[8]), float(b[9])
+    off = d["line_off"]
+    out = []
+    for k in range(len(d["K"])):
+        K = int(d["K"][k])
+        out.append(dict(K=K, coeff=d["coeff"][k][:, :K, :].copy(), seg=d["line_seg"][off[k]:off[k + 1]].astype(np.int32), nd=d["line_nd"][off[k]:off[k + 1]].copy(),
+                        expected=int(d["expected"][k]), t_first=float(d["t_first"][k]), t_relaxed=float(d["t_relaxed"][k]), ball=bool(d["ball"][k]),
+                        device_status_at_dump=int(d["device_status_at_dump"][k]), hard=bool(d["hard"][k])))
+    return p, out

@@ -331,6 +331,17 @@ def test_per_agent_one_copy_in_one_copy_out(be, oracle):
     s2.close()
 
 
+def test_exact_signature_shim_solves_through_the_c_abi(be, tmp_path):
+    """tests/cpp/shim_signature_check.cpp on the GPU: `class PolySolverGurobi` (the reference's signatures) constructed and driven in
+    Neptune's call order against the stand-in type declarations (tests/cpp/ref_types_min/README.md) — optimize() returns true, K
+    segments and K T / dc + 1 states come back, times are shifted by t_start (solver_gurobi_poly.cpp:898)."""
+    import test_abi
+    if test_abi._find_eigen() is not None:
+        pytest.skip("Eigen present")
+    r = test_abi._build_shim_check(tmp_path / "shim_signature_check")
+    assert r.returncode == 0 and "optimize -> 1" in r.stdout and "segments 4 states 41 t0 3.00" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_call_sequence_errors(be):
     from neptune_amd._lib import BackendError
     p = scene.scaled_params(2, 0)
@@ -1045,6 +1056,48 @@ def test_parity_distribution_on_front_end_guesses(be, oracle):
     assert np.percentile(dco, 99) <= 1e-6 and dco.max() <= 1e-4, (np.percentile(dco, 99), dco.max())
     assert max(dpos) <= 5e-5 and max(dob) <= 1e-8, (max(dpos), max(dob))
     bb.close()
+
+
+def test_hard_closed_loop_replans_status_against_highs_and_the_oracle(be, oracle):
+    """The closed loop's hard replans (tests/golden/moving_hard_cases.npz, see tests/test_oracle_golden.py) through the C ABI with the
+    dumped separating lines as input (nep_backend_debug_set_lines): the status PolySolverGurobi::optimize returns is decided by the
+    feasibility of the rows (solver_gurobi_poly.cpp:832-861), which HiGHS judges independently of the product and of the oracle.
+    Asserted: where the reference's linear rows are decisively infeasible the device fails the same way (first + relaxed problem ->
+    FAILED, first only -> RELAXED); where HiGHS finds an interior and the device still gives up (a degenerate optimum: the interior
+    point's gap stalls) — counted and bounded; device vs oracle: same status on all but a handful of razor-thin cases (round 4 saw 5
+    of 82 disagree, on a script's output; now in the suite), and where both solve, the same optimum."""
+    p, cases = helpers.load_moving_hard_cases()
+    s = _solver(be, p, 1)
+    s.setStaticObstVert([])
+    n_lab = {0: 0, 1: 0, 2: 0}; missed, differ, dcost = [], [], []
+    for k, c in enumerate(cases):
+        K = c["K"]
+        s.setInitTrajectory(np.arange(K + 1) * p.T_span, c["coeff"]); s.setHulls([]); s.debugSetLines(c["seg"], c["nd"])
+        ok, obj = s.optimize()
+        r = oracle.optimize(p, 1, c["coeff"], [], [], lines=(c["seg"], c["nd"]))
+        if s.status != r["status"]:
+            differ.append((k, s.status, r["status"], c["expected"]))
+        elif s.status != abi.NEP_FAILED:
+            dcost.append(abs(obj - r["objective"]) / (1 + abs(r["objective"])))
+        e = c["expected"]
+        if e < 0:
+            continue
+        n_lab[e] += 1
+        if e == 2:
+            assert s.status == abi.NEP_FAILED and not ok, (k, s.status)
+            _, coeff, _ = s.generatePwpOut(0.0, p.dc)
+            np.testing.assert_array_equal(coeff, c["coeff"])                     # output == the initial guess (:856-859)
+        elif e == 1:
+            assert s.status == abi.NEP_RELAXED, (k, s.status)
+        elif s.status != abi.NEP_OK:
+            missed.append((k, s.status, c["t_first"]))
+    s.close()
+    assert n_lab[2] >= 30 and n_lab[1] >= 5 and n_lab[0] >= 20
+    print("device gave up on %d of %d replans HiGHS finds strictly feasible: %r; device != oracle on %d of %d: %r; cost where both solve: max rel %.2e"
+          % (len(missed), n_lab[0], missed, len(differ), len(cases), differ, max(dcost)))
+    assert len(missed) <= 6 and len(differ) <= 6
+    assert not [d for d in differ if d[3] > 0]                                   # never on a decisively infeasible case
+    assert max(dcost) <= 1e-6
 
 
 def test_reference_tolerances(be, oracle):
