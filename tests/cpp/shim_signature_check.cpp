@@ -56,7 +56,7 @@ int main() {
     s.generatePwpOut(out, traj, 3.0, 0.05);                                      // :1527
     std::printf("optimize -> %d objective %.6f segments %zu states %zu t0 %.2f x(0) %.3f\n", ok ? 1 : 0, objective, out.coeff_x.size(), traj.size(),
                 out.times.empty() ? -1.0 : out.times[0], traj.empty() ? 0.0 : traj[0].pos(0));
-    return (ok && out.coeff_x.size() == (size_t)K && traj.size() == (size_t)(K * T / 0.05 + 1.5) && out.times[0] == 3.0) ? 0 : 2;
+    return (ok && out.coeff_x.size() == (size_t)K && traj.size() >= (size_t)(K * T / 0.05) && traj.size() <= (size_t)(K * T / 0.05) + 1 && out.times[0] == 3.0) ? 0 : 2;
   } catch (const std::exception& e) {
     std::printf("no solve: %s\n", e.what());                                     // (a box without a GPU: the back end has no CPU path)
     return 3;
