@@ -105,7 +105,7 @@ struct Engine {
   DevBuf<double> d_sampled, d_srep, d_slong; DevBuf<int> d_present, d_entangles;
   DevBuf<nep_fe_ent_state> d_fe_nodes, d_fe_work, d_fe_saved; DevBuf<double> d_fe_arc, d_fe_packed; bool have_reps = false;
   // big records of the entangle-aware front end (ent_device.h): a pool per handle, 0 = the default budget (4 per slot, at least 4 096)
-  DevBuf<double> d_fe_big_beta, d_fe_stf; DevBuf<long long> d_fe_stvox;
+  DevBuf<double> d_fe_big_beta, d_fe_stf; DevBuf<long long> d_fe_stvox; DevBuf<unsigned> d_fe_xpool;
   DevBuf<unsigned char> d_fe_big, d_fe_big_check; DevBuf<int> d_fe_big_count, d_fe_big_check_count; long fe_big_records = 0;
   int fe_fast_cap = NEP_FE_ENT_CAP, fe_fast_add = 32, fe_fast_bend = NEP_MAX_BEND;
   DevBuf<unsigned char> d_conflict, d_conflict_prev;
@@ -410,7 +410,7 @@ struct Engine {
   void release() {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_order.release(); d_fe_order_key.release(); d_fe_us.release(); d_fe_box.release();
-    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release(); d_fe_big.release(); d_fe_big_beta.release(); d_fe_stf.release(); d_fe_stvox.release(); d_fe_big_count.release(); d_fe_big_check.release(); d_fe_big_check_count.release();
+    d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release(); d_fe_big.release(); d_fe_big_beta.release(); d_fe_stf.release(); d_fe_stvox.release(); d_fe_xpool.release(); d_fe_big_count.release(); d_fe_big_check.release(); d_fe_big_check_count.release();
     d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
@@ -1144,6 +1144,11 @@ static int fe_ent_scratch(nep_batch* h, const nep_fe_cfg& cfg, FeEntArgs& ea) {
   if (int e = E.d_fe_stf.ensure((size_t)h->slots * cap)) return e;
   if (int e = E.d_fe_stvox.ensure((size_t)h->slots * cap)) return e;
   ea.st_f = E.d_fe_stf.p; ea.st_vox = E.d_fe_stvox.p;
+  {   // where a round's lists of new crossings go when the LDS pool is full (cross_round): one block of kEntAddCap words per (child, step)
+    const size_t xw = frontend_ent_xpool_words(E.sp, cfg, ea.ns);
+    if (int e = E.d_fe_xpool.ensure((size_t)h->slots * xw)) return e;
+    ea.xpool = E.d_fe_xpool.p; ea.xpool_stride = (int)xw;
+  }
   ea.pk_stride = 2 + 2 * kBend + 2 * (ea.ns + 1);      // (kEntPkHead + the samples: an even number of doubles)
   if (int e = E.d_fe_packed.ensure((size_t)h->cfg.n_scenes * h->cfg.num_agents * h->cfg.num_pol * ea.pk_stride)) return e;
   ea.packed = E.d_fe_packed.p;

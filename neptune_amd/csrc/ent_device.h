@@ -532,6 +532,100 @@ template <class ADD, class ST> __device__ int ent_propagate(const EntCtx& c, ST*
   if (too_long) return 1;
   return 0;
 }
+// ---- The front end's fast path, in two passes (round 5).  Which crossings a sampled step adds does not depend on the entangle state:
+// it is a function of the child's polynomial, the other agents' tethers and the static representatives alone.  So the kernel finds
+// them in a DENSE pass of its own — one thread per (child, sampled step), the candidates' packed records staged in LDS, the lists of
+// new crossings left in an LDS pool (ent_cross_step) — and the per-child pass that follows (ent_propagate_pre) is the list surgery
+// alone: merge, counts, bend points, tether length, in the reference's order, on exactly the lists ent_propagate would have made
+// (same ent_cross_agent / ent_cross_static, same operands, same order: bit-identical states).  Before, every child walked its
+// candidates' records in global memory inside the surgery loop: 17 visits of 4 000 - 8 000 cycles per propagation, the lanes of a wave
+// on different parents' candidate lists (65 % of a propagation).
+// A (child, step)'s list in the pool: header word = offset | n << 16 | overflow << 24 (kEntHdrNone: not made).
+constexpr unsigned kEntHdrOvf = 1u << 24, kEntHdrGlobal = 1u << 25;      // (global: the words are in the pair's block of FeEntArgs::xpool, the LDS pool was full)
+template <class REC> __device__ __forceinline__ void ent_cross_step(EntAdd& add, const EntCtx& c, Ev2 pk, Ev2 pk1, int index, int j, REC rec_of) {
+  const int ns = c.ns;
+  const Ev2 pb_self = ent_pb(c, c.own);
+  const int itv = index > c.num_pol ? c.num_pol - 1 : index - 1;
+  const int jl = index > c.num_pol ? ns : j - 1, jr = index > c.num_pol ? ns : j;
+  const int MWn = (c.N + 31) >> 5;
+  int mw = -1; unsigned cw = 0u;
+  auto next_cand = [&]() -> int {
+    while (cw == 0u) { if (++mw >= MWn) return c.N; cw = c.m_agent ? c.m_agent[mw] : ~0u; }
+    const int i = (mw << 5) + __ffs(cw) - 1; cw &= cw - 1u;
+    if (i >= c.N) { cw = 0u; mw = MWn; return c.N; }
+    return i;
+  };
+#ifdef NEP_PROFILE_PHASES
+  long long xt0_ = clock64(); int xv_ = 0;
+#endif
+  for (int i = next_cand(); i < c.N; i = next_cand()) {
+#ifdef NEP_PROFILE_PHASES
+    xv_++;
+#endif
+    if (i == c.own) continue;
+    const double* r = rec_of(i, itv);      // (LDS copy when the agent is staged, else the packed record itself)
+    const int2 hd = *(const int2*)r;
+    if (!hd.x) continue;
+    const double2 sa = *(const double2*)(r + kEntPkHead + 2 * jl), sb = *(const double2*)(r + kEntPkHead + 2 * jr), b0 = *(const double2*)(r + kEntPkBend), b1 = *(const double2*)(r + kEntPkBend + 2);
+    const int fk = !c.f_bits ? -1 : (index > c.num_pol ? 0 : (int)((c.f_bits[i] >> (j - 1)) & 1u));
+    ent_cross_agent(add, pk, pk1, Ev2{sa.x, sa.y}, Ev2{sb.x, sb.y}, pb_self, hd.y, r + kEntPkBend, i + 1, fk, true, Ev2{b0.x, b0.y}, Ev2{b1.x, b1.y});
+  }
+#ifdef NEP_PROFILE_PHASES
+  const long long xt1_ = clock64();
+#endif
+  ent_cross_static(add, pk, pk1, c);
+#ifdef NEP_PROFILE_PHASES
+  if (c.prof) { const long long xt2_ = clock64(); atomicAdd((unsigned long long*)c.prof + 0, (unsigned long long)(xt1_ - xt0_)); atomicAdd((unsigned long long*)c.prof + 1, (unsigned long long)(xt2_ - xt1_));
+    atomicAdd((unsigned long long*)c.prof + 5, 1ull); atomicAdd((unsigned long long*)c.prof + 15, (unsigned long long)xv_); atomicAdd((unsigned long long*)c.prof + 6, (unsigned long long)(add.n > 0)); }
+#endif
+}
+// the point of a child's polynomial at sampled step j (0: its start), as ent_propagate evaluates it
+__device__ __forceinline__ Ev2 ent_step_point(const EntCtx& c, const double* cxo, const double* cyo, Ev2 end, int j) {
+  if (j == 0) return Ev2{cxo[3], cyo[3]};
+  if (j >= c.ns) return end;
+  const double t = c.T_span * j / c.ns;
+  const double t3 = t * t * t, t2 = t * t;
+  return Ev2{((cxo[0] * t3 + cxo[1] * t2) + cxo[2] * t) + cxo[3] * 1.0, ((cyo[0] * t3 + cyo[1] * t2) + cyo[2] * t) + cyo[3] * 1.0};
+}
+// the list surgery of ent_propagate on lists made beforehand: hdr[j - 1] = the header word of step j's list, pool = the words' base
+// (a generic pointer into LDS), gblocks = the child's blocks in global memory (lists the LDS pool had no room for).  Same return codes as ent_propagate.
+template <class ST> __device__ int ent_propagate_pre(const EntCtx& c, ST* st, const unsigned* hdr, const unsigned* pool, const unsigned* gblocks, int add_lim, const double* cxo, const double* cyo, Ev2 end, double& arc, bool check_tether, int cap_mult) {
+  const int ns = c.ns;
+  const Ev2 pb_self = ent_pb(c, c.own);
+  Ev2 pk{cxo[3], cyo[3]}, pk1 = pk;
+  for (int j = 1; j <= ns; j++) {
+    pk1 = ent_step_point(c, cxo, cyo, end, j);
+    arc += ent_dist(pk1, pk);
+    const unsigned h = hdr[j - 1];
+    if (h & kEntHdrOvf) return 3;
+    EntAdd add; add.clear(); add.lim = add_lim;
+    add.n = (int)((h >> 16) & 0xffu);
+    const unsigned* w = (h & kEntHdrGlobal) ? gblocks + (j - 1) * kEntAddCap : pool + (h & 0xffffu);      // (gblocks: this child's blocks, one per step)
+    add.r0 = add.n > 0 ? w[0] : 0u; add.r1 = add.n > 1 ? w[1] : 0u; add.r2 = add.n > 2 ? w[2] : 0u; add.r3 = add.n > 3 ? w[3] : 0u;
+    add.rest = const_cast<unsigned*>(w) + EntAdd::reg;      // (read only from here on: the merge flags cancelled entries in `gone`)
+    if (st->n_alpha + add.n > (c.N + c.S) * cap_mult) return 1;
+    if (add.n > 0) {
+      const unsigned long long sig_before = ent_sig_of(st);
+      if (ent_merge(add, st, pk, pb_self, c)) return 2;
+      for (int e = 0; e < add.n;) {      // (the before / after counts of the agents the step touched: see ent_propagate)
+        const int id_ = add.id(e);
+        int init = 0, rem = 0;
+        do { rem += add.alive(e) ? 1 : 0; init++; e++; } while (e < add.n && add.id(e) == id_);
+        if (id_ > c.N) continue;
+        const int d = 2 * rem - init;
+        if (d <= 0) continue;
+        if (d >= 2) return 1;
+        if (!((sig_before >> (id_ & 63)) & 1ull)) continue;
+        if (ent_count(st->id, st->n_alpha, id_) >= 2) return 1;
+      }
+    }
+    if (ent_update_bends(st, pk1, pb_self, c)) return 4;
+    pk = pk1;
+  }
+  if (check_tether && ent_tether(st, pb_self, pk1, c) > c.cable) return 1;
+  return 0;
+}
+
 // A search node's state while its child is being merged (front end, phase two): the crossing list's ids and cases and the bend
 // indices in LDS (the list surgery scans and shifts them: a chain of dependent reads), the betas — written when an entry is
 // added or re-anchored, read once per step — in the thread's global working record.  Same member names as nep_fe_ent_state: the

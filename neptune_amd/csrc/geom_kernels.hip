@@ -1788,7 +1788,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
     // the crossing lists of the children being merged (phase two of the propagation pass) live where the shortlist's boxes and
     // vertices and the winners' f values are: dead between a depth's GJK pass and its compaction / the next depth's shortlist
     ent_lists = (unsigned char*)o_aabb;      // [n_merge][kEntLdsBytes]
-    my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(f_bits + N) + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
+    my_work = NEP_FE_ENT_WGS == 1 ? (nep_fe_ent_state*)(((size_t)(f_bits + N) + 3 + 8 * MW + 7) & ~(size_t)7) + tid : ea.work + ((long)slot * 256 + tid);      // (one working record per thread, in LDS: the list surgery is a chain of dependent loads)
     if (tid == 0) {
       nep_fe_ent_state* root = ent_node(0, 0);
       if (ea.init) {
@@ -2019,7 +2019,11 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         settle_voxel(id, ch, 0u);
       }
     };
-    auto propagate = [&](int id) {      // ENT, part two (see above)
+    // (fast instantiation: the lists of new crossings of the round's children were made by cross_round, below — hdr[rank * ns + j - 1] in
+    // s_f's storage, the words in s_vox's — and this pass is the list surgery alone, ent_propagate_pre)
+    unsigned* x_hdr = (unsigned*)s_f; unsigned* x_pool = (unsigned*)s_vox;
+    const int x_pool_cap = (int)(sizeof(long long) * (size_t)kFeCap / sizeof(unsigned)), x_hdr_cap = (int)(sizeof(double) * (size_t)kFeCap / sizeof(unsigned));
+    auto propagate = [&](int id, int rank_in_round) {      // ENT, part two (see above)
       const int pr_ = id / NC, cc = id % NC;
       FeChild ch;
       fe_child_again<true>(sp, fc, lat, b_end + (prv * MB + pr_) * 6, b_g[prv * MB + pr_], cc / ns, cc % ns, gx, gy, ch);
@@ -2031,6 +2035,7 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         // depth's ~140 survivors are one round instead of two)
         // (and then in s_f and s_vox, whose contents — f and voxel of the children that survive this pass — are parked in global memory
         // until the pass is over: 259 lists at config 5, every depth one round)
+        // (fast instantiation: s_f and s_vox hold the round's headers and pool instead — n_merge stops at n_lists_a + n_lists_b there)
         const lds_bytes base = (lds_bytes)(unsigned)(size_t)(tid < n_lists_a ? ent_lists + tid * kEntLdsBytes
                                                             : tid < n_lists_a + n_lists_b ? (unsigned char*)d_slot + (tid - n_lists_a) * kEntLdsBytes
                                                             : tid < n_lists_a + n_lists_b + n_lists_c ? (unsigned char*)s_f + (tid - n_lists_a - n_lists_b) * kEntLdsBytes
@@ -2060,8 +2065,12 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         FE_ENT_T(1);
       }
       if (loaded) {
-        unsigned add_tail[kEntAddCap - EntAdd::reg];
-        { FE_ENT_T0(); rc = ent_propagate<EntAdd>(ec, &L, EntAdd::Store{add_tail, ea.fast_add}, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
+        if constexpr (BIG) {
+          unsigned add_tail[kEntAddCap - EntAdd::reg];
+          { FE_ENT_T0(); rc = ent_propagate<EntAdd>(ec, &L, EntAdd::Store{add_tail, ea.fast_add}, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, depth, arc, true, 1); FE_ENT_T(2); }
+        } else {
+          FE_ENT_T0(); rc = ent_propagate_pre(ec, &L, x_hdr + rank_in_round * ec.ns, x_pool, ea.xpool ? ea.xpool + (long)slot * ea.xpool_stride + rank_in_round * ec.ns * kEntAddCap : nullptr, ea.fast_add, ch.cx, ch.cy, Ev2{ch.e[0], ch.e[1]}, arc, true, 1); FE_ENT_T(2);
+        }
       }
       // a capacity of the fixed record (its list, a step's new crossings, the bend points) or a big parent: the child is left for the
       // big-record pass below (rare: the flag keeps that pass out of every other depth's way)
@@ -2180,12 +2189,82 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
         __syncthreads();
       }
       const int n_prop = s_i[3];
-      int n_merge = n_lists_a + n_lists_b + 2 * n_lists_c;      // threads whose lists fit the borrowed LDS (o_aabb, o_V and, when it has storage of its own, r_f; the voxel table; s_f and s_vox)
+      int n_merge = BIG ? n_lists_a + n_lists_b + 2 * n_lists_c : n_lists_a + n_lists_b;      // threads whose lists fit the borrowed LDS (o_aabb, o_V and, when it has storage of its own, r_f; the voxel table; big-record instantiation: s_f and s_vox as well)
       if (n_merge > 256) n_merge = 256;
       if constexpr (BIG) { if (ea.big_lds_off) n_merge = 256; }      // (lists of their own)
+      if constexpr (!BIG) { if (n_merge * ec.ns > x_hdr_cap) n_merge = x_hdr_cap / ec.ns; }
       { const int rounds = (n_prop + n_merge - 1) / n_merge; if (rounds > 1) n_merge = (n_prop + rounds - 1) / rounds; }      // (even rounds: 178 survivors are 89 + 89, not 131 + 47)
+      // ---- cross_round (fast instantiation): the new crossings of every (child, sampled step) of a round, found in a dense pass of its
+      //      own — see ent_cross_step, ent_device.h.  The packed records of the depth's candidate agents (the union of the parents'
+      //      masks) are staged in the storage the crossing lists use AFTER this pass (o_aabb, o_V); one thread per (child, step) walks
+      //      its parent's candidates in index order out of LDS and leaves the step's list in the pool. ----
+      const int x_stage_cap = (ea.packed && ea.pk_stride > 0) ? (int)((sizeof(double) * (4 * (size_t)(N + S) + kFeObsLds * kHullV * 2)) / (sizeof(double) * (size_t)ea.pk_stride)) : 0;
+      unsigned* x_U = (unsigned*)(((size_t)(f_bits + N) + 3) & ~(size_t)3);      // [MW] union of the parents' agent masks; [MW] popcounts before each word (storage of their own behind f_bits)
+      unsigned short* x_ids = (unsigned short*)o_id;           // [n_stage] the staged agents, ascending (the shortlist's ids are dead by now)
+      double* x_rec = o_aabb;                                  // [n_stage][pk_stride]
+      auto cross_round = [&](int b0, int nr, bool first) {
+        if (first) {      // (once per depth: who is staged)
+          if (tid < MW) { unsigned u = 0u; for (int q = 0; q < nb_prev; q++) u |= m_ent[q * MW + tid]; x_U[tid] = u; }
+          __syncthreads();
+          if (tid == 0) {
+            int acc = 0; for (int w = 0; w < MW; w++) { x_U[MW + w] = (unsigned)acc; acc += __popc(x_U[w]); }
+            const int lim = 2 * (N + S);                           // (ids that fit o_id's storage)
+            int n_st = acc < x_stage_cap ? acc : x_stage_cap; if (n_st > lim) n_st = lim;
+            s_i[13] = n_st;
+          }
+          __syncthreads();
+          const int n_st = s_i[13];
+          if (tid < MW) { unsigned u = x_U[tid]; int k = (int)x_U[MW + tid]; while (u && k < n_st) { const int b = __ffs(u) - 1; u &= u - 1u; x_ids[k++] = (unsigned short)((tid << 5) + b); } }
+          __syncthreads();
+        }
+        const int n_st = s_i[13];
+        const int itv0 = depth > D ? D - 1 : depth - 1;
+        // (every round: the previous round's crossing lists were written over the records)
+        for (int e = tid; e < n_st * ea.pk_stride; e += 256) { const int sl = e / ea.pk_stride, d_ = e - sl * ea.pk_stride; x_rec[e] = ent_rec(ec, x_ids[sl], itv0)[d_]; }
+        if (tid == 0) s_i[12] = 0;                                 // the pool's fill
+        __syncthreads();
+#ifdef NEP_PROFILE_PHASES
+        const long long t_staged_ = clock64();
+#endif
+        auto rec_of = [&](int i, int itv) -> const double* {
+          const int w = i >> 5;
+          const int sl = (int)x_U[MW + w] + __popc(x_U[w] & ((1u << (i & 31)) - 1u));
+          return (sl < n_st && itv == itv0) ? x_rec + (long)sl * ea.pk_stride : ent_rec(ec, i, itv);
+        };
+        for (int q = tid; q < nr * ec.ns; q += 256) {
+          const int rk = q / ec.ns, j = q - rk * ec.ns + 1;
+          const int id = p_list[b0 + rk];
+          const int pr_ = id / NC, cc = id % NC;
+          FeChild ch;
+          fe_child_again<false>(sp, fc, lat, b_end + (prv * MB + pr_) * 6, b_g[prv * MB + pr_], cc / ns, cc % ns, gx, gy, ch);      // (the polynomial and its end point: no control points here)
+          const Ev2 end{ch.e[0], ch.e[1]};
+          const Ev2 pk = ent_step_point(ec, ch.cx, ch.cy, end, j - 1), pk1 = ent_step_point(ec, ch.cx, ch.cy, end, j);
+          ec.m_agent = m_ent + pr_ * MW; ec.m_static = m_stat + pr_ * SW;
+          unsigned add_tail[kEntAddCap - EntAdd::reg];
+          EntAdd add; add.attach(EntAdd::Store{add_tail, ea.fast_add}); add.clear(); add.r0 = add.r1 = add.r2 = add.r3 = 0u;
+          ent_cross_step(add, ec, pk, pk1, depth, j, rec_of);
+          unsigned h = kEntHdrOvf;
+          if (!add.overflow) {
+            const int off = add.n > 0 ? atomicAdd(&s_i[12], add.n) : 0;
+            if (off + add.n <= x_pool_cap) {
+              for (int e = 0; e < add.n; e++) x_pool[off + e] = add.get(e);
+              h = (unsigned)off | ((unsigned)add.n << 16);
+            } else if (ea.xpool && (q + 1) * kEntAddCap <= ea.xpool_stride) {      // the LDS pool is full: this pair's block in global memory
+              unsigned* g = ea.xpool + (long)slot * ea.xpool_stride + q * kEntAddCap;
+              for (int e = 0; e < add.n; e++) g[e] = add.get(e);
+              h = kEntHdrGlobal | ((unsigned)add.n << 16);
+            }
+          }
+          x_hdr[q] = h;
+        }
+#ifdef NEP_PROFILE_PHASES
+        tent[1] += clock64() - t_staged_;      // (profiling builds: this thread's own (child, step) pairs, without the barrier — in the state copy's slot)
+#endif
+        __syncthreads();
+      };
       for (int b0 = 0; b0 < n_prop; b0 += n_merge) {             // that many survivors at a time, one per thread
-        if (tid < n_merge && b0 + tid < n_prop) propagate(p_list[b0 + tid]);
+        if constexpr (!BIG) { FE_ENT_T0(); const int nr = n_prop - b0 < n_merge ? n_prop - b0 : n_merge; cross_round(b0, nr, b0 == 0); FE_ENT_T(0); }      // (profiling builds: counted with the base squares, tent[0])
+        if (tid < n_merge && b0 + tid < n_prop) propagate(p_list[b0 + tid], tid);
         __syncthreads();
       }
       for (int k = tid; k < kFeDd; k += 256) d_slot[k] = -1;     // (lent to the lists above)
@@ -2412,6 +2491,16 @@ void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const
 
 static bool getenv_fe_three() { static const bool v = getenv("NEP_FE_THREE") != nullptr; return v; }      // (A/B: keep the three-workgroup instantiation)
 size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol) { return (size_t)fe_sizes(fc.beam_width, fc.num_samples, num_pol).cap; }
+// survivors per round of the entangle front end's propagation pass (fast instantiation: the crossing lists that fit the borrowed LDS,
+// as the kernel counts them) x sampled steps x kEntAddCap words: the global fallback of cross_round's LDS pool
+size_t frontend_ent_xpool_words(const SceneParams& sp, const nep_fe_cfg& fc, int ent_ns) {
+  const size_t NS = (size_t)sp.num_agents + sp.n_static;
+  const FeSizes z = fe_sizes(fc.beam_width, fc.num_samples, sp.num_pol);
+  const bool rf_alias = 4 * NS + kFeObsLds * kHullV * 2 >= (size_t)z.cap;
+  size_t n = (sizeof(double) * (4 * NS + kFeObsLds * kHullV * 2 + (rf_alias ? 0 : (size_t)z.cap))) / kEntLdsBytes + (sizeof(int) * (size_t)z.dd) / kEntLdsBytes;
+  if (n > 256) n = 256;
+  return n * (size_t)(ent_ns > 0 ? ent_ns : 1) * kEntAddCap;
+}
 size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc, bool ent) {
   const size_t NS = (size_t)sp.num_agents + sp.n_static;
   const FeSizes z = fe_sizes(fc.beam_width, fc.num_samples, sp.num_pol);
@@ -2420,7 +2509,7 @@ size_t frontend_lds_bytes(const SceneParams& sp, const nep_fe_cfg& fc, bool ent)
   size_t b = sizeof(double) * ((size_t)z.cap * (rf_alias ? 1 : 2) + 2 * MB * 6 + 2 * MB + 2 * MB + 4 * MB + 4 * NS + kFeObsLds * kHullV * 2 + 4 * NEP_FE_MAX_SAMPLES)
            + sizeof(long long) * ((size_t)z.cap + z.vis) + sizeof(int) * (z.dd + 2 * NS + 32)
            + sizeof(unsigned short) * z.cap + z.cap + 2 * (NEP_MAX_POL + 1) * MB + MB;
-  if (ent) b = ((b + 3) & ~(size_t)3) + sizeof(unsigned) * MB * (2 * (size_t)((sp.num_agents + 31) >> 5) + (size_t)((sp.n_static + 31) >> 5)) + (size_t)sp.num_agents + (NEP_FE_ENT_WGS == 1 ? 256 * sizeof(nep_fe_ent_state) + 8 : 0);
+  if (ent) b = ((b + 3) & ~(size_t)3) + sizeof(unsigned) * MB * (2 * (size_t)((sp.num_agents + 31) >> 5) + (size_t)((sp.n_static + 31) >> 5)) + (((size_t)sp.num_agents + 3) & ~(size_t)3) + sizeof(unsigned) * 2 * (size_t)((sp.num_agents + 31) >> 5) + (NEP_FE_ENT_WGS == 1 ? 256 * sizeof(nep_fe_ent_state) + 8 : 0);      // (f_bits, then cross_round's union mask and its prefix counts)
   return (b + 15) & ~(size_t)15;
 }
 

@@ -190,9 +190,11 @@ struct FeEntArgs {
   int big_lds_off;               // big-record instantiation: byte offset, in the dynamic LDS, of its per-thread lists (kEntBigLdsBytes each), or 0: none (the launch's LDS would not hold them)
   double* big_beta;              // [redo_cap][256][kEntBigLdsCap] betas of those lists
   int* redo_list; int* redo_count; int redo_cap;      // front end: searches in which a child outgrew the fixed record, listed by frontend_kernel<true, W> for frontend_kernel<true, 2, true> (beyond redo_cap: they stay flagged)
+  unsigned* xpool; int xpool_stride;      // front end (fast instantiation): per slot, room for the lists of new crossings of a round's (child, step) pairs that do not fit the LDS pool ([slots][xpool_stride] words: kEntAddCap per pair), see cross_round
   int fast_cap, fast_add, fast_bend;      // front end: what the fixed record's path accepts (<= NEP_FE_ENT_CAP, 32, NEP_MAX_BEND; nep_batch_set_fe_ent_fast_caps — the tests shrink them to drive ordinary scenes through the big records)
 };
-size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol);      // children per depth of one search (beam_width x lattice)
+size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol);
+size_t frontend_ent_xpool_words(const SceneParams& sp, const nep_fe_cfg& fc, int ent_ns);      // words per slot of FeEntArgs::xpool      // children per depth of one search (beam_width x lattice)
 // (order_buf: [slots] scratch for the launch order, used when the previous launch left its keys — have_history — and the launch is
 // more than one wave of workgroups; null: slot order)
 void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps, const nep_fe_cfg& fc, const nep_fe_start* starts,
