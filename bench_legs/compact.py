@@ -50,7 +50,8 @@ def compact_line(d, detail_path="bench_detail.json"):
     if rs:
         out["reference_solvers"] = {k: _short(rs[k], 40) for k in ("glpk", "gurobi", "eigen") if k in rs}
     rc = d.get("rccl") or {}
-    out["rccl"] = {**_pick(rc, ("initialised", "nranks", "one_rank_all_gather_matches")), **({"exchange": _short(rc["exchange"], 80)} if rc.get("exchange") else {})}
+    out["rccl"] = {**_pick(rc, ("initialised", "nranks", "one_rank_all_gather_matches")), **({"exchange": _short(rc["exchange"], 80)} if rc.get("exchange") else {}),
+                   **({"note": _short(rc["note"], 160)} if rc.get("note") else {})}
     if d.get("per_rank"):
         out["per_rank"] = [{"rank": r["rank"], **_pick(r["kernel_ms"], ("hull", "separator", "qp", "exchange_wait"), 3),
                             "step_ms_p50": _r(r["step_ms_p50"], 3), "wall_s": _r(r["wall_s"], 3)} for r in d["per_rank"]]

@@ -265,12 +265,15 @@ def workload(ctx):
     d_ent = [torch.from_numpy(np.ascontiguousarray(case[k * Sc:(k + 1) * Sc]).reshape(-1)).to(dev) for k in range(C)]
     hull_ev, gather_ev = [], []
     _ev_lists = {"hull": hull_ev, "wait": gather_ev, "frontend": []}
-    with ctx.stdout_to_stderr():
-        rounds = ndist.ShardedRounds(bes, d_local, d_guess, world, rank, native=native, d_ent=d_ent, carry=_carry_ranges(),
-                                     timer=lambda name: ctx.timed(_ev_lists[name]))
+    def build(nat):
+        for k in range(C):                                    # (fresh records: a failed first native step may have half-made a round)
+            d_local[k].copy_(bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])))
+        return ndist.ShardedRounds(bes, d_local, d_guess, world, rank, native=nat, d_ent=d_ent, carry=_carry_ranges(),
+                                   timer=lambda name: ctx.timed(_ev_lists[name]))
+    rounds, native, steps_made, exchange_note = ctx.rounds_with_fallback(build, native)
     nranks = native_nranks(ctx, rounds) if native else ([tdist.get_world_size()] * world if ctx.use_dist and ctx.dist_backend == "nccl" else None)
     step = rounds.step
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup - steps_made, 0)):
         step()
     # what the scenes' replans are after the warm-up rounds: two runs (another N, another chunking) must agree byte for byte
     torch.cuda.synchronize(dev)
@@ -339,7 +342,7 @@ def workload(ctx):
                      "note": ("with the presolve the separator reads a 32-byte box instead of the hull of every obstacle it skips, so it moves a small part of the bytes "
                               "SURVEY 8d prices (traffic_over_algorithmic): frac is the contract's quotient, not a statement about the memory system" if cull > 0.0 else "")},
         "per_gpu_value": value / world, "per_rank": per_rank,
-        "rccl": rccl_record(ctx, nranks, native),
+        "rccl": dict(rccl_record(ctx, nranks, native), **({"note": exchange_note} if exchange_note else {})),
         "scene_digest": scene_digest, "scene_digest_note": "sha1 over (status, K, coefficients) of the 256 replans of each of the first scenes after the warm-up rounds: equal "
                                                            "for any N and any chunking (tests/test_gpu_bench_launch.py)",
         "scene_generation_wait_s": pool.wait_s,

@@ -111,6 +111,43 @@ class Ctx:
             return float(t.item())
         return dt
 
+    def agree(self, ok):
+        """True iff every rank says so (one all-reduce): the ranks must take the same branch"""
+        if not self.use_dist or self.world == 1:
+            return bool(ok)
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.dev if self.dist_backend == "nccl" else "cpu")
+        self.tdist.all_reduce(t, op=self.tdist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def rounds_with_fallback(self, build, native):
+        """build(native) -> dist.ShardedRounds on FRESH device buffers.  With native=True the exchange is the C ABI's own RCCL binding
+        (dlopen'ed librccl, its own communicator, captured into the step's graph) — which no box this was developed on could run
+        with more than one rank.  So the first step is made here, eagerly, under a guard: if the communicator does not come up or
+        the first all-gather fails on ANY rank, every rank falls back to torch.distributed's collective (host-launched steps) and
+        the line says so, instead of the run dying.  -> (rounds, native in force, steps already made, note or None)"""
+        note = None
+        if native:
+            rounds, ok = None, True
+            try:
+                with _stdout_to_stderr():
+                    rounds = build(True)
+                rounds.step()
+                self.torch.cuda.synchronize(self.dev)
+            except Exception as e:                      # noqa: BLE001 — whatever went wrong, the fallback is the same
+                ok = False; note = "native RCCL exchange unusable on this box (%r): torch.distributed exchange instead" % (e,)
+            if self.agree(ok):
+                return rounds, True, 1, None
+            if rounds is not None and rounds.native is not None:
+                try:
+                    rounds.native.close()
+                except Exception:
+                    pass
+            note = note or "native RCCL exchange failed on another rank: torch.distributed exchange instead"
+            print("[bench] rank %d: %s" % (self.rank, note), file=sys.stderr)
+        with _stdout_to_stderr():
+            rounds = build(False)
+        return rounds, False, 0, note
+
     def share(self, arr, S):
         """[scenes per GPU][...] of every rank -> [S][...] on every rank (scene generation is spread over the ranks)"""
         torch, tdist = self.torch, self.tdist

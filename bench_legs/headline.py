@@ -77,14 +77,20 @@ def setup(ctx, c5=None):
     _ev_lists = {"hull": hull_ev, "wait": gather_ev, "frontend": fe_ev}
     rounds = None
     nranks = None
+    H.steps_made, H.exchange_note = 0, None
     if sharded_hulls and not args.safety:
-        with ctx.stdout_to_stderr():                      # (a second communicator: RCCL may print again)
-            rounds = ndist.ShardedRounds(bes, d_local_c, d_guess_c, world, rank, native=native,
-                                         fe=(fe_cfg, d_fe_start_c, d_fe_res_c) if args.frontend else None,
-                                         timer=lambda name: ctx.timed(_ev_lists[name]))
+        def build(nat):
+            for k in range(C):                                # (fresh records: a failed first native step may have half-made a round)
+                d_local_c[k].copy_(bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])))
+            return ndist.ShardedRounds(bes, d_local_c, d_guess_c, world, rank, native=nat,
+                                       fe=(fe_cfg, d_fe_start_c, d_fe_res_c) if args.frontend else None,
+                                       timer=lambda name: ctx.timed(_ev_lists[name]))
+        rounds, native, H.steps_made, H.exchange_note = ctx.rounds_with_fallback(build, native)
         hxs = rounds.hx
         if native:
             nranks = native_nranks(ctx, rounds)
+        elif ctx.use_dist and ctx.dist_backend == "nccl":
+            nranks = [tdist.get_world_size()] * world
     elif ctx.use_dist and ctx.dist_backend == "nccl":
         nranks = [tdist.get_world_size()] * world      # (N = 1: the one-rank process group this run created)
 
@@ -166,7 +172,7 @@ def run(ctx, H):
     torch, tdist, args = ctx.torch, ctx.tdist, ctx.args
     import os
     be, bes = H.be, H.bes
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup - H.steps_made, 0)):
         H.step()
     if ctx.world == 1 and ctx.use_dist and ctx.dist_backend == "nccl" and not (args.safety or args.frontend) and H.C == 1:
         # one rank: the timed steps copy (nothing to exchange); the collective path itself — the all-gather of the committed
@@ -374,7 +380,7 @@ def record(ctx, H):
                              "gives each kernel's own bytes over its own time.  Latency-bound path: ~%d dependent interior-point "
                              "iterations per replan" % round(float(iters.mean()))},
         "per_gpu_value": H.value / world,
-        "rccl": rccl_record(ctx, H.nranks, H.native, H.rccl_one_rank_ok),
+        "rccl": dict(rccl_record(ctx, H.nranks, H.native, H.rccl_one_rank_ok), **({"note": H.exchange_note} if H.exchange_note else {})),
         "roofline_fp64": fp64,
         "reference_budget": "reference TimeLimit 0.05 s/solve, replan timer 20 Hz/agent => <= %d replans/s for %d agents" % (20 * N, N),
     }

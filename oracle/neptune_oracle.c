@@ -604,6 +604,7 @@ static void qr_apply(int rows, int cols, const double* A, const double* beta, in
   }
 }
 
+static int give_up_polish_blocked(int qc, double lam_q, double s_q) { return qc && lam_q > s_q; }   /* (experiment: the ball row active: no polish) */
 /* Mehrotra predictor-corrector primal-dual interior point on
  *   min 1/2 th'P th + q'th  s.t.  E th = e,  G th <= h,  c(th) <= 0.
  * The equality rows are removed numerically first (Householder QR of E': th = th_p + Z y), then
@@ -777,6 +778,59 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     if (alpha < 1e-8) { if (++stall >= 3) break; } else stall = 0;
     for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];
     for (int r = 0; r < mt; r++) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; }
+  }
+  /* EXPERIMENT (ORC_EXP_POLISH): active-set polish of an iterate that never passed the strict tests.  Active set = rows with
+     lam > s at the last iterate; the equality-constrained QP on it is solved exactly (KKT system, Gaussian elimination with
+     partial pivoting); rows with a negative multiplier are dropped, violated rows added, a few times; a point that is primal
+     feasible to 1e-9 with multipliers >= -1e-9 is the optimum (KKT) and is returned as converged. */
+  if (ret != 0 && getenv("ORC_EXP_POLISH") && !give_up_polish_blocked(qc, qc ? lam[m] : 0.0, qc ? s[m] : 1.0)) {
+    int* act = (int*)malloc(sizeof(int) * (m + 1)); int na = 0;
+    for (int r = 0; r < m; r++) if (lam[r] > s[r]) act[na++] = r;
+    int ok = 0, rounds = 0;
+    double* ys = (double*)malloc(sizeof(double) * (ny + 1));
+    double* nu = (double*)malloc(sizeof(double) * (m + 1));
+    for (rounds = 0; rounds < 12; rounds++) {
+      /* keep a maximal independent subset of the active rows (modified Gram-Schmidt, in order): dependent rows of a degenerate
+         vertex make the KKT system singular; the rows left out are checked with everybody else below */
+      { double* Qb = (double*)malloc(sizeof(double) * (size_t)(ny + 1) * ny); int nq = 0, keep = 0;
+        for (int i = 0; i < na; i++) {
+          const double* g = Gy + (size_t)act[i] * ny; double v[64]; double n0 = 0, n1 = 0;
+          for (int c = 0; c < ny; c++) { v[c] = g[c]; n0 += g[c] * g[c]; }
+          for (int k = 0; k < nq; k++) { double d = 0; for (int c = 0; c < ny; c++) d += Qb[k * ny + c] * v[c]; for (int c = 0; c < ny; c++) v[c] -= d * Qb[k * ny + c]; }
+          for (int c = 0; c < ny; c++) n1 += v[c] * v[c];
+          if (nq < ny && n1 > 1e-16 * n0 && n0 > 0) { const double inv = 1.0 / sqrt(n1); for (int c = 0; c < ny; c++) Qb[nq * ny + c] = v[c] * inv; nq++; act[keep++] = act[i]; }
+        }
+        na = keep; free(Qb); }
+      const int nk = ny + na;
+      double* K = (double*)calloc((size_t)nk * (nk + 1), sizeof(double));
+      for (int a = 0; a < ny; a++) { for (int b = 0; b < ny; b++) K[a * (nk + 1) + b] = Py[a * ny + b]; K[a * (nk + 1) + nk] = -qy[a]; }
+      for (int i = 0; i < na; i++) { const double* g = Gy + (size_t)act[i] * ny; for (int c = 0; c < ny; c++) { K[(ny + i) * (nk + 1) + c] = g[c]; K[c * (nk + 1) + ny + i] = g[c]; } K[(ny + i) * (nk + 1) + nk] = hy[act[i]]; }
+      int sing = 0;
+      for (int c = 0; c < nk && !sing; c++) {
+        int pv = c; double best = fabs(K[c * (nk + 1) + c]);
+        for (int r = c + 1; r < nk; r++) if (fabs(K[r * (nk + 1) + c]) > best) { best = fabs(K[r * (nk + 1) + c]); pv = r; }
+        if (!(best > 1e-10)) { sing = 1; break; }
+        if (pv != c) for (int k = 0; k <= nk; k++) { double t = K[c * (nk + 1) + k]; K[c * (nk + 1) + k] = K[pv * (nk + 1) + k]; K[pv * (nk + 1) + k] = t; }
+        for (int r = c + 1; r < nk; r++) { const double f = K[r * (nk + 1) + c] / K[c * (nk + 1) + c]; if (f != 0.0) for (int k = c; k <= nk; k++) K[r * (nk + 1) + k] -= f * K[c * (nk + 1) + k]; }
+      }
+      if (sing) { free(K); break; }
+      double* x = (double*)malloc(sizeof(double) * nk);
+      for (int r = nk - 1; r >= 0; r--) { double v = K[r * (nk + 1) + nk]; for (int k = r + 1; k < nk; k++) v -= K[r * (nk + 1) + k] * x[k]; x[r] = v / K[r * (nk + 1) + r]; }
+      for (int a = 0; a < ny; a++) ys[a] = x[a];
+      for (int i = 0; i < na; i++) nu[i] = x[ny + i];
+      free(x); free(K);
+      int worst = -1; double wv = -1e-9; double numax = 0; for (int i = 0; i < na; i++) if (fabs(nu[i]) > numax) numax = fabs(nu[i]);
+      for (int i = 0; i < na; i++) if (nu[i] < wv * (1.0 + numax)) { wv = nu[i] / (1.0 + numax); worst = i; }
+      if (worst >= 0) { for (int i = worst; i + 1 < na; i++) act[i] = act[i + 1]; na--; continue; }
+      int viol = -1; double vv = 1e-9;
+      for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = -hy[r]; for (int c = 0; c < ny; c++) a += g[c] * ys[c]; if (a > vv) { vv = a; viol = r; } }
+      if (viol >= 0) { int have = 0; for (int i = 0; i < na; i++) have |= act[i] == viol; if (have) break; act[na++] = viol; continue; }
+      if (qc) { double c_; QCY(ys, (double*)NULL, c_); if (c_ > 1e-9) break; }
+      ok = 1; break;
+    }
+    if (trace) fprintf(stderr, "polish: %s after %d rounds, %d active rows\n", ok ? "certified" : "no", rounds, na);
+    if (ok) { memcpy(y, ys, sizeof(double) * ny); ret = 0; loose_ok = 0; }
+    free(act); free(ys); free(nu);
   }
 #undef QCY
   if (ret != 0 && loose_ok) { memcpy(y, yl, sizeof(double) * ny); ret = 0; }
