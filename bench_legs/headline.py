@@ -309,7 +309,7 @@ def record(ctx, H):
     fp64 = {"bound": "fp64 vector (reported next to the HBM roofline, SURVEY 8d)", "achieved": fp64_ach, "peak": 78.6, "unit": "TFLOP/s",
             "frac": fp64_ach / 78.6, "algorithmic_flops_per_replan": flops,
             "note": "an upper bound: SURVEY 8d's count assumes the dense G'WG product; the kernel's structured assembly over 64 base rows executes fewer "
-                    "(executed_*: the instructions the kernel issues, profiles/isa_flops_latest.json)"}
+                    "(executed_*: the fp64 instructions the kernel issues, from the hardware counters of profiles/pmc_summary_latest.txt)"}
     ex_f = acc.executed_flops("nep::" + be.qp_kernel_name()) if launch_replans == 8192 else None
     if ex_f and qp_ms > 0:
         # the fp64 work the kernel ISSUES per launch (hardware instruction counters of the committed PMC summary of this command,

@@ -419,6 +419,18 @@ int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule);
 int nep_batch_set_tolerances(nep_batch_t* h, double residual_tol, double gap_tol);
 int nep_backend_set_tolerances(nep_backend_t* h, double residual_tol, double gap_tol);
 
+/* The active-set polish (on by default).  An interior-point solve that never passes the strict tests ends either on its best LOOSELY
+ * converged iterate (the dual residual sits on a rounding floor above 1e-9: the answer is then within ~1e-4 of the optimum in the
+ * coefficients) or by giving up — which happens on infeasible problems, and on feasible ones whose optimum is degenerate.  With
+ * the polish such a solve is finished exactly: the rows active at its last iterate define an equality-constrained QP that is solved
+ * directly; rows with a negative multiplier leave, violated rows enter, a few times; a point that satisfies every row with
+ * non-negative multipliers is the optimum (KKT) and the solve counts as converged — NEP_OK for the first problem even if the
+ * interior point had gone on to the relaxed one, which is what a solver that finds the optimum reports (solver_gurobi_poly.cpp:
+ * 832-861).  Without a certificate nothing changes.  Not applied to problems with the terminal ball row, nor under the line
+ * presolve.  oracle/ runs the same rule (orc_set_polish).                                                                     */
+int nep_batch_set_polish(nep_batch_t* h, int32_t on);
+int nep_backend_set_polish(nep_backend_t* h, int32_t on);
+
 /* setMaxRuntime for the batched handle (0 = no wall-clock limit, the default): see nep_backend_set_max_runtime. */
 int nep_batch_set_max_runtime(nep_batch_t* h, double seconds);
 

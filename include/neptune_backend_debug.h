@@ -100,6 +100,9 @@ int nep_batch_fe_search_us(nep_batch_t* h, float* us, int32_t cap);
  * The results do not depend on these.                                                                                          */
 int nep_batch_set_fe_ent_fast_caps(nep_batch_t* h, int32_t list_cap, int32_t add_cap, int32_t bend_cap);
 
+/* Test hook: the polish pass of the last replan (nep_batch_set_polish) — how many replans were listed for it and how many it certified. */
+int nep_batch_debug_polish_count(nep_batch_t* h, int32_t* listed, int32_t* certified);
+
 #ifdef __cplusplus
 }
 #endif

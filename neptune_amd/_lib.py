@@ -22,12 +22,13 @@ EXPORTS = [
     "nep_batch_exchange_records", "nep_batch_exchange_slots", "nep_comm_reserve", "nep_batch_ent_bytes",
     "nep_batch_safety_commit", "nep_batch_set_line_cull", "nep_batch_get_line_cull", "nep_batch_reserve_row_scratch",
     "nep_batch_set_line_capacity", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule",
-    "nep_batch_set_tolerances", "nep_backend_set_tolerances", "nep_batch_set_max_runtime",
+    "nep_batch_set_tolerances", "nep_backend_set_tolerances", "nep_batch_set_polish", "nep_backend_set_polish", "nep_batch_set_max_runtime",
     "nep_batch_set_safety_check_prev", "nep_batch_wait", "nep_batch_check", "nep_abi_sizeof", "nep_last_error",
     "nep_version",
 ]
 # every symbol include/neptune_backend_debug.h declares (test hooks, measurement aids, A/B knobs)
 DEBUG_EXPORTS = [
+    "nep_batch_debug_polish_count",
     "nep_backend_debug_time_sequence", "nep_backend_debug_set_lines", "nep_backend_debug_get_lines",
     "nep_debug_regroup_records", "nep_batch_debug_redo_count", "nep_batch_debug_redo_list",
     "nep_batch_line_bucket_bytes", "nep_batch_row_scratch_bytes", "nep_batch_active_rows",

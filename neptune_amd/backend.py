@@ -68,6 +68,10 @@ class PolySolver:
         """not in the reference (which leaves Gurobi's defaults, 1e-6 / 1e-8): the interior point's strict tests (nep_backend_set_tolerances)"""
         check(lib().nep_backend_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
 
+    def setPolish(self, on=True):
+        """not in the reference: the active-set polish of solves that end without the strict tests (nep_backend_set_polish; on by default)"""
+        check(lib().nep_backend_set_polish(self._h, 1 if on else 0))
+
     def setMaxRuntime(self, runtime):
         check(lib().nep_backend_set_max_runtime(self._h, runtime))
 
@@ -433,6 +437,16 @@ class BatchBackend:
     def set_tolerances(self, residual_tol=1e-9, gap_tol=1e-10):
         """the interior point's strict tests (nep_batch_set_tolerances); (1e-6, 1e-8) = Gurobi's defaults, what the reference's solver stops at"""
         check(lib().nep_batch_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
+
+    def set_polish(self, on=True):
+        """the active-set polish of solves that end without the strict tests (on by default): nep_batch_set_polish"""
+        check(lib().nep_batch_set_polish(self._h, 1 if on else 0))
+
+    def polish_count(self):
+        """(replans listed for the polish pass of the last replan, replans it certified): nep_batch_debug_polish_count"""
+        a = C.c_int32(0); b = C.c_int32(0)
+        check(lib().nep_batch_debug_polish_count(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def set_safety_check_prev(self, on=True):
         """also turn down new trajectories that collide with another agent's PREVIOUS record (nep_batch_set_safety_check_prev)"""

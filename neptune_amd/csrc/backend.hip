@@ -99,6 +99,7 @@ struct Engine {
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
   DevBuf<int> d_line_skip, d_redo_list, d_redo_count;   // spatial presolve: skipped LPs per segment, replans listed for the redo pass
+  DevBuf<double> d_polish_z; DevBuf<int> d_polish_flag, d_polish_list, d_polish_count; bool polish = true;      // the active-set polish of solves that end without the strict tests (qp_polish_kernel.hip; nep_*_set_polish)
   DevBuf<long long> d_dbg; bool profile_phases = false;
   DevBuf<int> d_flags;
   // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
@@ -242,6 +243,10 @@ struct Engine {
     if (int e = d_redo_list.ensure((size_t)slots)) return e;
     if (!d_redo_count.p) { if (int e = d_redo_count.ensure(4)) return e; HIPCHK(hipMemset(d_redo_count.p, 0, 4 * sizeof(int))); }      // [0] listed replans, [1] parked line violated, [2] moved beyond the radius
     if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
+    if (int e = d_polish_z.ensure((size_t)slots * 2 * 24)) return e;
+    if (int e = d_polish_flag.ensure((size_t)slots)) return e;
+    if (int e = d_polish_list.ensure((size_t)slots)) return e;
+    if (!d_polish_count.p) { if (int e = d_polish_count.ensure(8)) return e; HIPCHK(hipMemset(d_polish_count.p, 0, 8 * sizeof(int))); }
     profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 32)) return e; }      // (the QP kernels use 16 per slot, the front end 32)
     if (int e = size_row_scratch()) return e;
@@ -266,6 +271,11 @@ struct Engine {
     ps.dbg = profile_phases ? d_dbg.p : nullptr;
     ps.flags = d_flags.p;
     ps.fe_box = d_fe_box.p;
+    // the polish pass finishes what the register kernel's plain instantiation leaves (no presolve: there the parked rows are verified by
+    // the QP kernel itself and a polished point would have to go through that verification again)
+    const bool pol = polish && use_reg && !(sp.cull_radius > 0.0) && d_polish_z.p != nullptr;
+    ps.polish_z = pol ? d_polish_z.p : nullptr; ps.polish_flag = pol ? d_polish_flag.p : nullptr;
+    ps.polish_list = pol ? d_polish_list.p : nullptr; ps.polish_count = pol ? d_polish_count.p : nullptr;
   }
   // packs n polygons into the fixed-stride device layout (vertices, vertex counts, edge lengths)
   bool statics_boxy = true;      // every static polygon uploaded so far has an edge on each side of its bounding box (see pack_statics)
@@ -402,6 +412,7 @@ struct Engine {
       pr.scratch_by_block = ps.scratch_chunks > 0 ? 1 : 0;
       launch_qp_reg(slots, sp, pr, d_tables.p, sc, lds_bytes, st);
     }
+    if (ps.polish_list) launch_qp_polish(slots, sp, ps, d_tables.p, sc, st);      // (the slots the QP kernel listed: nearly always none — workgroups beyond the count return at once)
     have_history = ps.order_key != nullptr;
     if (timing) hipEventRecord(next_event(), st);
     HIPCHK(hipGetLastError());
@@ -411,7 +422,7 @@ struct Engine {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_order.release(); d_fe_order_key.release(); d_fe_us.release(); d_fe_box.release();
     d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release(); d_fe_big.release(); d_fe_big_beta.release(); d_fe_stf.release(); d_fe_stvox.release(); d_fe_xpool.release(); d_fe_big_count.release(); d_fe_big_check.release(); d_fe_big_check_count.release();
-    d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
+    d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_polish_z.release(); d_polish_flag.release(); d_polish_list.release(); d_polish_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
   }
@@ -1393,6 +1404,18 @@ namespace { int set_tol(Engine& E, double res, double gap) {
 int nep_batch_set_tolerances(nep_batch_t* h, double residual_tol, double gap_tol) { if (!h) return fail(NEP_E_ARG, "null handle"); return set_tol(h->eng, residual_tol, gap_tol); }
 int nep_backend_set_tolerances(nep_backend_t* h, double residual_tol, double gap_tol) { if (!h) return fail(NEP_E_ARG, "null handle"); return set_tol(h->eng, residual_tol, gap_tol); }
 
+int nep_batch_set_polish(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; return 0; }
+int nep_backend_set_polish(nep_backend_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; return 0; }
+// Test hook: the last replan's polish pass — replans listed for it (solves that ended without the strict tests), replans certified
+int nep_batch_debug_polish_count(nep_batch_t* h, int32_t* listed, int32_t* certified) {
+  if (!h) return fail(NEP_E_ARG, "null handle");
+  int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipDeviceSynchronize());
+  if (h->eng.d_polish_count.p) HIPCHK(hipMemcpy(c, h->eng.d_polish_count.p, sizeof(c), hipMemcpyDeviceToHost));
+  if (listed) *listed = c[2];
+  if (certified) *certified = c[4];
+  return 0;
+}
 int nep_batch_set_safety_check_prev(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.safety_check_prev = on != 0; return 0; }
 
 int nep_batch_debug_conflicts(nep_batch_t* h, int32_t scene, uint8_t* conflict_out) {

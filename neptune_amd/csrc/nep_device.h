@@ -94,6 +94,10 @@ struct ProblemSet {
   double* states;                // [slots][max_states][12] or null
   nep_traj_rec* commit;          // [slots] or null
   const nep_traj_rec* prev_commit; // [scenes][N] records before this round, or null: what a failed replan's commit slot carries over
+  // active-set polish (qp_polish_kernel.hip): solves that ended without the strict tests leave their last iterate and are listed
+  double* polish_z;              // [slots][2][24] last iterate of the first / relaxed solve (axis stride nz), or null: no polish
+  int* polish_flag;              // [slots] bit m: mode m's solve ended on the loose snapshot or gave up
+  int* polish_list; int* polish_count;      // [slots] listed slots; counters (see qp_polish_kernel)
   long long* dbg;                // [slots][16] phase cycle counters (development aid) or null
   int* flags;                    // [1] sticky NEP_FLAG_* bits raised by the kernels (capacity overflows), or null
   double* fe_box;                // [scenes][num_agents + n_static][num_pol][4] (x0, x1, y0, y1) of the front end's obstacles (fe_box_kernel)
@@ -160,6 +164,7 @@ void launch_qp_order(int n_slots, const int* key, int* order, hipStream_t st);
 void launch_order_xcd(int n_slots, const int* key, int* order, hipStream_t st);      // (key may be null: the XCD placement alone; n_slots % 8 == 0)
 void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                    const SampleSched& sched, size_t lds_bytes, hipStream_t st);
+void launch_qp_polish(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables, const SampleSched& sched, hipStream_t st);
 int qp_reg_slots();
 size_t qp_reg_lds_bytes();
 // pool of big records (ent_device.h: a search node's entangle state beyond the fixed record's capacities), claimed by atomic

@@ -1,0 +1,302 @@
+// qp_polish_kernel.hip — the active-set polish of interior-point solves that ended without passing the strict tests.
+//
+// PolySolverGurobi::optimize (reference neptune/src/solver_gurobi_poly.cpp:804-887) hands the QP to a solver that returns its
+// optimum; the status it reports (:832-861) is decided by whether the rows are feasible.  The interior point of qp_reg_kernel /
+// qp_kernel ends a solve in one of three ways: the strict tests pass (nearly always); the iterate is only LOOSELY converged (the
+// dual residual sits on its rounding floor: the best iterate of a three-iteration window is returned, up to 8e-5 from the optimum
+// in the coefficients); or the iteration gives up — on infeasible problems, but also on feasible ones whose optimum is degenerate
+// (no strict complementarity: the gap stalls near 1e-2; tests/golden/moving_hard_cases.npz has them with HiGHS's verdict).
+// The last two are finished here, exactly, by a kernel of its own over the few slots the QP kernel listed (ps.polish_list):
+//
+//   active set  = the rows whose slack at the solve's last iterate is below 1e-6 (1 + |rhs|);
+//   repeat <= 12 times: solve the equality-constrained QP on a maximal independent subset of it (Schur complement of the
+//   block-diagonal Hessian, Cholesky with dependent rows left out); drop the row with the most negative multiplier, else add the
+//   most violated row, else stop;
+//   certificate: every row satisfied to 1e-9 (1 + |rhs|), every multiplier >= -1e-9 (1 + max|nu|) — the KKT conditions of a
+//   strictly convex QP: the point IS the optimum, whatever iterate it was found from; an infeasible problem can never pass.
+//
+// A certified mode-0 problem is NEP_OK (also when the interior point had gone on to the relaxed solve), a certified relaxed one
+// NEP_RELAXED; without a certificate everything stays as the QP kernel left it.  Not for problems with the terminal ball row (a
+// quadratic constraint, :680-702) and not under the line presolve (whose parked rows are verified by the QP kernel itself).
+// oracle/neptune_oracle.c::qp_solve runs the same rule; the two agree to the accuracy of a 24 x 24 solve (tests compare them).
+#include <hip/hip_runtime.h>
+
+#include "nep_device.h"
+
+namespace nep {
+namespace {
+constexpr int PN = 24;          // reduced variables: 3 axes x nz <= 8
+constexpr int PA = 40;          // active rows carried (an independent subset has at most PN)
+constexpr int PST = PA + 1;     // LDS row stride of the Schur complement
+constexpr double kActTol = 1e-6, kFeasTol = 1e-9, kDualTol = 1e-9, kPivTol = 1e-12;
+}  // namespace
+
+// one listed slot (a wave); returns true when a problem of the slot was certified and its outputs rewritten
+__device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const QpTable* __restrict__ tables, const SampleSched& sched, int slot) {
+  const int flags = ps.polish_flag[slot];
+  const int lane = threadIdx.x;
+  const nep_guess* g = ps.guess + slot;
+  nep_solution* sol = ps.solution + slot;
+  const int K = g->K;
+  if (K < 1 || K > NEP_MAX_POL || K > sp.num_pol) return false;
+  const int R = 8 * K;
+  const double T = sp.T_span;
+
+  __shared__ double sB[kMaxR][kNZ], sOff[kMaxR][3], sHi[kNZ][kNZ], sG[PN], sZ[PN], sZ0[PN], sInit[9], sFin[3], sCoef[96], sTheta[96];
+  __shared__ double sA[PA][PN + 1], sHA[PA][PN + 1], sS[PA][PST], sRhs[PA], sNu[PA], sRowH[PA], sRed[64];
+  __shared__ int sAct[PA], sDrop[PA], sCnt[NEP_MAX_POL + 1], sI[8], sRedI[64];
+
+  if (lane < 96) sCoef[lane] = ((lane % 32) / 4 < K) ? (&g->coeff[0][0][0])[lane] : 0.0;
+  for (int e = 64 + lane; e < 96; e += 64) sCoef[e] = ((e % 32) / 4 < K) ? (&g->coeff[0][0][0])[e] : 0.0;
+  if (lane <= NEP_MAX_POL) {
+    int o = 0;
+    for (int i = 0; i < NEP_MAX_POL; i++) { if (i == lane) sCnt[i] = o; o += i < K ? line_count(ps.line_cnt[(long)slot * NEP_MAX_POL + i]) : 0; }
+    if (lane == NEP_MAX_POL) sCnt[NEP_MAX_POL] = o;
+  }
+  __syncthreads();
+  if (lane < 9) sInit[lane] = sCoef[((lane / 3) * 8 + 0) * 4 + 1 + (lane % 3)];      // b0, c0, d0 per axis (:390-396)
+  if (lane < 3) { const double* c = sCoef + (lane * 8 + (K - 1)) * 4; sFin[lane] = ((T * T * T) * c[0] + (T * T) * c[1] + T * c[2]) + c[3]; }      // final_pos_ (:226-228)
+  __syncthreads();
+  {
+    const double dx = sCoef[3] - sFin[0], dy = sCoef[32 + 3] - sFin[1], dz = sCoef[64 + 3] - sFin[2];
+    if (sqrt(dx * dx + dy * dy + dz * dz) < 1.0) return false;      // the terminal ball row is part of this problem (:697-702): not polished
+  }
+  const int L = sCnt[NEP_MAX_POL];
+  const int n_rows = 6 * R + 4 * L;
+  const double* bucket0 = ps.line_nd + (long)slot * NEP_MAX_POL * sp.lines_cap * 3;
+
+  for (int mode = 0; mode < 2; mode++) {
+    if (!((flags >> mode) & 1)) { if (mode == 0) continue; else break; }
+    const QpTable* __restrict__ tb = tables + mode * (kMaxK + 1) + K;
+    const int nz = mode == 1 ? K : (K > 2 ? K - 2 : 0), n = 3 * nz;
+    if (nz == 0) continue;
+    __syncthreads();
+    for (int e = lane; e < kMaxR * kNZ; e += 64) sB[e / kNZ][e % kNZ] = (e / kNZ) < R ? tb->B[e / kNZ][e % kNZ] : 0.0;
+    for (int e = lane; e < kMaxR * 3; e += 64) { const int rho = e / 3, ax = e % 3; sOff[rho][ax] = rho < R ? tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2] : 0.0; }
+    sHi[lane / kNZ][lane % kNZ] = tb->HaxInv[lane / kNZ][lane % kNZ];
+    if (lane < PN) {
+      const int ax = lane / kNZ, e = lane % kNZ;      // (kNZ = 8: the axis blocks are padded to eight here; entries e >= nz stay zero)
+      double gv = 0.0;
+      if (e < nz && ax < 3) gv = (tb->Gi[e][0] * sInit[ax * 3] + tb->Gi[e][1] * sInit[ax * 3 + 1] + tb->Gi[e][2] * sInit[ax * 3 + 2]) - 2.0 * sp.weight * tb->ep[e] * sFin[ax];
+      sG[lane] = gv;
+      sZ[lane] = (e < nz) ? ps.polish_z[((long)slot * 2 + mode) * PN + ax * nz + e] : 0.0;
+    }
+    __syncthreads();
+    // (from here on a variable is addressed as [axis][e] with stride kNZ: n_pad = 24 slots, unused ones zero)
+    bool finite = true;
+    for (int c = 0; c < PN; c++) finite = finite && (fabs(sZ[c]) < 1e100);
+    if (!finite) continue;
+    if (lane < PN) { const int ax = lane / kNZ, e = lane % kNZ; double v = 0.0; for (int c = 0; c < kNZ; c++) v -= sHi[e][c] * sG[ax * kNZ + c]; sZ0[lane] = v; }      // the minimiser without rows: -H^-1 g
+
+    // a row of the problem: r < 6R: box row of (axis, base row, side); else line row (line l, control point k)
+    auto row_eval = [&](int r, const double* z, double& rhs) -> double {      // -> slack h - a.z, rhs = the reference row's right-hand side
+      if (r < 6 * R) {
+        const int side = r & 1, q = r >> 1, ax = q / R, rho = q - ax * R;
+        const double hi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
+        const double lo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
+        double v = sOff[rho][ax];
+        for (int c = 0; c < kNZ; c++) v += sB[rho][c] * z[ax * kNZ + c];
+        rhs = side ? -lo : hi;
+        return side ? v - lo : hi - v;
+      }
+      const int q = r - 6 * R, l = q >> 2, k = q & 3;
+      int i = 0;
+      for (int j = 1; j < NEP_MAX_POL; j++) i += (l >= sCnt[j]) ? 1 : 0;
+      const double* nd = bucket0 + ((long)i * sp.lines_cap + (l - sCnt[i])) * 3;
+      const int rho = 4 * i + k;
+      double vx = sOff[rho][0], vy = sOff[rho][1];
+      for (int c = 0; c < kNZ; c++) { vx += sB[rho][c] * z[c]; vy += sB[rho][c] * z[kNZ + c]; }
+      rhs = 1.0 - nd[2];
+      return rhs - (nd[0] * vx + nd[1] * vy);
+    };
+    auto row_vec = [&](int r, double* a, double& h) {      // the row in z-space: a.z <= h
+      for (int c = 0; c < PN; c++) a[c] = 0.0;
+      if (r < 6 * R) {
+        const int side = r & 1, q = r >> 1, ax = q / R, rho = q - ax * R;
+        const double hi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
+        const double lo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
+        for (int c = 0; c < kNZ; c++) a[ax * kNZ + c] = side ? -sB[rho][c] : sB[rho][c];
+        h = side ? sOff[rho][ax] - lo : hi - sOff[rho][ax];
+        return;
+      }
+      const int q = r - 6 * R, l = q >> 2, k = q & 3;
+      int i = 0;
+      for (int j = 1; j < NEP_MAX_POL; j++) i += (l >= sCnt[j]) ? 1 : 0;
+      const double* nd = bucket0 + ((long)i * sp.lines_cap + (l - sCnt[i])) * 3;
+      const int rho = 4 * i + k;
+      for (int c = 0; c < kNZ; c++) { a[c] = nd[0] * sB[rho][c]; a[kNZ + c] = nd[1] * sB[rho][c]; }
+      h = (1.0 - nd[2]) - (nd[0] * sOff[rho][0] + nd[1] * sOff[rho][1]);
+    };
+
+    // ---- the active set at the solve's last iterate ----
+    if (lane == 0) sI[0] = 0;
+    __syncthreads();
+    for (int r0 = 0; r0 < n_rows; r0 += 64) {      // (in row order: the ballot keeps the list sorted)
+      const int r = r0 + lane;
+      bool act = false;
+      if (r < n_rows) { double rhs; const double s = row_eval(r, sZ, rhs); act = s < kActTol * (1.0 + fabs(rhs)); }
+      const unsigned long long m = __ballot(act);
+      const int base = sI[0];
+      if (act) { const int p = base + __popcll(m & ((1ull << lane) - 1ull)); if (p < PA) sAct[p] = r; }
+      __syncthreads();
+      if (lane == 0) sI[0] = base + __popcll(m);
+      __syncthreads();
+    }
+    int na = sI[0];
+    if (na > PA) continue;                                     // (more candidate rows than the kernel carries: left as it is)
+    bool certified = false;
+    for (int round = 0; round < 12; round++) {
+      __syncthreads();
+      // rows of the active set in z-space, H^-1 A', the Schur complement S = A H^-1 A' and its right-hand side A z0 - h
+      if (lane < na) {
+        double a[PN], h;
+        row_vec(sAct[lane], a, h);
+        double az0 = 0.0;
+        for (int c = 0; c < PN; c++) { sA[lane][c] = a[c]; az0 += a[c] * sZ0[c]; }
+        for (int ax = 0; ax < 3; ax++) for (int e = 0; e < kNZ; e++) { double v = 0.0; for (int c = 0; c < kNZ; c++) v += sHi[e][c] * a[ax * kNZ + c]; sHA[lane][ax * kNZ + e] = v; }
+        sRhs[lane] = az0 - h; sRowH[lane] = h;
+      }
+      __syncthreads();
+      for (int e = lane; e < na * na; e += 64) { const int i = e / na, j = e - i * na; double v = 0.0; for (int c = 0; c < PN; c++) v += sA[i][c] * sHA[j][c]; sS[i][j] = v; }
+      __syncthreads();
+      // Cholesky, column by column; a row whose pivot vanishes is dependent on the rows before it: left out (nu = 0)
+      if (lane < na) sDrop[lane] = 0;
+      for (int j = 0; j < na; j++) {
+        __syncthreads();
+        if (lane == 0) {
+          double d = sS[j][j]; const double d0 = d;
+          for (int k = 0; k < j; k++) d -= sS[j][k] * sS[j][k];
+          if (!(d > kPivTol * d0) || !(d0 > 0.0)) { sDrop[j] = 1; for (int k = 0; k < j; k++) sS[j][k] = 0.0; sS[j][j] = 1.0; sRhs[j] = 0.0; }
+          else sS[j][j] = sqrt(d);
+        }
+        __syncthreads();
+        if (lane > j && lane < na) {
+          double v = 0.0;
+          if (!sDrop[j]) { v = sS[lane][j]; for (int k = 0; k < j; k++) v -= sS[lane][k] * sS[j][k]; v /= sS[j][j]; }
+          sS[lane][j] = v;
+        }
+      }
+      __syncthreads();
+      if (lane == 0) {      // L y = rhs, L' nu = y (na <= 40: a few hundred operations)
+        for (int i = 0; i < na; i++) { double v = sRhs[i]; for (int k = 0; k < i; k++) v -= sS[i][k] * sNu[k]; sNu[i] = v / sS[i][i]; }
+        for (int i = na - 1; i >= 0; i--) { double v = sNu[i]; for (int k = i + 1; k < na; k++) v -= sS[k][i] * sNu[k]; sNu[i] = sDrop[i] ? 0.0 : v / sS[i][i]; }
+      }
+      __syncthreads();
+      if (lane < PN) { double v = sZ0[lane]; for (int i = 0; i < na; i++) v -= sHA[i][lane] * sNu[i]; sZ[lane] = v; }      // z = z0 - H^-1 A' nu
+      __syncthreads();
+      // multipliers: the most negative one leaves
+      {
+        double numax = 0.0; for (int i = 0; i < na; i++) numax = fmax(numax, fabs(sNu[i]));
+        int worst = -1; double wv = -kDualTol * (1.0 + numax);
+        for (int i = 0; i < na; i++) if (!sDrop[i] && sNu[i] < wv) { wv = sNu[i]; worst = i; }
+        if (worst >= 0) {
+          __syncthreads();
+          if (lane == 0) { for (int i = worst; i + 1 < na; i++) sAct[i] = sAct[i + 1]; }
+          na--;
+          continue;
+        }
+      }
+      // every row at the new point: the most violated one enters
+      double vmax = 0.0; int vrow = -1;
+      for (int r = lane; r < n_rows; r += 64) { double rhs; const double s = row_eval(r, sZ, rhs); const double v = -s / (1.0 + fabs(rhs)); if (v > kFeasTol && v > vmax) { vmax = v; vrow = r; } }
+      sRed[lane] = vmax; sRedI[lane] = vrow;
+      __syncthreads();
+      if (lane == 0) { double bv = 0.0; int br = -1; for (int t = 0; t < 64; t++) if (sRedI[t] >= 0 && (sRed[t] > bv || (sRed[t] == bv && sRedI[t] < br))) { bv = sRed[t]; br = sRedI[t]; } sI[1] = br; }
+      __syncthreads();
+      const int viol = sI[1];
+      if (viol < 0) { certified = true; break; }
+      bool have = false; for (int i = 0; i < na; i++) have = have || sAct[i] == viol;
+      if (have || na >= PA) break;                              // (a row of the set still violated: dependent rows in conflict — no certificate)
+      __syncthreads();
+      if (lane == 0) { int pos = na; while (pos > 0 && sAct[pos - 1] > viol) { sAct[pos] = sAct[pos - 1]; pos--; } sAct[pos] = viol; }
+      na++;
+    }
+    if (!certified) continue;
+    // ---- the optimum: coefficients, objective, outputs — as the interior-point kernels write them ----
+    __syncthreads();
+    for (int t = lane; t < 12 * K; t += 64) {      // theta = Th z + ThU init
+      const int ax = t / (4 * K), r = t - ax * 4 * K;
+      double v = tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2];
+      for (int c = 0; c < kNZ; c++) v += c < nz ? tb->Th[r][c] * sZ[ax * kNZ + c] : 0.0;
+      sTheta[(ax * 8 + r / 4) * 4 + (r % 4)] = v;
+    }
+    for (int t = lane; t < 96; t += 64) if ((t % 32) / 4 >= K) sTheta[t] = 0.0;
+    __syncthreads();
+    double obj = 0.0;
+    if (lane == 0) {      // the reference's objective on the returned coefficients (:322-383; relaxed: :838-861)
+      for (int ax = 0; ax < 3; ax++) {
+        for (int i = 0; i < K; i++) { const double a = sTheta[(ax * 8 + i) * 4]; obj += 36.0 * T * a * a; }
+        const double* c = sTheta + (ax * 8 + (K - 1)) * 4;
+        const double pe = ((T * T * T) * c[0] + (T * T) * c[1] + T * c[2]) + c[3], ve = (3 * T * T) * c[0] + (2 * T) * c[1] + c[2], ae = (6 * T) * c[0] + 2 * c[1];
+        obj += sp.weight * (pe - sFin[ax]) * (pe - sFin[ax]);
+        if (mode == 1) obj += sp.weight * (ve * ve + ae * ae);
+      }
+    }
+    const double dix = sCoef[3] - sFin[0], diy = sCoef[32 + 3] - sFin[1];
+    if (sqrt(dix * dix + diy * diy) < 1.0) { if (lane < 32) sTheta[64 + lane] = sCoef[64 + lane]; }      // :879-880
+    __syncthreads();
+    for (int t = lane; t < 96; t += 64) (&sol->coeff[0][0][0])[t] = sTheta[t];
+    if (lane <= NEP_MAX_POL) sol->times[lane] = (lane <= K) ? g->t_start + lane * T : 0.0;
+    const int ns_all = sched.n[K];
+    const int ns = ns_all < sp.max_states ? ns_all : sp.max_states;
+    if (lane == 0) {
+      sol->stats.status = mode; sol->stats.objective = obj; sol->K = K; sol->n_states = ns;
+    }
+    if (ps.states) {
+      for (int s = lane; s < ns; s += 64) {      // generatePwpOut's samples (:911-934)
+        const int i = sched.seg[K * sp.max_states + s]; const double dt = sched.dt[K * sp.max_states + s];
+        double* st = ps.states + ((long)slot * sp.max_states + s) * NEP_STATE_DOUBLES;
+        for (int ax = 0; ax < 3; ax++) {
+          const double* c = sTheta + (ax * 8 + i) * 4;
+          st[ax] = ((c[0] * (dt * dt * dt) + c[1] * (dt * dt)) + c[2] * dt) + c[3];
+          st[3 + ax] = (c[0] * (3 * dt * dt) + c[1] * (2 * dt)) + c[2];
+          st[6 + ax] = c[0] * (6 * dt) + c[1] * 2;
+          st[9 + ax] = c[0] * 6;
+        }
+      }
+    }
+    if (ps.commit) {      // the record the agent publishes (neptune_ros.cpp:434-480), as the interior-point kernels write it
+      nep_traj_rec* cr = ps.commit + slot;
+      const int own = sp.first_local + (slot % sp.n_local);
+      if (lane == 0) {
+        cr->id = own + 1; cr->is_agent = 1; cr->n_bend = 1; cr->valid = 1;
+        for (int a = 0; a < 3; a++) { cr->bbox[a] = 2 * sp.drone_radius; cr->pos[a] = sTheta[(a * 8) * 4 + 3]; }
+        cr->bend[0][0] = ps.pb[2 * own]; cr->bend[0][1] = ps.pb[2 * own + 1];
+        cr->pwp.n_seg = K;
+      }
+      if (lane <= NEP_TRAJ_MAX_SEG) cr->pwp.times[lane] = (lane <= K) ? g->t_start + lane * T : 0.0;
+      for (int e = lane; e < 3 * NEP_TRAJ_MAX_SEG * 4; e += 64) {
+        const int ax = e / (NEP_TRAJ_MAX_SEG * 4), r = e % (NEP_TRAJ_MAX_SEG * 4), seg = r / 4, j = r % 4;
+        (&cr->pwp.coeff[0][0][0])[e] = (seg < K) ? sTheta[(ax * 8 + seg) * 4 + j] : 0.0;
+      }
+    }
+    return true;      // (a certified first problem is the answer: the relaxed one is not looked at)
+  }
+  return false;
+}
+
+// ps.polish_count: [0] slots listed by the QP kernel(s) of this launch sequence, [1] workgroups of this kernel that are done, [2] the
+// listed count of the last launch and [4] how many of them were certified (test hook), [3] certified so far.  The last workgroup to
+// finish zeroes [0], [1], [3] for the next launch sequence: no memset node in a captured step.
+__global__ __launch_bounds__(64) void qp_polish_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
+  const int n_listed = ps.polish_count[0];
+  bool ok = false;
+  if ((int)blockIdx.x < n_listed) ok = polish_slot(sp, ps, tables, sched, ps.polish_list[blockIdx.x]);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (ok) atomicAdd(ps.polish_count + 3, 1);
+    __threadfence();
+    if (atomicAdd(ps.polish_count + 1, 1) == (int)gridDim.x - 1) {
+      ps.polish_count[2] = n_listed; ps.polish_count[4] = atomicAdd(ps.polish_count + 3, 0);
+      ps.polish_count[0] = 0; ps.polish_count[1] = 0; ps.polish_count[3] = 0;
+    }
+  }
+}
+
+// grid: one workgroup per entry the list can hold; workgroups beyond the device-side count return at once (graph-capturable)
+void launch_qp_polish(int cap, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables, const SampleSched& sched, hipStream_t st) {
+  if (cap <= 0 || !ps.polish_list) return;
+  hipLaunchKernelGGL(qp_polish_kernel, dim3(cap), dim3(64), 0, st, sp, ps, tables, sched);
+}
+
+}  // namespace nep

@@ -604,7 +604,10 @@ static void qr_apply(int rows, int cols, const double* A, const double* beta, in
   }
 }
 
-static int give_up_polish_blocked(int qc, double lam_q, double s_q) { return qc && lam_q > s_q; }   /* (experiment: the ball row active: no polish) */
+static int g_polish = 1, g_last_polished = 0;      /* orc_set_polish: the active-set polish of solves that end without the strict tests (on by default) */
+void orc_set_polish(int on) { g_polish = on; }
+int orc_last_polished(void) { const int v = g_last_polished; g_last_polished = 0; return v; }      /* (test hook: did a solve since the last call end on the polish?) */
+static double hy_abs_slack(const double* g, const double* y, double h, int ny) { double a = h; for (int c = 0; c < ny; c++) a -= g[c] * y[c]; return a; }
 /* Mehrotra predictor-corrector primal-dual interior point on
  *   min 1/2 th'P th + q'th  s.t.  E th = e,  G th <= h,  c(th) <= 0.
  * The equality rows are removed numerically first (Householder QR of E': th = th_p + Z y), then
@@ -779,20 +782,26 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     for (int a = 0; a < ny; a++) y[a] += alpha * dy[a];
     for (int r = 0; r < mt; r++) { s[r] += alpha * ds[r]; lam[r] += alpha * dl[r]; }
   }
-  /* EXPERIMENT (ORC_EXP_POLISH): active-set polish of an iterate that never passed the strict tests.  Active set = rows with
-     lam > s at the last iterate; the equality-constrained QP on it is solved exactly (KKT system, Gaussian elimination with
-     partial pivoting); rows with a negative multiplier are dropped, violated rows added, a few times; a point that is primal
-     feasible to 1e-9 with multipliers >= -1e-9 is the optimum (KKT) and is returned as converged. */
-  if (ret != 0 && getenv("ORC_EXP_POLISH") && !give_up_polish_blocked(qc, qc ? lam[m] : 0.0, qc ? s[m] : 1.0)) {
+  /* Active-set polish (round 5; the product runs the same rule in qp_polish_kernel).  A solve that never passed the strict tests
+     ends on the loose snapshot, or gives up (discarded predictors, stall, iteration cap, lost pivot) — the first on iterates whose
+     dual residual sits on its rounding floor, the second also on FEASIBLE problems whose optimum is degenerate (no strict
+     complementarity: the gap stalls at 1e-2, tests/golden/moving_hard_cases.npz).  Both are finished exactly: the rows whose slack
+     at the last iterate is below 1e-6 (1 + |h|) are taken as the active set, the equality-constrained QP on a maximal independent
+     subset of them is solved directly (KKT system), rows with a negative multiplier are dropped and violated rows added, at most
+     twelve times; a point that satisfies every row to 1e-9 (1 + |h|) with multipliers >= -1e-9 (1 + max|nu|) is the optimum of a
+     strictly convex QP whatever iterate it was found from, and the solve counts as converged.  Not for problems with the terminal
+     ball row (a quadratic constraint); an infeasible problem can never be certified (every row is checked). */
+  if (ret != 0 && !qc && g_polish) {
+    const double* ysrc = loose_ok ? yl : y;
+    int finite = 1; for (int c = 0; c < ny; c++) if (!(fabs(ysrc[c]) < 1e100)) finite = 0;
     int* act = (int*)malloc(sizeof(int) * (m + 1)); int na = 0;
-    for (int r = 0; r < m; r++) if (lam[r] > s[r]) act[na++] = r;
+    if (finite) for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = hy_abs_slack(g, ysrc, hy[r], ny); if (a < 1e-6 * (1.0 + fabs(Q->rows[r].rhs))) act[na++] = r; }
     int ok = 0, rounds = 0;
     double* ys = (double*)malloc(sizeof(double) * (ny + 1));
     double* nu = (double*)malloc(sizeof(double) * (m + 1));
-    for (rounds = 0; rounds < 12; rounds++) {
-      /* keep a maximal independent subset of the active rows (modified Gram-Schmidt, in order): dependent rows of a degenerate
-         vertex make the KKT system singular; the rows left out are checked with everybody else below */
-      { double* Qb = (double*)malloc(sizeof(double) * (size_t)(ny + 1) * ny); int nq = 0, keep = 0;
+    double* Qb = (double*)malloc(sizeof(double) * (size_t)(ny + 1) * ny);
+    for (rounds = 0; finite && rounds < 12; rounds++) {
+      { int nq = 0, keep = 0;      /* a maximal independent subset, in row order (modified Gram-Schmidt) */
         for (int i = 0; i < na; i++) {
           const double* g = Gy + (size_t)act[i] * ny; double v[64]; double n0 = 0, n1 = 0;
           for (int c = 0; c < ny; c++) { v[c] = g[c]; n0 += g[c] * g[c]; }
@@ -800,10 +809,10 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
           for (int c = 0; c < ny; c++) n1 += v[c] * v[c];
           if (nq < ny && n1 > 1e-16 * n0 && n0 > 0) { const double inv = 1.0 / sqrt(n1); for (int c = 0; c < ny; c++) Qb[nq * ny + c] = v[c] * inv; nq++; act[keep++] = act[i]; }
         }
-        na = keep; free(Qb); }
+        na = keep; }
       const int nk = ny + na;
       double* K = (double*)calloc((size_t)nk * (nk + 1), sizeof(double));
-      for (int a = 0; a < ny; a++) { for (int b = 0; b < ny; b++) K[a * (nk + 1) + b] = Py[a * ny + b]; K[a * (nk + 1) + nk] = -qy[a]; }
+      for (int a_ = 0; a_ < ny; a_++) { for (int b_ = 0; b_ < ny; b_++) K[a_ * (nk + 1) + b_] = Py[a_ * ny + b_]; K[a_ * (nk + 1) + nk] = -qy[a_]; }
       for (int i = 0; i < na; i++) { const double* g = Gy + (size_t)act[i] * ny; for (int c = 0; c < ny; c++) { K[(ny + i) * (nk + 1) + c] = g[c]; K[c * (nk + 1) + ny + i] = g[c]; } K[(ny + i) * (nk + 1) + nk] = hy[act[i]]; }
       int sing = 0;
       for (int c = 0; c < nk && !sing; c++) {
@@ -816,21 +825,20 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       if (sing) { free(K); break; }
       double* x = (double*)malloc(sizeof(double) * nk);
       for (int r = nk - 1; r >= 0; r--) { double v = K[r * (nk + 1) + nk]; for (int k = r + 1; k < nk; k++) v -= K[r * (nk + 1) + k] * x[k]; x[r] = v / K[r * (nk + 1) + r]; }
-      for (int a = 0; a < ny; a++) ys[a] = x[a];
+      for (int a_ = 0; a_ < ny; a_++) ys[a_] = x[a_];
       for (int i = 0; i < na; i++) nu[i] = x[ny + i];
       free(x); free(K);
-      int worst = -1; double wv = -1e-9; double numax = 0; for (int i = 0; i < na; i++) if (fabs(nu[i]) > numax) numax = fabs(nu[i]);
-      for (int i = 0; i < na; i++) if (nu[i] < wv * (1.0 + numax)) { wv = nu[i] / (1.0 + numax); worst = i; }
+      int worst = -1; double numax = 0; for (int i = 0; i < na; i++) if (fabs(nu[i]) > numax) numax = fabs(nu[i]);
+      { double wv = -1e-9 * (1.0 + numax); for (int i = 0; i < na; i++) if (nu[i] < wv) { wv = nu[i]; worst = i; } }
       if (worst >= 0) { for (int i = worst; i + 1 < na; i++) act[i] = act[i + 1]; na--; continue; }
-      int viol = -1; double vv = 1e-9;
-      for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = -hy[r]; for (int c = 0; c < ny; c++) a += g[c] * ys[c]; if (a > vv) { vv = a; viol = r; } }
-      if (viol >= 0) { int have = 0; for (int i = 0; i < na; i++) have |= act[i] == viol; if (have) break; act[na++] = viol; continue; }
-      if (qc) { double c_; QCY(ys, (double*)NULL, c_); if (c_ > 1e-9) break; }
+      int viol = -1; double vv = 0.0;
+      for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; const double a = -hy_abs_slack(g, ys, hy[r], ny) / (1.0 + fabs(Q->rows[r].rhs)); if (a > 1e-9 && a > vv) { vv = a; viol = r; } }
+      if (viol >= 0) { int have = 0; for (int i = 0; i < na; i++) have |= act[i] == viol; if (have) break; int pos = na; while (pos > 0 && act[pos - 1] > viol) { act[pos] = act[pos - 1]; pos--; } act[pos] = viol; na++; continue; }
       ok = 1; break;
     }
     if (trace) fprintf(stderr, "polish: %s after %d rounds, %d active rows\n", ok ? "certified" : "no", rounds, na);
-    if (ok) { memcpy(y, ys, sizeof(double) * ny); ret = 0; loose_ok = 0; }
-    free(act); free(ys); free(nu);
+    if (ok) { memcpy(y, ys, sizeof(double) * ny); ret = 0; loose_ok = 0; g_last_polished = 1; }
+    free(act); free(ys); free(nu); free(Qb);
   }
 #undef QCY
   if (ret != 0 && loose_ok) { memcpy(y, yl, sizeof(double) * ny); ret = 0; }

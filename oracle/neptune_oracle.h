@@ -99,6 +99,9 @@ void orc_set_separator_rule(int rule);
 
 /* the interior point's strict tests (thread-local; defaults 1e-9 / 1e-10; checker of nep_batch_set_tolerances) */
 void orc_set_qp_tolerances(double residual_tol, double gap_tol);
+/* the active-set polish of interior-point solves that end without passing the strict tests (qp_solve; on by default) */
+void orc_set_polish(int on);
+int orc_last_polished(void);
 
 /* PolySolverGurobi::optimize (solver_gurobi_poly.cpp:804-887) for one agent.
  *   K, coeff_init: setInitTrajectory (:187-244)

@@ -78,6 +78,8 @@ def lib():
         L.orc_separator_glpk_class.restype = C.c_int
         L.orc_set_separator_rule.argtypes = [C.c_int]; L.orc_set_separator_rule.restype = None
         L.orc_set_qp_tolerances.argtypes = [C.c_double, C.c_double]; L.orc_set_qp_tolerances.restype = None
+        L.orc_set_polish.argtypes = [C.c_int]; L.orc_set_polish.restype = None
+        L.orc_last_polished.argtypes = []; L.orc_last_polished.restype = C.c_int
         L.orc_optimize.argtypes = [C.POINTER(orc_params), C.c_int, C.c_void_p, C.c_int,
                                    C.POINTER(orc_polys), C.POINTER(orc_polys), C.POINTER(orc_ent),
                                    C.c_int, C.c_void_p, C.c_void_p, C.POINTER(orc_result)]
@@ -162,6 +164,15 @@ def set_separator_rule(rule):
     """0: the largest-gap vertex (default); 1: the GLPK-class simplex's vertex — for every separator call of the restated path
     made from this thread afterwards (checker of nep_batch_set_separator_rule)"""
     lib().orc_set_separator_rule(int(rule))
+
+
+def set_polish(on=True):
+    """the active-set polish of solves that end without the strict tests (on by default; the product's twin: nep_batch_set_polish)"""
+    lib().orc_set_polish(1 if on else 0)
+
+
+def last_polished():
+    return bool(lib().orc_last_polished())
 
 
 def set_qp_tolerances(residual_tol=1e-9, gap_tol=1e-10):

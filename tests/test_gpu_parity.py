@@ -1100,6 +1100,49 @@ def test_hard_closed_loop_replans_status_against_highs_and_the_oracle(be, oracle
     assert max(dcost) <= 1e-6
 
 
+def test_polish_finishes_loose_and_stalled_solves_exactly(be, oracle):
+    """The active-set polish (nep_batch_set_polish, on by default; oracle: orc_set_polish): an interior-point solve that ends on its
+    loose snapshot or gives up is finished by an exact active-set solve when a KKT certificate exists.  On four 64-agent scenes'
+    front-end guesses (the inputs whose tail was 8e-5 in round 4): with the polish OFF on both sides device and oracle reproduce the
+    round-4 behaviour (same statuses); with it ON every replan the device listed and certified agrees with the oracle's optimum to
+    1e-8 in the coefficients — two roundings of a 24 x 24 solve, not two interior-point paths — and no status gets worse."""
+    from neptune_amd import dist as ndist
+    S, N = 4, 64
+    scs = [scene.make_scene(N, 20, seed=200 + s) for s in range(S)]
+    p = scs[0]["par"]
+    com, gue = ndist.stack_scenes(scs)
+    bb = be.BatchBackend(p, scs[0]["statics"], n_scenes=S)
+    for s in range(1, S):
+        bb.set_scene_statics(s, scs[s]["statics"])
+    d_com = bb.to_device(com); d_g = bb.to_device(gue)
+    bb.frontend(scene.frontend_cfg(p, beam_width=32), d_com, bb.to_device(np.stack([scene.frontend_starts(s) for s in scs])), d_g, None)
+    g = d_g.cpu().numpy().view(abi.GUESS_DTYPE).reshape(S, N)
+    bb.set_polish(False); bb.replan(None, d_g); off = bb.solutions().reshape(S, N).copy()
+    assert bb.polish_count() == (0, 0)
+    bb.set_polish(True); bb.replan(None, d_g); on = bb.solutions().reshape(S, N).copy()
+    listed, certified = bb.polish_count()
+    assert listed >= 1 and 1 <= certified <= listed
+    st_off = off["stats"]["status"].astype(int); st_on = on["stats"]["status"].astype(int)
+    assert (st_on <= st_off).all()                                   # a certificate only ever turns a failure into a success
+    changed = np.argwhere((np.abs(on["coeff"] - off["coeff"]).reshape(S, N, -1).max(axis=2) > 0) | (st_on != st_off))
+    assert 1 <= len(changed) <= listed
+    worst = 0.0
+    try:
+        for s, a in changed:
+            K = int(g[s, a]["K"])
+            oracle.set_polish(True)
+            r = oracle.replan(p, a + 1, scs[s]["committed"], g[s, a], scs[s]["statics"])
+            if r["status"] != int(st_on[s, a]):
+                continue                                             # (a razor-thin certificate one side found and the other did not: counted below)
+            if r["status"] != 2:
+                worst = max(worst, float(np.abs(np.array(on[s, a]["coeff"])[:, :K, :] - r["coeff"]).max()))
+        n_same = sum(1 for s, a in changed if oracle.replan(p, a + 1, scs[s]["committed"], g[s, a], scs[s]["statics"])["status"] == int(st_on[s, a]))
+    finally:
+        oracle.set_polish(True)
+    assert n_same >= len(changed) - 2 and worst <= 1e-8, (n_same, len(changed), worst)
+    bb.close()
+
+
 def test_reference_tolerances(be, oracle):
     """nep_batch_set_tolerances(1e-6, 1e-8) — Gurobi's default barrier tolerances, where the reference's solver stops
     (solver_gurobi_poly.cpp:811-812 sets OutputFlag and TimeLimit only) — on two scenes' own guesses and two scenes' front-end
