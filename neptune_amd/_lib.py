@@ -176,6 +176,7 @@ def lib():
     L.nep_batch_frontend_ent_hulls.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, i, vp, vp, vp, vp, vp, vp]
     L.nep_batch_exchange_slots.argtypes = [vp, vp, vp, vp, C.c_int64, vp]
     L.nep_batch_set_ent_samples.argtypes = [vp, i]
+    L.nep_batch_set_polish.argtypes = [vp, i]; L.nep_backend_set_polish.argtypes = [vp, i]; L.nep_batch_debug_polish_count.argtypes = [vp, pi, pi]
     # the records this mirror builds with ctypes must have the library's layout (a library compiled from other headers would read
     # them at another stride): fail loudly at load, not as wrong numbers later
     L.nep_abi_sizeof.argtypes = [i]; L.nep_abi_sizeof.restype = i

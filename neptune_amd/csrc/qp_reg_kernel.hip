@@ -106,7 +106,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   int status = NEP_FAILED, L_used = 0, L_all = 0;
   // (what only the last lines need — iteration counts, the objective, 1 / rows — waits in LDS, not in registers that would be
   // spilled to scratch for the whole solve: sI[31] iterations of the last solve, sI[32] of the first, sc[sObjOut], sc[sInvMt])
-  if (tid == 0) { sI[31] = 0; sI[32] = 0; sI[26] = 0; sI[28] = 0; sI[29] = 0; sc[sObjOut] = 0.0; }      // (sI[28]: the strict tests passed in this iteration; sI[29]: solves left for the polish pass, bit per mode)      // (written and read back by thread 0 only; a replan that never reaches a solve — K = 0 — reports zeros; sI[26]: sent to the redo pass)
+  if (tid == 0) { sI[31] = 0; sI[32] = 0; sI[26] = 0; sI[28] = 0; sI[29] = 0; sI[30] = 0; sc[sObjOut] = 0.0; }      // (sI[28]: the strict tests passed in this iteration; sI[29]: solves left for the polish pass, bit per mode)      // (written and read back by thread 0 only; a replan that never reaches a solve — K = 0 — reports zeros; sI[26]: sent to the redo pass)
   bool has_qc = false, z_override = false;
 
   // Line coefficients in LDS: [n1 | n2 | h][segment][SEGCAP], SEGCAP = 8 RS entries per segment whatever its line count — the
@@ -733,11 +733,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const double gap = sc[sMu] * sc[sMtD], nr = sc[sNrp], qs = sc[sQscale];
             int flag = 0;
             if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-9, 1e-9, 1e-10 unless nep_batch_set_tolerances says otherwise)
-            if (!CULL && l1 == 0) sI[28] = flag;                  // (1: the STRICT tests passed — flag 1 below may also mean "the loose window ends on this iterate")
             else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
+            if (!CULL && l1 == 0) sI[28] = flag;                  // (1: the STRICT tests passed — flag 1 below may also mean "the loose window ends on this iterate")
             if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
             if (sI[17] >= 3) flag = 3;                           // stalled
-            if (sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks) flag = 3;   // TimeLimit without an accepted iterate: "no solution" (:832-836)
+            if (sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks) { flag = 3; if (!CULL && l1 == 0) sI[30] = 1; }   // TimeLimit without an accepted iterate: "no solution" (:832-836) — and out of budget: nothing is left for the polish pass either
             if (flag == 2 || (flag == 0 && sI[22] >= 0)) {       // loosely converged iterates: see qp_kernel
               const double merit = fmax(fmax(nr * sp.tol_res_inv, nrd / qs * sp.tol_res_inv), gap / (1.0 + fabs(o)) * sp.tol_gap_inv);
               const bool better = flag == 2 && (!sI[16] || merit < sc[sBestMerit]);
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         if constexpr (!CULL) {
           // a solve that ends without the strict tests (the loose snapshot, or no convergence at all) on a problem without the ball row
           // leaves its last point for the active-set polish (qp_polish_kernel.hip), which finishes it exactly or leaves it alone
-          if (ps.polish_z && !has_qc && !uncon && !(converged && __builtin_amdgcn_readfirstlane(sI[28]) == 1)) {
+          if (ps.polish_z && !has_qc && !uncon && !(converged && __builtin_amdgcn_readfirstlane(sI[28]) == 1) && __builtin_amdgcn_readfirstlane(sI[30]) == 0) {
             __syncthreads();
             if (tid < n) ps.polish_z[((long)slot * 2 + mode) * 24 + tid] = sZ[tid];
             if (tid == 0) sI[29] |= 1 << mode;

@@ -1052,9 +1052,10 @@ def test_parity_distribution_on_front_end_guesses(be, oracle):
             dpos.append(max(float(np.abs(((dc[..., 0] * t + dc[..., 1]) * t + dc[..., 2]) * t + dc[..., 3]).max()) for t in (0.0, 0.125, 0.25, 0.375, 0.5)))
             dob.append(abs(float(sol[s, a]["stats"]["objective"]) - r["objective"]) / (1 + abs(r["objective"])))
     dco = np.array(dco)
+    print("front-end guesses, %d replans: coefficients p50 %.2e p99 %.2e max %.2e; positions max %.2e m; cost max %.2e" % (len(dco), np.percentile(dco, 50), np.percentile(dco, 99), dco.max(), max(dpos), max(dob)))
     assert len(dco) >= 230
-    assert np.percentile(dco, 99) <= 1e-6 and dco.max() <= 1e-4, (np.percentile(dco, 99), dco.max())
-    assert max(dpos) <= 5e-5 and max(dob) <= 1e-8, (max(dpos), max(dob))
+    assert np.percentile(dco, 99) <= 1e-6 and dco.max() <= 5e-6, (np.percentile(dco, 99), dco.max())
+    assert max(dpos) <= 2e-6 and max(dob) <= 1e-8, (max(dpos), max(dob))
     bb.close()
 
 
@@ -1126,20 +1127,25 @@ def test_polish_finishes_loose_and_stalled_solves_exactly(be, oracle):
     assert (st_on <= st_off).all()                                   # a certificate only ever turns a failure into a success
     changed = np.argwhere((np.abs(on["coeff"] - off["coeff"]).reshape(S, N, -1).max(axis=2) > 0) | (st_on != st_off))
     assert 1 <= len(changed) <= listed
-    worst = 0.0
-    try:
-        for s, a in changed:
-            K = int(g[s, a]["K"])
-            oracle.set_polish(True)
-            r = oracle.replan(p, a + 1, scs[s]["committed"], g[s, a], scs[s]["statics"])
-            if r["status"] != int(st_on[s, a]):
-                continue                                             # (a razor-thin certificate one side found and the other did not: counted below)
-            if r["status"] != 2:
-                worst = max(worst, float(np.abs(np.array(on[s, a]["coeff"])[:, :K, :] - r["coeff"]).max()))
-        n_same = sum(1 for s, a in changed if oracle.replan(p, a + 1, scs[s]["committed"], g[s, a], scs[s]["statics"])["status"] == int(st_on[s, a]))
-    finally:
-        oracle.set_polish(True)
-    assert n_same >= len(changed) - 2 and worst <= 1e-8, (n_same, len(changed), worst)
+    worst_both, worst_one, n_same, n_both = 0.0, 0.0, 0, 0
+    oracle.set_polish(True)
+    for s, a in changed:
+        K = int(g[s, a]["K"])
+        oracle.last_polished()
+        r = oracle.replan(p, a + 1, scs[s]["committed"], g[s, a], scs[s]["statics"])
+        both = oracle.last_polished()                            # the oracle's solve of this replan ended on the polish too
+        if r["status"] != int(st_on[s, a]):
+            continue                                             # (a razor-thin certificate one side found and the other did not: counted below)
+        n_same += 1
+        if r["status"] != 2:
+            d = float(np.abs(np.array(on[s, a]["coeff"])[:, :K, :] - r["coeff"]).max())
+            if both:
+                n_both += 1; worst_both = max(worst_both, d)
+            else:
+                worst_one = max(worst_one, d)
+    # both polished: two roundings of one small linear solve; only the device did (the oracle's interior point passed its strict tests):
+    # the device's exact optimum against an iterate that is converged to 1e-9 in the residuals
+    assert n_same >= len(changed) - 2 and worst_both <= 1e-8 and worst_one <= COEF_TOL, (n_same, len(changed), n_both, worst_both, worst_one)
     bb.close()
 
 
