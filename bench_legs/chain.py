@@ -44,7 +44,7 @@ def run(ctx, H):
                        solve_us=acc.solve_us_stats(be), terminal_ball_rows=int(sol3["stats"]["qc_active"].sum()),
                        ipm_iters_quantiles=acc.quantiles(sol3["stats"]["iters"]), line_cull_radius_m=args.chain_cull_radius,
                        rows_solved_mean=float(sol3["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(),
-                       active_rows=acc.active_summary(be),
+                       polish_listed_certified_last_step=list(be.polish_count()), active_rows=acc.active_summary(be),
                        note="front-end beam search -> separating lines -> QP -> safety check + commit, every step; the guesses are the "
                             "device-made lattice paths (they end at cruise speed and cut corners around obstacles), not the scene's; "
                             "point A stays where it is, so after a few steps every step poses the same problems", **acc.status_counts(sol3))
@@ -92,7 +92,7 @@ def run(ctx, H):
                               K_mean=float(sol4["K"].mean()), solve_us=acc.solve_us_stats(be),
                               terminal_ball_rows=int(sol4["stats"]["qc_active"].sum()), lines_mean=float(sol4["stats"]["n_lines"].mean()),
                               ipm_iters_quantiles=acc.quantiles(sol4["stats"]["iters"]), line_cull_radius_m=cull,
-                              rows_solved_mean=float(sol4["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(),
+                              rows_solved_mean=float(sol4["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(), polish_listed_certified_last_step=list(be.polish_count()),
                               simulated_seconds=float(st_now["t_start"].max() - starts_in["t_start"].max()),
                               displacement_m_mean=float(moved.mean()), agents_with_swapped_goal=swaps,
                               failed_frac=float((sol4["stats"]["status"] == 2).mean()), active_rows=acc.active_summary(be),

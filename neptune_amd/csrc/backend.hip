@@ -398,9 +398,9 @@ struct Engine {
     ps.order = nullptr; last_ordered = false;
     ps.order_key = (lpt && d_order_key.n >= (size_t)slots) ? d_order_key.p : nullptr;
     if (ps.order_key && have_history && slots > 1024 && d_order.n >= (size_t)slots) {   // (more than one wave of workgroups)
-      launch_qp_order(slots, d_order_key.p, d_order.p, st);
+      launch_qp_order(slots, d_order_key.p, d_order.p, st, ps.polish_count);      // (zeroes the polish pass's counters on its way)
       ps.order = d_order.p; last_ordered = true;
-    }
+    } else if (ps.polish_count) launch_qp_polish_zero(ps.polish_count, st);
     if (use_reg) launch_qp_reg(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     else launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     if (skip && !no_redo) {      // (NEP_SEP_NO_REDO, read in size_scratch: development aid — the flagged replans keep their presolved result for inspection)
@@ -1412,8 +1412,8 @@ int nep_batch_debug_polish_count(nep_batch_t* h, int32_t* listed, int32_t* certi
   int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHK(hipDeviceSynchronize());
   if (h->eng.d_polish_count.p) HIPCHK(hipMemcpy(c, h->eng.d_polish_count.p, sizeof(c), hipMemcpyDeviceToHost));
-  if (listed) *listed = c[2];
-  if (certified) *certified = c[4];
+  if (listed) *listed = c[0];
+  if (certified) *certified = c[3];
   return 0;
 }
 int nep_batch_set_safety_check_prev(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.safety_check_prev = on != 0; return 0; }

@@ -160,7 +160,8 @@ void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const Q
                const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 size_t qp_lds_fixed_bytes();
 // the register-resident placement of the same solver (qp_reg_kernel.hip)
-void launch_qp_order(int n_slots, const int* key, int* order, hipStream_t st);
+void launch_qp_order(int n_slots, const int* key, int* order, hipStream_t st, int* zero_these = nullptr);      // (zero_these: four ints zeroed on the way, or null)
+void launch_qp_polish_zero(int* counters, hipStream_t st);
 void launch_order_xcd(int n_slots, const int* key, int* order, hipStream_t st);      // (key may be null: the XCD placement alone; n_slots % 8 == 0)
 void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                    const SampleSched& sched, size_t lds_bytes, hipStream_t st);

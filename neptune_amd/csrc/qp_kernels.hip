@@ -832,7 +832,8 @@ void launch_qp(int n_slots, const SceneParams& sp, const ProblemSet& ps, const Q
 // replan of the same slot is the predictor (a receding-horizon replanner re-solves almost the same problem): a counting
 // sort of the slots by its measured device time (stats.solve_us; the kernel leaves it in 8 us bins in ps.order_key), descending.  Results do not depend on the order
 // (every workgroup owns its slot).
-__global__ __launch_bounds__(1024) void order_kernel(int n, const int* __restrict__ key, int* __restrict__ order) {
+__global__ __launch_bounds__(1024) void order_kernel(int n, const int* __restrict__ key, int* __restrict__ order, int* __restrict__ zero_these) {
+  if (zero_these && threadIdx.x < 4) zero_these[threadIdx.x] = 0;      // (the polish pass's counters of the launch sequence that starts here: no kernel or memset node of their own)
   // (sixteen sub-histograms by thread index: most keys fall into two or three bins, and one counter per bin would serialise
   // the whole launch's atomics on them)
   __shared__ int hist[64][16], tot[64];
@@ -871,8 +872,8 @@ __global__ __launch_bounds__(1024) void order_xcd_kernel(int n, const int* __res
 void launch_order_xcd(int n_slots, const int* key, int* order, hipStream_t st) {
   if (n_slots > 0) hipLaunchKernelGGL(order_xcd_kernel, dim3(1), dim3(1024), 0, st, n_slots, key, order);
 }
-void launch_qp_order(int n_slots, const int* key, int* order, hipStream_t st) {
-  if (n_slots > 0) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, n_slots, key, order);
+void launch_qp_order(int n_slots, const int* key, int* order, hipStream_t st, int* zero_these) {
+  if (n_slots > 0) hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, st, n_slots, key, order, zero_these);
 }
 
 }  // namespace nep

@@ -21,6 +21,8 @@
 // oracle/neptune_oracle.c::qp_solve runs the same rule; the two agree to the accuracy of a 24 x 24 solve (tests compare them).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "nep_device.h"
 
 namespace nep {
@@ -28,7 +30,8 @@ namespace {
 constexpr int PN = 24;          // reduced variables: 3 axes x nz <= 8
 constexpr int PA = 40;          // active rows carried (an independent subset has at most PN)
 constexpr int PST = PA + 1;     // LDS row stride of the Schur complement
-constexpr double kActTol = 1e-6, kFeasTol = 1e-9, kDualTol = 1e-9, kPivTol = 1e-12;
+constexpr int kPolLines = 768;  // lines staged in LDS (a config-4 replan has ~510; beyond: read where they lie)
+constexpr double kActTol = 1e-6, kFeasTol = 1e-9, kDualTol = 1e-9, kPivTol = 1e-12, kStartTol = 1e-4;
 }  // namespace
 
 // one listed slot (a wave); returns true when a problem of the slot was certified and its outputs rewritten
@@ -45,6 +48,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
   __shared__ double sB[kMaxR][kNZ], sOff[kMaxR][3], sHi[kNZ][kNZ], sG[PN], sZ[PN], sZ0[PN], sInit[9], sFin[3], sCoef[96], sTheta[96];
   __shared__ double sA[PA][PN + 1], sHA[PA][PN + 1], sS[PA][PST], sRhs[PA], sNu[PA], sRowH[PA], sRed[64];
   __shared__ int sAct[PA], sDrop[PA], sCnt[NEP_MAX_POL + 1], sI[8], sRedI[64];
+  __shared__ double sNd[kPolLines][3];      // the slot's separating lines (n1, n2, d): every scan of the rows reads them (from global memory a scan was a chain of round trips: most of a polish)
 
   if (lane < 96) sCoef[lane] = ((lane % 32) / 4 < K) ? (&g->coeff[0][0][0])[lane] : 0.0;
   for (int e = 64 + lane; e < 96; e += 64) sCoef[e] = ((e % 32) / 4 < K) ? (&g->coeff[0][0][0])[e] : 0.0;
@@ -64,6 +68,16 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
   const int L = sCnt[NEP_MAX_POL];
   const int n_rows = 6 * R + 4 * L;
   const double* bucket0 = ps.line_nd + (long)slot * NEP_MAX_POL * sp.lines_cap * 3;
+  for (int l = lane; l < L && l < kPolLines; l += 64) {
+    int i = 0;
+    for (int j = 1; j < NEP_MAX_POL; j++) i += (l >= sCnt[j]) ? 1 : 0;
+    const double* nd = bucket0 + ((long)i * sp.lines_cap + (l - sCnt[i])) * 3;
+    sNd[l][0] = nd[0]; sNd[l][1] = nd[1]; sNd[l][2] = nd[2];
+  }
+  auto line_nd = [&](int l, int i, double& n1, double& n2, double& d) {
+    if (l < kPolLines) { n1 = sNd[l][0]; n2 = sNd[l][1]; d = sNd[l][2]; }
+    else { const double* nd = bucket0 + ((long)i * sp.lines_cap + (l - sCnt[i])) * 3; n1 = nd[0]; n2 = nd[1]; d = nd[2]; }
+  };
 
   for (int mode = 0; mode < 2; mode++) {
     if (!((flags >> mode) & 1)) { if (mode == 0) continue; else break; }
@@ -92,8 +106,8 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     auto row_eval = [&](int r, const double* z, double& rhs) -> double {      // -> slack h - a.z, rhs = the reference row's right-hand side
       if (r < 6 * R) {
         const int side = r & 1, q = r >> 1, ax = q / R, rho = q - ax * R;
-        const double hi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
-        const double lo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
+        const double hi = rho < 4 * K ? (ax == 0 ? sp.maxs[0] : ax == 1 ? sp.maxs[1] : sp.maxs[2]) : (rho < 7 * K ? sp.v_max : sp.a_max);      // (selected, not indexed: a kernel argument indexed by a variable is copied to scratch memory)
+        const double lo = rho < 4 * K ? (ax == 0 ? sp.mins[0] : ax == 1 ? sp.mins[1] : sp.mins[2]) : (rho < 7 * K ? -sp.v_max : -sp.a_max);
         double v = sOff[rho][ax];
         for (int c = 0; c < kNZ; c++) v += sB[rho][c] * z[ax * kNZ + c];
         rhs = side ? -lo : hi;
@@ -102,39 +116,40 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
       const int q = r - 6 * R, l = q >> 2, k = q & 3;
       int i = 0;
       for (int j = 1; j < NEP_MAX_POL; j++) i += (l >= sCnt[j]) ? 1 : 0;
-      const double* nd = bucket0 + ((long)i * sp.lines_cap + (l - sCnt[i])) * 3;
+      double n1, n2, d; line_nd(l, i, n1, n2, d);
       const int rho = 4 * i + k;
       double vx = sOff[rho][0], vy = sOff[rho][1];
       for (int c = 0; c < kNZ; c++) { vx += sB[rho][c] * z[c]; vy += sB[rho][c] * z[kNZ + c]; }
-      rhs = 1.0 - nd[2];
-      return rhs - (nd[0] * vx + nd[1] * vy);
+      rhs = 1.0 - d;
+      return rhs - (n1 * vx + n2 * vy);
     };
-    auto row_vec = [&](int r, double* a, double& h) {      // the row in z-space: a.z <= h
-      for (int c = 0; c < PN; c++) a[c] = 0.0;
+    auto row_vec = [&](int r, int slot_a, double& h) {      // the row in z-space, a.z <= h, written to sA[slot_a] (LDS: a private array indexed by a variable would live in scratch memory)
+      for (int c = 0; c < PN; c++) sA[slot_a][c] = 0.0;
       if (r < 6 * R) {
         const int side = r & 1, q = r >> 1, ax = q / R, rho = q - ax * R;
-        const double hi = rho < 4 * K ? sp.maxs[ax] : (rho < 7 * K ? sp.v_max : sp.a_max);
-        const double lo = rho < 4 * K ? sp.mins[ax] : (rho < 7 * K ? -sp.v_max : -sp.a_max);
-        for (int c = 0; c < kNZ; c++) a[ax * kNZ + c] = side ? -sB[rho][c] : sB[rho][c];
+        const double hi = rho < 4 * K ? (ax == 0 ? sp.maxs[0] : ax == 1 ? sp.maxs[1] : sp.maxs[2]) : (rho < 7 * K ? sp.v_max : sp.a_max);      // (selected, not indexed: a kernel argument indexed by a variable is copied to scratch memory)
+        const double lo = rho < 4 * K ? (ax == 0 ? sp.mins[0] : ax == 1 ? sp.mins[1] : sp.mins[2]) : (rho < 7 * K ? -sp.v_max : -sp.a_max);
+        for (int c = 0; c < kNZ; c++) sA[slot_a][ax * kNZ + c] = side ? -sB[rho][c] : sB[rho][c];
         h = side ? sOff[rho][ax] - lo : hi - sOff[rho][ax];
         return;
       }
       const int q = r - 6 * R, l = q >> 2, k = q & 3;
       int i = 0;
       for (int j = 1; j < NEP_MAX_POL; j++) i += (l >= sCnt[j]) ? 1 : 0;
-      const double* nd = bucket0 + ((long)i * sp.lines_cap + (l - sCnt[i])) * 3;
+      double n1, n2, d; line_nd(l, i, n1, n2, d);
       const int rho = 4 * i + k;
-      for (int c = 0; c < kNZ; c++) { a[c] = nd[0] * sB[rho][c]; a[kNZ + c] = nd[1] * sB[rho][c]; }
-      h = (1.0 - nd[2]) - (nd[0] * sOff[rho][0] + nd[1] * sOff[rho][1]);
+      for (int c = 0; c < kNZ; c++) { sA[slot_a][c] = n1 * sB[rho][c]; sA[slot_a][kNZ + c] = n2 * sB[rho][c]; }
+      h = (1.0 - d) - (n1 * sOff[rho][0] + n2 * sOff[rho][1]);
     };
 
     // ---- the active set at the solve's last iterate ----
     if (lane == 0) sI[0] = 0;
     __syncthreads();
+    double vmax0 = 0.0;                            // the start point's worst violation (see below)
     for (int r0 = 0; r0 < n_rows; r0 += 64) {      // (in row order: the ballot keeps the list sorted)
       const int r = r0 + lane;
       bool act = false;
-      if (r < n_rows) { double rhs; const double s = row_eval(r, sZ, rhs); act = s < kActTol * (1.0 + fabs(rhs)); }
+      if (r < n_rows) { double rhs; const double s = row_eval(r, sZ, rhs); act = s < kActTol * (1.0 + fabs(rhs)); vmax0 = fmax(vmax0, -s / (1.0 + fabs(rhs))); }
       const unsigned long long m = __ballot(act);
       const int base = sI[0];
       if (act) { const int p = base + __popcll(m & ((1ull << lane) - 1ull)); if (p < PA) sAct[p] = r; }
@@ -144,16 +159,25 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     }
     int na = sI[0];
     if (na > PA) continue;                                     // (more candidate rows than the kernel carries: left as it is)
+    {   // a start point that violates a row by more than 1e-4 (1 + |rhs|) is not "nearly there": an interior point that gives up on
+        // a feasible problem has long driven the primal residual down; what is left are the infeasible problems, which no polish
+        // can certify — twelve rounds each were most of this kernel's time in the closed loop
+      sRed[lane] = vmax0;
+      __syncthreads();
+      double vm = 0.0; for (int t = 0; t < 64; t++) vm = fmax(vm, sRed[t]);
+      __syncthreads();
+      if (vm > kStartTol) continue;
+    }
     bool certified = false;
-    for (int round = 0; round < 12; round++) {
+    for (int round = 0; round < 12; round++) {      // (a certificate takes one to three rounds; twelve is a bound, as in the oracle)
       __syncthreads();
       // rows of the active set in z-space, H^-1 A', the Schur complement S = A H^-1 A' and its right-hand side A z0 - h
       if (lane < na) {
-        double a[PN], h;
-        row_vec(sAct[lane], a, h);
+        double h;
+        row_vec(sAct[lane], lane, h);
         double az0 = 0.0;
-        for (int c = 0; c < PN; c++) { sA[lane][c] = a[c]; az0 += a[c] * sZ0[c]; }
-        for (int ax = 0; ax < 3; ax++) for (int e = 0; e < kNZ; e++) { double v = 0.0; for (int c = 0; c < kNZ; c++) v += sHi[e][c] * a[ax * kNZ + c]; sHA[lane][ax * kNZ + e] = v; }
+        for (int c = 0; c < PN; c++) az0 += sA[lane][c] * sZ0[c];
+        for (int ax = 0; ax < 3; ax++) for (int e = 0; e < kNZ; e++) { double v = 0.0; for (int c = 0; c < kNZ; c++) v += sHi[e][c] * sA[lane][ax * kNZ + c]; sHA[lane][ax * kNZ + e] = v; }
         sRhs[lane] = az0 - h; sRowH[lane] = h;
       }
       __syncthreads();
@@ -177,9 +201,22 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
         }
       }
       __syncthreads();
-      if (lane == 0) {      // L y = rhs, L' nu = y (na <= 40: a few hundred operations)
-        for (int i = 0; i < na; i++) { double v = sRhs[i]; for (int k = 0; k < i; k++) v -= sS[i][k] * sNu[k]; sNu[i] = v / sS[i][i]; }
-        for (int i = na - 1; i >= 0; i--) { double v = sNu[i]; for (int k = i + 1; k < na; k++) v -= sS[k][i] * sNu[k]; sNu[i] = sDrop[i] ? 0.0 : v / sS[i][i]; }
+      // L y = rhs, L' nu = y, a column at a time with the lanes on the rows (on one lane the two substitutions were a chain of 1 600
+      // dependent LDS reads: most of a round)
+      if (lane < na) sNu[lane] = sRhs[lane];
+      for (int i = 0; i < na; i++) {
+        __syncthreads();
+        const double yi = sNu[i] / sS[i][i];
+        __syncthreads();
+        if (lane == i) sNu[i] = yi;
+        else if (lane > i && lane < na) sNu[lane] -= sS[lane][i] * yi;
+      }
+      for (int i = na - 1; i >= 0; i--) {
+        __syncthreads();
+        const double xi = sDrop[i] ? 0.0 : sNu[i] / sS[i][i];
+        __syncthreads();
+        if (lane == i) sNu[i] = xi;
+        else if (lane < i) sNu[lane] -= sS[i][lane] * xi;
       }
       __syncthreads();
       if (lane < PN) { double v = sZ0[lane]; for (int i = 0; i < na; i++) v -= sHA[i][lane] * sNu[i]; sZ[lane] = v; }      // z = z0 - H^-1 A' nu
@@ -275,28 +312,24 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
   return false;
 }
 
-// ps.polish_count: [0] slots listed by the QP kernel(s) of this launch sequence, [1] workgroups of this kernel that are done, [2] the
-// listed count of the last launch and [4] how many of them were certified (test hook), [3] certified so far.  The last workgroup to
-// finish zeroes [0], [1], [3] for the next launch sequence: no memset node in a captured step.
+// ps.polish_count: [0] slots listed by the QP kernel(s) of this launch sequence, [3] how many of them this kernel certified.  They are
+// zeroed at the START of the next launch sequence — by order_kernel on its way, else by qp_polish_zero_kernel — so that a step
+// has no memset node, no kernel behind this one and no "last workgroup done" counter (512 atomics on one address were 0.08 ms of
+// every step, listed slots or not); until then the host reads them (nep_batch_debug_polish_count).
 __global__ __launch_bounds__(64) void qp_polish_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
   const int n_listed = ps.polish_count[0];
-  bool ok = false;
-  if ((int)blockIdx.x < n_listed) ok = polish_slot(sp, ps, tables, sched, ps.polish_list[blockIdx.x]);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (ok) atomicAdd(ps.polish_count + 3, 1);
-    __threadfence();
-    if (atomicAdd(ps.polish_count + 1, 1) == (int)gridDim.x - 1) {
-      ps.polish_count[2] = n_listed; ps.polish_count[4] = atomicAdd(ps.polish_count + 3, 0);
-      ps.polish_count[0] = 0; ps.polish_count[1] = 0; ps.polish_count[3] = 0;
-    }
-  }
+  int n_ok = 0;
+  for (int e = blockIdx.x; e < n_listed; e += gridDim.x) { n_ok += polish_slot(sp, ps, tables, sched, ps.polish_list[e]) ? 1 : 0; __syncthreads(); }
+  if (threadIdx.x == 0 && n_ok) atomicAdd(ps.polish_count + 3, n_ok);
 }
+__global__ void qp_polish_zero_kernel(int* __restrict__ c) { if (threadIdx.x < 4) c[threadIdx.x] = 0; }
+void launch_qp_polish_zero(int* counters, hipStream_t st) { if (counters) hipLaunchKernelGGL(qp_polish_zero_kernel, dim3(1), dim3(64), 0, st, counters); }
 
-// grid: one workgroup per entry the list can hold; workgroups beyond the device-side count return at once (graph-capturable)
-void launch_qp_polish(int cap, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables, const SampleSched& sched, hipStream_t st) {
-  if (cap <= 0 || !ps.polish_list) return;
-  hipLaunchKernelGGL(qp_polish_kernel, dim3(cap), dim3(64), 0, st, sp, ps, tables, sched);
+// a fixed small grid walks the list (it holds a per cent of the slots at most)
+void launch_qp_polish(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables, const SampleSched& sched, hipStream_t st) {
+  if (n_slots <= 0 || !ps.polish_list) return;
+  static const int g_env = getenv("NEP_POLISH_GRID") ? atoi(getenv("NEP_POLISH_GRID")) : 128;      // (A/B)
+  hipLaunchKernelGGL(qp_polish_kernel, dim3(n_slots < g_env ? n_slots : g_env), dim3(64), 0, st, sp, ps, tables, sched);
 }
 
 }  // namespace nep

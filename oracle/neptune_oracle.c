@@ -795,6 +795,9 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
     const double* ysrc = loose_ok ? yl : y;
     int finite = 1; for (int c = 0; c < ny; c++) if (!(fabs(ysrc[c]) < 1e100)) finite = 0;
     int* act = (int*)malloc(sizeof(int) * (m + 1)); int na = 0;
+    /* (a start point that violates a row by more than 1e-4 (1 + |rhs|) is not polished: an interior point that gives up on a feasible
+       problem has long driven the primal residual down; what is left are infeasible problems, which cannot be certified) */
+    if (finite) for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = hy_abs_slack(g, ysrc, hy[r], ny); if (-a > 1e-4 * (1.0 + fabs(Q->rows[r].rhs))) finite = 0; }
     if (finite) for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = hy_abs_slack(g, ysrc, hy[r], ny); if (a < 1e-6 * (1.0 + fabs(Q->rows[r].rhs))) act[na++] = r; }
     int ok = 0, rounds = 0;
     double* ys = (double*)malloc(sizeof(double) * (ny + 1));
