@@ -9,7 +9,7 @@
 // The last two are finished here, exactly, by a kernel of its own over the few slots the QP kernel listed (ps.polish_list):
 //
 //   active set  = the rows whose slack at the solve's last iterate is below 1e-6 (1 + |rhs|);
-//   repeat <= 12 times: solve the equality-constrained QP on a maximal independent subset of it (Schur complement of the
+//   repeat <= 6 times: solve the equality-constrained QP on a maximal independent subset of it (Schur complement of the
 //   block-diagonal Hessian, Cholesky with dependent rows left out); drop the row with the most negative multiplier, else add the
 //   most violated row, else stop;
 //   certificate: every row satisfied to 1e-9 (1 + |rhs|), every multiplier >= -1e-9 (1 + max|nu|) — the KKT conditions of a
@@ -30,14 +30,16 @@ namespace {
 constexpr int PN = 24;          // reduced variables: 3 axes x nz <= 8
 constexpr int PA = 40;          // active rows carried (an independent subset has at most PN)
 constexpr int PST = PA + 1;     // LDS row stride of the Schur complement
+constexpr int kPolRounds = 6;   // a certificate takes one to three rounds (oracle: the same bound)
 constexpr int kPolLines = 768;  // lines staged in LDS (a config-4 replan has ~510; beyond: read where they lie)
 constexpr double kActTol = 1e-6, kFeasTol = 1e-9, kDualTol = 1e-9, kPivTol = 1e-12, kStartTol = 1e-4;
 }  // namespace
 
-// one listed slot (a wave); returns true when a problem of the slot was certified and its outputs rewritten
+// one listed slot (a workgroup of 256); returns true when a problem of the slot was certified and its outputs rewritten
 __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const QpTable* __restrict__ tables, const SampleSched& sched, int slot) {
   const int flags = ps.polish_flag[slot];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x;      // (256 threads: the row scans, the table loads and the Schur complement on all of them, the small dense algebra on the first wave's)
+  constexpr int NT = 256;
   const nep_guess* g = ps.guess + slot;
   nep_solution* sol = ps.solution + slot;
   const int K = g->K;
@@ -46,12 +48,11 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
   const double T = sp.T_span;
 
   __shared__ double sB[kMaxR][kNZ], sOff[kMaxR][3], sHi[kNZ][kNZ], sG[PN], sZ[PN], sZ0[PN], sInit[9], sFin[3], sCoef[96], sTheta[96];
-  __shared__ double sA[PA][PN + 1], sHA[PA][PN + 1], sS[PA][PST], sRhs[PA], sNu[PA], sRowH[PA], sRed[64];
-  __shared__ int sAct[PA], sDrop[PA], sCnt[NEP_MAX_POL + 1], sI[8], sRedI[64];
+  __shared__ double sA[PA][PN + 1], sHA[PA][PN + 1], sS[PA][PST], sRhs[PA], sNu[PA], sRowH[PA], sRed[256];
+  __shared__ int sAct[PA], sDrop[PA], sCnt[NEP_MAX_POL + 1], sI[8], sRedI[256], sDropped[12];
   __shared__ double sNd[kPolLines][3];      // the slot's separating lines (n1, n2, d): every scan of the rows reads them (from global memory a scan was a chain of round trips: most of a polish)
 
   if (lane < 96) sCoef[lane] = ((lane % 32) / 4 < K) ? (&g->coeff[0][0][0])[lane] : 0.0;
-  for (int e = 64 + lane; e < 96; e += 64) sCoef[e] = ((e % 32) / 4 < K) ? (&g->coeff[0][0][0])[e] : 0.0;
   if (lane <= NEP_MAX_POL) {
     int o = 0;
     for (int i = 0; i < NEP_MAX_POL; i++) { if (i == lane) sCnt[i] = o; o += i < K ? line_count(ps.line_cnt[(long)slot * NEP_MAX_POL + i]) : 0; }
@@ -68,7 +69,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
   const int L = sCnt[NEP_MAX_POL];
   const int n_rows = 6 * R + 4 * L;
   const double* bucket0 = ps.line_nd + (long)slot * NEP_MAX_POL * sp.lines_cap * 3;
-  for (int l = lane; l < L && l < kPolLines; l += 64) {
+  for (int l = lane; l < L && l < kPolLines; l += NT) {
     int i = 0;
     for (int j = 1; j < NEP_MAX_POL; j++) i += (l >= sCnt[j]) ? 1 : 0;
     const double* nd = bucket0 + ((long)i * sp.lines_cap + (l - sCnt[i])) * 3;
@@ -85,9 +86,9 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     const int nz = mode == 1 ? K : (K > 2 ? K - 2 : 0), n = 3 * nz;
     if (nz == 0) continue;
     __syncthreads();
-    for (int e = lane; e < kMaxR * kNZ; e += 64) sB[e / kNZ][e % kNZ] = (e / kNZ) < R ? tb->B[e / kNZ][e % kNZ] : 0.0;
-    for (int e = lane; e < kMaxR * 3; e += 64) { const int rho = e / 3, ax = e % 3; sOff[rho][ax] = rho < R ? tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2] : 0.0; }
-    sHi[lane / kNZ][lane % kNZ] = tb->HaxInv[lane / kNZ][lane % kNZ];
+    for (int e = lane; e < kMaxR * kNZ; e += NT) sB[e / kNZ][e % kNZ] = (e / kNZ) < R ? tb->B[e / kNZ][e % kNZ] : 0.0;
+    for (int e = lane; e < kMaxR * 3; e += NT) { const int rho = e / 3, ax = e % 3; sOff[rho][ax] = rho < R ? tb->U[rho][0] * sInit[ax * 3] + tb->U[rho][1] * sInit[ax * 3 + 1] + tb->U[rho][2] * sInit[ax * 3 + 2] : 0.0; }
+    if (lane < kNZ * kNZ) sHi[lane / kNZ][lane % kNZ] = tb->HaxInv[lane / kNZ][lane % kNZ];
     if (lane < PN) {
       const int ax = lane / kNZ, e = lane % kNZ;      // (kNZ = 8: the axis blocks are padded to eight here; entries e >= nz stay zero)
       double gv = 0.0;
@@ -105,7 +106,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     // a row of the problem: r < 6R: box row of (axis, base row, side); else line row (line l, control point k)
     auto row_eval = [&](int r, const double* z, double& rhs) -> double {      // -> slack h - a.z, rhs = the reference row's right-hand side
       if (r < 6 * R) {
-        const int side = r & 1, q = r >> 1, ax = q / R, rho = q - ax * R;
+        const int side = r & 1, q = r >> 1, ax = (q >= R ? 1 : 0) + (q >= 2 * R ? 1 : 0), rho = q - ax * R;      // (no integer division: forty instructions on the VALU)
         const double hi = rho < 4 * K ? (ax == 0 ? sp.maxs[0] : ax == 1 ? sp.maxs[1] : sp.maxs[2]) : (rho < 7 * K ? sp.v_max : sp.a_max);      // (selected, not indexed: a kernel argument indexed by a variable is copied to scratch memory)
         const double lo = rho < 4 * K ? (ax == 0 ? sp.mins[0] : ax == 1 ? sp.mins[1] : sp.mins[2]) : (rho < 7 * K ? -sp.v_max : -sp.a_max);
         double v = sOff[rho][ax];
@@ -126,7 +127,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     auto row_vec = [&](int r, int slot_a, double& h) {      // the row in z-space, a.z <= h, written to sA[slot_a] (LDS: a private array indexed by a variable would live in scratch memory)
       for (int c = 0; c < PN; c++) sA[slot_a][c] = 0.0;
       if (r < 6 * R) {
-        const int side = r & 1, q = r >> 1, ax = q / R, rho = q - ax * R;
+        const int side = r & 1, q = r >> 1, ax = (q >= R ? 1 : 0) + (q >= 2 * R ? 1 : 0), rho = q - ax * R;      // (no integer division: forty instructions on the VALU)
         const double hi = rho < 4 * K ? (ax == 0 ? sp.maxs[0] : ax == 1 ? sp.maxs[1] : sp.maxs[2]) : (rho < 7 * K ? sp.v_max : sp.a_max);      // (selected, not indexed: a kernel argument indexed by a variable is copied to scratch memory)
         const double lo = rho < 4 * K ? (ax == 0 ? sp.mins[0] : ax == 1 ? sp.mins[1] : sp.mins[2]) : (rho < 7 * K ? -sp.v_max : -sp.a_max);
         for (int c = 0; c < kNZ; c++) sA[slot_a][ax * kNZ + c] = side ? -sB[rho][c] : sB[rho][c];
@@ -146,30 +147,36 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     if (lane == 0) sI[0] = 0;
     __syncthreads();
     double vmax0 = 0.0;                            // the start point's worst violation (see below)
-    for (int r0 = 0; r0 < n_rows; r0 += 64) {      // (in row order: the ballot keeps the list sorted)
-      const int r = r0 + lane;
+    for (int r0 = 0; r0 < n_rows; r0 += NT) {      // (in row order: ballots inside a wave, the waves' counts in front of each other)
+      const int r = r0 + lane, wv = lane >> 6, ln = lane & 63;
       bool act = false;
       if (r < n_rows) { double rhs; const double s = row_eval(r, sZ, rhs); act = s < kActTol * (1.0 + fabs(rhs)); vmax0 = fmax(vmax0, -s / (1.0 + fabs(rhs))); }
       const unsigned long long m = __ballot(act);
-      const int base = sI[0];
-      if (act) { const int p = base + __popcll(m & ((1ull << lane) - 1ull)); if (p < PA) sAct[p] = r; }
+      if (ln == 0) sI[4 + wv] = __popcll(m);
       __syncthreads();
-      if (lane == 0) sI[0] = base + __popcll(m);
+      const int base = sI[0];
+      int off = base; for (int w_ = 0; w_ < wv; w_++) off += sI[4 + w_];
+      if (act) { const int p = off + __popcll(m & ((1ull << ln) - 1ull)); if (p < PA) sAct[p] = r; }
+      __syncthreads();
+      if (lane == 0) sI[0] = base + sI[4] + sI[5] + sI[6] + sI[7];
       __syncthreads();
     }
     int na = sI[0];
     if (na > PA) continue;                                     // (more candidate rows than the kernel carries: left as it is)
     {   // a start point that violates a row by more than 1e-4 (1 + |rhs|) is not "nearly there": an interior point that gives up on
         // a feasible problem has long driven the primal residual down; what is left are the infeasible problems, which no polish
-        // can certify — twelve rounds each were most of this kernel's time in the closed loop
+        // can certify — the full number of rounds each was most of this kernel's time in the closed loop
       sRed[lane] = vmax0;
+      __syncthreads();
+      if (lane < 64) sRed[lane] = fmax(fmax(sRed[lane], sRed[lane + 64]), fmax(sRed[lane + 128], sRed[lane + 192]));
       __syncthreads();
       double vm = 0.0; for (int t = 0; t < 64; t++) vm = fmax(vm, sRed[t]);
       __syncthreads();
       if (vm > kStartTol) continue;
     }
     bool certified = false;
-    for (int round = 0; round < 12; round++) {      // (a certificate takes one to three rounds; twelve is a bound, as in the oracle)
+    int n_dropped = 0;                   // (rows that left with a negative multiplier: sDropped, LDS)
+    for (int round = 0; round < kPolRounds; round++) {      // (a certificate takes one to three rounds; the bound is the oracle's)
       __syncthreads();
       // rows of the active set in z-space, H^-1 A', the Schur complement S = A H^-1 A' and its right-hand side A z0 - h
       if (lane < na) {
@@ -181,68 +188,82 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
         sRhs[lane] = az0 - h; sRowH[lane] = h;
       }
       __syncthreads();
-      for (int e = lane; e < na * na; e += 64) { const int i = e / na, j = e - i * na; double v = 0.0; for (int c = 0; c < PN; c++) v += sA[i][c] * sHA[j][c]; sS[i][j] = v; }
+      for (int e = lane; e < na * na; e += NT) { const int i = e / na, j = e - i * na; double v = 0.0; for (int c = 0; c < PN; c++) v += sA[i][c] * sHA[j][c]; sS[i][j] = v; }
       __syncthreads();
-      // Cholesky, column by column; a row whose pivot vanishes is dependent on the rows before it: left out (nu = 0)
-      if (lane < na) sDrop[lane] = 0;
-      for (int j = 0; j < na; j++) {
-        __syncthreads();
-        if (lane == 0) {
-          double d = sS[j][j]; const double d0 = d;
-          for (int k = 0; k < j; k++) d -= sS[j][k] * sS[j][k];
-          if (!(d > kPivTol * d0) || !(d0 > 0.0)) { sDrop[j] = 1; for (int k = 0; k < j; k++) sS[j][k] = 0.0; sS[j][j] = 1.0; sRhs[j] = 0.0; }
-          else sS[j][j] = sqrt(d);
+      // Cholesky, column by column; a row whose pivot vanishes is dependent on the rows before it: left out (nu = 0).  The small dense
+      // algebra runs on the first wave alone, its steps separated by wave-level fences (LDS operations of one wave are in order): as
+      // workgroup barriers the ~200 steps of a polish were half its time
+      if (lane < 64) {
+        auto wsync = [] { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); };
+        if (lane < na) sDrop[lane] = 0;
+        for (int j = 0; j < na; j++) {
+          wsync();
+          if (lane == 0) {
+            double d = sS[j][j]; const double d0 = d;
+            for (int k = 0; k < j; k++) d -= sS[j][k] * sS[j][k];
+            if (!(d > kPivTol * d0) || !(d0 > 0.0)) { sDrop[j] = 1; for (int k = 0; k < j; k++) sS[j][k] = 0.0; sS[j][j] = 1.0; sRhs[j] = 0.0; }
+            else sS[j][j] = sqrt(d);
+          }
+          wsync();
+          if (lane > j && lane < na) {
+            double v = 0.0;
+            if (!sDrop[j]) { v = sS[lane][j]; for (int k = 0; k < j; k++) v -= sS[lane][k] * sS[j][k]; v /= sS[j][j]; }
+            sS[lane][j] = v;
+          }
         }
-        __syncthreads();
-        if (lane > j && lane < na) {
-          double v = 0.0;
-          if (!sDrop[j]) { v = sS[lane][j]; for (int k = 0; k < j; k++) v -= sS[lane][k] * sS[j][k]; v /= sS[j][j]; }
-          sS[lane][j] = v;
+        wsync();
+        // L y = rhs, L' nu = y, a column at a time with the lanes on the rows
+        if (lane < na) sNu[lane] = sRhs[lane];
+        for (int i = 0; i < na; i++) {
+          wsync();
+          const double yi = sNu[i] / sS[i][i];
+          wsync();
+          if (lane == i) sNu[i] = yi;
+          else if (lane > i && lane < na) sNu[lane] -= sS[lane][i] * yi;
         }
-      }
-      __syncthreads();
-      // L y = rhs, L' nu = y, a column at a time with the lanes on the rows (on one lane the two substitutions were a chain of 1 600
-      // dependent LDS reads: most of a round)
-      if (lane < na) sNu[lane] = sRhs[lane];
-      for (int i = 0; i < na; i++) {
-        __syncthreads();
-        const double yi = sNu[i] / sS[i][i];
-        __syncthreads();
-        if (lane == i) sNu[i] = yi;
-        else if (lane > i && lane < na) sNu[lane] -= sS[lane][i] * yi;
-      }
-      for (int i = na - 1; i >= 0; i--) {
-        __syncthreads();
-        const double xi = sDrop[i] ? 0.0 : sNu[i] / sS[i][i];
-        __syncthreads();
-        if (lane == i) sNu[i] = xi;
-        else if (lane < i) sNu[lane] -= sS[i][lane] * xi;
+        for (int i = na - 1; i >= 0; i--) {
+          wsync();
+          const double xi = sDrop[i] ? 0.0 : sNu[i] / sS[i][i];
+          wsync();
+          if (lane == i) sNu[i] = xi;
+          else if (lane < i) sNu[lane] -= sS[i][lane] * xi;
+        }
       }
       __syncthreads();
       if (lane < PN) { double v = sZ0[lane]; for (int i = 0; i < na; i++) v -= sHA[i][lane] * sNu[i]; sZ[lane] = v; }      // z = z0 - H^-1 A' nu
       __syncthreads();
-      // multipliers: the most negative one leaves
+      // multipliers: the rows with a negative one leave, all at once (one at a time a certificate took a round per weakly active row
+      // of the start set; a row that is missed comes back through the violation test)
       {
         double numax = 0.0; for (int i = 0; i < na; i++) numax = fmax(numax, fabs(sNu[i]));
-        int worst = -1; double wv = -kDualTol * (1.0 + numax);
-        for (int i = 0; i < na; i++) if (!sDrop[i] && sNu[i] < wv) { wv = sNu[i]; worst = i; }
-        if (worst >= 0) {
+        const double wv = -kDualTol * (1.0 + numax);
+        int n_neg = 0; for (int i = 0; i < na; i++) n_neg += (!sDrop[i] && sNu[i] < wv) ? 1 : 0;
+        if (n_neg > 0) {
           __syncthreads();
-          if (lane == 0) { for (int i = worst; i + 1 < na; i++) sAct[i] = sAct[i + 1]; }
-          na--;
+          if (lane == 0) {
+            int keep = 0, nd_ = n_dropped;
+            for (int i = 0; i < na; i++) { if (!sDrop[i] && sNu[i] < wv) { if (nd_ < 12) sDropped[nd_++] = sAct[i]; } else sAct[keep++] = sAct[i]; }
+          }
+          n_dropped = n_dropped + n_neg < 12 ? n_dropped + n_neg : 12;
+          na -= n_neg;
           continue;
         }
       }
       // every row at the new point: the most violated one enters
       double vmax = 0.0; int vrow = -1;
-      for (int r = lane; r < n_rows; r += 64) { double rhs; const double s = row_eval(r, sZ, rhs); const double v = -s / (1.0 + fabs(rhs)); if (v > kFeasTol && v > vmax) { vmax = v; vrow = r; } }
+      for (int r = lane; r < n_rows; r += NT) { double rhs; const double s = row_eval(r, sZ, rhs); const double v = -s / (1.0 + fabs(rhs)); if (v > kFeasTol && v > vmax) { vmax = v; vrow = r; } }
       sRed[lane] = vmax; sRedI[lane] = vrow;
       __syncthreads();
-      if (lane == 0) { double bv = 0.0; int br = -1; for (int t = 0; t < 64; t++) if (sRedI[t] >= 0 && (sRed[t] > bv || (sRed[t] == bv && sRedI[t] < br))) { bv = sRed[t]; br = sRedI[t]; } sI[1] = br; }
+      // (two levels: sixteen threads take sixteen entries each, then one takes their sixteen — on one thread the 256 entries were a
+      // chain of dependent LDS reads, a quarter of a round; largest violation first, the lower row on a tie: the same whoever reduces)
+      if (lane < 16) { double bv = 0.0; int br = -1; for (int t = lane * 16; t < lane * 16 + 16; t++) if (sRedI[t] >= 0 && (sRed[t] > bv || (sRed[t] == bv && sRedI[t] < br))) { bv = sRed[t]; br = sRedI[t]; } sRed[lane * 16] = bv; sRedI[lane * 16] = br; }
+      __syncthreads();
+      if (lane == 0) { double bv = 0.0; int br = -1; for (int t = 0; t < NT; t += 16) if (sRedI[t] >= 0 && (sRed[t] > bv || (sRed[t] == bv && sRedI[t] < br))) { bv = sRed[t]; br = sRedI[t]; } sI[1] = br; }
       __syncthreads();
       const int viol = sI[1];
       if (viol < 0) { certified = true; break; }
       bool have = false; for (int i = 0; i < na; i++) have = have || sAct[i] == viol;
+      for (int i = 0; i < n_dropped; i++) have = have || sDropped[i] == viol;      // (a row that left with a negative multiplier comes back: the iteration would go round in circles)
       if (have || na >= PA) break;                              // (a row of the set still violated: dependent rows in conflict — no certificate)
       __syncthreads();
       if (lane == 0) { int pos = na; while (pos > 0 && sAct[pos - 1] > viol) { sAct[pos] = sAct[pos - 1]; pos--; } sAct[pos] = viol; }
@@ -251,13 +272,13 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     if (!certified) continue;
     // ---- the optimum: coefficients, objective, outputs — as the interior-point kernels write them ----
     __syncthreads();
-    for (int t = lane; t < 12 * K; t += 64) {      // theta = Th z + ThU init
+    for (int t = lane; t < 12 * K; t += NT) {      // theta = Th z + ThU init
       const int ax = t / (4 * K), r = t - ax * 4 * K;
       double v = tb->ThU[r][0] * sInit[ax * 3] + tb->ThU[r][1] * sInit[ax * 3 + 1] + tb->ThU[r][2] * sInit[ax * 3 + 2];
       for (int c = 0; c < kNZ; c++) v += c < nz ? tb->Th[r][c] * sZ[ax * kNZ + c] : 0.0;
       sTheta[(ax * 8 + r / 4) * 4 + (r % 4)] = v;
     }
-    for (int t = lane; t < 96; t += 64) if ((t % 32) / 4 >= K) sTheta[t] = 0.0;
+    for (int t = lane; t < 96; t += NT) if ((t % 32) / 4 >= K) sTheta[t] = 0.0;
     __syncthreads();
     double obj = 0.0;
     if (lane == 0) {      // the reference's objective on the returned coefficients (:322-383; relaxed: :838-861)
@@ -272,7 +293,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     const double dix = sCoef[3] - sFin[0], diy = sCoef[32 + 3] - sFin[1];
     if (sqrt(dix * dix + diy * diy) < 1.0) { if (lane < 32) sTheta[64 + lane] = sCoef[64 + lane]; }      // :879-880
     __syncthreads();
-    for (int t = lane; t < 96; t += 64) (&sol->coeff[0][0][0])[t] = sTheta[t];
+    for (int t = lane; t < 96; t += NT) (&sol->coeff[0][0][0])[t] = sTheta[t];
     if (lane <= NEP_MAX_POL) sol->times[lane] = (lane <= K) ? g->t_start + lane * T : 0.0;
     const int ns_all = sched.n[K];
     const int ns = ns_all < sp.max_states ? ns_all : sp.max_states;
@@ -280,7 +301,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
       sol->stats.status = mode; sol->stats.objective = obj; sol->K = K; sol->n_states = ns;
     }
     if (ps.states) {
-      for (int s = lane; s < ns; s += 64) {      // generatePwpOut's samples (:911-934)
+      for (int s = lane; s < ns; s += NT) {      // generatePwpOut's samples (:911-934)
         const int i = sched.seg[K * sp.max_states + s]; const double dt = sched.dt[K * sp.max_states + s];
         double* st = ps.states + ((long)slot * sp.max_states + s) * NEP_STATE_DOUBLES;
         for (int ax = 0; ax < 3; ax++) {
@@ -302,7 +323,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
         cr->pwp.n_seg = K;
       }
       if (lane <= NEP_TRAJ_MAX_SEG) cr->pwp.times[lane] = (lane <= K) ? g->t_start + lane * T : 0.0;
-      for (int e = lane; e < 3 * NEP_TRAJ_MAX_SEG * 4; e += 64) {
+      for (int e = lane; e < 3 * NEP_TRAJ_MAX_SEG * 4; e += NT) {
         const int ax = e / (NEP_TRAJ_MAX_SEG * 4), r = e % (NEP_TRAJ_MAX_SEG * 4), seg = r / 4, j = r % 4;
         (&cr->pwp.coeff[0][0][0])[e] = (seg < K) ? sTheta[(ax * 8 + seg) * 4 + j] : 0.0;
       }
@@ -316,7 +337,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
 // zeroed at the START of the next launch sequence — by order_kernel on its way, else by qp_polish_zero_kernel — so that a step
 // has no memset node, no kernel behind this one and no "last workgroup done" counter (512 atomics on one address were 0.08 ms of
 // every step, listed slots or not); until then the host reads them (nep_batch_debug_polish_count).
-__global__ __launch_bounds__(64) void qp_polish_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
+__global__ __launch_bounds__(256) void qp_polish_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
   const int n_listed = ps.polish_count[0];
   int n_ok = 0;
   for (int e = blockIdx.x; e < n_listed; e += gridDim.x) { n_ok += polish_slot(sp, ps, tables, sched, ps.polish_list[e]) ? 1 : 0; __syncthreads(); }
@@ -328,8 +349,8 @@ void launch_qp_polish_zero(int* counters, hipStream_t st) { if (counters) hipLau
 // a fixed small grid walks the list (it holds a per cent of the slots at most)
 void launch_qp_polish(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables, const SampleSched& sched, hipStream_t st) {
   if (n_slots <= 0 || !ps.polish_list) return;
-  static const int g_env = getenv("NEP_POLISH_GRID") ? atoi(getenv("NEP_POLISH_GRID")) : 128;      // (A/B)
-  hipLaunchKernelGGL(qp_polish_kernel, dim3(n_slots < g_env ? n_slots : g_env), dim3(64), 0, st, sp, ps, tables, sched);
+  static const int g_env = getenv("NEP_POLISH_GRID") ? atoi(getenv("NEP_POLISH_GRID")) : 256;      // (A/B)
+  hipLaunchKernelGGL(qp_polish_kernel, dim3(n_slots < g_env ? n_slots : g_env), dim3(256), 0, st, sp, ps, tables, sched);
 }
 
 }  // namespace nep

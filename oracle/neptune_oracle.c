@@ -788,7 +788,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
      complementarity: the gap stalls at 1e-2, tests/golden/moving_hard_cases.npz).  Both are finished exactly: the rows whose slack
      at the last iterate is below 1e-6 (1 + |h|) are taken as the active set, the equality-constrained QP on a maximal independent
      subset of them is solved directly (KKT system), rows with a negative multiplier are dropped and violated rows added, at most
-     twelve times; a point that satisfies every row to 1e-9 (1 + |h|) with multipliers >= -1e-9 (1 + max|nu|) is the optimum of a
+     six times (a certificate takes one to three; a row that comes back after leaving ends the attempt); a point that satisfies every row to 1e-9 (1 + |h|) with multipliers >= -1e-9 (1 + max|nu|) is the optimum of a
      strictly convex QP whatever iterate it was found from, and the solve counts as converged.  Not for problems with the terminal
      ball row (a quadratic constraint); an infeasible problem can never be certified (every row is checked). */
   if (ret != 0 && !qc && g_polish) {
@@ -799,11 +799,11 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
        problem has long driven the primal residual down; what is left are infeasible problems, which cannot be certified) */
     if (finite) for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = hy_abs_slack(g, ysrc, hy[r], ny); if (-a > 1e-4 * (1.0 + fabs(Q->rows[r].rhs))) finite = 0; }
     if (finite) for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; double a = hy_abs_slack(g, ysrc, hy[r], ny); if (a < 1e-6 * (1.0 + fabs(Q->rows[r].rhs))) act[na++] = r; }
-    int ok = 0, rounds = 0;
+    int ok = 0, rounds = 0, n_dropped = 0, dropped[12];
     double* ys = (double*)malloc(sizeof(double) * (ny + 1));
     double* nu = (double*)malloc(sizeof(double) * (m + 1));
     double* Qb = (double*)malloc(sizeof(double) * (size_t)(ny + 1) * ny);
-    for (rounds = 0; finite && rounds < 12; rounds++) {
+    for (rounds = 0; finite && rounds < 6; rounds++) {
       { int nq = 0, keep = 0;      /* a maximal independent subset, in row order (modified Gram-Schmidt) */
         for (int i = 0; i < na; i++) {
           const double* g = Gy + (size_t)act[i] * ny; double v[64]; double n0 = 0, n1 = 0;
@@ -831,12 +831,14 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
       for (int a_ = 0; a_ < ny; a_++) ys[a_] = x[a_];
       for (int i = 0; i < na; i++) nu[i] = x[ny + i];
       free(x); free(K);
-      int worst = -1; double numax = 0; for (int i = 0; i < na; i++) if (fabs(nu[i]) > numax) numax = fabs(nu[i]);
-      { double wv = -1e-9 * (1.0 + numax); for (int i = 0; i < na; i++) if (nu[i] < wv) { wv = nu[i]; worst = i; } }
-      if (worst >= 0) { for (int i = worst; i + 1 < na; i++) act[i] = act[i + 1]; na--; continue; }
+      double numax = 0; for (int i = 0; i < na; i++) if (fabs(nu[i]) > numax) numax = fabs(nu[i]);
+      { /* the rows with a negative multiplier leave, all at once (a row that is missed comes back through the violation test) */
+        const double wv = -1e-9 * (1.0 + numax); int keep = 0, n_neg = 0;
+        for (int i = 0; i < na; i++) { if (nu[i] < wv) { n_neg++; if (n_dropped < 12) dropped[n_dropped++] = act[i]; } else act[keep++] = act[i]; }
+        if (n_neg > 0) { na = keep; continue; } }
       int viol = -1; double vv = 0.0;
       for (int r = 0; r < m; r++) { const double* g = Gy + (size_t)r * ny; const double a = -hy_abs_slack(g, ys, hy[r], ny) / (1.0 + fabs(Q->rows[r].rhs)); if (a > 1e-9 && a > vv) { vv = a; viol = r; } }
-      if (viol >= 0) { int have = 0; for (int i = 0; i < na; i++) have |= act[i] == viol; if (have) break; int pos = na; while (pos > 0 && act[pos - 1] > viol) { act[pos] = act[pos - 1]; pos--; } act[pos] = viol; na++; continue; }
+      if (viol >= 0) { int have = 0; for (int i = 0; i < na; i++) have |= act[i] == viol; for (int i = 0; i < n_dropped; i++) have |= dropped[i] == viol; if (have) break;      /* (a row of the set still violated, or one that left with a negative multiplier comes back: the iteration would go round in circles — no certificate) */ int pos = na; while (pos > 0 && act[pos - 1] > viol) { act[pos] = act[pos - 1]; pos--; } act[pos] = viol; na++; continue; }
       ok = 1; break;
     }
     if (trace) fprintf(stderr, "polish: %s after %d rounds, %d active rows\n", ok ? "certified" : "no", rounds, na);
