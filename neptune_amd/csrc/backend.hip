@@ -400,7 +400,7 @@ struct Engine {
     if (ps.order_key && have_history && slots > 1024 && d_order.n >= (size_t)slots) {   // (more than one wave of workgroups)
       launch_qp_order(slots, d_order_key.p, d_order.p, st, ps.polish_count);      // (zeroes the polish pass's counters on its way)
       ps.order = d_order.p; last_ordered = true;
-    } else if (ps.polish_count) launch_qp_polish_zero(ps.polish_count, st);
+    } else if (ps.polish_count && !(use_reg && slots == 1)) launch_qp_polish_zero(ps.polish_count, st);      // (a one-workgroup launch — the per-agent handle — sets the counters itself: qp_reg_kernel's last lines)
     if (use_reg) launch_qp_reg(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     else launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     if (skip && !no_redo) {      // (NEP_SEP_NO_REDO, read in size_scratch: development aid — the flagged replans keep their presolved result for inspection)

@@ -1053,7 +1053,13 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((CULL && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;
     sol->stats.objective = sc[sObjOut]; { const long long dt_ = (long long)wall_clock64() - t_wg0; const double us_ = (double)dt_ * sp.us_per_tick; sol->stats.solve_us = us_; if (ps.order_key) { const double k_ = us_ * 0.125; const int kn = k_ > 63.0 ? 63 : (int)k_, ko = ps.order_key[slot] - sp.qp_key_decay; ps.order_key[slot] = (sp.qp_key_decay > 0 && ko > kn) ? ko : kn; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
     sol->K = Ko; sol->n_states = ns;
-    if constexpr (!CULL) { if (ps.polish_list && sI[29] != 0) { ps.polish_flag[slot] = sI[29]; ps.polish_list[atomicAdd(ps.polish_count, 1)] = slot; } }
+    if constexpr (!CULL) {
+      if (ps.polish_list) {
+        // (a launch of one workgroup — the per-agent handle's — is its own list: no counter to zero beforehand, no kernel to do it)
+        if (gridDim.x == 1) { ps.polish_count[0] = sI[29] != 0 ? 1 : 0; ps.polish_count[3] = 0; if (sI[29] != 0) { ps.polish_flag[slot] = sI[29]; ps.polish_list[0] = slot; } }
+        else if (sI[29] != 0) { ps.polish_flag[slot] = sI[29]; ps.polish_list[atomicAdd(ps.polish_count, 1)] = slot; }
+      }
+    }
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)
     for (int s = tid; s < ns; s += BS) {
