@@ -70,7 +70,7 @@ class PolySolver:
 
     def setPolish(self, on=True):
         """not in the reference: the active-set polish of solves that end without the strict tests (nep_backend_set_polish; on by default)"""
-        check(lib().nep_backend_set_polish(self._h, 1 if on else 0))
+        check(lib().nep_backend_set_polish(self._h, 2 if (on == 2 and on is not True) else (1 if on else 0)))
 
     def setMaxRuntime(self, runtime):
         check(lib().nep_backend_set_max_runtime(self._h, runtime))
@@ -439,8 +439,9 @@ class BatchBackend:
         check(lib().nep_batch_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
 
     def set_polish(self, on=True):
-        """the active-set polish of solves that end without the strict tests (on by default): nep_batch_set_polish"""
-        check(lib().nep_batch_set_polish(self._h, 1 if on else 0))
+        """the active-set polish of solves that end without the strict tests (on by default; 2: under the line presolve as well):
+        nep_batch_set_polish"""
+        check(lib().nep_batch_set_polish(self._h, 2 if (on == 2 and on is not True) else (1 if on else 0)))
 
     def polish_count(self):
         """(replans listed for the polish pass of the last replan, replans it certified): nep_batch_debug_polish_count"""

@@ -99,7 +99,7 @@ struct Engine {
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
   DevBuf<int> d_line_skip, d_redo_list, d_redo_count;   // spatial presolve: skipped LPs per segment, replans listed for the redo pass
-  DevBuf<double> d_polish_z; DevBuf<int> d_polish_flag, d_polish_list, d_polish_count; bool polish = true;      // the active-set polish of solves that end without the strict tests (qp_polish_kernel.hip; nep_*_set_polish)
+  DevBuf<double> d_polish_z; DevBuf<int> d_polish_flag, d_polish_list, d_polish_count; bool polish = true, polish_presolve = false;      // the active-set polish of solves that end without the strict tests (qp_polish_kernel.hip; nep_*_set_polish)
   DevBuf<long long> d_dbg; bool profile_phases = false;
   DevBuf<int> d_flags;
   // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
@@ -271,9 +271,10 @@ struct Engine {
     ps.dbg = profile_phases ? d_dbg.p : nullptr;
     ps.flags = d_flags.p;
     ps.fe_box = d_fe_box.p;
-    // the polish pass finishes what the register kernel's plain instantiation leaves (no presolve: there the parked rows are verified by
-    // the QP kernel itself and a polished point would have to go through that verification again)
-    const bool pol = polish && use_reg && !(sp.cull_radius > 0.0) && d_polish_z.p != nullptr;
+    // the polish pass finishes what the register kernel leaves.  Under the presolve only on request (nep_batch_set_polish(h, 2): on the
+    // near lines, and a certified point goes through the presolve's verification of the parked lines and the skipped LPs again —
+    // polish_slot): a pass over a handful of slots is 0.03-0.06 ms, 8 % of a presolved step
+    const bool pol = polish && use_reg && (polish_presolve || !(sp.cull_radius > 0.0)) && d_polish_z.p != nullptr;
     ps.polish_z = pol ? d_polish_z.p : nullptr; ps.polish_flag = pol ? d_polish_flag.p : nullptr;
     ps.polish_list = pol ? d_polish_list.p : nullptr; ps.polish_count = pol ? d_polish_count.p : nullptr;
   }
@@ -1404,8 +1405,8 @@ namespace { int set_tol(Engine& E, double res, double gap) {
 int nep_batch_set_tolerances(nep_batch_t* h, double residual_tol, double gap_tol) { if (!h) return fail(NEP_E_ARG, "null handle"); return set_tol(h->eng, residual_tol, gap_tol); }
 int nep_backend_set_tolerances(nep_backend_t* h, double residual_tol, double gap_tol) { if (!h) return fail(NEP_E_ARG, "null handle"); return set_tol(h->eng, residual_tol, gap_tol); }
 
-int nep_batch_set_polish(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; return 0; }
-int nep_backend_set_polish(nep_backend_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; return 0; }
+int nep_batch_set_polish(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; h->eng.polish_presolve = on == 2; return 0; }
+int nep_backend_set_polish(nep_backend_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; h->eng.polish_presolve = on == 2; return 0; }
 // Test hook: the last replan's polish pass — replans listed for it (solves that ended without the strict tests), replans certified
 int nep_batch_debug_polish_count(nep_batch_t* h, int32_t* listed, int32_t* certified) {
   if (!h) return fail(NEP_E_ARG, "null handle");

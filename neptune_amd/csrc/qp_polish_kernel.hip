@@ -17,7 +17,8 @@
 //
 // A certified mode-0 problem is NEP_OK (also when the interior point had gone on to the relaxed solve), a certified relaxed one
 // NEP_RELAXED; without a certificate everything stays as the QP kernel left it.  Not for problems with the terminal ball row (a
-// quadratic constraint, :680-702) and not under the line presolve (whose parked rows are verified by the QP kernel itself).
+// quadratic constraint, :680-702).  Under the line presolve the pass works on the near lines and accepts a certified point only if it
+// also passes the presolve's own verification (parked lines, movement bound of the skipped LPs): see polish_slot.
 // oracle/neptune_oracle.c::qp_solve runs the same rule; the two agree to the accuracy of a 24 x 24 solve (tests compare them).
 #include <hip/hip_runtime.h>
 
@@ -33,6 +34,13 @@ constexpr int PST = PA + 1;     // LDS row stride of the Schur complement
 constexpr int kPolRounds = 6;   // a certificate takes one to three rounds (oracle: the same bound)
 constexpr int kPolLines = 768;  // lines staged in LDS (a config-4 replan has ~510; beyond: read where they lie)
 constexpr double kActTol = 1e-6, kFeasTol = 1e-9, kDualTol = 1e-9, kPivTol = 1e-12, kStartTol = 1e-4;
+// MINVO position basis inverse on [0, 1] (qp_common.h::cQpAPosInv, the literals of nep_tables.h::kAPosInv): the control points of the
+// polished trajectory, for the presolve's parked-line and movement tests
+__constant__ double cPolAPosInv[4][4] = {
+    {-0.03203276669713047, -0.09273093424558249, 0.3420572455666699, 1.1023313949144335},
+    {-0.05111494245568798, -0.046272612998418894, 0.5458234872124772, 1.0979806946005568},
+    {-0.07454781852812224, 0.203951949894552, 0.796048050105448, 1.0745478185281223},
+    {1.0, 1.0, 0.9999999999999996, 0.9999999999999993}};
 }  // namespace
 
 // one listed slot (a workgroup of 256); returns true when a problem of the slot was certified and its outputs rewritten
@@ -280,6 +288,49 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
     }
     for (int t = lane; t < 96; t += NT) if ((t % 32) / 4 >= K) sTheta[t] = 0.0;
     __syncthreads();
+    if (ps.line_far && !ps.lines_override) {
+      // Under the line presolve the rows above are the NEAR lines only (section 7 of DESIGN.md).  The certified point is the optimum of
+      // the full problem if it also satisfies what the presolve set aside, tested as qp_reg_kernel tests its own solution: every parked
+      // line at the trajectory's position control points, and — where LPs were skipped — every control point within cull_radius of the
+      // guess's.  A point that fails either is dropped (the slot keeps the interior point's verified result).
+      if (lane == 0) sI[2] = 0;
+      __syncthreads();
+      if (lane == 0) {      // (the parked lines' counts, as prefix sums: sDrop's storage — the rounds are over)
+        int o = 0, sk = 0;
+        for (int i = 0; i < NEP_MAX_POL; i++) { sDrop[i] = o; if (i < K) { o += ps.line_far[(long)slot * NEP_MAX_POL + i]; sk += ps.line_skip ? ps.line_skip[(long)slot * NEP_MAX_POL + i] : 0; } }
+        sDrop[NEP_MAX_POL] = o; sDrop[NEP_MAX_POL + 1] = sk;
+      }
+      __syncthreads();
+      const int n_far = sDrop[NEP_MAX_POL], n_skip = sDrop[NEP_MAX_POL + 1];
+      double* sCp = sRed;      // [4 K][2]
+      if (lane < 8 * K) {
+        const int rho = lane >> 1, ax = lane & 1, sg = rho >> 2, k = rho & 3;
+        const double c0 = (T * T * T) * cPolAPosInv[0][k], c1 = (T * T) * cPolAPosInv[1][k], c2 = T * cPolAPosInv[2][k], c3 = cPolAPosInv[3][k];
+        const double* Q = sTheta + (ax * 8 + sg) * 4;
+        const double v = ((Q[0] * c0 + Q[1] * c1) + Q[2] * c2) + Q[3] * c3;
+        sCp[rho * 2 + ax] = v;
+        if (n_skip > 0) {
+          const double* P = sCoef + (ax * 8 + sg) * 4;
+          const double gq = ((P[0] * c0 + P[1] * c1) + P[2] * c2) + P[3] * c3;
+          double d2 = (v - gq) * (v - gq);
+          d2 += __shfl_xor(d2, 1);                        // (x and y of a control point sit on neighbouring lanes)
+          if (d2 > sp.cull_radius * sp.cull_radius) sI[2] = 1;
+        }
+      }
+      __syncthreads();
+      bool bad = false;
+      for (int e = lane; e < n_far; e += NT) {
+        int i = 0;
+        for (int j = 1; j < NEP_MAX_POL; j++) i += (e >= sDrop[j]) ? 1 : 0;
+        const double* nd = bucket0 + ((long)i * sp.lines_cap + ((long)sp.lines_cap - 1 - (e - sDrop[i]))) * 3;
+        for (int k = 0; k < 4; k++) bad = bad || (nd[0] * sCp[(4 * i + k) * 2] + nd[1] * sCp[(4 * i + k) * 2 + 1] + nd[2] - 1.0 > 0.0);
+      }
+      if (bad) sI[2] = 1;
+      __syncthreads();
+      const bool refuse = sI[2] != 0;
+      __syncthreads();
+      if (refuse) continue;
+    }
     double obj = 0.0;
     if (lane == 0) {      // the reference's objective on the returned coefficients (:322-383; relaxed: :838-861)
       for (int ax = 0; ax < 3; ax++) {

@@ -77,7 +77,9 @@ typedef double isd_t;
 __device__ __forceinline__ double is_of(double s, isd_t) { return frcp(s); }
 #endif
 
-template <bool CULL, int RS>
+// (PST: the hooks of the polish pass under the presolve — an instantiation of their own, chosen when nep_batch_set_polish(h, 2) asks
+// for it: they cost the presolve's kernel two more spilled registers and 3 % of its time, which the default does not pay)
+template <bool CULL, int RS, bool PST = true>
 __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sB = smem + oB; double* sOff = smem + oOff; double* sAccL = smem + oAccL;
@@ -289,7 +291,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
       }
     };
 
-    status = NEP_FAILED; if (tid == 0) { sI[31] = 0; sI[32] = 0; sc[sObjOut] = 0.0; }
+    status = NEP_FAILED; if (tid == 0) { sI[31] = 0; sI[32] = 0; sc[sObjOut] = 0.0; if (CULL) sI[29] = 0; }      // (sI[29]: a second attempt supersedes what the first one left for the polish pass)
 
     for (int mode = 0; mode < 2; mode++) {
       const QpTable* __restrict__ tb = tables + mode * (kMaxK + 1) + K;
@@ -948,10 +950,18 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
         }
         if (uncon) converged = true;
         if (!converged && have_loose) { __syncthreads(); if (tid < n) sZ[tid] = sZl[tid]; if (tid == 0) sc[sObj] = sc[sObjLoose]; converged = true; }
-        if constexpr (!CULL) {
+        {
           // a solve that ends without the strict tests (the loose snapshot, or no convergence at all) on a problem without the ball row
-          // leaves its last point for the active-set polish (qp_polish_kernel.hip), which finishes it exactly or leaves it alone
-          if (ps.polish_z && !has_qc && !uncon && !(converged && __builtin_amdgcn_readfirstlane(sI[28]) == 1) && __builtin_amdgcn_readfirstlane(sI[30]) == 0) {
+          // leaves its last point for the active-set polish (qp_polish_kernel.hip), which finishes it exactly or leaves it alone.
+          // Under the presolve: the first attempt's solves only (near lines; the polish pass re-verifies the parked lines and the
+          // movement bound of the skipped LPs before it accepts a point) — a second attempt's rows are not what the pass would stage
+          // (the presolve's instantiation keeps no per-iteration note of the strict tests — its registers are short as it is: a solve
+          // counts as loose there when the loose window was ever opened (sI[22]; a strict pass inside the window is polished too, which
+          // changes nothing but the last digits), and the TimeLimit is read off the clock again)
+          bool leave;
+          if constexpr (CULL) leave = !use_far && (!converged || __builtin_amdgcn_readfirstlane(sI[22]) >= 0) && !(sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks);
+          else leave = !(converged && __builtin_amdgcn_readfirstlane(sI[28]) == 1) && __builtin_amdgcn_readfirstlane(sI[30]) == 0;
+          if ((!CULL || PST) && ps.polish_z && !has_qc && !uncon && leave) {
             __syncthreads();
             if (tid < n) ps.polish_z[((long)slot * 2 + mode) * 24 + tid] = sZ[tid];
             if (tid == 0) sI[29] |= 1 << mode;
@@ -1053,12 +1063,11 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
     sol->stats.n_rows = K_ok ? 48 * K + 4 * ((CULL && L_used < L_all) ? L_used : L_used - n_lpf) : 0; sol->stats.qc_active = has_qc ? 1 : 0;
     sol->stats.objective = sc[sObjOut]; { const long long dt_ = (long long)wall_clock64() - t_wg0; const double us_ = (double)dt_ * sp.us_per_tick; sol->stats.solve_us = us_; if (ps.order_key) { const double k_ = us_ * 0.125; const int kn = k_ > 63.0 ? 63 : (int)k_, ko = ps.order_key[slot] - sp.qp_key_decay; ps.order_key[slot] = (sp.qp_key_decay > 0 && ko > kn) ? ko : kn; } }   // the per-replan device time, and the next launch's ordering key (8 us bins)
     sol->K = Ko; sol->n_states = ns;
-    if constexpr (!CULL) {
-      if (ps.polish_list) {
-        // (a launch of one workgroup — the per-agent handle's — is its own list: no counter to zero beforehand, no kernel to do it)
-        if (gridDim.x == 1) { ps.polish_count[0] = sI[29] != 0 ? 1 : 0; ps.polish_count[3] = 0; if (sI[29] != 0) { ps.polish_flag[slot] = sI[29]; ps.polish_list[0] = slot; } }
-        else if (sI[29] != 0) { ps.polish_flag[slot] = sI[29]; ps.polish_list[atomicAdd(ps.polish_count, 1)] = slot; }
-      }
+    if (ps.polish_list) {
+      const bool listed = sI[29] != 0 && !(CULL && sI[26] != 0);      // (a replan sent to the redo pass is listed there, if at all)
+      // (a launch of one workgroup — the per-agent handle's — is its own list: no counter to zero beforehand, no kernel to do it)
+      if (gridDim.x == 1) { ps.polish_count[0] = listed ? 1 : 0; ps.polish_count[3] = 0; if (listed) { ps.polish_flag[slot] = sI[29]; ps.polish_list[0] = slot; } }
+      else if (listed) { ps.polish_flag[slot] = sI[29]; ps.polish_list[atomicAdd(ps.polish_count, 1)] = slot; }
     }
   }
   if (ps.states) {  // generatePwpOut's samples (:911-934)
@@ -1121,9 +1130,11 @@ void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, con
                    const SampleSched& sched, size_t lds_bytes, hipStream_t st) {
   if (n_slots <= 0) return;
   const bool cull = ps.line_far != nullptr && !ps.lines_override;
-  static DynLdsAttr attr[2];
-  (void)attr[cull].ensure(cull ? (const void*)qp_reg_kernel<true, kRegSlots> : (const void*)qp_reg_kernel<false, kRegSlots>, lds_bytes);
-  if (cull) hipLaunchKernelGGL((qp_reg_kernel<true, kRegSlots>), dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
+  const int which = !cull ? 0 : (ps.polish_z ? 2 : 1);
+  static DynLdsAttr attr[3];
+  (void)attr[which].ensure(which == 0 ? (const void*)qp_reg_kernel<false, kRegSlots> : which == 1 ? (const void*)qp_reg_kernel<true, kRegSlots, false> : (const void*)qp_reg_kernel<true, kRegSlots, true>, lds_bytes);
+  if (which == 2) hipLaunchKernelGGL((qp_reg_kernel<true, kRegSlots, true>), dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
+  else if (which == 1) hipLaunchKernelGGL((qp_reg_kernel<true, kRegSlots, false>), dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
   else hipLaunchKernelGGL((qp_reg_kernel<false, kRegSlots>), dim3(n_slots), dim3(BS), lds_bytes, st, sp, ps, tables, sched);
 }
 

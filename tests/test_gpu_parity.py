@@ -777,6 +777,39 @@ def test_line_presolve_leaves_the_optimum_unchanged(be, oracle, n_agents, n_stat
     bb.close()
 
 
+@pytest.mark.parametrize("radius", [4.0, 1.0, 0.3])
+def test_line_presolve_on_front_end_guesses_with_the_polish_pass(be, radius):
+    """Front-end guesses are where interior-point solves end on the loose snapshot, and a culled problem takes another path to another
+    loose iterate than the full one: before the polish pass ran under the presolve the two differed by up to 9e-5 in the coefficients
+    on these scenes (scripts/presolve_vs_full_fe.py).  Now both end on the certified vertex — the presolve's polish on the near lines,
+    accepted only if the point passes the parked lines and the movement bound again: same statuses, coefficients within 2e-6 (what is
+    left is two strictly converged interior-point paths), and the polish pass did run under the presolve."""
+    from neptune_amd import dist as ndist
+    S, N = 8, 64
+    scs = [scene.make_scene(N, 20, seed=200 + s) for s in range(S)]
+    p = scs[0]["par"]
+    com, gue = ndist.stack_scenes(scs)
+    bb = be.BatchBackend(p, scs[0]["statics"], n_scenes=S)
+    for s in range(1, S):
+        bb.set_scene_statics(s, scs[s]["statics"])
+    d_com = bb.to_device(com); d_g = bb.to_device(gue)
+    bb.frontend(scene.frontend_cfg(p, beam_width=32), d_com, bb.to_device(np.stack([scene.frontend_starts(s) for s in scs])), d_g, None)
+    bb.replan(d_com, d_g); full = bb.solutions().copy()
+    listed_full, _ = bb.polish_count()
+    assert listed_full >= 1                                          # (loose exits exist on these inputs)
+    bb.set_line_cull(radius); bb.set_polish(2)                       # (2: the pass under the presolve as well — not the default, it costs 8 % of a presolved step)
+    bb.replan(d_com, d_g); cut = bb.solutions().copy()
+    listed, certified = bb.polish_count()
+    assert listed >= 1 and certified >= 1
+    if radius < 1.0:
+        assert bb.redo_count() > S * N // 2                          # (most replans move farther than that: every LP, every row, the plain kernel's hooks)
+    np.testing.assert_array_equal(cut["stats"]["status"], full["stats"]["status"])
+    ok = full["stats"]["status"] != abi.NEP_FAILED
+    d = np.abs(np.array(cut["coeff"]) - np.array(full["coeff"])).reshape(len(full), -1).max(axis=1)[ok]
+    assert d.max() <= 2e-6 and (d > 1e-7).sum() <= 0.03 * ok.sum(), (d.max(), int((d > 1e-7).sum()))
+    bb.close()
+
+
 def test_gjk_batch_matches_the_oracle(be, oracle):
     """gjk::collision on the device (safety check, front end) against the restatement: identical verdicts
     on control polygons scattered around real interval hulls and inflated statics."""
