@@ -145,7 +145,7 @@ def test_exact_signature_shim_compiles_against_minimal_type_declarations(L, tmp_
     tests/cpp/ref_types_min/ (this repo's own few dozen lines naming what the class touches of Eigen, mader_types.hpp and
     entangle_utils.hpp; NOT the reference's headers, NOT Eigen: syntax + signatures + conversions only).  The program
     static_asserts every method's type and makes the calls in Neptune's order (neptune.cpp:102-107, 663, 1514-1527); without a
-    GPU the constructor throws (no CPU path) — the `-m gpu` twin in tests/test_gpu_parity.py checks the solve."""
+    GPU the constructor throws (no CPU path) — the `-m gpu` twin in tests/test_gpu_per_agent_api.py checks the solve."""
     if _find_eigen() is not None:
         pytest.skip("Eigen present: the stand-in <Eigen/Dense> would shadow it; the reference-header test above is the check")
     r = _build_shim_check(tmp_path / "shim_signature_check")

@@ -1,6 +1,6 @@
 """CPU: the front-end beam rule (include/neptune_frontend.h) as stated by the oracle —
 properties every guess must have, and hand-worked cases.  The GPU kernel is compared with this
-bit for bit in tests/test_gpu_parity.py."""
+bit for bit in tests/test_gpu_frontend_safety.py."""
 import numpy as np
 import pytest
 

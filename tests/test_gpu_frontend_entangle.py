@@ -92,7 +92,7 @@ def test_entangle_front_end_matches_the_oracle_bit_for_bit(be, oracle, n_agents,
         assert int(sol[a]["stats"]["status"]) == r["status"]
         assert np.abs(np.array(sol[a]["coeff"])[:, :K, :] - r["coeff"]).max() <= 1e-6
     assert extra >= 0     # (whether a case yields an LP depends on the bend points' distance cull, solver_gurobi_poly.cpp:738-745:
-    bb.close()            #  tests/test_gpu_parity.py::test_real_entangle_states_drive_the_entangle_rows covers scenes where they do)
+    bb.close()            #  tests/test_gpu_entangle_config5.py::test_real_entangle_states_drive_the_entangle_rows covers scenes where they do)
 
 
 @pytest.mark.parametrize("fast_caps", [(0, 32, 8), (2, 32, 8), (40, 1, 8), (40, 32, 0), (1, 0, 0)])
