@@ -117,7 +117,7 @@ struct Engine {
   DevBuf<int> d_order, d_order_key; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double clock_hz = 1e8;       // wall_clock64() rate of the handle's device (set_clock)
-  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; if (!(sp.tol_res > 0.0)) { sp.tol_res = 1e-9; sp.tol_gap = 1e-10; sp.tol_res_inv = 1e9; sp.tol_gap_inv = 1e10; sp.tol_gap_floor = 0.1 * 1e-10; } }      // (called by both create paths: the strict tests' defaults with it)
+  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; { static const int cf = getenv("NEP_CORR_FROM") ? atoi(getenv("NEP_CORR_FROM")) : kCorrFromItDefault, cm = getenv("NEP_CORR_MAX") ? atoi(getenv("NEP_CORR_MAX")) : kCorrMaxCountDefault; sp.corr_from_it = cf; sp.corr_max_count = cm; } if (!(sp.tol_res > 0.0)) { sp.tol_res = 1e-9; sp.tol_gap = 1e-10; sp.tol_res_inv = 1e9; sp.tol_gap_inv = 1e10; sp.tol_gap_floor = 0.1 * 1e-10; } }      // (called by both create paths: the strict tests' defaults with it)
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
   // timing

@@ -15,6 +15,7 @@ constexpr int kHullCP = NEP_HULL_MAX_CP; // 16
 constexpr int kBend = NEP_MAX_BEND;      // 8
 
 // Scene-level constants (setMaxValues, ctor arguments; solver_gurobi_poly.cpp:25-175)
+constexpr int kCorrFromItDefault = 10, kCorrMaxCountDefault = 8;      // (qp_common.h: kCorrFromIt, kCorrMaxCount)
 struct SceneParams {
   int num_agents;     // N (pb.size())
   int num_pol;        // planning intervals
@@ -33,6 +34,7 @@ struct SceneParams {
   double long_length; // solver_gurobi_poly.cpp:173
   double cull_radius; // > 0: separating lines farther than this from the guess are presolved away (verified after the solve)
   long long time_limit_ticks;   // > 0: wall-clock budget of ONE solve in wall_clock64() ticks (setMaxRuntime -> Gurobi TimeLimit, solver_gurobi_poly.cpp:812)
+  int corr_from_it, corr_max_count;      // the interior point's give-up rule (qp_common.h: kCorrFromIt, kCorrMaxCount; NEP_CORR_FROM / NEP_CORR_MAX: development A/B)
   double tol_res, tol_gap, tol_res_inv, tol_gap_inv, tol_gap_floor;      // (tol_gap_floor = 0.1 tol_gap: the centring target's floor)      // the interior point's strict tests: residuals (absolute, the dual one scaled), relative gap; their reciprocals for the merit (nep_batch_set_tolerances)
   int sep_rule;                 // which vertex of the separator LP is returned: 0 the largest-gap one (default), 1 the one a primal simplex of GLPK's default class reaches (nep_batch_set_separator_rule)
   int qp_key_decay;             // the same for the QP workgroups' key (8 us bins; 2: chain QP launch 1.63 -> 1.55 ms, crossing 2.29 -> 2.26; NEP_QP_KEY_DECAY for A/Bs, 0 = the last solve's bin)

@@ -19,7 +19,12 @@ constexpr int kMaxIt = 60;
 // with the primal residual), sigma as computed.  With the full term marginally feasible problems cycle (gap down 10x, back up
 // over three short steps, for ever) and infeasible ones blow up to 1e18 and idle to the iteration cap; without it the former
 // converge and the latter stall within a few iterations (oracle: qp_solve).
-constexpr int kCorrFromIt = 10;
+// (round 5 tried from the sixth iteration / five times at most — scripts/giveup_rule_sweep.py: on the closed loop's hard replans the 38
+// decisively infeasible ones end after 37.7 passes instead of 49.3 and none of the 39 strictly feasible ones is lost, `moving` 1.91 ->
+// 2.01 M replans/s — and took it back: in a fleet flown to its goals (scripts/closed_loop_failures.py) the QP then gives up on 1.54 % of
+// the replans instead of 0.81 %; 10 / 5: 1.22 %, 8 / 5: 1.10 %.  Every earlier give-up loses solves the reference's solver would return.
+// The two are run-time values (SceneParams::corr_from_it / corr_max_count; NEP_CORR_FROM / NEP_CORR_MAX for such A/Bs).)
+constexpr int kCorrFromIt = 10;      // (the default of SceneParams::corr_from_it: nep_device.h's kCorrFromItDefault says the same)
 constexpr double kCorrMinStep = 0.1;
 constexpr int kCorrMaxCount = 8;            // a solve that needs this more often is given up (converging ones: at most five times in 16 000)
 // start point of the rows: slack = max(h - a.x0, kSlackFloor), lambda = kMu0 / slack.  Chosen on this path's two kinds of

@@ -606,10 +606,10 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           // lambda/s ~ 1e17, and the rounding of that last step shows up as 1e-6 in the flat directions of the coefficients
           sm = fmax(sm, sp.tol_gap_floor * (1.0 + fabs(sc[sObj])) * inv_mt);
           if (nopred) sm = sm_keep;            // (sigma mu of the discarded predictor)
-          else if (it >= kCorrFromIt && aaff < kCorrMinStep) {
+          else if (it >= sp.corr_from_it && aaff < kCorrMinStep) {
             // the affine step is too short for its second-order term to mean anything: the iteration is repeated from the same
             // point (a step of length zero) with the predictor discarded — identical in every thread, rare and late
-            if (n_nopred >= kCorrMaxCount) break;             // (not going to end: give this attempt up)
+            if (n_nopred >= sp.corr_max_count) break;             // (not going to end: give this attempt up)
             alpha_prev = 0.0; sm_keep = sm; sI[23] = 1; n_nopred++;
             it--;
             continue;

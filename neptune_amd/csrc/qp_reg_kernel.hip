@@ -32,6 +32,8 @@
 
 #include "qp_common.h"
 
+static_assert(nep::kCorrFromIt == nep::kCorrFromItDefault && nep::kCorrMaxCount == nep::kCorrMaxCountDefault, "the give-up rule's constants are stated twice");
+
 // line rows a thread keeps in registers (8 per segment and slot: 9 slots = 72 lines per segment before the global scratch is used)
 #ifndef NEP_QP_REG_SLOTS
 #define NEP_QP_REG_SLOTS 9
@@ -848,10 +850,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             sm = rr * rr * rr * mu;
             sm = fmax(sm, sp.tol_gap_floor * (1.0 + fabs(sc[sObj])) * inv_mt);
             if (nopred) sm = sc[sSigKeep];       // (sigma mu of the discarded predictor)
-            else if (__builtin_amdgcn_readfirstlane((int)(it >= kCorrFromIt && aaff < kCorrMinStep))) {
+            else if (__builtin_amdgcn_readfirstlane((int)(it >= sp.corr_from_it && aaff < kCorrMinStep))) {
               // the affine step is too short for its second-order term to mean anything: repeat the iteration from the same point
               // (a step of length zero) with the predictor discarded.  Rare and late, so the repeated assembly does not matter.
-              if (n_nopred >= kCorrMaxCount) break;                 // (not going to end: give this attempt up)
+              if (n_nopred >= sp.corr_max_count) break;                 // (not going to end: give this attempt up)
               sc[sAlpha] = 0.0; sc[sSigKeep] = sm; sI[23] = 1; sI[24] = n_nopred + 1;      // (every thread stores the same values)
               it--;
               continue;

@@ -606,6 +606,8 @@ static void qr_apply(int rows, int cols, const double* A, const double* beta, in
 
 static int g_polish = 1, g_last_polished = 0;      /* orc_set_polish: the active-set polish of solves that end without the strict tests (on by default) */
 void orc_set_polish(int on) { g_polish = on; }
+static long g_stat_iters = 0, g_stat_trig = 0;      /* interior-point iterations and discarded predictors since the last orc_pass_stats (a device solve's passes = their sum) */
+void orc_pass_stats(long* iters, long* trig) { if (iters) *iters = g_stat_iters; if (trig) *trig = g_stat_trig; g_stat_iters = 0; g_stat_trig = 0; }
 int orc_last_polished(void) { const int v = g_last_polished; g_last_polished = 0; return v; }      /* (test hook: did a solve since the last call end on the polish?) */
 static double hy_abs_slack(const double* g, const double* y, double h, int ny) { double a = h; for (int c = 0; c < ny; c++) a -= g[c] * y[c]; return a; }
 /* Mehrotra predictor-corrector primal-dual interior point on
@@ -684,7 +686,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
      back up over three short steps, for ever) and infeasible ones blow up to 1e18 and idle to the iteration cap; without it the
      former converge and the latter stall within a few iterations.  Overridable for experiments. */
   const double EXP_CORR = getenv("ORC_EXP_CORR") ? atof(getenv("ORC_EXP_CORR")) : 0.1;
-  const int EXP_CORR_IT = getenv("ORC_EXP_CORR_IT") ? atoi(getenv("ORC_EXP_CORR_IT")) : 10;
+  const int EXP_CORR_IT = getenv("ORC_EXP_CORR_IT") ? atoi(getenv("ORC_EXP_CORR_IT")) : 10;      /* (the kernels' kCorrFromIt / kCorrMaxCount; round 5 tried 6 / 5 and took it back: scripts/giveup_rule_sweep.py, qp_common.h) */
   double alpha_aff = 1.0;
   int ntrig = 0, give_up = 0;
   const int EXP_CORR_MAX = getenv("ORC_EXP_CORR_MAX") ? atoi(getenv("ORC_EXP_CORR_MAX")) : 8;
@@ -698,6 +700,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
   int ret = 1, it = 0, loose_ok = 0, stall = 0, first_loose = -1;
   double best_merit = 0.0;
   for (it = 0; it < 100; it++) {
+    g_stat_iters++;      /* (test hook: orc_pass_stats) */
     for (int a = 0; a < ny; a++) { double v = qy[a]; for (int b = 0; b < ny; b++) v += Py[a * ny + b] * y[b]; rd[a] = v; }
     for (int r = 0; r < m; r++) { double a = 0; const double* g = Gy + (size_t)r * ny; for (int c = 0; c < ny; c++) { a += g[c] * y[c]; rd[c] += g[c] * lam[r]; } rp[r] = a + s[r] - hy[r]; }
     if (qc) { double c; QCY(y, gq, c); rp[m] = c + s[m]; for (int a = 0; a < ny; a++) rd[a] += lam[m] * gq[a]; }
@@ -734,6 +737,7 @@ static int qp_solve(const qp_t* Q, double* th, int* iters_out) {
          ~1e-15 in the last iteration and the weights lam/s with it to ~1e17) */
       double smu = sigma * mu; { const double fl = 0.1 * EXP_GAPTOL * (1.0 + fabs(obj)) / (mt > 0 ? mt : 1); if (smu < fl) smu = fl; }
       if (pass == 1 && it >= EXP_CORR_IT && alpha_aff < EXP_CORR) {
+        g_stat_trig++;
         if (++ntrig > EXP_CORR_MAX) { give_up = 1; break; }     /* a solve that needs this more than eight times is not going to end (converging ones: at most five in 16 000) */
         for (int r = 0; r < mt; r++) { dsa[r] = -rp[r]; dla[r] = -lam[r] + w[r] * rp[r]; }
       }

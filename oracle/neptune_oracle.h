@@ -102,6 +102,7 @@ void orc_set_qp_tolerances(double residual_tol, double gap_tol);
 /* the active-set polish of interior-point solves that end without passing the strict tests (qp_solve; on by default) */
 void orc_set_polish(int on);
 int orc_last_polished(void);
+void orc_pass_stats(long* iters, long* trig);      /* test hook: interior-point iterations / discarded predictors since the last call */
 
 /* PolySolverGurobi::optimize (solver_gurobi_poly.cpp:804-887) for one agent.
  *   K, coeff_init: setInitTrajectory (:187-244)

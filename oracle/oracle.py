@@ -79,6 +79,7 @@ def lib():
         L.orc_set_separator_rule.argtypes = [C.c_int]; L.orc_set_separator_rule.restype = None
         L.orc_set_qp_tolerances.argtypes = [C.c_double, C.c_double]; L.orc_set_qp_tolerances.restype = None
         L.orc_set_polish.argtypes = [C.c_int]; L.orc_set_polish.restype = None
+        L.orc_pass_stats.argtypes = [C.POINTER(C.c_long), C.POINTER(C.c_long)]; L.orc_pass_stats.restype = None
         L.orc_last_polished.argtypes = []; L.orc_last_polished.restype = C.c_int
         L.orc_optimize.argtypes = [C.POINTER(orc_params), C.c_int, C.c_void_p, C.c_int,
                                    C.POINTER(orc_polys), C.POINTER(orc_polys), C.POINTER(orc_ent),
@@ -164,6 +165,13 @@ def set_separator_rule(rule):
     """0: the largest-gap vertex (default); 1: the GLPK-class simplex's vertex — for every separator call of the restated path
     made from this thread afterwards (checker of nep_batch_set_separator_rule)"""
     lib().orc_set_separator_rule(int(rule))
+
+
+def pass_stats():
+    """(interior-point iterations, discarded predictors) since the last call: a device solve's passes are their sum"""
+    a, b = C.c_long(0), C.c_long(0)
+    lib().orc_pass_stats(C.byref(a), C.byref(b))
+    return int(a.value), int(b.value)
 
 
 def set_polish(on=True):
