@@ -171,7 +171,11 @@ int nep_batch_set_static_reps(nep_batch_t* h, int32_t scene, const double* rep, 
  * nep_batch_set_fe_ent_fast_caps     (neptune_backend_debug.h) what the fixed record's path accepts before a child goes to a big record: list
  *                                    entries (<= NEP_FE_ENT_CAP), new crossings per sampled step (<= 32), bend points
  *                                    (<= NEP_MAX_BEND).  The results do not depend on these — the tests set them to
- *                                    0 / 1 / 2 to drive ordinary scenes through the big records.                      */
+ *                                    0 / 1 / 2 to drive ordinary scenes through the big records.
+ * The FIRST entangle-aware front-end call of a handle (and the first after a setting that changes a size) allocates the search's
+ * device scratch — per-child states, the big-record pool and its betas, ≈ 0.3 GB at BASELINE configs[4] with 32 scenes — so it
+ * must be made eagerly, before any stream capture: inside a capture the allocation fails with NEP_E_HIP.  Later calls with the
+ * same sizes allocate nothing and can be captured (bench_legs/ does exactly that: warm-up steps first, then the graph).       */
 int nep_batch_set_fe_ent_big_records(nep_batch_t* h, int64_t records);
 int nep_batch_frontend_ent(nep_batch_t* h, const nep_fe_cfg* cfg, const nep_traj_rec* d_committed, const nep_fe_start* d_start,
                            const nep_fe_ent_state* d_ent_init, nep_guess* d_guess, nep_fe_result* d_result,
