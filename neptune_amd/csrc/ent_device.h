@@ -91,8 +91,11 @@ struct EntAddBig {
 constexpr int kEntPkHead = 2 + 2 * kBend;      // doubles of a packed record before the samples: [present, bend count | pad] [8 bend points] (everything 16-byte aligned)
 constexpr int kEntPkBend = 2;
 
-__device__ __forceinline__ Ev2 ent_pb(const EntCtx& c, int j) { return Ev2{c.pb[2 * j], c.pb[2 * j + 1]}; }
-__device__ __forceinline__ Ev2 ent_srep(const EntCtx& c, int s, int col) { return Ev2{c.srep[(s * 2 + col) * 2], c.srep[(s * 2 + col) * 2 + 1]}; }
+// (pb and srep are device buffers: read through global-typed pointers.  As members of a struct their address space is unknown to the
+// compiler, and a FLAT load counts against the LDS counter as well — every wait for an LDS read then also waits for these)
+typedef __attribute__((address_space(1))) const double* ent_gcd;
+__device__ __forceinline__ Ev2 ent_pb(const EntCtx& c, int j) { const ent_gcd q = (ent_gcd)c.pb; return Ev2{q[2 * j], q[2 * j + 1]}; }
+__device__ __forceinline__ Ev2 ent_srep(const EntCtx& c, int s, int col) { const ent_gcd q = (ent_gcd)c.srep; return Ev2{q[(s * 2 + col) * 2], q[(s * 2 + col) * 2 + 1]}; }
 // (hr: hull_ref of agent i — the samples and the presence flags travel with the hull data, in one array or in all-gathered blocks)
 __device__ __forceinline__ Ev2 ent_sampled(const EntCtx& c, const HullRef& hr, int interval, int col) {
   const double* q = blk(c.sampled, hr.boff) + ((hr.e * c.num_pol + interval) * (c.ns + 1) + col) * 2; return Ev2{q[0], q[1]};
@@ -181,7 +184,7 @@ __device__ __forceinline__ bool ent_static_may_cross(const EntCtx& c, const EntB
 // (f_known: -1 = evaluate the base-sweep test here; 0 / 1 = its outcome, from EntCtx::f_bits)
 // (b0: bend point 0 in registers, where the caller has fetched it with the record's header — most tethers have no other, and a load
 // issued here waits for everything the caller has requested ahead, i.e. for the NEXT obstacle's record)
-template <class ADD> __device__ __forceinline__ void ent_cross_agent(ADD& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, const double* __restrict__ bp, int agent_id, int f_known = -1, bool have_b0 = false, Ev2 b0 = Ev2{0, 0}, Ev2 b1 = Ev2{0, 0}) {
+template <class ADD, class BP = const double*> __device__ __forceinline__ void ent_cross_agent(ADD& add, Ev2 pk, Ev2 pk1, Ev2 pik, Ev2 pik1, Ev2 pb_self, int nb, BP bp, int agent_id, int f_known = -1, bool have_b0 = false, Ev2 b0 = Ev2{0, 0}, Ev2 b1 = Ev2{0, 0}) {
   bool base_addition = false;
   // (have_b0: bend points 0 AND 1 are in registers, fetched by the caller with the record's header; a segment's far end is kept for
   // the next segment's near end.  Read where they are used, a tether of two to four bend points — the bench's config-5 tethers — cost
@@ -228,12 +231,12 @@ template <class ADD> __device__ __forceinline__ void ent_cross_static(ADD& add, 
       return i;
     };
     int s = next_cand();
-    const double2* r = (const double2*)(c.srep + (long)(s < c.S ? s : 0) * 4);
-    double2 q0 = r[0], q1 = r[1];
+    const ent_gcd r = (ent_gcd)c.srep + (long)(s < c.S ? s : 0) * 4;
+    double2 q0{r[0], r[1]}, q1{r[2], r[3]};
     while (s < c.S) {
       const int sn = next_cand();
-      const double2* rn = (const double2*)(c.srep + (long)(sn < c.S ? sn : 0) * 4);
-      const double2 n0 = rn[0], n1 = rn[1];
+      const ent_gcd rn = (ent_gcd)c.srep + (long)(sn < c.S ? sn : 0) * 4;
+      const double2 n0{rn[0], rn[1]}, n1{rn[2], rn[3]};
       const Ev2 pik{q1.x, q1.y}, pbi{q0.x, q0.y};
       Ev2 u, v;
       const double c1 = ent_wedge2(pk, pik, pbi, u, v), c2 = ent_wedge(pk1, pik, pbi);
@@ -563,11 +566,23 @@ template <class REC> __device__ __forceinline__ void ent_cross_step(EntAdd& add,
     xv_++;
 #endif
     if (i == c.own) continue;
-    const double* r = rec_of(i, itv);      // (LDS copy when the agent is staged, else the packed record itself)
+    const int fk = !c.f_bits ? -1 : (index > c.num_pol ? 0 : (int)((c.f_bits[i] >> (j - 1)) & 1u));
+    // (a staged record is read through an LDS-typed pointer — ds_read: through a generic pointer the same reads are FLAT loads, which
+    // take the vector-memory path even when the address is LDS; the agent loop is two dependent round trips of them per visit)
+    const int lo = rec_of(i, itv);      // byte offset of the record's LDS copy, or -1: not staged
+    if (lo >= 0) {
+      typedef __attribute__((address_space(3))) const double* lcd; typedef __attribute__((address_space(3))) const int* lci;
+      const lcd r = (lcd)(unsigned)lo;
+      if (!((lci)r)[0]) continue;
+      const int nbv = ((lci)r)[1];
+      const Ev2 sa{r[kEntPkHead + 2 * jl], r[kEntPkHead + 2 * jl + 1]}, sb{r[kEntPkHead + 2 * jr], r[kEntPkHead + 2 * jr + 1]}, b0{r[kEntPkBend], r[kEntPkBend + 1]}, b1{r[kEntPkBend + 2], r[kEntPkBend + 3]};
+      ent_cross_agent(add, pk, pk1, sa, sb, pb_self, nbv, r + kEntPkBend, i + 1, fk, true, b0, b1);
+      continue;
+    }
+    const double* r = ent_rec(c, i, itv);
     const int2 hd = *(const int2*)r;
     if (!hd.x) continue;
     const double2 sa = *(const double2*)(r + kEntPkHead + 2 * jl), sb = *(const double2*)(r + kEntPkHead + 2 * jr), b0 = *(const double2*)(r + kEntPkBend), b1 = *(const double2*)(r + kEntPkBend + 2);
-    const int fk = !c.f_bits ? -1 : (index > c.num_pol ? 0 : (int)((c.f_bits[i] >> (j - 1)) & 1u));
     ent_cross_agent(add, pk, pk1, Ev2{sa.x, sa.y}, Ev2{sb.x, sb.y}, pb_self, hd.y, r + kEntPkBend, i + 1, fk, true, Ev2{b0.x, b0.y}, Ev2{b1.x, b1.y});
   }
 #ifdef NEP_PROFILE_PHASES
@@ -596,12 +611,21 @@ template <class ST> __device__ int ent_propagate_pre(const EntCtx& c, ST* st, co
   for (int j = 1; j <= ns; j++) {
     pk1 = ent_step_point(c, cxo, cyo, end, j);
     arc += ent_dist(pk1, pk);
-    const unsigned h = hdr[j - 1];
+    // (hdr and pool are LDS: read through LDS-typed pointers — ds_read instead of flat loads, see ent_cross_step)
+    typedef __attribute__((address_space(3))) const unsigned* lcu;
+    const unsigned h = ((lcu)(unsigned)(unsigned long long)hdr)[j - 1];
     if (h & kEntHdrOvf) return 3;
     EntAdd add; add.clear(); add.lim = add_lim;
     add.n = (int)((h >> 16) & 0xffu);
-    const unsigned* w = (h & kEntHdrGlobal) ? gblocks + (j - 1) * kEntAddCap : pool + (h & 0xffffu);      // (gblocks: this child's blocks, one per step)
-    add.r0 = add.n > 0 ? w[0] : 0u; add.r1 = add.n > 1 ? w[1] : 0u; add.r2 = add.n > 2 ? w[2] : 0u; add.r3 = add.n > 3 ? w[3] : 0u;
+    const unsigned* w;
+    if (h & kEntHdrGlobal) {
+      w = gblocks + (j - 1) * kEntAddCap;      // (gblocks: this child's blocks, one per step)
+      add.r0 = add.n > 0 ? w[0] : 0u; add.r1 = add.n > 1 ? w[1] : 0u; add.r2 = add.n > 2 ? w[2] : 0u; add.r3 = add.n > 3 ? w[3] : 0u;
+    } else {
+      w = pool + (h & 0xffffu);
+      const lcu wl = (lcu)(unsigned)(unsigned long long)w;
+      add.r0 = add.n > 0 ? wl[0] : 0u; add.r1 = add.n > 1 ? wl[1] : 0u; add.r2 = add.n > 2 ? wl[2] : 0u; add.r3 = add.n > 3 ? wl[3] : 0u;
+    }
     add.rest = const_cast<unsigned*>(w) + EntAdd::reg;      // (read only from here on: the merge flags cancelled entries in `gone`)
     if (st->n_alpha + add.n > (c.N + c.S) * cap_mult) return 1;
     if (add.n > 0) {

@@ -2226,10 +2226,13 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
 #ifdef NEP_PROFILE_PHASES
         const long long t_staged_ = clock64();
 #endif
-        auto rec_of = [&](int i, int itv) -> const double* {
+        typedef __attribute__((address_space(3))) const unsigned* x_lcu;
+        const x_lcu x_U_l = (x_lcu)(unsigned)(unsigned long long)x_U;      // (x_U's address went through an integer: the compiler no longer knows it is LDS)
+        const unsigned x_rec_lds = (unsigned)(unsigned long long)x_rec;      // (a generic pointer into LDS: its low half is the LDS address)
+        auto rec_of = [&](int i, int itv) -> int {      // LDS byte offset of agent i's staged record, -1: read the packed record where it lies
           const int w = i >> 5;
-          const int sl = (int)x_U[MW + w] + __popc(x_U[w] & ((1u << (i & 31)) - 1u));
-          return (sl < n_st && itv == itv0) ? x_rec + (long)sl * ea.pk_stride : ent_rec(ec, i, itv);
+          const int sl = (int)x_U_l[MW + w] + __popc(x_U_l[w] & ((1u << (i & 31)) - 1u));
+          return (sl < n_st && itv == itv0) ? (int)(x_rec_lds + (unsigned)sl * (unsigned)(ea.pk_stride * 8)) : -1;
         };
         for (int q = tid; q < nr * ec.ns; q += 256) {
           const int rk = q / ec.ns, j = q - rk * ec.ns + 1;
