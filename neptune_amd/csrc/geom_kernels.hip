@@ -1260,7 +1260,7 @@ void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start,
 // ---------------------------------------------------------------------------------------------
 // post-solve safety check (neptune.cpp:719-806, gjk.cpp:76-149)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ int gjk_furthest(int n, const double* __restrict__ V, double dx, double dy) {
+template <class VP> __device__ __forceinline__ int gjk_furthest(int n, VP V, double dx, double dy) {
   double mx = dx * V[0] + dy * V[1]; int idx = 0;
   for (int i = 1; i < n; i++) { const double p = dx * V[2 * i] + dy * V[2 * i + 1]; if (p > mx) { mx = p; idx = i; } }
   return idx;
@@ -1274,7 +1274,9 @@ __device__ __forceinline__ void gjk_furthest4(const Pts4& B, double dx, double d
   for (int i = 1; i < 4; i++) { const double p = dx * B.x[i] + dy * B.y[i]; if (p > mx) { mx = p; px = B.x[i]; py = B.y[i]; } }
 }
 // gjk::collision(vertices1 = V1 [n1][2], vertices2 = the four control points in B)
-__device__ bool gjk_collision(int n1, const double* __restrict__ V1, const Pts4& B) {
+// (VP: the vertices' pointer type — the front end passes an LDS-typed pointer for the obstacles it staged: through a generic pointer the
+// support queries' reads are FLAT loads, a vector-memory round trip each even when the address is LDS)
+template <class VP> __device__ bool gjk_collision(int n1, VP V1, const Pts4& B) {
   if (n1 <= 0) return false;
   double p1x = 0, p1y = 0, p2x = 0, p2y = 0;
   for (int i = 0; i < n1; i++) { p1x += V1[2 * i]; p1y += V1[2 * i + 1]; }
@@ -2163,7 +2165,8 @@ __global__ __launch_bounds__(256, WGS) void frontend_kernel(SceneParams sp, Prob
       bool hit = false;
       while (cand_mask && !hit) {
         const int o = __ffsll((long long)cand_mask) - 1; cand_mask &= cand_mask - 1;
-        hit = gjk_collision(o_nv[o], obstacle_V(o), B);
+        if (o < kFeObsLds) { typedef __attribute__((address_space(3))) const double* lcd; hit = gjk_collision(o_nv[o], (lcd)(unsigned)(unsigned long long)(o_V + o * kHullV * 2), B); }
+        else hit = gjk_collision(o_nv[o], obstacle_V(o), B);
       }
       if (hit) s_state[id] = 0; else settle(id, ch);
     }
