@@ -146,3 +146,94 @@ def test_single_rank_hull_exchange_is_in_place():
     hx = ndist.HullExchange(1024, 1, 0)
     hx.local.fill_(7)
     assert hx.gather() is hx.blocks and int(hx.blocks.sum()) == 7 * 1024
+
+
+# ---- ShardedRounds (bench.py's multi-GPU step, torch.distributed exchange) with a stand-in back end ------------------------------
+class _StubBackend:
+    """What ShardedRounds asks of a BatchBackend, on CPU tensors: `hulls` digests my agents' records into my block, `replan_hulls`
+    writes new commit records from ALL blocks (so a stale or misplaced block changes the result) — and, like the QP kernel, it writes
+    only part of a record: bytes [CARRY_LO, CARRY_HI) of a commit slot come out zero (the tether fields of a config-5 record)."""
+    CARRY_LO, CARRY_HI = 96, 160
+
+    def __init__(self, n_scenes, n_local, first_local):
+        self.torch, self.device = torch, "cpu"
+        self.S, self.nl, self.first = n_scenes, n_local, first_local
+        self.d_commit = torch.zeros(n_scenes * n_local * ndist.REC_BYTES, dtype=torch.uint8)
+
+    def hull_block_bytes(self):
+        return self.S * self.nl * 8
+
+    def hulls(self, src, d_guess, out_local):
+        rec = src.view(self.S, self.nl, ndist.REC_BYTES).to(torch.int64)
+        w = torch.arange(1, ndist.REC_BYTES + 1, dtype=torch.int64)
+        dig = (rec * w).sum(dim=2) + d_guess.view(self.S, self.nl).to(torch.int64)          # [S][nl]: every byte of the record counts
+        out_local.copy_(dig.contiguous().view(torch.uint8).view(-1))
+
+    def replan_hulls(self, blocks, d_guess, d_ent=None):
+        world = blocks.numel() // self.hull_block_bytes()
+        allb = blocks.view(torch.int64).view(world, self.S, self.nl)
+        tot = allb.sum(dim=(0, 2))                                                         # [S]: everybody's digest of the scene
+        old = self.d_commit.view(self.S, self.nl, ndist.REC_BYTES)
+        ids = torch.arange(self.first, self.first + self.nl, dtype=torch.int64)
+        new = (old.to(torch.int64) * 3 + tot[:, None, None] + ids[None, :, None] * 7 + torch.arange(ndist.REC_BYTES, dtype=torch.int64)[None, None, :]) % 251
+        new[:, :, self.CARRY_LO:self.CARRY_HI] = 0
+        self.d_commit.copy_(new.to(torch.uint8).view(-1))
+
+
+def _rounds_reference(local0, guess, S, N, steps):
+    """one process, one chunk, every agent local: the result any sharding must reproduce"""
+    be = _StubBackend(S, N, 0)
+    d_local = [torch.from_numpy(local0.copy()).view(-1)]
+    rounds = ndist.ShardedRounds([be], d_local, [torch.from_numpy(guess.copy()).view(-1)], 1, 0, native=False,
+                                 carry=((0, _StubBackend.CARRY_LO), (_StubBackend.CARRY_HI, ndist.REC_BYTES)))
+    for _ in range(steps):
+        rounds.step()
+    return d_local[0].view(S, N, ndist.REC_BYTES).numpy().copy()
+
+
+def _rounds_worker(rank, world, port, S, N, C, steps, local_bytes, guess_bytes, result_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, nl = ndist.shard(N, world, rank)
+    local0 = np.frombuffer(local_bytes, dtype=np.uint8).reshape(S, N, ndist.REC_BYTES)
+    guess = np.frombuffer(guess_bytes, dtype=np.uint8).reshape(S, N)
+    Sc = S // C
+    bes = [_StubBackend(Sc, nl, first) for _ in range(C)]
+    d_local = [torch.from_numpy(np.ascontiguousarray(local0[k * Sc:(k + 1) * Sc, first:first + nl]).copy()).view(-1) for k in range(C)]
+    d_guess = [torch.from_numpy(np.ascontiguousarray(guess[k * Sc:(k + 1) * Sc, first:first + nl]).copy()).view(-1) for k in range(C)]
+    rounds = ndist.ShardedRounds(bes, d_local, d_guess, world, rank, native=False,
+                                 carry=((0, _StubBackend.CARRY_LO), (_StubBackend.CARRY_HI, ndist.REC_BYTES)))
+    for _ in range(steps):
+        rounds.step()
+    result_q.put((rank, first, nl, [d.numpy().tobytes() for d in d_local]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("chunks", [1, 2])
+def test_two_rank_sharded_rounds_with_carried_fields_match_one_rank(chunks):
+    """bench.py's N > 1 step (`--workload config5` included: the tethers' fields of a record are carried rank-locally, not written by
+    the replan) over gloo with two ranks and one or two scene chunks against one rank with one chunk: the same records, byte for
+    byte, after three steps — every block reaches every rank in rank order, a chunk's exchange is never a step stale, and the carried
+    byte ranges survive the replan's partial writes."""
+    S, N, steps, world = 4, 6, 3, 2
+    rng = np.random.default_rng(7)
+    local0 = rng.integers(0, 251, size=(S, N, ndist.REC_BYTES), dtype=np.uint8)
+    guess = rng.integers(0, 100, size=(S, N), dtype=np.uint8)
+    want = _rounds_reference(local0, guess, S, N, steps)
+    assert (want[:, :, _StubBackend.CARRY_LO:_StubBackend.CARRY_HI] == local0[:, :, _StubBackend.CARRY_LO:_StubBackend.CARRY_HI]).all()      # (carried, not zeroed)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_rounds_worker, args=(r, world, port, S, N, chunks, steps, local0.tobytes(), guess.tobytes(), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    Sc = S // chunks
+    for rank, first, nl, parts in got:
+        for k, b in enumerate(parts):
+            mine = np.frombuffer(b, dtype=np.uint8).reshape(Sc, nl, ndist.REC_BYTES)
+            assert mine.tobytes() == np.ascontiguousarray(want[k * Sc:(k + 1) * Sc, first:first + nl]).tobytes(), "rank %d chunk %d differs from the one-rank run" % (rank, k)
