@@ -315,3 +315,37 @@ def test_reference_tolerances(be, oracle):
     assert max(dcost_o) <= 1e-6 and max(dcost_s) <= 1e-6, (max(dcost_o), max(dcost_s))
     assert max(dpos_s) <= 1e-3, max(dpos_s)
     bb.close()
+
+
+def test_one_slot_launch_lists_itself_for_the_polish_pass(be):
+    """A launch of ONE replan (the per-agent handle's shape: one workgroup) keeps no counter to zero beforehand — qp_reg_kernel's last
+    lines set the polish pass's list themselves.  One-agent shards of a 64-agent scene, on front-end guesses whose solves end loose,
+    give the full batch's trajectories bit for bit: plain (every row) and under the presolve with the pass on (set_polish(2), the
+    third instantiation); the counters say 1 listed where the batch listed that agent."""
+    sc = scene.make_scene(64, 20, seed=203)
+    p = sc["par"]; N = p.num_agents
+    full = be.BatchBackend(p, sc["statics"])
+    d_com = full.to_device(sc["committed"][None]); d_g = full.to_device(sc["guesses"][None])
+    full.frontend(scene.frontend_cfg(p, beam_width=32), d_com, full.to_device(scene.frontend_starts(sc)[None]), d_g, None)
+    g = d_g.cpu().numpy().view(abi.GUESS_DTYPE).reshape(N)
+    full.set_polish(False); full.replan(d_com, d_g); off = full.solutions().copy()
+    for mode, cull in ((1, 0.0), (2, 4.0)):
+        full.set_line_cull(cull); full.set_polish(mode); full.replan(d_com, d_g); want = full.solutions().copy()
+        listed_all, _ = full.polish_count()
+        assert listed_all >= 1
+        changed = [a for a in range(N) if np.abs(np.array(want[a]["coeff"]) - np.array(off[a]["coeff"])).max() > 0 or want[a]["stats"]["status"] != off[a]["stats"]["status"]]
+        picks = (changed[:3] + [a for a in range(N) if a not in changed][:2]) if cull == 0.0 else list(range(0, N, 9))
+        n_listed = 0
+        for a in picks:
+            one = be.BatchBackend(p, sc["statics"], first_local=a, n_local=1)
+            one.set_line_cull(cull); one.set_polish(mode)
+            one.replan(one.to_device(sc["committed"][None]), one.to_device(g[a:a + 1]))
+            got = one.solutions()[0]
+            n_listed += one.polish_count()[0]
+            assert one.polish_count()[0] in (0, 1)
+            assert int(got["stats"]["status"]) == int(want[a]["stats"]["status"]), (mode, a)
+            np.testing.assert_array_equal(np.array(got["coeff"]), np.array(want[a]["coeff"]))
+            one.close()
+        if cull == 0.0:
+            assert n_listed >= min(len(changed), 3) and len(changed) >= 1
+    full.close()
