@@ -50,13 +50,14 @@ def parse_args(argv=None):
                          "sharded with the agents) or the trajectory records themselves (every rank rebuilds all hulls)")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1 with --exchange hulls: scene chunks pipelined so that one chunk's all-gather overlaps the other's kernels")
-    ap.add_argument("--presolve-radius", type=float, default=4.0,
-                    help="radius of the separately reported presolve leg (0: skip it); ignored when --cull-radius is set")
-    ap.add_argument("--cull-radius", type=float, default=0.0,
-                    help="presolve of the separating-line rows (nep_batch_set_line_cull): lines farther than this many metres "
-                         "from the guess are left out of the QP and verified after the solve; 0 = off (config5: the handle's default)")
-    ap.add_argument("--chain-cull-radius", type=float, default=0.0,
-                    help="line presolve radius of the chain and moving legs (0: every row through the interior point)")
+    ap.add_argument("--presolve-radius", type=float, default=4.0, help="(older command lines; the presolve is the handle's default since round 6: ignored)")
+    ap.add_argument("--no-full-rows", action="store_true", help="skip the separately reported full_rows legs (presolve off: every separating-line row through the interior point)")
+    ap.add_argument("--cull-radius", type=float, default=None,
+                    help="verified presolve of the separating-line rows (nep_batch_set_line_cull): lines farther than this many metres "
+                         "from the guess are left out of the QP and verified after the solve.  Default: the handle's own default (4 m at every scene "
+                         "size); 0 = off, every row through the interior point (rounds 1-5's headline)")
+    ap.add_argument("--chain-cull-radius", type=float, default=None,
+                    help="the same for the chain / moving / crossing legs (default: the handle's default; 0: every row)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange-torch", action="store_true",
                     help="N > 1 with --exchange hulls: the all-gather through torch.distributed (host-launched steps) instead of the "
@@ -107,7 +108,7 @@ def run_config4(ctx):
     """the default command: headline + the separately reported legs -> detail record (rank 0) or None"""
     from bench_legs import chain as chain_legs, config5, cpu, headline, small
     args, world, rank = ctx.args, ctx.world, ctx.rank
-    extra = world == 1 and not args.no_extra_legs and not args.frontend and not args.safety and args.cull_radius == 0.0
+    extra = world == 1 and not args.no_extra_legs and not args.frontend and not args.safety and args.cull_radius is None
     want_c5 = (extra and not args.no_config5) or args.config5_only
     pool = None
     if want_c5 and rank == 0:
@@ -133,12 +134,19 @@ def run_config4(ctx):
         return None
     out = headline.record(ctx, H)
     mv, cr = legs.get("moving"), legs.get("crossing")
-    out["what_value_is"] = ("throughput of %d INDEPENDENT scenes in flight, every row through the interior point, QP workgroups ordered by the previous "
-                            "step's measured times (exact here: the same problems every step).  The representative figures are the closed-loop legs, "
+    out["what_value_is"] = ("throughput of %d INDEPENDENT scenes in flight on the handle's default solve path (verified line presolve + polish; full_rows has every row "
+                            "through the interior point), QP workgroups ordered by the previous step's measured times (exact here: the same problems every step).  The representative figures are the closed-loop legs, "
                             "where every step poses new problems from device-made guesses: moving %s replans/s, crossing (the whole fleet through the middle) %s "
                             "replans/s — see also launch_order_off, single_scene, active_rows"
                             % (H.S, ("%.3g" % mv["value"]) if mv else "n/a", ("%.3g" % cr["value"]) if cr else "n/a"))
     out.update(legs)
+    pa4 = next((v for k, v in (legs.get("per_agent_api") or {}).items() if k.startswith("config4") and isinstance(v, dict)), None)
+    if pa4:
+        # the metric's "p50 solve ms": one replan = setters + separator loop + QP + generatePwpOut — measured where that is one
+        # blocking call sequence, the drop-in's (neptune.cpp:1514-1527), at this workload's size; the batch view stays in batch_sequence_ms
+        out["p50_solve_ms"] = pa4["sequence_ms"]["p50"]; out["p99_solve_ms"] = pa4["sequence_ms"]["p99"]
+        out["solve_ms_definition"] = ("the six-call drop-in sequence of ONE replan through the per-agent C ABI (setInitTrajectory .. generatePwpOut, host buffers in and "
+                                      "out, blocking) against %d hull lists: per_agent_api; a batched replan completes with its launch sequence, batch_sequence_ms" % pa4["hull_lists"])
     out["per_rank"] = per_rank
     if ctx.graph_notes:
         out["graph_notes"] = ctx.graph_notes

@@ -14,7 +14,9 @@ def run(ctx, H):
     from neptune_amd.backend import BatchBackend
     be, p, N, S, com, mine = H.be, H.p, H.N, H.S, H.com, H.mine
     cfg_fe = scene.frontend_cfg(p, beam_width=args.beam)
-    be.set_line_cull(args.chain_cull_radius)
+    cull_default = be.line_cull()
+    cull_c = cull_default if args.chain_cull_radius is None else args.chain_cull_radius
+    be.set_line_cull(cull_c)
     starts_np = np.stack([scene.frontend_starts(s_) for s_ in mine])
     d_st = be.to_device(starts_np)
     d_gfe = torch.zeros_like(H.d_guess)
@@ -42,7 +44,7 @@ def run(ctx, H):
                        ipm_iters_mean=float(sol3["stats"]["iters"].mean()), ipm_iters_max=int(sol3["stats"]["iters"].max()),
                        lp_failed=int(sol3["stats"]["n_lp_failed"].sum()), accepted_frac=float(d_acc.float().mean().item()),
                        solve_us=acc.solve_us_stats(be), terminal_ball_rows=int(sol3["stats"]["qc_active"].sum()),
-                       ipm_iters_quantiles=acc.quantiles(sol3["stats"]["iters"]), line_cull_radius_m=args.chain_cull_radius,
+                       ipm_iters_quantiles=acc.quantiles(sol3["stats"]["iters"]), line_cull_radius_m=cull_c,
                        rows_solved_mean=float(sol3["stats"]["n_rows"].mean()), presolve_redo_last_step=be.redo_count(),
                        polish_listed_certified_last_step=list(be.polish_count()), active_rows=acc.active_summary(be),
                        note="front-end beam search -> separating lines -> QP -> safety check + commit, every step; the guesses are the "
@@ -102,7 +104,7 @@ def run(ctx, H):
                              "closed loop on the device, one HIP graph per round: front end -> lines -> QP -> safety check + commit -> point A of "
                              "the next round 0.5 s ahead on the committed trajectory; arrived agents turn around.  Every step solves NEW problems; the "
                              "launch-order predictor is the same agent's previous replan")
-    moving = run_moving(args.chain_cull_radius)
+    moving = run_moving(cull_c)
     # ---- crossing: the same closed loop on the hard variant of every scene — all 64 agents start at rest on the base circle
     # and fly to the antipodal point, so the whole fleet meets in the middle (and turns around on arrival) --------------
     cross = [scene.crossing_scene(s_) for s_ in mine]
@@ -110,7 +112,7 @@ def run(ctx, H):
                             "the closed loop of `moving` on the circle-swap variant of the same scenes: every agent starts at rest on the base circle, "
                             "its goal is the antipodal point (the start of the agent opposite), arrived agents turn around — the fleet crosses the middle of "
                             "the world together, against the scene's static obstacles.  The hard leg: see active_rows, failed_frac, ipm_iters")
-    crossing = run_cross(args.chain_cull_radius)
+    crossing = run_cross(cull_c)
     # ---- moving, as two scene groups on two streams inside the one captured step: the tail of one group's kernels (the QP
     # launch ends with a handful of failing solves of ~1.2 ms each on an otherwise empty GPU) runs beside the other group's
     # kernels.  Same scenes, same results; what a deployment that keeps several fleets in flight does ------------------
@@ -121,7 +123,7 @@ def run(ctx, H):
             b_ = BatchBackend(p, H.statics, n_scenes=Sg, device=dev)
             for s_ in range(Sg):
                 b_.set_scene_statics(s_, H.all_statics[k_ * Sg + s_])
-            b_.set_line_cull(args.chain_cull_radius)
+            b_.set_line_cull(cull_c)
             gb.append(b_)
         g_st = [gb[k_].to_device(np.ascontiguousarray(starts_np[k_ * Sg:(k_ + 1) * Sg])) for k_ in range(2)]
         g_alt = [torch.from_numpy(np.ascontiguousarray(starts_np[k_ * Sg:(k_ + 1) * Sg]["pos"].reshape(Sg * N, 3)).copy()).to(dev) for k_ in range(2)]
@@ -162,19 +164,19 @@ def run(ctx, H):
                                         "otherwise empty GPU) runs beside the other group's front end" % (Sg, RG), **acc.status_counts(solg)}
         for b_ in gb:
             b_.close()
-    # ---- both again with the verified presolve (what a deployment runs, and the handle's default at config-5 size) ----
-    if args.chain_cull_radius == 0.0 and args.presolve_radius > 0.0:
-        be.set_line_cull(args.presolve_radius)
+    # ---- all three again with the presolve OFF: every row through the interior point (rounds 1-5's way of quoting these legs) ----
+    if args.chain_cull_radius is None and not args.no_full_rows:
+        be.set_line_cull(0.0)
         d_com2.copy_(be.to_device(com))
         dt3p, ms3p, _ = ctx.run_leg(chain_step, [be], aux_steps, max(args.warmup, 2), clear=(fe2, sf2))
         qp3p, _ = be.kernel_time_ms(2); sep3p, _ = be.kernel_time_ms(1)
         be.enable_timing(False)
         sol3p = be.solutions()
-        chain["with_presolve"] = leg_record(H, dt3p, aux_steps, ms3p, cull_radius_m=args.presolve_radius,
-                                            kernel_ms={"frontend_with_hulls": ctx.mean_ms(fe2), "separator": sep3p, "qp": qp3p, "safety": ctx.mean_ms(sf2)},
-                                            rows_solved_mean=float(sol3p["stats"]["n_rows"].mean()), ipm_iters_mean=float(sol3p["stats"]["iters"].mean()),
-                                            presolve_redo_last_step=be.redo_count(), **acc.status_counts(sol3p))
-        moving["with_presolve"] = run_moving(args.presolve_radius)
-        crossing["with_presolve"] = run_cross(args.presolve_radius)
-    be.set_line_cull(0.0)
+        chain["full_rows"] = leg_record(H, dt3p, aux_steps, ms3p, cull_radius_m=0.0,
+                                        kernel_ms={"frontend_with_hulls": ctx.mean_ms(fe2), "separator": sep3p, "qp": qp3p, "safety": ctx.mean_ms(sf2)},
+                                        rows_solved_mean=float(sol3p["stats"]["n_rows"].mean()), ipm_iters_mean=float(sol3p["stats"]["iters"].mean()),
+                                        polish_listed_certified_last_step=list(be.polish_count()), **acc.status_counts(sol3p))
+        moving["full_rows"] = run_moving(0.0)
+        crossing["full_rows"] = run_cross(0.0)
+    be.set_line_cull(cull_default)
     return chain, moving, crossing

@@ -59,7 +59,7 @@ def compact_line(d, detail_path="bench_detail.json"):
         out["scene_digest"] = d["scene_digest"][:4]
     # scalar highlights of the other legs (replans/s unless named otherwise)
     hl = {}
-    for name in ("long_run", "presolve", "chain", "moving", "crossing", "single_scene"):
+    for name in ("long_run", "full_rows", "chain", "moving", "crossing", "single_scene"):
         leg = d.get(name)
         if leg:
             hl[name] = _r(leg["value"], 5)

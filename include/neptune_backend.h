@@ -365,12 +365,15 @@ int nep_batch_safety_commit(nep_batch_t* h, const nep_traj_rec* d_prev, const ne
  * with a host-built inverse): if every box row, every line and the terminal ball hold there, that point with zero
  * multipliers satisfies the KKT conditions of the full problem and is returned as the optimum without a single
  * interior-point iteration (nep_stats.iters == 0); otherwise the interior point runs as usual.
- * Default: off (radius 0) for scenes whose expected lines per segment fit the register slots of the interior-point kernel
- * (BASELINE configs 1-4); ON with radius 4 m for bigger scenes (config 5: 256 agents + 100 obstacles, ~260 lines per segment,
- * of which a few dozen are near) — the near lines then fit the register-resident placement, the parked ones are verified,
- * and the optimum is still that of the full problem.  An explicit call (any radius, 0 included) overrides the default;
- * nep_batch_get_line_cull returns the radius in force.                                                             */
+ * Default (round 6): ON with radius 4 m for every handle, batched and per-agent, at every scene size — this is the library's
+ * one solve path, as the presolve inside GRBModel::optimize is the reference's (solver_gurobi_poly.cpp:823); the result is the
+ * full problem's optimum by construction and the polish pass (below) runs under it.  Until round 5 it was on only for scenes
+ * whose lines do not fit the register slots of the interior-point kernel (config 5).  An explicit call (any radius, 0 included)
+ * overrides the default: radius 0 = every separating-line row through the interior point, lines in the reference's call order
+ * (what the line-order parity tests ask for); nep_batch_get_line_cull returns the radius in force.  The per-agent handle has the
+ * same setter (its hull lists are the caller's, so no LP is skipped there: parked lines and the zero-iteration test only).       */
 int nep_batch_set_line_cull(nep_batch_t* h, double radius);
+int nep_backend_set_line_cull(nep_backend_t* h, double radius);
 double nep_batch_get_line_cull(nep_batch_t* h);
 /* With the presolve on (largest-gap rule, batched handle) the separator does not even SOLVE the LPs whose line must be far: a
  * hull or inflated static whose bounding box is farther than the radius from the box of the guess's control points along x or
@@ -426,11 +429,15 @@ int nep_backend_set_tolerances(nep_backend_t* h, double residual_tol, double gap
  * directly; rows with a negative multiplier leave, violated rows enter, a few times; a point that satisfies every row with
  * non-negative multipliers is the optimum (KKT) and the solve counts as converged — NEP_OK for the first problem even if the
  * interior point had gone on to the relaxed one, which is what a solver that finds the optimum reports (solver_gurobi_poly.cpp:
- * 832-861).  Without a certificate nothing changes.  Not applied to problems with the terminal ball row.  on = 1 (the default): not
- * under the line presolve either; on = 2: there too — the pass works on the near lines and accepts a certified point only if it
- * passes the presolve's own verification (parked lines, movement bound of the skipped LPs) again, so that presolved and every-row
- * solves agree to 1e-6 on loose exits as well (9e-5 otherwise), at 0.03-0.06 ms per launch.  oracle/ runs the same rule
- * (orc_set_polish).                                                                                                              */
+ * 832-861).  Without a certificate nothing changes.  Not applied to problems with the terminal ball row.  on = 1 (the default; 2 is
+ * accepted as a synonym): on every path of the register-resident interior point, the line presolve included — there the pass works
+ * on the near lines and accepts a certified point only if it passes the presolve's own verification (parked lines, movement bound
+ * of the skipped LPs) again, so that presolved and every-row solves agree to 1e-6 on loose exits as well (9e-5 otherwise), at
+ * 0.03-0.06 ms per launch; on = 3: round 5's default (every-row solves only, not under the presolve); on = 0: off.
+ * SCOPE: the pass finishes solves of qp_reg_kernel.  The LDS-placement kernel (qp_kernel: only reachable with the presolve turned
+ * off, nep_batch_set_line_cull(h, 0), at scene sizes whose lines exceed the register slots — config 5 with every row) keeps its
+ * loose exits: nep_batch_debug_polish_count reports (0, 0) for such a launch, and a parity check against oracle/ must call
+ * orc_set_polish(0) for it.  oracle/ runs the same rule (orc_set_polish).                                                            */
 int nep_batch_set_polish(nep_batch_t* h, int32_t on);
 int nep_backend_set_polish(nep_backend_t* h, int32_t on);
 

@@ -68,6 +68,25 @@ int nep_batch_qp_placement(nep_batch_t* h);
 int nep_batch_set_launch_order(nep_batch_t* h, int32_t enable);
 int nep_batch_debug_launch_order(nep_batch_t* h, int32_t* order, int32_t cap, int32_t* n_out);
 
+/* Development aids that were environment variables until round 5 (the library reads no environment variable that changes what it
+ * computes or how it schedules; NEP_QP_PROFILE, read at handle creation for the per-phase cycle counters of `make PROFILE=1`, is the
+ * one exception and changes no result).  Per handle, by name:
+ *   "qp_kernel"    0 automatic | 1 qp_reg_kernel (row state in registers) | 2 qp_kernel (row state in LDS)
+ *   "sep_skip"     1 (default) LPs whose line is known to be far by the box test are not solved | 0 they are solved and parked
+ *   "sep_no_redo"  1: replans the presolve could not verify keep their first-pass result (inspection only: NOT the optimum)
+ *   "sep_pack"     as nep_batch_debug_set_separator_pack
+ *   "qp_lpt" / "fe_lpt"   launch order of the QP workgroups / the searches: 1 longest-expected-first (default) | 0 slot order
+ *   "qp_key_decay" / "fe_key_decay"   bins an ordering key loses per launch (defaults 2 / 1; 0: the key is the last time's bin)
+ *   "corr_from" / "corr_max"   the short-step give-up rule of the interior point (defaults 10 / 8):
+ *                  these two DO change which hard replans are given up on; they exist for that trade's A/B only
+ *   "qp_profile"   1: collect the phase counters (PROFILE builds)
+ * Process-wide (launcher choices, results do not depend on them): "fe_three" (keep the three-workgroup front-end instantiation),
+ * "fe_xcd" (0: no XCD placement of the searches), "polish_grid" (workgroups of the polish pass, default 256).
+ * Unknown names are refused (NEP_E_ARG).                                                                                      */
+int nep_batch_debug_set_option(nep_batch_t* h, const char* name, int32_t value);
+int nep_backend_debug_set_option(nep_backend_t* h, const char* name, int32_t value);
+int nep_debug_set_global_option(const char* name, int32_t value);
+
 /* Which kernel builds the interval hulls (same hulls, bit for bit): 0 = by batch size (eight hulls per wave from ~2 000
  * trajectories per launch on, one per wave below: DESIGN.md section 6), 1 = one hull per wave, 2 = eight per wave.       */
 int nep_batch_set_hull_kernel(nep_batch_t* h, int32_t mode);

@@ -20,7 +20,7 @@ EXPORTS = [
     "nep_batch_set_ent_samples", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_comm_unique_id",
     "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks", "nep_batch_exchange_hulls",
     "nep_batch_exchange_records", "nep_batch_exchange_slots", "nep_comm_reserve", "nep_batch_ent_bytes",
-    "nep_batch_safety_commit", "nep_batch_set_line_cull", "nep_batch_get_line_cull", "nep_batch_reserve_row_scratch",
+    "nep_batch_safety_commit", "nep_batch_set_line_cull", "nep_backend_set_line_cull", "nep_batch_get_line_cull", "nep_batch_reserve_row_scratch",
     "nep_batch_set_line_capacity", "nep_batch_set_separator_rule", "nep_backend_set_separator_rule",
     "nep_batch_set_tolerances", "nep_backend_set_tolerances", "nep_batch_set_polish", "nep_backend_set_polish", "nep_batch_set_max_runtime",
     "nep_batch_set_safety_check_prev", "nep_batch_wait", "nep_batch_check", "nep_abi_sizeof", "nep_last_error",
@@ -36,7 +36,7 @@ DEBUG_EXPORTS = [
     "nep_batch_debug_launch_order", "nep_batch_set_hull_kernel", "nep_batch_debug_conflicts",
     "nep_batch_kernel_time", "nep_batch_enable_timing", "nep_batch_reset_timing", "nep_batch_debug_hulls",
     "nep_batch_debug_lines", "nep_batch_debug_phase_cycles", "nep_batch_fe_search_us",
-    "nep_batch_set_fe_ent_fast_caps",
+    "nep_batch_set_fe_ent_fast_caps", "nep_batch_debug_set_option", "nep_backend_debug_set_option", "nep_debug_set_global_option",
 ]
 # every symbol include/neptune_plan.h declares (host-only: no HIP call behind them)
 PLAN_EXPORTS = [
@@ -113,7 +113,8 @@ def lib():
     L.nep_batch_safety_commit.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.nep_batch_debug_conflicts.argtypes = [vp, i, C.POINTER(C.c_uint8)]
     L.nep_batch_set_safety_check_prev.argtypes = [vp, i]
-    L.nep_batch_set_line_cull.argtypes = [vp, d]
+    L.nep_batch_set_line_cull.argtypes = [vp, d]; L.nep_backend_set_line_cull.argtypes = [vp, d]
+    L.nep_batch_debug_set_option.argtypes = [vp, C.c_char_p, i]; L.nep_backend_debug_set_option.argtypes = [vp, C.c_char_p, i]; L.nep_debug_set_global_option.argtypes = [C.c_char_p, i]
     L.nep_batch_get_line_cull.argtypes = [vp]; L.nep_batch_get_line_cull.restype = d
     L.nep_batch_debug_redo_count.argtypes = [vp, pi]
     L.nep_batch_debug_redo_list.argtypes = [vp, pi, i]

@@ -69,8 +69,18 @@ class PolySolver:
         check(lib().nep_backend_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
 
     def setPolish(self, on=True):
-        """not in the reference: the active-set polish of solves that end without the strict tests (nep_backend_set_polish; on by default)"""
-        check(lib().nep_backend_set_polish(self._h, 2 if (on == 2 and on is not True) else (1 if on else 0)))
+        """not in the reference: the active-set polish of solves that end without the strict tests (nep_backend_set_polish; on by default,
+        under the line presolve as well; 3: every-row solves only)"""
+        check(lib().nep_backend_set_polish(self._h, int(on) if (on is not True and on is not False) else (1 if on else 0)))
+
+    def setLineCull(self, radius):
+        """not in the reference: the verified line presolve's radius (nep_backend_set_line_cull; 4 m by default, 0 = every row through the
+        interior point, lines in the reference's call order)"""
+        check(lib().nep_backend_set_line_cull(self._h, float(radius)))
+
+    def debug_option(self, name, value):
+        """development aid (include/neptune_backend_debug.h: nep_backend_debug_set_option)"""
+        check(lib().nep_backend_debug_set_option(self._h, name.encode(), int(value)))
 
     def setMaxRuntime(self, runtime):
         check(lib().nep_backend_set_max_runtime(self._h, runtime))
@@ -382,7 +392,7 @@ class BatchBackend:
         check(lib().nep_batch_set_line_cull(self._h, float(radius)))
 
     def line_cull(self):
-        """the presolve radius in force (0: off): nep_batch_get_line_cull — on by default for config-5 sized scenes"""
+        """the presolve radius in force (0: off): nep_batch_get_line_cull — 4 m by default at every scene size"""
         return float(lib().nep_batch_get_line_cull(self._h))
 
     def redo_count(self):
@@ -439,9 +449,13 @@ class BatchBackend:
         check(lib().nep_batch_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
 
     def set_polish(self, on=True):
-        """the active-set polish of solves that end without the strict tests (on by default; 2: under the line presolve as well):
-        nep_batch_set_polish"""
-        check(lib().nep_batch_set_polish(self._h, 2 if (on == 2 and on is not True) else (1 if on else 0)))
+        """the active-set polish of solves that end without the strict tests (on by default, under the line presolve as well — 2 is a
+        synonym; 3: every-row solves only, round 5's default; False / 0: off): nep_batch_set_polish"""
+        check(lib().nep_batch_set_polish(self._h, int(on) if (on is not True and on is not False) else (1 if on else 0)))
+
+    def debug_option(self, name, value):
+        """development aid (include/neptune_backend_debug.h: nep_batch_debug_set_option)"""
+        check(lib().nep_batch_debug_set_option(self._h, name.encode(), int(value)))
 
     def polish_count(self):
         """(replans listed for the polish pass of the last replan, replans it certified): nep_batch_debug_polish_count"""

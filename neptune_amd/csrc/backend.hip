@@ -18,6 +18,8 @@
 
 using namespace nep;
 
+namespace nep { DebugGlobals g_debug; }
+
 namespace {
 
 thread_local std::string g_err;
@@ -99,7 +101,7 @@ struct Engine {
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
   DevBuf<int> d_line_skip, d_redo_list, d_redo_count;   // spatial presolve: skipped LPs per segment, replans listed for the redo pass
-  DevBuf<double> d_polish_z; DevBuf<int> d_polish_flag, d_polish_list, d_polish_count; bool polish = true, polish_presolve = false;      // the active-set polish of solves that end without the strict tests (qp_polish_kernel.hip; nep_*_set_polish)
+  DevBuf<double> d_polish_z; DevBuf<int> d_polish_flag, d_polish_list, d_polish_count; bool polish = true, polish_presolve = true;      // the active-set polish of solves that end without the strict tests (qp_polish_kernel.hip; nep_*_set_polish)
   DevBuf<long long> d_dbg; bool profile_phases = false;
   DevBuf<int> d_flags;
   // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
@@ -117,7 +119,8 @@ struct Engine {
   DevBuf<int> d_order, d_order_key; bool have_history = false, lpt = true, last_ordered = false;   // QP workgroups launched longest-expected-first (order_kernel)
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double clock_hz = 1e8;       // wall_clock64() rate of the handle's device (set_clock)
-  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; { static const int cf = getenv("NEP_CORR_FROM") ? atoi(getenv("NEP_CORR_FROM")) : kCorrFromItDefault, cm = getenv("NEP_CORR_MAX") ? atoi(getenv("NEP_CORR_MAX")) : kCorrMaxCountDefault; sp.corr_from_it = cf; sp.corr_max_count = cm; } if (!(sp.tol_res > 0.0)) { sp.tol_res = 1e-9; sp.tol_gap = 1e-10; sp.tol_res_inv = 1e9; sp.tol_gap_inv = 1e10; sp.tol_gap_floor = 0.1 * 1e-10; } }      // (called by both create paths: the strict tests' defaults with it)
+  // (the short-step give-up rule's two numbers: run-time values for A/B, nep_*_debug_set_option "corr_from" / "corr_max"; never read from the environment)
+  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; sp.corr_from_it = opt_corr_from; sp.corr_max_count = opt_corr_max; if (!(sp.tol_res > 0.0)) { sp.tol_res = 1e-9; sp.tol_gap = 1e-10; sp.tol_res_inv = 1e9; sp.tol_gap_inv = 1e10; sp.tol_gap_floor = 0.1 * 1e-10; } }      // (called by both create paths: the strict tests' defaults with it)
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
   // timing
@@ -148,7 +151,7 @@ struct Engine {
   }
   // which interior-point kernel the next replan launches, and its LDS carve (see size_scratch)
   static constexpr double kAutoCullRadius = 4.0;
-  bool fits_reg = true, cull_user_set = false, skip_lps = true, no_redo = false; int lds_lines_lds = 0, sep_pack = 0;
+  bool fits_reg = true, cull_user_set = false, skip_lps = true, no_redo = false; int lds_lines_lds = 0, sep_pack = 0, force_kernel = 0, opt_qp_key_decay = 2, opt_fe_key_decay = 1, opt_corr_from = kCorrFromItDefault, opt_corr_max = kCorrMaxCountDefault;      // (skip_lps, no_redo, sep_pack, force_kernel: development aids behind nep_*_debug_set_option, include/neptune_backend_debug.h)
   // Row scratch (rows and coefficients beyond the register slots / the LDS carve): one area per slot in general.  With the presolve's
   // redo pass (skip_mode()) the first pass never needs one — a replan whose near lines exceed the slots is sent to the redo pass —
   // so the handle keeps a pool of kScratchPool areas for that pass (config 5: 1.9 GB instead of 15.3 per 32 scenes);
@@ -165,7 +168,7 @@ struct Engine {
   }
   void choose_placement() {
     use_reg = fits_reg || sp.cull_radius > 0.0;
-    if (const char* f = getenv("NEP_QP_KERNEL")) { if (!strcmp(f, "reg")) use_reg = true; else if (!strcmp(f, "lds")) use_reg = false; }
+    if (force_kernel == 1) use_reg = true; else if (force_kernel == 2) use_reg = false;      // (nep_*_debug_set_option "qp_kernel": tests, A/B)
     if (use_reg) { lds_lines = NEP_MAX_POL * 8 * qp_reg_slots(); lds_rows = 4 * lds_lines; lds_bytes = qp_reg_lds_bytes(); }
     else { lds_lines = lds_lines_lds; lds_rows = 4 * lds_lines; lds_bytes = qp_lds_fixed_bytes() + (size_t)(lds_lines + 2) * 11 * 8; }   // + the dummy line of the padded row groups
   }
@@ -204,23 +207,15 @@ struct Engine {
     // nep_batch_set_line_cull): the few dozen near lines fit the register slots, the parked ones are checked at the solution,
     // and only a replan that violates one is solved again with every row, the rows beyond the slots going through the per-slot
     // global scratch.  With the presolve turned off (radius 0) such problems keep the LDS placement of qp_kernel.
-    // NEP_QP_KERNEL=reg|lds overrides the choice (tests, A/B).
+    // nep_*_debug_set_option(h, "qp_kernel", 1 | 2) overrides the choice (tests, A/B).
     fits_reg = expect / NEP_MAX_POL <= 8L * qp_reg_slots() + 8;
-    if (!cull_user_set) {
-      bool auto_cull = !fits_reg;
-      if (const char* f = getenv("NEP_QP_AUTOCULL")) auto_cull = auto_cull && atoi(f) != 0;
-      sp.cull_radius = auto_cull ? kAutoCullRadius : 0.0;
-    }
-    if (const char* f = getenv("NEP_SEP_SKIP")) skip_lps = atoi(f) != 0;      // (A/B: 0 solves every LP of a presolved replan too)
-    if (const char* f = getenv("NEP_QP_LPT")) lpt = atoi(f) != 0;
-    if (const char* f = getenv("NEP_FE_LPT")) fe_lpt = atoi(f) != 0;      // (A/B: the front end's launch order alone)
-    sp.fe_key_decay = 1; sp.qp_key_decay = 2;
-    if (const char* f = getenv("NEP_QP_KEY_DECAY")) sp.qp_key_decay = atoi(f);      // (A/B)
-    if (const char* f = getenv("NEP_FE_KEY_DECAY")) sp.fe_key_decay = atoi(f);      // (A/B)
-    no_redo = getenv("NEP_SEP_NO_REDO") != nullptr;
-    // (development aids, read here once and not per replan: NEP_SEP_UNPACKED, NEP_SEP_PACK=n — see nep_batch_debug_set_separator_pack)
-    if (getenv("NEP_SEP_UNPACKED")) sep_pack = -1;
-    else if (const char* f = getenv("NEP_SEP_PACK")) { const int v = atoi(f); if (v >= 1 && v <= NEP_MAX_POL) sep_pack = v; }
+    // The verified line presolve is the handle's default at EVERY size (round 6; until then only where the lines did not fit the
+    // register slots): it is what the reference's solver does inside optimize() (Gurobi's presolve drops redundant rows before the
+    // barrier, solver_gurobi_poly.cpp:823), its result is the full problem's optimum by construction (parked lines and skipped LPs
+    // are verified at the solution, a replan that fails the verification is solved again with every row), and the polish pass runs
+    // under it by default, so that one handle has one optimum whatever path its solves take.  nep_batch_set_line_cull(h, 0) turns it off.
+    if (!cull_user_set) sp.cull_radius = kAutoCullRadius;
+    sp.fe_key_decay = opt_fe_key_decay; sp.qp_key_decay = opt_qp_key_decay;      // (nep_*_debug_set_option "qp_key_decay" / "fe_key_decay": A/B)
     // (the keys remember — a new key is the maximum of the measured bin and the old key less a decay — so a fresh buffer starts at zero;
     // only a fresh one: the per-agent handle sizes its scratch on every replan and a memset there was 30 us of its 100)
     if (lpt) { if (int e = d_order.ensure((size_t)slots)) return e; const int* was = d_order_key.p; if (int e = d_order_key.ensure((size_t)slots)) return e; if (d_order_key.p != was) hipMemset(d_order_key.p, 0, d_order_key.n * sizeof(int)); }
@@ -247,7 +242,7 @@ struct Engine {
     if (int e = d_polish_flag.ensure((size_t)slots)) return e;
     if (int e = d_polish_list.ensure((size_t)slots)) return e;
     if (!d_polish_count.p) { if (int e = d_polish_count.ensure(8)) return e; HIPCHK(hipMemset(d_polish_count.p, 0, 8 * sizeof(int))); }
-    profile_phases = getenv("NEP_QP_PROFILE") != nullptr;
+    if (!profile_phases) profile_phases = getenv("NEP_QP_PROFILE") != nullptr;      // (profiling only: the per-phase cycle counters of make PROFILE=1; also nep_*_debug_set_option "qp_profile")
     if (profile_phases) { if (int e = d_dbg.ensure((size_t)slots * 32)) return e; }      // (the QP kernels use 16 per slot, the front end 32)
     if (int e = size_row_scratch()) return e;
     return 0;
@@ -1345,6 +1340,38 @@ int nep_batch_debug_launch_order(nep_batch_t* h, int32_t* order, int32_t cap, in
   return 0;
 }
 
+// Development aids that used to be environment variables (rounds 2-5: NEP_QP_KERNEL, NEP_SEP_SKIP, NEP_SEP_NO_REDO, NEP_QP_LPT, NEP_FE_LPT,
+// NEP_QP_KEY_DECAY, NEP_FE_KEY_DECAY, NEP_SEP_UNPACKED / NEP_SEP_PACK, NEP_CORR_FROM / NEP_CORR_MAX, NEP_FE_THREE, NEP_FE_XCD,
+// NEP_POLISH_GRID, NEP_HULL_KERNEL): explicit setters now, so that a caller's environment cannot change what the library computes.
+static int engine_option(Engine& E, const char* name, int32_t v) {
+  if (!name) return fail(NEP_E_ARG, "null option name");
+  const std::string n(name);
+  if (n == "qp_kernel") { if (v < 0 || v > 2) return fail(NEP_E_ARG, "qp_kernel: 0 automatic, 1 register placement, 2 LDS placement"); E.force_kernel = v; E.choose_placement(); }
+  else if (n == "sep_skip") E.skip_lps = v != 0;                 // 0: a presolved replan's far LPs are solved too (parked), none skipped
+  else if (n == "sep_no_redo") E.no_redo = v != 0;               // 1: flagged replans keep their presolved result (inspection)
+  else if (n == "qp_lpt") E.lpt = v != 0;
+  else if (n == "fe_lpt") E.fe_lpt = v != 0;
+  else if (n == "qp_key_decay") E.opt_qp_key_decay = v;
+  else if (n == "fe_key_decay") E.opt_fe_key_decay = v;
+  else if (n == "sep_pack") { if (v < -1 || v > NEP_MAX_POL) return fail(NEP_E_ARG, "sep_pack: -1 unpacked, 0 automatic, 1..NEP_MAX_POL"); E.sep_pack = v; }
+  else if (n == "corr_from") { if (v < 1) return fail(NEP_E_ARG, "corr_from >= 1"); E.opt_corr_from = v; E.sp.corr_from_it = v; }
+  else if (n == "corr_max") { if (v < 1) return fail(NEP_E_ARG, "corr_max >= 1"); E.opt_corr_max = v; E.sp.corr_max_count = v; }
+  else if (n == "qp_profile") E.profile_phases = v != 0;
+  else return fail(NEP_E_ARG, "unknown debug option: " + n);
+  return 0;
+}
+int nep_batch_debug_set_option(nep_batch_t* h, const char* name, int32_t value) { if (!h) return fail(NEP_E_ARG, "null handle"); return engine_option(h->eng, name, value); }
+int nep_backend_debug_set_option(nep_backend_t* h, const char* name, int32_t value) { if (!h) return fail(NEP_E_ARG, "null handle"); return engine_option(h->eng, name, value); }
+int nep_debug_set_global_option(const char* name, int32_t value) {
+  if (!name) return fail(NEP_E_ARG, "null option name");
+  const std::string n(name);
+  if (n == "fe_three") g_debug.fe_three = value != 0;
+  else if (n == "fe_xcd") g_debug.fe_xcd = value;
+  else if (n == "polish_grid") { if (value < 1) return fail(NEP_E_ARG, "polish_grid >= 1"); g_debug.polish_grid = value; }
+  else return fail(NEP_E_ARG, "unknown global debug option: " + n);
+  return 0;
+}
+
 int nep_batch_set_hull_kernel(nep_batch_t* h, int32_t mode) {
   if (!h || mode < 0 || mode > 2) return fail(NEP_E_ARG, "mode: 0 automatic, 1 one hull per wave, 2 eight hulls per wave");
   h->eng.sp.hull_mode = mode;
@@ -1365,6 +1392,12 @@ int nep_batch_set_line_cull(nep_batch_t* h, double radius) {
   return h->eng.size_row_scratch();      // (the row scratch follows the mode: a pool with the redo pass, one area per slot without — never inside a capture)
 }
 double nep_batch_get_line_cull(nep_batch_t* h) { return h ? h->eng.sp.cull_radius : -1.0; }
+// (the per-agent handle sizes its scratch and picks its placement at every optimize(): nothing to re-size here)
+int nep_backend_set_line_cull(nep_backend_t* h, double radius) {
+  if (!h || !(radius >= 0.0)) return fail(NEP_E_ARG, "bad arguments");
+  h->eng.sp.cull_radius = radius; h->eng.cull_user_set = true;
+  return 0;
+}
 
 int nep_batch_set_separator_rule(nep_batch_t* h, int32_t rule) {
   if (!h || (rule != 0 && rule != 1)) return fail(NEP_E_ARG, "separator rule: 0 largest gap, 1 GLPK-class simplex");
@@ -1405,8 +1438,9 @@ namespace { int set_tol(Engine& E, double res, double gap) {
 int nep_batch_set_tolerances(nep_batch_t* h, double residual_tol, double gap_tol) { if (!h) return fail(NEP_E_ARG, "null handle"); return set_tol(h->eng, residual_tol, gap_tol); }
 int nep_backend_set_tolerances(nep_backend_t* h, double residual_tol, double gap_tol) { if (!h) return fail(NEP_E_ARG, "null handle"); return set_tol(h->eng, residual_tol, gap_tol); }
 
-int nep_batch_set_polish(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; h->eng.polish_presolve = on == 2; return 0; }
-int nep_backend_set_polish(nep_backend_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; h->eng.polish_presolve = on == 2; return 0; }
+// (on: 0 off; 1 — the default — and 2 everywhere, under the presolve as well; 3: every-row solves only, round 5's default)
+int nep_batch_set_polish(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; h->eng.polish_presolve = on == 1 || on == 2; return 0; }
+int nep_backend_set_polish(nep_backend_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.polish = on != 0; h->eng.polish_presolve = on == 1 || on == 2; return 0; }
 // Test hook: the last replan's polish pass — replans listed for it (solves that ended without the strict tests), replans certified
 int nep_batch_debug_polish_count(nep_batch_t* h, int32_t* listed, int32_t* certified) {
   if (!h) return fail(NEP_E_ARG, "null handle");

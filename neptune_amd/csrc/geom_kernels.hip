@@ -400,9 +400,8 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
   // Eight hulls per wave when there are enough trajectories to fill the chip with such waves (a wave of eight takes ~60 us,
   // one hull per wave ~26 us: below ~2 000 trajectories the launch is one round of waves either way and the short waves
   // finish first — 0.026 against 0.058 ms for one 64-agent scene; 0.077 both at 32 scenes; 0.271 against 0.183 ms at 128).
-  // nep_batch_set_hull_kernel / NEP_HULL_KERNEL=wave|group force one (tests, A/B).
-  static const char* force = getenv("NEP_HULL_KERNEL");
-  const bool grouped = sp.hull_mode ? sp.hull_mode == 2 : (force ? strcmp(force, "wave") != 0 : (long)n_scenes * n_rec > 2048);
+  // nep_batch_set_hull_kernel forces one (tests, A/B).
+  const bool grouped = sp.hull_mode ? sp.hull_mode == 2 : (long)n_scenes * n_rec > 2048;
   if (sp.num_pol <= 8 && grouped) {
     hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * n_rec), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
                        sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
@@ -2495,7 +2494,6 @@ void launch_gjk_explicit(int n_prob, const int* a_off, const double* a_xy, const
   hipLaunchKernelGGL(gjk_explicit_kernel, dim3((n_prob + 63) / 64), dim3(64), 0, st, n_prob, a_off, a_xy, b_xy, hit);
 }
 
-static bool getenv_fe_three() { static const bool v = getenv("NEP_FE_THREE") != nullptr; return v; }      // (A/B: keep the three-workgroup instantiation)
 size_t frontend_children_cap(const nep_fe_cfg& fc, int num_pol) { return (size_t)fe_sizes(fc.beam_width, fc.num_samples, num_pol).cap; }
 // survivors per round of the entangle front end's propagation pass (fast instantiation: the crossing lists that fit the borrowed LDS,
 // as the kernel counts them) x sampled steps x kEntAddCap words: the global fallback of cross_round's LDS pool
@@ -2524,7 +2522,7 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps_in
   if (n_slots <= 0) return;
   ProblemSet ps = ps_in;
   ps.fe_order = nullptr;
-  static const int xcd_mode = getenv("NEP_FE_XCD") ? atoi(getenv("NEP_FE_XCD")) : 1;      // (A/B: 0 = the launch order without the XCD placement)
+  const int xcd_mode = g_debug.fe_xcd;      // (A/B, nep_debug_set_global_option "fe_xcd": 0 = the launch order without the XCD placement)
   if (order_buf && n_slots > 1024 && n_slots % 8 == 0 && xcd_mode) {      // a few whole scenes per XCD, the longest expected searches first within each (order_xcd_kernel)
     launch_order_xcd(n_slots, (ps.fe_order_key && have_history) ? ps.fe_order_key : nullptr, order_buf, st);
     ps.fe_order = order_buf;
@@ -2536,7 +2534,7 @@ void launch_frontend(int n_slots, const SceneParams& sp, const ProblemSet& ps_in
   const size_t lds = frontend_lds_bytes(sp, fc, ent);
   // a search whose LDS leaves room for four workgroups on a CU (160 KB / 4) runs the instantiation bounded to 128 registers
   // (11 spilled); larger ones — more obstacles, a wider beam — the one bounded for three
-  const bool four = !ent && lds <= (size_t)40 * 1024 && !getenv_fe_three();
+  const bool four = !ent && lds <= (size_t)40 * 1024 && !g_debug.fe_three;      // (A/B, nep_debug_set_global_option "fe_three": keep the three-workgroup instantiation)
   static DynLdsAttr attr[3];
   const void* fn = ent ? (const void*)frontend_kernel<true, NEP_FE_ENT_WGS> : four ? (const void*)frontend_kernel<false, 4> : (const void*)frontend_kernel<false, NEP_FE_WAVES>;
   (void)attr[ent ? 0 : four ? 1 : 2].ensure(fn, lds);

@@ -14,6 +14,11 @@ constexpr int kHullV = NEP_HULL_MAX_V;   // 16
 constexpr int kHullCP = NEP_HULL_MAX_CP; // 16
 constexpr int kBend = NEP_MAX_BEND;      // 8
 
+// Process-wide A/B knobs of the launchers (nep_debug_set_global_option, include/neptune_backend_debug.h): scheduling and placement
+// only — results do not depend on them — and never read from the environment (the library behaves the same under any environment).
+struct DebugGlobals { bool fe_three = false; int fe_xcd = 1; int polish_grid = 256; };
+extern DebugGlobals g_debug;
+
 // Scene-level constants (setMaxValues, ctor arguments; solver_gurobi_poly.cpp:25-175)
 constexpr int kCorrFromItDefault = 10, kCorrMaxCountDefault = 8;      // (qp_common.h: kCorrFromIt, kCorrMaxCount)
 struct SceneParams {

@@ -400,7 +400,7 @@ void launch_qp_polish_zero(int* counters, hipStream_t st) { if (counters) hipLau
 // a fixed small grid walks the list (it holds a per cent of the slots at most)
 void launch_qp_polish(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables, const SampleSched& sched, hipStream_t st) {
   if (n_slots <= 0 || !ps.polish_list) return;
-  static const int g_env = getenv("NEP_POLISH_GRID") ? atoi(getenv("NEP_POLISH_GRID")) : 256;      // (A/B)
+  const int g_env = g_debug.polish_grid > 0 ? g_debug.polish_grid : 256;      // (A/B: nep_debug_set_global_option "polish_grid")
   hipLaunchKernelGGL(qp_polish_kernel, dim3(n_slots < g_env ? n_slots : g_env), dim3(256), 0, st, sp, ps, tables, sched);
 }
 

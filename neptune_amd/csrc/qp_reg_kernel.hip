@@ -738,10 +738,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             int flag = 0;
             if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-9, 1e-9, 1e-10 unless nep_batch_set_tolerances says otherwise)
             else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
-            if (!CULL && l1 == 0) sI[28] = flag;                  // (1: the STRICT tests passed — flag 1 below may also mean "the loose window ends on this iterate")
+            if ((!CULL || PST) && l1 == 0) sI[28] = flag;         // (1: the STRICT tests passed — flag 1 below may also mean "the loose window ends on this iterate")
             if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
             if (sI[17] >= 3) flag = 3;                           // stalled
-            if (sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks) { flag = 3; if (!CULL && l1 == 0) sI[30] = 1; }   // TimeLimit without an accepted iterate: "no solution" (:832-836) — and out of budget: nothing is left for the polish pass either
+            if (sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks) { flag = 3; if ((!CULL || PST) && l1 == 0) sI[30] = 1; }   // TimeLimit without an accepted iterate: "no solution" (:832-836) — and out of budget: nothing is left for the polish pass either
             if (flag == 2 || (flag == 0 && sI[22] >= 0)) {       // loosely converged iterates: see qp_kernel
               const double merit = fmax(fmax(nr * sp.tol_res_inv, nrd / qs * sp.tol_res_inv), gap / (1.0 + fabs(o)) * sp.tol_gap_inv);
               const bool better = flag == 2 && (!sI[16] || merit < sc[sBestMerit]);
@@ -960,9 +960,12 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
           // (the presolve's instantiation keeps no per-iteration note of the strict tests — its registers are short as it is: a solve
           // counts as loose there when the loose window was ever opened (sI[22]; a strict pass inside the window is polished too, which
           // changes nothing but the last digits), and the TimeLimit is read off the clock again)
+          // (round 6: the presolve's instantiation with the hooks keeps the per-iteration note of the strict tests too — sI[28], one LDS
+          // store by one lane — so that ONLY solves that really ended loose or stalled are listed: with "the loose window was ever opened"
+          // as the criterion, half of a closed loop's replans were listed, 3 837 of 8 192 per step, and the pass took 0.4 ms)
           bool leave;
-          if constexpr (CULL) leave = !use_far && (!converged || __builtin_amdgcn_readfirstlane(sI[22]) >= 0) && !(sp.time_limit_ticks > 0 && (long long)wall_clock64() - t_solve0 > sp.time_limit_ticks);
-          else leave = !(converged && __builtin_amdgcn_readfirstlane(sI[28]) == 1) && __builtin_amdgcn_readfirstlane(sI[30]) == 0;
+          if constexpr (CULL && !PST) leave = false;
+          else leave = !(CULL && use_far) && !(converged && __builtin_amdgcn_readfirstlane(sI[28]) == 1) && __builtin_amdgcn_readfirstlane(sI[30]) == 0;
           if ((!CULL || PST) && ps.polish_z && !has_qc && !uncon && leave) {
             __syncthreads();
             if (tid < n) ps.polish_z[((long)slot * 2 + mode) * 24 + tid] = sZ[tid];

@@ -63,6 +63,31 @@ def test_fails_loudly_without_a_gpu(L):
     assert rc < 0
 
 
+def test_the_library_reads_no_environment_variable_that_changes_what_it_computes(L):
+    """Round-5 review: 17 getenv names in the product (NEP_QP_KERNEL, NEP_SEP_SKIP, NEP_SEP_NO_REDO, NEP_CORR_*, ...), several of which
+    changed which solves succeed.  They are explicit setters of include/neptune_backend_debug.h now.  Here: the sources call getenv
+    once (NEP_QP_PROFILE: the per-phase cycle counters of `make PROFILE=1`, no result depends on it), the built library holds no other
+    NEP_* name to look up, and the option setters exist and refuse unknown names.  (The GPU suite runs a replan under a hostile
+    environment and compares bytes: tests/test_gpu_robustness.py.)"""
+    src = os.path.join(ROOT, "neptune_amd", "csrc")
+    sites = []
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            for n, line in enumerate(open(os.path.join(src, f)), 1):
+                code = line.split("//")[0]
+                sites += [(f, n, m) for m in re.findall(r'getenv\("([A-Z_0-9]+)"\)', code)]
+                assert "getenv(" not in re.sub(r'getenv\("[A-Z_0-9]+"\)', "", code), (f, n)      # no computed names
+    assert {m for _, _, m in sites} == {"NEP_QP_PROFILE"} and len(sites) <= 3, sites
+    blob = open(_lib.LIB_PATH, "rb").read()
+    names = set(re.findall(rb"NEP_[A-Z][A-Z_0-9]{3,}", blob)) - {b"NEP_QP_PROFILE"}
+    old = {b"NEP_QP_KERNEL", b"NEP_QP_AUTOCULL", b"NEP_SEP_SKIP", b"NEP_SEP_NO_REDO", b"NEP_QP_LPT", b"NEP_FE_LPT", b"NEP_QP_KEY_DECAY", b"NEP_FE_KEY_DECAY",
+           b"NEP_SEP_UNPACKED", b"NEP_SEP_PACK", b"NEP_CORR_FROM", b"NEP_CORR_MAX", b"NEP_HULL_KERNEL", b"NEP_FE_THREE", b"NEP_FE_XCD", b"NEP_POLISH_GRID"}
+    assert not (names & old), names & old
+    assert L.nep_debug_set_global_option(b"fe_xcd", 1) == 0 and L.nep_debug_set_global_option(b"polish_grid", 256) == 0
+    assert L.nep_debug_set_global_option(b"no_such_option", 1) < 0 and b"unknown" in L.nep_last_error()
+    assert L.nep_batch_debug_set_option(None, b"qp_kernel", 1) < 0
+
+
 def test_oracle_is_not_reachable_from_the_product():
     """The product package must not import or link the oracle."""
     for dirpath, _, files in os.walk(os.path.join(ROOT, "neptune_amd")):

@@ -66,10 +66,10 @@ def test_the_drivers_command_prints_one_short_parsable_line(tmp_path):
     assert 0 < out["roofline"]["frac"] < 1 and out["roofline"]["bound"] == "hbm" and out["roofline"]["peak"] == 8000.0
     assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0 and out["cpu_baseline"]["cores"] >= 1
     assert out["rccl"]["nranks"] == [1]
-    for k in ("moving", "crossing", "chain", "presolve", "config5", "config5_chain", "per_agent_api_p50_ms"):
+    for k in ("moving", "crossing", "chain", "full_rows", "config5", "config5_chain", "per_agent_api_p50_ms"):
         assert out["highlights"][k] > 0, k
     assert detail is not None
-    for leg in ("long_run", "launch_order_off", "reference_tolerances", "presolve", "chain", "moving", "crossing", "single_scene", "small_configs",
+    for leg in ("long_run", "launch_order_off", "reference_tolerances", "full_rows", "chain", "moving", "crossing", "single_scene", "small_configs",
                 "per_agent_api", "config5", "cpu_baseline", "roofline_fp64"):
         assert detail.get(leg), leg
     assert detail["value"] == pytest.approx(out["value"], rel=1e-5)

@@ -6,7 +6,7 @@ import pytest
 
 import helpers
 from neptune_amd import abi, scene
-from gpu_util import _bounds, _solver, COEF_TOL, COST_RTOL
+from gpu_util import _bounds, _solver, solver_lines_match, COEF_TOL, COST_RTOL
 
 pytestmark = pytest.mark.gpu
 
@@ -34,12 +34,18 @@ def test_per_agent_api_matches_batch(be, oracle):
     s.setHullsNoInflation([[h0[j, i, :n0[j, i]] for i in range(p.num_pol)] if j != aid - 1 else [] for j in range(5)])
     ok, obj = s.optimize()
     r = oracle.replan(p, aid, sc["committed"], g, sc["statics"])
-    seg, nd = s.debugGetLines()
-    np.testing.assert_array_equal(nd, r["line_nd"])
+    solver_lines_match(s, r)                            # the default path: verified presolve (near lines first, parked after)
     times, coeff, traj = s.generatePwpOut(12.5, p.dc)
     assert ok and np.abs(coeff - r["coeff"]).max() <= COEF_TOL
     np.testing.assert_allclose(times, 12.5 + np.arange(K + 1) * p.T_span)
     assert s.stats()["solve_us"] > 0
+    # every row through the interior point (nep_backend_set_line_cull(h, 0)): the lines in the reference's call order, the same optimum
+    s.setLineCull(0.0)
+    ok2, obj2 = s.optimize()
+    solver_lines_match(s, r, ordered=True)
+    _, coeff2, _ = s.generatePwpOut(12.5, p.dc)
+    assert ok2 and np.abs(coeff2 - r["coeff"]).max() <= COEF_TOL and np.abs(coeff2 - coeff).max() <= COEF_TOL
+    assert abs(obj2 - obj) <= COST_RTOL * (1 + abs(obj))
     s.close()
 
 
@@ -140,8 +146,7 @@ def test_entangle_through_per_agent_api(be, oracle):
     s.setEntStateVector(ent, bend)
     ok, obj = s.optimize()
     r = oracle.replan(p, aid, sc["committed"], g, sc["statics"], case_id=case_id[aid - 1])
-    seg, nd = s.debugGetLines()
-    np.testing.assert_array_equal(nd, r["line_nd"])
+    solver_lines_match(s, r)
     t, coeff, traj = s.generatePwpOut(0.0, p.dc)
     assert np.abs(coeff - r["coeff"]).max() <= COEF_TOL
     s.close()

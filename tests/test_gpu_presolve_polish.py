@@ -28,6 +28,7 @@ def test_line_presolve_leaves_the_optimum_unchanged(be, oracle, n_agents, n_stat
     p = sc["par"]; N = p.num_agents
     bb = be.BatchBackend(p, sc["statics"])
     d_com = bb.to_device(sc["committed"]); d_gue = bb.to_device(sc["guesses"])
+    bb.set_line_cull(0.0)              # (every row: the presolve is the handle's default)
     bb.replan(d_com, d_gue)
     full = bb.solutions()
     bb.set_line_cull(radius)
@@ -75,10 +76,11 @@ def test_line_presolve_on_front_end_guesses_with_the_polish_pass(be, radius):
         bb.set_scene_statics(s, scs[s]["statics"])
     d_com = bb.to_device(com); d_g = bb.to_device(gue)
     bb.frontend(scene.frontend_cfg(p, beam_width=32), d_com, bb.to_device(np.stack([scene.frontend_starts(s) for s in scs])), d_g, None)
+    bb.set_line_cull(0.0)
     bb.replan(d_com, d_g); full = bb.solutions().copy()
     listed_full, _ = bb.polish_count()
     assert listed_full >= 1                                          # (loose exits exist on these inputs)
-    bb.set_line_cull(radius); bb.set_polish(2)                       # (2: the pass under the presolve as well — not the default, it costs 8 % of a presolved step)
+    bb.set_line_cull(radius)                                         # (the polish pass runs under the presolve by default since round 6)
     bb.replan(d_com, d_g); cut = bb.solutions().copy()
     listed, certified = bb.polish_count()
     assert listed >= 1 and certified >= 1
@@ -207,7 +209,7 @@ def test_hard_closed_loop_replans_status_against_highs_and_the_oracle(be, oracle
     assert n_lab[2] >= 30 and n_lab[1] >= 5 and n_lab[0] >= 20
     print("device gave up on %d of %d replans HiGHS finds strictly feasible: %r; device != oracle on %d of %d: %r; cost where both solve: max rel %.2e"
           % (len(missed), n_lab[0], missed, len(differ), len(cases), differ, max(dcost)))
-    assert len(missed) <= 8 and len(differ) <= 8
+    assert len(missed) <= 2 and len(differ) <= 5                                 # (measured: 1 and 4, rounds 5 and 6; one of slack each)
     assert not [d for d in differ if d[3] > 0]                                   # never on a decisively infeasible case
     assert max(dcost) <= 1e-6
 
@@ -229,6 +231,7 @@ def test_polish_finishes_loose_and_stalled_solves_exactly(be, oracle):
     d_com = bb.to_device(com); d_g = bb.to_device(gue)
     bb.frontend(scene.frontend_cfg(p, beam_width=32), d_com, bb.to_device(np.stack([scene.frontend_starts(s) for s in scs])), d_g, None)
     g = d_g.cpu().numpy().view(abi.GUESS_DTYPE).reshape(S, N)
+    bb.set_line_cull(0.0)              # (every row: the interior point's loose exits as they are; the presolved path is the next tests')
     bb.set_polish(False); bb.replan(None, d_g); off = bb.solutions().reshape(S, N).copy()
     assert bb.polish_count() == (0, 0)
     bb.set_polish(True); bb.replan(None, d_g); on = bb.solutions().reshape(S, N).copy()
@@ -286,7 +289,8 @@ def test_reference_tolerances(be, oracle):
     bb.set_tolerances()                                          # back to 1e-9 / 1e-10
     bb.replan(d_com, d_mix); again = bb.solutions().reshape(S, N)
     assert again["coeff"].tobytes() == strict["coeff"].tobytes() and (again["stats"]["status"] == strict["stats"]["status"]).all()
-    it_s, it_l = strict["stats"]["iters"].mean(), loose["stats"]["iters"].mean()
+    it_on = strict["stats"]["iters"] > 0                         # (the presolve — the default — ends most own-guess replans without an iteration)
+    it_s, it_l = strict["stats"]["iters"][it_on].mean(), loose["stats"]["iters"][it_on].mean()
     assert it_l <= it_s - 0.3, (it_s, it_l)
     oracle.set_qp_tolerances(1e-6, 1e-8)
     try:
@@ -320,7 +324,7 @@ def test_reference_tolerances(be, oracle):
 def test_one_slot_launch_lists_itself_for_the_polish_pass(be):
     """A launch of ONE replan (the per-agent handle's shape: one workgroup) keeps no counter to zero beforehand — qp_reg_kernel's last
     lines set the polish pass's list themselves.  One-agent shards of a 64-agent scene, on front-end guesses whose solves end loose,
-    give the full batch's trajectories bit for bit: plain (every row) and under the presolve with the pass on (set_polish(2), the
+    give the full batch's trajectories bit for bit: plain (every row) and under the presolve (the default; the pass runs there too, the
     third instantiation); the counters say 1 listed where the batch listed that agent."""
     sc = scene.make_scene(64, 20, seed=203)
     p = sc["par"]; N = p.num_agents
@@ -328,8 +332,8 @@ def test_one_slot_launch_lists_itself_for_the_polish_pass(be):
     d_com = full.to_device(sc["committed"][None]); d_g = full.to_device(sc["guesses"][None])
     full.frontend(scene.frontend_cfg(p, beam_width=32), d_com, full.to_device(scene.frontend_starts(sc)[None]), d_g, None)
     g = d_g.cpu().numpy().view(abi.GUESS_DTYPE).reshape(N)
-    full.set_polish(False); full.replan(d_com, d_g); off = full.solutions().copy()
-    for mode, cull in ((1, 0.0), (2, 4.0)):
+    full.set_line_cull(0.0); full.set_polish(False); full.replan(d_com, d_g); off = full.solutions().copy()
+    for mode, cull in ((1, 0.0), (1, 4.0)):
         full.set_line_cull(cull); full.set_polish(mode); full.replan(d_com, d_g); want = full.solutions().copy()
         listed_all, _ = full.polish_count()
         assert listed_all >= 1

@@ -3,6 +3,7 @@ publishes, polygon orientation at upload, the hull capacity flag, one static-obs
 import numpy as np
 import pytest
 
+import helpers
 from neptune_amd import abi, scene
 
 pytestmark = pytest.mark.gpu
@@ -78,6 +79,7 @@ def test_clockwise_polygons_are_reoriented_and_nonconvex_refused(be, oracle):
     outs = []
     for statics in (sc["statics"], cw):
         bb = be.BatchBackend(p, statics)
+        bb.set_line_cull(0.0)                   # (every line, in the reference's call order: compared with the oracle's list below)
         bb.replan(bb.to_device(sc["committed"]), bb.to_device(sc["guesses"]))
         outs.append((bb.solutions(), [bb.debug_lines(a) for a in range(5)]))
         bb.close()
@@ -514,3 +516,46 @@ def test_line_buckets_smaller_than_the_worst_case_flag_an_overflow(be):
             for a in np.nonzero(~failed)[0]:
                 assert sol[a].tobytes() == ref[a].tobytes()
     bb.close()
+
+
+def test_a_hostile_environment_changes_nothing(be):
+    """Round-5 review: the drop-in's numerics must not depend on the caller's environment.  The same replan (24 agents + 12 obstacles,
+    entangle rows on; then a front-end search) in two child processes — a clean environment, and one with every variable the library
+    used to read (rounds 2-5) set to the value that used to change its behaviour most: the two print the same digests."""
+    import hashlib, os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import dataclasses, hashlib, sys
+        import numpy as np
+        sys.path.insert(0, %r)
+        from neptune_amd import abi, scene
+        from neptune_amd.backend import BatchBackend
+        sc = scene.make_scene(24, 12, seed=33)
+        case = scene.synthetic_entangle(sc, seed=733, frac=0.3)
+        p = dataclasses.replace(sc["par"], enable_entangle=True)
+        bb = BatchBackend(p, sc["statics"])
+        d_ent = bb.torch.from_numpy(np.ascontiguousarray(case).reshape(-1)).to(bb.device)
+        d_com = bb.to_device(sc["committed"]); d_g = bb.to_device(sc["guesses"])
+        bb.replan(d_com, d_g, d_ent=d_ent)
+        h = hashlib.sha256(bb.solutions().tobytes())
+        for a in range(24):
+            seg, nd = bb.debug_lines(a, cap=8192)
+            h.update(seg.tobytes()); h.update(nd.tobytes())
+        h.update(np.array([bb.line_cull(), float(bb.qp_kernel_name() == "qp_reg_kernel"), float(bb.redo_count())]).tobytes())
+        d_gfe = bb.torch.zeros(24 * abi.GUESS_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
+        p0 = sc["par"]; b0 = BatchBackend(p0, sc["statics"])
+        b0.frontend(scene.frontend_cfg(p0, beam_width=16), b0.to_device(sc["committed"]), b0.to_device(scene.frontend_starts(sc)), d_gfe, None)
+        b0.replan(None, d_gfe)
+        h.update(d_gfe.cpu().numpy().tobytes()); h.update(b0.solutions().tobytes())
+        print("DIGEST", h.hexdigest())
+    """ % helpers.ROOT)
+    hostile = {"NEP_QP_KERNEL": "lds", "NEP_QP_AUTOCULL": "0", "NEP_SEP_SKIP": "0", "NEP_SEP_NO_REDO": "1", "NEP_QP_LPT": "0", "NEP_FE_LPT": "0",
+               "NEP_QP_KEY_DECAY": "0", "NEP_FE_KEY_DECAY": "0", "NEP_SEP_UNPACKED": "1", "NEP_SEP_PACK": "3", "NEP_CORR_FROM": "2", "NEP_CORR_MAX": "1",
+               "NEP_HULL_KERNEL": "wave", "NEP_FE_THREE": "1", "NEP_FE_XCD": "0", "NEP_POLISH_GRID": "1"}
+    outs = []
+    for extra in ({}, hostile):
+        env = {k: v for k, v in os.environ.items() if not (k.startswith("NEP_") and k != "NEP_BACKEND_LIB")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert outs[0] == outs[1]
