@@ -235,9 +235,9 @@ def retimed_legs(ctx, H):
             residual_tol=1e-6, gap_tol=1e-8,
             note="nep_batch_set_tolerances(1e-6, 1e-8): the strict tests at Gurobi's defaults (FeasibilityTol = OptimalityTol = "
                  "1e-6, BarConvTol = 1e-8), which is where the reference's solver stops (PolySolverGurobi sets OutputFlag and "
-                 "TimeLimit only, solver_gurobi_poly.cpp:811-812); the headline and every other leg use 1e-9 / 1e-10", **acc.status_counts(sol_t))
+                 "TimeLimit only, solver_gurobi_poly.cpp:811-812); the headline and every other leg use the library's defaults, 1e-10 / 1e-11", **acc.status_counts(sol_t))
         for b in bes:
-            b.enable_timing(False); b.set_tolerances(1e-9, 1e-10)
+            b.enable_timing(False); b.set_tolerances()
         for _ in range(2):
             step()
     # ---- full_rows: the same steps with the presolve OFF — every separating-line row of every replan through the interior point

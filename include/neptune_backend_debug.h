@@ -121,6 +121,10 @@ int nep_batch_set_fe_ent_fast_caps(nep_batch_t* h, int32_t list_cap, int32_t add
 
 /* Test hook: the polish pass of the last replan (nep_batch_set_polish) — how many replans were listed for it and how many it certified. */
 int nep_batch_debug_polish_count(nep_batch_t* h, int32_t* listed, int32_t* certified);
+/* ... and per slot: flags [slots] (host) — 0 = not listed; bit 0 / bit 1: the first / the relaxed problem's solve was left for the pass; bit 8: the
+ * pass certified an optimum and wrote the slot's status, objective and trajectory (nep_stats.iters / iters_first stay the interior point's;
+ * nep_stats.solve_us includes the pass's device time).                                                                                  */
+int nep_batch_debug_polish_flags(nep_batch_t* h, int32_t* flags, int32_t cap);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ EXPORTS = [
 ]
 # every symbol include/neptune_backend_debug.h declares (test hooks, measurement aids, A/B knobs)
 DEBUG_EXPORTS = [
-    "nep_batch_debug_polish_count",
+    "nep_batch_debug_polish_count", "nep_batch_debug_polish_flags",
     "nep_backend_debug_time_sequence", "nep_backend_debug_set_lines", "nep_backend_debug_get_lines",
     "nep_debug_regroup_records", "nep_batch_debug_redo_count", "nep_batch_debug_redo_list",
     "nep_batch_line_bucket_bytes", "nep_batch_row_scratch_bytes", "nep_batch_active_rows",
@@ -177,7 +177,7 @@ def lib():
     L.nep_batch_frontend_ent_hulls.argtypes = [vp, C.POINTER(abi.nep_fe_cfg), vp, i, vp, vp, vp, vp, vp, vp]
     L.nep_batch_exchange_slots.argtypes = [vp, vp, vp, vp, C.c_int64, vp]
     L.nep_batch_set_ent_samples.argtypes = [vp, i]
-    L.nep_batch_set_polish.argtypes = [vp, i]; L.nep_backend_set_polish.argtypes = [vp, i]; L.nep_batch_debug_polish_count.argtypes = [vp, pi, pi]
+    L.nep_batch_set_polish.argtypes = [vp, i]; L.nep_backend_set_polish.argtypes = [vp, i]; L.nep_batch_debug_polish_count.argtypes = [vp, pi, pi]; L.nep_batch_debug_polish_flags.argtypes = [vp, pi, i]
     # the records this mirror builds with ctypes must have the library's layout (a library compiled from other headers would read
     # them at another stride): fail loudly at load, not as wrong numbers later
     L.nep_abi_sizeof.argtypes = [i]; L.nep_abi_sizeof.restype = i

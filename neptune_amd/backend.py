@@ -64,7 +64,7 @@ class PolySolver:
         """not in the reference: which LP vertex the separator returns (nep_backend_set_separator_rule)"""
         check(lib().nep_backend_set_separator_rule(self._h, int(rule)))
 
-    def setTolerances(self, residual_tol=1e-9, gap_tol=1e-10):
+    def setTolerances(self, residual_tol=1e-10, gap_tol=1e-11):
         """not in the reference (which leaves Gurobi's defaults, 1e-6 / 1e-8): the interior point's strict tests (nep_backend_set_tolerances)"""
         check(lib().nep_backend_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
 
@@ -444,7 +444,7 @@ class BatchBackend:
         default class reaches (nep_batch_set_separator_rule)"""
         check(lib().nep_batch_set_separator_rule(self._h, int(rule)))
 
-    def set_tolerances(self, residual_tol=1e-9, gap_tol=1e-10):
+    def set_tolerances(self, residual_tol=1e-10, gap_tol=1e-11):
         """the interior point's strict tests (nep_batch_set_tolerances); (1e-6, 1e-8) = Gurobi's defaults, what the reference's solver stops at"""
         check(lib().nep_batch_set_tolerances(self._h, float(residual_tol), float(gap_tol)))
 
@@ -462,6 +462,13 @@ class BatchBackend:
         a = C.c_int32(0); b = C.c_int32(0)
         check(lib().nep_batch_debug_polish_count(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def polish_flags(self):
+        """per slot of the last replan: 0 not listed for the polish pass; bit 0 / 1 the first / relaxed solve was left for it; bit 8 (256) the pass
+        certified an optimum and wrote the result (nep_batch_debug_polish_flags)"""
+        out = np.zeros(self.n_scenes * self.n_local, dtype=np.int32)
+        check(lib().nep_batch_debug_polish_flags(self._h, abi.iptr(out), len(out)))
+        return out
 
     def set_safety_check_prev(self, on=True):
         """also turn down new trajectories that collide with another agent's PREVIOUS record (nep_batch_set_safety_check_prev)"""

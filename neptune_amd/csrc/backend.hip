@@ -101,7 +101,7 @@ struct Engine {
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
   DevBuf<int> d_line_skip, d_redo_list, d_redo_count;   // spatial presolve: skipped LPs per segment, replans listed for the redo pass
-  DevBuf<double> d_polish_z; DevBuf<int> d_polish_flag, d_polish_list, d_polish_count; bool polish = true, polish_presolve = true;      // the active-set polish of solves that end without the strict tests (qp_polish_kernel.hip; nep_*_set_polish)
+  DevBuf<double> d_polish_z; DevBuf<int> d_polish_flag, d_polish_list, d_polish_count; bool polish = true, polish_presolve = true, last_polish_armed = false;      // the active-set polish of solves that end without the strict tests (qp_polish_kernel.hip; nep_*_set_polish)
   DevBuf<long long> d_dbg; bool profile_phases = false;
   DevBuf<int> d_flags;
   // entangle-aware front end / safety re-check (nep_batch_frontend_ent, nep_batch_safety_commit_ent)
@@ -120,7 +120,7 @@ struct Engine {
   bool use_reg = false;        // the QP runs as qp_reg_kernel (row state in registers, four workgroups per CU)
   double clock_hz = 1e8;       // wall_clock64() rate of the handle's device (set_clock)
   // (the short-step give-up rule's two numbers: run-time values for A/B, nep_*_debug_set_option "corr_from" / "corr_max"; never read from the environment)
-  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; sp.corr_from_it = opt_corr_from; sp.corr_max_count = opt_corr_max; if (!(sp.tol_res > 0.0)) { sp.tol_res = 1e-9; sp.tol_gap = 1e-10; sp.tol_res_inv = 1e9; sp.tol_gap_inv = 1e10; sp.tol_gap_floor = 0.1 * 1e-10; } }      // (called by both create paths: the strict tests' defaults with it)
+  void set_clock() { clock_hz = wall_clock_hz(); sp.us_per_tick = 1e6 / clock_hz; sp.corr_from_it = opt_corr_from; sp.corr_max_count = opt_corr_max; if (!(sp.tol_res > 0.0)) { sp.tol_res = 1e-10; sp.tol_gap = 1e-11; sp.tol_res_inv = 1e10; sp.tol_gap_inv = 1e11; sp.tol_gap_floor = 0.1 * 1e-11; } }      // (called by both create paths: the strict tests' defaults with it)
   double sched_dc = -1, tab_T = -1, tab_w = -1; int sched_cap = 0;
   std::vector<int> h_sched_n, h_sched_seg; std::vector<double> h_sched_dt;
   // timing
@@ -272,6 +272,7 @@ struct Engine {
     const bool pol = polish && use_reg && (polish_presolve || !(sp.cull_radius > 0.0)) && d_polish_z.p != nullptr;
     ps.polish_z = pol ? d_polish_z.p : nullptr; ps.polish_flag = pol ? d_polish_flag.p : nullptr;
     ps.polish_list = pol ? d_polish_list.p : nullptr; ps.polish_count = pol ? d_polish_count.p : nullptr;
+    last_polish_armed = pol;
   }
   // packs n polygons into the fixed-stride device layout (vertices, vertex counts, edge lengths)
   bool statics_boxy = true;      // every static polygon uploaded so far has an edge on each side of its bounding box (see pack_statics)
@@ -1432,7 +1433,7 @@ int nep_backend_set_separator_rule(nep_backend_t* h, int32_t rule) {
 namespace { int set_tol(Engine& E, double res, double gap) {
   if (!(res >= 1e-12 && res <= 1e-6) || !(gap >= 1e-13 && gap <= 1e-7)) return fail(NEP_E_ARG, "tolerances: residuals in [1e-12, 1e-6], relative gap in [1e-13, 1e-7]");
   E.sp.tol_res = res; E.sp.tol_gap = gap;
-  E.sp.tol_res_inv = res == 1e-9 ? 1e9 : 1.0 / res; E.sp.tol_gap_inv = gap == 1e-10 ? 1e10 : 1.0 / gap; E.sp.tol_gap_floor = 0.1 * gap;      // (the defaults' reciprocals as the literals the kernels were validated with)
+  E.sp.tol_res_inv = res == 1e-10 ? 1e10 : (res == 1e-9 ? 1e9 : 1.0 / res); E.sp.tol_gap_inv = gap == 1e-11 ? 1e11 : (gap == 1e-10 ? 1e10 : 1.0 / gap); E.sp.tol_gap_floor = 0.1 * gap;      // (the defaults' reciprocals as the literals the kernels were validated with)
   return 0;
 } }
 int nep_batch_set_tolerances(nep_batch_t* h, double residual_tol, double gap_tol) { if (!h) return fail(NEP_E_ARG, "null handle"); return set_tol(h->eng, residual_tol, gap_tol); }
@@ -1446,9 +1447,28 @@ int nep_batch_debug_polish_count(nep_batch_t* h, int32_t* listed, int32_t* certi
   if (!h) return fail(NEP_E_ARG, "null handle");
   int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   HIPCHK(hipDeviceSynchronize());
-  if (h->eng.d_polish_count.p) HIPCHK(hipMemcpy(c, h->eng.d_polish_count.p, sizeof(c), hipMemcpyDeviceToHost));
+  // (a launch whose pass was not armed — polish off, or the LDS-placement kernel, which has no hooks — leaves the counters of an earlier
+  // launch behind: reported as (0, 0), round-5 advisor finding)
+  if (h->eng.d_polish_count.p && h->eng.last_polish_armed) HIPCHK(hipMemcpy(c, h->eng.d_polish_count.p, sizeof(c), hipMemcpyDeviceToHost));
   if (listed) *listed = c[0];
   if (certified) *certified = c[3];
+  return 0;
+}
+// Test hook: per slot of the last replan, 0 = not listed for the polish pass, else the flag word — bit m: the solve of mode m (0 first
+// problem, 1 relaxed) was left for the pass; bit 8: the pass certified an optimum and wrote the slot's result.
+int nep_batch_debug_polish_flags(nep_batch_t* h, int32_t* flags, int32_t cap) {
+  if (!h || !flags || cap < h->slots) return fail(NEP_E_ARG, "bad arguments");
+  for (int i = 0; i < h->slots; i++) flags[i] = 0;
+  if (!h->eng.d_polish_count.p || !h->eng.last_polish_armed) return 0;
+  int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(c, h->eng.d_polish_count.p, sizeof(c), hipMemcpyDeviceToHost));
+  const int n = c[0] < h->slots ? c[0] : h->slots;
+  if (n <= 0) return 0;
+  std::vector<int> list(n), fl(h->slots);
+  HIPCHK(hipMemcpy(list.data(), h->eng.d_polish_list.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(fl.data(), h->eng.d_polish_flag.p, (size_t)h->slots * sizeof(int), hipMemcpyDeviceToHost));
+  for (int i = 0; i < n; i++) if (list[i] >= 0 && list[i] < h->slots) flags[list[i]] = fl[list[i]];
   return 0;
 }
 int nep_batch_set_safety_check_prev(nep_batch_t* h, int32_t on) { if (!h) return fail(NEP_E_ARG, "null handle"); h->eng.safety_check_prev = on != 0; return 0; }

@@ -490,7 +490,7 @@ __global__ __launch_bounds__(BS, 2) void qp_kernel(SceneParams sp, ProblemSet ps
           const double o = sc[sObj0] + wave_sum(tid < n ? sDxa[tid] : 0.0);
           const double gap = sc[sMu] * mt, nr = sc[sNrp], qs = sc[sQscale];
           int flag = 0;
-          if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-9, 1e-9, 1e-10 unless nep_batch_set_tolerances says otherwise)
+          if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-10, 1e-10, 1e-11 unless nep_batch_set_tolerances says otherwise)
           else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
           if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN
           if (sI[17] >= 3) flag = 3;                           // stalled

@@ -391,7 +391,24 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
 __global__ __launch_bounds__(256) void qp_polish_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
   const int n_listed = ps.polish_count[0];
   int n_ok = 0;
-  for (int e = blockIdx.x; e < n_listed; e += gridDim.x) { n_ok += polish_slot(sp, ps, tables, sched, ps.polish_list[e]) ? 1 : 0; __syncthreads(); }
+  for (int e = blockIdx.x; e < n_listed; e += gridDim.x) {
+    const int slot = ps.polish_list[e];
+    const long long t0 = (long long)wall_clock64();
+    const bool ok = polish_slot(sp, ps, tables, sched, slot);
+    __syncthreads();
+    // (round-5 advisor finding) the pass's device time belongs to the replan's: nep_stats.solve_us and the next launch's ordering key count
+    // it, and a slot the pass certified is marked (bit 8 of its flag word: nep_batch_debug_polish_flags) — its status, objective and
+    // trajectory are the pass's, its iteration counts still the interior point's
+    if (threadIdx.x == 0) {
+      nep_solution* sol = ps.solution + slot;
+      const double us_ = sol->stats.solve_us + (double)((long long)wall_clock64() - t0) * sp.us_per_tick;
+      sol->stats.solve_us = us_;
+      if (ps.order_key) { const double k_ = us_ * 0.125; const int kn = k_ > 63.0 ? 63 : (int)k_; if (kn > ps.order_key[slot]) ps.order_key[slot] = kn; }
+      if (ok) ps.polish_flag[slot] |= 0x100;
+    }
+    n_ok += ok ? 1 : 0;
+    __syncthreads();
+  }
   if (threadIdx.x == 0 && n_ok) atomicAdd(ps.polish_count + 3, n_ok);
 }
 __global__ void qp_polish_zero_kernel(int* __restrict__ c) { if (threadIdx.x < 4) c[threadIdx.x] = 0; }

@@ -736,7 +736,7 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
             const double o = sc[sObj0] + wave_sum(l1 < n ? sDx[l1] : 0.0);      // (the objective's terms: written next to rd, see above)
             const double gap = sc[sMu] * sc[sMtD], nr = sc[sNrp], qs = sc[sQscale];
             int flag = 0;
-            if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-9, 1e-9, 1e-10 unless nep_batch_set_tolerances says otherwise)
+            if (nr <= sp.tol_res && nrd <= sp.tol_res * qs && gap <= sp.tol_gap * (1.0 + fabs(o))) flag = 1;      // (1e-10, 1e-10, 1e-11 unless nep_batch_set_tolerances says otherwise)
             else if (nr <= 1e-6 && nrd <= 1e-6 * qs && gap <= 1e-7 * (1.0 + fabs(o))) flag = 2;
             if ((!CULL || PST) && l1 == 0) sI[28] = flag;         // (1: the STRICT tests passed — flag 1 below may also mean "the loose window ends on this iterate")
             if (!(sc[sMu] < 1e30) || !(nrd < 1e300)) flag = 3;  // diverged / NaN

@@ -97,7 +97,7 @@ int orc_separator_glpk_class(int nA, const double (*A)[2], int nB, const double 
 /* which separator rule the restated path uses from now on (thread-local): 0 largest gap, 1 GLPK-class simplex */
 void orc_set_separator_rule(int rule);
 
-/* the interior point's strict tests (thread-local; defaults 1e-9 / 1e-10; checker of nep_batch_set_tolerances) */
+/* the interior point's strict tests (thread-local; defaults 1e-10 / 1e-11 as the device's; checker of nep_batch_set_tolerances) */
 void orc_set_qp_tolerances(double residual_tol, double gap_tol);
 /* the active-set polish of interior-point solves that end without passing the strict tests (qp_solve; on by default) */
 void orc_set_polish(int on);

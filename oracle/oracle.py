@@ -183,7 +183,7 @@ def last_polished():
     return bool(lib().orc_last_polished())
 
 
-def set_qp_tolerances(residual_tol=1e-9, gap_tol=1e-10):
+def set_qp_tolerances(residual_tol=1e-10, gap_tol=1e-11):
     """the interior point's strict tests, for every solve made from this thread afterwards (checker of nep_batch_set_tolerances)"""
     lib().orc_set_qp_tolerances(float(residual_tol), float(gap_tol))
 

@@ -54,6 +54,14 @@ def main():
               % (r, {NAMES[k]: int((res["status"] == k).sum()) for k in NAMES}, (st == 0).sum(), (st == 1).sum(), (st == 2).sum(), float(d_ac.float().mean().item())), flush=True)
     print("device beam WITH the entangle check, last round, all %d searches: %s; children pruned by the check %d; ent_overflow %d"
           % (S * N, {NAMES[k]: int((res["status"] == k).sum()) for k in NAMES}, int(res["n_entangled"].sum()), int(res["ent_overflow"].sum())))
+    # the same searches once more with the widest beam this build has (64): how many of the lost ones would a wider-beam retry find?
+    cfg64 = scene.frontend_cfg(p, beam_width=abi.NEP_FE_MAX_BEAM if hasattr(abi, "NEP_FE_MAX_BEAM") else 64, entangle=True)
+    d_g2 = torch.zeros_like(d_g); d_r2 = torch.zeros_like(d_r); d_case2 = torch.zeros_like(d_case)
+    be.frontend_ent(cfg64, d_c, d_s, d_g2, d_r2, d_case2)
+    res64 = d_r2.cpu().numpy().view(abi.FE_RESULT_DTYPE).copy()
+    lost32 = (res["status"] >= 2)
+    print("device beam of width 64 WITH the entangle check, same inputs: %s; of the %d searches the width-32 beam ended without a plan (died out / no solution), width 64 finds a plan for %d"
+          % ({NAMES[k]: int((res64["status"] == k).sum()) for k in NAMES}, int(lost32.sum()), int((lost32 & (res64["status"] < 2)).sum())))
     oracle.lib()
     jobs = [(s, a) for s in range(min(SH, S)) for a in range(N)]
 

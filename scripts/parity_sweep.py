@@ -26,6 +26,8 @@ def oracle_one(job):
     from oracle import oracle
     sc = scene.make_scene(N, M, seed=SEED0 + seed)
     tighten(sc["par"])
+    if os.environ.get("NEP_TOL"):           # experiment: the strict tests' tolerances "residual,gap" on both sides
+        oracle.set_qp_tolerances(*[float(x) for x in os.environ["NEP_TOL"].split(",")])
     r = oracle.replan(sc["par"], a + 1, sc["committed"], g, sc["statics"])          # every scene has its own statics, on both sides
     strict = None
     if os.environ.get("NEP_SWEEP_STRICT"):
@@ -49,6 +51,10 @@ def main():
     for s_ in range(1, S):
         be.set_scene_statics(s_, scs[s_]["statics"])
     d_com = be.to_device(com); d_gue = be.to_device(gue)
+    if os.environ.get("NEP_TOL"):
+        be.set_tolerances(*[float(x) for x in os.environ["NEP_TOL"].split(",")])
+    if os.environ.get("NEP_CULL") is not None:
+        be.set_line_cull(float(os.environ["NEP_CULL"]))
     if use_fe:
         d_start = be.to_device(np.stack([scene.frontend_starts(s) for s in scs]))
         be.frontend(scene.frontend_cfg(p, beam_width=32), d_com, d_start, d_gue, None)
@@ -85,7 +91,7 @@ def main():
     if len(dco) == 0:
         print("replans compared 0 (status mismatches %d): nothing solved on either side" % st_bad)
         return
-    print("statuses on the device: ok %d relaxed %d failed %d" % tuple(np.bincount(sol["stats"]["status"].astype(int), minlength=3)[:3]))
+    print("statuses on the device: ok %d relaxed %d failed %d; iterations mean %.3f (line presolve radius %g)" % (tuple(np.bincount(sol["stats"]["status"].astype(int), minlength=3)[:3]) + (float(sol["stats"]["iters"].mean()), be.line_cull())))
     print("replans compared %d (status mismatches %d) | coeff diff: p50 %.2e p99 %.2e max %.2e, > 1e-6: %d, > 1e-5: %d | position diff along the trajectories: p99 %.2e max %.2e m | rel cost diff max %.2e | worst (diff, scene, agent, gpu iters, oracle iters) %s"
           % (len(dco), st_bad, np.percentile(dco, 50), np.percentile(dco, 99), dco.max(), int((dco > 1e-6).sum()), int((dco > 1e-5).sum()), np.percentile(dpos, 99), dpos.max(), dob.max(), worst))
     if d_gs:

@@ -5,7 +5,7 @@ set -u
 OUT=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
-run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" -o pmc --output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-chain --presolve-radius 0 ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1; }
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$name" -o pmc --output-format csv -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-chain --no-full-rows ${BENCH_ARGS:-} > "$OUT/$name.log" 2>&1; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY

@@ -8,13 +8,13 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/$TAG; mkdir -p "$OUT"
 python bench.py --gpus 1 --steps 20 --warmup 5 --detail "$OUT/bench_detail.json" > "$OUT/bench_line.json" 2> "$OUT/bench_line.err"      # the driver's command; bench_line.json = the short line it parses
 HEAD="--steps 20 --warmup 3 --no-cpu-baseline --no-extra-legs --no-graph"
-CHAIN="--steps 10 --warmup 3 --no-cpu-baseline --no-config5 --no-graph --presolve-radius 0 --aux-steps 10"
+CHAIN="--steps 10 --warmup 3 --no-cpu-baseline --no-config5 --no-graph --no-full-rows --aux-steps 10"
 rocprofv3 --kernel-trace --stats -d "$OUT/kt" -o kt --output-format rocpd -- python bench.py $HEAD > "$OUT/kt.log" 2>&1
 python scripts/rocpd_summary.py "$(find "$OUT/kt" -name "*.db" | head -1)" > "$OUT/bench_kernel_stats.txt" 2>> "$OUT/kt.log"
 rocprofv3 --kernel-trace --stats -d "$OUT/ktc" -o kt --output-format rocpd -- python bench.py $CHAIN > "$OUT/ktc.log" 2>&1
 python scripts/rocpd_summary.py "$(find "$OUT/ktc" -name "*.db" | head -1)" > "$OUT/bench_chain_kernel_stats.txt" 2>> "$OUT/ktc.log"
 pmc() { dir=$1; shift; args=$1; shift; name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" -d "$OUT/$dir/$name" -o pmc --output-format csv -- python bench.py $args > "$OUT/${dir}_$name.log" 2>&1; }
-for leg in "pmc|--steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs --no-graph" "pmcc|--steps 4 --warmup 2 --no-cpu-baseline --no-config5 --no-graph --presolve-radius 0 --aux-steps 4"; do
+for leg in "pmc|--steps 6 --warmup 2 --no-cpu-baseline --no-extra-legs --no-graph" "pmcc|--steps 4 --warmup 2 --no-cpu-baseline --no-config5 --no-graph --no-full-rows --aux-steps 4"; do
   dir=${leg%%|*}; args=${leg#*|}
   pmc $dir "$args" fetch FETCH_SIZE
   pmc $dir "$args" write WRITE_SIZE

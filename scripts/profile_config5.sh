@@ -19,7 +19,7 @@ run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU
 run sq2 SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 python scripts/pmc_summary.py "$OUT/pmc" > "$OUT/pmc_summary_config5.txt"
 # the config-5 chain (frontend_kernel<true>, ent_check_kernel, ...): kernel trace of the default command with short legs
-rocprofv3 --kernel-trace --stats -d "$OUT/ktf" -o kt --output-format rocpd -- python bench.py --steps 5 --warmup 2 --aux-steps 10 --presolve-radius 0 --no-cpu-baseline --no-graph > "$OUT/ktf.log" 2>&1
+rocprofv3 --kernel-trace --stats -d "$OUT/ktf" -o kt --output-format rocpd -- python bench.py --steps 5 --warmup 2 --aux-steps 10 --no-full-rows --no-cpu-baseline --no-graph > "$OUT/ktf.log" 2>&1
 python scripts/rocpd_summary.py "$(find "$OUT/ktf" -name "*.db" | head -1)" > "$OUT/config5_chain_kernel_stats.txt" 2>> "$OUT/ktf.log"
 rm -rf "$OUT/kt" "$OUT/pmc" "$OUT/ktf"
 head -12 "$OUT/config5_kernel_stats.txt"; python -c "

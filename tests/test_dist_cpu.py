@@ -154,10 +154,11 @@ class _StubBackend:
     writes new commit records from ALL blocks (so a stale or misplaced block changes the result) — and, like the QP kernel, it writes
     only part of a record: bytes [CARRY_LO, CARRY_HI) of a commit slot come out zero (the tether fields of a config-5 record)."""
     CARRY_LO, CARRY_HI = 96, 160
+    FAIL_EVERY = int(os.environ.get("NEP_TEST_STUB_FAIL_EVERY", "0"))            # > 0: the replan of (scene, agent id) with (scene + id + round) % FAIL_EVERY == 0 FAILS: its commit slot keeps what it held
 
-    def __init__(self, n_scenes, n_local, first_local):
+    def __init__(self, n_scenes, n_local, first_local, scene0=0):
         self.torch, self.device = torch, "cpu"
-        self.S, self.nl, self.first = n_scenes, n_local, first_local
+        self.S, self.nl, self.first, self.scene0, self.round = n_scenes, n_local, first_local, scene0, 0
         self.d_commit = torch.zeros(n_scenes * n_local * ndist.REC_BYTES, dtype=torch.uint8)
 
     def hull_block_bytes(self):
@@ -177,6 +178,11 @@ class _StubBackend:
         ids = torch.arange(self.first, self.first + self.nl, dtype=torch.int64)
         new = (old.to(torch.int64) * 3 + tot[:, None, None] + ids[None, :, None] * 7 + torch.arange(ndist.REC_BYTES, dtype=torch.int64)[None, None, :]) % 251
         new[:, :, self.CARRY_LO:self.CARRY_HI] = 0
+        if self.FAIL_EVERY > 0:              # a failed replan publishes nothing (neptune_ros.cpp:651-663): the slot keeps the record it held, carried bytes included
+            sc = torch.arange(self.scene0, self.scene0 + self.S, dtype=torch.int64)[:, None]
+            failed = ((sc + ids[None, :] + self.round) % self.FAIL_EVERY) == 0
+            new = torch.where(failed[:, :, None], old.to(torch.int64), new)
+        self.round += 1
         self.d_commit.copy_(new.to(torch.uint8).view(-1))
 
 
@@ -198,7 +204,7 @@ def _rounds_worker(rank, world, port, S, N, C, steps, local_bytes, guess_bytes, 
     local0 = np.frombuffer(local_bytes, dtype=np.uint8).reshape(S, N, ndist.REC_BYTES)
     guess = np.frombuffer(guess_bytes, dtype=np.uint8).reshape(S, N)
     Sc = S // C
-    bes = [_StubBackend(Sc, nl, first) for _ in range(C)]
+    bes = [_StubBackend(Sc, nl, first, scene0=k * Sc) for k in range(C)]
     d_local = [torch.from_numpy(np.ascontiguousarray(local0[k * Sc:(k + 1) * Sc, first:first + nl]).copy()).view(-1) for k in range(C)]
     d_guess = [torch.from_numpy(np.ascontiguousarray(guess[k * Sc:(k + 1) * Sc, first:first + nl]).copy()).view(-1) for k in range(C)]
     rounds = ndist.ShardedRounds(bes, d_local, d_guess, world, rank, native=False,
@@ -237,3 +243,58 @@ def test_two_rank_sharded_rounds_with_carried_fields_match_one_rank(chunks):
         for k, b in enumerate(parts):
             mine = np.frombuffer(b, dtype=np.uint8).reshape(Sc, nl, ndist.REC_BYTES)
             assert mine.tobytes() == np.ascontiguousarray(want[k * Sc:(k + 1) * Sc, first:first + nl]).tobytes(), "rank %d chunk %d differs from the one-rank run" % (rank, k)
+
+
+def _run_sharded(S, N, C, steps, world, seed):
+    rng = np.random.default_rng(seed)
+    local0 = rng.integers(0, 251, size=(S, N, ndist.REC_BYTES), dtype=np.uint8)
+    guess = rng.integers(0, 100, size=(S, N), dtype=np.uint8)
+    want = _rounds_reference(local0, guess, S, N, steps)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_rounds_worker, args=(r, world, port, S, N, C, steps, local0.tobytes(), guess.tobytes(), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=400) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    Sc = S // C
+    seen = set()
+    for rank, first, nl, parts in got:
+        seen.add(rank)
+        for k, b in enumerate(parts):
+            mine = np.frombuffer(b, dtype=np.uint8).reshape(Sc, nl, ndist.REC_BYTES)
+            assert mine.tobytes() == np.ascontiguousarray(want[k * Sc:(k + 1) * Sc, first:first + nl]).tobytes(), "rank %d chunk %d differs from the one-rank run" % (rank, k)
+    assert seen == set(range(world))
+    return want, local0
+
+
+@pytest.mark.timeout(600)
+def test_eight_rank_sharded_rounds_at_the_config4_layout_match_one_rank():
+    """BASELINE configs[3]'s layout — 64 agents block-sharded 8 per rank over EIGHT ranks, two scene chunks pipelined — over gloo on CPU
+    (the 8-GPU RCCL run itself is the driver's; no such node is reachable from here): after three steps every rank's records equal
+    the one-rank, one-chunk run byte for byte.  The exchange replaces neptune_ros.cpp:379-480."""
+    assert ndist.shard(64, 8, 5) == (40, 8)
+    _run_sharded(S=4, N=64, C=2, steps=3, world=8, seed=11)
+
+
+@pytest.mark.timeout(300)
+def test_sharded_rounds_with_failing_replans_keep_the_previous_records(monkeypatch):
+    """Round-5 advisor finding (dist.py, carry mode): a slot whose replan FAILS keeps the record it held — ShardedRounds seeds every
+    commit slot from d_local before the first round, so the copy of the non-carried byte ranges back into d_local never overwrites a
+    valid record with an unwritten slot.  Stub replans fail for a third of the (scene, agent, round) triples, first round included: two
+    ranks, two chunks == one rank, and no record is ever all zeros."""
+    monkeypatch.setattr(_StubBackend, "FAIL_EVERY", 3)
+    os.environ["NEP_TEST_STUB_FAIL_EVERY"] = "3"
+    try:
+        want, local0 = _run_sharded(S=4, N=6, C=2, steps=3, world=2, seed=13)
+    finally:
+        del os.environ["NEP_TEST_STUB_FAIL_EVERY"]
+    assert (want.reshape(-1, ndist.REC_BYTES).astype(np.int64).sum(axis=1) > 0).all()
+    # a slot that failed in every round still holds its initial record
+    ids = np.arange(6)[None, :]; sc = np.arange(4)[:, None]
+    always = np.ones((4, 6), dtype=bool)
+    for r in range(3):
+        always &= ((sc + ids + r) % 3) == 0
+    assert not always.any() or (want[always] == local0[always]).all()

@@ -176,6 +176,7 @@ def test_wall_clock_time_limit(be, oracle):
     sc = scene.make_scene(5, 3, seed=4)
     p = sc["par"]
     bb = be.BatchBackend(p, sc["statics"])
+    bb.set_line_cull(0.0)                    # (every replan iterates: under the presolve — the default — these scenes need no iteration and no time)
     d_com = bb.to_device(sc["committed"]); d_g = bb.to_device(sc["guesses"])
     bb.replan(d_com, d_g)
     ref = bb.solutions()
@@ -292,6 +293,7 @@ def test_short_affine_steps_discard_the_predictor(be, oracle):
         fe = scene.frontend_cfg(p, beam_width=32)
         starts = scene.frontend_starts(sc)
         bb = be.BatchBackend(p, sc["statics"])
+        bb.set_line_cull(0.0)                # (the safeguard is the interior point's: every row, the problem the oracle poses; the presolved path of these two hard replans: below)
         d_com = bb.to_device(sc["committed"]); d_start = bb.to_device(starts)
         d_guess = bb.torch.zeros(N * abi.GUESS_DTYPE.itemsize, dtype=bb.torch.uint8, device=bb.device)
         bb.frontend(fe, d_com, d_start, d_guess)
