@@ -244,6 +244,20 @@ def retimed_legs(ctx, H):
     # (rounds 1-5's headline; the handle's default is the verified presolve) ---------------------------------
     if args.cull_radius is None and not args.no_full_rows and not args.no_extra_legs:
         cull_default = be.line_cull()
+        # the SAME replans on both paths (a leg's steps feed each other — every step's new trajectories are the next step's obstacles — so
+        # the last steps of two legs are not the same problems): one launch of each path against one snapshot of the committed records
+        vs_default = None
+        if H.C == 1 and not H.sharded_hulls and H.d_committed is not None and not args.frontend and not args.safety:
+            snap = H.d_committed.clone()
+            be.replan(snap, H.d_guess); sol_a = be.solutions().copy()
+            be.set_line_cull(0.0)
+            be.replan(snap, H.d_guess); sol_b = be.solutions().copy()
+            same = sol_a["stats"]["status"] == sol_b["stats"]["status"]
+            okk = same & (sol_a["stats"]["status"] != 2)
+            dco = np.abs(np.array(sol_a["coeff"]) - np.array(sol_b["coeff"])).reshape(len(sol_a), -1).max(axis=1)
+            vs_default = {"replans": int(len(sol_a)), "status_mismatches": int((~same).sum()), "coeff_diff_max": float(dco[okk].max()) if okk.any() else None,
+                          "coeff_diff_above_1e-6": int((dco[okk] > 1e-6).sum()),
+                          "note": "one launch of the default path and one of the every-row path against the same snapshot of the committed records: statuses and coefficients"}
         for b in bes:
             b.set_line_cull(0.0)
         dt2, ms2, _ = ctx.run_leg(step, bes, aux_steps, max(args.warmup, 2), graph_ok=H.graph_plain)
@@ -251,9 +265,6 @@ def retimed_legs(ctx, H):
         for b in bes:
             b.enable_timing(False)
         sol2 = np.concatenate([b.solutions() for b in bes])
-        same = sol2["stats"]["status"] == H.sol["stats"]["status"]
-        okk = same & (sol2["stats"]["status"] != 2)
-        dco = np.abs(np.array(sol2["coeff"]) - np.array(H.sol["coeff"])).reshape(len(sol2), -1).max(axis=1)
         legs["full_rows"] = leg_record(
             H, dt2, aux_steps, ms2, cull_radius_m=0.0, qp_kernel=be.qp_kernel_name(),
             kernel_ms={"hull": hull2, "separator": sep2, "qp": qp2, "sequence": seq2},
@@ -261,8 +272,7 @@ def retimed_legs(ctx, H):
             ipm_iters_mean=float(sol2["stats"]["iters"].mean()), ipm_iters_max=int(sol2["stats"]["iters"].max()),
             solve_us=acc.solve_us_stats(be), active_rows=acc.active_summary(be),
             polish_listed_certified_last_step=list(be.polish_count()),
-            vs_default={"status_mismatches": int((~same).sum()), "coeff_diff_max": float(dco[okk].max()) if okk.any() else None,
-                        "note": "the same replans as the headline's last step, solved with every row: statuses and coefficients against the default path's"},
+            vs_default=vs_default,
             note="nep_batch_set_line_cull(0): every separating-line row of every replan through the interior point — the conservative reading "
                  "of the metric that rounds 1-5 quoted as the headline; the default path (verified presolve + polish) returns the same optimum",
             **acc.status_counts(sol2))

@@ -80,6 +80,8 @@ int nep_batch_debug_launch_order(nep_batch_t* h, int32_t* order, int32_t cap, in
  *   "corr_from" / "corr_max"   the short-step give-up rule of the interior point (defaults 10 / 8):
  *                  these two DO change which hard replans are given up on; they exist for that trade's A/B only
  *   "qp_profile"   1: collect the phase counters (PROFILE builds)
+ *   "presolve_kernel"  1 (default): the presolve's zero-iteration certificate runs as a kernel of its own before the interior point
+ *                  (qp_presolve_kernel.hip, one wave per replan) | 0: only inside qp_reg_kernel<true>, as in rounds 3-5
  * Process-wide (launcher choices, results do not depend on them): "fe_three" (keep the three-workgroup front-end instantiation),
  * "fe_xcd" (0: no XCD placement of the searches), "polish_grid" (workgroups of the polish pass, default 256).
  * Unknown names are refused (NEP_E_ARG).                                                                                      */

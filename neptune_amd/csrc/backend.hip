@@ -100,6 +100,7 @@ struct Engine {
   DevBuf<double> d_pb, d_static_xy, d_static_el; DevBuf<int> d_static_nv;
   DevBuf<double> d_hull_xy, d_hull0_xy, d_bend_xy, d_line_nd, d_row_scratch;
   DevBuf<int> d_hull_nv, d_hull0_nv, d_bend_n, d_line_cnt, d_line_far, d_lp_stats;
+  DevBuf<int> d_presolved; bool presolve_kernel = true;      // qp_presolve_kernel's marks (one per slot); debug option "presolve_kernel" = 0: the test runs inside qp_reg_kernel<true> as in rounds 3-5
   DevBuf<int> d_line_skip, d_redo_list, d_redo_count;   // spatial presolve: skipped LPs per segment, replans listed for the redo pass
   DevBuf<double> d_polish_z; DevBuf<int> d_polish_flag, d_polish_list, d_polish_count; bool polish = true, polish_presolve = true, last_polish_armed = false;      // the active-set polish of solves that end without the strict tests (qp_polish_kernel.hip; nep_*_set_polish)
   DevBuf<long long> d_dbg; bool profile_phases = false;
@@ -236,6 +237,7 @@ struct Engine {
     if (int e = d_lp_stats.ensure((size_t)slots * NEP_MAX_POL * 2)) return e;   // per (slot, segment): LPs attempted, LPs without a line
     if (int e = d_line_skip.ensure((size_t)slots * NEP_MAX_POL)) return e;
     if (int e = d_redo_list.ensure((size_t)slots)) return e;
+    if (int e = d_presolved.ensure((size_t)slots)) return e;
     if (!d_redo_count.p) { if (int e = d_redo_count.ensure(4)) return e; HIPCHK(hipMemset(d_redo_count.p, 0, 4 * sizeof(int))); }      // [0] listed replans, [1] parked line violated, [2] moved beyond the radius
     if (!d_flags.p) { if (int e = d_flags.ensure(1)) return e; HIPCHK(hipMemset(d_flags.p, 0, sizeof(int))); }
     if (int e = d_polish_z.ensure((size_t)slots * 2 * 24)) return e;
@@ -264,6 +266,7 @@ struct Engine {
     ps.sep_pack = sep_pack;
     ps.row_scratch = d_row_scratch.p; ps.rows_cap = rows_cap; ps.lds_rows = lds_rows; ps.lds_lines = lds_lines;
     ps.dbg = profile_phases ? d_dbg.p : nullptr;
+    ps.presolved = nullptr;      // (set by run() for a launch sequence in which qp_presolve_kernel goes first)
     ps.flags = d_flags.p;
     ps.fe_box = d_fe_box.p;
     // the polish pass finishes what the register kernel leaves.  Under the presolve only on request (nep_batch_set_polish(h, 2): on the
@@ -398,6 +401,12 @@ struct Engine {
       launch_qp_order(slots, d_order_key.p, d_order.p, st, ps.polish_count);      // (zeroes the polish pass's counters on its way)
       ps.order = d_order.p; last_ordered = true;
     } else if (ps.polish_count && !(use_reg && slots == 1)) launch_qp_polish_zero(ps.polish_count, st);      // (a one-workgroup launch — the per-agent handle — sets the counters itself: qp_reg_kernel's last lines)
+    // the presolve's zero-iteration certificate as a kernel of its own, one wave per replan: the replans it finishes (nine in ten of the
+    // bench's scenes) cost the interior-point launch an immediate return (qp_presolve_kernel.hip)
+    if (use_reg && presolve_kernel && ps.line_far != nullptr && !ps.lines_override && d_presolved.n >= (size_t)slots) {
+      ps.presolved = d_presolved.p;
+      launch_qp_presolve(slots, sp, ps, d_tables.p, sc, d_presolved.p, st);
+    }
     if (use_reg) launch_qp_reg(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     else launch_qp(slots, sp, ps, d_tables.p, sc, lds_bytes, st);
     if (skip && !no_redo) {      // (NEP_SEP_NO_REDO, read in size_scratch: development aid — the flagged replans keep their presolved result for inspection)
@@ -419,7 +428,7 @@ struct Engine {
     d_tables.release(); d_sched_n.release(); d_sched_seg.release(); d_sched_dt.release(); d_pb.release(); d_static_xy.release();
     d_static_nv.release(); d_static_el.release(); d_hull_xy.release(); d_hull0_xy.release(); d_bend_xy.release(); d_line_nd.release(); d_row_scratch.release(); d_order.release(); d_order_key.release(); d_fe_order.release(); d_fe_order_key.release(); d_fe_us.release(); d_fe_box.release();
     d_sampled.release(); d_srep.release(); d_slong.release(); d_present.release(); d_entangles.release(); d_fe_nodes.release(); d_fe_work.release(); d_fe_saved.release(); d_fe_arc.release(); d_fe_packed.release(); d_fe_big.release(); d_fe_big_beta.release(); d_fe_stf.release(); d_fe_stvox.release(); d_fe_xpool.release(); d_fe_big_count.release(); d_fe_big_check.release(); d_fe_big_check_count.release();
-    d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_polish_z.release(); d_polish_flag.release(); d_polish_list.release(); d_polish_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
+    d_presolved.release(); d_line_skip.release(); d_redo_list.release(); d_redo_count.release(); d_polish_z.release(); d_polish_flag.release(); d_polish_list.release(); d_polish_count.release(); d_flags.release(); d_conflict.release(); d_conflict_prev.release(); d_hull_nv.release(); d_hull0_nv.release(); d_bend_n.release(); d_line_cnt.release(); d_line_far.release(); d_lp_stats.release();
     for (auto e : ev) hipEventDestroy(e);
     ev.clear();
   }
@@ -1358,6 +1367,7 @@ static int engine_option(Engine& E, const char* name, int32_t v) {
   else if (n == "corr_from") { if (v < 1) return fail(NEP_E_ARG, "corr_from >= 1"); E.opt_corr_from = v; E.sp.corr_from_it = v; }
   else if (n == "corr_max") { if (v < 1) return fail(NEP_E_ARG, "corr_max >= 1"); E.opt_corr_max = v; E.sp.corr_max_count = v; }
   else if (n == "qp_profile") E.profile_phases = v != 0;
+  else if (n == "presolve_kernel") E.presolve_kernel = v != 0;      // 0: the zero-iteration test only inside qp_reg_kernel<true> (rounds 3-5); same results up to the last place of the objective
   else return fail(NEP_E_ARG, "unknown debug option: " + n);
   return 0;
 }

@@ -105,6 +105,7 @@ struct ProblemSet {
   double* polish_z;              // [slots][2][24] last iterate of the first / relaxed solve (axis stride nz), or null: no polish
   int* polish_flag;              // [slots] bit m: mode m's solve ended on the loose snapshot or gave up
   int* polish_list; int* polish_count;      // [slots] listed slots; counters (see qp_polish_kernel)
+  int* presolved;                // [slots] 1: qp_presolve_kernel finished this replan (its certificate held); the interior-point kernel returns at once.  Null: that kernel did not run
   long long* dbg;                // [slots][16] phase cycle counters (development aid) or null
   int* flags;                    // [1] sticky NEP_FLAG_* bits raised by the kernels (capacity overflows), or null
   double* fe_box;                // [scenes][num_agents + n_static][num_pol][4] (x0, x1, y0, y1) of the front end's obstacles (fe_box_kernel)
@@ -173,6 +174,7 @@ void launch_order_xcd(int n_slots, const int* key, int* order, hipStream_t st); 
 void launch_qp_reg(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables,
                    const SampleSched& sched, size_t lds_bytes, hipStream_t st);
 void launch_qp_polish(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables, const SampleSched& sched, hipStream_t st);
+void launch_qp_presolve(int n_slots, const SceneParams& sp, const ProblemSet& ps, const QpTable* tables, const SampleSched& sched, int* presolved, hipStream_t st);
 int qp_reg_slots();
 size_t qp_reg_lds_bytes();
 // pool of big records (ent_device.h: a search node's entangle state beyond the fixed record's capacities), claimed by atomic

@@ -96,6 +96,10 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   const int tid = threadIdx.x;
   if (ps.order_count && (int)blockIdx.x >= *ps.order_count) return;     // (the presolve's redo pass: a list that is empty nearly always)
   const int slot = ps.order ? ps.order[blockIdx.x] : (int)blockIdx.x;   // (launch order: see order_kernel)
+  if (CULL && ps.presolved && ps.presolved[slot] != 0) {      // qp_presolve_kernel finished this replan (round 6): nothing left to do here
+    if (gridDim.x == 1 && tid == 0 && ps.polish_list) { ps.polish_count[0] = 0; ps.polish_count[3] = 0; }      // (a one-workgroup launch is its own, empty, polish list)
+    return;
+  }
   const long long t_wg0 = (long long)wall_clock64();          // this workgroup's lifetime goes to stats.solve_us (wall-clock ticks: sp.us_per_tick)
   const nep_guess* __restrict__ g = ps.guess + slot;
   const int K_in = g->K;

@@ -74,6 +74,11 @@ def test_the_drivers_command_prints_one_short_parsable_line(tmp_path):
         assert detail.get(leg), leg
     assert detail["value"] == pytest.approx(out["value"], rel=1e-5)
     assert detail["config5"]["chain"]["ent_overflow"] == 0
+    # the headline times the handle's default solve path and says so; the every-row solve of the same replans agrees with it
+    assert "verified line presolve 4 m, polish on" in out["config"]["workload"] and detail["solver"]["line_cull_radius_m"] == 4.0
+    vd = detail["full_rows"]["vs_default"]
+    assert vd["status_mismatches"] == 0 and vd["coeff_diff_max"] <= 1e-6, vd
+    assert out["p50_solve_ms"] == pytest.approx(detail["per_agent_api"]["config4_64_agents_20_obstacles"]["sequence_ms"]["p50"]) and "solve_ms_definition" in detail
 
 
 @pytest.mark.gpu
