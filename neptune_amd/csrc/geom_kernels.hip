@@ -195,9 +195,9 @@ __global__ __launch_bounds__(64) void hull_kernel(const nep_traj_rec* __restrict
 // ---- the batched hulls, eight to a wave -----------------------------------------------------------
 // hull_kernel above spends most of its instructions with two active lanes (the two monotone chains).  Here one wave takes
 // ALL planning intervals of one committed trajectory: interval i is worked by the eight lanes 8 i .. 8 i + 7, each holding up
-// to eight of the interval's (<= 64) inflated control points.  Same algorithm per hull — rank sort, duplicate removal, the
-// two chains with the same cross products in the same order — so the output is the same bits; per wave the chains of eight
-// hulls advance together and the sort's comparisons are spread over all 64 lanes.
+// to eight of the interval's (<= 64) inflated control points.  Same algorithm per hull — lexicographic sort (a bitonic network since
+// round 6), duplicate removal, the two chains with the same cross products in the same order — so the output is the same bits; per
+// wave the chains of eight hulls advance together and the sort's compare-exchanges are spread over all 64 lanes.
 constexpr int kGrpPts = 8;                         // points per lane
 constexpr int kGrpSxy = 2 * 64;                    // doubles per group: the sorted points
 
@@ -207,36 +207,73 @@ constexpr int kGrpSxy = 2 * 64;                    // doubles per group: the sor
 // set bit) instead of two coordinate stacks in LDS: a wave of eight hulls needs 10 KB instead of 27, and three times as many
 // waves fit a CU.  Writes the first min(k, cap) vertices to out_xy (lower chain, then the upper chain without its two end
 // points: the lower chain's ends) and returns k.
-__device__ __forceinline__ int group_hull(int n, const double (&px)[kGrpPts], const double (&py)[kGrpPts], double* sxy, int g, int sub,
-                                          bool write, double* __restrict__ out_xy, int cap) {
-  __syncthreads();
+// Lexicographic sort of the group's points as a bitonic network over 8 lanes x J registers (round 6; until then a rank sort: every
+// point against every point, 64 x 64 lexicographic comparisons per hull — 4 100 of the wave's 6 300 VALU instructions,
+// DESIGN.md section 12 item 2).  Element e = sub * J + r lives in register r of lane sub: compare-exchanges at distances below J are
+// register to register, the others fetch the partner's point from lane sub ^ m (m = 1, 2: DPP quad permutes; m = 4: one
+// ds_bpermute round).  A sort is a sort: the sorted sequence of the (distinct) points is unique, equal points are identical, so
+// what the chains walk is the same array the rank sort produced — the hulls stay bit-identical to the oracle's.  Entries beyond n
+// carry (+inf, +inf) and end up behind the points.
+template <int M> __device__ __forceinline__ double grp_xor(double v) {
+  if constexpr (M == 4) return __shfl_xor(v, 4);
+  else {
+    constexpr int ctrl = M == 1 ? 0xB1 : 0x4E;          // quad_perm [1,0,3,2] / [2,3,0,1]
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), ctrl, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+  }
+}
+template <int J, int K_, int JJ> __device__ __forceinline__ void grp_bitonic_step(double (&kx)[J], double (&ky)[J], int sub) {
+  if constexpr (JJ < J) {            // partner in the same lane: registers r and r ^ JJ
 #pragma unroll
-  for (int j = 0; j < kGrpPts; j++) { const int p = sub + 8 * j; if (p < n) { sxy[2 * p] = px[j]; sxy[2 * p + 1] = py[j]; } }
-  __syncthreads();
-  int rank[kGrpPts];
-#pragma unroll
-  for (int j = 0; j < kGrpPts; j++) rank[j] = 0;
-  // (ties by point index so that the ranks are a permutation: as wave_hull.  The point slots in use are bounded for the whole wave
-  // — a scalar branch per slot — and the comparison is written without short circuits: lane-divergent exits cost more here than
-  // the comparisons they skip)
-  int nmax = 0;
-#pragma unroll
-  for (int gg = 0; gg < 8; gg++) { const int ng = __builtin_amdgcn_readlane(n, 8 * gg); nmax = ng > nmax ? ng : nmax; }
-  const int jmax = (nmax + 7) >> 3;
-  for (int i = 0; i < nmax; i++) {
-    const bool live = i < n;
-    const double qx = live ? sxy[2 * i] : 0.0, qy = live ? sxy[2 * i + 1] : 0.0;
-#pragma unroll
-    for (int j = 0; j < kGrpPts; j++) {
-      if (j < jmax) {
-        const bool lt = (qx < px[j]) | ((qx == px[j]) & ((qy < py[j]) | ((qy == py[j]) & (i < sub + 8 * j))));
-        rank[j] += (live & lt) ? 1 : 0;
+    for (int r = 0; r < J; r++) {
+      const int l = r ^ JJ;
+      if (l > r) {
+        const bool asc = ((sub * J + r) & K_) == 0;
+        const bool l_lt_r = (kx[l] < kx[r]) | ((kx[l] == kx[r]) & (ky[l] < ky[r]));
+        const bool r_lt_l = (kx[r] < kx[l]) | ((kx[r] == kx[l]) & (ky[r] < ky[l]));
+        const bool sw = asc ? l_lt_r : r_lt_l;
+        const double tx = kx[r], ty = ky[r];
+        kx[r] = sw ? kx[l] : tx; ky[r] = sw ? ky[l] : ty;
+        kx[l] = sw ? tx : kx[l]; ky[l] = sw ? ty : ky[l];
       }
     }
-  }
-  __syncthreads();
+  } else {                           // partner in lane sub ^ (JJ / J): I keep the smaller point when I am the pair's lower index in an ascending run (or the upper one in a descending run)
+    constexpr int M = JJ / J;
+    const bool asc = ((sub * J) & K_) == 0, lower = (sub & M) == 0;
+    const bool want_min = lower == asc;
 #pragma unroll
-  for (int j = 0; j < kGrpPts; j++) { if (sub + 8 * j < n) { sxy[2 * rank[j]] = px[j]; sxy[2 * rank[j] + 1] = py[j]; } }
+    for (int r = 0; r < J; r++) {
+      const double ox = grp_xor<M>(kx[r]), oy = grp_xor<M>(ky[r]);
+      const bool o_lt = (ox < kx[r]) | ((ox == kx[r]) & (oy < ky[r]));
+      const bool m_lt = (kx[r] < ox) | ((kx[r] == ox) & (ky[r] < oy));
+      const bool take = want_min ? o_lt : m_lt;
+      kx[r] = take ? ox : kx[r]; ky[r] = take ? oy : ky[r];
+    }
+  }
+}
+template <int J, int K_, int JJ> __device__ __forceinline__ void grp_bitonic_merge(double (&kx)[J], double (&ky)[J], int sub) {
+  grp_bitonic_step<J, K_, JJ>(kx, ky, sub);
+  if constexpr (JJ > 1) grp_bitonic_merge<J, K_, JJ / 2>(kx, ky, sub);
+}
+template <int J, int K_> __device__ __forceinline__ void grp_bitonic(double (&kx)[J], double (&ky)[J], int sub) {
+  if constexpr (K_ > 2) grp_bitonic<J, K_ / 2>(kx, ky, sub);
+  grp_bitonic_merge<J, K_, K_ / 2>(kx, ky, sub);
+}
+
+template <int J>
+__device__ __forceinline__ int group_hull(int n, const double (&px)[J], const double (&py)[J], double* sxy, int g, int sub,
+                                          bool write, double* __restrict__ out_xy, int cap) {
+  constexpr int kGrpPts = J;          // (points per lane in this instantiation: 8 for the inflated hull's <= 64 points, 2 for the <= 16 control points)
+  __syncthreads();
+  {
+    double kx[J], ky[J];
+#pragma unroll
+    for (int j = 0; j < J; j++) { const bool in = sub + 8 * j < n; kx[j] = in ? px[j] : NEP_INF; ky[j] = in ? py[j] : NEP_INF; }
+    grp_bitonic<J, 8 * J>(kx, ky, sub);
+#pragma unroll
+    for (int r = 0; r < J; r++) { const int e = sub * J + r; if (e < n) { sxy[2 * e] = kx[r]; sxy[2 * e + 1] = ky[r]; } }
+  }
   __syncthreads();
   // unique: sorted position p survives if it differs from its predecessor; new position = number of survivors before it
   double ux[kGrpPts], uy[kGrpPts]; int pos[kGrpPts]; bool keep[kGrpPts];
@@ -375,13 +412,14 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
       } else { px[j] = cpx[p]; py[j] = cpy[p]; }
     }
   }
-  int k = group_hull(np, px, py, s_sxy[g], g, sub, act, hull_xy + out * kHullV * 2, kHullV);
+  int k = group_hull<kGrpPts>(np, px, py, s_sxy[g], g, sub, act, hull_xy + out * kHullV * 2, kHullV);
   if (k > kHullV) { k = kHullV; if (act && sub == 0 && flags) atomicOr(flags, NEP_FLAG_HULL_OVERFLOW); }
   if (act && sub == 0) hull_nv[out] = k;
   if (hull0_nv) {
+    double qx[2], qy[2];              // (<= 16 control points: two per lane)
 #pragma unroll
-    for (int j = 0; j < kGrpPts; j++) { const int p = sub + 8 * j; px[j] = p < np0 ? cpx[p] : 0; py[j] = p < np0 ? cpy[p] : 0; }
-    int k0 = group_hull(np0, px, py, s_sxy[g], g, sub, act, hull0_xy + out * 2, 1);      // only col(0) is read (:722-734)
+    for (int j = 0; j < 2; j++) { const int p = sub + 8 * j; qx[j] = p < np0 ? cpx[p] : 0; qy[j] = p < np0 ? cpy[p] : 0; }
+    int k0 = group_hull<2>(np0, qx, qy, s_sxy[g], g, sub, act, hull0_xy + out * 2, 1);      // only col(0) is read (:722-734)
     if (k0 > kHullV) k0 = kHullV;
     if (act && sub == 0) hull0_nv[out] = k0;
   }

@@ -42,6 +42,12 @@ struct QpTable {
   double Th[4 * kMaxK][kNZ]; // coefficient recovery: theta[4i+j] = Th.z + ThU.init
   double ThU[4 * kMaxK][3];
   double Hax[kNZ][kNZ];      // per-axis Hessian of the cost in z
+  // (round 6, qp_presolve_kernel) the minimiser of the cost without inequality rows is LINEAR in v = (b0, c0, d0, f) of an axis —
+  // z* = -HaxInv (Gi init - 2 w ep f) — and so is everything evaluated there: base row rho = RowMap[rho] . v, coefficient r = ThMap[r] . v,
+  // cost of the axis = v' ObjQ v.  One 32-byte table row per lane instead of the chain g -> z* -> B z* + U init.
+  double RowMap[kMaxR][4];
+  double ThMap[4 * kMaxK][4];
+  double ObjQ[4][4];
   double Gi[kNZ][3];         // gradient map of the init state; g = Gi.init - 2 w ep f
   double ep[kNZ], ev[kNZ], ea[kNZ]; // end position / velocity / acceleration maps (z part)
   double up[3], uv[3], ua[3];       // (init part)
@@ -203,6 +209,25 @@ inline void build_qp_table(int K, double T, double weight, int mode, QpTable* t)
       for (int r = 0; r < nz; r++) if (r != c) { const double f = G[r][c]; if (f != 0.0) for (int j = 0; j < 2 * nz; j++) G[r][j] -= f * G[c][j]; }
     }
     for (int a = 0; a < nz; a++) for (int b = 0; b < nz; b++) t->HaxInv[a][b] = G[a][nz + b];
+  }
+  // the unconstrained minimiser as a linear map of v = (b0, c0, d0, f): z* = Zm v (see RowMap / ThMap / ObjQ)
+  {
+    double Zm[kNZ][4] = {{0}}, Gm[kNZ][4] = {{0}};
+    for (int c = 0; c < nz; c++) {
+      for (int u = 0; u < 3; u++) Gm[c][u] = t->Gi[c][u];
+      Gm[c][3] = -2 * weight * t->ep[c];
+    }
+    for (int c = 0; c < nz; c++) for (int m = 0; m < 4; m++) { double v = 0; for (int e = 0; e < nz; e++) v -= t->HaxInv[c][e] * Gm[e][m]; Zm[c][m] = v; }
+    for (int rho = 0; rho < 8 * K; rho++) for (int m = 0; m < 4; m++) { double v = m < 3 ? t->U[rho][m] : 0.0; for (int c = 0; c < nz; c++) v += t->B[rho][c] * Zm[c][m]; t->RowMap[rho][m] = v; }
+    for (int r = 0; r < 4 * K; r++) for (int m = 0; m < 4; m++) { double v = m < 3 ? t->ThU[r][m] : 0.0; for (int c = 0; c < nz; c++) v += t->Th[r][c] * Zm[c][m]; t->ThMap[r][m] = v; }
+    // cost of an axis at z*: sum_r 36 T (Pp_r . init)^2 + w (up . init - f)^2 + z*'(0.5 Hax z* + g), g = Gm v   (the first problem's cost, :322-383)
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) {
+      double q = 0;
+      for (int r = 0; r < K; r++) q += 36 * T * (a < 3 ? Pp[r * 3 + a] : 0.0) * (b < 3 ? Pp[r * 3 + b] : 0.0);
+      q += weight * (a < 3 ? t->up[a] : -1.0) * (b < 3 ? t->up[b] : -1.0);
+      for (int c = 0; c < nz; c++) { double hz = 0; for (int e = 0; e < nz; e++) hz += t->Hax[c][e] * Zm[e][b]; q += Zm[c][a] * (0.5 * hz + Gm[c][b]); }
+      t->ObjQ[a][b] = q;
+    }
   }
 }
 

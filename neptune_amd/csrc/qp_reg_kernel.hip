@@ -96,8 +96,47 @@ __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams 
   const int tid = threadIdx.x;
   if (ps.order_count && (int)blockIdx.x >= *ps.order_count) return;     // (the presolve's redo pass: a list that is empty nearly always)
   const int slot = ps.order ? ps.order[blockIdx.x] : (int)blockIdx.x;   // (launch order: see order_kernel)
-  if (CULL && ps.presolved && ps.presolved[slot] != 0) {      // qp_presolve_kernel finished this replan (round 6): nothing left to do here
+  if (CULL && ps.presolved && ps.presolved[slot] != 0) {
+    // qp_presolve_kernel certified and returned this replan's trajectory (round 6): what is left are the stores that depend on nothing
+    // but the coefficients — generatePwpOut's samples (:911-934) and the record the agent publishes (neptune_ros.cpp:434-480) — written
+    // here, beside the iterating replans' workgroups, and not by the wave that made the certificate
     if (gridDim.x == 1 && tid == 0 && ps.polish_list) { ps.polish_count[0] = 0; ps.polish_count[3] = 0; }      // (a one-workgroup launch is its own, empty, polish list)
+    const nep_solution* __restrict__ so = ps.solution + slot;
+    const int Kp = so->K;
+    double* sTh = smem;                                       // [3][8][4]
+    if (tid < 96) sTh[tid] = (&so->coeff[0][0][0])[tid];
+    __syncthreads();
+    if (ps.states) {
+      const int ns_all = sched.n[Kp];
+      const int ns = ns_all < sp.max_states ? ns_all : sp.max_states;
+      for (int s = tid; s < ns; s += BS) {
+        const int i = sched.seg[Kp * sp.max_states + s]; const double dt = sched.dt[Kp * sp.max_states + s];
+        double* st = ps.states + ((long)slot * sp.max_states + s) * NEP_STATE_DOUBLES;
+        for (int ax = 0; ax < 3; ax++) {
+          const double* c = sTh + (ax * 8 + i) * 4;
+          st[ax] = ((c[0] * (dt * dt * dt) + c[1] * (dt * dt)) + c[2] * dt) + c[3];
+          st[3 + ax] = (c[0] * (3 * dt * dt) + c[1] * (2 * dt)) + c[2];
+          st[6 + ax] = c[0] * (6 * dt) + c[1] * 2;
+          st[9 + ax] = c[0] * 6;
+        }
+      }
+    }
+    if (ps.commit) {
+      nep_traj_rec* cr = ps.commit + slot;
+      const int own = sp.first_local + (slot % sp.n_local);
+      const double t_start = ps.guess[slot].t_start, Tp = sp.T_span;
+      if (tid == 0) {
+        cr->id = own + 1; cr->is_agent = 1; cr->n_bend = 1; cr->valid = 1;
+        for (int a = 0; a < 3; a++) { cr->bbox[a] = 2 * sp.drone_radius; cr->pos[a] = sTh[(a * 8) * 4 + 3]; }
+        cr->bend[0][0] = ps.pb[2 * own]; cr->bend[0][1] = ps.pb[2 * own + 1];
+        cr->pwp.n_seg = Kp;
+      }
+      if (tid <= NEP_TRAJ_MAX_SEG) cr->pwp.times[tid] = (tid <= Kp) ? t_start + tid * Tp : 0.0;
+      for (int e = tid; e < 3 * NEP_TRAJ_MAX_SEG * 4; e += BS) {
+        const int ax = e / (NEP_TRAJ_MAX_SEG * 4), r = e % (NEP_TRAJ_MAX_SEG * 4), seg = r / 4, j = r % 4;
+        (&cr->pwp.coeff[0][0][0])[e] = (seg < Kp) ? sTh[(ax * 8 + seg) * 4 + j] : 0.0;
+      }
+    }
     return;
   }
   const long long t_wg0 = (long long)wall_clock64();          // this workgroup's lifetime goes to stats.solve_us (wall-clock ticks: sp.us_per_tick)
