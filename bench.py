@@ -48,6 +48,12 @@ def parse_args(argv=None):
     ap.add_argument("--exchange", choices=["hulls", "records"], default="hulls",
                     help="N > 1: all-gather the interval hulls of the local agents' committed trajectories (hull work "
                          "sharded with the agents) or the trajectory records themselves (every rank rebuilds all hulls)")
+    ap.add_argument("--groups", type=int, default=1,
+                    help="one GPU: run the scenes in flight as this many groups, each a launch sequence on its own HIP stream inside the one captured "
+                         "graph per step (the scenes are independent fleets).  Default 1 = one launch sequence on one stream; measured in round 6 "
+                         "(same box, 50 steps): 1 group 16.65 M replans/s, 2 groups 17.00 M, 4 groups 11.5 M, 8 groups 8.5 M — every group's "
+                         "interior-point launch keeps its own tail of long solves, so the overlap buys 2 % at best; with G > 1 the one-sequence "
+                         "step is reported as `one_stream`")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1 with --exchange hulls: scene chunks pipelined so that one chunk's all-gather overlaps the other's kernels")
     ap.add_argument("--presolve-radius", type=float, default=4.0, help="(older command lines; the presolve is the handle's default since round 6: ignored)")
@@ -120,8 +126,11 @@ def run_config4(ctx):
     H = headline.setup(ctx, pool)
     headline.run(ctx, H)
     legs = headline.retimed_legs(ctx, H)
-    if extra and not args.no_chain and H.C == 1:
-        legs["chain"], legs["moving"], legs["crossing"] = chain_legs.run(ctx, H)
+    Hc = headline.full_handle_view(ctx, H) if (extra and (H.C == 1 or H.G > 1)) else None
+    if Hc is not None and H.G > 1:
+        legs["one_stream"] = headline.one_stream_leg(ctx, H, Hc)
+    if Hc is not None and not args.no_chain:
+        legs["chain"], legs["moving"], legs["crossing"] = chain_legs.run(ctx, Hc)
     if extra:
         legs["single_scene"] = small.single_scene(ctx, H)
         if rank == 0:
@@ -134,7 +143,8 @@ def run_config4(ctx):
         return None
     out = headline.record(ctx, H)
     mv, cr = legs.get("moving"), legs.get("crossing")
-    out["what_value_is"] = ("throughput of %d INDEPENDENT scenes in flight on the handle's default solve path (verified line presolve + polish; full_rows has every row "
+    out["what_value_is"] = (("%d scene groups on %d HIP streams inside one captured graph per step (one_stream: the same step as one launch sequence); " % (H.G, H.G) if H.G > 1 else "") +
+                            "throughput of %d INDEPENDENT scenes in flight on the handle's default solve path (verified line presolve + polish; full_rows has every row "
                             "through the interior point), QP workgroups ordered by the previous step's measured times (exact here: the same problems every step).  The representative figures are the closed-loop legs, "
                             "where every step poses new problems from device-made guesses: moving %s replans/s, crossing (the whole fleet through the middle) %s "
                             "replans/s — see also launch_order_off, single_scene, active_rows"

@@ -27,7 +27,7 @@ def compact_line(d, detail_path="bench_detail.json"):
     """d: the detail record of rank 0 -> dict for the last stdout line"""
     out = _pick(d, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"), 6)
     cfg = d.get("config", {})
-    out["config"] = {"workload": _short(cfg.get("workload", ""), 240), **_pick(cfg, ("agents", "obstacles", "scenes_per_gpu", "scenes_in_flight", "replans_per_step", "replans_per_gpu_per_step")),
+    out["config"] = {"workload": _short(cfg.get("workload", ""), 240), **_pick(cfg, ("agents", "obstacles", "scenes_per_gpu", "scenes_in_flight", "scene_groups", "replans_per_step", "replans_per_gpu_per_step")),
                      "sharding": _short(cfg.get("sharding", ""), 200)}
     out.update(_pick(d, ("p50_solve_ms", "p99_solve_ms", "per_gpu_value")))
     out["kernel_ms"] = _pick(d.get("kernel_ms", {}), ("hull", "separator", "qp", "sequence", "exchange_wait"))
@@ -59,7 +59,7 @@ def compact_line(d, detail_path="bench_detail.json"):
         out["scene_digest"] = d["scene_digest"][:4]
     # scalar highlights of the other legs (replans/s unless named otherwise)
     hl = {}
-    for name in ("long_run", "full_rows", "chain", "moving", "crossing", "single_scene"):
+    for name in ("long_run", "one_stream", "full_rows", "chain", "moving", "crossing", "single_scene"):
         leg = d.get(name)
         if leg:
             hl[name] = _r(leg["value"], 5)

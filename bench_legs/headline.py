@@ -44,6 +44,13 @@ def setup(ctx, c5=None):
     sharded_hulls = world > 1 and args.exchange == "hulls"
     native = sharded_hulls and not args.exchange_torch and not args.safety and ctx.dist_backend == "nccl"
     C = args.chunks if (sharded_hulls and not args.safety and S % max(args.chunks, 1) == 0) else 1
+    # One GPU: the scenes in flight are INDEPENDENT fleets, so a step may run them as G groups, each a launch sequence of its own on its
+    # own HIP stream inside the one captured graph (--groups; north star: "agents shard one-per-stream").  A group's interior-point launch
+    # ends with a handful of long solves on an otherwise idle chip, its separator and presolve kernels wait on memory: another group's
+    # kernels fill those gaps.  Same kernels, same results per scene; `one_stream` re-times the step as ONE sequence.
+    G = args.groups if (world == 1 and not args.frontend and not args.safety and not sharded_hulls and args.groups > 1 and S % args.groups == 0 and not args.no_graph) else 1
+    if G > 1:
+        C = G
     Sc = S // C
     # one handle per scene chunk (C == 1: all scenes); chunk k holds scenes [k*Sc, (k+1)*Sc)
     bes = [BatchBackend(p, statics, first_local=first_local, n_local=n_local, n_scenes=Sc, device=dev) for _ in range(C)]
@@ -59,6 +66,12 @@ def setup(ctx, c5=None):
     d_guess_c = [bes[k].to_device(np.ascontiguousarray(gue[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)]
     d_guess = d_guess_c[0]
     ex = ndist.RoundExchange(S, N, world, rank, device=dev)
+    # scene groups on streams (G > 1): every group has its records, its exchange (a copy at one rank) and its stream
+    d_com_g = [bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc])) for k in range(C)] if G > 1 else None
+    ex_g = [ndist.RoundExchange(Sc, N, world, rank, device=dev) for _ in range(C)] if G > 1 else None
+    g_streams = [torch.cuda.Stream(device=dev) for _ in range(C)] if G > 1 else None
+    if G > 1:
+        d_committed = d_com_g[0]; ex = ex_g[0]          # (group 0's: what the one-rank RCCL check and the same-replans comparison use)
     hxs = [ndist.HullExchange(bes[k].hull_block_bytes(), world, rank, device=dev) for k in range(C)] if (sharded_hulls and args.safety) else None
     d_local_c = [bes[k].to_device(np.ascontiguousarray(com[k * Sc:(k + 1) * Sc, first_local:first_local + n_local])) for k in range(C)] if sharded_hulls else None
     d_committed_next = torch.empty_like(d_committed) if args.safety else None
@@ -102,7 +115,20 @@ def setup(ctx, c5=None):
         hull_ev.append((e0, ctx.ev()))
         pending[k] = hxs[k].gather_async()
 
+    def step_groups():
+        cur = torch.cuda.current_stream(dev)
+        for k in range(C):
+            g_streams[k].wait_stream(cur)
+            with torch.cuda.stream(g_streams[k]):
+                bes[k].replan(d_com_g[k], d_guess_c[k])
+                ex_g[k].gather(bes[k].d_commit, d_com_g[k])
+        for k in range(C):
+            cur.wait_stream(g_streams[k])
+
     def step():
+        if G > 1:
+            step_groups()
+            return
         if rounds is not None:
             rounds.step()          # chunks pipelined: one chunk's all-gather runs under another chunk's kernels (dist.ShardedRounds)
             return
@@ -139,8 +165,43 @@ def setup(ctx, c5=None):
                       all_statics=all_statics, statics=statics, com=com, gue=gue, sharded_hulls=sharded_hulls, native=native,
                       bes=bes, be=be, d_committed=d_committed, d_guess=d_guess, ex=ex, rounds=rounds, nranks=nranks, step=step,
                       safety_ev=safety_ev, hull_ev=hull_ev, gather_ev=gather_ev, fe_ev=fe_ev, d_fe_res=d_fe_res, d_accept=d_accept,
-                      graph_plain=can_graph and not args.frontend and not args.safety, replans_per_step=S * N, rccl_one_rank_ok=None)
+                      graph_plain=can_graph and not args.frontend and not args.safety, replans_per_step=S * N, rccl_one_rank_ok=None,
+                      G=G, d_com_g=d_com_g, d_guess_c=d_guess_c)
     return H
+
+
+def full_handle_view(ctx, H):
+    """the legs that need ONE handle over all S scenes (chain, moving, crossing, one_stream): H itself when the headline runs as one launch
+    sequence, else a copy of H whose `be` is a handle of all S scenes (the headline's group handles hold S / G scenes each)"""
+    if H.G == 1:
+        return H
+    from neptune_amd.backend import BatchBackend
+    be_full = BatchBackend(H.p, H.statics, first_local=H.first_local, n_local=H.n_local, n_scenes=H.S, device=ctx.dev)
+    for s_ in range(H.S):
+        be_full.set_scene_statics(s_, H.all_statics[s_])
+    Hc = SimpleNamespace(**H.__dict__)
+    Hc.be, Hc.bes, Hc.C, Hc.Sc, Hc.G = be_full, [be_full], 1, H.S, 1
+    Hc.d_guess = be_full.to_device(np.ascontiguousarray(H.gue[:, H.first_local:H.first_local + H.n_local]))
+    Hc.d_committed = be_full.to_device(H.com)
+    return Hc
+
+
+def one_stream_leg(ctx, H, Hc):
+    """G > 1 only: the headline's step as ONE launch sequence of all S scenes on one stream (rounds 1-5's shape of the step)"""
+    from neptune_amd import dist as ndist
+    be = Hc.be
+    ex = ndist.RoundExchange(H.S, H.N, ctx.world, ctx.rank, device=ctx.dev)
+
+    def step1():
+        be.replan(Hc.d_committed, Hc.d_guess)
+        ex.gather(be.d_commit, Hc.d_committed)
+    dt, ms, _ = ctx.run_leg(step1, [be], ctx.aux_steps, max(ctx.args.warmup, 2), graph_ok=True, eager_after=10)
+    k_ = {n_: be.kernel_time_ms(i_)[0] for i_, n_ in ((0, "hull"), (1, "separator"), (2, "qp"), (3, "sequence"))}
+    be.enable_timing(False)
+    sol = be.solutions()
+    return leg_record(H, dt, ctx.aux_steps, ms, kernel_ms=k_, ipm_iters_mean=float(sol["stats"]["iters"].mean()),
+                      note="the same step as ONE launch sequence of all %d scenes on one stream (the headline runs it as %d groups of %d scenes on %d streams inside "
+                           "one captured graph): what the groups' overlap is worth" % (H.S, H.G, H.Sc, H.G), **acc.status_counts(sol))
 
 
 def native_nranks(ctx, rounds):
@@ -175,7 +236,7 @@ def run(ctx, H):
     be, bes = H.be, H.bes
     for _ in range(max(args.warmup - H.steps_made, 0)):
         H.step()
-    if ctx.world == 1 and ctx.use_dist and ctx.dist_backend == "nccl" and not (args.safety or args.frontend) and H.C == 1:
+    if ctx.world == 1 and ctx.use_dist and ctx.dist_backend == "nccl" and not (args.safety or args.frontend) and (H.C == 1 or H.G > 1):
         # one rank: the timed steps copy (nothing to exchange); the collective path itself — the all-gather of the committed
         # records through RCCL — is exercised once here, outside the timed region, and must give the same bytes
         chk = torch.empty_like(H.d_committed)
@@ -198,7 +259,7 @@ def run(ctx, H):
     for b in bes:
         b.enable_timing(False)
     H.sol = np.concatenate([b.solutions() for b in bes])
-    H.active = acc.active_summary(be) if H.C == 1 else None          # (chunk 0's handle when the scenes are chunked: see sharding)
+    H.active = acc.active_summary(be) if (H.C == 1 or H.G > 1) else None          # (group 0's handle when the scenes run as groups)
     H.solve_us = acc.solve_us_stats(be)
     H.n_states = int(H.sol[0]["n_states"])
     H.value = H.replans_per_step * args.steps / dt
@@ -247,7 +308,7 @@ def retimed_legs(ctx, H):
         # the SAME replans on both paths (a leg's steps feed each other — every step's new trajectories are the next step's obstacles — so
         # the last steps of two legs are not the same problems): one launch of each path against one snapshot of the committed records
         vs_default = None
-        if H.C == 1 and not H.sharded_hulls and H.d_committed is not None and not args.frontend and not args.safety:
+        if (H.C == 1 or H.G > 1) and not H.sharded_hulls and H.d_committed is not None and not args.frontend and not args.safety:
             snap = H.d_committed.clone()
             be.replan(snap, H.d_guess); sol_a = be.solutions().copy()
             be.set_line_cull(0.0)
@@ -348,6 +409,8 @@ def record(ctx, H):
         fp64["executed_source"] = ex_f["source"]
     if world == 1:
         sharding = "one GPU: all %d agents of every scene" % N
+        if H.G > 1:
+            sharding += "; the %d scenes in flight run as %d groups of %d scenes, each group a launch sequence on its own HIP stream, all inside one captured graph per step" % (S, H.G, Sc)
     elif H.sharded_hulls:
         sharding = ("agents of every scene block-sharded by id, %d per GPU; per step and scene chunk (%d chunks, pipelined) one all-gather "
                     "(RCCL, %s) of the interval hulls of the local agents' committed trajectories (%d B per agent and scene)"
@@ -362,11 +425,12 @@ def record(ctx, H):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "%d agents + %d static obstacles, K=8, %d seeded scenes in flight per GPU per step (seeds 0..%d over %d GPU%s); %s"
                                % (N, M, args.scenes, S - 1, world, "" if world == 1 else "s",
-                                  ("the handle's default solve path: verified line presolve %g m, polish on" % cull_m) if cull_m > 0.0 else
-                                  "line presolve off: every separating-line row through the interior point, polish on"),
+                                  (("the handle's default solve path: verified line presolve %g m, polish on" % cull_m) if cull_m > 0.0 else
+                                   "line presolve off: every separating-line row through the interior point, polish on")
+                                  + ("; %d scene groups on %d HIP streams" % (H.G, H.G) if H.G > 1 else "")),
                    "agents": N, "obstacles": M, "scenes_in_flight": S, "scenes_per_gpu": args.scenes,
                    "replans_per_step": H.replans_per_step, "replans_per_gpu_per_step": S * n_local,
-                   "sharding": sharding,
+                   "sharding": sharding, "scene_groups": H.G,
                    "params": "reference neptune_mtlp_benchmark.yaml (T_span 0.5, num_pol 8, weight 1000, v 2, a 3)"},
         "solver": {"status_ok": int((status == 0).sum()), "status_relaxed": int((status == 1).sum()),
                    "status_failed": int((status == 2).sum()), "ipm_iters_mean": float(iters.mean()),
