@@ -35,14 +35,18 @@ def pmc_means(kernel, name="pmc_summary_latest.txt"):
     path = os.path.join(ROOT, "profiles", name)
     if not os.path.exists(path):
         return {}
-    cur, vals = None, {}
+    # (several instantiations of one template may be in the file — the presolve's redo pass launches qp_reg_kernel<false> over an empty
+    # list next to the step's qp_reg_kernel<true>: the block with the most wave cycles is the kernel that did the work)
+    cur, blocks = None, {}
     for line in open(path):
         if line.startswith("nep::"):
             cur = line.strip()
         elif cur is not None and cur.split("<")[0] == kernel and "mean" in line:
             parts = line.split()
-            vals[parts[0]] = float(parts[2])
-    return vals
+            blocks.setdefault(cur, {})[parts[0]] = float(parts[2])
+    if not blocks:
+        return {}
+    return max(blocks.values(), key=lambda v: v.get("SQ_WAVE_CYCLES", v.get("SQ_BUSY_CYCLES", 0.0)))
 
 
 def measured_traffic(kernel, name="pmc_summary_latest.txt"):
