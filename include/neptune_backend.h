@@ -278,6 +278,18 @@ int nep_batch_set_scene_statics(nep_batch_t* h, int32_t scene, int32_t n_static,
 int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess,
                      const void* d_ent, nep_solution* d_solution, double* d_states,
                      nep_traj_rec* d_commit, void* stream);
+/* The same round as two enqueues, so that a host with several scene groups in flight (one handle per group) can put the
+ * halves on different streams: nep_batch_replan_lines = interval hulls + separating-line LPs into the handle's scratch
+ * (the chip-filling, VALU-bound half), nep_batch_replan_solve = the QPs on those lines + sampled states + commit records (a few
+ * long solves on a mostly idle chip at its end: another group's _lines fits under it).  _lines then _solve with the same
+ * arguments == nep_batch_replan, bit for bit; the caller orders the two (same stream, or an event), keeps d_committed /
+ * d_guess / d_ent unchanged in between, and does not start the handle's next _lines before its _solve has completed.
+ * bench.py's headline runs its scene groups this way.                                            */
+int nep_batch_replan_lines(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess,
+                           const void* d_ent, void* stream);
+int nep_batch_replan_solve(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess,
+                           const void* d_ent, nep_solution* d_solution, double* d_states,
+                           nep_traj_rec* d_commit, void* stream);
 
 /* Sharded hulls for multi-GPU rounds.  Instead of every rank rebuilding the hulls of all N
  * committed trajectories, a rank computes the interval hulls of ITS n_local agents (every scene)

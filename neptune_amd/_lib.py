@@ -16,7 +16,7 @@ EXPORTS = [
     "nep_backend_set_hulls", "nep_backend_set_hulls_no_inflation", "nep_backend_set_ent_state_vector",
     "nep_backend_optimize", "nep_backend_generate_pwp_out", "nep_backend_get_stats", "nep_inflate_static",
     "nep_separator_batch", "nep_separator_batch_rule", "nep_gjk_batch", "nep_hulls_batch", "nep_batch_create",
-    "nep_batch_destroy", "nep_batch_set_scene_statics", "nep_batch_replan", "nep_batch_hull_block_bytes",
+    "nep_batch_destroy", "nep_batch_set_scene_statics", "nep_batch_replan", "nep_batch_replan_lines", "nep_batch_replan_solve", "nep_batch_hull_block_bytes",
     "nep_batch_set_ent_samples", "nep_batch_hulls", "nep_batch_replan_hulls", "nep_comm_unique_id",
     "nep_comm_create", "nep_comm_destroy", "nep_comm_nranks", "nep_batch_exchange_hulls",
     "nep_batch_exchange_records", "nep_batch_exchange_slots", "nep_comm_reserve", "nep_batch_ent_bytes",
@@ -102,6 +102,8 @@ def lib():
     L.nep_batch_create.argtypes = [C.POINTER(abi.nep_batch_cfg)]; L.nep_batch_create.restype = vp
     L.nep_batch_destroy.argtypes = [vp]; L.nep_batch_destroy.restype = None
     L.nep_batch_replan.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.nep_batch_replan_lines.argtypes = [vp, vp, vp, vp, vp]
+    L.nep_batch_replan_solve.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.nep_batch_ent_bytes.argtypes = [vp]; L.nep_batch_ent_bytes.restype = C.c_int64
     L.nep_batch_wait.argtypes = [vp, vp]
     L.nep_batch_kernel_time.argtypes = [vp, i, pd, pi]

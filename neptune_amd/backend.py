@@ -272,6 +272,20 @@ class BatchBackend:
                                      self.d_solution.data_ptr(), self.d_states.data_ptr(),
                                      self.d_commit.data_ptr() if want_commit else None, st.cuda_stream))
 
+    def replan_lines(self, d_committed, d_guess, d_ent=None, stream=None):
+        """first half of replan(): interval hulls + separating lines into the handle's scratch (nep_batch_replan_lines)"""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_replan_lines(self._h, d_committed.data_ptr(), d_guess.data_ptr(),
+                                           d_ent.data_ptr() if d_ent is not None else None, st.cuda_stream))
+
+    def replan_solve(self, d_committed, d_guess, d_ent=None, stream=None, want_commit=True):
+        """second half of replan(): the QPs on the lines replan_lines left (nep_batch_replan_solve)"""
+        st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+        check(lib().nep_batch_replan_solve(self._h, d_committed.data_ptr(), d_guess.data_ptr(),
+                                           d_ent.data_ptr() if d_ent is not None else None,
+                                           self.d_solution.data_ptr(), self.d_states.data_ptr(),
+                                           self.d_commit.data_ptr() if want_commit else None, st.cuda_stream))
+
     # ---- sharded hulls (multi-GPU rounds): hulls of the local agents -> all-gather -> replan -------
     def hull_block_bytes(self):
         return int(lib().nep_batch_hull_block_bytes(self._h))

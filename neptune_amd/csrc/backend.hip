@@ -376,11 +376,14 @@ struct Engine {
     return ev[ev_used++];
   }
   // separator + QP (+ hulls when recs != nullptr) on `st`
-  int run(const nep_traj_rec* d_recs, int n_rec, ProblemSet& ps, hipStream_t st) {
+  // phases: 1 = the geometry half (hulls, boxes, separating lines into the handle's scratch), 2 = the QP half on the lines that are there,
+  // 3 = both (nep_batch_replan); the halves of one round may be enqueued on different streams, ordered by the caller (nep_batch_replan_lines)
+  int run(const nep_traj_rec* d_recs, int n_rec, ProblemSet& ps, hipStream_t st, int phases = 3) {
     const int slots = n_scenes * sp.n_local;
     SampleSched sc{d_sched_n.p, d_sched_seg.p, d_sched_dt.p};
+    const bool geo = (phases & 1) != 0, qp = (phases & 2) != 0;
     if (timing) hipEventRecord(next_event(), st);
-    if (d_recs) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st);
+    if (d_recs && geo) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st);
     if (timing) hipEventRecord(next_event(), st);
     if (ps.lines_override) { ps.skip_box = nullptr; ps.line_skip = nullptr; ps.redo_list = nullptr; ps.redo_count = nullptr; }
     if (scratch_chunks > 0 && ps.scratch_chunks == 0) {      // (a pooled handle asked for a replan without the redo pass — lines from the host, a rule or hull layout that cannot skip LPs: one area per slot after all)
@@ -390,11 +393,12 @@ struct Engine {
       ps.row_scratch = d_row_scratch.p;
     }
     const bool skip = ps.skip_box != nullptr;
-    if (!ps.lines_override) {
+    if (!ps.lines_override && geo) {
       if (skip) launch_boxes(n_scenes, sp, ps, st);      // (zeroes the redo counters as well)
       launch_separator(slots, sp, ps, st);
     }
     if (timing) hipEventRecord(next_event(), st);
+    if (!qp) { if (timing) hipEventRecord(next_event(), st); HIPCHK(hipGetLastError()); return 0; }
     ps.order = nullptr; last_ordered = false;
     ps.order_key = (lpt && d_order_key.n >= (size_t)slots) ? d_order_key.p : nullptr;
     if (ps.order_key && have_history && slots > 1024 && d_order.n >= (size_t)slots) {   // (more than one wave of workgroups)
@@ -962,6 +966,30 @@ int nep_batch_replan(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_
   ps.lines_override = 0;
   // d_committed == NULL: the interval hulls of this round are already in the handle's scratch (nep_batch_frontend)
   return E.run(d_committed, h->cfg.num_agents, ps, (hipStream_t)stream);
+}
+
+// The two halves of nep_batch_replan as calls of their own (include/neptune_backend.h): hulls + separating lines, then the QP on them
+int nep_batch_replan_lines(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess, const void* d_ent, void* stream) {
+  if (!h || !d_guess || !d_committed) return fail(NEP_E_ARG, "null argument");
+  Engine& E = h->eng;
+  ProblemSet ps{};
+  E.fill(ps);
+  ps.guess = d_guess;
+  ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
+  ps.lines_override = 0;
+  return E.run(d_committed, h->cfg.num_agents, ps, (hipStream_t)stream, 1);
+}
+int nep_batch_replan_solve(nep_batch_t* h, const nep_traj_rec* d_committed, const nep_guess* d_guess, const void* d_ent,
+                           nep_solution* d_solution, double* d_states, nep_traj_rec* d_commit, void* stream) {
+  if (!h || !d_guess || !d_solution || !d_committed) return fail(NEP_E_ARG, "null argument");
+  Engine& E = h->eng;
+  ProblemSet ps{};
+  E.fill(ps);
+  ps.guess = d_guess; ps.solution = d_solution; ps.states = d_states; ps.commit = d_commit;
+  ps.prev_commit = d_committed;
+  ps.case_id = (E.sp.ent_enabled && d_ent) ? (const int*)d_ent : nullptr;
+  ps.lines_override = 0;
+  return E.run(d_committed, h->cfg.num_agents, ps, (hipStream_t)stream, 2);
 }
 
 // ---- sharded hulls: a rank computes the interval hulls of its own agents' committed trajectories

@@ -1012,9 +1012,13 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
 __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(SceneParams sp, ProblemSet ps, int pool_pairs, int kSepPack) {
   const int kSepGroups = (NEP_MAX_POL + kSepPack - 1) / kSepPack;
   extern __shared__ __attribute__((aligned(16))) double sdyn[];
+  const int rh = (sp.n_hull + 63) >> 6, rb = (sp.num_agents + 63) >> 6, rs = (sp.n_static + 63) >> 6, rounds = rh + rb + rs;      // candidate rounds of a segment: hulls, bases, statics
   double2* sA = (double2*)sdyn;                      // [pool_pairs] the batch's point sets A, packed
   double* sBx = sdyn + 2 * pool_pairs; double* sBy = sBx + 4 * NEP_MAX_POL;      // [segment][4] control points
-  int* sCnt = (int*)(sBy + 4 * NEP_MAX_POL);          // [segment][6]: near, far, failed, attempted, skipped (running)
+  double* sEl = sBy + 4 * NEP_MAX_POL;                // [segment][3] lengths of the control polygon's edges
+  double* sBb = sEl + 3 * NEP_MAX_POL;                // [segment][4] box of the control points (x0, x1, y0, y1)
+  unsigned long long* sMask = (unsigned long long*)(sBb + 4 * NEP_MAX_POL);      // [segment][round][2]: lanes whose candidate is an LP to solve / known to give a far line
+  int* sCnt = (int*)(sMask + 2 * NEP_MAX_POL * rounds);          // [segment][6]: near, far, failed, attempted, skipped (running)
   unsigned short* sAtt = (unsigned short*)(sCnt + 6 * NEP_MAX_POL);      // entries (segment << 13 | candidate)
   const int lane = threadIdx.x;
   const int slot = blockIdx.x / kSepGroups, grp = blockIdx.x % kSepGroups;
@@ -1028,10 +1032,11 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   const bool cull = sp.cull_radius > 0.0 && ps.line_far != nullptr;      // (the line presolve: far lines parked at the back of the bucket)
   cx.skip_box = cull ? ps.skip_box : nullptr; cx.skip_r = sp.cull_radius;      // (the spatial presolve on top: LPs known to give a far line are not solved)
   const int total = cx.total, cap = total + 8;
+  int seg_end = seg_hi < K ? seg_hi : K; if (seg_end > sp.num_pol) seg_end = sp.num_pol;      // segments [seg_lo, seg_end) exist
   if (lane < 6 * NEP_MAX_POL) sCnt[lane] = 0;
   if (lane < 4 * (seg_hi - seg_lo)) {  // ctrlPtsInit_[seg] (solver_gurobi_poly.cpp:232-243)
     const int seg = seg_lo + (lane >> 2), k = lane & 3;
-    if (seg < K && seg < sp.num_pol) {
+    if (seg < seg_end) {
       const double tp0 = T * T * T, tp1 = T * T, tp2 = T;
       const double m0 = tp0 * cAPosInv[0][k], m1 = tp1 * cAPosInv[1][k], m2 = tp2 * cAPosInv[2][k], m3 = 1.0 * cAPosInv[3][k];
       const double* Px = g->coeff[0][seg]; const double* Py = g->coeff[1][seg];
@@ -1040,10 +1045,124 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     }
   }
   __syncthreads();
+  if (lane < 4 * (seg_hi - seg_lo) && seg_lo + (lane >> 2) < seg_end) {      // (one lane per value instead of every lane of the wave repeating a segment's three square roots and its box)
+    const int seg = seg_lo + (lane >> 2), k = lane & 3;
+    const double* bx_ = sBx + seg * 4; const double* by_ = sBy + seg * 4;
+    if (k < 3) { const double ex = bx_[k + 1] - bx_[k], ey = by_[k + 1] - by_[k]; sEl[seg * 3 + k] = sqrt(ex * ex + ey * ey); }
+    const double* q_ = k < 2 ? bx_ : by_;
+    sBb[seg * 4 + k] = (k & 1) ? fmax(fmax(q_[0], q_[1]), fmax(q_[2], q_[3])) : fmin(fmin(q_[0], q_[1]), fmin(q_[2], q_[3]));
+  }
+  __syncthreads();
+  // ---- step 1a: which candidates of which segment are LPs to solve / LPs known to give a far line — the reference's proximity culls
+  // (cand_eval, mode 0) and the spatial presolve's box test, as ballots per (segment, round of 64 candidates).  Candidate-major: what
+  // a lane reads of its candidate (base position, static polygon's first vertex, edge lengths and box; an interval hull's eight boxes,
+  // which lie side by side) is loaded ONCE, every load of a round issued before the first is used, and then tested against each
+  // segment's control points (LDS).  The segment-major form of this step — one dependent global round trip after another, eight
+  // segments in turn, four waves per SIMD to hide them — was two thirds of the kernel's time (0.097 of 0.144 ms per 8 192 replans).
+  const int nsv = seg_end - seg_lo;
+  if (nsv > 0) {
+    const double rr = cx.skip_r;
+#if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 1)
+    for (int c0 = 0; c0 < cx.nH; c0 += 64) {      // interval hulls: decided by their boxes alone (empty: x0 = +inf, never called)
+      const int j = c0 + lane; const bool in = j < cx.nH;
+      const bool valid0 = in && !(sp.skip_own && j == cx.own);
+      if (cx.skip_box) {
+        const double2* q = (const double2*)(cx.skip_box + ((long)cx.scene * (cx.N + cx.S) + (in ? j : 0)) * sp.num_pol * 4);
+        for (int s0 = seg_lo; s0 < seg_end; s0 += 4) {
+          double2 qa[4], qb[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) { const int sg = s0 + u < seg_end ? s0 + u : seg_end - 1; qa[u] = q[sg * 2]; qb[u] = q[sg * 2 + 1]; }
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int sg = s0 + u;
+            if (sg < seg_end) {
+              const double* bb = sBb + sg * 4;
+              const bool valid = valid0 && qa[u].x < NEP_INF;
+              const bool far = (qa[u].x - bb[1] > rr) | (bb[0] - qa[u].y > rr) | (qb[u].x - bb[3] > rr) | (bb[2] - qb[u].y > rr);
+              const unsigned long long ma = __ballot(valid && !far), mk = __ballot(valid && far);
+              if (lane == 0) { sMask[(sg * rounds + (c0 >> 6)) * 2] = ma; sMask[(sg * rounds + (c0 >> 6)) * 2 + 1] = mk; }
+            }
+          }
+        }
+      } else {
+        for (int sg = seg_lo; sg < seg_end; sg++) {
+          int nA; int ord; const double2* unused = nullptr;
+          const bool att = in && cand_eval(cx, sg, j, sBx + sg * 4, sBy + sg * 4, 0.0, 0, nullptr, nA, ord, unused);
+          const unsigned long long ma = __ballot(att);
+          if (lane == 0) { sMask[(sg * rounds + (c0 >> 6)) * 2] = ma; sMask[(sg * rounds + (c0 >> 6)) * 2 + 1] = 0ull; }
+        }
+      }
+    }
+#endif
+#if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 2)
+    for (int j0 = 0; j0 < cx.N; j0 += 64) {      // bases (:521-553): within 3 x 0.7 m of one of the four control points
+      const int j = j0 + lane; const bool in = j < cx.N;
+      const double base_radius = 0.7;
+      const double pbx = ps.pb[2 * (in ? j : 0)], pby = ps.pb[2 * (in ? j : 0) + 1];
+      for (int sg = seg_lo; sg < seg_end; sg++) {
+        const double* bx_ = sBx + sg * 4; const double* by_ = sBy + sg * 4; const double* bb = sBb + sg * 4;
+        bool close_to_base = false;
+        // (a base farther than 2.2 m from the box of the four control points along x or y is farther than that from each of them: a
+        // round of 64 far bases skips the per-point test as a whole)
+        if (in && !((pbx < bb[0] - 2.2) | (pbx > bb[1] + 2.2) | (pby < bb[2] - 2.2) | (pby > bb[3] + 2.2))) {
+          bool near_any = false; double d2[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const double ddx = bx_[k] - pbx, ddy = by_[k] - pby;
+            d2[k] = ddx * ddx + ddy * ddy;
+            const bool nr = !((fabs(ddx) > 2.2) | (fabs(ddy) > 2.2));
+            if (!nr) d2[k] = 1e30;
+            near_any |= nr;
+          }
+          if (near_any) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) close_to_base |= sqrt(d2[k]) < base_radius * 3;
+          }
+        }
+        const unsigned long long ma = __ballot(close_to_base);
+        if (lane == 0) { sMask[(sg * rounds + rh + (j0 >> 6)) * 2] = ma; sMask[(sg * rounds + rh + (j0 >> 6)) * 2 + 1] = 0ull; }
+      }
+    }
+#endif
+#if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 4)
+    for (int c0 = 0; c0 < cx.S; c0 += 64) {      // static polygons (:556-593): the perimeter cull, then the box
+      const int js = c0 + lane; const bool in = js < cx.S;
+      const long j = (long)cx.scene * sp.static_stride + (in ? js : 0);
+      const int nv = in ? ps.static_nv[j] : 0;
+      const double* src = ps.static_xy + j * kHullV * 2;
+      const double sx0 = src[0], sy0 = src[1];
+      const double* elp = ps.static_el + j * kHullV;
+      const double e0 = elp[0], e1 = elp[1], e2 = elp[2];      // (a polygon's first edges — all of a square's — ahead of the loop that consumes them)
+      double2 qa = make_double2(0, 0), qb = qa;      // the polygon's box: the same in every interval
+      if (cx.skip_box) { const double2* q = (const double2*)(cx.skip_box + (((long)cx.scene * (cx.N + cx.S) + cx.N + (in ? js : 0)) * sp.num_pol + seg_lo) * 4); qa = q[0]; qb = q[1]; }
+      for (int sg = seg_lo; sg < seg_end; sg++) {
+        const double* bb = sBb + sg * 4;
+        bool close_s = false;
+        if (nv > 0) {          // :558-578
+          const double ddx = sBx[sg * 4] - sx0, ddy = sBy[sg * 4] - sy0;
+          double dist = sqrt(ddx * ddx + ddy * ddy);
+#pragma unroll
+          for (int k = 0; k < 3; k++) { dist -= sEl[sg * 3 + k]; close_s |= dist < 0; }
+          if (nv > 1) { dist -= e0; close_s |= dist < 0; }
+          if (nv > 2) { dist -= e1; close_s |= dist < 0; }
+          if (nv > 3) { dist -= e2; close_s |= dist < 0; }
+          for (int k = 3; k < nv - 1; k++) { dist -= elp[k]; close_s |= dist < 0; }
+        }
+        const bool far = cx.skip_box != nullptr && ((qa.x - bb[1] > rr) | (bb[0] - qa.y > rr) | (qb.x - bb[3] > rr) | (bb[2] - qb.y > rr));
+        const unsigned long long ma = __ballot(close_s && !far), mk = __ballot(close_s && far);
+        if (lane == 0) { sMask[(sg * rounds + rh + rb + (c0 >> 6)) * 2] = ma; sMask[(sg * rounds + rh + rb + (c0 >> 6)) * 2 + 1] = mk; }
+      }
+    }
+#endif
+  }
+  __syncthreads();
   int n_list = 0;
   // ---- the LPs gathered so far, 64 to a batch across the segments ----
   auto flush = [&]() {
     __syncthreads();
+#if defined(NEP_SEP_EXP) && NEP_SEP_EXP == 2
+    n_list = 0;
+#endif
     for (int a0 = 0; a0 < n_list; a0 += 64) {
       const int a = a0 + lane;
       const bool active = a < n_list;
@@ -1066,7 +1185,11 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         if (!myA && made_here) myA = priv;
         const double2* Ause = myA;
         cand_eval(cx, sl, c, sBx, sBy, 0.0, 1, myA, nA, ord, Ause);
+#if defined(NEP_SEP_EXP) && NEP_SEP_EXP == 1
+        nd[0] = Ause[0].x; nd[1] = Ause[nA - 1].y; nd[2] = B4.x[0];
+#else
         ok = separator_impl(nA, Ause, ord, B4, nd);
+#endif
         if (!ok) { nd[0] = nd[1] = nd[2] = 0.0; }
         if (cull) {
           double worst = -NEP_INF;
@@ -1096,77 +1219,90 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     n_list = 0;
   };
   // ---- step 1, segment by segment: which LPs does the reference call, in order (as separator_body with the spatial presolve) ----
-  for (int seg = seg_lo; seg < seg_hi; seg++) {
-    if (seg >= K || seg >= sp.num_pol) continue;
-    const double* bx = sBx + seg * 4; const double* by = sBy + seg * 4;
-    const int tag = seg << 13;
-    double hulldist = 0;  // :738-742
-    for (int k = 0; k < 3; k++) { const double ex = bx[k + 1] - bx[k], ey = by[k + 1] - by[k]; cx.el[k] = sqrt(ex * ex + ey * ey); hulldist += cx.el[k]; }
-    cx.bb[0] = fmin(fmin(bx[0], bx[1]), fmin(bx[2], bx[3])); cx.bb[1] = fmax(fmax(bx[0], bx[1]), fmax(bx[2], bx[3]));
-    cx.bb[2] = fmin(fmin(by[0], by[1]), fmin(by[2], by[3])); cx.bb[3] = fmax(fmax(by[0], by[1]), fmax(by[2], by[3]));
-    int n_att = 0, n_skip = 0;
-    const int n_plain = cx.nH + cx.N + cx.S;
-    int c_first = 0;
-    if (cx.skip_box) {
-      const double* bx0 = cx.skip_box + ((long)cx.scene * (cx.N + cx.S) * sp.num_pol + seg) * 4;
-      auto load_box = [&](int j, double2& a, double2& b) {
-        const bool v = j < cx.nH;
-        const double2* q = (const double2*)(bx0 + (long)(v ? j : 0) * sp.num_pol * 4);
-        a = q[0]; b = q[1];
-      };
-      double2 ca, cb, na, nb2;
-      load_box(lane, ca, cb);
-      for (int c0 = 0; c0 < cx.nH; c0 += 64) {
-        if (n_list + 64 > cap) flush();
-        const int j = c0 + lane;
-        load_box(j + 64, na, nb2);
-        const bool valid = j < cx.nH && !(sp.skip_own && j == cx.own) && ca.x < NEP_INF;
-        const bool far = (ca.x - cx.bb[1] > cx.skip_r) | (cx.bb[0] - ca.y > cx.skip_r) | (cb.x - cx.bb[3] > cx.skip_r) | (cx.bb[2] - cb.y > cx.skip_r);
-        const unsigned long long mask = __ballot(valid && !far);
-        if (valid && !far) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | j);
+  // Written as ONE loop over candidate rounds — (segment, kind of candidate, first candidate) advance as wave-uniform state — with ONE
+  // call site of flush(): the lambda is inlined, and with a call site in each of the three round loops plus the final one the kernel
+  // carried four copies of the LP code (9 300 VALU instructions, more than the instruction cache two CUs share).
+  int seg = seg_lo - 1, ph = 4, c0 = 0, n_att = 0, n_skip = 0, n_act = 0;      // ph: 1 the ballots of step 1a, 2 entangle agents, 3 entangle pairs, 4 next segment
+  const int n_plain = cx.nH + cx.N + cx.S;
+  const double* bx = sBx; const double* by = sBy;
+  double hulldist = 0;
+  int tag = 0;
+  unsigned short* sAct = sAtt + cap;
+#if defined(NEP_SEP_SKIPA) && (NEP_SEP_SKIPA & 8)
+  bool more = false;
+#else
+  bool more = true;
+#endif
+  // Without entangle candidates the list is the ballots read out in (segment, round) order: a flat walk, a few instructions a round
+  // (the kernel is bound by instruction issue — every 1 000 instructions of a wave are 17 us of the launch —, and the general walk
+  // below, whose state machine also serves the entangle rounds, cost 26 us for this).
+  const bool ent_c = n_plain < total;
+  int it_sg = seg_lo, it_r = 0;
+  if (!ent_c && lane < nsv) {      // attempted / skipped per segment, straight from the ballots
+    int na_ = 0, nk_ = 0;
+    for (int r = 0; r < rounds; r++) { na_ += __popcll(sMask[((seg_lo + lane) * rounds + r) * 2]); nk_ += __popcll(sMask[((seg_lo + lane) * rounds + r) * 2 + 1]); }
+    sCnt[(seg_lo + lane) * 6 + 3] = na_; sCnt[(seg_lo + lane) * 6 + 4] = nk_;
+  }
+  while (more) {
+    if (!ent_c) {
+      for (; it_sg < seg_end; ) {
+        if (n_list > 0 && n_list + 64 > cap) break;
+        const unsigned long long mv = sMask[(it_sg * rounds + it_r) * 2];
+        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mv), mhi = __builtin_amdgcn_readfirstlane((unsigned)(mv >> 32));
+        const int cb_ = it_r < rh ? (it_r << 6) : (it_r < rh + rb ? cx.nH + ((it_r - rh) << 6) : cx.nH + cx.N + ((it_r - rh - rb) << 6));
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        if ((((lane & 32) ? mhi : mlo) >> (lane & 31)) & 1u) sAtt[n_list + rank] = (unsigned short)((it_sg << 13) | (cb_ + lane));
+        n_list += __popc(mlo) + __popc(mhi);
+        if (++it_r == rounds) { it_r = 0; it_sg++; }
+      }
+      if (it_sg >= seg_end) more = false;
+    } else
+    for (;;) {
+      if (ph == 4) {
+        if (seg >= seg_lo && seg < seg_end && lane == 0) { sCnt[seg * 6 + 3] = n_att; sCnt[seg * 6 + 4] = n_skip; }
+        seg++;
+        if (seg >= seg_end) { more = false; break; }
+        bx = sBx + seg * 4; by = sBy + seg * 4; tag = seg << 13;
+        hulldist = 0;  // :738-742
+        for (int k = 0; k < 3; k++) { cx.el[k] = sEl[seg * 3 + k]; hulldist += cx.el[k]; }
+        for (int k = 0; k < 4; k++) cx.bb[k] = sBb[seg * 4 + k];
+        n_att = 0; n_skip = 0; c0 = 0; ph = 1;
+      }
+      if (ph == 1 && c0 >= rounds) { ph = n_plain < total ? 2 : 4; continue; }
+      if (ph == 3 && c0 >= n_act * kBend) { ph = 4; continue; }
+      if (ph != 2 && n_list > 0 && n_list + 64 > cap) break;      // (the round might not fit: what has been gathered is solved first; a round alone always fits)
+      if (ph == 1) {
+        const unsigned long long mask = sMask[(seg * rounds + c0) * 2], msk = sMask[(seg * rounds + c0) * 2 + 1];
+        const int c = c0 < rh ? (c0 << 6) + lane : (c0 < rh + rb ? cx.nH + ((c0 - rh) << 6) + lane : cx.nH + cx.N + ((c0 - rh - rb) << 6) + lane);
+        if ((mask >> lane) & 1ull) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | c);
         n_list += __popcll(mask); n_att += __popcll(mask);
-        n_skip += __popcll(__ballot(valid && far));
-        ca = na; cb = nb2;
-      }
-      c_first = cx.nH;
-    }
-    for (int c0 = c_first; c0 < n_plain; c0 += 64) {
-      if (n_list + 64 > cap) flush();
-      const int c = c0 + lane;
-      int nA; int ord; bool skp = false;
-      const double2* unused = nullptr;
-      const bool att = c < n_plain && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused, &skp);
-      const unsigned long long mask = __ballot(att && !skp);
-      if (att && !skp) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | c);
-      n_list += __popcll(mask); n_att += __popcll(mask);
-      n_skip += __popcll(__ballot(att && skp));
-    }
-    if (n_plain < total) {      // entangle candidates (agent j, bend segment k): the agents with an active case first, then their pairs densely
-      unsigned short* sAct = sAtt + cap;
-      int n_act = 0;
-      __syncthreads();
-      for (int j0 = 0; j0 < cx.N; j0 += 64) {
-        const int j = j0 + lane;
-        const bool act = j < cx.N && j != cx.own && ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * cx.N + j] != 0;
-        const unsigned long long mask = __ballot(act);
-        if (act) sAct[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
-        n_act += __popcll(mask);
-      }
-      __syncthreads();
-      for (int p0 = 0; p0 < n_act * kBend; p0 += 64) {
-        if (n_list + 64 > cap) flush();
-        const int pp = p0 + lane;
+        n_skip += __popcll(msk);
+        c0++;
+      } else if (ph == 2) {      // entangle candidates (agent j, bend segment k): the agents with an active case first, then their pairs densely
+        n_act = 0;
+        __syncthreads();
+        for (int j0 = 0; j0 < cx.N; j0 += 64) {
+          const int j = j0 + lane;
+          const bool act = j < cx.N && j != cx.own && ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * cx.N + j] != 0;
+          const unsigned long long mask = __ballot(act);
+          if (act) sAct[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
+          n_act += __popcll(mask);
+        }
+        __syncthreads();
+        ph = 3; c0 = 0;
+      } else {
+        const int pp = c0 + lane;
         int nA; int ord; const double2* unused = nullptr;
         const int c = pp < n_act * kBend ? n_plain + (int)sAct[pp / kBend] * kBend + (pp % kBend) : 0;
         const bool att = pp < n_act * kBend && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused);
         const unsigned long long mask = __ballot(att);
         if (att) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | c);
         n_list += __popcll(mask); n_att += __popcll(mask);
+        c0 += 64;
       }
     }
-    if (lane == 0) { sCnt[seg * 6 + 3] = n_att; sCnt[seg * 6 + 4] = n_skip; }
+    flush();
   }
-  flush();
   __syncthreads();
   if (lane < seg_hi - seg_lo) {
     const int seg = seg_lo + lane;
@@ -1216,9 +1352,14 @@ void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, 
   // the packed kernel's list entries are (segment << 13 | candidate) in 16 bits: candidates beyond 8 191 (about 800 agents with the
   // entangle rows, 4 000 without) take the unpacked kernel, whose entries hold 65 535 (size_scratch refuses more)
   if (ps.skip_box && ps.line_far && sp.sep_rule == 0 && sp.cull_radius > 0.0 && ps.sep_pack >= 0 && total <= 8191) {
-    const int pairs = separator_pool_pairs(sp);
-    const size_t lds_p = ((size_t)pairs * 16 + 8 * NEP_MAX_POL * sizeof(double) + 6 * NEP_MAX_POL * sizeof(int)
-                          + (size_t)(total + 8 + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short) + 15) & ~(size_t)15;
+    // (the wave's LDS stays within the 10 KB sixteen waves per CU allow: the pool of point sets takes what the tables leave, 64 x 8 pairs at least)
+    const size_t rounds_ = (size_t)((sp.n_hull + 63) / 64 + (sp.num_agents + 63) / 64 + (sp.n_static + 63) / 64);
+    const size_t extras = 15 * NEP_MAX_POL * sizeof(double) + 2 * NEP_MAX_POL * rounds_ * sizeof(unsigned long long) + 6 * NEP_MAX_POL * sizeof(int)
+                          + (size_t)(total + 8 + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short);
+    size_t pool_b = extras + 64 * 8 * 16 <= (size_t)kSepLdsTarget ? (size_t)kSepLdsTarget - extras : (size_t)64 * 8 * 16;
+    pool_b &= ~(size_t)15;
+    const int pairs = (int)(pool_b / 16);
+    const size_t lds_p = (pool_b + extras + 15) & ~(size_t)15;
     static DynLdsAttr attr_p;
     (void)attr_p.ensure((const void*)separator_packed_kernel, lds_p);
     int pack = 1; while (pack < NEP_MAX_POL && (long)n_slots * (NEP_MAX_POL / (pack * 2)) >= 4096) pack *= 2;      // (at least ~4 000 waves while the launch allows it)

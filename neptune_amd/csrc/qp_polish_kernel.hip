@@ -389,6 +389,7 @@ __device__ bool polish_slot(const SceneParams& sp, const ProblemSet& ps, const Q
 // has no memset node, no kernel behind this one and no "last workgroup done" counter (512 atomics on one address were 0.08 ms of
 // every step, listed slots or not); until then the host reads them (nep_batch_debug_polish_count).
 __global__ __launch_bounds__(256) void qp_polish_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
+  __builtin_amdgcn_s_setprio(3);      // (latency-bound waves: when another scene group's hull / separator waves share the SIMD — bench.py's pipelined groups — these issue first)
   const int n_listed = ps.polish_count[0];
   int n_ok = 0;
   for (int e = blockIdx.x; e < n_listed; e += gridDim.x) {

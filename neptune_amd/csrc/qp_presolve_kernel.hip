@@ -54,6 +54,7 @@ __device__ __forceinline__ double pre_wave_sum(double v) {
 // a lane loads ONE 32-byte row of each map as soon as K is known — no chain g -> z* -> rows — and the guess's twelve numbers come
 // through the scalar unit (wave-uniform addresses).
 __global__ __launch_bounds__(64, NEP_PRE_WAVES) void qp_presolve_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched, int* __restrict__ presolved) {
+  __builtin_amdgcn_s_setprio(3);      // (latency-bound waves: when another scene group's hull / separator waves share the SIMD — bench.py's pipelined groups — these issue first)
   const int lane = threadIdx.x;
   const int slot = blockIdx.x;
   const long long t0 = (long long)wall_clock64();

@@ -83,6 +83,7 @@ __device__ __forceinline__ double is_of(double s, isd_t) { return frcp(s); }
 // for it: they cost the presolve's kernel two more spilled registers and 3 % of its time, which the default does not pay)
 template <bool CULL, int RS, bool PST = true>
 __global__ __launch_bounds__(BS, NEP_QP_REG_WGS) void qp_reg_kernel(SceneParams sp, ProblemSet ps, const QpTable* __restrict__ tables, SampleSched sched) {
+  __builtin_amdgcn_s_setprio(3);      // (latency-bound waves: when another scene group's hull / separator waves share the SIMD — bench.py's pipelined groups — these issue first)
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sB = smem + oB; double* sOff = smem + oOff; double* sAccL = smem + oAccL;
   double* sDc = smem + oDc; double* sTc = smem + oTc;
