@@ -1009,7 +1009,30 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
 // a round of candidates might not fit, what has been gathered is solved first.
 // (segments per wave, chosen by the host from the launch's size — 2: 0.555, 3: 0.511, 4: 0.497, 8: 0.488 ms per 8 192 config-5
 // replans against 0.639 unpacked; small launches keep more, shorter waves)
+// inclusive prefix sum of an int over the wave's 64 lanes in the data-parallel-primitive moves of gfx9: four shifts within the rows of 16,
+// then lane 15 of a row to the next row and lane 31 to the upper half (eight moves; the ds_bpermute form is six LDS-crossbar round trips)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 -> rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
+  return v;
+}
+// entries of the packed kernel's LP list: a segment's worst case (the unpacked kernel's capacity), and room for what all eight segments
+// of a replan usually gather together (about 130 LPs at 64 agents + 20 obstacles), so that the list is placed in one go
+__host__ __device__ inline int sep_packed_cap(int total) { return total + 8 < 320 ? 320 : total + 8; }
+#ifdef NEP_SEP_PROF
+__device__ unsigned long long g_sep_prof[16384 * 16];
+#define SEP_PT(k) do { const long long t_ = clock64(); pa_[k] += t_ - pt_; pt_ = t_; } while (0)
+#else
+#define SEP_PT(k) do { } while (0)
+#endif
 __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(SceneParams sp, ProblemSet ps, int pool_pairs, int kSepPack) {
+#ifdef NEP_SEP_PROF
+  long long pt_ = clock64(); long long pa_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   const int kSepGroups = (NEP_MAX_POL + kSepPack - 1) / kSepPack;
   extern __shared__ __attribute__((aligned(16))) double sdyn[];
   const int rh = (sp.n_hull + 63) >> 6, rb = (sp.num_agents + 63) >> 6, rs = (sp.n_static + 63) >> 6, rounds = rh + rb + rs;      // candidate rounds of a segment: hulls, bases, statics
@@ -1031,18 +1054,17 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   cx.total = cx.nH + cx.N + cx.S + ((sp.ent_enabled && ps.case_id) ? cx.N * kBend : 0);
   const bool cull = sp.cull_radius > 0.0 && ps.line_far != nullptr;      // (the line presolve: far lines parked at the back of the bucket)
   cx.skip_box = cull ? ps.skip_box : nullptr; cx.skip_r = sp.cull_radius;      // (the spatial presolve on top: LPs known to give a far line are not solved)
-  const int total = cx.total, cap = total + 8;
+  const int total = cx.total, cap = sep_packed_cap(total);
   int seg_end = seg_hi < K ? seg_hi : K; if (seg_end > sp.num_pol) seg_end = sp.num_pol;      // segments [seg_lo, seg_end) exist
   if (lane < 6 * NEP_MAX_POL) sCnt[lane] = 0;
   if (lane < 4 * (seg_hi - seg_lo)) {  // ctrlPtsInit_[seg] (solver_gurobi_poly.cpp:232-243)
     const int seg = seg_lo + (lane >> 2), k = lane & 3;
-    if (seg < seg_end) {
-      const double tp0 = T * T * T, tp1 = T * T, tp2 = T;
-      const double m0 = tp0 * cAPosInv[0][k], m1 = tp1 * cAPosInv[1][k], m2 = tp2 * cAPosInv[2][k], m3 = 1.0 * cAPosInv[3][k];
-      const double* Px = g->coeff[0][seg]; const double* Py = g->coeff[1][seg];
-      sBx[seg * 4 + k] = ((Px[0] * m0 + Px[1] * m1) + Px[2] * m2) + Px[3] * m3;
-      sBy[seg * 4 + k] = ((Py[0] * m0 + Py[1] * m1) + Py[2] * m2) + Py[3] * m3;
-    }
+    // (the coefficients are read whether or not the segment exists — the arrays do —, so that these loads do not wait for K's)
+    const double4 Px = *(const double4*)g->coeff[0][seg], Py = *(const double4*)g->coeff[1][seg];
+    const double tp0 = T * T * T, tp1 = T * T, tp2 = T;
+    const double m0 = tp0 * cAPosInv[0][k], m1 = tp1 * cAPosInv[1][k], m2 = tp2 * cAPosInv[2][k], m3 = 1.0 * cAPosInv[3][k];
+    const double vx_ = ((Px.x * m0 + Px.y * m1) + Px.z * m2) + Px.w * m3, vy_ = ((Py.x * m0 + Py.y * m1) + Py.z * m2) + Py.w * m3;
+    if (seg < seg_end) { sBx[seg * 4 + k] = vx_; sBy[seg * 4 + k] = vy_; }
   }
   __syncthreads();
   if (lane < 4 * (seg_hi - seg_lo) && seg_lo + (lane >> 2) < seg_end) {      // (one lane per value instead of every lane of the wave repeating a segment's three square roots and its box)
@@ -1053,6 +1075,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     sBb[seg * 4 + k] = (k & 1) ? fmax(fmax(q_[0], q_[1]), fmax(q_[2], q_[3])) : fmin(fmin(q_[0], q_[1]), fmin(q_[2], q_[3]));
   }
   __syncthreads();
+  SEP_PT(0);
   // ---- step 1a: which candidates of which segment are LPs to solve / LPs known to give a far line — the reference's proximity culls
   // (cand_eval, mode 0) and the spatial presolve's box test, as ballots per (segment, round of 64 candidates).  Candidate-major: what
   // a lane reads of its candidate (base position, static polygon's first vertex, edge lengths and box; an interval hull's eight boxes,
@@ -1094,36 +1117,31 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       }
     }
 #endif
+    SEP_PT(1);
 #if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 2)
     for (int j0 = 0; j0 < cx.N; j0 += 64) {      // bases (:521-553): within 3 x 0.7 m of one of the four control points
       const int j = j0 + lane; const bool in = j < cx.N;
-      const double base_radius = 0.7;
+      constexpr double base_radius = 0.7;
       const double pbx = ps.pb[2 * (in ? j : 0)], pby = ps.pb[2 * (in ? j : 0) + 1];
       for (int sg = seg_lo; sg < seg_end; sg++) {
         const double* bx_ = sBx + sg * 4; const double* by_ = sBy + sg * 4; const double* bb = sBb + sg * 4;
+        // cand_eval's test — sqrt(d^2) < 3 x 0.7 for one of the four control points, behind its two coarse "farther than 2.2 m along an axis"
+        // exits — without the square roots: for a correctly rounded square root, sqrt(x) < 0.7 * 3 (= 0x1.0ccccccccccccp+1) exactly when
+        // x < kBaseNear2, the smallest double whose root rounds to that or more; a point within that distance passes both coarse tests
+        // (2.1 < 2.2, roundings of 1e-16 apart), so the verdict is cand_eval's, bit for bit (the GPU tests compare the line lists).
+        constexpr double kBaseNear2 = 0x1.1a3d70a3d70a2p+2;
+        static_assert(base_radius * 3 == 0x1.0ccccccccccccp+1, "kBaseNear2 belongs to 0.7 * 3");
         bool close_to_base = false;
-        // (a base farther than 2.2 m from the box of the four control points along x or y is farther than that from each of them: a
-        // round of 64 far bases skips the per-point test as a whole)
-        if (in && !((pbx < bb[0] - 2.2) | (pbx > bb[1] + 2.2) | (pby < bb[2] - 2.2) | (pby > bb[3] + 2.2))) {
-          bool near_any = false; double d2[4];
 #pragma unroll
-          for (int k = 0; k < 4; k++) {
-            const double ddx = bx_[k] - pbx, ddy = by_[k] - pby;
-            d2[k] = ddx * ddx + ddy * ddy;
-            const bool nr = !((fabs(ddx) > 2.2) | (fabs(ddy) > 2.2));
-            if (!nr) d2[k] = 1e30;
-            near_any |= nr;
-          }
-          if (near_any) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) close_to_base |= sqrt(d2[k]) < base_radius * 3;
-          }
-        }
+        for (int k = 0; k < 4; k++) { const double ddx = bx_[k] - pbx, ddy = by_[k] - pby; close_to_base |= ddx * ddx + ddy * ddy < kBaseNear2; }
+        close_to_base &= in;
+        (void)bb;
         const unsigned long long ma = __ballot(close_to_base);
         if (lane == 0) { sMask[(sg * rounds + rh + (j0 >> 6)) * 2] = ma; sMask[(sg * rounds + rh + (j0 >> 6)) * 2 + 1] = 0ull; }
       }
     }
 #endif
+    SEP_PT(2);
 #if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 4)
     for (int c0 = 0; c0 < cx.S; c0 += 64) {      // static polygons (:556-593): the perimeter cull, then the box
       const int js = c0 + lane; const bool in = js < cx.S;
@@ -1133,14 +1151,23 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       const double sx0 = src[0], sy0 = src[1];
       const double* elp = ps.static_el + j * kHullV;
       const double e0 = elp[0], e1 = elp[1], e2 = elp[2];      // (a polygon's first edges — all of a square's — ahead of the loop that consumes them)
+      double perim = 0;
+      if (nv > 1) perim += e0; if (nv > 2) perim += e1; if (nv > 3) perim += e2;
+      for (int k = 3; k < nv - 1; k++) perim += elp[k];
       double2 qa = make_double2(0, 0), qb = qa;      // the polygon's box: the same in every interval
       if (cx.skip_box) { const double2* q = (const double2*)(cx.skip_box + (((long)cx.scene * (cx.N + cx.S) + cx.N + (in ? js : 0)) * sp.num_pol + seg_lo) * 4); qa = q[0]; qb = q[1]; }
       for (int sg = seg_lo; sg < seg_end; sg++) {
         const double* bb = sBb + sg * 4;
         bool close_s = false;
+        const double ddx = sBx[sg * 4] - sx0, ddy = sBy[sg * 4] - sy0;
+        const double d2s = ddx * ddx + ddy * ddy;
+        // (the cull below can only fire when the distance is less than what it subtracts — the control polygon's length plus the
+        // polygon's edges; a round of polygons all farther than that, with a margin a million times the roundings, skips the
+        // square roots and the chain as a whole: same verdicts)
+        const double thr = ((sEl[sg * 3] + sEl[sg * 3 + 1]) + sEl[sg * 3 + 2] + perim) * 1.000001 + 1e-6;
+        if (__ballot(nv > 0 && d2s <= thr * thr) != 0ull)
         if (nv > 0) {          // :558-578
-          const double ddx = sBx[sg * 4] - sx0, ddy = sBy[sg * 4] - sy0;
-          double dist = sqrt(ddx * ddx + ddy * ddy);
+          double dist = sqrt(d2s);
 #pragma unroll
           for (int k = 0; k < 3; k++) { dist -= sEl[sg * 3 + k]; close_s |= dist < 0; }
           if (nv > 1) { dist -= e0; close_s |= dist < 0; }
@@ -1154,12 +1181,14 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       }
     }
 #endif
+    SEP_PT(3);
   }
   __syncthreads();
   int n_list = 0;
   // ---- the LPs gathered so far, 64 to a batch across the segments ----
   auto flush = [&]() {
     __syncthreads();
+    SEP_PT(4);
 #if defined(NEP_SEP_EXP) && NEP_SEP_EXP == 2
     n_list = 0;
 #endif
@@ -1175,9 +1204,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       bool far = false, ok = true;
       int nA = 0; int ord = 0;
       if (active) { const double2* u_ = nullptr; cand_eval(cx, sl, c, sBx, sBy, 0.0, 2, nullptr, nA, ord, u_); }
-      int incl = nA;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o); if (lane >= o) incl += v; }
+      const int incl = wave_incl_scan(nA);
       if (active) {
         double2 priv[4];
         double2* myA = (incl <= pool_pairs) ? sA + (incl - nA) : nullptr;
@@ -1185,10 +1212,16 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         if (!myA && made_here) myA = priv;
         const double2* Ause = myA;
         cand_eval(cx, sl, c, sBx, sBy, 0.0, 1, myA, nA, ord, Ause);
+#ifdef NEP_SEP_PROF
+        SEP_PT(5);
+#endif
 #if defined(NEP_SEP_EXP) && NEP_SEP_EXP == 1
         nd[0] = Ause[0].x; nd[1] = Ause[nA - 1].y; nd[2] = B4.x[0];
 #else
         ok = separator_impl(nA, Ause, ord, B4, nd);
+#endif
+#ifdef NEP_SEP_PROF
+        SEP_PT(6);
 #endif
         if (!ok) { nd[0] = nd[1] = nd[2] = 0.0; }
         if (cull) {
@@ -1215,6 +1248,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         if (lane == 0) { sCnt[s_ * 6] = base_n + __popcll(mn); sCnt[s_ * 6 + 1] = base_f + __popcll(mf); sCnt[s_ * 6 + 2] += __popcll(mx); }
         __syncthreads();
       }
+      SEP_PT(7);
     }
     n_list = 0;
   };
@@ -1243,8 +1277,35 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     for (int r = 0; r < rounds; r++) { na_ += __popcll(sMask[((seg_lo + lane) * rounds + r) * 2]); nk_ += __popcll(sMask[((seg_lo + lane) * rounds + r) * 2 + 1]); }
     sCnt[(seg_lo + lane) * 6 + 3] = na_; sCnt[(seg_lo + lane) * 6 + 4] = nk_;
   }
+  // (when every LP of the wave's segments fits the list at once — nearly always — an entry's place is known from the ballots' counts: a
+  // scan over the (segment, round) items, one per lane, then the entries are written item by item with nothing carried from one item
+  // to the next; the serial walk below, an LDS round trip and a scalar chain per round, was 18 % of the wave's cycles)
+  bool placed = false;
+  const int n_items = nsv > 0 ? nsv * rounds : 0;
+  if (!ent_c && n_items > 0 && n_items <= 64) {
+    int cnt_ = lane < n_items ? __popcll(sMask[(seg_lo * rounds + lane) * 2]) : 0;
+    const int incl_ = wave_incl_scan(cnt_);
+    const int tot_ = __builtin_amdgcn_readlane(incl_, 63);
+    if (tot_ <= cap) {
+      __syncthreads();
+      if (lane < n_items) sMask[(seg_lo * rounds + lane) * 2 + 1] = (unsigned long long)(incl_ - cnt_);      // (the skip ballot has been counted: its place holds the item's offset)
+      __syncthreads();
+      int sg_ = seg_lo, r_ = 0;
+      for (int it = 0; it < n_items; it++) {
+        const ulonglong2 mo = *(const ulonglong2*)&sMask[(seg_lo * rounds + it) * 2];
+        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mo.x), mhi = __builtin_amdgcn_readfirstlane((unsigned)(mo.x >> 32));
+        const int off_ = __builtin_amdgcn_readfirstlane((int)mo.y);
+        const int cb_ = r_ < rh ? (r_ << 6) : (r_ < rh + rb ? cx.nH + ((r_ - rh) << 6) : cx.nH + cx.N + ((r_ - rh - rb) << 6));
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
+        if ((((lane & 32) ? mhi : mlo) >> (lane & 31)) & 1u) sAtt[off_ + rank] = (unsigned short)((sg_ << 13) | (cb_ + lane));
+        if (++r_ == rounds) { r_ = 0; sg_++; }
+      }
+      n_list = tot_; placed = true;
+    }
+  }
   while (more) {
     if (!ent_c) {
+      if (placed) it_sg = seg_end;
       for (; it_sg < seg_end; ) {
         if (n_list > 0 && n_list + 64 > cap) break;
         const unsigned long long mv = sMask[(it_sg * rounds + it_r) * 2];
@@ -1315,7 +1376,20 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     if (ps.line_skip) ps.line_skip[o] = sCnt[seg * 6 + 4];
     ps.lp_stats[o * 2] = sCnt[seg * 6 + 3] + sCnt[seg * 6 + 4]; ps.lp_stats[o * 2 + 1] = sCnt[seg * 6 + 2];
   }
+  SEP_PT(8);
+#ifdef NEP_SEP_PROF
+  if (lane == 0 && blockIdx.x < 16384) { for (int k = 0; k < 9; k++) g_sep_prof[blockIdx.x * 16 + k] += (unsigned long long)pa_[k]; g_sep_prof[blockIdx.x * 16 + 15] += 1ull; }
+#endif
 }
+#ifdef NEP_SEP_PROF
+extern "C" int nep_debug_sep_prof(unsigned long long* out16, int reset) {      // sums over the blocks
+  std::vector<unsigned long long> h((size_t)16384 * 16);
+  (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_sep_prof), h.size() * 8);
+  if (out16) { for (int k = 0; k < 16; k++) out16[k] = 0; for (size_t b = 0; b < 16384; b++) for (int k = 0; k < 16; k++) out16[k] += h[b * 16 + k]; }
+  if (reset) { std::fill(h.begin(), h.end(), 0ull); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sep_prof), h.data(), h.size() * 8); }
+  return 0;
+}
+#endif
 
 // The redo pass of the presolve: every segment of the replans the QP kernel listed (ps.redo_list / ps.redo_count: a parked
 // line violated, or the solution moved farther from the guess than the skipped LPs allow) with every LP solved and every line
@@ -1355,7 +1429,7 @@ void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, 
     // (the wave's LDS stays within the 10 KB sixteen waves per CU allow: the pool of point sets takes what the tables leave, 64 x 8 pairs at least)
     const size_t rounds_ = (size_t)((sp.n_hull + 63) / 64 + (sp.num_agents + 63) / 64 + (sp.n_static + 63) / 64);
     const size_t extras = 15 * NEP_MAX_POL * sizeof(double) + 2 * NEP_MAX_POL * rounds_ * sizeof(unsigned long long) + 6 * NEP_MAX_POL * sizeof(int)
-                          + (size_t)(total + 8 + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short);
+                          + (size_t)(sep_packed_cap(total) + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short);
     size_t pool_b = extras + 64 * 8 * 16 <= (size_t)kSepLdsTarget ? (size_t)kSepLdsTarget - extras : (size_t)64 * 8 * 16;
     pool_b &= ~(size_t)15;
     const int pairs = (int)(pool_b / 16);

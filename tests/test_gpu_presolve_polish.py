@@ -353,3 +353,39 @@ def test_one_slot_launch_lists_itself_for_the_polish_pass(be):
         if cull == 0.0:
             assert n_listed >= min(len(changed), 3) and len(changed) >= 1
     full.close()
+
+
+def test_replan_as_two_enqueues_is_the_same_replan(be):
+    """nep_batch_replan_lines (hulls + separating lines) then nep_batch_replan_solve (the QPs on them), on two streams ordered by an event,
+    against nep_batch_replan: every byte of the solutions, sampled states and commit records, and the same lines."""
+    import torch
+    sc = scene.make_scene(64, 20, seed=5)
+    p = sc["par"]
+    bb = be.BatchBackend(p, sc["statics"])
+    d_com = bb.to_device(sc["committed"]); d_gue = bb.to_device(sc["guesses"])
+    bb.replan(d_com, d_gue)
+    torch.cuda.synchronize()
+    sol1 = bb.solutions().copy()
+    one = (bb.d_states.clone(), bb.d_commit.clone())
+    lines_one = [bb.debug_lines(a) for a in range(0, p.num_agents, 7)]
+    for t in (bb.d_solution, bb.d_states, bb.d_commit):
+        t.zero_()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    s1.wait_stream(torch.cuda.current_stream())
+    bb.replan_lines(d_com, d_gue, stream=s1)
+    ev.record(s1)
+    s2.wait_event(ev)
+    bb.replan_solve(d_com, d_gue, stream=s2)
+    torch.cuda.synchronize()
+    for a, b in zip(one, (bb.d_states, bb.d_commit)):
+        assert torch.equal(a, b)
+    sol2 = bb.solutions()
+    np.testing.assert_array_equal(np.array(sol1["coeff"]), np.array(sol2["coeff"]))
+    for f in ("status", "iters", "objective", "n_lines", "n_rows", "n_lp"):      # (everything but the measured times)
+        np.testing.assert_array_equal(sol1["stats"][f], sol2["stats"][f])
+    for a, (seg, nd) in zip(range(0, p.num_agents, 7), lines_one):
+        seg2, nd2 = bb.debug_lines(a)
+        np.testing.assert_array_equal(seg, seg2); np.testing.assert_array_equal(nd, nd2)
+    assert (sol2["stats"]["status"] != abi.NEP_FAILED).sum() > 32
+    bb.close()
