@@ -1083,6 +1083,16 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   // segment's control points (LDS).  The segment-major form of this step — one dependent global round trip after another, eight
   // segments in turn, four waves per SIMD to hide them — was two thirds of the kernel's time (0.097 of 0.144 ms per 8 192 replans).
   const int nsv = seg_end - seg_lo;
+  // The ballots of a (segment, round) item: kept by lane `item` in two registers when the wave's items fit its lanes and there are no
+  // entangle candidates (then the list is laid out from the registers: a scan, and one v_readlane per item instead of an LDS round
+  // trip); in LDS otherwise ([segment][round][2]).
+  const int n_items = nsv > 0 ? nsv * rounds : 0;
+  const bool reg_items = cx.total == cx.nH + cx.N + cx.S && n_items <= 64;
+  unsigned long long my_a = 0ull, my_k = 0ull;
+  auto put_mask = [&](int sg, int round, unsigned long long ma, unsigned long long mk) {
+    if (reg_items) { if (lane == (sg - seg_lo) * rounds + round) { my_a = ma; my_k = mk; } }
+    else if (lane == 0) { sMask[(sg * rounds + round) * 2] = ma; sMask[(sg * rounds + round) * 2 + 1] = mk; }
+  };
   if (nsv > 0) {
     const double rr = cx.skip_r;
 #if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 1)
@@ -1103,7 +1113,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
               const bool valid = valid0 && qa[u].x < NEP_INF;
               const bool far = (qa[u].x - bb[1] > rr) | (bb[0] - qa[u].y > rr) | (qb[u].x - bb[3] > rr) | (bb[2] - qb[u].y > rr);
               const unsigned long long ma = __ballot(valid && !far), mk = __ballot(valid && far);
-              if (lane == 0) { sMask[(sg * rounds + (c0 >> 6)) * 2] = ma; sMask[(sg * rounds + (c0 >> 6)) * 2 + 1] = mk; }
+              put_mask(sg, c0 >> 6, ma, mk);
             }
           }
         }
@@ -1112,7 +1122,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
           int nA; int ord; const double2* unused = nullptr;
           const bool att = in && cand_eval(cx, sg, j, sBx + sg * 4, sBy + sg * 4, 0.0, 0, nullptr, nA, ord, unused);
           const unsigned long long ma = __ballot(att);
-          if (lane == 0) { sMask[(sg * rounds + (c0 >> 6)) * 2] = ma; sMask[(sg * rounds + (c0 >> 6)) * 2 + 1] = 0ull; }
+          put_mask(sg, c0 >> 6, ma, 0ull);
         }
       }
     }
@@ -1137,14 +1147,18 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         close_to_base &= in;
         (void)bb;
         const unsigned long long ma = __ballot(close_to_base);
-        if (lane == 0) { sMask[(sg * rounds + rh + (j0 >> 6)) * 2] = ma; sMask[(sg * rounds + rh + (j0 >> 6)) * 2 + 1] = 0ull; }
+        put_mask(sg, rh + (j0 >> 6), ma, 0ull);
       }
     }
 #endif
     SEP_PT(2);
 #if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 4)
-    for (int c0 = 0; c0 < cx.S; c0 += 64) {      // static polygons (:556-593): the perimeter cull, then the box
-      const int js = c0 + lane; const bool in = js < cx.S;
+    // static polygons (:556-593): the perimeter cull, then the box.  With S <= 32 polygons a round of lanes takes 64 / S SEGMENTS of
+    // them (lane = segment-in-round x S + polygon: 20 obstacles, three segments a round — three rounds instead of eight a third full)
+    const int spr = (cx.S > 0 && cx.S <= 32) ? 64 / cx.S : 1;      // segments per round
+    for (int c0 = 0; c0 < cx.S; c0 += 64) {
+      const int qs = spr > 1 ? lane / cx.S : 0;                     // this lane's segment within the round
+      const int js = spr > 1 ? lane - qs * cx.S : c0 + lane; const bool in = js < cx.S && qs < spr;
       const long j = (long)cx.scene * sp.static_stride + (in ? js : 0);
       const int nv = in ? ps.static_nv[j] : 0;
       const double* src = ps.static_xy + j * kHullV * 2;
@@ -1156,20 +1170,23 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       for (int k = 3; k < nv - 1; k++) perim += elp[k];
       double2 qa = make_double2(0, 0), qb = qa;      // the polygon's box: the same in every interval
       if (cx.skip_box) { const double2* q = (const double2*)(cx.skip_box + (((long)cx.scene * (cx.N + cx.S) + cx.N + (in ? js : 0)) * sp.num_pol + seg_lo) * 4); qa = q[0]; qb = q[1]; }
-      for (int sg = seg_lo; sg < seg_end; sg++) {
-        const double* bb = sBb + sg * 4;
+      for (int sg0 = seg_lo; sg0 < seg_end; sg0 += spr) {
+        const int sg = sg0 + qs;                         // (per lane when spr > 1)
+        const bool on = nv > 0 && sg < seg_end;
+        const int sgc = sg < seg_end ? sg : seg_end - 1;
+        const double* bb = sBb + sgc * 4;
+        const double el0 = sEl[sgc * 3], el1 = sEl[sgc * 3 + 1], el2 = sEl[sgc * 3 + 2];
         bool close_s = false;
-        const double ddx = sBx[sg * 4] - sx0, ddy = sBy[sg * 4] - sy0;
+        const double ddx = sBx[sgc * 4] - sx0, ddy = sBy[sgc * 4] - sy0;
         const double d2s = ddx * ddx + ddy * ddy;
         // (the cull below can only fire when the distance is less than what it subtracts — the control polygon's length plus the
         // polygon's edges; a round of polygons all farther than that, with a margin a million times the roundings, skips the
         // square roots and the chain as a whole: same verdicts)
-        const double thr = ((sEl[sg * 3] + sEl[sg * 3 + 1]) + sEl[sg * 3 + 2] + perim) * 1.000001 + 1e-6;
-        if (__ballot(nv > 0 && d2s <= thr * thr) != 0ull)
-        if (nv > 0) {          // :558-578
+        const double thr = ((el0 + el1) + el2 + perim) * 1.000001 + 1e-6;
+        if (__ballot(on && d2s <= thr * thr) != 0ull)
+        if (on) {          // :558-578
           double dist = sqrt(d2s);
-#pragma unroll
-          for (int k = 0; k < 3; k++) { dist -= sEl[sg * 3 + k]; close_s |= dist < 0; }
+          dist -= el0; close_s |= dist < 0; dist -= el1; close_s |= dist < 0; dist -= el2; close_s |= dist < 0;
           if (nv > 1) { dist -= e0; close_s |= dist < 0; }
           if (nv > 2) { dist -= e1; close_s |= dist < 0; }
           if (nv > 3) { dist -= e2; close_s |= dist < 0; }
@@ -1177,8 +1194,12 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         }
         const bool far = cx.skip_box != nullptr && ((qa.x - bb[1] > rr) | (bb[0] - qa.y > rr) | (qb.x - bb[3] > rr) | (bb[2] - qb.y > rr));
         const unsigned long long ma = __ballot(close_s && !far), mk = __ballot(close_s && far);
-        if (lane == 0) { sMask[(sg * rounds + rh + rb + (c0 >> 6)) * 2] = ma; sMask[(sg * rounds + rh + rb + (c0 >> 6)) * 2 + 1] = mk; }
+        if (spr > 1) {
+          const unsigned long long sm = (1ull << cx.S) - 1ull;
+          for (int u = 0; u < spr && sg0 + u < seg_end; u++) put_mask(sg0 + u, rh + rb, (ma >> (u * cx.S)) & sm, (mk >> (u * cx.S)) & sm);
+        } else put_mask(sg0, rh + rb + (c0 >> 6), ma, mk);
       }
+      if (spr > 1) break;
     }
 #endif
     SEP_PT(3);
@@ -1232,20 +1253,26 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
           far = !ok || -worst > sp.cull_radius * len;
         }
       }
-      const unsigned long long below = (1ull << lane) - 1ull;
-      for (int s_ = seg_lo; s_ < seg_hi; s_++) {           // (near lines keep their call order at the front of their segment's bucket, far ones from its end)
-        const bool mine = active && sl == s_;
-        const unsigned long long mS = __ballot(mine);
-        if (mS == 0ull) continue;
-        const unsigned long long mn = __ballot(mine && !far), mf = __ballot(mine && far), mx = __ballot(mine && !ok);
-        const int base_n = sCnt[s_ * 6], base_f = sCnt[s_ * 6 + 1];
-        if (mine) {
-          double* bucket = ps.line_nd + ((long)slot * NEP_MAX_POL + s_) * sp.lines_cap * 3;
-          const long pos = far ? (long)sp.lines_cap - 1 - (base_f + __popcll(mf & below)) : (long)base_n + __popcll(mn & below);
+      // Near lines keep their call order at the front of their segment's bucket, far ones from its end.  The list is segment-major, so
+      // the lanes of a segment are a run of consecutive lanes: a lane's place is its rank among the near (far) lanes of its run on top
+      // of the segment's running counts, and the run's last lane brings the counts forward — no loop over the segments.
+      {
+        const unsigned long long below = (1ull << lane) - 1ull;
+        const unsigned long long mact = __ballot(active), mn = __ballot(active && !far), mf = __ballot(active && far), mx = __ballot(active && !ok);
+        const int sl_prev = __builtin_amdgcn_update_dpp(-1, sl, 0x138, 0xf, 0xf, false);      // wave_shr:1 (lane 0 keeps -1)
+        const unsigned long long ms = __ballot(active && (lane == 0 || sl != sl_prev));        // first lanes of the runs
+        const unsigned long long upto = ms & (below | (1ull << lane));
+        const int s0_ = upto ? 63 - __clzll((long long)upto) : 0;
+        const unsigned long long run_below = below & ~((1ull << s0_) - 1ull), run_incl = run_below | (1ull << lane);
+        const bool last = active && (lane == 63 || (((~mact | ms) >> (lane + 1)) & 1ull));
+        const int base_n = active ? sCnt[sl * 6] : 0, base_f = active ? sCnt[sl * 6 + 1] : 0;
+        if (active) {
+          double* bucket = ps.line_nd + ((long)slot * NEP_MAX_POL + sl) * sp.lines_cap * 3;
+          const long pos = far ? (long)sp.lines_cap - 1 - (base_f + __popcll(mf & run_below)) : (long)base_n + __popcll(mn & run_below);
           if (pos >= 0 && pos < sp.lines_cap) { bucket[3 * pos] = nd[0]; bucket[3 * pos + 1] = nd[1]; bucket[3 * pos + 2] = nd[2]; }
         }
         __syncthreads();
-        if (lane == 0) { sCnt[s_ * 6] = base_n + __popcll(mn); sCnt[s_ * 6 + 1] = base_f + __popcll(mf); sCnt[s_ * 6 + 2] += __popcll(mx); }
+        if (last) { sCnt[sl * 6] = base_n + __popcll(mn & run_incl); sCnt[sl * 6 + 1] = base_f + __popcll(mf & run_incl); sCnt[sl * 6 + 2] += __popcll(mx & run_incl); }
         __syncthreads();
       }
       SEP_PT(7);
@@ -1272,7 +1299,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   // below, whose state machine also serves the entangle rounds, cost 26 us for this).
   const bool ent_c = n_plain < total;
   int it_sg = seg_lo, it_r = 0;
-  if (!ent_c && lane < nsv) {      // attempted / skipped per segment, straight from the ballots
+  if (!ent_c && !reg_items && lane < nsv) {      // attempted / skipped per segment, straight from the ballots
     int na_ = 0, nk_ = 0;
     for (int r = 0; r < rounds; r++) { na_ += __popcll(sMask[((seg_lo + lane) * rounds + r) * 2]); nk_ += __popcll(sMask[((seg_lo + lane) * rounds + r) * 2 + 1]); }
     sCnt[(seg_lo + lane) * 6 + 3] = na_; sCnt[(seg_lo + lane) * 6 + 4] = nk_;
@@ -1281,26 +1308,30 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   // scan over the (segment, round) items, one per lane, then the entries are written item by item with nothing carried from one item
   // to the next; the serial walk below, an LDS round trip and a scalar chain per round, was 18 % of the wave's cycles)
   bool placed = false;
-  const int n_items = nsv > 0 ? nsv * rounds : 0;
-  if (!ent_c && n_items > 0 && n_items <= 64) {
-    int cnt_ = lane < n_items ? __popcll(sMask[(seg_lo * rounds + lane) * 2]) : 0;
-    const int incl_ = wave_incl_scan(cnt_);
+  if (reg_items) {
+    const int cnt_ = __popcll(my_a), cntk_ = __popcll(my_k);
+    const int incl_ = wave_incl_scan(cnt_), inclk_ = wave_incl_scan(cntk_);
     const int tot_ = __builtin_amdgcn_readlane(incl_, 63);
+    {      // attempted / skipped per segment: differences of the scans at the segments' last items (every lane takes part in the shuffles)
+      const int hi_ = lane < nsv ? (lane + 1) * rounds - 1 : 0, lo_ = (lane < nsv && lane > 0) ? lane * rounds - 1 : 0;
+      const int a_hi = __shfl(incl_, hi_), k_hi = __shfl(inclk_, hi_), a_lo = __shfl(incl_, lo_), k_lo = __shfl(inclk_, lo_);
+      if (lane < nsv) { sCnt[(seg_lo + lane) * 6 + 3] = a_hi - (lane > 0 ? a_lo : 0); sCnt[(seg_lo + lane) * 6 + 4] = k_hi - (lane > 0 ? k_lo : 0); }
+    }
     if (tot_ <= cap) {
-      __syncthreads();
-      if (lane < n_items) sMask[(seg_lo * rounds + lane) * 2 + 1] = (unsigned long long)(incl_ - cnt_);      // (the skip ballot has been counted: its place holds the item's offset)
-      __syncthreads();
-      int sg_ = seg_lo, r_ = 0;
+      const int sgi_ = lane / rounds, r_ = lane - sgi_ * rounds;      // this lane's item
+      const int cb_ = r_ < rh ? (r_ << 6) : (r_ < rh + rb ? cx.nH + ((r_ - rh) << 6) : cx.nH + cx.N + ((r_ - rh - rb) << 6));
+      const int ebase_ = ((seg_lo + sgi_) << 13) | cb_, off_ = incl_ - cnt_;
+      const unsigned alo_ = (unsigned)my_a, ahi_ = (unsigned)(my_a >> 32);
       for (int it = 0; it < n_items; it++) {
-        const ulonglong2 mo = *(const ulonglong2*)&sMask[(seg_lo * rounds + it) * 2];
-        const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)mo.x), mhi = __builtin_amdgcn_readfirstlane((unsigned)(mo.x >> 32));
-        const int off_ = __builtin_amdgcn_readfirstlane((int)mo.y);
-        const int cb_ = r_ < rh ? (r_ << 6) : (r_ < rh + rb ? cx.nH + ((r_ - rh) << 6) : cx.nH + cx.N + ((r_ - rh - rb) << 6));
+        const unsigned mlo = __builtin_amdgcn_readlane(alo_, it), mhi = __builtin_amdgcn_readlane(ahi_, it);
+        const int o_ = __builtin_amdgcn_readlane(off_, it), eb_ = __builtin_amdgcn_readlane(ebase_, it);
         const unsigned rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-        if ((((lane & 32) ? mhi : mlo) >> (lane & 31)) & 1u) sAtt[off_ + rank] = (unsigned short)((sg_ << 13) | (cb_ + lane));
-        if (++r_ == rounds) { r_ = 0; sg_++; }
+        if ((((lane & 32) ? mhi : mlo) >> (lane & 31)) & 1u) sAtt[o_ + rank] = (unsigned short)(eb_ + lane);
       }
       n_list = tot_; placed = true;
+    } else {      // (more LPs than the list holds at once: the ballots go to LDS for the serial walk below)
+      if (lane < n_items) { sMask[(seg_lo * rounds + lane) * 2] = my_a; sMask[(seg_lo * rounds + lane) * 2 + 1] = my_k; }
+      __syncthreads();
     }
   }
   while (more) {
@@ -1425,7 +1456,7 @@ void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, 
   const int total = sp.n_hull + sp.num_agents + sp.n_static + (sp.ent_enabled ? sp.num_agents * kBend : 0);
   // the packed kernel's list entries are (segment << 13 | candidate) in 16 bits: candidates beyond 8 191 (about 800 agents with the
   // entangle rows, 4 000 without) take the unpacked kernel, whose entries hold 65 535 (size_scratch refuses more)
-  if (ps.skip_box && ps.line_far && sp.sep_rule == 0 && sp.cull_radius > 0.0 && ps.sep_pack >= 0 && total <= 8191) {
+  if (((ps.skip_box && ps.line_far && sp.cull_radius > 0.0 && ps.sep_pack >= 0) || (sp.cull_radius == 0.0 && ps.sep_pack >= 1)) && sp.sep_rule == 0 && total <= 8191) {
     // (the wave's LDS stays within the 10 KB sixteen waves per CU allow: the pool of point sets takes what the tables leave, 64 x 8 pairs at least)
     const size_t rounds_ = (size_t)((sp.n_hull + 63) / 64 + (sp.num_agents + 63) / 64 + (sp.n_static + 63) / 64);
     const size_t extras = 15 * NEP_MAX_POL * sizeof(double) + 2 * NEP_MAX_POL * rounds_ * sizeof(unsigned long long) + 6 * NEP_MAX_POL * sizeof(int)
