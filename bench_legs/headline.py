@@ -405,6 +405,9 @@ def record(ctx, H):
         fp64["executed_flops_per_replan"] = ex_f["flops_per_launch"] / launch_replans
         fp64["executed_achieved"] = ex_f["flops_per_launch"] / (qp_ms * 1e-3) / 1e12
         fp64["executed_frac"] = fp64["executed_achieved"] / 78.6
+        if fp64["executed_frac"] > 1.0:      # (the committed counter summary is of another build's kernel — e.g. the every-row solve — than the one this run timed)
+            fp64["executed_note"] = "profiles/pmc_summary_latest.txt does not belong to this build's kernel (its instruction count over this run's duration exceeds the peak): ignored"
+            fp64["executed_achieved"] = None; fp64["executed_frac"] = None
         fp64["executed_mfma_share"] = ex_f["mfma_flops_per_launch"] / ex_f["flops_per_launch"] if ex_f["flops_per_launch"] > 0 else None
         fp64["executed_source"] = ex_f["source"]
     if world == 1:

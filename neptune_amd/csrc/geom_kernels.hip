@@ -796,6 +796,22 @@ __device__ bool cand_eval(const SepCtx& cx, int seg, int c, const double* bx, co
     const int e = c - nH - N - S;
     const int j = e / kBend, k = e % kBend + 1;
     if (j == cx.own) return false;
+    // (modes 1 and 2 are asked for LISTED candidates only — they passed the tests below in step 1 —: the vertex count is 2 without a
+    // read, and staging reads the two points alone: one round trip, two for k = 1, instead of the five of the chain of tests)
+    if (mode == 2) { nA = 2; return true; }
+    if (mode == 1) {
+      const HullRef hr1 = hull_ref(ps, N, cx.scene, j);
+      const double2* bp2 = (const double2*)(blk(ps.bend_xy, hr1.boff) + hr1.e * kBend * 2);
+      if (k == 1) {  // :719-724
+        const int nb1 = blk(ps.bend_n, hr1.boff)[hr1.e];
+        const double2 h0 = ((const double2*)blk(ps.hull0_xy, hr1.boff))[hr1.e * sp.num_pol + seg];
+        const double2 bl = bp2[nb1 - 1];
+        myA[0] = make_double2((1 - sp.long_length) * bl.x + sp.long_length * h0.x, (1 - sp.long_length) * bl.y + sp.long_length * h0.y);
+        myA[1] = h0;
+      } else { myA[0] = bp2[k - 2]; myA[1] = bp2[k - 1]; }  // :725-730
+      nA = 2;
+      return true;
+    }
     const int case_id = ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * N + j];
     const HullRef hr = hull_ref(ps, N, cx.scene, j);
     const int nb = blk(ps.bend_n, hr.boff)[hr.e];
@@ -1020,9 +1036,11 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 -> rows 2 and 3
   return v;
 }
-// entries of the packed kernel's LP list: a segment's worst case (the unpacked kernel's capacity), and room for what all eight segments
-// of a replan usually gather together (about 130 LPs at 64 agents + 20 obstacles), so that the list is placed in one go
-__host__ __device__ inline int sep_packed_cap(int total) { return total + 8 < 320 ? 320 : total + 8; }
+// entries of the packed kernel's LP list: what one segment's hulls, bases and statics can list at most (they are laid out a segment at
+// a time; a round of 64 entangle pairs fits as well), and room for what all eight segments of a replan usually gather together (about
+// 130 LPs at 64 agents + 20 obstacles), so that the list is placed in one go.  (Until round 6 the list had the unpacked kernel's
+// capacity, every candidate of a segment with the entangle pairs: 5.3 KB of a config-5 wave's LDS for a list of some 140 entries.)
+__host__ __device__ inline int sep_packed_cap(int n_plain) { return n_plain + 72 < 320 ? 320 : n_plain + 72; }
 #ifdef NEP_SEP_PROF
 __device__ unsigned long long g_sep_prof[16384 * 16];
 #define SEP_PT(k) do { const long long t_ = clock64(); pa_[k] += t_ - pt_; pt_ = t_; } while (0)
@@ -1031,7 +1049,7 @@ __device__ unsigned long long g_sep_prof[16384 * 16];
 #endif
 __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(SceneParams sp, ProblemSet ps, int pool_pairs, int kSepPack) {
 #ifdef NEP_SEP_PROF
-  long long pt_ = clock64(); long long pa_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long pt_ = clock64(); long long pa_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   const int kSepGroups = (NEP_MAX_POL + kSepPack - 1) / kSepPack;
   extern __shared__ __attribute__((aligned(16))) double sdyn[];
@@ -1041,7 +1059,9 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   double* sEl = sBy + 4 * NEP_MAX_POL;                // [segment][3] lengths of the control polygon's edges
   double* sBb = sEl + 3 * NEP_MAX_POL;                // [segment][4] box of the control points (x0, x1, y0, y1)
   unsigned long long* sMask = (unsigned long long*)(sBb + 4 * NEP_MAX_POL);      // [segment][round][2]: lanes whose candidate is an LP to solve / known to give a far line
-  int* sCnt = (int*)(sMask + 2 * NEP_MAX_POL * rounds);          // [segment][6]: near, far, failed, attempted, skipped (running)
+  const bool ent_any = sp.ent_enabled && ps.case_id;
+  unsigned long long* sEMask = sMask + 2 * NEP_MAX_POL * rounds;      // [segment][rb]: agents with an active entangle case (only with the entangle rows)
+  int* sCnt = (int*)(sEMask + (ent_any ? NEP_MAX_POL * rb : 0));          // [segment][6]: near, far, failed, attempted, skipped (running)
   unsigned short* sAtt = (unsigned short*)(sCnt + 6 * NEP_MAX_POL);      // entries (segment << 13 | candidate)
   const int lane = threadIdx.x;
   const int slot = blockIdx.x / kSepGroups, grp = blockIdx.x % kSepGroups;
@@ -1054,7 +1074,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   cx.total = cx.nH + cx.N + cx.S + ((sp.ent_enabled && ps.case_id) ? cx.N * kBend : 0);
   const bool cull = sp.cull_radius > 0.0 && ps.line_far != nullptr;      // (the line presolve: far lines parked at the back of the bucket)
   cx.skip_box = cull ? ps.skip_box : nullptr; cx.skip_r = sp.cull_radius;      // (the spatial presolve on top: LPs known to give a far line are not solved)
-  const int total = cx.total, cap = sep_packed_cap(total);
+  const int total = cx.total, cap = sep_packed_cap(cx.nH + cx.N + cx.S);
   int seg_end = seg_hi < K ? seg_hi : K; if (seg_end > sp.num_pol) seg_end = sp.num_pol;      // segments [seg_lo, seg_end) exist
   if (lane < 6 * NEP_MAX_POL) sCnt[lane] = 0;
   if (lane < 4 * (seg_hi - seg_lo)) {  // ctrlPtsInit_[seg] (solver_gurobi_poly.cpp:232-243)
@@ -1101,12 +1121,12 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       const bool valid0 = in && !(sp.skip_own && j == cx.own);
       if (cx.skip_box) {
         const double2* q = (const double2*)(cx.skip_box + ((long)cx.scene * (cx.N + cx.S) + (in ? j : 0)) * sp.num_pol * 4);
-        for (int s0 = seg_lo; s0 < seg_end; s0 += 4) {
-          double2 qa[4], qb[4];
+        for (int s0 = seg_lo; s0 < seg_end; s0 += 8) {
+          double2 qa[8], qb[8];
 #pragma unroll
-          for (int u = 0; u < 4; u++) { const int sg = s0 + u < seg_end ? s0 + u : seg_end - 1; qa[u] = q[sg * 2]; qb[u] = q[sg * 2 + 1]; }
+          for (int u = 0; u < 8; u++) { const int sg = s0 + u < seg_end ? s0 + u : seg_end - 1; qa[u] = q[sg * 2]; qb[u] = q[sg * 2 + 1]; }
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
+          for (int u = 0; u < 8; u++) {
             const int sg = s0 + u;
             if (sg < seg_end) {
               const double* bb = sBb + sg * 4;
@@ -1202,6 +1222,30 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       if (spr > 1) break;
     }
 #endif
+    if (ent_any) {      // agents with an active entangle case, per segment (:624-631): an agent's case ids of the wave's segments in one go
+      for (int j0 = 0; j0 < cx.N; j0 += 256) {      // (four rounds of agents x eight segments: 32 reads in flight)
+        for (int s0 = seg_lo; s0 < seg_end; s0 += 8) {
+          int cv[4][8];
+#pragma unroll
+          for (int w = 0; w < 4; w++) {
+            const int j = j0 + 64 * w + lane;
+            const int* cp = ps.case_id + ((long)cx.slot * NEP_MAX_POL + seg_lo) * cx.N + (j < cx.N ? j : 0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int sg = s0 + u < seg_end ? s0 + u : seg_end - 1; cv[w][u] = cp[(long)(sg - seg_lo) * cx.N]; }
+          }
+#pragma unroll
+          for (int w = 0; w < 4; w++) {
+            const int j = j0 + 64 * w + lane; const bool in = j < cx.N && j != cx.own;
+            if (j0 + 64 * w < cx.N) {
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                if (s0 + u < seg_end) { const unsigned long long m = __ballot(in && cv[w][u] != 0); if (lane == 0) sEMask[(s0 + u) * rb + ((j0 >> 6) + w)] = m; }
+              }
+            }
+          }
+        }
+      }
+    }
     SEP_PT(3);
   }
   __syncthreads();
@@ -1321,13 +1365,9 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       const int sgi_ = lane / rounds, r_ = lane - sgi_ * rounds;      // this lane's item
       const int cb_ = r_ < rh ? (r_ << 6) : (r_ < rh + rb ? cx.nH + ((r_ - rh) << 6) : cx.nH + cx.N + ((r_ - rh - rb) << 6));
       const int ebase_ = ((seg_lo + sgi_) << 13) | cb_, off_ = incl_ - cnt_;
-      const unsigned alo_ = (unsigned)my_a, ahi_ = (unsigned)(my_a >> 32);
-      for (int it = 0; it < n_items; it++) {
-        const unsigned mlo = __builtin_amdgcn_readlane(alo_, it), mhi = __builtin_amdgcn_readlane(ahi_, it);
-        const int o_ = __builtin_amdgcn_readlane(off_, it), eb_ = __builtin_amdgcn_readlane(ebase_, it);
-        const unsigned rank = __builtin_amdgcn_mbcnt_hi(mhi, __builtin_amdgcn_mbcnt_lo(mlo, 0u));
-        if ((((lane & 32) ? mhi : mlo) >> (lane & 31)) & 1u) sAtt[o_ + rank] = (unsigned short)(eb_ + lane);
-      }
+      // (every lane writes the entries of ITS item, one set bit after the other: as many rounds as the fullest ballot has bits,
+      // instead of one round per item)
+      { unsigned long long m_ = my_a; int o_ = off_; while (m_) { const int b_ = __builtin_ctzll(m_); m_ &= m_ - 1ull; sAtt[o_++] = (unsigned short)(ebase_ + b_); } }
       n_list = tot_; placed = true;
     } else {      // (more LPs than the list holds at once: the ballots go to LDS for the serial walk below)
       if (lane < n_items) { sMask[(seg_lo * rounds + lane) * 2] = my_a; sMask[(seg_lo * rounds + lane) * 2 + 1] = my_k; }
@@ -1360,37 +1400,102 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         for (int k = 0; k < 4; k++) cx.bb[k] = sBb[seg * 4 + k];
         n_att = 0; n_skip = 0; c0 = 0; ph = 1;
       }
-      if (ph == 1 && c0 >= rounds) { ph = n_plain < total ? 2 : 4; continue; }
       if (ph == 3 && c0 >= n_act * kBend) { ph = 4; continue; }
-      if (ph != 2 && n_list > 0 && n_list + 64 > cap) break;      // (the round might not fit: what has been gathered is solved first; a round alone always fits)
+      if (ph == 3 && n_list > 0 && n_list + 64 > cap) break;      // (the round might not fit: what has been gathered is solved first; a round alone always fits)
       if (ph == 1) {
-        const unsigned long long mask = sMask[(seg * rounds + c0) * 2], msk = sMask[(seg * rounds + c0) * 2 + 1];
-        const int c = c0 < rh ? (c0 << 6) + lane : (c0 < rh + rb ? cx.nH + ((c0 - rh) << 6) + lane : cx.nH + cx.N + ((c0 - rh - rb) << 6) + lane);
-        if ((mask >> lane) & 1ull) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | c);
-        n_list += __popcll(mask); n_att += __popcll(mask);
-        n_skip += __popcll(msk);
-        c0++;
-      } else if (ph == 2) {      // entangle candidates (agent j, bend segment k): the agents with an active case first, then their pairs densely
+        // the segment's plain candidates (hulls, bases, statics) from step 1a's ballots: lane r takes round r's ballot and writes its
+        // entries one set bit after the other, at the place a scan of the rounds' counts gives it (the serial form — a round per turn of
+        // this loop, ballots through LDS and the scalar unit — was 30 % of the wave's cycles at config 5, 80 rounds a replan)
+        int tot_seg = 0, skip_seg = 0;
+        for (int r0 = 0; r0 < rounds; r0 += 64) {
+          const int r = r0 + lane;
+          const unsigned long long m0 = r < rounds ? sMask[(seg * rounds + r) * 2] : 0ull, k0_ = r < rounds ? sMask[(seg * rounds + r) * 2 + 1] : 0ull;
+          tot_seg += __builtin_amdgcn_readlane(wave_incl_scan(__popcll(m0)), 63); skip_seg += __builtin_amdgcn_readlane(wave_incl_scan(__popcll(k0_)), 63);
+        }
+        if (n_list > 0 && n_list + tot_seg > cap) break;      // (a segment's plain candidates always fit an empty list)
+        for (int r0 = 0; r0 < rounds; r0 += 64) {
+          const int r = r0 + lane;
+          unsigned long long m_ = r < rounds ? sMask[(seg * rounds + r) * 2] : 0ull;
+          const int cnt_ = __popcll(m_), incl_ = wave_incl_scan(cnt_);
+          const int cb_ = r < rh ? (r << 6) : (r < rh + rb ? cx.nH + ((r - rh) << 6) : cx.nH + cx.N + ((r - rh - rb) << 6));
+          int o_ = n_list + incl_ - cnt_;
+          while (m_) { const int b_ = __builtin_ctzll(m_); m_ &= m_ - 1ull; sAtt[o_++] = (unsigned short)(tag | (cb_ + b_)); }
+          n_list += __builtin_amdgcn_readlane(incl_, 63);
+        }
+        n_att += tot_seg; n_skip += skip_seg;
+        ph = n_plain < total ? 2 : 4;
+      } else if (ph == 2) {      // entangle candidates (agent j, bend segment k): the agents with an active case first (step 1a's ballots), then their pairs densely
+        SEP_PT(4);
         n_act = 0;
         __syncthreads();
-        for (int j0 = 0; j0 < cx.N; j0 += 64) {
-          const int j = j0 + lane;
-          const bool act = j < cx.N && j != cx.own && ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * cx.N + j] != 0;
-          const unsigned long long mask = __ballot(act);
-          if (act) sAct[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)j;
+        for (int ch = 0; ch < rb; ch++) {
+          const unsigned long long mask = sEMask[seg * rb + ch];
+          if ((mask >> lane) & 1ull) sAct[n_act + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)((ch << 6) + lane);
           n_act += __popcll(mask);
         }
         __syncthreads();
         ph = 3; c0 = 0;
+        SEP_PT(9);
       } else {
-        const int pp = c0 + lane;
-        int nA; int ord; const double2* unused = nullptr;
-        const int c = pp < n_act * kBend ? n_plain + (int)sAct[pp / kBend] * kBend + (pp % kBend) : 0;
-        const bool att = pp < n_act * kBend && cand_eval(cx, seg, c, bx, by, hulldist, 0, nullptr, nA, ord, unused);
-        const unsigned long long mask = __ballot(att);
-        if (att) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | c);
-        n_list += __popcll(mask); n_att += __popcll(mask);
-        c0 += 64;
+        SEP_PT(4);
+        // up to four rounds of (agent, bend segment) pairs at a time: what a pair reads — the agent's case id, its bend count, the two bend
+        // points (or, for k = 1, col(0) of its uninflated hull) — is requested for all four rounds before the first is looked at, then the
+        // one dependent read (k = 1: the last bend point, at index nb - 1); cand_eval's chain of tests in between used to make every
+        // one of them a round trip of its own, four to five per round and thirty-odd rounds per replan at config 5
+        const int n_pairs = n_act * kBend;
+        int nr = (n_pairs - c0 + 63) >> 6; if (nr > 4) nr = 4;
+        while (nr > 1 && n_list + 64 * nr > cap) nr--;      // (every round of the group must fit the list; one round always does)
+        int cid[4], nbv[4], h0n[4], jj[4]; double2 X[4], Y[4], Z[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int pp = c0 + 64 * u + lane; const bool in = u < nr && pp < n_pairs;
+          const int j = in ? (int)sAct[pp / kBend] : 0, k = pp % kBend + 1;
+          jj[u] = j;
+          const HullRef hr = hull_ref(ps, cx.N, cx.scene, j);
+          cid[u] = ps.case_id[((long)cx.slot * NEP_MAX_POL + seg) * cx.N + j];
+          nbv[u] = blk(ps.bend_n, hr.boff)[hr.e];
+          const double2* bp = (const double2*)(blk(ps.bend_xy, hr.boff) + hr.e * kBend * 2);
+          const long h0 = hr.e * sp.num_pol + seg;
+          h0n[u] = blk(ps.hull0_nv, hr.boff)[h0];
+          X[u] = k == 1 ? ((const double2*)blk(ps.hull0_xy, hr.boff))[h0] : bp[k - 2];
+          Y[u] = bp[k - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int pp = c0 + 64 * u + lane; const int k = pp % kBend + 1;
+          const HullRef hr = hull_ref(ps, cx.N, cx.scene, jj[u]);
+          const double2* bp = (const double2*)(blk(ps.bend_xy, hr.boff) + hr.e * kBend * 2);
+          int nbc = nbv[u]; if (nbc < 1) nbc = 1; if (nbc > kBend) nbc = kBend;
+          Z[u] = bp[k == 1 ? nbc - 1 : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          if (u < nr) {
+            const int pp = c0 + 64 * u + lane; const int k = pp % kBend + 1;
+            bool att = pp < n_pairs && cid[u] != 0 && k != cid[u] && k <= nbv[u];      // :631-636
+            double pAx, pAy, pBx, pBy;
+            if (k == 1) {  // :719-724
+              att = att && h0n[u] > 0;
+              pAx = (1 - sp.long_length) * Z[u].x + sp.long_length * X[u].x; pAy = (1 - sp.long_length) * Z[u].y + sp.long_length * X[u].y;
+              pBx = X[u].x; pBy = X[u].y;
+            } else { pAx = X[u].x; pAy = X[u].y; pBx = Y[u].x; pBy = Y[u].y; }  // :725-730
+            const double ax_ = pAx - bx[0], ay_ = pAy - by[0], bx_ = pBx - bx[0], by_ = pBy - by[0];
+            // :743-745  sqrt(d^2) - hulldist > 0 for both points.  The difference of two doubles is positive exactly when the first is the
+            // larger, and the rounded root exceeds hulldist for every d^2 above hulldist^2 (1 + 1e-12), never below hulldist^2 (1 - 1e-12) (a
+            // margin of ten thousand roundings): the two roots are only taken when a lane of the round falls in between
+            const double d2a = ax_ * ax_ + ay_ * ay_, d2b = bx_ * bx_ + by_ * by_;
+            const double h2 = hulldist * hulldist, h2hi = h2 * (1.0 + 1e-12), h2lo = h2 * (1.0 - 1e-12);
+            bool ga = d2a > h2hi, gb = d2b > h2hi;
+            if (__ballot(att && ((!ga && !(d2a < h2lo)) || (!gb && !(d2b < h2lo)))) != 0ull) { ga = sqrt(d2a) - hulldist > 0; gb = sqrt(d2b) - hulldist > 0; }
+            if (att && ga && gb) att = false;
+            const int c = n_plain + jj[u] * kBend + (k - 1);
+            const unsigned long long mask = __ballot(att);
+            if (att) sAtt[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)(tag | c);
+            n_list += __popcll(mask); n_att += __popcll(mask);
+          }
+        }
+        c0 += 64 * nr;
+        SEP_PT(10);
       }
     }
     flush();
@@ -1409,7 +1514,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   }
   SEP_PT(8);
 #ifdef NEP_SEP_PROF
-  if (lane == 0 && blockIdx.x < 16384) { for (int k = 0; k < 9; k++) g_sep_prof[blockIdx.x * 16 + k] += (unsigned long long)pa_[k]; g_sep_prof[blockIdx.x * 16 + 15] += 1ull; }
+  if (lane == 0 && blockIdx.x < 16384) { for (int k = 0; k < 12; k++) g_sep_prof[blockIdx.x * 16 + k] += (unsigned long long)pa_[k]; g_sep_prof[blockIdx.x * 16 + 15] += 1ull; }
 #endif
 }
 #ifdef NEP_SEP_PROF
@@ -1460,8 +1565,9 @@ void launch_separator(int n_slots, const SceneParams& sp, const ProblemSet& ps, 
     // (the wave's LDS stays within the 10 KB sixteen waves per CU allow: the pool of point sets takes what the tables leave, 64 x 8 pairs at least)
     const size_t rounds_ = (size_t)((sp.n_hull + 63) / 64 + (sp.num_agents + 63) / 64 + (sp.n_static + 63) / 64);
     const size_t extras = 15 * NEP_MAX_POL * sizeof(double) + 2 * NEP_MAX_POL * rounds_ * sizeof(unsigned long long) + 6 * NEP_MAX_POL * sizeof(int)
-                          + (size_t)(sep_packed_cap(total) + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short);
-    size_t pool_b = extras + 64 * 8 * 16 <= (size_t)kSepLdsTarget ? (size_t)kSepLdsTarget - extras : (size_t)64 * 8 * 16;
+                          + ((sp.ent_enabled && ps.case_id) ? (size_t)NEP_MAX_POL * ((sp.num_agents + 63) / 64) * sizeof(unsigned long long) : 0)
+                          + (size_t)(sep_packed_cap(sp.n_hull + sp.num_agents + sp.n_static) + (sp.ent_enabled ? sp.num_agents : 0)) * sizeof(unsigned short);
+    size_t pool_b = extras + 64 * 6 * 16 <= (size_t)kSepLdsTarget ? (size_t)kSepLdsTarget - extras : (size_t)64 * 6 * 16;
     pool_b &= ~(size_t)15;
     const int pairs = (int)(pool_b / 16);
     const size_t lds_p = (pool_b + extras + 15) & ~(size_t)15;
