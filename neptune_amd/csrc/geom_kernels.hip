@@ -348,8 +348,16 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
                                                         double* __restrict__ hull_xy, int* __restrict__ hull_nv,
                                                         double* __restrict__ hull0_xy, int* __restrict__ hull0_nv,
                                                         double* __restrict__ bend_xy, int* __restrict__ bend_n, int* __restrict__ flags) {
+  // LDS of a wave: the groups' sorted points (8 KB) and their control points (2 KB, read again after the hull by the uninflated hull
+  // of the entangle rows).  The knot vector lives in the last group's point area — it is dead before the first point is stored — so
+  // that the wave takes exactly 10 KB: sixteen waves per CU, and the 8 192 waves of a 128-scene launch are two full rounds (with the
+  // 144 bytes of a knot array of its own the CU held fifteen, and the launch was two rounds and a nearly empty third: 0.110 -> 0.099 ms)
+  // (measured too: the control points in their group's point area as well — 8 KB a wave, twenty waves per CU, 1.6 rounds: 0.116 ms,
+  // slower than both; sixteen waves and two full rounds it is)
   __shared__ __attribute__((aligned(16))) double s_sxy[8][kGrpSxy];
-  __shared__ double s_cpx[8][kHullCP], s_cpy[8][kHullCP], stimes[NEP_TRAJ_MAX_SEG + 2];
+  __shared__ double s_cpx[8][kHullCP], s_cpy[8][kHullCP];
+  double* stimes = &s_sxy[7][0];
+  static_assert(NEP_TRAJ_MAX_SEG + 2 <= kGrpSxy, "the knot vector borrows a group's point area");
   const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
   const int jt = blockIdx.x;                      // scene * n_rec + j
   const int scene = jt / n_rec_per_scene;
