@@ -338,8 +338,11 @@ def test_sharded_hull_blocks_equal_the_single_rank_replan(be, world, entangle):
     full.close()
 
 
-@pytest.mark.parametrize("n_agents,n_static,seed,ent", [(64, 20, 31, False), (5, 0, 32, False), (24, 12, 33, True)])
-def test_packed_separator_gives_the_unpacked_kernels_lines(be, n_agents, n_static, seed, ent):
+@pytest.mark.parametrize("n_agents,n_static,seed,ent,radius", [(64, 20, 31, False, 2.0), (5, 0, 32, False, 2.0), (24, 12, 33, True, 2.0),
+                                                               (64, 40, 34, False, 2.0),      # more than 32 static polygons: one segment of them per round of lanes
+                                                               (64, 20, 35, False, 500.0),    # nothing is far: every LP of the eight segments is listed — more than the list holds at once
+                                                               (40, 36, 36, True, 6.0)])
+def test_packed_separator_gives_the_unpacked_kernels_lines(be, n_agents, n_static, seed, ent, radius):
     """separator_packed_kernel (the spatial presolve's separator: several segments of a slot per wave, LPs solved 64 to a batch
     across the segments) against separator_kernel<0> on the same launch: every line bucket (near lines in call order, parked lines
     from the end), every count and every solution byte for byte — with 1, 3 and 8 segments per wave (the host picks by launch
@@ -350,7 +353,7 @@ def test_packed_separator_gives_the_unpacked_kernels_lines(be, n_agents, n_stati
     N = p.num_agents
     case = scene.synthetic_entangle(sc, seed=700 + seed, frac=0.3) if ent else None
     bb = be.BatchBackend(p, sc["statics"])
-    bb.set_line_cull(2.0)
+    bb.set_line_cull(radius)
     d_com = bb.to_device(sc["committed"]); d_gue = bb.to_device(sc["guesses"])
     d_ent = bb.torch.from_numpy(np.ascontiguousarray(case).reshape(-1)).to(bb.device) if ent else None
 
