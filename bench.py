@@ -54,6 +54,10 @@ def parse_args(argv=None):
                          "(same box, 50 steps): 1 group 16.65 M replans/s, 2 groups 17.00 M, 4 groups 11.5 M, 8 groups 8.5 M — every group's "
                          "interior-point launch keeps its own tail of long solves, so the overlap buys 2 % at best; with G > 1 the one-sequence "
                          "step is reported as `one_stream`")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="with --groups G: the groups' rounds PIPELINED on streams instead of forked and joined inside one graph per step — the geometry halves "
+                         "(nep_batch_replan_lines) of all groups in turn on one stream, each group's QP half (nep_batch_replan_solve) on the group's own stream, "
+                         "ordered by events only; host-launched (DESIGN section 16)")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N > 1 with --exchange hulls: scene chunks pipelined so that one chunk's all-gather overlaps the other's kernels")
     ap.add_argument("--presolve-radius", type=float, default=4.0, help="(older command lines; the presolve is the handle's default since round 6: ignored)")
@@ -129,6 +133,9 @@ def run_config4(ctx):
     Hc = headline.full_handle_view(ctx, H) if (extra and (H.C == 1 or H.G > 1)) else None
     if Hc is not None and H.G > 1:
         legs["one_stream"] = headline.one_stream_leg(ctx, H, Hc)
+        if getattr(H, "PIPE", False):      # (per-kernel HIP events belong to ONE launch sequence: the pipelined groups overlap, so the line's kernel_ms are the one-stream leg's)
+            k1 = legs["one_stream"]["kernel_ms"]
+            H.hull_ms, H.sep_ms, H.qp_ms, H.seq_ms = k1["hull"], k1["separator"], k1["qp"], k1["sequence"]
     if Hc is not None and not args.no_chain:
         legs["chain"], legs["moving"], legs["crossing"] = chain_legs.run(ctx, Hc)
     if extra:
@@ -143,7 +150,14 @@ def run_config4(ctx):
         return None
     out = headline.record(ctx, H)
     mv, cr = legs.get("moving"), legs.get("crossing")
-    out["what_value_is"] = (("%d scene groups on %d HIP streams inside one captured graph per step (one_stream: the same step as one launch sequence); " % (H.G, H.G) if H.G > 1 else "") +
+    if H.G > 1 and getattr(H, "PIPE", False):
+        how = ("%d scene groups PIPELINED on streams (the geometry halves in turn on one stream, each group's QP half on its own, ordered by events only; every "
+               "step is one round of every group, all of them inside the timed region; kernel_ms and one_stream: the same step as one launch sequence); " % H.G)
+    elif H.G > 1:
+        how = "%d scene groups on %d HIP streams inside one captured graph per step (one_stream: the same step as one launch sequence); " % (H.G, H.G)
+    else:
+        how = ""
+    out["what_value_is"] = (how +
                             "throughput of %d INDEPENDENT scenes in flight on the handle's default solve path (verified line presolve + polish; full_rows has every row "
                             "through the interior point), QP workgroups ordered by the previous step's measured times (exact here: the same problems every step).  The representative figures are the closed-loop legs, "
                             "where every step poses new problems from device-made guesses: moving %s replans/s, crossing (the whole fleet through the middle) %s "

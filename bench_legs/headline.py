@@ -125,7 +125,34 @@ def setup(ctx, c5=None):
         for k in range(C):
             cur.wait_stream(g_streams[k])
 
+    PIPE = G > 1 and getattr(args, "pipeline", False)
+    if PIPE:
+        s_geo = torch.cuda.Stream(device=dev)
+        s_qp = [torch.cuda.Stream(device=dev, priority=-1) for _ in range(C)]
+        e_geo = [torch.cuda.Event() for _ in range(C)]; e_qp = [torch.cuda.Event() for _ in range(C)]
+        for k in range(C):
+            e_qp[k].record(torch.cuda.current_stream(dev))
+
+    def step_pipelined():
+        """every group one round: lines(k) on the geometry stream once solve(k) of the previous round is done, solve(k) on the group's stream
+        once its lines are there; nothing else orders the groups (the leg's barriers synchronise the device)"""
+        for k in range(C):
+            bes[k].enable_timing(False)
+            s_geo.wait_event(e_qp[k])
+            with torch.cuda.stream(s_geo):
+                bes[k].replan_lines(d_com_g[k], d_guess_c[k])
+                e_geo[k].record(s_geo)
+            s_qp[k].wait_event(e_geo[k])
+            with torch.cuda.stream(s_qp[k]):
+                bes[k].replan_solve(d_com_g[k], d_guess_c[k])
+                ex_g[k].gather(bes[k].d_commit, d_com_g[k])
+                e_qp[k].record(s_qp[k])
+        torch.cuda.current_stream(dev).wait_event(e_geo[C - 1])      # (the per-step events of the timed region follow the geometry stream)
+
     def step():
+        if PIPE:
+            step_pipelined()
+            return
         if G > 1:
             step_groups()
             return
@@ -165,8 +192,8 @@ def setup(ctx, c5=None):
                       all_statics=all_statics, statics=statics, com=com, gue=gue, sharded_hulls=sharded_hulls, native=native,
                       bes=bes, be=be, d_committed=d_committed, d_guess=d_guess, ex=ex, rounds=rounds, nranks=nranks, step=step,
                       safety_ev=safety_ev, hull_ev=hull_ev, gather_ev=gather_ev, fe_ev=fe_ev, d_fe_res=d_fe_res, d_accept=d_accept,
-                      graph_plain=can_graph and not args.frontend and not args.safety, replans_per_step=S * N, rccl_one_rank_ok=None,
-                      G=G, d_com_g=d_com_g, d_guess_c=d_guess_c)
+                      graph_plain=can_graph and not args.frontend and not args.safety and not PIPE, replans_per_step=S * N, rccl_one_rank_ok=None,
+                      G=G, d_com_g=d_com_g, d_guess_c=d_guess_c, PIPE=PIPE)
     return H
 
 
@@ -413,7 +440,9 @@ def record(ctx, H):
     if world == 1:
         sharding = "one GPU: all %d agents of every scene" % N
         if H.G > 1:
-            sharding += "; the %d scenes in flight run as %d groups of %d scenes, each group a launch sequence on its own HIP stream, all inside one captured graph per step" % (S, H.G, Sc)
+            sharding += ("; the %d scenes in flight run as %d groups of %d scenes, pipelined on streams: the groups' geometry halves in turn on one stream, each group's QP half on its own, ordered by events" % (S, H.G, Sc)
+                         if getattr(H, "PIPE", False) else
+                         "; the %d scenes in flight run as %d groups of %d scenes, each group a launch sequence on its own HIP stream, all inside one captured graph per step" % (S, H.G, Sc))
     elif H.sharded_hulls:
         sharding = ("agents of every scene block-sharded by id, %d per GPU; per step and scene chunk (%d chunks, pipelined) one all-gather "
                     "(RCCL, %s) of the interval hulls of the local agents' committed trajectories (%d B per agent and scene)"
@@ -430,7 +459,7 @@ def record(ctx, H):
                                % (N, M, args.scenes, S - 1, world, "" if world == 1 else "s",
                                   (("the handle's default solve path: verified line presolve %g m, polish on" % cull_m) if cull_m > 0.0 else
                                    "line presolve off: every separating-line row through the interior point, polish on")
-                                  + ("; %d scene groups on %d HIP streams" % (H.G, H.G) if H.G > 1 else "")),
+                                  + (("; %d scene groups pipelined on streams" % H.G) if getattr(H, "PIPE", False) else ("; %d scene groups on %d HIP streams" % (H.G, H.G) if H.G > 1 else ""))),
                    "agents": N, "obstacles": M, "scenes_in_flight": S, "scenes_per_gpu": args.scenes,
                    "replans_per_step": H.replans_per_step, "replans_per_gpu_per_step": S * n_local,
                    "sharding": sharding, "scene_groups": H.G,
@@ -463,7 +492,8 @@ def record(ctx, H):
         "kernel_ms": {"hull": hull_ms, "separator": sep_ms, "qp": qp_ms, "sequence": seq_ms, "exchange_wait": ctx.mean_ms(H.gather_ev),
                       "launches": H.n_launch, "launches_per_step": C},
         "launch": ("one captured HIP graph per step, replayed (per-kernel events from %d eager steps after the timed region)" % min(args.steps, 40)
-                   if H.graph is not None else ("; ".join(ctx.graph_notes) or "host launches")),
+                   if H.graph is not None else ("host launches: two enqueues per scene group and step (nep_batch_replan_lines / _solve) on the groups' streams"
+                                                if getattr(H, "PIPE", False) else ("; ".join(ctx.graph_notes) or "host launches"))),
         "frontend": ({"ms": ctx.mean_ms(H.fe_ev), "beam_width": args.beam,
                       "status_goal_reached": int((fe_res["status"] == 1).sum()), "status_no_solution": int((fe_res["status"] == 3).sum()),
                       "children_mean": float(fe_res["n_children"].mean())} if args.frontend else None),
