@@ -1024,15 +1024,25 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_kernel(SceneParam
   separator_body<RULE>(sp, ps, pool_pairs, blockIdx.x / NEP_MAX_POL, blockIdx.x % NEP_MAX_POL, true);
 }
 // The spatial presolve's separator (launched instead of separator_kernel<0> when LPs may be skipped, ps.skip_box != null): one wave
-// takes kSepPack consecutive segments of a slot (all eight in a large launch).  With the skipping a segment is left with a dozen or two LPs (17 on average at
-// config 5) — a quarter of a wave's lanes, and an LP batch costs the same whatever its fill — so step 1 runs for the wave's
-// segments one after the other, appending (segment, candidate) entries to ONE list, and the LPs are then solved 64 to a batch
-// across the segments: three batches per slot instead of eight.  Same candidates, same culls, same per-LP arithmetic and the same
-// order within every segment as separator_body (lines and counts are bit-identical: the presolve tests compare them); a lane's
-// segment only enters through its control points (LDS) and the hull interval.  The list has the unpacked kernel's capacity: when
-// a round of candidates might not fit, what has been gathered is solved first.
+// takes kSepPack consecutive segments of a slot (all eight in a large launch).  With the skipping a segment is left with a dozen or
+// two LPs (17 on average at config 5) — a quarter of a wave's lanes, and an LP batch costs the same whatever its fill — so the LPs of
+// the wave's segments go to ONE list of (segment, candidate) entries, segment-major, and are solved 64 to a batch across the
+// segments: three batches per slot instead of eight.  Same candidates, same culls, same per-LP arithmetic and the same order within
+// every segment as separator_body (lines and counts are bit-identical: the presolve tests compare them).
+// Round 6 — the kernel is bound by instruction issue at four waves per SIMD (every 1 000 instructions of a wave
+// are 17 us of an 8 192-wave launch) once its loads stop being serial round trips:
+//   step 1a  which candidates are LPs, CANDIDATE-major: what a lane reads of its candidate (a hull's eight boxes, a base, a static
+//            polygon's first vertex / edges / box, an agent's eight case ids) is loaded once, every load of a round in flight, then
+//            tested against each segment's control points (LDS); the verdicts are ballots per (segment, round of 64 candidates),
+//            kept by lanes (one item per lane) when they fit, in LDS otherwise;
+//   step 1b  the list: a DPP scan over the items' counts gives every item its place, and every lane writes its own item's entries
+//            one set bit after the other (with entangle candidates: per segment, followed by the segment's (agent, bend segment)
+//            pairs, four rounds of pairs at a time with their reads issued first); when the list cannot hold what is gathered, what
+//            is there is solved first (one call site of the LP code);
+//   step 2   64 LPs a batch: point sets staged at a DPP prefix sum of the vertex counts, separator_impl, line placement by the
+//            runs of a segment's lanes.
 // (segments per wave, chosen by the host from the launch's size — 2: 0.555, 3: 0.511, 4: 0.497, 8: 0.488 ms per 8 192 config-5
-// replans against 0.639 unpacked; small launches keep more, shorter waves)
+// replans against 0.639 unpacked, measured before the round-6 work; small launches keep more, shorter waves)
 // inclusive prefix sum of an int over the wave's 64 lanes in the data-parallel-primitive moves of gfx9: four shifts within the rows of 16,
 // then lane 15 of a row to the next row and lane 31 to the upper half (eight moves; the ds_bpermute form is six LDS-crossbar round trips)
 __device__ __forceinline__ int wave_incl_scan(int v) {
@@ -1112,8 +1122,8 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   // segments in turn, four waves per SIMD to hide them — was two thirds of the kernel's time (0.097 of 0.144 ms per 8 192 replans).
   const int nsv = seg_end - seg_lo;
   // The ballots of a (segment, round) item: kept by lane `item` in two registers when the wave's items fit its lanes and there are no
-  // entangle candidates (then the list is laid out from the registers: a scan, and one v_readlane per item instead of an LDS round
-  // trip); in LDS otherwise ([segment][round][2]).
+  // entangle candidates (then the list is laid out from the registers: a scan over the items' counts, every lane writing its own
+  // item's entries); in LDS otherwise ([segment][round][2]).
   const int n_items = nsv > 0 ? nsv * rounds : 0;
   const bool reg_items = cx.total == cx.nH + cx.N + cx.S && n_items <= 64;
   unsigned long long my_a = 0ull, my_k = 0ull;
@@ -1123,7 +1133,6 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   };
   if (nsv > 0) {
     const double rr = cx.skip_r;
-#if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 1)
     for (int c0 = 0; c0 < cx.nH; c0 += 64) {      // interval hulls: decided by their boxes alone (empty: x0 = +inf, never called)
       const int j = c0 + lane; const bool in = j < cx.nH;
       const bool valid0 = in && !(sp.skip_own && j == cx.own);
@@ -1154,15 +1163,13 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
         }
       }
     }
-#endif
     SEP_PT(1);
-#if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 2)
     for (int j0 = 0; j0 < cx.N; j0 += 64) {      // bases (:521-553): within 3 x 0.7 m of one of the four control points
       const int j = j0 + lane; const bool in = j < cx.N;
       constexpr double base_radius = 0.7;
       const double pbx = ps.pb[2 * (in ? j : 0)], pby = ps.pb[2 * (in ? j : 0) + 1];
       for (int sg = seg_lo; sg < seg_end; sg++) {
-        const double* bx_ = sBx + sg * 4; const double* by_ = sBy + sg * 4; const double* bb = sBb + sg * 4;
+        const double* bx_ = sBx + sg * 4; const double* by_ = sBy + sg * 4;
         // cand_eval's test — sqrt(d^2) < 3 x 0.7 for one of the four control points, behind its two coarse "farther than 2.2 m along an axis"
         // exits — without the square roots: for a correctly rounded square root, sqrt(x) < 0.7 * 3 (= 0x1.0ccccccccccccp+1) exactly when
         // x < kBaseNear2, the smallest double whose root rounds to that or more; a point within that distance passes both coarse tests
@@ -1173,14 +1180,11 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
 #pragma unroll
         for (int k = 0; k < 4; k++) { const double ddx = bx_[k] - pbx, ddy = by_[k] - pby; close_to_base |= ddx * ddx + ddy * ddy < kBaseNear2; }
         close_to_base &= in;
-        (void)bb;
         const unsigned long long ma = __ballot(close_to_base);
         put_mask(sg, rh + (j0 >> 6), ma, 0ull);
       }
     }
-#endif
     SEP_PT(2);
-#if !defined(NEP_SEP_SKIPA) || !(NEP_SEP_SKIPA & 4)
     // static polygons (:556-593): the perimeter cull, then the box.  With S <= 32 polygons a round of lanes takes 64 / S SEGMENTS of
     // them (lane = segment-in-round x S + polygon: 20 obstacles, three segments a round — three rounds instead of eight a third full)
     const int spr = (cx.S > 0 && cx.S <= 32) ? 64 / cx.S : 1;      // segments per round
@@ -1229,7 +1233,6 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
       }
       if (spr > 1) break;
     }
-#endif
     if (ent_any) {      // agents with an active entangle case, per segment (:624-631): an agent's case ids of the wave's segments in one go
       for (int j0 = 0; j0 < cx.N; j0 += 256) {      // (four rounds of agents x eight segments: 32 reads in flight)
         for (int s0 = seg_lo; s0 < seg_end; s0 += 8) {
@@ -1262,9 +1265,6 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
   auto flush = [&]() {
     __syncthreads();
     SEP_PT(4);
-#if defined(NEP_SEP_EXP) && NEP_SEP_EXP == 2
-    n_list = 0;
-#endif
     for (int a0 = 0; a0 < n_list; a0 += 64) {
       const int a = a0 + lane;
       const bool active = a < n_list;
@@ -1288,11 +1288,7 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
 #ifdef NEP_SEP_PROF
         SEP_PT(5);
 #endif
-#if defined(NEP_SEP_EXP) && NEP_SEP_EXP == 1
-        nd[0] = Ause[0].x; nd[1] = Ause[nA - 1].y; nd[2] = B4.x[0];
-#else
         ok = separator_impl(nA, Ause, ord, B4, nd);
-#endif
 #ifdef NEP_SEP_PROF
         SEP_PT(6);
 #endif
@@ -1331,21 +1327,15 @@ __global__ __launch_bounds__(64, NEP_SEP_WAVES) void separator_packed_kernel(Sce
     }
     n_list = 0;
   };
-  // ---- step 1, segment by segment: which LPs does the reference call, in order (as separator_body with the spatial presolve) ----
-  // Written as ONE loop over candidate rounds — (segment, kind of candidate, first candidate) advance as wave-uniform state — with ONE
-  // call site of flush(): the lambda is inlined, and with a call site in each of the three round loops plus the final one the kernel
-  // carried four copies of the LP code (9 300 VALU instructions, more than the instruction cache two CUs share).
+  // ---- step 1b: the list of LPs from the ballots, segment-major, the reference's call order within a segment; ONE call site of flush()
+  // (the lambda is inlined: with a call site in each round loop the kernel once carried four copies of the LP code, 70 KB)
   int seg = seg_lo - 1, ph = 4, c0 = 0, n_att = 0, n_skip = 0, n_act = 0;      // ph: 1 the ballots of step 1a, 2 entangle agents, 3 entangle pairs, 4 next segment
   const int n_plain = cx.nH + cx.N + cx.S;
   const double* bx = sBx; const double* by = sBy;
   double hulldist = 0;
   int tag = 0;
   unsigned short* sAct = sAtt + cap;
-#if defined(NEP_SEP_SKIPA) && (NEP_SEP_SKIPA & 8)
-  bool more = false;
-#else
   bool more = true;
-#endif
   // Without entangle candidates the list is the ballots read out in (segment, round) order: a flat walk, a few instructions a round
   // (the kernel is bound by instruction issue — every 1 000 instructions of a wave are 17 us of the launch —, and the general walk
   // below, whose state machine also serves the entangle rounds, cost 26 us for this).
