@@ -341,7 +341,8 @@ def test_sharded_hull_blocks_equal_the_single_rank_replan(be, world, entangle):
 @pytest.mark.parametrize("n_agents,n_static,seed,ent,radius", [(64, 20, 31, False, 2.0), (5, 0, 32, False, 2.0), (24, 12, 33, True, 2.0),
                                                                (64, 40, 34, False, 2.0),      # more than 32 static polygons: one segment of them per round of lanes
                                                                (64, 20, 35, False, 500.0),    # nothing is far: every LP of the eight segments is listed — more than the list holds at once
-                                                               (40, 36, 36, True, 6.0)])
+                                                               (40, 36, 36, True, 6.0),
+                                                               (200, 20, 37, False, 4.0)])    # 72 (segment, round) items: more than a wave's lanes — the ballots go through LDS, the list is walked serially
 def test_packed_separator_gives_the_unpacked_kernels_lines(be, n_agents, n_static, seed, ent, radius):
     """separator_packed_kernel (the spatial presolve's separator: several segments of a slot per wave, LPs solved 64 to a batch
     across the segments) against separator_kernel<0> on the same launch: every line bucket (near lines in call order, parked lines
