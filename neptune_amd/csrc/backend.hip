@@ -159,6 +159,7 @@ struct Engine {
   // nep_batch_reserve_row_scratch asks for the worst case.
   static constexpr int kScratchPool = 1024;
   bool scratch_full = false; int scratch_chunks = 0;
+  bool static_boxes_ok = false;      // the static polygons' entries of d_fe_box are those of the polygons now uploaded (set by a fe_box_kernel launch of run())
   int lines_cap_user = 0;      // 0: the default budget; -1: the reference's worst case; n > 0: n lines per segment (nep_batch_set_line_capacity)
   bool skip_mode() const { return sp.cull_radius > 0.0 && use_reg && sp.sep_rule == 0 && sp.skip_own == 1 && sp.n_hull == sp.num_agents && skip_lps && statics_boxy && !no_redo; }
   int size_row_scratch() {
@@ -226,6 +227,7 @@ struct Engine {
     rows_cap = 4 * (int)lines_total; rows_cap = (rows_cap + 3) & ~3;
     if (int e = d_hull_xy.ensure((size_t)n_scenes * sp.n_hull * np * kHullV * 2)) return e;
     if (int e = d_fe_box.ensure((size_t)n_scenes * (N + (sp.n_static > 0 ? sp.n_static : 0)) * np * 4)) return e;
+    static_boxes_ok = false;      // (the buffer may be a new one)
     if (int e = d_hull_nv.ensure((size_t)n_scenes * sp.n_hull * np)) return e;
     if (int e = d_hull0_xy.ensure((size_t)n_scenes * N * np * 2)) return e;
     if (int e = d_hull0_nv.ensure((size_t)n_scenes * N * np)) return e;
@@ -318,6 +320,7 @@ struct Engine {
     return 0;
   }
   int upload_statics(int n, const int32_t* off, const double* xy) {
+    static_boxes_ok = false;
     std::vector<double> sx, el; std::vector<int> nv;
     statics_boxy = true;       // (a new shared set replaces every earlier polygon)
     if (int e = pack_statics(n, off, xy, sx, nv, el)) return e;
@@ -335,6 +338,7 @@ struct Engine {
   // One static-obstacle set per scene (same polygon count S in every scene): the first call replicates the handle's
   // shared set into [n_scenes][S] arrays, then scene `scene` gets its own polygons.
   int upload_scene_statics(int scene, int n, const int32_t* off, const double* xy) {
+    static_boxes_ok = false;
     const int S = sp.n_static;
     if (n != S) return fail(NEP_E_ARG, "every scene must have the handle's n_static polygons");
     if (S == 0) return 0;
@@ -383,7 +387,11 @@ struct Engine {
     SampleSched sc{d_sched_n.p, d_sched_seg.p, d_sched_dt.p};
     const bool geo = (phases & 1) != 0, qp = (phases & 2) != 0;
     if (timing) hipEventRecord(next_event(), st);
-    if (d_recs && geo) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st);
+    // the hull kernel makes the hulls' boxes itself (and zeroes the redo counters) when it is the eight-hulls-per-wave kernel over one hull list
+    // per agent and the static polygons' boxes are in place from an earlier fe_box_kernel launch: one launch less per round
+    const bool fused_boxes = d_recs && geo && ps.skip_box != nullptr && !ps.lines_override && static_boxes_ok && ps.hull_pb <= 0
+                             && n_rec == sp.num_agents && sp.n_hull == sp.num_agents && hulls_grouped(sp, n_scenes, n_rec);
+    if (d_recs && geo) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st, fused_boxes);
     if (timing) hipEventRecord(next_event(), st);
     if (ps.lines_override) { ps.skip_box = nullptr; ps.line_skip = nullptr; ps.redo_list = nullptr; ps.redo_count = nullptr; }
     if (scratch_chunks > 0 && ps.scratch_chunks == 0) {      // (a pooled handle asked for a replan without the redo pass — lines from the host, a rule or hull layout that cannot skip LPs: one area per slot after all)
@@ -394,7 +402,7 @@ struct Engine {
     }
     const bool skip = ps.skip_box != nullptr;
     if (!ps.lines_override && geo) {
-      if (skip) launch_boxes(n_scenes, sp, ps, st);      // (zeroes the redo counters as well)
+      if (skip && !fused_boxes) { launch_boxes(n_scenes, sp, ps, st); static_boxes_ok = true; }      // (zeroes the redo counters as well)
       launch_separator(slots, sp, ps, st);
     }
     if (timing) hipEventRecord(next_event(), st);

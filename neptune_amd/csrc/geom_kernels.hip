@@ -347,7 +347,8 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
                                                         int num_pol, double T_span, double drone_radius,
                                                         double* __restrict__ hull_xy, int* __restrict__ hull_nv,
                                                         double* __restrict__ hull0_xy, int* __restrict__ hull0_nv,
-                                                        double* __restrict__ bend_xy, int* __restrict__ bend_n, int* __restrict__ flags) {
+                                                        double* __restrict__ bend_xy, int* __restrict__ bend_n, int* __restrict__ flags,
+                                                        double* __restrict__ box_out, int box_per_scene, int* __restrict__ zero4) {
   // LDS of a wave: the groups' sorted points (8 KB) and their control points (2 KB, read again after the hull by the uninflated hull
   // of the entangle rows).  The knot vector lives in the last group's point area — it is dead before the first point is stored — so
   // that the wave takes exactly 10 KB: sixteen waves per CU, and the 8 192 waves of a 128-scene launch are two full rounds (with the
@@ -369,8 +370,12 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
   }
   const bool act = g < num_pol;                   // this group has an interval
   const long out = (long)jt * num_pol + g;
+  if (zero4 && blockIdx.x == 0 && lane < 4) zero4[lane] = 0;      // (the presolve's redo list starts empty: fe_box_kernel's chore when that kernel runs)
+  // the hull's box for the front end's shortlist and the separator's LP skipping (fe_box_kernel's output, made here when box_out is given:
+  // one launch less per round).  [scene][box_per_scene][num_pol] x (x0, x1, y0, y1); an empty polygon gets a box nothing meets
+  double* box = box_out ? box_out + (((long)scene * box_per_scene + (jt - scene * n_rec_per_scene)) * num_pol + g) * 4 : nullptr;
   if (!(r->valid && r->is_agent) || r->pwp.n_seg <= 0) {   // neptune.cpp:244-262, 332
-    if (act && sub == 0) { hull_nv[out] = 0; if (hull0_nv) hull0_nv[out] = 0; }
+    if (act && sub == 0) { hull_nv[out] = 0; if (hull0_nv) hull0_nv[out] = 0; if (box) { box[0] = NEP_INF; box[1] = -NEP_INF; box[2] = NEP_INF; box[3] = -NEP_INF; } }
     return;
   }
   // bulk-synchronous round: every agent of a scene replans from the same t_start (that of its first local slot)
@@ -420,6 +425,25 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
       } else { px[j] = cpx[p]; py[j] = cpy[p]; }
     }
   }
+  if (box) {
+    // The box of the hull's vertices is the box of the points it is the hull of (an extreme point is a vertex), and x -> x +- dx is monotone
+    // in floating point too: min over the corners (x - dx) = (min x) - dx.  So: extremes of the control points over the group's lanes
+    // (two points a lane, three exchange steps), then the corner offsets — the same four doubles fe_box_kernel reads off the vertices
+    // (a hull of more than kHullV vertices is cut and flagged either way).
+    double x0 = NEP_INF, x1 = -NEP_INF, y0 = NEP_INF, y1 = -NEP_INF;
+#pragma unroll
+    for (int j = 0; j < 2; j++) { const int p = sub + 8 * j; if (p < np0) { const double x = cpx[p], y = cpy[p]; x0 = fmin(x0, x); x1 = fmax(x1, x); y0 = fmin(y0, y); y1 = fmax(y1, y); } }
+    // (towards the group's lane 0, which writes: lanes 0-3 take lanes 4-7 by a row shift, then two quad permutes — DPP moves only)
+    auto shl4 = [](double v) { return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), 0x104, 0xf, 0xf, false), __builtin_amdgcn_mov_dpp(__double2loint(v), 0x104, 0xf, 0xf, false)); };      // row_shl:4
+    x0 = fmin(x0, shl4(x0)); x1 = fmax(x1, shl4(x1)); y0 = fmin(y0, shl4(y0)); y1 = fmax(y1, shl4(y1));
+    x0 = fmin(x0, grp_xor<2>(x0)); x1 = fmax(x1, grp_xor<2>(x1)); y0 = fmin(y0, grp_xor<2>(y0)); y1 = fmax(y1, grp_xor<2>(y1));
+    x0 = fmin(x0, grp_xor<1>(x0)); x1 = fmax(x1, grp_xor<1>(x1)); y0 = fmin(y0, grp_xor<1>(y0)); y1 = fmax(y1, grp_xor<1>(y1));
+    if (act && sub == 0) {
+      if (np0 <= 0) { box[0] = NEP_INF; box[1] = -NEP_INF; box[2] = NEP_INF; box[3] = -NEP_INF; }
+      else if (inflate) { box[0] = x0 - dx; box[1] = x1 + dx; box[2] = y0 - dy; box[3] = y1 + dy; }
+      else { box[0] = x0; box[1] = x1; box[2] = y0; box[3] = y1; }
+    }
+  }
   int k = group_hull<kGrpPts>(np, px, py, s_sxy[g], g, sub, act, hull_xy + out * kHullV * 2, kHullV);
   if (k > kHullV) { k = kHullV; if (act && sub == 0 && flags) atomicOr(flags, NEP_FLAG_HULL_OVERFLOW); }
   if (act && sub == 0) hull_nv[out] = k;
@@ -433,12 +457,15 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
   }
 }
 
+bool hulls_grouped(const SceneParams& sp, int n_scenes, int n_rec) {
+  return sp.num_pol <= 8 && (sp.hull_mode ? sp.hull_mode == 2 : (long)n_scenes * n_rec > 2048);
+}
 void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_guess* guess,
-                  const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
-  launch_hulls_ts(recs, n_scenes, n_rec, &guess->t_start, (long)sizeof(nep_guess), sp, ps, st);
+                  const SceneParams& sp, const ProblemSet& ps, hipStream_t st, bool boxes) {
+  launch_hulls_ts(recs, n_scenes, n_rec, &guess->t_start, (long)sizeof(nep_guess), sp, ps, st, boxes);
 }
 void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const double* ts0, long ts_slot_stride,
-                     const SceneParams& sp, const ProblemSet& ps, hipStream_t st) {
+                     const SceneParams& sp, const ProblemSet& ps, hipStream_t st, bool boxes) {
   int blocks = n_scenes * n_rec * sp.num_pol;
   if (blocks <= 0) return;
   // the uninflated hull is read only by the entangle rows (col(0), solver_gurobi_poly.cpp:722-734)
@@ -451,7 +478,8 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
   if (sp.num_pol <= 8 && grouped) {
     hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * n_rec), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
                        sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
-                       need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr, ps.flags);
+                       need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr, ps.flags,
+                       boxes ? ps.fe_box : nullptr, sp.num_agents + sp.n_static, boxes ? ps.redo_count : nullptr);
     return;
   }
   hipLaunchKernelGGL(hull_kernel, dim3(blocks), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
@@ -1843,7 +1871,8 @@ void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_sc
   auto hulls_of = [&](const nep_traj_rec* recs) {      // interval hulls of one record set on the round's grid (eight per wave, as in the replan)
     if (sp.num_pol <= 8 && (sp.hull_mode ? sp.hull_mode == 2 : (long)n_scenes * N > 2048))
       hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * N), dim3(64), 0, st, recs, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
-                         sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
+                         sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags,
+                         (double*)nullptr, 0, (int*)nullptr);
     else
       hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, recs, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
                          sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);

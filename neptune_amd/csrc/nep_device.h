@@ -151,10 +151,13 @@ struct SampleSched {             // per K: n, seg[], dt[]
   const double* dt;              // [kMaxK+1][max_states]
 };
 
+// boxes: the hull kernel also writes the hulls' boxes (ps.fe_box, entries of the agents: what fe_box_kernel would make of them) and zeroes the
+// presolve's redo counters — only honoured by the eight-hulls-per-wave kernel (hulls_grouped) with one hull list per agent of the scene
+bool hulls_grouped(const SceneParams& sp, int n_scenes, int n_rec);
 void launch_hulls(const nep_traj_rec* recs, int n_scenes, int n_rec, const nep_guess* guess,
-                  const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
+                  const SceneParams& sp, const ProblemSet& ps, hipStream_t st, bool boxes = false);
 void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const double* ts0, long ts_slot_stride,
-                     const SceneParams& sp, const ProblemSet& ps, hipStream_t st);
+                     const SceneParams& sp, const ProblemSet& ps, hipStream_t st, bool boxes = false);
 void launch_hulls_explicit(const nep_traj_rec* recs, int n_traj, double t_start, int num_pol,
                            double T_span, double drone_radius, double* hull_xy, int* hull_nv,
                            double* hull0_xy, int* hull0_nv, int* flags, hipStream_t st);
