@@ -391,6 +391,11 @@ struct Engine {
     // per agent and the static polygons' boxes are in place from an earlier fe_box_kernel launch: one launch less per round
     const bool fused_boxes = d_recs && geo && ps.skip_box != nullptr && !ps.lines_override && static_boxes_ok && ps.hull_pb <= 0
                              && n_rec == sp.num_agents && sp.n_hull == sp.num_agents && hulls_grouped(sp, n_scenes, n_rec);
+    // ... and, in one wave more, this round's launch order of the QP workgroups (order_kernel's counting sort: it only needs the previous
+    // round's measured times), when the same call goes on to the QP half
+    const bool want_order = qp && lpt && have_history && slots > 1024 && d_order_key.n >= (size_t)slots && d_order.n >= (size_t)slots;
+    const bool fused_order = fused_boxes && want_order;
+    if (fused_order) { ps.order = d_order.p; ps.order_key = d_order_key.p; }
     if (d_recs && geo) launch_hulls(d_recs, n_scenes, n_rec, ps.guess, sp, ps, st, fused_boxes);
     if (timing) hipEventRecord(next_event(), st);
     if (ps.lines_override) { ps.skip_box = nullptr; ps.line_skip = nullptr; ps.redo_list = nullptr; ps.redo_count = nullptr; }
@@ -410,7 +415,7 @@ struct Engine {
     ps.order = nullptr; last_ordered = false;
     ps.order_key = (lpt && d_order_key.n >= (size_t)slots) ? d_order_key.p : nullptr;
     if (ps.order_key && have_history && slots > 1024 && d_order.n >= (size_t)slots) {   // (more than one wave of workgroups)
-      launch_qp_order(slots, d_order_key.p, d_order.p, st, ps.polish_count);      // (zeroes the polish pass's counters on its way)
+      if (!fused_order) launch_qp_order(slots, d_order_key.p, d_order.p, st, ps.polish_count);      // (zeroes the polish pass's counters on its way; fused_order: the hull launch has done both)
       ps.order = d_order.p; last_ordered = true;
     } else if (ps.polish_count && !(use_reg && slots == 1)) launch_qp_polish_zero(ps.polish_count, st);      // (a one-workgroup launch — the per-agent handle — sets the counters itself: qp_reg_kernel's last lines)
     // the presolve's zero-iteration certificate as a kernel of its own, one wave per replan: the replans it finishes (nine in ten of the

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
                                                         double* __restrict__ hull_xy, int* __restrict__ hull_nv,
                                                         double* __restrict__ hull0_xy, int* __restrict__ hull0_nv,
                                                         double* __restrict__ bend_xy, int* __restrict__ bend_n, int* __restrict__ flags,
-                                                        double* __restrict__ box_out, int box_per_scene, int* __restrict__ zero4) {
+                                                        double* __restrict__ box_out, int box_per_scene, int* __restrict__ zero4,
+                                                        int n_traj, int ord_n, const int* __restrict__ ord_key, int* __restrict__ ord_out, int* __restrict__ ord_zero4) {
   // LDS of a wave: the groups' sorted points (8 KB) and their control points (2 KB, read again after the hull by the uninflated hull
   // of the entangle rows).  The knot vector lives in the last group's point area — it is dead before the first point is stored — so
   // that the wave takes exactly 10 KB: sixteen waves per CU, and the 8 192 waves of a 128-scene launch are two full rounds (with the
@@ -360,7 +361,42 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
   double* stimes = &s_sxy[7][0];
   static_assert(NEP_TRAJ_MAX_SEG + 2 <= kGrpSxy, "the knot vector borrows a group's point area");
   const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
-  const int jt = blockIdx.x;                      // scene * n_rec + j
+  if (ord_n > 0 && blockIdx.x == 0) {
+    // One wave more than there are trajectories — the FIRST, so that it is dispatched at once and ends long before the launch does (as the
+    // last block it started in the second round of waves and ended 20 us after the hulls): the QP workgroups' launch order of this round — order_kernel's counting sort of the
+    // slots by their key (63 - key: longest expected first; the order within a bin is whatever the atomics make it, as there), on 64
+    // threads and in this launch's shadow instead of a launch of its own between the separator and the QP kernels.  It also zeroes
+    // the polish pass's counters, as order_kernel does on its way.
+    if (ord_zero4 && lane < 4) ord_zero4[lane] = 0;
+    int* hist = (int*)&s_sxy[0][0];               // [64 bins][16 sub-histograms], then tot[64]: 4.25 KB of the wave's point area
+    int* tot = hist + 64 * 16;
+    for (int i = lane; i < 64 * 16; i += 64) hist[i] = 0;
+    __syncthreads();
+    const int su = lane & 15;
+    // (sixteen keys a lane at a time, their reads in flight together: one wave walks 8 192 keys in two passes — read one at a time that is
+    // 256 dependent round trips, longer than the whole hull launch)
+    for (int i0 = 0; i0 < ord_n; i0 += 1024) {
+      int kk[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; kk[u] = i < ord_n ? ord_key[i] : 0; }
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; if (i < ord_n) atomicAdd(&hist[(63 - (kk[u] & 63)) * 16 + su], 1); }
+    }
+    __syncthreads();
+    { int o = 0; for (int u = 0; u < 16; u++) { const int c = hist[lane * 16 + u]; hist[lane * 16 + u] = o; o += c; } tot[lane] = o; }
+    __syncthreads();
+    if (lane == 0) { int o = 0; for (int b = 0; b < 64; b++) { const int c = tot[b]; tot[b] = o; o += c; } }
+    __syncthreads();
+    for (int i0 = 0; i0 < ord_n; i0 += 1024) {
+      int kk[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; kk[u] = i < ord_n ? ord_key[i] : 0; }
+#pragma unroll
+      for (int u = 0; u < 16; u++) { const int i = i0 + 64 * u + lane; if (i < ord_n) { const int b = 63 - (kk[u] & 63); ord_out[tot[b] + atomicAdd(&hist[b * 16 + su], 1)] = i; } }
+    }
+    return;
+  }
+  const int jt = (int)blockIdx.x - (ord_n > 0 ? 1 : 0);                      // scene * n_rec + j
   const int scene = jt / n_rec_per_scene;
   const nep_traj_rec* r = recs + jt;
   if (lane == 0 && bend_n) {                      // bend points travel with the record (neptune_ros.cpp:457-476)
@@ -370,7 +406,7 @@ __global__ __launch_bounds__(64) void hull_group_kernel(const nep_traj_rec* __re
   }
   const bool act = g < num_pol;                   // this group has an interval
   const long out = (long)jt * num_pol + g;
-  if (zero4 && blockIdx.x == 0 && lane < 4) zero4[lane] = 0;      // (the presolve's redo list starts empty: fe_box_kernel's chore when that kernel runs)
+  if (zero4 && jt == 0 && lane < 4) zero4[lane] = 0;      // (the presolve's redo list starts empty: fe_box_kernel's chore when that kernel runs)
   // the hull's box for the front end's shortlist and the separator's LP skipping (fe_box_kernel's output, made here when box_out is given:
   // one launch less per round).  [scene][box_per_scene][num_pol] x (x0, x1, y0, y1); an empty polygon gets a box nothing meets
   double* box = box_out ? box_out + (((long)scene * box_per_scene + (jt - scene * n_rec_per_scene)) * num_pol + g) * 4 : nullptr;
@@ -476,10 +512,13 @@ void launch_hulls_ts(const nep_traj_rec* recs, int n_scenes, int n_rec, const do
   // nep_batch_set_hull_kernel forces one (tests, A/B).
   const bool grouped = sp.hull_mode ? sp.hull_mode == 2 : (long)n_scenes * n_rec > 2048;
   if (sp.num_pol <= 8 && grouped) {
-    hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * n_rec), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
+    // (ps.order != null on the way in: the caller wants this round's QP launch order made in the launch's shadow — ps.order_key / ps.order_n)
+    const bool ord = boxes && ps.order != nullptr && ps.order_key != nullptr;
+    hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * n_rec + (ord ? 1 : 0)), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
                        sp.num_pol, sp.T_span, sp.drone_radius, ps.hull_xy, ps.hull_nv, need0 ? ps.hull0_xy : nullptr,
                        need0 ? ps.hull0_nv : nullptr, need0 ? ps.bend_xy : nullptr, need0 ? ps.bend_n : nullptr, ps.flags,
-                       boxes ? ps.fe_box : nullptr, sp.num_agents + sp.n_static, boxes ? ps.redo_count : nullptr);
+                       boxes ? ps.fe_box : nullptr, sp.num_agents + sp.n_static, boxes ? ps.redo_count : nullptr,
+                       n_scenes * n_rec, ord ? n_scenes * sp.n_local : 0, ord ? (const int*)ps.order_key : nullptr, ord ? (int*)ps.order : nullptr, ord ? ps.polish_count : nullptr);
     return;
   }
   hipLaunchKernelGGL(hull_kernel, dim3(blocks), dim3(64), 0, st, recs, n_rec, ts0, ts_slot_stride * sp.n_local,
@@ -1872,7 +1911,7 @@ void launch_safety(const nep_traj_rec* prev, const nep_traj_rec* fresh, int n_sc
     if (sp.num_pol <= 8 && (sp.hull_mode ? sp.hull_mode == 2 : (long)n_scenes * N > 2048))
       hipLaunchKernelGGL(hull_group_kernel, dim3(n_scenes * N), dim3(64), 0, st, recs, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
                          sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags,
-                         (double*)nullptr, 0, (int*)nullptr);
+                         (double*)nullptr, 0, (int*)nullptr, n_scenes * N, 0, (const int*)nullptr, (int*)nullptr, (int*)nullptr);
     else
       hipLaunchKernelGGL(hull_kernel, dim3(n_scenes * N * sp.num_pol), dim3(64), 0, st, recs, N, &ps.guess->t_start, (long)sizeof(nep_guess) * sp.n_local, sp.num_pol, sp.T_span,
                          sp.drone_radius, ps.hull_xy, ps.hull_nv, (double*)nullptr, (int*)nullptr, (double*)nullptr, (int*)nullptr, ps.flags);
